@@ -1,0 +1,530 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python modules (authoring container only).
+
+Run:  python oracle/make_golden.py [--only frontend,augment,...]
+
+* imports /root/reference behind the third-party stand-ins in oracle/ref_shims/ (timm, torchaudio,
+  codecarbon, sed_scores_eval, tensorboard -- none of which are installed here);
+* every random draw the reference makes on the path is captured (by wrapping torch.rand / torch.randint /
+  random.gauss / random.random while the reference function runs) and stored next to the outputs, so the
+  oracle and the HIP path can be driven with *injected* draws;
+* inputs and weights are regenerated from transformer4sed_amd/synth.py (pure integer hashing), so only the
+  reference OUTPUTS (mostly strided samples) are stored -- small fixtures, no reference source or bytecode.
+
+Nothing in tests/, smoke() or bench.py imports this file or /root/reference.
+"""
+import argparse
+import contextlib
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = "/root/reference"
+GOLD = os.path.join(REPO, "tests", "golden")
+
+sys.path.insert(0, os.path.join(HERE, "ref_shims"))
+sys.path.insert(0, REF)
+sys.path.insert(0, REPO)
+
+# torch.utils.tensorboard needs the (absent) tensorboard package: inject an empty stand-in module
+_tb = types.ModuleType("torch.utils.tensorboard")
+_tb.SummaryWriter = type("SummaryWriter", (), {"__init__": lambda self, *a, **k: None})
+sys.modules["torch.utils.tensorboard"] = _tb
+for _name, _attrs in (("torchmetrics", ()), ("psds_eval", ("PSDSEval", "plot_psd_roc")), ("sed_eval", ())):
+    _m = types.ModuleType(_name)  # metric libraries: imported by the trainers, never called by this script
+    for _a in _attrs:
+        setattr(_m, _a, None)
+    sys.modules[_name] = _m
+
+import matplotlib  # noqa: E402
+
+matplotlib.use("Agg")
+
+from transformer4sed_amd import synth  # noqa: E402
+
+
+# ------------------------------------------------------------------------------------------------
+class DrawRecorder:
+    """Wraps torch.rand / torch.randint / random.gauss / random.random and logs what they return."""
+
+    def __init__(self):
+        self.log = []
+
+    @contextlib.contextmanager
+    def recording(self):
+        o_rand, o_randint, o_gauss, o_random, o_perm = torch.rand, torch.randint, random.gauss, random.random, torch.randperm
+
+        def rand(*a, **k):
+            r = o_rand(*a, **k)
+            self.log.append(("rand", r.detach().cpu().clone()))
+            return r
+
+        def randint(*a, **k):
+            r = o_randint(*a, **k)
+            self.log.append(("randint", r.detach().cpu().clone()))
+            return r
+
+        def gauss(mu, sigma):
+            r = o_gauss(mu, sigma)
+            self.log.append(("gauss", r))
+            return r
+
+        def rnd():
+            r = o_random()
+            self.log.append(("random", r))
+            return r
+
+        def randperm(*a, **k):
+            r = o_perm(*a, **k)
+            self.log.append(("randperm", r.clone()))
+            return r
+
+        torch.rand, torch.randint, random.gauss, random.random, torch.randperm = rand, randint, gauss, rnd, randperm
+        try:
+            yield self
+        finally:
+            torch.rand, torch.randint, random.gauss, random.random, torch.randperm = o_rand, o_randint, o_gauss, o_random, o_perm
+
+    def of(self, kind):
+        return [v for k, v in self.log if k == kind]
+
+
+def save(name, **arrays):
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"  wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_frontend():
+    from src.models.passt.passt_feature_extraction import PasstFeatureExtractor
+    ext = PasstFeatureExtractor(n_mels=128, sr=32000, win_length=800, hopsize=320, n_fft=1024, htk=False, fmin=0.0,
+                                fmax=None, wav_norm=True, fmin_aug_range=10, fmax_aug_range=2000)
+    wav = torch.from_numpy(synth.synth_wav(2, seed=1000))
+    out = {}
+    ext.eval()
+    with torch.no_grad():
+        mel = ext(wav)
+        out["mel_eval_raw_s"] = t2n(mel[:, ::4, ::5])
+        out["mel_eval_s"] = t2n(ext.normalize(mel)[:, ::4, ::5])
+        out["mel_eval_clip0_frames"] = t2n(ext.normalize(mel)[0, :, [0, 1, 2, 500, 997, 998, 999]])
+    ext.train()
+    pairs = []
+    for seed in (3, 11, 29):
+        torch.manual_seed(seed)
+        rec = DrawRecorder()
+        with rec.recording(), torch.no_grad():
+            mel = ext.normalize(ext(wav))
+        d = [int(x.item()) for x in rec.of("randint")]
+        fmin = 0.0 + d[0]
+        fmax = 15000 + 1000 - d[1]
+        pairs.append((fmin, fmax))
+        out[f"mel_train{len(pairs) - 1}_s"] = t2n(mel[:, ::4, ::5])
+    out["train_fmin_fmax"] = np.asarray(pairs, dtype=np.float64)
+    # the filterbank the shim produced for eval (documents the unpinned third-party boundary)
+    save("frontend", **out)
+
+
+def gen_augment():
+    from src.preprocess import data_aug
+    B = 6
+    mel = torch.from_numpy(synth.det_uniform("aug/mel", (B, 128, 1000), -1.5, 1.5))
+    label = torch.from_numpy(synth.synth_strong_labels(B, seed=77))
+    out = {}
+    random.seed(5)
+    rec = DrawRecorder()
+    with rec.recording():
+        m2, l2 = data_aug.frame_shift(mel, label, net_pooling=1)
+    shifts = [int(g) for g in rec.of("gauss")]
+    out["shift_draws"] = np.asarray(shifts)
+    out["shift_mel_s"] = t2n(m2[:, ::8, ::7])
+    out["shift_label_rowsum"] = t2n(l2.sum(1))
+    # net_pooling 4 exercises the floor-division branch for negative shifts
+    random.seed(6)
+    rec = DrawRecorder()
+    with rec.recording():
+        _, l4 = data_aug.frame_shift(mel, label[:, :, :250].contiguous(), net_pooling=4)
+    out["shift4_draws"] = np.asarray([int(g) for g in rec.of("gauss")])
+    out["shift4_label_rowsum"] = t2n(l4.sum(1))
+    random.seed(7)
+    rec = DrawRecorder()
+    with rec.recording():
+        m3 = data_aug.frame_shift(mel)
+    out["shift_nolabel_draws"] = np.asarray([int(g) for g in rec.of("gauss")])
+    out["shift_nolabel_mel_s"] = t2n(m3[:, ::8, ::7])
+    # mixup with explicit permutation / c (the trainer passes c, data_aug.py draws perm)
+    perm = torch.tensor([2, 0, 5, 1, 3, 4])
+    c = 0.9375
+    mm, ml = data_aug.mixup(mel, label, permutation=perm, c=c)
+    out["mix_perm"] = t2n(perm)
+    out["mix_c"] = np.float64(c)
+    out["mix_mel_s"] = t2n(mm[:, ::8, ::7])
+    out["mix_label_rowsum"] = t2n(ml.sum(1))
+    # freq_nonlinear
+    random.seed(9)
+    rec = DrawRecorder()
+    bias = 0.03 * 0.6180339887
+    with rec.recording():
+        w = data_aug.freq_nonlinear(mel.numpy(), bias=bias)
+    out["warp_bias"] = np.float64(bias)
+    out["warp_phi"] = np.float64(rec.of("random")[0])
+    out["warp_mel_s"] = np.asarray(w)[:, ::2, ::13].astype(np.float32)
+    # filt_aug (step)
+    torch.manual_seed(13)
+    rec = DrawRecorder()
+    with rec.recording():
+        fa = data_aug.filt_aug(mel, db_range=[-26, 26], n_band=[2, 5], min_bw=4, filter_type="step", log=True,
+                               norm_std=5.0)
+    ri = rec.of("randint")
+    n_band = int(ri[0].item())
+    bounds = (torch.sort(ri[1])[0] + torch.arange(1, n_band) * 4).tolist()
+    bounds = [0] + bounds + [128]
+    band_db = rec.of("rand")[0] * 52.0 + (-26.0)
+    out["filt_bounds"] = np.asarray(bounds)
+    out["filt_band_db"] = t2n(band_db)
+    out["filt_mel_s"] = t2n(fa[:, ::2, ::13])
+    # full feature_transformation (two views): draws in call order
+    random.seed(21)
+    torch.manual_seed(22)
+    rec = DrawRecorder()
+    with rec.recording():
+        views = data_aug.feature_transformation(mel, n_transform=2, choice=[1, 0, 0, 1], filter_db_range=[-26, 26],
+                                                filter_bands=[2, 5], filter_minimum_bandwidth=4, filter_type="step",
+                                                log=True, norm_std=5.0)
+    rr = rec.of("random")  # per view: bias draw, phi draw
+    ri = rec.of("randint")
+    ru = rec.of("rand")
+    for v in range(2):
+        out[f"ft{v}_bias"] = np.float64(0.03 * rr[2 * v])
+        out[f"ft{v}_phi"] = np.float64(rr[2 * v + 1])
+        nb = int(ri[2 * v].item())
+        bd = [0] + (torch.sort(ri[2 * v + 1])[0] + torch.arange(1, nb) * 4).tolist() + [128]
+        out[f"ft{v}_bounds"] = np.asarray(bd)
+        out[f"ft{v}_band_db"] = t2n(ru[v] * 52.0 - 26.0)
+        out[f"ft{v}_mel_s"] = t2n(views[v][:, ::2, ::13])
+    save("augment", **out)
+
+
+# ------------------------------------------------------------------------------------------------
+def build_reference_model(embed_dim, mlm, depth, feature_layer):
+    """PaSST_SED from the reference with synth weights; encoder truncated to `depth` blocks
+    (discrepancy 2).  torch.load is patched because the PaSST checkpoint is unavailable."""
+    from src.models.passt.passt_sed import PaSST_SED
+    o_load = torch.load
+    torch.load = lambda *a, **k: {}
+    try:
+        kw = dict(passt_feature_layer=feature_layer, f_pool="mean_pool", decode_ratio=10, at_adapter=True,
+                  decoder="transformerXL", decoder_layer_num=3, decoder_pos_emd_len=1000, mlm=mlm,
+                  embed_dim=embed_dim, decoder_dim=embed_dim, load_pretrained_model=True)
+        if mlm:
+            kw["mlm_dict"] = dict(strategy="block", block_width=10, mask_rate=0.75, out_dim=embed_dim)
+        net = PaSST_SED(**kw)
+    finally:
+        torch.load = o_load
+    sd_np = synth.matsed_state_dict_np(tag=f"w{embed_dim}", embed_dim=embed_dim, depth=12, mlm=mlm)
+    missing, unexpected = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    assert not missing and not unexpected
+    # state_dict contract check: every key/shape we generate is exactly what the reference owns
+    ref_shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert ref_shapes == {k: tuple(v.shape) for k, v in sd_np.items()}, "state_dict contract drifted"
+    if depth < 12:
+        net.backbone.blocks = net.backbone.blocks[:depth]
+    return net
+
+
+def model_fixture(tag, embed_dim, depth, feature_layer, B, do_windows, do_grads):
+    out = {}
+    mel = torch.from_numpy(synth.det_uniform(f"{tag}/mel", (B, 128, 1000), -1.2, 1.2))
+    S = (slice(None), slice(None, None, 25), slice(None, None, max(1, embed_dim // 48)))  # strided sample
+
+    # ---- finetune-mode forward (eval) ---------------------------------------------------------
+    net = build_reference_model(embed_dim, False, depth, feature_layer)
+    net.eval()
+    hooks = {}
+
+    def grab(name):
+        def fn(_m, _i, o):
+            hooks[name] = o
+        return fn
+
+    net.backbone.patch_embed.register_forward_hook(grab("patch"))
+    for i, blk in enumerate(net.backbone.blocks):
+        blk.register_forward_hook(grab(f"enc{i}"))
+    for i, blk in enumerate(net.decoder.encoder_blocks):
+        blk.register_forward_hook(grab(f"dec{i}"))
+    net.interpolate_module.register_forward_hook(grab("interp"))
+    net.decoder.register_forward_hook(grab("decoder"))
+    with torch.no_grad():
+        strong, weak, other = net(mel, encoder_win=False, temp_w=1)
+    out["strong"] = t2n(strong)
+    out["weak"] = t2n(weak)
+    out["at_out"] = t2n(other["at_out"])
+    out["patch_s"] = t2n(hooks["patch"].flatten(2).transpose(1, 2)[S])
+    for i in range(depth):
+        out[f"enc{i}_s"] = t2n(hooks[f"enc{i}"][S])
+    out["interp_s"] = t2n(hooks["interp"][S])
+    for i in range(3):
+        out[f"dec{i}_s"] = t2n(hooks[f"dec{i}"].permute(1, 0, 2)[S])
+    out["decoder_s"] = t2n(hooks["decoder"][S])
+    with torch.no_grad():
+        pm = torch.zeros(B, 1000, dtype=torch.bool)
+        pm[0, 900:] = True
+        s2, w2, _ = net(mel, encoder_win=False, temp_w=0.5, pad_mask=pm)
+    out["strong_t05_pad"] = t2n(s2)
+    out["weak_t05_pad"] = t2n(w2)
+    if do_windows:
+        for step in (49, 31):
+            with torch.no_grad():
+                s3, w3, o3 = net(mel, encoder_win=True, mix_rate=0.5, win_param=[512, step], temp_w=0.5)
+            out[f"strong_win{step}"] = t2n(s3)
+            out[f"weak_win{step}"] = t2n(w3)
+            out[f"fbm_win{step}_s"] = t2n(o3["frame_before_mask"][S])
+            out[f"fbm_win{step}_tail"] = t2n(o3["frame_before_mask"][:, 985:, :8])
+        # train-mode windows draw a random time-pos offset per window (passt.py:504-511)
+        net.train()
+        torch.manual_seed(41)
+        rec = DrawRecorder()
+        with rec.recording(), torch.no_grad():
+            s4, w4, o4 = net(mel, encoder_win=True, mix_rate=0.5, win_param=[512, 49], temp_w=1)
+        out["win49_train_toffsets"] = np.asarray([int(x.item()) for x in rec.of("randint")])
+        out["strong_win49_train"] = t2n(s4)
+        out["fbm_win49_train_s"] = t2n(o4["frame_before_mask"][S])
+        net.eval()
+
+    if do_grads:
+        net.train()  # dropout p=0 everywhere; train only changes RNG draws (none without windows)
+        for p in net.parameters():
+            p.requires_grad_(True)
+        strong, weak, other = net(mel, encoder_win=False, temp_w=1)
+        wgt_s = torch.from_numpy(synth.det_uniform(f"{tag}/gs", tuple(strong.shape)))
+        wgt_w = torch.from_numpy(synth.det_uniform(f"{tag}/gw", tuple(weak.shape)))
+        wgt_a = torch.from_numpy(synth.det_uniform(f"{tag}/ga", tuple(other["at_out"].shape)))
+        loss = (strong * wgt_s).sum() + (weak * wgt_w).sum() + (other["at_out"] * wgt_a).sum()
+        loss.backward()
+        out["ft_loss"] = t2n(loss)
+        names, norms, heads = [], [], []
+        for k, p in net.named_parameters():
+            if p.grad is None:
+                continue
+            names.append(k)
+            norms.append(float(p.grad.double().norm()))
+            heads.append(t2n(p.grad.reshape(-1)[:8]))
+        out["ft_grad_names"] = np.asarray(names)
+        out["ft_grad_norms"] = np.asarray(norms)
+        out["ft_grad_heads"] = np.stack(heads)
+
+    # ---- MLM-mode forward (+ backward) -------------------------------------------------------
+    net = build_reference_model(embed_dim, True, depth, feature_layer)
+    net.train()
+    for p in net.backbone.parameters():  # recipes/desed/mlm/mlm_passt/passt_mlm_setting.py:5-9
+        p.requires_grad_(False)
+    torch.manual_seed(43)
+    rec = DrawRecorder()
+    with rec.recording():
+        pred, other = net(mel, encoder_win=False)
+    ru = rec.of("rand")
+    ri = rec.of("randint")
+    out["mlm_noise"] = t2n(ru[0])
+    out["mlm_probs"] = t2n(ru[1])
+    out["mlm_rand_idx"] = t2n(ri[0])
+    out["mlm_mask_ids"] = t2n(other["mask_id_seq"])
+    out["mlm_pred_s"] = t2n(pred[S])
+    out["mlm_fbm_s"] = t2n(other["frame_before_mask"][S])
+    loss = torch.nn.functional.mse_loss(other["frame_before_mask"][other["mask_id_seq"]], pred[other["mask_id_seq"]])
+    out["mlm_loss"] = t2n(loss)
+    if do_grads:
+        loss.backward()
+        names, norms, heads = [], [], []
+        for k, p in net.named_parameters():
+            if p.grad is None:
+                continue
+            names.append(k)
+            norms.append(float(p.grad.double().norm()))
+            heads.append(t2n(p.grad.reshape(-1)[:8]))
+        out["mlm_grad_names"] = np.asarray(names)
+        out["mlm_grad_norms"] = np.asarray(norms)
+        out["mlm_grad_heads"] = np.stack(heads)
+    if do_windows:
+        # MLM + sliding windows: here the masked sequence IS contiguous, so the in-place masking takes effect
+        # (unlike the encoder_win=False path, where mask.py:66,73 writes into a temporary copy -- see
+        # DESIGN.md "reference quirk 15").  eval mode => deterministic window offsets.
+        net.eval()
+        torch.manual_seed(47)
+        rec = DrawRecorder()
+        with rec.recording(), torch.no_grad():
+            predw, otherw = net(mel, encoder_win=True, win_param=[512, 49])
+        ru = rec.of("rand")
+        ri = rec.of("randint")
+        out["mlmw_noise"] = t2n(ru[0])
+        out["mlmw_probs"] = t2n(ru[1])
+        out["mlmw_rand_idx"] = t2n(ri[0])
+        out["mlmw_pred_s"] = t2n(predw[S])
+    save(tag, **out)
+
+
+def gen_micro():
+    # micro model, 12 heads x head_dim 8, encoder truncated to 2 blocks, full T/F input
+    model_fixture("model_micro96", embed_dim=96, depth=2, feature_layer=2, B=2, do_windows=False, do_grads=True)  # windows hard-code out_dim 768 (encoder_slide_window.py:11)
+
+
+def gen_full():
+    # full width (768), depth-2 encoder incl. grads (what the GPU parity tests also run live vs the oracle)
+    model_fixture("model_d768_l2", embed_dim=768, depth=2, feature_layer=2, B=2, do_windows=True, do_grads=True)
+
+
+def gen_full12():
+    # the real depth-12 / feature-layer-10 configuration: forward only (B=1)
+    model_fixture("model_d768_l12", embed_dim=768, depth=12, feature_layer=10, B=1, do_windows=False, do_grads=False)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_schedule():
+    from src.utils.scheduler import ExponentialDown, update_ema
+    out = {}
+    cfgs = {  # (n_epochs, n_epochs_cut, exponent, warmup_epochs, warmup_rate) from config/mat-sed/base/*.yaml
+        "pretrain": (15, 10, -0.5, 1, 0.1),
+        "finetune1": (15, 10, -1, 0, 0.1),
+        "finetune2": (30, 15, -1, 1, 0.1),
+    }
+    epoch_len = 40
+    for name, (ne, ncut, expo, wu, wr) in cfgs.items():
+        lin = torch.nn.Linear(2, 2)
+        opt = torch.optim.AdamW([{"params": lin.parameters(), "lr": 1.0}])
+        sch = ExponentialDown(opt, start_iter=ncut * epoch_len, total_iter=ne * epoch_len, exponent=expo,
+                              warmup_iter=wu * epoch_len, warmup_rate=wr)
+        scales = []
+        for _ in range(ne * epoch_len):
+            sch.step()
+            scales.append(opt.param_groups[0]["lr"])
+        out[f"lr_{name}"] = np.asarray(scales)
+    out["epoch_len"] = np.int64(epoch_len)
+    # EMA over 5 steps on a tiny module, step numbers as the trainer passes them (scheduler.step_num after step())
+    torch.manual_seed(3)
+    net = torch.nn.Linear(4, 3)
+    ema = torch.nn.Linear(4, 3)
+    w_hist, e_hist = [], []
+    for step in range(2, 7):
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(0.1 * step)
+        ema = update_ema(net, ema, step, 0.999)
+        w_hist.append(t2n(net.weight).copy())
+        e_hist.append(t2n(ema.weight).copy())
+    out["ema_w0"] = t2n(torch.nn.Linear(4, 3).weight) * 0  # placeholder shape
+    torch.manual_seed(3)
+    out["ema_net_init"] = t2n(torch.nn.Linear(4, 3).weight)
+    out["ema_ema_init"] = t2n(torch.nn.Linear(4, 3).weight)
+    out["ema_w_hist"] = np.stack(w_hist)
+    out["ema_e_hist"] = np.stack(e_hist)
+    # AdamW: 3 steps of torch.optim.AdamW with the reference's kwargs (recipes/desed/setting.py:254-258)
+    p = torch.nn.Parameter(torch.from_numpy(synth.det_uniform("adamw/p", (64,))))
+    opt = torch.optim.AdamW([{"params": [p], "lr": 1e-3, "weight_decay": 1e-4}], betas=(0.9, 0.999), eps=1e-8,
+                            weight_decay=1e-8)
+    hist = []
+    for s in range(3):
+        p.grad = torch.from_numpy(synth.det_uniform(f"adamw/g{s}", (64,)))
+        opt.step()
+        hist.append(t2n(p).copy())
+    out["adamw_hist"] = np.stack(hist)
+    save("schedule", **out)
+
+
+def gen_postprocess():
+    from scipy import ndimage
+    from src.postprocess.filter import median_filter_torch
+    from src.codec.encoder import Encoder
+    out = {}
+    x = synth.det_uniform("post/x", (3, 1000, 10), 0.0, 1.0)
+    x[0, 100:400, :] = np.round(x[0, 100:400, :] * 4) / 4  # ties
+    x[1, :50, 3] = 0.0
+    x[2, -40:, 5] = 1.0
+    sizes = [int(i / 156 * 1000) for i in [5, 20, 5, 5, 5, 20, 20, 20, 5, 20]]
+    out["sizes"] = np.asarray(sizes)
+    out["x"] = x
+    out["torchpath"] = t2n(median_filter_torch(torch.from_numpy(x), sizes))
+    sp = np.zeros_like(x)
+    mx = np.zeros_like(x)
+    for b in range(x.shape[0]):
+        for c in range(10):
+            # the call made at src/codec/decoder.py:91 / :94 (ndimage.filters.* is the same function)
+            sp[b, :, c] = ndimage.median_filter(x[b, :, c], (sizes[c]))
+            mx[b, :, c] = ndimage.maximum_filter(x[b, :, c], (sizes[c]))
+    out["scipypath"] = sp
+    out["scipymax"] = mx
+    odd = [7, 9, 5, 33, 1, 3, 11, 13, 15, 17]
+    out["odd_sizes"] = np.asarray(odd)
+    out["torchpath_odd"] = t2n(median_filter_torch(torch.from_numpy(x), odd))
+    so = np.zeros_like(x)
+    for b in range(x.shape[0]):
+        for c in range(10):
+            so[b, :, c] = ndimage.median_filter(x[b, :, c], (odd[c]))
+    out["scipypath_odd"] = so
+    labels = ["Alarm_bell_ringing", "Blender", "Cat", "Dishes", "Dog", "Electric_shaver_toothbrush", "Frying",
+              "Running_water", "Speech", "Vacuum_cleaner"]
+    enc = Encoder(labels, audio_len=10, frame_len=1024, frame_hop=320, net_pooling=1, sr=32000)
+    out["timestamps"] = enc._frame_to_time(np.arange(1001))
+    binm = (out["torchpath"][0] > 0.5).astype(np.float32)
+    ev = enc.decode_strong(binm)
+    out["decode_labels"] = np.asarray([e[0] for e in ev])
+    out["decode_on_off"] = np.asarray([[e[1], e[2]] for e in ev], dtype=np.float64)
+    save("postprocess", **out)
+
+
+def gen_losses():
+    """Six finetune loss terms + total (recipes/desed/finetune/train.py:160-188) on synthetic predictions,
+    computed with the same torch calls the reference trainer makes."""
+    B, sn, wn = 12, 4, 4
+    labels = torch.from_numpy(synth.synth_batch_labels(sn, wn, B - sn - wn, seed=5))
+    from recipes.desed.finetune.train import pool_strong_labels
+    lw = torch.zeros(B, 10)
+    lw[sn:sn + wn] = labels[sn:sn + wn].sum(-1)
+    lw[:sn] = pool_strong_labels(labels[:sn])
+    def pr(name, shape):
+        return torch.from_numpy(synth.det_uniform(name, shape, 0.02, 0.98))
+    stu = dict(strong=pr("l/ss", (B, 10, 1000)), weak=pr("l/sw", (B, 10)), at=pr("l/sa", (B, 10)))
+    tch = dict(strong=pr("l/ts", (B, 10, 1000)), weak=pr("l/tw", (B, 10)), at=pr("l/ta", (B, 10)))
+    bce, mse = torch.nn.BCELoss(), torch.nn.MSELoss()
+    ms = torch.zeros(B, dtype=torch.bool); ms[:sn] = True
+    mw = torch.zeros(B, dtype=torch.bool); mw[sn:sn + wn] = True
+    terms = dict(
+        loss_class_at_specific=bce(stu["at"][mw], lw[mw]),
+        loss_cons_at_specific=mse(stu["at"], tch["at"]),
+        loss_class_strong=bce(stu["strong"][ms], labels[ms]),
+        loss_class_weak=bce(stu["weak"][mw], lw[mw]),
+        loss_cons_strong=mse(stu["strong"], tch["strong"]),
+        loss_cons_weak=mse(stu["weak"], tch["at"]),
+    )
+    w_cons = 1.7
+    total = terms["loss_class_strong"] + 0.5 * terms["loss_class_weak"] + \
+        (terms["loss_cons_strong"] + 0.5 * terms["loss_cons_weak"] + 2 * terms["loss_cons_at_specific"]) * w_cons + \
+        terms["loss_class_at_specific"] * 2
+    out = {k: t2n(v) for k, v in terms.items()}
+    out["loss_total"] = t2n(total)
+    out["labels_weak"] = t2n(lw)
+    out["w_cons"] = np.float64(w_cons)
+    save("losses", **out)
+
+
+GENS = dict(frontend=gen_frontend, augment=gen_augment, micro=gen_micro, full=gen_full, full12=gen_full12,
+            schedule=gen_schedule, postprocess=gen_postprocess, losses=gen_losses)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    todo = [s for s in a.only.split(",") if s] or list(GENS)
+    for name in todo:
+        print(f"[make_golden] {name}")
+        GENS[name]()

@@ -1,0 +1,8 @@
+import collections.abc
+from itertools import repeat
+
+
+def to_2tuple(x):
+    if isinstance(x, collections.abc.Iterable) and not isinstance(x, str):
+        return tuple(x)
+    return tuple(repeat(x, 2))

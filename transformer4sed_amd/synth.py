@@ -1,0 +1,196 @@
+"""Deterministic synthetic weights / audio / labels (no RNG library state involved).
+
+Everything here is pure integer hashing (splitmix64 on a counter) so that the exact same
+tensors can be regenerated in the authoring container (to feed the reference import when the
+golden fixtures are produced), on the GPU box (tests, smoke, bench) and inside the oracle's
+callers.  Pretrained PaSST weights cannot be downloaded (no network), so the benchmark and the
+parity tests use these "DESED-shaped" synthetic inputs.
+"""
+import math
+import zlib
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(z: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = (z + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def det_uniform(name: str, shape, lo: float = -1.0, hi: float = 1.0) -> np.ndarray:
+    """float32 array of `shape`, i.i.d.-looking uniform in [lo, hi), a pure function of (name, shape)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    seed = np.uint64(zlib.crc32(name.encode("utf-8")))
+    with np.errstate(over="ignore"):
+        base = _splitmix64(np.asarray([seed], dtype=np.uint64))[0]
+        idx = (np.arange(n, dtype=np.uint64) + base) & _M64
+    z = _splitmix64(idx)
+    u = (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return (lo + (hi - lo) * u).astype(np.float32).reshape(shape)
+
+
+def det_normal(name: str, shape, std: float = 1.0) -> np.ndarray:
+    """Approximately normal (sum of 4 uniforms, variance matched), deterministic."""
+    acc = np.zeros(shape, dtype=np.float64)
+    for k in range(4):
+        acc += det_uniform(f"{name}#n{k}", shape).astype(np.float64)
+    return (acc * (std / math.sqrt(4.0 / 3.0))).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------------------
+# MAT-SED state_dict (names/shapes follow SURVEY.md section 8(b); reference definition sites:
+# src/models/passt/passt.py:392-452, src/models/passt/passt_sed.py:104-144,
+# src/models/transformer/transformerXL.py:147-165, src/models/pooling.py:39-43)
+# --------------------------------------------------------------------------------------------------
+def matsed_param_shapes(embed_dim=768, depth=12, dec_layers=3, class_num=10, mlm=False, n_heads=12,
+                        mlp_ratio=4, with_dead_heads=True, at_adapter=True):
+    D = embed_dim
+    hd = D // n_heads
+    s = {}
+    s["backbone.cls_token"] = (1, 1, D)
+    s["backbone.dist_token"] = (1, 1, D)
+    s["backbone.new_pos_embed"] = (1, 2, D)
+    s["backbone.freq_new_pos_embed"] = (1, D, 12, 1)
+    s["backbone.time_new_pos_embed"] = (1, D, 1, 99)
+    s["backbone.patch_embed.proj.weight"] = (D, 1, 16, 16)
+    s["backbone.patch_embed.proj.bias"] = (D,)
+    for i in range(depth):
+        p = f"backbone.blocks.{i}."
+        s[p + "norm1.weight"] = (D,)
+        s[p + "norm1.bias"] = (D,)
+        s[p + "attn.qkv.weight"] = (3 * D, D)
+        s[p + "attn.qkv.bias"] = (3 * D,)
+        s[p + "attn.proj.weight"] = (D, D)
+        s[p + "attn.proj.bias"] = (D,)
+        s[p + "norm2.weight"] = (D,)
+        s[p + "norm2.bias"] = (D,)
+        s[p + "mlp.fc1.weight"] = (mlp_ratio * D, D)
+        s[p + "mlp.fc1.bias"] = (mlp_ratio * D,)
+        s[p + "mlp.fc2.weight"] = (D, mlp_ratio * D)
+        s[p + "mlp.fc2.bias"] = (D,)
+    s["backbone.norm.weight"] = (D,)
+    s["backbone.norm.bias"] = (D,)
+    if with_dead_heads:  # never used in forward but part of the checkpoint contract
+        s["backbone.head.0.weight"] = (D,)
+        s["backbone.head.0.bias"] = (D,)
+        s["backbone.head.1.weight"] = (527, D)
+        s["backbone.head.1.bias"] = (527,)
+        s["backbone.head_dist.weight"] = (527, D)
+        s["backbone.head_dist.bias"] = (527,)
+    s["out_norm.weight"] = (D,)
+    s["out_norm.bias"] = (D,)
+    if mlm:
+        s["mask_token"] = (1, 1, D)
+        s["mlm_mlp.0.weight"] = (D, D)
+        s["mlm_mlp.0.bias"] = (D,)
+        s["mlm_mlp.2.weight"] = (D, D)
+        s["mlm_mlp.2.bias"] = (D,)
+    for i in range(dec_layers):
+        p = f"decoder.encoder_blocks.{i}."
+        s[p + "norm1.weight"] = (D,)
+        s[p + "norm1.bias"] = (D,)
+        s[p + "attn.pos_bias_u"] = (n_heads, hd)
+        s[p + "attn.pos_bias_v"] = (n_heads, hd)
+        s[p + "attn.in_proj.weight"] = (3 * D, D)
+        s[p + "attn.in_proj.bias"] = (3 * D,)
+        s[p + "attn.out_proj.weight"] = (D, D)
+        s[p + "attn.out_proj.bias"] = (D,)
+        s[p + "attn.linear_pos.weight"] = (D, D)
+        s[p + "norm2.weight"] = (D,)
+        s[p + "norm2.bias"] = (D,)
+        s[p + "mlp.fc1.weight"] = (D, D)
+        s[p + "mlp.fc1.bias"] = (D,)
+        s[p + "mlp.fc2.weight"] = (D, D)
+        s[p + "mlp.fc2.bias"] = (D,)
+    s["classifier.weight"] = (class_num, D)
+    s["classifier.bias"] = (class_num,)
+    if at_adapter:
+        s["at_adpater.0.f_att_token"] = (1, 1, D)
+        s["at_adpater.0.frequency_att.in_proj_weight"] = (3 * D, D)
+        s["at_adpater.0.frequency_att.in_proj_bias"] = (3 * D,)
+        s["at_adpater.0.frequency_att.out_proj.weight"] = (D, D)
+        s["at_adpater.0.frequency_att.out_proj.bias"] = (D,)
+        s["at_adpater.1.weight"] = (class_num, D)
+        s["at_adpater.1.bias"] = (class_num,)
+    return s
+
+
+def matsed_state_dict_np(tag="w0", **kw):
+    """Deterministic 'active' weights: O(1) activations, non-trivial softmax and LayerNorm affine."""
+    shapes = matsed_param_shapes(**kw)
+    out = {}
+    for name, shp in shapes.items():
+        key = f"{tag}/{name}"
+        if name.endswith("norm1.weight") or name.endswith("norm2.weight") or name in (
+                "backbone.norm.weight", "out_norm.weight", "backbone.head.0.weight"):
+            w = 1.0 + 0.2 * det_uniform(key, shp)
+        elif name.endswith(".bias") or name.endswith("in_proj_bias"):
+            w = 0.1 * det_uniform(key, shp)
+        elif "pos_bias_" in name:
+            w = 0.5 * det_uniform(key, shp)
+        elif name.endswith("_token") or "pos_embed" in name:
+            w = 0.5 * det_uniform(key, shp)
+        elif name == "backbone.patch_embed.proj.weight":
+            w = det_uniform(key, shp) * (1.5 * math.sqrt(3.0) / 16.0)
+        else:  # linear weights [out, in]
+            fan_in = shp[-1]
+            gain = 1.6 if ("qkv" in name or "in_proj" in name or "linear_pos" in name) else 1.0
+            w = det_uniform(key, shp) * (gain * math.sqrt(3.0 / fan_in))
+        out[name] = w.astype(np.float32)
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# DESED-shaped synthetic clips (SURVEY.md section 8(d) "Synthetic inputs")
+# --------------------------------------------------------------------------------------------------
+def synth_wav(n_clips: int, n_samples: int = 320000, seed: int = 1000) -> np.ndarray:
+    """Noise floor + a few gated sinusoid / noise bursts per clip, clipped to [-1, 1]."""
+    wav = 0.1 * det_normal(f"wav{seed}", (n_clips, n_samples))
+    t = np.arange(n_samples, dtype=np.float64) / 32000.0
+    for b in range(n_clips):
+        ev = det_uniform(f"wavev{seed}/{b}", (3, 4), 0.0, 1.0)
+        n_ev = 1 + int(ev[0, 3] * 3) % 3
+        for e in range(n_ev):
+            on = ev[e, 0] * 9.0
+            dur = 0.25 + ev[e, 1] * 4.0
+            f0 = 200.0 + ev[e, 2] * 6000.0
+            gate = ((t >= on) & (t < on + dur)).astype(np.float64)
+            wav[b] += (0.3 * np.sin(2 * np.pi * f0 * t) * gate).astype(np.float32)
+    return np.clip(wav, -1.0, 1.0).astype(np.float32)
+
+
+def synth_strong_labels(n_clips: int, n_classes: int = 10, n_frames: int = 1000, seed: int = 1000) -> np.ndarray:
+    """[B, C, T] {0,1}: 0-4 events per clip, onset U(0,9)s, duration U(.25,10)s, frame = t*32000/320
+    (encoding as src/codec/encoder.py:30-39: onset=round(frame), offset=round(ceil(frame)))."""
+    lab = np.zeros((n_clips, n_classes, n_frames), dtype=np.float32)
+    for b in range(n_clips):
+        ev = det_uniform(f"lab{seed}/{b}", (5, 3), 0.0, 1.0)
+        n_ev = int(ev[4, 0] * 5) % 5
+        for e in range(n_ev):
+            on_t = ev[e, 0] * 9.0
+            off_t = min(10.0, on_t + 0.25 + ev[e, 1] * 9.75)
+            c = int(ev[e, 2] * n_classes) % n_classes
+            on = int(round(min(max(on_t * 100.0, 0), n_frames)))
+            off = int(round(math.ceil(min(max(off_t * 100.0, 0), n_frames))))
+            lab[b, c, on:off] = 1.0
+    return lab
+
+
+def synth_batch_labels(strong_n: int, weak_n: int, unl_n: int, seed: int = 1000) -> np.ndarray:
+    """Labels in the reference's positional batch order strong|weak|unlabeled
+    (src/preprocess/dataset.py:178-188); weak clips keep the clip vector in frame 0
+    (src/preprocess/dataset.py:109-113); unlabeled are zeros."""
+    B = strong_n + weak_n + unl_n
+    lab = synth_strong_labels(B, seed=seed)
+    w = lab[strong_n:strong_n + weak_n]
+    clip = (w.sum(-1) > 0).astype(np.float32)
+    w[:] = 0
+    w[:, :, 0] = clip
+    lab[strong_n + weak_n:] = 0
+    return lab
