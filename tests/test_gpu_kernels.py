@@ -1,0 +1,402 @@
+"""Per-kernel parity tests (need an MI355X): every HIP op called through the C ABI against a plain PyTorch fp32
+reference of the same op (inputs pre-rounded to bf16 where the kernel consumes bf16 operands, so the comparison
+isolates the kernel and not the operand rounding)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from transformer4sed_amd import ops  # noqa: E402
+from transformer4sed_amd.ops import call, gemm_nt, gemm_dw, transpose_bf16, pad64, BF16, F32  # noqa: E402
+
+DEV = "cuda"
+LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "kernel_errors.log")
+
+
+def report(name, err, scale=None):
+    os.makedirs(os.path.dirname(LOG), exist_ok=True)
+    with open(LOG, "a") as f:
+        f.write(f"{name}: max_abs_err={err:.4e}" + (f" ref_scale={scale:.3e}" if scale is not None else "") + "\n")
+
+
+def maxerr(a, b):
+    return float((a.double() - b.double()).abs().max())
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def r16(x):
+    return x.to(BF16).float()
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 256, 192), (2380, 768, 768), (1204, 2304, 768), (77, 128, 3072)])
+def test_gemm_epilogues(M, N, K):
+    A, B = r16(rnd(M, K, seed=1)), r16(rnd(N, K, scale=0.05, seed=2))
+    bias = rnd(N, seed=3)
+    ref = A @ B.t()
+    A16, B16 = A.to(BF16), B.to(BF16)
+    tol = 2e-3 * math.sqrt(K / 64)
+    out = torch.full((M, N), 7.0, device=DEV)
+    gemm_nt(A16, B16, ops.EPI_F32, bias=bias, outF=out, alpha=0.5)
+    e = maxerr(out, 0.5 * ref + bias); report(f"gemm f32 {M}x{N}x{K}", e); assert e < tol
+    res = rnd(M, N, seed=4)
+    out2 = torch.empty(M, N, device=DEV)
+    gemm_nt(A16, B16, ops.EPI_F32_RESID, bias=bias, res=res, outF=out2)
+    assert maxerr(out2, res + ref + bias) < tol
+    inplace = res.clone()
+    gemm_nt(A16, B16, ops.EPI_F32_RESID, bias=bias, res=inplace, outF=inplace)
+    assert maxerr(inplace, out2) == 0.0
+    o16 = torch.empty(M, N, dtype=BF16, device=DEV)
+    gemm_nt(A16, B16, ops.EPI_BF16, bias=bias, outH=o16)
+    assert maxerr(o16.float(), (ref + bias).to(BF16).float()) < 0.02 * float((ref + bias).abs().max())
+    h16 = torch.empty(M, N, dtype=BF16, device=DEV)
+    a16 = torch.empty(M, N, dtype=BF16, device=DEV)
+    gemm_nt(A16, B16, ops.EPI_GELU, bias=bias, outH=h16, outH2=a16)
+    hr = ref + bias
+    assert maxerr(h16.float(), hr) < 0.01 * float(hr.abs().max()) + 1e-2
+    assert maxerr(a16.float(), torch.nn.functional.gelu(hr)) < 0.01 * float(hr.abs().max()) + 1e-2
+    d16 = torch.empty(M, N, dtype=BF16, device=DEV)
+    gemm_nt(A16, B16, ops.EPI_DGELU, outH=d16, aux=h16)
+    hh = h16.float().requires_grad_(True)
+    torch.nn.functional.gelu(hh).backward(ref)
+    e = maxerr(d16.float(), hh.grad); report(f"gemm dgelu {M}x{N}x{K}", e); assert e < 0.01 * float(hh.grad.abs().max()) + 1e-2
+    both_f = torch.empty(M, N, device=DEV); both_h = torch.empty(M, N, dtype=BF16, device=DEV)
+    gemm_nt(A16, B16, ops.EPI_F32_BF16, bias=bias, outF=both_f, outH=both_h)
+    assert maxerr(both_f, ref + bias) < tol and maxerr(both_h.float(), both_f.to(BF16).float()) == 0.0
+    acc = torch.zeros(M, N, device=DEV)
+    gemm_nt(A16, B16, ops.EPI_ATOMIC, outF=acc, ksplit=max(1, K // 64))
+    e = maxerr(acc, ref); report(f"gemm atomic split-K {M}x{N}x{K}", e); assert e < tol
+
+
+def test_gemm_asymmetric_identity():
+    """A = I with an asymmetric B catches transposed C writes (guide rule 16)."""
+    K = 128
+    A = torch.eye(K, device=DEV)
+    B = (torch.arange(256 * K, device=DEV).reshape(256, K) % 251).float()
+    out = torch.empty(K, 256, device=DEV)
+    gemm_nt(A.to(BF16), B.to(BF16), ops.EPI_F32, outF=out)
+    assert torch.equal(out, B.to(BF16).float().t())
+
+
+def test_transpose_and_dw():
+    R, C = 1190 * 2, 768
+    x = rnd(R, C, seed=5)
+    Rp = pad64(R)
+    xt = torch.full((C, Rp), 3.0, dtype=BF16, device=DEV)
+    xs = torch.empty(R, C, dtype=BF16, device=DEV)
+    cs = torch.zeros(C, device=DEV)
+    transpose_bf16(x, R, C, xt, out_s=xs, colsum=cs)
+    assert torch.equal(xs, x.to(BF16)) and torch.equal(xt[:, :R], x.to(BF16).t()) and float(xt[:, R:].abs().max()) == 0
+    assert maxerr(cs, x.sum(0)) < 2e-3
+    y = r16(rnd(R, 256, seed=6))
+    yt = torch.empty(256, Rp, dtype=BF16, device=DEV)
+    transpose_bf16(y.to(BF16), R, 256, yt)
+    dW = torch.zeros(C, 256, device=DEV)
+    gemm_dw(xt, yt, dW)
+    ref = xs.float().t() @ y
+    e = maxerr(dW, ref); report("dW gemm", e, float(ref.abs().max())); assert e < 2e-2
+
+
+def test_gemm_qkv_split():
+    B, N, Hh = 2, 70, 12
+    Npad = pad64(N)
+    M = B * N
+    x = r16(rnd(M, 768, seed=7)); W = r16(rnd(2304, 768, scale=0.05, seed=8)); b = rnd(2304, seed=9)
+    u, v = rnd(Hh, 64, seed=10), rnd(Hh, 64, seed=11)
+    mk = lambda: torch.full((B * Hh, N, 64), 9.0, dtype=BF16, device=DEV)
+    mkt = lambda: torch.zeros(B * Hh, 64, Npad, dtype=BF16, device=DEV)
+    q, k, vv, q2 = mk(), mk(), mk(), mk()
+    qt, kt, vt, q2t = mkt(), mkt(), mkt(), mkt()
+    call("sed_gemm_qkv", x.to(BF16), W.to(BF16), b, M, 768, Hh, N, Npad, q, k, vv, qt, kt, vt, q2, q2t, u, v)
+    ref = (x @ W.t() + b).view(B, N, 3, Hh, 64).permute(2, 0, 3, 1, 4)  # [3,B,H,N,64]
+    rq, rk, rv = [ref[i].reshape(B * Hh, N, 64) for i in range(3)]
+    uu = u.view(1, Hh, 1, 64).expand(B, Hh, N, 64).reshape(B * Hh, N, 64)
+    vvb = v.view(1, Hh, 1, 64).expand(B, Hh, N, 64).reshape(B * Hh, N, 64)
+    for got, want, nm in ((q, rq + uu, "q+u"), (q2, rq + vvb, "q+v"), (k, rk, "k"), (vv, rv, "v")):
+        e = maxerr(got.float(), want); report("qkv " + nm, e); assert e < 0.03
+    for got, src in ((qt, q), (kt, k), (vt, vv), (q2t, q2)):
+        assert torch.equal(got[:, :, :N], src.transpose(1, 2)) and float(got[:, :, N:].abs().max()) == 0
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _split(B, N, seed, scale=1.0):
+    Hh = 12
+    Npad = pad64(N)
+    q, k, v = [r16(rnd(B * Hh, N, 64, scale=scale, seed=seed + i)) for i in range(3)]
+    tr = lambda t: torch.nn.functional.pad(t.transpose(1, 2), (0, Npad - N)).to(BF16).contiguous()
+    return q, k, v, tr(q), tr(k), tr(v), Npad
+
+
+@pytest.mark.parametrize("B,N", [(1, 70), (2, 602), (2, 1190)])
+def test_mhsa_fwd_bwd(B, N):
+    Hh = 12
+    q, k, v, qt, kt, vt, Npad = _split(B, N, 20, scale=1.3)
+    O = torch.empty(B, N, 768, dtype=BF16, device=DEV)
+    lse = torch.empty(B * Hh, N, device=DEV)
+    call("sed_mhsa_fwd", q.to(BF16), k.to(BF16), vt, O, lse, B, Hh, N, Npad)
+    qq, kk, vv = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    s = (qq @ kk.transpose(1, 2)) * 0.125
+    p = torch.softmax(s, dim=-1)
+    o = p @ vv  # [BH,N,64]
+    oref = o.view(B, Hh, N, 64).permute(0, 2, 1, 3).reshape(B, N, 768)
+    e = maxerr(O.float(), oref); report(f"mhsa fwd N={N}", e); assert e < 2e-2
+    lref = torch.logsumexp(s, dim=-1) / math.log(2.0)
+    assert maxerr(lse, lref) < 2e-3
+    dO = r16(rnd(B, N, 768, seed=33))
+    oref.backward(dO)
+    dqkv = torch.empty(B * N, 2304, dtype=BF16, device=DEV)
+    Dt = torch.empty(B * Hh, N, device=DEV)
+    dOh = torch.empty(B * Hh, N, 64, dtype=BF16, device=DEV)
+    dOt = torch.empty(B * Hh, 64, Npad, dtype=BF16, device=DEV)
+    call("sed_mhsa_bwd", q.to(BF16), qt, k.to(BF16), kt, v.to(BF16), O, dO.to(BF16), lse, Dt, dOh, dOt, dqkv, B, Hh, N, Npad)
+    g = dqkv.float().view(B, N, 3, Hh, 64).permute(2, 0, 3, 1, 4).reshape(3, B * Hh, N, 64)
+    for i, (ref, nm) in enumerate(((qq.grad, "dq"), (kk.grad, "dk"), (vv.grad, "dv"))):
+        e = maxerr(g[i], ref); sc = float(ref.abs().max()); report(f"mhsa bwd {nm} N={N}", e, sc)
+        assert e < 0.03 * sc + 5e-3
+
+
+def _relpos_ref(qu, qv, k, v, P, T):
+    """qu,qv,k,v [BH,T,64] fp32; P [H,R,64] -> out [BH,T,64] (transformerXL.py:510-576)."""
+    BH = qu.shape[0]
+    Hh = P.shape[0]
+    B = BH // Hh
+    ac = qu @ k.transpose(1, 2)
+    bd_full = qv.view(B, Hh, T, 64) @ P.transpose(1, 2).unsqueeze(0)  # [B,H,T,R]
+    i = torch.arange(T, device=qu.device).unsqueeze(1)
+    j = torch.arange(T, device=qu.device).unsqueeze(0)
+    idx = (j - i + T - 1).expand(B, Hh, T, T)
+    bd = torch.gather(bd_full, 3, idx).reshape(BH, T, T)
+    s = (ac + bd) * 0.125
+    return torch.softmax(s, dim=-1) @ v, s
+
+
+@pytest.mark.parametrize("B,T", [(1, 200), (2, 1000)])
+def test_relpos_fwd_bwd(B, T):
+    Hh = 12
+    Tpad = pad64(T)
+    R = 2 * T - 1
+    Rpad = pad64(R)
+    qu, k, v, qut, kt, vt, _ = _split(B, T, 40, scale=1.2)
+    qv = r16(rnd(B * Hh, T, 64, scale=1.2, seed=47))
+    qvt = torch.nn.functional.pad(qv.transpose(1, 2), (0, Tpad - T)).to(BF16).contiguous()
+    P = r16(rnd(Hh, R, 64, scale=0.7, seed=48))
+    Pp = torch.zeros(Hh, Rpad, 64, dtype=BF16, device=DEV); Pp[:, :R] = P.to(BF16)
+    Pt = torch.zeros(Hh, 64, Rpad, dtype=BF16, device=DEV); Pt[:, :, :R] = P.to(BF16).transpose(1, 2)
+    O = torch.empty(B, T, 768, dtype=BF16, device=DEV)
+    lse = torch.empty(B * Hh, T, device=DEV)
+    call("sed_relpos_attn_fwd", qu.to(BF16), qv.to(BF16), k.to(BF16), vt, Pp, O, lse, B, Hh, T, Tpad, Rpad)
+    leaves = [t.clone().requires_grad_(True) for t in (qu, qv, k, v, P)]
+    o, s = _relpos_ref(*leaves, T)
+    oref = o.view(B, Hh, T, 64).permute(0, 2, 1, 3).reshape(B, T, 768)
+    e = maxerr(O.float(), oref); report(f"relpos fwd T={T}", e); assert e < 2e-2
+    assert maxerr(lse, torch.logsumexp(s, -1) / math.log(2.0)) < 3e-3
+    dO = r16(rnd(B, T, 768, seed=53))
+    oref.backward(dO)
+    dqkv = torch.empty(B * T, 2304, dtype=BF16, device=DEV)
+    Dt = torch.empty(B * Hh, T, device=DEV)
+    dOh = torch.empty(B * Hh, T, 64, dtype=BF16, device=DEV)
+    dOt = torch.empty(B * Hh, 64, Tpad, dtype=BF16, device=DEV)
+    dSt = torch.zeros(B * Hh, Tpad, Tpad, dtype=BF16, device=DEV)
+    dP = torch.zeros(Rpad, 768, device=DEV)
+    du = torch.zeros(Hh, 64, device=DEV); dv = torch.zeros(Hh, 64, device=DEV)
+    call("sed_relpos_attn_bwd", qu.to(BF16), qut, qv.to(BF16), qvt, k.to(BF16), kt, v.to(BF16), Pp, Pt, O, dO.to(BF16),
+         lse, Dt, dOh, dOt, dqkv, dSt, dP, du, dv, B, Hh, T, Tpad, Rpad, 1)
+    g = dqkv.float().view(B, T, 3, Hh, 64).permute(2, 0, 3, 1, 4).reshape(3, B * Hh, T, 64)
+    dq_ref = leaves[0].grad + leaves[1].grad
+    for got, ref, nm in ((g[0], dq_ref, "dq"), (g[1], leaves[2].grad, "dk"), (g[2], leaves[3].grad, "dv")):
+        e = maxerr(got, ref); sc = float(ref.abs().max()); report(f"relpos bwd {nm} T={T}", e, sc)
+        assert e < 0.03 * sc + 5e-3
+    du_ref = leaves[0].grad.view(B, Hh, T, 64).sum((0, 2)); dv_ref = leaves[1].grad.view(B, Hh, T, 64).sum((0, 2))
+    for got, ref, nm in ((du, du_ref, "du"), (dv, dv_ref, "dv_bias")):
+        e = maxerr(got, ref); sc = float(ref.abs().max()); report(f"relpos bwd {nm} T={T}", e, sc); assert e < 0.03 * sc + 2e-2
+    dP_ref = leaves[4].grad.permute(1, 0, 2).reshape(R, 768)
+    e = maxerr(dP[:R], dP_ref); sc = float(dP_ref.abs().max()); report(f"relpos bwd dP T={T}", e, sc)
+    assert e < 0.03 * sc + 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ norms & glue
+def test_layernorm_fwd_bwd():
+    M = 1190 * 2 + 3
+    x = rnd(M, 768, scale=2.0, seed=60); g = 1 + 0.2 * rnd(768, seed=61); b = 0.1 * rnd(768, seed=62)
+    for in_scale, eps in ((1.0, 1e-6), (math.sqrt(768.0), 1e-5)):
+        y16 = torch.empty(M, 768, dtype=BF16, device=DEV); y32 = torch.empty(M, 768, device=DEV)
+        mu = torch.empty(M, device=DEV); rs = torch.empty(M, device=DEV)
+        call("sed_layernorm_fwd", x, g, b, eps, in_scale, y16, y32, mu, rs, M, 768)
+        xx = x.clone().requires_grad_(True); gg = g.clone().requires_grad_(True); bb = b.clone().requires_grad_(True)
+        ref = torch.nn.functional.layer_norm(xx * in_scale, (768,), gg, bb, eps)
+        e = maxerr(y32, ref); report(f"layernorm fwd scale={in_scale:.1f}", e); assert e < 2e-5
+        assert torch.equal(y16, y32.to(BF16))
+        dy = rnd(M, 768, seed=63)
+        ref.backward(dy)
+        acc = rnd(M, 768, seed=64); base = acc.clone()
+        dg = torch.zeros(768, device=DEV); db = torch.zeros(768, device=DEV)
+        call("sed_layernorm_bwd", dy, x, mu, rs, g, in_scale, acc, 1, dg, db, M, 768)
+        e = maxerr(acc - base, xx.grad); sc = float(xx.grad.abs().max()); report("layernorm bwd dx", e, sc); assert e < 1e-4 * sc + 1e-5
+        assert maxerr(dg, gg.grad) < 2e-3 * float(gg.grad.abs().max()) and maxerr(db, bb.grad) < 2e-3 * float(bb.grad.abs().max())
+        st = torch.empty(M, 768, device=DEV)
+        call("sed_layernorm_bwd", dy, x, mu, rs, g, in_scale, st, 0, None, None, M, 768)
+        assert maxerr(st, xx.grad) < 1e-4 * sc + 1e-5
+
+
+def test_patch_tokens_fpool_interp():
+    B, T, tp = 2, 1000, 99
+    mel = rnd(B, 128, T, seed=70)
+    cols = torch.empty(B * 12 * tp, 256, dtype=BF16, device=DEV)
+    call("sed_im2col", mel, cols, B, T, 0, tp)
+    ref = mel.unfold(1, 16, 10).unfold(2, 16, 10).reshape(B * 12 * tp, 256)
+    assert torch.equal(cols, ref.to(BF16))
+    colw = torch.empty(B * 12 * 50, 256, dtype=BF16, device=DEV)
+    call("sed_im2col", mel, colw, B, T, 490, 50)
+    assert torch.equal(colw, mel[:, :, 490:1000].unfold(1, 16, 10).unfold(2, 16, 10).reshape(B * 12 * 50, 256).to(BF16))
+    conv = rnd(B * 12 * tp, 768, seed=71)
+    cls, dist, npe = rnd(768, seed=72), rnd(768, seed=73), rnd(2, 768, seed=74)
+    fpe, tpe = rnd(768, 12, seed=75), rnd(768, 99, seed=76)
+    N = 2 + 12 * tp
+    x = torch.empty(B, N, 768, device=DEV)
+    call("sed_assemble_tokens", conv, cls, dist, npe, fpe, tpe, 0, x, B, tp)
+    xr = conv.view(B, 12, tp, 768) + tpe.t().view(1, 1, 99, 768) + fpe.t().view(1, 12, 1, 768)
+    xr = torch.cat([(cls + npe[0]).expand(B, 1, 768), (dist + npe[1]).expand(B, 1, 768), xr.reshape(B, 12 * tp, 768)], 1)
+    assert maxerr(x, xr) < 1e-6
+    # backward of the assembly
+    dx = rnd(B, N, 768, seed=77)
+    dconv = torch.empty(B * 12 * tp, 768, dtype=BF16, device=DEV)
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    dcls, ddist, dnp, dfr, dti = z(768), z(768), z(2, 768), z(768, 12), z(768, 99)
+    call("sed_assemble_tokens_bwd", dx, dconv, dcls, ddist, dnp, dfr, dti, 0, B, tp)
+    assert torch.equal(dconv, dx[:, 2:].reshape(-1, 768).to(BF16))
+    assert maxerr(dcls, dx[:, 0].sum(0)) < 1e-5 and maxerr(dnp[1], dx[:, 1].sum(0)) < 1e-5
+    d4 = dx[:, 2:].view(B, 12, tp, 768)
+    assert maxerr(dfr, d4.sum((0, 2)).t()) < 1e-3 and maxerr(dti, d4.sum((0, 1)).t()) < 1e-3
+    # f_pool fwd/bwd
+    g = 1 + 0.2 * rnd(768, seed=78); b = 0.1 * rnd(768, seed=79)
+    pooled = torch.empty(B, tp, 768, device=DEV); pm = torch.zeros(B * N, device=DEV); pr = torch.zeros(B * N, device=DEV)
+    call("sed_fpool_fwd", x, g, b, 1e-5, pooled, pm, pr, B, tp)
+    xx = x.clone().requires_grad_(True); gg = g.clone().requires_grad_(True); bb = b.clone().requires_grad_(True)
+    pref = torch.nn.functional.layer_norm(xx[:, 2:], (768,), gg, bb, 1e-5).view(B, 12, tp, 768).mean(1)
+    e = maxerr(pooled, pref); report("fpool fwd", e); assert e < 2e-5
+    # interp fwd/bwd (with the replicated 100th frame)
+    out = torch.empty(B, 1000, 768, device=DEV)
+    call("sed_interp_fwd", pooled, out, B, tp, 1, 10)
+    padded = torch.cat([pref, pref[:, -1:]], 1)
+    iref = torch.nn.functional.interpolate(padded.transpose(1, 2), scale_factor=10, mode="linear").transpose(1, 2)
+    e = maxerr(out, iref); report("interp fwd", e); assert e < 2e-5
+    dout = rnd(B, 1000, 768, seed=80)
+    iref.backward(dout)
+    dpool = torch.empty(B, tp, 768, device=DEV)
+    call("sed_interp_bwd", dout, dpool, B, tp, 1, 10)
+    # torch gave d(pooled) through interp AND f_pool; check the f_pool backward composed with it
+    dtok = torch.empty(B, N, 768, device=DEV); dxa = z(B, N, 768); dg, db = z(768), z(768)
+    call("sed_fpool_bwd", dpool, x, pm, pr, g, dtok, dxa, dg, db, B, tp)
+    e = maxerr(dxa, xx.grad); sc = float(xx.grad.abs().max()); report("interp+fpool bwd dx", e, sc); assert e < 2e-4 * sc + 1e-6
+    assert maxerr(dg, gg.grad) < 2e-3 * float(gg.grad.abs().max()) and maxerr(db, bb.grad) < 2e-3 * float(bb.grad.abs().max())
+    # sliding-window merge
+    nW, tpw = 11, 50
+    pw = rnd(nW, B, tpw, 768, seed=81)
+    lefts = torch.tensor([49 * i for i in range(nW)], dtype=torch.int32, device=DEV)
+    xg = rnd(B, 1000, 768, seed=82); xg0 = xg.clone()
+    call("sed_window_mix", pw, lefts, nW, xg, 0.5, B, 1000, tpw, 10)
+    emb = torch.zeros(B, 1000, 768, device=DEV); cnt = torch.zeros(B, 1000, 768, device=DEV)
+    for w in range(nW):
+        fr = torch.nn.functional.interpolate(pw[w].transpose(1, 2), scale_factor=10, mode="linear").transpose(1, 2)
+        emb[:, 49 * w:49 * w + 500] += fr; cnt[:, 49 * w:49 * w + 500] += 1
+    loc = emb / cnt; loc[torch.isnan(loc)] = 0
+    e = maxerr(xg, 0.5 * loc + 0.5 * xg0); report("window mix", e); assert e < 2e-5
+    assert float(loc[:, 990:].abs().max()) == 0
+
+
+def test_heads_and_small_ops():
+    B, T, C = 3, 1000, 10
+    x = rnd(B, T, 768, seed=90); W = rnd(C, 768, scale=0.05, seed=91); b = rnd(C, scale=0.3, seed=92)
+    pm = torch.zeros(B, T, dtype=torch.uint8, device=DEV); pm[0, 900:] = 1
+    for temp, mask in ((1.0, None), (0.5, pm)):
+        strong = torch.empty(B, C, T, device=DEV); weak = torch.empty(B, C, device=DEV); sums = torch.empty(B, C, 2, device=DEV)
+        call("sed_head_fwd", x, W, b, temp, mask, strong, weak, sums, B, T, C)
+        xx = x.clone().requires_grad_(True); WW = W.clone().requires_grad_(True); bb = b.clone().requires_grad_(True)
+        s = torch.sigmoid((xx @ WW.t() + bb) / temp)
+        if mask is not None:
+            s = s.masked_fill(mask.bool().unsqueeze(-1), 0.0)
+        wk = torch.clamp((s * s).sum(1) / s.sum(1), 1e-7, 1.0)
+        e = maxerr(strong, s.transpose(1, 2)); report(f"head fwd strong temp={temp}", e); assert e < 2e-5
+        assert maxerr(weak, wk) < 2e-5
+        ds, dw = rnd(B, C, T, seed=93), rnd(B, C, seed=94)
+        ((s.transpose(1, 2) * ds).sum() + (wk * dw).sum()).backward()
+        dx = torch.empty(B, T, 768, device=DEV); dW = torch.zeros(C, 768, device=DEV); db = torch.zeros(C, device=DEV)
+        call("sed_head_bwd", x, W, strong, sums, ds, dw, temp, dx, dW, db, B, T, C)
+        e = maxerr(dx, xx.grad); report(f"head bwd dx temp={temp}", e, float(xx.grad.abs().max())); assert e < 1e-4
+        assert maxerr(dW, WW.grad) < 2e-3 * float(WW.grad.abs().max()) and maxerr(db, bb.grad) < 2e-3 * float(bb.grad.abs().max())
+    # small linear fwd/bwd (+ sigmoid)
+    a = rnd(5, 768, seed=95); w = rnd(10, 768, scale=0.05, seed=96); bb = rnd(10, seed=97)
+    out = torch.empty(5, 10, device=DEV)
+    call("sed_small_linear", a, w, bb, out, 5, 10, 768, 1)
+    aa, ww, b2 = [t.clone().requires_grad_(True) for t in (a, w, bb)]
+    ref = torch.sigmoid(aa @ ww.t() + b2)
+    assert maxerr(out, ref) < 1e-5
+    dout = rnd(5, 10, seed=98)
+    ref.backward(dout)
+    da = torch.empty(5, 768, device=DEV); dw_ = torch.zeros(10, 768, device=DEV); db_ = torch.zeros(10, device=DEV)
+    call("sed_small_linear_bwd", a, w, out, dout, da, dw_, db_, 5, 10, 768, 1)
+    assert maxerr(da, aa.grad) < 1e-5 and maxerr(dw_, ww.grad) < 1e-4 and maxerr(db_, b2.grad) < 1e-5
+    # attention pooling
+    N, Hh = 1190, 12
+    kv = r16(rnd(B, N, 1536, seed=99)); q = rnd(1, 768, seed=100)
+    pooled = torch.empty(B, 768, device=DEV); probs = torch.empty(B * Hh, N - 2, device=DEV)
+    call("sed_attnpool_fwd", kv.to(BF16), q, pooled, probs, B, N, Hh)
+    kvv = kv.clone().requires_grad_(True); qq = q.clone().requires_grad_(True)
+    kk = kvv[:, 2:, :768].reshape(B, N - 2, Hh, 64).permute(0, 2, 1, 3); vv = kvv[:, 2:, 768:].reshape(B, N - 2, Hh, 64).permute(0, 2, 1, 3)
+    att = torch.softmax((qq.view(1, Hh, 1, 64) @ kk.transpose(-2, -1)) * 0.125, -1)
+    pref = (att @ vv).reshape(B, 768)
+    e = maxerr(pooled, pref); report("attnpool fwd", e); assert e < 1e-4
+    dp = rnd(B, 768, seed=101)
+    pref.backward(dp)
+    dkv = torch.full((B, N, 1536), 5.0, dtype=BF16, device=DEV); dq = torch.zeros(1, 768, device=DEV)
+    call("sed_attnpool_bwd", kv.to(BF16), q, probs, dp, dkv, dq, B, N, Hh)
+    e = maxerr(dkv.float(), kvv.grad); sc = float(kvv.grad.abs().max()); report("attnpool bwd dkv", e, sc); assert e < 0.02 * sc
+    assert maxerr(dq, qq.grad) < 2e-3 * float(qq.grad.abs().max()) + 1e-5
+
+
+def test_mlm_mse_adamw():
+    B, T = 2, 1000
+    rows = B * T
+    x = rnd(rows, 768, seed=110); tok = rnd(768, seed=111)
+    g = torch.Generator().manual_seed(5)
+    action = torch.randint(0, 3, (rows,), generator=g).to(torch.uint8).to(DEV)
+    src = torch.randint(0, rows, (rows,), generator=g).to(torch.int32).to(DEV)
+    out = torch.empty(rows, 768, device=DEV)
+    call("sed_mlm_apply", x, tok, action, src, out, rows)
+    ref = x.clone(); ref[action == 1] = tok; ref[action == 2] = x[src.long()[action == 2]]
+    assert torch.equal(out, ref)
+    dout = rnd(rows, 768, seed=112)
+    dx = torch.zeros(rows, 768, device=DEV); dtok = torch.zeros(768, device=DEV)
+    call("sed_mlm_apply_bwd", dout, action, src, dx, dtok, rows)
+    dref = torch.zeros(rows, 768, device=DEV); dref[action == 0] = dout[action == 0]
+    dref.index_add_(0, src.long()[action == 2], dout[action == 2])
+    assert maxerr(dx, dref) < 1e-5 and maxerr(dtok, dout[action == 1].sum(0)) < 2e-3
+    pred, tgt = rnd(rows, 768, seed=113), rnd(rows, 768, seed=114)
+    mask = (action != 0)
+    nm = int(mask.sum())
+    loss = torch.zeros(1, device=DEV); dp = torch.empty(rows, 768, device=DEV); dt = torch.empty(rows, 768, device=DEV)
+    call("sed_masked_mse", pred, tgt, mask.to(torch.uint8), nm, loss, dp, dt, rows)
+    pp = pred.clone().requires_grad_(True); tt = tgt.clone().requires_grad_(True)
+    lref = torch.nn.functional.mse_loss(tt[mask], pp[mask]); lref.backward()
+    assert abs(float(loss) - float(lref)) < 1e-5 * float(lref) + 1e-6
+    assert maxerr(dp, pp.grad) < 1e-9 + 1e-6 * float(pp.grad.abs().max()) and maxerr(dt, tt.grad) < 1e-9 + 1e-6 * float(tt.grad.abs().max())
+    n = 4096 * 3
+    p = rnd(n, seed=115); gr = rnd(n, seed=116); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    ema = p.clone() * 0.5
+    pt = torch.nn.Parameter(p.clone()); opt = torch.optim.AdamW([pt], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
+    e_ref = ema.clone()
+    for step in range(1, 4):
+        pt.grad = gr * step
+        opt.step()
+        alpha = min(1 - 1 / (step + 1), 0.999)
+        e_ref = e_ref * alpha + pt.detach() * (1 - alpha)
+        call("sed_adamw_ema", p, (gr * step).contiguous(), m, v, ema, n, 1e-3, 1e-4, 0.9, 0.999, 1e-8, step, alpha, 1)
+        assert maxerr(p, pt.detach()) < 2e-6 and maxerr(ema, e_ref) < 2e-6

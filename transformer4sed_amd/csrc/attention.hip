@@ -1,0 +1,409 @@
+// Fused multi-head self-attention (flash style) for the PaSST encoder, forward + backward, gfx950.
+//
+// Replaces src/models/passt/passt.py:335-341 (scores, softmax, attn @ v; 68 MB/clip/layer of materialised
+// probabilities in the reference) and its autograd backward.  head_dim = 64, any sequence length
+// (1190 tokens for the global pass, 602 for the 512-frame windows).
+//
+// Inputs come head-split from the qkv GEMM epilogue (gemm.hip, EPI_QKV):
+//   Q, K, V : [B*H, N, 64] bf16,   Qt, Kt, Vt : [B*H, 64, Npad] bf16 (zero padded to a multiple of 64)
+//
+// Forward ("swapped" form so that a lane owns one query column of every accumulator):
+//   S^T[key, q] = K . Q^T   -> online softmax along registers (+1 cross-half shuffle) ->
+//   O^T[d, q]  += V^T[d, key] . P^T[key, q]     with P^T taken straight from the S^T accumulator registers
+//   (the MFMA k-index permutation is chosen to match the accumulator row pattern, so no cross-lane traffic).
+// 4 waves x 32 queries per workgroup, 64-key tiles, K and V^T tiles double buffered in XOR-swizzled LDS,
+// next tile's global loads in flight during the MFMA phase.
+#include "common.h"
+#include "../../include/sed_hip.h"
+
+#include "attn_common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mhsa_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                       const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
+                                                       float* __restrict__ LSE, int N, int Npad, int H) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][KVB * 128];  // [buf][K | Vt]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const bf16_t* Qb = Q + (size_t)bh * N * HD;
+    const bf16_t* Kb = K + (size_t)bh * N * HD;
+    const bf16_t* Vtb = Vt + (size_t)bh * HD * Npad;
+
+    int qrow = q0 + lr;
+    qrow = qrow < N ? qrow : N - 1;
+    s16x8_t qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const s16x8_t*>(Qb + (size_t)qrow * HD + 16 * s + 8 * lg);
+
+    f32x16_t o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    const int ntiles = (N + KVB - 1) / KVB;
+    TileRegs rk, rv;
+    tile_gload(rk, Kb, 0, N, HD, 0, tid);
+    tile_gload(rv, Vtb, 0, HD, Npad, 0, tid);
+    tile_lstore_rows(rk, lds[0][0], tid);
+    tile_lstore_cols(rv, lds[0][1], tid);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1, j0 = t * KVB;
+        if (t + 1 < ntiles) {
+            tile_gload(rk, Kb, j0 + KVB, N, HD, 0, tid);
+            tile_gload(rv, Vtb, 0, HD, Npad, j0 + KVB, tid);
+        }
+        const unsigned char* lk = lds[buf][0];
+        const unsigned char* lv = lds[buf][1];
+        f32x16_t st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) st[kb] = mfma32(lds_frag_rows(lk, 32 * kb + lr, 2 * s + lg), qf[s], st[kb]);
+        }
+        // scale (log2 domain) + mask keys >= N (last tile only)
+        float mloc = -1e30f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sv = st[kb][r] * SCALE_LOG2E;
+                if (j0 + KVB > N) {
+                    const int key = j0 + 32 * kb + mfma32_row(r, lg);
+                    sv = key < N ? sv : -1e30f;
+                }
+                st[kb][r] = sv;
+                mloc = fmaxf(mloc, sv);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(st[kb][r] - m_new);
+                st[kb][r] = p;
+                psum += p;
+            }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        // O^T[d, q] += V^T[d, key] P^T[key, q]
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const s16x8_t pf = pack_frag(st[kb], s);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    o[db] = mfma32(lds_frag_cols(lv, 32 * db + lr, 8 * kb + 4 * s + lg), pf, o[db]);
+            }
+        if (t + 1 < ntiles) {
+            tile_lstore_rows(rk, lds[buf ^ 1][0], tid);
+            tile_lstore_cols(rv, lds[buf ^ 1][1], tid);
+        }
+        __syncthreads();
+    }
+
+    const int q = q0 + lr;
+    if (q < N) {
+        const float inv = 1.0f / l_run;
+        bf16_t* orow = O + ((size_t)b * N + q) * (H * HD) + h * HD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                uint2 pk;
+                pk.x = pack2bf(o[db][4 * qd] * inv, o[db][4 * qd + 1] * inv);
+                pk.y = pack2bf(o[db][4 * qd + 2] * inv, o[db][4 * qd + 3] * inv);
+                *reinterpret_cast<uint2*>(orow + 32 * db + 8 * qd + 4 * lg) = pk;
+            }
+        if (lg == 0 && LSE != nullptr) LSE[(size_t)bh * N + q] = m_run + log2f(l_run);  // log2 domain
+    }
+}
+
+extern "C" int sed_mhsa_fwd(const void* Q, const void* K, const void* Vt, void* O, float* LSE, int B, int H, int N,
+                            int Npad, hipStream_t stream) {
+    if (N <= 0 || Npad % 64 || Npad < N) return SED_ERR_ARG;
+    dim3 grid(cdiv(N, 128), B * H);
+    hipLaunchKernelGGL(mhsa_fwd_kernel, grid, dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,
+                       (const bf16_t*)Vt, (bf16_t*)O, LSE, N, Npad, H);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward pre-pass: D[bh, q] = sum_d dO * O ; head-split copies dOh [BH, N, 64] and dOt [BH, 64, Npad]
+// one wave per (b, q, h-pair): 64 lanes x 2 elements = 128 channels = 2 heads
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mhsa_bwd_prep_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O,
+                                                            float* __restrict__ Dv, bf16_t* __restrict__ dOh,
+                                                            bf16_t* __restrict__ dOt, int B, int N, int Npad, int H) {
+    // block handles 64 consecutive tokens of one (b, h): transposes through LDS
+    __shared__ bf16_t tile[64][66];
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int t0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int t = t0 + ty * 16 + i;
+        float prod = 0.f;
+        bf16_t g = 0;
+        if (t < N) {
+            const size_t idx = ((size_t)b * N + t) * (H * HD) + h * HD + tx;
+            g = dO[idx];
+            prod = bf2f(g) * bf2f(O[idx]);
+            dOh[((size_t)bh * N + t) * HD + tx] = g;
+        }
+        tile[ty * 16 + i][tx] = g;
+        prod = wave_sum(prod);
+        if (tx == 0 && t < N) Dv[(size_t)bh * N + t] = prod;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int d = ty * 16 + i, t = t0 + tx;
+        if (t < Npad) dOt[((size_t)bh * HD + d) * Npad + t] = (t < N) ? tile[tx][d] : (bf16_t)0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward kernel 1: dK, dV.  Workgroup = 128 keys (4 waves x 32), loops over 64-query tiles.
+//   S[q, key]  = Q . K^T  (A = Q rows from LDS, B = K fragments in registers)  -> lane owns a key column
+//   P = exp2(S c - L2[q]);  dP[q, key] = dO . V^T ;  dS = P (dP - D[q])
+//   dV[key, d] += P^T[key, q] dO[q, d]   (A from the P registers, B = dO^T tile)
+//   dK[key, d] += dS^T[key, q] Q[q, d] * scale   (B = Q^T tile)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mhsa_bwd_dkdv_kernel(
+    const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Qt, const bf16_t* __restrict__ K,
+    const bf16_t* __restrict__ V, const bf16_t* __restrict__ dOh, const bf16_t* __restrict__ dOt,
+    const float* __restrict__ LSE, const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, int N, int Npad, int H) {
+    // LDS per stage: Q rows [64][64], dO rows [64][64], Q^T [64 d][64 q], dO^T [64 d][64 q], L2[64], D[64]
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][4][KVB * 128];
+    __shared__ __attribute__((aligned(16))) float lstat[2][2][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int key0 = blockIdx.x * 128 + wave * 32;
+    const size_t hb = (size_t)bh * N * HD, hbt = (size_t)bh * HD * Npad;
+
+    int krow = key0 + lr;
+    const bool key_valid_lane = krow < N;
+    krow = krow < N ? krow : N - 1;
+    s16x8_t kf[4], vf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        kf[s] = *reinterpret_cast<const s16x8_t*>(K + hb + (size_t)krow * HD + 16 * s + 8 * lg);
+        vf[s] = *reinterpret_cast<const s16x8_t*>(V + hb + (size_t)krow * HD + 16 * s + 8 * lg);
+    }
+    f32x16_t dk[2], dv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+
+    const int ntiles = (N + 63) / 64;
+    TileRegs rq, rdo, rqt, rdot;
+    float rs = 0.f;
+    auto gload = [&](int t) {
+        const int i0 = t * 64;
+        tile_gload(rq, Q + hb, i0, N, HD, 0, tid);
+        tile_gload(rdo, dOh + hb, i0, N, HD, 0, tid);
+        tile_gload(rqt, Qt + hbt, 0, HD, Npad, i0, tid);
+        tile_gload(rdot, dOt + hbt, 0, HD, Npad, i0, tid);
+        if (tid < 128) {
+            const int qi = i0 + (tid & 63);
+            const float* src = (tid < 64) ? LSE : Dv;
+            rs = qi < N ? src[(size_t)bh * N + qi] : (tid < 64 ? 1e30f : 0.f);  // L2 = +big -> P = 0 for padded queries
+        }
+    };
+    auto lstore = [&](int buf) {
+        tile_lstore_rows(rq, lds[buf][0], tid);
+        tile_lstore_rows(rdo, lds[buf][1], tid);
+        tile_lstore_cols(rqt, lds[buf][2], tid);
+        tile_lstore_cols(rdot, lds[buf][3], tid);
+        if (tid < 128) lstat[buf][tid >> 6][tid & 63] = rs;
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) gload(t + 1);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {  // 32-query sub-blocks of the tile
+            f32x16_t s_, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s_[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                s_ = mfma32(lds_frag_rows(lds[buf][0], 32 * qb + lr, 2 * s + lg), kf[s], s_);
+                dp = mfma32(lds_frag_rows(lds[buf][1], 32 * qb + lr, 2 * s + lg), vf[s], dp);
+            }
+            // rows of the accumulators are queries 32 qb + mfma32_row(r, lg); column = this lane's key
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int qq = 32 * qb + 8 * qd + 4 * lg;
+                const f32x4_t l2 = *reinterpret_cast<const f32x4_t*>(&lstat[buf][0][qq]);
+                const f32x4_t dd = *reinterpret_cast<const f32x4_t*>(&lstat[buf][1][qq]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * qd + j;
+                    float p = exp2f(s_[r] * SCALE_LOG2E - l2[j]);
+                    p = key_valid_lane ? p : 0.f;
+                    s_[r] = p;
+                    dp[r] = p * (dp[r] - dd[j]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const s16x8_t pf = pack_frag(s_, s), dsf = pack_frag(dp, s);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    dv[db] = mfma32(pf, lds_frag_cols(lds[buf][3], 32 * db + lr, 8 * qb + 4 * s + lg), dv[db]);
+                    dk[db] = mfma32(dsf, lds_frag_cols(lds[buf][2], 32 * db + lr, 8 * qb + 4 * s + lg), dk[db]);
+                }
+            }
+        }
+        if (t + 1 < ntiles) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // dk/dv accumulators: row = key (mfma32_row), column = d = 32 db + lr
+    const int ldq = 3 * H * HD;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + mfma32_row(r, lg);
+            if (key < N) {
+                bf16_t* row = dqkv + ((size_t)b * N + key) * ldq + h * HD + 32 * db + lr;
+                row[H * HD] = f2bf(dk[db][r] * SCALE);
+                row[2 * H * HD] = f2bf(dv[db][r]);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward kernel 2: dQ.  Workgroup = 128 queries, loops over 64-key tiles (swapped form as in forward).
+//   S^T[key, q] = K . Q^T ; dP^T[key, q] = V . dO^T ; dS^T = P^T (dP^T - D[q])
+//   dQ^T[d, q] += K^T[d, key] dS^T[key, q]
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                          const bf16_t* __restrict__ Kt, const bf16_t* __restrict__ V,
+                                                          const bf16_t* __restrict__ dOh, const float* __restrict__ LSE,
+                                                          const float* __restrict__ Dv, bf16_t* __restrict__ dqkv,
+                                                          int N, int Npad, int H) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][3][KVB * 128];  // K rows, V rows, K^T
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const size_t hb = (size_t)bh * N * HD, hbt = (size_t)bh * HD * Npad;
+    int qrow = q0 + lr;
+    const bool qvalid = qrow < N;
+    qrow = qvalid ? qrow : N - 1;
+    s16x8_t qf[4], dof[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        qf[s] = *reinterpret_cast<const s16x8_t*>(Q + hb + (size_t)qrow * HD + 16 * s + 8 * lg);
+        dof[s] = *reinterpret_cast<const s16x8_t*>(dOh + hb + (size_t)qrow * HD + 16 * s + 8 * lg);
+    }
+    const float l2 = LSE[(size_t)bh * N + qrow], dd = Dv[(size_t)bh * N + qrow];
+    f32x16_t dq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+    const int ntiles = (N + KVB - 1) / KVB;
+    TileRegs rk, rv, rkt;
+    auto gload = [&](int t) {
+        tile_gload(rk, K + hb, t * KVB, N, HD, 0, tid);
+        tile_gload(rv, V + hb, t * KVB, N, HD, 0, tid);
+        tile_gload(rkt, Kt + hbt, 0, HD, Npad, t * KVB, tid);
+    };
+    auto lstore = [&](int buf) {
+        tile_lstore_rows(rk, lds[buf][0], tid);
+        tile_lstore_rows(rv, lds[buf][1], tid);
+        tile_lstore_cols(rkt, lds[buf][2], tid);
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1, j0 = t * KVB;
+        if (t + 1 < ntiles) gload(t + 1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16_t st, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                st = mfma32(lds_frag_rows(lds[buf][0], 32 * kb + lr, 2 * s + lg), qf[s], st);
+                dp = mfma32(lds_frag_rows(lds[buf][1], 32 * kb + lr, 2 * s + lg), dof[s], dp);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = j0 + 32 * kb + mfma32_row(r, lg);
+                float p = exp2f(st[r] * SCALE_LOG2E - l2);
+                p = key < N ? p : 0.f;
+                dp[r] = p * (dp[r] - dd);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const s16x8_t dsf = pack_frag(dp, s);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    dq[db] = mfma32(lds_frag_cols(lds[buf][2], 32 * db + lr, 8 * kb + 4 * s + lg), dsf, dq[db]);
+            }
+        }
+        if (t + 1 < ntiles) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    if (qvalid) {
+        bf16_t* row = dqkv + ((size_t)b * N + q0 + lr) * (3 * H * HD) + h * HD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                uint2 pk;
+                pk.x = pack2bf(dq[db][4 * qd] * SCALE, dq[db][4 * qd + 1] * SCALE);
+                pk.y = pack2bf(dq[db][4 * qd + 2] * SCALE, dq[db][4 * qd + 3] * SCALE);
+                *reinterpret_cast<uint2*>(row + 32 * db + 8 * qd + 4 * lg) = pk;
+            }
+    }
+}
+
+extern "C" int sed_mhsa_bwd_prep(const void* dO, const void* O, float* Dtmp, void* dOh, void* dOt, int B, int H, int N,
+                                 int Npad, hipStream_t stream) {
+    if (N <= 0 || Npad % 64 || Npad < N) return SED_ERR_ARG;
+    hipLaunchKernelGGL(mhsa_bwd_prep_kernel, dim3(Npad / 64, B * H), dim3(256), 0, stream, (const bf16_t*)dO,
+                       (const bf16_t*)O, Dtmp, (bf16_t*)dOh, (bf16_t*)dOt, B, N, Npad, H);
+    return sed_check_launch();
+}
+
+extern "C" int sed_mhsa_bwd(const void* Q, const void* Qt, const void* K, const void* Kt, const void* V,
+                            const void* O, const void* dO, const float* LSE, float* Dtmp, void* dOh, void* dOt,
+                            void* dqkv, int B, int H, int N, int Npad, hipStream_t stream) {
+    if (N <= 0 || Npad % 64 || Npad < N) return SED_ERR_ARG;
+    hipLaunchKernelGGL(mhsa_bwd_prep_kernel, dim3(Npad / 64, B * H), dim3(256), 0, stream, (const bf16_t*)dO,
+                       (const bf16_t*)O, Dtmp, (bf16_t*)dOh, (bf16_t*)dOt, B, N, Npad, H);
+    dim3 grid(cdiv(N, 128), B * H);
+    hipLaunchKernelGGL(mhsa_bwd_dkdv_kernel, grid, dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)Qt,
+                       (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dOh, (const bf16_t*)dOt, LSE, Dtmp,
+                       (bf16_t*)dqkv, N, Npad, H);
+    hipLaunchKernelGGL(mhsa_bwd_dq_kernel, grid, dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,
+                       (const bf16_t*)Kt, (const bf16_t*)V, (const bf16_t*)dOh, LSE, Dtmp, (bf16_t*)dqkv, N, Npad, H);
+    return sed_check_launch();
+}

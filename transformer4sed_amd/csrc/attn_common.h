@@ -1,0 +1,59 @@
+// Shared LDS tile images / fragment helpers for the attention kernels (attention.hip, relpos_attention.hip).
+#pragma once
+#include "common.h"
+
+#define HD 64
+#define KVB 64
+#define SCALE_LOG2E 0.18033688011112042f  // (1/sqrt(64)) * log2(e)
+#define SCALE 0.125f
+
+// LDS tile images: K-like tile [64 rows][64 bf16] (128-B rows), 16-B chunks swizzled with (row>>1)&7;
+// V^T-like tile [64 rows][64 bf16], 8-B chunks swizzled with (row>>1)&15.
+__device__ __forceinline__ int k_off(int row, int ch16) { return row * 128 + ((ch16 ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int vt_off(int row, int ch8) { return row * 128 + ((ch8 ^ ((row >> 1) & 15)) << 3); }
+
+__device__ __forceinline__ s16x8_t lds_frag_rows(const unsigned char* base, int row, int ch16) {
+    return *reinterpret_cast<const s16x8_t*>(base + k_off(row, ch16));
+}
+// fragment whose 8 k-elements are {c..c+3, c+8..c+11} (4-element chunk index ch8 and ch8 + 2)
+__device__ __forceinline__ s16x8_t lds_frag_cols(const unsigned char* base, int row, int ch8) {
+    const s16x4_t lo = *reinterpret_cast<const s16x4_t*>(base + vt_off(row, ch8));
+    const s16x4_t hi = *reinterpret_cast<const s16x4_t*>(base + vt_off(row, ch8 + 2));
+    s16x8_t r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+__device__ __forceinline__ s16x8_t pack_frag(const f32x16_t& p, int s) {  // registers 8s..8s+7 -> 8 bf16
+    s16x8_t r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (short)f2bf(p[8 * s + e]);
+    return r;
+}
+
+// cooperative stage of one [64][64] bf16 tile (rows r0.., row stride `ld` elements) : 256 threads x 2 x 16 B
+// (named members, not an array: keeps the staged tile in VGPRs instead of scratch)
+struct TileRegs { uint4 a, b; };
+__device__ __forceinline__ uint4 tile_gload1(const bf16_t* src, int row_first, int nrows_valid, int ld, int col_first,
+                                             int r, int c) {
+    int rr = row_first + r;
+    rr = rr < nrows_valid ? rr : nrows_valid - 1;
+    return *reinterpret_cast<const uint4*>(src + (size_t)rr * ld + col_first + c * 8);
+}
+__device__ __forceinline__ void tile_gload(TileRegs& t, const bf16_t* src, int row_first, int nrows_valid, int ld,
+                                           int col_first, int tid) {
+    t.a = tile_gload1(src, row_first, nrows_valid, ld, col_first, tid >> 3, tid & 7);
+    t.b = tile_gload1(src, row_first, nrows_valid, ld, col_first, (tid >> 3) + 32, tid & 7);
+}
+__device__ __forceinline__ void tile_lstore_rows(const TileRegs& t, unsigned char* dst, int tid) {
+    const int r = tid >> 3, c = tid & 7;
+    *reinterpret_cast<uint4*>(dst + k_off(r, c)) = t.a;
+    *reinterpret_cast<uint4*>(dst + k_off(r + 32, c)) = t.b;
+}
+__device__ __forceinline__ void tile_lstore_cols(const TileRegs& t, unsigned char* dst, int tid) {
+    const int r = tid >> 3, c = tid & 7;
+    *reinterpret_cast<uint2*>(dst + vt_off(r, 2 * c)) = make_uint2(t.a.x, t.a.y);
+    *reinterpret_cast<uint2*>(dst + vt_off(r, 2 * c + 1)) = make_uint2(t.a.z, t.a.w);
+    *reinterpret_cast<uint2*>(dst + vt_off(r + 32, 2 * c)) = make_uint2(t.b.x, t.b.y);
+    *reinterpret_cast<uint2*>(dst + vt_off(r + 32, 2 * c + 1)) = make_uint2(t.b.z, t.b.w);
+}

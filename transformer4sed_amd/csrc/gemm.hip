@@ -1,0 +1,374 @@
+// bf16 MFMA GEMM (NT form) with fused epilogues, for gfx950.
+//
+//   C[M,N] = A[M,K] . B[N,K]^T        A, B bf16 row-major with K contiguous (nn.Linear weight layout for B)
+//
+// 128x128x64 workgroup tile, 4 waves (2x2), each wave a 64x64 sub-tile = 2x2 v_mfma_f32_32x32x16_bf16 blocks,
+// fp32 accumulation.  Operand tiles are register-staged (global_load_dwordx4 issued before the MFMA phase,
+// ds_write_b128 after it) into double-buffered, XOR-swizzled LDS so that the fragment ds_read_b128s are
+// bank-conflict free (128-byte rows: 16-B chunk index ^= (row >> 1) & 7).  One barrier per K tile.
+// Workgroup ids are remapped XCD-aware so that neighbouring tiles (which share A rows / B columns) hit the
+// same per-XCD L2.
+//
+// Replaces (reference, all relative to /root/reference): F.linear / nn.Linear calls at
+// src/models/passt/passt.py:271,274,332,342; src/models/transformer/transformerXL.py:382,493,584;
+// timm Mlp fc1/fc2 in the context blocks; the conv2d of passt.py:307 (as im2col GEMM);
+// src/models/passt/passt_sed.py:196 (mlm_mlp) and their autograd backward GEMMs.
+#include "common.h"
+#include "../../include/sed_hip.h"
+
+enum {
+    EPI_F32 = 0,          // outF = acc*alpha + bias
+    EPI_F32_RESID = 1,    // outF = resF + acc + bias                (residual stream; resF may alias outF)
+    EPI_BF16 = 2,         // outH = bf16(acc + bias)
+    EPI_GELU = 3,         // outH = bf16(h = acc + bias), outH2 = bf16(gelu(h))
+    EPI_DGELU = 4,        // outH = bf16(acc * gelu'(auxH))
+    EPI_ATOMIC = 5,       // atomicAdd(outF, acc*alpha)               (split-K weight gradients)
+    EPI_QKV = 6,          // head-split q/k/v (+ transposed copies, + rel-pos biased queries)
+    EPI_F32_BF16 = 7,     // outF = acc + bias and outH = bf16(same)
+};
+
+struct GemmArgs {
+    const bf16_t* A;
+    const bf16_t* B;
+    int M, N, K, lda, ldb, ldc, ksplit;
+    float alpha;
+    const float* bias;
+    const float* resF;
+    float* outF;
+    bf16_t* outH;
+    bf16_t* outH2;
+    const bf16_t* auxH;
+    // EPI_QKV
+    bf16_t *q, *k, *v, *qt, *kt, *vt, *q2, *q2t;
+    const float *pu, *pv;
+    int seq, seq_pad, heads;
+};
+
+#define TILE 128
+#define BK 64
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_quad(const GemmArgs& g, int m_base, int n, const float v4[4], int M) {
+    // v4[j] belongs to row m_base + j (4 consecutive rows), column n
+    const float b = (g.bias != nullptr) ? g.bias[n] : 0.0f;
+    if (EPI == EPI_QKV) {
+        const int D = g.heads * 64;
+        const int which = n / D, hn = n - which * D, h = hn >> 6, d = hn & 63;
+        const int bidx = m_base / g.seq, t0 = m_base - bidx * g.seq;
+        const int bh = bidx * g.heads + h;
+        bf16_t* row_dst = which == 0 ? g.q : (which == 1 ? g.k : g.v);
+        bf16_t* tr_dst = which == 0 ? g.qt : (which == 1 ? g.kt : g.vt);
+        float extra = 0.f, extra2 = 0.f;
+        if (which == 0 && g.pu != nullptr) { extra = g.pu[h * 64 + d]; extra2 = g.pv[h * 64 + d]; }
+        float val[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) val[j] = v4[j] + b;
+        const bool fast = (t0 + 3 < g.seq) && ((t0 & 3) == 0) && (m_base + 3 < M);
+        if (fast) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                row_dst[((size_t)bh * g.seq + t0 + j) * 64 + d] = f2bf(val[j] + extra);
+            if (tr_dst != nullptr) {
+                uint2 pk;
+                pk.x = pack2bf(val[0] + extra, val[1] + extra);
+                pk.y = pack2bf(val[2] + extra, val[3] + extra);
+                *reinterpret_cast<uint2*>(&tr_dst[((size_t)bh * 64 + d) * g.seq_pad + t0]) = pk;
+            }
+            if (which == 0 && g.q2 != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    g.q2[((size_t)bh * g.seq + t0 + j) * 64 + d] = f2bf(val[j] + extra2);
+                if (g.q2t != nullptr) {
+                    uint2 pk;
+                    pk.x = pack2bf(val[0] + extra2, val[1] + extra2);
+                    pk.y = pack2bf(val[2] + extra2, val[3] + extra2);
+                    *reinterpret_cast<uint2*>(&g.q2t[((size_t)bh * 64 + d) * g.seq_pad + t0]) = pk;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = m_base + j;
+                if (m >= M) break;
+                const int bj = m / g.seq, t = m - bj * g.seq, bhj = bj * g.heads + h;
+                row_dst[((size_t)bhj * g.seq + t) * 64 + d] = f2bf(val[j] + extra);
+                if (tr_dst != nullptr) tr_dst[((size_t)bhj * 64 + d) * g.seq_pad + t] = f2bf(val[j] + extra);
+                if (which == 0 && g.q2 != nullptr) {
+                    g.q2[((size_t)bhj * g.seq + t) * 64 + d] = f2bf(val[j] + extra2);
+                    if (g.q2t != nullptr) g.q2t[((size_t)bhj * 64 + d) * g.seq_pad + t] = f2bf(val[j] + extra2);
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m_base + j;
+        if (m >= M) break;
+        const size_t o = (size_t)m * g.ldc + n;
+        const float acc = v4[j];
+        if (EPI == EPI_F32) {
+            g.outF[o] = acc * g.alpha + b;
+        } else if (EPI == EPI_F32_RESID) {
+            g.outF[o] = g.resF[o] + acc + b;
+        } else if (EPI == EPI_BF16) {
+            g.outH[o] = f2bf(acc + b);
+        } else if (EPI == EPI_GELU) {
+            const float h = acc + b;
+            g.outH[o] = f2bf(h);
+            g.outH2[o] = f2bf(gelu_erf(h));
+        } else if (EPI == EPI_DGELU) {
+            g.outH[o] = f2bf(acc * gelu_erf_grad(bf2f(g.auxH[o])));
+        } else if (EPI == EPI_ATOMIC) {
+            unsafeAtomicAdd(&g.outF[o], acc * g.alpha);
+        } else if (EPI == EPI_F32_BF16) {
+            g.outF[o] = acc + b;
+            g.outH[o] = f2bf(acc + b);
+        }
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][TILE * BK * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = g.N / TILE, ntm = (g.M + TILE - 1) / TILE, nwg = ntm * ntn;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int m0 = (t / ntn) * TILE, n0 = (t % ntn) * TILE;
+    const int ktiles = g.K / BK;
+    const int kt_begin = (int)(((long long)blockIdx.y * ktiles) / g.ksplit);
+    const int kt_end = (int)(((long long)(blockIdx.y + 1) * ktiles) / g.ksplit);
+
+    // staging: thread -> 16-B chunk c of rows r0 + 32 i
+    const int c = tid & 7, r0 = tid >> 3;
+    const bf16_t* aptr[4];
+    const bf16_t* bptr[4];
+    int lds_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 32 * i;
+        int am = m0 + r;
+        am = am < g.M ? am : g.M - 1;
+        aptr[i] = g.A + (size_t)am * g.lda + c * 8;
+        bptr[i] = g.B + (size_t)(n0 + r) * g.ldb + c * 8;
+        lds_off[i] = r * 128 + ((c ^ ((r >> 1) & 7)) << 4);
+    }
+    uint4 ra[4], rb[4];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *reinterpret_cast<const uint4*>(aptr[i] + (size_t)kt * BK);
+            rb[i] = *reinterpret_cast<const uint4*>(bptr[i] + (size_t)kt * BK);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<uint4*>(&lds[buf][0][lds_off[i]]) = ra[i];
+            *reinterpret_cast<uint4*>(&lds[buf][1][lds_off[i]]) = rb[i];
+        }
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets (row part), chunk part depends on the k-step
+    const int lr = lane & 31, lg = lane >> 5;
+    int arow[2], brow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        arow[i] = wm * 64 + i * 32 + lr;
+        brow[i] = wn * 64 + i * 32 + lr;
+    }
+
+    if (kt_begin < kt_end) {
+        gload(kt_begin);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) gload(kt + 1);
+        const unsigned char* la = lds[buf][0];
+        const unsigned char* lb = lds[buf][1];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int ch = 2 * s + lg;
+            s16x8_t af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = *reinterpret_cast<const s16x8_t*>(la + arow[i] * 128 + ((ch ^ ((arow[i] >> 1) & 7)) << 4));
+                bfr[i] = *reinterpret_cast<const s16x8_t*>(lb + brow[i] * 128 + ((ch ^ ((brow[i] >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[i], bfr[j], acc[i][j]);
+        }
+        if (kt + 1 < kt_end) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + lr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m_base = m0 + wm * 64 + i * 32 + 8 * q + 4 * lg;
+                if (m_base >= g.M) continue;
+                float v4[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                epilogue_quad<EPI>(g, m_base, n, v4, g.M);
+            }
+        }
+}
+
+template <int EPI>
+static int launch_gemm(const GemmArgs& g, hipStream_t s) {
+    if (g.M <= 0 || g.N % TILE != 0 || g.K % BK != 0 || g.ksplit < 1) return SED_ERR_ARG;
+    if ((g.lda % 8) || (g.ldb % 8)) return SED_ERR_ARG;
+    dim3 grid(cdiv(g.M, TILE) * (g.N / TILE), g.ksplit);
+    hipLaunchKernelGGL(gemm_nt_kernel<EPI>, grid, dim3(256), 0, s, g);
+    return sed_check_launch();
+}
+
+extern "C" int sed_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi,
+                           const float* bias, const float* resF, float* outF, void* outH, void* outH2,
+                           const void* auxH, int ldc, float alpha, int ksplit, hipStream_t stream) {
+    GemmArgs g = {};
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ksplit = ksplit > 0 ? ksplit : 1;
+    g.alpha = alpha; g.bias = bias; g.resF = resF; g.outF = outF; g.outH = (bf16_t*)outH; g.outH2 = (bf16_t*)outH2;
+    g.auxH = (const bf16_t*)auxH;
+    switch (epi) {
+        case EPI_F32: return launch_gemm<EPI_F32>(g, stream);
+        case EPI_F32_RESID: return launch_gemm<EPI_F32_RESID>(g, stream);
+        case EPI_BF16: return launch_gemm<EPI_BF16>(g, stream);
+        case EPI_GELU: return launch_gemm<EPI_GELU>(g, stream);
+        case EPI_DGELU: return launch_gemm<EPI_DGELU>(g, stream);
+        case EPI_ATOMIC: return launch_gemm<EPI_ATOMIC>(g, stream);
+        case EPI_F32_BF16: return launch_gemm<EPI_F32_BF16>(g, stream);
+        default: return SED_ERR_ARG;
+    }
+}
+
+extern "C" int sed_gemm_qkv(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq,
+                            int seq_pad, void* q, void* k, void* v, void* qt, void* kt, void* vt, void* q2,
+                            void* q2t, const float* pos_u, const float* pos_v, hipStream_t stream) {
+    GemmArgs g = {};
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)W;
+    g.M = M; g.N = 3 * heads * 64; g.K = K; g.lda = K; g.ldb = K; g.ldc = g.N; g.ksplit = 1; g.alpha = 1.f;
+    g.bias = bias;
+    g.q = (bf16_t*)q; g.k = (bf16_t*)k; g.v = (bf16_t*)v; g.qt = (bf16_t*)qt; g.kt = (bf16_t*)kt; g.vt = (bf16_t*)vt;
+    g.q2 = (bf16_t*)q2; g.q2t = (bf16_t*)q2t; g.pu = pos_u; g.pv = pos_v;
+    g.seq = seq; g.seq_pad = seq_pad; g.heads = heads;
+    if (seq <= 0 || (seq_pad % 64) || M % seq) return SED_ERR_ARG;
+    return launch_gemm<EPI_QKV>(g, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Layout helpers around the GEMM: casts, transposes (with zero padding of the reduction dim), column sums.
+// ---------------------------------------------------------------------------------------------------
+// in fp32 [R, C] -> out bf16 [R, C]  (grid-stride, float4 in / 8 B out)
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(in)[i];
+        uint2 p;
+        p.x = pack2bf(v.x, v.y);
+        p.y = pack2bf(v.z, v.w);
+        reinterpret_cast<uint2*>(out)[i] = p;
+    }
+}
+
+extern "C" int sed_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream_t stream) {
+    if (n % 4) return SED_ERR_ARG;
+    const size_t n4 = n / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(blocks), dim3(256), 0, stream, in, (bf16_t*)out, n4);
+    return sed_check_launch();
+}
+
+// Transpose [R, C] (fp32 or bf16 in) -> bf16 out^T [C, Rpad] (rows R..Rpad-1 written as zeros), optionally also
+// the straight bf16 copy [R, C] and the fp32 column sums (atomicAdd into colsum[C]) -- one pass over the input.
+// 64x64 tiles through LDS; 256 threads.
+template <typename TIN>
+__global__ __launch_bounds__(256) void transpose_kernel(const TIN* __restrict__ in, int R, int C, int ldin,
+                                                        bf16_t* __restrict__ outT, int Rpad,
+                                                        bf16_t* __restrict__ outS, float* __restrict__ colsum) {
+    __shared__ float tile[64][65];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // ty 0..3
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty * 16 + i, cc = c0 + tx;
+        float v = 0.f;
+        if (r < R && cc < C) {
+            if (sizeof(TIN) == 4) v = ((const float*)in)[(size_t)r * ldin + cc];
+            else v = bf2f(((const bf16_t*)in)[(size_t)r * ldin + cc]);
+            if (outS != nullptr) outS[(size_t)r * C + cc] = f2bf(v);
+        }
+        tile[ty * 16 + i][tx] = v;
+    }
+    __syncthreads();
+    if (colsum != nullptr && ty == 0) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) s += tile[i][tx];
+        if (c0 + tx < C) unsafeAtomicAdd(&colsum[c0 + tx], s);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int cc = c0 + ty * 16 + i, r = r0 + tx;
+        if (cc < C && r < Rpad) outT[(size_t)cc * Rpad + r] = f2bf(tile[tx][ty * 16 + i]);
+    }
+}
+
+extern "C" int sed_transpose_to_bf16(const void* in, int in_is_f32, int R, int C, int ldin, void* outT, int Rpad,
+                                     void* outS, float* colsum, hipStream_t stream) {
+    if (Rpad < R) return SED_ERR_ARG;
+    dim3 grid(cdiv(C, 64), cdiv(Rpad, 64));
+    if (in_is_f32)
+        hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, stream, (const float*)in, R, C, ldin,
+                           (bf16_t*)outT, Rpad, (bf16_t*)outS, colsum);
+    else
+        hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)in, R, C, ldin,
+                           (bf16_t*)outT, Rpad, (bf16_t*)outS, colsum);
+    return sed_check_launch();
+}
+
+// Small-M fp32 linear: out[m, n] = sum_k a[m, k] w[n, k] + b[n]   (one wave per output element row-chunk).
+// Used for the batch-independent / per-clip tiny projections (AT-head query, out_proj, 768->10 classifier).
+__global__ void small_linear_kernel(const float* __restrict__ a, const float* __restrict__ w,
+                                    const float* __restrict__ b, float* __restrict__ out, int M, int N, int K,
+                                    int act) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= M * N) return;
+    const int m = wave / N, n = wave - m * N;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += a[(size_t)m * K + k] * w[(size_t)n * K + k];
+    s = wave_sum(s);
+    if (lane == 0) {
+        s += (b != nullptr ? b[n] : 0.f);
+        if (act == 1) s = sigmoidf_(s);
+        out[(size_t)m * N + n] = s;
+    }
+}
+
+extern "C" int sed_small_linear(const float* a, const float* w, const float* b, float* out, int M, int N, int K,
+                                int act, hipStream_t stream) {
+    const int64_t waves = (int64_t)M * N;
+    hipLaunchKernelGGL(small_linear_kernel, dim3(cdiv(waves * 64, 256)), dim3(256), 0, stream, a, w, b, out, M, N,
+                       K, act);
+    return sed_check_launch();
+}

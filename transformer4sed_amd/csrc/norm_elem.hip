@@ -1,0 +1,799 @@
+// HBM-bound kernels of the MAT-SED model path: LayerNorm fwd/bwd, patch im2col / token assembly, frequency
+// pooling + x10 linear interpolation (+ sliding-window merge), classifier/pooling heads, attention-pooling
+// AT head, MLM masking and loss, fused AdamW + EMA.  All fp32 math; bf16 only as GEMM-operand outputs.
+// Wave64: one wavefront per 768-wide row, 12 channels per lane held as 3 x float4, shuffle reductions.
+#include "common.h"
+#include "../../include/sed_hip.h"
+
+#define DM 768
+#define NV 3  // float4 per lane per row
+
+struct Row { float4 v[NV]; };
+
+__device__ __forceinline__ void row_load(Row& r, const float* p, int lane) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) r.v[i] = reinterpret_cast<const float4*>(p)[lane + 64 * i];
+}
+__device__ __forceinline__ void row_store(const Row& r, float* p, int lane) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) reinterpret_cast<float4*>(p)[lane + 64 * i] = r.v[i];
+}
+__device__ __forceinline__ void row_store_bf16(const Row& r, bf16_t* p, int lane) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        uint2 pk;
+        pk.x = pack2bf(r.v[i].x, r.v[i].y);
+        pk.y = pack2bf(r.v[i].z, r.v[i].w);
+        reinterpret_cast<uint2*>(p)[lane + 64 * i] = pk;
+    }
+}
+#define ROW_FOREACH(i, c) for (int i = 0; i < NV; ++i) for (int c = 0; c < 4; ++c)
+__device__ __forceinline__ float& f4(float4& v, int c) { return reinterpret_cast<float*>(&v)[c]; }
+__device__ __forceinline__ const float& f4(const float4& v, int c) { return reinterpret_cast<const float*>(&v)[c]; }
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm   y = LN(in_scale * x) * gamma + beta      (passt.py:361-362,580; timm Block norms; out_norm)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, float in_scale,
+                                                            bf16_t* __restrict__ y16, float* __restrict__ y32,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int M) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    Row r, g, b;
+    row_load(r, x + (size_t)row * DM, lane);
+    row_load(g, gamma, lane);
+    row_load(b, beta, lane);
+    float s = 0.f;
+#pragma unroll
+    ROW_FOREACH(i, c) { f4(r.v[i], c) *= in_scale; s += f4(r.v[i], c); }
+    const float mu = wave_sum(s) * (1.0f / DM);
+    float q = 0.f;
+#pragma unroll
+    ROW_FOREACH(i, c) { const float d = f4(r.v[i], c) - mu; q += d * d; }
+    const float rs = rsqrtf(wave_sum(q) * (1.0f / DM) + eps);
+#pragma unroll
+    ROW_FOREACH(i, c) f4(r.v[i], c) = (f4(r.v[i], c) - mu) * rs * f4(g.v[i], c) + f4(b.v[i], c);
+    if (y16 != nullptr) row_store_bf16(r, y16 + (size_t)row * DM, lane);
+    if (y32 != nullptr) row_store(r, y32 + (size_t)row * DM, lane);
+    if (lane == 0 && mean != nullptr) { mean[row] = mu; rstd[row] = rs; }
+}
+
+extern "C" int sed_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float in_scale,
+                                 void* y_bf16, float* y_f32, float* mean, float* rstd, int M, int D, hipStream_t stream) {
+    if (D != DM || M <= 0) return SED_ERR_ARG;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, stream, x, gamma, beta, eps, in_scale,
+                       (bf16_t*)y_bf16, y_f32, mean, rstd, M);
+    return sed_check_launch();
+}
+
+// dx = in_scale * rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat)),  dyg = dy * gamma.
+// dx is ADDED into dx_acc when accumulate != 0 (residual-stream gradient), else stored.
+// dgamma/dbeta: per-wave register partials over a grid-stride row loop -> LDS block reduce -> atomicAdd.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, float in_scale,
+                                                            float* __restrict__ dx_acc, int accumulate,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
+                                                            float dy_scale) {
+    __shared__ float red[4][DM];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Row g, pg, pb;
+    row_load(g, gamma, lane);
+#pragma unroll
+    ROW_FOREACH(i, c) { f4(pg.v[i], c) = 0.f; f4(pb.v[i], c) = 0.f; }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        Row d, xr;
+        row_load(d, dy + (size_t)row * DM, lane);
+        row_load(xr, x + (size_t)row * DM, lane);
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        ROW_FOREACH(i, c) {
+            const float xh = (f4(xr.v[i], c) * in_scale - mu) * rs;
+            const float dyv = f4(d.v[i], c) * dy_scale;
+            f4(pg.v[i], c) += dyv * xh;
+            f4(pb.v[i], c) += dyv;
+            const float dg = dyv * f4(g.v[i], c);
+            f4(d.v[i], c) = dg;
+            f4(xr.v[i], c) = xh;
+            s1 += dg;
+            s2 += dg * xh;
+        }
+        s1 = wave_sum(s1) * (1.0f / DM);
+        s2 = wave_sum(s2) * (1.0f / DM);
+        float* out = dx_acc + (size_t)row * DM;
+        Row o;
+        if (accumulate) row_load(o, out, lane);
+#pragma unroll
+        ROW_FOREACH(i, c) {
+            const float v = in_scale * rs * (f4(d.v[i], c) - s1 - f4(xr.v[i], c) * s2);
+            f4(o.v[i], c) = accumulate ? f4(o.v[i], c) + v : v;
+        }
+        row_store(o, out, lane);
+    }
+    if (dgamma == nullptr) return;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const Row& p = pass == 0 ? pg : pb;
+        row_store(p, red[wave], lane);
+        __syncthreads();
+        for (int c = threadIdx.x; c < DM; c += 256) {
+            const float s = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+            unsafeAtomicAdd(pass == 0 ? &dgamma[c] : &dbeta[c], s);
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int sed_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                                 const float* gamma, float in_scale, float* dx, int accumulate, float* dgamma,
+                                 float* dbeta, int M, int D, hipStream_t stream) {
+    if (D != DM || M <= 0) return SED_ERR_ARG;
+    int blocks = cdiv(M, 4);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, stream, dy, x, mean, rstd, gamma, in_scale, dx,
+                       accumulate, dgamma, dbeta, M, 1.0f);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Patch embedding plumbing (passt.py:302-315, 503-569): im2col for the 16x16/stride-10 conv, token assembly.
+// ---------------------------------------------------------------------------------------------------
+// mel [B, 128, T] fp32 -> cols bf16 [B * 12 * tp, 256];  row (b, f, t), col 16 i + j = mel[b, 10 f + i, tstart + 10 t + j]
+// (tstart selects a sliding-window slab without copying it)
+__global__ void im2col_kernel(const float* __restrict__ mel, bf16_t* __restrict__ cols, int B, int T, int tstart,
+                              int tp) {
+    const size_t total = (size_t)B * 12 * tp * 128;  // pairs
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int pr = (int)(idx & 127);
+        const size_t row = idx >> 7;
+        const int t = (int)(row % tp), f = (int)((row / tp) % 12), b = (int)(row / ((size_t)tp * 12));
+        const int i = pr >> 3, j = (pr & 7) * 2;
+        const float* src = mel + ((size_t)b * 128 + 10 * f + i) * T + tstart + 10 * t + j;
+        reinterpret_cast<unsigned*>(cols)[idx] = pack2bf(src[0], src[1]);
+    }
+}
+extern "C" int sed_im2col(const float* mel, void* cols, int B, int T, int tstart, int tp, hipStream_t stream) {
+    if (tp < 1 || tstart < 0 || tstart + 10 * (tp - 1) + 16 > T) return SED_ERR_ARG;
+    hipLaunchKernelGGL(im2col_kernel, dim3(2048), dim3(256), 0, stream, mel, (bf16_t*)cols, B, T, tstart, tp);
+    return sed_check_launch();
+}
+// d mel is never needed (the mel input is data).
+
+// conv [B * 12 * tp, D] (bias already added) -> x [B, 2 + 12 tp, D] with the three positional tables.
+// freq_pe [D, 12], time_pe [D, 99] in the reference's checkpoint layout ([1,D,12,1] / [1,D,1,99]).
+__global__ void assemble_tokens_kernel(const float* __restrict__ conv, const float* __restrict__ cls,
+                                       const float* __restrict__ dist, const float* __restrict__ new_pos,
+                                       const float* __restrict__ freq_pe, const float* __restrict__ time_pe,
+                                       int toffset, float* __restrict__ x, int B, int tp) {
+    const int N = 2 + 12 * tp;
+    const size_t total = (size_t)B * N * DM;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(idx % DM);
+        const size_t tok = idx / DM;
+        const int n = (int)(tok % N), b = (int)(tok / N);
+        float v;
+        if (n == 0) v = cls[d] + new_pos[d];
+        else if (n == 1) v = dist[d] + new_pos[DM + d];
+        else {
+            const int p = n - 2, f = p / tp, t = p - f * tp;
+            v = conv[((size_t)b * 12 * tp + p) * DM + d] + time_pe[d * 99 + toffset + t] + freq_pe[d * 12 + f];
+        }
+        x[idx] = v;
+    }
+}
+extern "C" int sed_assemble_tokens(const float* conv, const float* cls, const float* dist, const float* new_pos,
+                                   const float* freq_pe, const float* time_pe, int toffset, float* x, int B, int tp,
+                                   hipStream_t stream) {
+    if (tp < 1 || toffset < 0 || toffset + tp > 99) return SED_ERR_ARG;
+    hipLaunchKernelGGL(assemble_tokens_kernel, dim3(2048), dim3(256), 0, stream, conv, cls, dist, new_pos, freq_pe,
+                       time_pe, toffset, x, B, tp);
+    return sed_check_launch();
+}
+// backward: dx [B, N, D] -> dconv bf16 rows (GEMM operand), d cls/dist/new_pos, d freq_pe, d time_pe (atomics)
+__global__ void assemble_tokens_bwd_kernel(const float* __restrict__ dx, bf16_t* __restrict__ dconv,
+                                           float* __restrict__ dcls, float* __restrict__ ddist,
+                                           float* __restrict__ dnew_pos, float* __restrict__ dfreq,
+                                           float* __restrict__ dtime, int toffset, int B, int tp) {
+    // one block per (f or token-pair, d-chunk): reduce over b (and t / f) in registers, few atomics
+    const int N = 2 + 12 * tp;
+    const int d = blockIdx.y * 256 + threadIdx.x;
+    if (d >= DM) return;
+    const int job = blockIdx.x;  // 0: cls/dist, 1..12: freq row f = job-1 (also writes dconv), 13..: time cols
+    if (job == 0) {
+        float a = 0.f, c = 0.f;
+        for (int b = 0; b < B; ++b) {
+            a += dx[((size_t)b * N) * DM + d];
+            c += dx[((size_t)b * N + 1) * DM + d];
+        }
+        dcls[d] += a; ddist[d] += c; dnew_pos[d] += a; dnew_pos[DM + d] += c;
+    } else if (job <= 12) {
+        const int f = job - 1;
+        float a = 0.f;
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < tp; ++t) {
+                const float v = dx[((size_t)b * N + 2 + f * tp + t) * DM + d];
+                a += v;
+                dconv[((size_t)b * 12 * tp + f * tp + t) * DM + d] = f2bf(v);
+            }
+        dfreq[d * 12 + f] += a;
+    } else {
+        const int t = job - 13;
+        float a = 0.f;
+        for (int b = 0; b < B; ++b)
+            for (int f = 0; f < 12; ++f) a += dx[((size_t)b * N + 2 + f * tp + t) * DM + d];
+        dtime[d * 99 + toffset + t] += a;
+    }
+}
+extern "C" int sed_assemble_tokens_bwd(const float* dx, void* dconv, float* dcls, float* ddist, float* dnew_pos,
+                                       float* dfreq, float* dtime, int toffset, int B, int tp, hipStream_t stream) {
+    hipLaunchKernelGGL(assemble_tokens_bwd_kernel, dim3(13 + tp, DM / 256), dim3(256), 0, stream, dx, (bf16_t*)dconv,
+                       dcls, ddist, dnew_pos, dfreq, dtime, toffset, B, tp);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// f_pool (passt_sed.py:199-218, 'mean_pool'):  pooled[b, t] = mean_f LN_out_norm(x[b, 2 + f tp + t])
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        float* __restrict__ pooled, float* __restrict__ mean,
+                                                        float* __restrict__ rstd, int B, int tp) {
+    const int lane = threadIdx.x & 63;
+    const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (job >= B * tp) return;
+    const int b = job / tp, t = job - b * tp, N = 2 + 12 * tp;
+    Row g, bt, acc;
+    row_load(g, gamma, lane);
+    row_load(bt, beta, lane);
+#pragma unroll
+    ROW_FOREACH(i, c) f4(acc.v[i], c) = 0.f;
+    for (int f = 0; f < 12; ++f) {
+        const size_t tok = (size_t)b * N + 2 + f * tp + t;
+        Row r;
+        row_load(r, x + tok * DM, lane);
+        float s = 0.f;
+#pragma unroll
+        ROW_FOREACH(i, c) s += f4(r.v[i], c);
+        const float mu = wave_sum(s) * (1.0f / DM);
+        float q = 0.f;
+#pragma unroll
+        ROW_FOREACH(i, c) { const float d = f4(r.v[i], c) - mu; q += d * d; }
+        const float rs = rsqrtf(wave_sum(q) * (1.0f / DM) + eps);
+#pragma unroll
+        ROW_FOREACH(i, c) f4(acc.v[i], c) += (f4(r.v[i], c) - mu) * rs * f4(g.v[i], c) + f4(bt.v[i], c);
+        if (lane == 0 && mean != nullptr) { mean[tok] = mu; rstd[tok] = rs; }
+    }
+#pragma unroll
+    ROW_FOREACH(i, c) f4(acc.v[i], c) *= (1.0f / 12.0f);
+    row_store(acc, pooled + (size_t)job * DM, lane);
+}
+extern "C" int sed_fpool_fwd(const float* x, const float* gamma, const float* beta, float eps, float* pooled,
+                             float* mean, float* rstd, int B, int tp, hipStream_t stream) {
+    hipLaunchKernelGGL(fpool_fwd_kernel, dim3(cdiv(B * tp, 4)), dim3(256), 0, stream, x, gamma, beta, eps, pooled, mean,
+                       rstd, B, tp);
+    return sed_check_launch();
+}
+// backward = LayerNorm backward of the 12 B tp token rows with dy = dpooled[b, t] / 12, dx accumulated into the
+// residual-stream gradient at rows 2 + f tp + t.  Implemented by expanding dpooled to token rows (cheap) and
+// calling the LN backward kernel with dy_scale = 1/12.
+__global__ void fpool_expand_kernel(const float* __restrict__ dpooled, float* __restrict__ dtok, int B, int tp) {
+    const int N = 2 + 12 * tp;
+    const size_t total = (size_t)B * N * (DM / 4);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int d4 = (int)(idx % (DM / 4));
+        const size_t tok = idx / (DM / 4);
+        const int n = (int)(tok % N), b = (int)(tok / N);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n >= 2) {
+            const int t = (n - 2) % tp;
+            v = reinterpret_cast<const float4*>(dpooled)[((size_t)b * tp + t) * (DM / 4) + d4];
+        }
+        reinterpret_cast<float4*>(dtok)[idx] = v;
+    }
+}
+extern "C" int sed_fpool_bwd(const float* dpooled, const float* x, const float* mean, const float* rstd,
+                             const float* gamma, float* dtok_tmp, float* dx_acc, float* dgamma, float* dbeta, int B,
+                             int tp, hipStream_t stream) {
+    const int N = 2 + 12 * tp, M = B * N;
+    hipLaunchKernelGGL(fpool_expand_kernel, dim3(2048), dim3(256), 0, stream, dpooled, dtok_tmp, B, tp);
+    // rows 0,1 of every clip have dy = 0 (and mean/rstd never written there -> use finite placeholders: the host
+    // zero-fills mean/rstd once); their contribution is exactly 0 * finite.
+    int blocks = cdiv(M, 4);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)dtok_tmp, x, mean, rstd,
+                       gamma, 1.0f, dx_acc, 1, dgamma, dbeta, M, 1.0f / 12.0f);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// x`ratio` linear interpolation along time, align_corners=False (passt_sed.py:13-34,258-259)
+// in [B, tin, D] (+ `pad` replicated frames at the end) -> out [B, ratio (tin + pad), D]
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void interp_coeff(int j, int ratio, int tlen, int tin, int& i0, int& i1, float& lam) {
+    float src = ((float)j + 0.5f) / (float)ratio - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    i1 = i0 + 1 < tlen ? i0 + 1 : tlen - 1;
+    lam = src - (float)i0;
+    i0 = i0 < tin ? i0 : tin - 1;  // replicated padding frames
+    i1 = i1 < tin ? i1 : tin - 1;
+}
+__global__ void interp_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int tin, int pad,
+                                  int ratio) {
+    const int tlen = tin + pad, tout = tlen * ratio;
+    const size_t total = (size_t)B * tout * (DM / 4);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int d4 = (int)(idx % (DM / 4));
+        const size_t row = idx / (DM / 4);
+        const int j = (int)(row % tout), b = (int)(row / tout);
+        int i0, i1; float lam;
+        interp_coeff(j, ratio, tlen, tin, i0, i1, lam);
+        const float4 a = reinterpret_cast<const float4*>(in)[((size_t)b * tin + i0) * (DM / 4) + d4];
+        const float4 c = reinterpret_cast<const float4*>(in)[((size_t)b * tin + i1) * (DM / 4) + d4];
+        float4 o;
+        o.x = (1.f - lam) * a.x + lam * c.x; o.y = (1.f - lam) * a.y + lam * c.y;
+        o.z = (1.f - lam) * a.z + lam * c.z; o.w = (1.f - lam) * a.w + lam * c.w;
+        reinterpret_cast<float4*>(out)[idx] = o;
+    }
+}
+extern "C" int sed_interp_fwd(const float* in, float* out, int B, int tin, int pad, int ratio, hipStream_t stream) {
+    hipLaunchKernelGGL(interp_fwd_kernel, dim3(2048), dim3(256), 0, stream, in, out, B, tin, pad, ratio);
+    return sed_check_launch();
+}
+__global__ void interp_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int B, int tin, int pad,
+                                  int ratio) {
+    const int tlen = tin + pad, tout = tlen * ratio;
+    const size_t total = (size_t)B * tin * (DM / 4);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int d4 = (int)(idx % (DM / 4));
+        const size_t row = idx / (DM / 4);
+        const int i = (int)(row % tin), b = (int)(row / tin);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int jlo = (i - 1) * ratio - ratio, jhi = (i == tin - 1) ? tout - 1 : (i + 1) * ratio + ratio;
+        jlo = jlo < 0 ? 0 : jlo;
+        jhi = jhi > tout - 1 ? tout - 1 : jhi;
+        for (int j = jlo; j <= jhi; ++j) {
+            int i0, i1; float lam;
+            interp_coeff(j, ratio, tlen, tin, i0, i1, lam);
+            float w = 0.f;
+            if (i0 == i) w += 1.f - lam;
+            if (i1 == i) w += lam;
+            if (w != 0.f) {
+                const float4 g = reinterpret_cast<const float4*>(dout)[((size_t)b * tout + j) * (DM / 4) + d4];
+                acc.x += w * g.x; acc.y += w * g.y; acc.z += w * g.z; acc.w += w * g.w;
+            }
+        }
+        reinterpret_cast<float4*>(din)[idx] = acc;
+    }
+}
+extern "C" int sed_interp_bwd(const float* dout, float* din, int B, int tin, int pad, int ratio, hipStream_t stream) {
+    hipLaunchKernelGGL(interp_bwd_kernel, dim3(1024), dim3(256), 0, stream, dout, din, B, tin, pad, ratio);
+    return sed_check_launch();
+}
+
+// Sliding-window merge (encoder_slide_window.py:16-36 + passt_sed.py:266-271), windows folded into the batch:
+// pooled_win [nW, B, tpw, D] -> x[b, j] = (1 - mix) x[b, j] + mix * (sum_w interp(pooled_win[w, b])[j - left_w]) / cnt_j
+// (cnt_j == 0 -> local part is 0, the reference's NaN -> 0).
+__global__ void window_mix_kernel(const float* __restrict__ pooled_win, const int* __restrict__ lefts, int nW,
+                                  float* __restrict__ x, float mix, int B, int T, int tpw, int ratio) {
+    const int wlen = tpw * ratio;
+    const size_t total = (size_t)B * T * (DM / 4);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int d4 = (int)(idx % (DM / 4));
+        const size_t row = idx / (DM / 4);
+        const int j = (int)(row % T), b = (int)(row / T);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int cnt = 0;
+        for (int w = 0; w < nW; ++w) {
+            const int jj = j - lefts[w];
+            if (jj < 0 || jj >= wlen) continue;
+            int i0, i1; float lam;
+            interp_coeff(jj, ratio, tpw, tpw, i0, i1, lam);
+            const float* base = pooled_win + (((size_t)w * B + b) * tpw) * DM;
+            const float4 a = reinterpret_cast<const float4*>(base)[(size_t)i0 * (DM / 4) + d4];
+            const float4 c = reinterpret_cast<const float4*>(base)[(size_t)i1 * (DM / 4) + d4];
+            acc.x += (1.f - lam) * a.x + lam * c.x; acc.y += (1.f - lam) * a.y + lam * c.y;
+            acc.z += (1.f - lam) * a.z + lam * c.z; acc.w += (1.f - lam) * a.w + lam * c.w;
+            ++cnt;
+        }
+        const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.f;
+        float4 g = reinterpret_cast<float4*>(x)[idx];
+        g.x = mix * (acc.x * inv) + (1.f - mix) * g.x; g.y = mix * (acc.y * inv) + (1.f - mix) * g.y;
+        g.z = mix * (acc.z * inv) + (1.f - mix) * g.z; g.w = mix * (acc.w * inv) + (1.f - mix) * g.w;
+        reinterpret_cast<float4*>(x)[idx] = g;
+    }
+}
+extern "C" int sed_window_mix(const float* pooled_win, const int* lefts, int nW, float* x, float mix, int B, int T,
+                              int tpw, int ratio, hipStream_t stream) {
+    hipLaunchKernelGGL(window_mix_kernel, dim3(2048), dim3(256), 0, stream, pooled_win, lefts, nW, x, mix, B, T, tpw,
+                       ratio);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// MLM masking (mask.py:62-85) and masked MSE (mlm_passt/train.py:36-38)
+// ---------------------------------------------------------------------------------------------------
+// action[row]: 0 keep, 1 -> mask_token, 2 -> copy row src_idx[row] of the ORIGINAL sequence
+__global__ void mlm_apply_kernel(const float* __restrict__ x, const float* __restrict__ mask_token,
+                                 const unsigned char* __restrict__ action, const int* __restrict__ src_idx,
+                                 float* __restrict__ out, int rows) {
+    const size_t total = (size_t)rows * (DM / 4);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int d4 = (int)(idx % (DM / 4));
+        const int row = (int)(idx / (DM / 4));
+        const unsigned char a = action[row];
+        float4 v;
+        if (a == 1) v = reinterpret_cast<const float4*>(mask_token)[d4];
+        else if (a == 2) v = reinterpret_cast<const float4*>(x)[(size_t)src_idx[row] * (DM / 4) + d4];
+        else v = reinterpret_cast<const float4*>(x)[idx];
+        reinterpret_cast<float4*>(out)[idx] = v;
+    }
+}
+extern "C" int sed_mlm_apply(const float* x, const float* mask_token, const uint8_t* action, const int* src_idx,
+                             float* out, int rows, hipStream_t stream) {
+    hipLaunchKernelGGL(mlm_apply_kernel, dim3(2048), dim3(256), 0, stream, x, mask_token, action, src_idx, out, rows);
+    return sed_check_launch();
+}
+// backward of the masking: dx[row] = (action == 0) * dout[row] + scatter-add of 'copy' rows; dmask_token = sum of
+// 'mask' rows.  (Only reached when the masking is effective, see DESIGN.md reference quirk 15.)
+__global__ void mlm_apply_bwd_kernel(const float* __restrict__ dout, const unsigned char* __restrict__ action,
+                                     const int* __restrict__ src_idx, float* __restrict__ dx,
+                                     float* __restrict__ dtoken, int rows) {
+    const size_t total = (size_t)rows * DM;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(idx % DM);
+        const int row = (int)(idx / DM);
+        const unsigned char a = action[row];
+        const float g = dout[idx];
+        if (a == 0) unsafeAtomicAdd(&dx[idx], g);
+        else if (a == 1) unsafeAtomicAdd(&dtoken[d], g);
+        else unsafeAtomicAdd(&dx[(size_t)src_idx[row] * DM + d], g);
+    }
+}
+extern "C" int sed_mlm_apply_bwd(const float* dout, const uint8_t* action, const int* src_idx, float* dx_zeroed,
+                                 float* dtoken, int rows, hipStream_t stream) {
+    hipLaunchKernelGGL(mlm_apply_bwd_kernel, dim3(2048), dim3(256), 0, stream, dout, action, src_idx, dx_zeroed, dtoken,
+                       rows);
+    return sed_check_launch();
+}
+
+// loss = mean over masked rows x D of (target - pred)^2 ; dpred = 2 (pred - target) / n, dtarget = -dpred.
+__global__ __launch_bounds__(256) void masked_mse_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                         const unsigned char* __restrict__ mask, float inv_n,
+                                                         float* __restrict__ loss, float* __restrict__ dpred,
+                                                         float* __restrict__ dtarget, int rows) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc = 0.f;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const bool m = mask[row] != 0;
+        Row p, t;
+        if (m) {
+            row_load(p, pred + (size_t)row * DM, lane);
+            row_load(t, target + (size_t)row * DM, lane);
+        }
+#pragma unroll
+        ROW_FOREACH(i, c) {
+            const float d = m ? f4(p.v[i], c) - f4(t.v[i], c) : 0.f;
+            acc += d * d;
+            f4(p.v[i], c) = 2.f * d * inv_n;
+            f4(t.v[i], c) = -2.f * d * inv_n;
+        }
+        if (dpred != nullptr) row_store(p, dpred + (size_t)row * DM, lane);
+        if (dtarget != nullptr) row_store(t, dtarget + (size_t)row * DM, lane);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+}
+extern "C" int sed_masked_mse(const float* pred, const float* target, const uint8_t* mask, int n_masked_rows,
+                              float* loss_zeroed, float* dpred, float* dtarget, int rows, hipStream_t stream) {
+    if (n_masked_rows <= 0) return SED_ERR_ARG;
+    const float inv_n = 1.0f / ((float)n_masked_rows * (float)DM);
+    hipLaunchKernelGGL(masked_mse_kernel, dim3(512), dim3(256), 0, stream, pred, target, mask, inv_n, loss_zeroed, dpred,
+                       dtarget, rows);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SED head (passt_sed.py:285-296): logits = W x + b, s = sigmoid(logit / temp), pad mask, linear-softmax pooling
+// ---------------------------------------------------------------------------------------------------
+#define NCLS_MAX 16
+__global__ __launch_bounds__(256) void sed_head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, float inv_temp,
+                                                           const unsigned char* __restrict__ pad_mask,
+                                                           float* __restrict__ strong, int B, int T, int C) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * T) return;
+    const int b = row / T, t = row - b * T;
+    Row r;
+    row_load(r, x + (size_t)row * DM, lane);
+    const bool masked = pad_mask != nullptr && pad_mask[row] != 0;
+    for (int c = 0; c < C; ++c) {
+        Row w;
+        row_load(w, W + (size_t)c * DM, lane);
+        float s = 0.f;
+#pragma unroll
+        ROW_FOREACH(i, k) s += f4(r.v[i], k) * f4(w.v[i], k);
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float p = masked ? 0.f : sigmoidf_((s + bias[c]) * inv_temp);
+            strong[((size_t)b * C + c) * T + t] = p;
+        }
+    }
+}
+// weak[b, c] = clamp(sum s^2 / sum s, 1e-7, 1); sums saved for backward
+__global__ __launch_bounds__(256) void weak_pool_kernel(const float* __restrict__ strong, float* __restrict__ weak,
+                                                        float* __restrict__ sums, int T) {
+    __shared__ float ra[4], rb[4];
+    const float* s = strong + (size_t)blockIdx.x * T;
+    float a = 0.f, bsum = 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) { const float v = s[t]; a += v * v; bsum += v; }
+    a = wave_sum(a); bsum = wave_sum(bsum);
+    if ((threadIdx.x & 63) == 0) { ra[threadIdx.x >> 6] = a; rb[threadIdx.x >> 6] = bsum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = ra[0] + ra[1] + ra[2] + ra[3];
+        bsum = rb[0] + rb[1] + rb[2] + rb[3];
+        float w = a / bsum;
+        w = fminf(fmaxf(w, 1e-7f), 1.0f);
+        weak[blockIdx.x] = w;
+        if (sums != nullptr) { sums[2 * blockIdx.x] = a; sums[2 * blockIdx.x + 1] = bsum; }
+    }
+}
+extern "C" int sed_head_fwd(const float* x, const float* W, const float* bias, float temp, const uint8_t* pad_mask,
+                            float* strong, float* weak, float* sums, int B, int T, int C, hipStream_t stream) {
+    if (C > NCLS_MAX) return SED_ERR_ARG;
+    hipLaunchKernelGGL(sed_head_fwd_kernel, dim3(cdiv(B * T, 4)), dim3(256), 0, stream, x, W, bias, 1.0f / temp, pad_mask,
+                       strong, B, T, C);
+    hipLaunchKernelGGL(weak_pool_kernel, dim3(B * C), dim3(256), 0, stream, (const float*)strong, weak, sums, T);
+    return sed_check_launch();
+}
+// backward: dlogit[b,t,c] = (dstrong[b,c,t] + dweak[b,c] * (2 s B - A) / B^2 [if unclamped]) * s (1 - s) / temp
+// dx[row] = sum_c dlogit W[c];  dW[c] += sum_rows dlogit x[row];  db[c] += sum dlogit
+__global__ __launch_bounds__(256) void sed_head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                           const float* __restrict__ strong,
+                                                           const float* __restrict__ sums,
+                                                           const float* __restrict__ dstrong,
+                                                           const float* __restrict__ dweak, float inv_temp,
+                                                           float* __restrict__ dx, float* __restrict__ dW,
+                                                           float* __restrict__ db, int B, int T, int C) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = 0; c < C; ++c) {
+        // process class by class to keep register use small: per-lane dW partial for this class
+        Row w, pw;
+        row_load(w, W + (size_t)c * DM, lane);
+#pragma unroll
+        ROW_FOREACH(i, k) f4(pw.v[i], k) = 0.f;
+        float pb = 0.f;
+        for (int row = blockIdx.x * 4 + wave; row < B * T; row += gridDim.x * 4) {
+            const int b = row / T, t = row - b * T;
+            const size_t si = ((size_t)b * C + c) * T + t;
+            const float s = strong[si];
+            float g = dstrong != nullptr ? dstrong[si] : 0.f;
+            if (dweak != nullptr) {
+                const float A = sums[2 * (b * C + c)], Bs = sums[2 * (b * C + c) + 1];
+                const float wv = A / Bs;
+                if (wv > 1e-7f && wv < 1.0f) g += dweak[b * C + c] * (2.f * s * Bs - A) / (Bs * Bs);
+            }
+            const float dl = g * s * (1.f - s) * inv_temp;
+            pb += dl;
+            Row xr, o;
+            row_load(xr, x + (size_t)row * DM, lane);
+            if (c > 0) row_load(o, dx + (size_t)row * DM, lane);
+#pragma unroll
+            ROW_FOREACH(i, k) {
+                f4(pw.v[i], k) += dl * f4(xr.v[i], k);
+                const float v = dl * f4(w.v[i], k);
+                f4(o.v[i], k) = c > 0 ? f4(o.v[i], k) + v : v;
+            }
+            row_store(o, dx + (size_t)row * DM, lane);
+        }
+        if (dW != nullptr) {
+#pragma unroll
+            ROW_FOREACH(i, k) unsafeAtomicAdd(&dW[(size_t)c * DM + 4 * (lane + 64 * i) + k], f4(pw.v[i], k));
+            if (lane == 0) unsafeAtomicAdd(&db[c], pb);
+        }
+    }
+}
+extern "C" int sed_head_bwd(const float* x, const float* W, const float* strong, const float* sums,
+                            const float* dstrong, const float* dweak, float temp, float* dx, float* dW, float* db,
+                            int B, int T, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(sed_head_bwd_kernel, dim3(256), dim3(256), 0, stream, x, W, strong, sums, dstrong, dweak,
+                       1.0f / temp, dx, dW, db, B, T, C);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// AT head: single-query multi-head attention pooling (pooling.py:45-51).  kv bf16 [B, N, 2 D] (K | V), tokens 2..N-1
+//   one workgroup per (b, h): scores over the P = N - 2 patch tokens, softmax, weighted V sum.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attnpool_fwd_kernel(const bf16_t* __restrict__ kv, const float* __restrict__ q,
+                                                           float* __restrict__ out, float* __restrict__ probs, int N,
+                                                           int H) {
+    extern __shared__ float sc[];  // [P]
+    __shared__ float red[4];
+    __shared__ float part[4][64];
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H, P = N - 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bf16_t* base = kv + ((size_t)b * N + 2) * (2 * DM);
+    const float qd = q[h * 64 + lane];
+    float mx = -1e30f;
+    for (int t = wave; t < P; t += 4) {
+        float s = qd * bf2f(base[(size_t)t * 2 * DM + h * 64 + lane]);
+        s = wave_sum(s) * 0.125f;
+        if (lane == 0) sc[t] = s;
+        mx = fmaxf(mx, s);
+    }
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int t = threadIdx.x; t < P; t += 256) { const float e = __expf(sc[t] - mx); sc[t] = e; sum += e; }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    float acc = 0.f;
+    for (int t = wave; t < P; t += 4) acc += sc[t] * inv * bf2f(base[(size_t)t * 2 * DM + DM + h * 64 + lane]);
+    part[wave][lane] = acc;
+    if (probs != nullptr)
+        for (int t = threadIdx.x; t < P; t += 256) probs[(size_t)blockIdx.x * P + t] = sc[t] * inv;
+    __syncthreads();
+    if (wave == 0) out[(size_t)b * DM + h * 64 + lane] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+}
+extern "C" int sed_attnpool_fwd(const void* kv, const float* q, float* out, float* probs, int B, int N, int H,
+                                hipStream_t stream) {
+    hipLaunchKernelGGL(attnpool_fwd_kernel, dim3(B * H), dim3(256), (N - 2) * sizeof(float), stream, (const bf16_t*)kv, q,
+                       out, probs, N, H);
+    return sed_check_launch();
+}
+// backward: dout [B, D] -> dkv bf16 [B, N, 2D] (rows 0,1 zero), dq [D] (atomic over b)
+__global__ __launch_bounds__(256) void attnpool_bwd_kernel(const bf16_t* __restrict__ kv, const float* __restrict__ q,
+                                                           const float* __restrict__ probs,
+                                                           const float* __restrict__ dout, bf16_t* __restrict__ dkv,
+                                                           float* __restrict__ dq, int N, int H) {
+    extern __shared__ float dp[];  // [P]
+    __shared__ float red[4];
+    __shared__ float part[4][64];
+    const int b = blockIdx.x / H, h = blockIdx.x - b * H, P = N - 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bf16_t* base = kv + ((size_t)b * N + 2) * (2 * DM);
+    bf16_t* dbase = dkv + ((size_t)b * N + 2) * (2 * DM);
+    const float* pr = probs + (size_t)blockIdx.x * P;
+    const float go = dout[(size_t)b * DM + h * 64 + lane], qd = q[h * 64 + lane];
+    float dot = 0.f;
+    for (int t = wave; t < P; t += 4) {
+        float v = go * bf2f(base[(size_t)t * 2 * DM + DM + h * 64 + lane]);
+        v = wave_sum(v);
+        if (lane == 0) dp[t] = v;
+        dot += v * pr[t];
+    }
+    if (lane == 0) red[wave] = dot;
+    __syncthreads();
+    dot = red[0] + red[1] + red[2] + red[3];
+    float dqa = 0.f;
+    for (int t = wave; t < P; t += 4) {
+        const float p = pr[t];
+        const float ds = p * (dp[t] - dot) * 0.125f;
+        dqa += ds * bf2f(base[(size_t)t * 2 * DM + h * 64 + lane]);
+        dbase[(size_t)t * 2 * DM + h * 64 + lane] = f2bf(ds * qd);
+        dbase[(size_t)t * 2 * DM + DM + h * 64 + lane] = f2bf(p * go);
+    }
+    if (wave == 0) {  // cls/dist rows receive no gradient from the AT head
+        bf16_t* z = dkv + ((size_t)b * N) * (2 * DM);
+        z[h * 64 + lane] = 0; z[DM + h * 64 + lane] = 0;
+        z[2 * DM + h * 64 + lane] = 0; z[2 * DM + DM + h * 64 + lane] = 0;
+    }
+    part[wave][lane] = dqa;
+    __syncthreads();
+    if (wave == 0) unsafeAtomicAdd(&dq[h * 64 + lane], part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+}
+extern "C" int sed_attnpool_bwd(const void* kv, const float* q, const float* probs, const float* dout, void* dkv,
+                                float* dq, int B, int N, int H, hipStream_t stream) {
+    hipLaunchKernelGGL(attnpool_bwd_kernel, dim3(B * H), dim3(256), (N - 2) * sizeof(float), stream, (const bf16_t*)kv, q,
+                       probs, dout, (bf16_t*)dkv, dq, N, H);
+    return sed_check_launch();
+}
+
+// small fp32 linear backward: out = act(a W^T + b);  given dout (w.r.t. the activated output when act == 1, with
+// `out` supplied), produce da [M, K] (=), dW [N, K] (+=), db [N] (+=).  One wave per (n) for dW/db, per (m) for da.
+__global__ void small_linear_bwd_kernel(const float* __restrict__ a, const float* __restrict__ w,
+                                        const float* __restrict__ out, const float* __restrict__ dout,
+                                        float* __restrict__ da, float* __restrict__ dw, float* __restrict__ db, int M,
+                                        int N, int K, int act) {
+    const int wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wv < N) {
+        const int n = wv;
+        float bacc = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            float acc = 0.f;
+            for (int m = 0; m < M; ++m) {
+                float g = dout[(size_t)m * N + n];
+                if (act == 1) { const float o = out[(size_t)m * N + n]; g *= o * (1.f - o); }
+                acc += g * a[(size_t)m * K + k];
+            }
+            if (dw != nullptr) dw[(size_t)n * K + k] += acc;
+        }
+        if (lane == 0 && db != nullptr) {
+            for (int m = 0; m < M; ++m) {
+                float g = dout[(size_t)m * N + n];
+                if (act == 1) { const float o = out[(size_t)m * N + n]; g *= o * (1.f - o); }
+                bacc += g;
+            }
+            db[n] += bacc;
+        }
+    } else if (wv < N + M && da != nullptr) {
+        const int m = wv - N;
+        for (int k = lane; k < K; k += 64) {
+            float acc = 0.f;
+            for (int n = 0; n < N; ++n) {
+                float g = dout[(size_t)m * N + n];
+                if (act == 1) { const float o = out[(size_t)m * N + n]; g *= o * (1.f - o); }
+                acc += g * w[(size_t)n * K + k];
+            }
+            da[(size_t)m * K + k] = acc;
+        }
+    }
+}
+extern "C" int sed_small_linear_bwd(const float* a, const float* w, const float* out, const float* dout, float* da,
+                                    float* dw, float* db, int M, int N, int K, int act, hipStream_t stream) {
+    const int64_t waves = (int64_t)N + M;
+    hipLaunchKernelGGL(small_linear_bwd_kernel, dim3(cdiv(waves * 64, 256)), dim3(256), 0, stream, a, w, out, dout, da,
+                       dw, db, M, N, K, act);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused AdamW (decoupled weight decay, torch.optim.AdamW semantics; recipes/desed/setting.py:254-258) + EMA teacher
+// update (src/utils/scheduler.py:125-130) over a contiguous slice of the flat parameter arena.
+// ---------------------------------------------------------------------------------------------------
+__global__ void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, float* __restrict__ ema, size_t n4, float lr, float wd, float b1,
+                                 float b2, float eps, float bc1, float bc2_sqrt, float ema_alpha, int do_adam) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        if (do_adam) {
+            const float4 gg = reinterpret_cast<const float4*>(g)[i];
+            float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float& pc = f4(pp, c);
+                const float gc = f4(gg, c);
+                pc *= (1.f - lr * wd);
+                const float mc = b1 * f4(mm, c) + (1.f - b1) * gc;
+                const float vc = b2 * f4(vv, c) + (1.f - b2) * gc * gc;
+                f4(mm, c) = mc; f4(vv, c) = vc;
+                const float denom = sqrtf(vc) / bc2_sqrt + eps;
+                pc -= (lr / bc1) * (mc / denom);
+            }
+            reinterpret_cast<float4*>(p)[i] = pp;
+            reinterpret_cast<float4*>(m)[i] = mm;
+            reinterpret_cast<float4*>(v)[i] = vv;
+        }
+        if (ema != nullptr) {
+            float4 ee = reinterpret_cast<float4*>(ema)[i];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) f4(ee, c) = f4(ee, c) * ema_alpha + f4(pp, c) * (1.f - ema_alpha);
+            reinterpret_cast<float4*>(ema)[i] = ee;
+        }
+    }
+}
+extern "C" int sed_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr, float wd,
+                             float beta1, float beta2, float eps, int step, float ema_alpha, int do_adam,
+                             hipStream_t stream) {
+    if (n % 4) return SED_ERR_ARG;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    size_t n4 = n / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    blocks = blocks > 8192 ? 8192 : (blocks < 1 ? 1 : blocks);
+    hipLaunchKernelGGL(adamw_ema_kernel, dim3(blocks), dim3(256), 0, stream, p, g, m, v, ema, n4, lr, wd, beta1, beta2,
+                       eps, bc1, sqrtf(bc2), ema_alpha, do_adam);
+    return sed_check_launch();
+}

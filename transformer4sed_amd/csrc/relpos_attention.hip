@@ -1,0 +1,589 @@
+// Transformer-XL relative-position multi-head attention for the MAT-SED context network (gfx950),
+// forward + backward, without ever materialising the [B,12,T,2T-1] "BD" tensor of the reference.
+//
+// Replaces src/models/transformer/transformerXL.py:493-576 (linear_pos is a plain GEMM, see gemm.hip):
+//   S[i,j] = ((q_i + u) . k_j  +  (q_i + v) . p_{j-i+T-1}) / sqrt(64),   softmax_j,   @ v
+// `rel_shift` (transformerXL.py:254-297) is folded into the tile indexing: for a (32-query x 64-key) tile only
+// the 95-row band p[j0-i0-31+T-1 ...] of the positional table matters; the band product is computed on the
+// matrix cores as G^T[rho, q] and then *skewed* through a wave-private LDS buffer:
+//   BD^T[key, q] = G^T[key - q + 31, q].
+//
+// Operands (head-split by gemm.hip EPI_QKV; all bf16):
+//   Qu = q+u, Qv = q+v : [B*H, T, 64]      K, V : [B*H, T, 64]       Kt, Vt, Qut, Qvt : [B*H, 64, Tpad]
+//   P  = linear_pos(pos_emb) head-split : [H, Rpad, 64],   Pt : [H, 64, Rpad]      (R = 2T-1 rows, Rpad % 64 == 0)
+// Requires T % 8 == 0 (band columns of Pt are then 16-byte aligned); T = 1000 in MAT-SED.
+#include "common.h"
+#include "../../include/sed_hip.h"
+
+#include "attn_common.h"
+
+#define BAND_ROWS 192
+
+struct BandRegs { uint4 x0, x1, x2, x3, x4, x5; };
+
+__device__ __forceinline__ uint4 band_load1(const bf16_t* Ph, int row, int R, int c) {
+    row = row < 0 ? 0 : (row >= R ? R - 1 : row);
+    return *reinterpret_cast<const uint4*>(Ph + (size_t)row * HD + c * 8);
+}
+// band rows [RB, RB + 192) of P_h [R][64] -> registers (thread: chunk c of rows (tid>>3) + 32 i)
+__device__ __forceinline__ void band_gload(BandRegs& b, const bf16_t* Ph, int RB, int R, int tid) {
+    const int r = RB + (tid >> 3), c = tid & 7;
+    b.x0 = band_load1(Ph, r, R, c);
+    b.x1 = band_load1(Ph, r + 32, R, c);
+    b.x2 = band_load1(Ph, r + 64, R, c);
+    b.x3 = band_load1(Ph, r + 96, R, c);
+    b.x4 = band_load1(Ph, r + 128, R, c);
+    b.x5 = band_load1(Ph, r + 160, R, c);
+}
+__device__ __forceinline__ void band_lstore(const BandRegs& b, unsigned char* dst, int tid) {
+    const int r = tid >> 3, c = tid & 7;
+    *reinterpret_cast<uint4*>(dst + k_off(r, c)) = b.x0;
+    *reinterpret_cast<uint4*>(dst + k_off(r + 32, c)) = b.x1;
+    *reinterpret_cast<uint4*>(dst + k_off(r + 64, c)) = b.x2;
+    *reinterpret_cast<uint4*>(dst + k_off(r + 96, c)) = b.x3;
+    *reinterpret_cast<uint4*>(dst + k_off(r + 128, c)) = b.x4;
+    *reinterpret_cast<uint4*>(dst + k_off(r + 160, c)) = b.x5;
+}
+// transposed band image [64 d][192 rho] bf16 (384-B rows), 16-B chunks swizzled inside groups of 8
+__device__ __forceinline__ int bt_off(int row, int ch16) { return row * 384 + ((ch16 ^ ((row >> 1) & 7)) << 4); }
+// columns [CB, CB+192) of Pt_h [64][Rpad] -> LDS; CB % 8 == 0; out-of-range columns are clamped (never used
+// by valid pairs).  64 rows x 24 chunks = 1536 chunks = 6 per thread.
+__device__ __forceinline__ void bandT_stage(const bf16_t* Pth, int CB, int Rpad, unsigned char* dst, int tid) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx / 24, ch = idx - row * 24;
+        int col = CB + ch * 8;
+        col = col < 0 ? 0 : (col + 8 > Rpad ? Rpad - 8 : col);
+        const uint4 v = *reinterpret_cast<const uint4*>(Pth + (size_t)row * Rpad + col);
+        *reinterpret_cast<uint4*>(dst + bt_off(row, ch)) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relpos_fwd_kernel(const bf16_t* __restrict__ Qu, const bf16_t* __restrict__ Qv,
+                                                         const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
+                                                         const bf16_t* __restrict__ P, bf16_t* __restrict__ O,
+                                                         float* __restrict__ LSE, int T, int Tpad, int H, int Rpad) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_kv[2][2][KVB * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_band[2][BAND_ROWS * 128];
+    __shared__ __attribute__((aligned(16))) float lds_g[4][96 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int I0 = blockIdx.x * 128, q0 = I0 + wave * 32;
+    const int R = 2 * T - 1;
+    const size_t hb = (size_t)bh * T * HD;
+    const bf16_t* Vtb = Vt + (size_t)bh * HD * Tpad;
+    const bf16_t* Ph = P + (size_t)h * Rpad * HD;
+
+    int qrow = q0 + lr;
+    qrow = qrow < T ? qrow : T - 1;
+    s16x8_t quf[4], qvf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        quf[s] = *reinterpret_cast<const s16x8_t*>(Qu + hb + (size_t)qrow * HD + 16 * s + 8 * lg);
+        qvf[s] = *reinterpret_cast<const s16x8_t*>(Qv + hb + (size_t)qrow * HD + 16 * s + 8 * lg);
+    }
+    f32x16_t o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    float* gs = lds_g[wave];
+    const int band_row0 = 32 * (3 - wave);
+
+    const int ntiles = (T + KVB - 1) / KVB;
+    TileRegs rk, rv;
+    BandRegs rb;
+    tile_gload(rk, K + hb, 0, T, HD, 0, tid);
+    tile_gload(rv, Vtb, 0, HD, Tpad, 0, tid);
+    band_gload(rb, Ph, 0 - I0 - 127 + T - 1, R, tid);
+    tile_lstore_rows(rk, lds_kv[0][0], tid);
+    tile_lstore_cols(rv, lds_kv[0][1], tid);
+    band_lstore(rb, lds_band[0], tid);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1, j0 = t * KVB;
+        if (t + 1 < ntiles) {
+            tile_gload(rk, K + hb, j0 + KVB, T, HD, 0, tid);
+            tile_gload(rv, Vtb, 0, HD, Tpad, j0 + KVB, tid);
+            band_gload(rb, Ph, j0 + KVB - I0 - 127 + T - 1, R, tid);
+        }
+        const unsigned char* lk = lds_kv[buf][0];
+        const unsigned char* lv = lds_kv[buf][1];
+        const unsigned char* lb = lds_band[buf];
+        // band product G^T[rho, q] -> wave-private LDS
+#pragma unroll
+        for (int blk = 0; blk < 3; ++blk) {
+            f32x16_t g;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) g = mfma32(lds_frag_rows(lb, band_row0 + 32 * blk + lr, 2 * s + lg), qvf[s], g);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gs[(32 * blk + mfma32_row(r, lg)) * 32 + lr] = g[r];
+        }
+        f32x16_t st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) st[kb] = mfma32(lds_frag_rows(lk, 32 * kb + lr, 2 * s + lg), quf[s], st[kb]);
+        }
+        __syncthreads();  // G^T visible (wave-private buffer, but keep it simple and safe)
+        float mloc = -1e30f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jj = 32 * kb + mfma32_row(r, lg);
+                float sv = (st[kb][r] + gs[(jj - lr + 31) * 32 + lr]) * SCALE_LOG2E;
+                sv = (j0 + jj < T) ? sv : -1e30f;
+                st[kb][r] = sv;
+                mloc = fmaxf(mloc, sv);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(st[kb][r] - m_new);
+                st[kb][r] = p;
+                psum += p;
+            }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const s16x8_t pf = pack_frag(st[kb], s);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    o[db] = mfma32(lds_frag_cols(lv, 32 * db + lr, 8 * kb + 4 * s + lg), pf, o[db]);
+            }
+        if (t + 1 < ntiles) {
+            tile_lstore_rows(rk, lds_kv[buf ^ 1][0], tid);
+            tile_lstore_cols(rv, lds_kv[buf ^ 1][1], tid);
+            band_lstore(rb, lds_band[buf ^ 1], tid);
+        }
+        __syncthreads();
+    }
+    const int q = q0 + lr;
+    if (q < T) {
+        const float inv = 1.0f / l_run;
+        bf16_t* orow = O + ((size_t)b * T + q) * (H * HD) + h * HD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                uint2 pk;
+                pk.x = pack2bf(o[db][4 * qd] * inv, o[db][4 * qd + 1] * inv);
+                pk.y = pack2bf(o[db][4 * qd + 2] * inv, o[db][4 * qd + 3] * inv);
+                *reinterpret_cast<uint2*>(orow + 32 * db + 8 * qd + 4 * lg) = pk;
+            }
+        if (lg == 0 && LSE != nullptr) LSE[(size_t)bh * T + q] = m_run + log2f(l_run);
+    }
+}
+
+extern "C" int sed_relpos_attn_fwd(const void* Qu, const void* Qv, const void* K, const void* Vt, const void* P,
+                                   void* O, float* LSE, int B, int H, int T, int Tpad, int Rpad, hipStream_t stream) {
+    if (T <= 0 || (T % 8) || Tpad % 64 || Tpad < T || Rpad % 64 || Rpad < 2 * T - 1) return SED_ERR_ARG;
+    dim3 grid(cdiv(T, 128), B * H);
+    hipLaunchKernelGGL(relpos_fwd_kernel, grid, dim3(256), 0, stream, (const bf16_t*)Qu, (const bf16_t*)Qv,
+                       (const bf16_t*)K, (const bf16_t*)Vt, (const bf16_t*)P, (bf16_t*)O, LSE, T, Tpad, H, Rpad);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward kernel 1: dK, dV   (workgroup = 128 keys; loops over 64-query tiles; lane owns a key column)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relpos_bwd_dkdv_kernel(
+    const bf16_t* __restrict__ Qu, const bf16_t* __restrict__ Qut, const bf16_t* __restrict__ Qv,
+    const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, const bf16_t* __restrict__ P,
+    const bf16_t* __restrict__ dOh, const bf16_t* __restrict__ dOt, const float* __restrict__ LSE,
+    const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, int T, int Tpad, int H, int Rpad) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[5][KVB * 128];  // Qu rows, Qv rows, dO rows, Qu^T, dO^T
+    __shared__ __attribute__((aligned(16))) unsigned char lds_band[BAND_ROWS * 128];
+    __shared__ __attribute__((aligned(16))) float lds_g[4][32 * 65];
+    __shared__ __attribute__((aligned(16))) float lstat[2][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int J0 = blockIdx.x * 128, key0 = J0 + wave * 32;
+    const int R = 2 * T - 1;
+    const size_t hb = (size_t)bh * T * HD, hbt = (size_t)bh * HD * Tpad;
+    const bf16_t* Ph = P + (size_t)h * Rpad * HD;
+    int krow = key0 + lr;
+    const bool key_valid_lane = krow < T;
+    krow = krow < T ? krow : T - 1;
+    s16x8_t kf[4], vf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        kf[s] = *reinterpret_cast<const s16x8_t*>(K + hb + (size_t)krow * HD + 16 * s + 8 * lg);
+        vf[s] = *reinterpret_cast<const s16x8_t*>(V + hb + (size_t)krow * HD + 16 * s + 8 * lg);
+    }
+    f32x16_t dk[2], dv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+    float* gs = lds_g[wave];
+    const int ntiles = (T + 63) / 64;
+    for (int t = 0; t < ntiles; ++t) {
+        const int i0 = t * 64;
+        {
+            TileRegs r0, r1, r2, r3, r4;
+            BandRegs rb;
+            tile_gload(r0, Qu + hb, i0, T, HD, 0, tid);
+            tile_gload(r1, Qv + hb, i0, T, HD, 0, tid);
+            tile_gload(r2, dOh + hb, i0, T, HD, 0, tid);
+            tile_gload(r3, Qut + hbt, 0, HD, Tpad, i0, tid);
+            tile_gload(r4, dOt + hbt, 0, HD, Tpad, i0, tid);
+            band_gload(rb, Ph, J0 - (i0 + 63) + T - 1, R, tid);
+            tile_lstore_rows(r0, lds[0], tid);
+            tile_lstore_rows(r1, lds[1], tid);
+            tile_lstore_rows(r2, lds[2], tid);
+            tile_lstore_cols(r3, lds[3], tid);
+            tile_lstore_cols(r4, lds[4], tid);
+            band_lstore(rb, lds_band, tid);
+            if (tid < 128) {
+                const int qi = i0 + (tid & 63);
+                const float* src = (tid < 64) ? LSE : Dv;
+                lstat[tid >> 6][tid & 63] = qi < T ? src[(size_t)bh * T + qi] : (tid < 64 ? 1e30f : 0.f);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int rowoff = 32 * (wave - qb + 1);
+            // band product G[i, rho] (rows = queries, column = rho): A = Qv rows, B = band rows
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                f32x16_t g;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) g[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    g = mfma32(lds_frag_rows(lds[1], 32 * qb + lr, 2 * s + lg),
+                               lds_frag_rows(lds_band, rowoff + 32 * blk + lr, 2 * s + lg), g);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gs[mfma32_row(r, lg) * 65 + 32 * blk + lr] = g[r];
+            }
+            f32x16_t s_, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s_[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                s_ = mfma32(lds_frag_rows(lds[0], 32 * qb + lr, 2 * s + lg), kf[s], s_);
+                dp = mfma32(lds_frag_rows(lds[2], 32 * qb + lr, 2 * s + lg), vf[s], dp);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int qq = 32 * qb + 8 * qd + 4 * lg;
+                const f32x4_t l2 = *reinterpret_cast<const f32x4_t*>(&lstat[0][qq]);
+                const f32x4_t dd = *reinterpret_cast<const f32x4_t*>(&lstat[1][qq]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * qd + j, ii = mfma32_row(r, lg);
+                    const float bd = gs[ii * 65 + lr - ii + 31];
+                    float p = exp2f((s_[r] + bd) * SCALE_LOG2E - l2[j]);
+                    p = key_valid_lane ? p : 0.f;
+                    s_[r] = p;
+                    dp[r] = p * (dp[r] - dd[j]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const s16x8_t pf = pack_frag(s_, s), dsf = pack_frag(dp, s);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    dv[db] = mfma32(pf, lds_frag_cols(lds[4], 32 * db + lr, 8 * qb + 4 * s + lg), dv[db]);
+                    dk[db] = mfma32(dsf, lds_frag_cols(lds[3], 32 * db + lr, 8 * qb + 4 * s + lg), dk[db]);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int ldq = 3 * H * HD;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + mfma32_row(r, lg);
+            if (key < T) {
+                bf16_t* row = dqkv + ((size_t)b * T + key) * ldq + h * HD + 32 * db + lr;
+                row[H * HD] = f2bf(dk[db][r] * SCALE);
+                row[2 * H * HD] = f2bf(dv[db][r]);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward kernel 2: dQ (= dQu + dQv), per-head sums for pos_bias_u / pos_bias_v, and dS^T for the dP kernel.
+// workgroup = 128 queries; loops over 64-key tiles; lane owns a query column (as in forward).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relpos_bwd_dq_kernel(
+    const bf16_t* __restrict__ Qu, const bf16_t* __restrict__ Qv, const bf16_t* __restrict__ K,
+    const bf16_t* __restrict__ Kt, const bf16_t* __restrict__ V, const bf16_t* __restrict__ P,
+    const bf16_t* __restrict__ Pt, const bf16_t* __restrict__ dOh, const float* __restrict__ LSE,
+    const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, bf16_t* __restrict__ dSt, float* __restrict__ du,
+    float* __restrict__ dvb, int T, int Tpad, int H, int Rpad) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3][KVB * 128];  // K rows, V rows, K^T
+    __shared__ __attribute__((aligned(16))) unsigned char lds_band[BAND_ROWS * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_bandT[64 * 384];
+    __shared__ __attribute__((aligned(16))) float lds_g[4][96 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int I0 = blockIdx.x * 128, q0 = I0 + wave * 32;
+    const int R = 2 * T - 1;
+    const size_t hb = (size_t)bh * T * HD, hbt = (size_t)bh * HD * Tpad;
+    const bf16_t* Ph = P + (size_t)h * Rpad * HD;
+    const bf16_t* Pth = Pt + (size_t)h * HD * Rpad;
+    int qrow = q0 + lr;
+    const bool qvalid = qrow < T;
+    qrow = qvalid ? qrow : T - 1;
+    s16x8_t quf[4], qvf[4], dof[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        quf[s] = *reinterpret_cast<const s16x8_t*>(Qu + hb + (size_t)qrow * HD + 16 * s + 8 * lg);
+        qvf[s] = *reinterpret_cast<const s16x8_t*>(Qv + hb + (size_t)qrow * HD + 16 * s + 8 * lg);
+        dof[s] = *reinterpret_cast<const s16x8_t*>(dOh + hb + (size_t)qrow * HD + 16 * s + 8 * lg);
+    }
+    const float l2 = LSE[(size_t)bh * T + qrow], dd = Dv[(size_t)bh * T + qrow];
+    f32x16_t dqu[2], dqv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dqu[i][r] = 0.f; dqv[i][r] = 0.f; }
+    float* gs = lds_g[wave];
+    const int band_row0 = 32 * (3 - wave);
+    const int ntiles = (T + KVB - 1) / KVB;
+    for (int t = 0; t < ntiles; ++t) {
+        const int j0 = t * KVB;
+        const int RB = j0 - I0 - 127 + T - 1;  // multiple of 8 because T % 8 == 0
+        {
+            TileRegs r0, r1, r2;
+            BandRegs rb;
+            tile_gload(r0, K + hb, j0, T, HD, 0, tid);
+            tile_gload(r1, V + hb, j0, T, HD, 0, tid);
+            tile_gload(r2, Kt + hbt, 0, HD, Tpad, j0, tid);
+            band_gload(rb, Ph, RB, R, tid);
+            tile_lstore_rows(r0, lds[0], tid);
+            tile_lstore_rows(r1, lds[1], tid);
+            tile_lstore_cols(r2, lds[2], tid);
+            band_lstore(rb, lds_band, tid);
+            bandT_stage(Pth, RB, Rpad, lds_bandT, tid);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int blk = 0; blk < 3; ++blk) {
+            f32x16_t g;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                g = mfma32(lds_frag_rows(lds_band, band_row0 + 32 * blk + lr, 2 * s + lg), qvf[s], g);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gs[(32 * blk + mfma32_row(r, lg)) * 32 + lr] = g[r];
+        }
+        f32x16_t st[2], dp[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[kb][r] = 0.f; dp[kb][r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                st[kb] = mfma32(lds_frag_rows(lds[0], 32 * kb + lr, 2 * s + lg), quf[s], st[kb]);
+                dp[kb] = mfma32(lds_frag_rows(lds[1], 32 * kb + lr, 2 * s + lg), dof[s], dp[kb]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jj = 32 * kb + mfma32_row(r, lg);
+                float p = exp2f((st[kb][r] + gs[(jj - lr + 31) * 32 + lr]) * SCALE_LOG2E - l2);
+                p = (qvalid && (j0 + jj < T)) ? p : 0.f;
+                dp[kb][r] = p * (dp[kb][r] - dd);  // dS^T[key, q]
+            }
+        __syncthreads();  // everyone has read G^T before it is overwritten with dG^T
+        // dS^T -> global (for the dP kernel) and -> skewed LDS image dG^T[rho, q]
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jj = 32 * kb + mfma32_row(r, lg);
+                gs[(jj - lr + 31) * 32 + lr] = dp[kb][r];
+                if (qvalid && (j0 + jj < T)) dSt[((size_t)bh * Tpad + j0 + jj) * Tpad + q0 + lr] = f2bf(dp[kb][r]);
+            }
+        // dQu^T[d, q] += K^T[d, key] dS^T[key, q]
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const s16x8_t dsf = pack_frag(dp[kb], s);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    dqu[db] = mfma32(lds_frag_cols(lds[2], 32 * db + lr, 8 * kb + 4 * s + lg), dsf, dqu[db]);
+            }
+        __syncthreads();
+        // dQv^T[d, q] += P_band^T[d, rho] dG^T[rho, q]   (rho = 16 s + 8 g + e, natural k order)
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            s16x8_t gf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int rho = 16 * s + 8 * lg + e, jj = rho + lr - 31;
+                const float v = (jj >= 0 && jj < 64) ? gs[rho * 32 + lr] : 0.f;
+                gf[e] = (short)f2bf(v);
+            }
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int row = 32 * db + lr, ch = (band_row0 >> 3) + 2 * s + lg;
+                const s16x8_t pf = *reinterpret_cast<const s16x8_t*>(lds_bandT + bt_off(row, ch));
+                dqv[db] = mfma32(pf, gf, dqv[db]);
+            }
+        }
+        __syncthreads();
+    }
+    // outputs
+    if (qvalid) {
+        bf16_t* row = dqkv + ((size_t)b * T + q0 + lr) * (3 * H * HD) + h * HD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                float v0 = (dqu[db][4 * qd] + dqv[db][4 * qd]) * SCALE, v1 = (dqu[db][4 * qd + 1] + dqv[db][4 * qd + 1]) * SCALE;
+                float v2 = (dqu[db][4 * qd + 2] + dqv[db][4 * qd + 2]) * SCALE, v3 = (dqu[db][4 * qd + 3] + dqv[db][4 * qd + 3]) * SCALE;
+                uint2 pk;
+                pk.x = pack2bf(v0, v1);
+                pk.y = pack2bf(v2, v3);
+                *reinterpret_cast<uint2*>(row + 32 * db + 8 * qd + 4 * lg) = pk;
+            }
+    }
+    // pos_bias grads: sum over the wave's 32 queries (invalid queries contributed exact zeros)
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float su = dqu[db][r] * SCALE, sv = dqv[db][r] * SCALE;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                su += __shfl_xor(su, o, 64);
+                sv += __shfl_xor(sv, o, 64);
+            }
+            if (lr == 0) {
+                const int d = 32 * db + mfma32_row(r, lg);
+                unsafeAtomicAdd(&du[h * HD + d], su);
+                unsafeAtomicAdd(&dvb[h * HD + d], sv);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward kernel 3: dP[r, h*64 + d] += scale * sum_{b, i} dS_b[i, i + r - (T-1)] * Qv_b[i, d]
+//   grid (Rpad/64, H, Bsplit); each workgroup: one 64-row block of r, loops over its batch slice and all i tiles.
+//   dS^T tile staged with a 33-word row stride so that the diagonal gather is bank-conflict free.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relpos_bwd_dp_kernel(const bf16_t* __restrict__ dSt, const bf16_t* __restrict__ Qvt,
+                                                            float* __restrict__ dP, int B, int T, int Tpad, int H,
+                                                            int ldp) {
+    __shared__ __attribute__((aligned(16))) unsigned int lds_s[128 * 33];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_q[KVB * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
+    const int R0 = blockIdx.x * 64, h = blockIdx.y;
+    const int rb = wave >> 1, db = wave & 1;
+    const int bper = (B + gridDim.z - 1) / gridDim.z;
+    const int b_begin = blockIdx.z * bper, b_end = min(B, b_begin + bper);
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int ntiles = (T + 63) / 64;
+    const unsigned short* ls16 = reinterpret_cast<const unsigned short*>(lds_s);
+    for (int b = b_begin; b < b_end; ++b) {
+        const int bh = b * H + h;
+        for (int t = 0; t < ntiles; ++t) {
+            const int i0 = t * 64;
+            const int jbase = i0 + R0 - (T - 1);
+            if (jbase + 127 < 0 || jbase >= T) continue;  // whole tile outside the score matrix (block-uniform)
+            // stage dS^T rows j = jbase + jl (jl 0..127), columns i0..i0+63
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int jl = (tid >> 3) + 32 * i, c = tid & 7, j = jbase + jl;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (j >= 0 && j < T) v = *reinterpret_cast<const uint4*>(dSt + ((size_t)bh * Tpad + j) * Tpad + i0 + c * 8);
+                unsigned int* d = &lds_s[jl * 33 + c * 4];
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+            TileRegs rq;
+            tile_gload(rq, Qvt + (size_t)bh * HD * Tpad, 0, HD, Tpad, i0, tid);
+            tile_lstore_rows(rq, lds_q, tid);
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                s16x8_t af;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int ii = 16 * s + 8 * lg + e, rr = 32 * rb + lr;
+                    af[e] = (short)ls16[(ii + rr) * 66 + ii];
+                }
+                acc = mfma32(af, lds_frag_rows(lds_q, 32 * db + lr, 2 * s + lg), acc);
+            }
+            __syncthreads();
+        }
+    }
+    const int R = 2 * T - 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rr = R0 + 32 * rb + mfma32_row(r, lg);
+        if (rr < R) unsafeAtomicAdd(&dP[(size_t)rr * ldp + h * HD + 32 * db + lr], acc[r] * SCALE);
+    }
+}
+
+extern "C" int sed_relpos_attn_bwd(const void* Qu, const void* Qut, const void* Qv, const void* Qvt, const void* K,
+                                   const void* Kt, const void* V, const void* P, const void* Pt, const void* O,
+                                   const void* dO, const float* LSE, float* Dtmp, void* dOh, void* dOt, void* dqkv,
+                                   void* dSt, float* dP, float* du, float* dv, int B, int H, int T, int Tpad,
+                                   int Rpad, int need_param_grads, hipStream_t stream);
+
+// the pre-pass (D = rowsum(dO * O), head-split dO copies) is shared with the encoder attention
+extern "C" int sed_mhsa_bwd_prep(const void* dO, const void* O, float* Dtmp, void* dOh, void* dOt, int B, int H, int N,
+                                 int Npad, hipStream_t stream);
+
+extern "C" int sed_relpos_attn_bwd(const void* Qu, const void* Qut, const void* Qv, const void* Qvt, const void* K,
+                                   const void* Kt, const void* V, const void* P, const void* Pt, const void* O,
+                                   const void* dO, const float* LSE, float* Dtmp, void* dOh, void* dOt, void* dqkv,
+                                   void* dSt, float* dP, float* du, float* dv, int B, int H, int T, int Tpad,
+                                   int Rpad, int need_param_grads, hipStream_t stream) {
+    if (T <= 0 || (T % 8) || Tpad % 64 || Tpad < T || Rpad % 64 || Rpad < 2 * T - 1) return SED_ERR_ARG;
+    int rc = sed_mhsa_bwd_prep(dO, O, Dtmp, dOh, dOt, B, H, T, Tpad, stream);
+    if (rc) return rc;
+    dim3 grid(cdiv(T, 128), B * H);
+    hipLaunchKernelGGL(relpos_bwd_dkdv_kernel, grid, dim3(256), 0, stream, (const bf16_t*)Qu, (const bf16_t*)Qut,
+                       (const bf16_t*)Qv, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)P, (const bf16_t*)dOh,
+                       (const bf16_t*)dOt, LSE, Dtmp, (bf16_t*)dqkv, T, Tpad, H, Rpad);
+    hipLaunchKernelGGL(relpos_bwd_dq_kernel, grid, dim3(256), 0, stream, (const bf16_t*)Qu, (const bf16_t*)Qv,
+                       (const bf16_t*)K, (const bf16_t*)Kt, (const bf16_t*)V, (const bf16_t*)P, (const bf16_t*)Pt,
+                       (const bf16_t*)dOh, LSE, Dtmp, (bf16_t*)dqkv, (bf16_t*)dSt, du, dv, T, Tpad, H, Rpad);
+    if (need_param_grads) {
+        int bsplit = B < 8 ? B : 8;
+        hipLaunchKernelGGL(relpos_bwd_dp_kernel, dim3(Rpad / 64, H, bsplit), dim3(256), 0, stream, (const bf16_t*)dSt,
+                           (const bf16_t*)Qvt, dP, B, T, Tpad, H, H * HD);
+    }
+    return sed_check_launch();
+}

@@ -1,0 +1,631 @@
+"""Forward/backward engine of the MI355X-native MAT-SED model.
+
+This is the host-side orchestration of the HIP kernels behind `PaSST_SED.forward`
+(reference: src/models/passt/passt_sed.py:242-296 and everything it calls).  It owns
+  * the bf16 operand copies of all GEMM weights (straight [out,in] and transposed [in,out]),
+  * the explicit forward schedule (saving exactly what the hand-written backward needs),
+  * the explicit backward schedule writing into ONE flat fp32 gradient arena (views of which become `p.grad`,
+    and which the data-parallel layer all-reduces in buckets, see ddp.py).
+There is no autograd tape inside: `_SedFunction` in passt_sed.py exposes the whole model as a single
+autograd node so that the reference's training loops (loss via torch ops, loss.backward()) keep working.
+"""
+import math
+
+import torch
+
+from . import ops
+from .ops import BF16, F32, call, gemm_nt, gemm_dw, pad64, transpose_bf16
+from .ops import EPI_F32, EPI_F32_RESID, EPI_BF16, EPI_GELU, EPI_DGELU, EPI_F32_BF16
+
+D = 768
+H = 12
+NCLS_MAX = 16
+
+
+def window_starts(n_in=1000, win=512, step=49):
+    """src/models/encoder_slide_window.py:27."""
+    return list(range(0, n_in + step - win, step))
+
+
+def rel_pos_table(T, Dm=D):
+    """Sin/cos relative-position table [2T-1, D]; row k encodes relative position T-1-k
+    (src/models/transformer/transformerXL.py:84-127).  Host-built once per T (fp32, like the reference)."""
+    pos = torch.arange(0, T, dtype=torch.float32).unsqueeze(1)
+    div = torch.exp(torch.arange(0, Dm, 2, dtype=torch.float32) * -(math.log(10000.0) / Dm))
+    pp = torch.zeros(T, Dm)
+    pn = torch.zeros(T, Dm)
+    pp[:, 0::2] = torch.sin(pos * div)
+    pp[:, 1::2] = torch.cos(pos * div)
+    pn[:, 0::2] = torch.sin(-1 * pos * div)
+    pn[:, 1::2] = torch.cos(-1 * pos * div)
+    return torch.cat([torch.flip(pp, [0]), pn[1:]], dim=0)
+
+
+class _W:
+    """bf16 operand images of one fp32 weight matrix [n_out, k_in]."""
+    __slots__ = ("w", "wt")
+
+    def __init__(self, w, wt):
+        self.w, self.wt = w, wt
+
+
+class SedEngine:
+    def __init__(self, module):
+        self.m = module
+        self.dev = None
+        self.cache = {}
+        self.pos_cache = {}
+
+    def __deepcopy__(self, memo):
+        return None  # `ema_net = deepcopy(net)` (finetune/passt/setting.py:8-15): the copy rebuilds its engine lazily
+
+    # ------------------------------------------------------------------ parameters
+    def P(self, name):
+        return self.m._param_by_name[name]
+
+    def _weights(self, need_t):
+        """(Re)build bf16 copies of every GEMM weight from the fp32 masters (one transpose kernel each)."""
+        m = self.m
+        names = ["backbone.patch_embed.proj.weight"]
+        for i in range(m.depth):
+            p = f"backbone.blocks.{i}."
+            names += [p + "attn.qkv.weight", p + "attn.proj.weight", p + "mlp.fc1.weight", p + "mlp.fc2.weight"]
+        for i in range(m.decoder_layer_num):
+            p = f"decoder.encoder_blocks.{i}."
+            names += [p + "attn.in_proj.weight", p + "attn.out_proj.weight", p + "attn.linear_pos.weight",
+                      p + "mlp.fc1.weight", p + "mlp.fc2.weight"]
+        if m.mlm:
+            names += ["mlm_mlp.0.weight", "mlm_mlp.2.weight"]
+        if m.has_at:
+            names += ["at_adpater.0.frequency_att.in_proj_weight"]
+        for n in names:
+            w32 = self.P(n).detach()
+            n_out = w32.shape[0]
+            w2 = w32.reshape(n_out, -1)
+            k_in = w2.shape[1]
+            ent = self.cache.get(n)
+            if ent is None or ent.w.device != w32.device:
+                ent = _W(torch.empty(n_out, k_in, dtype=BF16, device=w32.device),
+                         torch.empty(k_in, n_out, dtype=BF16, device=w32.device))
+                self.cache[n] = ent
+            transpose_bf16(w2, n_out, k_in, ent.wt, out_s=ent.w)
+        return self.cache
+
+    def _pos(self, T, dev):
+        key = (T, str(dev))
+        if key not in self.pos_cache:
+            R = 2 * T - 1
+            Rpad = pad64(R)
+            tab = torch.zeros(Rpad, D)
+            tab[:R] = rel_pos_table(T)
+            tab = tab.to(dev)
+            pos16 = tab.to(BF16).contiguous()
+            posT16 = torch.empty(D, Rpad, dtype=BF16, device=dev)
+            transpose_bf16(tab, Rpad, D, posT16)
+            self.pos_cache[key] = (pos16, posT16, Rpad)
+        return self.pos_cache[key]
+
+    # ------------------------------------------------------------------ encoder
+    def _encoder_fwd(self, W, mel, tstarts, tp, toffsets, save, want_frame):
+        """PaSST encoder on `len(tstarts)` slabs of every clip (slabs folded into the batch, slab-major).
+        mel [B,128,T]; returns pooled [nS*B, tp, D] (f_pool of layer `feature_layer`), frame16 (final norm), ctx."""
+        m = self.m
+        dev = mel.device
+        B, _, T = mel.shape
+        nS = len(tstarts)
+        Bx = nS * B
+        N = 2 + 12 * tp
+        Npad = pad64(N)
+        M = Bx * N
+        E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
+        ctx = dict(B=Bx, N=N, Npad=Npad, tp=tp, layers=[], toffsets=toffsets, nS=nS)
+        cols = E(Bx * 12 * tp, 256, dt=BF16)
+        for s, ts in enumerate(tstarts):
+            call("sed_im2col", mel, cols[s * B * 12 * tp:(s + 1) * B * 12 * tp], B, T, ts, tp)
+        conv = E(Bx * 12 * tp, D)
+        gemm_nt(cols, W["backbone.patch_embed.proj.weight"].w, EPI_F32, bias=self.P("backbone.patch_embed.proj.bias"),
+                outF=conv)
+        x = E(Bx, N, D)
+        fpe = self.P("backbone.freq_new_pos_embed").reshape(D, 12)
+        tpe = self.P("backbone.time_new_pos_embed").reshape(D, 99)
+        for s in range(nS):
+            call("sed_assemble_tokens", conv[s * B * 12 * tp:(s + 1) * B * 12 * tp], self.P("backbone.cls_token"),
+                 self.P("backbone.dist_token"), self.P("backbone.new_pos_embed"), fpe, tpe, int(toffsets[s]),
+                 x[s * B:(s + 1) * B], B, tp)
+        if save:
+            ctx["cols"] = cols
+        # per-call scratch (reused across layers when not saving)
+        mk_qkv = lambda: [E(Bx * H, N, 64, dt=BF16) for _ in range(3)]
+        mk_t = lambda: [torch.zeros(Bx * H, 64, Npad, dtype=BF16, device=dev) for _ in range(3)]
+        scratch = None
+        pooled = None
+        for li in range(m.depth):
+            p = f"backbone.blocks.{li}."
+            L = {}
+            if save or scratch is None:
+                h16 = E(M, D, dt=BF16)
+                q, k, v = mk_qkv()
+                qt, kt, vt = mk_t() if save else (None, None, torch.zeros(Bx * H, 64, Npad, dtype=BF16, device=dev))
+                o16 = E(M, D, dt=BF16)
+                lse = E(Bx * H, N)
+                h2 = E(M, D, dt=BF16)
+                hpre = E(M, 4 * D, dt=BF16)
+                act = E(M, 4 * D, dt=BF16)
+                mean1, rstd1, mean2, rstd2 = (E(M), E(M), E(M), E(M)) if save else (None, None, None, None)
+                scratch = (h16, q, k, v, qt, kt, vt, o16, lse, h2, hpre, act)
+            else:
+                h16, q, k, v, qt, kt, vt, o16, lse, h2, hpre, act = scratch
+                mean1 = rstd1 = mean2 = rstd2 = None
+            x_in = x
+            call("sed_layernorm_fwd", x_in, self.P(p + "norm1.weight"), self.P(p + "norm1.bias"), 1e-6, 1.0, h16, None,
+                 mean1, rstd1, M, D)
+            call("sed_gemm_qkv", h16, W[p + "attn.qkv.weight"].w, self.P(p + "attn.qkv.bias"), M, D, H, N, Npad, q, k,
+                 v, qt, kt, vt, None, None, None, None)
+            call("sed_mhsa_fwd", q, k, vt, o16, lse, Bx, H, N, Npad)
+            x_mid = E(Bx, N, D) if save else x_in
+            gemm_nt(o16, W[p + "attn.proj.weight"].w, EPI_F32_RESID, bias=self.P(p + "attn.proj.bias"), res=x_in,
+                    outF=x_mid)
+            call("sed_layernorm_fwd", x_mid, self.P(p + "norm2.weight"), self.P(p + "norm2.bias"), 1e-6, 1.0, h2, None,
+                 mean2, rstd2, M, D)
+            gemm_nt(h2, W[p + "mlp.fc1.weight"].w, EPI_GELU, bias=self.P(p + "mlp.fc1.bias"), outH=hpre, outH2=act)
+            x_out = E(Bx, N, D) if save else x_mid
+            gemm_nt(act, W[p + "mlp.fc2.weight"].w, EPI_F32_RESID, bias=self.P(p + "mlp.fc2.bias"), res=x_mid,
+                    outF=x_out)
+            if save:
+                L.update(x_in=x_in, h16=h16, q=q, k=k, v=v, qt=qt, kt=kt, o16=o16, lse=lse, x_mid=x_mid, h2=h2,
+                         hpre=hpre, act=act, mean1=mean1, rstd1=rstd1, mean2=mean2, rstd2=rstd2)
+                ctx["layers"].append(L)
+            x = x_out
+            if li + 1 == m.passt_feature_layer:
+                pooled = E(Bx, tp, D)
+                pm = torch.zeros(M, device=dev) if save else None
+                pr = torch.zeros(M, device=dev) if save else None
+                call("sed_fpool_fwd", x, self.P("out_norm.weight"), self.P("out_norm.bias"), 1e-5, pooled, pm, pr, Bx,
+                     tp)
+                if save:
+                    ctx.update(pool_x=x, pool_mean=pm, pool_rstd=pr)
+                if not want_frame:
+                    break  # later blocks only feed the AT head (`frame`); windows never need them
+        frame16 = None
+        if want_frame:
+            frame16 = E(M, D, dt=BF16)
+            fm, fr = (E(M), E(M)) if save else (None, None)
+            call("sed_layernorm_fwd", x, self.P("backbone.norm.weight"), self.P("backbone.norm.bias"), 1e-6, 1.0,
+                 frame16, None, fm, fr, M, D)
+            if save:
+                ctx.update(x_final=x, fmean=fm, frstd=fr, frame16=frame16)
+        return pooled, frame16, ctx
+
+    # ------------------------------------------------------------------ context network
+    def _decoder_fwd(self, W, x, save):
+        """TransformerXLDecoder (src/models/transformer_decoder.py:110-122, transformerXL.py:31-35). x [B,T,D] f32."""
+        m = self.m
+        dev = x.device
+        B, T, _ = x.shape
+        Tpad = pad64(T)
+        M = B * T
+        pos16, posT16, Rpad = self._pos(T, dev)
+        E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
+        ctx = dict(B=B, T=T, Tpad=Tpad, Rpad=Rpad, layers=[])
+        cur = x
+        for li in range(m.decoder_layer_num):
+            p = f"decoder.encoder_blocks.{li}."
+            in_scale = math.sqrt(D) if li == 0 else 1.0
+            y16 = E(M, D, dt=BF16)
+            y32 = E(B, T, D)
+            mean1, rstd1 = (E(M), E(M)) if save else (None, None)
+            call("sed_layernorm_fwd", cur, self.P(p + "norm1.weight"), self.P(p + "norm1.bias"), 1e-5, in_scale, y16,
+                 y32, mean1, rstd1, M, D)
+            # p = linear_pos(pos_emb), head-split [H, Rpad, 64] (+ transposed [H, 64, Rpad] for backward)
+            Ph = E(H, Rpad, 64, dt=BF16)
+            Pt = torch.zeros(H, 64, Rpad, dtype=BF16, device=dev) if save else None
+            Wpos = W[p + "attn.linear_pos.weight"].w
+            # reuse the head-split epilogue with a "qkv" weight made of [Wpos; Wpos; Wpos]? -> no: plain GEMM + split
+            ptmp = E(Rpad, D, dt=BF16)
+            gemm_nt(pos16, Wpos, EPI_BF16, outH=ptmp)
+            Ph.copy_(ptmp.view(Rpad, H, 64).permute(1, 0, 2))
+            if save:
+                Pt.copy_(ptmp.view(Rpad, H, 64).permute(1, 2, 0))
+            qu, k, v = [E(B * H, T, 64, dt=BF16) for _ in range(3)]
+            qv = E(B * H, T, 64, dt=BF16)
+            vt = torch.zeros(B * H, 64, Tpad, dtype=BF16, device=dev)
+            qut = kt = qvt = None
+            if save:
+                qut, kt, qvt = [torch.zeros(B * H, 64, Tpad, dtype=BF16, device=dev) for _ in range(3)]
+            call("sed_gemm_qkv", y16, W[p + "attn.in_proj.weight"].w, self.P(p + "attn.in_proj.bias"), M, D, H, T, Tpad,
+                 qu, k, v, qut, kt, vt, qv, qvt, self.P(p + "attn.pos_bias_u"), self.P(p + "attn.pos_bias_v"))
+            o16 = E(M, D, dt=BF16)
+            lse = E(B * H, T)
+            call("sed_relpos_attn_fwd", qu, qv, k, vt, Ph, o16, lse, B, H, T, Tpad, Rpad)
+            x1 = E(B, T, D)
+            gemm_nt(o16, W[p + "attn.out_proj.weight"].w, EPI_F32_RESID, bias=self.P(p + "attn.out_proj.bias"), res=y32,
+                    outF=x1)
+            h2 = E(M, D, dt=BF16)
+            mean2, rstd2 = (E(M), E(M)) if save else (None, None)
+            call("sed_layernorm_fwd", x1, self.P(p + "norm2.weight"), self.P(p + "norm2.bias"), 1e-5, 1.0, h2, None,
+                 mean2, rstd2, M, D)
+            hpre = E(M, D, dt=BF16)
+            act = E(M, D, dt=BF16)
+            gemm_nt(h2, W[p + "mlp.fc1.weight"].w, EPI_GELU, bias=self.P(p + "mlp.fc1.bias"), outH=hpre, outH2=act)
+            x2 = E(B, T, D)
+            gemm_nt(act, W[p + "mlp.fc2.weight"].w, EPI_F32_RESID, bias=self.P(p + "mlp.fc2.bias"), res=x1, outF=x2)
+            if save:
+                ctx["layers"].append(dict(x_in=cur, in_scale=in_scale, y16=y16, mean1=mean1, rstd1=rstd1, Ph=Ph, Pt=Pt,
+                                          qu=qu, qut=qut, qv=qv, qvt=qvt, k=k, kt=kt, v=v, o16=o16, lse=lse, x1=x1,
+                                          h2=h2, mean2=mean2, rstd2=rstd2, hpre=hpre, act=act))
+            cur = x2
+        return cur, ctx
+
+    # ------------------------------------------------------------------ full forward
+    def forward(self, mel, encoder_win=False, mix_rate=0.5, win_param=(512, 49), temp_w=1.0, pad_mask=None,
+                mlm_plan=None, toffsets=None, save=False):
+        m = self.m
+        dev = mel.device
+        if mel.dtype != F32 or not mel.is_contiguous():
+            mel = mel.contiguous().float()
+        B, Fm, T = mel.shape
+        assert Fm == 128
+        W = self._weights(need_t=save)
+        out = {}
+        tp = (T - 16) // 10 + 1
+        tp = min(tp, 99)
+        pooled, frame16, ectx = self._encoder_fwd(W, mel, [0], tp, [0], save, want_frame=m.has_at)
+        E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
+        ratio = m.decode_ratio
+        pad = 1  # 99 -> 100 frames (passt_sed.py:258)
+        Tdec = (tp + pad) * ratio
+        assert Tdec == 1000, "MAT-SED expects 1000 decoder frames (passt_sed.py:260)"
+        xg = E(B, Tdec, D)
+        call("sed_interp_fwd", pooled, xg, B, tp, pad, ratio)
+        if encoder_win:
+            if save:
+                raise NotImplementedError("gradient through the sliding-window path is not needed by any MAT-SED "
+                                          "config (only the no-grad teacher / validation use it)")
+            win, step = win_param
+            starts = window_starts(T, win, step)
+            tpw = (win - 16) // 10 + 1
+            if toffsets is None:
+                toffsets = [0] * len(starts)
+            pw, _, _ = self._encoder_fwd(W, mel, starts, tpw, list(toffsets), False, want_frame=False)
+            lefts = torch.tensor([round(s * (Tdec / T)) for s in starts], dtype=torch.int32, device=dev)
+            call("sed_window_mix", pw, lefts, len(starts), xg, float(mix_rate), B, Tdec, tpw, ratio)
+        out["frame_before_mask"] = xg
+        dec_in = xg
+        if m.mlm and mlm_plan is not None:
+            out["mask_id_seq"] = mlm_plan["mask_ids"]
+            if mlm_plan["effective"]:
+                dec_in = E(B, Tdec, D)
+                call("sed_mlm_apply", xg, self.P("mask_token").reshape(D), mlm_plan["action"], mlm_plan["src_idx"],
+                     dec_in, B * Tdec)
+        xd, dctx = self._decoder_fwd(W, dec_in, save)
+        actx = None
+        if m.has_at:
+            actx = self._at_fwd(W, frame16, ectx, save)
+            out["at_out"] = actx["at_out"]
+        hctx = {}
+        if m.mlm:
+            M = B * Tdec
+            xd16 = E(M, D, dt=BF16)
+            call("sed_cast_f32_bf16", xd, xd16, M * D)
+            hpre = E(M, D, dt=BF16)
+            act = E(M, D, dt=BF16)
+            gemm_nt(xd16, W["mlm_mlp.0.weight"].w, EPI_GELU, bias=self.P("mlm_mlp.0.bias"), outH=hpre, outH2=act)
+            pred = E(B, Tdec, D)
+            gemm_nt(act, W["mlm_mlp.2.weight"].w, EPI_F32, bias=self.P("mlm_mlp.2.bias"), outF=pred)
+            out["mlm_pred"] = pred
+            hctx = dict(xd16=xd16, hpre=hpre, act=act)
+        else:
+            C = m.class_num
+            strong = E(B, C, Tdec)
+            weak = E(B, C)
+            sums = E(B, C, 2)
+            pm = None
+            if pad_mask is not None:
+                pm = pad_mask.to(device=dev, dtype=torch.uint8).contiguous()
+            call("sed_head_fwd", xd, self.P("classifier.weight"), self.P("classifier.bias"), float(temp_w), pm, strong,
+                 weak, sums, B, Tdec, C)
+            out["strong"], out["weak"] = strong, weak
+            hctx = dict(strong=strong, sums=sums, temp=float(temp_w))
+        ctx = None
+        if save:
+            ctx = dict(B=B, T=T, tp=tp, Tdec=Tdec, ectx=ectx, dctx=dctx, actx=actx, hctx=hctx, xd=xd, W=W,
+                       mlm_plan=mlm_plan if (m.mlm and mlm_plan is not None and mlm_plan["effective"]) else None,
+                       pooled=pooled)
+        return out, ctx
+
+    # ------------------------------------------------------------------ AT head
+    def _at_fwd(self, W, frame16, ectx, save):
+        m = self.m
+        dev = frame16.device
+        B, N = ectx["B"], ectx["N"]
+        E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
+        pre = "at_adpater.0."
+        win = self.P(pre + "frequency_att.in_proj_weight")
+        bin_ = self.P(pre + "frequency_att.in_proj_bias")
+        q = E(1, D)
+        call("sed_small_linear", self.P(pre + "f_att_token").reshape(1, D), win[:D], bin_[:D], q, 1, D, D, 0)
+        kv16 = E(B * N, 2 * D, dt=BF16)
+        gemm_nt(frame16, W[pre + "frequency_att.in_proj_weight"].w[D:], EPI_BF16, bias=bin_[D:], outH=kv16)
+        pooled = E(B, D)
+        probs = E(B * H, N - 2) if save else None
+        call("sed_attnpool_fwd", kv16, q, pooled, probs, B, N, H)
+        att = E(B, D)
+        call("sed_small_linear", pooled, self.P(pre + "frequency_att.out_proj.weight"),
+             self.P(pre + "frequency_att.out_proj.bias"), att, B, D, D, 0)
+        C = m.class_num
+        at_out = E(B, C)
+        call("sed_small_linear", att, self.P("at_adpater.1.weight"), self.P("at_adpater.1.bias"), at_out, B, C, D, 1)
+        return dict(q=q, kv16=kv16, pooled=pooled, probs=probs, att=att, at_out=at_out)
+
+    # ==================================================================== backward
+    def backward(self, ctx, grads, garena):
+        """grads: dict of upstream gradients (strong / weak / at_out / mlm_pred / frame_before_mask, any may be None).
+        garena: callable name -> fp32 gradient view (zero-initialised) or None when the parameter is frozen."""
+        m = self.m
+        W = ctx["W"]
+        B, Tdec = ctx["B"], ctx["Tdec"]
+        dev = ctx["xd"].device
+        E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
+        Z = lambda *s, dt=F32: torch.zeros(*s, dtype=dt, device=dev)
+        G = garena
+        M = B * Tdec
+        Mpad = pad64(M)
+        # ---------------- heads -> d(decoder output)
+        if m.mlm:
+            dpred = grads.get("mlm_pred")
+            hc = ctx["hctx"]
+            if dpred is None:
+                g = Z(B, Tdec, D)
+            else:
+                dpred = dpred.contiguous().float()
+                g = self._mlp_bwd(W, "mlm_mlp.0", "mlm_mlp.2", dpred.view(M, D), hc["xd16"], hc["hpre"], hc["act"], M,
+                                  G, residual=None)
+        else:
+            hc = ctx["hctx"]
+            ds, dw = grads.get("strong"), grads.get("weak")
+            g = E(B, Tdec, D)
+            if ds is None and dw is None:
+                g.zero_()
+            else:
+                ds = None if ds is None else ds.contiguous().float()
+                dw = None if dw is None else dw.contiguous().float()
+                call("sed_head_bwd", ctx["xd"], self.P("classifier.weight"), hc["strong"], hc["sums"], ds, dw, hc["temp"],
+                     g, G("classifier.weight"), G("classifier.bias"), B, Tdec, m.class_num)
+        # ---------------- context network
+        dec_trainable = G("decoder.encoder_blocks.0.attn.in_proj.weight") is not None
+        g = self._decoder_bwd(W, ctx["dctx"], g, G, dec_trainable)
+        # g = d(decoder input) [B, Tdec, D]
+        if ctx["mlm_plan"] is not None:
+            plan = ctx["mlm_plan"]
+            gx = Z(B, Tdec, D)
+            dtok = G("mask_token")
+            call("sed_mlm_apply_bwd", g, plan["action"], plan["src_idx"], gx, dtok if dtok is not None else Z(D), M)
+            g = gx
+        dfbm = grads.get("frame_before_mask")
+        if dfbm is not None:
+            g = g + dfbm.contiguous().float()
+        # ---------------- interp + f_pool -> encoder layer `feature_layer`
+        ectx = ctx["ectx"]
+        tp = ctx["tp"]
+        dpooled = E(B, tp, D)
+        call("sed_interp_bwd", g, dpooled, B, tp, 1, m.decode_ratio)
+        enc_trainable = G("backbone.blocks.0.attn.qkv.weight") is not None
+        N = ectx["N"]
+        Me = B * N
+        genc = None  # gradient of the encoder residual stream, built from the top
+        if m.has_at and grads.get("at_out") is not None:
+            genc = self._at_bwd(W, ctx["actx"], ectx, grads["at_out"].contiguous().float(), G, need_dx=enc_trainable)
+        need_pool_dx = enc_trainable
+        depth = len(ectx["layers"])
+        gpool = Z(B, N, D) if need_pool_dx else None
+        dtok_tmp = E(B, N, D)
+        # out_norm grads (+ dx into the stream at the feature layer)
+        pool_dx = gpool if need_pool_dx else E(B, N, D)
+        if not need_pool_dx:
+            pool_dx.zero_()
+        call("sed_fpool_bwd", dpooled, ectx["pool_x"], ectx["pool_mean"], ectx["pool_rstd"], self.P("out_norm.weight"),
+             dtok_tmp, pool_dx, G("out_norm.weight"), G("out_norm.bias"), B, tp)
+        if not enc_trainable:
+            return
+        if genc is None:
+            genc = Z(B, N, D)
+        for li in range(depth - 1, -1, -1):
+            if li + 1 == m.passt_feature_layer:
+                genc.add_(gpool)
+            genc = self._enc_layer_bwd(W, ectx, li, genc, G)
+        # patch embedding + positional tables
+        dconv16 = E(B * 12 * tp, D, dt=BF16)
+        toff = int(ectx["toffsets"][0])
+        call("sed_assemble_tokens_bwd", genc, dconv16, G("backbone.cls_token"), G("backbone.dist_token"),
+             G("backbone.new_pos_embed"), G("backbone.freq_new_pos_embed"), G("backbone.time_new_pos_embed"), toff, B, tp)
+        Mp = B * 12 * tp
+        Mppad = pad64(Mp)
+        dT = E(D, Mppad, dt=BF16)
+        transpose_bf16(dconv16, Mp, D, dT, colsum=G("backbone.patch_embed.proj.bias"))
+        cT = E(256, Mppad, dt=BF16)
+        transpose_bf16(ectx["cols"], Mp, 256, cT)
+        gemm_dw(dT, cT, G("backbone.patch_embed.proj.weight"))
+
+    def _mlp_bwd(self, W, n1, n2, dy, x16, hpre, act, M, G, residual):
+        """Backward of y = fc2(gelu(fc1(x))) given dy [M, n_out] f32.  Returns dx f32 [M, D] (new tensor), or adds
+        into `residual` (f32 [M, D]) when given.  Weight/bias grads go to the arena when trainable."""
+        dev = dy.device
+        E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
+        Mpad = pad64(M)
+        w1, w2 = W[n1 + ".weight"], W[n2 + ".weight"]
+        hid = w1.w.shape[0]
+        n_out = w2.w.shape[0]
+        train = G(n1 + ".weight") is not None
+        g16 = E(M, n_out, dt=BF16)
+        gT = E(n_out, Mpad, dt=BF16)
+        transpose_bf16(dy, M, n_out, gT, out_s=g16, colsum=G(n2 + ".bias") if train else None)
+        dh16 = E(M, hid, dt=BF16)
+        gemm_nt(g16, w2.wt, EPI_DGELU, outH=dh16, aux=hpre)
+        if train:
+            aT = E(hid, Mpad, dt=BF16)
+            transpose_bf16(act, M, hid, aT)
+            gemm_dw(gT, aT, G(n2 + ".weight"))
+            del aT
+            dhT = E(hid, Mpad, dt=BF16)
+            transpose_bf16(dh16, M, hid, dhT, colsum=G(n1 + ".bias"))
+            xT = E(x16.shape[1], Mpad, dt=BF16)
+            transpose_bf16(x16, M, x16.shape[1], xT)
+            gemm_dw(dhT, xT, G(n1 + ".weight"))
+        if residual is not None:
+            gemm_nt(dh16, w1.wt, EPI_F32_RESID, res=residual, outF=residual)
+            return residual
+        dx = E(M, w1.wt.shape[0])
+        gemm_nt(dh16, w1.wt, EPI_F32, outF=dx)
+        return dx
+
+    def _enc_layer_bwd(self, W, ectx, li, g, G):
+        p = f"backbone.blocks.{li}."
+        L = ectx["layers"][li]
+        B, N, Npad = ectx["B"], ectx["N"], ectx["Npad"]
+        M = B * N
+        Mpad = pad64(M)
+        dev = g.device
+        E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
+        g2 = g.view(M, D)
+        # ---- MLP branch: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
+        dln = self._mlp_bwd(W, p + "mlp.fc1", p + "mlp.fc2", g2, L["h2"], L["hpre"], L["act"], M, G, residual=None)
+        call("sed_layernorm_bwd", dln, L["x_mid"], L["mean2"], L["rstd2"], self.P(p + "norm2.weight"), 1.0, g2, 1,
+             G(p + "norm2.weight"), G(p + "norm2.bias"), M, D)
+        del dln
+        # ---- attention branch: x_mid = x_in + proj(attn(LN1(x_in)))
+        g16 = E(M, D, dt=BF16)
+        gT = E(D, Mpad, dt=BF16)
+        transpose_bf16(g2, M, D, gT, out_s=g16, colsum=G(p + "attn.proj.bias"))
+        oT = E(D, Mpad, dt=BF16)
+        transpose_bf16(L["o16"], M, D, oT)
+        gemm_dw(gT, oT, G(p + "attn.proj.weight"))
+        del oT, gT
+        do16 = E(M, D, dt=BF16)
+        gemm_nt(g16, W[p + "attn.proj.weight"].wt, EPI_BF16, outH=do16)
+        dqkv = E(M, 3 * D, dt=BF16)
+        Dtmp = E(B * H, N)
+        dOh = E(B * H, N, 64, dt=BF16)
+        dOt = E(B * H, 64, Npad, dt=BF16)
+        call("sed_mhsa_bwd", L["q"], L["qt"], L["k"], L["kt"], L["v"], L["o16"], do16, L["lse"], Dtmp, dOh, dOt, dqkv, B,
+             H, N, Npad)
+        del dOh, dOt, do16
+        dqT = E(3 * D, Mpad, dt=BF16)
+        transpose_bf16(dqkv, M, 3 * D, dqT, colsum=G(p + "attn.qkv.bias"))
+        hT = E(D, Mpad, dt=BF16)
+        transpose_bf16(L["h16"], M, D, hT)
+        gemm_dw(dqT, hT, G(p + "attn.qkv.weight"))
+        del dqT, hT
+        dln = E(M, D)
+        gemm_nt(dqkv, W[p + "attn.qkv.weight"].wt, EPI_F32, outF=dln)
+        call("sed_layernorm_bwd", dln, L["x_in"], L["mean1"], L["rstd1"], self.P(p + "norm1.weight"), 1.0, g2, 1,
+             G(p + "norm1.weight"), G(p + "norm1.bias"), M, D)
+        ectx["layers"][li] = None  # free saved activations
+        return g
+
+    def _decoder_bwd(self, W, dctx, g, G, trainable):
+        m = self.m
+        B, T, Tpad, Rpad = dctx["B"], dctx["T"], dctx["Tpad"], dctx["Rpad"]
+        M = B * T
+        Mpad = pad64(M)
+        dev = g.device
+        E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
+        Z = lambda *s, dt=F32: torch.zeros(*s, dtype=dt, device=dev)
+        pos16, posT16, _ = self._pos(T, dev)
+        g = g.contiguous()
+        for li in range(m.decoder_layer_num - 1, -1, -1):
+            p = f"decoder.encoder_blocks.{li}."
+            L = dctx["layers"][li]
+            Gl = G if trainable else (lambda n: None)
+            g2 = g.view(M, D)
+            # MLP branch
+            dln = self._mlp_bwd(W, p + "mlp.fc1", p + "mlp.fc2", g2, L["h2"], L["hpre"], L["act"], M, Gl, residual=None)
+            call("sed_layernorm_bwd", dln, L["x1"], L["mean2"], L["rstd2"], self.P(p + "norm2.weight"), 1.0, g2, 1,
+                 Gl(p + "norm2.weight"), Gl(p + "norm2.bias"), M, D)
+            del dln
+            # attention branch: x1 = y + out_proj(relattn(y)),  y = LN1(in_scale * x_in)
+            g16 = E(M, D, dt=BF16)
+            gT = E(D, Mpad, dt=BF16)
+            transpose_bf16(g2, M, D, gT, out_s=g16, colsum=Gl(p + "attn.out_proj.bias"))
+            if trainable:
+                oT = E(D, Mpad, dt=BF16)
+                transpose_bf16(L["o16"], M, D, oT)
+                gemm_dw(gT, oT, G(p + "attn.out_proj.weight"))
+                del oT
+            del gT
+            do16 = E(M, D, dt=BF16)
+            gemm_nt(g16, W[p + "attn.out_proj.weight"].wt, EPI_BF16, outH=do16)
+            dqkv = E(M, 3 * D, dt=BF16)
+            Dtmp = E(B * H, T)
+            dOh = E(B * H, T, 64, dt=BF16)
+            dOt = E(B * H, 64, Tpad, dt=BF16)
+            dSt = Z(B * H, Tpad, Tpad, dt=BF16)
+            dP = Z(Rpad, D)
+            du = Gl(p + "attn.pos_bias_u")
+            dv = Gl(p + "attn.pos_bias_v")
+            scratch_uv = Z(2, D)
+            call("sed_relpos_attn_bwd", L["qu"], L["qut"], L["qv"], L["qvt"], L["k"], L["kt"], L["v"], L["Ph"], L["Pt"],
+                 L["o16"], do16, L["lse"], Dtmp, dOh, dOt, dqkv, dSt, dP, du if du is not None else scratch_uv[0],
+                 dv if dv is not None else scratch_uv[1], B, H, T, Tpad, Rpad, 1 if trainable else 0)
+            del dSt, dOh, dOt, do16
+            if trainable:
+                dPT = E(D, Rpad, dt=BF16)
+                transpose_bf16(dP, Rpad, D, dPT)
+                gemm_dw(dPT, posT16, G(p + "attn.linear_pos.weight"))
+                dqT = E(3 * D, Mpad, dt=BF16)
+                transpose_bf16(dqkv, M, 3 * D, dqT, colsum=G(p + "attn.in_proj.bias"))
+                yT = E(D, Mpad, dt=BF16)
+                transpose_bf16(L["y16"], M, D, yT)
+                gemm_dw(dqT, yT, G(p + "attn.in_proj.weight"))
+                del dqT, yT
+            # dy = g (residual from the normalised input) + dqkv @ W_in
+            gemm_nt(dqkv, W[p + "attn.in_proj.weight"].wt, EPI_F32_RESID, res=g2, outF=g2)
+            gnew = E(B, T, D)
+            call("sed_layernorm_bwd", g2, L["x_in"], L["mean1"], L["rstd1"], self.P(p + "norm1.weight"), L["in_scale"],
+                 gnew.view(M, D), 0, Gl(p + "norm1.weight"), Gl(p + "norm1.bias"), M, D)
+            g = gnew
+            dctx["layers"][li] = None
+        return g
+
+    def _at_bwd(self, W, a, ectx, dat, G, need_dx):
+        """Backward of the AT head.  Returns d(encoder residual stream) [B, N, D] (or None when not needed)."""
+        m = self.m
+        dev = dat.device
+        B, N = ectx["B"], ectx["N"]
+        M = B * N
+        Mpad = pad64(M)
+        E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
+        Z = lambda *s, dt=F32: torch.zeros(*s, dtype=dt, device=dev)
+        pre = "at_adpater.0."
+        C = m.class_num
+        train = G("at_adpater.1.weight") is not None
+        datt = E(B, D)
+        call("sed_small_linear_bwd", a["att"], self.P("at_adpater.1.weight"), a["at_out"], dat, datt,
+             G("at_adpater.1.weight"), G("at_adpater.1.bias"), B, C, D, 1)
+        dpool = E(B, D)
+        call("sed_small_linear_bwd", a["pooled"], self.P(pre + "frequency_att.out_proj.weight"), None, datt, dpool,
+             G(pre + "frequency_att.out_proj.weight"), G(pre + "frequency_att.out_proj.bias"), B, D, D, 0)
+        dkv = E(M, 2 * D, dt=BF16)
+        dq = Z(1, D)
+        call("sed_attnpool_bwd", a["kv16"], a["q"], a["probs"], dpool, dkv, dq, B, N, H)
+        gin = G(pre + "frequency_att.in_proj_weight")
+        gib = G(pre + "frequency_att.in_proj_bias")
+        win = self.P(pre + "frequency_att.in_proj_weight")
+        if train:
+            dtok = Z(1, D)
+            call("sed_small_linear_bwd", self.P(pre + "f_att_token").reshape(1, D), win[:D], None, dq, dtok, gin[:D],
+                 gib[:D], 1, D, D, 0)
+            G(pre + "f_att_token").view(1, D).add_(dtok)
+            dkT = E(2 * D, Mpad, dt=BF16)
+            transpose_bf16(dkv, M, 2 * D, dkT, colsum=gib[D:])
+            fT = E(D, Mpad, dt=BF16)
+            transpose_bf16(ectx["frame16"], M, D, fT)
+            gemm_dw(dkT, fT, gin[D:])
+        norm_train = G("backbone.norm.weight") is not None
+        if not (need_dx or norm_train):
+            return None
+        dframe = E(M, D)
+        gemm_nt(dkv, W[pre + "frequency_att.in_proj_weight"].wt[:, D:].contiguous(), EPI_F32, outF=dframe)
+        genc = E(B, N, D)
+        call("sed_layernorm_bwd", dframe, ectx["x_final"], ectx["fmean"], ectx["frstd"], self.P("backbone.norm.weight"),
+             1.0, genc.view(M, D), 0, G("backbone.norm.weight"), G("backbone.norm.bias"), M, D)
+        return genc if need_dx else None

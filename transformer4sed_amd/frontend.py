@@ -1,0 +1,93 @@
+"""HIP log-mel frontend behind the reference's `PasstFeatureExtractor` contract
+(src/models/passt/passt_feature_extraction.py:7-94): `extractor(wav[B,N]) -> mel[B,128,T]`, `extractor.normalize(mel)`,
+train-mode random (fmin, fmax) drawn with the same torch.randint calls (same seed -> same draws)."""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .ops import call
+
+
+def kaldi_mel_banks(fmin, fmax, n_mels=128, n_fft=1024, sr=32000):
+    """Host-side Kaldi triangular filterbank [n_mels, n_fft/2+1] (last column zero), restating
+    torchaudio.compliance.kaldi.get_mel_banks as called at passt_feature_extraction.py:73-82 (fp32 tensor math)."""
+    n_bins = n_fft // 2
+    bin_width = sr / n_fft
+    mel_lo = 1127.0 * math.log(1.0 + fmin / 700.0)
+    mel_hi = 1127.0 * math.log(1.0 + fmax / 700.0)
+    delta = (mel_hi - mel_lo) / (n_mels + 1)
+    b = torch.arange(n_mels, dtype=torch.float32).unsqueeze(1)
+    left, center, right = mel_lo + b * delta, mel_lo + (b + 1.0) * delta, mel_lo + (b + 2.0) * delta
+    mel = (1127.0 * (1.0 + (bin_width * torch.arange(n_bins, dtype=torch.float32)) / 700.0).log()).unsqueeze(0)
+    w = torch.clamp(torch.minimum((mel - left) / (center - left), (right - mel) / (right - center)), min=0.0)
+    return torch.nn.functional.pad(w, (0, 1))
+
+
+class PasstFeatureExtractor(nn.Module):
+    def __init__(self, n_mels=128, sr=32000, win_length=800, hopsize=320, n_fft=1024, htk=False, fmin=0.0, fmax=None,
+                 wav_norm=True, fmin_aug_range=1, fmax_aug_range=1000):
+        super().__init__()
+        if (n_mels, sr, win_length, hopsize, n_fft, wav_norm) != (128, 32000, 800, 320, 1024, True):
+            raise NotImplementedError("the HIP frontend is specialised to the MAT-SED configuration "
+                                      "(128 mel, 32 kHz, win 800, hop 320, n_fft 1024, wav_norm)")
+        self.n_mels, self.sr, self.win_length, self.hopsize, self.n_fft = n_mels, sr, win_length, hopsize, n_fft
+        self.fmin = fmin
+        self.fmax = sr // 2 - fmax_aug_range // 2 if fmax is None else fmax
+        self.fmin_aug_range, self.fmax_aug_range = fmin_aug_range, fmax_aug_range
+        k = torch.arange(win_length, dtype=torch.float64)
+        self.register_buffer("window", (0.5 - 0.5 * torch.cos(2 * math.pi * k / (win_length - 1))).float(),
+                             persistent=False)
+        ang = -2.0 * math.pi * torch.arange(n_fft, dtype=torch.float64) / n_fft
+        self.register_buffer("twiddle", torch.stack([torch.cos(ang), torch.sin(ang)], dim=1).float().contiguous(),
+                             persistent=False)
+        self._banks = {}
+        self.last_fmin_fmax = None
+
+    def _bank(self, fmin, fmax, dev):
+        key = (float(fmin), float(fmax), str(dev))
+        if key not in self._banks:
+            w = kaldi_mel_banks(fmin, fmax)
+            nz = (w > 0).numpy()
+            rng = np.zeros((self.n_mels, 2), dtype=np.int32)
+            for m in range(self.n_mels):
+                idx = np.nonzero(nz[m])[0]
+                if len(idx):
+                    rng[m] = (idx[0], idx[-1] + 1)
+            if len(self._banks) > 64:
+                self._banks.clear()
+            self._banks[key] = (w.contiguous().to(dev), torch.from_numpy(rng).to(dev))
+        return self._banks[key]
+
+    def forward(self, x, fmin_fmax=None):
+        """wav [B, L] -> raw mel power [B, 128, T] (the reference applies `.normalize` separately)."""
+        return self._run(x, fmin_fmax, do_log=0)
+
+    def logmel(self, x, fmin_fmax=None):
+        """Fused `normalize(forward(x))` in one kernel (what the trainers in this package use)."""
+        return self._run(x, fmin_fmax, do_log=1)
+
+    def _run(self, x, fmin_fmax, do_log):
+        # same RNG call order as the reference (passt_feature_extraction.py:66-71): always draw, use only in train
+        fmin = self.fmin + torch.randint(self.fmin_aug_range, (1,)).item()
+        fmax = self.fmax + self.fmax_aug_range // 2 - torch.randint(self.fmax_aug_range, (1,)).item()
+        if not self.training:
+            fmin, fmax = self.fmin, self.fmax
+        if fmin_fmax is not None:
+            fmin, fmax = fmin_fmax
+        self.last_fmin_fmax = (fmin, fmax)
+        x = x.contiguous().float()
+        B, L = x.shape
+        T = 1 + (L - 1) // self.hopsize
+        melw, rng = self._bank(fmin, fmax, x.device)
+        out = torch.empty(B, self.n_mels, T, dtype=torch.float32, device=x.device)
+        tmp = torch.empty(B, dtype=torch.int32, device=x.device)
+        call("sed_logmel_fwd", x, out, tmp, self.window, self.twiddle, melw, rng, B, L, T, do_log)
+        return out
+
+    def normalize(self, melspec):
+        return ((melspec + 0.00001).log() + 4.5) / 5.0
+
+    def extra_repr(self):
+        return "winsize={}, hopsize={}".format(self.win_length, self.hopsize)
