@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""MAT-SED train-step benchmark (BASELINE.json metric: clips/sec, 10 s clips, full train step).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1 is launched by torch.distributed.run, one rank per GPU)
+
+Workload (config.workload): the finetune2 mean-teacher step of config/mat-sed/base/finetune2.yaml on DESED-shaped
+synthetic clips (320 000 samples @ 32 kHz): log-mel frontend -> frame_shift / mixup / freq-warp + FilterAugment (two views)
+-> student forward+backward (all 100.95 M parameters trainable) -> EMA teacher forward with 11 sliding windows (no grad)
+-> six BCE/MSE losses -> fused AdamW + EMA.  Per-GPU batch 32 (strong+synth 11 / weak 11 / unlabeled 10): weak scaling.
+Weights are deterministic synthetic (no network for the PaSST checkpoint).  One JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# values of config/mat-sed/base/finetune2.yaml (reference), restated: lines 11-38 (training), 62-86 (PaSST_SED), 88-100 (opt)
+FINETUNE2 = {
+    "training": {
+        "batch_size": [3, 1, 4, 4], "ema_factor": 0.999, "w_weak": 0.5, "w_cons_max": 40, "w_cons_min": 0,
+        "w_weak_cons": 0.5, "w_AT": 2, "self_loss_warmup": 15, "cons_scheduler_name": "Sigmoid",
+        "scheduler": {"n_epochs": 30, "n_epochs_cut": 15, "exponent": -1, "lr_warmup_rate": 0.1, "lr_warmup_epochs": 1},
+        "transform": {"n_transform": 2, "choice": [1, 0, 0, 1], "filter_db_range": [-26, 26], "filter_bands": [2, 5],
+                      "filter_minimum_bandwidth": 4, "filter_type": "step"},
+    },
+    "PaSST_SED": {
+        "init_kwargs": {"passt_feature_layer": 10, "f_pool": "mean_pool", "decode_ratio": 10, "at_adapter": True,
+                        "decoder": "transformerXL", "decoder_layer_num": 3, "decoder_pos_emd_len": 1000, "mlm": False},
+        "train_stu_kwargs": {"encoder_win": False, "win_param": [512, 49], "mix_rate": 0.5, "temp_w": 1},
+        "train_tch_kwargs": {"encoder_win": True, "win_param": [512, 49], "mix_rate": 0.5, "temp_w": 1},
+    },
+    "opt": {"param_groups": {"encoder": {"lr": 5.0e-6, "weight_decay": 1.0e-4, "freeze_layer": 0, "step_lr": 4},
+                             "decoder": {"lr": 1.0e-4, "weight_decay": 1.0e-4},
+                             "head": {"lr": 1.0e-4, "weight_decay": 1.0e-4}}},
+}
+GFLOP_PER_CLIP = 2463.16      # finetune2 step, algorithmic GEMM+conv FLOPs per clip (a-term)
+GFLOP_PER_BATCH = 21.22       # batch-shared linear_pos GEMMs (b-term)
+PEAK_BF16_TFLOPS = 2500.0     # dense 16-bit MFMA peak, MI355X_MICROARCH.md
+
+
+def build(per_gpu_batch, depth, device):
+    from copy import deepcopy
+    from transformer4sed_amd import synth
+    from transformer4sed_amd.passt_sed import PaSST_SED
+    from transformer4sed_amd.scheduler import ExponentialDown
+    from transformer4sed_amd.trainer import FusedAdamWEMA, MatSedTrainer, get_params
+    cfg = FINETUNE2
+    kw = dict(cfg["PaSST_SED"]["init_kwargs"])
+    net = PaSST_SED(load_pretrained_model=False, encoder_depth=depth,
+                    **{**kw, "passt_feature_layer": min(kw["passt_feature_layer"], depth)})
+    sd = synth.matsed_state_dict_np(tag="w768", depth=12)
+    own = net.state_dict()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items() if k in own}, strict=True)
+    net = net.to(device)
+    ema_net = deepcopy(net)  # recipes/desed/finetune/passt/setting.py:8-15
+    for p in ema_net.parameters():
+        p.detach_()
+    groups = get_params(net, cfg["opt"]["param_groups"])
+    opt = FusedAdamWEMA(net, groups, ema_net=ema_net, betas=(0.9, 0.999), eps=1e-8)
+    epoch_len = 1000
+    sc = cfg["training"]["scheduler"]
+    sched = ExponentialDown(opt, start_iter=sc["n_epochs_cut"] * epoch_len, total_iter=sc["n_epochs"] * epoch_len,
+                            exponent=sc["exponent"], warmup_iter=sc["lr_warmup_epochs"] * epoch_len,
+                            warmup_rate=sc["lr_warmup_rate"])
+    net.train()
+    ema_net.train()  # the teacher runs in train mode during training (finetune/train.py:131-132)
+    trainer = MatSedTrainer(net, ema_net, opt, sched, cfg, epoch_len)
+    return net, ema_net, opt, trainer, sd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU (multiple of 12 ratio 4:4:4 not required: 11/11/10)")
+    ap.add_argument("--depth", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    a = ap.parse_args()
+
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import __graft_entry__
+    __graft_entry__.build()
+    from transformer4sed_amd import ops, synth
+    from transformer4sed_amd.ddp import GradBucketReducer
+    import random
+    random.seed(1000 + rank); np.random.seed(1000 + rank); torch.manual_seed(1000 + rank)
+
+    B = a.batch
+    net, ema_net, opt, trainer, sd = build(B, a.depth, dev)
+    # batch composition strong+synth | weak | unlabeled in the reference's positional order (dataset.py:178-188)
+    sn = (B * 4 + 11) // 12
+    wn = (B * 4 + 11) // 12
+    un = B - sn - wn
+    trainer.cfg = json.loads(json.dumps(FINETUNE2))
+    trainer.cfg["training"]["batch_size"] = [sn, 0, wn, un]
+    wav = torch.from_numpy(synth.synth_wav(B, seed=1000 + rank)).to(dev)
+    labels = torch.from_numpy(synth.synth_batch_labels(sn, wn, un, seed=1000 + rank)).to(dev)
+    if world > 1:
+        trainer.ddp = GradBucketReducer(net, opt)
+
+    def step():
+        return trainer.finetune_step(wav, labels.clone())
+
+    for _ in range(a.warmup):
+        step()
+    timer = None if a.no_kernel_timer else ops.KernelTimer(["sed_gemm_nt", "sed_gemm_qkv"])
+    ops.TIMER = timer
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.TIMER = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(out["loss_total"])
+    if not np.isfinite(loss):
+        raise SystemExit("non-finite loss in the timed region")
+    clips = a.steps * B * world
+    value = clips / dt
+    line = {
+        "metric": "clips/sec (10 s clips) MAT-SED finetune2 train step", "value": round(value, 3), "unit": "clips/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * dt / a.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16 fwd / bf16 bwd MFMA operands, fp32 accumulate + residual stream",
+        "data": "synthetic (DESED-shaped 320000-sample clips @32 kHz, deterministic synthetic weights)",
+        "config": {"workload": "MAT-SED base finetune2 mean-teacher step (config/mat-sed/base/finetune2.yaml), student fwd+bwd "
+                               "all-trainable + teacher fwd with 11 sliding windows + AdamW + EMA",
+                   "model": f"PaSST_SED depth {a.depth} + 3x TransformerXL context net (100.95 M params)",
+                   "global_batch": B * world, "per_gpu_batch": B, "seq_len": "1190 encoder tokens / 1000 decoder frames",
+                   "parallelism": f"dp{world}", "final_loss": loss},
+        "step_mfma_frac": round(value / world * (GFLOP_PER_CLIP + GFLOP_PER_BATCH / B) / 1000.0 / PEAK_BF16_TFLOPS, 4),
+    }
+    if rank == 0 and timer is not None:
+        summ = timer.summarize()
+        ms = sum(v["ms"] for v in summ.values())
+        fl = sum(v["flops"] for v in summ.values())
+        n = sum(v["launches"] for v in summ.values())
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        line["roofline"] = {"kernel": "gemm_nt_kernel<EPI,F16> (all GEMM launches of the step: linears, qkv, dX, dW)",
+                            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                            "launches_per_step": n // max(1, a.steps), "avg_launch_ms": round(ms / max(1, n), 4),
+                            "gemm_share_of_step": round(ms / (1000 * dt), 3),
+                            "flops_per_launch": round(fl / max(1, n) / 1e9, 3)}
+    if rank == 0 and not a.no_cpu_baseline:
+        try:
+            from oracle import cpu_step
+            cores = os.cpu_count() or 1
+            nb = 1
+            sec = cpu_step.finetune2_step_seconds(sd, synth.synth_wav(nb, seed=1), synth.synth_batch_labels(1, 0, 0, seed=1),
+                                                  1, 0, depth=a.depth, feature_layer=min(10, a.depth), threads=cores)
+            line["cpu_baseline"] = {"value": round(nb / sec, 4), "unit": "clips/s", "cores": cores, "kind": "port",
+                                    "sample": f"1 finetune2 step at batch {nb} (oracle, torch CPU fp32, {sec:.1f} s)"}
+        except Exception as e:  # the baseline leg must never take the GPU number down with it
+            line["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

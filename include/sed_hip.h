@@ -8,7 +8,8 @@
  * (transformer4sed_amd/_lib.py) turns into RuntimeError.  Each entry cites the reference code it replaces
  * (paths relative to the reference repository root).
  *
- * Conventions: f32 = float, bf16 = raw uint16 bit patterns (void*), row-major, "D" = 768 channels,
+ * Conventions: f32 = float, 16-bit operands = raw uint16 bit patterns (void*): bf16, or IEEE half where an `f16` flag is
+ * set (forward activations/weights; gradient-side operands are always bf16), row-major, "D" = 768 channels,
  * H = 12 heads x 64.  Sequence-padded buffers ("pad") must be zero-initialised once by the caller.
  */
 #pragma once
@@ -43,16 +44,18 @@ int sed_median_filter(const float* in, float* out, const int* sizes, const float
  * 332,342; src/models/transformer/transformerXL.py:382,493,584; src/models/passt/passt_sed.py:196; conv2d passt.py:307 */
 int sed_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi, const float* bias,
                 const float* resF, float* outF, void* outH, void* outH2, const void* auxH, int ldc, float alpha,
-                int ksplit, hipStream_t stream);
+                int ksplit, int f16, hipStream_t stream);
 /* qkv / in_proj GEMM with head-split epilogue: q,k,v [B*H,seq,64], transposed copies [B*H,64,seq_pad] (nullable),
  * optional rel-pos biased queries q = q+u, q2 = q+v (passt.py:332-333; transformerXL.py:382-384,497-503) */
 int sed_gemm_qkv(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq, int seq_pad, void* q,
                  void* k, void* v, void* qt, void* kt, void* vt, void* q2, void* q2t, const float* pos_u,
-                 const float* pos_v, hipStream_t stream);
-int sed_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream_t stream);
-/* in [R,C] (f32 or bf16) -> outT bf16 [C,Rpad] (zero padded), optional straight bf16 copy and fp32 column sums (+=) */
-int sed_transpose_to_bf16(const void* in, int in_is_f32, int R, int C, int ldin, void* outT, int Rpad, void* outS,
-                          float* colsum, hipStream_t stream);
+                 const float* pos_v, int f16, hipStream_t stream);
+int sed_cast_f32_bf16(const float* in, void* out, int64_t n, int f16, hipStream_t stream);
+int sed_f16_to_bf16_inplace(void* p, int64_t n, hipStream_t stream);
+/* in [R,C] -> outT [C,Rpad] (zero padded; nullable), optional straight 16-bit copy and fp32 column sums (+=).
+ * kinds: 0 bf16, 1 f32 (input only), 2 f16 */
+int sed_transpose_to_bf16(const void* in, int in_kind, int R, int C, int ldin, void* outT, int Rpad, int outT_kind,
+                          void* outS, int outS_kind, float* colsum, hipStream_t stream);
 /* tiny fp32 linears (AT-head query / out_proj / 768->10 classifier; src/models/pooling.py:45-51, passt_sed.py:143) */
 int sed_small_linear(const float* a, const float* w, const float* b, float* out, int M, int N, int K, int act,
                      hipStream_t stream);
@@ -62,30 +65,31 @@ int sed_small_linear_bwd(const float* a, const float* w, const float* out, const
 /* ------------------------------------------------------------------ attention */
 /* encoder MHSA (src/models/passt/passt.py:335-341), flash style; O [B,N,768] bf16, LSE [B*H,N] (log2 domain) */
 int sed_mhsa_fwd(const void* Q, const void* K, const void* Vt, void* O, float* LSE, int B, int H, int N, int Npad,
-                 hipStream_t stream);
+                 int f16, hipStream_t stream);
 int sed_mhsa_bwd_prep(const void* dO, const void* O, float* Dtmp, void* dOh, void* dOt, int B, int H, int N, int Npad,
-                      hipStream_t stream);
-/* dqkv [B*N, 3*768] bf16 (dq | dk | dv) */
+                      int o_f16, hipStream_t stream);
+/* dqkv [B*N, 3*768] bf16 (dq | dk | dv).  f16 != 0: Q, K, O are IEEE half (as the f16 forward wrote them, used for the
+ * score recompute), all gradient-side operands (Qt, Kt, V, dO) are bf16. */
 int sed_mhsa_bwd(const void* Q, const void* Qt, const void* K, const void* Kt, const void* V, const void* O,
                  const void* dO, const float* LSE, float* Dtmp, void* dOh, void* dOt, void* dqkv, int B, int H, int N,
-                 int Npad, hipStream_t stream);
+                 int Npad, int f16, hipStream_t stream);
 /* Transformer-XL rel-pos attention (src/models/transformer/transformerXL.py:493-576 incl. rel_shift 254-297) */
 int sed_relpos_attn_fwd(const void* Qu, const void* Qv, const void* K, const void* Vt, const void* P, void* O,
-                        float* LSE, int B, int H, int T, int Tpad, int Rpad, hipStream_t stream);
+                        float* LSE, int B, int H, int T, int Tpad, int Rpad, int f16, hipStream_t stream);
 int sed_relpos_attn_bwd(const void* Qu, const void* Qut, const void* Qv, const void* Qvt, const void* K, const void* Kt,
                         const void* V, const void* P, const void* Pt, const void* O, const void* dO, const float* LSE,
                         float* Dtmp, void* dOh, void* dOt, void* dqkv, void* dSt, float* dP, float* du, float* dv, int B,
-                        int H, int T, int Tpad, int Rpad, int need_param_grads, hipStream_t stream);
+                        int H, int T, int Tpad, int Rpad, int need_param_grads, int f16, hipStream_t stream);
 
 /* ------------------------------------------------------------------ norms / glue / heads / optimiser */
 /* nn.LayerNorm over D=768 (passt.py:361-362,580; passt_sed.py:128; timm Block norms); y = LN(in_scale*x) */
 int sed_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float in_scale, void* y_bf16,
-                      float* y_f32, float* mean, float* rstd, int M, int D, hipStream_t stream);
+                      float* y_f32, float* mean, float* rstd, int M, int D, int f16, hipStream_t stream);
 int sed_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                       float in_scale, float* dx, int accumulate, float* dgamma, float* dbeta, int M, int D,
                       hipStream_t stream);
 /* patch embedding plumbing (passt.py:302-315, 503-569) */
-int sed_im2col(const float* mel, void* cols, int B, int T, int tstart, int tp, hipStream_t stream);
+int sed_im2col(const float* mel, void* cols, int B, int T, int tstart, int tp, int f16, hipStream_t stream);
 int sed_assemble_tokens(const float* conv, const float* cls, const float* dist, const float* new_pos,
                         const float* freq_pe, const float* time_pe, int toffset, float* x, int B, int tp,
                         hipStream_t stream);
@@ -100,8 +104,8 @@ int sed_fpool_bwd(const float* dpooled, const float* x, const float* mean, const
 int sed_interp_fwd(const float* in, float* out, int B, int tin, int pad, int ratio, hipStream_t stream);
 int sed_interp_bwd(const float* dout, float* din, int B, int tin, int pad, int ratio, hipStream_t stream);
 /* EncoderSlideWindow merge + global/local mix (src/models/encoder_slide_window.py:16-36; passt_sed.py:266-271) */
-int sed_window_mix(const float* pooled_win, const int* lefts, int nW, float* x, float mix, int B, int T, int tpw,
-                   int ratio, hipStream_t stream);
+int sed_window_mix(const float* pooled_win, const int* lefts, const int* tps, const int* offs, int nW, float* x,
+                   float mix, int B, int T, int ratio, hipStream_t stream);
 /* MlmModule.setence_mask application (src/models/transformer/mask.py:62-85) and masked MSE (mlm_passt/train.py:36-38) */
 int sed_mlm_apply(const float* x, const float* mask_token, const uint8_t* action, const int* src_idx, float* out,
                   int rows, hipStream_t stream);
@@ -116,9 +120,10 @@ int sed_head_bwd(const float* x, const float* W, const float* strong, const floa
                  const float* dweak, float temp, float* dx, float* dW, float* db, int B, int T, int C,
                  hipStream_t stream);
 /* AttentionPooling (src/models/pooling.py:45-51): 1-query MHA over the patch tokens; kv [B,N,1536] bf16 */
-int sed_attnpool_fwd(const void* kv, const float* q, float* out, float* probs, int B, int N, int H, hipStream_t stream);
+int sed_attnpool_fwd(const void* kv, const float* q, float* out, float* probs, int B, int N, int H, int f16,
+                     hipStream_t stream);
 int sed_attnpool_bwd(const void* kv, const float* q, const float* probs, const float* dout, void* dkv, float* dq, int B,
-                     int N, int H, hipStream_t stream);
+                     int N, int H, int f16, hipStream_t stream);
 /* torch.optim.AdamW step (recipes/desed/setting.py:254-258) fused with update_ema (src/utils/scheduler.py:125-130) */
 int sed_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr, float wd, float beta1,
                   float beta2, float eps, int step, float ema_alpha, int do_adam, hipStream_t stream);

@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from transformer4sed_amd import ops  # noqa: E402
-from transformer4sed_amd.ops import call, gemm_nt, gemm_dw, transpose_bf16, pad64, BF16, F32  # noqa: E402
+from transformer4sed_amd.ops import call, gemm_nt, gemm_dw, transpose_bf16, pad64, BF16, F16, F32  # noqa: E402
 
 DEV = "cuda"
 LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "kernel_errors.log")
@@ -37,8 +37,10 @@ def r16(x):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("DT", [BF16, F16])
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 256, 192), (2380, 768, 768), (1204, 2304, 768), (77, 128, 3072)])
-def test_gemm_epilogues(M, N, K):
+def test_gemm_epilogues(M, N, K, DT):
+    BF16 = DT  # operands/outputs of this test in the parametrised 16-bit type (inputs are exact in both)
     A, B = r16(rnd(M, K, seed=1)), r16(rnd(N, K, scale=0.05, seed=2))
     bias = rnd(N, seed=3)
     ref = A @ B.t()
@@ -96,6 +98,13 @@ def test_transpose_and_dw():
     transpose_bf16(x, R, C, xt, out_s=xs, colsum=cs)
     assert torch.equal(xs, x.to(BF16)) and torch.equal(xt[:, :R], x.to(BF16).t()) and float(xt[:, R:].abs().max()) == 0
     assert maxerr(cs, x.sum(0)) < 2e-3
+    xh = x.to(F16)
+    xt2 = torch.empty(C, Rp, dtype=BF16, device=DEV); xs2 = torch.empty(R, C, dtype=F16, device=DEV)
+    transpose_bf16(xh, R, C, xt2, out_s=xs2)
+    assert torch.equal(xs2, xh) and torch.equal(xt2[:, :R], xh.float().to(BF16).t())
+    from transformer4sed_amd.ops import to_bf16_
+    conv = xh.clone()
+    assert torch.equal(to_bf16_(conv), xh.float().to(BF16))
     y = r16(rnd(R, 256, seed=6))
     yt = torch.empty(256, Rp, dtype=BF16, device=DEV)
     transpose_bf16(y.to(BF16), R, 256, yt)
@@ -105,7 +114,9 @@ def test_transpose_and_dw():
     e = maxerr(dW, ref); report("dW gemm", e, float(ref.abs().max())); assert e < 2e-2
 
 
-def test_gemm_qkv_split():
+@pytest.mark.parametrize("DT", [BF16, F16])
+def test_gemm_qkv_split(DT):
+    BF16 = DT
     B, N, Hh = 2, 70, 12
     Npad = pad64(N)
     M = B * N
@@ -115,7 +126,8 @@ def test_gemm_qkv_split():
     mkt = lambda: torch.zeros(B * Hh, 64, Npad, dtype=BF16, device=DEV)
     q, k, vv, q2 = mk(), mk(), mk(), mk()
     qt, kt, vt, q2t = mkt(), mkt(), mkt(), mkt()
-    call("sed_gemm_qkv", x.to(BF16), W.to(BF16), b, M, 768, Hh, N, Npad, q, k, vv, qt, kt, vt, q2, q2t, u, v)
+    call("sed_gemm_qkv", x.to(BF16), W.to(BF16), b, M, 768, Hh, N, Npad, q, k, vv, qt, kt, vt, q2, q2t, u, v,
+         1 if DT == F16 else 0)
     ref = (x @ W.t() + b).view(B, N, 3, Hh, 64).permute(2, 0, 3, 1, 4)  # [3,B,H,N,64]
     rq, rk, rv = [ref[i].reshape(B * Hh, N, 64) for i in range(3)]
     uu = u.view(1, Hh, 1, 64).expand(B, Hh, N, 64).reshape(B * Hh, N, 64)
@@ -127,27 +139,30 @@ def test_gemm_qkv_split():
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def _split(B, N, seed, scale=1.0):
+def _split(B, N, seed, scale=1.0, dt=BF16):
     Hh = 12
     Npad = pad64(N)
     q, k, v = [r16(rnd(B * Hh, N, 64, scale=scale, seed=seed + i)) for i in range(3)]
-    tr = lambda t: torch.nn.functional.pad(t.transpose(1, 2), (0, Npad - N)).to(BF16).contiguous()
-    return q, k, v, tr(q), tr(k), tr(v), Npad
+    tr = lambda t, d: torch.nn.functional.pad(t.transpose(1, 2), (0, Npad - N)).to(d).contiguous()
+    # forward consumes V^T in the forward type; the backward consumes Q^T / K^T as bf16 gradient-side operands
+    return q, k, v, tr(q, BF16), tr(k, BF16), tr(v, dt), Npad
 
 
+@pytest.mark.parametrize("DT", [BF16, F16])
 @pytest.mark.parametrize("B,N", [(1, 70), (2, 602), (2, 1190)])
-def test_mhsa_fwd_bwd(B, N):
+def test_mhsa_fwd_bwd(B, N, DT):
     Hh = 12
-    q, k, v, qt, kt, vt, Npad = _split(B, N, 20, scale=1.3)
-    O = torch.empty(B, N, 768, dtype=BF16, device=DEV)
+    f16 = 1 if DT == F16 else 0
+    q, k, v, qt, kt, vt, Npad = _split(B, N, 20, scale=1.3, dt=DT)
+    O = torch.empty(B, N, 768, dtype=DT, device=DEV)
     lse = torch.empty(B * Hh, N, device=DEV)
-    call("sed_mhsa_fwd", q.to(BF16), k.to(BF16), vt, O, lse, B, Hh, N, Npad)
+    call("sed_mhsa_fwd", q.to(DT), k.to(DT), vt, O, lse, B, Hh, N, Npad, f16)
     qq, kk, vv = [t.clone().requires_grad_(True) for t in (q, k, v)]
     s = (qq @ kk.transpose(1, 2)) * 0.125
     p = torch.softmax(s, dim=-1)
     o = p @ vv  # [BH,N,64]
     oref = o.view(B, Hh, N, 64).permute(0, 2, 1, 3).reshape(B, N, 768)
-    e = maxerr(O.float(), oref); report(f"mhsa fwd N={N}", e); assert e < 2e-2
+    e = maxerr(O.float(), oref); report(f"mhsa fwd N={N} {DT}", e); assert e < (4e-3 if f16 else 2e-2)
     lref = torch.logsumexp(s, dim=-1) / math.log(2.0)
     assert maxerr(lse, lref) < 2e-3
     dO = r16(rnd(B, N, 768, seed=33))
@@ -156,10 +171,10 @@ def test_mhsa_fwd_bwd(B, N):
     Dt = torch.empty(B * Hh, N, device=DEV)
     dOh = torch.empty(B * Hh, N, 64, dtype=BF16, device=DEV)
     dOt = torch.empty(B * Hh, 64, Npad, dtype=BF16, device=DEV)
-    call("sed_mhsa_bwd", q.to(BF16), qt, k.to(BF16), kt, v.to(BF16), O, dO.to(BF16), lse, Dt, dOh, dOt, dqkv, B, Hh, N, Npad)
+    call("sed_mhsa_bwd", q.to(DT), qt, k.to(DT), kt, v.to(BF16), O, dO.to(BF16), lse, Dt, dOh, dOt, dqkv, B, Hh, N, Npad, f16)
     g = dqkv.float().view(B, N, 3, Hh, 64).permute(2, 0, 3, 1, 4).reshape(3, B * Hh, N, 64)
     for i, (ref, nm) in enumerate(((qq.grad, "dq"), (kk.grad, "dk"), (vv.grad, "dv"))):
-        e = maxerr(g[i], ref); sc = float(ref.abs().max()); report(f"mhsa bwd {nm} N={N}", e, sc)
+        e = maxerr(g[i], ref); sc = float(ref.abs().max()); report(f"mhsa bwd {nm} N={N} {DT}", e, sc)
         assert e < 0.03 * sc + 5e-3
 
 
@@ -178,25 +193,27 @@ def _relpos_ref(qu, qv, k, v, P, T):
     return torch.softmax(s, dim=-1) @ v, s
 
 
+@pytest.mark.parametrize("DT", [BF16, F16])
 @pytest.mark.parametrize("B,T", [(1, 200), (2, 1000)])
-def test_relpos_fwd_bwd(B, T):
+def test_relpos_fwd_bwd(B, T, DT):
     Hh = 12
+    f16 = 1 if DT == F16 else 0
     Tpad = pad64(T)
     R = 2 * T - 1
     Rpad = pad64(R)
-    qu, k, v, qut, kt, vt, _ = _split(B, T, 40, scale=1.2)
+    qu, k, v, qut, kt, vt, _ = _split(B, T, 40, scale=1.2, dt=DT)
     qv = r16(rnd(B * Hh, T, 64, scale=1.2, seed=47))
     qvt = torch.nn.functional.pad(qv.transpose(1, 2), (0, Tpad - T)).to(BF16).contiguous()
     P = r16(rnd(Hh, R, 64, scale=0.7, seed=48))
-    Pp = torch.zeros(Hh, Rpad, 64, dtype=BF16, device=DEV); Pp[:, :R] = P.to(BF16)
+    Pp = torch.zeros(Hh, Rpad, 64, dtype=DT, device=DEV); Pp[:, :R] = P.to(DT)
     Pt = torch.zeros(Hh, 64, Rpad, dtype=BF16, device=DEV); Pt[:, :, :R] = P.to(BF16).transpose(1, 2)
-    O = torch.empty(B, T, 768, dtype=BF16, device=DEV)
+    O = torch.empty(B, T, 768, dtype=DT, device=DEV)
     lse = torch.empty(B * Hh, T, device=DEV)
-    call("sed_relpos_attn_fwd", qu.to(BF16), qv.to(BF16), k.to(BF16), vt, Pp, O, lse, B, Hh, T, Tpad, Rpad)
+    call("sed_relpos_attn_fwd", qu.to(DT), qv.to(DT), k.to(DT), vt, Pp, O, lse, B, Hh, T, Tpad, Rpad, f16)
     leaves = [t.clone().requires_grad_(True) for t in (qu, qv, k, v, P)]
     o, s = _relpos_ref(*leaves, T)
     oref = o.view(B, Hh, T, 64).permute(0, 2, 1, 3).reshape(B, T, 768)
-    e = maxerr(O.float(), oref); report(f"relpos fwd T={T}", e); assert e < 2e-2
+    e = maxerr(O.float(), oref); report(f"relpos fwd T={T} {DT}", e); assert e < (4e-3 if f16 else 2e-2)
     assert maxerr(lse, torch.logsumexp(s, -1) / math.log(2.0)) < 3e-3
     dO = r16(rnd(B, T, 768, seed=53))
     oref.backward(dO)
@@ -207,8 +224,8 @@ def test_relpos_fwd_bwd(B, T):
     dSt = torch.zeros(B * Hh, Tpad, Tpad, dtype=BF16, device=DEV)
     dP = torch.zeros(Rpad, 768, device=DEV)
     du = torch.zeros(Hh, 64, device=DEV); dv = torch.zeros(Hh, 64, device=DEV)
-    call("sed_relpos_attn_bwd", qu.to(BF16), qut, qv.to(BF16), qvt, k.to(BF16), kt, v.to(BF16), Pp, Pt, O, dO.to(BF16),
-         lse, Dt, dOh, dOt, dqkv, dSt, dP, du, dv, B, Hh, T, Tpad, Rpad, 1)
+    call("sed_relpos_attn_bwd", qu.to(DT), qut, qv.to(DT), qvt, k.to(DT), kt, v.to(BF16), Pp, Pt, O, dO.to(BF16),
+         lse, Dt, dOh, dOt, dqkv, dSt, dP, du, dv, B, Hh, T, Tpad, Rpad, 1, f16)
     g = dqkv.float().view(B, T, 3, Hh, 64).permute(2, 0, 3, 1, 4).reshape(3, B * Hh, T, 64)
     dq_ref = leaves[0].grad + leaves[1].grad
     for got, ref, nm in ((g[0], dq_ref, "dq"), (g[1], leaves[2].grad, "dk"), (g[2], leaves[3].grad, "dv")):
@@ -229,7 +246,10 @@ def test_layernorm_fwd_bwd():
     for in_scale, eps in ((1.0, 1e-6), (math.sqrt(768.0), 1e-5)):
         y16 = torch.empty(M, 768, dtype=BF16, device=DEV); y32 = torch.empty(M, 768, device=DEV)
         mu = torch.empty(M, device=DEV); rs = torch.empty(M, device=DEV)
-        call("sed_layernorm_fwd", x, g, b, eps, in_scale, y16, y32, mu, rs, M, 768)
+        call("sed_layernorm_fwd", x, g, b, eps, in_scale, y16, y32, mu, rs, M, 768, 0)
+        yh = torch.empty(M, 768, dtype=F16, device=DEV)
+        call("sed_layernorm_fwd", x, g, b, eps, in_scale, yh, None, None, None, M, 768, 1)
+        assert torch.equal(yh, y32.to(F16))
         xx = x.clone().requires_grad_(True); gg = g.clone().requires_grad_(True); bb = b.clone().requires_grad_(True)
         ref = torch.nn.functional.layer_norm(xx * in_scale, (768,), gg, bb, eps)
         e = maxerr(y32, ref); report(f"layernorm fwd scale={in_scale:.1f}", e); assert e < 2e-5
@@ -250,11 +270,14 @@ def test_patch_tokens_fpool_interp():
     B, T, tp = 2, 1000, 99
     mel = rnd(B, 128, T, seed=70)
     cols = torch.empty(B * 12 * tp, 256, dtype=BF16, device=DEV)
-    call("sed_im2col", mel, cols, B, T, 0, tp)
+    call("sed_im2col", mel, cols, B, T, 0, tp, 0)
+    colh = torch.empty(B * 12 * tp, 256, dtype=F16, device=DEV)
+    call("sed_im2col", mel, colh, B, T, 0, tp, 1)
+    assert torch.equal(colh, mel.unfold(1, 16, 10).unfold(2, 16, 10).reshape(B * 12 * tp, 256).to(F16))
     ref = mel.unfold(1, 16, 10).unfold(2, 16, 10).reshape(B * 12 * tp, 256)
     assert torch.equal(cols, ref.to(BF16))
     colw = torch.empty(B * 12 * 50, 256, dtype=BF16, device=DEV)
-    call("sed_im2col", mel, colw, B, T, 490, 50)
+    call("sed_im2col", mel, colw, B, T, 490, 50, 0)
     assert torch.equal(colw, mel[:, :, 490:1000].unfold(1, 16, 10).unfold(2, 16, 10).reshape(B * 12 * 50, 256).to(BF16))
     conv = rnd(B * 12 * tp, 768, seed=71)
     cls, dist, npe = rnd(768, seed=72), rnd(768, seed=73), rnd(2, 768, seed=74)
@@ -302,7 +325,9 @@ def test_patch_tokens_fpool_interp():
     pw = rnd(nW, B, tpw, 768, seed=81)
     lefts = torch.tensor([49 * i for i in range(nW)], dtype=torch.int32, device=DEV)
     xg = rnd(B, 1000, 768, seed=82); xg0 = xg.clone()
-    call("sed_window_mix", pw, lefts, nW, xg, 0.5, B, 1000, tpw, 10)
+    tps = torch.full((nW,), tpw, dtype=torch.int32, device=DEV)
+    offs = torch.arange(nW, dtype=torch.int32, device=DEV) * (B * tpw)
+    call("sed_window_mix", pw, lefts, tps, offs, nW, xg, 0.5, B, 1000, 10)
     emb = torch.zeros(B, 1000, 768, device=DEV); cnt = torch.zeros(B, 1000, 768, device=DEV)
     for w in range(nW):
         fr = torch.nn.functional.interpolate(pw[w].transpose(1, 2), scale_factor=10, mode="linear").transpose(1, 2)
@@ -348,7 +373,10 @@ def test_heads_and_small_ops():
     N, Hh = 1190, 12
     kv = r16(rnd(B, N, 1536, seed=99)); q = rnd(1, 768, seed=100)
     pooled = torch.empty(B, 768, device=DEV); probs = torch.empty(B * Hh, N - 2, device=DEV)
-    call("sed_attnpool_fwd", kv.to(BF16), q, pooled, probs, B, N, Hh)
+    pooled_h = torch.empty(B, 768, device=DEV)
+    call("sed_attnpool_fwd", kv.to(F16), q, pooled_h, None, B, N, Hh, 1)
+    call("sed_attnpool_fwd", kv.to(BF16), q, pooled, probs, B, N, Hh, 0)
+    assert maxerr(pooled, pooled_h) < 1e-5
     kvv = kv.clone().requires_grad_(True); qq = q.clone().requires_grad_(True)
     kk = kvv[:, 2:, :768].reshape(B, N - 2, Hh, 64).permute(0, 2, 1, 3); vv = kvv[:, 2:, 768:].reshape(B, N - 2, Hh, 64).permute(0, 2, 1, 3)
     att = torch.softmax((qq.view(1, Hh, 1, 64) @ kk.transpose(-2, -1)) * 0.125, -1)
@@ -357,7 +385,7 @@ def test_heads_and_small_ops():
     dp = rnd(B, 768, seed=101)
     pref.backward(dp)
     dkv = torch.full((B, N, 1536), 5.0, dtype=BF16, device=DEV); dq = torch.zeros(1, 768, device=DEV)
-    call("sed_attnpool_bwd", kv.to(BF16), q, probs, dp, dkv, dq, B, N, Hh)
+    call("sed_attnpool_bwd", kv.to(BF16), q, probs, dp, dkv, dq, B, N, Hh, 0)
     e = maxerr(dkv.float(), kvv.grad); sc = float(kvv.grad.abs().max()); report("attnpool bwd dkv", e, sc); assert e < 0.02 * sc
     assert maxerr(dq, qq.grad) < 2e-3 * float(qq.grad.abs().max()) + 1e-5
 

@@ -21,6 +21,7 @@
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
+template <bool F16>
 __global__ __launch_bounds__(256) void mhsa_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
                                                        float* __restrict__ LSE, int N, int Npad, int H) {
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) st[kb] = mfma32(lds_frag_rows(lk, 32 * kb + lr, 2 * s + lg), qf[s], st[kb]);
+            for (int s = 0; s < 4; ++s) st[kb] = mfma32t<F16>(lds_frag_rows(lk, 32 * kb + lr, 2 * s + lg), qf[s], st[kb]);
         }
         // scale (log2 domain) + mask keys >= N (last tile only)
         float mloc = -1e30f;
@@ -107,10 +108,10 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(const bf16_t* __restrict_
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const s16x8_t pf = pack_frag(st[kb], s);
+                const s16x8_t pf = pack_frag_t<F16>(st[kb], s);
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
-                    o[db] = mfma32(lds_frag_cols(lv, 32 * db + lr, 8 * kb + 4 * s + lg), pf, o[db]);
+                    o[db] = mfma32t<F16>(lds_frag_cols(lv, 32 * db + lr, 8 * kb + 4 * s + lg), pf, o[db]);
             }
         if (t + 1 < ntiles) {
             tile_lstore_rows(rk, lds[buf ^ 1][0], tid);
@@ -128,8 +129,8 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 uint2 pk;
-                pk.x = pack2bf(o[db][4 * qd] * inv, o[db][4 * qd + 1] * inv);
-                pk.y = pack2bf(o[db][4 * qd + 2] * inv, o[db][4 * qd + 3] * inv);
+                pk.x = pack2<F16>(o[db][4 * qd] * inv, o[db][4 * qd + 1] * inv);
+                pk.y = pack2<F16>(o[db][4 * qd + 2] * inv, o[db][4 * qd + 3] * inv);
                 *reinterpret_cast<uint2*>(orow + 32 * db + 8 * qd + 4 * lg) = pk;
             }
         if (lg == 0 && LSE != nullptr) LSE[(size_t)bh * N + q] = m_run + log2f(l_run);  // log2 domain
@@ -137,10 +138,12 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(const bf16_t* __restrict_
 }
 
 extern "C" int sed_mhsa_fwd(const void* Q, const void* K, const void* Vt, void* O, float* LSE, int B, int H, int N,
-                            int Npad, hipStream_t stream) {
+                            int Npad, int f16, hipStream_t stream) {
     if (N <= 0 || Npad % 64 || Npad < N) return SED_ERR_ARG;
     dim3 grid(cdiv(N, 128), B * H);
-    hipLaunchKernelGGL(mhsa_fwd_kernel, grid, dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,
+    if (f16) hipLaunchKernelGGL(mhsa_fwd_kernel<true>, grid, dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,
+                                (const bf16_t*)Vt, (bf16_t*)O, LSE, N, Npad, H);
+    else hipLaunchKernelGGL(mhsa_fwd_kernel<false>, grid, dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,
                        (const bf16_t*)Vt, (bf16_t*)O, LSE, N, Npad, H);
     return sed_check_launch();
 }
@@ -151,7 +154,8 @@ extern "C" int sed_mhsa_fwd(const void* Q, const void* K, const void* Vt, void* 
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mhsa_bwd_prep_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O,
                                                             float* __restrict__ Dv, bf16_t* __restrict__ dOh,
-                                                            bf16_t* __restrict__ dOt, int B, int N, int Npad, int H) {
+                                                            bf16_t* __restrict__ dOt, int B, int N, int Npad, int H,
+                                                            int o_f16) {
     // block handles 64 consecutive tokens of one (b, h): transposes through LDS
     __shared__ bf16_t tile[64][66];
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_prep_kernel(const bf16_t* __rest
         if (t < N) {
             const size_t idx = ((size_t)b * N + t) * (H * HD) + h * HD + tx;
             g = dO[idx];
-            prod = bf2f(g) * bf2f(O[idx]);
+            prod = bf2f(g) * (o_f16 ? h2f(O[idx]) : bf2f(O[idx]));
             dOh[((size_t)bh * N + t) * HD + tx] = g;
         }
         tile[ty * 16 + i][tx] = g;
@@ -187,6 +191,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_prep_kernel(const bf16_t* __rest
 //   dV[key, d] += P^T[key, q] dO[q, d]   (A from the P registers, B = dO^T tile)
 //   dK[key, d] += dS^T[key, q] Q[q, d] * scale   (B = Q^T tile)
 // ---------------------------------------------------------------------------------------------------
+template <bool SF16>
 __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Qt, const bf16_t* __restrict__ K,
     const bf16_t* __restrict__ V, const bf16_t* __restrict__ dOh, const bf16_t* __restrict__ dOt,
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_kernel(
             for (int r = 0; r < 16; ++r) { s_[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                s_ = mfma32(lds_frag_rows(lds[buf][0], 32 * qb + lr, 2 * s + lg), kf[s], s_);
+                s_ = mfma32t<SF16>(lds_frag_rows(lds[buf][0], 32 * qb + lr, 2 * s + lg), kf[s], s_);
                 dp = mfma32(lds_frag_rows(lds[buf][1], 32 * qb + lr, 2 * s + lg), vf[s], dp);
             }
             // rows of the accumulators are queries 32 qb + mfma32_row(r, lg); column = this lane's key
@@ -300,6 +305,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_kernel(
 //   S^T[key, q] = K . Q^T ; dP^T[key, q] = V . dO^T ; dS^T = P^T (dP^T - D[q])
 //   dQ^T[d, q] += K^T[d, key] dS^T[key, q]
 // ---------------------------------------------------------------------------------------------------
+template <bool SF16>
 __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                           const bf16_t* __restrict__ Kt, const bf16_t* __restrict__ V,
                                                           const bf16_t* __restrict__ dOh, const float* __restrict__ LSE,
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const bf16_t* __restri
             for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                st = mfma32(lds_frag_rows(lds[buf][0], 32 * kb + lr, 2 * s + lg), qf[s], st);
+                st = mfma32t<SF16>(lds_frag_rows(lds[buf][0], 32 * kb + lr, 2 * s + lg), qf[s], st);
                 dp = mfma32(lds_frag_rows(lds[buf][1], 32 * kb + lr, 2 * s + lg), dof[s], dp);
             }
 #pragma unroll
@@ -386,24 +392,28 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const bf16_t* __restri
 }
 
 extern "C" int sed_mhsa_bwd_prep(const void* dO, const void* O, float* Dtmp, void* dOh, void* dOt, int B, int H, int N,
-                                 int Npad, hipStream_t stream) {
+                                 int Npad, int o_f16, hipStream_t stream) {
     if (N <= 0 || Npad % 64 || Npad < N) return SED_ERR_ARG;
     hipLaunchKernelGGL(mhsa_bwd_prep_kernel, dim3(Npad / 64, B * H), dim3(256), 0, stream, (const bf16_t*)dO,
-                       (const bf16_t*)O, Dtmp, (bf16_t*)dOh, (bf16_t*)dOt, B, N, Npad, H);
+                       (const bf16_t*)O, Dtmp, (bf16_t*)dOh, (bf16_t*)dOt, B, N, Npad, H, o_f16);
     return sed_check_launch();
 }
 
 extern "C" int sed_mhsa_bwd(const void* Q, const void* Qt, const void* K, const void* Kt, const void* V,
                             const void* O, const void* dO, const float* LSE, float* Dtmp, void* dOh, void* dOt,
-                            void* dqkv, int B, int H, int N, int Npad, hipStream_t stream) {
+                            void* dqkv, int B, int H, int N, int Npad, int f16, hipStream_t stream) {
+    // f16 != 0: Q, K (score recompute) and O are IEEE half as written by the forward; Qt, Kt, V, dO are bf16.
     if (N <= 0 || Npad % 64 || Npad < N) return SED_ERR_ARG;
-    hipLaunchKernelGGL(mhsa_bwd_prep_kernel, dim3(Npad / 64, B * H), dim3(256), 0, stream, (const bf16_t*)dO,
-                       (const bf16_t*)O, Dtmp, (bf16_t*)dOh, (bf16_t*)dOt, B, N, Npad, H);
+    int rc = sed_mhsa_bwd_prep(dO, O, Dtmp, dOh, dOt, B, H, N, Npad, f16, stream);
+    if (rc) return rc;
     dim3 grid(cdiv(N, 128), B * H);
-    hipLaunchKernelGGL(mhsa_bwd_dkdv_kernel, grid, dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)Qt,
-                       (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dOh, (const bf16_t*)dOt, LSE, Dtmp,
-                       (bf16_t*)dqkv, N, Npad, H);
-    hipLaunchKernelGGL(mhsa_bwd_dq_kernel, grid, dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,
+#define SED_LAUNCH_BWD(F)                                                                                              \
+    hipLaunchKernelGGL(mhsa_bwd_dkdv_kernel<F>, grid, dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)Qt,       \
+                       (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dOh, (const bf16_t*)dOt, LSE, Dtmp,          \
+                       (bf16_t*)dqkv, N, Npad, H);                                                                     \
+    hipLaunchKernelGGL(mhsa_bwd_dq_kernel<F>, grid, dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,          \
                        (const bf16_t*)Kt, (const bf16_t*)V, (const bf16_t*)dOh, LSE, Dtmp, (bf16_t*)dqkv, N, Npad, H);
+    if (f16) { SED_LAUNCH_BWD(true) } else { SED_LAUNCH_BWD(false) }
+#undef SED_LAUNCH_BWD
     return sed_check_launch();
 }

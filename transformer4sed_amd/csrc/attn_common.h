@@ -24,12 +24,14 @@ __device__ __forceinline__ s16x8_t lds_frag_cols(const unsigned char* base, int 
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
 }
-__device__ __forceinline__ s16x8_t pack_frag(const f32x16_t& p, int s) {  // registers 8s..8s+7 -> 8 bf16
+template <bool F16>
+__device__ __forceinline__ s16x8_t pack_frag_t(const f32x16_t& p, int s) {  // registers 8s..8s+7 -> 8 x 16-bit
     s16x8_t r;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] = (short)f2bf(p[8 * s + e]);
+    for (int e = 0; e < 8; ++e) r[e] = (short)to_16<F16>(p[8 * s + e]);
     return r;
 }
+__device__ __forceinline__ s16x8_t pack_frag(const f32x16_t& p, int s) { return pack_frag_t<false>(p, s); }
 
 // cooperative stage of one [64][64] bf16 tile (rows r0.., row stride `ld` elements) : 256 threads x 2 x 16 B
 // (named members, not an array: keeps the staged tile in VGPRs instead of scratch)

@@ -47,7 +47,7 @@ struct GemmArgs {
 #define TILE 128
 #define BK 64
 
-template <int EPI>
+template <int EPI, bool F16>
 __device__ __forceinline__ void epilogue_quad(const GemmArgs& g, int m_base, int n, const float v4[4], int M) {
     // v4[j] belongs to row m_base + j (4 consecutive rows), column n
     const float b = (g.bias != nullptr) ? g.bias[n] : 0.0f;
@@ -67,21 +67,21 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs& g, int m_base, int
         if (fast) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                row_dst[((size_t)bh * g.seq + t0 + j) * 64 + d] = f2bf(val[j] + extra);
+                row_dst[((size_t)bh * g.seq + t0 + j) * 64 + d] = to_16<F16>(val[j] + extra);
             if (tr_dst != nullptr) {
                 uint2 pk;
-                pk.x = pack2bf(val[0] + extra, val[1] + extra);
-                pk.y = pack2bf(val[2] + extra, val[3] + extra);
+                pk.x = pack2<F16>(val[0] + extra, val[1] + extra);
+                pk.y = pack2<F16>(val[2] + extra, val[3] + extra);
                 *reinterpret_cast<uint2*>(&tr_dst[((size_t)bh * 64 + d) * g.seq_pad + t0]) = pk;
             }
             if (which == 0 && g.q2 != nullptr) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    g.q2[((size_t)bh * g.seq + t0 + j) * 64 + d] = f2bf(val[j] + extra2);
+                    g.q2[((size_t)bh * g.seq + t0 + j) * 64 + d] = to_16<F16>(val[j] + extra2);
                 if (g.q2t != nullptr) {
                     uint2 pk;
-                    pk.x = pack2bf(val[0] + extra2, val[1] + extra2);
-                    pk.y = pack2bf(val[2] + extra2, val[3] + extra2);
+                    pk.x = pack2<F16>(val[0] + extra2, val[1] + extra2);
+                    pk.y = pack2<F16>(val[2] + extra2, val[3] + extra2);
                     *reinterpret_cast<uint2*>(&g.q2t[((size_t)bh * 64 + d) * g.seq_pad + t0]) = pk;
                 }
             }
@@ -91,11 +91,11 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs& g, int m_base, int
                 const int m = m_base + j;
                 if (m >= M) break;
                 const int bj = m / g.seq, t = m - bj * g.seq, bhj = bj * g.heads + h;
-                row_dst[((size_t)bhj * g.seq + t) * 64 + d] = f2bf(val[j] + extra);
-                if (tr_dst != nullptr) tr_dst[((size_t)bhj * 64 + d) * g.seq_pad + t] = f2bf(val[j] + extra);
+                row_dst[((size_t)bhj * g.seq + t) * 64 + d] = to_16<F16>(val[j] + extra);
+                if (tr_dst != nullptr) tr_dst[((size_t)bhj * 64 + d) * g.seq_pad + t] = to_16<F16>(val[j] + extra);
                 if (which == 0 && g.q2 != nullptr) {
-                    g.q2[((size_t)bhj * g.seq + t) * 64 + d] = f2bf(val[j] + extra2);
-                    if (g.q2t != nullptr) g.q2t[((size_t)bhj * 64 + d) * g.seq_pad + t] = f2bf(val[j] + extra2);
+                    g.q2[((size_t)bhj * g.seq + t) * 64 + d] = to_16<F16>(val[j] + extra2);
+                    if (g.q2t != nullptr) g.q2t[((size_t)bhj * 64 + d) * g.seq_pad + t] = to_16<F16>(val[j] + extra2);
                 }
             }
         }
@@ -112,23 +112,23 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs& g, int m_base, int
         } else if (EPI == EPI_F32_RESID) {
             g.outF[o] = g.resF[o] + acc + b;
         } else if (EPI == EPI_BF16) {
-            g.outH[o] = f2bf(acc + b);
+            g.outH[o] = to_16<F16>(acc + b);
         } else if (EPI == EPI_GELU) {
             const float h = acc + b;
-            g.outH[o] = f2bf(h);
-            g.outH2[o] = f2bf(gelu_erf(h));
+            g.outH[o] = to_16<F16>(h);
+            g.outH2[o] = to_16<F16>(gelu_erf(h));
         } else if (EPI == EPI_DGELU) {
-            g.outH[o] = f2bf(acc * gelu_erf_grad(bf2f(g.auxH[o])));
+            g.outH[o] = to_16<F16>(acc * gelu_erf_grad(to_f32<F16>(g.auxH[o])));
         } else if (EPI == EPI_ATOMIC) {
             unsafeAtomicAdd(&g.outF[o], acc * g.alpha);
         } else if (EPI == EPI_F32_BF16) {
             g.outF[o] = acc + b;
-            g.outH[o] = f2bf(acc + b);
+            g.outH[o] = to_16<F16>(acc + b);
         }
     }
 }
 
-template <int EPI>
+template <int EPI, bool F16>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][TILE * BK * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[i], bfr[j], acc[i][j]);
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32t<F16>(af[i], bfr[j], acc[i][j]);
         }
         if (kt + 1 < kt_end) lstore(buf ^ 1);
         __syncthreads();
@@ -225,43 +225,44 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
                 const int m_base = m0 + wm * 64 + i * 32 + 8 * q + 4 * lg;
                 if (m_base >= g.M) continue;
                 float v4[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                epilogue_quad<EPI>(g, m_base, n, v4, g.M);
+                epilogue_quad<EPI, F16>(g, m_base, n, v4, g.M);
             }
         }
 }
 
 template <int EPI>
-static int launch_gemm(const GemmArgs& g, hipStream_t s) {
+static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
     if (g.M <= 0 || g.N % TILE != 0 || g.K % BK != 0 || g.ksplit < 1) return SED_ERR_ARG;
     if ((g.lda % 8) || (g.ldb % 8)) return SED_ERR_ARG;
     dim3 grid(cdiv(g.M, TILE) * (g.N / TILE), g.ksplit);
-    hipLaunchKernelGGL(gemm_nt_kernel<EPI>, grid, dim3(256), 0, s, g);
+    if (f16) hipLaunchKernelGGL((gemm_nt_kernel<EPI, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_nt_kernel<EPI, false>), grid, dim3(256), 0, s, g);
     return sed_check_launch();
 }
 
 extern "C" int sed_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi,
                            const float* bias, const float* resF, float* outF, void* outH, void* outH2,
-                           const void* auxH, int ldc, float alpha, int ksplit, hipStream_t stream) {
+                           const void* auxH, int ldc, float alpha, int ksplit, int f16, hipStream_t stream) {
     GemmArgs g = {};
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ksplit = ksplit > 0 ? ksplit : 1;
     g.alpha = alpha; g.bias = bias; g.resF = resF; g.outF = outF; g.outH = (bf16_t*)outH; g.outH2 = (bf16_t*)outH2;
     g.auxH = (const bf16_t*)auxH;
     switch (epi) {
-        case EPI_F32: return launch_gemm<EPI_F32>(g, stream);
-        case EPI_F32_RESID: return launch_gemm<EPI_F32_RESID>(g, stream);
-        case EPI_BF16: return launch_gemm<EPI_BF16>(g, stream);
-        case EPI_GELU: return launch_gemm<EPI_GELU>(g, stream);
-        case EPI_DGELU: return launch_gemm<EPI_DGELU>(g, stream);
-        case EPI_ATOMIC: return launch_gemm<EPI_ATOMIC>(g, stream);
-        case EPI_F32_BF16: return launch_gemm<EPI_F32_BF16>(g, stream);
+        case EPI_F32: return launch_gemm<EPI_F32>(g, f16, stream);
+        case EPI_F32_RESID: return launch_gemm<EPI_F32_RESID>(g, f16, stream);
+        case EPI_BF16: return launch_gemm<EPI_BF16>(g, f16, stream);
+        case EPI_GELU: return launch_gemm<EPI_GELU>(g, f16, stream);
+        case EPI_DGELU: return launch_gemm<EPI_DGELU>(g, f16, stream);
+        case EPI_ATOMIC: return launch_gemm<EPI_ATOMIC>(g, f16, stream);
+        case EPI_F32_BF16: return launch_gemm<EPI_F32_BF16>(g, f16, stream);
         default: return SED_ERR_ARG;
     }
 }
 
 extern "C" int sed_gemm_qkv(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq,
                             int seq_pad, void* q, void* k, void* v, void* qt, void* kt, void* vt, void* q2,
-                            void* q2t, const float* pos_u, const float* pos_v, hipStream_t stream) {
+                            void* q2t, const float* pos_u, const float* pos_v, int f16, hipStream_t stream) {
     GemmArgs g = {};
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)W;
     g.M = M; g.N = 3 * heads * 64; g.K = K; g.lda = K; g.ldb = K; g.ldc = g.N; g.ksplit = 1; g.alpha = 1.f;
@@ -270,42 +271,52 @@ extern "C" int sed_gemm_qkv(const void* A, const void* W, const float* bias, int
     g.q2 = (bf16_t*)q2; g.q2t = (bf16_t*)q2t; g.pu = pos_u; g.pv = pos_v;
     g.seq = seq; g.seq_pad = seq_pad; g.heads = heads;
     if (seq <= 0 || (seq_pad % 64) || M % seq) return SED_ERR_ARG;
-    return launch_gemm<EPI_QKV>(g, stream);
+    return launch_gemm<EPI_QKV>(g, f16, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------
 // Layout helpers around the GEMM: casts, transposes (with zero padding of the reduction dim), column sums.
 // ---------------------------------------------------------------------------------------------------
 // in fp32 [R, C] -> out bf16 [R, C]  (grid-stride, float4 in / 8 B out)
+template <bool F16>
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n4) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n4; i += stride) {
         const float4 v = reinterpret_cast<const float4*>(in)[i];
         uint2 p;
-        p.x = pack2bf(v.x, v.y);
-        p.y = pack2bf(v.z, v.w);
+        p.x = pack2<F16>(v.x, v.y);
+        p.y = pack2<F16>(v.z, v.w);
         reinterpret_cast<uint2*>(out)[i] = p;
     }
 }
 
-extern "C" int sed_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream_t stream) {
+extern "C" int sed_cast_f32_bf16(const float* in, void* out, int64_t n, int f16, hipStream_t stream) {
     if (n % 4) return SED_ERR_ARG;
     const size_t n4 = n / 4;
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(blocks), dim3(256), 0, stream, in, (bf16_t*)out, n4);
+    if (f16) hipLaunchKernelGGL(cast_f32_bf16_kernel<true>, dim3(blocks), dim3(256), 0, stream, in, (bf16_t*)out, n4);
+    else hipLaunchKernelGGL(cast_f32_bf16_kernel<false>, dim3(blocks), dim3(256), 0, stream, in, (bf16_t*)out, n4);
     return sed_check_launch();
 }
 
 // Transpose [R, C] (fp32 or bf16 in) -> bf16 out^T [C, Rpad] (rows R..Rpad-1 written as zeros), optionally also
 // the straight bf16 copy [R, C] and the fp32 column sums (atomicAdd into colsum[C]) -- one pass over the input.
 // 64x64 tiles through LDS; 256 threads.
-template <typename TIN>
-__global__ __launch_bounds__(256) void transpose_kernel(const TIN* __restrict__ in, int R, int C, int ldin,
-                                                        bf16_t* __restrict__ outT, int Rpad,
-                                                        bf16_t* __restrict__ outS, float* __restrict__ colsum) {
+// kinds: 0 = bf16, 1 = f32 (input only), 2 = f16
+__device__ __forceinline__ float load_kind(const void* p, size_t i, int kind) {
+    if (kind == 1) return ((const float*)p)[i];
+    const bf16_t h = ((const bf16_t*)p)[i];
+    return kind == 2 ? h2f(h) : bf2f(h);
+}
+__device__ __forceinline__ bf16_t store_kind(float v, int kind) { return kind == 2 ? f2h(v) : f2bf(v); }
+
+__global__ __launch_bounds__(256) void transpose_kernel(const void* __restrict__ in, int in_kind, int R, int C, int ldin,
+                                                        bf16_t* __restrict__ outT, int Rpad, int outT_kind,
+                                                        bf16_t* __restrict__ outS, int outS_kind,
+                                                        float* __restrict__ colsum) {
     __shared__ float tile[64][65];
     const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // ty 0..3
@@ -314,9 +325,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TIN* __restrict__ 
         const int r = r0 + ty * 16 + i, cc = c0 + tx;
         float v = 0.f;
         if (r < R && cc < C) {
-            if (sizeof(TIN) == 4) v = ((const float*)in)[(size_t)r * ldin + cc];
-            else v = bf2f(((const bf16_t*)in)[(size_t)r * ldin + cc]);
-            if (outS != nullptr) outS[(size_t)r * C + cc] = f2bf(v);
+            v = load_kind(in, (size_t)r * ldin + cc, in_kind);
+            if (outS != nullptr) outS[(size_t)r * C + cc] = store_kind(v, outS_kind);
         }
         tile[ty * 16 + i][tx] = v;
     }
@@ -327,23 +337,39 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TIN* __restrict__ 
         for (int i = 0; i < 64; ++i) s += tile[i][tx];
         if (c0 + tx < C) unsafeAtomicAdd(&colsum[c0 + tx], s);
     }
+    if (outT == nullptr) return;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int cc = c0 + ty * 16 + i, r = r0 + tx;
-        if (cc < C && r < Rpad) outT[(size_t)cc * Rpad + r] = f2bf(tile[tx][ty * 16 + i]);
+        if (cc < C && r < Rpad) outT[(size_t)cc * Rpad + r] = store_kind(tile[tx][ty * 16 + i], outT_kind);
     }
 }
 
-extern "C" int sed_transpose_to_bf16(const void* in, int in_is_f32, int R, int C, int ldin, void* outT, int Rpad,
-                                     void* outS, float* colsum, hipStream_t stream) {
-    if (Rpad < R) return SED_ERR_ARG;
+extern "C" int sed_transpose_to_bf16(const void* in, int in_kind, int R, int C, int ldin, void* outT, int Rpad,
+                                     int outT_kind, void* outS, int outS_kind, float* colsum, hipStream_t stream) {
+    if (Rpad < R || in_kind < 0 || in_kind > 2) return SED_ERR_ARG;
     dim3 grid(cdiv(C, 64), cdiv(Rpad, 64));
-    if (in_is_f32)
-        hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, stream, (const float*)in, R, C, ldin,
-                           (bf16_t*)outT, Rpad, (bf16_t*)outS, colsum);
-    else
-        hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)in, R, C, ldin,
-                           (bf16_t*)outT, Rpad, (bf16_t*)outS, colsum);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, in, in_kind, R, C, ldin, (bf16_t*)outT, Rpad,
+                       outT_kind, (bf16_t*)outS, outS_kind, colsum);
+    return sed_check_launch();
+}
+
+// in-place f16 -> bf16 conversion of saved forward operands that the backward consumes as bf16 MFMA operands
+__global__ void f16_to_bf16_kernel(bf16_t* __restrict__ p, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        uint4 v = reinterpret_cast<uint4*>(p)[i];
+        unsigned* w = reinterpret_cast<unsigned*>(&v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = pack2bf(h2f((bf16_t)(w[k] & 0xFFFF)), h2f((bf16_t)(w[k] >> 16)));
+        reinterpret_cast<uint4*>(p)[i] = v;
+    }
+}
+extern "C" int sed_f16_to_bf16_inplace(void* p, int64_t n, hipStream_t stream) {
+    if (n % 8) return SED_ERR_ARG;
+    size_t n8 = n / 8;
+    int blocks = (int)((n8 + 255) / 256);
+    blocks = blocks > 4096 ? 4096 : (blocks < 1 ? 1 : blocks);
+    hipLaunchKernelGGL(f16_to_bf16_kernel, dim3(blocks), dim3(256), 0, stream, (bf16_t*)p, n8);
     return sed_check_launch();
 }
 

@@ -18,12 +18,12 @@ __device__ __forceinline__ void row_store(const Row& r, float* p, int lane) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) reinterpret_cast<float4*>(p)[lane + 64 * i] = r.v[i];
 }
-__device__ __forceinline__ void row_store_bf16(const Row& r, bf16_t* p, int lane) {
+__device__ __forceinline__ void row_store_bf16(const Row& r, bf16_t* p, int lane, int f16) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         uint2 pk;
-        pk.x = pack2bf(r.v[i].x, r.v[i].y);
-        pk.y = pack2bf(r.v[i].z, r.v[i].w);
+        pk.x = f16 ? pack2<true>(r.v[i].x, r.v[i].y) : pack2bf(r.v[i].x, r.v[i].y);
+        pk.y = f16 ? pack2<true>(r.v[i].z, r.v[i].w) : pack2bf(r.v[i].z, r.v[i].w);
         reinterpret_cast<uint2*>(p)[lane + 64 * i] = pk;
     }
 }
@@ -37,7 +37,7 @@ __device__ __forceinline__ const float& f4(const float4& v, int c) { return rein
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, float in_scale,
                                                             bf16_t* __restrict__ y16, float* __restrict__ y32,
-                                                            float* __restrict__ mean, float* __restrict__ rstd, int M) {
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int M, int f16) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -55,16 +55,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const float rs = rsqrtf(wave_sum(q) * (1.0f / DM) + eps);
 #pragma unroll
     ROW_FOREACH(i, c) f4(r.v[i], c) = (f4(r.v[i], c) - mu) * rs * f4(g.v[i], c) + f4(b.v[i], c);
-    if (y16 != nullptr) row_store_bf16(r, y16 + (size_t)row * DM, lane);
+    if (y16 != nullptr) row_store_bf16(r, y16 + (size_t)row * DM, lane, f16);
     if (y32 != nullptr) row_store(r, y32 + (size_t)row * DM, lane);
     if (lane == 0 && mean != nullptr) { mean[row] = mu; rstd[row] = rs; }
 }
 
 extern "C" int sed_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float in_scale,
-                                 void* y_bf16, float* y_f32, float* mean, float* rstd, int M, int D, hipStream_t stream) {
+                                 void* y_bf16, float* y_f32, float* mean, float* rstd, int M, int D, int f16, hipStream_t stream) {
     if (D != DM || M <= 0) return SED_ERR_ARG;
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, stream, x, gamma, beta, eps, in_scale,
-                       (bf16_t*)y_bf16, y_f32, mean, rstd, M);
+                       (bf16_t*)y_bf16, y_f32, mean, rstd, M, f16);
     return sed_check_launch();
 }
 
@@ -144,7 +144,7 @@ extern "C" int sed_layernorm_bwd(const float* dy, const float* x, const float* m
 // mel [B, 128, T] fp32 -> cols bf16 [B * 12 * tp, 256];  row (b, f, t), col 16 i + j = mel[b, 10 f + i, tstart + 10 t + j]
 // (tstart selects a sliding-window slab without copying it)
 __global__ void im2col_kernel(const float* __restrict__ mel, bf16_t* __restrict__ cols, int B, int T, int tstart,
-                              int tp) {
+                              int tp, int f16) {
     const size_t total = (size_t)B * 12 * tp * 128;  // pairs
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int pr = (int)(idx & 127);
@@ -152,12 +152,12 @@ __global__ void im2col_kernel(const float* __restrict__ mel, bf16_t* __restrict_
         const int t = (int)(row % tp), f = (int)((row / tp) % 12), b = (int)(row / ((size_t)tp * 12));
         const int i = pr >> 3, j = (pr & 7) * 2;
         const float* src = mel + ((size_t)b * 128 + 10 * f + i) * T + tstart + 10 * t + j;
-        reinterpret_cast<unsigned*>(cols)[idx] = pack2bf(src[0], src[1]);
+        reinterpret_cast<unsigned*>(cols)[idx] = f16 ? pack2<true>(src[0], src[1]) : pack2bf(src[0], src[1]);
     }
 }
-extern "C" int sed_im2col(const float* mel, void* cols, int B, int T, int tstart, int tp, hipStream_t stream) {
+extern "C" int sed_im2col(const float* mel, void* cols, int B, int T, int tstart, int tp, int f16, hipStream_t stream) {
     if (tp < 1 || tstart < 0 || tstart + 10 * (tp - 1) + 16 > T) return SED_ERR_ARG;
-    hipLaunchKernelGGL(im2col_kernel, dim3(2048), dim3(256), 0, stream, mel, (bf16_t*)cols, B, T, tstart, tp);
+    hipLaunchKernelGGL(im2col_kernel, dim3(2048), dim3(256), 0, stream, mel, (bf16_t*)cols, B, T, tstart, tp, f16);
     return sed_check_launch();
 }
 // d mel is never needed (the mel input is data).
@@ -375,11 +375,13 @@ extern "C" int sed_interp_bwd(const float* dout, float* din, int B, int tin, int
 }
 
 // Sliding-window merge (encoder_slide_window.py:16-36 + passt_sed.py:266-271), windows folded into the batch:
-// pooled_win [nW, B, tpw, D] -> x[b, j] = (1 - mix) x[b, j] + mix * (sum_w interp(pooled_win[w, b])[j - left_w]) / cnt_j
+// window w's pooled frames live at pooled_win + offs[w] * D as [B, tps[w], D] (the last window of a sweep can be one
+// patch shorter than the others);
+//   x[b, j] = (1 - mix) x[b, j] + mix * (sum_w interp(pooled_w[b])[j - left_w]) / cnt_j
 // (cnt_j == 0 -> local part is 0, the reference's NaN -> 0).
-__global__ void window_mix_kernel(const float* __restrict__ pooled_win, const int* __restrict__ lefts, int nW,
-                                  float* __restrict__ x, float mix, int B, int T, int tpw, int ratio) {
-    const int wlen = tpw * ratio;
+__global__ void window_mix_kernel(const float* __restrict__ pooled_win, const int* __restrict__ lefts,
+                                  const int* __restrict__ tps, const int* __restrict__ offs, int nW,
+                                  float* __restrict__ x, float mix, int B, int T, int ratio) {
     const size_t total = (size_t)B * T * (DM / 4);
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int d4 = (int)(idx % (DM / 4));
@@ -388,11 +390,11 @@ __global__ void window_mix_kernel(const float* __restrict__ pooled_win, const in
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         int cnt = 0;
         for (int w = 0; w < nW; ++w) {
-            const int jj = j - lefts[w];
-            if (jj < 0 || jj >= wlen) continue;
+            const int jj = j - lefts[w], tpw = tps[w];
+            if (jj < 0 || jj >= tpw * ratio) continue;
             int i0, i1; float lam;
             interp_coeff(jj, ratio, tpw, tpw, i0, i1, lam);
-            const float* base = pooled_win + (((size_t)w * B + b) * tpw) * DM;
+            const float* base = pooled_win + ((size_t)offs[w] + (size_t)b * tpw) * DM;
             const float4 a = reinterpret_cast<const float4*>(base)[(size_t)i0 * (DM / 4) + d4];
             const float4 c = reinterpret_cast<const float4*>(base)[(size_t)i1 * (DM / 4) + d4];
             acc.x += (1.f - lam) * a.x + lam * c.x; acc.y += (1.f - lam) * a.y + lam * c.y;
@@ -406,10 +408,10 @@ __global__ void window_mix_kernel(const float* __restrict__ pooled_win, const in
         reinterpret_cast<float4*>(x)[idx] = g;
     }
 }
-extern "C" int sed_window_mix(const float* pooled_win, const int* lefts, int nW, float* x, float mix, int B, int T,
-                              int tpw, int ratio, hipStream_t stream) {
-    hipLaunchKernelGGL(window_mix_kernel, dim3(2048), dim3(256), 0, stream, pooled_win, lefts, nW, x, mix, B, T, tpw,
-                       ratio);
+extern "C" int sed_window_mix(const float* pooled_win, const int* lefts, const int* tps, const int* offs, int nW,
+                              float* x, float mix, int B, int T, int ratio, hipStream_t stream) {
+    hipLaunchKernelGGL(window_mix_kernel, dim3(2048), dim3(256), 0, stream, pooled_win, lefts, tps, offs, nW, x, mix, B,
+                       T, ratio);
     return sed_check_launch();
 }
 
@@ -615,7 +617,7 @@ extern "C" int sed_head_bwd(const float* x, const float* W, const float* strong,
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attnpool_fwd_kernel(const bf16_t* __restrict__ kv, const float* __restrict__ q,
                                                            float* __restrict__ out, float* __restrict__ probs, int N,
-                                                           int H) {
+                                                           int H, int f16) {
     extern __shared__ float sc[];  // [P]
     __shared__ float red[4];
     __shared__ float part[4][64];
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(256) void attnpool_fwd_kernel(const bf16_t* __restr
     const float qd = q[h * 64 + lane];
     float mx = -1e30f;
     for (int t = wave; t < P; t += 4) {
-        float s = qd * bf2f(base[(size_t)t * 2 * DM + h * 64 + lane]);
+        float s = qd * (f16 ? h2f(base[(size_t)t * 2 * DM + h * 64 + lane]) : bf2f(base[(size_t)t * 2 * DM + h * 64 + lane]));
         s = wave_sum(s) * 0.125f;
         if (lane == 0) sc[t] = s;
         mx = fmaxf(mx, s);
@@ -641,7 +643,7 @@ __global__ __launch_bounds__(256) void attnpool_fwd_kernel(const bf16_t* __restr
     __syncthreads();
     const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
     float acc = 0.f;
-    for (int t = wave; t < P; t += 4) acc += sc[t] * inv * bf2f(base[(size_t)t * 2 * DM + DM + h * 64 + lane]);
+    for (int t = wave; t < P; t += 4) acc += sc[t] * inv * (f16 ? h2f(base[(size_t)t * 2 * DM + DM + h * 64 + lane]) : bf2f(base[(size_t)t * 2 * DM + DM + h * 64 + lane]));
     part[wave][lane] = acc;
     if (probs != nullptr)
         for (int t = threadIdx.x; t < P; t += 256) probs[(size_t)blockIdx.x * P + t] = sc[t] * inv;
@@ -649,16 +651,16 @@ __global__ __launch_bounds__(256) void attnpool_fwd_kernel(const bf16_t* __restr
     if (wave == 0) out[(size_t)b * DM + h * 64 + lane] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
 }
 extern "C" int sed_attnpool_fwd(const void* kv, const float* q, float* out, float* probs, int B, int N, int H,
-                                hipStream_t stream) {
+                                int f16, hipStream_t stream) {
     hipLaunchKernelGGL(attnpool_fwd_kernel, dim3(B * H), dim3(256), (N - 2) * sizeof(float), stream, (const bf16_t*)kv, q,
-                       out, probs, N, H);
+                       out, probs, N, H, f16);
     return sed_check_launch();
 }
 // backward: dout [B, D] -> dkv bf16 [B, N, 2D] (rows 0,1 zero), dq [D] (atomic over b)
 __global__ __launch_bounds__(256) void attnpool_bwd_kernel(const bf16_t* __restrict__ kv, const float* __restrict__ q,
                                                            const float* __restrict__ probs,
                                                            const float* __restrict__ dout, bf16_t* __restrict__ dkv,
-                                                           float* __restrict__ dq, int N, int H) {
+                                                           float* __restrict__ dq, int N, int H, int f16) {
     extern __shared__ float dp[];  // [P]
     __shared__ float red[4];
     __shared__ float part[4][64];
@@ -670,7 +672,7 @@ __global__ __launch_bounds__(256) void attnpool_bwd_kernel(const bf16_t* __restr
     const float go = dout[(size_t)b * DM + h * 64 + lane], qd = q[h * 64 + lane];
     float dot = 0.f;
     for (int t = wave; t < P; t += 4) {
-        float v = go * bf2f(base[(size_t)t * 2 * DM + DM + h * 64 + lane]);
+        float v = go * (f16 ? h2f(base[(size_t)t * 2 * DM + DM + h * 64 + lane]) : bf2f(base[(size_t)t * 2 * DM + DM + h * 64 + lane]));
         v = wave_sum(v);
         if (lane == 0) dp[t] = v;
         dot += v * pr[t];
@@ -682,7 +684,7 @@ __global__ __launch_bounds__(256) void attnpool_bwd_kernel(const bf16_t* __restr
     for (int t = wave; t < P; t += 4) {
         const float p = pr[t];
         const float ds = p * (dp[t] - dot) * 0.125f;
-        dqa += ds * bf2f(base[(size_t)t * 2 * DM + h * 64 + lane]);
+        dqa += ds * (f16 ? h2f(base[(size_t)t * 2 * DM + h * 64 + lane]) : bf2f(base[(size_t)t * 2 * DM + h * 64 + lane]));
         dbase[(size_t)t * 2 * DM + h * 64 + lane] = f2bf(ds * qd);
         dbase[(size_t)t * 2 * DM + DM + h * 64 + lane] = f2bf(p * go);
     }
@@ -696,9 +698,9 @@ __global__ __launch_bounds__(256) void attnpool_bwd_kernel(const bf16_t* __restr
     if (wave == 0) unsafeAtomicAdd(&dq[h * 64 + lane], part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
 }
 extern "C" int sed_attnpool_bwd(const void* kv, const float* q, const float* probs, const float* dout, void* dkv,
-                                float* dq, int B, int N, int H, hipStream_t stream) {
+                                float* dq, int B, int N, int H, int f16, hipStream_t stream) {
     hipLaunchKernelGGL(attnpool_bwd_kernel, dim3(B * H), dim3(256), (N - 2) * sizeof(float), stream, (const bf16_t*)kv, q,
-                       probs, dout, (bf16_t*)dkv, dq, N, H);
+                       probs, dout, (bf16_t*)dkv, dq, N, H, f16);
     return sed_check_launch();
 }
 

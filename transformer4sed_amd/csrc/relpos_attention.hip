@@ -63,6 +63,7 @@ __device__ __forceinline__ void bandT_stage(const bf16_t* Pth, int CB, int Rpad,
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
+template <bool F16>
 __global__ __launch_bounds__(256) void relpos_fwd_kernel(const bf16_t* __restrict__ Qu, const bf16_t* __restrict__ Qv,
                                                          const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
                                                          const bf16_t* __restrict__ P, bf16_t* __restrict__ O,
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void relpos_fwd_kernel(const bf16_t* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) g[r] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) g = mfma32(lds_frag_rows(lb, band_row0 + 32 * blk + lr, 2 * s + lg), qvf[s], g);
+            for (int s = 0; s < 4; ++s) g = mfma32t<F16>(lds_frag_rows(lb, band_row0 + 32 * blk + lr, 2 * s + lg), qvf[s], g);
 #pragma unroll
             for (int r = 0; r < 16; ++r) gs[(32 * blk + mfma32_row(r, lg)) * 32 + lr] = g[r];
         }
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void relpos_fwd_kernel(const bf16_t* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) st[kb] = mfma32(lds_frag_rows(lk, 32 * kb + lr, 2 * s + lg), quf[s], st[kb]);
+            for (int s = 0; s < 4; ++s) st[kb] = mfma32t<F16>(lds_frag_rows(lk, 32 * kb + lr, 2 * s + lg), quf[s], st[kb]);
         }
         __syncthreads();  // G^T visible (wave-private buffer, but keep it simple and safe)
         float mloc = -1e30f;
@@ -170,10 +171,10 @@ __global__ __launch_bounds__(256) void relpos_fwd_kernel(const bf16_t* __restric
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const s16x8_t pf = pack_frag(st[kb], s);
+                const s16x8_t pf = pack_frag_t<F16>(st[kb], s);
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
-                    o[db] = mfma32(lds_frag_cols(lv, 32 * db + lr, 8 * kb + 4 * s + lg), pf, o[db]);
+                    o[db] = mfma32t<F16>(lds_frag_cols(lv, 32 * db + lr, 8 * kb + 4 * s + lg), pf, o[db]);
             }
         if (t + 1 < ntiles) {
             tile_lstore_rows(rk, lds_kv[buf ^ 1][0], tid);
@@ -191,8 +192,8 @@ __global__ __launch_bounds__(256) void relpos_fwd_kernel(const bf16_t* __restric
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 uint2 pk;
-                pk.x = pack2bf(o[db][4 * qd] * inv, o[db][4 * qd + 1] * inv);
-                pk.y = pack2bf(o[db][4 * qd + 2] * inv, o[db][4 * qd + 3] * inv);
+                pk.x = pack2<F16>(o[db][4 * qd] * inv, o[db][4 * qd + 1] * inv);
+                pk.y = pack2<F16>(o[db][4 * qd + 2] * inv, o[db][4 * qd + 3] * inv);
                 *reinterpret_cast<uint2*>(orow + 32 * db + 8 * qd + 4 * lg) = pk;
             }
         if (lg == 0 && LSE != nullptr) LSE[(size_t)bh * T + q] = m_run + log2f(l_run);
@@ -200,10 +201,13 @@ __global__ __launch_bounds__(256) void relpos_fwd_kernel(const bf16_t* __restric
 }
 
 extern "C" int sed_relpos_attn_fwd(const void* Qu, const void* Qv, const void* K, const void* Vt, const void* P,
-                                   void* O, float* LSE, int B, int H, int T, int Tpad, int Rpad, hipStream_t stream) {
+                                   void* O, float* LSE, int B, int H, int T, int Tpad, int Rpad, int f16,
+                                   hipStream_t stream) {
     if (T <= 0 || (T % 8) || Tpad % 64 || Tpad < T || Rpad % 64 || Rpad < 2 * T - 1) return SED_ERR_ARG;
     dim3 grid(cdiv(T, 128), B * H);
-    hipLaunchKernelGGL(relpos_fwd_kernel, grid, dim3(256), 0, stream, (const bf16_t*)Qu, (const bf16_t*)Qv,
+    if (f16) hipLaunchKernelGGL(relpos_fwd_kernel<true>, grid, dim3(256), 0, stream, (const bf16_t*)Qu, (const bf16_t*)Qv,
+                                (const bf16_t*)K, (const bf16_t*)Vt, (const bf16_t*)P, (bf16_t*)O, LSE, T, Tpad, H, Rpad);
+    else hipLaunchKernelGGL(relpos_fwd_kernel<false>, grid, dim3(256), 0, stream, (const bf16_t*)Qu, (const bf16_t*)Qv,
                        (const bf16_t*)K, (const bf16_t*)Vt, (const bf16_t*)P, (bf16_t*)O, LSE, T, Tpad, H, Rpad);
     return sed_check_launch();
 }
@@ -211,6 +215,7 @@ extern "C" int sed_relpos_attn_fwd(const void* Qu, const void* Qv, const void* K
 // ---------------------------------------------------------------------------------------------------
 // backward kernel 1: dK, dV   (workgroup = 128 keys; loops over 64-query tiles; lane owns a key column)
 // ---------------------------------------------------------------------------------------------------
+template <bool SF16>
 __global__ __launch_bounds__(256) void relpos_bwd_dkdv_kernel(
     const bf16_t* __restrict__ Qu, const bf16_t* __restrict__ Qut, const bf16_t* __restrict__ Qv,
     const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, const bf16_t* __restrict__ P,
@@ -277,8 +282,8 @@ __global__ __launch_bounds__(256) void relpos_bwd_dkdv_kernel(
                 for (int r = 0; r < 16; ++r) g[r] = 0.f;
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
-                    g = mfma32(lds_frag_rows(lds[1], 32 * qb + lr, 2 * s + lg),
-                               lds_frag_rows(lds_band, rowoff + 32 * blk + lr, 2 * s + lg), g);
+                    g = mfma32t<SF16>(lds_frag_rows(lds[1], 32 * qb + lr, 2 * s + lg),
+                                      lds_frag_rows(lds_band, rowoff + 32 * blk + lr, 2 * s + lg), g);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gs[mfma32_row(r, lg) * 65 + 32 * blk + lr] = g[r];
             }
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(256) void relpos_bwd_dkdv_kernel(
             for (int r = 0; r < 16; ++r) { s_[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                s_ = mfma32(lds_frag_rows(lds[0], 32 * qb + lr, 2 * s + lg), kf[s], s_);
+                s_ = mfma32t<SF16>(lds_frag_rows(lds[0], 32 * qb + lr, 2 * s + lg), kf[s], s_);
                 dp = mfma32(lds_frag_rows(lds[2], 32 * qb + lr, 2 * s + lg), vf[s], dp);
             }
             __syncthreads();
@@ -336,6 +341,7 @@ __global__ __launch_bounds__(256) void relpos_bwd_dkdv_kernel(
 // backward kernel 2: dQ (= dQu + dQv), per-head sums for pos_bias_u / pos_bias_v, and dS^T for the dP kernel.
 // workgroup = 128 queries; loops over 64-key tiles; lane owns a query column (as in forward).
 // ---------------------------------------------------------------------------------------------------
+template <bool SF16>
 __global__ __launch_bounds__(256) void relpos_bwd_dq_kernel(
     const bf16_t* __restrict__ Qu, const bf16_t* __restrict__ Qv, const bf16_t* __restrict__ K,
     const bf16_t* __restrict__ Kt, const bf16_t* __restrict__ V, const bf16_t* __restrict__ P,
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(256) void relpos_bwd_dq_kernel(
             for (int r = 0; r < 16; ++r) g[r] = 0.f;
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                g = mfma32(lds_frag_rows(lds_band, band_row0 + 32 * blk + lr, 2 * s + lg), qvf[s], g);
+                g = mfma32t<SF16>(lds_frag_rows(lds_band, band_row0 + 32 * blk + lr, 2 * s + lg), qvf[s], g);
 #pragma unroll
             for (int r = 0; r < 16; ++r) gs[(32 * blk + mfma32_row(r, lg)) * 32 + lr] = g[r];
         }
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(256) void relpos_bwd_dq_kernel(
             for (int r = 0; r < 16; ++r) { st[kb][r] = 0.f; dp[kb][r] = 0.f; }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                st[kb] = mfma32(lds_frag_rows(lds[0], 32 * kb + lr, 2 * s + lg), quf[s], st[kb]);
+                st[kb] = mfma32t<SF16>(lds_frag_rows(lds[0], 32 * kb + lr, 2 * s + lg), quf[s], st[kb]);
                 dp[kb] = mfma32(lds_frag_rows(lds[1], 32 * kb + lr, 2 * s + lg), dof[s], dp[kb]);
             }
         }
@@ -555,31 +561,29 @@ __global__ __launch_bounds__(256) void relpos_bwd_dp_kernel(const bf16_t* __rest
     }
 }
 
-extern "C" int sed_relpos_attn_bwd(const void* Qu, const void* Qut, const void* Qv, const void* Qvt, const void* K,
-                                   const void* Kt, const void* V, const void* P, const void* Pt, const void* O,
-                                   const void* dO, const float* LSE, float* Dtmp, void* dOh, void* dOt, void* dqkv,
-                                   void* dSt, float* dP, float* du, float* dv, int B, int H, int T, int Tpad,
-                                   int Rpad, int need_param_grads, hipStream_t stream);
-
 // the pre-pass (D = rowsum(dO * O), head-split dO copies) is shared with the encoder attention
 extern "C" int sed_mhsa_bwd_prep(const void* dO, const void* O, float* Dtmp, void* dOh, void* dOt, int B, int H, int N,
-                                 int Npad, hipStream_t stream);
+                                 int Npad, int o_f16, hipStream_t stream);
 
 extern "C" int sed_relpos_attn_bwd(const void* Qu, const void* Qut, const void* Qv, const void* Qvt, const void* K,
                                    const void* Kt, const void* V, const void* P, const void* Pt, const void* O,
                                    const void* dO, const float* LSE, float* Dtmp, void* dOh, void* dOt, void* dqkv,
                                    void* dSt, float* dP, float* du, float* dv, int B, int H, int T, int Tpad,
-                                   int Rpad, int need_param_grads, hipStream_t stream) {
+                                   int Rpad, int need_param_grads, int f16, hipStream_t stream) {
+    // f16 != 0: Qu, Qv, K, P (score recompute) and O are IEEE half; Qut, Qvt, Kt, V, Pt, dO are bf16.
     if (T <= 0 || (T % 8) || Tpad % 64 || Tpad < T || Rpad % 64 || Rpad < 2 * T - 1) return SED_ERR_ARG;
-    int rc = sed_mhsa_bwd_prep(dO, O, Dtmp, dOh, dOt, B, H, T, Tpad, stream);
+    int rc = sed_mhsa_bwd_prep(dO, O, Dtmp, dOh, dOt, B, H, T, Tpad, f16, stream);
     if (rc) return rc;
     dim3 grid(cdiv(T, 128), B * H);
-    hipLaunchKernelGGL(relpos_bwd_dkdv_kernel, grid, dim3(256), 0, stream, (const bf16_t*)Qu, (const bf16_t*)Qut,
-                       (const bf16_t*)Qv, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)P, (const bf16_t*)dOh,
-                       (const bf16_t*)dOt, LSE, Dtmp, (bf16_t*)dqkv, T, Tpad, H, Rpad);
-    hipLaunchKernelGGL(relpos_bwd_dq_kernel, grid, dim3(256), 0, stream, (const bf16_t*)Qu, (const bf16_t*)Qv,
-                       (const bf16_t*)K, (const bf16_t*)Kt, (const bf16_t*)V, (const bf16_t*)P, (const bf16_t*)Pt,
+#define SED_LAUNCH_RP(F)                                                                                               \
+    hipLaunchKernelGGL(relpos_bwd_dkdv_kernel<F>, grid, dim3(256), 0, stream, (const bf16_t*)Qu, (const bf16_t*)Qut,   \
+                       (const bf16_t*)Qv, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)P, (const bf16_t*)dOh,    \
+                       (const bf16_t*)dOt, LSE, Dtmp, (bf16_t*)dqkv, T, Tpad, H, Rpad);                                \
+    hipLaunchKernelGGL(relpos_bwd_dq_kernel<F>, grid, dim3(256), 0, stream, (const bf16_t*)Qu, (const bf16_t*)Qv,      \
+                       (const bf16_t*)K, (const bf16_t*)Kt, (const bf16_t*)V, (const bf16_t*)P, (const bf16_t*)Pt,     \
                        (const bf16_t*)dOh, LSE, Dtmp, (bf16_t*)dqkv, (bf16_t*)dSt, du, dv, T, Tpad, H, Rpad);
+    if (f16) { SED_LAUNCH_RP(true) } else { SED_LAUNCH_RP(false) }
+#undef SED_LAUNCH_RP
     if (need_param_grads) {
         int bsplit = B < 8 ? B : 8;
         hipLaunchKernelGGL(relpos_bwd_dp_kernel, dim3(Rpad / 64, H, bsplit), dim3(256), 0, stream, (const bf16_t*)dSt,

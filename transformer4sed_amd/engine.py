@@ -14,7 +14,9 @@ import math
 import torch
 
 from . import ops
-from .ops import BF16, F32, call, gemm_nt, gemm_dw, pad64, transpose_bf16
+import os
+
+from .ops import BF16, F16, F32, call, gemm_nt, gemm_dw, pad64, transpose_bf16, to_bf16_, is_f16
 from .ops import EPI_F32, EPI_F32_RESID, EPI_BF16, EPI_GELU, EPI_DGELU, EPI_F32_BF16
 
 D = 768
@@ -55,6 +57,9 @@ class SedEngine:
         self.dev = None
         self.cache = {}
         self.pos_cache = {}
+        # 16-bit type of the FORWARD MFMA operands (activations + weight images).  IEEE half (default) keeps the frame
+        # posteriors within 1e-3 of the fp32 reference at the bf16 MFMA rate; gradient-side operands are always bf16.
+        self.act = {"f16": F16, "bf16": BF16}[os.environ.get("SED_FWD_DTYPE", "f16")]
 
     def __deepcopy__(self, memo):
         return None  # `ema_net = deepcopy(net)` (finetune/passt/setting.py:8-15): the copy rebuilds its engine lazily
@@ -85,7 +90,7 @@ class SedEngine:
             k_in = w2.shape[1]
             ent = self.cache.get(n)
             if ent is None or ent.w.device != w32.device:
-                ent = _W(torch.empty(n_out, k_in, dtype=BF16, device=w32.device),
+                ent = _W(torch.empty(n_out, k_in, dtype=self.act, device=w32.device),
                          torch.empty(k_in, n_out, dtype=BF16, device=w32.device))
                 self.cache[n] = ent
             transpose_bf16(w2, n_out, k_in, ent.wt, out_s=ent.w)
@@ -99,7 +104,7 @@ class SedEngine:
             tab = torch.zeros(Rpad, D)
             tab[:R] = rel_pos_table(T)
             tab = tab.to(dev)
-            pos16 = tab.to(BF16).contiguous()
+            pos16 = tab.to(self.act).contiguous()
             posT16 = torch.empty(D, Rpad, dtype=BF16, device=dev)
             transpose_bf16(tab, Rpad, D, posT16)
             self.pos_cache[key] = (pos16, posT16, Rpad)
@@ -118,10 +123,12 @@ class SedEngine:
         Npad = pad64(N)
         M = Bx * N
         E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
+        A16 = self.act
+        f16 = 1 if A16 == F16 else 0
         ctx = dict(B=Bx, N=N, Npad=Npad, tp=tp, layers=[], toffsets=toffsets, nS=nS)
-        cols = E(Bx * 12 * tp, 256, dt=BF16)
+        cols = E(Bx * 12 * tp, 256, dt=A16)
         for s, ts in enumerate(tstarts):
-            call("sed_im2col", mel, cols[s * B * 12 * tp:(s + 1) * B * 12 * tp], B, T, ts, tp)
+            call("sed_im2col", mel, cols[s * B * 12 * tp:(s + 1) * B * 12 * tp], B, T, ts, tp, f16)
         conv = E(Bx * 12 * tp, D)
         gemm_nt(cols, W["backbone.patch_embed.proj.weight"].w, EPI_F32, bias=self.P("backbone.patch_embed.proj.bias"),
                 outF=conv)
@@ -135,22 +142,22 @@ class SedEngine:
         if save:
             ctx["cols"] = cols
         # per-call scratch (reused across layers when not saving)
-        mk_qkv = lambda: [E(Bx * H, N, 64, dt=BF16) for _ in range(3)]
-        mk_t = lambda: [torch.zeros(Bx * H, 64, Npad, dtype=BF16, device=dev) for _ in range(3)]
+        mk_qkv = lambda: [E(Bx * H, N, 64, dt=A16) for _ in range(3)]
+        mk_t = lambda: [torch.zeros(Bx * H, 64, Npad, dtype=A16, device=dev) for _ in range(3)]
         scratch = None
         pooled = None
         for li in range(m.depth):
             p = f"backbone.blocks.{li}."
             L = {}
             if save or scratch is None:
-                h16 = E(M, D, dt=BF16)
+                h16 = E(M, D, dt=A16)
                 q, k, v = mk_qkv()
-                qt, kt, vt = mk_t() if save else (None, None, torch.zeros(Bx * H, 64, Npad, dtype=BF16, device=dev))
-                o16 = E(M, D, dt=BF16)
+                qt, kt, vt = mk_t() if save else (None, None, torch.zeros(Bx * H, 64, Npad, dtype=A16, device=dev))
+                o16 = E(M, D, dt=A16)
                 lse = E(Bx * H, N)
-                h2 = E(M, D, dt=BF16)
-                hpre = E(M, 4 * D, dt=BF16)
-                act = E(M, 4 * D, dt=BF16)
+                h2 = E(M, D, dt=A16)
+                hpre = E(M, 4 * D, dt=A16)
+                act = E(M, 4 * D, dt=A16)
                 mean1, rstd1, mean2, rstd2 = (E(M), E(M), E(M), E(M)) if save else (None, None, None, None)
                 scratch = (h16, q, k, v, qt, kt, vt, o16, lse, h2, hpre, act)
             else:
@@ -158,15 +165,15 @@ class SedEngine:
                 mean1 = rstd1 = mean2 = rstd2 = None
             x_in = x
             call("sed_layernorm_fwd", x_in, self.P(p + "norm1.weight"), self.P(p + "norm1.bias"), 1e-6, 1.0, h16, None,
-                 mean1, rstd1, M, D)
+                 mean1, rstd1, M, D, f16)
             call("sed_gemm_qkv", h16, W[p + "attn.qkv.weight"].w, self.P(p + "attn.qkv.bias"), M, D, H, N, Npad, q, k,
-                 v, qt, kt, vt, None, None, None, None)
-            call("sed_mhsa_fwd", q, k, vt, o16, lse, Bx, H, N, Npad)
+                 v, qt, kt, vt, None, None, None, None, f16)
+            call("sed_mhsa_fwd", q, k, vt, o16, lse, Bx, H, N, Npad, f16)
             x_mid = E(Bx, N, D) if save else x_in
             gemm_nt(o16, W[p + "attn.proj.weight"].w, EPI_F32_RESID, bias=self.P(p + "attn.proj.bias"), res=x_in,
                     outF=x_mid)
             call("sed_layernorm_fwd", x_mid, self.P(p + "norm2.weight"), self.P(p + "norm2.bias"), 1e-6, 1.0, h2, None,
-                 mean2, rstd2, M, D)
+                 mean2, rstd2, M, D, f16)
             gemm_nt(h2, W[p + "mlp.fc1.weight"].w, EPI_GELU, bias=self.P(p + "mlp.fc1.bias"), outH=hpre, outH2=act)
             x_out = E(Bx, N, D) if save else x_mid
             gemm_nt(act, W[p + "mlp.fc2.weight"].w, EPI_F32_RESID, bias=self.P(p + "mlp.fc2.bias"), res=x_mid,
@@ -188,10 +195,10 @@ class SedEngine:
                     break  # later blocks only feed the AT head (`frame`); windows never need them
         frame16 = None
         if want_frame:
-            frame16 = E(M, D, dt=BF16)
+            frame16 = E(M, D, dt=A16)
             fm, fr = (E(M), E(M)) if save else (None, None)
             call("sed_layernorm_fwd", x, self.P("backbone.norm.weight"), self.P("backbone.norm.bias"), 1e-6, 1.0,
-                 frame16, None, fm, fr, M, D)
+                 frame16, None, fm, fr, M, D, f16)
             if save:
                 ctx.update(x_final=x, fmean=fm, frstd=fr, frame16=frame16)
         return pooled, frame16, ctx
@@ -206,46 +213,48 @@ class SedEngine:
         M = B * T
         pos16, posT16, Rpad = self._pos(T, dev)
         E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
+        A16 = self.act
+        f16 = 1 if A16 == F16 else 0
         ctx = dict(B=B, T=T, Tpad=Tpad, Rpad=Rpad, layers=[])
         cur = x
         for li in range(m.decoder_layer_num):
             p = f"decoder.encoder_blocks.{li}."
             in_scale = math.sqrt(D) if li == 0 else 1.0
-            y16 = E(M, D, dt=BF16)
+            y16 = E(M, D, dt=A16)
             y32 = E(B, T, D)
             mean1, rstd1 = (E(M), E(M)) if save else (None, None)
             call("sed_layernorm_fwd", cur, self.P(p + "norm1.weight"), self.P(p + "norm1.bias"), 1e-5, in_scale, y16,
-                 y32, mean1, rstd1, M, D)
+                 y32, mean1, rstd1, M, D, f16)
             # p = linear_pos(pos_emb), head-split [H, Rpad, 64] (+ transposed [H, 64, Rpad] for backward)
-            Ph = E(H, Rpad, 64, dt=BF16)
-            Pt = torch.zeros(H, 64, Rpad, dtype=BF16, device=dev) if save else None
+            Ph = E(H, Rpad, 64, dt=A16)
+            Pt = torch.zeros(H, 64, Rpad, dtype=A16, device=dev) if save else None
             Wpos = W[p + "attn.linear_pos.weight"].w
             # reuse the head-split epilogue with a "qkv" weight made of [Wpos; Wpos; Wpos]? -> no: plain GEMM + split
-            ptmp = E(Rpad, D, dt=BF16)
+            ptmp = E(Rpad, D, dt=A16)
             gemm_nt(pos16, Wpos, EPI_BF16, outH=ptmp)
             Ph.copy_(ptmp.view(Rpad, H, 64).permute(1, 0, 2))
             if save:
                 Pt.copy_(ptmp.view(Rpad, H, 64).permute(1, 2, 0))
-            qu, k, v = [E(B * H, T, 64, dt=BF16) for _ in range(3)]
-            qv = E(B * H, T, 64, dt=BF16)
-            vt = torch.zeros(B * H, 64, Tpad, dtype=BF16, device=dev)
+            qu, k, v = [E(B * H, T, 64, dt=A16) for _ in range(3)]
+            qv = E(B * H, T, 64, dt=A16)
+            vt = torch.zeros(B * H, 64, Tpad, dtype=A16, device=dev)
             qut = kt = qvt = None
             if save:
-                qut, kt, qvt = [torch.zeros(B * H, 64, Tpad, dtype=BF16, device=dev) for _ in range(3)]
+                qut, kt, qvt = [torch.zeros(B * H, 64, Tpad, dtype=A16, device=dev) for _ in range(3)]
             call("sed_gemm_qkv", y16, W[p + "attn.in_proj.weight"].w, self.P(p + "attn.in_proj.bias"), M, D, H, T, Tpad,
-                 qu, k, v, qut, kt, vt, qv, qvt, self.P(p + "attn.pos_bias_u"), self.P(p + "attn.pos_bias_v"))
-            o16 = E(M, D, dt=BF16)
+                 qu, k, v, qut, kt, vt, qv, qvt, self.P(p + "attn.pos_bias_u"), self.P(p + "attn.pos_bias_v"), f16)
+            o16 = E(M, D, dt=A16)
             lse = E(B * H, T)
-            call("sed_relpos_attn_fwd", qu, qv, k, vt, Ph, o16, lse, B, H, T, Tpad, Rpad)
+            call("sed_relpos_attn_fwd", qu, qv, k, vt, Ph, o16, lse, B, H, T, Tpad, Rpad, f16)
             x1 = E(B, T, D)
             gemm_nt(o16, W[p + "attn.out_proj.weight"].w, EPI_F32_RESID, bias=self.P(p + "attn.out_proj.bias"), res=y32,
                     outF=x1)
-            h2 = E(M, D, dt=BF16)
+            h2 = E(M, D, dt=A16)
             mean2, rstd2 = (E(M), E(M)) if save else (None, None)
             call("sed_layernorm_fwd", x1, self.P(p + "norm2.weight"), self.P(p + "norm2.bias"), 1e-5, 1.0, h2, None,
-                 mean2, rstd2, M, D)
-            hpre = E(M, D, dt=BF16)
-            act = E(M, D, dt=BF16)
+                 mean2, rstd2, M, D, f16)
+            hpre = E(M, D, dt=A16)
+            act = E(M, D, dt=A16)
             gemm_nt(h2, W[p + "mlp.fc1.weight"].w, EPI_GELU, bias=self.P(p + "mlp.fc1.bias"), outH=hpre, outH2=act)
             x2 = E(B, T, D)
             gemm_nt(act, W[p + "mlp.fc2.weight"].w, EPI_F32_RESID, bias=self.P(p + "mlp.fc2.bias"), res=x1, outF=x2)
@@ -283,12 +292,26 @@ class SedEngine:
                                           "config (only the no-grad teacher / validation use it)")
             win, step = win_param
             starts = window_starts(T, win, step)
-            tpw = (win - 16) // 10 + 1
             if toffsets is None:
                 toffsets = [0] * len(starts)
-            pw, _, _ = self._encoder_fwd(W, mel, starts, tpw, list(toffsets), False, want_frame=False)
-            lefts = torch.tensor([round(s * (Tdec / T)) for s in starts], dtype=torch.int32, device=dev)
-            call("sed_window_mix", pw, lefts, len(starts), xg, float(mix_rate), B, Tdec, tpw, ratio)
+            # group the windows by their number of time patches (the last slab of a sweep can be shorter:
+            # min(left + win, T) - left frames, encoder_slide_window.py:28) and fold each group into the batch
+            groups = {}
+            for wi, left in enumerate(starts):
+                width = min(left + win, T) - left
+                groups.setdefault((width - 16) // 10 + 1, []).append(wi)
+            lefts, tps, offs, chunks, row = [0] * len(starts), [0] * len(starts), [0] * len(starts), [], 0
+            for tpw, wis in groups.items():
+                pw, _, _ = self._encoder_fwd(W, mel, [starts[w] for w in wis], tpw, [toffsets[w] for w in wis], False,
+                                             want_frame=False)
+                chunks.append(pw.view(-1, D))
+                for k, w in enumerate(wis):
+                    lefts[w], tps[w], offs[w] = round(starts[w] * (Tdec / T)), tpw, row + k * B * tpw
+                row += len(wis) * B * tpw
+            packed = chunks[0] if len(chunks) == 1 else torch.cat(chunks, 0)
+            i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+            call("sed_window_mix", packed, i32(lefts), i32(tps), i32(offs), len(starts), xg, float(mix_rate), B, Tdec,
+                 ratio)
         out["frame_before_mask"] = xg
         dec_in = xg
         if m.mlm and mlm_plan is not None:
@@ -305,10 +328,10 @@ class SedEngine:
         hctx = {}
         if m.mlm:
             M = B * Tdec
-            xd16 = E(M, D, dt=BF16)
-            call("sed_cast_f32_bf16", xd, xd16, M * D)
-            hpre = E(M, D, dt=BF16)
-            act = E(M, D, dt=BF16)
+            xd16 = E(M, D, dt=self.act)
+            call("sed_cast_f32_bf16", xd, xd16, M * D, is_f16(xd16))
+            hpre = E(M, D, dt=self.act)
+            act = E(M, D, dt=self.act)
             gemm_nt(xd16, W["mlm_mlp.0.weight"].w, EPI_GELU, bias=self.P("mlm_mlp.0.bias"), outH=hpre, outH2=act)
             pred = E(B, Tdec, D)
             gemm_nt(act, W["mlm_mlp.2.weight"].w, EPI_F32, bias=self.P("mlm_mlp.2.bias"), outF=pred)
@@ -344,11 +367,11 @@ class SedEngine:
         bin_ = self.P(pre + "frequency_att.in_proj_bias")
         q = E(1, D)
         call("sed_small_linear", self.P(pre + "f_att_token").reshape(1, D), win[:D], bin_[:D], q, 1, D, D, 0)
-        kv16 = E(B * N, 2 * D, dt=BF16)
+        kv16 = E(B * N, 2 * D, dt=self.act)
         gemm_nt(frame16, W[pre + "frequency_att.in_proj_weight"].w[D:], EPI_BF16, bias=bin_[D:], outH=kv16)
         pooled = E(B, D)
         probs = E(B * H, N - 2) if save else None
-        call("sed_attnpool_fwd", kv16, q, pooled, probs, B, N, H)
+        call("sed_attnpool_fwd", kv16, q, pooled, probs, B, N, H, is_f16(kv16))
         att = E(B, D)
         call("sed_small_linear", pooled, self.P(pre + "frequency_att.out_proj.weight"),
              self.P(pre + "frequency_att.out_proj.bias"), att, B, D, D, 0)
@@ -358,7 +381,7 @@ class SedEngine:
         return dict(q=q, kv16=kv16, pooled=pooled, probs=probs, att=att, at_out=at_out)
 
     # ==================================================================== backward
-    def backward(self, ctx, grads, garena):
+    def backward(self, ctx, grads, garena, hook=None):
         """grads: dict of upstream gradients (strong / weak / at_out / mlm_pred / frame_before_mask, any may be None).
         garena: callable name -> fp32 gradient view (zero-initialised) or None when the parameter is frozen."""
         m = self.m
@@ -394,6 +417,8 @@ class SedEngine:
         # ---------------- context network
         dec_trainable = G("decoder.encoder_blocks.0.attn.in_proj.weight") is not None
         g = self._decoder_bwd(W, ctx["dctx"], g, G, dec_trainable)
+        if hook is not None:
+            hook("decoder")  # classifier / mlm head / context-network gradients are final
         # g = d(decoder input) [B, Tdec, D]
         if ctx["mlm_plan"] is not None:
             plan = ctx["mlm_plan"]
@@ -425,6 +450,8 @@ class SedEngine:
             pool_dx.zero_()
         call("sed_fpool_bwd", dpooled, ectx["pool_x"], ectx["pool_mean"], ectx["pool_rstd"], self.P("out_norm.weight"),
              dtok_tmp, pool_dx, G("out_norm.weight"), G("out_norm.bias"), B, tp)
+        if hook is not None:
+            hook("heads")  # AT head, out_norm (and backbone.norm) gradients are final
         if not enc_trainable:
             return
         if genc is None:
@@ -433,6 +460,8 @@ class SedEngine:
             if li + 1 == m.passt_feature_layer:
                 genc.add_(gpool)
             genc = self._enc_layer_bwd(W, ectx, li, genc, G)
+            if hook is not None:
+                hook(("block", li))
         # patch embedding + positional tables
         dconv16 = E(B * 12 * tp, D, dt=BF16)
         toff = int(ectx["toffsets"][0])
@@ -445,6 +474,8 @@ class SedEngine:
         cT = E(256, Mppad, dt=BF16)
         transpose_bf16(ectx["cols"], Mp, 256, cT)
         gemm_dw(dT, cT, G("backbone.patch_embed.proj.weight"))
+        if hook is not None:
+            hook("embed")
 
     def _mlp_bwd(self, W, n1, n2, dy, x16, hpre, act, M, G, residual):
         """Backward of y = fc2(gelu(fc1(x))) given dy [M, n_out] f32.  Returns dx f32 [M, D] (new tensor), or adds
@@ -456,6 +487,7 @@ class SedEngine:
         hid = w1.w.shape[0]
         n_out = w2.w.shape[0]
         train = G(n1 + ".weight") is not None
+        hpre = to_bf16_(hpre)
         g16 = E(M, n_out, dt=BF16)
         gT = E(n_out, Mpad, dt=BF16)
         transpose_bf16(dy, M, n_out, gT, out_s=g16, colsum=G(n2 + ".bias") if train else None)
@@ -506,8 +538,9 @@ class SedEngine:
         Dtmp = E(B * H, N)
         dOh = E(B * H, N, 64, dt=BF16)
         dOt = E(B * H, 64, Npad, dt=BF16)
-        call("sed_mhsa_bwd", L["q"], L["qt"], L["k"], L["kt"], L["v"], L["o16"], do16, L["lse"], Dtmp, dOh, dOt, dqkv, B,
-             H, N, Npad)
+        f16 = is_f16(L["q"])
+        call("sed_mhsa_bwd", L["q"], to_bf16_(L["qt"]), L["k"], to_bf16_(L["kt"]), to_bf16_(L["v"]), L["o16"], do16,
+             L["lse"], Dtmp, dOh, dOt, dqkv, B, H, N, Npad, f16)
         del dOh, dOt, do16
         dqT = E(3 * D, Mpad, dt=BF16)
         transpose_bf16(dqkv, M, 3 * D, dqT, colsum=G(p + "attn.qkv.bias"))
@@ -563,9 +596,11 @@ class SedEngine:
             du = Gl(p + "attn.pos_bias_u")
             dv = Gl(p + "attn.pos_bias_v")
             scratch_uv = Z(2, D)
-            call("sed_relpos_attn_bwd", L["qu"], L["qut"], L["qv"], L["qvt"], L["k"], L["kt"], L["v"], L["Ph"], L["Pt"],
-                 L["o16"], do16, L["lse"], Dtmp, dOh, dOt, dqkv, dSt, dP, du if du is not None else scratch_uv[0],
-                 dv if dv is not None else scratch_uv[1], B, H, T, Tpad, Rpad, 1 if trainable else 0)
+            f16 = is_f16(L["qu"])
+            call("sed_relpos_attn_bwd", L["qu"], to_bf16_(L["qut"]), L["qv"], to_bf16_(L["qvt"]), L["k"],
+                 to_bf16_(L["kt"]), to_bf16_(L["v"]), L["Ph"], to_bf16_(L["Pt"]), L["o16"], do16, L["lse"], Dtmp, dOh, dOt,
+                 dqkv, dSt, dP, du if du is not None else scratch_uv[0], dv if dv is not None else scratch_uv[1], B, H, T,
+                 Tpad, Rpad, 1 if trainable else 0, f16)
             del dSt, dOh, dOt, do16
             if trainable:
                 dPT = E(D, Rpad, dt=BF16)
@@ -606,7 +641,7 @@ class SedEngine:
              G(pre + "frequency_att.out_proj.weight"), G(pre + "frequency_att.out_proj.bias"), B, D, D, 0)
         dkv = E(M, 2 * D, dt=BF16)
         dq = Z(1, D)
-        call("sed_attnpool_bwd", a["kv16"], a["q"], a["probs"], dpool, dkv, dq, B, N, H)
+        call("sed_attnpool_bwd", a["kv16"], a["q"], a["probs"], dpool, dkv, dq, B, N, H, is_f16(a["kv16"]))
         gin = G(pre + "frequency_att.in_proj_weight")
         gib = G(pre + "frequency_att.in_proj_bias")
         win = self.P(pre + "frequency_att.in_proj_weight")

@@ -5,7 +5,17 @@ import torch
 from ._lib import lib
 
 BF16 = torch.bfloat16
+F16 = torch.float16
 F32 = torch.float32
+
+
+def kind(t):
+    """operand-kind code of the C ABI: 0 bf16, 1 f32, 2 f16."""
+    return {BF16: 0, F32: 1, F16: 2}[t.dtype]
+
+
+def is_f16(t):
+    return 1 if t.dtype == F16 else 0
 
 EPI_F32, EPI_F32_RESID, EPI_BF16, EPI_GELU, EPI_DGELU, EPI_ATOMIC, EPI_QKV, EPI_F32_BF16 = range(8)
 
@@ -20,8 +30,43 @@ def _ptr(t):
     return t.data_ptr()
 
 
+class KernelTimer:
+    """Brackets selected C-ABI launches with HIP events on the launch stream (used by bench.py for the roofline line)."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.records = []  # (name, start_event, end_event, flops)
+
+    def summarize(self):
+        out = {}
+        for name, e0, e1, fl in self.records:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+        return out
+
+
+TIMER = None
+
+
+def _flops_of(name, args):
+    if name == "sed_gemm_nt":
+        return 2.0 * args[2] * args[3] * args[4]
+    if name == "sed_gemm_qkv":
+        return 2.0 * args[3] * args[4] * (3 * args[5] * 64)
+    return 0.0
+
+
 def call(name, *args):
     conv = [(_ptr(a) if (a is None or isinstance(a, torch.Tensor)) else a) for a in args]
+    if TIMER is not None and name in TIMER.names:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        lib().call(name, *conv, torch.cuda.current_stream().cuda_stream)
+        e1.record()
+        TIMER.records.append((name, e0, e1, _flops_of(name, args)))
+        return
     lib().call(name, *conv, torch.cuda.current_stream().cuda_stream)
 
 
@@ -34,8 +79,10 @@ def gemm_nt(A, B, epi, M=None, bias=None, res=None, outF=None, outH=None, outH2=
     """C[M,N] = A[M,K] . B[N,K]^T (bf16 operands) with fused epilogue; see include/sed_hip.h."""
     M = A.shape[0] if M is None else M
     N, K = B.shape[0], B.shape[1]
+    if A.dtype != B.dtype or any(t is not None and t.dtype != A.dtype for t in (outH, outH2, aux)):
+        raise RuntimeError("gemm_nt: all 16-bit operands/outputs of one GEMM must share one type (f16 or bf16)")
     call("sed_gemm_nt", A, B, M, N, K, lda or A.shape[1], ldb or K, epi, bias, res, outF, outH, outH2, aux, ldc or N,
-         float(alpha), ksplit)
+         float(alpha), ksplit, is_f16(A))
 
 
 def dw_ksplit(n_out, k_in, mpad):
@@ -52,6 +99,15 @@ def gemm_dw(dYt, Xt, dW, n_out=None):
 
 
 def transpose_bf16(x, rows, cols, out_t, out_s=None, colsum=None, ld=None):
-    """x [rows, cols] (f32 or bf16) -> out_t bf16 [cols, Rpad]; optional straight bf16 copy / fp32 column sums (+=)."""
-    call("sed_transpose_to_bf16", x, 1 if x.dtype == F32 else 0, rows, cols, ld or cols, out_t, out_t.shape[1], out_s,
-         colsum)
+    """x [rows, cols] (f32 / bf16 / f16) -> out_t [cols, Rpad] (nullable); optional straight 16-bit copy / fp32 column
+    sums (+=).  Output kinds follow the output tensors' dtypes."""
+    call("sed_transpose_to_bf16", x, kind(x), rows, cols, ld or cols, out_t, out_t.shape[1] if out_t is not None else rows,
+         kind(out_t) if out_t is not None else 0, out_s, kind(out_s) if out_s is not None else 0, colsum)
+
+
+def to_bf16_(t):
+    """In-place f16 -> bf16 conversion of a saved forward operand; returns the bf16 view (no-op for bf16 tensors)."""
+    if t is None or t.dtype == BF16:
+        return t
+    call("sed_f16_to_bf16_inplace", t, t.numel())
+    return t.view(BF16)

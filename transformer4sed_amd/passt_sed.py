@@ -154,14 +154,22 @@ class _SedFunction(torch.autograd.Function):
         names = module._param_names
         params = [module._param_by_name[n] for n in names]
         live = [(n, p) for n, p in zip(names, params) if p.requires_grad and not n.startswith("backbone.head")]
-        total = sum((p.numel() + 63) // 64 * 64 for _, p in live)
-        arena = torch.zeros(total, dtype=torch.float32, device=params[0].device)
-        views, off = {}, 0
-        for n, p in live:
-            views[n] = arena[off:off + p.numel()].view(p.shape)
-            off += (p.numel() + 63) // 64 * 64
+        flat = getattr(module, "_flat_layout", None)
+        views = {}
+        if flat is not None:  # optimiser-owned layout: gradient arena offsets == parameter arena offsets
+            arena = torch.zeros(flat.total, dtype=torch.float32, device=params[0].device)
+            for n, p in live:
+                o, k = flat.offset[n]
+                views[n] = arena[o:o + k].view(p.shape)
+        else:
+            total = sum((p.numel() + 63) // 64 * 64 for _, p in live)
+            arena = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+            off = 0
+            for n, p in live:
+                views[n] = arena[off:off + p.numel()].view(p.shape)
+                off += (p.numel() + 63) // 64 * 64
         module._last_grad_arena = arena
-        module.engine.backward(ctx.ectx, grads, lambda n: views.get(n))
+        module.engine.backward(ctx.ectx, grads, lambda n: views.get(n), hook=getattr(module, "_grad_ready_hook", None))
         ctx.ectx = None
         touched = module._grad_names()
         return (None, None, None) + tuple(views.get(n) if n in touched else None for n in names)
@@ -297,12 +305,15 @@ class PaSST_SED(SEDModel):
         kw = dict(encoder_win=bool(encoder_win), mix_rate=float(mix_rate), win_param=tuple(win_param),
                   temp_w=float(temp_w), pad_mask=pad_mask)
         if encoder_win:
-            n_w = len(window_starts(T, win_param[0], win_param[1]))
-            tpw = (win_param[0] - 16) // 10 + 1
+            starts = window_starts(T, win_param[0], win_param[1])
             if self._win_toffsets is not None:
                 kw["toffsets"] = list(self._win_toffsets)
-            elif self.training and tpw < 99:  # passt.py:504-509: one random offset per window pass
-                kw["toffsets"] = [int(torch.randint(1 + 99 - tpw, (1,)).item()) for _ in range(n_w)]
+            elif self.training:  # passt.py:504-509: one random time-pos offset per (short) window pass
+                offs = []
+                for left in starts:
+                    tpw = (min(left + win_param[0], T) - left - 16) // 10 + 1
+                    offs.append(int(torch.randint(1 + 99 - tpw, (1,)).item()) if tpw < 99 else 0)
+                kw["toffsets"] = offs
         self._last_mask_effective = False
         if self.mlm:
             kw["mlm_plan"] = self._mlm_plan(B, (99 + 1) * self.decode_ratio, input.device, encoder_win)

@@ -1,0 +1,272 @@
+"""Training steps of MAT-SED on the HIP path, in the reference's call order:
+
+  * `MatSedTrainer.pretrain_step`  <-> MLMTrainer.train   (recipes/desed/mlm/mlm_passt/train.py:16-49)
+  * `MatSedTrainer.finetune_step`  <-> Trainer.train      (recipes/desed/finetune/train.py:129-213)
+
+plus `FusedAdamWEMA`: torch.optim.AdamW semantics (recipes/desed/setting.py:254-258, per-group lr / weight_decay from
+`get_params`) fused with the EMA teacher update (src/utils/scheduler.py:125-130) in one kernel sweep over a flat fp32
+parameter arena.  The gradient arena produced by the model's backward uses the same layout, so the optimiser (and the
+data-parallel all-reduce, ddp.py) work on contiguous slices -- no per-tensor launches.
+"""
+import random
+import re
+
+import numpy as np
+import torch
+
+from . import data_aug
+from .ops import call
+from .scheduler import cons_weight, ema_alpha
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def check_tensor_name_decoder(name):
+    return any(k in name for k in ("decoder", "f_pool_module", "transformer_projector"))
+
+
+def get_params(net, lr_dict):
+    """Parameter groups + freezing exactly as recipes/desed/finetune/passt/setting.py:28-103 (names, step_lr, freeze rules).
+    Returns a list of dicts {params: [(name, p)], lr, weight_decay}."""
+    enc = lr_dict["encoder"]
+    named_bb = list(net.backbone.named_parameters())
+    if not enc.get("step_lr"):
+        passt_lr = [dict(params=[("backbone." + k, p) for k, p in named_bb], lr=enc["lr"], weight_decay=enc["weight_decay"])]
+    else:
+        low, high = [], []
+        for k, p in named_bb:
+            mt = re.search(r"blocks.(\d+)", k)
+            if mt and (12 - int(mt.group(1)) <= enc["step_lr"]):
+                high.append(("backbone." + k, p))
+            elif "norm." in k:
+                high.append(("backbone." + k, p))
+            else:
+                low.append(("backbone." + k, p))
+        passt_lr = [dict(params=low, lr=enc["lr"], weight_decay=enc["weight_decay"]),
+                    dict(params=high, lr=enc["lr"] * 2, weight_decay=enc["weight_decay"])]
+    if enc["lr"] <= 0:
+        for k, p in named_bb:
+            if "norm." not in k:
+                p.requires_grad = False
+    if enc.get("freeze_layer", 0) > 0:
+        for k, p in named_bb:
+            mt = re.search(r"blocks.(\d+)", k)
+            p.requires_grad = bool((mt and int(mt.group(1)) + 1 > enc["freeze_layer"]) or "norm." in k)
+    passt_ids = {id(p) for _, p in named_bb}
+    dec = [(k, p) for k, p in net.named_parameters() if check_tensor_name_decoder(k)]
+    dec_ids = {id(p) for _, p in dec}
+    if lr_dict["decoder"]["lr"] <= 0:
+        for _, p in dec:
+            p.requires_grad = False
+    head = [(k, p) for k, p in net.named_parameters() if id(p) not in passt_ids and id(p) not in dec_ids]
+    groups = passt_lr + [dict(params=dec, lr=lr_dict["decoder"]["lr"], weight_decay=lr_dict["decoder"]["weight_decay"]),
+                         dict(params=head, lr=lr_dict["head"]["lr"], weight_decay=lr_dict["head"]["weight_decay"])]
+    return groups
+
+
+class FusedAdamWEMA:
+    """Flat-arena AdamW (+ optional EMA teacher).  `param_groups` exposes 'lr' like torch optimisers so that
+    `ExponentialDown` can drive it unchanged."""
+
+    def __init__(self, net, groups, ema_net=None, betas=(0.9, 0.999), eps=1e-8):
+        self.net, self.ema_net = net, ema_net
+        self.betas, self.eps = betas, eps
+        self.step_count = 0
+        dev = next(net.parameters()).device
+        names_in_groups = set()
+        layout, off = [], 0
+        self.param_groups = []
+        for g in groups:
+            start = off
+            for n, p in g["params"]:
+                names_in_groups.add(n)
+                layout.append((n, off, p.numel()))
+                off += (p.numel() + 63) // 64 * 64
+            self.param_groups.append(dict(lr=g["lr"], weight_decay=g["weight_decay"], start=start, end=off,
+                                          names=[n for n, _ in g["params"]]))
+        rest_start = off
+        for n, p in net.named_parameters():  # parameters outside every group still take part in the EMA
+            if n not in names_in_groups:
+                layout.append((n, off, p.numel()))
+                off += (p.numel() + 63) // 64 * 64
+        self.rest = (rest_start, off)
+        self.total = off
+        self.layout = layout
+        self.offset = {n: (o, k) for n, o, k in layout}
+        self.arena = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(off, dtype=torch.float32, device=dev)
+        byname = dict(net.named_parameters())
+        with torch.no_grad():
+            for n, o, k in layout:
+                p = byname[n]
+                self.arena[o:o + k].copy_(p.detach().reshape(-1))
+                p.data = self.arena[o:o + k].view(p.shape)
+        self.ema_arena = None
+        if ema_net is not None:
+            self.ema_arena = torch.zeros(off, dtype=torch.float32, device=dev)
+            eby = dict(ema_net.named_parameters())
+            with torch.no_grad():
+                for n, o, k in layout:
+                    p = eby[n]
+                    self.ema_arena[o:o + k].copy_(p.detach().reshape(-1))
+                    p.data = self.ema_arena[o:o + k].view(p.shape)
+        net._flat_layout = self  # the model's backward lays its gradient arena out identically
+        self.grad_arena = None
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.net.parameters():
+            p.grad = None
+        self.grad_arena = None
+
+    def _runs(self, names, touched):
+        """Contiguous [start, end) arena runs of the parameters in `names` that received a gradient."""
+        runs, cur = [], None
+        for n in names:
+            o, k = self.offset[n]
+            e = o + (k + 63) // 64 * 64
+            if n in touched:
+                if cur is not None and cur[1] == o:
+                    cur[1] = e
+                else:
+                    cur = [o, e]
+                    runs.append(cur)
+            else:
+                cur = None
+        return runs
+
+    def step(self, ema_alpha_value=None):
+        """One AdamW step on every parameter that has a gradient (torch skips grad-less params, so do we), then
+        ema = alpha * ema + (1 - alpha) * p over ALL parameters when `ema_alpha_value` is given."""
+        net = self.net
+        garena = getattr(net, "_last_grad_arena", None)
+        if garena is None or garena.numel() != self.total:
+            raise RuntimeError("FusedAdamWEMA.step(): no flat gradient arena (call loss.backward() on the model output first)")
+        self.step_count += 1
+        touched = {n for n, p in net.named_parameters() if p.grad is not None}
+        b1, b2 = self.betas
+        done = []
+        for g in self.param_groups:
+            for s, e in self._runs(g["names"], touched):
+                ema = self.ema_arena[s:e] if (self.ema_arena is not None and ema_alpha_value is not None) else None
+                call("sed_adamw_ema", self.arena[s:e], garena[s:e], self.m[s:e], self.v[s:e], ema, e - s, float(g["lr"]),
+                     float(g["weight_decay"]), b1, b2, self.eps, self.step_count,
+                     float(ema_alpha_value) if ema_alpha_value is not None else 0.0, 1)
+                done.append((s, e))
+        if self.ema_arena is not None and ema_alpha_value is not None:
+            done.sort()
+            pos = 0
+            for s, e in done + [(self.total, self.total)]:
+                if s > pos:  # EMA-only sweep over everything the AdamW launches did not cover
+                    call("sed_adamw_ema", self.arena[pos:s], self.arena[pos:s], self.m[pos:s], self.v[pos:s],
+                         self.ema_arena[pos:s], s - pos, 0.0, 0.0, b1, b2, self.eps, 1, float(ema_alpha_value), 0)
+                pos = max(pos, e)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def pool_strong_labels(x):
+    """recipes/desed/finetune/train.py:26-29."""
+    x = torch.clamp(x, 1e-5, 1.0)
+    return torch.clamp((x * x).sum(dim=-1) / x.sum(dim=-1), 1e-7, 1.0)
+
+
+class MaskedMSE(torch.autograd.Function):
+    """mse_loss(target[mask], pred[mask]) (mlm_passt/train.py:36-38) in one fused kernel; gradient flows to BOTH
+    arguments like in the reference (the target is not detached)."""
+
+    @staticmethod
+    def forward(ctx, target, pred, mask):
+        rows = mask.numel()
+        m8 = mask.reshape(-1).to(torch.uint8).contiguous()
+        n = int(mask.sum().item())
+        loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
+        dp = torch.empty_like(pred, memory_format=torch.contiguous_format)
+        dt = torch.empty_like(pred, memory_format=torch.contiguous_format)
+        call("sed_masked_mse", pred.contiguous(), target.contiguous(), m8, n, loss, dp, dt, rows)
+        ctx.save_for_backward(dp, dt)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dp, dt = ctx.saved_tensors
+        return dt * g, dp * g, None
+
+
+class MatSedTrainer:
+    def __init__(self, net, ema_net, optimizer, scheduler, config, epoch_len, net_pooling=1, ddp=None):
+        self.net, self.ema_net = net, ema_net
+        self.optimizer, self.scheduler = optimizer, scheduler
+        self.cfg = config
+        self.epoch_len = epoch_len
+        self.net_pooling = net_pooling
+        self.ddp = ddp
+        self.bce = torch.nn.BCELoss()
+        self.mse = torch.nn.MSELoss()
+
+    # ---- recipes/desed/finetune/train.py:69-88
+    def preprocess(self, wav, label, strong_n, weak_n):
+        tr = self.cfg["training"]
+        ext = self.net.get_feature_extractor()
+        mel = ext.logmel(wav)
+        mel, label = data_aug.frame_shift(mel, label, net_pooling=self.net_pooling)
+        if random.random() < 0.5:
+            for lo, hi in ((0, strong_n), (strong_n, strong_n + weak_n)):
+                mm, ml = data_aug.mixup(mel[lo:hi], label[lo:hi], c=np.random.beta(10, 0.5))
+                mel[lo:hi], label[lo:hi] = mm, ml
+        stu_mel, tch_mel = data_aug.feature_transformation(mel, log=True, norm_std=5.0, **tr["transform"])
+        label_weak = torch.zeros((label.shape[0], label.shape[1]), device=label.device)
+        label_weak[strong_n:strong_n + weak_n] = torch.sum(label[strong_n:strong_n + weak_n], -1)
+        label_weak[:strong_n] = pool_strong_labels(label[:strong_n])
+        return stu_mel, tch_mel, label, label_weak
+
+    def finetune_step(self, wav, labels):
+        """One mean-teacher step (train.py:143-208).  Returns the dict of scalar losses (device tensors; no host sync)."""
+        tr = self.cfg["training"]
+        kw = self.cfg["PaSST_SED"]
+        sn, syn, wn, un = tr["batch_size"]
+        scale = wav.shape[0] // (sn + syn + wn + un)
+        strong_n, weak_n = (sn + syn) * scale, wn * scale
+        self.optimizer.zero_grad()
+        # NB the reference swaps the view names at the call site: student <- 2nd view, teacher <- 1st
+        tch_feat, stu_feat, labels, labels_weak = self.preprocess(wav, labels, strong_n, weak_n)
+        stu_strong, stu_weak, stu_other = self.net(stu_feat, **kw["train_stu_kwargs"])
+        with torch.no_grad():
+            tch_strong, tch_weak, tch_other = self.ema_net(tch_feat, **kw["train_tch_kwargs"])
+        at_s, at_t = stu_other["at_out"], tch_other["at_out"].detach()
+        ws = slice(strong_n, strong_n + weak_n)
+        l_at = self.bce(at_s[ws], labels_weak[ws])
+        lc_at = self.mse(at_s, at_t)
+        l_strong = self.bce(stu_strong[:strong_n], labels[:strong_n])
+        l_weak = self.bce(stu_weak[ws], labels_weak[ws])
+        lc_strong = self.mse(stu_strong, tch_strong.detach())
+        lc_weak = self.mse(stu_weak, at_t)
+        w_cons = cons_weight(self.scheduler.step_num, tr["self_loss_warmup"] * self.epoch_len, tr["cons_scheduler_name"],
+                             tr["w_cons_max"], tr["w_cons_min"])
+        self_loss = (lc_strong + tr["w_weak_cons"] * lc_weak + tr["w_AT"] * lc_at) * w_cons
+        loss_total = l_strong + tr["w_weak"] * l_weak + self_loss + l_at * tr["w_AT"]
+        loss_total.backward()  # (the reference's clip_grad_norm before backward is a no-op)
+        if self.ddp is not None:
+            self.ddp.allreduce_grads(self.net)
+        # reference order (train.py:197-201): optimizer.step() with the current lr, scheduler.step(), then update_ema with
+        # the already incremented step_num -> alpha = min(1 - 1/(step_num + 1), ema_factor) fused into the same sweep
+        self.optimizer.step(ema_alpha(self.scheduler.step_num + 1, tr["ema_factor"]))
+        self.scheduler.step()
+        return dict(loss_total=loss_total.detach(), loss_class_strong=l_strong.detach(), loss_class_weak=l_weak.detach(),
+                    loss_class_at_specific=l_at.detach(), loss_cons_strong=lc_strong.detach(),
+                    loss_cons_weak=lc_weak.detach(), loss_cons_at_specific=lc_at.detach(), w_cons=w_cons)
+
+    def pretrain_step(self, wav):
+        """One masked-reconstruction step (mlm_passt/train.py:23-45)."""
+        tr = self.cfg["training"]
+        ext = self.net.get_feature_extractor()
+        mel = ext.logmel(wav)
+        mel = data_aug.frame_shift(mel)
+        mel = data_aug.feature_transformation(mel, log=True, norm_std=5.0, **tr["transform"])
+        pred, other = self.net(mel, encoder_win=tr["encoder_win"])
+        loss = MaskedMSE.apply(other["frame_before_mask"], pred, other["mask_id_seq"])
+        loss.backward()
+        if self.ddp is not None:
+            self.ddp.allreduce_grads(self.net)
+        self.optimizer.step(None)
+        self.optimizer.zero_grad()
+        self.scheduler.step()
+        return dict(loss=loss.detach())
