@@ -4,7 +4,7 @@
  * Python call contracts of SURVEY.md section 8(b).  This header is the native boundary behind those contracts:
  * every entry point takes raw DEVICE pointers, sizes and a hipStream_t, never allocates or frees caller-visible
  * memory, keeps no static state, is stream-ordered and re-entrant, and returns 0 or a negative error code
- * (SED_ERR_ARG = -1 bad argument, SED_ERR_LAUNCH = -2 HIP launch failure) which the Python binding
+ * (-1 bad argument, -2 HIP launch failure, -(1000 + hipError_t) for a failed launch with the HIP error code) which the Python binding
  * (transformer4sed_amd/_lib.py) turns into RuntimeError.  Each entry cites the reference code it replaces
  * (paths relative to the reference repository root).
  *

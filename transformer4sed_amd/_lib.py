@@ -57,7 +57,8 @@ class _Lib:
     def call(self, name, *args):
         rc = getattr(self, "_raw_" + name)(*args)
         if rc != 0:
-            raise SedHipError(f"{name} failed with code {rc} ({'bad argument' if rc == -1 else 'HIP launch failure'})")
+            what = "bad argument" if rc == -1 else (f"HIP error {-rc - 1000}" if rc <= -1000 else "HIP launch failure")
+            raise SedHipError(f"{name} failed with code {rc} ({what})")
 
 
 _lib = None

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(const bf16_t* __restrict_
     tile_gload(rv, Vtb, 0, HD, Npad, 0, tid);
     tile_lstore_rows(rk, lds[0][0], tid);
     tile_lstore_cols(rv, lds[0][1], tid);
+    pin_frags(qf);
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(const bf16_t* __restrict_
 
 extern "C" int sed_mhsa_fwd(const void* Q, const void* K, const void* Vt, void* O, float* LSE, int B, int H, int N,
                             int Npad, int f16, hipStream_t stream) {
+    (void)hipGetLastError();
     if (N <= 0 || Npad % 64 || Npad < N) return SED_ERR_ARG;
     dim3 grid(cdiv(N, 128), B * H);
     if (f16) hipLaunchKernelGGL(mhsa_fwd_kernel<true>, grid, dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,
@@ -243,6 +245,8 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_kernel(
     };
     gload(0);
     lstore(0);
+    pin_frags(kf);
+    pin_frags(vf);
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
@@ -345,6 +349,8 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const bf16_t* __restri
     };
     gload(0);
     lstore(0);
+    pin_frags(qf);
+    pin_frags(dof);
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1, j0 = t * KVB;
@@ -393,6 +399,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const bf16_t* __restri
 
 extern "C" int sed_mhsa_bwd_prep(const void* dO, const void* O, float* Dtmp, void* dOh, void* dOt, int B, int H, int N,
                                  int Npad, int o_f16, hipStream_t stream) {
+    (void)hipGetLastError();
     if (N <= 0 || Npad % 64 || Npad < N) return SED_ERR_ARG;
     hipLaunchKernelGGL(mhsa_bwd_prep_kernel, dim3(Npad / 64, B * H), dim3(256), 0, stream, (const bf16_t*)dO,
                        (const bf16_t*)O, Dtmp, (bf16_t*)dOh, (bf16_t*)dOt, B, N, Npad, H, o_f16);
@@ -402,6 +409,7 @@ extern "C" int sed_mhsa_bwd_prep(const void* dO, const void* O, float* Dtmp, voi
 extern "C" int sed_mhsa_bwd(const void* Q, const void* Qt, const void* K, const void* Kt, const void* V,
                             const void* O, const void* dO, const float* LSE, float* Dtmp, void* dOh, void* dOt,
                             void* dqkv, int B, int H, int N, int Npad, int f16, hipStream_t stream) {
+    (void)hipGetLastError();
     // f16 != 0: Q, K (score recompute) and O are IEEE half as written by the forward; Qt, Kt, V, dO are bf16.
     if (N <= 0 || Npad % 64 || Npad < N) return SED_ERR_ARG;
     int rc = sed_mhsa_bwd_prep(dO, O, Dtmp, dOh, dOt, B, H, N, Npad, f16, stream);

@@ -59,3 +59,11 @@ __device__ __forceinline__ void tile_lstore_cols(const TileRegs& t, unsigned cha
     *reinterpret_cast<uint2*>(dst + vt_off(r + 32, 2 * c)) = make_uint2(t.b.x, t.b.y);
     *reinterpret_cast<uint2*>(dst + vt_off(r + 32, 2 * c + 1)) = make_uint2(t.b.z, t.b.w);
 }
+
+// Make the compiler wait for (and mark as arrived) register fragments that were loaded from global memory before a
+// pipelined loop; otherwise its waitcnt pass conservatively emits s_waitcnt vmcnt(0) at their first in-loop use, which
+// also drains the next tile's prefetch every iteration.
+__device__ __forceinline__ void pin_frags(const s16x8_t (&f)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(f[s]));
+}

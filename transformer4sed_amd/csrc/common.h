@@ -72,6 +72,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 static inline int sed_check_launch() {
     hipError_t e = hipGetLastError();
-    return e == hipSuccess ? SED_OK : SED_ERR_LAUNCH;
+    return e == hipSuccess ? SED_OK : -(1000 + (int)e);  // -(1000 + hipError_t): decoded by the Python binding
 }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

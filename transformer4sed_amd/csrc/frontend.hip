@@ -19,6 +19,11 @@
 #define NBIN 513
 #define FR_PER_WG 8
 
+__global__ void zero_u32_kernel(unsigned* __restrict__ p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
 __global__ void wav_absmax_kernel(const float* __restrict__ wav, unsigned* __restrict__ maxbits, int L) {
     const int b = blockIdx.y;
     const float* w = wav + (size_t)b * L;
@@ -127,9 +132,9 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
 extern "C" int sed_logmel_fwd(const float* wav, float* out, uint32_t* maxbits_tmp, const float* window,
                               const float* twiddle, const float* melw, const int* mel_range, int B, int L, int T,
                               int do_log, hipStream_t stream) {
+    (void)hipGetLastError();
     if (B <= 0 || T != 1 + (L - 1) / HOP || L < NFFT) return SED_ERR_ARG;
-    hipError_t e = hipMemsetAsync(maxbits_tmp, 0, sizeof(uint32_t) * B, stream);
-    if (e != hipSuccess) return SED_ERR_LAUNCH;
+    hipLaunchKernelGGL(zero_u32_kernel, dim3(cdiv(B, 256)), dim3(256), 0, stream, maxbits_tmp, B);
     hipLaunchKernelGGL(wav_absmax_kernel, dim3(64, B), dim3(256), 0, stream, wav, maxbits_tmp, L);
     hipLaunchKernelGGL(logmel_kernel, dim3(cdiv(T, FR_PER_WG), B), dim3(256), 0, stream, wav, maxbits_tmp, window,
                        (const float2*)twiddle, melw, mel_range, out, L, T, do_log);
@@ -167,6 +172,7 @@ __global__ void roll_mix_kernel(const float* __restrict__ in, float* __restrict_
 }
 extern "C" int sed_roll_mix(const float* in, float* out, const int* shift, const int* perm, const float* cmix, int B,
                             int F, int T, int clamp01, hipStream_t stream) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(roll_mix_kernel, dim3(2048), dim3(256), 0, stream, in, out, shift, perm, cmix, B, F, T, clamp01);
     return sed_check_launch();
 }
@@ -198,6 +204,7 @@ __global__ void warp_filt_kernel(const float* __restrict__ in, float* __restrict
 }
 extern "C" int sed_warp_filt(const float* in, float* out, const int* kidx, const float* lam, const float* add, int B,
                              int F, int T, hipStream_t stream) {
+    (void)hipGetLastError();
     if (T % 4) return SED_ERR_ARG;
     hipLaunchKernelGGL(warp_filt_kernel, dim3(2048), dim3(256), 0, stream, in, out, kidx, lam, add, B, F, T);
     return sed_check_launch();
@@ -259,6 +266,7 @@ __global__ __launch_bounds__(256) void median_filter_kernel(const float* __restr
 }
 extern "C" int sed_median_filter(const float* in, float* out, const int* sizes, const float* scale, int B, int T, int C,
                                  int mode, hipStream_t stream) {
+    (void)hipGetLastError();
     if (mode < 0 || mode > 2 || T > 12288) return SED_ERR_ARG;
     hipLaunchKernelGGL(median_filter_kernel, dim3(B * C), dim3(256), T * sizeof(float), stream, in, out, sizes, scale, T,
                        C, mode);

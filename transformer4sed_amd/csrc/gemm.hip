@@ -134,41 +134,60 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = g.N / TILE, ntm = (g.M + TILE - 1) / TILE, nwg = ntm * ntn;
+    // XCD-contiguous linear tile id, then "grouped" order inside it: 8 tile-rows x all tile-columns form a group whose
+    // A panel (8 x 192 KB at K = 768) and B panel stay resident in the XCD's 4 MB L2 while its ~64 concurrent
+    // workgroups sweep it (otherwise every tile-row re-streams the whole weight matrix: ~64 FLOP/B, bandwidth-bound).
     const int t = xcd_remap(blockIdx.x, nwg);
-    const int m0 = (t / ntn) * TILE, n0 = (t % ntn) * TILE;
+    const int group_size = 8 * ntn, gid = t / group_size, first_m = gid * 8;
+    const int gm = (ntm - first_m) < 8 ? (ntm - first_m) : 8;
+    const int tin = t - gid * group_size;
+    const int m0 = (first_m + tin % gm) * TILE, n0 = (tin / gm) * TILE;
     const int ktiles = g.K / BK;
     const int kt_begin = (int)(((long long)blockIdx.y * ktiles) / g.ksplit);
     const int kt_end = (int)(((long long)(blockIdx.y + 1) * ktiles) / g.ksplit);
 
-    // staging: thread -> 16-B chunk c of rows r0 + 32 i
+    // staging: thread -> 16-B chunk c of rows r0 + 32 i (i = 0..3) of both operand tiles.  Named registers (not arrays
+    // captured by lambdas): arrays end up in scratch and every prefetch then stalls on vmcnt(0) + scratch_store.
     const int c = tid & 7, r0 = tid >> 3;
-    const bf16_t* aptr[4];
-    const bf16_t* bptr[4];
-    int lds_off[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = r0 + 32 * i;
-        int am = m0 + r;
-        am = am < g.M ? am : g.M - 1;
-        aptr[i] = g.A + (size_t)am * g.lda + c * 8;
-        bptr[i] = g.B + (size_t)(n0 + r) * g.ldb + c * 8;
-        lds_off[i] = r * 128 + ((c ^ ((r >> 1) & 7)) << 4);
+    const int am_last = g.M - 1;
+    const int am0 = (m0 + r0) < g.M ? (m0 + r0) : am_last, am1 = (m0 + r0 + 32) < g.M ? (m0 + r0 + 32) : am_last;
+    const int am2 = (m0 + r0 + 64) < g.M ? (m0 + r0 + 64) : am_last, am3 = (m0 + r0 + 96) < g.M ? (m0 + r0 + 96) : am_last;
+    const bf16_t* ap0 = g.A + (size_t)am0 * g.lda + c * 8;
+    const bf16_t* ap1 = g.A + (size_t)am1 * g.lda + c * 8;
+    const bf16_t* ap2 = g.A + (size_t)am2 * g.lda + c * 8;
+    const bf16_t* ap3 = g.A + (size_t)am3 * g.lda + c * 8;
+    const bf16_t* bp0 = g.B + (size_t)(n0 + r0) * g.ldb + c * 8;
+    const bf16_t* bp1 = bp0 + (size_t)32 * g.ldb;
+    const bf16_t* bp2 = bp0 + (size_t)64 * g.ldb;
+    const bf16_t* bp3 = bp0 + (size_t)96 * g.ldb;
+    const int lo0 = r0 * 128 + ((c ^ ((r0 >> 1) & 7)) << 4);
+    const int lo1 = (r0 + 32) * 128 + ((c ^ (((r0 + 32) >> 1) & 7)) << 4);
+    const int lo2 = (r0 + 64) * 128 + ((c ^ (((r0 + 64) >> 1) & 7)) << 4);
+    const int lo3 = (r0 + 96) * 128 + ((c ^ (((r0 + 96) >> 1) & 7)) << 4);
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define GEMM_GLOAD(kt)                                                          \
+    {                                                                           \
+        const size_t ko = (size_t)(kt) * BK;                                    \
+        ra0 = *reinterpret_cast<const uint4*>(ap0 + ko);                        \
+        ra1 = *reinterpret_cast<const uint4*>(ap1 + ko);                        \
+        ra2 = *reinterpret_cast<const uint4*>(ap2 + ko);                        \
+        ra3 = *reinterpret_cast<const uint4*>(ap3 + ko);                        \
+        rb0 = *reinterpret_cast<const uint4*>(bp0 + ko);                        \
+        rb1 = *reinterpret_cast<const uint4*>(bp1 + ko);                        \
+        rb2 = *reinterpret_cast<const uint4*>(bp2 + ko);                        \
+        rb3 = *reinterpret_cast<const uint4*>(bp3 + ko);                        \
     }
-    uint4 ra[4], rb[4];
-    auto gload = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const uint4*>(aptr[i] + (size_t)kt * BK);
-            rb[i] = *reinterpret_cast<const uint4*>(bptr[i] + (size_t)kt * BK);
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<uint4*>(&lds[buf][0][lds_off[i]]) = ra[i];
-            *reinterpret_cast<uint4*>(&lds[buf][1][lds_off[i]]) = rb[i];
-        }
-    };
+#define GEMM_LSTORE(buf)                                                        \
+    {                                                                           \
+        *reinterpret_cast<uint4*>(&lds[buf][0][lo0]) = ra0;                     \
+        *reinterpret_cast<uint4*>(&lds[buf][0][lo1]) = ra1;                     \
+        *reinterpret_cast<uint4*>(&lds[buf][0][lo2]) = ra2;                     \
+        *reinterpret_cast<uint4*>(&lds[buf][0][lo3]) = ra3;                     \
+        *reinterpret_cast<uint4*>(&lds[buf][1][lo0]) = rb0;                     \
+        *reinterpret_cast<uint4*>(&lds[buf][1][lo1]) = rb1;                     \
+        *reinterpret_cast<uint4*>(&lds[buf][1][lo2]) = rb2;                     \
+        *reinterpret_cast<uint4*>(&lds[buf][1][lo3]) = rb3;                     \
+    }
 
     f32x16_t acc[2][2];
 #pragma unroll
@@ -188,13 +207,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
     }
 
     if (kt_begin < kt_end) {
-        gload(kt_begin);
-        lstore(0);
+        GEMM_GLOAD(kt_begin);
+        GEMM_LSTORE(0);
     }
     __syncthreads();
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int buf = (kt - kt_begin) & 1;
-        if (kt + 1 < kt_end) gload(kt + 1);
+        // phase 1: prefetch the next K tile into registers (unconditional: the last iteration re-loads its own tile,
+        // which keeps the loop body straight-line so the scheduler cannot sink the loads next to their ds_writes)
+        GEMM_GLOAD(kt + 1 < kt_end ? kt + 1 : kt);
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 2: MFMA on the current LDS buffer (global loads stay in flight underneath)
         const unsigned char* la = lds[buf][0];
         const unsigned char* lb = lds[buf][1];
 #pragma unroll
@@ -211,7 +234,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma32t<F16>(af[i], bfr[j], acc[i][j]);
         }
-        if (kt + 1 < kt_end) lstore(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 3: registers -> the other LDS buffer, one barrier per K tile
+        GEMM_LSTORE(buf ^ 1);
         __syncthreads();
     }
 
@@ -243,6 +268,7 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
 extern "C" int sed_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi,
                            const float* bias, const float* resF, float* outF, void* outH, void* outH2,
                            const void* auxH, int ldc, float alpha, int ksplit, int f16, hipStream_t stream) {
+    (void)hipGetLastError();
     GemmArgs g = {};
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ksplit = ksplit > 0 ? ksplit : 1;
@@ -263,6 +289,7 @@ extern "C" int sed_gemm_nt(const void* A, const void* B, int M, int N, int K, in
 extern "C" int sed_gemm_qkv(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq,
                             int seq_pad, void* q, void* k, void* v, void* qt, void* kt, void* vt, void* q2,
                             void* q2t, const float* pos_u, const float* pos_v, int f16, hipStream_t stream) {
+    (void)hipGetLastError();
     GemmArgs g = {};
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)W;
     g.M = M; g.N = 3 * heads * 64; g.K = K; g.lda = K; g.ldb = K; g.ldc = g.N; g.ksplit = 1; g.alpha = 1.f;
@@ -292,6 +319,7 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __res
 }
 
 extern "C" int sed_cast_f32_bf16(const float* in, void* out, int64_t n, int f16, hipStream_t stream) {
+    (void)hipGetLastError();
     if (n % 4) return SED_ERR_ARG;
     const size_t n4 = n / 4;
     int blocks = (int)((n4 + 255) / 256);
@@ -347,6 +375,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const void* __restrict__
 
 extern "C" int sed_transpose_to_bf16(const void* in, int in_kind, int R, int C, int ldin, void* outT, int Rpad,
                                      int outT_kind, void* outS, int outS_kind, float* colsum, hipStream_t stream) {
+    (void)hipGetLastError();
     if (Rpad < R || in_kind < 0 || in_kind > 2) return SED_ERR_ARG;
     dim3 grid(cdiv(C, 64), cdiv(Rpad, 64));
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, in, in_kind, R, C, ldin, (bf16_t*)outT, Rpad,
@@ -365,6 +394,7 @@ __global__ void f16_to_bf16_kernel(bf16_t* __restrict__ p, size_t n8) {
     }
 }
 extern "C" int sed_f16_to_bf16_inplace(void* p, int64_t n, hipStream_t stream) {
+    (void)hipGetLastError();
     if (n % 8) return SED_ERR_ARG;
     size_t n8 = n / 8;
     int blocks = (int)((n8 + 255) / 256);
@@ -393,6 +423,7 @@ __global__ void small_linear_kernel(const float* __restrict__ a, const float* __
 
 extern "C" int sed_small_linear(const float* a, const float* w, const float* b, float* out, int M, int N, int K,
                                 int act, hipStream_t stream) {
+    (void)hipGetLastError();
     const int64_t waves = (int64_t)M * N;
     hipLaunchKernelGGL(small_linear_kernel, dim3(cdiv(waves * 64, 256)), dim3(256), 0, stream, a, w, b, out, M, N,
                        K, act);

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 
 extern "C" int sed_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float in_scale,
                                  void* y_bf16, float* y_f32, float* mean, float* rstd, int M, int D, int f16, hipStream_t stream) {
+    (void)hipGetLastError();
     if (D != DM || M <= 0) return SED_ERR_ARG;
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, stream, x, gamma, beta, eps, in_scale,
                        (bf16_t*)y_bf16, y_f32, mean, rstd, M, f16);
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 extern "C" int sed_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                                  const float* gamma, float in_scale, float* dx, int accumulate, float* dgamma,
                                  float* dbeta, int M, int D, hipStream_t stream) {
+    (void)hipGetLastError();
     if (D != DM || M <= 0) return SED_ERR_ARG;
     int blocks = cdiv(M, 4);
     if (blocks > 1024) blocks = 1024;
@@ -156,6 +158,7 @@ __global__ void im2col_kernel(const float* __restrict__ mel, bf16_t* __restrict_
     }
 }
 extern "C" int sed_im2col(const float* mel, void* cols, int B, int T, int tstart, int tp, int f16, hipStream_t stream) {
+    (void)hipGetLastError();
     if (tp < 1 || tstart < 0 || tstart + 10 * (tp - 1) + 16 > T) return SED_ERR_ARG;
     hipLaunchKernelGGL(im2col_kernel, dim3(2048), dim3(256), 0, stream, mel, (bf16_t*)cols, B, T, tstart, tp, f16);
     return sed_check_launch();
@@ -187,6 +190,7 @@ __global__ void assemble_tokens_kernel(const float* __restrict__ conv, const flo
 extern "C" int sed_assemble_tokens(const float* conv, const float* cls, const float* dist, const float* new_pos,
                                    const float* freq_pe, const float* time_pe, int toffset, float* x, int B, int tp,
                                    hipStream_t stream) {
+    (void)hipGetLastError();
     if (tp < 1 || toffset < 0 || toffset + tp > 99) return SED_ERR_ARG;
     hipLaunchKernelGGL(assemble_tokens_kernel, dim3(2048), dim3(256), 0, stream, conv, cls, dist, new_pos, freq_pe,
                        time_pe, toffset, x, B, tp);
@@ -229,6 +233,7 @@ __global__ void assemble_tokens_bwd_kernel(const float* __restrict__ dx, bf16_t*
 }
 extern "C" int sed_assemble_tokens_bwd(const float* dx, void* dconv, float* dcls, float* ddist, float* dnew_pos,
                                        float* dfreq, float* dtime, int toffset, int B, int tp, hipStream_t stream) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(assemble_tokens_bwd_kernel, dim3(13 + tp, DM / 256), dim3(256), 0, stream, dx, (bf16_t*)dconv,
                        dcls, ddist, dnew_pos, dfreq, dtime, toffset, B, tp);
     return sed_check_launch();
@@ -272,6 +277,7 @@ __global__ __launch_bounds__(256) void fpool_fwd_kernel(const float* __restrict_
 }
 extern "C" int sed_fpool_fwd(const float* x, const float* gamma, const float* beta, float eps, float* pooled,
                              float* mean, float* rstd, int B, int tp, hipStream_t stream) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(fpool_fwd_kernel, dim3(cdiv(B * tp, 4)), dim3(256), 0, stream, x, gamma, beta, eps, pooled, mean,
                        rstd, B, tp);
     return sed_check_launch();
@@ -297,6 +303,7 @@ __global__ void fpool_expand_kernel(const float* __restrict__ dpooled, float* __
 extern "C" int sed_fpool_bwd(const float* dpooled, const float* x, const float* mean, const float* rstd,
                              const float* gamma, float* dtok_tmp, float* dx_acc, float* dgamma, float* dbeta, int B,
                              int tp, hipStream_t stream) {
+    (void)hipGetLastError();
     const int N = 2 + 12 * tp, M = B * N;
     hipLaunchKernelGGL(fpool_expand_kernel, dim3(2048), dim3(256), 0, stream, dpooled, dtok_tmp, B, tp);
     // rows 0,1 of every clip have dy = 0 (and mean/rstd never written there -> use finite placeholders: the host
@@ -340,6 +347,7 @@ __global__ void interp_fwd_kernel(const float* __restrict__ in, float* __restric
     }
 }
 extern "C" int sed_interp_fwd(const float* in, float* out, int B, int tin, int pad, int ratio, hipStream_t stream) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(interp_fwd_kernel, dim3(2048), dim3(256), 0, stream, in, out, B, tin, pad, ratio);
     return sed_check_launch();
 }
@@ -370,6 +378,7 @@ __global__ void interp_bwd_kernel(const float* __restrict__ dout, float* __restr
     }
 }
 extern "C" int sed_interp_bwd(const float* dout, float* din, int B, int tin, int pad, int ratio, hipStream_t stream) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(interp_bwd_kernel, dim3(1024), dim3(256), 0, stream, dout, din, B, tin, pad, ratio);
     return sed_check_launch();
 }
@@ -410,6 +419,7 @@ __global__ void window_mix_kernel(const float* __restrict__ pooled_win, const in
 }
 extern "C" int sed_window_mix(const float* pooled_win, const int* lefts, const int* tps, const int* offs, int nW,
                               float* x, float mix, int B, int T, int ratio, hipStream_t stream) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(window_mix_kernel, dim3(2048), dim3(256), 0, stream, pooled_win, lefts, tps, offs, nW, x, mix, B,
                        T, ratio);
     return sed_check_launch();
@@ -436,6 +446,7 @@ __global__ void mlm_apply_kernel(const float* __restrict__ x, const float* __res
 }
 extern "C" int sed_mlm_apply(const float* x, const float* mask_token, const uint8_t* action, const int* src_idx,
                              float* out, int rows, hipStream_t stream) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(mlm_apply_kernel, dim3(2048), dim3(256), 0, stream, x, mask_token, action, src_idx, out, rows);
     return sed_check_launch();
 }
@@ -457,6 +468,7 @@ __global__ void mlm_apply_bwd_kernel(const float* __restrict__ dout, const unsig
 }
 extern "C" int sed_mlm_apply_bwd(const float* dout, const uint8_t* action, const int* src_idx, float* dx_zeroed,
                                  float* dtoken, int rows, hipStream_t stream) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(mlm_apply_bwd_kernel, dim3(2048), dim3(256), 0, stream, dout, action, src_idx, dx_zeroed, dtoken,
                        rows);
     return sed_check_launch();
@@ -494,6 +506,7 @@ __global__ __launch_bounds__(256) void masked_mse_kernel(const float* __restrict
 }
 extern "C" int sed_masked_mse(const float* pred, const float* target, const uint8_t* mask, int n_masked_rows,
                               float* loss_zeroed, float* dpred, float* dtarget, int rows, hipStream_t stream) {
+    (void)hipGetLastError();
     if (n_masked_rows <= 0) return SED_ERR_ARG;
     const float inv_n = 1.0f / ((float)n_masked_rows * (float)DM);
     hipLaunchKernelGGL(masked_mse_kernel, dim3(512), dim3(256), 0, stream, pred, target, mask, inv_n, loss_zeroed, dpred,
@@ -550,6 +563,7 @@ __global__ __launch_bounds__(256) void weak_pool_kernel(const float* __restrict_
 }
 extern "C" int sed_head_fwd(const float* x, const float* W, const float* bias, float temp, const uint8_t* pad_mask,
                             float* strong, float* weak, float* sums, int B, int T, int C, hipStream_t stream) {
+    (void)hipGetLastError();
     if (C > NCLS_MAX) return SED_ERR_ARG;
     hipLaunchKernelGGL(sed_head_fwd_kernel, dim3(cdiv(B * T, 4)), dim3(256), 0, stream, x, W, bias, 1.0f / temp, pad_mask,
                        strong, B, T, C);
@@ -606,6 +620,7 @@ __global__ __launch_bounds__(256) void sed_head_bwd_kernel(const float* __restri
 extern "C" int sed_head_bwd(const float* x, const float* W, const float* strong, const float* sums,
                             const float* dstrong, const float* dweak, float temp, float* dx, float* dW, float* db,
                             int B, int T, int C, hipStream_t stream) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(sed_head_bwd_kernel, dim3(256), dim3(256), 0, stream, x, W, strong, sums, dstrong, dweak,
                        1.0f / temp, dx, dW, db, B, T, C);
     return sed_check_launch();
@@ -652,6 +667,7 @@ __global__ __launch_bounds__(256) void attnpool_fwd_kernel(const bf16_t* __restr
 }
 extern "C" int sed_attnpool_fwd(const void* kv, const float* q, float* out, float* probs, int B, int N, int H,
                                 int f16, hipStream_t stream) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(attnpool_fwd_kernel, dim3(B * H), dim3(256), (N - 2) * sizeof(float), stream, (const bf16_t*)kv, q,
                        out, probs, N, H, f16);
     return sed_check_launch();
@@ -699,56 +715,59 @@ __global__ __launch_bounds__(256) void attnpool_bwd_kernel(const bf16_t* __restr
 }
 extern "C" int sed_attnpool_bwd(const void* kv, const float* q, const float* probs, const float* dout, void* dkv,
                                 float* dq, int B, int N, int H, int f16, hipStream_t stream) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(attnpool_bwd_kernel, dim3(B * H), dim3(256), (N - 2) * sizeof(float), stream, (const bf16_t*)kv, q,
                        probs, dout, (bf16_t*)dkv, dq, N, H, f16);
     return sed_check_launch();
 }
 
 // small fp32 linear backward: out = act(a W^T + b);  given dout (w.r.t. the activated output when act == 1, with
-// `out` supplied), produce da [M, K] (=), dW [N, K] (+=), db [N] (+=).  One wave per (n) for dW/db, per (m) for da.
+// `out` supplied), produce da [M, K] (=), dW [N, K] (+=), db [N] (+=).  One thread per output element, coalesced over k.
+__device__ __forceinline__ float slb_g(const float* dout, const float* out, size_t i, int act) {
+    float g = dout[i];
+    if (act == 1) { const float o = out[i]; g *= o * (1.f - o); }
+    return g;
+}
 __global__ void small_linear_bwd_kernel(const float* __restrict__ a, const float* __restrict__ w,
                                         const float* __restrict__ out, const float* __restrict__ dout,
                                         float* __restrict__ da, float* __restrict__ dw, float* __restrict__ db, int M,
                                         int N, int K, int act) {
-    const int wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (wv < N) {
-        const int n = wv;
-        float bacc = 0.f;
-        for (int k = lane; k < K; k += 64) {
-            float acc = 0.f;
-            for (int m = 0; m < M; ++m) {
-                float g = dout[(size_t)m * N + n];
-                if (act == 1) { const float o = out[(size_t)m * N + n]; g *= o * (1.f - o); }
-                acc += g * a[(size_t)m * K + k];
-            }
-            if (dw != nullptr) dw[(size_t)n * K + k] += acc;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n_dw = (size_t)N * K, n_da = (size_t)M * K;
+    if (idx < n_dw) {
+        if (dw == nullptr) return;
+        const int n = (int)(idx / K), k = (int)(idx - (size_t)n * K);
+        float acc = 0.f;
+        for (int m = 0; m < M; ++m) acc += slb_g(dout, out, (size_t)m * N + n, act) * a[(size_t)m * K + k];
+        dw[idx] += acc;
+    } else if (idx < n_dw + n_da) {
+        if (da == nullptr) return;
+        const size_t j = idx - n_dw;
+        const int m = (int)(j / K), k = (int)(j - (size_t)m * K);
+        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+        int n = 0;
+        for (; n + 3 < N; n += 4) {
+            acc0 += slb_g(dout, out, (size_t)m * N + n, act) * w[(size_t)n * K + k];
+            acc1 += slb_g(dout, out, (size_t)m * N + n + 1, act) * w[(size_t)(n + 1) * K + k];
+            acc2 += slb_g(dout, out, (size_t)m * N + n + 2, act) * w[(size_t)(n + 2) * K + k];
+            acc3 += slb_g(dout, out, (size_t)m * N + n + 3, act) * w[(size_t)(n + 3) * K + k];
         }
-        if (lane == 0 && db != nullptr) {
-            for (int m = 0; m < M; ++m) {
-                float g = dout[(size_t)m * N + n];
-                if (act == 1) { const float o = out[(size_t)m * N + n]; g *= o * (1.f - o); }
-                bacc += g;
-            }
-            db[n] += bacc;
-        }
-    } else if (wv < N + M && da != nullptr) {
-        const int m = wv - N;
-        for (int k = lane; k < K; k += 64) {
-            float acc = 0.f;
-            for (int n = 0; n < N; ++n) {
-                float g = dout[(size_t)m * N + n];
-                if (act == 1) { const float o = out[(size_t)m * N + n]; g *= o * (1.f - o); }
-                acc += g * w[(size_t)n * K + k];
-            }
-            da[(size_t)m * K + k] = acc;
-        }
+        for (; n < N; ++n) acc0 += slb_g(dout, out, (size_t)m * N + n, act) * w[(size_t)n * K + k];
+        da[j] = (acc0 + acc1) + (acc2 + acc3);
+    } else if (idx < n_dw + n_da + N) {
+        if (db == nullptr) return;
+        const int n = (int)(idx - n_dw - n_da);
+        float acc = 0.f;
+        for (int m = 0; m < M; ++m) acc += slb_g(dout, out, (size_t)m * N + n, act);
+        db[n] += acc;
     }
 }
 extern "C" int sed_small_linear_bwd(const float* a, const float* w, const float* out, const float* dout, float* da,
                                     float* dw, float* db, int M, int N, int K, int act, hipStream_t stream) {
-    const int64_t waves = (int64_t)N + M;
-    hipLaunchKernelGGL(small_linear_bwd_kernel, dim3(cdiv(waves * 64, 256)), dim3(256), 0, stream, a, w, out, dout, da,
-                       dw, db, M, N, K, act);
+    (void)hipGetLastError();
+    const int64_t total = (int64_t)N * K + (int64_t)M * K + N;
+    hipLaunchKernelGGL(small_linear_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a, w, out, dout, da, dw, db,
+                       M, N, K, act);
     return sed_check_launch();
 }
 
@@ -790,6 +809,7 @@ __global__ void adamw_ema_kernel(float* __restrict__ p, const float* __restrict_
 extern "C" int sed_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr, float wd,
                              float beta1, float beta2, float eps, int step, float ema_alpha, int do_adam,
                              hipStream_t stream) {
+    (void)hipGetLastError();
     if (n % 4) return SED_ERR_ARG;
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     size_t n4 = n / 4;

@@ -105,6 +105,8 @@ __global__ __launch_bounds__(256) void relpos_fwd_kernel(const bf16_t* __restric
     tile_lstore_rows(rk, lds_kv[0][0], tid);
     tile_lstore_cols(rv, lds_kv[0][1], tid);
     band_lstore(rb, lds_band[0], tid);
+    pin_frags(quf);
+    pin_frags(qvf);
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(256) void relpos_fwd_kernel(const bf16_t* __restric
 extern "C" int sed_relpos_attn_fwd(const void* Qu, const void* Qv, const void* K, const void* Vt, const void* P,
                                    void* O, float* LSE, int B, int H, int T, int Tpad, int Rpad, int f16,
                                    hipStream_t stream) {
+    (void)hipGetLastError();
     if (T <= 0 || (T % 8) || Tpad % 64 || Tpad < T || Rpad % 64 || Rpad < 2 * T - 1) return SED_ERR_ARG;
     dim3 grid(cdiv(T, 128), B * H);
     if (f16) hipLaunchKernelGGL(relpos_fwd_kernel<true>, grid, dim3(256), 0, stream, (const bf16_t*)Qu, (const bf16_t*)Qv,
@@ -570,6 +573,7 @@ extern "C" int sed_relpos_attn_bwd(const void* Qu, const void* Qut, const void* 
                                    const void* dO, const float* LSE, float* Dtmp, void* dOh, void* dOt, void* dqkv,
                                    void* dSt, float* dP, float* du, float* dv, int B, int H, int T, int Tpad,
                                    int Rpad, int need_param_grads, int f16, hipStream_t stream) {
+    (void)hipGetLastError();
     // f16 != 0: Qu, Qv, K, P (score recompute) and O are IEEE half; Qut, Qvt, Kt, V, Pt, dO are bf16.
     if (T <= 0 || (T % 8) || Tpad % 64 || Tpad < T || Rpad % 64 || Rpad < 2 * T - 1) return SED_ERR_ARG;
     int rc = sed_mhsa_bwd_prep(dO, O, Dtmp, dOh, dOt, B, H, T, Tpad, f16, stream);
