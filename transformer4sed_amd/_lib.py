@@ -43,6 +43,9 @@ class _Lib:
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `python -m transformer4sed_amd.build` "
                 "(the MAT-SED hot path has no non-HIP fallback)")
+        # torch must initialise ITS HIP runtime first: loading libsed_hip.so before torch pulls in a second copy of
+        # libamdhip64 (system ROCm vs the one bundled with torch) and every launch then fails with hipErrorNoDevice.
+        import torch  # noqa: F401
         self._dll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
         for name, args in self.protos.items():
