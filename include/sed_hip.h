@@ -40,7 +40,7 @@ int sed_median_filter(const float* in, float* out, const int* sizes, const float
 /* ------------------------------------------------------------------ GEMM family (nn.Linear / conv / autograd GEMMs) */
 /* C[M,N] = A[M,K] . B[N,K]^T, bf16 operands, fp32 accumulate, fused epilogue `epi`:
  * 0 outF=acc*alpha+bias | 1 outF=resF+acc+bias (resF may alias outF) | 2 outH=bf16(acc+bias) | 3 outH=h, outH2=gelu(h) | 4 outH=acc*gelu'(auxH)
- * 5 atomicAdd(outF, acc*alpha) (split-K) | 7 outF and outH.  Replaces F.linear at src/models/passt/passt.py:271,274,
+ * 5 atomicAdd(outF, acc*alpha) (split-K) | 7 outF and outH | 8 outH=h, outF=gelu(h) fp32.  Replaces F.linear at src/models/passt/passt.py:271,274,
  * 332,342; src/models/transformer/transformerXL.py:382,493,584; src/models/passt/passt_sed.py:196; conv2d passt.py:307 */
 int sed_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi, const float* bias,
                 const float* resF, float* outF, void* outH, void* outH2, const void* auxH, int ldc, float alpha,
@@ -52,6 +52,8 @@ int sed_gemm_qkv(const void* A, const void* W, const float* bias, int M, int K, 
                  const float* pos_v, int f16, hipStream_t stream);
 int sed_cast_f32_bf16(const float* in, void* out, int64_t n, int f16, hipStream_t stream);
 int sed_f16_to_bf16_inplace(void* p, int64_t n, hipStream_t stream);
+/* split-precision operand image: fp32 [M,K] -> f16 [M,3K]; mode 0 [hi|lo|hi] (activations), 1 [hi|hi|lo] (weights) */
+int sed_split3_f16(const float* in, void* out, int64_t M, int K, int mode, hipStream_t stream);
 /* in [R,C] -> outT [C,Rpad] (zero padded; nullable), optional straight 16-bit copy and fp32 column sums (+=).
  * kinds: 0 bf16, 1 f32 (input only), 2 f16 */
 int sed_transpose_to_bf16(const void* in, int in_kind, int R, int C, int ldin, void* outT, int Rpad, int outT_kind,
@@ -75,11 +77,11 @@ int sed_mhsa_bwd(const void* Q, const void* Qt, const void* K, const void* Kt, c
                  int Npad, int f16, hipStream_t stream);
 /* Transformer-XL rel-pos attention (src/models/transformer/transformerXL.py:493-576 incl. rel_shift 254-297) */
 int sed_relpos_attn_fwd(const void* Qu, const void* Qv, const void* K, const void* Vt, const void* P, void* O,
-                        float* LSE, int B, int H, int T, int Tpad, int Rpad, int f16, hipStream_t stream);
+                        float* LSE, int B, int H, int T, int Tpad, int Rpad, int f16, int o_f32, hipStream_t stream);
 int sed_relpos_attn_bwd(const void* Qu, const void* Qut, const void* Qv, const void* Qvt, const void* K, const void* Kt,
                         const void* V, const void* P, const void* Pt, const void* O, const void* dO, const float* LSE,
                         float* Dtmp, void* dOh, void* dOt, void* dqkv, void* dSt, float* dP, float* du, float* dv, int B,
-                        int H, int T, int Tpad, int Rpad, int need_param_grads, int f16, hipStream_t stream);
+                        int H, int T, int Tpad, int Rpad, int need_param_grads, int f16, int o_kind, hipStream_t stream);
 
 /* ------------------------------------------------------------------ norms / glue / heads / optimiser */
 /* nn.LayerNorm over D=768 (passt.py:361-362,580; passt_sed.py:128; timm Block norms); y = LN(in_scale*x) */

@@ -78,6 +78,28 @@ def test_gemm_epilogues(M, N, K, DT):
     e = maxerr(acc, ref); report(f"gemm atomic split-K {M}x{N}x{K}", e); assert e < tol
 
 
+def test_split_precision_gemm():
+    """[A_hi|A_lo|A_hi] . [W_hi|W_hi|W_lo]^T through the ordinary f16 GEMM ~ fp32 product (context-network path)."""
+    from transformer4sed_amd.ops import split3
+    M, N, K = 1000, 768, 768
+    A, W = rnd(M, K, seed=21), rnd(N, K, scale=0.05, seed=22)
+    bias = rnd(N, seed=23)
+    As, Ws = split3(A, M, K), split3(W, N, K, weight=True)
+    hi = A.to(F16)
+    assert torch.equal(As[:, :K], hi) and torch.equal(As[:, 2 * K:], hi) and torch.equal(As[:, K:2 * K], (A - hi.float()).to(F16))
+    assert torch.equal(Ws[:, :K], W.to(F16)) and torch.equal(Ws[:, K:2 * K], W.to(F16))
+    out = torch.empty(M, N, device=DEV)
+    gemm_nt(As, Ws, ops.EPI_F32, bias=bias, outF=out)
+    ref = (A.double() @ W.double().t() + bias.double()).float()
+    e = maxerr(out, ref); report("split-precision gemm", e, float(ref.abs().max())); assert e < 2e-5
+    single = torch.empty(M, N, device=DEV)
+    gemm_nt(A.to(F16), W.to(F16), ops.EPI_F32, bias=bias, outF=single)
+    assert maxerr(single, ref) > 20 * e  # the point of the exercise
+    h16 = torch.empty(M, N, dtype=F16, device=DEV); act = torch.empty(M, N, device=DEV)
+    gemm_nt(As, Ws, ops.EPI_GELU32, bias=bias, outH=h16, outF=act)
+    assert maxerr(act, torch.nn.functional.gelu(ref)) < 5e-5 and maxerr(h16.float(), ref) < 2e-3 * float(ref.abs().max())
+
+
 def test_gemm_asymmetric_identity():
     """A = I with an asymmetric B catches transposed C writes (guide rule 16)."""
     K = 128
@@ -209,7 +231,10 @@ def test_relpos_fwd_bwd(B, T, DT):
     Pt = torch.zeros(Hh, 64, Rpad, dtype=BF16, device=DEV); Pt[:, :, :R] = P.to(BF16).transpose(1, 2)
     O = torch.empty(B, T, 768, dtype=DT, device=DEV)
     lse = torch.empty(B * Hh, T, device=DEV)
-    call("sed_relpos_attn_fwd", qu.to(DT), qv.to(DT), k.to(DT), vt, Pp, O, lse, B, Hh, T, Tpad, Rpad, f16)
+    call("sed_relpos_attn_fwd", qu.to(DT), qv.to(DT), k.to(DT), vt, Pp, O, lse, B, Hh, T, Tpad, Rpad, f16, 0)
+    O32 = torch.empty(B, T, 768, device=DEV)
+    call("sed_relpos_attn_fwd", qu.to(DT), qv.to(DT), k.to(DT), vt, Pp, O32, None, B, Hh, T, Tpad, Rpad, f16, 1)
+    assert maxerr(O32.to(DT).float(), O.float()) == 0
     leaves = [t.clone().requires_grad_(True) for t in (qu, qv, k, v, P)]
     o, s = _relpos_ref(*leaves, T)
     oref = o.view(B, Hh, T, 64).permute(0, 2, 1, 3).reshape(B, T, 768)
@@ -225,7 +250,7 @@ def test_relpos_fwd_bwd(B, T, DT):
     dP = torch.zeros(Rpad, 768, device=DEV)
     du = torch.zeros(Hh, 64, device=DEV); dv = torch.zeros(Hh, 64, device=DEV)
     call("sed_relpos_attn_bwd", qu.to(DT), qut, qv.to(DT), qvt, k.to(DT), kt, v.to(BF16), Pp, Pt, O, dO.to(BF16),
-         lse, Dt, dOh, dOt, dqkv, dSt, dP, du, dv, B, Hh, T, Tpad, Rpad, 1, f16)
+         lse, Dt, dOh, dOt, dqkv, dSt, dP, du, dv, B, Hh, T, Tpad, Rpad, 1, f16, f16)
     g = dqkv.float().view(B, T, 3, Hh, 64).permute(2, 0, 3, 1, 4).reshape(3, B * Hh, T, 64)
     dq_ref = leaves[0].grad + leaves[1].grad
     for got, ref, nm in ((g[0], dq_ref, "dq"), (g[1], leaves[2].grad, "dk"), (g[2], leaves[3].grad, "dv")):

@@ -154,7 +154,7 @@ extern "C" int sed_mhsa_fwd(const void* Q, const void* K, const void* Vt, void* 
 // backward pre-pass: D[bh, q] = sum_d dO * O ; head-split copies dOh [BH, N, 64] and dOt [BH, 64, Npad]
 // one wave per (b, q, h-pair): 64 lanes x 2 elements = 128 channels = 2 heads
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mhsa_bwd_prep_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O,
+__global__ __launch_bounds__(256) void mhsa_bwd_prep_kernel(const bf16_t* __restrict__ dO, const void* __restrict__ O,
                                                             float* __restrict__ Dv, bf16_t* __restrict__ dOh,
                                                             bf16_t* __restrict__ dOt, int B, int N, int Npad, int H,
                                                             int o_f16) {
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_prep_kernel(const bf16_t* __rest
         if (t < N) {
             const size_t idx = ((size_t)b * N + t) * (H * HD) + h * HD + tx;
             g = dO[idx];
-            prod = bf2f(g) * (o_f16 ? h2f(O[idx]) : bf2f(O[idx]));
+            prod = bf2f(g) * (o_f16 == 2 ? ((const float*)O)[idx] : (o_f16 ? h2f(((const bf16_t*)O)[idx]) : bf2f(((const bf16_t*)O)[idx])));
             dOh[((size_t)bh * N + t) * HD + tx] = g;
         }
         tile[ty * 16 + i][tx] = g;
@@ -402,7 +402,7 @@ extern "C" int sed_mhsa_bwd_prep(const void* dO, const void* O, float* Dtmp, voi
     (void)hipGetLastError();
     if (N <= 0 || Npad % 64 || Npad < N) return SED_ERR_ARG;
     hipLaunchKernelGGL(mhsa_bwd_prep_kernel, dim3(Npad / 64, B * H), dim3(256), 0, stream, (const bf16_t*)dO,
-                       (const bf16_t*)O, Dtmp, (bf16_t*)dOh, (bf16_t*)dOt, B, N, Npad, H, o_f16);
+                       O, Dtmp, (bf16_t*)dOh, (bf16_t*)dOt, B, N, Npad, H, o_f16);
     return sed_check_launch();
 }
 

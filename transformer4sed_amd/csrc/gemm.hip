@@ -25,6 +25,7 @@ enum {
     EPI_ATOMIC = 5,       // atomicAdd(outF, acc*alpha)               (split-K weight gradients)
     EPI_QKV = 6,          // head-split q/k/v (+ transposed copies, + rel-pos biased queries)
     EPI_F32_BF16 = 7,     // outF = acc + bias and outH = bf16(same)
+    EPI_GELU32 = 8,       // outH = 16-bit(h = acc + bias) (kept for backward), outF = fp32 gelu(h) (split-precision consumers)
 };
 
 struct GemmArgs {
@@ -124,6 +125,10 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs& g, int m_base, int
         } else if (EPI == EPI_F32_BF16) {
             g.outF[o] = acc + b;
             g.outH[o] = to_16<F16>(acc + b);
+        } else if (EPI == EPI_GELU32) {
+            const float h = acc + b;
+            g.outH[o] = to_16<F16>(h);
+            g.outF[o] = gelu_erf(h);
         }
     }
 }
@@ -282,6 +287,7 @@ extern "C" int sed_gemm_nt(const void* A, const void* B, int M, int N, int K, in
         case EPI_DGELU: return launch_gemm<EPI_DGELU>(g, f16, stream);
         case EPI_ATOMIC: return launch_gemm<EPI_ATOMIC>(g, f16, stream);
         case EPI_F32_BF16: return launch_gemm<EPI_F32_BF16>(g, f16, stream);
+        case EPI_GELU32: return launch_gemm<EPI_GELU32>(g, f16, stream);
         default: return SED_ERR_ARG;
     }
 }
@@ -380,6 +386,35 @@ extern "C" int sed_transpose_to_bf16(const void* in, int in_kind, int R, int C, 
     dim3 grid(cdiv(C, 64), cdiv(Rpad, 64));
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, in, in_kind, R, C, ldin, (bf16_t*)outT, Rpad,
                        outT_kind, (bf16_t*)outS, outS_kind, colsum);
+    return sed_check_launch();
+}
+
+// Split-precision operand images (f16 hi + f16 lo carries ~22 significand bits): a GEMM over the concatenated reduction
+// dimension [A_hi | A_lo | A_hi] . [W_hi | W_hi | W_lo]^T accumulates A_hi W_hi + A_lo W_hi + A_hi W_lo in fp32 inside the
+// ordinary MFMA kernel.  Used for the context-network GEMMs, whose operand rounding dominates the posterior error.
+// in fp32 [M, K] -> out f16 [M, 3K]; mode 0: [hi | lo | hi] (activations), mode 1: [hi | hi | lo] (weights)
+__global__ void split3_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t M, int K, int mode) {
+    const size_t total = M * (size_t)(K / 2);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = idx / (K / 2);
+        const int k = (int)(idx - m * (K / 2)) * 2;
+        const float2 v = *reinterpret_cast<const float2*>(in + m * K + k);
+        const bf16_t h0 = f2h(v.x), h1 = f2h(v.y);
+        const bf16_t l0 = f2h(v.x - h2f(h0)), l1 = f2h(v.y - h2f(h1));
+        const unsigned hi = (unsigned)h0 | ((unsigned)h1 << 16), lo = (unsigned)l0 | ((unsigned)l1 << 16);
+        unsigned* row = reinterpret_cast<unsigned*>(out + m * (size_t)(3 * K));
+        row[k / 2] = hi;
+        row[(K + k) / 2] = mode == 0 ? lo : hi;
+        row[(2 * K + k) / 2] = mode == 0 ? hi : lo;
+    }
+}
+extern "C" int sed_split3_f16(const float* in, void* out, int64_t M, int K, int mode, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (K % 2 || M <= 0) return SED_ERR_ARG;
+    size_t total = (size_t)M * (K / 2);
+    int blocks = (int)((total + 255) / 256);
+    blocks = blocks > 4096 ? 4096 : blocks;
+    hipLaunchKernelGGL(split3_kernel, dim3(blocks), dim3(256), 0, stream, in, (bf16_t*)out, (size_t)M, K, mode);
     return sed_check_launch();
 }
 

@@ -63,7 +63,7 @@ __device__ __forceinline__ void bandT_stage(const bf16_t* Pth, int CB, int Rpad,
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
-template <bool F16>
+template <bool F16, bool O32>
 __global__ __launch_bounds__(256) void relpos_fwd_kernel(const bf16_t* __restrict__ Qu, const bf16_t* __restrict__ Qv,
                                                          const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
                                                          const bf16_t* __restrict__ P, bf16_t* __restrict__ O,
@@ -188,30 +188,44 @@ __global__ __launch_bounds__(256) void relpos_fwd_kernel(const bf16_t* __restric
     const int q = q0 + lr;
     if (q < T) {
         const float inv = 1.0f / l_run;
-        bf16_t* orow = O + ((size_t)b * T + q) * (H * HD) + h * HD;
+        if (O32) {
+            float* orow = reinterpret_cast<float*>(O) + ((size_t)b * T + q) * (H * HD) + h * HD;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                uint2 pk;
-                pk.x = pack2<F16>(o[db][4 * qd] * inv, o[db][4 * qd + 1] * inv);
-                pk.y = pack2<F16>(o[db][4 * qd + 2] * inv, o[db][4 * qd + 3] * inv);
-                *reinterpret_cast<uint2*>(orow + 32 * db + 8 * qd + 4 * lg) = pk;
-            }
+                for (int qd = 0; qd < 4; ++qd)
+                    *reinterpret_cast<float4*>(orow + 32 * db + 8 * qd + 4 * lg) =
+                        make_float4(o[db][4 * qd] * inv, o[db][4 * qd + 1] * inv, o[db][4 * qd + 2] * inv, o[db][4 * qd + 3] * inv);
+        } else {
+            bf16_t* orow = O + ((size_t)b * T + q) * (H * HD) + h * HD;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    uint2 pk;
+                    pk.x = pack2<F16>(o[db][4 * qd] * inv, o[db][4 * qd + 1] * inv);
+                    pk.y = pack2<F16>(o[db][4 * qd + 2] * inv, o[db][4 * qd + 3] * inv);
+                    *reinterpret_cast<uint2*>(orow + 32 * db + 8 * qd + 4 * lg) = pk;
+                }
+        }
         if (lg == 0 && LSE != nullptr) LSE[(size_t)bh * T + q] = m_run + log2f(l_run);
     }
 }
 
 extern "C" int sed_relpos_attn_fwd(const void* Qu, const void* Qv, const void* K, const void* Vt, const void* P,
-                                   void* O, float* LSE, int B, int H, int T, int Tpad, int Rpad, int f16,
+                                   void* O, float* LSE, int B, int H, int T, int Tpad, int Rpad, int f16, int o_f32,
                                    hipStream_t stream) {
     (void)hipGetLastError();
     if (T <= 0 || (T % 8) || Tpad % 64 || Tpad < T || Rpad % 64 || Rpad < 2 * T - 1) return SED_ERR_ARG;
     dim3 grid(cdiv(T, 128), B * H);
-    if (f16) hipLaunchKernelGGL(relpos_fwd_kernel<true>, grid, dim3(256), 0, stream, (const bf16_t*)Qu, (const bf16_t*)Qv,
-                                (const bf16_t*)K, (const bf16_t*)Vt, (const bf16_t*)P, (bf16_t*)O, LSE, T, Tpad, H, Rpad);
-    else hipLaunchKernelGGL(relpos_fwd_kernel<false>, grid, dim3(256), 0, stream, (const bf16_t*)Qu, (const bf16_t*)Qv,
-                       (const bf16_t*)K, (const bf16_t*)Vt, (const bf16_t*)P, (bf16_t*)O, LSE, T, Tpad, H, Rpad);
+#define SED_RP_FWD(F, O32)                                                                                            \
+    hipLaunchKernelGGL((relpos_fwd_kernel<F, O32>), grid, dim3(256), 0, stream, (const bf16_t*)Qu, (const bf16_t*)Qv, \
+                       (const bf16_t*)K, (const bf16_t*)Vt, (const bf16_t*)P, (bf16_t*)O, LSE, T, Tpad, H, Rpad)
+    if (f16 && o_f32) SED_RP_FWD(true, true);
+    else if (f16) SED_RP_FWD(true, false);
+    else if (o_f32) SED_RP_FWD(false, true);
+    else SED_RP_FWD(false, false);
+#undef SED_RP_FWD
     return sed_check_launch();
 }
 
@@ -572,11 +586,12 @@ extern "C" int sed_relpos_attn_bwd(const void* Qu, const void* Qut, const void* 
                                    const void* Kt, const void* V, const void* P, const void* Pt, const void* O,
                                    const void* dO, const float* LSE, float* Dtmp, void* dOh, void* dOt, void* dqkv,
                                    void* dSt, float* dP, float* du, float* dv, int B, int H, int T, int Tpad,
-                                   int Rpad, int need_param_grads, int f16, hipStream_t stream) {
+                                   int Rpad, int need_param_grads, int f16, int o_kind, hipStream_t stream) {
     (void)hipGetLastError();
-    // f16 != 0: Qu, Qv, K, P (score recompute) and O are IEEE half; Qut, Qvt, Kt, V, Pt, dO are bf16.
+    // f16 != 0: Qu, Qv, K, P (score recompute) are IEEE half; Qut, Qvt, Kt, V, Pt, dO are bf16.
+    // o_kind: storage type of O (0 bf16, 1 f16, 2 f32).
     if (T <= 0 || (T % 8) || Tpad % 64 || Tpad < T || Rpad % 64 || Rpad < 2 * T - 1) return SED_ERR_ARG;
-    int rc = sed_mhsa_bwd_prep(dO, O, Dtmp, dOh, dOt, B, H, T, Tpad, f16, stream);
+    int rc = sed_mhsa_bwd_prep(dO, O, Dtmp, dOh, dOt, B, H, T, Tpad, o_kind, stream);
     if (rc) return rc;
     dim3 grid(cdiv(T, 128), B * H);
 #define SED_LAUNCH_RP(F)                                                                                               \

@@ -17,7 +17,7 @@ def kind(t):
 def is_f16(t):
     return 1 if t.dtype == F16 else 0
 
-EPI_F32, EPI_F32_RESID, EPI_BF16, EPI_GELU, EPI_DGELU, EPI_ATOMIC, EPI_QKV, EPI_F32_BF16 = range(8)
+EPI_F32, EPI_F32_RESID, EPI_BF16, EPI_GELU, EPI_DGELU, EPI_ATOMIC, EPI_QKV, EPI_F32_BF16, EPI_GELU32 = range(9)
 
 
 def _ptr(t):
@@ -111,3 +111,16 @@ def to_bf16_(t):
         return t
     call("sed_f16_to_bf16_inplace", t, t.numel())
     return t.view(BF16)
+
+
+def split3(x32, rows, cols, weight=False):
+    """fp32 [rows, cols] -> f16 [rows, 3 cols] split-precision operand image: [hi|lo|hi] (activations) or [hi|hi|lo]
+    (weights); a GEMM over the concatenated K accumulates hi*hi + lo*hi + hi*lo in fp32."""
+    out = torch.empty(rows, 3 * cols, dtype=F16, device=x32.device)
+    call("sed_split3_f16", x32, out, rows, cols, 1 if weight else 0)
+    return out
+
+
+def o_kind(t):
+    """storage code of an attention output for the backward pre-pass: 0 bf16, 1 f16, 2 f32."""
+    return {BF16: 0, F16: 1, F32: 2}[t.dtype]
