@@ -182,7 +182,8 @@ class SedEngine:
                     outF=x_mid)
             call("sed_layernorm_fwd", x_mid, self.P(p + "norm2.weight"), self.P(p + "norm2.bias"), 1e-6, 1.0, h2, None,
                  mean2, rstd2, M, D, f16)
-            gemm_nt(h2, W[p + "mlp.fc1.weight"].w, EPI_GELU, bias=self.P(p + "mlp.fc1.bias"), outH=hpre, outH2=act)
+            gemm_nt(h2, W[p + "mlp.fc1.weight"].w, EPI_GELU, bias=self.P(p + "mlp.fc1.bias"), outH=hpre if save else None,
+                    outH2=act)
             x_out = E(Bx, N, D) if save else x_mid
             gemm_nt(act, W[p + "mlp.fc2.weight"].w, EPI_F32_RESID, bias=self.P(p + "mlp.fc2.bias"), res=x_mid,
                     outF=x_out)

@@ -79,7 +79,7 @@ def gemm_nt(A, B, epi, M=None, bias=None, res=None, outF=None, outH=None, outH2=
     """C[M,N] = A[M,K] . B[N,K]^T (bf16 operands) with fused epilogue; see include/sed_hip.h."""
     M = A.shape[0] if M is None else M
     N, K = B.shape[0], B.shape[1]
-    if A.dtype != B.dtype or any(t is not None and t.dtype != A.dtype for t in (outH, outH2, aux)):
+    if A.dtype != B.dtype or any(t is not None and t.dtype != A.dtype for t in (outH, outH2, aux)):  # noqa: E501
         raise RuntimeError("gemm_nt: all 16-bit operands/outputs of one GEMM must share one type (f16 or bf16)")
     call("sed_gemm_nt", A, B, M, N, K, lda or A.shape[1], ldb or K, epi, bias, res, outF, outH, outH2, aux, ldc or N,
          float(alpha), ksplit, is_f16(A))
