@@ -418,6 +418,276 @@ __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(const GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// v3: 256 x 256 x 64 workgroup tile, 8 waves (2 x 4), 128 x 64 per wave (4 x 2 MFMA 32x32x16 blocks, 128 accumulator
+// registers), two 64-KiB LDS stages filled by direct-to-LDS DMA one K tile ahead.
+// Why (tools/ablate, MI355X): with 64x64 per-wave tiles the LDS is the shared bottleneck -- DMA fills and fragment reads
+// together take as long as the MFMAs (MFMA-only 1571 TFLOP/s, DMA-only about the same, combined ~900).  This geometry
+// needs 27 % fewer LDS read bytes and 50 % fewer LDS write bytes per FLOP and 6 ds_read_b128 per 8 MFMAs, and one K tile
+// of MFMA work per wave pair (~2k cycles) covers the DMA latency.
+// ---------------------------------------------------------------------------------------------------------------------
+// ---- v3 staged epilogue ------------------------------------------------------------------------------------------------
+// After the K loop each wave owns a private 17 KiB LDS region.  The accumulators (C^T layout: lane = row, register quad = 4
+// columns) are written there as a row-major [rows][64] sub-tile (padded row stride: conflict-free), then read back so that
+// 8 (16-bit) or 16 (fp32) consecutive lanes cover one full output row: every global store / residual load is a run of whole
+// 128- / 256-byte rows instead of 64 different cache lines per instruction.
+#define V3_WLDS 17408          // per-wave bytes: 128 rows x 136 B (16-bit) or 64 rows x 264 B (fp32, two passes)
+#define V3_RS16 136
+#define V3_RS32 264
+
+template <bool F16>
+__device__ __forceinline__ void v3_stage16(unsigned char* wl, const f32x16_t (&acc)[4][2], const float* bias_n, int lr, int lg,
+                                           int mode, const float* extra) {
+    // mode 0: acc + bias (+ extra[col])   1: gelu_fast(acc + bias)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = j * 32 + 8 * q + 4 * lg;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[i][j][4 * q + e] + (bias_n != nullptr ? bias_n[col + e] : 0.f);
+                    if (extra != nullptr) x += extra[col + e];
+                    v[e] = mode == 1 ? gelu_fast(x) : x;
+                }
+                uint2 pk;
+                pk.x = pack2<F16>(v[0], v[1]);
+                pk.y = pack2<F16>(v[2], v[3]);
+                *reinterpret_cast<uint2*>(wl + (i * 32 + lr) * V3_RS16 + col * 2) = pk;
+            }
+}
+// 64 staged rows (accumulator blocks i0, i0 + 1) as fp32
+__device__ __forceinline__ void v3_stage32(unsigned char* wl, const f32x16_t (&acc)[4][2], int i0, int lr, int lg) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = j * 32 + 8 * q + 4 * lg;
+                const f32x16_t& a = acc[i0 + ii][j];
+                *reinterpret_cast<float4*>(wl + (ii * 32 + lr) * V3_RS32 + col * 4) =
+                    make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+            }
+}
+
+template <int EPI, bool F16>
+__device__ __forceinline__ void v3_epilogue(const GemmArgs& g, const f32x16_t (&acc)[4][2], unsigned char* wl, int mb, int nb,
+                                            int lane) {
+    // mb = first row of this wave's 128 x 64 sub-tile, nb = its first column
+    const int lr = lane & 31, lg = lane >> 5;
+    const float* bias_n = g.bias != nullptr ? g.bias + nb : nullptr;
+    if (EPI == EPI_BF16 || EPI == EPI_GELU) {
+        const int npass = EPI == EPI_GELU ? 2 : 1;
+        for (int pass = 0; pass < npass; ++pass) {
+            bf16_t* out = (EPI == EPI_GELU && pass == 1) ? g.outH2 : g.outH;
+            if (out == nullptr) continue;
+            v3_stage16<F16>(wl, acc, bias_n, lr, lg, (EPI == EPI_GELU && pass == 1) ? 1 : 0, nullptr);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+            for (int rr = 0; rr < 16; ++rr) {
+                const int row = rr * 8 + (lane >> 3), c16 = lane & 7;
+                const uint4 v = *reinterpret_cast<const uint4*>(wl + row * V3_RS16 + c16 * 16);
+                if (mb + row < g.M) *reinterpret_cast<uint4*>(out + (size_t)(mb + row) * g.ldc + nb + c16 * 8) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+    if (EPI == EPI_QKV) {
+        const int D = g.heads * 64;
+        const int which = nb / D, h = (nb - which * D) >> 6;
+        bf16_t* row_dst = which == 0 ? g.q : (which == 1 ? g.k : g.v);
+        bf16_t* tr_dst = which == 0 ? g.qt : (which == 1 ? g.kt : g.vt);
+        const int npass = (which == 0 && g.q2 != nullptr) ? 2 : 1;
+        for (int pass = 0; pass < npass; ++pass) {
+            const float* extra = nullptr;
+            if (which == 0 && g.pu != nullptr) extra = (pass == 0 ? g.pu : g.pv) + h * 64;
+            bf16_t* rd = pass == 0 ? row_dst : g.q2;
+            bf16_t* td = pass == 0 ? tr_dst : g.q2t;
+            v3_stage16<F16>(wl, acc, bias_n, lr, lg, 0, extra);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+            for (int rr = 0; rr < 16; ++rr) {
+                const int row = rr * 8 + (lane >> 3), c16 = lane & 7;
+                const int m = mb + row;
+                if (m < g.M) {
+                    const int bidx = m / g.seq, t = m - bidx * g.seq;
+                    const uint4 v = *reinterpret_cast<const uint4*>(wl + row * V3_RS16 + c16 * 16);
+                    *reinterpret_cast<uint4*>(rd + ((size_t)(bidx * g.heads + h) * g.seq + t) * 64 + c16 * 8) = v;
+                }
+            }
+            if (td != nullptr) {
+                // transposed copy [bh][d][seq_pad]: lane -> row (token), loop over the 64 d columns: 64 consecutive tokens per
+                // store instruction (contiguous unless the run crosses a clip boundary)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int row = half * 64 + lane, m = mb + row;
+                    if (m < g.M) {
+                        const int bidx = m / g.seq, t = m - bidx * g.seq;
+                        bf16_t* base = td + (size_t)(bidx * g.heads + h) * 64 * g.seq_pad + t;
+                        const unsigned short* src = reinterpret_cast<const unsigned short*>(wl + row * V3_RS16);
+#pragma unroll 8
+                        for (int d = 0; d < 64; ++d) base[(size_t)d * g.seq_pad] = src[d];
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+    if (EPI == EPI_ATOMIC) {  // split-K weight gradients: small outputs, direct atomics
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mb + i * 32 + lr;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = nb + j * 32 + 8 * q + 4 * lg;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(&g.outF[(size_t)m * g.ldc + n + e], acc[i][j][4 * q + e] * g.alpha);
+                }
+        }
+        return;
+    }
+    // fp32-staged epilogues (two passes of 64 rows): EPI_F32, EPI_F32_RESID, EPI_F32_BF16, EPI_GELU32, EPI_DGELU
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        v3_stage32(wl, acc, 2 * pass, lr, lg);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = rr * 4 + (lane >> 4), c4 = lane & 15;  // 16 lanes x 16 B = one 256-B fp32 row
+            const int m = mb + pass * 64 + row;
+            if (m >= g.M) continue;
+            float4 v = *reinterpret_cast<const float4*>(wl + row * V3_RS32 + c4 * 16);
+            const int n = nb + c4 * 4;
+            const size_t o = (size_t)m * g.ldc + n;
+            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g.bias != nullptr) b = *reinterpret_cast<const float4*>(g.bias + n);
+            if (EPI == EPI_F32) {
+                *reinterpret_cast<float4*>(g.outF + o) = make_float4(v.x * g.alpha + b.x, v.y * g.alpha + b.y, v.z * g.alpha + b.z, v.w * g.alpha + b.w);
+            } else if (EPI == EPI_F32_RESID) {
+                const float4 r = *reinterpret_cast<const float4*>(g.resF + o);
+                *reinterpret_cast<float4*>(g.outF + o) = make_float4(r.x + v.x + b.x, r.y + v.y + b.y, r.z + v.z + b.z, r.w + v.w + b.w);
+            } else if (EPI == EPI_F32_BF16) {
+                v = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
+                *reinterpret_cast<float4*>(g.outF + o) = v;
+                uint2 pk; pk.x = pack2<F16>(v.x, v.y); pk.y = pack2<F16>(v.z, v.w);
+                *reinterpret_cast<uint2*>(g.outH + o) = pk;
+            } else if (EPI == EPI_GELU32) {
+                v = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
+                uint2 pk; pk.x = pack2<F16>(v.x, v.y); pk.y = pack2<F16>(v.z, v.w);
+                *reinterpret_cast<uint2*>(g.outH + o) = pk;
+                *reinterpret_cast<float4*>(g.outF + o) = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+            } else if (EPI == EPI_DGELU) {
+                const uint2 a = *reinterpret_cast<const uint2*>(g.auxH + o);
+                const float h0 = to_f32<F16>((bf16_t)(a.x & 0xFFFF)), h1 = to_f32<F16>((bf16_t)(a.x >> 16));
+                const float h2 = to_f32<F16>((bf16_t)(a.y & 0xFFFF)), h3 = to_f32<F16>((bf16_t)(a.y >> 16));
+                uint2 pk;
+                pk.x = pack2<F16>(v.x * gelu_fast_grad(h0), v.y * gelu_fast_grad(h1));
+                pk.y = pack2<F16>(v.z * gelu_fast_grad(h2), v.w * gelu_fast_grad(h3));
+                *reinterpret_cast<uint2*>(g.outH + o) = pk;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+#define V3_T 256
+#define V3_STAGE (64 * 1024)
+#define V3_LDS (8 * V3_WLDS > 2 * V3_STAGE ? 8 * V3_WLDS : 2 * V3_STAGE)
+template <int EPI, bool F16>
+__global__ __launch_bounds__(512) void gemm_nt_v3_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntn = g.N / V3_T, ntm = (g.M + V3_T - 1) / V3_T, nwg = ntm * ntn;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int group_size = 4 * ntn, gid = t / group_size, first_m = gid * 4;
+    const int gm = (ntm - first_m) < 4 ? (ntm - first_m) : 4;
+    const int tin = t - gid * group_size;
+    const int m0 = (first_m + tin % gm) * V3_T, n0 = (tin / gm) * V3_T;
+    const int ktiles = g.K / BK;
+    const int kt_begin = (int)(((long long)blockIdx.y * ktiles) / g.ksplit);
+    const int kt_end = (int)(((long long)(blockIdx.y + 1) * ktiles) / g.ksplit);
+    const int nk = kt_end - kt_begin;
+
+    // DMA: 32 (A) + 32 (B) pieces of 8 rows x 128 B per stage; wave w owns pieces 8 w .. 8 w + 7 (waves 0-3: A, 4-7: B)
+    const int prow = lane >> 3, pch = lane & 7;
+    const bf16_t* src[8];
+    int dst[8];
+    const bool isB = wave >= 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int piece = (wave & 3) * 8 + i;
+        const int row = piece * 8 + prow;
+        const int cl = pch ^ ((row >> 1) & 7);
+        int am = m0 + row;
+        am = am < g.M ? am : g.M - 1;
+        src[i] = isB ? g.B + (size_t)(n0 + row) * g.ldb + cl * 8 : g.A + (size_t)am * g.lda + cl * 8;
+        dst[i] = (isB ? 32768 : 0) + piece * 1024;
+    }
+#define V3_DMA(kt, stage)                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                         \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)(kt) * BK),     \
+                                         (__attribute__((address_space(3))) void*)(lds3 + (stage) * V3_STAGE + dst[i]),   \
+                                         16, 0, 0);
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int lr = lane & 31, lg = lane >> 5;
+    int aoff[4], boff[2], aswz[4], bswz[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int r = wm * 128 + i * 32 + lr; aoff[i] = r * 128; aswz[i] = (r >> 1) & 7; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int r = wn * 64 + j * 32 + lr; boff[j] = 32768 + r * 128; bswz[j] = (r >> 1) & 7; }
+
+    if (nk > 0) { V3_DMA(kt_begin, 0); }
+    for (int it = 0; it < nk; ++it) {
+        const int stage = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // tile `it` landed (all waves); the other stage is no longer being read
+        if (it + 1 < nk) { V3_DMA(kt_begin + it + 1, stage ^ 1); }
+        const unsigned char* base = lds3 + stage * V3_STAGE;
+        s16x8_t af[2][4], bfr[2][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[0][i] = *reinterpret_cast<const s16x8_t*>(base + aoff[i] + ((lg ^ aswz[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bfr[0][j] = *reinterpret_cast<const s16x8_t*>(base + boff[j] + ((lg ^ bswz[j]) << 4));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s < 3) {
+                const int ch = 2 * (s + 1) + lg;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    af[nxt][i] = *reinterpret_cast<const s16x8_t*>(base + aoff[i] + ((ch ^ aswz[i]) << 4));
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    bfr[nxt][j] = *reinterpret_cast<const s16x8_t*>(base + boff[j] + ((ch ^ bswz[j]) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32t<F16>(bfr[cur][j], af[cur][i], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __builtin_amdgcn_s_barrier();  // every wave is done reading the operand stages: LDS becomes the per-wave C staging area
+    v3_epilogue<EPI, F16>(g, acc, lds3 + wave * V3_WLDS, m0 + wm * 128, n0 + wn * 64, lane);
+}
+
 template <int EPI>
 static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
     if (g.M <= 0 || g.N % TILE != 0 || g.K % BK != 0 || g.ksplit < 1) return SED_ERR_ARG;
@@ -426,6 +696,19 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
     static const int glds = []() { const char* e = getenv("SED_GEMM_GLDS"); return (e == nullptr || e[0] != '0') ? 1 : 0; }();
     // v2 (128x256, 3-stage) measures within +-5 % of v1 on this model's shapes (tools/gemm_bench.py): opt-in
     static const int v2 = []() { const char* e = getenv("SED_GEMM_V2"); return (e != nullptr && e[0] == '1') ? 1 : 0; }();
+    static const int v3 = []() { const char* e = getenv("SED_GEMM_V3"); return (e == nullptr || e[0] != '0') ? 1 : 0; }();
+    if (v3 && g.N % V3_T == 0 && g.M >= 1024) {
+        dim3 grid3(cdiv(g.M, V3_T) * (g.N / V3_T), g.ksplit);
+        static bool attr3[2] = {false, false};
+        if (f16) {
+            if (!attr3[1]) { hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr3[1] = true; }
+            hipLaunchKernelGGL((gemm_nt_v3_kernel<EPI, true>), grid3, dim3(512), V3_LDS, s, g);
+        } else {
+            if (!attr3[0]) { hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr3[0] = true; }
+            hipLaunchKernelGGL((gemm_nt_v3_kernel<EPI, false>), grid3, dim3(512), V3_LDS, s, g);
+        }
+        return sed_check_launch();
+    }
     if (v2 && g.N % V2_TN == 0) {
         dim3 grid2(cdiv(g.M, V2_TM) * (g.N / V2_TN), g.ksplit);
         static bool attr_set[2] = {false, false};
