@@ -21,38 +21,46 @@
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
-template <bool F16>
+// NQ = query blocks (of 32) per wave: 2 for the bulk of the sequence (256 queries per workgroup: every K / V^T fragment
+// read from LDS feeds two MFMAs and each staged K/V tile serves twice as many queries), 1 for a short tail block.
+template <bool F16, int NQ>
 __global__ __launch_bounds__(256) void mhsa_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
-                                                       float* __restrict__ LSE, int N, int Npad, int H) {
+                                                       float* __restrict__ LSE, int N, int Npad, int H, int q_begin) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][KVB * 128];  // [buf][K | Vt]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = q_begin + blockIdx.x * (128 * NQ) + wave * (32 * NQ);
     const bf16_t* Qb = Q + (size_t)bh * N * HD;
     const bf16_t* Kb = K + (size_t)bh * N * HD;
     const bf16_t* Vtb = Vt + (size_t)bh * HD * Npad;
 
-    int qrow = q0 + lr;
-    qrow = qrow < N ? qrow : N - 1;
-    s16x8_t qf[4];
+    s16x8_t qf[NQ][4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const s16x8_t*>(Qb + (size_t)qrow * HD + 16 * s + 8 * lg);
-
-    f32x16_t o[2];
+    for (int u = 0; u < NQ; ++u) {
+        int qrow = q0 + 32 * u + lr;
+        qrow = qrow < N ? qrow : N - 1;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int s = 0; s < 4; ++s) qf[u][s] = *reinterpret_cast<const s16x8_t*>(Qb + (size_t)qrow * HD + 16 * s + 8 * lg);
+    }
+    f32x16_t o[NQ][2];
+    float m_run[NQ], l_run[NQ];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
-
+    for (int u = 0; u < NQ; ++u) {
+        m_run[u] = -1e30f; l_run[u] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[u][i][r] = 0.f;
+    }
     const int ntiles = (N + KVB - 1) / KVB;
     TileRegs rk, rv;
     tile_gload(rk, Kb, 0, N, HD, 0, tid);
     tile_gload(rv, Vtb, 0, HD, Npad, 0, tid);
     tile_lstore_rows(rk, lds[0][0], tid);
     tile_lstore_cols(rv, lds[0][1], tid);
-    pin_frags(qf);
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) pin_frags(qf[u]);
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
@@ -63,56 +71,73 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(const bf16_t* __restrict_
         }
         const unsigned char* lk = lds[buf][0];
         const unsigned char* lv = lds[buf][1];
-        f32x16_t st[2];
+        f32x16_t st[NQ][2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int u = 0; u < NQ; ++u)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) st[kb] = mfma32t<F16>(lds_frag_rows(lk, 32 * kb + lr, 2 * s + lg), qf[s], st[kb]);
-        }
-        // scale (log2 domain) + mask keys >= N (last tile only)
-        float mloc = -1e30f;
+                for (int r = 0; r < 16; ++r) st[u][kb][r] = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float sv = st[kb][r] * SCALE_LOG2E;
-                if (j0 + KVB > N) {
-                    const int key = j0 + 32 * kb + mfma32_row(r, lg);
-                    sv = key < N ? sv : -1e30f;
+            for (int s = 0; s < 4; ++s) {
+                const s16x8_t kfr = lds_frag_rows(lk, 32 * kb + lr, 2 * s + lg);
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) st[u][kb] = mfma32t<F16>(kfr, qf[u][s], st[u][kb]);
+            }
+        // online softmax per query block (log2 domain); keys >= N masked on the last tile
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            float mloc = -1e30f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float sv = st[u][kb][r] * SCALE_LOG2E;
+                    if (j0 + KVB > N) {
+                        const int key = j0 + 32 * kb + mfma32_row(r, lg);
+                        sv = key < N ? sv : -1e30f;
+                    }
+                    st[u][kb][r] = sv;
+                    mloc = fmaxf(mloc, sv);
                 }
-                st[kb][r] = sv;
-                mloc = fmaxf(mloc, sv);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run[u], mloc);
+            const float alpha = exp2f(m_run[u] - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = exp2f(st[u][kb][r] - m_new);
+                    st[u][kb][r] = p;
+                    psum += p;
+                }
+            psum += __shfl_xor(psum, 32, 64);
+            l_run[u] = l_run[u] * alpha + psum;
+            m_run[u] = m_new;
+            if (__any(alpha != 1.0f)) {  // wave-uniform skip of the O rescale when no running max moved
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[u][i][r] *= alpha;
             }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = exp2f(m_run - m_new);
-        float psum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(st[kb][r] - m_new);
-                st[kb][r] = p;
-                psum += p;
-            }
-        psum += __shfl_xor(psum, 32, 64);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        }
         // O^T[d, q] += V^T[d, key] P^T[key, q]
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const s16x8_t pf = pack_frag_t<F16>(st[kb], s);
+                s16x8_t pf[NQ];
 #pragma unroll
-                for (int db = 0; db < 2; ++db)
-                    o[db] = mfma32t<F16>(lds_frag_cols(lv, 32 * db + lr, 8 * kb + 4 * s + lg), pf, o[db]);
+                for (int u = 0; u < NQ; ++u) pf[u] = pack_frag_t<F16>(st[u][kb], s);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const s16x8_t vfr = lds_frag_cols(lv, 32 * db + lr, 8 * kb + 4 * s + lg);
+#pragma unroll
+                    for (int u = 0; u < NQ; ++u) o[u][db] = mfma32t<F16>(vfr, pf[u], o[u][db]);
+                }
             }
         if (t + 1 < ntiles) {
             tile_lstore_rows(rk, lds[buf ^ 1][0], tid);
@@ -120,33 +145,41 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(const bf16_t* __restrict_
         }
         __syncthreads();
     }
-
-    const int q = q0 + lr;
-    if (q < N) {
-        const float inv = 1.0f / l_run;
-        bf16_t* orow = O + ((size_t)b * N + q) * (H * HD) + h * HD;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+    for (int u = 0; u < NQ; ++u) {
+        const int q = q0 + 32 * u + lr;
+        if (q < N) {
+            const float inv = 1.0f / l_run[u];
+            bf16_t* orow = O + ((size_t)b * N + q) * (H * HD) + h * HD;
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                uint2 pk;
-                pk.x = pack2<F16>(o[db][4 * qd] * inv, o[db][4 * qd + 1] * inv);
-                pk.y = pack2<F16>(o[db][4 * qd + 2] * inv, o[db][4 * qd + 3] * inv);
-                *reinterpret_cast<uint2*>(orow + 32 * db + 8 * qd + 4 * lg) = pk;
-            }
-        if (lg == 0 && LSE != nullptr) LSE[(size_t)bh * N + q] = m_run + log2f(l_run);  // log2 domain
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    uint2 pk;
+                    pk.x = pack2<F16>(o[u][db][4 * qd] * inv, o[u][db][4 * qd + 1] * inv);
+                    pk.y = pack2<F16>(o[u][db][4 * qd + 2] * inv, o[u][db][4 * qd + 3] * inv);
+                    *reinterpret_cast<uint2*>(orow + 32 * db + 8 * qd + 4 * lg) = pk;
+                }
+            if (lg == 0 && LSE != nullptr) LSE[(size_t)bh * N + q] = m_run[u] + log2f(l_run[u]);  // log2 domain
+        }
     }
+}
+
+template <bool F16>
+static void launch_mhsa_fwd(const void* Q, const void* K, const void* Vt, void* O, float* LSE, int B, int H, int N, int Npad,
+                            hipStream_t stream) {
+    // NQ = 2 (256-query workgroups) halves LDS traffic per MFMA but drops to one wave per SIMD (202 VGPRs) and measured
+    // slower on MI355X (24.9 vs 20.8 ms/step); NQ = 1 (two waves per SIMD) is the shipped configuration.
+    hipLaunchKernelGGL((mhsa_fwd_kernel<F16, 1>), dim3(cdiv(N, 128), B * H), dim3(256), 0, stream, (const bf16_t*)Q,
+                       (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, LSE, N, Npad, H, 0);
 }
 
 extern "C" int sed_mhsa_fwd(const void* Q, const void* K, const void* Vt, void* O, float* LSE, int B, int H, int N,
                             int Npad, int f16, hipStream_t stream) {
     (void)hipGetLastError();
     if (N <= 0 || Npad % 64 || Npad < N) return SED_ERR_ARG;
-    dim3 grid(cdiv(N, 128), B * H);
-    if (f16) hipLaunchKernelGGL(mhsa_fwd_kernel<true>, grid, dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,
-                                (const bf16_t*)Vt, (bf16_t*)O, LSE, N, Npad, H);
-    else hipLaunchKernelGGL(mhsa_fwd_kernel<false>, grid, dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,
-                       (const bf16_t*)Vt, (bf16_t*)O, LSE, N, Npad, H);
+    if (f16) launch_mhsa_fwd<true>(Q, K, Vt, O, LSE, B, H, N, Npad, stream);
+    else launch_mhsa_fwd<false>(Q, K, Vt, O, LSE, B, H, N, Npad, stream);
     return sed_check_launch();
 }
 

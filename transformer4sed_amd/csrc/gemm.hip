@@ -151,7 +151,7 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs& g, int m, int n, c
 // MFMA phase over one 64-deep K tile for a wave's 2x2 accumulator blocks, with the LDS->register fragment loads of
 // k-step s+1 issued BEFORE the four MFMAs of k-step s (register double buffering), so ds_read latency hides under MFMA
 // issue instead of serialising "4 reads - wait - 4 MFMAs" per k-step.
-template <bool F16>
+template <bool F16, bool SWAP>
 __device__ __forceinline__ void mfma_tile(const unsigned char* la, const unsigned char* lb, const int (&arow)[2],
                                           const int (&brow)[2], int lg, f32x16_t (&acc)[2][2]) {
     s16x8_t af[2][2], bfr[2][2];
@@ -175,7 +175,8 @@ __device__ __forceinline__ void mfma_tile(const unsigned char* la, const unsigne
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = mfma32t<F16>(bfr[cur][j], af[cur][i], acc[i][j]);
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = SWAP ? mfma32t<F16>(bfr[cur][j], af[cur][i], acc[i][j]) : mfma32t<F16>(af[cur][i], bfr[cur][j], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -258,7 +259,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
         brow[i] = wn * 64 + i * 32 + lr;
     }
 
-#define GEMM_COMPUTE(buf) mfma_tile<F16>(lds[buf][0], lds[buf][1], arow, brow, lg, acc)
+// split-K weight gradients keep the un-swapped accumulator layout (lane = output column): their atomics then hit 2 cache
+// lines per instruction instead of 64
+#define GEMM_COMPUTE(buf) mfma_tile<F16, EPI != EPI_ATOMIC>(lds[buf][0], lds[buf][1], arow, brow, lg, acc)
     if (GLDS) {
         // Direct-to-LDS staging (global_load_lds_dwordx4): each wave-instruction DMAs 64 x 16 B = 8 tile rows straight
         // into LDS (lane-linear destination), no VGPR round trip and no ds_write pass.  The XOR swizzle therefore moves to
@@ -311,6 +314,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
         }
     }
 
+    if (EPI == EPI_ATOMIC) {  // un-swapped: column = lane & 31, rows from the register index
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + lr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + i * 32 + mfma32_row(r, lg);
+                    if (m < g.M) unsafeAtomicAdd(&g.outF[(size_t)m * g.ldc + n], acc[i][j][r] * g.alpha);
+                }
+            }
+        return;
+    }
     // accumulator block (i, j) holds C^T: column index (lane & 31) = row m of C, register rows = columns n of C
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -400,7 +417,7 @@ __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(const GemmArgs g) {
             V2_DMA(kt_begin + it + 2, st2);
         }
         const unsigned char* la = lds2 + stage * V2_STAGE;
-        mfma_tile<F16>(la, la + 16384, arow, brow, lg, acc);
+        mfma_tile<F16, true>(la, la + 16384, arow, brow, lg, acc);
         stage = stage == 2 ? 0 : stage + 1;
     }
 #pragma unroll
