@@ -826,42 +826,80 @@ __device__ __forceinline__ float load_kind(const void* p, size_t i, int kind) {
 }
 __device__ __forceinline__ bf16_t store_kind(float v, int kind) { return kind == 2 ? f2h(v) : f2bf(v); }
 
+// 64 x 64 tiles through an fp32 LDS tile; 16-byte global loads along input rows and 16-byte stores along output rows
+// (requires C % 64 == 0, which holds for every feature width on this path; R is arbitrary, rows R..Rpad-1 become zeros).
 __global__ __launch_bounds__(256) void transpose_kernel(const void* __restrict__ in, int in_kind, int R, int C, int ldin,
                                                         bf16_t* __restrict__ outT, int Rpad, int outT_kind,
                                                         bf16_t* __restrict__ outS, int outS_kind,
                                                         float* __restrict__ colsum) {
     __shared__ float tile[64][65];
     const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // ty 0..3
+    const int t = threadIdx.x;
+    {
+        const int row = t >> 2, cg = (t & 3) * 16, r = r0 + row;
+        float v[16];
+        if (r < R) {
+            if (in_kind == 1) {
+                const float4* src = reinterpret_cast<const float4*>((const float*)in + (size_t)r * ldin + c0 + cg);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int r = r0 + ty * 16 + i, cc = c0 + tx;
-        float v = 0.f;
-        if (r < R && cc < C) {
-            v = load_kind(in, (size_t)r * ldin + cc, in_kind);
-            if (outS != nullptr) outS[(size_t)r * C + cc] = store_kind(v, outS_kind);
+                for (int k = 0; k < 4; ++k) { const float4 f = src[k]; v[4 * k] = f.x; v[4 * k + 1] = f.y; v[4 * k + 2] = f.z; v[4 * k + 3] = f.w; }
+            } else {
+                const uint4* src = reinterpret_cast<const uint4*>((const bf16_t*)in + (size_t)r * ldin + c0 + cg);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const uint4 u = src[k];
+                    const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bf16_t lo = (bf16_t)(w[e] & 0xFFFF), hi = (bf16_t)(w[e] >> 16);
+                        v[8 * k + 2 * e] = in_kind == 2 ? h2f(lo) : bf2f(lo);
+                        v[8 * k + 2 * e + 1] = in_kind == 2 ? h2f(hi) : bf2f(hi);
+                    }
+                }
+            }
+            if (outS != nullptr) {
+                unsigned pk[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    pk[e] = (unsigned)store_kind(v[2 * e], outS_kind) | ((unsigned)store_kind(v[2 * e + 1], outS_kind) << 16);
+                uint4* dst = reinterpret_cast<uint4*>(outS + (size_t)r * C + c0 + cg);
+                dst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                dst[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = 0.f;
         }
-        tile[ty * 16 + i][tx] = v;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tile[row][cg + e] = v[e];
     }
     __syncthreads();
-    if (colsum != nullptr && ty == 0) {
+    if (colsum != nullptr && t < 64) {
         float s = 0.f;
 #pragma unroll 8
-        for (int i = 0; i < 64; ++i) s += tile[i][tx];
-        if (c0 + tx < C) unsafeAtomicAdd(&colsum[c0 + tx], s);
+        for (int i = 0; i < 64; ++i) s += tile[i][t];
+        unsafeAtomicAdd(&colsum[c0 + t], s);
     }
     if (outT == nullptr) return;
+    {
+        const int oc = t >> 2, seg = (t & 3) * 16;
+        if (r0 + seg < Rpad) {
+            unsigned pk[8];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int cc = c0 + ty * 16 + i, r = r0 + tx;
-        if (cc < C && r < Rpad) outT[(size_t)cc * Rpad + r] = store_kind(tile[tx][ty * 16 + i], outT_kind);
+            for (int e = 0; e < 8; ++e)
+                pk[e] = (unsigned)store_kind(tile[seg + 2 * e][oc], outT_kind) |
+                        ((unsigned)store_kind(tile[seg + 2 * e + 1][oc], outT_kind) << 16);
+            uint4* dst = reinterpret_cast<uint4*>(outT + (size_t)(c0 + oc) * Rpad + r0 + seg);
+            dst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            dst[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+        }
     }
 }
 
 extern "C" int sed_transpose_to_bf16(const void* in, int in_kind, int R, int C, int ldin, void* outT, int Rpad,
                                      int outT_kind, void* outS, int outS_kind, float* colsum, hipStream_t stream) {
     (void)hipGetLastError();
-    if (Rpad < R || in_kind < 0 || in_kind > 2) return SED_ERR_ARG;
+    if (Rpad < R || in_kind < 0 || in_kind > 2 || (C % 64) || (Rpad % 16) || (ldin % 8)) return SED_ERR_ARG;
     dim3 grid(cdiv(C, 64), cdiv(Rpad, 64));
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, in, in_kind, R, C, ldin, (bf16_t*)outT, Rpad,
                        outT_kind, (bf16_t*)outS, outS_kind, colsum);
