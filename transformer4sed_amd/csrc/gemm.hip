@@ -45,6 +45,7 @@ struct GemmArgs {
     bf16_t *q, *k, *v, *qt, *kt, *vt, *q2, *q2t;
     const float *pu, *pv;
     int seq, seq_pad, heads;
+    int stagger;  // v3: first-round workgroups start phase * stagger wall-clock ticks (10 ns) late, phase = 0..7
 };
 
 #define TILE 128
@@ -452,10 +453,28 @@ __global__ __launch_bounds__(512) void gemm_nt_v2_kernel(const GemmArgs g) {
 #define V3_RS16 136
 #define V3_RS32 264
 
+// Per-lane column constants (bias, plus the rel-pos u / v vector for the q projection) for the 32 columns a lane owns in
+// the C^T accumulator layout: fetched ONCE, before any store -- the output pointers may alias them as far as the compiler
+// knows, so a load placed between stores costs a full `s_waitcnt vmcnt(0)` round trip each time (measured: 8 us / tile).
+__device__ __forceinline__ void v3_col_consts(float (&bv)[2][4][4], const float* bias_n, const float* extra, int lg) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = j * 32 + 8 * q + 4 * lg;
+            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias_n != nullptr) b = *reinterpret_cast<const float4*>(bias_n + col);
+            if (extra != nullptr) {
+                const float4 x = *reinterpret_cast<const float4*>(extra + col);
+                b.x += x.x; b.y += x.y; b.z += x.z; b.w += x.w;
+            }
+            bv[j][q][0] = b.x; bv[j][q][1] = b.y; bv[j][q][2] = b.z; bv[j][q][3] = b.w;
+        }
+}
+
 template <bool F16, int MODE>
-__device__ __forceinline__ void v3_stage16(unsigned char* wl, const f32x16_t (&acc)[4][2], const float* bias_n, int lr, int lg,
-                                           const float* extra) {
-    // mode 0: acc + bias (+ extra[col])   1: gelu_fast(acc + bias)
+__device__ __forceinline__ void v3_stage16(unsigned char* wl, const f32x16_t (&acc)[4][2], const float (&bv)[2][4][4], int lr, int lg) {
+    // mode 0: acc + column constant   1: gelu_fast(acc + column constant)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -466,8 +485,7 @@ __device__ __forceinline__ void v3_stage16(unsigned char* wl, const f32x16_t (&a
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float x = acc[i][j][4 * q + e] + (bias_n != nullptr ? bias_n[col + e] : 0.f);
-                    if (extra != nullptr) x += extra[col + e];
+                    const float x = acc[i][j][4 * q + e] + bv[j][q][e];
                     v[e] = MODE == 1 ? gelu_fast(x) : x;
                 }
                 uint2 pk;
@@ -491,31 +509,61 @@ __device__ __forceinline__ void v3_stage32(unsigned char* wl, const f32x16_t (&a
             }
 }
 
+template <int EPI>
+struct V3Consts {  // per-lane bias values, fetched before the K loop so their latency is off the epilogue's critical path
+    static constexpr bool kStaged16 = (EPI == EPI_BF16 || EPI == EPI_GELU);  // QKV is at the VGPR cap: it loads late
+    float bv[kStaged16 ? 2 : 1][kStaged16 ? 4 : 1][4];
+};
+template <int EPI>
+__device__ __forceinline__ void v3_load_consts(V3Consts<EPI>& c, const GemmArgs& g, int nb, int lane) {
+    if (EPI == EPI_QKV) {
+        c.bv[0][0][0] = 0.f;
+    } else if (V3Consts<EPI>::kStaged16) {
+        float t[2][4][4];
+        v3_col_consts(t, g.bias != nullptr ? g.bias + nb : nullptr, nullptr, lane >> 5);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c.bv[V3Consts<EPI>::kStaged16 ? j : 0][V3Consts<EPI>::kStaged16 ? q : 0][e] = t[j][q][e];
+    } else {
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias != nullptr) b = *reinterpret_cast<const float4*>(g.bias + nb + (lane & 15) * 4);
+        c.bv[0][0][0] = b.x; c.bv[0][0][1] = b.y; c.bv[0][0][2] = b.z; c.bv[0][0][3] = b.w;
+    }
+}
+
 template <int EPI, bool F16>
-__device__ __forceinline__ void v3_epilogue(const GemmArgs& g, const f32x16_t (&acc)[4][2], unsigned char* wl, int mb, int nb,
-                                            int lane) {
+__device__ __forceinline__ void v3_epilogue(const GemmArgs& g, const f32x16_t (&acc)[4][2], const V3Consts<EPI>& cc,
+                                            unsigned char* wl, int mb, int nb, int lane) {
     // mb = first row of this wave's 128 x 64 sub-tile, nb = its first column
     const int lr = lane & 31, lg = lane >> 5;
-    const float* bias_n = g.bias != nullptr ? g.bias + nb : nullptr;
-    if (EPI == EPI_BF16 || EPI == EPI_GELU) {
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
+        const float (&bv)[2][4][4] = cc.bv;
 #pragma unroll
         for (int pass = 0; pass < (EPI == EPI_GELU ? 2 : 1); ++pass) {
             bf16_t* out = (EPI == EPI_GELU && pass == 1) ? g.outH2 : g.outH;
             if (out == nullptr) continue;
-            if (EPI == EPI_GELU && pass == 1) v3_stage16<F16, 1>(wl, acc, bias_n, lr, lg, nullptr);
-            else v3_stage16<F16, 0>(wl, acc, bias_n, lr, lg, nullptr);
+            if (EPI == EPI_GELU && pass == 1) v3_stage16<F16, 1>(wl, acc, bv, lr, lg);
+            else v3_stage16<F16, 0>(wl, acc, bv, lr, lg);
             __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-            for (int rr = 0; rr < 16; ++rr) {
-                const int row = rr * 8 + (lane >> 3), c16 = lane & 7;
-                const uint4 v = *reinterpret_cast<const uint4*>(wl + row * V3_RS16 + c16 * 16);
-                if (mb + row < g.M) *reinterpret_cast<uint4*>(out + (size_t)(mb + row) * g.ldc + nb + c16 * 8) = v;
+#pragma unroll
+            for (int rb = 0; rb < 16; rb += 8) {
+                uint4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint4*>(wl + ((rb + u) * 8 + (lane >> 3)) * V3_RS16 + (lane & 7) * 16);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int row = (rb + u) * 8 + (lane >> 3);
+                    if (mb + row < g.M) *reinterpret_cast<uint4*>(out + (size_t)(mb + row) * g.ldc + nb + (lane & 7) * 8) = v[u];
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
         return;
     }
-    if (EPI == EPI_QKV) {
+    if constexpr (EPI == EPI_QKV) {
         const int D = g.heads * 64;
         const int which = nb / D, h = (nb - which * D) >> 6;
         bf16_t* row_dst = which == 0 ? g.q : (which == 1 ? g.k : g.v);
@@ -526,21 +574,44 @@ __device__ __forceinline__ void v3_epilogue(const GemmArgs& g, const f32x16_t (&
             if (which == 0 && g.pu != nullptr) extra = (pass == 0 ? g.pu : g.pv) + h * 64;
             bf16_t* rd = pass == 0 ? row_dst : g.q2;
             bf16_t* td = pass == 0 ? tr_dst : g.q2t;
-            v3_stage16<F16, 0>(wl, acc, bias_n, lr, lg, extra);
+            float bv[2][4][4];
+            v3_col_consts(bv, g.bias != nullptr ? g.bias + nb : nullptr, extra, lg);
+            v3_stage16<F16, 0>(wl, acc, bv, lr, lg);
             __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-            for (int rr = 0; rr < 16; ++rr) {
-                const int row = rr * 8 + (lane >> 3), c16 = lane & 7;
-                const int m = mb + row;
-                if (m < g.M) {
-                    const int bidx = m / g.seq, t = m - bidx * g.seq;
-                    const uint4 v = *reinterpret_cast<const uint4*>(wl + row * V3_RS16 + c16 * 16);
-                    *reinterpret_cast<uint4*>(rd + ((size_t)(bidx * g.heads + h) * g.seq + t) * 64 + c16 * 8) = v;
+#pragma unroll
+            for (int rb = 0; rb < 16; rb += 8) {
+                uint4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint4*>(wl + ((rb + u) * 8 + (lane >> 3)) * V3_RS16 + (lane & 7) * 16);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int m = mb + (rb + u) * 8 + (lane >> 3);
+                    if (m < g.M) {
+                        const int bidx = m / g.seq, t = m - bidx * g.seq;
+                        *reinterpret_cast<uint4*>(rd + ((size_t)(bidx * g.heads + h) * g.seq + t) * 64 + (lane & 7) * 8) = v[u];
+                    }
                 }
             }
-            if (td != nullptr) {
-                // transposed copy [bh][d][seq_pad]: lane -> row (token), loop over the 64 d columns: 64 consecutive tokens per
-                // store instruction (contiguous unless the run crosses a clip boundary)
+            if (td != nullptr && (g.seq & 1) == 0) {
+                // transposed copy [bh][d][seq_pad]: a lane owns a PAIR of consecutive tokens (same clip: seq is even and
+                // the pair starts on an even row) and one of two interleaved d columns -> 4-byte stores, 32 lanes = 128 B
+                const int pr = (lane & 31) * 2, dsel = lane >> 5;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int row = half * 64 + pr, m = mb + row;
+                    if (m < g.M) {
+                        const int bidx = m / g.seq, t = m - bidx * g.seq;
+                        bf16_t* base = td + (size_t)(bidx * g.heads + h) * 64 * g.seq_pad + t;
+                        const unsigned short* s0 = reinterpret_cast<const unsigned short*>(wl + row * V3_RS16);
+                        const unsigned short* s1 = reinterpret_cast<const unsigned short*>(wl + (row + 1) * V3_RS16);
+#pragma unroll 8
+                        for (int dd = 0; dd < 32; ++dd) {
+                            const int d = dd * 2 + dsel;
+                            *reinterpret_cast<unsigned*>(base + (size_t)d * g.seq_pad) = (unsigned)s0[d] | ((unsigned)s1[d] << 16);
+                        }
+                    }
+                }
+            } else if (td != nullptr) {
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int row = half * 64 + lane, m = mb + row;
@@ -557,7 +628,7 @@ __device__ __forceinline__ void v3_epilogue(const GemmArgs& g, const f32x16_t (&
         }
         return;
     }
-    if (EPI == EPI_ATOMIC) {  // split-K weight gradients: small outputs, direct atomics
+    if constexpr (EPI == EPI_ATOMIC) {  // split-K weight gradients: small outputs, direct atomics
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = mb + i * 32 + lr;
@@ -574,43 +645,59 @@ __device__ __forceinline__ void v3_epilogue(const GemmArgs& g, const f32x16_t (&
         return;
     }
     // fp32-staged epilogues (two passes of 64 rows): EPI_F32, EPI_F32_RESID, EPI_F32_BF16, EPI_GELU32, EPI_DGELU
+    // 16 lanes x 16 B = one 256-B fp32 row; the lane's 4 columns (and so its bias) are the same for every row.  Loads of the
+    // residual / saved pre-activation are issued 8 rows at a time ahead of the stores they feed (see v3_col_consts).
+    const int c4 = lane & 15, n = nb + c4 * 4;
+    const float4 b = make_float4(cc.bv[0][0][0], cc.bv[0][0][1], cc.bv[0][0][2], cc.bv[0][0][3]);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         v3_stage32(wl, acc, 2 * pass, lr, lg);
         __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-        for (int rr = 0; rr < 16; ++rr) {
-            const int row = rr * 4 + (lane >> 4), c4 = lane & 15;  // 16 lanes x 16 B = one 256-B fp32 row
-            const int m = mb + pass * 64 + row;
-            if (m >= g.M) continue;
-            float4 v = *reinterpret_cast<const float4*>(wl + row * V3_RS32 + c4 * 16);
-            const int n = nb + c4 * 4;
-            const size_t o = (size_t)m * g.ldc + n;
-            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g.bias != nullptr) b = *reinterpret_cast<const float4*>(g.bias + n);
-            if (EPI == EPI_F32) {
-                *reinterpret_cast<float4*>(g.outF + o) = make_float4(v.x * g.alpha + b.x, v.y * g.alpha + b.y, v.z * g.alpha + b.z, v.w * g.alpha + b.w);
-            } else if (EPI == EPI_F32_RESID) {
-                const float4 r = *reinterpret_cast<const float4*>(g.resF + o);
-                *reinterpret_cast<float4*>(g.outF + o) = make_float4(r.x + v.x + b.x, r.y + v.y + b.y, r.z + v.z + b.z, r.w + v.w + b.w);
-            } else if (EPI == EPI_F32_BF16) {
-                v = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
-                *reinterpret_cast<float4*>(g.outF + o) = v;
-                uint2 pk; pk.x = pack2<F16>(v.x, v.y); pk.y = pack2<F16>(v.z, v.w);
-                *reinterpret_cast<uint2*>(g.outH + o) = pk;
-            } else if (EPI == EPI_GELU32) {
-                v = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
-                uint2 pk; pk.x = pack2<F16>(v.x, v.y); pk.y = pack2<F16>(v.z, v.w);
-                *reinterpret_cast<uint2*>(g.outH + o) = pk;
-                *reinterpret_cast<float4*>(g.outF + o) = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
-            } else if (EPI == EPI_DGELU) {
-                const uint2 a = *reinterpret_cast<const uint2*>(g.auxH + o);
-                const float h0 = to_f32<F16>((bf16_t)(a.x & 0xFFFF)), h1 = to_f32<F16>((bf16_t)(a.x >> 16));
-                const float h2 = to_f32<F16>((bf16_t)(a.y & 0xFFFF)), h3 = to_f32<F16>((bf16_t)(a.y >> 16));
-                uint2 pk;
-                pk.x = pack2<F16>(v.x * gelu_fast_grad(h0), v.y * gelu_fast_grad(h1));
-                pk.y = pack2<F16>(v.z * gelu_fast_grad(h2), v.w * gelu_fast_grad(h3));
-                *reinterpret_cast<uint2*>(g.outH + o) = pk;
+#pragma unroll
+        for (int rb = 0; rb < 16; rb += 8) {
+            float4 r[8];
+            uint2 a[8];
+            if (EPI == EPI_F32_RESID || EPI == EPI_DGELU) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int m = mb + pass * 64 + (rb + u) * 4 + (lane >> 4);
+                    const size_t o = (size_t)(m < g.M ? m : g.M - 1) * g.ldc + n;
+                    if (EPI == EPI_F32_RESID) r[u] = *reinterpret_cast<const float4*>(g.resF + o);
+                    else a[u] = *reinterpret_cast<const uint2*>(g.auxH + o);
+                }
+            }
+            float4 vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = *reinterpret_cast<const float4*>(wl + ((rb + u) * 4 + (lane >> 4)) * V3_RS32 + c4 * 16);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = (rb + u) * 4 + (lane >> 4);
+                const int m = mb + pass * 64 + row;
+                if (m >= g.M) continue;
+                float4 v = vv[u];
+                const size_t o = (size_t)m * g.ldc + n;
+                if (EPI == EPI_F32) {
+                    *reinterpret_cast<float4*>(g.outF + o) = make_float4(v.x * g.alpha + b.x, v.y * g.alpha + b.y, v.z * g.alpha + b.z, v.w * g.alpha + b.w);
+                } else if (EPI == EPI_F32_RESID) {
+                    *reinterpret_cast<float4*>(g.outF + o) = make_float4(r[u].x + v.x + b.x, r[u].y + v.y + b.y, r[u].z + v.z + b.z, r[u].w + v.w + b.w);
+                } else if (EPI == EPI_F32_BF16) {
+                    v = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
+                    *reinterpret_cast<float4*>(g.outF + o) = v;
+                    uint2 pk; pk.x = pack2<F16>(v.x, v.y); pk.y = pack2<F16>(v.z, v.w);
+                    *reinterpret_cast<uint2*>(g.outH + o) = pk;
+                } else if (EPI == EPI_GELU32) {
+                    v = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
+                    uint2 pk; pk.x = pack2<F16>(v.x, v.y); pk.y = pack2<F16>(v.z, v.w);
+                    *reinterpret_cast<uint2*>(g.outH + o) = pk;
+                    *reinterpret_cast<float4*>(g.outF + o) = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+                } else if (EPI == EPI_DGELU) {
+                    const float h0 = to_f32<F16>((bf16_t)(a[u].x & 0xFFFF)), h1 = to_f32<F16>((bf16_t)(a[u].x >> 16));
+                    const float h2 = to_f32<F16>((bf16_t)(a[u].y & 0xFFFF)), h3 = to_f32<F16>((bf16_t)(a[u].y >> 16));
+                    uint2 pk;
+                    pk.x = pack2<F16>(v.x * gelu_fast_grad(h0), v.y * gelu_fast_grad(h1));
+                    pk.y = pack2<F16>(v.z * gelu_fast_grad(h2), v.w * gelu_fast_grad(h3));
+                    *reinterpret_cast<uint2*>(g.outH + o) = pk;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -619,13 +706,39 @@ __device__ __forceinline__ void v3_epilogue(const GemmArgs& g, const f32x16_t (&
 
 #define V3_T 256
 #define V3_STAGE (64 * 1024)
+#ifdef SED_GEMM_TRACE  // developer build only (tools/ablate/trace_v3.py): per-workgroup phase timestamps
+__device__ unsigned long long* sed_trace_buf = nullptr;
+extern "C" int sed_debug_set_gemm_trace(unsigned long long* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(sed_trace_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#define V3_TRACE(slot) do { if (tid == 0 && sed_trace_buf != nullptr) sed_trace_buf[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define V3_TRACE(slot) do {} while (0)
+#endif
 #define V3_LDS (8 * V3_WLDS > 2 * V3_STAGE ? 8 * V3_WLDS : 2 * V3_STAGE)
 template <int EPI, bool F16>
 __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
+    V3_TRACE(0);
+#ifdef SED_GEMM_TRACE
+    if (tid == 0 && sed_trace_buf != nullptr) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        sed_trace_buf[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     const int ntn = g.N / V3_T, ntm = (g.M + V3_T - 1) / V3_T, nwg = ntm * ntn;
+    if (g.stagger > 0 && blockIdx.x < 256) {
+        // De-phase the first round: identical workgroups launched together reach their epilogues together and the
+        // whole chip's C tiles hit HBM in one burst (measured: 8-25 us of store issue per tile vs ~2 us alone).
+        const unsigned long long wait = (unsigned long long)(((blockIdx.x >> 3) & 7) * g.stagger);
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
     const int t = xcd_remap(blockIdx.x, nwg);
     const int group_size = 4 * ntn, gid = t / group_size, first_m = gid * 4;
     const int gm = (ntm - first_m) < 4 ? (ntm - first_m) : 4;
@@ -670,11 +783,14 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(const GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) { const int r = wn * 64 + j * 32 + lr; boff[j] = 32768 + r * 128; bswz[j] = (r >> 1) & 7; }
 
+    V3Consts<EPI> cc;
+    v3_load_consts<EPI>(cc, g, n0 + wn * 64, lane);
     if (nk > 0) { V3_DMA(kt_begin, 0); }
     for (int it = 0; it < nk; ++it) {
         const int stage = it & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // tile `it` landed (all waves); the other stage is no longer being read
+        if (it == 0) V3_TRACE(1);
         if (it + 1 < nk) { V3_DMA(kt_begin + it + 1, stage ^ 1); }
         const unsigned char* base = lds3 + stage * V3_STAGE;
         s16x8_t af[2][4], bfr[2][2];
@@ -703,7 +819,13 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(const GemmArgs g) {
         }
     }
     __builtin_amdgcn_s_barrier();  // every wave is done reading the operand stages: LDS becomes the per-wave C staging area
-    v3_epilogue<EPI, F16>(g, acc, lds3 + wave * V3_WLDS, m0 + wm * 128, n0 + wn * 64, lane);
+    V3_TRACE(2);
+    v3_epilogue<EPI, F16>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * 128, n0 + wn * 64, lane);
+    V3_TRACE(3);
+#ifdef SED_GEMM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    V3_TRACE(4);
+#endif
 }
 
 template <int EPI>
@@ -717,12 +839,16 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
     static const int v3 = []() { const char* e = getenv("SED_GEMM_V3"); return (e == nullptr || e[0] != '0') ? 1 : 0; }();
     if (v3 && g.N % V3_T == 0 && g.M >= 1024 && EPI != EPI_ATOMIC) {  // split-K dW: v1 (128 tiles spread the atomics better)
         dim3 grid3(cdiv(g.M, V3_T) * (g.N / V3_T), g.ksplit);
+        static const float stagger_us = []() { const char* e = getenv("SED_GEMM_STAGGER_US"); return e ? (float)atof(e) : 0.f; }();
+        GemmArgs gs = g;
+        gs.stagger = (int)(stagger_us * 100.f / 8.f);
+        const GemmArgs& g = gs;
         static bool attr3[2] = {false, false};
         if (f16) {
-            if (!attr3[1]) { hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr3[1] = true; }
+            if (!attr3[1]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr3[1] = true; }
             hipLaunchKernelGGL((gemm_nt_v3_kernel<EPI, true>), grid3, dim3(512), V3_LDS, s, g);
         } else {
-            if (!attr3[0]) { hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr3[0] = true; }
+            if (!attr3[0]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr3[0] = true; }
             hipLaunchKernelGGL((gemm_nt_v3_kernel<EPI, false>), grid3, dim3(512), V3_LDS, s, g);
         }
         return sed_check_launch();
@@ -731,10 +857,10 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
         dim3 grid2(cdiv(g.M, V2_TM) * (g.N / V2_TN), g.ksplit);
         static bool attr_set[2] = {false, false};
         if (f16) {
-            if (!attr_set[1]) { hipFuncSetAttribute((const void*)gemm_nt_v2_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * V2_STAGE); attr_set[1] = true; }
+            if (!attr_set[1]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v2_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * V2_STAGE); attr_set[1] = true; }
             hipLaunchKernelGGL((gemm_nt_v2_kernel<EPI, true>), grid2, dim3(512), 3 * V2_STAGE, s, g);
         } else {
-            if (!attr_set[0]) { hipFuncSetAttribute((const void*)gemm_nt_v2_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * V2_STAGE); attr_set[0] = true; }
+            if (!attr_set[0]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v2_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * V2_STAGE); attr_set[0] = true; }
             hipLaunchKernelGGL((gemm_nt_v2_kernel<EPI, false>), grid2, dim3(512), 3 * V2_STAGE, s, g);
         }
         return sed_check_launch();
