@@ -15,6 +15,7 @@ Nothing in tests/, smoke() or bench.py imports this file or /root/reference.
 """
 import argparse
 import contextlib
+import json
 import os
 import random
 import sys
@@ -516,8 +517,95 @@ def gen_losses():
     save("losses", **out)
 
 
+TRAINSTEP_CFG = dict(  # config/mat-sed/base/finetune2.yaml values; batch 1+1 / 2 / 2, depth-2 encoder (feature layer 2)
+    training=dict(batch_size=[1, 1, 2, 2], clip_grad=True, self_loss_warmup=15, cons_scheduler_name="Sigmoid",
+                  ema_factor=0.999, w_weak=0.5, w_cons_max=40, w_cons_min=0, w_weak_cons=0.5, w_AT=2,
+                  transform=dict(n_transform=2, choice=[1, 0, 0, 1], filter_db_range=[-26, 26], filter_bands=[2, 5],
+                                 filter_minimum_bandwidth=4, filter_type="step")),
+    PaSST_SED=dict(train_stu_kwargs=dict(encoder_win=False, win_param=[512, 49], mix_rate=0.5, temp_w=1),
+                   train_tch_kwargs=dict(encoder_win=True, win_param=[512, 49], mix_rate=0.5, temp_w=1)),
+    opt=dict(param_groups=dict(encoder=dict(lr=5.0e-6, weight_decay=1.0e-4, freeze_layer=0, step_lr=4),
+                               decoder=dict(lr=1.0e-4, weight_decay=1.0e-4), head=dict(lr=1.0e-4, weight_decay=1.0e-4))),
+)
+TRAINSTEP_SEEDS = (101, 102, 103)          # random / numpy / torch, set once before the first step
+TRAINSTEP_SCHED = dict(epoch_len=4, n_epochs=30, n_epochs_cut=15, exponent=-1, warmup_epochs=1, warmup_rate=0.1)
+TRAINSTEP_PROBES = ["backbone.patch_embed.proj.weight", "backbone.blocks.1.attn.qkv.weight", "backbone.blocks.1.mlp.fc2.bias",
+                    "backbone.norm.weight", "backbone.head.1.weight", "out_norm.bias",
+                    "decoder.encoder_blocks.0.attn.in_proj.weight", "decoder.encoder_blocks.1.attn.pos_bias_u",
+                    "decoder.encoder_blocks.2.attn.linear_pos.weight", "decoder.encoder_blocks.2.mlp.fc1.weight",
+                    "classifier.weight", "at_adpater.0.mha.in_proj_weight", "at_adpater.1.bias"]
+
+
+def gen_trainstep():
+    """Three consecutive optimisation steps of the REFERENCE trainer itself (recipes/desed/finetune/train.py:Trainer.train,
+    finetune2 settings: global student, sliding-window EMA teacher in train mode, AdamW groups from
+    recipes/desed/finetune/passt/setting.py:get_params, ExponentialDown, update_ema), each run as a one-batch epoch so the
+    per-step scalars appear in the trainer's own log.  Records the logged scalars, the learning rates, and a probe of the
+    student / EMA parameters after every step (SURVEY 8(c) "pins")."""
+    import logging
+    from copy import deepcopy
+    from recipes.desed.finetune.train import Trainer
+    from recipes.desed.finetune.passt.setting import get_params
+    from src.utils.scheduler import ExponentialDown
+    cfg = json.loads(json.dumps(TRAINSTEP_CFG))
+    net = build_reference_model(768, False, 2, 2)
+    probes = [n for n in TRAINSTEP_PROBES if n in dict(net.named_parameters())]
+    assert len(probes) >= 10, [n for n in TRAINSTEP_PROBES if n not in probes]
+    ema_net = deepcopy(net)
+    for prm in ema_net.parameters():
+        prm.detach_()
+    groups = get_params(net, cfg, logging.getLogger("golden"))
+    opt = torch.optim.AdamW(groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-8)   # recipes/desed/setting.py:256-258
+    sc = TRAINSTEP_SCHED
+    sch = ExponentialDown(optimizer=opt, start_iter=sc["n_epochs_cut"] * sc["epoch_len"], total_iter=sc["n_epochs"] * sc["epoch_len"],
+                          exponent=sc["exponent"], warmup_iter=sc["warmup_epochs"] * sc["epoch_len"], warmup_rate=sc["warmup_rate"])
+
+    scalars = []
+
+    class _TB:
+        def add_scalar(self, key, value, global_step=None):
+            scalars[-1][key.split("/", 1)[1]] = float(value)
+
+    class _Log:
+        tensorboard_writer = _TB()
+        logger = logging.getLogger("golden")
+
+    enc = types.SimpleNamespace(net_pooling=1)
+    tr = Trainer(optimizer=opt, my_logger=_Log(), net=net, ema_net=ema_net, scheduler=sch, encoder=enc, train_loader=None,
+                 val_loader=None, test_loader=None, config=cfg, device="cpu")
+    random.seed(TRAINSTEP_SEEDS[0]); np.random.seed(TRAINSTEP_SEEDS[1]); torch.manual_seed(TRAINSTEP_SEEDS[2])
+    out = dict(probe_names=np.array(probes))
+    name2p = lambda m: dict(m.named_parameters())
+    n_steps = 3
+    for step in range(n_steps):
+        wav = torch.from_numpy(synth.synth_wav(6, seed=2000 + step))
+        labels = torch.from_numpy(synth.synth_batch_labels(2, 2, 2, seed=300 + step))
+        tr.train_loader = [(wav, labels, None, None)]
+        if hasattr(tr, "_train_epoch_len"):
+            del tr._train_epoch_len
+        scalars.append({})
+        rec = DrawRecorder()
+        with rec.recording():
+            tr.train(step)
+        for k, v in scalars[-1].items():
+            out[f"s{step}_{k}"] = np.float64(v)
+        out[f"s{step}_lrs"] = np.array([g["lr"] for g in opt.param_groups], dtype=np.float64)
+        out[f"s{step}_n_draws"] = np.int64(len(rec.log))
+        out[f"s{step}_draw_kinds"] = np.array([k for k, _ in rec.log])
+        sp, ep = name2p(tr.net.module if hasattr(tr.net, "module") else tr.net), name2p(tr.ema_net.module if hasattr(tr.ema_net, "module") else tr.ema_net)
+        for i, n in enumerate(probes):
+            out[f"s{step}_stu{i}"] = t2n(sp[n]).reshape(-1)[:512].astype(np.float32).copy()
+            out[f"s{step}_ema{i}"] = t2n(ep[n]).reshape(-1)[:512].astype(np.float32).copy()
+        print(f"   step {step}: " + " ".join(f"{k}={v:.6f}" for k, v in scalars[-1].items()), flush=True)
+    out["n_steps"] = np.int64(n_steps)
+    out["config_json"] = np.array(json.dumps(dict(cfg=TRAINSTEP_CFG, sched=TRAINSTEP_SCHED, seeds=TRAINSTEP_SEEDS,
+                                                  wav_seed0=2000, label_seed0=300, groups=[2, 2, 2])))
+    out["group_sizes"] = np.array([len(g["params"]) for g in opt.param_groups])
+    save("trainstep", **out)
+
+
 GENS = dict(frontend=gen_frontend, augment=gen_augment, micro=gen_micro, full=gen_full, full12=gen_full12,
-            schedule=gen_schedule, postprocess=gen_postprocess, losses=gen_losses)
+            schedule=gen_schedule, postprocess=gen_postprocess, losses=gen_losses, trainstep=gen_trainstep)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
