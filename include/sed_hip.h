@@ -40,7 +40,7 @@ int sed_median_filter(const float* in, float* out, const int* sizes, const float
 /* ------------------------------------------------------------------ GEMM family (nn.Linear / conv / autograd GEMMs) */
 /* C[M,N] = A[M,K] . B[N,K]^T, bf16 operands, fp32 accumulate, fused epilogue `epi`:
  * 0 outF=acc*alpha+bias | 1 outF=resF+acc+bias (resF may alias outF) | 2 outH=bf16(acc+bias) | 3 outH=h, outH2=gelu(h) | 4 outH=acc*gelu'(auxH)
- * 5 atomicAdd(outF, acc*alpha) (split-K) | 7 outF and outH | 8 outH=h, outF=gelu(h) fp32.  Replaces F.linear at src/models/passt/passt.py:271,274,
+ * 5 atomicAdd(outF, acc*alpha) (split-K; `ksplit` is a hint, the library re-derives it for the tile shape it dispatches) | 7 outF and outH | 8 outH=h, outF=gelu(h) fp32.  Replaces F.linear at src/models/passt/passt.py:271,274,
  * 332,342; src/models/transformer/transformerXL.py:382,493,584; src/models/passt/passt_sed.py:196; conv2d passt.py:307 */
 int sed_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi, const float* bias,
                 const float* resF, float* outF, void* outH, void* outH2, const void* auxH, int ldc, float alpha,

@@ -628,19 +628,20 @@ __device__ __forceinline__ void v3_epilogue(const GemmArgs& g, const f32x16_t (&
         }
         return;
     }
-    if constexpr (EPI == EPI_ATOMIC) {  // split-K weight gradients: small outputs, direct atomics
+    if constexpr (EPI == EPI_ATOMIC) {
+        // split-K weight gradients: stage the tile row-major, then one atomic per lane with the 64 lanes on 64 consecutive
+        // columns (256 contiguous bytes per instruction)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = mb + i * 32 + lr;
-            if (m >= g.M) continue;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = nb + j * 32 + 8 * q + 4 * lg;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(&g.outF[(size_t)m * g.ldc + n + e], acc[i][j][4 * q + e] * g.alpha);
-                }
+        for (int pass = 0; pass < 2; ++pass) {
+            v3_stage32(wl, acc, 2 * pass, lr, lg);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 8
+            for (int row = 0; row < 64; ++row) {
+                const int m = mb + pass * 64 + row;
+                const float v = *reinterpret_cast<const float*>(wl + row * V3_RS32 + lane * 4);
+                if (m < g.M) unsafeAtomicAdd(&g.outF[(size_t)m * g.ldc + nb + lane], v * g.alpha);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         return;
     }
@@ -837,10 +838,22 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
     // v2 (128x256, 3-stage) measures within +-5 % of v1 on this model's shapes (tools/gemm_bench.py): opt-in
     static const int v2 = []() { const char* e = getenv("SED_GEMM_V2"); return (e != nullptr && e[0] == '1') ? 1 : 0; }();
     static const int v3 = []() { const char* e = getenv("SED_GEMM_V3"); return (e == nullptr || e[0] != '0') ? 1 : 0; }();
-    if (v3 && g.N % V3_T == 0 && g.M >= 1024 && EPI != EPI_ATOMIC) {  // split-K dW: v1 (128 tiles spread the atomics better)
-        dim3 grid3(cdiv(g.M, V3_T) * (g.N / V3_T), g.ksplit);
+    // split-K dW through the 256^2 kernel measured slower in the train step (178 vs 171 ms): one workgroup per CU leaves the
+    // long atomic epilogue uncovered, whereas the 128^2 kernel keeps a second workgroup's MFMAs running under it.  Opt-in.
+    static const int v3dw = []() { const char* e = getenv("SED_GEMM_V3_DW"); return (e != nullptr && e[0] == '1') ? 1 : 0; }();
+    const bool v3_ok = EPI == EPI_ATOMIC ? (v3dw && g.M >= 512 && g.K >= 32 * BK) : (g.M >= 1024 && g.ksplit == 1);
+    if (v3 && g.N % V3_T == 0 && v3_ok) {
+        int ks3 = 1;
+        if (EPI == EPI_ATOMIC) {  // split-K weight gradients: one workgroup per CU, at least 16 K tiles per split
+            const int tiles3 = cdiv(g.M, V3_T) * (g.N / V3_T), ktiles = g.K / BK;
+            ks3 = cdiv(256, tiles3);
+            if (ks3 > ktiles / 16) ks3 = ktiles / 16;
+            if (ks3 < 1) ks3 = 1;
+        }
+        dim3 grid3(cdiv(g.M, V3_T) * (g.N / V3_T), ks3);
         static const float stagger_us = []() { const char* e = getenv("SED_GEMM_STAGGER_US"); return e ? (float)atof(e) : 0.f; }();
         GemmArgs gs = g;
+        gs.ksplit = ks3;
         gs.stagger = (int)(stagger_us * 100.f / 8.f);
         const GemmArgs& g = gs;
         static bool attr3[2] = {false, false};
