@@ -8,7 +8,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsed_hip.so")
 SOURCES = ["gemm.hip", "attention.hip", "relpos_attention.hip", "norm_elem.hip", "frontend.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
-         "-Wno-unused-result"]
+         "-Wno-unused-result",
+         # MFMA accumulators stay in (unified-file) VGPRs: the AGPR form costs a v_accvgpr_read/write per softmax operand
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def _hipcc():

@@ -21,6 +21,53 @@
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
+// One 64-key tile of the online softmax for a lane's query: st holds the raw scores S^T (2 blocks x 16 keys per lane; the
+// other 32 keys of the tile live in lane ^ 32), and leaves P = exp2(c s - m) there.  The VALU work per score is the binding
+// resource of this kernel (16 MFMAs = 512 matrix-pipe cycles per tile against 4 cycles per VALU instruction), so: max on the
+// raw scores (v_max3), scale and max-subtract in one packed FMA, raw v_exp_f32, packed row sums, masking only when MASKED.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <bool MASKED>
+__device__ __forceinline__ void softmax_tile(f32x16_t (&st)[2], f32x16_t (&o)[2], float& m_run, float& l_run, int j0, int N, int lg) {
+    if (MASKED) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = j0 + 32 * kb + mfma32_row(r, lg);
+                st[kb][r] = key < N ? st[kb][r] : -1e30f;
+            }
+    }
+    float mloc = -1e30f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mloc = max3_raw(mloc, st[kb][r], st[kb][r + 1]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m_run, mloc * SCALE_LOG2E);   // SCALE_LOG2E > 0: max(c s) = c max(s)
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    const f32x2_t c2 = {SCALE_LOG2E, SCALE_LOG2E}, nm2 = {-m_new, -m_new};
+    f32x2_t ps2 = {0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            f32x2_t x = {st[kb][r], st[kb][r + 1]};
+            x = __builtin_elementwise_fma(x, c2, nm2);
+            f32x2_t pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+            st[kb][r] = pv.x; st[kb][r + 1] = pv.y;
+            ps2 += pv;
+        }
+    float psum = ps2.x + ps2.y;
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    // (a wave-uniform "max did not move" skip costs more in register copies at the join than the 16 packed multiplies)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+}
+
 // NQ = query blocks (of 32) per wave: 2 for the bulk of the sequence (256 queries per workgroup: every K / V^T fragment
 // read from LDS feeds two MFMAs and each staged K/V tile serves twice as many queries), 1 for a short tail block.
 template <bool F16, int NQ>
@@ -72,57 +119,20 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(const bf16_t* __restrict_
         const unsigned char* lk = lds[buf][0];
         const unsigned char* lv = lds[buf][1];
         f32x16_t st[NQ][2];
-#pragma unroll
-        for (int u = 0; u < NQ; ++u)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[u][kb][r] = 0.f;
+        const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const s16x8_t kfr = lds_frag_rows(lk, 32 * kb + lr, 2 * s + lg);
 #pragma unroll
-                for (int u = 0; u < NQ; ++u) st[u][kb] = mfma32t<F16>(kfr, qf[u][s], st[u][kb]);
+                for (int u = 0; u < NQ; ++u) st[u][kb] = mfma32t<F16>(kfr, qf[u][s], s == 0 ? zero16 : st[u][kb]);  // C = inline 0
             }
-        // online softmax per query block (log2 domain); keys >= N masked on the last tile
+        // online softmax per query block (log2 domain); keys >= N are masked on the last tile only
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
-            float mloc = -1e30f;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float sv = st[u][kb][r] * SCALE_LOG2E;
-                    if (j0 + KVB > N) {
-                        const int key = j0 + 32 * kb + mfma32_row(r, lg);
-                        sv = key < N ? sv : -1e30f;
-                    }
-                    st[u][kb][r] = sv;
-                    mloc = fmaxf(mloc, sv);
-                }
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            const float m_new = fmaxf(m_run[u], mloc);
-            const float alpha = exp2f(m_run[u] - m_new);
-            float psum = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = exp2f(st[u][kb][r] - m_new);
-                    st[u][kb][r] = p;
-                    psum += p;
-                }
-            psum += __shfl_xor(psum, 32, 64);
-            l_run[u] = l_run[u] * alpha + psum;
-            m_run[u] = m_new;
-            if (__any(alpha != 1.0f)) {  // wave-uniform skip of the O rescale when no running max moved
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[u][i][r] *= alpha;
-            }
+            if (j0 + KVB > N) softmax_tile<true>(st[u], o[u], m_run[u], l_run[u], j0, N, lg);
+            else softmax_tile<false>(st[u], o[u], m_run[u], l_run[u], j0, N, lg);
         }
         // O^T[d, q] += V^T[d, key] P^T[key, q]
 #pragma unroll

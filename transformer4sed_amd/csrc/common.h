@@ -43,6 +43,12 @@ __device__ __forceinline__ f32x16_t mfma32(s16x8_t a, s16x8_t b, f32x16_t c) {
 // Row of accumulator register r (0..15) of a 32x32 MFMA tile for lane group g = lane >> 5; column = lane & 31.
 __device__ __forceinline__ int mfma32_row(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 
+// max of three without the canonicalisation moves the compiler adds around fmaxf for possibly-signalling inputs
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

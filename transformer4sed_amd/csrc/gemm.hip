@@ -509,6 +509,64 @@ __device__ __forceinline__ void v3_stage32(unsigned char* wl, const f32x16_t (&a
             }
 }
 
+// Side input of one batch (8 rows per lane, rows m0 + 4 u + lane/16): residual rows (fp32) or saved pre-activations (16-bit)
+template <int EPI>
+struct V3Side {
+    float4 r[EPI == EPI_F32_RESID ? 8 : 1];
+    uint2 a[EPI == EPI_DGELU ? 8 : 1];
+};
+template <int EPI>
+__device__ __forceinline__ void v3_side_load(V3Side<EPI>& sd, const GemmArgs& g, int m0, int n, int lane) {
+    if constexpr (EPI == EPI_F32_RESID || EPI == EPI_DGELU) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int m = m0 + u * 4 + (lane >> 4);
+            const size_t o = (size_t)(m < g.M ? m : g.M - 1) * g.ldc + n;
+            if constexpr (EPI == EPI_F32_RESID) sd.r[u] = *reinterpret_cast<const float4*>(g.resF + o);
+            else sd.a[u] = *reinterpret_cast<const uint2*>(g.auxH + o);
+        }
+    }
+}
+// rows m0 .. m0 + 31 of the output = staged rows srow0 .. srow0 + 31
+template <int EPI, bool F16>
+__device__ __forceinline__ void v3_store_batch(const GemmArgs& g, const unsigned char* wl, const V3Side<EPI>& sd, const float4 b,
+                                               int m0, int srow0, int n, int c4, int lane) {
+    float4 vv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) vv[u] = *reinterpret_cast<const float4*>(wl + (srow0 + u * 4 + (lane >> 4)) * V3_RS32 + c4 * 16);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int m = m0 + u * 4 + (lane >> 4);
+        if (m >= g.M) continue;
+        float4 v = vv[u];
+        const size_t o = (size_t)m * g.ldc + n;
+        if constexpr (EPI == EPI_F32) {
+            *reinterpret_cast<float4*>(g.outF + o) = make_float4(v.x * g.alpha + b.x, v.y * g.alpha + b.y, v.z * g.alpha + b.z, v.w * g.alpha + b.w);
+        } else if constexpr (EPI == EPI_F32_RESID) {
+            const float4 r = sd.r[u];
+            *reinterpret_cast<float4*>(g.outF + o) = make_float4(r.x + v.x + b.x, r.y + v.y + b.y, r.z + v.z + b.z, r.w + v.w + b.w);
+        } else if constexpr (EPI == EPI_F32_BF16) {
+            v = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
+            *reinterpret_cast<float4*>(g.outF + o) = v;
+            uint2 pk; pk.x = pack2<F16>(v.x, v.y); pk.y = pack2<F16>(v.z, v.w);
+            *reinterpret_cast<uint2*>(g.outH + o) = pk;
+        } else if constexpr (EPI == EPI_GELU32) {
+            v = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
+            uint2 pk; pk.x = pack2<F16>(v.x, v.y); pk.y = pack2<F16>(v.z, v.w);
+            *reinterpret_cast<uint2*>(g.outH + o) = pk;
+            *reinterpret_cast<float4*>(g.outF + o) = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+        } else if constexpr (EPI == EPI_DGELU) {
+            const uint2 a = sd.a[u];
+            const float h0 = to_f32<F16>((bf16_t)(a.x & 0xFFFF)), h1 = to_f32<F16>((bf16_t)(a.x >> 16));
+            const float h2 = to_f32<F16>((bf16_t)(a.y & 0xFFFF)), h3 = to_f32<F16>((bf16_t)(a.y >> 16));
+            uint2 pk;
+            pk.x = pack2<F16>(v.x * gelu_fast_grad(h0), v.y * gelu_fast_grad(h1));
+            pk.y = pack2<F16>(v.z * gelu_fast_grad(h2), v.w * gelu_fast_grad(h3));
+            *reinterpret_cast<uint2*>(g.outH + o) = pk;
+        }
+    }
+}
+
 template <int EPI>
 struct V3Consts {  // per-lane bias values, fetched before the K loop so their latency is off the epilogue's critical path
     static constexpr bool kStaged16 = (EPI == EPI_BF16 || EPI == EPI_GELU);  // QKV is at the VGPR cap: it loads late
@@ -646,63 +704,26 @@ __device__ __forceinline__ void v3_epilogue(const GemmArgs& g, const f32x16_t (&
         return;
     }
     // fp32-staged epilogues (two passes of 64 rows): EPI_F32, EPI_F32_RESID, EPI_F32_BF16, EPI_GELU32, EPI_DGELU
-    // 16 lanes x 16 B = one 256-B fp32 row; the lane's 4 columns (and so its bias) are the same for every row.  Loads of the
-    // residual / saved pre-activation are issued 8 rows at a time ahead of the stores they feed (see v3_col_consts).
+    // 16 lanes x 16 B = one 256-B fp32 row; the lane's 4 columns (and so its bias) are the same for every row.  Four batches
+    // of 8 rows-per-lane; the residual / saved pre-activation of batch k+1 is requested before batch k is stored, so its
+    // latency hides under the stores (loads placed between stores would each cost a full wait, see v3_col_consts).
     const int c4 = lane & 15, n = nb + c4 * 4;
     const float4 b = make_float4(cc.bv[0][0][0], cc.bv[0][0][1], cc.bv[0][0][2], cc.bv[0][0][3]);
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        v3_stage32(wl, acc, 2 * pass, lr, lg);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int rb = 0; rb < 16; rb += 8) {
-            float4 r[8];
-            uint2 a[8];
-            if (EPI == EPI_F32_RESID || EPI == EPI_DGELU) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int m = mb + pass * 64 + (rb + u) * 4 + (lane >> 4);
-                    const size_t o = (size_t)(m < g.M ? m : g.M - 1) * g.ldc + n;
-                    if (EPI == EPI_F32_RESID) r[u] = *reinterpret_cast<const float4*>(g.resF + o);
-                    else a[u] = *reinterpret_cast<const uint2*>(g.auxH + o);
-                }
-            }
-            float4 vv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) vv[u] = *reinterpret_cast<const float4*>(wl + ((rb + u) * 4 + (lane >> 4)) * V3_RS32 + c4 * 16);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int row = (rb + u) * 4 + (lane >> 4);
-                const int m = mb + pass * 64 + row;
-                if (m >= g.M) continue;
-                float4 v = vv[u];
-                const size_t o = (size_t)m * g.ldc + n;
-                if (EPI == EPI_F32) {
-                    *reinterpret_cast<float4*>(g.outF + o) = make_float4(v.x * g.alpha + b.x, v.y * g.alpha + b.y, v.z * g.alpha + b.z, v.w * g.alpha + b.w);
-                } else if (EPI == EPI_F32_RESID) {
-                    *reinterpret_cast<float4*>(g.outF + o) = make_float4(r[u].x + v.x + b.x, r[u].y + v.y + b.y, r[u].z + v.z + b.z, r[u].w + v.w + b.w);
-                } else if (EPI == EPI_F32_BF16) {
-                    v = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
-                    *reinterpret_cast<float4*>(g.outF + o) = v;
-                    uint2 pk; pk.x = pack2<F16>(v.x, v.y); pk.y = pack2<F16>(v.z, v.w);
-                    *reinterpret_cast<uint2*>(g.outH + o) = pk;
-                } else if (EPI == EPI_GELU32) {
-                    v = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
-                    uint2 pk; pk.x = pack2<F16>(v.x, v.y); pk.y = pack2<F16>(v.z, v.w);
-                    *reinterpret_cast<uint2*>(g.outH + o) = pk;
-                    *reinterpret_cast<float4*>(g.outF + o) = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
-                } else if (EPI == EPI_DGELU) {
-                    const float h0 = to_f32<F16>((bf16_t)(a[u].x & 0xFFFF)), h1 = to_f32<F16>((bf16_t)(a[u].x >> 16));
-                    const float h2 = to_f32<F16>((bf16_t)(a[u].y & 0xFFFF)), h3 = to_f32<F16>((bf16_t)(a[u].y >> 16));
-                    uint2 pk;
-                    pk.x = pack2<F16>(v.x * gelu_fast_grad(h0), v.y * gelu_fast_grad(h1));
-                    pk.y = pack2<F16>(v.z * gelu_fast_grad(h2), v.w * gelu_fast_grad(h3));
-                    *reinterpret_cast<uint2*>(g.outH + o) = pk;
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
+    V3Side<EPI> s0, s1;
+    v3_side_load<EPI>(s0, g, mb, n, lane);
+    v3_stage32(wl, acc, 0, lr, lg);
+    __builtin_amdgcn_wave_barrier();
+    v3_side_load<EPI>(s1, g, mb + 32, n, lane);
+    v3_store_batch<EPI, F16>(g, wl, s0, b, mb, 0, n, c4, lane);
+    v3_side_load<EPI>(s0, g, mb + 64, n, lane);
+    v3_store_batch<EPI, F16>(g, wl, s1, b, mb + 32, 32, n, c4, lane);
+    __builtin_amdgcn_wave_barrier();
+    v3_stage32(wl, acc, 2, lr, lg);
+    __builtin_amdgcn_wave_barrier();
+    v3_side_load<EPI>(s1, g, mb + 96, n, lane);
+    v3_store_batch<EPI, F16>(g, wl, s0, b, mb + 64, 0, n, c4, lane);
+    v3_store_batch<EPI, F16>(g, wl, s1, b, mb + 96, 32, n, c4, lane);
+    __builtin_amdgcn_wave_barrier();
 }
 
 #define V3_T 256
