@@ -25,7 +25,7 @@
 // other 32 keys of the tile live in lane ^ 32), and leaves P = exp2(c s - m) there.  The VALU work per score is the binding
 // resource of this kernel (16 MFMAs = 512 matrix-pipe cycles per tile against 4 cycles per VALU instruction), so: max on the
 // raw scores (v_max3), scale and max-subtract in one packed FMA, raw v_exp_f32, packed row sums, masking only when MASKED.
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
 template <bool MASKED>
 __device__ __forceinline__ void softmax_tile(f32x16_t (&st)[2], f32x16_t (&o)[2], float& m_run, float& l_run, int j0, int N, int lg) {
     if (MASKED) {
@@ -119,7 +119,6 @@ __global__ __launch_bounds__(256) void mhsa_fwd_kernel(const bf16_t* __restrict_
         const unsigned char* lk = lds[buf][0];
         const unsigned char* lv = lds[buf][1];
         f32x16_t st[NQ][2];
-        const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -298,25 +297,28 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_kernel(
         for (int qb = 0; qb < 2; ++qb) {  // 32-query sub-blocks of the tile
             f32x16_t s_, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s_[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
             for (int s = 0; s < 4; ++s) {
-                s_ = mfma32t<SF16>(lds_frag_rows(lds[buf][0], 32 * qb + lr, 2 * s + lg), kf[s], s_);
-                dp = mfma32(lds_frag_rows(lds[buf][1], 32 * qb + lr, 2 * s + lg), vf[s], dp);
+                s_ = mfma32t<SF16>(lds_frag_rows(lds[buf][0], 32 * qb + lr, 2 * s + lg), kf[s], s == 0 ? zero16 : s_);
+                dp = mfma32(lds_frag_rows(lds[buf][1], 32 * qb + lr, 2 * s + lg), vf[s], s == 0 ? zero16 : dp);
             }
-            // rows of the accumulators are queries 32 qb + mfma32_row(r, lg); column = this lane's key
+            // rows of the accumulators are queries 32 qb + mfma32_row(r, lg); column = this lane's key.  A lane whose key is
+            // >= N needs no masking here: its P / dS columns only feed the dK / dV rows of that key, which are never stored
+            // (its K / V rows are clamped copies of the last real key, so everything stays finite).
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 const int qq = 32 * qb + 8 * qd + 4 * lg;
                 const f32x4_t l2 = *reinterpret_cast<const f32x4_t*>(&lstat[buf][0][qq]);
                 const f32x4_t dd = *reinterpret_cast<const f32x4_t*>(&lstat[buf][1][qq]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 4; j += 2) {
                     const int r = 4 * qd + j;
-                    float p = exp2f(s_[r] * SCALE_LOG2E - l2[j]);
-                    p = key_valid_lane ? p : 0.f;
-                    s_[r] = p;
-                    dp[r] = p * (dp[r] - dd[j]);
+                    const f32x2_t c2 = {SCALE_LOG2E, SCALE_LOG2E}, nl = {-l2[j], -l2[j + 1]}, nd = {-dd[j], -dd[j + 1]};
+                    f32x2_t x = {s_[r], s_[r + 1]}, d2 = {dp[r], dp[r + 1]};
+                    x = __builtin_elementwise_fma(x, c2, nl);
+                    const f32x2_t pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                    d2 = pv * (d2 + nd);
+                    s_[r] = pv.x; s_[r + 1] = pv.y;
+                    dp[r] = d2.x; dp[r + 1] = d2.y;
                 }
             }
 #pragma unroll
@@ -402,18 +404,23 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const bf16_t* __restri
         for (int kb = 0; kb < 2; ++kb) {
             f32x16_t st, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
             for (int s = 0; s < 4; ++s) {
-                st = mfma32t<SF16>(lds_frag_rows(lds[buf][0], 32 * kb + lr, 2 * s + lg), qf[s], st);
-                dp = mfma32(lds_frag_rows(lds[buf][1], 32 * kb + lr, 2 * s + lg), dof[s], dp);
+                st = mfma32t<SF16>(lds_frag_rows(lds[buf][0], 32 * kb + lr, 2 * s + lg), qf[s], s == 0 ? zero16 : st);
+                dp = mfma32(lds_frag_rows(lds[buf][1], 32 * kb + lr, 2 * s + lg), dof[s], s == 0 ? zero16 : dp);
             }
+            const f32x2_t c2 = {SCALE_LOG2E, SCALE_LOG2E}, nl = {-l2, -l2}, nd = {-dd, -dd};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = j0 + 32 * kb + mfma32_row(r, lg);
-                float p = exp2f(st[r] * SCALE_LOG2E - l2);
-                p = key < N ? p : 0.f;
-                dp[r] = p * (dp[r] - dd);
+            for (int r = 0; r < 16; r += 2) {
+                f32x2_t x = {st[r], st[r + 1]}, d2 = {dp[r], dp[r + 1]};
+                x = __builtin_elementwise_fma(x, c2, nl);
+                f32x2_t pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                if (j0 + KVB > N) {  // keys >= N exist only in the last tile
+                    const int key = j0 + 32 * kb + mfma32_row(r, lg);
+                    pv.x = key < N ? pv.x : 0.f;
+                    pv.y = key + 1 < N ? pv.y : 0.f;
+                }
+                d2 = pv * (d2 + nd);
+                dp[r] = d2.x; dp[r + 1] = d2.y;
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {

@@ -67,3 +67,8 @@ __device__ __forceinline__ void pin_frags(const s16x8_t (&f)[4]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(f[s]));
 }
+
+// packed-fp32 helper type (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) and an all-zero accumulator: passing it as the C
+// operand of the first MFMA of a chain makes the instruction read the inline constant 0 instead of 16 zeroed registers
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#define zero16 (f32x16_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f})

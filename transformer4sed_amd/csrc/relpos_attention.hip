@@ -48,16 +48,31 @@ __device__ __forceinline__ void band_lstore(const BandRegs& b, unsigned char* ds
 __device__ __forceinline__ int bt_off(int row, int ch16) { return row * 384 + ((ch16 ^ ((row >> 1) & 7)) << 4); }
 // columns [CB, CB+192) of Pt_h [64][Rpad] -> LDS; CB % 8 == 0; out-of-range columns are clamped (never used
 // by valid pairs).  64 rows x 24 chunks = 1536 chunks = 6 per thread.
-__device__ __forceinline__ void bandT_stage(const bf16_t* Pth, int CB, int Rpad, unsigned char* dst, int tid) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int idx = tid + 256 * i;
-        const int row = idx / 24, ch = idx - row * 24;
-        int col = CB + ch * 8;
-        col = col < 0 ? 0 : (col + 8 > Rpad ? Rpad - 8 : col);
-        const uint4 v = *reinterpret_cast<const uint4*>(Pth + (size_t)row * Rpad + col);
-        *reinterpret_cast<uint4*>(dst + bt_off(row, ch)) = v;
-    }
+__device__ __forceinline__ uint4 bandT_load1(const bf16_t* Pth, int CB, int Rpad, int idx) {
+    const int row = idx / 24, ch = idx - row * 24;
+    int col = CB + ch * 8;
+    col = col < 0 ? 0 : (col + 8 > Rpad ? Rpad - 8 : col);
+    return *reinterpret_cast<const uint4*>(Pth + (size_t)row * Rpad + col);
+}
+__device__ __forceinline__ void bandT_gload(BandRegs& b, const bf16_t* Pth, int CB, int Rpad, int tid) {
+    b.x0 = bandT_load1(Pth, CB, Rpad, tid);
+    b.x1 = bandT_load1(Pth, CB, Rpad, tid + 256);
+    b.x2 = bandT_load1(Pth, CB, Rpad, tid + 512);
+    b.x3 = bandT_load1(Pth, CB, Rpad, tid + 768);
+    b.x4 = bandT_load1(Pth, CB, Rpad, tid + 1024);
+    b.x5 = bandT_load1(Pth, CB, Rpad, tid + 1280);
+}
+__device__ __forceinline__ void bandT_lstore1(unsigned char* dst, int idx, uint4 v) {
+    const int row = idx / 24, ch = idx - row * 24;
+    *reinterpret_cast<uint4*>(dst + bt_off(row, ch)) = v;
+}
+__device__ __forceinline__ void bandT_lstore(const BandRegs& b, unsigned char* dst, int tid) {
+    bandT_lstore1(dst, tid, b.x0);
+    bandT_lstore1(dst, tid + 256, b.x1);
+    bandT_lstore1(dst, tid + 512, b.x2);
+    bandT_lstore1(dst, tid + 768, b.x3);
+    bandT_lstore1(dst, tid + 1024, b.x4);
+    bandT_lstore1(dst, tid + 1280, b.x5);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -124,9 +139,8 @@ __global__ __launch_bounds__(256) void relpos_fwd_kernel(const bf16_t* __restric
         for (int blk = 0; blk < 3; ++blk) {
             f32x16_t g;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) g[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) g = mfma32t<F16>(lds_frag_rows(lb, band_row0 + 32 * blk + lr, 2 * s + lg), qvf[s], g);
+            for (int s = 0; s < 4; ++s)
+                g = mfma32t<F16>(lds_frag_rows(lb, band_row0 + 32 * blk + lr, 2 * s + lg), qvf[s], s == 0 ? zero16 : g);
 #pragma unroll
             for (int r = 0; r < 16; ++r) gs[(32 * blk + mfma32_row(r, lg)) * 32 + lr] = g[r];
         }
@@ -134,34 +148,41 @@ __global__ __launch_bounds__(256) void relpos_fwd_kernel(const bf16_t* __restric
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) st[kb] = mfma32t<F16>(lds_frag_rows(lk, 32 * kb + lr, 2 * s + lg), quf[s], st[kb]);
+            for (int s = 0; s < 4; ++s)
+                st[kb] = mfma32t<F16>(lds_frag_rows(lk, 32 * kb + lr, 2 * s + lg), quf[s], s == 0 ? zero16 : st[kb]);
         }
         __syncthreads();  // G^T visible (wave-private buffer, but keep it simple and safe)
+        // raw score = AC + skewed BD; max on raw scores, scale + max-subtract as one packed FMA, raw v_exp_f32
         float mloc = -1e30f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 16; r += 2) {
                 const int jj = 32 * kb + mfma32_row(r, lg);
-                float sv = (st[kb][r] + gs[(jj - lr + 31) * 32 + lr]) * SCALE_LOG2E;
-                sv = (j0 + jj < T) ? sv : -1e30f;
-                st[kb][r] = sv;
-                mloc = fmaxf(mloc, sv);
+                float s0 = st[kb][r] + gs[(jj - lr + 31) * 32 + lr], s1 = st[kb][r + 1] + gs[(jj - lr + 32) * 32 + lr];
+                if (j0 + KVB > T) {  // keys >= T exist only in the last tile
+                    s0 = (j0 + jj < T) ? s0 : -1e30f;
+                    s1 = (j0 + jj + 1 < T) ? s1 : -1e30f;
+                }
+                st[kb][r] = s0; st[kb][r + 1] = s1;
+                mloc = max3_raw(mloc, s0, s1);
             }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = exp2f(m_run - m_new);
-        float psum = 0.f;
+        const float m_new = fmaxf(m_run, mloc * SCALE_LOG2E);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        const f32x2_t c2 = {SCALE_LOG2E, SCALE_LOG2E}, nm2 = {-m_new, -m_new};
+        f32x2_t ps2 = {0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(st[kb][r] - m_new);
-                st[kb][r] = p;
-                psum += p;
+            for (int r = 0; r < 16; r += 2) {
+                f32x2_t x = {st[kb][r], st[kb][r + 1]};
+                x = __builtin_elementwise_fma(x, c2, nm2);
+                const f32x2_t pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                st[kb][r] = pv.x; st[kb][r + 1] = pv.y;
+                ps2 += pv;
             }
+        float psum = ps2.x + ps2.y;
         psum += __shfl_xor(psum, 32, 64);
         l_run = l_run * alpha + psum;
         m_run = m_new;
@@ -264,30 +285,38 @@ __global__ __launch_bounds__(256) void relpos_bwd_dkdv_kernel(
         for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
     float* gs = lds_g[wave];
     const int ntiles = (T + 63) / 64;
-    for (int t = 0; t < ntiles; ++t) {
+    // next tile's operands travel HBM -> registers while the current tile is being consumed, registers -> LDS afterwards
+    TileRegs r0, r1, r2, r3, r4;
+    BandRegs rb;
+    float rstat = 0.f;
+    auto gload = [&](int t) {
         const int i0 = t * 64;
-        {
-            TileRegs r0, r1, r2, r3, r4;
-            BandRegs rb;
-            tile_gload(r0, Qu + hb, i0, T, HD, 0, tid);
-            tile_gload(r1, Qv + hb, i0, T, HD, 0, tid);
-            tile_gload(r2, dOh + hb, i0, T, HD, 0, tid);
-            tile_gload(r3, Qut + hbt, 0, HD, Tpad, i0, tid);
-            tile_gload(r4, dOt + hbt, 0, HD, Tpad, i0, tid);
-            band_gload(rb, Ph, J0 - (i0 + 63) + T - 1, R, tid);
-            tile_lstore_rows(r0, lds[0], tid);
-            tile_lstore_rows(r1, lds[1], tid);
-            tile_lstore_rows(r2, lds[2], tid);
-            tile_lstore_cols(r3, lds[3], tid);
-            tile_lstore_cols(r4, lds[4], tid);
-            band_lstore(rb, lds_band, tid);
-            if (tid < 128) {
-                const int qi = i0 + (tid & 63);
-                const float* src = (tid < 64) ? LSE : Dv;
-                lstat[tid >> 6][tid & 63] = qi < T ? src[(size_t)bh * T + qi] : (tid < 64 ? 1e30f : 0.f);
-            }
+        tile_gload(r0, Qu + hb, i0, T, HD, 0, tid);
+        tile_gload(r1, Qv + hb, i0, T, HD, 0, tid);
+        tile_gload(r2, dOh + hb, i0, T, HD, 0, tid);
+        tile_gload(r3, Qut + hbt, 0, HD, Tpad, i0, tid);
+        tile_gload(r4, dOt + hbt, 0, HD, Tpad, i0, tid);
+        band_gload(rb, Ph, J0 - (i0 + 63) + T - 1, R, tid);
+        if (tid < 128) {
+            const int qi = i0 + (tid & 63);
+            const float* src = (tid < 64) ? LSE : Dv;
+            rstat = qi < T ? src[(size_t)bh * T + qi] : (tid < 64 ? 1e30f : 0.f);  // L2 = +big -> P = 0 for padded queries
         }
-        __syncthreads();
+    };
+    auto lstore = [&]() {
+        tile_lstore_rows(r0, lds[0], tid);
+        tile_lstore_rows(r1, lds[1], tid);
+        tile_lstore_rows(r2, lds[2], tid);
+        tile_lstore_cols(r3, lds[3], tid);
+        tile_lstore_cols(r4, lds[4], tid);
+        band_lstore(rb, lds_band, tid);
+        if (tid < 128) lstat[tid >> 6][tid & 63] = rstat;
+    };
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) gload(t + 1);
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             const int rowoff = 32 * (wave - qb + 1);
@@ -296,36 +325,36 @@ __global__ __launch_bounds__(256) void relpos_bwd_dkdv_kernel(
             for (int blk = 0; blk < 2; ++blk) {
                 f32x16_t g;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) g[r] = 0.f;
-#pragma unroll
                 for (int s = 0; s < 4; ++s)
                     g = mfma32t<SF16>(lds_frag_rows(lds[1], 32 * qb + lr, 2 * s + lg),
-                                      lds_frag_rows(lds_band, rowoff + 32 * blk + lr, 2 * s + lg), g);
+                                      lds_frag_rows(lds_band, rowoff + 32 * blk + lr, 2 * s + lg), s == 0 ? zero16 : g);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) gs[mfma32_row(r, lg) * 65 + 32 * blk + lr] = g[r];
             }
             f32x16_t s_, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s_[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
             for (int s = 0; s < 4; ++s) {
-                s_ = mfma32t<SF16>(lds_frag_rows(lds[0], 32 * qb + lr, 2 * s + lg), kf[s], s_);
-                dp = mfma32(lds_frag_rows(lds[2], 32 * qb + lr, 2 * s + lg), vf[s], dp);
+                s_ = mfma32t<SF16>(lds_frag_rows(lds[0], 32 * qb + lr, 2 * s + lg), kf[s], s == 0 ? zero16 : s_);
+                dp = mfma32(lds_frag_rows(lds[2], 32 * qb + lr, 2 * s + lg), vf[s], s == 0 ? zero16 : dp);
             }
             __syncthreads();
+            // (a lane whose key is >= T needs no masking: its columns only feed dK / dV rows that are never stored)
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 const int qq = 32 * qb + 8 * qd + 4 * lg;
                 const f32x4_t l2 = *reinterpret_cast<const f32x4_t*>(&lstat[0][qq]);
                 const f32x4_t dd = *reinterpret_cast<const f32x4_t*>(&lstat[1][qq]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 4; j += 2) {
                     const int r = 4 * qd + j, ii = mfma32_row(r, lg);
-                    const float bd = gs[ii * 65 + lr - ii + 31];
-                    float p = exp2f((s_[r] + bd) * SCALE_LOG2E - l2[j]);
-                    p = key_valid_lane ? p : 0.f;
-                    s_[r] = p;
-                    dp[r] = p * (dp[r] - dd[j]);
+                    const f32x2_t bd = {gs[ii * 65 + lr - ii + 31], gs[(ii + 1) * 65 + lr - ii + 30]};
+                    const f32x2_t c2 = {SCALE_LOG2E, SCALE_LOG2E}, nl = {-l2[j], -l2[j + 1]}, nd = {-dd[j], -dd[j + 1]};
+                    f32x2_t x = {s_[r], s_[r + 1]}, d2 = {dp[r], dp[r + 1]};
+                    x = __builtin_elementwise_fma(x + bd, c2, nl);
+                    const f32x2_t pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                    d2 = pv * (d2 + nd);
+                    s_[r] = pv.x; s_[r + 1] = pv.y;
+                    dp[r] = d2.x; dp[r + 1] = d2.y;
                 }
             }
 #pragma unroll
@@ -337,6 +366,10 @@ __global__ __launch_bounds__(256) void relpos_bwd_dkdv_kernel(
                     dk[db] = mfma32(dsf, lds_frag_cols(lds[3], 32 * db + lr, 8 * qb + 4 * s + lg), dk[db]);
                 }
             }
+            __syncthreads();
+        }
+        if (t + 1 < ntiles) {
+            lstore();
             __syncthreads();
         }
     }
@@ -395,31 +428,37 @@ __global__ __launch_bounds__(256) void relpos_bwd_dq_kernel(
     float* gs = lds_g[wave];
     const int band_row0 = 32 * (3 - wave);
     const int ntiles = (T + KVB - 1) / KVB;
-    for (int t = 0; t < ntiles; ++t) {
+    // next tile's operands travel HBM -> registers while the current tile is being consumed, registers -> LDS afterwards
+    TileRegs r0, r1, r2;
+    BandRegs rb, rbt;
+    auto gload = [&](int t) {
         const int j0 = t * KVB;
         const int RB = j0 - I0 - 127 + T - 1;  // multiple of 8 because T % 8 == 0
-        {
-            TileRegs r0, r1, r2;
-            BandRegs rb;
-            tile_gload(r0, K + hb, j0, T, HD, 0, tid);
-            tile_gload(r1, V + hb, j0, T, HD, 0, tid);
-            tile_gload(r2, Kt + hbt, 0, HD, Tpad, j0, tid);
-            band_gload(rb, Ph, RB, R, tid);
-            tile_lstore_rows(r0, lds[0], tid);
-            tile_lstore_rows(r1, lds[1], tid);
-            tile_lstore_cols(r2, lds[2], tid);
-            band_lstore(rb, lds_band, tid);
-            bandT_stage(Pth, RB, Rpad, lds_bandT, tid);
-        }
-        __syncthreads();
+        tile_gload(r0, K + hb, j0, T, HD, 0, tid);
+        tile_gload(r1, V + hb, j0, T, HD, 0, tid);
+        tile_gload(r2, Kt + hbt, 0, HD, Tpad, j0, tid);
+        band_gload(rb, Ph, RB, R, tid);
+        bandT_gload(rbt, Pth, RB, Rpad, tid);
+    };
+    auto lstore = [&]() {
+        tile_lstore_rows(r0, lds[0], tid);
+        tile_lstore_rows(r1, lds[1], tid);
+        tile_lstore_cols(r2, lds[2], tid);
+        band_lstore(rb, lds_band, tid);
+        bandT_lstore(rbt, lds_bandT, tid);
+    };
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int j0 = t * KVB;
+        if (t + 1 < ntiles) gload(t + 1);
 #pragma unroll
         for (int blk = 0; blk < 3; ++blk) {
             f32x16_t g;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) g[r] = 0.f;
-#pragma unroll
             for (int s = 0; s < 4; ++s)
-                g = mfma32t<SF16>(lds_frag_rows(lds_band, band_row0 + 32 * blk + lr, 2 * s + lg), qvf[s], g);
+                g = mfma32t<SF16>(lds_frag_rows(lds_band, band_row0 + 32 * blk + lr, 2 * s + lg), qvf[s], s == 0 ? zero16 : g);
 #pragma unroll
             for (int r = 0; r < 16; ++r) gs[(32 * blk + mfma32_row(r, lg)) * 32 + lr] = g[r];
         }
@@ -427,11 +466,9 @@ __global__ __launch_bounds__(256) void relpos_bwd_dq_kernel(
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { st[kb][r] = 0.f; dp[kb][r] = 0.f; }
-#pragma unroll
             for (int s = 0; s < 4; ++s) {
-                st[kb] = mfma32t<SF16>(lds_frag_rows(lds[0], 32 * kb + lr, 2 * s + lg), quf[s], st[kb]);
-                dp[kb] = mfma32(lds_frag_rows(lds[1], 32 * kb + lr, 2 * s + lg), dof[s], dp[kb]);
+                st[kb] = mfma32t<SF16>(lds_frag_rows(lds[0], 32 * kb + lr, 2 * s + lg), quf[s], s == 0 ? zero16 : st[kb]);
+                dp[kb] = mfma32(lds_frag_rows(lds[1], 32 * kb + lr, 2 * s + lg), dof[s], s == 0 ? zero16 : dp[kb]);
             }
         }
         __syncthreads();
@@ -440,7 +477,7 @@ __global__ __launch_bounds__(256) void relpos_bwd_dq_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int jj = 32 * kb + mfma32_row(r, lg);
-                float p = exp2f((st[kb][r] + gs[(jj - lr + 31) * 32 + lr]) * SCALE_LOG2E - l2);
+                float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r] + gs[(jj - lr + 31) * 32 + lr], SCALE_LOG2E, -l2));
                 p = (qvalid && (j0 + jj < T)) ? p : 0.f;
                 dp[kb][r] = p * (dp[kb][r] - dd);  // dS^T[key, q]
             }
@@ -483,6 +520,10 @@ __global__ __launch_bounds__(256) void relpos_bwd_dq_kernel(
             }
         }
         __syncthreads();
+        if (t + 1 < ntiles) {
+            lstore();
+            __syncthreads();
+        }
     }
     // outputs
     if (qvalid) {
