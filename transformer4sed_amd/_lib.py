@@ -46,7 +46,8 @@ class _Lib:
         # torch must initialise ITS HIP runtime first: loading libsed_hip.so before torch pulls in a second copy of
         # libamdhip64 (system ROCm vs the one bundled with torch) and every launch then fails with hipErrorNoDevice.
         import torch  # noqa: F401
-        self._dll = ctypes.CDLL(LIB_PATH)
+        # SED_HIP_LIB: developer A/B switch to another build of the same library (tools/ablate)
+        self._dll = ctypes.CDLL(os.environ.get("SED_HIP_LIB") or LIB_PATH)
         self.protos = parse_header()
         for name, args in self.protos.items():
             try:

@@ -70,8 +70,11 @@ __device__ __forceinline__ void softmax_tile(f32x16_t (&st)[2], f32x16_t (&o)[2]
 
 // NQ = query blocks (of 32) per wave: 2 for the bulk of the sequence (256 queries per workgroup: every K / V^T fragment
 // read from LDS feeds two MFMAs and each staged K/V tile serves twice as many queries), 1 for a short tail block.
+#ifndef WPE
+#define WPE 3  // 167 VGPRs: three waves per SIMD (four would spill)
+#endif
 template <bool F16, int NQ>
-__global__ __launch_bounds__(256) void mhsa_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void mhsa_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
                                                        float* __restrict__ LSE, int N, int Npad, int H, int q_begin) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][KVB * 128];  // [buf][K | Vt]
