@@ -188,9 +188,17 @@ def main():
         fl = sum(v["flops"] for v in summ.values())
         n = sum(v["launches"] for v in summ.values())
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        line["roofline"] = {"kernel": "gemm_nt_kernel<EPI,F16> (all GEMM launches of the step: linears, qkv, dX, dW)",
+        by = sum(v["bytes"] for v in summ.values())
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r1_gemm_traffic.json")   # PMC passes (tools/gemm_traffic.py), offline
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("avg_bytes_per_launch")
+            traffic_src = "profiles/r1_gemm_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes over this command)"
+        line["roofline"] = {"kernel": "gemm_nt_v3_kernel<EPI,F16> / gemm_nt_kernel (all GEMM launches of the step: linears, qkv, "
+                                      "dX, split-K dW)",
                             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                            "traffic_source": traffic_src, "alg_bytes_per_launch": round(by / max(1, n)),
                             "launches_per_step": n // max(1, a.steps), "avg_launch_ms": round(ms / max(1, n), 4),
                             "gemm_share_of_step": round(ms / (1000 * dt), 3),
                             "flops_per_launch": round(fl / max(1, n) / 1e9, 3)}

@@ -35,15 +35,16 @@ class KernelTimer:
 
     def __init__(self, names):
         self.names = set(names)
-        self.records = []  # (name, start_event, end_event, flops)
+        self.records = []  # (name, start_event, end_event, flops, algorithmic bytes)
 
     def summarize(self):
         out = {}
-        for name, e0, e1, fl in self.records:
-            d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
+        for name, e0, e1, fl, by in self.records:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["flops"] += fl
+            d["bytes"] += by
         return out
 
 
@@ -58,6 +59,19 @@ def _flops_of(name, args):
     return 0.0
 
 
+def _bytes_of(name, args):
+    """Algorithmic HBM bytes of one GEMM launch: operands once + every output / side input once."""
+    if name == "sed_gemm_nt":
+        M, N, K, epi = args[2], args[3], args[4], args[7]
+        out = {0: 4, 1: 8, 2: 2, 3: 2 * ((args[11] is not None) + (args[12] is not None)), 4: 4, 5: 8, 7: 6, 8: 6}.get(epi, 4)
+        return 2.0 * K * (M + N) + float(out) * M * N
+    if name == "sed_gemm_qkv":
+        M, K, D = args[3], args[4], args[5] * 64
+        nout = sum(a is not None for a in args[8:16])
+        return 2.0 * K * (M + 3 * D) + 2.0 * M * D * nout
+    return 0.0
+
+
 def call(name, *args):
     conv = [(_ptr(a) if (a is None or isinstance(a, torch.Tensor)) else a) for a in args]
     if TIMER is not None and name in TIMER.names:
@@ -65,7 +79,7 @@ def call(name, *args):
         e0.record()
         lib().call(name, *conv, torch.cuda.current_stream().cuda_stream)
         e1.record()
-        TIMER.records.append((name, e0, e1, _flops_of(name, args)))
+        TIMER.records.append((name, e0, e1, _flops_of(name, args), _bytes_of(name, args)))
         return
     lib().call(name, *conv, torch.cuda.current_stream().cuda_stream)
 
