@@ -7,11 +7,11 @@ import random
 import numpy as np
 import torch
 
-from .ops import call
+from .ops import call, h2d
 
 
 def _i32(x, dev):
-    return torch.as_tensor(np.asarray(x, dtype=np.int32), device=dev)
+    return h2d(np.asarray(x, dtype=np.int32), torch.int32, dev)
 
 
 def label_shift_of(shift, net_pooling):
@@ -28,7 +28,7 @@ def roll_mix(x, shifts, perm=None, c=None, clamp01=False):
     if perm is not None:
         pm = _i32(perm, x.device)
         c = 1.0 if c is None else float(c)
-        cm = torch.tensor([[c, 1.0 - c]] * B, dtype=torch.float32, device=x.device)
+        cm = h2d([[c, 1.0 - c]] * B, torch.float32, x.device)
     call("sed_roll_mix", x, out, sh, pm, cm, B, Fd, T, 1 if clamp01 else 0)
     return out
 
@@ -103,9 +103,9 @@ def warp_filt(features, warp=None, add=None):
     out = torch.empty_like(x)
     k = lam = None
     if warp is not None:
-        k = torch.as_tensor(warp[0], device=x.device)
-        lam = torch.as_tensor(warp[1], device=x.device)
-    a = None if add is None else add.to(x.device).contiguous()
+        k = h2d(warp[0], torch.int32, x.device)
+        lam = h2d(warp[1], torch.float32, x.device)
+    a = None if add is None else h2d(add, torch.float32, x.device)
     call("sed_warp_filt", x, out, k, lam, a, B, Fd, T)
     return out
 

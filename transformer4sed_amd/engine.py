@@ -16,7 +16,7 @@ import torch
 from . import ops
 import os
 
-from .ops import BF16, F16, F32, call, gemm_nt, gemm_dw, pad64, transpose_bf16, to_bf16_, is_f16, split3, o_kind
+from .ops import BF16, F16, F32, call, h2d, gemm_nt, gemm_dw, pad64, transpose_bf16, to_bf16_, is_f16, split3, o_kind
 from .ops import EPI_F32, EPI_F32_RESID, EPI_BF16, EPI_GELU, EPI_DGELU, EPI_F32_BF16, EPI_GELU32
 
 D = 768
@@ -326,7 +326,7 @@ class SedEngine:
                     lefts[w], tps[w], offs[w] = round(starts[w] * (Tdec / T)), tpw, row + k * B * tpw
                 row += len(wis) * B * tpw
             packed = chunks[0] if len(chunks) == 1 else torch.cat(chunks, 0)
-            i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+            i32 = lambda v: h2d(v, torch.int32, dev)
             call("sed_window_mix", packed, i32(lefts), i32(tps), i32(offs), len(starts), xg, float(mix_rate), B, Tdec,
                  ratio)
         out["frame_before_mask"] = xg

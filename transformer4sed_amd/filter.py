@@ -2,7 +2,7 @@
 (src/postprocess/filter.py:4-36 and the scipy calls at src/codec/decoder.py:91,94)."""
 import torch
 
-from .ops import call
+from .ops import call, h2d
 
 
 def _run(x, sizes, mode, scale=None):
@@ -13,7 +13,7 @@ def _run(x, sizes, mode, scale=None):
         raise ValueError("Length of median_filter_sizes must match the number of classes")
     x = x.contiguous().float()
     out = torch.empty_like(x)
-    sz = torch.tensor(list(sizes), dtype=torch.int32, device=x.device)
+    sz = h2d(list(sizes), torch.int32, x.device)
     sc = None if scale is None else scale.contiguous().float()
     call("sed_median_filter", x, out, sz, sc, B, T, C, mode)
     return out

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .ops import call
+from .ops import call, h2d
 
 
 def kaldi_mel_banks(fmin, fmax, n_mels=128, n_fft=1024, sr=32000):
@@ -57,7 +57,7 @@ class PasstFeatureExtractor(nn.Module):
                     rng[m] = (idx[0], idx[-1] + 1)
             if len(self._banks) > 64:
                 self._banks.clear()
-            self._banks[key] = (w.contiguous().to(dev), torch.from_numpy(rng).to(dev))
+            self._banks[key] = (h2d(w, torch.float32, dev), h2d(rng, torch.int32, dev))
         return self._banks[key]
 
     def forward(self, x, fmin_fmax=None):

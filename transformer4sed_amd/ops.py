@@ -20,6 +20,18 @@ def is_f16(t):
 EPI_F32, EPI_F32_RESID, EPI_BF16, EPI_GELU, EPI_DGELU, EPI_ATOMIC, EPI_QKV, EPI_F32_BF16, EPI_GELU32 = range(9)
 
 
+def h2d(x, dtype, dev):
+    """Small host array -> device tensor WITHOUT a host/stream synchronisation: staged in pinned memory and copied with
+    non_blocking=True (torch.tensor(list, device=...) / .to(device) from pageable memory block the host until the stream has
+    drained, which serialises the Python schedule against the GPU at every call)."""
+    import numpy as np
+    t = x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))
+    t = t.to(dtype).contiguous()
+    if t.device.type != "cpu":
+        return t.to(dev)
+    return t.pin_memory().to(dev, non_blocking=True)
+
+
 def _ptr(t):
     if t is None:
         return None
