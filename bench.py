@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU (multiple of 12 ratio 4:4:4 not required: 11/11/10)")
     ap.add_argument("--depth", type=int, default=12)
+    ap.add_argument("--mode", default="finetune2", choices=["finetune2", "val"],
+                    help="finetune2 = the headline train step (default); val = Trainer.validation's per-batch body "
+                         "(student + teacher, 17 sliding windows, score tables + event decoding), SURVEY 8(f) rank 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     a = ap.parse_args()
@@ -142,8 +145,23 @@ def main():
     if world > 1:
         trainer.ddp = GradBucketReducer(net, opt)
 
-    def step():
-        return trainer.finetune_step(wav, labels.clone())
+    if a.mode == "val":
+        from transformer4sed_amd.evaluation import Encoder, Evaluator
+        enc = Encoder(["Alarm_bell_ringing", "Blender", "Cat", "Dishes", "Dog", "Electric_shaver_toothbrush", "Frying",
+                       "Running_water", "Speech", "Vacuum_cleaner"], audio_len=10, frame_len=1024, frame_hop=320, net_pooling=1,
+                      sr=32000)
+        vcfg = {"training": {"median_window": [5, 20, 5, 5, 5, 20, 20, 20, 5, 20], "filter_type": "median", "weak_mask": True},
+                "PaSST_SED": {"val_kwargs": {"encoder_win": True, "win_param": [512, 31], "mix_rate": 0.5, "temp_w": 0.5}}}
+        pad_mask = torch.zeros(B, 1000, dtype=torch.bool)
+        paths = [f"/synthetic/val/clip_{rank}_{i}.wav" for i in range(B)]
+
+        def step():
+            ev = Evaluator(net, ema_net, enc, vcfg)
+            ev.step(wav, labels, pad_mask, paths)
+            return {"loss_total": torch.tensor(float(len(ev.scores.post_student)))}
+    else:
+        def step():
+            return trainer.finetune_step(wav, labels.clone())
 
     for _ in range(a.warmup):
         step()
@@ -169,8 +187,11 @@ def main():
         raise SystemExit("non-finite loss in the timed region")
     clips = a.steps * B * world
     value = clips / dt
+    gflop_clip, gflop_batch = (GFLOP_PER_CLIP, GFLOP_PER_BATCH) if a.mode == "finetune2" else (2 * 2264.3, 2 * 7.07)
     line = {
-        "metric": "clips/sec (10 s clips) MAT-SED finetune2 train step", "value": round(value, 3), "unit": "clips/s",
+        "metric": "clips/sec (10 s clips) MAT-SED finetune2 train step" if a.mode == "finetune2" else
+                  "clips/sec (10 s clips) MAT-SED validation step (student + teacher, 17 windows, score tables + events)",
+        "value": round(value, 3), "unit": "clips/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * dt / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16 fwd / bf16 bwd MFMA operands, fp32 accumulate + residual stream",
@@ -180,7 +201,7 @@ def main():
                    "model": f"PaSST_SED depth {a.depth} + 3x TransformerXL context net (100.95 M params)",
                    "global_batch": B * world, "per_gpu_batch": B, "seq_len": "1190 encoder tokens / 1000 decoder frames",
                    "parallelism": f"dp{world}", "final_loss": loss},
-        "step_mfma_frac": round(value / world * (GFLOP_PER_CLIP + GFLOP_PER_BATCH / B) / 1000.0 / PEAK_BF16_TFLOPS, 4),
+        "step_mfma_frac": round(value / world * (gflop_clip + gflop_batch / B) / 1000.0 / PEAK_BF16_TFLOPS, 4),
     }
     if rank == 0 and timer is not None:
         summ = timer.summarize()
@@ -202,7 +223,12 @@ def main():
                             "launches_per_step": n // max(1, a.steps), "avg_launch_ms": round(ms / max(1, n), 4),
                             "gemm_share_of_step": round(ms / (1000 * dt), 3),
                             "flops_per_launch": round(fl / max(1, n) / 1e9, 3)}
-    if rank == 0 and not a.no_cpu_baseline:
+    if a.mode == "val":
+        line["config"]["workload"] = ("MAT-SED validation batch (recipes/desed/finetune/train.py:296-366): eval frontend, student and "
+                                      "EMA teacher forward with val_kwargs (17 windows of 512 frames, step 31, temp 0.5), soft-masked "
+                                      "scipy-median score tables and half-point event decoding")
+        line["config"].pop("final_loss", None)
+    if rank == 0 and not a.no_cpu_baseline and a.mode == "finetune2":
         line["cpu_baseline"] = cpu_baseline(a.depth)
     if rank == 0:
         print(json.dumps(line), flush=True)

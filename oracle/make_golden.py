@@ -604,8 +604,49 @@ def gen_trainstep():
     save("trainstep", **out)
 
 
+def gen_evalpath():
+    """Score tables and event lists from the reference's own decode functions (src/codec/decoder.py:15-103) on synthetic
+    posteriors.  pandas 2 dropped DataFrame.append and scipy dropped the ndimage.filters namespace the reference still uses:
+    both are aliased to their documented replacements for the duration of the calls."""
+    import pandas as pd
+    from scipy import ndimage
+    from oracle import eval_oracle as EO
+    had_append = hasattr(pd.DataFrame, "append")
+    if not had_append:
+        pd.DataFrame.append = lambda self, other, ignore_index=False: pd.concat([self, other], ignore_index=ignore_index)
+    if not hasattr(ndimage, "filters"):
+        ndimage.filters = ndimage
+    try:
+        from src.codec.decoder import batched_decode_preds, decode_pred_batch_fast
+        from src.codec.encoder import Encoder
+        enc = Encoder(EO.LABELS, audio_len=10, frame_len=1024, frame_hop=320, net_pooling=1, sr=32000)
+        B = 4
+        strong_np, weak_np = EO.synth_posteriors(B, seed=11)
+        strong, weak = torch.from_numpy(strong_np), torch.from_numpy(weak_np)
+        names = [f"/data/val/clip_{i:02d}.wav" for i in range(B)]
+        sizes = [int(i / 156 * 1000) for i in [5, 20, 5, 5, 5, 20, 20, 20, 5, 20]]
+        out = dict(sizes=np.asarray(sizes), names=np.asarray(names))
+        for tag, mask, ftype in (("soft_median", True, "median"), ("nomask_median", False, "median"), ("soft_max", True, "max")):
+            raw, post = batched_decode_preds(strong_preds=strong.clone(), filenames=names, encoder=enc, filter=sizes,
+                                             weak_preds=weak.clone(), need_weak_mask=mask, filter_type=ftype)
+            assert list(raw) == [f"clip_{i:02d}" for i in range(B)]
+            out[f"{tag}_columns"] = np.asarray(list(raw["clip_00"].columns))
+            out[f"{tag}_raw"] = np.stack([raw[k].to_numpy() for k in raw])        # [B, T, 2 + C] float64
+            out[f"{tag}_post"] = np.stack([post[k].to_numpy() for k in post])
+        for th in (0.5, 0.3):
+            dfs = decode_pred_batch_fast(strong.clone(), weak.clone(), names, enc, [th], sizes)
+            df = dfs[th]
+            out[f"fast{th}_label"] = df["event_label"].to_numpy().astype(str)
+            out[f"fast{th}_onoff"] = df[["onset", "offset"]].to_numpy().astype(np.float64)
+            out[f"fast{th}_file"] = df["filename"].to_numpy().astype(str)
+    finally:
+        if not had_append:
+            del pd.DataFrame.append
+    save("evalpath", **out)
+
+
 GENS = dict(frontend=gen_frontend, augment=gen_augment, micro=gen_micro, full=gen_full, full12=gen_full12,
-            schedule=gen_schedule, postprocess=gen_postprocess, losses=gen_losses, trainstep=gen_trainstep)
+            schedule=gen_schedule, postprocess=gen_postprocess, losses=gen_losses, trainstep=gen_trainstep, evalpath=gen_evalpath)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

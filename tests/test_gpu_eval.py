@@ -1,0 +1,102 @@
+"""Evaluation path on the device against the reference's decode functions (tests/golden/evalpath.npz) and
+the oracle."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+from oracle import eval_oracle as EO  # noqa: E402  (checker only)
+from transformer4sed_amd import synth  # noqa: E402
+from transformer4sed_amd.evaluation import (Encoder, Evaluator, WeakF1Macro, batched_decode_preds, decode_pred_batch_fast,  # noqa: E402
+                                            read_sed_scores, write_sed_scores)
+
+
+def _enc():
+    return Encoder(EO.LABELS, audio_len=10, frame_len=1024, frame_hop=320, net_pooling=1, sr=32000)
+
+
+def test_score_tables_and_events_vs_reference(golden, tmp_path):
+    g = golden("evalpath")
+    strong_np, weak_np = EO.synth_posteriors(4, seed=11)
+    strong, weak = torch.from_numpy(strong_np).to(DEV), torch.from_numpy(weak_np).to(DEV)
+    names, sizes, enc = g["names"].tolist(), g["sizes"].tolist(), _enc()
+    for tag, mask, ftype in (("soft_median", True, "median"), ("nomask_median", False, "median"), ("soft_max", True, "max")):
+        raw, post = batched_decode_preds(strong_preds=strong, filenames=names, encoder=enc, filter=sizes, weak_preds=weak,
+                                         need_weak_mask=mask, filter_type=ftype)
+        assert list(raw) == [f"clip_{i:02d}" for i in range(4)]
+        assert list(raw["clip_00"].columns) == g[f"{tag}_columns"].tolist()
+        assert np.array_equal(np.stack([raw[k].to_numpy() for k in raw]), g[f"{tag}_raw"]), tag       # bit-exact
+        assert np.array_equal(np.stack([post[k].to_numpy() for k in post]), g[f"{tag}_post"]), tag
+    write_sed_scores(post, tmp_path / "post")
+    back = read_sed_scores(tmp_path / "post")
+    assert list(back) == list(post) and np.allclose(back["clip_03"].to_numpy(), post["clip_03"].to_numpy(), rtol=0, atol=1e-12)
+    for th in (0.5, 0.3):
+        df = decode_pred_batch_fast(strong, weak, names, enc, [th], sizes)[th]
+        assert df["event_label"].tolist() == g[f"fast{th}_label"].tolist()
+        assert df["filename"].tolist() == g[f"fast{th}_file"].tolist()
+        assert np.array_equal(df[["onset", "offset"]].to_numpy().astype(np.float64), g[f"fast{th}_onoff"])
+    # live oracle on another draw, ragged batch (fewer clips), no filter
+    s2, w2 = EO.synth_posteriors(3, seed=5)
+    raw, post = batched_decode_preds(torch.from_numpy(s2).to(DEV), ["a.wav", "b.wav", "c.wav"], enc, filter=None,
+                                     weak_preds=torch.from_numpy(w2).to(DEV), need_weak_mask=True)
+    r_o, _, _ = EO.batched_decode(s2, w2, sizes, need_weak_mask=True)
+    assert np.array_equal(raw["b"].to_numpy()[:, 2:], r_o[1].astype(np.float64)) and post["b"] is raw["b"]
+    with pytest.raises(IndexError):
+        batched_decode_preds(strong, names[:2], enc, filter=sizes)
+    assert batched_decode_preds(strong[:0], [], enc, filter=sizes) == ({}, {})
+
+
+def test_weak_f1_macro():
+    from sklearn.metrics import f1_score
+    rng = np.random.RandomState(0)
+    m = WeakF1Macro(10)
+    P, T = [], []
+    for _ in range(3):
+        p = rng.rand(7, 10).astype(np.float32); t = (rng.rand(7, 10) > 0.6)
+        t[:, 4] = False; p[:, 4] = 0.1                       # a class with neither positives nor predictions scores 0
+        m.update(torch.from_numpy(p).to(DEV), torch.from_numpy(t).to(DEV))
+        P.append(p > 0.5); T.append(t)
+    want = f1_score(np.concatenate(T), np.concatenate(P), average="macro", zero_division=0)
+    assert abs(m.compute() - want) < 1e-12
+
+
+def test_evaluator_step_depth2(tmp_path):
+    """Trainer.validation's per-batch body end to end: eval frontend, 17-window student/teacher forward, tables and events."""
+    from copy import deepcopy
+    from test_gpu_model import _build
+    import oracle.matsed_oracle as O
+    net, sd = _build(False, 2, 2)
+    ema = deepcopy(net)
+    cfg = {"training": {"median_window": [5, 20, 5, 5, 5, 20, 20, 20, 5, 20], "filter_type": "median", "weak_mask": True},
+           "PaSST_SED": {"val_kwargs": {"encoder_win": True, "win_param": [512, 31], "mix_rate": 0.5, "temp_w": 0.5}}}
+    ev = Evaluator(net, ema, _enc(), cfg)
+    assert ev.median_filter == [32, 128, 32, 32, 32, 128, 128, 128, 32, 128]
+    B = 2
+    wav = torch.from_numpy(synth.synth_wav(B, seed=77)).to(DEV)
+    labels = torch.from_numpy(synth.synth_batch_labels(B, 0, 0, seed=78)).to(DEV)
+    pad = torch.zeros(B, 1000, dtype=torch.bool); pad[1, 800:] = True
+    paths = ["/x/val/u1.wav", "/x/val/u2.wav"]
+    out = ev.step(wav, labels, pad, paths)
+    strong, weak, at = out["student"]
+    assert strong.shape == (B, 10, 1000) and float(strong[1, :, 800:].abs().max()) == 0.0       # padded frames are zeroed
+    # the tables are exactly the oracle's decode of the model's own posteriors
+    r_o, p_o, ts = EO.batched_decode(strong.cpu().numpy(), weak.cpu().numpy(), ev.median_filter, need_weak_mask=True)
+    assert np.array_equal(ev.scores.post_student["u2"].to_numpy()[:, 2:], p_o[1].astype(np.float64))
+    assert np.array_equal(ev.scores.raw_teacher["u1"].to_numpy()[:, 0], ts[:-1])
+    # and the posteriors are the oracle model's (eval frontend + 17 windows + temperature 0.5 + pad mask)
+    mel = O.logmel(wav.cpu())
+    o = O.passt_sed_forward({k: v for k, v in sd.items()}, mel, depth=2, feature_layer=2, encoder_win=True, win_param=(512, 31),
+                            temp_w=0.5, pad_mask=pad)
+    err = float((strong.cpu() - o["strong"]).abs().max())
+    assert err < 1e-3, err
+    ev.write(tmp_path)
+    assert sorted(os.listdir(tmp_path)) == ["post_student", "post_teacher", "raw_student", "raw_teacher"]
+    assert ev.weak_f1["student"].compute() >= 0.0 and len(ev.event_frame("teacher").columns) in (0, 4)
