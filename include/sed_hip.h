@@ -45,7 +45,7 @@ int sed_median_filter(const float* in, float* out, const int* sizes, const float
 int sed_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi, const float* bias,
                 const float* resF, float* outF, void* outH, void* outH2, const void* auxH, int ldc, float alpha,
                 int ksplit, int f16, hipStream_t stream);
-/* qkv / in_proj GEMM with head-split epilogue: q,k,v [B*H,seq,64], transposed copies [B*H,64,seq_pad] (nullable),
+/* qkv / in_proj GEMM with head-split epilogue: q,k,v [B*H,seq,64] (each nullable), transposed copies [B*H,64,seq_pad] (nullable),
  * optional rel-pos biased queries q = q+u, q2 = q+v (passt.py:332-333; transformerXL.py:382-384,497-503) */
 int sed_gemm_qkv(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq, int seq_pad, void* q,
                  void* k, void* v, void* qt, void* kt, void* vt, void* q2, void* q2t, const float* pos_u,

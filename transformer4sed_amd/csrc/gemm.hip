@@ -79,7 +79,7 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs& g, int m, int n, c
         uint2 pk;
         pk.x = pack2<F16>(val[0] + e1[0], val[1] + e1[1]);
         pk.y = pack2<F16>(val[2] + e1[2], val[3] + e1[3]);
-        *reinterpret_cast<uint2*>(&row_dst[((size_t)bh * g.seq + t) * 64 + d]) = pk;
+        if (row_dst != nullptr) *reinterpret_cast<uint2*>(&row_dst[((size_t)bh * g.seq + t) * 64 + d]) = pk;
         if (tr_dst != nullptr) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) tr_dst[((size_t)bh * 64 + d + j) * g.seq_pad + t] = to_16<F16>(val[j] + e1[j]);
@@ -661,17 +661,19 @@ __device__ __forceinline__ void v3_epilogue(const GemmArgs& g, const f32x16_t (&
             v3_col_consts(bv, g.bias != nullptr ? g.bias + nb : nullptr, extra, lg);
             v3_stage16<F16, 0>(wl, acc, bv, lr, lg);
             __builtin_amdgcn_wave_barrier();
+            if (rd != nullptr) {  // (the row-major V is only needed by the backward: inference passes v = NULL)
 #pragma unroll
-            for (int rb = 0; rb < 16; rb += 8) {
-                uint4 v[8];
+                for (int rb = 0; rb < 16; rb += 8) {
+                    uint4 v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint4*>(wl + ((rb + u) * 8 + (lane >> 3)) * V3_RS16 + (lane & 7) * 16);
+                    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint4*>(wl + ((rb + u) * 8 + (lane >> 3)) * V3_RS16 + (lane & 7) * 16);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int m = mb + (rb + u) * 8 + (lane >> 3);
-                    if (m < g.M) {
-                        const int bidx = m / g.seq, t = m - bidx * g.seq;
-                        v3_st<uint4>(rd + ((size_t)(bidx * g.heads + h) * g.seq + t) * 64 + (lane & 7) * 8, v[u]);
+                    for (int u = 0; u < 8; ++u) {
+                        const int m = mb + (rb + u) * 8 + (lane >> 3);
+                        if (m < g.M) {
+                            const int bidx = m / g.seq, t = m - bidx * g.seq;
+                            v3_st<uint4>(rd + ((size_t)(bidx * g.heads + h) * g.seq + t) * 64 + (lane & 7) * 8, v[u]);
+                        }
                     }
                 }
             }

@@ -175,7 +175,7 @@ class SedEngine:
             call("sed_layernorm_fwd", x_in, self.P(p + "norm1.weight"), self.P(p + "norm1.bias"), 1e-6, 1.0, h16, None,
                  mean1, rstd1, M, D, f16)
             call("sed_gemm_qkv", h16, W[p + "attn.qkv.weight"].w, self.P(p + "attn.qkv.bias"), M, D, H, N, Npad, q, k,
-                 v, qt, kt, vt, None, None, None, None, f16)
+                 v if save else None, qt, kt, vt, None, None, None, None, f16)  # row-major V is a backward-only operand
             call("sed_mhsa_fwd", q, k, vt, o16, lse, Bx, H, N, Npad, f16)
             x_mid = E(Bx, N, D) if save else x_in
             gemm_nt(o16, W[p + "attn.proj.weight"].w, EPI_F32_RESID, bias=self.P(p + "attn.proj.bias"), res=x_in,
