@@ -180,24 +180,36 @@ extern "C" int sed_im2col(const float* mel, void* cols, int B, int T, int tstart
 
 // conv [B * 12 * tp, D] (bias already added) -> x [B, 2 + 12 tp, D] with the three positional tables.
 // freq_pe [D, 12], time_pe [D, 99] in the reference's checkpoint layout ([1,D,12,1] / [1,D,1,99]).
-__global__ void assemble_tokens_kernel(const float* __restrict__ conv, const float* __restrict__ cls,
-                                       const float* __restrict__ dist, const float* __restrict__ new_pos,
-                                       const float* __restrict__ freq_pe, const float* __restrict__ time_pe,
-                                       int toffset, float* __restrict__ x, int B, int tp) {
-    const int N = 2 + 12 * tp;
-    const size_t total = (size_t)B * N * DM;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int d = (int)(idx % DM);
-        const size_t tok = idx / DM;
-        const int n = (int)(tok % N), b = (int)(tok / N);
-        float v;
-        if (n == 0) v = cls[d] + new_pos[d];
-        else if (n == 1) v = dist[d] + new_pos[DM + d];
-        else {
-            const int p = n - 2, f = p / tp, t = p - f * tp;
-            v = conv[((size_t)b * 12 * tp + p) * DM + d] + time_pe[d * 99 + toffset + t] + freq_pe[d * 12 + f];
-        }
-        x[idx] = v;
+// One workgroup per token position n: the position's additive row (cls / dist + new_pos, or time_pe + freq_pe -- a strided gather
+// from the checkpoint layout) is fetched once into registers and reused for all B clips; rows move as float4.
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const float* __restrict__ conv, const float* __restrict__ cls,
+                                                              const float* __restrict__ dist, const float* __restrict__ new_pos,
+                                                              const float* __restrict__ freq_pe, const float* __restrict__ time_pe,
+                                                              int toffset, float* __restrict__ x, int B, int tp) {
+    const int N = 2 + 12 * tp, n = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Row pe;
+    if (n < 2) {
+        Row a, c;
+        row_load(a, n == 0 ? cls : dist, lane);
+        row_load(c, new_pos + n * DM, lane);
+#pragma unroll
+        ROW_FOREACH(i, k) f4(pe.v[i], k) = f4(a.v[i], k) + f4(c.v[i], k);
+        for (int bi = wave; bi < B; bi += 4) row_store(pe, x + ((size_t)bi * N + n) * DM, lane);
+        return;
+    }
+    const int p = n - 2, f = p / tp, t = p - f * tp;
+#pragma unroll
+    ROW_FOREACH(i, k) {
+        const int d = 4 * (lane + 64 * i) + k;
+        f4(pe.v[i], k) = time_pe[d * 99 + toffset + t] + freq_pe[d * 12 + f];
+    }
+    for (int bi = wave; bi < B; bi += 4) {
+        Row r;
+        row_load(r, conv + ((size_t)bi * 12 * tp + p) * DM, lane);
+#pragma unroll
+        ROW_FOREACH(i, k) f4(r.v[i], k) += f4(pe.v[i], k);
+        row_store(r, x + ((size_t)bi * N + n) * DM, lane);
     }
 }
 extern "C" int sed_assemble_tokens(const float* conv, const float* cls, const float* dist, const float* new_pos,
@@ -205,7 +217,7 @@ extern "C" int sed_assemble_tokens(const float* conv, const float* cls, const fl
                                    hipStream_t stream) {
     (void)hipGetLastError();
     if (tp < 1 || toffset < 0 || toffset + tp > 99) return SED_ERR_ARG;
-    hipLaunchKernelGGL(assemble_tokens_kernel, dim3(2048), dim3(256), 0, stream, conv, cls, dist, new_pos, freq_pe,
+    hipLaunchKernelGGL(assemble_tokens_kernel, dim3(2 + 12 * tp), dim3(256), 0, stream, conv, cls, dist, new_pos, freq_pe,
                        time_pe, toffset, x, B, tp);
     return sed_check_launch();
 }
@@ -585,6 +597,30 @@ extern "C" int sed_head_fwd(const float* x, const float* W, const float* bias, f
 }
 // backward: dlogit[b,t,c] = (dstrong[b,c,t] + dweak[b,c] * (2 s B - A) / B^2 [if unclamped]) * s (1 - s) / temp
 // dx[row] = sum_c dlogit W[c];  dW[c] += sum_rows dlogit x[row];  db[c] += sum dlogit
+#define HEAD_C 10
+// lane c (< 10) evaluates class c, then the ten values are broadcast with readlane: one set of loads per row, not ten
+__device__ __forceinline__ void head_dlogits(float (&dl)[HEAD_C], const float* __restrict__ strong, const float* __restrict__ sums,
+                                             const float* __restrict__ dstrong, const float* __restrict__ dweak, float inv_temp,
+                                             int b, int t, int T, int lane) {
+    float mine = 0.f;
+    if (lane < HEAD_C) {
+        const int c = lane;
+        const size_t si = ((size_t)b * HEAD_C + c) * T + t;
+        const float s = strong[si];
+        float g = dstrong != nullptr ? dstrong[si] : 0.f;
+        if (dweak != nullptr) {
+            const float A = sums[2 * (b * HEAD_C + c)], Bs = sums[2 * (b * HEAD_C + c) + 1];
+            const float wv = A / Bs;
+            if (wv > 1e-7f && wv < 1.0f) g += dweak[b * HEAD_C + c] * (2.f * s * Bs - A) / (Bs * Bs);
+        }
+        mine = g * s * (1.f - s) * inv_temp;
+    }
+#pragma unroll
+    for (int c = 0; c < HEAD_C; ++c) dl[c] = __shfl(mine, c, 64);
+}
+// Two sweeps over the rows inside one launch: (1) dx = sum_c dlogit_c W_c with the 10 classifier rows held in registers (one
+// write of dx, nothing re-read), (2) dW_c += dlogit_c x with the 10 per-lane partial rows in registers (one read of x).  The
+// class-by-class version re-read x and read-modify-wrote dx ten times (0.79 ms per step).
 __global__ __launch_bounds__(256) void sed_head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                            const float* __restrict__ strong,
                                                            const float* __restrict__ sums,
@@ -593,48 +629,60 @@ __global__ __launch_bounds__(256) void sed_head_bwd_kernel(const float* __restri
                                                            float* __restrict__ dx, float* __restrict__ dW,
                                                            float* __restrict__ db, int B, int T, int C) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = 0; c < C; ++c) {
-        // process class by class to keep register use small: per-lane dW partial for this class
-        Row w, pw;
-        row_load(w, W + (size_t)c * DM, lane);
+    {
+        Row w[HEAD_C];
 #pragma unroll
-        ROW_FOREACH(i, k) f4(pw.v[i], k) = 0.f;
-        float pb = 0.f;
+        for (int c = 0; c < HEAD_C; ++c) row_load(w[c], W + (size_t)c * DM, lane);
         for (int row = blockIdx.x * 4 + wave; row < B * T; row += gridDim.x * 4) {
             const int b = row / T, t = row - b * T;
-            const size_t si = ((size_t)b * C + c) * T + t;
-            const float s = strong[si];
-            float g = dstrong != nullptr ? dstrong[si] : 0.f;
-            if (dweak != nullptr) {
-                const float A = sums[2 * (b * C + c)], Bs = sums[2 * (b * C + c) + 1];
-                const float wv = A / Bs;
-                if (wv > 1e-7f && wv < 1.0f) g += dweak[b * C + c] * (2.f * s * Bs - A) / (Bs * Bs);
-            }
-            const float dl = g * s * (1.f - s) * inv_temp;
-            pb += dl;
-            Row xr, o;
-            row_load(xr, x + (size_t)row * DM, lane);
-            if (c > 0) row_load(o, dx + (size_t)row * DM, lane);
+            float dl[HEAD_C];
+            head_dlogits(dl, strong, sums, dstrong, dweak, inv_temp, b, t, T, lane);
+            Row o;
 #pragma unroll
             ROW_FOREACH(i, k) {
-                f4(pw.v[i], k) += dl * f4(xr.v[i], k);
-                const float v = dl * f4(w.v[i], k);
-                f4(o.v[i], k) = c > 0 ? f4(o.v[i], k) + v : v;
+                float v = 0.f;
+#pragma unroll
+                for (int c = 0; c < HEAD_C; ++c) v += dl[c] * f4(w[c].v[i], k);
+                f4(o.v[i], k) = v;
             }
             row_store(o, dx + (size_t)row * DM, lane);
         }
-        if (dW != nullptr) {
+    }
+    if (dW == nullptr) return;
+    Row pw[HEAD_C];
+    float pb[HEAD_C];
 #pragma unroll
-            ROW_FOREACH(i, k) unsafeAtomicAdd(&dW[(size_t)c * DM + 4 * (lane + 64 * i) + k], f4(pw.v[i], k));
-            if (lane == 0) unsafeAtomicAdd(&db[c], pb);
+    for (int c = 0; c < HEAD_C; ++c) {
+        pb[c] = 0.f;
+#pragma unroll
+        ROW_FOREACH(i, k) f4(pw[c].v[i], k) = 0.f;
+    }
+    for (int row = blockIdx.x * 4 + wave; row < B * T; row += gridDim.x * 4) {
+        const int b = row / T, t = row - b * T;
+        float dl[HEAD_C];
+        head_dlogits(dl, strong, sums, dstrong, dweak, inv_temp, b, t, T, lane);
+        Row xr;
+        row_load(xr, x + (size_t)row * DM, lane);
+#pragma unroll
+        for (int c = 0; c < HEAD_C; ++c) {
+            pb[c] += dl[c];
+#pragma unroll
+            ROW_FOREACH(i, k) f4(pw[c].v[i], k) += dl[c] * f4(xr.v[i], k);
         }
+    }
+#pragma unroll
+    for (int c = 0; c < HEAD_C; ++c) {
+#pragma unroll
+        ROW_FOREACH(i, k) unsafeAtomicAdd(&dW[(size_t)c * DM + 4 * (lane + 64 * i) + k], f4(pw[c].v[i], k));
+        if (lane == 0) unsafeAtomicAdd(&db[c], pb[c]);
     }
 }
 extern "C" int sed_head_bwd(const float* x, const float* W, const float* strong, const float* sums,
                             const float* dstrong, const float* dweak, float temp, float* dx, float* dW, float* db,
                             int B, int T, int C, hipStream_t stream) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(sed_head_bwd_kernel, dim3(256), dim3(256), 0, stream, x, W, strong, sums, dstrong, dweak,
+    if (C != HEAD_C) return SED_ERR_ARG;
+    hipLaunchKernelGGL(sed_head_bwd_kernel, dim3(512), dim3(256), 0, stream, x, W, strong, sums, dstrong, dweak,
                        1.0f / temp, dx, dW, db, B, T, C);
     return sed_check_launch();
 }
