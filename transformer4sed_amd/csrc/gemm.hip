@@ -877,6 +877,284 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(const GemmArgs g) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// v5 = v3's main loop as a PERSISTENT kernel (one workgroup per CU walks its XCD's share of the tiles).  What it buys: the next
+// tile's first K-tile DMA is issued right after the last MFMA of the current tile, BEFORE the epilogue, so the ~3 us DMA
+// prologue that every short-K tile paid (K = 768: 22 us main loop) runs under the epilogue's LDS staging and stores.  The
+// epilogue therefore may only use LDS outside stage 0: per-wave staging shrinks to 8.5 KiB (64 rows of 16-bit / 32 rows of
+// fp32 per pass) placed on stage 1 and the 27 KiB above the stages.
+// ---------------------------------------------------------------------------------------------------------------------
+#define V5_WLDS 8704
+#define V5_LDS (V3_STAGE + 8 * V5_WLDS)
+template <bool F16, int MODE>
+__device__ __forceinline__ void v5_stage16(unsigned char* wl, const f32x16_t (&acc)[4][2], const float (&bv)[2][4][4], int p, int lr,
+                                           int lg) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = j * 32 + 8 * q + 4 * lg;
+                const f32x16_t& a = p == 0 ? acc[ii][j] : acc[2 + ii][j];
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = a[4 * q + e] + bv[j][q][e];
+                    v[e] = MODE == 1 ? gelu_fast(x) : x;
+                }
+                uint2 pk;
+                pk.x = pack2<F16>(v[0], v[1]);
+                pk.y = pack2<F16>(v[2], v[3]);
+                *reinterpret_cast<uint2*>(wl + (ii * 32 + lr) * V3_RS16 + col * 2) = pk;
+            }
+}
+__device__ __forceinline__ void v5_stage32(unsigned char* wl, const f32x16_t (&a2)[2], int lr, int lg) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = j * 32 + 8 * q + 4 * lg;
+            *reinterpret_cast<float4*>(wl + lr * V3_RS32 + col * 4) =
+                make_float4(a2[j][4 * q], a2[j][4 * q + 1], a2[j][4 * q + 2], a2[j][4 * q + 3]);
+        }
+}
+
+template <int EPI, bool F16>
+__device__ __forceinline__ void v5_epilogue(const GemmArgs& g, const f32x16_t (&acc)[4][2], const V3Consts<EPI>& cc,
+                                            unsigned char* wl, int mb, int nb, int lane) {
+    const int lr = lane & 31, lg = lane >> 5;
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
+        const float (&bv)[2][4][4] = cc.bv;
+#pragma unroll
+        for (int pass = 0; pass < (EPI == EPI_GELU ? 2 : 1); ++pass) {
+            bf16_t* out = (EPI == EPI_GELU && pass == 1) ? g.outH2 : g.outH;
+            if (out == nullptr) continue;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                if (EPI == EPI_GELU && pass == 1) v5_stage16<F16, 1>(wl, acc, bv, p, lr, lg);
+                else v5_stage16<F16, 0>(wl, acc, bv, p, lr, lg);
+                __builtin_amdgcn_wave_barrier();
+                uint4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint4*>(wl + (u * 8 + (lane >> 3)) * V3_RS16 + (lane & 7) * 16);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int m = mb + p * 64 + u * 8 + (lane >> 3);
+                    if (m < g.M) v3_st<uint4>(out + (size_t)m * g.ldc + nb + (lane & 7) * 8, v[u]);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        return;
+    }
+    if constexpr (EPI == EPI_QKV) {
+        const int D = g.heads * 64;
+        const int which = nb / D, h = (nb - which * D) >> 6;
+        bf16_t* row_dst = which == 0 ? g.q : (which == 1 ? g.k : g.v);
+        bf16_t* tr_dst = which == 0 ? g.qt : (which == 1 ? g.kt : g.vt);
+        const int npass = (which == 0 && g.q2 != nullptr) ? 2 : 1;
+        for (int pass = 0; pass < npass; ++pass) {
+            const float* extra = nullptr;
+            if (which == 0 && g.pu != nullptr) extra = (pass == 0 ? g.pu : g.pv) + h * 64;
+            bf16_t* rd = pass == 0 ? row_dst : g.q2;
+            bf16_t* td = pass == 0 ? tr_dst : g.q2t;
+            float bv[2][4][4];
+            v3_col_consts(bv, g.bias != nullptr ? g.bias + nb : nullptr, extra, lg);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                v5_stage16<F16, 0>(wl, acc, bv, p, lr, lg);
+                __builtin_amdgcn_wave_barrier();
+                if (rd != nullptr) {  // (the row-major V is only needed by the backward: inference passes v = NULL)
+#pragma unroll
+                    for (int ub = 0; ub < 8; ub += 4) {  // batches of 4: this epilogue sits at the VGPR cap
+                        uint4 v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            v[u] = *reinterpret_cast<const uint4*>(wl + ((ub + u) * 8 + (lane >> 3)) * V3_RS16 + (lane & 7) * 16);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int m = mb + p * 64 + (ub + u) * 8 + (lane >> 3);
+                            if (m < g.M) {
+                                const int bidx = m / g.seq, tt = m - bidx * g.seq;
+                                v3_st<uint4>(rd + ((size_t)(bidx * g.heads + h) * g.seq + tt) * 64 + (lane & 7) * 8, v[u]);
+                            }
+                        }
+                    }
+                }
+                if (td != nullptr && (g.seq & 1) == 0) {
+                    // transposed copy [bh][d][seq_pad]: a lane owns a PAIR of consecutive tokens (same clip: seq is even, the
+                    // pair starts on an even row) and one of two interleaved d columns -> 4-byte stores, 32 lanes = 128 B
+                    const int pr = (lane & 31) * 2, dsel = lane >> 5;
+                    const int m = mb + p * 64 + pr;
+                    if (m < g.M) {
+                        const int bidx = m / g.seq, t = m - bidx * g.seq;
+                        bf16_t* base = td + (size_t)(bidx * g.heads + h) * 64 * g.seq_pad + t;
+                        const unsigned short* s0 = reinterpret_cast<const unsigned short*>(wl + pr * V3_RS16);
+                        const unsigned short* s1 = reinterpret_cast<const unsigned short*>(wl + (pr + 1) * V3_RS16);
+#pragma unroll 8
+                        for (int dd = 0; dd < 32; ++dd) {
+                            const int d = dd * 2 + dsel;
+                            *reinterpret_cast<unsigned*>(base + (size_t)d * g.seq_pad) = (unsigned)s0[d] | ((unsigned)s1[d] << 16);
+                        }
+                    }
+                } else if (td != nullptr) {
+                    const int m = mb + p * 64 + lane;
+                    if (m < g.M) {
+                        const int bidx = m / g.seq, t = m - bidx * g.seq;
+                        bf16_t* base = td + (size_t)(bidx * g.heads + h) * 64 * g.seq_pad + t;
+                        const unsigned short* src = reinterpret_cast<const unsigned short*>(wl + lane * V3_RS16);
+#pragma unroll 8
+                        for (int d = 0; d < 64; ++d) base[(size_t)d * g.seq_pad] = src[d];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        return;
+    }
+    if constexpr (EPI == EPI_ATOMIC) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v5_stage32(wl, acc[i], lr, lg);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 8
+            for (int row = 0; row < 32; ++row) {
+                const int m = mb + i * 32 + row;
+                const float v = *reinterpret_cast<const float*>(wl + row * V3_RS32 + lane * 4);
+                if (m < g.M) unsafeAtomicAdd(&g.outF[(size_t)m * g.ldc + nb + lane], v * g.alpha);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+    // fp32-staged epilogues, four passes of 32 rows; the side input of pass i + 1 is requested before pass i is stored
+    const int c4 = lane & 15, n = nb + c4 * 4;
+    const float4 b = make_float4(cc.bv[0][0][0], cc.bv[0][0][1], cc.bv[0][0][2], cc.bv[0][0][3]);
+    V3Side<EPI> s0, s1;
+    v3_side_load<EPI>(s0, g, mb, n, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v5_stage32(wl, acc[i], lr, lg);
+        __builtin_amdgcn_wave_barrier();
+        if (i < 3) v3_side_load<EPI>((i & 1) ? s0 : s1, g, mb + 32 * (i + 1), n, lane);
+        v3_store_batch<EPI, F16>(g, wl, (i & 1) ? s1 : s0, b, mb + 32 * i, 0, n, c4, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int EPI, bool F16>
+__global__ __launch_bounds__(512) void gemm_nt_v5_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntn = g.N / V3_T, ntm = (g.M + V3_T - 1) / V3_T, nwg = ntm * ntn;
+    // workgroup w sits on XCD w % 8 (round-robin dispatch) and walks that XCD's contiguous share of the tile list, so the 32
+    // workgroups of an XCD work on neighbouring tiles (4 tile-rows x 8 tile-columns) at any time
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int tpx = (nwg + 7) >> 3;
+    const int t_hi = (xcd + 1) * tpx < nwg ? (xcd + 1) * tpx : nwg;
+    int t = xcd * tpx + slot;
+    if (t >= t_hi) return;
+    const int ktiles = g.K / BK;
+    const int kt_begin = (int)(((long long)blockIdx.y * ktiles) / g.ksplit);
+    const int kt_end = (int)(((long long)(blockIdx.y + 1) * ktiles) / g.ksplit);
+    const int nk = kt_end - kt_begin;
+    const int group_size = 4 * ntn;
+    const int prow = lane >> 3, pch = lane & 7;
+    const bool isB = wave >= 4;
+    unsigned src[8];  // element offsets from the operand base (32-bit: the launcher checks the operands are < 2^31 elements)
+    const bf16_t* const opbase = isB ? g.B : g.A;
+    int dst[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = (isB ? 32768 : 0) + ((wave & 3) * 8 + i) * 1024;
+    int m0, n0;
+#define V5_TILE(tt)                                                                                                        \
+    {                                                                                                                      \
+        const int gid = (tt) / group_size, first_m = gid * 4;                                                              \
+        const int gm = (ntm - first_m) < 4 ? (ntm - first_m) : 4;                                                          \
+        const int tin = (tt) - gid * group_size;                                                                           \
+        m0 = (first_m + tin % gm) * V3_T;                                                                                  \
+        n0 = (tin / gm) * V3_T;                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                    \
+            const int row = ((wave & 3) * 8 + i) * 8 + prow;                                                               \
+            const int cl = pch ^ ((row >> 1) & 7);                                                                         \
+            int am = m0 + row;                                                                                             \
+            am = am < g.M ? am : g.M - 1;                                                                                  \
+            src[i] = (unsigned)((isB ? (n0 + row) * g.ldb : am * g.lda) + cl * 8 + kt_begin * BK);                         \
+        }                                                                                                                  \
+    }
+#define V5_DMA(kt, stage)                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                         \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(opbase + src[i] + (kt) * BK),    \
+                                         (__attribute__((address_space(3))) void*)(lds3 + (stage) * V3_STAGE + dst[i]),   \
+                                         16, 0, 0);
+    const int lr = lane & 31, lg = lane >> 5;
+    int aoff[4], boff[2], aswz[4], bswz[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int r = wm * 128 + i * 32 + lr; aoff[i] = r * 128; aswz[i] = (r >> 1) & 7; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int r = wn * 64 + j * 32 + lr; boff[j] = 32768 + r * 128; bswz[j] = (r >> 1) & 7; }
+
+    V5_TILE(t);
+    if (nk > 0) { V5_DMA(0, 0); }
+    while (true) {
+        f32x16_t acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int it = 0; it < nk; ++it) {
+            const int stage = it & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // tile `it` landed (all waves); the other stage (and the C staging) is idle
+            if (it + 1 < nk) { V5_DMA(it + 1, stage ^ 1); }
+            const unsigned char* base = lds3 + stage * V3_STAGE;
+            s16x8_t af[2][4], bfr[2][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[0][i] = *reinterpret_cast<const s16x8_t*>(base + aoff[i] + ((lg ^ aswz[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[0][j] = *reinterpret_cast<const s16x8_t*>(base + boff[j] + ((lg ^ bswz[j]) << 4));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int cur = s & 1, nxt = cur ^ 1;
+                if (s < 3) {
+                    const int ch = 2 * (s + 1) + lg;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        af[nxt][i] = *reinterpret_cast<const s16x8_t*>(base + aoff[i] + ((ch ^ aswz[i]) << 4));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        bfr[nxt][j] = *reinterpret_cast<const s16x8_t*>(base + boff[j] + ((ch ^ bswz[j]) << 4));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma32t<F16>(bfr[cur][j], af[cur][i], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const int mb = m0 + wm * 128, nb = n0 + wn * 64;
+        V3Consts<EPI> cc;  // bias values: requested once the operand fragments are dead, they land during the barrier + DMA issue
+        v3_load_consts<EPI>(cc, g, nb, lane);
+        __builtin_amdgcn_s_barrier();  // every wave is done reading the operand stages
+        const int tn = t + nslots;
+        const bool more = tn < t_hi;
+        if (more) {
+            V5_TILE(tn);
+            if (nk > 0) { V5_DMA(0, 0); }  // next tile's first K tile flies under this tile's epilogue
+        }
+        v5_epilogue<EPI, F16>(g, acc, cc, lds3 + V3_STAGE + wave * V5_WLDS, mb, nb, lane);
+        if (!more) break;
+        t = tn;
+    }
+#undef V5_TILE
+#undef V5_DMA
+}
+
 template <int EPI>
 static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
     if (g.M <= 0 || g.N % TILE != 0 || g.K % BK != 0 || g.ksplit < 1) return SED_ERR_ARG;
@@ -904,6 +1182,29 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
         gs.ksplit = ks3;
         gs.stagger = (int)(stagger_us * 100.f / 8.f);
         const GemmArgs& g = gs;
+        // persistent variant: measured no better than the per-tile launch (fc1 0.303 vs 0.290 ms, step 151.1 vs 149.2 ms) -- the
+        // hidden 3 us prologue is paid back by the smaller staging passes and the loss of dynamic tile balancing.  Opt-in.
+        static const int v5 = []() { const char* e = getenv("SED_GEMM_V5"); return (e != nullptr && e[0] == '1') ? 1 : 0; }();
+        const bool fits32 = (long long)g.M * g.lda < (1LL << 31) && (long long)g.N * g.ldb < (1LL << 31);
+        if (v5 && fits32) {
+            static const int ncu = []() {
+                int dev = 0, n = 0;
+                (void)hipGetDevice(&dev);
+                (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+                return n >= 8 ? (n & ~7) : 256;
+            }();
+            const int nwg3 = (int)grid3.x;
+            dim3 grid5(nwg3 < ncu ? ((nwg3 + 7) & ~7) : ncu, ks3);
+            static bool attr5[2] = {false, false};
+            if (f16) {
+                if (!attr5[1]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v5_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V5_LDS); attr5[1] = true; }
+                hipLaunchKernelGGL((gemm_nt_v5_kernel<EPI, true>), grid5, dim3(512), V5_LDS, s, g);
+            } else {
+                if (!attr5[0]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v5_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, V5_LDS); attr5[0] = true; }
+                hipLaunchKernelGGL((gemm_nt_v5_kernel<EPI, false>), grid5, dim3(512), V5_LDS, s, g);
+            }
+            return sed_check_launch();
+        }
         static bool attr3[2] = {false, false};
         if (f16) {
             if (!attr3[1]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr3[1] = true; }
