@@ -6,8 +6,9 @@ name=$1; shift
 out=tools/ablate/variants/$name.so
 mkdir -p tools/ablate/variants /tmp/variant_$name
 for f in gemm attention relpos_attention norm_elem frontend; do
+  ff=""; case $f in attention|relpos_attention) ff="-mllvm -amdgpu-mfma-vgpr-form=1";; esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -Wno-unused-result \
-     -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c transformer4sed_amd/csrc/$f.hip -o /tmp/variant_$name/$f.o &
+     $ff "$@" -c transformer4sed_amd/csrc/$f.hip -o /tmp/variant_$name/$f.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/variant_$name/*.o -o $out

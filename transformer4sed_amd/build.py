@@ -8,9 +8,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsed_hip.so")
 SOURCES = ["gemm.hip", "attention.hip", "relpos_attention.hip", "norm_elem.hip", "frontend.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
-         "-Wno-unused-result",
-         # MFMA accumulators stay in (unified-file) VGPRs: the AGPR form costs a v_accvgpr_read/write per softmax operand
-         "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+         "-Wno-unused-result"]
+# attention kernels: MFMA accumulators stay in (unified-file) VGPRs -- the AGPR form costs a v_accvgpr_read/write per softmax
+# operand.  The GEMM file is left to the compiler: its 128x128-per-wave kernel needs the AGPR half for its 256 accumulators.
+FILE_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "relpos_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc():
@@ -36,7 +37,7 @@ def build(force=False, verbose=True):
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
-        cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [_hipcc(), *FLAGS, *FILE_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
     for src, p in procs:

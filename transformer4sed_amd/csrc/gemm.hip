@@ -878,6 +878,121 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(const GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// v7: 256 x 256 workgroup tile, FOUR waves (2 x 2) with 128 x 128 per wave (16 MFMA blocks = 256 accumulator registers in the
+// AGPR half of the unified file, one wave per SIMD), K consumed in 32-deep tiles through FOUR 32 KiB LDS stages.
+// Why: v3 keeps one K tile in flight, so an iteration can never be shorter than one DMA round trip (~2 us under load = its
+// measured iteration time; halving the LDS fragment traffic alone -- the same 4-wave geometry at BK = 64 -- changed nothing).
+// Here two tiles are in flight while two have landed: tile it is being multiplied, tile it+1 is already visible (its first
+// fragments are pre-read under tile it's MFMAs, so no LDS latency is exposed after the barrier), tiles it+2 and it+3 fly.
+// Counted `s_waitcnt vmcnt(8)` (8 DMA instructions per wave per tile) + raw s_barrier per tile.
+// LDS rows are 64 B: 16-B chunk c of row r is stored at chunk c ^ ((r >> 2) & 3) (conflict-free for the ds_read_b128 lane groups).
+// ---------------------------------------------------------------------------------------------------------------------
+#define V7_BK 32
+#define V7_STAGE (32 * 1024)
+#define V7_NST 4
+#define V7_LDS (V7_NST * V7_STAGE)
+template <int EPI, bool F16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_v7_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = g.N / V3_T, ntm = (g.M + V3_T - 1) / V3_T, nwg = ntm * ntn;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int group_size = 4 * ntn, gid = t / group_size, first_m = gid * 4;
+    const int gm = (ntm - first_m) < 4 ? (ntm - first_m) : 4;
+    const int tin = t - gid * group_size;
+    const int m0 = (first_m + tin % gm) * V3_T, n0 = (tin / gm) * V3_T;
+    const int ktiles = g.K / V7_BK;
+    const int kt_begin = (int)(((long long)blockIdx.y * ktiles) / g.ksplit);
+    const int kt_end = (int)(((long long)(blockIdx.y + 1) * ktiles) / g.ksplit);
+    const int nk = kt_end - kt_begin;
+
+    // DMA: 16 (A) + 16 (B) pieces of 16 rows x 64 B per stage; waves 0,1 fetch A pieces, waves 2,3 B pieces (8 each)
+    const int prow = lane >> 2, pch = lane & 3;
+    const bool isB = wave >= 2;
+    const bf16_t* const opbase = isB ? g.B : g.A;
+    unsigned src[8];  // element offsets (the launcher checks they fit 32 bits)
+    const int dst0 = (isB ? 16384 : 0) + (wave & 1) * 8 * 1024;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = ((wave & 1) * 8 + i) * 16 + prow;
+        const int cl = pch ^ ((row >> 2) & 3);
+        int am = m0 + row;
+        am = am < g.M ? am : g.M - 1;
+        src[i] = (unsigned)((isB ? (n0 + row) * g.ldb : am * g.lda) + cl * 8 + kt_begin * V7_BK);
+    }
+#define V7_DMA(kt)                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                         \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(opbase + src[i] + (kt) * V7_BK), \
+                                         (__attribute__((address_space(3))) void*)(lds3 + ((kt) & 3) * V7_STAGE + dst0 + i * 1024), \
+                                         16, 0, 0);
+    f32x16_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int lr = lane & 31, lg = lane >> 5;
+    int aoff[4], boff[4], aswz[4], bswz[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int r = wm * 128 + i * 32 + lr; aoff[i] = r * 64; aswz[i] = (r >> 2) & 3; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int r = wn * 128 + j * 32 + lr; boff[j] = 16384 + r * 64; bswz[j] = (r >> 2) & 3; }
+#define V7_FRAGS(dstA, dstB, kt, s)                                                                                       \
+    {                                                                                                                     \
+        const unsigned char* fb = lds3 + ((kt) & 3) * V7_STAGE;                                                           \
+        const int ch = 2 * (s) + lg;                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) dstA[i] = *reinterpret_cast<const s16x8_t*>(fb + aoff[i] + ((ch ^ aswz[i]) << 4)); \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) dstB[j] = *reinterpret_cast<const s16x8_t*>(fb + boff[j] + ((ch ^ bswz[j]) << 4)); \
+    }
+#define V7_MFMA(fa, fb_)                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mfma32t<F16>(fb_[j], fa[i], acc[i][j]);
+
+    s16x8_t a0[4], b0[4], a1[4], b1[4];
+    if (nk > 0) {
+        V7_DMA(0);
+        if (nk > 1) { V7_DMA(1); }
+        if (nk > 2) { V7_DMA(2); }
+        if (nk > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        V7_FRAGS(a0, b0, 0, 0);
+    }
+    for (int it = 0; it < nk; ++it) {
+        // tile it + 1 must be visible before this iteration pre-reads its first fragments; tile it + 2 may stay in flight
+        if (it + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // ... for every wave's pieces; also: nobody still reads stage (it - 1) & 3
+        if (it + 3 < nk) { V7_DMA(it + 3); }
+        V7_FRAGS(a1, b1, it, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        V7_MFMA(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 < nk) { V7_FRAGS(a0, b0, it + 1, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        V7_MFMA(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_barrier();  // every wave is done reading the operand stages: LDS becomes the per-wave C staging area
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int nb = n0 + wn * 128 + h * 64;
+        V3Consts<EPI> cc;
+        v3_load_consts<EPI>(cc, g, nb, lane);
+        f32x16_t a2[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a2[i][0] = acc[i][2 * h]; a2[i][1] = acc[i][2 * h + 1]; }
+        v3_epilogue<EPI, F16>(g, a2, cc, lds3 + wave * V3_WLDS, m0 + wm * 128, nb, lane);
+    }
+#undef V7_DMA
+#undef V7_FRAGS
+#undef V7_MFMA
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // v5 = v3's main loop as a PERSISTENT kernel (one workgroup per CU walks its XCD's share of the tiles).  What it buys: the next
 // tile's first K-tile DMA is issued right after the last MFMA of the current tile, BEFORE the epilogue, so the ~3 us DMA
 // prologue that every short-K tile paid (K = 768: 22 us main loop) runs under the epilogue's LDS staging and stores.  The
@@ -1186,6 +1301,20 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
         // hidden 3 us prologue is paid back by the smaller staging passes and the loss of dynamic tile balancing.  Opt-in.
         static const int v5 = []() { const char* e = getenv("SED_GEMM_V5"); return (e != nullptr && e[0] == '1') ? 1 : 0; }();
         const bool fits32 = (long long)g.M * g.lda < (1LL << 31) && (long long)g.N * g.ldb < (1LL << 31);
+        // 4-wave / 128x128-per-wave / four 32-deep stages: measured slower than v3 (1009 vs 1089 TFLOP/s at 8192^3, fc1 0.344 vs
+        // 0.301 ms): neither fewer LDS fragment reads nor two K tiles in flight move the ~2 us per 256x256x64 step.  Opt-in.
+        static const int v7 = []() { const char* e = getenv("SED_GEMM_V7"); return (e != nullptr && e[0] == '1') ? 1 : 0; }();
+        if (v7 && fits32) {
+            static bool attr7[2] = {false, false};
+            if (f16) {
+                if (!attr7[1]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v7_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V7_LDS); attr7[1] = true; }
+                hipLaunchKernelGGL((gemm_nt_v7_kernel<EPI, true>), grid3, dim3(256), V7_LDS, s, g);
+            } else {
+                if (!attr7[0]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v7_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, V7_LDS); attr7[0] = true; }
+                hipLaunchKernelGGL((gemm_nt_v7_kernel<EPI, false>), grid3, dim3(256), V7_LDS, s, g);
+            }
+            return sed_check_launch();
+        }
         if (v5 && fits32) {
             static const int ncu = []() {
                 int dev = 0, n = 0;
