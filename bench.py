@@ -117,8 +117,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    force_ddp = os.environ.get("SED_DDP_FORCE") == "1"   # exercise the RCCL gradient path on a single rank (debugging aid)
+    if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -142,8 +146,9 @@ def main():
     trainer.cfg["training"]["batch_size"] = [sn, 0, wn, un]
     wav = torch.from_numpy(synth.synth_wav(B, seed=1000 + rank)).to(dev)
     labels = torch.from_numpy(synth.synth_batch_labels(sn, wn, un, seed=1000 + rank)).to(dev)
-    if world > 1:
+    if world > 1 or force_ddp:
         trainer.ddp = GradBucketReducer(net, opt)
+        trainer.ddp.force = force_ddp
 
     if a.mode == "val":
         from transformer4sed_amd.evaluation import Encoder, Evaluator
@@ -230,10 +235,19 @@ def main():
         line["config"].pop("final_loss", None)
     if rank == 0 and not a.no_cpu_baseline and a.mode == "finetune2":
         line["cpu_baseline"] = cpu_baseline(a.depth)
+    # RCCL writes its version banner through C stdio (block-buffered when piped): every rank pushes it out before the last
+    # barrier so that rank 0's JSON line is the last thing on the job's stdout
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if world > 1 or force_ddp:
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

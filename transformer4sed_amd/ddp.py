@@ -45,11 +45,12 @@ class GradBucketReducer:
             self.ranges[st] = merged
         self.pending = []
         self.fired = set()
+        self.force = False  # issue the collectives even at world size 1 (single-GPU check of the RCCL path)
         net._grad_ready_hook = self.on_stage
         self.use_avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
 
     def _reduce(self, t):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if self.use_avg:
             self.pending.append(dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
