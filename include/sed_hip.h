@@ -40,6 +40,8 @@ int sed_median_filter(const float* in, float* out, const int* sizes, const float
 /* ------------------------------------------------------------------ GEMM family (nn.Linear / conv / autograd GEMMs) */
 /* C[M,N] = A[M,K] . B[N,K]^T, bf16 operands, fp32 accumulate, fused epilogue `epi`:
  * 0 outF=acc*alpha+bias | 1 outF=resF+acc+bias (resF may alias outF) | 2 outH=bf16(acc+bias) | 3 outH=h, outH2=gelu(h) | 4 outH=acc*gelu'(auxH)
+ * `f16`: 0 = bf16 operands / outputs, 1 = IEEE half, 3 = half, but tensors only the bf16 backward consumes are written as bf16
+ *        (epi 3 / 8: the pre-activation outH;  sed_gemm_qkv: row-major v, qt, kt, q2t).
  * 5 atomicAdd(outF, acc*alpha) (split-K; `ksplit` is a hint, the library re-derives it for the tile shape it dispatches) | 7 outF and outH | 8 outH=h, outF=gelu(h) fp32.  Replaces F.linear at src/models/passt/passt.py:271,274,
  * 332,342; src/models/transformer/transformerXL.py:382,493,584; src/models/passt/passt_sed.py:196; conv2d passt.py:307 */
 int sed_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi, const float* bias,

@@ -45,6 +45,7 @@ struct GemmArgs {
     bf16_t *q, *k, *v, *qt, *kt, *vt, *q2, *q2t;
     const float *pu, *pv;
     int seq, seq_pad, heads;
+    int bwd_bf16; // f16 runs only: tensors that only the (bf16) backward consumes are written as bf16 straight away
     int stagger;  // v3: first-round workgroups start phase * stagger wall-clock ticks (10 ns) late, phase = 0..7
 };
 
@@ -54,6 +55,13 @@ struct GemmArgs {
 // Epilogue for one accumulator quad.  The MFMA operands are issued swapped (B fragment as the row operand), so the
 // accumulator block holds C^T: a lane owns ONE output row m and a register quad holds 4 CONSECUTIVE columns n..n+3 ->
 // 16-byte fp32 / 8-byte 16-bit vector stores instead of 4 scalar ones per quad.
+// two packed IEEE halves -> two packed bf16
+__device__ __forceinline__ unsigned h2x2_to_bf(unsigned p) { return pack2bf(h2f((bf16_t)(p & 0xFFFF)), h2f((bf16_t)(p >> 16))); }
+template <bool F16>
+__device__ __forceinline__ unsigned pack2_sel(float a, float b, int as_bf16) { return (F16 && !as_bf16) ? pack2<true>(a, b) : pack2<false>(a, b); }
+template <bool F16>
+__device__ __forceinline__ bf16_t to16_sel(float a, int as_bf16) { return (F16 && !as_bf16) ? to_16<true>(a) : to_16<false>(a); }
+
 template <int EPI, bool F16>
 __device__ __forceinline__ void epilogue_quad(const GemmArgs& g, int m, int n, const float v4[4]) {
     float b[4] = {0.f, 0.f, 0.f, 0.f};
@@ -76,13 +84,15 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs& g, int m, int n, c
         float val[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) val[j] = v4[j] + b[j];
+        // backward-only tensors (row-major V, every transposed copy except V^T) may be requested as bf16 (g.bwd_bf16)
+        const int row_bf = g.bwd_bf16 && which == 2, tr_bf = g.bwd_bf16 && which != 2;
         uint2 pk;
-        pk.x = pack2<F16>(val[0] + e1[0], val[1] + e1[1]);
-        pk.y = pack2<F16>(val[2] + e1[2], val[3] + e1[3]);
+        pk.x = pack2_sel<F16>(val[0] + e1[0], val[1] + e1[1], row_bf);
+        pk.y = pack2_sel<F16>(val[2] + e1[2], val[3] + e1[3], row_bf);
         if (row_dst != nullptr) *reinterpret_cast<uint2*>(&row_dst[((size_t)bh * g.seq + t) * 64 + d]) = pk;
         if (tr_dst != nullptr) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tr_dst[((size_t)bh * 64 + d + j) * g.seq_pad + t] = to_16<F16>(val[j] + e1[j]);
+            for (int j = 0; j < 4; ++j) tr_dst[((size_t)bh * 64 + d + j) * g.seq_pad + t] = to16_sel<F16>(val[j] + e1[j], tr_bf);
         }
         if (which == 0 && g.q2 != nullptr) {
             pk.x = pack2<F16>(val[0] + e2[0], val[1] + e2[1]);
@@ -90,7 +100,7 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs& g, int m, int n, c
             *reinterpret_cast<uint2*>(&g.q2[((size_t)bh * g.seq + t) * 64 + d]) = pk;
             if (g.q2t != nullptr) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) g.q2t[((size_t)bh * 64 + d + j) * g.seq_pad + t] = to_16<F16>(val[j] + e2[j]);
+                for (int j = 0; j < 4; ++j) g.q2t[((size_t)bh * 64 + d + j) * g.seq_pad + t] = to16_sel<F16>(val[j] + e2[j], g.bwd_bf16);
             }
         }
         return;
@@ -113,8 +123,8 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs& g, int m, int n, c
         for (int j = 0; j < 4; ++j) h[j] = v4[j] + b[j];
         uint2 pk;
         if (g.outH != nullptr) {  // pre-activation is only kept when a backward will need it
-            pk.x = pack2<F16>(h[0], h[1]);
-            pk.y = pack2<F16>(h[2], h[3]);
+            pk.x = pack2_sel<F16>(h[0], h[1], g.bwd_bf16);
+            pk.y = pack2_sel<F16>(h[2], h[3], g.bwd_bf16);
             *reinterpret_cast<uint2*>(g.outH + o) = pk;
         }
         pk.x = pack2<F16>(gelu_fast(h[0]), gelu_fast(h[1]));
@@ -142,8 +152,8 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs& g, int m, int n, c
 #pragma unroll
         for (int j = 0; j < 4; ++j) h[j] = v4[j] + b[j];
         uint2 pk;
-        pk.x = pack2<F16>(h[0], h[1]);
-        pk.y = pack2<F16>(h[2], h[3]);
+        pk.x = pack2_sel<F16>(h[0], h[1], g.bwd_bf16);
+        pk.y = pack2_sel<F16>(h[2], h[3], g.bwd_bf16);
         *reinterpret_cast<uint2*>(g.outH + o) = pk;
         *reinterpret_cast<float4*>(g.outF + o) = make_float4(gelu_erf(h[0]), gelu_erf(h[1]), gelu_erf(h[2]), gelu_erf(h[3]));
     }
@@ -577,7 +587,7 @@ __device__ __forceinline__ void v3_store_batch(const GemmArgs& g, const unsigned
             v3_st<uint2>(g.outH + o, pk);
         } else if constexpr (EPI == EPI_GELU32) {
             v = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
-            uint2 pk; pk.x = pack2<F16>(v.x, v.y); pk.y = pack2<F16>(v.z, v.w);
+            uint2 pk; pk.x = pack2_sel<F16>(v.x, v.y, g.bwd_bf16); pk.y = pack2_sel<F16>(v.z, v.w, g.bwd_bf16);
             v3_st<uint2>(g.outH + o, pk);
             v3_st<float4>(g.outF + o, make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)));
         } else if constexpr (EPI == EPI_DGELU) {
@@ -629,6 +639,7 @@ __device__ __forceinline__ void v3_epilogue(const GemmArgs& g, const f32x16_t (&
             bf16_t* out = (EPI == EPI_GELU && pass == 1) ? g.outH2 : g.outH;
             if (out == nullptr) continue;
             if (EPI == EPI_GELU && pass == 1) v3_stage16<F16, 1>(wl, acc, bv, lr, lg);
+            else if (EPI == EPI_GELU && F16 && g.bwd_bf16) v3_stage16<false, 0>(wl, acc, bv, lr, lg);  // pre-activation for the bf16 backward
             else v3_stage16<F16, 0>(wl, acc, bv, lr, lg);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -660,6 +671,11 @@ __device__ __forceinline__ void v3_epilogue(const GemmArgs& g, const f32x16_t (&
             float bv[2][4][4];
             v3_col_consts(bv, g.bias != nullptr ? g.bias + nb : nullptr, extra, lg);
             v3_stage16<F16, 0>(wl, acc, bv, lr, lg);
+            // Tensors that only the bf16 backward reads (row-major V; Q^T, K^T, (q+v)^T) are emitted as bf16 when g.bwd_bf16 is
+            // set: converted from the staged f16 tile on the way out (same double rounding as a later in-place conversion,
+            // without the extra pass over HBM); V^T and the row-major q / k stay f16.
+            const bool row_bf = F16 && g.bwd_bf16 && which == 2 && pass == 0;
+            const bool tr_bf = F16 && g.bwd_bf16 && !(which == 2 && pass == 0);
             __builtin_amdgcn_wave_barrier();
             if (rd != nullptr) {  // (the row-major V is only needed by the backward: inference passes v = NULL)
 #pragma unroll
@@ -667,6 +683,10 @@ __device__ __forceinline__ void v3_epilogue(const GemmArgs& g, const f32x16_t (&
                     uint4 v[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint4*>(wl + ((rb + u) * 8 + (lane >> 3)) * V3_RS16 + (lane & 7) * 16);
+                    if (row_bf) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = make_uint4(h2x2_to_bf(v[u].x), h2x2_to_bf(v[u].y), h2x2_to_bf(v[u].z), h2x2_to_bf(v[u].w));
+                    }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int m = mb + (rb + u) * 8 + (lane >> 3);
@@ -692,7 +712,9 @@ __device__ __forceinline__ void v3_epilogue(const GemmArgs& g, const f32x16_t (&
 #pragma unroll 8
                         for (int dd = 0; dd < 32; ++dd) {
                             const int d = dd * 2 + dsel;
-                            *reinterpret_cast<unsigned*>(base + (size_t)d * g.seq_pad) = (unsigned)s0[d] | ((unsigned)s1[d] << 16);
+                            unsigned pk = (unsigned)s0[d] | ((unsigned)s1[d] << 16);
+                            if (tr_bf) pk = h2x2_to_bf(pk);
+                            *reinterpret_cast<unsigned*>(base + (size_t)d * g.seq_pad) = pk;
                         }
                     }
                 }
@@ -705,7 +727,7 @@ __device__ __forceinline__ void v3_epilogue(const GemmArgs& g, const f32x16_t (&
                         bf16_t* base = td + (size_t)(bidx * g.heads + h) * 64 * g.seq_pad + t;
                         const unsigned short* src = reinterpret_cast<const unsigned short*>(wl + row * V3_RS16);
 #pragma unroll 8
-                        for (int d = 0; d < 64; ++d) base[(size_t)d * g.seq_pad] = src[d];
+                        for (int d = 0; d < 64; ++d) base[(size_t)d * g.seq_pad] = tr_bf ? f2bf(h2f(src[d])) : src[d];
                     }
                 }
             }
@@ -1315,7 +1337,7 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
             }
             return sed_check_launch();
         }
-        if (v5 && fits32) {
+        if (v5 && fits32 && !g.bwd_bf16) {
             static const int ncu = []() {
                 int dev = 0, n = 0;
                 (void)hipGetDevice(&dev);
@@ -1375,6 +1397,9 @@ extern "C" int sed_gemm_nt(const void* A, const void* B, int M, int N, int K, in
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ksplit = ksplit > 0 ? ksplit : 1;
     g.alpha = alpha; g.bias = bias; g.resF = resF; g.outF = outF; g.outH = (bf16_t*)outH; g.outH2 = (bf16_t*)outH2;
     g.auxH = (const bf16_t*)auxH;
+    g.bwd_bf16 = (f16 & 2) ? 1 : 0;
+    f16 &= 1;
+    if (g.bwd_bf16 && !f16) return SED_ERR_ARG;
     switch (epi) {
         case EPI_F32: return launch_gemm<EPI_F32>(g, f16, stream);
         case EPI_F32_RESID: return launch_gemm<EPI_F32_RESID>(g, f16, stream);
@@ -1400,6 +1425,9 @@ extern "C" int sed_gemm_qkv(const void* A, const void* W, const float* bias, int
     g.q2 = (bf16_t*)q2; g.q2t = (bf16_t*)q2t; g.pu = pos_u; g.pv = pos_v;
     g.seq = seq; g.seq_pad = seq_pad; g.heads = heads;
     if (seq <= 0 || (seq_pad % 64) || M % seq) return SED_ERR_ARG;
+    g.bwd_bf16 = (f16 & 2) ? 1 : 0;
+    f16 &= 1;
+    if (g.bwd_bf16 && !f16) return SED_ERR_ARG;
     return launch_gemm<EPI_QKV>(g, f16, stream);
 }
 

@@ -150,8 +150,12 @@ class SedEngine:
         if save:
             ctx["cols"] = cols
         # per-call scratch (reused across layers when not saving)
-        mk_qkv = lambda: [E(Bx * H, N, 64, dt=A16) for _ in range(3)]
-        mk_t = lambda: [torch.zeros(Bx * H, 64, Npad, dtype=A16, device=dev) for _ in range(3)]
+        # tensors that only the backward reads (row-major V, Q^T, K^T, GELU pre-activation) are produced as bf16 right away
+        B16 = BF16 if save else A16
+        qkv_flag = 3 if (save and f16) else f16
+        mk_qkv = lambda: [E(Bx * H, N, 64, dt=A16), E(Bx * H, N, 64, dt=A16), E(Bx * H, N, 64, dt=B16)]
+        mk_t = lambda: [torch.zeros(Bx * H, 64, Npad, dtype=B16, device=dev), torch.zeros(Bx * H, 64, Npad, dtype=B16, device=dev),
+                        torch.zeros(Bx * H, 64, Npad, dtype=A16, device=dev)]
         scratch = None
         pooled = None
         for li in range(m.depth):
@@ -164,7 +168,7 @@ class SedEngine:
                 o16 = E(M, D, dt=A16)
                 lse = E(Bx * H, N)
                 h2 = E(M, D, dt=A16)
-                hpre = E(M, 4 * D, dt=A16)
+                hpre = E(M, 4 * D, dt=B16)
                 act = E(M, 4 * D, dt=A16)
                 mean1, rstd1, mean2, rstd2 = (E(M), E(M), E(M), E(M)) if save else (None, None, None, None)
                 scratch = (h16, q, k, v, qt, kt, vt, o16, lse, h2, hpre, act)
@@ -175,7 +179,7 @@ class SedEngine:
             call("sed_layernorm_fwd", x_in, self.P(p + "norm1.weight"), self.P(p + "norm1.bias"), 1e-6, 1.0, h16, None,
                  mean1, rstd1, M, D, f16)
             call("sed_gemm_qkv", h16, W[p + "attn.qkv.weight"].w, self.P(p + "attn.qkv.bias"), M, D, H, N, Npad, q, k,
-                 v if save else None, qt, kt, vt, None, None, None, None, f16)  # row-major V is a backward-only operand
+                 v if save else None, qt, kt, vt, None, None, None, None, qkv_flag)  # row-major V is a backward-only operand
             call("sed_mhsa_fwd", q, k, vt, o16, lse, Bx, H, N, Npad, f16)
             x_mid = E(Bx, N, D) if save else x_in
             gemm_nt(o16, W[p + "attn.proj.weight"].w, EPI_F32_RESID, bias=self.P(p + "attn.proj.bias"), res=x_in,
@@ -246,14 +250,17 @@ class SedEngine:
             Ph.copy_(ptmp.view(Rpad, H, 64).permute(1, 0, 2))
             if save:
                 Pt.copy_(ptmp.view(Rpad, H, 64).permute(1, 2, 0))
-            qu, k, v = [E(B * H, T, 64, dt=A16) for _ in range(3)]
+            B16 = BF16 if save else A16   # backward-only tensors (row-major V, transposed q+u / q+v / K, pre-activations)
+            qu, k = [E(B * H, T, 64, dt=A16) for _ in range(2)]
+            v = E(B * H, T, 64, dt=B16)
             qv = E(B * H, T, 64, dt=A16)
             vt = torch.zeros(B * H, 64, Tpad, dtype=A16, device=dev)
             qut = kt = qvt = None
             if save:
-                qut, kt, qvt = [torch.zeros(B * H, 64, Tpad, dtype=A16, device=dev) for _ in range(3)]
+                qut, kt, qvt = [torch.zeros(B * H, 64, Tpad, dtype=B16, device=dev) for _ in range(3)]
             call("sed_gemm_qkv", yop, wk(p + "attn.in_proj.weight"), self.P(p + "attn.in_proj.bias"), M, KD, H, T, Tpad,
-                 qu, k, v, qut, kt, vt, qv, qvt, self.P(p + "attn.pos_bias_u"), self.P(p + "attn.pos_bias_v"), f16)
+                 qu, k, v, qut, kt, vt, qv, qvt, self.P(p + "attn.pos_bias_u"), self.P(p + "attn.pos_bias_v"),
+                 3 if (save and f16) else f16)
             o16 = E(M, D, dt=F32 if SP else A16)
             lse = E(B * H, T)
             call("sed_relpos_attn_fwd", qu, qv, k, vt, Ph, o16, lse, B, H, T, Tpad, Rpad, f16, 1 if SP else 0)
@@ -264,7 +271,7 @@ class SedEngine:
             mean2, rstd2 = (E(M), E(M)) if save else (None, None)
             call("sed_layernorm_fwd", x1, self.P(p + "norm2.weight"), self.P(p + "norm2.bias"), 1e-5, 1.0,
                  None if SP else h2, h2 if SP else None, mean2, rstd2, M, D, f16)
-            hpre = E(M, D, dt=A16)
+            hpre = E(M, D, dt=B16)
             if SP:
                 act = E(M, D)
                 gemm_nt(split3(h2, M, D), wk(p + "mlp.fc1.weight"), EPI_GELU32, bias=self.P(p + "mlp.fc1.bias"), outH=hpre,

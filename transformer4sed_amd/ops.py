@@ -105,10 +105,12 @@ def gemm_nt(A, B, epi, M=None, bias=None, res=None, outF=None, outH=None, outH2=
     """C[M,N] = A[M,K] . B[N,K]^T (bf16 operands) with fused epilogue; see include/sed_hip.h."""
     M = A.shape[0] if M is None else M
     N, K = B.shape[0], B.shape[1]
-    if A.dtype != B.dtype or any(t is not None and t.dtype != A.dtype for t in (outH, outH2, aux)):  # noqa: E501
+    # the saved pre-activation of a GELU GEMM (epi 3 / 8) is consumed only by the bf16 backward: it may be bf16 in an f16 GEMM
+    pre_bf16 = epi in (EPI_GELU, EPI_GELU32) and outH is not None and outH.dtype == BF16 and A.dtype == F16
+    if A.dtype != B.dtype or any(t is not None and t.dtype != A.dtype for t in ((None if pre_bf16 else outH), outH2, aux)):
         raise RuntimeError("gemm_nt: all 16-bit operands/outputs of one GEMM must share one type (f16 or bf16)")
     call("sed_gemm_nt", A, B, M, N, K, lda or A.shape[1], ldb or K, epi, bias, res, outF, outH, outH2, aux, ldc or N,
-         float(alpha), ksplit, is_f16(A))
+         float(alpha), ksplit, 3 if pre_bf16 else is_f16(A))
 
 
 def dw_ksplit(n_out, k_in, mpad):
