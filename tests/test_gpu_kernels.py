@@ -160,6 +160,44 @@ def test_gemm_qkv_split(DT):
         assert torch.equal(got[:, :, :N], src.transpose(1, 2)) and float(got[:, :, N:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("B,N", [(2, 70), (2, 602)])   # 128^2 kernel (M < 1024) and the 256^2 kernel with its staged epilogue
+def test_gemm_qkv_backward_only_outputs_as_bf16(B, N):
+    """f16 = 3: q, k (+ biased q2) and V^T stay IEEE half for the forward; row-major V, Q^T, K^T, q2^T come out as bf16."""
+    Hh = 12
+    Npad = pad64(N)
+    M = B * N
+    x = r16(rnd(M, 768, seed=7)); W = r16(rnd(2304, 768, scale=0.05, seed=8)); b = rnd(2304, seed=9)
+    u, v = rnd(Hh, 64, seed=10), rnd(Hh, 64, seed=11)
+    mk = lambda dt: torch.full((B * Hh, N, 64), 9.0, dtype=dt, device=DEV)
+    mkt = lambda dt: torch.zeros(B * Hh, 64, Npad, dtype=dt, device=DEV)
+    q, k, q2, vv = mk(F16), mk(F16), mk(F16), mk(BF16)
+    qt, kt, q2t, vt = mkt(BF16), mkt(BF16), mkt(BF16), mkt(F16)
+    call("sed_gemm_qkv", x.to(F16), W.to(F16), b, M, 768, Hh, N, Npad, q, k, vv, qt, kt, vt, q2, q2t, u, v, 3)
+    ref = (x @ W.t() + b).view(B, N, 3, Hh, 64).permute(2, 0, 3, 1, 4)
+    rq, rk, rv = [ref[i].reshape(B * Hh, N, 64) for i in range(3)]
+    uu = u.view(1, Hh, 1, 64).expand(B, Hh, N, 64).reshape(B * Hh, N, 64)
+    vvb = v.view(1, Hh, 1, 64).expand(B, Hh, N, 64).reshape(B * Hh, N, 64)
+    for got, want, nm in ((q, rq + uu, "q+u"), (q2, rq + vvb, "q+v"), (k, rk, "k"), (vv, rv, "v(bf16)"),
+                          (qt[:, :, :N].transpose(1, 2), rq + uu, "qt(bf16)"), (kt[:, :, :N].transpose(1, 2), rk, "kt(bf16)"),
+                          (q2t[:, :, :N].transpose(1, 2), rq + vvb, "q2t(bf16)"), (vt[:, :, :N].transpose(1, 2), rv, "vt")):
+        e = maxerr(got.float(), want); report(f"qkv flag3 N={N} " + nm, e); assert e < 0.03
+    # 256^2 kernel: the bf16 copies are the staged half values rounded once more (= the in-place conversion they replace);
+    # the 128^2 kernel rounds the fp32 accumulator to bf16 directly
+    if M >= 1024:
+        assert torch.equal(qt[:, :, :N], q.transpose(1, 2).float().to(BF16))
+    for t in (qt, kt, vt, q2t):
+        assert float(t[:, :, N:].float().abs().max()) == 0
+
+
+def test_gelu_preactivation_as_bf16():
+    M, N, K = 1100, 768, 256
+    A = r16(rnd(M, K, seed=3)); W = r16(rnd(N, K, scale=0.1, seed=4)); b = rnd(N, seed=5)
+    h_bf = torch.empty(M, N, dtype=BF16, device=DEV); a16 = torch.empty(M, N, dtype=F16, device=DEV)
+    gemm_nt(A.to(F16), W.to(F16), ops.EPI_GELU, bias=b, outH=h_bf, outH2=a16)
+    h = A @ W.t() + b
+    assert maxerr(h_bf.float(), h) < 0.03 and maxerr(a16.float(), torch.nn.functional.gelu(h)) < 0.01
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def _split(B, N, seed, scale=1.0, dt=BF16):
     Hh = 12
