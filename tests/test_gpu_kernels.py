@@ -180,7 +180,8 @@ def test_gemm_qkv_backward_only_outputs_as_bf16(B, N):
     for got, want, nm in ((q, rq + uu, "q+u"), (q2, rq + vvb, "q+v"), (k, rk, "k"), (vv, rv, "v(bf16)"),
                           (qt[:, :, :N].transpose(1, 2), rq + uu, "qt(bf16)"), (kt[:, :, :N].transpose(1, 2), rk, "kt(bf16)"),
                           (q2t[:, :, :N].transpose(1, 2), rq + vvb, "q2t(bf16)"), (vt[:, :, :N].transpose(1, 2), rv, "vt")):
-        e = maxerr(got.float(), want); report(f"qkv flag3 N={N} " + nm, e); assert e < 0.03
+        e = maxerr(got.float(), want); report(f"qkv flag3 N={N} " + nm, e)
+        assert e < (0.06 if "bf16" in nm else 0.03)   # |values| reach ~8: bf16 keeps 8 significant bits
     # 256^2 kernel: the bf16 copies are the staged half values rounded once more (= the in-place conversion they replace);
     # the 128^2 kernel rounds the fp32 accumulator to bf16 directly
     if M >= 1024:
