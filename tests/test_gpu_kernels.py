@@ -160,6 +160,21 @@ def test_gemm_qkv_split(DT):
         assert torch.equal(got[:, :, :N], src.transpose(1, 2)) and float(got[:, :, N:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("XDT", [BF16, F16])
+@pytest.mark.parametrize("T,M,N", [(1024, 256, 256), (2432, 768, 512), (38080, 768, 768)])
+def test_gemm_dw_tn(T, M, N, XDT):
+    """TN weight-gradient GEMM (transposing LDS reads, split-K atomics) against fp32 torch; accumulates into dW."""
+    dY = r16(rnd(T, M, scale=0.3, seed=21)).to(BF16)
+    X = rnd(T, N, seed=22).to(XDT)
+    dW = rnd(M, N, seed=23).contiguous()
+    # a half-precision X is rounded to bf16 in registers (the gradient-side MFMA is bf16): the reference does the same rounding
+    want = dW + dY.float().t() @ X.float().to(BF16).float()
+    ops.gemm_dw_tn(dY, X, dW)
+    e = float(((dW - want).abs() / (want.abs() + 1.0)).max())
+    report(f"gemm_dw_tn T={T} M={M} N={N} X={'f16' if XDT == F16 else 'bf16'}", e)
+    assert e < 1e-3 * (T / 1024) ** 0.5 + 1e-4
+
+
 @pytest.mark.parametrize("B,N", [(2, 70), (2, 602)])   # 128^2 kernel (M < 1024) and the 256^2 kernel with its staged epilogue
 def test_gemm_qkv_backward_only_outputs_as_bf16(B, N):
     """f16 = 3: q, k (+ biased q2) and V^T stay IEEE half for the forward; row-major V, Q^T, K^T, q2^T come out as bf16."""

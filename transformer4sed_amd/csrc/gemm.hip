@@ -1292,6 +1292,222 @@ __global__ __launch_bounds__(512) void gemm_nt_v5_kernel(const GemmArgs g) {
 #undef V5_DMA
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight-gradient GEMM in TN form: dW[m, n] += sum_t dY[t, m] * X[t, n] with BOTH operands read in their natural row-major
+// [token][feature] layout -- no transposed operand copies in HBM (the NT kernels need dY^T and X^T: 6.4 ms/step of transposes).
+// The contraction index is the slow dimension of both tiles, so the MFMA fragments (8 consecutive k per lane) are columns of the
+// LDS image: read with `ds_read_b64_tr_b16`.  Semantics measured on gfx950 (tools/ablate/trread.hip): the 16 lanes of a group
+// supply 16 addresses of 8-byte chunks, taken as a [4 rows r = a>>2][4 chunks c = a&3] grid = a 4 x 16 halfword matrix M;
+// lane i of the group receives column i: {M[0][i], M[1][i], M[2][i], M[3][i]}.  With rows = 4 consecutive tokens and columns =
+// 16 consecutive features, two such reads give the 8-token fragment of one feature per lane.
+// LDS stage = [64 tokens][256 features] per operand (512-B rows), filled by DMA; 64-B unit u of token row k is stored at unit
+// u ^ (k & 3), so that the four rows of a transposing read hit four different bank quarters.
+// Same 256 x 256 x 64 tiling / 8 waves (128 x 64 per wave) / two stages as v3; split-K over the tokens, atomic accumulate.
+// X may be IEEE half (saved forward activation): converted to bf16 in registers (the gradient-side MFMA is bf16).
+// ---------------------------------------------------------------------------------------------------------------------
+struct TnArgs {
+    const bf16_t* A;  // dY [T, lda]  bf16
+    const bf16_t* B;  // X  [T, ldb]  bf16 or f16
+    float* C;         // dW [M, ldc]  fp32 (accumulated)
+    float* ws;        // optional split-K workspace [ksplit][M][N] fp32 (plain stores + a reduce pass instead of atomics)
+    int M, N, T, lda, ldb, ldc, ksplit, b_f16;
+};
+template <int OFF>
+__device__ __forceinline__ unsigned long long lds_tr(unsigned addr) {
+    unsigned long long v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ s16x8_t tn_frag(unsigned long long lo, unsigned long long hi, bool cvt_f16) {
+    unsigned w[4] = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+    if (cvt_f16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = h2x2_to_bf(w[e]);
+    }
+    s16x8_t f;
+    __builtin_memcpy(&f, w, 16);
+    return f;
+}
+template <bool BF16_B>
+__global__ __launch_bounds__(512) void gemm_tn_dw_kernel(const TnArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntn = g.N / V3_T, ntm = g.M / V3_T, nwg = ntm * ntn;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int m0 = (t % ntm) * V3_T, n0 = (t / ntm) * V3_T;
+    const int ktiles = g.T / BK;
+    const int kt_begin = (int)(((long long)blockIdx.y * ktiles) / g.ksplit);
+    const int kt_end = (int)(((long long)(blockIdx.y + 1) * ktiles) / g.ksplit);
+    const int nk = kt_end - kt_begin;
+    // DMA: per operand 32 pieces of 2 token rows x 512 B; waves 0-3 fetch dY pieces, 4-7 X pieces (8 each)
+    const bool isB = wave >= 4;
+    const bf16_t* src[8];
+    int dst[8];
+    {
+        const int krow = lane >> 5, pc = lane & 31;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int piece = (wave & 3) * 8 + i, k = piece * 2 + krow;
+            const int col = (((pc >> 2) ^ (k & 3)) * 4 + (pc & 3)) * 8;   // logical feature offset stored at physical chunk pc
+            src[i] = (isB ? g.B + (size_t)k * g.ldb + n0 : g.A + (size_t)k * g.lda + m0) + col + (size_t)kt_begin * BK * (isB ? g.ldb : g.lda);
+            dst[i] = (isB ? 32768 : 0) + piece * 1024;
+        }
+    }
+    const size_t kstride = (size_t)BK * (isB ? g.ldb : g.lda);
+#define TN_DMA(kt, stage)                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                         \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)(kt) * kstride), \
+                                         (__attribute__((address_space(3))) void*)(lds3 + (stage) * V3_STAGE + dst[i]),   \
+                                         16, 0, 0);
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // transposing-read lane addresses: group G = lane >> 4 (k half g = G >> 1, 16-feature half = G & 1), a = lane & 15
+    const int a = lane & 15, G = lane >> 4, kg = G >> 1;
+    unsigned aaddr[4], baddr[2];
+    const unsigned lbase = (unsigned)(size_t)lds3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int col = wm * 128 + i * 32 + (G & 1) * 16 + 4 * (a & 3);
+        aaddr[i] = lbase + (8 * kg + (a >> 2)) * 512 + (((col >> 5) ^ (a >> 2)) << 6) + (col & 31) * 2;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = wn * 64 + j * 32 + (G & 1) * 16 + 4 * (a & 3);
+        baddr[j] = lbase + 32768 + (8 * kg + (a >> 2)) * 512 + (((col >> 5) ^ (a >> 2)) << 6) + (col & 31) * 2;
+    }
+    if (nk > 0) { TN_DMA(0, 0); }
+    for (int it = 0; it < nk; ++it) {
+        const int stage = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (it + 1 < nk) { TN_DMA(it + 1, stage ^ 1); }
+        const unsigned so = stage * V3_STAGE;
+#define TN_READS(S, al, ah, bl, bh)                                                                                       \
+        {                                                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) { al[i] = lds_tr<(S) * 8192>(aaddr[i] + so); ah[i] = lds_tr<(S) * 8192 + 2048>(aaddr[i] + so); } \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) { bl[j] = lds_tr<(S) * 8192>(baddr[j] + so); bh[j] = lds_tr<(S) * 8192 + 2048>(baddr[j] + so); } \
+        }
+        /* the compiler does not know the asm results are still in flight: every consumer is tied to the counted wait */       \
+#define TN_WAIT(CNT, al, ah, bl, bh)                                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                         \
+                     : "+v"(al[0]), "+v"(al[1]), "+v"(al[2]), "+v"(al[3]), "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3]), \
+                       "+v"(bl[0]), "+v"(bl[1]), "+v"(bh[0]), "+v"(bh[1])                                                  \
+                     :: "memory");
+#define TN_MFMA(al, ah, bl, bh)                                                                                            \
+        {                                                                                                                  \
+            s16x8_t af[4], bf_[2];                                                                                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) af[i] = tn_frag(al[i], ah[i], false);                            \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) bf_[j] = tn_frag(bl[j], bh[j], !BF16_B);                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mfma32t<false>(bf_[j], af[i], acc[i][j]);        \
+        }
+        // fragment reads run one k-step ahead of the MFMAs (12 transposing reads per k-step; lgkmcnt counts them in order)
+        unsigned long long pal[4], pah[4], pbl[2], pbh[2], qal[4], qah[4], qbl[2], qbh[2];
+        TN_READS(0, pal, pah, pbl, pbh)
+        TN_READS(1, qal, qah, qbl, qbh)
+        TN_WAIT(12, pal, pah, pbl, pbh)
+        TN_MFMA(pal, pah, pbl, pbh)
+        TN_READS(2, pal, pah, pbl, pbh)
+        TN_WAIT(12, qal, qah, qbl, qbh)
+        TN_MFMA(qal, qah, qbl, qbh)
+        TN_READS(3, qal, qah, qbl, qbh)
+        TN_WAIT(12, pal, pah, pbl, pbh)
+        TN_MFMA(pal, pah, pbl, pbh)
+        TN_WAIT(0, qal, qah, qbl, qbh)
+        TN_MFMA(qal, qah, qbl, qbh)
+#undef TN_READS
+#undef TN_WAIT
+#undef TN_MFMA
+    }
+    __builtin_amdgcn_s_barrier();
+    // Split-K partial sums.  With a workspace: plain coalesced stores of the tile into ws[split] (a reduce pass adds the splits
+    // into dW) -- one workgroup per CU cannot hide 64 Ki device-scope atomics behind anything (measured ~150-200 us per GEMM,
+    // as long as the whole K loop).  Without: atomics straight into dW.
+    unsigned char* wl = lds3 + wave * V3_WLDS;
+    const int lr = lane & 31, lg = lane >> 5;
+    const int mb = m0 + wm * 128, nb = n0 + wn * 64;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        v3_stage32(wl, acc, 2 * pass, lr, lg);
+        __builtin_amdgcn_wave_barrier();
+        if (g.ws != nullptr) {
+            float* dstp = g.ws + ((size_t)blockIdx.y * g.M + mb + pass * 64) * g.N + nb + (lane & 15) * 4;
+#pragma unroll
+            for (int rb = 0; rb < 16; rb += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(wl + ((rb + u) * 4 + (lane >> 4)) * V3_RS32 + (lane & 15) * 16);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v3_st<float4>(dstp + (size_t)((rb + u) * 4 + (lane >> 4)) * g.N, v[u]);
+            }
+        } else {
+#pragma unroll 8
+            for (int row = 0; row < 64; ++row) {
+                const float v = *reinterpret_cast<const float*>(wl + row * V3_RS32 + lane * 4);
+                unsafeAtomicAdd(&g.C[(size_t)(mb + pass * 64 + row) * g.ldc + nb + lane], v);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#undef TN_DMA
+}
+
+// dW[m, n] += sum_s ws[s][m][n]
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, int ks, int M, int N, float* __restrict__ C,
+                                                        int ldc) {
+    const size_t total4 = (size_t)M * N / 4, plane4 = total4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<const float4*>(ws)[i];
+        for (int s2 = 1; s2 < ks; ++s2) {
+            const float4 b = reinterpret_cast<const float4*>(ws)[(size_t)s2 * plane4 + i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        const size_t e = i * 4, m = e / N, n = e - m * N;
+        float4* dst = reinterpret_cast<float4*>(C + m * ldc + n);
+        float4 c = *dst;
+        c.x += a.x; c.y += a.y; c.z += a.z; c.w += a.w;
+        *dst = c;
+    }
+}
+
+extern "C" int sed_gemm_dw_tn(const void* dY, const void* X, int x_f16, int T, int M, int N, int ldy, int ldx, float* dW,
+                              int ldc, float* workspace, int64_t workspace_bytes, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (T <= 0 || (T % BK) || (M % V3_T) || (N % V3_T) || (ldy % 8) || (ldx % 8) || (ldc % 4) || M <= 0 || N <= 0) return SED_ERR_ARG;
+    TnArgs g;
+    g.A = (const bf16_t*)dY; g.B = (const bf16_t*)X; g.C = dW;
+    g.M = M; g.N = N; g.T = T; g.lda = ldy; g.ldb = ldx; g.ldc = ldc; g.b_f16 = x_f16;
+    const int tiles = (M / V3_T) * (N / V3_T), ktiles = T / BK;
+    // one workgroup per CU and ONE round: tiles * ks <= 256 (rounding the split count up instead costs a second, nearly empty
+    // round -- 36 tiles x 8 splits = 288 workgroups took twice the time of 36 x 7)
+    int ks = 256 / tiles;
+    if (ks > ktiles / 16) ks = ktiles / 16;
+    if (ks < 1) ks = 1;
+    g.ksplit = ks;
+    g.ws = (workspace != nullptr && workspace_bytes >= (int64_t)ks * M * N * 4) ? workspace : nullptr;
+    static bool attr[2] = {false, false};
+    dim3 grid(tiles, ks);
+    if (x_f16) {
+        if (!attr[1]) { (void)hipFuncSetAttribute((const void*)gemm_tn_dw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr[1] = true; }
+        hipLaunchKernelGGL((gemm_tn_dw_kernel<false>), grid, dim3(512), V3_LDS, stream, g);
+    } else {
+        if (!attr[0]) { (void)hipFuncSetAttribute((const void*)gemm_tn_dw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr[0] = true; }
+        hipLaunchKernelGGL((gemm_tn_dw_kernel<true>), grid, dim3(512), V3_LDS, stream, g);
+    }
+    if (g.ws != nullptr) {
+        int blocks = (int)(((size_t)M * N / 4 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks), dim3(256), 0, stream, g.ws, ks, M, N, dW, ldc);
+    }
+    return sed_check_launch();
+}
+
 template <int EPI>
 static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
     if (g.M <= 0 || g.N % TILE != 0 || g.K % BK != 0 || g.ksplit < 1) return SED_ERR_ARG;
@@ -1309,7 +1525,7 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
         int ks3 = 1;
         if (EPI == EPI_ATOMIC) {  // split-K weight gradients: one workgroup per CU, at least 16 K tiles per split
             const int tiles3 = cdiv(g.M, V3_T) * (g.N / V3_T), ktiles = g.K / BK;
-            ks3 = cdiv(256, tiles3);
+            ks3 = 256 / tiles3;  // one round of workgroups (see sed_gemm_dw_tn)
             if (ks3 > ktiles / 16) ks3 = ktiles / 16;
             if (ks3 < 1) ks3 = 1;
         }

@@ -126,6 +126,30 @@ def gemm_dw(dYt, Xt, dW, n_out=None):
     gemm_nt(dYt, Xt, EPI_ATOMIC, M=n_out, outF=dW, ksplit=dw_ksplit(n_out, k_in, mpad), ldc=k_in)
 
 
+def gemm_dw_tn(dY, X, dW, tokens=None, ldc=None):
+    """dW[n_out, k_in] (fp32) += dY[tokens, n_out]^T . X[tokens, k_in]; both operands in their row-major [token][feature] layout
+    (dY bf16, X bf16 or f16).  Needs tokens % 64 == 0 and both feature counts % 256 == 0 (see `dw_tn_ok`)."""
+    T = dY.shape[0] if tokens is None else tokens
+    ws = _dw_workspace(dY.device)
+    call("sed_gemm_dw_tn", dY, X, is_f16(X), T, dY.shape[1], X.shape[1], dY.shape[1], X.shape[1], dW, ldc or X.shape[1], ws,
+         ws.numel() * 4)
+
+
+_DW_WS = {}
+
+
+def _dw_workspace(dev):
+    """Split-K partial-sum workspace of the TN weight-gradient GEMM (96 MiB per device, allocated once)."""
+    key = str(dev)
+    if key not in _DW_WS:
+        _DW_WS[key] = torch.empty(24 << 20, dtype=F32, device=dev)
+    return _DW_WS[key]
+
+
+def dw_tn_ok(tokens, n_out, k_in):
+    return tokens % 64 == 0 and n_out % 256 == 0 and k_in % 256 == 0
+
+
 def transpose_bf16(x, rows, cols, out_t, out_s=None, colsum=None, ld=None):
     """x [rows, cols] (f32 / bf16 / f16) -> out_t [cols, Rpad] (nullable); optional straight 16-bit copy / fp32 column
     sums (+=).  Output kinds follow the output tensors' dtypes."""
