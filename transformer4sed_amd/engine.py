@@ -16,7 +16,7 @@ import torch
 from . import ops
 import os
 
-from .ops import BF16, F16, F32, call, h2d, gemm_nt, gemm_dw, pad64, transpose_bf16, to_bf16_, is_f16, split3, o_kind
+from .ops import BF16, F16, F32, call, h2d, gemm_nt, gemm_dw, gemm_dw_tn, dw_tn_ok, pad64, transpose_bf16, to_bf16_, is_f16, split3, o_kind
 from .ops import EPI_F32, EPI_F32_RESID, EPI_BF16, EPI_GELU, EPI_DGELU, EPI_F32_BF16, EPI_GELU32
 
 D = 768
@@ -64,6 +64,8 @@ class SedEngine:
         # concatenated reduction dim.  Their operand rounding is what limits posterior parity: with
         # it 1e-3 holds with a 10x margin, for ~4 % of step time.  SED_DECODER_SPLIT=0 turns it off.
         self.split = os.environ.get("SED_DECODER_SPLIT", "1") != "0" and self.act == F16
+        # weight gradients: TN kernel on the operands as they lie (default) or transposed copies + NT split-K kernel
+        self.dw_tn = os.environ.get("SED_DW_TN", "1") != "0"
 
     def __deepcopy__(self, memo):
         return None  # `ema_net = deepcopy(net)` (finetune/passt/setting.py:8-15): the copy rebuilds its engine lazily
@@ -499,14 +501,36 @@ class SedEngine:
         call("sed_assemble_tokens_bwd", genc, dconv16, G("backbone.cls_token"), G("backbone.dist_token"),
              G("backbone.new_pos_embed"), G("backbone.freq_new_pos_embed"), G("backbone.time_new_pos_embed"), toff, B, tp)
         Mp = B * 12 * tp
-        Mppad = pad64(Mp)
-        dT = E(D, Mppad, dt=BF16)
-        transpose_bf16(dconv16, Mp, D, dT, colsum=G("backbone.patch_embed.proj.bias"))
-        cT = E(256, Mppad, dt=BF16)
-        transpose_bf16(ectx["cols"], Mp, 256, cT)
-        gemm_dw(dT, cT, G("backbone.patch_embed.proj.weight"))
+        self._dw_accum(dconv16, ectx["cols"], Mp, G("backbone.patch_embed.proj.weight"), G("backbone.patch_embed.proj.bias"))
         if hook is not None:
             hook("embed")
+
+    def _dw_accum(self, dy, x, M, gW, bias=None):
+        """gW += dy^T x (weight gradient), bias += column sums of dy.  dy [M, n_out] f32 or bf16, x [M, k_in] (saved forward
+        operand, 16-bit or f32); gW / bias are arena views or None.  Returns dy as a bf16 [M, n_out] tensor (operand of the
+        dX GEMM that follows).  TN kernel on the operands as they lie when the shapes allow it (tokens % 64, features % 256);
+        otherwise transposed copies + the NT split-K kernel."""
+        dev = dy.device
+        n_out, k_in = dy.shape[1], x.shape[1]
+        E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
+        tn = self.dw_tn and dw_tn_ok(M, n_out, k_in) and x.dtype in (F16, BF16)
+        if tn:
+            g16 = E(M, n_out, dt=BF16) if dy.dtype == F32 else None
+            if g16 is not None or bias is not None:
+                transpose_bf16(dy, M, n_out, None, out_s=g16, colsum=bias)   # cast and/or column sums only, one pass
+            dy16 = g16 if g16 is not None else dy
+            if gW is not None:
+                gemm_dw_tn(dy16, x, gW, tokens=M)
+            return dy16
+        Mpad = pad64(M)
+        g16 = E(M, n_out, dt=BF16) if dy.dtype == F32 else None
+        gT = E(n_out, Mpad, dt=BF16)
+        transpose_bf16(dy, M, n_out, gT, out_s=g16, colsum=bias)
+        if gW is not None:
+            xT = E(k_in, Mpad, dt=BF16)
+            transpose_bf16(x, M, k_in, xT)
+            gemm_dw(gT, xT, gW)
+        return g16 if g16 is not None else dy
 
     def _mlp_bwd(self, W, n1, n2, dy, x16, hpre, act, M, G, residual):
         """Backward of y = fc2(gelu(fc1(x))) given dy [M, n_out] f32.  Returns dx f32 [M, D] (new tensor), or adds
@@ -519,21 +543,11 @@ class SedEngine:
         n_out = w2.w.shape[0]
         train = G(n1 + ".weight") is not None
         hpre = to_bf16_(hpre)
-        g16 = E(M, n_out, dt=BF16)
-        gT = E(n_out, Mpad, dt=BF16)
-        transpose_bf16(dy, M, n_out, gT, out_s=g16, colsum=G(n2 + ".bias") if train else None)
+        g16 = self._dw_accum(dy, act, M, G(n2 + ".weight") if train else None, G(n2 + ".bias") if train else None)
         dh16 = E(M, hid, dt=BF16)
         gemm_nt(g16, w2.wt, EPI_DGELU, outH=dh16, aux=hpre)
         if train:
-            aT = E(hid, Mpad, dt=BF16)
-            transpose_bf16(act, M, hid, aT)
-            gemm_dw(gT, aT, G(n2 + ".weight"))
-            del aT
-            dhT = E(hid, Mpad, dt=BF16)
-            transpose_bf16(dh16, M, hid, dhT, colsum=G(n1 + ".bias"))
-            xT = E(x16.shape[1], Mpad, dt=BF16)
-            transpose_bf16(x16, M, x16.shape[1], xT)
-            gemm_dw(dhT, xT, G(n1 + ".weight"))
+            self._dw_accum(dh16, x16, M, G(n1 + ".weight"), G(n1 + ".bias"))
         if residual is not None:
             gemm_nt(dh16, w1.wt, EPI_F32_RESID, res=residual, outF=residual)
             return residual
@@ -556,13 +570,7 @@ class SedEngine:
              G(p + "norm2.weight"), G(p + "norm2.bias"), M, D)
         del dln
         # ---- attention branch: x_mid = x_in + proj(attn(LN1(x_in)))
-        g16 = E(M, D, dt=BF16)
-        gT = E(D, Mpad, dt=BF16)
-        transpose_bf16(g2, M, D, gT, out_s=g16, colsum=G(p + "attn.proj.bias"))
-        oT = E(D, Mpad, dt=BF16)
-        transpose_bf16(L["o16"], M, D, oT)
-        gemm_dw(gT, oT, G(p + "attn.proj.weight"))
-        del oT, gT
+        g16 = self._dw_accum(g2, L["o16"], M, G(p + "attn.proj.weight"), G(p + "attn.proj.bias"))
         do16 = E(M, D, dt=BF16)
         gemm_nt(g16, W[p + "attn.proj.weight"].wt, EPI_BF16, outH=do16)
         dqkv = E(M, 3 * D, dt=BF16)
@@ -573,12 +581,7 @@ class SedEngine:
         call("sed_mhsa_bwd", L["q"], to_bf16_(L["qt"]), L["k"], to_bf16_(L["kt"]), to_bf16_(L["v"]), L["o16"], do16,
              L["lse"], Dtmp, dOh, dOt, dqkv, B, H, N, Npad, f16)
         del dOh, dOt, do16
-        dqT = E(3 * D, Mpad, dt=BF16)
-        transpose_bf16(dqkv, M, 3 * D, dqT, colsum=G(p + "attn.qkv.bias"))
-        hT = E(D, Mpad, dt=BF16)
-        transpose_bf16(L["h16"], M, D, hT)
-        gemm_dw(dqT, hT, G(p + "attn.qkv.weight"))
-        del dqT, hT
+        self._dw_accum(dqkv, L["h16"], M, G(p + "attn.qkv.weight"), G(p + "attn.qkv.bias"))
         dln = E(M, D)
         gemm_nt(dqkv, W[p + "attn.qkv.weight"].wt, EPI_F32, outF=dln)
         call("sed_layernorm_bwd", dln, L["x_in"], L["mean1"], L["rstd1"], self.P(p + "norm1.weight"), 1.0, g2, 1,
@@ -607,15 +610,8 @@ class SedEngine:
                  Gl(p + "norm2.weight"), Gl(p + "norm2.bias"), M, D)
             del dln
             # attention branch: x1 = y + out_proj(relattn(y)),  y = LN1(in_scale * x_in)
-            g16 = E(M, D, dt=BF16)
-            gT = E(D, Mpad, dt=BF16)
-            transpose_bf16(g2, M, D, gT, out_s=g16, colsum=Gl(p + "attn.out_proj.bias"))
-            if trainable:
-                oT = E(D, Mpad, dt=BF16)
-                transpose_bf16(L["o16"], M, D, oT)
-                gemm_dw(gT, oT, G(p + "attn.out_proj.weight"))
-                del oT
-            del gT
+            g16 = self._dw_accum(g2, L["o16"], M, G(p + "attn.out_proj.weight") if trainable else None,
+                                 Gl(p + "attn.out_proj.bias"))
             do16 = E(M, D, dt=BF16)
             gemm_nt(g16, W[p + "attn.out_proj.weight"].wt, EPI_BF16, outH=do16)
             dqkv = E(M, 3 * D, dt=BF16)
@@ -637,12 +633,7 @@ class SedEngine:
                 dPT = E(D, Rpad, dt=BF16)
                 transpose_bf16(dP, Rpad, D, dPT)
                 gemm_dw(dPT, posT16, G(p + "attn.linear_pos.weight"))
-                dqT = E(3 * D, Mpad, dt=BF16)
-                transpose_bf16(dqkv, M, 3 * D, dqT, colsum=G(p + "attn.in_proj.bias"))
-                yT = E(D, Mpad, dt=BF16)
-                transpose_bf16(L["y16"], M, D, yT)
-                gemm_dw(dqT, yT, G(p + "attn.in_proj.weight"))
-                del dqT, yT
+                self._dw_accum(dqkv, L["y16"], M, G(p + "attn.in_proj.weight"), G(p + "attn.in_proj.bias"))
             # dy = g (residual from the normalised input) + dqkv @ W_in
             gemm_nt(dqkv, W[p + "attn.in_proj.weight"].wt, EPI_F32_RESID, res=g2, outF=g2)
             gnew = E(B, T, D)
@@ -681,11 +672,7 @@ class SedEngine:
             call("sed_small_linear_bwd", self.P(pre + "f_att_token").reshape(1, D), win[:D], None, dq, dtok, gin[:D],
                  gib[:D], 1, D, D, 0)
             G(pre + "f_att_token").view(1, D).add_(dtok)
-            dkT = E(2 * D, Mpad, dt=BF16)
-            transpose_bf16(dkv, M, 2 * D, dkT, colsum=gib[D:])
-            fT = E(D, Mpad, dt=BF16)
-            transpose_bf16(ectx["frame16"], M, D, fT)
-            gemm_dw(dkT, fT, gin[D:])
+            self._dw_accum(dkv, ectx["frame16"], M, gin[D:], gib[D:])
         norm_train = G("backbone.norm.weight") is not None
         if not (need_dx or norm_train):
             return None

@@ -153,7 +153,7 @@ def dw_tn_ok(tokens, n_out, k_in):
 def transpose_bf16(x, rows, cols, out_t, out_s=None, colsum=None, ld=None):
     """x [rows, cols] (f32 / bf16 / f16) -> out_t [cols, Rpad] (nullable); optional straight 16-bit copy / fp32 column
     sums (+=).  Output kinds follow the output tensors' dtypes."""
-    call("sed_transpose_to_bf16", x, kind(x), rows, cols, ld or cols, out_t, out_t.shape[1] if out_t is not None else rows,
+    call("sed_transpose_to_bf16", x, kind(x), rows, cols, ld or cols, out_t, out_t.shape[1] if out_t is not None else pad64(rows),
          kind(out_t) if out_t is not None else 0, out_s, kind(out_s) if out_s is not None else 0, colsum)
 
 
