@@ -170,7 +170,7 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    timer = None if a.no_kernel_timer else ops.KernelTimer(["sed_gemm_nt", "sed_gemm_qkv"])
+    timer = None if a.no_kernel_timer else ops.KernelTimer(["sed_gemm_nt", "sed_gemm_qkv", "sed_gemm_dw_tn"])
     ops.TIMER = timer
     if world > 1:
         dist.barrier()
@@ -220,8 +220,8 @@ def main():
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("avg_bytes_per_launch")
             traffic_src = "profiles/r1_gemm_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes over this command)"
-        line["roofline"] = {"kernel": "gemm_nt_v3_kernel<EPI,F16> / gemm_nt_kernel (all GEMM launches of the step: linears, qkv, "
-                                      "dX, split-K dW)",
+        line["roofline"] = {"kernel": "gemm_nt_v3_kernel<EPI,F16> / gemm_tn_dw_kernel / gemm_nt_kernel (all GEMM launches of the step: "
+                                      "linears, qkv, dX, split-K dW)",
                             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                             "traffic_source": traffic_src, "alg_bytes_per_launch": round(by / max(1, n)),

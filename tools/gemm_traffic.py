@@ -5,14 +5,14 @@
   python tools/gemm_traffic.py DIR_F/f_counter_collection.csv DIR_W/w_counter_collection.csv profiles/r1_gemm_traffic.json
 
 Units / corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts
-128-byte read requests as 64 bytes, so reads are doubled.  Averages are per launch over every gemm_nt* kernel launch."""
+128-byte read requests as 64 bytes, so reads are doubled.  Averages are per launch over every gemm_nt* / gemm_tn* kernel launch."""
 import csv, json, sys, collections
 
 
 def load(path, counter):
     per = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != counter or "gemm_nt" not in r["Kernel_Name"]:
+        if r["Counter_Name"] != counter or not ("gemm_nt" in r["Kernel_Name"] or "gemm_tn" in r["Kernel_Name"]):
             continue
         k = r["Kernel_Name"].split("(")[0]
         per[k][0] += 1

@@ -68,6 +68,8 @@ def _flops_of(name, args):
         return 2.0 * args[2] * args[3] * args[4]
     if name == "sed_gemm_qkv":
         return 2.0 * args[3] * args[4] * (3 * args[5] * 64)
+    if name == "sed_gemm_dw_tn":
+        return 2.0 * args[3] * args[4] * args[5]
     return 0.0
 
 
@@ -81,6 +83,9 @@ def _bytes_of(name, args):
         M, K, D = args[3], args[4], args[5] * 64
         nout = sum(a is not None for a in args[8:16])
         return 2.0 * K * (M + 3 * D) + 2.0 * M * D * nout
+    if name == "sed_gemm_dw_tn":
+        T, M, N = args[3], args[4], args[5]
+        return 2.0 * T * (M + N) + 8.0 * M * N
     return 0.0
 
 
