@@ -40,28 +40,52 @@ FINETUNE2 = {
                              "decoder": {"lr": 1.0e-4, "weight_decay": 1.0e-4},
                              "head": {"lr": 1.0e-4, "weight_decay": 1.0e-4}}},
 }
+# config/mat-sed/base/finetune1.yaml (encoder + context net frozen, heads train; teacher without windows) -- lines 11-36, 70-95, 128-142
+FINETUNE1 = json.loads(json.dumps(FINETUNE2))
+FINETUNE1["training"].update({"self_loss_warmup": 8, "cons_scheduler_name": "Linear", "w_cons_max": 2,
+                              "scheduler": {"n_epochs": 15, "n_epochs_cut": 10, "exponent": -1, "lr_warmup_rate": 0.1,
+                                            "lr_warmup_epochs": 0}})
+FINETUNE1["PaSST_SED"]["train_tch_kwargs"] = {"encoder_win": False, "win_param": [512, 49], "mix_rate": 0.5, "temp_w": 1}
+FINETUNE1["opt"] = {"param_groups": {"encoder": {"lr": 0, "weight_decay": 1.0e-4, "freeze_layer": 0, "step_lr": 4},
+                                     "decoder": {"lr": 0, "weight_decay": 1.0e-4}, "head": {"lr": 2.0e-4, "weight_decay": 1.0e-4}}}
+# config/mat-sed/base/pretrain.yaml (masked-frame reconstruction, encoder frozen) -- lines 8-26, 41-54, 88-101
+PRETRAIN = {
+    "training": {"encoder_win": False, "batch_size": [4, 4, 16],
+                 "scheduler": {"n_epochs": 15, "n_epochs_cut": 10, "exponent": -0.5, "lr_warmup_rate": 0.1, "lr_warmup_epochs": 1},
+                 "transform": {"n_transform": 1, "choice": [1, 0, 0, 1], "filter_db_range": [-26, 26], "filter_bands": [2, 5],
+                               "filter_minimum_bandwidth": 4, "filter_type": "step"}},
+    "PaSST_SED": {"init_kwargs": {"passt_feature_layer": 10, "f_pool": "mean_pool", "decode_ratio": 10, "at_adapter": True,
+                                  "decoder": "transformerXL", "decoder_layer_num": 3, "decoder_pos_emd_len": 1000, "mlm": True,
+                                  "mlm_dict": {"strategy": "block", "block_width": 10, "mask_rate": 0.75, "out_dim": 768}}},
+    "opt": {"param_groups": {"encoder": {"lr": 0, "weight_decay": 1.0e-4, "freeze_layer": 0, "step_lr": 4},
+                             "decoder": {"lr": 1.0e-4, "weight_decay": 1.0e-4}, "head": {"lr": 1.0e-4, "weight_decay": 1.0e-4}}},
+}
+MODE_CFG = {"finetune2": FINETUNE2, "val": FINETUNE2, "finetune1": FINETUNE1, "pretrain": PRETRAIN}
+MODE_GFLOP = {"finetune2": (2463.16, 21.22), "finetune1": (649.13, 14.15), "pretrain": (383.68, 14.15), "val": (2 * 2264.3, 2 * 7.07)}
 GFLOP_PER_CLIP = 2463.16      # finetune2 step, algorithmic GEMM+conv FLOPs per clip (a-term)
 GFLOP_PER_BATCH = 21.22       # batch-shared linear_pos GEMMs (b-term)
 PEAK_BF16_TFLOPS = 2500.0     # dense 16-bit MFMA peak, MI355X_MICROARCH.md
 
 
-def build(per_gpu_batch, depth, device):
+def build(per_gpu_batch, depth, device, mode="finetune2"):
     from copy import deepcopy
     from transformer4sed_amd import synth
     from transformer4sed_amd.passt_sed import PaSST_SED
     from transformer4sed_amd.scheduler import ExponentialDown
     from transformer4sed_amd.trainer import FusedAdamWEMA, MatSedTrainer, get_params
-    cfg = FINETUNE2
+    cfg = MODE_CFG[mode]
     kw = dict(cfg["PaSST_SED"]["init_kwargs"])
     net = PaSST_SED(load_pretrained_model=False, encoder_depth=depth,
                     **{**kw, "passt_feature_layer": min(kw["passt_feature_layer"], depth)})
-    sd = synth.matsed_state_dict_np(tag="w768", depth=12)
+    sd = synth.matsed_state_dict_np(tag="w768", depth=12, mlm=bool(kw.get("mlm")))
     own = net.state_dict()
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items() if k in own}, strict=True)
     net = net.to(device)
-    ema_net = deepcopy(net)  # recipes/desed/finetune/passt/setting.py:8-15
-    for p in ema_net.parameters():
-        p.detach_()
+    ema_net = None
+    if mode != "pretrain":
+        ema_net = deepcopy(net)  # recipes/desed/finetune/passt/setting.py:8-15
+        for p in ema_net.parameters():
+            p.detach_()
     groups = get_params(net, cfg["opt"]["param_groups"])
     opt = FusedAdamWEMA(net, groups, ema_net=ema_net, betas=(0.9, 0.999), eps=1e-8)
     epoch_len = 1000
@@ -70,7 +94,8 @@ def build(per_gpu_batch, depth, device):
                             exponent=sc["exponent"], warmup_iter=sc["lr_warmup_epochs"] * epoch_len,
                             warmup_rate=sc["lr_warmup_rate"])
     net.train()
-    ema_net.train()  # the teacher runs in train mode during training (finetune/train.py:131-132)
+    if ema_net is not None:
+        ema_net.train()  # the teacher runs in train mode during training (finetune/train.py:131-132)
     trainer = MatSedTrainer(net, ema_net, opt, sched, cfg, epoch_len)
     return net, ema_net, opt, trainer, sd
 
@@ -106,9 +131,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU (multiple of 12 ratio 4:4:4 not required: 11/11/10)")
     ap.add_argument("--depth", type=int, default=12)
-    ap.add_argument("--mode", default="finetune2", choices=["finetune2", "val"],
-                    help="finetune2 = the headline train step (default); val = Trainer.validation's per-batch body "
-                         "(student + teacher, 17 sliding windows, score tables + event decoding), SURVEY 8(f) rank 1")
+    ap.add_argument("--mode", default="finetune2", choices=["finetune2", "finetune1", "pretrain", "val"],
+                    help="finetune2 = the headline train step (default); finetune1 / pretrain = the other two training stages of "
+                         "the MAT-SED recipe; val = Trainer.validation's per-batch body (student + teacher, 17 sliding windows, "
+                         "score tables + event decoding), SURVEY 8(f) rank 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     a = ap.parse_args()
@@ -137,13 +163,14 @@ def main():
     random.seed(1000 + rank); np.random.seed(1000 + rank); torch.manual_seed(1000 + rank)
 
     B = a.batch
-    net, ema_net, opt, trainer, sd = build(B, a.depth, dev)
+    net, ema_net, opt, trainer, sd = build(B, a.depth, dev, a.mode)
     # batch composition strong+synth | weak | unlabeled in the reference's positional order (dataset.py:178-188)
     sn = (B * 4 + 11) // 12
     wn = (B * 4 + 11) // 12
     un = B - sn - wn
-    trainer.cfg = json.loads(json.dumps(FINETUNE2))
-    trainer.cfg["training"]["batch_size"] = [sn, 0, wn, un]
+    trainer.cfg = json.loads(json.dumps(MODE_CFG[a.mode]))
+    if a.mode != "pretrain":
+        trainer.cfg["training"]["batch_size"] = [sn, 0, wn, un]
     wav = torch.from_numpy(synth.synth_wav(B, seed=1000 + rank)).to(dev)
     labels = torch.from_numpy(synth.synth_batch_labels(sn, wn, un, seed=1000 + rank)).to(dev)
     if world > 1 or force_ddp:
@@ -164,6 +191,10 @@ def main():
             ev = Evaluator(net, ema_net, enc, vcfg)
             ev.step(wav, labels, pad_mask, paths)
             return {"loss_total": torch.tensor(float(len(ev.scores.post_student)))}
+    elif a.mode == "pretrain":
+        def step():
+            out = trainer.pretrain_step(wav)
+            return {"loss_total": out["loss"]}
     else:
         def step():
             return trainer.finetune_step(wav, labels.clone())
@@ -192,10 +223,12 @@ def main():
         raise SystemExit("non-finite loss in the timed region")
     clips = a.steps * B * world
     value = clips / dt
-    gflop_clip, gflop_batch = (GFLOP_PER_CLIP, GFLOP_PER_BATCH) if a.mode == "finetune2" else (2 * 2264.3, 2 * 7.07)
+    gflop_clip, gflop_batch = MODE_GFLOP[a.mode]
     line = {
-        "metric": "clips/sec (10 s clips) MAT-SED finetune2 train step" if a.mode == "finetune2" else
-                  "clips/sec (10 s clips) MAT-SED validation step (student + teacher, 17 windows, score tables + events)",
+        "metric": {"finetune2": "clips/sec (10 s clips) MAT-SED finetune2 train step",
+                   "finetune1": "clips/sec (10 s clips) MAT-SED finetune1 train step",
+                   "pretrain": "clips/sec (10 s clips) MAT-SED masked-reconstruction pretrain step",
+                   "val": "clips/sec (10 s clips) MAT-SED validation step (student + teacher, 17 windows, score tables + events)"}[a.mode],
         "value": round(value, 3), "unit": "clips/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * dt / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -228,6 +261,11 @@ def main():
                             "launches_per_step": n // max(1, a.steps), "avg_launch_ms": round(ms / max(1, n), 4),
                             "gemm_share_of_step": round(ms / (1000 * dt), 3),
                             "flops_per_launch": round(fl / max(1, n) / 1e9, 3)}
+    if a.mode in ("finetune1", "pretrain"):
+        line["config"]["workload"] = {"finetune1": "MAT-SED base finetune1 step (config/mat-sed/base/finetune1.yaml): encoder and context "
+                                                   "net frozen, heads trained, mean-teacher losses, teacher without windows",
+                                      "pretrain": "MAT-SED base pretrain step (config/mat-sed/base/pretrain.yaml): masked-frame "
+                                                  "reconstruction (75 % block mask), encoder frozen, context net + MLM head trained"}[a.mode]
     if a.mode == "val":
         line["config"]["workload"] = ("MAT-SED validation batch (recipes/desed/finetune/train.py:296-366): eval frontend, student and "
                                       "EMA teacher forward with val_kwargs (17 windows of 512 frames, step 31, temp 0.5), soft-masked "
