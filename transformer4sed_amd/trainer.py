@@ -201,6 +201,9 @@ class MatSedTrainer:
         self.ddp = ddp
         self.bce = torch.nn.BCELoss()
         self.mse = torch.nn.MSELoss()
+        import os
+        self.overlap_teacher = os.environ.get("SED_OVERLAP_TEACHER", "0") == "1"
+        self._side = None
 
     # ---- recipes/desed/finetune/train.py:69-88
     def preprocess(self, wav, label, strong_n, weak_n):
@@ -228,9 +231,23 @@ class MatSedTrainer:
         self.optimizer.zero_grad()
         # NB the reference swaps the view names at the call site: student <- 2nd view, teacher <- 1st
         tch_feat, stu_feat, labels, labels_weak = self.preprocess(wav, labels, strong_n, weak_n)
-        stu_strong, stu_weak, stu_other = self.net(stu_feat, **kw["train_stu_kwargs"])
-        with torch.no_grad():
-            tch_strong, tch_weak, tch_other = self.ema_net(tch_feat, **kw["train_tch_kwargs"])
+        if self.overlap_teacher and wav.is_cuda:
+            # the no-grad teacher forward is independent of the student forward: issue it on a second HIP stream so that its
+            # workgroups fill the partially occupied rounds (tile-count tails, epilogue bursts) of the student's kernels
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side), torch.no_grad():
+                tch_strong, tch_weak, tch_other = self.ema_net(tch_feat, **kw["train_tch_kwargs"])
+            stu_strong, stu_weak, stu_other = self.net(stu_feat, **kw["train_stu_kwargs"])
+            main.wait_stream(self._side)
+            for t in (tch_strong, tch_weak, tch_other["at_out"], tch_feat):
+                t.record_stream(main)
+        else:
+            stu_strong, stu_weak, stu_other = self.net(stu_feat, **kw["train_stu_kwargs"])
+            with torch.no_grad():
+                tch_strong, tch_weak, tch_other = self.ema_net(tch_feat, **kw["train_tch_kwargs"])
         at_s, at_t = stu_other["at_out"], tch_other["at_out"].detach()
         ws = slice(strong_n, strong_n + weak_n)
         l_at = self.bce(at_s[ws], labels_weak[ws])
