@@ -156,7 +156,12 @@ def main():
     torch.cuda.set_device(dev)
 
     import __graft_entry__
-    __graft_entry__.build()
+    if world > 1:
+        # one builder per node: concurrent hipcc runs writing the same libsed_hip.so would corrupt it
+        if local == 0:
+            __graft_entry__.build()
+        dist.barrier()
+    __graft_entry__.build()   # up to date by now: dlopen + symbol check only
     from transformer4sed_amd import ops, synth
     from transformer4sed_amd.ddp import GradBucketReducer
     import random
