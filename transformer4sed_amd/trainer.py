@@ -118,6 +118,60 @@ class FusedAdamWEMA:
             p.grad = None
         self.grad_arena = None
 
+    # ---- optimiser state (the reference saves weights only, recipes/desed/finetune/passt/main.py:82-87; this is the state a true
+    # resume additionally needs).  Keyed by parameter NAME, so it survives a different grouping / arena layout.
+    def state_dict(self):
+        m, v = {}, {}
+        for n, o, k in self.layout:
+            m[n] = self.m[o:o + k].detach().cpu().clone()
+            v[n] = self.v[o:o + k].detach().cpu().clone()
+        return {"step": self.step_count, "exp_avg": m, "exp_avg_sq": v, "betas": tuple(self.betas), "eps": self.eps,
+                "param_groups": [{"lr": g["lr"], "weight_decay": g["weight_decay"], "names": list(g["names"])}
+                                 for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        with torch.no_grad():
+            for n, o, k in self.layout:
+                if n in sd["exp_avg"]:
+                    self.m[o:o + k].copy_(sd["exp_avg"][n].reshape(-1))
+                    self.v[o:o + k].copy_(sd["exp_avg_sq"][n].reshape(-1))
+        for g, gs in zip(self.param_groups, sd["param_groups"]):
+            g["lr"], g["weight_decay"] = gs["lr"], gs["weight_decay"]
+
+    def to_torch_adamw_state(self):
+        """The same state in torch.optim.AdamW.state_dict() form (parameter indices in group order, per-parameter `step`), so that
+        a run can continue under the reference's own optimiser (recipes/desed/setting.py:254-258) and vice versa."""
+        state, groups, idx = {}, [], 0
+        for g in self.param_groups:
+            ids = []
+            for n in g["names"]:
+                o, k = self.offset[n]
+                shape = dict(self.net.named_parameters())[n].shape
+                state[idx] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.m[o:o + k].detach().cpu().view(shape).clone(),
+                              "exp_avg_sq": self.v[o:o + k].detach().cpu().view(shape).clone()}
+                ids.append(idx)
+                idx += 1
+            groups.append({"lr": g["lr"], "betas": tuple(self.betas), "eps": self.eps, "weight_decay": g["weight_decay"],
+                           "amsgrad": False, "params": ids})
+        return {"state": state, "param_groups": groups}
+
+    def load_torch_adamw_state(self, sd):
+        idx, steps = 0, []
+        with torch.no_grad():
+            for g, gs in zip(self.param_groups, sd["param_groups"]):
+                g["lr"], g["weight_decay"] = gs["lr"], gs["weight_decay"]
+                for n in g["names"]:
+                    st = sd["state"].get(idx)
+                    if st is not None:
+                        o, k = self.offset[n]
+                        self.m[o:o + k].copy_(st["exp_avg"].reshape(-1))
+                        self.v[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
+                        steps.append(int(st["step"]))
+                    idx += 1
+        if steps:
+            self.step_count = max(steps)
+
     def _runs(self, names, touched):
         """Contiguous [start, end) arena runs of the parameters in `names` that received a gradient."""
         runs, cur = [], None
@@ -204,6 +258,34 @@ class MatSedTrainer:
         import os
         self.overlap_teacher = os.environ.get("SED_OVERLAP_TEACHER", "0") == "1"
         self._side = None
+
+    # ---- checkpoint / resume.  Weights use the reference's state_dict keys, so `best_student.pt` /
+    # `best_teacher.pt` written by either side load into the other (recipes/desed/finetune/passt/main.py:60-71,82-96); optimiser,
+    # scheduler step and RNG state are what the reference does not keep and a bit-faithful resume needs.
+    def state_dict(self):
+        import random as _r
+        return {"net": {k: v.detach().cpu().clone() for k, v in self.net.state_dict().items()},
+                "ema_net": None if self.ema_net is None else {k: v.detach().cpu().clone() for k, v in self.ema_net.state_dict().items()},
+                "optimizer": self.optimizer.state_dict(), "scheduler": {"step_num": self.scheduler.step_num},
+                "rng": {"python": _r.getstate(), "numpy": np.random.get_state(), "torch": torch.get_rng_state()}}
+
+    def load_state_dict(self, sd, restore_rng=True):
+        import random as _r
+        self.net.load_state_dict(sd["net"], strict=True)          # copies into the flat arena views
+        if self.ema_net is not None and sd.get("ema_net") is not None:
+            self.ema_net.load_state_dict(sd["ema_net"], strict=True)
+        self.optimizer.load_state_dict(sd["optimizer"])
+        self.scheduler.step_num = int(sd["scheduler"]["step_num"])
+        if restore_rng and "rng" in sd:
+            _r.setstate(sd["rng"]["python"]); np.random.set_state(sd["rng"]["numpy"]); torch.set_rng_state(sd["rng"]["torch"])
+
+    def save_weights(self, folder):
+        """best_student.pt / best_teacher.pt exactly as the reference writes them (weights-only state_dicts, log.py:86-89)."""
+        import os
+        os.makedirs(folder, exist_ok=True)
+        torch.save({k: v.detach().cpu() for k, v in self.net.state_dict().items()}, os.path.join(folder, "best_student.pt"))
+        if self.ema_net is not None:
+            torch.save({k: v.detach().cpu() for k, v in self.ema_net.state_dict().items()}, os.path.join(folder, "best_teacher.pt"))
 
     # ---- recipes/desed/finetune/train.py:69-88
     def preprocess(self, wav, label, strong_n, weak_n):
