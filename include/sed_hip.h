@@ -26,6 +26,10 @@ extern "C" {
  * melw [128,513] dense Kaldi bank (host-built per (fmin,fmax)), mel_range [128,2] non-zero bin range. */
 int sed_logmel_fwd(const float* wav, float* out, uint32_t* maxbits_tmp, const float* window, const float* twiddle,
                    const float* melw, const int* mel_range, int B, int L, int T, int do_log, hipStream_t stream);
+/* Polyphase FIR resampler, the device counterpart of the offline tool src/utils/resample.py:10-14 (16 kHz -> 32 kHz): x [B,L] ->
+ * y [B,Lout], taps h [ntaps] and alignment (n_pre_pad, n_pre_remove) as scipy.signal.resample_poly defines them (host-built). */
+int sed_resample_poly(const float* x, float* y, const float* h, int B, int L, int Lout, int up, int down, int ntaps,
+                      int n_pre_pad, int n_pre_remove, hipStream_t stream);
 /* frame_shift + mixup (src/preprocess/data_aug.py:11-28, 75-90); shift [B], perm [B] / cmix [B,2]={c,1-c} nullable */
 int sed_roll_mix(const float* in, float* out, const int* shift, const int* perm, const float* cmix, int B, int F, int T,
                  int clamp01, hipStream_t stream);

@@ -645,8 +645,45 @@ def gen_evalpath():
     save("evalpath", **out)
 
 
+def gen_datapipe():
+    """Items of the reference's own dataset classes (src/preprocess/dataset.py) and its batch sampler on the miniature layout above;
+    `librosa.load` is the PCM-16 stand-in of oracle/ref_shims (files are already at 32 kHz, so no resampling is involved)."""
+    import tempfile
+    import pandas as pd
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from datapipe_files import make_datapipe_files
+    from src.preprocess.dataset import StronglyLabeledDataset, WeaklyLabeledDataset, UnlabeledDataset, ConcatDatasetBatchSampler
+    from src.codec.encoder import Encoder
+    from oracle import eval_oracle as EO
+    root = tempfile.mkdtemp(prefix="datapipe_")
+    make_datapipe_files(root)
+    enc = Encoder(EO.LABELS, audio_len=10, frame_len=1024, frame_hop=320, net_pooling=1, sr=32000)
+    out = {}
+    sds = StronglyLabeledDataset(pd.read_csv(os.path.join(root, "strong.tsv"), sep="\t"), os.path.join(root, "strong"), True, enc)
+    wds = WeaklyLabeledDataset(pd.read_csv(os.path.join(root, "weak.tsv"), sep="\t"), os.path.join(root, "weak"), True, enc)
+    uds = UnlabeledDataset(os.path.join(root, "unlabel"), True, enc)
+    for tag, ds in (("strong", sds), ("weak", wds), ("unlabel", uds)):
+        names = []
+        for i in range(len(ds)):
+            wav, label, pad_mask, idx, filename, path = ds[i]
+            names.append(filename)
+            assert wav.shape == (320000,) and label.shape == (10, 1000) and pad_mask.shape == (1000,)
+            out[f"{tag}_{filename}_wav_head"] = t2n(wav[:64])
+            out[f"{tag}_{filename}_wav_sum"] = np.float64(wav.double().sum().item())
+            out[f"{tag}_{filename}_wav_abs"] = np.float64(wav.double().abs().sum().item())
+            out[f"{tag}_{filename}_label_idx"] = np.argwhere(t2n(label) > 0).astype(np.int32)
+            out[f"{tag}_{filename}_pad_first"] = np.int64(int(pad_mask.float().argmax()) if pad_mask.any() else -1)
+            out[f"{tag}_{filename}_pad_count"] = np.int64(int(pad_mask.sum()))
+        out[f"{tag}_names"] = np.asarray(names)
+    samplers = [torch.utils.data.SequentialSampler(x) for x in (sds, wds, uds)]
+    bs = ConcatDatasetBatchSampler(samplers, [2, 1, 1])
+    out["sampler_len"] = np.int64(len(bs))
+    out["sampler_batches"] = np.asarray(list(bs))
+    save("datapipe", **out)
+
+
 GENS = dict(frontend=gen_frontend, augment=gen_augment, micro=gen_micro, full=gen_full, full12=gen_full12,
-            schedule=gen_schedule, postprocess=gen_postprocess, losses=gen_losses, trainstep=gen_trainstep, evalpath=gen_evalpath)
+            schedule=gen_schedule, postprocess=gen_postprocess, losses=gen_losses, trainstep=gen_trainstep, evalpath=gen_evalpath, datapipe=gen_datapipe)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -1,0 +1,83 @@
+"""Input pipeline: host-side contracts against the reference's own dataset classes (tests/golden/datapipe.npz,
+recorded by oracle/make_golden.py:gen_datapipe) -- no GPU needed; the device resampler and prefetcher are checked in the gpu tests."""
+import os
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from datapipe_files import make_datapipe_files  # noqa: E402
+from transformer4sed_amd import data  # noqa: E402
+from transformer4sed_amd.evaluation import Encoder  # noqa: E402
+
+LABELS = ["Alarm_bell_ringing", "Blender", "Cat", "Dishes", "Dog", "Electric_shaver_toothbrush", "Frying", "Running_water", "Speech",
+          "Vacuum_cleaner"]
+
+
+def _datasets(root):
+    enc = Encoder(LABELS, audio_len=10, frame_len=1024, frame_hop=320, net_pooling=1, sr=32000)
+    sds = data.StronglyLabeledDataset(pd.read_csv(os.path.join(root, "strong.tsv"), sep="\t"), os.path.join(root, "strong"), True, enc)
+    wds = data.WeaklyLabeledDataset(pd.read_csv(os.path.join(root, "weak.tsv"), sep="\t"), os.path.join(root, "weak"), True, enc)
+    uds = data.UnlabeledDataset(os.path.join(root, "unlabel"), True, enc)
+    return enc, sds, wds, uds
+
+
+def test_dataset_items_and_sampler_vs_reference(golden, tmp_path):
+    g = golden("datapipe")
+    make_datapipe_files(str(tmp_path))
+    enc, sds, wds, uds = _datasets(str(tmp_path))
+    for tag, ds in (("strong", sds), ("weak", wds), ("unlabel", uds)):
+        assert sorted(ds[i][4] for i in range(len(ds))) == sorted(g[f"{tag}_names"].tolist())
+        if tag != "unlabel":      # (glob order is file-system order; the tsv-driven sets keep the reference's order)
+            assert [ds[i][4] for i in range(len(ds))] == g[f"{tag}_names"].tolist()
+        for i in range(len(ds)):
+            wav, label, pad_mask, idx, filename, path = ds[i]
+            assert idx == i and path.endswith(filename)
+            assert wav.dtype == torch.float32 and wav.shape == (320000,) and label.shape == (10, 1000) and pad_mask.dtype == torch.bool
+            assert np.array_equal(wav[:64].numpy(), g[f"{tag}_{filename}_wav_head"])
+            assert wav.double().sum().item() == float(g[f"{tag}_{filename}_wav_sum"])
+            assert wav.double().abs().sum().item() == float(g[f"{tag}_{filename}_wav_abs"])
+            assert np.array_equal(np.argwhere(label.numpy() > 0).astype(np.int32), g[f"{tag}_{filename}_label_idx"])
+            first = int(pad_mask.float().argmax()) if pad_mask.any() else -1
+            assert first == int(g[f"{tag}_{filename}_pad_first"]) and int(pad_mask.sum()) == int(g[f"{tag}_{filename}_pad_count"])
+    samplers = [torch.utils.data.SequentialSampler(x) for x in (sds, wds, uds)]
+    bs = data.ConcatDatasetBatchSampler(samplers, [2, 1, 1])
+    assert len(bs) == int(g["sampler_len"]) and np.array_equal(np.asarray(list(bs)), g["sampler_batches"])
+    # the reference's DataLoader construction works unchanged on top (recipes/desed/setting.py:164-166)
+    loader = torch.utils.data.DataLoader(torch.utils.data.ConcatDataset([sds, wds, uds]), batch_sampler=bs, num_workers=0)
+    wavs, labels, pads, idxs, names, paths = next(iter(loader))
+    assert wavs.shape == (4, 320000) and labels.shape == (4, 10, 1000) and pads.shape == (4, 1000) and len(names) == 4
+
+
+def test_wav_reader_formats_and_edges(tmp_path):
+    x = np.linspace(-0.9, 0.9, 1000).astype(np.float32)
+    data.write_wav(tmp_path / "f.wav", x, 16000, float32=True)
+    y, sr = data.read_wav(tmp_path / "f.wav")
+    assert sr == 16000 and np.array_equal(x, y)
+    data.write_wav(tmp_path / "i.wav", np.stack([x, -x], 1), 32000)
+    y, sr = data.read_wav(tmp_path / "i.wav")
+    assert y.shape == (1000, 2) and np.abs(y[:, 0] - x).max() <= 1.0 / 32768 and np.array_equal(data.to_mono(y), y.mean(-1))
+    with open(tmp_path / "bad.wav", "wb") as f:
+        f.write(b"not a wav file at all")
+    with pytest.raises(ValueError):
+        data.read_wav(tmp_path / "bad.wav")
+    enc = Encoder(LABELS, audio_len=10, frame_len=1024, frame_hop=320, net_pooling=1, sr=32000)
+    with pytest.raises(ValueError):       # a 16 kHz file needs the device resampler
+        data.waveform_modification(str(tmp_path / "f.wav"), 320000, enc)
+    w, m = data.pad_wav(np.zeros(0, dtype=np.float32), 320000, enc)       # empty clip: all frames padded
+    assert w.shape == (320000,) and bool(m.all())
+
+
+def test_resample_filter_matches_scipy_definition():
+    from scipy import signal
+    for up, down in ((2, 1), (1, 2), (3, 2), (160, 147)):
+        u, d, h, n_pre_pad, n_pre_remove = data.resample_filter(up, down)
+        half = 10 * max(u, d)
+        want = signal.firwin(2 * half + 1, 1.0 / max(u, d), window=("kaiser", 5.0)) * u
+        assert np.abs(h - want).max() < 1e-6 and n_pre_pad == d - half % d and n_pre_remove == (half + n_pre_pad) // d

@@ -100,3 +100,42 @@ def test_evaluator_step_depth2(tmp_path):
     ev.write(tmp_path)
     assert sorted(os.listdir(tmp_path)) == ["post_student", "post_teacher", "raw_student", "raw_teacher"]
     assert ev.weak_f1["student"].compute() >= 0.0 and len(ev.event_frame("teacher").columns) in (0, 4)
+
+
+# ------------------------------------------------------------------------------------------------ input pipeline on the device
+def test_device_resampler_vs_scipy():
+    """`sed_resample_poly` against scipy.signal.resample_poly (the definition it implements; the reference's offline tool uses
+    librosa/soxr whose taps are not reproduced -- parity unpinned, see data.py)."""
+    from scipy import signal
+    from transformer4sed_amd import data
+    rng = np.random.RandomState(4)
+    for up, down, L in ((2, 1, 160000), (1, 2, 32001), (3, 2, 5000), (160, 147, 44100), (2, 1, 7)):
+        x = rng.randn(3, L).astype(np.float32)
+        got = data.resample_poly_device(torch.from_numpy(x).to(DEV), up, down).cpu().numpy()
+        want = signal.resample_poly(x.astype(np.float64), up, down, axis=1)
+        assert got.shape == want.shape, (up, down, L, got.shape, want.shape)
+        assert np.abs(got - want).max() < 2e-5, (up, down, L)
+
+
+def test_waveform_modification_resamples_16k_and_prefetcher(tmp_path):
+    import pandas as pd
+    from scipy import signal
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from datapipe_files import make_datapipe_files, write_pcm16
+    from transformer4sed_amd import data
+    enc = _enc()
+    x16 = (0.4 * np.sin(2 * np.pi * 440 * np.arange(16000 * 4) / 16000)).astype(np.float32)
+    write_pcm16(str(tmp_path / "a16k.wav"), x16, 16000)
+    wav, pad = data.waveform_modification(str(tmp_path / "a16k.wav"), 320000, enc, resample_device=DEV)
+    q = np.round(x16 * 32768.0).clip(-32768, 32767) / 32768.0
+    want = signal.resample_poly(q.astype(np.float64), 2, 1)
+    assert wav.shape == (320000,) and np.abs(wav[:128000].numpy() - want).max() < 2e-5 and float(wav[128000:].abs().max()) == 0
+    assert int(pad.float().argmax()) == 400 and int(pad.sum()) == 600        # 4 s of audio = 400 frames of 10 ms
+    make_datapipe_files(str(tmp_path))
+    sds = data.StronglyLabeledDataset(pd.read_csv(tmp_path / "strong.tsv", sep="\t"), str(tmp_path / "strong"), False, enc)
+    loader = torch.utils.data.DataLoader(sds, batch_size=2, shuffle=False)
+    host = [b for b in loader]
+    dev_batches = list(data.DevicePrefetcher(loader, DEV))
+    assert len(dev_batches) == len(host) == 2
+    for hb, db in zip(host, dev_batches):
+        assert db[0].is_cuda and torch.equal(db[0].cpu(), hb[0]) and torch.equal(db[1].cpu(), hb[1]) and torch.equal(db[2].cpu(), hb[2])

@@ -272,3 +272,36 @@ extern "C" int sed_median_filter(const float* in, float* out, const int* sizes, 
                        C, mode);
     return sed_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Polyphase FIR resampler (src/utils/resample.py:10-14 does this offline with librosa; definition here = scipy.signal.resample_poly):
+//   y[n] = sum_m x[m] h[(n + n_pre_remove) * down - m * up - n_pre_pad],   h = Kaiser-windowed sinc taps * up (host-built)
+// One thread per output sample; taps in LDS.  HBM-bound: 4 B read (reused ~taps/up times from cache) + 4 B written per sample.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resample_poly_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            const float* __restrict__ h, int L, int Lout, int up, int down,
+                                                            int ntaps, int n_pre_pad, int n_pre_remove) {
+    extern __shared__ float taps[];
+    for (int i = threadIdx.x; i < ntaps; i += blockDim.x) taps[i] = h[i];
+    __syncthreads();
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Lout) return;
+    const float* xb = x + (size_t)blockIdx.y * L;
+    const long long c = (long long)(n + n_pre_remove) * down - n_pre_pad;   // tap index k = c - m * up must lie in [0, ntaps)
+    long long m_hi = c / up;                                                  // k >= 0
+    if (m_hi > L - 1) m_hi = L - 1;
+    long long m_lo = (c - (ntaps - 1) + up - 1) / up;                         // k <= ntaps - 1
+    if (c - (ntaps - 1) < 0) m_lo = 0;
+    if (m_lo < 0) m_lo = 0;
+    float acc = 0.f;
+    for (long long m = m_lo; m <= m_hi; ++m) acc += xb[m] * taps[(int)(c - m * up)];
+    y[(size_t)blockIdx.y * Lout + n] = acc;
+}
+extern "C" int sed_resample_poly(const float* x, float* y, const float* h, int B, int L, int Lout, int up, int down, int ntaps,
+                                 int n_pre_pad, int n_pre_remove, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (B <= 0 || L <= 0 || Lout <= 0 || up < 1 || down < 1 || ntaps < 1 || ntaps > 8192) return SED_ERR_ARG;
+    hipLaunchKernelGGL(resample_poly_kernel, dim3(cdiv(Lout, 256), B), dim3(256), ntaps * sizeof(float), stream, x, y, h, L, Lout,
+                       up, down, ntaps, n_pre_pad, n_pre_remove);
+    return sed_check_launch();
+}
