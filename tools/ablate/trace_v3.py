@@ -17,6 +17,7 @@ V = ctypes.c_void_p
 lib.sed_gemm_nt.argtypes = [V, V, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, V, V, V, V, V, V,
                             ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, V]
 lib.sed_debug_set_gemm_trace.argtypes = [V]
+lib.sed_debug_set_gemm_trace_wave.argtypes = [ctypes.c_int]
 EPI_F32, EPI_F32_RESID, EPI_BF16, EPI_GELU = 0, 1, 2, 3
 for name, M, N, K, epi in (("fc1 gelu", 38080, 3072, 768, EPI_GELU), ("plain f16", 38080, 3072, 768, EPI_BF16),
                            ("fc2 resid", 38080, 768, 3072, EPI_F32_RESID), ("square", 8192, 8192, 8192, EPI_BF16)):
@@ -34,6 +35,13 @@ for name, M, N, K, epi in (("fc1 gelu", 38080, 3072, 768, EPI_GELU), ("plain f16
                              p(outF), p(outH), p(outH2), None, N, 1.0, 1, 1, st)
         assert rc == 0, rc
     lib.sed_debug_set_gemm_trace(None); run(); torch.cuda.synchronize()
+    waits = []
+    for w in range(8):   # one launch per reporting wave
+        lib.sed_debug_set_gemm_trace_wave(w)
+        lib.sed_debug_set_gemm_trace(tr.data_ptr()); run(); torch.cuda.synchronize()
+        tt = tr.cpu().numpy().reshape(nwg, 8)
+        waits.append((np.median(tt[:, 5]) / max(1, K // 64 - 1), np.median(tt[:, 6]) / max(1, K // 64 - 1)))
+    lib.sed_debug_set_gemm_trace_wave(0)
     lib.sed_debug_set_gemm_trace(tr.data_ptr()); run(); torch.cuda.synchronize()
     t = tr.cpu().numpy().reshape(nwg, 8).astype(np.int64)
     t0 = t[:, 0].min()
@@ -43,6 +51,10 @@ for name, M, N, K, epi in (("fc1 gelu", 38080, 3072, 768, EPI_GELU), ("plain f16
     print(f"== {name} M={M} N={N} K={K} wgs={nwg} total {us[:, 4].max():.1f} us")
     print("  prologue ", q(pro)); print("  main loop", q(main), " per k-iter med %.2f" % (np.median(main) / (K // 64)))
     print("  epi issue", q(epi_t)); print("  drain    ", q(drain))
+    nkk = K // 64 - 1
+    cyc = (t[:, 2] - t[:, 1]) * 10.0   # ns of the main loop (100 MHz stamps)
+    print("  per K tile, shader cycles (DMA wait / barrier wait) by wave: " + "  ".join("w%d %.0f/%.0f" % (w, a, b) for w, (a, b) in enumerate(waits))
+          + "   (main loop %.0f ns per K tile)" % (np.median(cyc) / (K // 64)))
     hw = t[:, 7]
     cu = (hw >> 32) * 1000 + ((hw >> 8) & 0xF) + 16 * ((hw >> 13) & 0x7)   # xcc, cu_id, se_id
     gaps = []

@@ -779,8 +779,12 @@ __device__ __forceinline__ void v3_epilogue(const GemmArgs& g, const f32x16_t (&
 #define V3_STAGE (64 * 1024)
 #ifdef SED_GEMM_TRACE  // developer build only (tools/ablate/trace_v3.py): per-workgroup phase timestamps
 __device__ unsigned long long* sed_trace_buf = nullptr;
+__device__ int sed_trace_wave = 0;   // which wave of the workgroup reports its per-K-tile waits
 extern "C" int sed_debug_set_gemm_trace(unsigned long long* p) {
     return hipMemcpyToSymbol(HIP_SYMBOL(sed_trace_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+extern "C" int sed_debug_set_gemm_trace_wave(int w) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(sed_trace_wave), &w, sizeof(w)) == hipSuccess ? 0 : -1;
 }
 #define V3_TRACE(slot) do { if (tid == 0 && sed_trace_buf != nullptr) sed_trace_buf[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
 #else
@@ -856,11 +860,75 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(const GemmArgs g) {
 
     V3Consts<EPI> cc;
     v3_load_consts<EPI>(cc, g, n0 + wn * 64, lane);
+#ifndef V3_XBAR
+#define V3_XBAR 1
+#endif
+#if V3_XBAR
+    // The per-K-tile barrier sits BEFORE the last k-step's MFMAs instead of at the top of the tile: by then every wave has
+    // finished reading the current stage (its k-step-3 fragments are in registers), so right after the barrier the stage can be
+    // handed to the DMA of tile it+2, and the first fragments of tile it+1 (landed: vmcnt(0) + barrier) are requested from the
+    // other stage -- both latencies run under the 8 MFMAs of k-step 3 instead of stalling the top of the next tile (a phase trace
+    // showed the waves never wait for DMA data; they idle ~400 cycles per tile between barrier and first MFMA).
+#ifdef SED_GEMM_TRACE
+    unsigned long long tw = 0, tb = 0;   // (per-wave wait accounting exists for the V3_XBAR=0 loop only)
+#endif
+    s16x8_t af[2][4], bfr[2][2];
+#define V3_FRAGS(SET, BASE, KS)                                                                                           \
+    {                                                                                                                     \
+        const int ch_ = 2 * (KS) + lg;                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                     \
+            af[SET][i] = *reinterpret_cast<const s16x8_t*>((BASE) + aoff[i] + ((ch_ ^ aswz[i]) << 4));                    \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                     \
+            bfr[SET][j] = *reinterpret_cast<const s16x8_t*>((BASE) + boff[j] + ((ch_ ^ bswz[j]) << 4));                   \
+    }
+    if (nk > 0) {
+        V3_DMA(kt_begin, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        V3_TRACE(1);
+        if (nk > 1) { V3_DMA(kt_begin + 1, 1); }
+        V3_FRAGS(0, lds3, 0);
+    }
+    for (int it = 0; it < nk; ++it) {
+        const unsigned char* base = lds3 + (it & 1) * V3_STAGE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s < 3) {
+                V3_FRAGS(nxt, base, s + 1);
+            } else if (it + 1 < nk) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // next tile landed; my reads of this stage are done
+                __builtin_amdgcn_s_barrier();                                 // ... for every wave
+                if (it + 2 < nk) { V3_DMA(kt_begin + it + 2, it & 1); }       // this stage is free again
+                V3_FRAGS(nxt, lds3 + ((it + 1) & 1) * V3_STAGE, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32t<F16>(bfr[cur][j], af[cur][i], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef V3_FRAGS
+#else
     if (nk > 0) { V3_DMA(kt_begin, 0); }
+#ifdef SED_GEMM_TRACE
+    unsigned long long tw = 0, tb = 0;
+#endif
     for (int it = 0; it < nk; ++it) {
         const int stage = it & 1;
+#ifdef SED_GEMM_TRACE
+        const unsigned long long c0 = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long c1 = __builtin_readcyclecounter();
+        __builtin_amdgcn_s_barrier();
+        const unsigned long long c2 = __builtin_readcyclecounter();
+        if (it > 0) { tw += c1 - c0; tb += c2 - c1; }
+#else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // tile `it` landed (all waves); the other stage is no longer being read
+#endif
         if (it == 0) V3_TRACE(1);
         if (it + 1 < nk) { V3_DMA(kt_begin + it + 1, stage ^ 1); }
         const unsigned char* base = lds3 + stage * V3_STAGE;
@@ -889,8 +957,12 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(const GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+#endif
     __builtin_amdgcn_s_barrier();  // every wave is done reading the operand stages: LDS becomes the per-wave C staging area
     V3_TRACE(2);
+#ifdef SED_GEMM_TRACE
+    if (lane == 0 && wave == sed_trace_wave && sed_trace_buf != nullptr) { sed_trace_buf[(size_t)blockIdx.x * 8 + 5] = tw; sed_trace_buf[(size_t)blockIdx.x * 8 + 6] = tb; }
+#endif
     v3_epilogue<EPI, F16>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * 128, n0 + wn * 64, lane);
     V3_TRACE(3);
 #ifdef SED_GEMM_TRACE
