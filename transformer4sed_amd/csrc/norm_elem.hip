@@ -34,45 +34,44 @@ __device__ __forceinline__ const float& f4(const float4& v, int c) { return rein
 // ---------------------------------------------------------------------------------------------------
 // LayerNorm   y = LN(in_scale * x) * gamma + beta      (passt.py:361-362,580; timm Block norms; out_norm)
 // ---------------------------------------------------------------------------------------------------
-// Each wave walks row PAIRS in a grid-stride loop: gamma / beta are fetched once per wave (not once per row -- they doubled the
-// L2 traffic of a kernel that streams 4.6 KB per row), and both rows' loads are in flight before the first reduction starts.
+// two rows per wave: both rows' loads are in flight before the first reduction starts (the kernel is a latency chain
+// load -> 2 wave reductions -> store).  A persistent grid-stride variant (gamma / beta fetched once per wave) looked 2x faster in
+// a warm-cache loop but is slower on cold input (70 vs 56 us at M = 38080, tools/ln_bench.py) -- in the step the input was just
+// written with non-temporal stores, so the one-shot grid below is what ships.
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, float in_scale,
                                                             bf16_t* __restrict__ y16, float* __restrict__ y32,
                                                             float* __restrict__ mean, float* __restrict__ rstd, int M, int f16) {
     const int lane = threadIdx.x & 63;
-    Row g, b;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (row0 >= M) return;
+    const bool two = row0 + 1 < M;
+    Row r[2], g, b;
+    row_load(r[0], x + (size_t)row0 * DM, lane);
+    row_load(r[1], x + (size_t)(two ? row0 + 1 : row0) * DM, lane);
     row_load(g, gamma, lane);
     row_load(b, beta, lane);
-    const int npairs = (M + 1) >> 1;
-    for (int pair = blockIdx.x * 4 + (threadIdx.x >> 6); pair < npairs; pair += gridDim.x * 4) {
-        const int row0 = pair * 2;
-        const bool two = row0 + 1 < M;
-        Row r[2];
-        row_load(r[0], x + (size_t)row0 * DM, lane);
-        row_load(r[1], x + (size_t)(two ? row0 + 1 : row0) * DM, lane);
-        float s[2] = {0.f, 0.f};
+    float s[2] = {0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
-            ROW_FOREACH(i, c) { f4(r[k].v[i], c) *= in_scale; s[k] += f4(r[k].v[i], c); }
-        const float mu[2] = {wave_sum(s[0]) * (1.0f / DM), wave_sum(s[1]) * (1.0f / DM)};
-        float q[2] = {0.f, 0.f};
+        ROW_FOREACH(i, c) { f4(r[k].v[i], c) *= in_scale; s[k] += f4(r[k].v[i], c); }
+    const float mu[2] = {wave_sum(s[0]) * (1.0f / DM), wave_sum(s[1]) * (1.0f / DM)};
+    float q[2] = {0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
-            ROW_FOREACH(i, c) { const float d = f4(r[k].v[i], c) - mu[k]; q[k] += d * d; }
-        const float rs[2] = {rsqrtf(wave_sum(q[0]) * (1.0f / DM) + eps), rsqrtf(wave_sum(q[1]) * (1.0f / DM) + eps)};
+        ROW_FOREACH(i, c) { const float d = f4(r[k].v[i], c) - mu[k]; q[k] += d * d; }
+    const float rs[2] = {rsqrtf(wave_sum(q[0]) * (1.0f / DM) + eps), rsqrtf(wave_sum(q[1]) * (1.0f / DM) + eps)};
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (k == 1 && !two) break;
-            const int row = row0 + k;
+    for (int k = 0; k < 2; ++k) {
+        if (k == 1 && !two) break;
+        const int row = row0 + k;
 #pragma unroll
-            ROW_FOREACH(i, c) f4(r[k].v[i], c) = (f4(r[k].v[i], c) - mu[k]) * rs[k] * f4(g.v[i], c) + f4(b.v[i], c);
-            if (y16 != nullptr) row_store_bf16(r[k], y16 + (size_t)row * DM, lane, f16);
-            if (y32 != nullptr) row_store(r[k], y32 + (size_t)row * DM, lane);
-            if (lane == 0 && mean != nullptr) { mean[row] = mu[k]; rstd[row] = rs[k]; }
-        }
+        ROW_FOREACH(i, c) f4(r[k].v[i], c) = (f4(r[k].v[i], c) - mu[k]) * rs[k] * f4(g.v[i], c) + f4(b.v[i], c);
+        if (y16 != nullptr) row_store_bf16(r[k], y16 + (size_t)row * DM, lane, f16);
+        if (y32 != nullptr) row_store(r[k], y32 + (size_t)row * DM, lane);
+        if (lane == 0 && mean != nullptr) { mean[row] = mu[k]; rstd[row] = rs[k]; }
     }
 }
 
@@ -80,8 +79,7 @@ extern "C" int sed_layernorm_fwd(const float* x, const float* gamma, const float
                                  void* y_bf16, float* y_f32, float* mean, float* rstd, int M, int D, int f16, hipStream_t stream) {
     (void)hipGetLastError();
     if (D != DM || M <= 0) return SED_ERR_ARG;
-    const int lnb = cdiv(M, 8) < 1536 ? cdiv(M, 8) : 1536;   // 82 VGPRs: 6 workgroups per CU resident = one persistent round
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(lnb), dim3(256), 0, stream, x, gamma, beta, eps, in_scale,
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 8)), dim3(256), 0, stream, x, gamma, beta, eps, in_scale,
                        (bf16_t*)y_bf16, y_f32, mean, rstd, M, f16);
     return sed_check_launch();
 }
