@@ -3,37 +3,44 @@ import numpy as np
 import torch
 
 
-class ExponentialDown(object):
+def exponential_down_scale(step_num, start_iter, total_iter, exponent, warmup_iter=0, warmup_rate=0.1):
+    """LR multiplier of the MAT-SED recipes as a pure function of the (already incremented) step counter: linear warm-up from
+    `warmup_rate` to 1 over `warmup_iter` steps, flat until `start_iter`, then exp(exponent * phase^2) with phase running from 0 to 1
+    at `total_iter` (src/utils/scheduler.py:58-67)."""
+    if step_num < warmup_iter:
+        return warmup_rate + (1.0 - warmup_rate) * (step_num / warmup_iter)
+    if step_num <= start_iter:
+        return 1
+    phase = (step_num - start_iter) / (total_iter - start_iter)
+    return float(np.exp(exponent * phase * phase))
+
+
+class ExponentialDown:
+    """Drives the `lr` entries of an optimiser's param_groups (torch optimisers or FusedAdamWEMA) with `exponential_down_scale`.
+    Keeps the surface the reference trainers touch (src/utils/scheduler.py:41-76): `step_num` starts at 1 and `step()` increments it
+    BEFORE computing the scale, `_get_scale()` / `scale` for logging, `lr_init_list`, `zero_grad()`."""
+
     def __init__(self, optimizer, start_iter, total_iter, exponent=-0.5, warmup_iter=0, warmup_rate=0.1):
         self.optimizer = optimizer
-        self.total_iter = total_iter
-        self.start_iter = start_iter
-        self.step_num = 1
-        self.exponet = exponent
+        self.start_iter, self.total_iter, self.exponet = start_iter, total_iter, exponent
+        self.warmup_iter, self.warmup_rate = warmup_iter, warmup_rate
         self.lr_init_list = [g["lr"] for g in optimizer.param_groups]
-        self.warmup_iter = warmup_iter
-        self.warmup_rate = warmup_rate
-
-    def zero_grad(self):
-        self.optimizer.zero_grad()
+        self.step_num = 1
+        self.scale = 1
 
     def _get_scale(self):
-        if self.step_num < self.warmup_iter:
-            self.scale = (1 - self.warmup_rate) * (self.step_num / self.warmup_iter) + self.warmup_rate
-        elif self.step_num > self.start_iter:
-            phase = (self.step_num - self.start_iter) / (self.total_iter - self.start_iter)
-            self.scale = float(np.exp(self.exponet * phase * phase))
-        else:
-            self.scale = 1
+        self.scale = exponential_down_scale(self.step_num, self.start_iter, self.total_iter, self.exponet, self.warmup_iter,
+                                            self.warmup_rate)
         return self.scale
-
-    def _set_lr(self, scale):
-        for i, g in enumerate(self.optimizer.param_groups):
-            g["lr"] = self.lr_init_list[i] * scale
 
     def step(self):
         self.step_num += 1
-        self._set_lr(self._get_scale())
+        s = self._get_scale()
+        for lr0, g in zip(self.lr_init_list, self.optimizer.param_groups):
+            g["lr"] = lr0 * s
+
+    def zero_grad(self):
+        self.optimizer.zero_grad()
 
 
 def ema_alpha(step, ema_factor):
