@@ -583,7 +583,9 @@ __global__ __launch_bounds__(256) void weak_pool_kernel(const float* __restrict_
         a = ra[0] + ra[1] + ra[2] + ra[3];
         bsum = rb[0] + rb[1] + rb[2] + rb[3];
         float w = a / bsum;
-        w = fminf(fmaxf(w, 1e-7f), 1.0f);
+        // torch.clamp propagates NaN (a clip whose every frame is padded gives 0/0 in the reference, passt_sed.py:293-294);
+        // fminf/fmaxf would silently turn it into 1e-7
+        w = (w != w) ? w : fminf(fmaxf(w, 1e-7f), 1.0f);
         weak[blockIdx.x] = w;
         if (sums != nullptr) { sums[2 * blockIdx.x] = a; sums[2 * blockIdx.x + 1] = bsum; }
     }
