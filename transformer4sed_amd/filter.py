@@ -13,6 +13,12 @@ def _run(x, sizes, mode, scale=None):
         raise ValueError("Length of median_filter_sizes must match the number of classes")
     x = x.contiguous().float()
     out = torch.empty_like(x)
+    if B == 0 or T == 0:
+        return out                                    # the reference's loops simply do not run
+    if mode != 0 and max(int(s) for s in sizes) > T:
+        # scipy's line extension for windows longer than the sequence is not periodic reflection (ndimage.median_filter of a
+        # 5-sample line with size 33 returns zeros); that regime never occurs on this path (T = 1000, windows <= 129)
+        raise ValueError("scipy-semantics filter: window longer than the sequence is outside the reproduced domain")
     sz = h2d(list(sizes), torch.int32, x.device)
     sc = None if scale is None else scale.contiguous().float()
     call("sed_median_filter", x, out, sz, sc, B, T, C, mode)
