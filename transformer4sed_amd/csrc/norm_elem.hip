@@ -228,40 +228,43 @@ __global__ void assemble_tokens_bwd_kernel(const float* __restrict__ dx, bf16_t*
                                            float* __restrict__ dcls, float* __restrict__ ddist,
                                            float* __restrict__ dnew_pos, float* __restrict__ dfreq,
                                            float* __restrict__ dtime, int toffset, int B, int tp) {
-    // one block per (f or token-pair, d-chunk): reduce over b (and t / f) in registers, few atomics
+    // one block per (f or token-pair or time column, d-chunk, batch slice): partial sums over the slice's clips in registers,
+    // then one atomic per output (the batch slices run in parallel: a single block per job walked B * tp rows back to back)
     const int N = 2 + 12 * tp;
     const int d = blockIdx.y * 256 + threadIdx.x;
     if (d >= DM) return;
+    const int bper = (B + gridDim.z - 1) / gridDim.z, b0 = blockIdx.z * bper, b1 = (b0 + bper < B) ? b0 + bper : B;
     const int job = blockIdx.x;  // 0: cls/dist, 1..12: freq row f = job-1 (also writes dconv), 13..: time cols
     if (job == 0) {
         float a = 0.f, c = 0.f;
-        for (int b = 0; b < B; ++b) {
+        for (int b = b0; b < b1; ++b) {
             a += dx[((size_t)b * N) * DM + d];
             c += dx[((size_t)b * N + 1) * DM + d];
         }
-        dcls[d] += a; ddist[d] += c; dnew_pos[d] += a; dnew_pos[DM + d] += c;
+        unsafeAtomicAdd(&dcls[d], a); unsafeAtomicAdd(&ddist[d], c);
+        unsafeAtomicAdd(&dnew_pos[d], a); unsafeAtomicAdd(&dnew_pos[DM + d], c);
     } else if (job <= 12) {
         const int f = job - 1;
         float a = 0.f;
-        for (int b = 0; b < B; ++b)
+        for (int b = b0; b < b1; ++b)
             for (int t = 0; t < tp; ++t) {
                 const float v = dx[((size_t)b * N + 2 + f * tp + t) * DM + d];
                 a += v;
                 dconv[((size_t)b * 12 * tp + f * tp + t) * DM + d] = f2bf(v);
             }
-        dfreq[d * 12 + f] += a;
+        unsafeAtomicAdd(&dfreq[d * 12 + f], a);
     } else {
         const int t = job - 13;
         float a = 0.f;
-        for (int b = 0; b < B; ++b)
+        for (int b = b0; b < b1; ++b)
             for (int f = 0; f < 12; ++f) a += dx[((size_t)b * N + 2 + f * tp + t) * DM + d];
-        dtime[d * 99 + toffset + t] += a;
+        unsafeAtomicAdd(&dtime[d * 99 + toffset + t], a);
     }
 }
 extern "C" int sed_assemble_tokens_bwd(const float* dx, void* dconv, float* dcls, float* ddist, float* dnew_pos,
                                        float* dfreq, float* dtime, int toffset, int B, int tp, hipStream_t stream) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(assemble_tokens_bwd_kernel, dim3(13 + tp, DM / 256), dim3(256), 0, stream, dx, (bf16_t*)dconv,
+    hipLaunchKernelGGL(assemble_tokens_bwd_kernel, dim3(13 + tp, DM / 256, B < 8 ? B : 8), dim3(256), 0, stream, dx, (bf16_t*)dconv,
                        dcls, ddist, dnew_pos, dfreq, dtime, toffset, B, tp);
     return sed_check_launch();
 }
@@ -695,23 +698,42 @@ extern "C" int sed_head_bwd(const float* x, const float* W, const float* strong,
 // AT head: single-query multi-head attention pooling (pooling.py:45-51).  kv bf16 [B, N, 2 D] (K | V), tokens 2..N-1
 //   one workgroup per (b, h): scores over the P = N - 2 patch tokens, softmax, weighted V sum.
 // ---------------------------------------------------------------------------------------------------
+// 64-wide dot of one token row (64 consecutive 16-bit values = 8 x 16 B) with a vector held in LDS as float[64]
+__device__ __forceinline__ float attnpool_dot64(const bf16_t* row, const float* vec, int f16) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint4 u = reinterpret_cast<const uint4*>(row)[c];
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bf16_t lo = (bf16_t)(w[e] & 0xFFFF), hi = (bf16_t)(w[e] >> 16);
+            acc += (f16 ? h2f(lo) : bf2f(lo)) * vec[c * 8 + 2 * e] + (f16 ? h2f(hi) : bf2f(hi)) * vec[c * 8 + 2 * e + 1];
+        }
+    }
+    return acc;
+}
+// Scores: one LANE per token (no cross-lane reduction per token); weighted V sum: one lane per channel, 8 independent token rows in
+// flight per wave.  (The first version did one wave reduction per token: ~300 dependent round trips per wave, 320 us.)
 __global__ __launch_bounds__(256) void attnpool_fwd_kernel(const bf16_t* __restrict__ kv, const float* __restrict__ q,
                                                            float* __restrict__ out, float* __restrict__ probs, int N,
                                                            int H, int f16) {
     extern __shared__ float sc[];  // [P]
     __shared__ float red[4];
     __shared__ float part[4][64];
+    __shared__ float qs[64];
     const int b = blockIdx.x / H, h = blockIdx.x - b * H, P = N - 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bf16_t* base = kv + ((size_t)b * N + 2) * (2 * DM);
-    const float qd = q[h * 64 + lane];
+    const bf16_t* base = kv + ((size_t)b * N + 2) * (2 * DM) + h * 64;
+    if (threadIdx.x < 64) qs[threadIdx.x] = q[h * 64 + threadIdx.x];
+    __syncthreads();
     float mx = -1e30f;
-    for (int t = wave; t < P; t += 4) {
-        float s = qd * (f16 ? h2f(base[(size_t)t * 2 * DM + h * 64 + lane]) : bf2f(base[(size_t)t * 2 * DM + h * 64 + lane]));
-        s = wave_sum(s) * 0.125f;
-        if (lane == 0) sc[t] = s;
+    for (int t = threadIdx.x; t < P; t += 256) {
+        const float s = attnpool_dot64(base + (size_t)t * 2 * DM, qs, f16) * 0.125f;
+        sc[t] = s;
         mx = fmaxf(mx, s);
     }
+    mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
@@ -723,10 +745,19 @@ __global__ __launch_bounds__(256) void attnpool_fwd_kernel(const bf16_t* __restr
     __syncthreads();
     const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
     float acc = 0.f;
-    for (int t = wave; t < P; t += 4) acc += sc[t] * inv * (f16 ? h2f(base[(size_t)t * 2 * DM + DM + h * 64 + lane]) : bf2f(base[(size_t)t * 2 * DM + DM + h * 64 + lane]));
-    part[wave][lane] = acc;
+    const bf16_t* vbase = base + DM + lane;
+    int t = wave;
+    for (; t + 28 < P; t += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const bf16_t x = vbase[(size_t)(t + 4 * u) * 2 * DM]; v[u] = f16 ? h2f(x) : bf2f(x); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += sc[t + 4 * u] * v[u];
+    }
+    for (; t < P; t += 4) { const bf16_t x = vbase[(size_t)t * 2 * DM]; acc += sc[t] * (f16 ? h2f(x) : bf2f(x)); }
+    part[wave][lane] = acc * inv;
     if (probs != nullptr)
-        for (int t = threadIdx.x; t < P; t += 256) probs[(size_t)blockIdx.x * P + t] = sc[t] * inv;
+        for (int tt = threadIdx.x; tt < P; tt += 256) probs[(size_t)blockIdx.x * P + tt] = sc[tt] * inv;
     __syncthreads();
     if (wave == 0) out[(size_t)b * DM + h * 64 + lane] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
 }
@@ -742,32 +773,52 @@ __global__ __launch_bounds__(256) void attnpool_bwd_kernel(const bf16_t* __restr
                                                            const float* __restrict__ probs,
                                                            const float* __restrict__ dout, bf16_t* __restrict__ dkv,
                                                            float* __restrict__ dq, int N, int H, int f16) {
-    extern __shared__ float dp[];  // [P]
+    extern __shared__ float dp[];  // [P] -> dS
     __shared__ float red[4];
     __shared__ float part[4][64];
+    __shared__ float gos[64];
     const int b = blockIdx.x / H, h = blockIdx.x - b * H, P = N - 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bf16_t* base = kv + ((size_t)b * N + 2) * (2 * DM);
-    bf16_t* dbase = dkv + ((size_t)b * N + 2) * (2 * DM);
+    const bf16_t* base = kv + ((size_t)b * N + 2) * (2 * DM) + h * 64;
+    bf16_t* dbase = dkv + ((size_t)b * N + 2) * (2 * DM) + h * 64;
     const float* pr = probs + (size_t)blockIdx.x * P;
-    const float go = dout[(size_t)b * DM + h * 64 + lane], qd = q[h * 64 + lane];
+    if (threadIdx.x < 64) gos[threadIdx.x] = dout[(size_t)b * DM + h * 64 + threadIdx.x];
+    __syncthreads();
+    const float go = gos[lane], qd = q[h * 64 + lane];
+    // dP[t] = dout . V[t]  (one lane per token), dot = sum_t p[t] dP[t]
     float dot = 0.f;
-    for (int t = wave; t < P; t += 4) {
-        float v = go * (f16 ? h2f(base[(size_t)t * 2 * DM + DM + h * 64 + lane]) : bf2f(base[(size_t)t * 2 * DM + DM + h * 64 + lane]));
-        v = wave_sum(v);
-        if (lane == 0) dp[t] = v;
+    for (int t = threadIdx.x; t < P; t += 256) {
+        const float v = attnpool_dot64(base + (size_t)t * 2 * DM + DM, gos, f16);
+        dp[t] = v;
         dot += v * pr[t];
     }
+    dot = wave_sum(dot);
     if (lane == 0) red[wave] = dot;
     __syncthreads();
     dot = red[0] + red[1] + red[2] + red[3];
+    for (int t = threadIdx.x; t < P; t += 256) dp[t] = pr[t] * (dp[t] - dot) * 0.125f;   // dS[t]
+    __syncthreads();
+    // dq[d] = sum_t dS[t] K[t][d];  dK[t][d] = dS[t] q[d];  dV[t][d] = p[t] dout[d]   (one lane per channel, 8 rows in flight)
     float dqa = 0.f;
-    for (int t = wave; t < P; t += 4) {
-        const float p = pr[t];
-        const float ds = p * (dp[t] - dot) * 0.125f;
-        dqa += ds * (f16 ? h2f(base[(size_t)t * 2 * DM + h * 64 + lane]) : bf2f(base[(size_t)t * 2 * DM + h * 64 + lane]));
-        dbase[(size_t)t * 2 * DM + h * 64 + lane] = f2bf(ds * qd);
-        dbase[(size_t)t * 2 * DM + DM + h * 64 + lane] = f2bf(p * go);
+    int t = wave;
+    for (; t + 28 < P; t += 32) {
+        float kx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const bf16_t x = base[(size_t)(t + 4 * u) * 2 * DM + lane]; kx[u] = f16 ? h2f(x) : bf2f(x); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float ds = dp[t + 4 * u];
+            dqa += ds * kx[u];
+            dbase[(size_t)(t + 4 * u) * 2 * DM + lane] = f2bf(ds * qd);
+            dbase[(size_t)(t + 4 * u) * 2 * DM + DM + lane] = f2bf(pr[t + 4 * u] * go);
+        }
+    }
+    for (; t < P; t += 4) {
+        const bf16_t x = base[(size_t)t * 2 * DM + lane];
+        const float ds = dp[t];
+        dqa += ds * (f16 ? h2f(x) : bf2f(x));
+        dbase[(size_t)t * 2 * DM + lane] = f2bf(ds * qd);
+        dbase[(size_t)t * 2 * DM + DM + lane] = f2bf(pr[t] * go);
     }
     if (wave == 0) {  // cls/dist rows receive no gradient from the AT head
         bf16_t* z = dkv + ((size_t)b * N) * (2 * DM);
