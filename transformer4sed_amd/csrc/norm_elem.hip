@@ -605,25 +605,34 @@ extern "C" int sed_head_fwd(const float* x, const float* W, const float* bias, f
 // backward: dlogit[b,t,c] = (dstrong[b,c,t] + dweak[b,c] * (2 s B - A) / B^2 [if unclamped]) * s (1 - s) / temp
 // dx[row] = sum_c dlogit W[c];  dW[c] += sum_rows dlogit x[row];  db[c] += sum dlogit
 #define HEAD_C 10
-// lane c (< 10) evaluates class c, then the ten values are broadcast with readlane: one set of loads per row, not ten
-__device__ __forceinline__ void head_dlogits(float (&dl)[HEAD_C], const float* __restrict__ strong, const float* __restrict__ sums,
-                                             const float* __restrict__ dstrong, const float* __restrict__ dweak, float inv_temp,
-                                             int b, int t, int T, int lane) {
-    float mine = 0.f;
-    if (lane < HEAD_C) {
-        const int c = lane;
-        const size_t si = ((size_t)b * HEAD_C + c) * T + t;
-        const float s = strong[si];
-        float g = dstrong != nullptr ? dstrong[si] : 0.f;
-        if (dweak != nullptr) {
-            const float A = sums[2 * (b * HEAD_C + c)], Bs = sums[2 * (b * HEAD_C + c) + 1];
-            const float wv = A / Bs;
-            if (wv > 1e-7f && wv < 1.0f) g += dweak[b * HEAD_C + c] * (2.f * s * Bs - A) / (Bs * Bs);
-        }
-        mine = g * s * (1.f - s) * inv_temp;
-    }
+// A wave owns 16 consecutive rows (b, t): lane = (class group cg = lane >> 4, row rl = lane & 15) evaluates dlogit for classes
+// cg, cg + 4, cg + 8 of its row -- 64-byte coalesced segments of `strong` / `dstrong` along t; the value for (row rl, class c) then
+// lives in lane (c & 3) * 16 + rl, register c >> 2, and is broadcast with a uniform-index shuffle when the row is processed.
+__device__ __forceinline__ void head_dlogits16(float (&mine)[3], const float* __restrict__ strong, const float* __restrict__ sums,
+                                               const float* __restrict__ dstrong, const float* __restrict__ dweak, float inv_temp,
+                                               int row, int nrows, int T, int lane) {
+    const int cg = lane >> 4;
 #pragma unroll
-    for (int c = 0; c < HEAD_C; ++c) dl[c] = __shfl(mine, c, 64);
+    for (int k = 0; k < 3; ++k) {
+        const int c = cg + 4 * k;
+        mine[k] = 0.f;
+        if (c < HEAD_C && row < nrows) {
+            const int b = row / T, t = row - b * T;
+            const size_t si = ((size_t)b * HEAD_C + c) * T + t;
+            const float s = strong[si];
+            float g = dstrong != nullptr ? dstrong[si] : 0.f;
+            if (dweak != nullptr) {
+                const float A = sums[2 * (b * HEAD_C + c)], Bs = sums[2 * (b * HEAD_C + c) + 1];
+                const float wv = A / Bs;
+                if (wv > 1e-7f && wv < 1.0f) g += dweak[b * HEAD_C + c] * (2.f * s * Bs - A) / (Bs * Bs);
+            }
+            mine[k] = g * s * (1.f - s) * inv_temp;
+        }
+    }
+}
+__device__ __forceinline__ void head_dl_row(float (&dl)[HEAD_C], const float (&mine)[3], int rl) {
+#pragma unroll
+    for (int c = 0; c < HEAD_C; ++c) dl[c] = __shfl(mine[c >> 2], (c & 3) * 16 + rl, 64);
 }
 // Two sweeps over the rows inside one launch: (1) dx = sum_c dlogit_c W_c with the 10 classifier rows held in registers (one
 // write of dx, nothing re-read), (2) dW_c += dlogit_c x with the 10 per-lane partial rows in registers (one read of x).  The
@@ -636,23 +645,29 @@ __global__ __launch_bounds__(256) void sed_head_bwd_kernel(const float* __restri
                                                            float* __restrict__ dx, float* __restrict__ dW,
                                                            float* __restrict__ db, int B, int T, int C) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nrows = B * T, nblk = (nrows + 15) / 16;
     {
         Row w[HEAD_C];
 #pragma unroll
         for (int c = 0; c < HEAD_C; ++c) row_load(w[c], W + (size_t)c * DM, lane);
-        for (int row = blockIdx.x * 4 + wave; row < B * T; row += gridDim.x * 4) {
-            const int b = row / T, t = row - b * T;
-            float dl[HEAD_C];
-            head_dlogits(dl, strong, sums, dstrong, dweak, inv_temp, b, t, T, lane);
-            Row o;
+        for (int blk = blockIdx.x * 4 + wave; blk < nblk; blk += gridDim.x * 4) {
+            float mine[3];
+            head_dlogits16(mine, strong, sums, dstrong, dweak, inv_temp, blk * 16 + (lane & 15), nrows, T, lane);
+            for (int rl = 0; rl < 16; ++rl) {
+                const int row = blk * 16 + rl;
+                if (row >= nrows) break;
+                float dl[HEAD_C];
+                head_dl_row(dl, mine, rl);
+                Row o;
 #pragma unroll
-            ROW_FOREACH(i, k) {
-                float v = 0.f;
+                ROW_FOREACH(i, k) {
+                    float v = 0.f;
 #pragma unroll
-                for (int c = 0; c < HEAD_C; ++c) v += dl[c] * f4(w[c].v[i], k);
-                f4(o.v[i], k) = v;
+                    for (int c = 0; c < HEAD_C; ++c) v += dl[c] * f4(w[c].v[i], k);
+                    f4(o.v[i], k) = v;
+                }
+                row_store(o, dx + (size_t)row * DM, lane);
             }
-            row_store(o, dx + (size_t)row * DM, lane);
         }
     }
     if (dW == nullptr) return;
@@ -664,17 +679,22 @@ __global__ __launch_bounds__(256) void sed_head_bwd_kernel(const float* __restri
 #pragma unroll
         ROW_FOREACH(i, k) f4(pw[c].v[i], k) = 0.f;
     }
-    for (int row = blockIdx.x * 4 + wave; row < B * T; row += gridDim.x * 4) {
-        const int b = row / T, t = row - b * T;
-        float dl[HEAD_C];
-        head_dlogits(dl, strong, sums, dstrong, dweak, inv_temp, b, t, T, lane);
-        Row xr;
-        row_load(xr, x + (size_t)row * DM, lane);
+    for (int blk = blockIdx.x * 4 + wave; blk < nblk; blk += gridDim.x * 4) {
+        float mine[3];
+        head_dlogits16(mine, strong, sums, dstrong, dweak, inv_temp, blk * 16 + (lane & 15), nrows, T, lane);
+        for (int rl = 0; rl < 16; ++rl) {
+            const int row = blk * 16 + rl;
+            if (row >= nrows) break;
+            float dl[HEAD_C];
+            head_dl_row(dl, mine, rl);
+            Row xr;
+            row_load(xr, x + (size_t)row * DM, lane);
 #pragma unroll
-        for (int c = 0; c < HEAD_C; ++c) {
-            pb[c] += dl[c];
+            for (int c = 0; c < HEAD_C; ++c) {
+                pb[c] += dl[c];
 #pragma unroll
-            ROW_FOREACH(i, k) f4(pw[c].v[i], k) += dl[c] * f4(xr.v[i], k);
+                ROW_FOREACH(i, k) f4(pw[c].v[i], k) += dl[c] * f4(xr.v[i], k);
+            }
         }
     }
 #pragma unroll
