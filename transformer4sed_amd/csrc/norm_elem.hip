@@ -697,19 +697,27 @@ __global__ __launch_bounds__(256) void sed_head_bwd_kernel(const float* __restri
             }
         }
     }
-#pragma unroll
+    // 7680 + 10 addresses receive every workgroup's partial sums: combine the four waves in LDS first (the per-wave atomics of
+    // 2048 waves onto the same addresses were the whole 0.38 ms of this kernel)
+    __shared__ float red[4][DM];
+    __shared__ float redb[4][HEAD_C];
+#pragma unroll 1
     for (int c = 0; c < HEAD_C; ++c) {
-#pragma unroll
-        ROW_FOREACH(i, k) unsafeAtomicAdd(&dW[(size_t)c * DM + 4 * (lane + 64 * i) + k], f4(pw[c].v[i], k));
-        if (lane == 0) unsafeAtomicAdd(&db[c], pb[c]);
+        row_store(pw[c], red[wave], lane);
+        if (lane == 0) redb[wave][c] = pb[c];
+        __syncthreads();
+        for (int d = threadIdx.x; d < DM; d += 256)
+            unsafeAtomicAdd(&dW[(size_t)c * DM + d], (red[0][d] + red[1][d]) + (red[2][d] + red[3][d]));
+        __syncthreads();
     }
+    if (threadIdx.x < HEAD_C) unsafeAtomicAdd(&db[threadIdx.x], (redb[0][threadIdx.x] + redb[1][threadIdx.x]) + (redb[2][threadIdx.x] + redb[3][threadIdx.x]));
 }
 extern "C" int sed_head_bwd(const float* x, const float* W, const float* strong, const float* sums,
                             const float* dstrong, const float* dweak, float temp, float* dx, float* dW, float* db,
                             int B, int T, int C, hipStream_t stream) {
     (void)hipGetLastError();
     if (C != HEAD_C) return SED_ERR_ARG;
-    hipLaunchKernelGGL(sed_head_bwd_kernel, dim3(512), dim3(256), 0, stream, x, W, strong, sums, dstrong, dweak,
+    hipLaunchKernelGGL(sed_head_bwd_kernel, dim3(256), dim3(256), 0, stream, x, W, strong, sums, dstrong, dweak,
                        1.0f / temp, dx, dW, db, B, T, C);
     return sed_check_launch();
 }
