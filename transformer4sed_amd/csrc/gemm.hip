@@ -356,97 +356,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// v2: 128 x 256 x 64 tile, 8 waves (2 x 4, one 64 x 64 sub-tile each), THREE LDS stages (144 KiB, one workgroup per CU,
-// two waves per SIMD) filled by direct-to-LDS DMA two K tiles ahead.  The only waits in the loop are a counted
-// `s_waitcnt vmcnt(6)` (this wave's 6 pieces of the NEXT tile may stay in flight) and one raw s_barrier per K tile, so
-// memory latency (~2k cycles under load) is covered by two tiles of MFMA work instead of stalling every iteration --
-// what limits v1 on the K = 768 shapes of this model (12 iterations per tile).
-// ---------------------------------------------------------------------------------------------------------------------
-#define V2_TM 128
-#define V2_TN 256
-#define V2_STAGE (48 * 1024)
-template <int EPI, bool F16>
-__global__ __launch_bounds__(512) void gemm_nt_v2_kernel(const GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
-    const int ntn = g.N / V2_TN, ntm = (g.M + V2_TM - 1) / V2_TM, nwg = ntm * ntn;
-    const int t = xcd_remap(blockIdx.x, nwg);
-    const int group_size = 8 * ntn, gid = t / group_size, first_m = gid * 8;
-    const int gm = (ntm - first_m) < 8 ? (ntm - first_m) : 8;
-    const int tin = t - gid * group_size;
-    const int m0 = (first_m + tin % gm) * V2_TM, n0 = (tin / gm) * V2_TN;
-    const int ktiles = g.K / BK;
-    const int kt_begin = (int)(((long long)blockIdx.y * ktiles) / g.ksplit);
-    const int kt_end = (int)(((long long)(blockIdx.y + 1) * ktiles) / g.ksplit);
-    const int nk = kt_end - kt_begin;
-
-    // DMA pieces: 16 (A) + 32 (B) pieces of 8 rows x 128 B per stage; wave w owns pieces 6 w .. 6 w + 5
-    const int prow = lane >> 3, pch = lane & 7;
-    const bf16_t* src[6];
-    int dst[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int p = wave * 6 + i;
-        const bool isB = p >= 16;
-        const int row = (isB ? p - 16 : p) * 8 + prow;
-        const int cl = pch ^ ((row >> 1) & 7);
-        int am = m0 + row;
-        am = am < g.M ? am : g.M - 1;
-        src[i] = isB ? g.B + (size_t)(n0 + row) * g.ldb + cl * 8 : g.A + (size_t)am * g.lda + cl * 8;
-        dst[i] = (isB ? 16384 : 0) + (isB ? p - 16 : p) * 1024;
-    }
-#define V2_DMA(kt, stage)                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                                         \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)(kt) * BK),     \
-                                         (__attribute__((address_space(3))) void*)(lds2 + (stage) * V2_STAGE + dst[i]),   \
-                                         16, 0, 0);
-
-    f32x16_t acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int lr = lane & 31, lg = lane >> 5;
-    int arow[2], brow[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        arow[i] = wm * 64 + i * 32 + lr;
-        brow[i] = wn * 64 + i * 32 + lr;
-    }
-    if (nk > 0) { V2_DMA(kt_begin, 0); }
-    if (nk > 1) { V2_DMA(kt_begin + 1, 1); }
-    int stage = 0;
-    for (int it = 0; it < nk; ++it) {
-        if (it + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // tile `it` landed for every wave; stage (it - 1) % 3 is free again
-        if (it + 2 < nk) {
-            const int st2 = stage == 0 ? 2 : stage - 1;  // (stage + 2) % 3
-            V2_DMA(kt_begin + it + 2, st2);
-        }
-        const unsigned char* la = lds2 + stage * V2_STAGE;
-        mfma_tile<F16, true>(la, la + 16384, arow, brow, lg, acc);
-        stage = stage == 2 ? 0 : stage + 1;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 64 + i * 32 + lr;
-        if (m >= g.M) continue;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * lg;
-                const float v4[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                epilogue_quad<EPI, F16>(g, m, n, v4);
-            }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // v3: 256 x 256 x 64 workgroup tile, 8 waves (2 x 4), 128 x 64 per wave (4 x 2 MFMA 32x32x16 blocks, 128 accumulator
 // registers), two 64-KiB LDS stages filled by direct-to-LDS DMA one K tile ahead.
 // Why (tools/ablate, MI355X): with 64x64 per-wave tiles the LDS is the shared bottleneck -- DMA fills and fragment reads
@@ -1586,8 +1495,6 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
     if ((g.lda % 8) || (g.ldb % 8) || (g.ldc % 4)) return SED_ERR_ARG;
     dim3 grid(cdiv(g.M, TILE) * (g.N / TILE), g.ksplit);
     static const int glds = []() { const char* e = getenv("SED_GEMM_GLDS"); return (e == nullptr || e[0] != '0') ? 1 : 0; }();
-    // v2 (128x256, 3-stage) measures within +-5 % of v1 on this model's shapes (tools/gemm_bench.py): opt-in
-    static const int v2 = []() { const char* e = getenv("SED_GEMM_V2"); return (e != nullptr && e[0] == '1') ? 1 : 0; }();
     static const int v3 = []() { const char* e = getenv("SED_GEMM_V3"); return (e == nullptr || e[0] != '0') ? 1 : 0; }();
     // split-K dW through the 256^2 kernel measured slower in the train step (178 vs 171 ms): one workgroup per CU leaves the
     // long atomic epilogue uncovered, whereas the 128^2 kernel keeps a second workgroup's MFMAs running under it.  Opt-in.
@@ -1651,18 +1558,6 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
         } else {
             if (!attr3[0]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr3[0] = true; }
             hipLaunchKernelGGL((gemm_nt_v3_kernel<EPI, false>), grid3, dim3(512), V3_LDS, s, g);
-        }
-        return sed_check_launch();
-    }
-    if (v2 && g.N % V2_TN == 0) {
-        dim3 grid2(cdiv(g.M, V2_TM) * (g.N / V2_TN), g.ksplit);
-        static bool attr_set[2] = {false, false};
-        if (f16) {
-            if (!attr_set[1]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v2_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * V2_STAGE); attr_set[1] = true; }
-            hipLaunchKernelGGL((gemm_nt_v2_kernel<EPI, true>), grid2, dim3(512), 3 * V2_STAGE, s, g);
-        } else {
-            if (!attr_set[0]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v2_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * V2_STAGE); attr_set[0] = true; }
-            hipLaunchKernelGGL((gemm_nt_v2_kernel<EPI, false>), grid2, dim3(512), 3 * V2_STAGE, s, g);
         }
         return sed_check_launch();
     }
