@@ -139,3 +139,24 @@ def test_waveform_modification_resamples_16k_and_prefetcher(tmp_path):
     assert len(dev_batches) == len(host) == 2
     for hb, db in zip(host, dev_batches):
         assert db[0].is_cuda and torch.equal(db[0].cpu(), hb[0]) and torch.equal(db[1].cpu(), hb[1]) and torch.equal(db[2].cpu(), hb[2])
+
+
+# ------------------------------------------------------------------------------------------------ bench.py output contract
+def test_bench_json_contract():
+    """bench.py prints exactly one JSON object as its LAST stdout line with the fields the driver reads (small model / batch here)."""
+    import subprocess
+    env = dict(os.environ)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--depth", "2", "--batch", "6",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in line, k
+    assert line["unit"] == "clips/s" and line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1
+    assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None
+    assert "workload" in line["config"] and line["value"] > 0 and abs(line["value"] - 6 * 2 / (line["ms_per_step"] * 2 / 1000)) < 1e-2 * line["value"]
+    r = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
