@@ -753,6 +753,11 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(const GemmArgs g) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)(kt) * BK),     \
                                          (__attribute__((address_space(3))) void*)(lds3 + (stage) * V3_STAGE + dst[i]),   \
                                          16, 0, 0);
+#define V3_DMA2(kt, stage, I0)                                                                                            \
+    _Pragma("unroll") for (int i = (I0); i < (I0) + 2; ++i)                                                               \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)(kt) * BK),     \
+                                         (__attribute__((address_space(3))) void*)(lds3 + (stage) * V3_STAGE + dst[i]),   \
+                                         16, 0, 0);
     f32x16_t acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -771,6 +776,9 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(const GemmArgs g) {
     v3_load_consts<EPI>(cc, g, n0 + wn * 64, lane);
 #ifndef V3_XBAR
 #define V3_XBAR 1
+#endif
+#ifndef V3_DMA_SPREAD
+#define V3_DMA_SPREAD 1   // +4-5 % on every shape of tools/gemm_bench.py (ablation: the DMA's LDS writes cost the loop 22 %, the fragment reads 11 %)
 #endif
 #if V3_XBAR
     // The per-K-tile barrier sits BEFORE the last k-step's MFMAs instead of at the top of the tile: by then every wave has
@@ -795,22 +803,55 @@ __global__ __launch_bounds__(512) void gemm_nt_v3_kernel(const GemmArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         V3_TRACE(1);
+#if V3_DMA_SPREAD
+        if (nk > 1) { V3_DMA2(kt_begin + 1, 1, 0); }
+#else
         if (nk > 1) { V3_DMA(kt_begin + 1, 1); }
+#endif
         V3_FRAGS(0, lds3, 0);
+#ifdef V3_ABLATE
+        V3_FRAGS(1, lds3, 1);
+#endif
     }
     for (int it = 0; it < nk; ++it) {
         const unsigned char* base = lds3 + (it & 1) * V3_STAGE;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int cur = s & 1, nxt = cur ^ 1;
+#ifdef V3_ABLATE   // timing experiments only (results are wrong): bit 0 = no DMA, bit 1 = no fragment reads, bit 2 = no barrier
             if (s < 3) {
+                if (!(V3_ABLATE & 2)) { V3_FRAGS(nxt, base, s + 1); }
+            } else if (it + 1 < nk) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if (!(V3_ABLATE & 4)) __builtin_amdgcn_s_barrier();
+                if (!(V3_ABLATE & 1) && it + 2 < nk) { V3_DMA(kt_begin + it + 2, it & 1); }
+                if (!(V3_ABLATE & 2)) { V3_FRAGS(nxt, lds3 + ((it + 1) & 1) * V3_STAGE, 0); }
+            }
+            if (V3_ABLATE & 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(af[nxt][i]));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(bfr[nxt][j]));
+            }
+#else
+            if (s < 3) {
+#if V3_DMA_SPREAD
+                // the DMA of tile it+1 is spread over the k-steps (2 of this wave's 8 pieces each) instead of one burst of 64 KiB
+                // into the LDS right when every wave starts reading fragments
+                if (it + 1 < nk) { V3_DMA2(kt_begin + it + 1, (it + 1) & 1, 2 * s + 2); }
+#endif
                 V3_FRAGS(nxt, base, s + 1);
             } else if (it + 1 < nk) {
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // next tile landed; my reads of this stage are done
                 __builtin_amdgcn_s_barrier();                                 // ... for every wave
+#if V3_DMA_SPREAD
+                if (it + 2 < nk) { V3_DMA2(kt_begin + it + 2, it & 1, 0); }
+#else
                 if (it + 2 < nk) { V3_DMA(kt_begin + it + 2, it & 1); }       // this stage is free again
+#endif
                 V3_FRAGS(nxt, lds3 + ((it + 1) & 1) * V3_STAGE, 0);
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
