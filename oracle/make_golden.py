@@ -37,7 +37,8 @@ sys.path.insert(0, REPO)
 _tb = types.ModuleType("torch.utils.tensorboard")
 _tb.SummaryWriter = type("SummaryWriter", (), {"__init__": lambda self, *a, **k: None})
 sys.modules["torch.utils.tensorboard"] = _tb
-for _name, _attrs in (("torchmetrics", ()), ("psds_eval", ("PSDSEval", "plot_psd_roc")), ("sed_eval", ())):
+for _name, _attrs in (("torchmetrics", ()), ("psds_eval", ("PSDSEval", "plot_psd_roc")), ("sed_eval", ()),
+                      ("torchvision", ()), ("torchvision.ops", ("drop_block2d",))):   # torchvision: ResNet variant only
     _m = types.ModuleType(_name)  # metric libraries: imported by the trainers, never called by this script
     for _a in _attrs:
         setattr(_m, _a, None)
@@ -682,8 +683,116 @@ def gen_datapipe():
     save("datapipe", **out)
 
 
+PMAM_SYNTH = dict(gmm_name="pmam/gmm_means", label_seed=500)
+
+
+def build_reference_pmam(depth, feature_layer, conv_dropout, mlm=True, lora=True):
+    """PaSST_CNN of the reference with config/pmam/post_pretrain.yaml:47-80 and the synthetic weights of synth.pmam_state_dict_np."""
+    from src.models.cnn_transformer.passt_cnn import PaSST_CNN
+    passt = dict(passt_feature_layer=feature_layer, class_num=30, f_pool="attention", decode_ratio=10, at_adapter=True,
+                 decoder="transformerXL", decoder_layer_num=3, decoder_pos_emd_len=1000, decoder_dim=384, mlm=mlm)
+    if lora:
+        passt["lora_config"] = dict(r=8, lora_alpha=1, requires_grad_pretrain=False)
+    if mlm:
+        passt["mlm_dict"] = dict(strategy="block", block_width=10, mask_rate=0.8, out_dim=768, mask_style=[0.9, 0.05, 0.05])
+    cnn = dict(n_in_channel=1, activation="cg", conv_dropout=conv_dropout, kernel_size=[3] * 10, padding=[1] * 10, stride=[1] * 10,
+               nb_filters=list(synth.PMAM_FILTERS), pooling=[list(p) for p in synth.PMAM_POOLING])
+    o_load = torch.load
+    torch.load = lambda *a, **k: {}
+    try:
+        net = PaSST_CNN(passt_sed_param=passt, cnn_param=cnn)
+    finally:
+        torch.load = o_load
+    sd_np = synth.pmam_state_dict_np(depth=12, mlm=mlm, lora_r=8 if lora else 0)
+    ref_shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert ref_shapes == {k: tuple(v.shape) for k, v in sd_np.items()}, "PaSST_CNN state_dict contract drifted"
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=True)
+    if depth < 12:
+        net.backbone.blocks = net.backbone.blocks[:depth]
+    return net
+
+
+def gen_pmam():
+    """PMAM variant: PaSST_CNN forward in eval mode (LoRA merged, BatchNorm running statistics) at the real
+    depth, and a train-mode forward + prototype loss + backward at depth 2 (LoRA unmerged, batch statistics; conv dropout set to 0 so
+    that no 650 KB/clip of Bernoulli masks has to be stored -- dropout itself is covered by oracle-vs-HIP tests with injected masks)."""
+    from src.models.lora import mark_only_lora_as_trainable
+    from recipes.desed.pmam.train import Trainer
+    S = (slice(None), slice(None, None, 25), slice(None, None, 16))
+    for tag, depth, fl, B in (("pmam_d12", 12, 10, 1), ("pmam_d2", 2, 2, 2)):
+        out = {}
+        mel = torch.from_numpy(synth.det_uniform(f"{tag}/mel", (B, 128, 1000), -1.2, 1.2))
+        gmm = torch.from_numpy(synth.det_normal(PMAM_SYNTH["gmm_name"], (30, 768)))
+        labels = torch.from_numpy(synth.synth_strong_labels(B, n_classes=30, seed=PMAM_SYNTH["label_seed"]))
+        # ---- eval mode
+        net = build_reference_pmam(depth, fl, conv_dropout=0.5)
+        net.eval()
+        hooks = {}
+        net.cnn.register_forward_hook(lambda m, i, o: hooks.__setitem__("cnn", o))
+        net.interpolate_module.register_forward_hook(lambda m, i, o: hooks.__setitem__("interp", o))
+        torch.manual_seed(51)
+        rec = DrawRecorder()
+        with rec.recording(), torch.no_grad():
+            pred, other = net(mel, encoder_win=False)
+        out["ev_noise"], out["ev_probs"] = t2n(rec.of("rand")[0]), t2n(rec.of("rand")[1])
+        out["ev_rand_idx"] = t2n(rec.of("randint")[0])
+        out["ev_mask_ids"] = t2n(other["mask_id_seq"])
+        out["ev_pred_s"] = t2n(pred[S])
+        out["ev_fbm_s"] = t2n(other["frame_before_mask"][S])
+        out["ev_at_out"] = t2n(other["at_out"])
+        out["ev_cnn_s"] = t2n(hooks["cnn"].squeeze(-1)[:, ::16, ::10])
+        out["ev_interp_s"] = t2n(hooks["interp"][S])
+        tr = Trainer.__new__(Trainer)
+        tr.gmm_means = torch.nn.functional.normalize(gmm, dim=-1)
+        strong = tr.get_predict_from_logit(pred)
+        out["ev_strong_s"] = t2n(strong[:, ::25])
+        pm = torch.zeros(B, 1000, dtype=torch.bool)
+        pm[0, 900:] = True
+        sel = torch.logical_and(torch.logical_not(pm), other["mask_id_seq"])
+        out["ev_val_loss"] = t2n(torch.nn.functional.binary_cross_entropy(strong[sel], labels.transpose(1, 2)[sel]))
+        if depth == 12:
+            save(tag, **out)
+            continue
+        # ---- train mode, gradients (recipes/desed/pmam/main.py:105 + finetune/cnn_trans/setting.py get_param_lr with freeze_layer 0)
+        net = build_reference_pmam(depth, fl, conv_dropout=0.0)
+        mark_only_lora_as_trainable(net.backbone)
+        net.backbone.norm.weight.requires_grad_(True)      # "norm." rule of get_param_lr (setting.py:73-76)
+        net.backbone.norm.bias.requires_grad_(True)
+        net.train()
+        torch.manual_seed(53)
+        rec = DrawRecorder()
+        with rec.recording():
+            pred, other = net(mel, encoder_win=False)
+        out["tr_noise"], out["tr_probs"] = t2n(rec.of("rand")[0]), t2n(rec.of("rand")[1])
+        out["tr_rand_idx"] = t2n(rec.of("randint")[0])
+        out["tr_pred_s"] = t2n(pred[S])
+        out["tr_fbm_s"] = t2n(other["frame_before_mask"][S])
+        out["tr_at_out"] = t2n(other["at_out"])
+        strong = tr.get_predict_from_logit(pred)
+        m = other["mask_id_seq"]
+        loss_strong = torch.nn.functional.binary_cross_entropy(strong[m], labels.transpose(1, 2)[m])
+        loss_weak = torch.nn.functional.binary_cross_entropy(other["at_out"], (labels.sum(-1) >= 1).float())
+        loss = loss_strong + 0.1 * loss_weak
+        loss.backward()
+        out["tr_loss_strong"], out["tr_loss_weak"], out["tr_loss"] = t2n(loss_strong), t2n(loss_weak), t2n(loss)
+        names, norms, heads = [], [], []
+        for k, p in net.named_parameters():
+            if p.grad is None:
+                continue
+            names.append(k)
+            norms.append(float(p.grad.double().norm()))
+            g = p.grad.reshape(-1)
+            heads.append(t2n(torch.cat([g, g.new_zeros(8)])[:8]))
+        out["tr_grad_names"], out["tr_grad_norms"], out["tr_grad_heads"] = np.asarray(names), np.asarray(norms), np.stack(heads)
+        sd_after = net.state_dict()
+        for i in range(10):
+            for st in ("running_mean", "running_var"):
+                out[f"tr_bn{i}_{st}"] = t2n(sd_after[f"cnn.cnn.batchnorm{i}.{st}"])
+        save(tag, **out)
+
+
 GENS = dict(frontend=gen_frontend, augment=gen_augment, micro=gen_micro, full=gen_full, full12=gen_full12,
-            schedule=gen_schedule, postprocess=gen_postprocess, losses=gen_losses, trainstep=gen_trainstep, evalpath=gen_evalpath, datapipe=gen_datapipe)
+            schedule=gen_schedule, postprocess=gen_postprocess, losses=gen_losses, trainstep=gen_trainstep, evalpath=gen_evalpath, datapipe=gen_datapipe, pmam=gen_pmam)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -147,6 +147,101 @@ def matsed_state_dict_np(tag="w0", **kw):
 
 
 # --------------------------------------------------------------------------------------------------
+# PMAM `PaSST_CNN` state_dict (reference definition sites:
+# src/models/cnn_transformer/passt_cnn.py:11-20, src/models/cnn/base.py:62-98, src/models/lora/layers.py:107-116,
+# src/models/passt/passt_lora.py:116-125, src/models/pooling.py:39-43; values of config/pmam/post_pretrain.yaml:47-80)
+# --------------------------------------------------------------------------------------------------
+PMAM_FILTERS = (16, 16, 32, 32, 64, 64, 128, 128, 256, 384)
+PMAM_POOLING = ((2, 2), (1, 1), (2, 2), (1, 1), (1, 2), (1, 2), (1, 2), (1, 2), (1, 2), (1, 1))   # (time, freq) per layer
+
+
+def pmam_param_shapes(depth=12, decoder_dim=384, class_num=30, lora_r=8, mlm=True, mlm_out=768, nb_filters=PMAM_FILTERS):
+    D, Dd = 768, decoder_dim
+    s = matsed_param_shapes(embed_dim=D, depth=depth, class_num=class_num, mlm=False)
+    for k in [k for k in s if k.startswith(("decoder.", "classifier."))]:
+        del s[k]
+    if lora_r:
+        lin = [f"backbone.blocks.{i}.{m}" for i in range(depth) for m in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")]
+        for name in lin + ["backbone.head.1", "backbone.head_dist"]:
+            n_out, k_in = s[name + ".weight"]
+            s[name + ".lora_A"] = (lora_r, k_in)
+            s[name + ".lora_B"] = (n_out, lora_r)
+    s["f_pool_module.f_att_token"] = (1, 1, D)
+    s["f_pool_module.frequency_att.in_proj_weight"] = (3 * D, D)
+    s["f_pool_module.frequency_att.in_proj_bias"] = (3 * D,)
+    s["f_pool_module.frequency_att.out_proj.weight"] = (D, D)
+    s["f_pool_module.frequency_att.out_proj.bias"] = (D,)
+    dec = matsed_param_shapes(embed_dim=Dd, depth=0, class_num=class_num, mlm=False, at_adapter=False, with_dead_heads=False)
+    for k, v in dec.items():
+        if k.startswith(("decoder.", "classifier.")):
+            s[k] = v
+    if mlm:
+        s["mask_token"] = (1, 1, Dd)
+        s["mlm_mlp.0.weight"] = (Dd, Dd)
+        s["mlm_mlp.0.bias"] = (Dd,)
+        s["mlm_mlp.2.weight"] = (mlm_out, Dd)
+        s["mlm_mlp.2.bias"] = (mlm_out,)
+    cin = 1
+    for i, co in enumerate(nb_filters):
+        s[f"cnn.cnn.conv{i}.weight"] = (co, cin, 3, 3)
+        s[f"cnn.cnn.conv{i}.bias"] = (co,)
+        s[f"cnn.cnn.batchnorm{i}.weight"] = (co,)
+        s[f"cnn.cnn.batchnorm{i}.bias"] = (co,)
+        s[f"cnn.cnn.batchnorm{i}.running_mean"] = (co,)
+        s[f"cnn.cnn.batchnorm{i}.running_var"] = (co,)
+        s[f"cnn.cnn.batchnorm{i}.num_batches_tracked"] = ()
+        s[f"cnn.cnn.cg{i}.linear.weight"] = (co, co)
+        s[f"cnn.cnn.cg{i}.linear.bias"] = (co,)
+        cin = co
+    s["cnn_projector.weight"] = (Dd, nb_filters[-1])
+    s["cnn_projector.bias"] = (Dd,)
+    s["merge_weight"] = (1,)
+    s["transformer_projector.weight"] = (Dd, D)
+    s["transformer_projector.bias"] = (Dd,)
+    return s
+
+
+def pmam_state_dict_np(tag="pmam0", **kw):
+    """Deterministic 'active' PaSST_CNN weights (LoRA B non-zero so that the low-rank path matters; BatchNorm running statistics
+    away from (0, 1) so that eval mode differs from an identity normalisation)."""
+    shapes = pmam_param_shapes(**kw)
+    base = matsed_state_dict_np(tag=tag, embed_dim=768, depth=kw.get("depth", 12), class_num=kw.get("class_num", 30))
+    out = {}
+    for name, shp in shapes.items():
+        key = f"{tag}/{name}"
+        if name in base and base[name].shape == tuple(shp):
+            out[name] = base[name]
+            continue
+        if name.endswith("num_batches_tracked"):
+            out[name] = np.asarray(3, dtype=np.int64)
+            continue
+        if name.endswith("running_mean"):
+            w = 0.3 * det_uniform(key, shp)
+        elif name.endswith("running_var"):
+            w = 1.0 + 0.5 * det_uniform(key, shp)
+        elif "batchnorm" in name and name.endswith(".weight") or name.endswith(("norm1.weight", "norm2.weight")):
+            w = 1.0 + 0.2 * det_uniform(key, shp)
+        elif name == "merge_weight":
+            w = np.asarray([0.5], dtype=np.float32)
+        elif name.endswith(".bias") or name.endswith("in_proj_bias"):
+            w = 0.1 * det_uniform(key, shp)
+        elif "pos_bias_" in name or name.endswith("_token"):
+            w = 0.5 * det_uniform(key, shp)
+        elif name.endswith("lora_A"):
+            w = det_uniform(key, shp) * math.sqrt(3.0 / shp[-1])
+        elif name.endswith("lora_B"):
+            w = det_uniform(key, shp) * (2.0 * math.sqrt(3.0 / shp[-1]))
+        elif ".conv" in name:
+            fan_in = shp[1] * 9
+            w = det_uniform(key, shp) * (1.4 * math.sqrt(3.0 / fan_in))
+        else:
+            gain = 1.6 if ("in_proj" in name or "linear_pos" in name) else 1.0
+            w = det_uniform(key, shp) * (gain * math.sqrt(3.0 / shp[-1]))
+        out[name] = np.asarray(w, dtype=np.float32)
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
 # DESED-shaped synthetic clips (SURVEY.md section 8(d) "Synthetic inputs")
 # --------------------------------------------------------------------------------------------------
 def synth_wav(n_clips: int, n_samples: int = 320000, seed: int = 1000) -> np.ndarray:
