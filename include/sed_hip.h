@@ -142,6 +142,42 @@ int sed_attnpool_bwd(const void* kv, const float* q, const float* probs, const f
 int sed_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr, float wd, float beta1,
                   float beta2, float eps, int step, float ema_alpha, int do_adam, hipStream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * PMAM variant of the model path: PaSST_CNN.forward (src/models/cnn_transformer/passt_cnn.py:31-88).
+ * ------------------------------------------------------------------------------------------------------------------------- */
+/* LoRA merge W_eff = W + scaling * B A, fp32 [n_out, k_in] (src/models/lora/layers.py:120-153; r = rank, A [r, k_in], Bm [n_out, r]) */
+int sed_lora_merge(const float* W, const float* A, const float* Bm, float scaling, float* out, int n_out, int k_in, int r,
+                   hipStream_t stream);
+/* LayerNorm of width D (multiple of 128, <= 1024): the 384-wide context network (src/models/transformer/transformerXL.py:31-35).
+ * Same outputs as sed_layernorm_fwd (16-bit and/or fp32 result, per-row mean / rstd for the backward; all nullable). */
+int sed_ln_fwd_any(const float* x, const float* gamma, const float* beta, float eps, float in_scale, void* y16, float* y32,
+                   float* mean, float* rstd, int M, int D, int f16, hipStream_t stream);
+/* MlmModule.setence_mask application on rows of width C (src/models/transformer/mask.py:62-85); see sed_mlm_apply */
+int sed_mlm_apply_c(const float* x, const float* mask_token, const uint8_t* action, const int* src_idx, float* out, int rows,
+                    int C, hipStream_t stream);
+/* CNN branch (src/models/cnn/base.py:62-113): 3x3 / pad 1 patch gathers for the im2col GEMMs.  Layer 0 reads the mel
+ * spectrogram [B, 128, T] (the reference's input.transpose(1, 2).unsqueeze(1), passt_cnn.py:51) into col [B*T*128, 64]
+ * (9 taps + zeros); later layers read NHWC 16-bit activations X [B, H, W, Cp] into col [B*H*W, Kp], column = tap * C + c. */
+int sed_conv0_im2col(const float* mel, void* col, int B, int T, int f16, hipStream_t stream);
+int sed_conv3x3_im2col(const void* X, void* col, int B, int H, int W, int C, int Cp, int Kp, hipStream_t stream);
+/* BatchNorm2d(eps 1e-3) as the per-channel affine Z = Y * a + b (base.py:72-75): 16-bit operand of the ContextGating GEMM,
+ * channels C..Cp-1 zero.  Y [M, ldy] fp32 is the convolution output. */
+int sed_bn_act(const float* Y, int ldy, const float* a, const float* b, void* Z, int64_t M, int C, int Cp, int f16,
+               hipStream_t stream);
+/* ContextGating (base.py:19-30) + Dropout (mask [M, C] bytes, nullable; kept values * drop_scale) + AvgPool2d((ph, pw)):
+ * out[b, ho, wo, c] = mean of (Y a + b) * sigmoid(L) * keep.  out16 NHWC with channel pad Cpo and/or out32 [rows, C]. */
+int sed_cg_pool(const float* Y, int ldy, const float* a, const float* b, const float* L, int ldl, const uint8_t* mask,
+                float drop_scale, void* out16, float* out32, int B, int H, int W, int C, int Cpo, int ph, int pw, int f16,
+                hipStream_t stream);
+/* 'attention' frequency pooling (src/models/pooling.py:37-51, 6 heads; passt_sed.py:211-215): kv [B*N, 1536] 16-bit (k | v of the
+ * out_norm'ed tokens), q [768] projected query -> out [B*tp, 768] (16-bit and/or fp32), probs [B*tp, 6, 12] (nullable). */
+int sed_fpool_attn_fwd(const void* kv, const float* q, void* out16, float* out32, float* probs, int B, int N, int tp, int f16,
+                       hipStream_t stream);
+/* projector merge (passt_cnn.py:57-62): out[b, j] = lerp_r1(pad1(P1))[j] + mw[0] * lerp_r2(P2)[j], F.interpolate(linear,
+ * align_corners=False) arithmetic; P1 [B, tp1, C], P2 [B, tp2, C], (tp1 + pad1) * r1 == tp2 * r2 output frames. */
+int sed_pmam_merge(const float* P1, const float* P2, const float* mw, float* out, int B, int tp1, int pad1, int r1, int tp2,
+                   int r2, int C, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

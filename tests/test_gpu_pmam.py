@@ -1,0 +1,110 @@
+"""PMAM variant on the GPU: PaSST_CNN through the C ABI vs the reference goldens (tests/golden/pmam_*.npz)
+and vs the CPU oracle (oracle/pmam_oracle.py) on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from transformer4sed_amd import synth
+
+pytestmark = pytest.mark.gpu
+S = (slice(None), slice(None, None, 25), slice(None, None, 16))
+
+PASST = dict(class_num=30, f_pool="attention", decode_ratio=10, at_adapter=True, decoder="transformerXL", decoder_layer_num=3,
+             decoder_pos_emd_len=1000, decoder_dim=384, mlm=True, lora_config=dict(r=8, lora_alpha=1, requires_grad_pretrain=False),
+             mlm_dict=dict(strategy="block", block_width=10, mask_rate=0.8, out_dim=768, mask_style=[0.9, 0.05, 0.05]),
+             load_pretrained_model=False)
+CNN = dict(n_in_channel=1, activation="cg", conv_dropout=0.5, kernel_size=[3] * 10, padding=[1] * 10, stride=[1] * 10,
+           nb_filters=list(synth.PMAM_FILTERS), pooling=[list(p) for p in synth.PMAM_POOLING])
+
+
+def close(a, b, atol, rtol=0.0, what=""):
+    a = np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a, dtype=np.float64)
+    b = np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b)
+    assert (err <= atol + rtol * np.abs(b)).all(), f"{what}: max err {err.max():.3e} (tol {atol:g}+{rtol:g}*|ref|)"
+
+
+def build(depth, fl, dropout=0.5):
+    from transformer4sed_amd.passt_cnn import PaSST_CNN
+    net = PaSST_CNN(passt_sed_param=dict(PASST, passt_feature_layer=fl, encoder_depth=depth), cnn_param=dict(CNN, conv_dropout=dropout))
+    sd = synth.pmam_state_dict_np(depth=12)
+    own = net.state_dict()
+    missing = [k for k in own if k not in sd]
+    assert not missing, missing
+    net.load_state_dict({k: torch.from_numpy(np.asarray(sd[k])) for k in own}, strict=True)
+    return net.cuda()
+
+
+def draws(g, pre):
+    return dict(noise=torch.from_numpy(g[pre + "_noise"]), probs=torch.from_numpy(g[pre + "_probs"]), rand_idx=torch.from_numpy(g[pre + "_rand_idx"]))
+
+
+def _eval_vs_golden(golden, tag, depth, fl, B):
+    from oracle import pmam_oracle as PO
+    g = golden(tag)
+    net = build(depth, fl)
+    net.eval()
+    assert net.lora_merged
+    mel = torch.from_numpy(synth.det_uniform(f"{tag}/mel", (B, 128, 1000), -1.2, 1.2)).cuda()
+    net._mlm_draws = draws(g, "ev")
+    with torch.no_grad():
+        pred, other = net(mel, encoder_win=False)
+    assert (other["mask_id_seq"].cpu().numpy() == g["ev_mask_ids"]).all()
+    close(other["frame_before_mask"][S], g["ev_fbm_s"], 6e-3, 2e-3, what="merged projector sequence")
+    close(other["at_out"], g["ev_at_out"], 1e-3, what="AT head")
+    close(pred[S], g["ev_pred_s"], 8e-3, 2e-3, what="MLM logits")
+    gmm = torch.from_numpy(synth.det_normal("pmam/gmm_means", (30, 768)))
+    strong = PO.prototype_posteriors(pred.cpu(), gmm)
+    err = float((strong[:, ::25] - torch.from_numpy(g["ev_strong_s"])).abs().max())
+    print(f"{tag}: prototype posterior max err {err:.2e}")
+    assert err < 1e-3, "frame posteriors within 1e-3 of the reference (BASELINE north_star tolerance)"
+
+
+def test_pmam_eval_depth2_vs_reference(golden):
+    _eval_vs_golden(golden, "pmam_d2", 2, 2, 2)
+
+
+def test_pmam_eval_depth12_vs_reference(golden):
+    _eval_vs_golden(golden, "pmam_d12", 12, 10, 1)
+
+
+def test_pmam_train_forward_vs_reference_and_dropout_vs_oracle(golden):
+    """Train mode: unmerged LoRA, batch statistics (+ running-statistics update) vs the reference (dropout 0); then dropout 0.5 with
+    injected masks vs the oracle."""
+    from oracle import matsed_oracle as O, pmam_oracle as PO
+    g = golden("pmam_d2")
+    B = 2
+    mel_h = torch.from_numpy(synth.det_uniform("pmam_d2/mel", (B, 128, 1000), -1.2, 1.2))
+    net = build(2, 2, dropout=0.0)
+    net.train()
+    assert not net.lora_merged
+    net._mlm_draws = draws(g, "tr")
+    with torch.no_grad():
+        pred, other = net(mel_h.cuda(), encoder_win=False)
+    close(other["frame_before_mask"][S], g["tr_fbm_s"], 6e-3, 2e-3, what="train-mode merged sequence (batch statistics)")
+    close(pred[S], g["tr_pred_s"], 8e-3, 2e-3, what="train-mode MLM logits")
+    close(other["at_out"], g["tr_at_out"], 1e-3)
+    sd_after = net.state_dict()
+    for i in range(10):
+        for st in ("running_mean", "running_var"):
+            close(sd_after[f"cnn.cnn.batchnorm{i}.{st}"], g[f"tr_bn{i}_{st}"], 2e-3, 5e-3, what=f"BatchNorm {i} {st}")
+    assert int(sd_after["cnn.cnn.batchnorm0.num_batches_tracked"]) == 4
+    # dropout with injected masks
+    net = build(2, 2, dropout=0.5)
+    net.train()
+    net._mlm_draws = draws(g, "tr")
+    gen = torch.Generator().manual_seed(7)
+    Hc, Wc, masks_dev, masks_or = 1000, 128, [], []
+    for i, co in enumerate(synth.PMAM_FILTERS):
+        mk = torch.rand(B, Hc, Wc, co, generator=gen) >= 0.5
+        masks_dev.append(mk.reshape(-1, co).to(torch.uint8).cuda())
+        masks_or.append(mk.permute(0, 3, 1, 2))
+        Hc, Wc = Hc // synth.PMAM_POOLING[i][0], Wc // synth.PMAM_POOLING[i][1]
+    net._drop_masks = masks_dev
+    with torch.no_grad():
+        pred, other = net(mel_h.cuda(), encoder_win=False)
+        sd = O.to_torch_sd(synth.pmam_state_dict_np(depth=12))
+        o = PO.passt_cnn_forward(sd, mel_h, depth=2, feature_layer=2, train=True, mlm_draws=draws(g, "tr"), drop_masks=masks_or)
+    close(other["frame_before_mask"][S], o["frame_before_mask"][S], 6e-3, 2e-3, what="dropout path")
+    close(pred[S], o["mlm_pred"][S], 8e-3, 2e-3, what="dropout path logits")

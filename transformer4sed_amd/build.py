@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsed_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "relpos_attention.hip", "norm_elem.hip", "frontend.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "relpos_attention.hip", "norm_elem.hip", "frontend.hip", "pmam.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
          "-Wno-unused-result"]
 # attention kernels: MFMA accumulators stay in (unified-file) VGPRs -- the AGPR form costs a v_accvgpr_read/write per softmax

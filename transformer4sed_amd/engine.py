@@ -104,19 +104,19 @@ class SedEngine:
                 ent.ws = split3(w2.contiguous(), n_out, k_in, weight=True)
         return self.cache
 
-    def _pos(self, T, dev):
-        key = (T, str(dev))
+    def _pos(self, T, dev, Dm=D):
+        key = (T, str(dev), Dm)
         if key not in self.pos_cache:
             R = 2 * T - 1
             Rpad = pad64(R)
-            tab = torch.zeros(Rpad, D)
-            tab[:R] = rel_pos_table(T)
+            tab = torch.zeros(Rpad, Dm)
+            tab[:R] = rel_pos_table(T, Dm)
             tab = tab.to(dev)
             pos16 = tab.to(self.act).contiguous()
-            posT16 = torch.empty(D, Rpad, dtype=BF16, device=dev)
-            transpose_bf16(tab, Rpad, D, posT16)
+            posT16 = torch.empty(Dm, Rpad, dtype=BF16, device=dev)
+            transpose_bf16(tab, Rpad, Dm, posT16)
             if self.split:
-                pos16 = split3(tab, Rpad, D)
+                pos16 = split3(tab, Rpad, Dm)
             self.pos_cache[key] = (pos16, posT16, Rpad)
         return self.pos_cache[key]
 
@@ -199,13 +199,7 @@ class SedEngine:
                 ctx["layers"].append(L)
             x = x_out
             if li + 1 == m.passt_feature_layer:
-                pooled = E(Bx, tp, D)
-                pm = torch.zeros(M, device=dev) if save else None
-                pr = torch.zeros(M, device=dev) if save else None
-                call("sed_fpool_fwd", x, self.P("out_norm.weight"), self.P("out_norm.bias"), 1e-5, pooled, pm, pr, Bx,
-                     tp)
-                if save:
-                    ctx.update(pool_x=x, pool_mean=pm, pool_rstd=pr)
+                pooled = self._fpool_fwd(W, x, Bx, tp, save, ctx)
                 if not want_frame:
                     break  # later blocks only feed the AT head (`frame`); windows never need them
         frame16 = None
@@ -217,6 +211,18 @@ class SedEngine:
             if save:
                 ctx.update(x_final=x, fmean=fm, frstd=fr, frame16=frame16)
         return pooled, frame16, ctx
+
+    def _fpool_fwd(self, W, x, Bx, tp, save, ctx):
+        """'mean_pool' frequency pooling (passt_sed.py:199-210): out_norm + mean over the 12 frequency rows -> [Bx, tp, D]."""
+        dev = x.device
+        M = Bx * (2 + 12 * tp)
+        pooled = torch.empty(Bx, tp, D, dtype=F32, device=dev)
+        pm = torch.zeros(M, device=dev) if save else None
+        pr = torch.zeros(M, device=dev) if save else None
+        call("sed_fpool_fwd", x, self.P("out_norm.weight"), self.P("out_norm.bias"), 1e-5, pooled, pm, pr, Bx, tp)
+        if save:
+            ctx.update(pool_x=x, pool_mean=pm, pool_rstd=pr)
+        return pooled
 
     # ------------------------------------------------------------------ context network
     def _decoder_fwd(self, W, x, save):

@@ -34,27 +34,56 @@ class _Holder(nn.Module):
         raise RuntimeError("parameter container: the MAT-SED forward runs in transformer4sed_amd.engine (HIP)")
 
 
+class _LoraLinear(nn.Linear):
+    """Parameter layout and train/eval weight folding of the reference's LoRA linear (src/models/lora/layers.py:88-153): frozen
+    `weight` (+ bias), trainable `lora_A` [r, in] / `lora_B` [out, r]; `eval()` folds scaling * B A into `weight`, `train()` takes it
+    out again, so a state_dict saved after `eval()` holds merged weights exactly like the reference's checkpoints."""
+
+    def __init__(self, n_in, n_out, r, lora_alpha=1, requires_grad_pretrain=False):
+        super().__init__(n_in, n_out)
+        self.r, self.scaling, self.merged = r, lora_alpha / r, False
+        self.lora_A = nn.Parameter(torch.zeros(r, n_in))
+        self.lora_B = nn.Parameter(torch.zeros(n_out, r))
+        nn.init.kaiming_uniform_(self.lora_A, a=math.sqrt(5))
+        self.weight.requires_grad = requires_grad_pretrain
+
+    def train(self, mode=True):
+        super().train(mode)
+        if mode == self.merged:   # entering train while merged, or entering eval while unmerged
+            with torch.no_grad():
+                self.weight.add_(self.lora_B @ self.lora_A, alpha=-self.scaling if mode else self.scaling)
+            self.merged = not mode
+        return self
+
+    def forward(self, *a, **k):
+        raise RuntimeError("parameter container: the forward runs in transformer4sed_amd.pmam_engine (HIP)")
+
+
+def _linear(n_in, n_out, lora):
+    return _LoraLinear(n_in, n_out, **lora) if lora else nn.Linear(n_in, n_out)
+
+
 class _Mlp(_Holder):
-    def __init__(self, dim, hidden):
+    def __init__(self, dim, hidden, lora=None):
         super().__init__()
-        self.fc1 = nn.Linear(dim, hidden)
-        self.fc2 = nn.Linear(hidden, dim)
+        self.fc1 = _linear(dim, hidden, lora)
+        self.fc2 = _linear(hidden, dim, lora)
 
 
 class _Attn(_Holder):
-    def __init__(self, dim):
+    def __init__(self, dim, lora=None):
         super().__init__()
-        self.qkv = nn.Linear(dim, 3 * dim)
-        self.proj = nn.Linear(dim, dim)
+        self.qkv = _linear(dim, 3 * dim, lora)
+        self.proj = _linear(dim, dim, lora)
 
 
 class _Block(_Holder):
-    def __init__(self, dim, mlp_ratio, eps):
+    def __init__(self, dim, mlp_ratio, eps, lora=None):
         super().__init__()
         self.norm1 = nn.LayerNorm(dim, eps=eps)
-        self.attn = _Attn(dim)
+        self.attn = _Attn(dim, lora)
         self.norm2 = nn.LayerNorm(dim, eps=eps)
-        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio), lora)
 
 
 class _PatchEmbed(_Holder):
@@ -66,7 +95,7 @@ class _PatchEmbed(_Holder):
 class _Backbone(_Holder):
     """Parameter layout of `PaSST` (src/models/passt/passt.py:392-452)."""
 
-    def __init__(self, dim, depth):
+    def __init__(self, dim, depth, lora=None):
         super().__init__()
         self.patch_embed = _PatchEmbed(dim)
         self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
@@ -74,16 +103,17 @@ class _Backbone(_Holder):
         self.new_pos_embed = nn.Parameter(torch.zeros(1, 2, dim))
         self.freq_new_pos_embed = nn.Parameter(torch.zeros(1, dim, 12, 1))
         self.time_new_pos_embed = nn.Parameter(torch.zeros(1, dim, 1, 99))
-        self.blocks = nn.Sequential(*[_Block(dim, 4, 1e-6) for _ in range(depth)])
+        self.blocks = nn.Sequential(*[_Block(dim, 4, 1e-6, lora) for _ in range(depth)])
         self.norm = nn.LayerNorm(dim, eps=1e-6)
         # dead parameters kept for checkpoint compatibility (never used in forward)
-        self.head = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, 527))
-        self.head_dist = nn.Linear(dim, 527)
+        self.head = nn.Sequential(nn.LayerNorm(dim), _linear(dim, 527, lora))
+        self.head_dist = _linear(dim, 527, lora)
         for t in (self.cls_token, self.dist_token, self.new_pos_embed, self.freq_new_pos_embed, self.time_new_pos_embed):
             nn.init.trunc_normal_(t, std=0.02)
         for mod in self.modules():
             if isinstance(mod, nn.Linear):
-                nn.init.trunc_normal_(mod.weight, std=0.02)
+                with torch.no_grad():
+                    nn.init.trunc_normal_(mod.weight, std=0.02)
                 nn.init.zeros_(mod.bias)
 
 
@@ -179,17 +209,21 @@ class PaSST_SED(SEDModel):
     def __init__(self, decode_ratio=10, interpolate_mode="linear", passt_feature_layer=10, embed_dim=768,
                  decoder_dim=768, f_pool="mean_pool", s_patchout_f=0, s_patchout_t=0, decoder="gru", decoder_layer_num=2,
                  decoder_pos_emd_len=1000, load_pretrained_model=True, class_num=10, at_adapter=False,
-                 decoder_win_len=None, mlm=False, mlm_dict=dict(), lora_config=None, encoder_depth=12):
+                 decoder_win_len=None, mlm=False, mlm_dict=dict(), lora_config=None, encoder_depth=12, _pmam=False):
         super().__init__()
         unsupported = []
-        if embed_dim != D or decoder_dim != D: unsupported.append("embed_dim/decoder_dim != 768")
+        if _pmam:   # the PaSST_CNN subclass (passt_cnn.py): 384-wide context network, attention pooling, LoRA
+            if embed_dim != D or decoder_dim % 128 or decoder_dim // H > 64: unsupported.append("embed_dim != 768 / decoder_dim")
+            if f_pool not in ("mean_pool", "attention"): unsupported.append(f"f_pool={f_pool!r}")
+        else:
+            if embed_dim != D or decoder_dim != D: unsupported.append("embed_dim/decoder_dim != 768")
+            if f_pool != "mean_pool": unsupported.append(f"f_pool={f_pool!r}")
+            if lora_config is not None: unsupported.append("LoRA")
+            if class_num > 16: unsupported.append("class_num > 16")
         if decoder != "transformerXL": unsupported.append(f"decoder={decoder!r}")
-        if f_pool != "mean_pool": unsupported.append(f"f_pool={f_pool!r}")
         if s_patchout_f or s_patchout_t: unsupported.append("patchout")
-        if lora_config is not None: unsupported.append("LoRA")
         if decoder_win_len is not None: unsupported.append("decoder_win_len")
         if interpolate_mode != "linear": unsupported.append(f"interpolate_mode={interpolate_mode!r}")
-        if class_num > 16: unsupported.append("class_num > 16")
         if unsupported:
             raise NotImplementedError("the HIP MAT-SED path covers the MAT-SED configs only; unsupported: "
                                       + ", ".join(unsupported))
@@ -197,7 +231,13 @@ class PaSST_SED(SEDModel):
                                                fmin=0.0, fmax=None, wav_norm=True, fmin_aug_range=10,
                                                fmax_aug_range=2000)
         self.depth = encoder_depth
-        self.backbone = _Backbone(embed_dim, encoder_depth)
+        lora = None
+        self.lora_r, self.lora_scaling = 0, 0.0
+        if lora_config:
+            lora = dict(r=lora_config["r"], lora_alpha=lora_config.get("lora_alpha", 1),
+                        requires_grad_pretrain=lora_config.get("requires_grad_pretrain", False))
+            self.lora_r, self.lora_scaling = lora["r"], lora["lora_alpha"] / lora["r"]
+        self.backbone = _Backbone(embed_dim, encoder_depth, lora)
         if load_pretrained_model:
             sd = torch.load("./pretrained_model/passt-s-f128-p16-s10-ap.476-swa.pt", map_location="cpu")
             self.backbone.load_state_dict(sd, strict=False)
@@ -209,6 +249,8 @@ class PaSST_SED(SEDModel):
         self.embed_dim = embed_dim
         self.decoder_dim = decoder_dim
         self.out_norm = nn.LayerNorm(embed_dim)
+        if f_pool == "attention":
+            self.f_pool_module = _AttnPool(embed_dim, 6)
         self.interpolate_module = _Hookable()
         self.slide_window_layer = nn.Identity()
         self.mlm = mlm
@@ -220,6 +262,7 @@ class PaSST_SED(SEDModel):
             nn.init.normal_(self.mask_token, std=0.02)
             self.mlm_mlp = nn.Sequential(nn.Linear(decoder_dim, decoder_dim), nn.GELU(),
                                          nn.Linear(decoder_dim, mlm_dict["out_dim"]))
+            self.mlm_out = mlm_dict["out_dim"]
             if mlm_dict["out_dim"] != D:
                 raise NotImplementedError("mlm out_dim != 768")
         self.decoder_layer_num = decoder_layer_num
@@ -239,6 +282,14 @@ class PaSST_SED(SEDModel):
     def _index_params(self):
         self._param_names = [n for n, _ in self.named_parameters()]
         self._param_by_name = dict(self.named_parameters())
+        self._buffer_by_name = dict(self.named_buffers())
+
+    @property
+    def lora_merged(self):
+        return bool(self.lora_r) and self.backbone.blocks[0].attn.qkv.merged
+
+    def _make_engine(self):
+        return SedEngine(self)
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
@@ -288,7 +339,7 @@ class PaSST_SED(SEDModel):
         src[rm] = ridx.to(torch.int32)
         # Reference quirk: the in-place masking only takes effect when the sequence is contiguous
         # (sliding windows) or B == 1; otherwise the decoder sees the unmasked sequence.
-        eff = bool(encoder_win) or B == 1
+        eff = bool(encoder_win) or B == 1 or getattr(self, "_mask_always_effective", False)
         if self.mask_effective_override is not None:
             eff = bool(self.mask_effective_override)
         self._last_mask_effective = eff
@@ -300,7 +351,7 @@ class PaSST_SED(SEDModel):
             raise RuntimeError("PaSST_SED (transformer4sed_amd) runs on MI355X only: move the model and input to 'cuda'. "
                                "There is no CPU fallback on the product path.")
         if self.engine is None:
-            self.engine = SedEngine(self)
+            self.engine = self._make_engine()
         B, _, T = input.shape
         kw = dict(encoder_win=bool(encoder_win), mix_rate=float(mix_rate), win_param=tuple(win_param),
                   temp_w=float(temp_w), pad_mask=pad_mask)
@@ -317,6 +368,8 @@ class PaSST_SED(SEDModel):
         self._last_mask_effective = False
         if self.mlm:
             kw["mlm_plan"] = self._mlm_plan(B, (99 + 1) * self.decode_ratio, input.device, encoder_win)
+        if getattr(self, "_drop_masks", None) is not None:
+            kw["drop_masks"] = self._drop_masks
         params = [self._param_by_name[n] for n in self._param_names]
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         kw["save"] = need_grad
