@@ -178,6 +178,39 @@ int sed_fpool_attn_fwd(const void* kv, const float* q, void* out16, float* out32
 int sed_pmam_merge(const float* P1, const float* P2, const float* mw, float* out, int B, int tp1, int pad1, int r1, int tp2,
                    int r2, int C, hipStream_t stream);
 
+/* --- backward of the PMAM path --- */
+int sed_ln_bwd_any(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float in_scale,
+                   float* dx, int accumulate, float* dgamma, float* dbeta, int M, int D, hipStream_t stream);
+int sed_mlm_apply_bwd_c(const float* dout, const uint8_t* action, const int* src_idx, float* dx_zeroed, float* dtoken, int rows,
+                        int C, hipStream_t stream);
+/* dP1 / dP2 / d merge_weight of sed_pmam_merge (dmw += , nullable) */
+int sed_pmam_merge_bwd(const float* g, const float* P2, const float* mw, float* dP1, float* dP2, float* dmw, int B, int tp1,
+                       int pad1, int r1, int tp2, int r2, int C, hipStream_t stream);
+/* column sums over the M rows (+= into s1, s2): mode 0: sum A, sum A^2 (BatchNorm batch statistics, base.py:72-75 in train mode);
+ * mode 1: sum A, sum A * (Bm * a + b) (BatchNorm backward sums with xhat = Y * a + b) */
+int sed_colstats(const float* A, int lda, const float* Bm, int ldb, const float* a, const float* b, float* s1, float* s2,
+                 int64_t M, int C, int mode, hipStream_t stream);
+/* backward of sed_cg_pool: dzd [M, ldz] fp32 (direct path into the BatchNorm output; columns C..ldz-1 zero), dL16 [M, ldl16]
+ * bf16 (gate logits; columns C.. zero) */
+int sed_cg_pool_bwd(const float* dout, const float* Y, int ldy, const float* a, const float* b, const float* L, int ldl,
+                    const uint8_t* mask, float drop_scale, float* dzd, int ldz, void* dL16, int ldl16, int B, int H, int W, int C,
+                    int ph, int pw, hipStream_t stream);
+/* BatchNorm backward with batch statistics: dY bf16 [M, ldo] from dz, xhat = Y * ah + bh and the sed_colstats(mode 1) sums */
+int sed_bn_bwd(const float* dz, int ldz, const float* Y, int ldy, const float* ah, const float* bh, const float* gamma,
+               const float* s1, const float* s2, void* dY, int ldo, int64_t M, int C, hipStream_t stream);
+/* transpose of sed_conv3x3_im2col: dcol bf16 [B*H*W, Kp] -> dX fp32 [B, H, W, C] */
+int sed_col2im3x3(const void* dcol, int Kp, float* dX, int B, int H, int W, int C, hipStream_t stream);
+int sed_fpool_attn_bwd(const void* kv, const float* q, const float* probs, const float* dout, void* dkv, float* dq, int B, int N,
+                       int tp, int f16, hipStream_t stream);
+/* LoRA factor gradients from the merged-weight gradient: dB += s dW A^T, dA += s B^T dW (src/models/lora/layers.py:148-151) */
+int sed_lora_grad(const float* dW, const float* A, const float* Bm, float scaling, float* dA, float* dB, int n_out, int k_in,
+                  int r, hipStream_t stream);
+/* prototype-similarity BCE of the PMAM trainer (recipes/desed/pmam/train.py:82-87, 100-106): loss[0] += mean BCE over the
+ * `sel`ected frames x C classes; dlogit [B*T, 768] (nullable) = d loss / d logit; post [B*T, C] (nullable) = posteriors.
+ * protos [C, 768] are the row-normalised GMM means (train.py:31); labels [B, C, T]. */
+int sed_proto_bce(const float* logit, const float* protos, const float* labels, const uint8_t* sel, int n_selected,
+                  float temperature, float* loss, float* dlogit, float* post, int B, int T, int C, int D, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,7 @@
 """PMAM variant on the GPU: PaSST_CNN through the C ABI vs the reference goldens (tests/golden/pmam_*.npz)
 and vs the CPU oracle (oracle/pmam_oracle.py) on the same seeded inputs."""
+import re
+
 import numpy as np
 import pytest
 import torch
@@ -108,3 +110,54 @@ def test_pmam_train_forward_vs_reference_and_dropout_vs_oracle(golden):
         o = PO.passt_cnn_forward(sd, mel_h, depth=2, feature_layer=2, train=True, mlm_draws=draws(g, "tr"), drop_masks=masks_or)
     close(other["frame_before_mask"][S], o["frame_before_mask"][S], 6e-3, 2e-3, what="dropout path")
     close(pred[S], o["mlm_pred"][S], 8e-3, 2e-3, what="dropout path logits")
+
+
+def test_pmam_loss_and_gradients_vs_reference(golden):
+    """Train-mode forward + prototype loss + backward at depth 2 vs the reference's autograd (LoRA factors, CNN branch incl. BatchNorm
+    batch statistics, attention pooling, projector merge, 384-wide context network, MLM head, AT head)."""
+    from transformer4sed_amd.pmam_trainer import mark_only_lora_as_trainable, ProtoBCE
+    g = golden("pmam_d2")
+    B = 2
+    net = build(2, 2, dropout=0.0)
+    mark_only_lora_as_trainable(net.backbone)
+    net.backbone.norm.weight.requires_grad_(True)
+    net.backbone.norm.bias.requires_grad_(True)
+    net.train()
+    net._mlm_draws = draws(g, "tr")
+    mel = torch.from_numpy(synth.det_uniform("pmam_d2/mel", (B, 128, 1000), -1.2, 1.2)).cuda()
+    gmm = torch.from_numpy(synth.det_normal("pmam/gmm_means", (30, 768))).cuda()
+    labels = torch.from_numpy(synth.synth_strong_labels(B, n_classes=30, seed=500)).cuda()
+    pred, other = net(mel, encoder_win=False)
+    protos = torch.nn.functional.normalize(gmm, dim=-1)
+    loss_strong = ProtoBCE.apply(pred, protos, labels, other["mask_id_seq"].reshape(-1), 0.1)
+    loss_weak = torch.nn.functional.binary_cross_entropy(other["at_out"], (labels.sum(-1) >= 1).float())
+    loss = loss_strong + 0.1 * loss_weak
+    close(loss_strong, g["tr_loss_strong"], 0, 2e-3, what="prototype BCE")
+    close(loss_weak, g["tr_loss_weak"], 0, 1e-3, what="weak BCE")
+    loss.backward()
+    names = [str(n) for n in g["tr_grad_names"]]
+    got = {n for n, p in net.named_parameters() if p.grad is not None}
+    assert got == set(names), (sorted(got - set(names))[:5], sorted(set(names) - got)[:5])
+    pn = dict(net.named_parameters())
+    worst = []
+    for n, norm, head in zip(names, g["tr_grad_norms"], g["tr_grad_heads"]):
+        gr = pn[n].grad
+        rel = abs(float(gr.double().norm()) - norm) / max(norm, 1e-12)
+        k = min(8, gr.numel())
+        herr = float(np.abs(gr.reshape(-1)[:k].cpu().numpy() - head[:k]).max()) / max(float(np.abs(head).max()), 1e-12)
+        worst.append((max(rel, 0.0), herr, n))
+    worst.sort(reverse=True)
+    print("worst gradient-norm deviations:", [(f"{a:.3f}", f"{b:.3f}", n) for a, b, n in worst[:6]])
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/pmam_grad_errors.log", "w") as f:
+        for a, b, n in worst:
+            f.write(f"{a:.4f} {b:.4f} {n}\n")
+    for rel, herr, n in worst:
+        if re.fullmatch(r"cnn\.cnn\.conv\d\.bias", n):
+            # BatchNorm removes the batch mean, so the true gradient of a conv bias is zero: both sides hold rounding noise only
+            wn = float(pn[n.replace(".bias", ".weight")].grad.double().norm())
+            assert float(pn[n].grad.double().norm()) < 2e-2 * wn, n
+            continue
+        assert rel < 0.02, f"|grad {n}| off by {rel:.3f}"
+    assert sorted(h for _, h, _ in worst)[len(worst) // 2] < 0.05, "median relative error of the first gradient entries"

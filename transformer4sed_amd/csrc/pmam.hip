@@ -362,3 +362,475 @@ extern "C" int sed_pmam_merge(const float* P1, const float* P2, const float* mw,
                        pad1, r1, tp2, r2, C / 4);
     return sed_check_launch();
 }
+
+// ===================================================================================================
+// Backward kernels of the PMAM path
+// ===================================================================================================
+// LayerNorm backward of any width (see layernorm_bwd_kernel): dx = in_scale * rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat)),
+// dyg = dy * gamma; dx is ADDED into dx_acc when accumulate != 0; dgamma / dbeta (+=, nullable).
+__global__ __launch_bounds__(256) void ln_bwd_any_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, float in_scale, float* __restrict__ dx_acc,
+                                                         int accumulate, float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
+                                                         int D) {
+    __shared__ float red[4][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, G = D / 128;
+    float2 g[8], pg[8], pb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        pg[k] = make_float2(0.f, 0.f); pb[k] = make_float2(0.f, 0.f);
+        if (k < G) g[k] = reinterpret_cast<const float2*>(gamma)[lane + 64 * k];
+    }
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float2 d[8], xh[8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < G) {
+                const float2 dv = reinterpret_cast<const float2*>(dy + (size_t)row * D)[lane + 64 * k];
+                const float2 xv = reinterpret_cast<const float2*>(x + (size_t)row * D)[lane + 64 * k];
+                xh[k] = make_float2((xv.x * in_scale - mu) * rs, (xv.y * in_scale - mu) * rs);
+                pg[k].x += dv.x * xh[k].x; pg[k].y += dv.y * xh[k].y;
+                pb[k].x += dv.x; pb[k].y += dv.y;
+                d[k] = make_float2(dv.x * g[k].x, dv.y * g[k].y);
+                s1 += d[k].x + d[k].y;
+                s2 += d[k].x * xh[k].x + d[k].y * xh[k].y;
+            }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < G) {
+                float2* o = reinterpret_cast<float2*>(dx_acc + (size_t)row * D) + lane + 64 * k;
+                float2 v = make_float2(in_scale * rs * (d[k].x - s1 - xh[k].x * s2), in_scale * rs * (d[k].y - s1 - xh[k].y * s2));
+                if (accumulate) { const float2 old = *o; v.x += old.x; v.y += old.y; }
+                *o = v;
+            }
+    }
+    if (dgamma == nullptr) return;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < G) reinterpret_cast<float2*>(red[wave])[lane + 64 * k] = pass == 0 ? pg[k] : pb[k];
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += 256)
+            unsafeAtomicAdd(pass == 0 ? &dgamma[c] : &dbeta[c], red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+        __syncthreads();
+    }
+}
+extern "C" int sed_ln_bwd_any(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                              float in_scale, float* dx, int accumulate, float* dgamma, float* dbeta, int M, int D,
+                              hipStream_t stream) {
+    (void)hipGetLastError();
+    if (M <= 0 || D <= 0 || (D % 128) || D > 1024 || (dgamma == nullptr) != (dbeta == nullptr)) return SED_ERR_ARG;
+    int blocks = cdiv(M, 4);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(ln_bwd_any_kernel, dim3(blocks), dim3(256), 0, stream, dy, x, mean, rstd, gamma, in_scale, dx, accumulate, dgamma,
+                       dbeta, M, D);
+    return sed_check_launch();
+}
+
+// backward of sed_mlm_apply_c: dx (zero-initialised) receives kept rows and the scatter of 'copy' rows, dtoken the 'mask' rows
+__global__ void mlm_apply_bwd_c_kernel(const float* __restrict__ dout, const unsigned char* __restrict__ action,
+                                       const int* __restrict__ src_idx, float* __restrict__ dx, float* __restrict__ dtoken, int rows,
+                                       int C) {
+    const size_t total = (size_t)rows * C;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(idx % C);
+        const int row = (int)(idx / C);
+        const unsigned char a = action[row];
+        const float g = dout[idx];
+        if (a == 0) unsafeAtomicAdd(&dx[idx], g);
+        else if (a == 1) unsafeAtomicAdd(&dtoken[d], g);
+        else unsafeAtomicAdd(&dx[(size_t)src_idx[row] * C + d], g);
+    }
+}
+extern "C" int sed_mlm_apply_bwd_c(const float* dout, const uint8_t* action, const int* src_idx, float* dx_zeroed, float* dtoken,
+                                   int rows, int C, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (rows <= 0 || C <= 0) return SED_ERR_ARG;
+    hipLaunchKernelGGL(mlm_apply_bwd_c_kernel, dim3(grid_for((size_t)rows * C)), dim3(256), 0, stream, dout, action, src_idx, dx_zeroed,
+                       dtoken, rows, C);
+    return sed_check_launch();
+}
+
+// backward of sed_pmam_merge: dP1 [B, tp1, C], dP2 [B, tp2, C] (gather over the output frames each input frame feeds) and
+// dmw[0] += sum(g * lerp_r2(P2)).  grid.y: 0 -> dP1, 1 -> dP2 (+ dmw).
+__global__ void pmam_merge_bwd_kernel(const float* __restrict__ g, const float* __restrict__ P2, const float* __restrict__ mw,
+                                      float* __restrict__ dP1, float* __restrict__ dP2, float* __restrict__ dmw, int B, int tp1,
+                                      int pad1, int r1, int tp2, int r2, int C4) {
+    const int T = (tp1 + pad1) * r1;
+    const bool second = blockIdx.y == 1;
+    const int tin = second ? tp2 : tp1, ratio = second ? r2 : r1, tlen = second ? tp2 : tp1 + pad1;
+    const size_t total = (size_t)B * tin * C4;
+    const float w = mw[0];
+    float dw_part = 0.f;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int d4 = (int)(idx % C4);
+        const int i = (int)((idx / C4) % tin);
+        const size_t b = idx / ((size_t)C4 * tin);
+        int jlo = (i - 2) * ratio, jhi = (i == tin - 1) ? T - 1 : (i + 2) * ratio;
+        jlo = jlo < 0 ? 0 : jlo;
+        jhi = jhi > T - 1 ? T - 1 : jhi;
+        float4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j = jlo; j <= jhi; ++j) {
+            int i0, i1;
+            float lam;
+            lerp_idx(j, ratio, tlen, i0, i1, lam);
+            i0 = i0 < tin ? i0 : tin - 1;
+            i1 = i1 < tin ? i1 : tin - 1;
+            float wt = 0.f;
+            if (i0 == i) wt += 1.f - lam;
+            if (i1 == i) wt += lam;
+            if (wt != 0.f) {
+                const float4 gv = reinterpret_cast<const float4*>(g)[(b * T + j) * C4 + d4];
+                acc.x += wt * gv.x; acc.y += wt * gv.y; acc.z += wt * gv.z; acc.w += wt * gv.w;
+            }
+        }
+        if (second) {
+            const float4 p = reinterpret_cast<const float4*>(P2)[idx];
+            dw_part += acc.x * p.x + acc.y * p.y + acc.z * p.z + acc.w * p.w;    // sum_j g lerp(P2) = sum_i (lerp^T g)_i P2_i
+            acc.x *= w; acc.y *= w; acc.z *= w; acc.w *= w;
+            reinterpret_cast<float4*>(dP2)[idx] = acc;
+        } else {
+            reinterpret_cast<float4*>(dP1)[idx] = acc;
+        }
+    }
+    if (second && dmw != nullptr) {
+        dw_part = wave_sum(dw_part);
+        if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(dmw, dw_part);
+    }
+}
+extern "C" int sed_pmam_merge_bwd(const float* g, const float* P2, const float* mw, float* dP1, float* dP2, float* dmw, int B,
+                                  int tp1, int pad1, int r1, int tp2, int r2, int C, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (B <= 0 || (C % 4) || (tp1 + pad1) * r1 != tp2 * r2) return SED_ERR_ARG;
+    hipLaunchKernelGGL(pmam_merge_bwd_kernel, dim3(grid_for((size_t)B * tp2 * (C / 4), 256, 2048), 2), dim3(256), 0, stream, g, P2, mw,
+                       dP1, dP2, dmw, B, tp1, pad1, r1, tp2, r2, C / 4);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Column statistics over the rows of fp32 matrices: s1[c] += sum_m A[m, c] (* B[m, c] when B != NULL ... ) -- the BatchNorm
+// batch statistics and its backward sums.  mode 0: s1 = sum A, s2 = sum A^2.  mode 1: s1 = sum A, s2 = sum A * (B * a + b)
+// (A = dZ, B = Y: the BatchNorm backward sums with xhat folded into the affine a, b).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
+                                                       const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ s1,
+                                                       float* __restrict__ s2, size_t M, int C, int mode) {
+    // block = 64 columns (one per lane of a row group) x 4 row groups; grid.x over column groups, grid.y over row slabs
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    __shared__ float r1[4][64], r2[4][64];
+    float t1 = 0.f, t2 = 0.f;
+    if (c < C) {
+        const float aa = mode ? a[c] : 0.f, bb = mode ? b[c] : 0.f;
+        for (size_t m = (size_t)blockIdx.y * 4 + rg; m < M; m += (size_t)gridDim.y * 4) {
+            const float v = A[m * lda + c];
+            t1 += v;
+            t2 += mode ? v * fmaf(Bm[m * ldb + c], aa, bb) : v * v;
+        }
+    }
+    r1[rg][threadIdx.x & 63] = t1; r2[rg][threadIdx.x & 63] = t2;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        const int l = threadIdx.x;
+        unsafeAtomicAdd(&s1[c], (r1[0][l] + r1[1][l]) + (r1[2][l] + r1[3][l]));
+        unsafeAtomicAdd(&s2[c], (r2[0][l] + r2[1][l]) + (r2[2][l] + r2[3][l]));
+    }
+}
+extern "C" int sed_colstats(const float* A, int lda, const float* Bm, int ldb, const float* a, const float* b, float* s1,
+                            float* s2, int64_t M, int C, int mode, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (M <= 0 || C <= 0 || (mode && (Bm == nullptr || a == nullptr || b == nullptr))) return SED_ERR_ARG;
+    int slabs = (int)((M + 255) / 256);
+    if (slabs > 1024) slabs = 1024;
+    hipLaunchKernelGGL(colstats_kernel, dim3(cdiv(C, 64), slabs), dim3(256), 0, stream, A, lda, Bm, ldb, a, b, s1, s2, (size_t)M, C, mode);
+    return sed_check_launch();
+}
+
+// backward of sed_cg_pool: dout (fp32 [B, Ho, Wo, C]) -> dzd [M, C] fp32 = up * sigmoid(l)  (direct path of z) and
+// dL16 [M, ldl16] bf16 = up * z * s * (1 - s)  (gate logits; columns C..ldl16-1 zero), up = dout / (ph pw) * keep.
+__global__ void cg_pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ Y, int ldy, const float* __restrict__ a,
+                                   const float* __restrict__ b, const float* __restrict__ L, int ldl,
+                                   const unsigned char* __restrict__ mask, float drop_scale, float* __restrict__ dzd, int ldz,
+                                   bf16_t* __restrict__ dL16, int ldl16, int B, int H, int W, int C, int ph, int pw) {
+    const int Ho = H / ph, Wo = W / pw, c4n = ldl16 / 4;
+    const size_t total = (size_t)B * H * W * c4n;
+    const float inv = 1.0f / (float)(ph * pw);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        const size_t m = idx / c4n;
+        uint2 p = {0, 0};
+        if (c < C) {
+            const int w = (int)(m % W), h = (int)((m / W) % H);
+            const size_t bi = m / ((size_t)W * H);
+            const size_t mo = (bi * Ho + h / ph) * Wo + w / pw;
+            const float4 g = *reinterpret_cast<const float4*>(dout + mo * C + c);
+            const float4 y = *reinterpret_cast<const float4*>(Y + m * ldy + c), l = *reinterpret_cast<const float4*>(L + m * ldl + c);
+            const float4 aa = *reinterpret_cast<const float4*>(a + c), bb = *reinterpret_cast<const float4*>(b + c);
+            float4 k = {inv, inv, inv, inv};
+            if (mask != nullptr) {
+                const uchar4 mk = *reinterpret_cast<const uchar4*>(mask + m * C + c);
+                k.x = mk.x ? inv * drop_scale : 0.f; k.y = mk.y ? inv * drop_scale : 0.f;
+                k.z = mk.z ? inv * drop_scale : 0.f; k.w = mk.w ? inv * drop_scale : 0.f;
+            }
+            const float sx = sigmoidf_(l.x), sy = sigmoidf_(l.y), sz = sigmoidf_(l.z), sw = sigmoidf_(l.w);
+            const float ux = g.x * k.x, uy = g.y * k.y, uz = g.z * k.z, uw = g.w * k.w;
+            *reinterpret_cast<float4*>(dzd + m * ldz + c) = make_float4(ux * sx, uy * sy, uz * sz, uw * sw);
+            p.x = pack2bf(ux * fmaf(y.x, aa.x, bb.x) * sx * (1.f - sx), uy * fmaf(y.y, aa.y, bb.y) * sy * (1.f - sy));
+            p.y = pack2bf(uz * fmaf(y.z, aa.z, bb.z) * sz * (1.f - sz), uw * fmaf(y.w, aa.w, bb.w) * sw * (1.f - sw));
+        }
+        else if (c < ldz) *reinterpret_cast<float4*>(dzd + m * ldz + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<uint2*>(dL16 + m * ldl16 + c) = p;
+    }
+}
+extern "C" int sed_cg_pool_bwd(const float* dout, const float* Y, int ldy, const float* a, const float* b, const float* L, int ldl,
+                               const uint8_t* mask, float drop_scale, float* dzd, int ldz, void* dL16, int ldl16, int B, int H,
+                               int W, int C, int ph, int pw, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (B <= 0 || ph <= 0 || pw <= 0 || (H % ph) || (W % pw) || (C % 4) || (ldl16 % 4) || ldl16 < C || (ldy % 4) || (ldl % 4) || (ldz % 4) || ldz < C || ldz > ldl16)
+        return SED_ERR_ARG;
+    hipLaunchKernelGGL(cg_pool_bwd_kernel, dim3(grid_for((size_t)B * H * W * (ldl16 / 4), 256, 16384)), dim3(256), 0, stream, dout, Y, ldy, a,
+                       b, L, ldl, mask, drop_scale, dzd, ldz, (bf16_t*)dL16, ldl16, B, H, W, C, ph, pw);
+    return sed_check_launch();
+}
+// BatchNorm backward (batch statistics), given the column sums s1 = sum dz, s2 = sum dz * xhat (xhat = Y * ah + bh with
+// ah = rstd, bh = -mean * rstd):  dY = gamma * rstd * (dz - s1 / M - xhat * s2 / M) -> bf16 [M, ldo] (columns C.. zero).
+__global__ void bn_bwd_kernel(const float* __restrict__ dz, int ldz, const float* __restrict__ Y, int ldy, const float* __restrict__ ah,
+                              const float* __restrict__ bh, const float* __restrict__ gamma, const float* __restrict__ s1,
+                              const float* __restrict__ s2, bf16_t* __restrict__ dY, int ldo, size_t M, int C) {
+    const int c4n = ldo / 4;
+    const size_t total = M * c4n;
+    const float invM = 1.0f / (float)M;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        const size_t m = idx / c4n;
+        uint2 p = {0, 0};
+        if (c < C) {
+            float o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float xh = fmaf(Y[m * ldy + c + u], ah[c + u], bh[c + u]);
+                o[u] = gamma[c + u] * ah[c + u] * (dz[m * ldz + c + u] - s1[c + u] * invM - xh * s2[c + u] * invM);
+            }
+            p.x = pack2bf(o[0], o[1]);
+            p.y = pack2bf(o[2], o[3]);
+        }
+        *reinterpret_cast<uint2*>(dY + m * ldo + c) = p;
+    }
+}
+extern "C" int sed_bn_bwd(const float* dz, int ldz, const float* Y, int ldy, const float* ah, const float* bh, const float* gamma,
+                          const float* s1, const float* s2, void* dY, int ldo, int64_t M, int C, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (M <= 0 || (C % 4) || (ldo % 4) || ldo < C) return SED_ERR_ARG;
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3(grid_for((size_t)M * (ldo / 4), 256, 16384)), dim3(256), 0, stream, dz, ldz, Y, ldy, ah, bh, gamma,
+                       s1, s2, (bf16_t*)dY, ldo, (size_t)M, C);
+    return sed_check_launch();
+}
+// col2im: dX[b, h, w, c] = sum over the 9 taps of dcol[(b, h - dh, w - dw), tap * C + c]  (gather form of the im2col transpose)
+__global__ void col2im3x3_kernel(const bf16_t* __restrict__ dcol, int Kp, float* __restrict__ dX, int B, int H, int W, int C) {
+    const int c4n = C / 4;
+    const size_t total = (size_t)B * H * W * c4n;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        const size_t m = idx / c4n;
+        const int w = (int)(m % W), h = (int)((m / W) % H);
+        const size_t b = m / ((size_t)W * H);
+        float4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int hh = h - (tap / 3 - 1), ww = w - (tap % 3 - 1);   // the output pixel whose tap `tap` reads (h, w)
+            if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+            const uint2 v = *reinterpret_cast<const uint2*>(dcol + ((b * H + hh) * W + ww) * Kp + tap * C + c);
+            acc.x += bf2f((bf16_t)(v.x & 0xffff)); acc.y += bf2f((bf16_t)(v.x >> 16));
+            acc.z += bf2f((bf16_t)(v.y & 0xffff)); acc.w += bf2f((bf16_t)(v.y >> 16));
+        }
+        *reinterpret_cast<float4*>(dX + m * C + c) = acc;
+    }
+}
+extern "C" int sed_col2im3x3(const void* dcol, int Kp, float* dX, int B, int H, int W, int C, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (B <= 0 || (C % 4) || Kp < 9 * C) return SED_ERR_ARG;
+    hipLaunchKernelGGL(col2im3x3_kernel, dim3(grid_for((size_t)B * H * W * (C / 4), 256, 16384)), dim3(256), 0, stream, (const bf16_t*)dcol,
+                       Kp, dX, B, H, W, C);
+    return sed_check_launch();
+}
+
+// backward of sed_fpool_attn_fwd: dout [B*tp, 768] fp32 -> dkv bf16 [B*N, 1536] (the 12 token rows of the column; cls / dist rows
+// of each clip zeroed by the t == 0 workgroups), dq [768] (+=).
+__global__ __launch_bounds__(384) void fpool_attn_bwd_kernel(const bf16_t* __restrict__ kv, const float* __restrict__ q,
+                                                             const float* __restrict__ probs, const float* __restrict__ dout,
+                                                             bf16_t* __restrict__ dkv, float* __restrict__ dq, int N, int tp, int f16) {
+    const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
+    const int b = blockIdx.x / tp, t = blockIdx.x % tp;
+    const float2 qq = reinterpret_cast<const float2*>(q + h * 128)[lane];
+    const float2 go = reinterpret_cast<const float2*>(dout + (size_t)blockIdx.x * 768 + h * 128)[lane];
+    float p[12], dp[12];
+    float dot = 0.f;
+#pragma unroll
+    for (int f = 0; f < 12; ++f) {
+        p[f] = probs[((size_t)blockIdx.x * 6 + h) * 12 + f];
+        const bf16_t* row = kv + ((size_t)b * N + 2 + (size_t)f * tp + t) * 1536 + 768 + h * 128;
+        const unsigned vv = reinterpret_cast<const unsigned*>(row)[lane];
+        dp[f] = wave_sum(go.x * ld16((bf16_t)(vv & 0xffff), f16) + go.y * ld16((bf16_t)(vv >> 16), f16));
+        dot += p[f] * dp[f];
+    }
+    float dqx = 0.f, dqy = 0.f;
+#pragma unroll
+    for (int f = 0; f < 12; ++f) {
+        const float ds = p[f] * (dp[f] - dot) * 0.08838834764831845f;
+        const size_t r = ((size_t)b * N + 2 + (size_t)f * tp + t) * 1536 + h * 128;
+        const unsigned kk = reinterpret_cast<const unsigned*>(kv + r)[lane];
+        dqx = fmaf(ds, ld16((bf16_t)(kk & 0xffff), f16), dqx);
+        dqy = fmaf(ds, ld16((bf16_t)(kk >> 16), f16), dqy);
+        reinterpret_cast<unsigned*>(dkv + r)[lane] = pack2bf(ds * qq.x, ds * qq.y);
+        reinterpret_cast<unsigned*>(dkv + r + 768)[lane] = pack2bf(p[f] * go.x, p[f] * go.y);
+    }
+    unsafeAtomicAdd(&dq[h * 128 + 2 * lane], dqx);
+    unsafeAtomicAdd(&dq[h * 128 + 2 * lane + 1], dqy);
+    if (t == 0)
+        for (int i = threadIdx.x; i < 2 * 1536 / 2; i += 384) reinterpret_cast<unsigned*>(dkv + (size_t)b * N * 1536)[i] = 0;
+}
+extern "C" int sed_fpool_attn_bwd(const void* kv, const float* q, const float* probs, const float* dout, void* dkv, float* dq,
+                                  int B, int N, int tp, int f16, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (B <= 0 || tp <= 0 || N != 2 + 12 * tp) return SED_ERR_ARG;
+    hipLaunchKernelGGL(fpool_attn_bwd_kernel, dim3(B * tp), dim3(384), 0, stream, (const bf16_t*)kv, q, probs, dout, (bf16_t*)dkv, dq, N, tp,
+                       f16);
+    return sed_check_launch();
+}
+
+// LoRA gradients from the gradient of the merged weight (dW [n_out, k_in] fp32):  dB += s dW A^T  [n_out, r],
+// dA += s B^T dW  [r, k_in]   (r <= 16).  grid.y 0: one wave per row of dW (dB); grid.y 1: one thread per column (dA), row slabs.
+__global__ __launch_bounds__(256) void lora_grad_kernel(const float* __restrict__ dW, const float* __restrict__ A,
+                                                        const float* __restrict__ Bm, float s, float* __restrict__ dA,
+                                                        float* __restrict__ dB, int n_out, int k_in, int r) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.y == 0) {
+        for (int n = blockIdx.x * 4 + wave; n < n_out; n += gridDim.x * 4) {
+            float acc[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+            for (int k = lane; k < k_in; k += 64) {
+                const float g = dW[(size_t)n * k_in + k];
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (j < r) acc[j] = fmaf(g, A[(size_t)j * k_in + k], acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j < r) {
+                    const float v = wave_sum(acc[j]);
+                    if (lane == 0) dB[(size_t)n * r + j] += s * v;
+                }
+        }
+    } else {
+        const int slabs = gridDim.x, rows_per = (n_out + slabs - 1) / slabs;
+        const int n0 = blockIdx.x * rows_per, n1 = n0 + rows_per < n_out ? n0 + rows_per : n_out;
+        for (int k = threadIdx.x; k < k_in; k += 256) {
+            float acc[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+            for (int n = n0; n < n1; ++n) {
+                const float g = dW[(size_t)n * k_in + k];
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (j < r) acc[j] = fmaf(g, Bm[(size_t)n * r + j], acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (j < r) unsafeAtomicAdd(&dA[(size_t)j * k_in + k], s * acc[j]);
+        }
+    }
+}
+extern "C" int sed_lora_grad(const float* dW, const float* A, const float* Bm, float scaling, float* dA, float* dB, int n_out,
+                             int k_in, int r, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n_out <= 0 || k_in <= 0 || r <= 0 || r > 16) return SED_ERR_ARG;
+    hipLaunchKernelGGL(lora_grad_kernel, dim3(64, 2), dim3(256), 0, stream, dW, A, Bm, scaling, dA, dB, n_out, k_in, r);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Prototype-similarity loss of the PMAM trainer (recipes/desed/pmam/train.py:82-87, 100-106): for every selected frame
+//   z_c = 2 leaky_relu_0.2(cos(logit, proto_c)) - 1,  p_c = sigmoid(z_c / T),  loss = mean over (selected frames x classes) BCE(p, y)
+// protos [C, 768] row-normalised by the caller side (F.normalize of the GMM means, train.py:31), labels [B, C, T], sel [B*T] bytes.
+// One wave per frame; dlogit (nullable) receives d loss / d logit for selected rows, zeros elsewhere.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void proto_bce_kernel(const float* __restrict__ logit, const float* __restrict__ protos,
+                                                        const float* __restrict__ labels, const unsigned char* __restrict__ sel,
+                                                        float inv_count, float inv_temp, float* __restrict__ loss,
+                                                        float* __restrict__ dlogit, float* __restrict__ post, int rows, int T, int C) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float lsum = 0.f;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        float4 x[3], gacc[3];
+        if (!sel[row]) {
+            if (dlogit != nullptr)
+                for (int i = 0; i < 3; ++i) reinterpret_cast<float4*>(dlogit + (size_t)row * 768)[lane + 64 * i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (post != nullptr && lane < C) post[(size_t)row * C + lane] = 0.f;
+            continue;
+        }
+        float nn = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            x[i] = reinterpret_cast<const float4*>(logit + (size_t)row * 768)[lane + 64 * i];
+            nn += x[i].x * x[i].x + x[i].y * x[i].y + x[i].z * x[i].z + x[i].w * x[i].w;
+            gacc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float nrm = fmaxf(sqrtf(wave_sum(nn)), 1e-12f), rn = 1.0f / nrm;
+        const int b = row / T, t = row - b * T;
+        float sum_gc_cos = 0.f;
+        for (int c = 0; c < C; ++c) {
+            float4 pr[3];
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                pr[i] = reinterpret_cast<const float4*>(protos + (size_t)c * 768)[lane + 64 * i];
+                d += x[i].x * pr[i].x + x[i].y * pr[i].y + x[i].z * pr[i].z + x[i].w * pr[i].w;
+            }
+            const float cs = wave_sum(d) * rn;
+            const float slope = cs > 0.f ? 2.f : 0.4f;
+            const float z = (cs > 0.f ? cs : 0.2f * cs) * 2.f - 1.f;
+            const float p = sigmoidf_(z * inv_temp);
+            const float y = labels[((size_t)b * C + c) * T + t];
+            if (post != nullptr && lane == 0) post[(size_t)row * C + c] = p;
+            // torch BCELoss clamps each log at -100
+            const float lp = fmaxf(__logf(p), -100.f), lq = fmaxf(__logf(1.f - p), -100.f);
+            lsum += -(y * lp + (1.f - y) * lq);
+            const float gc = (p - y) * inv_temp * slope * inv_count;      // d loss / d cos_c
+            sum_gc_cos += gc * cs;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                gacc[i].x = fmaf(gc, pr[i].x, gacc[i].x); gacc[i].y = fmaf(gc, pr[i].y, gacc[i].y);
+                gacc[i].z = fmaf(gc, pr[i].z, gacc[i].z); gacc[i].w = fmaf(gc, pr[i].w, gacc[i].w);
+            }
+        }
+        if (dlogit != nullptr) {
+            // d cos_c / d x = (proto_c - cos_c * xhat) / |x|
+            const float k = sum_gc_cos * rn;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                float4 o;
+                o.x = (gacc[i].x - k * x[i].x) * rn; o.y = (gacc[i].y - k * x[i].y) * rn;
+                o.z = (gacc[i].z - k * x[i].z) * rn; o.w = (gacc[i].w - k * x[i].w) * rn;
+                reinterpret_cast<float4*>(dlogit + (size_t)row * 768)[lane + 64 * i] = o;
+            }
+        }
+    }
+    if (lane == 0 && lsum != 0.f) unsafeAtomicAdd(loss, lsum * inv_count);
+}
+extern "C" int sed_proto_bce(const float* logit, const float* protos, const float* labels, const uint8_t* sel, int n_selected,
+                             float temperature, float* loss, float* dlogit, float* post, int B, int T, int C, int D,
+                             hipStream_t stream) {
+    (void)hipGetLastError();
+    if (B <= 0 || T <= 0 || C <= 0 || C > 64 || D != 768 || n_selected <= 0 || temperature <= 0.f) return SED_ERR_ARG;
+    const int rows = B * T;
+    int blocks = cdiv(rows, 4);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(proto_bce_kernel, dim3(blocks), dim3(256), 0, stream, logit, protos, labels, sel, 1.0f / ((float)n_selected * (float)C),
+                       1.0f / temperature, loss, dlogit, post, rows, T, C);
+    return sed_check_launch();
+}

@@ -3,6 +3,8 @@ LoRA linears, a 10-layer CNN branch, attention frequency pooling and a 384-wide 
 kwargs (`passt_sed_param`, `cnn_param`), forward signature / return values, parameter and buffer names (state_dict interchange,
 including the BatchNorm running statistics and the eval-mode LoRA weight folding) follow the reference; forward runs on the HIP
 kernels of pmam_engine.py.  The nn.Modules are parameter containers only."""
+import re
+
 import torch
 import torch.nn as nn
 
@@ -67,6 +69,22 @@ class PaSST_CNN(PaSST_SED):
 
     def _make_engine(self):
         return PmamEngine(self)
+
+    def _grad_names(self):
+        """Parameters the PMAM losses reach (the reference leaves `.grad` None on the others): the classifier is unused in MLM mode;
+        the AT head, the final norm and the encoder blocks above the feature layer only through `at_out`."""
+        at = getattr(self, "_at_grad_seen", False)
+        names = set()
+        for n, p in self._param_by_name.items():
+            if not p.requires_grad or n.startswith("backbone.head") or (self.mlm and n.startswith("classifier.")):
+                continue
+            if n.startswith(("at_adpater", "backbone.norm.")) and not at:
+                continue
+            mt = re.match(r"backbone\.blocks\.(\d+)\.", n)
+            if mt and int(mt.group(1)) >= self.passt_feature_layer and not at:
+                continue
+            names.add(n)
+        return names
 
     def get_model_name(self):
         return "PaSST_CNN"

@@ -18,7 +18,7 @@ import math
 import torch
 
 from .engine import SedEngine, _W, D, H
-from .ops import BF16, F16, F32, call, gemm_nt, pad64, transpose_bf16, split3, is_f16
+from .ops import BF16, F16, F32, call, gemm_nt, gemm_dw, pad64, transpose_bf16, split3, is_f16, to_bf16_, o_kind
 from .ops import EPI_F32, EPI_F32_RESID, EPI_BF16, EPI_GELU32
 
 HD_PAD = 64          # head width the attention kernels are built for
@@ -103,7 +103,7 @@ class PmamEngine(SedEngine):
         cin = 1
         for i, co in enumerate(m.cnn_filters):
             Np = pad128(co)
-            Kp = 64 if i == 0 else pad64(9 * cin)
+            Kp = 64 if i == 0 else pad128(9 * cin)
             wc = self.P(f"cnn.cnn.conv{i}.weight").detach()
             img = wc.new_zeros(Np, Kp)
             img[:co, :9 * cin] = wc.permute(0, 2, 3, 1).reshape(co, 9 * cin)
@@ -113,9 +113,13 @@ class PmamEngine(SedEngine):
             gimg = wg.new_zeros(Np, Cp)
             gimg[:co, :co] = wg
             self._image(f"cnn.cnn.cg{i}.linear.weight", gimg)
+            wtg = None
+            if need_t:      # backward operand of the gate GEMM: [Np (N), Np (K)] = W_gate^T, zero padded
+                wtg = torch.zeros(Np, Np, dtype=BF16, device=dev)
+                wtg[:co, :co] = wg.t().to(BF16)
             bc = wc.new_zeros(Np); bc[:co] = self.P(f"cnn.cnn.conv{i}.bias").detach()
             bg = wc.new_zeros(Np); bg[:co] = self.P(f"cnn.cnn.cg{i}.linear.bias").detach()
-            self.cnn_aux.append(dict(Np=Np, Kp=Kp, Cp=Cp, cin=cin, co=co, bias=bc, gbias=bg))
+            self.cnn_aux.append(dict(Np=Np, Kp=Kp, Cp=Cp, cin=cin, co=co, bias=bc, gbias=bg, wtg=wtg))
             cin = co
         return self.cache
 
@@ -175,7 +179,10 @@ class PmamEngine(SedEngine):
             bn = f"cnn.cnn.batchnorm{i}."
             g, bt = self.P(bn + "weight").detach(), self.P(bn + "bias").detach()
             if train:
-                var, mean = torch.var_mean(Y[:, :co], dim=0, unbiased=False)      # TODO(stage 3): fused column-statistics kernel
+                s1, s2 = torch.zeros(co, device=dev), torch.zeros(co, device=dev)
+                call("sed_colstats", Y, Np, None, 0, None, None, s1, s2, Mi, co, 0)
+                mean = s1 / Mi
+                var = (s2 / Mi - mean * mean).clamp_(min=0)
                 rm, rv = m._buffer_by_name[bn + "running_mean"], m._buffer_by_name[bn + "running_var"]
                 rm.mul_(1 - 0.99).add_(mean, alpha=0.99)
                 rv.mul_(1 - 0.99).add_(var * (Mi / (Mi - 1)), alpha=0.99)
@@ -202,7 +209,8 @@ class PmamEngine(SedEngine):
                 scale = 1.0 / (1.0 - m.conv_dropout)
             call("sed_cg_pool", Y, Np, a, b, L, Np, mask, float(scale), Xn, feat, B, Hc, Wc, co, Cpo, ph, pw, f16)
             if save:
-                layers.append(dict(col=col, Y=Y, a=a, b=b, mean=mean, rstd=rstd, Z=Z, L=L, mask=mask, scale=scale, H=Hc, W=Wc))
+                layers.append(dict(col=col, Y=Y, a=a, b=b, ah=rstd.contiguous(), bh=(-mean * rstd).contiguous(), Z=Z, L=L, mask=mask,
+                                   scale=scale, H=Hc, W=Wc))
             X = Xn
             Hc, Wc = Hc // ph, Wc // pw
         assert Wc == 1
@@ -324,3 +332,243 @@ class PmamEngine(SedEngine):
             ctx = dict(B=B, T=T, tp=tp, Tdec=Tdec, ectx=ectx, dctx=dctx, actx=actx, cctx=cctx, xd=xd, W=W, pooled=pooled, feat=feat, P1=P1,
                        P2=P2, hctx=dict(xd=xd, hpre=hpre, act=act), mlm_plan=mlm_plan if mlm_plan["effective"] else None)
         return out, ctx
+
+    # ==================================================================== backward
+    def _dw_swapped(self, dy16, x, M, n_valid, k_valid):
+        """(dy^T x)^T = x^T dy for operand widths that are not multiples of 128 on the x side: returns fp32 [k, n] (zero padded
+        operands: only [:k_valid, :n_valid] is meaningful) and the fp32 column sums of dy."""
+        dev = dy16.device
+        n, k = dy16.shape[1], x.shape[1]
+        Mpad = pad64(M)
+        gT = torch.empty(n, Mpad, dtype=BF16, device=dev)
+        csum = torch.zeros(n, device=dev)
+        transpose_bf16(dy16, M, n, gT, colsum=csum)
+        xT = torch.empty(k, Mpad, dtype=BF16, device=dev)
+        transpose_bf16(x, M, k, xT)
+        gWT = torch.zeros(k, n, device=dev)
+        gemm_dw(xT, gT, gWT)
+        return gWT, csum
+
+    def _cnn_bwd(self, W, cctx, dfeat, B, G):
+        m = self.m
+        dev = dfeat.device
+        E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
+        dout = dfeat
+        for i in range(len(self.cnn_aux) - 1, -1, -1):
+            aux, L = self.cnn_aux[i], cctx["layers"][i]
+            co, Np, Kp, Cp, cin = aux["co"], aux["Np"], aux["Kp"], aux["Cp"], aux["cin"]
+            Hc, Wc = L["H"], L["W"]
+            Mi = B * Hc * Wc
+            ph, pw = m.cnn_pooling[i]
+            dz = E(Mi, Np)
+            dL16 = E(Mi, Np, dt=BF16)
+            call("sed_cg_pool_bwd", dout, L["Y"], Np, L["a"], L["b"], L["L"], Np, L["mask"], float(L["scale"]), dz, Np, dL16, Np, B, Hc,
+                 Wc, co, ph, pw)
+            gWT, gb = self._dw_swapped(dL16, L["Z"], Mi, co, co)
+            cg = f"cnn.cnn.cg{i}.linear."
+            if G(cg + "weight") is not None:
+                G(cg + "weight").add_(gWT[:co, :co].t())
+                G(cg + "bias").add_(gb[:co])
+            gemm_nt(dL16, aux["wtg"], EPI_F32_RESID, res=dz, outF=dz)      # dz += dL W_gate
+            s1, s2 = torch.zeros(co, device=dev), torch.zeros(co, device=dev)
+            call("sed_colstats", dz, Np, L["Y"], Np, L["ah"], L["bh"], s1, s2, Mi, co, 1)
+            bn = f"cnn.cnn.batchnorm{i}."
+            if G(bn + "weight") is not None:
+                G(bn + "weight").add_(s2)
+                G(bn + "bias").add_(s1)
+            dY16 = E(Mi, Np, dt=BF16)
+            call("sed_bn_bwd", dz, Np, L["Y"], Np, L["ah"], L["bh"], self.P(bn + "weight"), s1, s2, dY16, Np, Mi, co)
+            del dz, dL16
+            cWT, cb = self._dw_swapped(dY16, L["col"], Mi, co, 9 * cin)
+            cv = f"cnn.cnn.conv{i}."
+            if G(cv + "weight") is not None:
+                G(cv + "weight").add_(cWT[:9 * cin, :co].t().reshape(co, 3, 3, cin).permute(0, 3, 1, 2))
+                G(cv + "bias").add_(cb[:co])
+            if i > 0:
+                dcol = E(Mi, Kp, dt=BF16)
+                gemm_nt(dY16, W[cv + "weight"].wt, EPI_BF16, outH=dcol)
+                dout = E(B, Hc, Wc, cin)
+                call("sed_col2im3x3", dcol, Kp, dout, B, Hc, Wc, cin)
+            cctx["layers"][i] = None
+
+    def _decoder_bwd(self, W, dctx, g, G, trainable):
+        m = self.m
+        B, T, Tpad, Rpad = dctx["B"], dctx["T"], dctx["Tpad"], dctx["Rpad"]
+        Dd, hd = m.decoder_dim, m.decoder_dim // H
+        Dp = H * HD_PAD
+        M = B * T
+        dev = g.device
+        E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
+        Z = lambda *s, dt=F32: torch.zeros(*s, dtype=dt, device=dev)
+        pos16, posT16, _ = self._pos(T, dev, Dd)
+        unrows = lambda gp, sc=1.0: gp.view(H, HD_PAD, -1)[:, :hd].reshape(H * hd, -1) * sc
+        g = g.contiguous()
+        for li in range(m.decoder_layer_num - 1, -1, -1):
+            p = f"decoder.encoder_blocks.{li}."
+            L = dctx["layers"][li]
+            Gl = G if trainable else (lambda n: None)
+            g2 = g.view(M, Dd)
+            dln = self._mlp_bwd(W, p + "mlp.fc1", p + "mlp.fc2", g2, L["h2"], L["hpre"], L["act"], M, Gl, residual=None)
+            call("sed_ln_bwd_any", dln, L["x1"], L["mean2"], L["rstd2"], self.P(p + "norm2.weight"), 1.0, g2, 1, Gl(p + "norm2.weight"),
+                 Gl(p + "norm2.bias"), M, Dd)
+            del dln
+            gwo = Z(Dd, Dp) if trainable else None
+            g16 = self._dw_accum(g2, L["o16"], M, gwo, Gl(p + "attn.out_proj.bias"))
+            if trainable:
+                G(p + "attn.out_proj.weight").add_(gwo.view(Dd, H, HD_PAD)[:, :, :hd].reshape(Dd, Dd))
+            do16 = E(M, Dp, dt=BF16)
+            gemm_nt(g16, W[p + "attn.out_proj.weight"].wt, EPI_BF16, outH=do16)
+            dqkv = E(M, 3 * Dp, dt=BF16)
+            Dtmp = E(B * H, T)
+            dOh = E(B * H, T, 64, dt=BF16)
+            dOt = E(B * H, 64, Tpad, dt=BF16)
+            dSt = Z(B * H, Tpad, Tpad, dt=BF16)
+            dP = Z(Rpad, Dp)
+            duv = Z(2, Dp)
+            call("sed_relpos_attn_bwd", L["qu"], to_bf16_(L["qut"]), L["qv"], to_bf16_(L["qvt"]), L["k"], to_bf16_(L["kt"]),
+                 to_bf16_(L["v"]), L["Ph"], to_bf16_(L["Pt"]), L["o16"], do16, L["lse"], Dtmp, dOh, dOt, dqkv, dSt, dP, duv[0], duv[1], B, H,
+                 T, Tpad, Rpad, 1 if trainable else 0, 1, o_kind(L["o16"]))
+            del dSt, dOh, dOt, do16
+            if trainable:
+                G(p + "attn.pos_bias_u").add_(duv[0].view(H, HD_PAD)[:, :hd])
+                G(p + "attn.pos_bias_v").add_(duv[1].view(H, HD_PAD)[:, :hd])
+                dPT = E(Dp, Rpad, dt=BF16)
+                transpose_bf16(dP, Rpad, Dp, dPT)
+                gwp = Z(Dp, Dd)
+                gemm_dw(dPT, posT16, gwp)
+                G(p + "attn.linear_pos.weight").add_(unrows(gwp, SQRT2))
+                gwi, gbi = Z(3 * Dp, Dd), Z(3 * Dp)
+                self._dw_accum(dqkv, L["y16"], M, gwi, gbi)
+                gw, gb = G(p + "attn.in_proj.weight"), G(p + "attn.in_proj.bias")
+                for s_, sc in ((0, 1.0), (1, SQRT2), (2, 1.0)):
+                    gw[s_ * Dd:(s_ + 1) * Dd].add_(unrows(gwi[s_ * Dp:(s_ + 1) * Dp], sc))
+                    gb[s_ * Dd:(s_ + 1) * Dd].add_(unrows(gbi[s_ * Dp:(s_ + 1) * Dp].view(-1, 1), sc).view(-1))
+            gemm_nt(dqkv, W[p + "attn.in_proj.weight"].wt, EPI_F32_RESID, res=g2, outF=g2)
+            gnew = E(B, T, Dd)
+            call("sed_ln_bwd_any", g2, L["x_in"], L["mean1"], L["rstd1"], self.P(p + "norm1.weight"), L["in_scale"], gnew.view(M, Dd), 0,
+                 Gl(p + "norm1.weight"), Gl(p + "norm1.bias"), M, Dd)
+            g = gnew
+            dctx["layers"][li] = None
+        return g
+
+    def _fpool_bwd(self, W, ectx, dpooled, B, tp, G):
+        """-> gradient of the encoder residual stream at the feature layer [B, N, D] (cls / dist rows zero)."""
+        dev = dpooled.device
+        N = ectx["N"]
+        M = B * N
+        E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
+        Z = lambda *s, dt=F32: torch.zeros(*s, dtype=dt, device=dev)
+        pre = "f_pool_module."
+        train = G(pre + "frequency_att.out_proj.weight") is not None
+        g16 = self._dw_accum(dpooled, ectx["pool_att16"], B * tp, G(pre + "frequency_att.out_proj.weight"),
+                             G(pre + "frequency_att.out_proj.bias"))
+        datt = E(B * tp, D)
+        gemm_nt(g16, W[pre + "frequency_att.out_proj.weight"].wt, EPI_F32, outF=datt)
+        dkv = E(M, 2 * D, dt=BF16)
+        dq = Z(1, D)
+        call("sed_fpool_attn_bwd", ectx["pool_kv16"], ectx["pool_q"], ectx["pool_probs"], datt, dkv, dq, B, N, tp, is_f16(ectx["pool_kv16"]))
+        win = self.P(pre + "frequency_att.in_proj_weight")
+        if train:
+            gin, gib = G(pre + "frequency_att.in_proj_weight"), G(pre + "frequency_att.in_proj_bias")
+            dtok = Z(1, D)
+            call("sed_small_linear_bwd", self.P(pre + "f_att_token").reshape(1, D), win[:D], None, dq, dtok, gin[:D], gib[:D], 1, D, D, 0)
+            G(pre + "f_att_token").view(1, D).add_(dtok)
+            self._dw_accum(dkv, ectx["pool_h16"], M, gin[D:], gib[D:])
+        dh = E(M, D)
+        gemm_nt(dkv, W[pre + "frequency_att.in_proj_weight"].wt[:, D:].contiguous(), EPI_F32, outF=dh)
+        gpool = E(B, N, D)
+        call("sed_layernorm_bwd", dh, ectx["pool_x"], ectx["pool_mean"], ectx["pool_rstd"], self.P("out_norm.weight"), 1.0,
+             gpool.view(M, D), 0, G("out_norm.weight"), G("out_norm.bias"), M, D)
+        return gpool
+
+    def backward(self, ctx, grads, garena, hook=None):
+        m = self.m
+        W = ctx["W"]
+        B, Tdec, tp = ctx["B"], ctx["Tdec"], ctx["tp"]
+        Dd = m.decoder_dim
+        dev = ctx["xd"].device
+        E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
+        Z = lambda *s, dt=F32: torch.zeros(*s, dtype=dt, device=dev)
+        G = garena
+        M = B * Tdec
+        hc = ctx["hctx"]
+        dpred = grads.get("mlm_pred")
+        if dpred is None:
+            g = Z(B, Tdec, Dd)
+        else:
+            g = self._mlp_bwd(W, "mlm_mlp.0", "mlm_mlp.2", dpred.contiguous().float().view(M, m.mlm_out), hc["xd"].view(M, Dd), hc["hpre"],
+                              hc["act"], M, G, residual=None).view(B, Tdec, Dd)
+        g = self._decoder_bwd(W, ctx["dctx"], g, G, G("decoder.encoder_blocks.0.attn.in_proj.weight") is not None)
+        if hook is not None:
+            hook("decoder")
+        if ctx["mlm_plan"] is not None:
+            plan = ctx["mlm_plan"]
+            gx = Z(B, Tdec, Dd)
+            dtok = G("mask_token")
+            call("sed_mlm_apply_bwd_c", g, plan["action"], plan["src_idx"], gx, dtok if dtok is not None else Z(Dd), M, Dd)
+            g = gx
+        dfbm = grads.get("frame_before_mask")
+        if dfbm is not None:
+            g = g + dfbm.contiguous().float()
+        # projector merge and the two projections
+        Tc = ctx["cctx"]["Tc"]
+        dP1, dP2 = E(B * tp, Dd), E(B * Tc, Dd)
+        call("sed_pmam_merge_bwd", g.contiguous(), ctx["P2"], self.P("merge_weight"), dP1, dP2, G("merge_weight"), B, tp, 1, m.decode_ratio,
+             Tc, Tdec // Tc, Dd)
+        g16 = self._dw_accum(dP2, ctx["feat"], B * Tc, G("cnn_projector.weight"), G("cnn_projector.bias"))
+        dfeat = E(B * Tc, ctx["feat"].shape[1])
+        gemm_nt(g16, W["cnn_projector.weight"].wt, EPI_F32, outF=dfeat)
+        cnn_train = G("cnn.cnn.conv0.weight") is not None
+        if cnn_train:
+            self._cnn_bwd(W, ctx["cctx"], dfeat, B, G)
+        g16 = self._dw_accum(dP1, ctx["pooled"].view(B * tp, D), B * tp, G("transformer_projector.weight"), G("transformer_projector.bias"))
+        dpooled = E(B * tp, D)
+        gemm_nt(g16, W["transformer_projector.weight"].wt, EPI_F32, outF=dpooled)
+        ectx = ctx["ectx"]
+        N = ectx["N"]
+        # which encoder blocks still need a gradient: everything above the lowest block with a trainable (LoRA) parameter
+        def block_trainable(i):
+            pre = f"backbone.blocks.{i}."
+            return any(p.requires_grad for n, p in m._param_by_name.items() if n.startswith(pre))
+        live = [i for i in range(len(ectx["layers"])) if block_trainable(i)]
+        embed_train = any(m._param_by_name[n].requires_grad for n in ("backbone.patch_embed.proj.weight", "backbone.cls_token"))
+        lowest = 0 if embed_train else (min(live) if live else None)
+        need_dx = lowest is not None
+        genc = None
+        m._at_grad_seen = m.has_at and grads.get("at_out") is not None
+        if m._at_grad_seen:
+            genc = self._at_bwd(W, ctx["actx"], ectx, grads["at_out"].contiguous().float(), G, need_dx=need_dx)
+        gpool = self._fpool_bwd(W, ectx, dpooled, B, tp, G)
+        if hook is not None:
+            hook("heads")
+        if not need_dx:
+            return
+        if genc is None:
+            genc = Z(B, N, D)
+        s = float(m.lora_scaling)
+        for li in range(len(ectx["layers"]) - 1, lowest - 1, -1):
+            if li + 1 == m.passt_feature_layer:
+                genc.add_(gpool)
+            pre = f"backbone.blocks.{li}."
+            tmp = {}
+            def Gl(name, pre=pre, tmp=tmp):
+                if name.endswith(".weight") and name[:-7] + ".lora_A" in m._param_by_name and G(name[:-7] + ".lora_A") is not None \
+                        and G(name) is None:
+                    if name not in tmp:
+                        tmp[name] = torch.zeros_like(m._param_by_name[name])
+                    return tmp[name]
+                return G(name)
+            genc = self._enc_layer_bwd(W, ectx, li, genc, Gl)
+            for name, dW in tmp.items():
+                base = name[:-7]
+                call("sed_lora_grad", dW, self.P(base + ".lora_A").detach(), self.P(base + ".lora_B").detach(), s, G(base + ".lora_A"),
+                     G(base + ".lora_B"), dW.shape[0], dW.shape[1], m.lora_r)
+            if hook is not None:
+                hook(("block", li))
+        if embed_train:
+            dconv16 = E(B * 12 * tp, D, dt=BF16)
+            call("sed_assemble_tokens_bwd", genc, dconv16, G("backbone.cls_token"), G("backbone.dist_token"), G("backbone.new_pos_embed"),
+                 G("backbone.freq_new_pos_embed"), G("backbone.time_new_pos_embed"), int(ectx["toffsets"][0]), B, tp)
+            self._dw_accum(dconv16, ectx["cols"], B * 12 * tp, G("backbone.patch_embed.proj.weight"), G("backbone.patch_embed.proj.bias"))
+        if hook is not None:
+            hook("embed")
