@@ -60,8 +60,31 @@ PRETRAIN = {
     "opt": {"param_groups": {"encoder": {"lr": 0, "weight_decay": 1.0e-4, "freeze_layer": 0, "step_lr": 4},
                              "decoder": {"lr": 1.0e-4, "weight_decay": 1.0e-4}, "head": {"lr": 1.0e-4, "weight_decay": 1.0e-4}}},
 }
-MODE_CFG = {"finetune2": FINETUNE2, "val": FINETUNE2, "finetune1": FINETUNE1, "pretrain": PRETRAIN}
-MODE_GFLOP = {"finetune2": (2463.16, 21.22), "finetune1": (649.13, 14.15), "pretrain": (383.68, 14.15), "val": (2 * 2264.3, 2 * 7.07)}
+# config/pmam/post_pretrain.yaml (PMAM post-pretraining: PaSST + LoRA r=8, CNN branch, attention pooling, 384-wide context net,
+# prototype-similarity BCE on the masked frames) -- lines 8-37 (training), 47-89 (PaSST_CNN), 105-122 (opt)
+PMAM = {
+    "training": {"batch_size": [6, 6, 12], "w_AT": 0.1, "clip_grad": True,
+                 "scheduler": {"n_epochs": 30, "n_epochs_cut": 10, "exponent": -1.5, "lr_warmup_rate": 0.1, "lr_warmup_epochs": 0},
+                 "transform": {"n_transform": 1, "choice": [1, 0, 0, 1], "filter_db_range": [-26, 26], "filter_bands": [2, 5],
+                               "filter_minimum_bandwidth": 4, "filter_type": "step"}},
+    "PaSST_CNN": {
+        "init_kwargs": {
+            "passt_sed_param": {"passt_feature_layer": 10, "class_num": 30, "f_pool": "attention", "decode_ratio": 10, "at_adapter": True,
+                                "decoder": "transformerXL", "decoder_layer_num": 3, "decoder_pos_emd_len": 1000, "decoder_dim": 384,
+                                "mlm": True, "lora_config": {"r": 8, "lora_alpha": 1, "requires_grad_pretrain": False},
+                                "mlm_dict": {"strategy": "block", "block_width": 10, "mask_rate": 0.8, "out_dim": 768,
+                                             "mask_style": [0.9, 0.05, 0.05]}},
+            "cnn_param": {"n_in_channel": 1, "activation": "cg", "conv_dropout": 0.5, "kernel_size": [3] * 10, "padding": [1] * 10,
+                          "stride": [1] * 10, "nb_filters": [16, 16, 32, 32, 64, 64, 128, 128, 256, 384],
+                          "pooling": [[2, 2], [1, 1], [2, 2], [1, 1], [1, 2], [1, 2], [1, 2], [1, 2], [1, 2], [1, 1]]}},
+        "train_kwargs": {"encoder_win": False, "temp_w": 1}},
+    "opt": {"param_groups": {"cnn": {"lr": 1.5e-4, "weight_decay": 1.0e-4},
+                             "passt": {"lr": 5.0e-6, "weight_decay": 1, "freeze_layer": 8, "step_lr": 0},
+                             "decoder": {"lr": 1.5e-4, "weight_decay": 1.0e-4}, "head": {"lr": 2.0e-4}}},
+}
+MODE_CFG = {"finetune2": FINETUNE2, "val": FINETUNE2, "finetune1": FINETUNE1, "pretrain": PRETRAIN, "pmam": PMAM}
+MODE_GFLOP = {"finetune2": (2463.16, 21.22), "finetune1": (649.13, 14.15), "pretrain": (383.68, 14.15), "val": (2 * 2264.3, 2 * 7.07),
+              "pmam": (None, None)}
 GFLOP_PER_CLIP = 2463.16      # finetune2 step, algorithmic GEMM+conv FLOPs per clip (a-term)
 GFLOP_PER_BATCH = 21.22       # batch-shared linear_pos GEMMs (b-term)
 PEAK_BF16_TFLOPS = 2500.0     # dense 16-bit MFMA peak, MI355X_MICROARCH.md
@@ -100,6 +123,34 @@ def build(per_gpu_batch, depth, device, mode="finetune2"):
     return net, ema_net, opt, trainer, sd
 
 
+def build_pmam(depth, device):
+    """PaSST_CNN + PmamTrainer as recipes/desed/pmam/main.py:89-171 wires them (synthetic weights and GMM prototypes)."""
+    from transformer4sed_amd import synth
+    from transformer4sed_amd.passt_cnn import PaSST_CNN
+    from transformer4sed_amd.pmam_trainer import PmamTrainer, get_param_lr, mark_only_lora_as_trainable
+    from transformer4sed_amd.scheduler import ExponentialDown
+    from transformer4sed_amd.trainer import FusedAdamWEMA
+    cfg = json.loads(json.dumps(PMAM))
+    kw = cfg["PaSST_CNN"]["init_kwargs"]
+    ps = dict(kw["passt_sed_param"], load_pretrained_model=False, encoder_depth=depth)
+    ps["passt_feature_layer"] = min(ps["passt_feature_layer"], depth)
+    net = PaSST_CNN(passt_sed_param=ps, cnn_param=kw["cnn_param"])
+    sd = synth.pmam_state_dict_np(depth=12)
+    own = net.state_dict()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(sd[k])) for k in own}, strict=True)
+    net = net.to(device)
+    mark_only_lora_as_trainable(net.backbone)
+    groups = get_param_lr(net, cfg["opt"]["param_groups"])
+    opt = FusedAdamWEMA(net, groups, ema_net=None, betas=(0.9, 0.999), eps=1e-8)
+    epoch_len = 1000
+    sc = cfg["training"]["scheduler"]
+    sched = ExponentialDown(opt, start_iter=sc["n_epochs_cut"] * epoch_len, total_iter=sc["n_epochs"] * epoch_len, exponent=sc["exponent"],
+                            warmup_iter=sc["lr_warmup_epochs"] * epoch_len, warmup_rate=sc["lr_warmup_rate"])
+    gmm = torch.from_numpy(synth.det_normal("pmam/gmm_means", (30, 768)))
+    net.train()
+    return net, opt, PmamTrainer(net, opt, sched, gmm, cfg)
+
+
 def cpu_baseline(depth, budget_s=240):
     """Oracle (torch CPU fp32) timed on the host cores in a child process with a hard time budget: one finetune2-style
     step at batch 1 (student fwd+bwd, 11-window teacher fwd, losses, AdamW, EMA)."""
@@ -129,12 +180,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="clips per GPU (multiple of 12 ratio 4:4:4 not required: 11/11/10)")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default 32; 24 for --mode pmam, the reference's batch)")
     ap.add_argument("--depth", type=int, default=12)
-    ap.add_argument("--mode", default="finetune2", choices=["finetune2", "finetune1", "pretrain", "val"],
+    ap.add_argument("--mode", default="finetune2", choices=["finetune2", "finetune1", "pretrain", "val", "pmam"],
                     help="finetune2 = the headline train step (default); finetune1 / pretrain = the other two training stages of "
                          "the MAT-SED recipe; val = Trainer.validation's per-batch body (student + teacher, 17 sliding windows, "
-                         "score tables + event decoding), SURVEY 8(f) rank 1")
+                         "score tables + event decoding), SURVEY 8(f) rank 1; pmam = the PMAM post-pretrain step (PaSST_CNN, SURVEY 8(f) rank 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     a = ap.parse_args()
@@ -167,17 +218,24 @@ def main():
     import random
     random.seed(1000 + rank); np.random.seed(1000 + rank); torch.manual_seed(1000 + rank)
 
-    B = a.batch
-    net, ema_net, opt, trainer, sd = build(B, a.depth, dev, a.mode)
+    B = a.batch or (24 if a.mode == "pmam" else 32)
+    if a.mode == "pmam":
+        net, opt, trainer = build_pmam(a.depth, dev)
+        ema_net = None
+    else:
+        net, ema_net, opt, trainer, sd = build(B, a.depth, dev, a.mode)
     # batch composition strong+synth | weak | unlabeled in the reference's positional order (dataset.py:178-188)
     sn = (B * 4 + 11) // 12
     wn = (B * 4 + 11) // 12
     un = B - sn - wn
     trainer.cfg = json.loads(json.dumps(MODE_CFG[a.mode]))
-    if a.mode != "pretrain":
+    if a.mode not in ("pretrain", "pmam"):
         trainer.cfg["training"]["batch_size"] = [sn, 0, wn, un]
     wav = torch.from_numpy(synth.synth_wav(B, seed=1000 + rank)).to(dev)
-    labels = torch.from_numpy(synth.synth_batch_labels(sn, wn, un, seed=1000 + rank)).to(dev)
+    if a.mode == "pmam":   # frame-wise pseudo labels over the 30 GMM prototypes (FrameWiseLabeledDataset, pmam/setting.py:47-70)
+        labels = torch.from_numpy(synth.synth_strong_labels(B, n_classes=30, seed=1000 + rank)).to(dev)
+    else:
+        labels = torch.from_numpy(synth.synth_batch_labels(sn, wn, un, seed=1000 + rank)).to(dev)
     if world > 1 or force_ddp:
         trainer.ddp = GradBucketReducer(net, opt)
         trainer.ddp.force = force_ddp
@@ -200,6 +258,9 @@ def main():
         def step():
             out = trainer.pretrain_step(wav)
             return {"loss_total": out["loss"]}
+    elif a.mode == "pmam":
+        def step():
+            return trainer.step(wav, labels.clone())
     else:
         def step():
             return trainer.finetune_step(wav, labels.clone())
@@ -233,7 +294,8 @@ def main():
         "metric": {"finetune2": "clips/sec (10 s clips) MAT-SED finetune2 train step",
                    "finetune1": "clips/sec (10 s clips) MAT-SED finetune1 train step",
                    "pretrain": "clips/sec (10 s clips) MAT-SED masked-reconstruction pretrain step",
-                   "val": "clips/sec (10 s clips) MAT-SED validation step (student + teacher, 17 windows, score tables + events)"}[a.mode],
+                   "val": "clips/sec (10 s clips) MAT-SED validation step (student + teacher, 17 windows, score tables + events)",
+                   "pmam": "clips/sec (10 s clips) PMAM post-pretrain step (PaSST_CNN: LoRA encoder + CNN branch, prototype BCE)"}[a.mode],
         "value": round(value, 3), "unit": "clips/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * dt / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -244,7 +306,7 @@ def main():
                    "model": f"PaSST_SED depth {a.depth} + 3x TransformerXL context net (100.95 M params)",
                    "global_batch": B * world, "per_gpu_batch": B, "seq_len": "1190 encoder tokens / 1000 decoder frames",
                    "parallelism": f"dp{world}", "final_loss": loss},
-        "step_mfma_frac": round(value / world * (gflop_clip + gflop_batch / B) / 1000.0 / PEAK_BF16_TFLOPS, 4),
+        "step_mfma_frac": None if gflop_clip is None else round(value / world * (gflop_clip + gflop_batch / B) / 1000.0 / PEAK_BF16_TFLOPS, 4),
     }
     if rank == 0 and timer is not None:
         summ = timer.summarize()
@@ -271,6 +333,11 @@ def main():
                                                    "net frozen, heads trained, mean-teacher losses, teacher without windows",
                                       "pretrain": "MAT-SED base pretrain step (config/mat-sed/base/pretrain.yaml): masked-frame "
                                                   "reconstruction (75 % block mask), encoder frozen, context net + MLM head trained"}[a.mode]
+    if a.mode == "pmam":
+        line["config"]["workload"] = ("PMAM post-pretrain step (config/pmam/post_pretrain.yaml): PaSST encoder with LoRA r=8 (blocks 9-12 "
+                                      "trainable), 10-layer CNN branch, attention frequency pooling, 384-wide context net, 80 % block mask, "
+                                      "prototype-similarity BCE + 0.1 AT BCE, AdamW")
+        line["config"]["model"] = f"PaSST_CNN depth {a.depth} (97.8 M params, 11.7 M trainable)"
     if a.mode == "val":
         line["config"]["workload"] = ("MAT-SED validation batch (recipes/desed/finetune/train.py:296-366): eval frontend, student and "
                                       "EMA teacher forward with val_kwargs (17 windows of 512 frames, step 31, temp 0.5), soft-masked "

@@ -161,3 +161,34 @@ def test_pmam_loss_and_gradients_vs_reference(golden):
             continue
         assert rel < 0.02, f"|grad {n}| off by {rel:.3f}"
     assert sorted(h for _, h, _ in worst)[len(worst) // 2] < 0.05, "median relative error of the first gradient entries"
+
+
+def test_pmam_trainer_steps_and_bench_line():
+    """PmamTrainer end to end (frontend, augmentation, dropout 0.5, loss, backward, fused AdamW, scheduler): the loss stays finite and
+    decreases on a fixed batch, frozen parameters do not move, LoRA factors / CNN / context net do; `bench.py --mode pmam` emits its line."""
+    import json, os, subprocess, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    torch.manual_seed(3)
+    net, opt, trainer = bench.build_pmam(2, torch.device("cuda"))
+    for g in opt.param_groups:      # a fixed batch and a larger step: the loss has to move within a few iterations
+        g["lr"] *= 20
+    B = 4
+    wav = torch.from_numpy(synth.synth_wav(B, seed=77)).cuda()
+    labels = torch.from_numpy(synth.synth_strong_labels(B, n_classes=30, seed=77)).cuda()
+    before = {n: p.detach().clone() for n, p in net.named_parameters()}
+    losses = [float(trainer.step(wav, labels.clone())["loss_total"]) for _ in range(6)]
+    print("pmam losses:", [f"{x:.4f}" for x in losses])
+    assert all(np.isfinite(losses)) and min(losses[3:]) < losses[0]
+    moved = {n for n, p in net.named_parameters() if not torch.equal(p.detach(), before[n])}
+    assert "backbone.blocks.1.attn.qkv.weight" not in moved and "backbone.patch_embed.proj.weight" not in moved
+    assert not any(n.startswith("backbone.blocks.0.") for n in moved), "freeze_layer 8 freezes the LoRA factors of blocks 1-8 too"
+    for n in ("cnn.cnn.conv0.weight", "cnn.cnn.batchnorm3.weight", "decoder.encoder_blocks.1.attn.in_proj.weight", "merge_weight",
+              "mask_token", "f_pool_module.f_att_token", "transformer_projector.weight", "mlm_mlp.2.bias", "at_adpater.1.weight"):
+        assert n in moved, n
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "pmam", "--depth", "2", "--batch", "4", "--steps", "2",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["unit"] == "clips/s" and line["value"] > 0 and "PMAM" in line["metric"] and "roofline" in line

@@ -456,8 +456,6 @@ class SedEngine:
         # ---------------- context network
         dec_trainable = G("decoder.encoder_blocks.0.attn.in_proj.weight") is not None
         g = self._decoder_bwd(W, ctx["dctx"], g, G, dec_trainable)
-        if hook is not None:
-            hook("decoder")  # classifier / mlm head / context-network gradients are final
         # g = d(decoder input) [B, Tdec, D]
         if ctx["mlm_plan"] is not None:
             plan = ctx["mlm_plan"]
@@ -465,6 +463,8 @@ class SedEngine:
             dtok = G("mask_token")
             call("sed_mlm_apply_bwd", g, plan["action"], plan["src_idx"], gx, dtok if dtok is not None else Z(D), M)
             g = gx
+        if hook is not None:
+            hook("decoder")  # classifier / mlm head / context-network / mask_token gradients are final
         dfbm = grads.get("frame_before_mask")
         if dfbm is not None:
             g = g + dfbm.contiguous().float()

@@ -499,14 +499,14 @@ class PmamEngine(SedEngine):
             g = self._mlp_bwd(W, "mlm_mlp.0", "mlm_mlp.2", dpred.contiguous().float().view(M, m.mlm_out), hc["xd"].view(M, Dd), hc["hpre"],
                               hc["act"], M, G, residual=None).view(B, Tdec, Dd)
         g = self._decoder_bwd(W, ctx["dctx"], g, G, G("decoder.encoder_blocks.0.attn.in_proj.weight") is not None)
-        if hook is not None:
-            hook("decoder")
         if ctx["mlm_plan"] is not None:
             plan = ctx["mlm_plan"]
             gx = Z(B, Tdec, Dd)
             dtok = G("mask_token")
             call("sed_mlm_apply_bwd_c", g, plan["action"], plan["src_idx"], gx, dtok if dtok is not None else Z(Dd), M, Dd)
             g = gx
+        if hook is not None:
+            hook("decoder")  # MLM head / context-network / mask_token gradients are final
         dfbm = grads.get("frame_before_mask")
         if dfbm is not None:
             g = g + dfbm.contiguous().float()
