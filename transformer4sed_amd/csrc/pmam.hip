@@ -520,32 +520,38 @@ extern "C" int sed_pmam_merge_bwd(const float* g, const float* P2, const float* 
 __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
                                                        const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ s1,
                                                        float* __restrict__ s2, size_t M, int C, int mode) {
-    // block = 64 columns (one per lane of a row group) x 4 row groups; grid.x over column groups, grid.y over row slabs
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
-    __shared__ float r1[4][64], r2[4][64];
+    // a block covers Cw = min(C, 64) columns (grid.x column groups) and 256 / Cw rows per iteration (grid.y row slabs), so that
+    // narrow matrices (16 / 32 channels) still use every lane; partials are combined through LDS before the atomics
+    const int Cw = C < 64 ? C : 64, rpi = 256 / Cw;
+    const int cl = threadIdx.x % Cw, rsub = threadIdx.x / Cw;
+    const int c = blockIdx.x * 64 + cl;
+    __shared__ float r1[256], r2[256];
     float t1 = 0.f, t2 = 0.f;
-    if (c < C) {
+    if (c < C && rsub < rpi) {
         const float aa = mode ? a[c] : 0.f, bb = mode ? b[c] : 0.f;
-        for (size_t m = (size_t)blockIdx.y * 4 + rg; m < M; m += (size_t)gridDim.y * 4) {
+        for (size_t m = (size_t)blockIdx.y * rpi + rsub; m < M; m += (size_t)gridDim.y * rpi) {
             const float v = A[m * lda + c];
             t1 += v;
             t2 += mode ? v * fmaf(Bm[m * ldb + c], aa, bb) : v * v;
         }
     }
-    r1[rg][threadIdx.x & 63] = t1; r2[rg][threadIdx.x & 63] = t2;
+    r1[threadIdx.x] = t1; r2[threadIdx.x] = t2;
     __syncthreads();
-    if (rg == 0 && c < C) {
-        const int l = threadIdx.x;
-        unsafeAtomicAdd(&s1[c], (r1[0][l] + r1[1][l]) + (r1[2][l] + r1[3][l]));
-        unsafeAtomicAdd(&s2[c], (r2[0][l] + r2[1][l]) + (r2[2][l] + r2[3][l]));
+    if (rsub == 0 && c < C) {
+        float u1 = 0.f, u2 = 0.f;
+        for (int j = 0; j < rpi; ++j) { u1 += r1[j * Cw + cl]; u2 += r2[j * Cw + cl]; }
+        unsafeAtomicAdd(&s1[c], u1);
+        unsafeAtomicAdd(&s2[c], u2);
     }
 }
 extern "C" int sed_colstats(const float* A, int lda, const float* Bm, int ldb, const float* a, const float* b, float* s1,
                             float* s2, int64_t M, int C, int mode, hipStream_t stream) {
     (void)hipGetLastError();
-    if (M <= 0 || C <= 0 || (mode && (Bm == nullptr || a == nullptr || b == nullptr))) return SED_ERR_ARG;
-    int slabs = (int)((M + 255) / 256);
-    if (slabs > 1024) slabs = 1024;
+    if (M <= 0 || C <= 0 || (C < 64 && (256 % C)) || (mode && (Bm == nullptr || a == nullptr || b == nullptr))) return SED_ERR_ARG;
+    const int rpi = 256 / (C < 64 ? C : 64);
+    int slabs = (int)((M + (size_t)rpi * 16 - 1) / ((size_t)rpi * 16));
+    if (slabs > 2048) slabs = 2048;
+    if (slabs < 1) slabs = 1;
     hipLaunchKernelGGL(colstats_kernel, dim3(cdiv(C, 64), slabs), dim3(256), 0, stream, A, lda, Bm, ldb, a, b, s1, s2, (size_t)M, C, mode);
     return sed_check_launch();
 }
@@ -749,7 +755,7 @@ extern "C" int sed_lora_grad(const float* dW, const float* A, const float* Bm, f
                              int k_in, int r, hipStream_t stream) {
     (void)hipGetLastError();
     if (n_out <= 0 || k_in <= 0 || r <= 0 || r > 16) return SED_ERR_ARG;
-    hipLaunchKernelGGL(lora_grad_kernel, dim3(64, 2), dim3(256), 0, stream, dW, A, Bm, scaling, dA, dB, n_out, k_in, r);
+    hipLaunchKernelGGL(lora_grad_kernel, dim3(256, 2), dim3(256), 0, stream, dW, A, Bm, scaling, dA, dB, n_out, k_in, r);
     return sed_check_launch();
 }
 

@@ -58,13 +58,23 @@ class PmamEngine(SedEngine):
         for i in range(m.depth):
             for sub in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"):
                 n = f"backbone.blocks.{i}.{sub}"
-                w = self.P(n + ".weight").detach()
+                wp = self.P(n + ".weight")
+                parts = [wp] + ([self.P(n + ".lora_A"), self.P(n + ".lora_B")] if m.lora_r else [])
+                # frozen operands (the blocks below `freeze_layer`, cnn_trans/setting.py:66-82) keep their images across steps
+                key = (merged, wp.data_ptr(), wp._version) if not any(p.requires_grad for p in parts) else None
+                ent = self.cache.get(n + ".weight")
+                if key is not None and ent is not None and getattr(self, "_static_keys", {}).get(n) == key:
+                    continue
+                w = wp.detach()
                 if not merged:      # train mode: the reference adds s * B (A x) to the frozen W x (lora/layers.py:148-151)
                     eff = torch.empty_like(w)
-                    call("sed_lora_merge", w, self.P(n + ".lora_A").detach(), self.P(n + ".lora_B").detach(), float(m.lora_scaling), eff,
-                         w.shape[0], w.shape[1], m.lora_r)
+                    call("sed_lora_merge", w, parts[1].detach(), parts[2].detach(), float(m.lora_scaling), eff, w.shape[0], w.shape[1],
+                         m.lora_r)
                     w = eff
                 self._image(n + ".weight", w)
+                if not hasattr(self, "_static_keys"):
+                    self._static_keys = {}
+                self._static_keys[n] = key
         for n in ("at_adpater.0.frequency_att.in_proj_weight", "f_pool_module.frequency_att.in_proj_weight",
                   "f_pool_module.frequency_att.out_proj.weight"):
             self._image(n, self.P(n).detach())
