@@ -791,8 +791,85 @@ def gen_pmam():
         save(tag, **out)
 
 
+PMAMSTEP_CFG = dict(   # config/pmam/post_pretrain.yaml values; batch 2 + 2 + 2, depth-2 encoder (feature layer 2), conv dropout 0
+    training=dict(batch_size=[2, 2, 2], w_AT=0.1, clip_grad=True,
+                  transform=dict(n_transform=1, choice=[1, 0, 0, 1], filter_db_range=[-26, 26], filter_bands=[2, 5],
+                                 filter_minimum_bandwidth=4, filter_type="step")),
+    PaSST_CNN=dict(train_kwargs=dict(encoder_win=False, temp_w=1)),
+    opt=dict(param_groups=dict(cnn=dict(lr=1.5e-4, weight_decay=1.0e-4), passt=dict(lr=5.0e-5, weight_decay=1, freeze_layer=1, step_lr=0),
+                               decoder=dict(lr=1.5e-4, weight_decay=1.0e-4), head=dict(lr=2.0e-4))))
+PMAMSTEP_SCHED = dict(n_epochs=30, n_epochs_cut=10, exponent=-1.5, warmup_epochs=1, warmup_rate=0.1, epoch_len=4)
+PMAMSTEP_SEEDS = (31, 32, 33)
+PMAMSTEP_PROBES = ["backbone.blocks.1.attn.qkv.lora_A", "backbone.blocks.1.attn.qkv.lora_B", "backbone.blocks.1.mlp.fc2.lora_B",
+                   "backbone.blocks.0.attn.qkv.lora_A", "backbone.norm.weight", "cnn.cnn.conv0.weight", "cnn.cnn.conv5.weight",
+                   "cnn.cnn.batchnorm2.weight", "cnn.cnn.cg7.linear.weight", "cnn_projector.weight", "transformer_projector.bias",
+                   "merge_weight", "mask_token", "f_pool_module.f_att_token", "f_pool_module.frequency_att.in_proj_weight",
+                   "decoder.encoder_blocks.0.attn.in_proj.weight", "decoder.encoder_blocks.1.attn.pos_bias_u",
+                   "decoder.encoder_blocks.2.attn.linear_pos.weight", "mlm_mlp.2.weight", "at_adpater.1.weight", "out_norm.weight"]
+
+
+def gen_pmamstep():
+    """Three optimisation steps of the reference's own PMAM `Trainer.train` (recipes/desed/pmam/train.py:89-143) with
+    `mark_only_lora_as_trainable` + `get_param_lr` + AdamW + ExponentialDown wired as recipes/desed/pmam/main.py:105-155 does."""
+    import logging
+    from recipes.desed.pmam.train import Trainer
+    from recipes.desed.finetune.cnn_trans.setting import get_param_lr
+    from src.models.lora import mark_only_lora_as_trainable
+    from src.utils.scheduler import ExponentialDown
+    cfg = json.loads(json.dumps(PMAMSTEP_CFG))
+    net = build_reference_pmam(2, 2, conv_dropout=0.0)
+    mark_only_lora_as_trainable(net.backbone)
+    groups = get_param_lr(net, cfg, logging.getLogger("golden"))
+    opt = torch.optim.AdamW(groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-8)
+    sc = PMAMSTEP_SCHED
+    sch = ExponentialDown(optimizer=opt, start_iter=sc["n_epochs_cut"] * sc["epoch_len"], total_iter=sc["n_epochs"] * sc["epoch_len"],
+                          exponent=sc["exponent"], warmup_iter=sc["warmup_epochs"] * sc["epoch_len"], warmup_rate=sc["warmup_rate"])
+    scalars = []
+
+    class _TB:
+        def add_scalar(self, key, value, global_step=None):
+            scalars[-1][key.split("/", 1)[1]] = float(value)
+
+    class _Log:
+        tensorboard_writer = _TB()
+        logger = logging.getLogger("golden")
+
+    gmm = torch.from_numpy(synth.det_normal(PMAM_SYNTH["gmm_name"], (30, 768)))
+    tr = Trainer(optimizer=opt, my_logger=_Log(), net=net, scheduler=sch, encoder=types.SimpleNamespace(net_pooling=1), train_loader=None,
+                 val_loader=None, test_loader=None, gmm_means=gmm, config=cfg, device="cpu")
+    random.seed(PMAMSTEP_SEEDS[0]); np.random.seed(PMAMSTEP_SEEDS[1]); torch.manual_seed(PMAMSTEP_SEEDS[2])
+    names = dict(net.named_parameters())
+    probes = [n for n in PMAMSTEP_PROBES if n in names]
+    assert len(probes) == len(PMAMSTEP_PROBES)
+    out = dict(probe_names=np.array(probes), trainable=np.array([n for n, p in net.named_parameters() if p.requires_grad]))
+    for step in range(3):
+        wav = torch.from_numpy(synth.synth_wav(6, seed=2100 + step))
+        labels = torch.from_numpy(synth.synth_strong_labels(6, n_classes=30, seed=600 + step))
+        tr.train_loader = [(wav, labels, None, None)]
+        scalars.append({})
+        rec = DrawRecorder()
+        with rec.recording():
+            tr.train(step)
+        for k, v in scalars[-1].items():
+            out[f"s{step}_{k}"] = np.float64(v)
+        out[f"s{step}_lrs"] = np.array([g["lr"] for g in opt.param_groups], dtype=np.float64)
+        out[f"s{step}_draw_kinds"] = np.array([k for k, _ in rec.log])
+        ru, ri = rec.of("rand"), rec.of("randint")
+        out[f"s{step}_mlm_noise"], out[f"s{step}_mlm_probs"], out[f"s{step}_mlm_rand_idx"] = t2n(ru[-2]), t2n(ru[-1]), t2n(ri[-1])
+        sp = dict(net.named_parameters())
+        for i, n in enumerate(probes):
+            out[f"s{step}_p{i}"] = t2n(sp[n]).reshape(-1)[:256].astype(np.float32).copy()
+        sd = net.state_dict()
+        out[f"s{step}_bn3_mean"] = t2n(sd["cnn.cnn.batchnorm3.running_mean"]).copy()     # copies: the buffers are updated in place
+        out[f"s{step}_bn3_var"] = t2n(sd["cnn.cnn.batchnorm3.running_var"]).copy()
+        print(f"   step {step}: " + " ".join(f"{k}={v:.6f}" for k, v in scalars[-1].items()), flush=True)
+    out["group_sizes"] = np.array([len(g["params"]) for g in opt.param_groups])
+    out["config_json"] = np.array(json.dumps(dict(cfg=PMAMSTEP_CFG, sched=PMAMSTEP_SCHED, seeds=PMAMSTEP_SEEDS, wav_seed0=2100, label_seed0=600)))
+    save("pmamstep", **out)
+
+
 GENS = dict(frontend=gen_frontend, augment=gen_augment, micro=gen_micro, full=gen_full, full12=gen_full12,
-            schedule=gen_schedule, postprocess=gen_postprocess, losses=gen_losses, trainstep=gen_trainstep, evalpath=gen_evalpath, datapipe=gen_datapipe, pmam=gen_pmam)
+            schedule=gen_schedule, postprocess=gen_postprocess, losses=gen_losses, trainstep=gen_trainstep, evalpath=gen_evalpath, datapipe=gen_datapipe, pmam=gen_pmam, pmamstep=gen_pmamstep)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

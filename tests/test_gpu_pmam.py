@@ -192,3 +192,61 @@ def test_pmam_trainer_steps_and_bench_line():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["unit"] == "clips/s" and line["value"] > 0 and "PMAM" in line["metric"] and "roofline" in line
+
+
+def test_pmam_trainer_three_steps_vs_reference_trainer(golden):
+    """PmamTrainer.step (HIP path, fused AdamW) for three consecutive steps against the scalars the REFERENCE PMAM Trainer.train logged
+    and the parameters / BatchNorm statistics it left behind (tests/golden/pmamstep.npz).  Same seeds => same augmentation draws (the
+    frontend, frame_shift, mixup and FilterAugment RNG order is pinned by this); the MLM masking draws, which the reference takes
+    from the torch CPU generator inside the model, are injected per step."""
+    import json, random
+    from transformer4sed_amd.passt_cnn import PaSST_CNN
+    from transformer4sed_amd.pmam_trainer import PmamTrainer, get_param_lr, mark_only_lora_as_trainable
+    from transformer4sed_amd.scheduler import ExponentialDown
+    from transformer4sed_amd.trainer import FusedAdamWEMA
+    g = golden("pmamstep")
+    meta = json.loads(str(g["config_json"]))
+    cfg, sc = meta["cfg"], meta["sched"]
+    net = build(2, 2, dropout=0.0)
+    mark_only_lora_as_trainable(net.backbone)
+    groups = get_param_lr(net, cfg["opt"]["param_groups"])
+    assert [len(x["params"]) for x in groups] == list(g["group_sizes"])
+    assert sorted(n for n, p in net.named_parameters() if p.requires_grad) == sorted(str(n) for n in g["trainable"])
+    opt = FusedAdamWEMA(net, groups, ema_net=None, betas=(0.9, 0.999), eps=1e-8)
+    sched = ExponentialDown(opt, start_iter=sc["n_epochs_cut"] * sc["epoch_len"], total_iter=sc["n_epochs"] * sc["epoch_len"],
+                            exponent=sc["exponent"], warmup_iter=sc["warmup_epochs"] * sc["epoch_len"], warmup_rate=sc["warmup_rate"])
+    gmm = torch.from_numpy(synth.det_normal("pmam/gmm_means", (30, 768)))
+    tr = PmamTrainer(net, opt, sched, gmm, cfg)
+    random.seed(meta["seeds"][0]); np.random.seed(meta["seeds"][1]); torch.manual_seed(meta["seeds"][2])
+    names = [str(n) for n in g["probe_names"]]
+    for step in range(3):
+        wav = torch.from_numpy(synth.synth_wav(6, seed=meta["wav_seed0"] + step)).cuda()
+        labels = torch.from_numpy(synth.synth_strong_labels(6, n_classes=30, seed=meta["label_seed0"] + step)).cuda()
+        net._mlm_draws = dict(noise=torch.from_numpy(g[f"s{step}_mlm_noise"]), probs=torch.from_numpy(g[f"s{step}_mlm_probs"]),
+                              rand_idx=torch.from_numpy(g[f"s{step}_mlm_rand_idx"]))
+        # the reference's model-side draws advance the torch CPU generator after the augmentation draws: keep the streams aligned
+        out = tr.step(wav, labels)
+        torch.rand(g[f"s{step}_mlm_noise"].shape); torch.rand(g[f"s{step}_mlm_probs"].shape)
+        torch.randint(0, 6000, (len(g[f"s{step}_mlm_rand_idx"]),))
+        for k in ("loss_total", "loss_strong", "loss_weak"):
+            ref, got = float(g[f"s{step}_{k}"]), float(out[k])
+            print(f"pmam trainer step {step} {k}: got {got:.6f} ref {ref:.6f}")
+            assert abs(got - ref) <= 4e-3 * max(abs(ref), 0.05), (step, k, got, ref)
+        assert abs(sched._get_scale() - float(g[f"s{step}_lr_scaler"])) < 1e-12
+        np.testing.assert_allclose([x["lr"] for x in opt.param_groups], g[f"s{step}_lrs"], rtol=1e-12)
+        sp = dict(net.named_parameters())
+        worst = 0.0
+        for i, n in enumerate(names):
+            lr = max(x["lr"] for x in opt.param_groups if n in x["names"])
+            ref = g[f"s{step}_p{i}"]
+            d = sp[n].detach().reshape(-1)[:256].cpu().numpy() - ref
+            if not sp[n].requires_grad:
+                assert float(np.abs(d).max()) == 0.0, n
+                continue
+            ms = float(np.abs(d).mean()) / lr
+            worst = max(worst, ms)
+            assert ms < 0.15, (step, n, ms)
+        print(f"pmam trainer step {step}: worst probe mean|dp|/lr {worst:.4f}")
+        sd = net.state_dict()
+        close(sd["cnn.cnn.batchnorm3.running_mean"], g[f"s{step}_bn3_mean"], 3e-3, 1e-2, what="running mean")
+        close(sd["cnn.cnn.batchnorm3.running_var"], g[f"s{step}_bn3_var"], 3e-3, 1e-2, what="running var")
