@@ -142,6 +142,12 @@ int sed_attnpool_bwd(const void* kv, const float* q, const float* probs, const f
 int sed_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t n, float lr, float wd, float beta1,
                   float beta2, float eps, int step, float ema_alpha, int do_adam, hipStream_t stream);
 
+/* every weight image of a model in one launch (what sed_transpose_to_bf16 + sed_split3_f16 produce per weight): desc is a device
+ * table of n_desc x 8 int64 {fp32 master [R, C], transposed bf16 image [C, R] or 0, straight 16-bit image [R, C] or 0,
+ * split-precision f16 image [R, 3C] = [hi | hi | lo] or 0, R (multiple of 16), C (multiple of 64), straight-image kind
+ * (0 bf16, 2 f16), index of the weight's first 64 x 64 tile}; total_tiles = sum of ceil(R / 64) * (C / 64). */
+int sed_weight_images(const int64_t* desc, int n_desc, int total_tiles, hipStream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------------------
  * PMAM variant of the model path: PaSST_CNN.forward (src/models/cnn_transformer/passt_cnn.py:31-88).
  * ------------------------------------------------------------------------------------------------------------------------- */

@@ -1775,6 +1775,87 @@ extern "C" int sed_transpose_to_bf16(const void* in, int in_kind, int R, int C, 
     return sed_check_launch();
 }
 
+// All weight images of a model in ONE launch.  Per step the engine rebuilds, from the fp32 masters, the straight 16-bit image of
+// every GEMM weight, its transposed bf16 image (backward operand) and, for the split-precision layers, the [hi | hi | lo] f16
+// image: ~130 launches of 5-20 us for student + teacher.  desc: n_desc x 8 int64 {in fp32 [R, C], outT bf16 [C, R] or 0,
+// outS [R, C] or 0, split f16 [R, 3C] or 0, R, C, outS kind (0 bf16 / 2 f16), first tile index}; one workgroup per 64 x 64 tile.
+__global__ __launch_bounds__(256) void weight_images_kernel(const long long* __restrict__ desc, int n_desc) {
+    __shared__ float tile[64][65];
+    int lo = 0, hi = n_desc - 1;
+    while (lo < hi) {   // last descriptor whose first tile <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[(size_t)mid * 8 + 7] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long long* d = desc + (size_t)lo * 8;
+    const float* in = reinterpret_cast<const float*>(d[0]);
+    bf16_t* outT = reinterpret_cast<bf16_t*>(d[1]);
+    bf16_t* outS = reinterpret_cast<bf16_t*>(d[2]);
+    bf16_t* outP = reinterpret_cast<bf16_t*>(d[3]);
+    const int R = (int)d[4], C = (int)d[5], skind = (int)d[6];
+    const int tl = blockIdx.x - (int)d[7], tx = C / 64;
+    const int c0 = (tl % tx) * 64, r0 = (tl / tx) * 64;
+    const int t = threadIdx.x;
+    {
+        const int row = t >> 2, cg = (t & 3) * 16, r = r0 + row;
+        float v[16];
+        if (r < R) {
+            const float4* src = reinterpret_cast<const float4*>(in + (size_t)r * C + c0 + cg);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float4 f = src[k]; v[4 * k] = f.x; v[4 * k + 1] = f.y; v[4 * k + 2] = f.z; v[4 * k + 3] = f.w; }
+            if (outS != nullptr) {
+                unsigned pk[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pk[e] = (unsigned)store_kind(v[2 * e], skind) | ((unsigned)store_kind(v[2 * e + 1], skind) << 16);
+                uint4* dst = reinterpret_cast<uint4*>(outS + (size_t)r * C + c0 + cg);
+                dst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                dst[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+            }
+            if (outP != nullptr) {
+                unsigned ph[8], pl[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bf16_t h0 = f2h(v[2 * e]), h1 = f2h(v[2 * e + 1]);
+                    ph[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+                    pl[e] = (unsigned)f2h(v[2 * e] - h2f(h0)) | ((unsigned)f2h(v[2 * e + 1] - h2f(h1)) << 16);
+                }
+                bf16_t* prow = outP + (size_t)r * 3 * C + c0 + cg;
+                uint4* d0 = reinterpret_cast<uint4*>(prow);
+                uint4* d1 = reinterpret_cast<uint4*>(prow + C);
+                uint4* d2 = reinterpret_cast<uint4*>(prow + 2 * C);
+                d0[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]); d0[1] = make_uint4(ph[4], ph[5], ph[6], ph[7]);
+                d1[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]); d1[1] = make_uint4(ph[4], ph[5], ph[6], ph[7]);
+                d2[0] = make_uint4(pl[0], pl[1], pl[2], pl[3]); d2[1] = make_uint4(pl[4], pl[5], pl[6], pl[7]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = 0.f;
+        }
+        if (outT != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tile[row][cg + e] = v[e];
+        }
+    }
+    if (outT == nullptr) return;    // uniform per workgroup
+    __syncthreads();
+    {
+        const int oc = t >> 2, seg = (t & 3) * 16;
+        if (r0 + seg < R) {
+            unsigned pk[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pk[e] = pack2bf(tile[seg + 2 * e][oc], tile[seg + 2 * e + 1][oc]);
+            uint4* dst = reinterpret_cast<uint4*>(outT + (size_t)(c0 + oc) * R + r0 + seg);
+            dst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            dst[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+        }
+    }
+}
+extern "C" int sed_weight_images(const int64_t* desc, int n_desc, int total_tiles, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n_desc <= 0 || total_tiles <= 0) return SED_ERR_ARG;
+    hipLaunchKernelGGL(weight_images_kernel, dim3(total_tiles), dim3(256), 0, stream, (const long long*)desc, n_desc);
+    return sed_check_launch();
+}
+
 // Split-precision operand images (f16 hi + f16 lo carries ~22 significand bits): a GEMM over the concatenated reduction
 // dimension [A_hi | A_lo | A_hi] . [W_hi | W_hi | W_lo]^T accumulates A_hi W_hi + A_lo W_hi + A_hi W_lo in fp32 inside the
 // ordinary MFMA kernel.  Used for the context-network GEMMs, whose operand rounding dominates the posterior error.

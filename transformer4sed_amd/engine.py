@@ -75,7 +75,7 @@ class SedEngine:
         return self.m._param_by_name[name]
 
     def _weights(self, need_t):
-        """(Re)build bf16 copies of every GEMM weight from the fp32 masters (one transpose kernel each)."""
+        """(Re)build the 16-bit operand images of every GEMM weight from the fp32 masters: one `sed_weight_images` launch."""
         m = self.m
         names = ["backbone.patch_embed.proj.weight"]
         for i in range(m.depth):
@@ -89,19 +89,45 @@ class SedEngine:
             names += ["mlm_mlp.0.weight", "mlm_mlp.2.weight"]
         if m.has_at:
             names += ["at_adpater.0.frequency_att.in_proj_weight"]
-        for n in names:
-            w32 = self.P(n).detach()
-            n_out = w32.shape[0]
-            w2 = w32.reshape(n_out, -1)
-            k_in = w2.shape[1]
-            ent = self.cache.get(n)
-            if ent is None or ent.w.device != w32.device:
-                ent = _W(torch.empty(n_out, k_in, dtype=self.act, device=w32.device),
-                         torch.empty(k_in, n_out, dtype=BF16, device=w32.device))
-                self.cache[n] = ent
-            transpose_bf16(w2, n_out, k_in, ent.wt, out_s=ent.w)
-            if self.split and (n.startswith("decoder.") or n.startswith("mlm_mlp")):
-                ent.ws = split3(w2.contiguous(), n_out, k_in, weight=True)
+        if os.environ.get("SED_WIMG_BATCH", "1") == "0":   # one transpose (+ split) launch per weight: A/B switch
+            for n in names:
+                w32 = self.P(n).detach()
+                n_out = w32.shape[0]
+                w2 = w32.reshape(n_out, -1)
+                k_in = w2.shape[1]
+                ent = self.cache.get(n)
+                if ent is None or ent.w.device != w32.device:
+                    ent = _W(torch.empty(n_out, k_in, dtype=self.act, device=w32.device),
+                             torch.empty(k_in, n_out, dtype=BF16, device=w32.device))
+                    self.cache[n] = ent
+                transpose_bf16(w2, n_out, k_in, ent.wt, out_s=ent.w)
+                if self.split and (n.startswith("decoder.") or n.startswith("mlm_mlp")):
+                    ent.ws = split3(w2.contiguous(), n_out, k_in, weight=True)
+            return self.cache
+        ptrs = tuple(self.P(n).data_ptr() for n in names) + (bool(need_t), self.split)
+        if getattr(self, "_wimg_key", None) != ptrs:
+            # descriptor table of sed_weight_images: rebuilt only when a master moved (optimizer arenas, .to(device))
+            rows, tiles = [], 0
+            for n in names:
+                w32 = self.P(n).detach()
+                n_out = w32.shape[0]
+                k_in = w32.numel() // n_out
+                if not w32.is_contiguous() or n_out % 16 or k_in % 64:
+                    raise RuntimeError(f"weight {n}: unsupported shape / layout for the operand images")
+                ent = self.cache.get(n)
+                if ent is None or ent.w.device != w32.device:
+                    ent = _W(torch.empty(n_out, k_in, dtype=self.act, device=w32.device),
+                             torch.empty(k_in, n_out, dtype=BF16, device=w32.device))
+                    self.cache[n] = ent
+                want_split = self.split and (n.startswith("decoder.") or n.startswith("mlm_mlp"))
+                if want_split and (ent.ws is None or ent.ws.device != w32.device):
+                    ent.ws = torch.empty(n_out, 3 * k_in, dtype=F16, device=w32.device)
+                rows.append([w32.data_ptr(), ent.wt.data_ptr() if need_t else 0, ent.w.data_ptr(), ent.ws.data_ptr() if want_split else 0,
+                             n_out, k_in, 2 if self.act == F16 else 0, tiles])
+                tiles += ((n_out + 63) // 64) * (k_in // 64)
+            self._wimg_desc = h2d(rows, torch.int64, self.P(names[0]).device)
+            self._wimg_n, self._wimg_tiles, self._wimg_key = len(rows), tiles, ptrs
+        call("sed_weight_images", self._wimg_desc, self._wimg_n, self._wimg_tiles)
         return self.cache
 
     def _pos(self, T, dev, Dm=D):
