@@ -48,6 +48,16 @@ class KernelTimer:
     def __init__(self, names):
         self.names = set(names)
         self.records = []  # (name, start_event, end_event, flops, algorithmic bytes)
+        self.pool = []     # recycled events: creating ~600 HIP events inside a timed step costs tens of ms of host time
+
+    def event(self):
+        return self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
+
+    def recycle(self):
+        """Drop the records, keep their events for the next instrumented step."""
+        for _, e0, e1, _, _ in self.records:
+            self.pool += [e0, e1]
+        self.records = []
 
     def summarize(self):
         out = {}
@@ -92,7 +102,7 @@ def _bytes_of(name, args):
 def call(name, *args):
     conv = [(_ptr(a) if (a is None or isinstance(a, torch.Tensor)) else a) for a in args]
     if TIMER is not None and name in TIMER.names:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1 = TIMER.event(), TIMER.event()
         e0.record()
         lib().call(name, *conv, torch.cuda.current_stream().cuda_stream)
         e1.record()

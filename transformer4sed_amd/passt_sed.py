@@ -162,10 +162,14 @@ class _Hookable(nn.Module):
 
 
 class _SedFunction(torch.autograd.Function):
-    """The whole MAT-SED network as ONE autograd node: forward = engine.forward, backward = engine.backward."""
+    """The whole MAT-SED network as ONE autograd node: forward = engine.forward, backward = engine.backward.
+
+    The parameters are NOT inputs of the node (torch walks every argument of `Function.apply` several times per call: with the
+    ~220 parameter tensors that was 20 ms of host time per step); a one-element `anchor` leaf keeps the node in the graph and the
+    backward assigns / accumulates `p.grad` itself, as views of the flat gradient arena."""
 
     @staticmethod
-    def forward(ctx, module, kw, mel, *params):
+    def forward(ctx, module, kw, mel, anchor):
         save = kw.pop("save")
         ctx.set_materialize_grads(False)
         out, ectx = module.engine.forward(mel, save=save, **kw)
@@ -202,7 +206,11 @@ class _SedFunction(torch.autograd.Function):
         module.engine.backward(ctx.ectx, grads, lambda n: views.get(n), hook=getattr(module, "_grad_ready_hook", None))
         ctx.ectx = None
         touched = module._grad_names()
-        return (None, None, None) + tuple(views.get(n) if n in touched else None for n in names)
+        for n, p in live:
+            if n in touched:
+                v = views[n]
+                p.grad = v if p.grad is None else p.grad + v     # autograd's accumulate semantics
+        return None, None, None, None
 
 
 class PaSST_SED(SEDModel):
@@ -370,10 +378,12 @@ class PaSST_SED(SEDModel):
             kw["mlm_plan"] = self._mlm_plan(B, (99 + 1) * self.decode_ratio, input.device, encoder_win)
         if getattr(self, "_drop_masks", None) is not None:
             kw["drop_masks"] = self._drop_masks
-        params = [self._param_by_name[n] for n in self._param_names]
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._param_by_name.values())
         kw["save"] = need_grad
-        outs = _SedFunction.apply(self, kw, input, *params)
+        anchor = getattr(self, "_anchor", None)
+        if anchor is None or anchor.device != input.device:
+            anchor = self._anchor = torch.zeros(1, device=input.device, requires_grad=True)
+        outs = _SedFunction.apply(self, kw, input, anchor if need_grad else anchor.detach())
         o = dict(zip(self._out_keys, outs))
         other = {"frame_before_mask": o["frame_before_mask"]}
         if self.mlm:
