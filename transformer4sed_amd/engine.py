@@ -545,14 +545,20 @@ class SedEngine:
         dev = dy.device
         n_out, k_in = dy.shape[1], x.shape[1]
         E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
-        tn = self.dw_tn and dw_tn_ok(M, n_out, k_in) and x.dtype in (F16, BF16)
+        Mt = M // 64 * 64      # the TN kernel walks the tokens in steps of 64: a ragged tail goes through the NT kernel
+        tn = self.dw_tn and Mt >= 1024 and dw_tn_ok(Mt, n_out, k_in) and x.dtype in (F16, BF16)
         if tn:
             g16 = E(M, n_out, dt=BF16) if dy.dtype == F32 else None
             if g16 is not None or bias is not None:
                 transpose_bf16(dy, M, n_out, None, out_s=g16, colsum=bias)   # cast and/or column sums only, one pass
             dy16 = g16 if g16 is not None else dy
             if gW is not None:
-                gemm_dw_tn(dy16, x, gW, tokens=M)
+                gemm_dw_tn(dy16, x, gW, tokens=Mt)
+                if Mt < M:
+                    gT, xT = E(n_out, 64, dt=BF16), E(k_in, 64, dt=BF16)
+                    transpose_bf16(dy16[Mt:], M - Mt, n_out, gT)
+                    transpose_bf16(x[Mt:], M - Mt, k_in, xT)
+                    gemm_dw(gT, xT, gW)
             return dy16
         Mpad = pad64(M)
         g16 = E(M, n_out, dt=BF16) if dy.dtype == F32 else None

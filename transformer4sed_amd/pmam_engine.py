@@ -345,16 +345,19 @@ class PmamEngine(SedEngine):
 
     # ==================================================================== backward
     def _dw_swapped(self, dy16, x, M, n_valid, k_valid):
-        """(dy^T x)^T = x^T dy for operand widths that are not multiples of 128 on the x side: returns fp32 [k, n] (zero padded
-        operands: only [:k_valid, :n_valid] is meaningful) and the fp32 column sums of dy."""
+        """(dy^T x)^T = x^T dy for operand widths that are not multiples of 128 on the x side: returns fp32 [k, n] and the fp32 column
+        sums of dy; only [:k_valid, :n_valid] / [:n_valid] are meaningful.  The operands are zero padded to GEMM-friendly widths
+        (16 filters sit in 128 columns): only the 64-column groups that hold valid data are transposed, the other rows of the
+        transposed images stay uninitialised and only feed output elements nobody reads."""
         dev = dy16.device
         n, k = dy16.shape[1], x.shape[1]
+        n_eff, k_eff = min(n, pad64(n_valid)), min(k, pad64(k_valid))
         Mpad = pad64(M)
         gT = torch.empty(n, Mpad, dtype=BF16, device=dev)
         csum = torch.zeros(n, device=dev)
-        transpose_bf16(dy16, M, n, gT, colsum=csum)
+        transpose_bf16(dy16, M, n_eff, gT, colsum=csum, ld=n)
         xT = torch.empty(k, Mpad, dtype=BF16, device=dev)
-        transpose_bf16(x, M, k, xT)
+        transpose_bf16(x, M, k_eff, xT, ld=k)
         gWT = torch.zeros(k, n, device=dev)
         gemm_dw(xT, gT, gWT)
         return gWT, csum
