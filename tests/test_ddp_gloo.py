@@ -22,7 +22,10 @@ class _FakeNet:
 
 NAMES = ["backbone.blocks.0.attn.qkv.weight", "backbone.blocks.0.mlp.fc1.weight", "backbone.blocks.1.attn.qkv.weight",
          "backbone.norm.weight", "backbone.patch_embed.proj.weight", "decoder.encoder_blocks.0.attn.in_proj.weight",
-         "classifier.weight", "out_norm.weight", "at_adpater.1.weight"]
+         "classifier.weight", "out_norm.weight", "at_adpater.1.weight",
+         # PMAM variant (PaSST_CNN): LoRA factors ride with their block, everything else with the last stage
+         "backbone.blocks.1.attn.qkv.lora_A", "cnn.cnn.conv0.weight", "cnn.cnn.batchnorm3.weight", "f_pool_module.f_att_token",
+         "transformer_projector.weight", "merge_weight", "mask_token", "mlm_mlp.2.weight"]
 
 
 def _layout():
