@@ -686,10 +686,10 @@ def gen_datapipe():
 PMAM_SYNTH = dict(gmm_name="pmam/gmm_means", label_seed=500)
 
 
-def build_reference_pmam(depth, feature_layer, conv_dropout, mlm=True, lora=True):
+def build_reference_pmam(depth, feature_layer, conv_dropout, mlm=True, lora=True, class_num=30):
     """PaSST_CNN of the reference with config/pmam/post_pretrain.yaml:47-80 and the synthetic weights of synth.pmam_state_dict_np."""
     from src.models.cnn_transformer.passt_cnn import PaSST_CNN
-    passt = dict(passt_feature_layer=feature_layer, class_num=30, f_pool="attention", decode_ratio=10, at_adapter=True,
+    passt = dict(passt_feature_layer=feature_layer, class_num=class_num, f_pool="attention", decode_ratio=10, at_adapter=True,
                  decoder="transformerXL", decoder_layer_num=3, decoder_pos_emd_len=1000, decoder_dim=384, mlm=mlm)
     if lora:
         passt["lora_config"] = dict(r=8, lora_alpha=1, requires_grad_pretrain=False)
@@ -703,7 +703,7 @@ def build_reference_pmam(depth, feature_layer, conv_dropout, mlm=True, lora=True
         net = PaSST_CNN(passt_sed_param=passt, cnn_param=cnn)
     finally:
         torch.load = o_load
-    sd_np = synth.pmam_state_dict_np(depth=12, mlm=mlm, lora_r=8 if lora else 0)
+    sd_np = synth.pmam_state_dict_np(depth=12, mlm=mlm, lora_r=8 if lora else 0, class_num=class_num)
     ref_shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
     assert ref_shapes == {k: tuple(v.shape) for k, v in sd_np.items()}, "PaSST_CNN state_dict contract drifted"
     net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=True)
@@ -868,8 +868,49 @@ def gen_pmamstep():
     save("pmamstep", **out)
 
 
+def gen_pmamft():
+    """PMAM finetune stage (config/pmam/finetune1.yaml / finetune2.yaml: PaSST_CNN with mlm False, no LoRA, 10 classes): eval forward
+    with the validation temperature and a pad mask, sliding windows (step 49 / 31, eval offsets), train-mode gradients (dropout 0)."""
+    tag, depth, fl, B = "pmam_ft_d2", 2, 2, 2
+    out = {}
+    mel = torch.from_numpy(synth.det_uniform(f"{tag}/mel", (B, 128, 1000), -1.2, 1.2))
+    net = build_reference_pmam(depth, fl, conv_dropout=0.5, mlm=False, lora=False, class_num=10)
+    net.eval()
+    pm = torch.zeros(B, 1000, dtype=torch.bool)
+    pm[0, 900:] = True
+    with torch.no_grad():
+        s1, w1, o1 = net(mel, encoder_win=False, temp_w=1)
+        s2, w2, _ = net(mel, encoder_win=False, temp_w=0.5, pad_mask=pm)
+    out["strong"], out["weak"], out["at_out"] = t2n(s1), t2n(w1), t2n(o1["at_out"])
+    out["strong_t05_pad"], out["weak_t05_pad"] = t2n(s2), t2n(w2)
+    for step in (49, 31):
+        with torch.no_grad():
+            s3, w3, o3 = net(mel, encoder_win=True, mix_rate=0.5, win_param=[512, step], temp_w=0.5)
+        out[f"strong_win{step}"], out[f"weak_win{step}"] = t2n(s3), t2n(w3)
+        out[f"fbm_win{step}_s"] = t2n(o3["frame_before_mask"][:, ::25, ::16])
+    net = build_reference_pmam(depth, fl, conv_dropout=0.0, mlm=False, lora=False, class_num=10)
+    net.train()
+    strong, weak, other = net(mel, encoder_win=False, temp_w=1)
+    wgt_s = torch.from_numpy(synth.det_uniform(f"{tag}/gs", tuple(strong.shape)))
+    wgt_w = torch.from_numpy(synth.det_uniform(f"{tag}/gw", tuple(weak.shape)))
+    wgt_a = torch.from_numpy(synth.det_uniform(f"{tag}/ga", tuple(other["at_out"].shape)))
+    loss = (strong * wgt_s).sum() + (weak * wgt_w).sum() + (other["at_out"] * wgt_a).sum()
+    loss.backward()
+    out["tr_strong"], out["tr_weak"], out["tr_loss"] = t2n(strong), t2n(weak), t2n(loss)
+    names, norms, heads = [], [], []
+    for k, p in net.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(k)
+        norms.append(float(p.grad.double().norm()))
+        g = p.grad.reshape(-1)
+        heads.append(t2n(torch.cat([g, g.new_zeros(8)])[:8]))
+    out["tr_grad_names"], out["tr_grad_norms"], out["tr_grad_heads"] = np.asarray(names), np.asarray(norms), np.stack(heads)
+    save(tag, **out)
+
+
 GENS = dict(frontend=gen_frontend, augment=gen_augment, micro=gen_micro, full=gen_full, full12=gen_full12,
-            schedule=gen_schedule, postprocess=gen_postprocess, losses=gen_losses, trainstep=gen_trainstep, evalpath=gen_evalpath, datapipe=gen_datapipe, pmam=gen_pmam, pmamstep=gen_pmamstep)
+            schedule=gen_schedule, postprocess=gen_postprocess, losses=gen_losses, trainstep=gen_trainstep, evalpath=gen_evalpath, datapipe=gen_datapipe, pmam=gen_pmam, pmamstep=gen_pmamstep, pmamft=gen_pmamft)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -238,9 +238,13 @@ def window_starts(n_in=1000, win=512, step=49):
     return list(range(0, n_in + step - win, step))  # encoder_slide_window.py:27
 
 
-def slide_window_features(sd, mel, win_param=(512, 49), depth=12, feature_layer=10, toffsets=None, ratio=10):
+def slide_window_features(sd, mel, win_param=(512, 49), depth=12, feature_layer=10, toffsets=None, ratio=10, pool_fn=None,
+                          encoder_fn=None):
     """encoder_slide_window.py:16-36 + passt_win.py:23-41: overlap-average of per-window encodings;
-    frames no window covers come out 0 (NaN -> 0).  `toffsets[w]` = the train-mode random time-pos offsets."""
+    frames no window covers come out 0 (NaN -> 0).  `toffsets[w]` = the train-mode random time-pos offsets.
+    `pool_fn` / `encoder_fn`: frequency pooling and encoder of the model at hand (defaults: MAT-SED's mean pooling / plain PaSST)."""
+    pool_fn = pool_fn or f_pool_mean
+    encoder_fn = encoder_fn or passt_encoder
     B, _, T = mel.shape
     win, step = win_param
     emb_len = T  # decode_ratio * 100 frames == input frames here
@@ -250,9 +254,8 @@ def slide_window_features(sd, mel, win_param=(512, 49), depth=12, feature_layer=
     acc = torch.zeros(B, emb_len, D)
     for wi, left in enumerate(window_starts(T, win, step)):
         right = min(left + win, T)
-        enc = passt_encoder(sd, mel[:, :, left:right], depth=depth,
-                            toffset=0 if toffsets is None else int(toffsets[wi]))
-        fr = f_pool_mean(sd, enc["layers"][feature_layer - 1], enc["f_dim"], enc["t_dim"])
+        enc = encoder_fn(sd, mel[:, :, left:right], depth=depth, toffset=0 if toffsets is None else int(toffsets[wi]))
+        fr = pool_fn(sd, enc["layers"][feature_layer - 1], enc["f_dim"], enc["t_dim"])
         fr = interp_linear(fr, ratio)
         o_left = round(left * scale)
         o_right = int(min(emb_len, o_left + fr.shape[1]))

@@ -116,14 +116,20 @@ def prototype_posteriors(logit, gmm_means, temperature=0.1):
 
 
 def passt_cnn_forward(sd, mel, depth=12, feature_layer=10, dec_layers=3, lora_scaling=1.0 / 8, train=True, mlm=True, mlm_draws=None,
-                      drop_masks=None, temp_w=1.0, pad_mask=None, stats_out=None, mask_style=(0.9, 0.05, 0.05), mask_rate=0.8):
-    """PaSST_CNN.forward without sliding windows (every PMAM pretrain config sets encoder_win False, post_pretrain.yaml:82-89)."""
+                      drop_masks=None, temp_w=1.0, pad_mask=None, stats_out=None, mask_style=(0.9, 0.05, 0.05), mask_rate=0.8,
+                      encoder_win=False, win_param=(512, 49), mix_rate=0.5, toffsets=None):
+    """PaSST_CNN.forward (passt_cnn.py:31-88).  Sliding windows (finetune2 / validation of the PMAM finetune stage, no LoRA there) mix
+    the local features in at encoder width BEFORE the projector (passt_cnn.py:41-46)."""
     out = {}
     enc = encoder_lora(sd, mel, depth, lora_scaling, merged=not train)
     pooled = f_pool_attention(sd, enc["layers"][feature_layer - 1], enc["f_dim"], enc["t_dim"])
     out["pooled"] = pooled
     x = O.interp_linear(torch.cat([pooled, pooled[:, -1:, :]], dim=1), 10)
     out["global_frames"] = x
+    if encoder_win:
+        assert "backbone.blocks.0.attn.qkv.lora_A" not in sd, "windows + LoRA: no PMAM config combines them"
+        x_local = O.slide_window_features(sd, mel, win_param, depth, feature_layer, toffsets, pool_fn=f_pool_attention)
+        x = mix_rate * x_local + (1 - mix_rate) * x
     cnn = cnn_branch(sd, mel, train, drop_masks, stats_out=stats_out)
     assert cnn.shape[-1] == 1
     out["cnn_feat"] = cnn.squeeze(-1)                                                  # [B, C, T/4]

@@ -250,3 +250,97 @@ def test_pmam_trainer_three_steps_vs_reference_trainer(golden):
         sd = net.state_dict()
         close(sd["cnn.cnn.batchnorm3.running_mean"], g[f"s{step}_bn3_mean"], 3e-3, 1e-2, what="running mean")
         close(sd["cnn.cnn.batchnorm3.running_var"], g[f"s{step}_bn3_var"], 3e-3, 1e-2, what="running var")
+
+
+def build_ft(dropout=0.5):
+    """PaSST_CNN of the PMAM finetune stage (config/pmam/finetune1.yaml:62-81): mlm False, no LoRA, 10 classes."""
+    from transformer4sed_amd.passt_cnn import PaSST_CNN
+    ps = {k: v for k, v in PASST.items() if k not in ("lora_config", "mlm_dict")}
+    ps.update(mlm=False, class_num=10, passt_feature_layer=2, encoder_depth=2)
+    net = PaSST_CNN(passt_sed_param=ps, cnn_param=dict(CNN, conv_dropout=dropout))
+    sd = synth.pmam_state_dict_np(depth=12, mlm=False, lora_r=0, class_num=10)
+    own = net.state_dict()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(sd[k])) for k in own}, strict=True)
+    return net.cuda()
+
+
+def test_pmam_finetune_stage_vs_reference(golden):
+    """Frame posteriors of PaSST_CNN in finetune mode within 1e-3 of the reference: plain, validation temperature + pad mask, sliding
+    windows with both steps; gradients of a train-mode step."""
+    g = golden("pmam_ft_d2")
+    B = 2
+    mel = torch.from_numpy(synth.det_uniform("pmam_ft_d2/mel", (B, 128, 1000), -1.2, 1.2)).cuda()
+    net = build_ft()
+    net.eval()
+    pm = torch.zeros(B, 1000, dtype=torch.bool)
+    pm[0, 900:] = True
+    errs = {}
+    with torch.no_grad():
+        s1, w1, o1 = net(mel, encoder_win=False, temp_w=1)
+        s2, w2, _ = net(mel, encoder_win=False, temp_w=0.5, pad_mask=pm.cuda())
+        errs["strong"] = float((s1.cpu() - torch.from_numpy(g["strong"])).abs().max())
+        errs["weak"] = float((w1.cpu() - torch.from_numpy(g["weak"])).abs().max())
+        errs["at"] = float((o1["at_out"].cpu() - torch.from_numpy(g["at_out"])).abs().max())
+        errs["strong_t05_pad"] = float((s2.cpu() - torch.from_numpy(g["strong_t05_pad"])).abs().max())
+        errs["weak_t05_pad"] = float((w2.cpu() - torch.from_numpy(g["weak_t05_pad"])).abs().max())
+        assert float(s2[0, :, 900:].abs().max()) == 0.0
+        for step in (49, 31):
+            s3, w3, o3 = net(mel, encoder_win=True, mix_rate=0.5, win_param=[512, step], temp_w=0.5)
+            errs[f"strong_win{step}"] = float((s3.cpu() - torch.from_numpy(g[f"strong_win{step}"])).abs().max())
+            errs[f"weak_win{step}"] = float((w3.cpu() - torch.from_numpy(g[f"weak_win{step}"])).abs().max())
+            close(o3["frame_before_mask"][:, ::25, ::16], g[f"fbm_win{step}_s"], 8e-3, 2e-3, what="windowed merged sequence")
+    print("PMAM finetune-stage posterior errors:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert max(errs.values()) < 1e-3, errs
+    # gradients
+    net = build_ft(dropout=0.0)
+    net.train()
+    strong, weak, other = net(mel, encoder_win=False, temp_w=1)
+    loss = (strong * torch.from_numpy(synth.det_uniform("pmam_ft_d2/gs", tuple(strong.shape))).cuda()).sum() + \
+           (weak * torch.from_numpy(synth.det_uniform("pmam_ft_d2/gw", tuple(weak.shape))).cuda()).sum() + \
+           (other["at_out"] * torch.from_numpy(synth.det_uniform("pmam_ft_d2/ga", tuple(other["at_out"].shape))).cuda()).sum()
+    close(loss, g["tr_loss"], 5e-2, 2e-4, what="loss")
+    loss.backward()
+    names = [str(n) for n in g["tr_grad_names"]]
+    got = {n for n, p in net.named_parameters() if p.grad is not None}
+    assert got == set(names), (sorted(got - set(names))[:5], sorted(set(names) - got)[:5])
+    pn = dict(net.named_parameters())
+    worst = 0.0
+    for n, norm in zip(names, g["tr_grad_norms"]):
+        if re.fullmatch(r"cnn\.cnn\.conv\d\.bias", n):
+            continue
+        rel = abs(float(pn[n].grad.double().norm()) - norm) / max(norm, 1e-12)
+        worst = max(worst, rel)
+        assert rel < 0.03, f"|grad {n}| off by {rel:.3f}"
+    print(f"PMAM finetune-stage worst gradient-norm deviation {worst:.4f}")
+
+
+def test_pmam_finetune_trainer_runs_mean_teacher_steps():
+    """The PMAM finetune stage reuses the mean-teacher trainer (recipes/desed/finetune/cnn_trans/train.py subclasses the MAT-SED one):
+    PaSST_CNN student + EMA teacher with sliding windows through MatSedTrainer / FusedAdamWEMA / get_param_lr."""
+    import json
+    from copy import deepcopy
+    import bench
+    from transformer4sed_amd.pmam_trainer import get_param_lr
+    from transformer4sed_amd.scheduler import ExponentialDown
+    from transformer4sed_amd.trainer import FusedAdamWEMA, MatSedTrainer
+    net = build_ft(dropout=0.5)
+    ema = deepcopy(net)
+    for p in ema.parameters():
+        p.detach_()
+    cfg = json.loads(json.dumps(bench.FINETUNE2))
+    cfg["PaSST_CNN"] = cfg.pop("PaSST_SED")
+    cfg["training"]["batch_size"] = [2, 0, 2, 2]
+    lr = dict(cnn=dict(lr=1e-3, weight_decay=1e-4), passt=dict(lr=1e-4, weight_decay=1e-4, freeze_layer=0, step_lr=1),
+              decoder=dict(lr=1e-3, weight_decay=1e-4), head=dict(lr=1e-3, weight_decay=1e-4))
+    opt = FusedAdamWEMA(net, get_param_lr(net, lr), ema_net=ema)
+    sched = ExponentialDown(opt, start_iter=100, total_iter=200, exponent=-1, warmup_iter=0, warmup_rate=0.1)
+    net.train(); ema.train()
+    tr = MatSedTrainer(net, ema, opt, sched, cfg, epoch_len=10)
+    wav = torch.from_numpy(synth.synth_wav(6, seed=5)).cuda()
+    labels = torch.from_numpy(synth.synth_batch_labels(2, 2, 2, seed=5)).cuda()
+    w0, e0 = net.cnn.cnn.conv3.weight.detach().clone(), ema.cnn.cnn.conv3.weight.detach().clone()
+    losses = [float(tr.finetune_step(wav, labels.clone())["loss_total"]) for _ in range(3)]
+    print("PMAM finetune losses:", [f"{x:.4f}" for x in losses])
+    assert all(np.isfinite(losses))
+    assert not torch.equal(w0, net.cnn.cnn.conv3.weight.detach()) and not torch.equal(e0, ema.cnn.cnn.conv3.weight.detach())
+    assert int(ema.state_dict()["cnn.cnn.batchnorm0.num_batches_tracked"]) == 6, "the teacher runs in train mode (finetune/train.py:131-132)"

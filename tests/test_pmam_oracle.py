@@ -89,3 +89,44 @@ def test_dropout_and_lora_merge_identities():
         y1 = PO.cnn_branch(sd, mel, train=True, drop_masks=ones, n_layers=2)
     assert y0.shape == (1, 16, 500, 64)
     assert float((y1 - y0).abs().max()) > 1e-3     # the x2 of layer 0 changes what BatchNorm 1 sees only through the conv bias
+
+
+def test_pmam_finetune_stage_vs_reference(golden):
+    """PaSST_CNN in finetune mode (mlm False, no LoRA, 10 classes): eval forward, temperature + pad mask, sliding windows, gradients."""
+    g = golden("pmam_ft_d2")
+    B = 2
+    mel = torch.from_numpy(synth.det_uniform("pmam_ft_d2/mel", (B, 128, 1000), -1.2, 1.2))
+    sd = O.to_torch_sd(synth.pmam_state_dict_np(depth=12, mlm=False, lora_r=0, class_num=10))
+    kw = dict(depth=2, feature_layer=2, mlm=False, lora_scaling=0.0)
+    pm = torch.zeros(B, 1000, dtype=torch.bool)
+    pm[0, 900:] = True
+    with torch.no_grad():
+        o1 = PO.passt_cnn_forward(sd, mel, train=False, **kw)
+        o2 = PO.passt_cnn_forward(sd, mel, train=False, temp_w=0.5, pad_mask=pm, **kw)
+    close(o1["strong"], g["strong"], 2e-5, what="strong")
+    close(o1["weak"], g["weak"], 2e-5, what="weak")
+    close(o1["at_out"], g["at_out"], 1e-5, what="at_out")
+    close(o2["strong"], g["strong_t05_pad"], 3e-5, what="strong T=0.5 + pad mask")
+    close(o2["weak"], g["weak_t05_pad"], 3e-5)
+    for step in (49, 31):
+        with torch.no_grad():
+            o3 = PO.passt_cnn_forward(sd, mel, train=False, temp_w=0.5, encoder_win=True, win_param=(512, step), **kw)
+        close(o3["strong"], g[f"strong_win{step}"], 3e-5, what=f"windows step {step}")
+        close(o3["weak"], g[f"weak_win{step}"], 3e-5)
+        close(o3["frame_before_mask"][:, ::25, ::16], g[f"fbm_win{step}_s"], 5e-5, 1e-4)
+    names = [str(n) for n in g["tr_grad_names"]]
+    sdg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    o = PO.passt_cnn_forward(sdg, mel, train=True, **kw)
+    close(o["strong"].detach(), g["tr_strong"], 2e-5)
+    loss = (o["strong"] * torch.from_numpy(synth.det_uniform("pmam_ft_d2/gs", tuple(o["strong"].shape)))).sum() + \
+           (o["weak"] * torch.from_numpy(synth.det_uniform("pmam_ft_d2/gw", tuple(o["weak"].shape)))).sum() + \
+           (o["at_out"] * torch.from_numpy(synth.det_uniform("pmam_ft_d2/ga", tuple(o["at_out"].shape)))).sum()
+    close(loss.detach(), g["tr_loss"], 1e-2, 1e-5)
+    loss.backward()
+    for n, norm, head in zip(names, g["tr_grad_norms"], g["tr_grad_heads"]):
+        gr = sdg[n].grad
+        assert gr is not None, n
+        if ".conv" in n and n.endswith(".bias"):
+            continue    # BatchNorm removes the batch mean: the true gradient is zero, both sides hold rounding noise
+        close(float(gr.double().norm()), norm, 1e-6, 3e-3, what=f"|grad {n}|")
+    assert "merge_weight" not in names, "merge_weight only trains in MLM mode (passt_cnn.py:19)"

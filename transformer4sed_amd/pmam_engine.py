@@ -18,7 +18,7 @@ import math
 import torch
 
 from .engine import SedEngine, _W, D, H
-from .ops import BF16, F16, F32, call, gemm_nt, gemm_dw, pad64, transpose_bf16, split3, is_f16, to_bf16_, o_kind
+from .ops import BF16, F16, F32, call, h2d, gemm_nt, gemm_dw, pad64, transpose_bf16, split3, is_f16, to_bf16_, o_kind
 from .ops import EPI_F32, EPI_F32_RESID, EPI_BF16, EPI_GELU32
 
 HD_PAD = 64          # head width the attention kernels are built for
@@ -291,11 +291,6 @@ class PmamEngine(SedEngine):
                 toffsets=None, save=False, drop_masks=None):
         m = self.m
         dev = mel.device
-        if encoder_win:
-            raise NotImplementedError("PaSST_CNN with sliding windows (config/pmam/finetune2.yaml) is not built yet; every PMAM "
-                                      "pretrain config sets encoder_win False (post_pretrain.yaml:82-89)")
-        if not m.mlm:
-            raise NotImplementedError("PaSST_CNN classifier head (PMAM finetune stages) is not built yet")
         if mel.dtype != F32 or not mel.is_contiguous():
             mel = mel.contiguous().float()
         B, Fm, T = mel.shape
@@ -306,41 +301,88 @@ class PmamEngine(SedEngine):
         out = {}
         tp = 99
         pooled, frame16, ectx = self._encoder_fwd(W, mel, [0], tp, [0], save, want_frame=m.has_at)
-        # transformer_projector / cnn_projector before the interpolations
-        P1 = E(B * tp, Dd)
-        gemm_nt(split3(pooled.view(B * tp, D), B * tp, D), W["transformer_projector.weight"].ws, EPI_F32,
-                bias=self.P("transformer_projector.bias"), outF=P1)
+        Tdec = (tp + 1) * m.decode_ratio
         feat, cctx = self._cnn_fwd(W, mel, train=m.training, save=save, drop_masks=drop_masks)
         Tc = cctx["Tc"]
         Cl = feat.shape[1]
         P2 = E(B * Tc, Dd)
         gemm_nt(split3(feat, B * Tc, Cl), W["cnn_projector.weight"].ws, EPI_F32, bias=self.P("cnn_projector.bias"), outF=P2)
-        Tdec = (tp + 1) * m.decode_ratio
         assert Tdec % Tc == 0
         xg = E(B, Tdec, Dd)
-        call("sed_pmam_merge", P1, P2, self.P("merge_weight"), xg, B, tp, 1, m.decode_ratio, Tc, Tdec // Tc, Dd)
+        if encoder_win:
+            # sliding windows (teacher / validation of the PMAM finetune stage): local and global features are mixed at encoder
+            # width (passt_cnn.py:41-46), so the projector runs on all Tdec frames
+            if save:
+                raise NotImplementedError("gradient through the sliding-window path is not needed by any PMAM config")
+            from .engine import window_starts
+            x768 = E(B, Tdec, D)
+            call("sed_interp_fwd", pooled, x768, B, tp, 1, m.decode_ratio)
+            win, step = win_param
+            starts = window_starts(T, win, step)
+            if toffsets is None:
+                toffsets = [0] * len(starts)
+            groups = {}
+            for wi, left in enumerate(starts):
+                groups.setdefault((min(left + win, T) - left - 16) // 10 + 1, []).append(wi)
+            lefts, tps, offs, chunks, row = [0] * len(starts), [0] * len(starts), [0] * len(starts), [], 0
+            for tpw, wis in groups.items():
+                pw, _, _ = self._encoder_fwd(W, mel, [starts[w] for w in wis], tpw, [toffsets[w] for w in wis], False, want_frame=False)
+                chunks.append(pw.view(-1, D))
+                for k, w in enumerate(wis):
+                    lefts[w], tps[w], offs[w] = round(starts[w] * (Tdec / T)), tpw, row + k * B * tpw
+                row += len(wis) * B * tpw
+            packed = chunks[0] if len(chunks) == 1 else torch.cat(chunks, 0)
+            i32 = lambda v: h2d(v, torch.int32, dev)
+            call("sed_window_mix", packed, i32(lefts), i32(tps), i32(offs), len(starts), x768, float(mix_rate), B, Tdec, m.decode_ratio)
+            P1 = E(B * Tdec, Dd)
+            gemm_nt(split3(x768.view(B * Tdec, D), B * Tdec, D), W["transformer_projector.weight"].ws, EPI_F32,
+                    bias=self.P("transformer_projector.bias"), outF=P1)
+            call("sed_pmam_merge", P1, P2, self.P("merge_weight"), xg, B, Tdec, 0, 1, Tc, Tdec // Tc, Dd)
+        else:
+            # transformer_projector / cnn_projector before the interpolations
+            P1 = E(B * tp, Dd)
+            gemm_nt(split3(pooled.view(B * tp, D), B * tp, D), W["transformer_projector.weight"].ws, EPI_F32,
+                    bias=self.P("transformer_projector.bias"), outF=P1)
+            call("sed_pmam_merge", P1, P2, self.P("merge_weight"), xg, B, tp, 1, m.decode_ratio, Tc, Tdec // Tc, Dd)
         out["frame_before_mask"] = xg
         dec_in = xg
-        out["mask_id_seq"] = mlm_plan["mask_ids"]
-        if mlm_plan["effective"]:
-            dec_in = E(B, Tdec, Dd)
-            call("sed_mlm_apply_c", xg, self.P("mask_token").reshape(Dd), mlm_plan["action"], mlm_plan["src_idx"], dec_in, B * Tdec, Dd)
+        plan = mlm_plan if (m.mlm and mlm_plan is not None) else None
+        if plan is not None:
+            out["mask_id_seq"] = plan["mask_ids"]
+            if plan["effective"]:
+                dec_in = E(B, Tdec, Dd)
+                call("sed_mlm_apply_c", xg, self.P("mask_token").reshape(Dd), plan["action"], plan["src_idx"], dec_in, B * Tdec, Dd)
         xd, dctx = self._decoder_fwd(W, dec_in, save)
         actx = None
         if m.has_at:
             actx = self._at_fwd(W, frame16, ectx, save)
             out["at_out"] = actx["at_out"]
         M = B * Tdec
-        hpre = E(M, Dd, dt=BF16 if save else self.act)
-        act = E(M, Dd)
-        gemm_nt(split3(xd.view(M, Dd), M, Dd), W["mlm_mlp.0.weight"].ws, EPI_GELU32, bias=self.P("mlm_mlp.0.bias"), outH=hpre, outF=act)
-        pred = E(B, Tdec, m.mlm_out)
-        gemm_nt(split3(act, M, Dd), W["mlm_mlp.2.weight"].ws, EPI_F32, bias=self.P("mlm_mlp.2.bias"), outF=pred.view(M, m.mlm_out))
-        out["mlm_pred"] = pred
+        if m.mlm:
+            hpre = E(M, Dd, dt=BF16 if save else self.act)
+            act = E(M, Dd)
+            gemm_nt(split3(xd.view(M, Dd), M, Dd), W["mlm_mlp.0.weight"].ws, EPI_GELU32, bias=self.P("mlm_mlp.0.bias"), outH=hpre, outF=act)
+            pred = E(B, Tdec, m.mlm_out)
+            gemm_nt(split3(act, M, Dd), W["mlm_mlp.2.weight"].ws, EPI_F32, bias=self.P("mlm_mlp.2.bias"), outF=pred.view(M, m.mlm_out))
+            out["mlm_pred"] = pred
+            hctx = dict(xd=xd, hpre=hpre, act=act)
+        else:
+            # classifier + sigmoid + linear-softmax pooling (passt_cnn.py:74-86) on the 768-wide head kernel: decoder output and
+            # classifier weight zero-padded from Dd to 768 columns (the dot products are unchanged)
+            C = m.class_num
+            xd_pad = torch.zeros(B, Tdec, D, dtype=F32, device=dev)
+            xd_pad[:, :, :Dd] = xd
+            w_pad = torch.zeros(C, D, dtype=F32, device=dev)
+            w_pad[:, :Dd] = self.P("classifier.weight").detach()
+            strong, weak, sums = E(B, C, Tdec), E(B, C), E(B, C, 2)
+            pm = None if pad_mask is None else pad_mask.to(device=dev, dtype=torch.uint8).contiguous()
+            call("sed_head_fwd", xd_pad, w_pad, self.P("classifier.bias"), float(temp_w), pm, strong, weak, sums, B, Tdec, C)
+            out["strong"], out["weak"] = strong, weak
+            hctx = dict(strong=strong, sums=sums, temp=float(temp_w), xd_pad=xd_pad, w_pad=w_pad)
         ctx = None
         if save:
             ctx = dict(B=B, T=T, tp=tp, Tdec=Tdec, ectx=ectx, dctx=dctx, actx=actx, cctx=cctx, xd=xd, W=W, pooled=pooled, feat=feat, P1=P1,
-                       P2=P2, hctx=dict(xd=xd, hpre=hpre, act=act), mlm_plan=mlm_plan if mlm_plan["effective"] else None)
+                       P2=P2, hctx=hctx, mlm_plan=plan if (plan is not None and plan["effective"]) else None)
         return out, ctx
 
     # ==================================================================== backward
@@ -505,12 +547,27 @@ class PmamEngine(SedEngine):
         G = garena
         M = B * Tdec
         hc = ctx["hctx"]
-        dpred = grads.get("mlm_pred")
-        if dpred is None:
-            g = Z(B, Tdec, Dd)
+        if m.mlm:
+            dpred = grads.get("mlm_pred")
+            if dpred is None:
+                g = Z(B, Tdec, Dd)
+            else:
+                g = self._mlp_bwd(W, "mlm_mlp.0", "mlm_mlp.2", dpred.contiguous().float().view(M, m.mlm_out), hc["xd"].view(M, Dd),
+                                  hc["hpre"], hc["act"], M, G, residual=None).view(B, Tdec, Dd)
         else:
-            g = self._mlp_bwd(W, "mlm_mlp.0", "mlm_mlp.2", dpred.contiguous().float().view(M, m.mlm_out), hc["xd"].view(M, Dd), hc["hpre"],
-                              hc["act"], M, G, residual=None).view(B, Tdec, Dd)
+            ds, dw = grads.get("strong"), grads.get("weak")
+            if ds is None and dw is None:
+                g = Z(B, Tdec, Dd)
+            else:
+                ds = None if ds is None else ds.contiguous().float()
+                dw = None if dw is None else dw.contiguous().float()
+                g_pad = E(B, Tdec, D)
+                gw_pad = Z(m.class_num, D)
+                call("sed_head_bwd", hc["xd_pad"], hc["w_pad"], hc["strong"], hc["sums"], ds, dw, hc["temp"], g_pad, gw_pad,
+                     G("classifier.bias") if G("classifier.bias") is not None else Z(m.class_num), B, Tdec, m.class_num)
+                if G("classifier.weight") is not None:
+                    G("classifier.weight").add_(gw_pad[:, :Dd])
+                g = g_pad[:, :, :Dd].contiguous()
         g = self._decoder_bwd(W, ctx["dctx"], g, G, G("decoder.encoder_blocks.0.attn.in_proj.weight") is not None)
         if ctx["mlm_plan"] is not None:
             plan = ctx["mlm_plan"]

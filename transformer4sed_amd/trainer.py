@@ -306,7 +306,7 @@ class MatSedTrainer:
     def finetune_step(self, wav, labels):
         """One mean-teacher step (train.py:143-208).  Returns the dict of scalar losses (device tensors; no host sync)."""
         tr = self.cfg["training"]
-        kw = self.cfg["PaSST_SED"]
+        kw = self.cfg[self.net.get_model_name()]     # "PaSST_SED", or "PaSST_CNN" for the PMAM finetune stage (cnn_trans/train.py)
         sn, syn, wn, un = tr["batch_size"]
         scale = wav.shape[0] // (sn + syn + wn + un)
         strong_n, weak_n = (sn + syn) * scale, wn * scale
