@@ -66,20 +66,35 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
-// erf via Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7) with the hardware exp: ~12 VALU ops instead of the libm erff call.
-// Used where the result is rounded to 16 bits anyway (encoder GELU epilogue, GELU' in the backward).
-__device__ __forceinline__ float erf_fast(float x) {
-    const float ax = fabsf(x);
-    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float r = 1.0f - poly * __expf(-ax * ax);
-    return copysignf(r, x);
+// Phi(x) = 0.5 (1 + erf(x / sqrt 2)) through Abramowitz-Stegun 7.1.28: erf(t) = 1 - (1 + a1 t + ... + a6 t^6)^-16 for t >= 0
+// (|error| <= 3e-7): six FMAs, four squarings and ONE reciprocal -- no exp, and everything but the reciprocal runs as packed
+// fp32 math on element pairs.  The GELU epilogue of a 256 x 256 tile is 128 elements per lane: with the former 7.1.26 form
+// (rcp + exp + 12 scalar ops) it cost as many cycles as the tile's K = 768 main loop.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2v gelu_half_tail2(f32x2v x) {   // 0.5 * (1 - erf(|x| / sqrt 2)) = upper-tail probability of |x|
+    f32x2v t = {fabsf(x.x) * 0.70710678118654752f, fabsf(x.y) * 0.70710678118654752f};
+    f32x2v p = {0.0000430638f, 0.0000430638f};
+    p = p * t + 0.0002765672f;
+    p = p * t + 0.0001520143f;
+    p = p * t + 0.0092705272f;
+    p = p * t + 0.0422820123f;
+    p = p * t + 0.0705230784f;
+    p = p * t + 1.0f;
+    p = p * p; p = p * p; p = p * p; p = p * p;     // overflows to +inf for |x| > ~17: rcp(inf) = 0, the exact limit
+    return f32x2v{0.5f * __builtin_amdgcn_rcpf(p.x), 0.5f * __builtin_amdgcn_rcpf(p.y)};
 }
-__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_fast_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f));
-    return cdf + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+__device__ __forceinline__ f32x2v gelu_fast2(f32x2v x) {
+    const f32x2v h = gelu_half_tail2(x);
+    return f32x2v{x.x * (x.x >= 0.f ? 1.0f - h.x : h.x), x.y * (x.y >= 0.f ? 1.0f - h.y : h.y)};
 }
+__device__ __forceinline__ float gelu_fast(float x) { return gelu_fast2(f32x2v{x, x}).x; }
+__device__ __forceinline__ f32x2v gelu_fast_grad2(f32x2v x) {    // Phi(x) + x phi(x)
+    const f32x2v h = gelu_half_tail2(x);
+    const f32x2v e = {__expf(-0.5f * x.x * x.x), __expf(-0.5f * x.y * x.y)};
+    return f32x2v{(x.x >= 0.f ? 1.0f - h.x : h.x) + x.x * 0.39894228040143268f * e.x,
+                  (x.y >= 0.f ? 1.0f - h.y : h.y) + x.y * 0.39894228040143268f * e.y};
+}
+__device__ __forceinline__ float gelu_fast_grad(float x) { return gelu_fast_grad2(f32x2v{x, x}).x; }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // XCD-aware remap of a linear workgroup id: consecutive logical tiles land on the same XCD (private L2).

@@ -403,9 +403,10 @@ __device__ __forceinline__ void v3_stage16(unsigned char* wl, const f32x16_t (&a
                 const int col = j * 32 + 8 * q + 4 * lg;
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float x = acc[i][j][4 * q + e] + bv[j][q][e];
-                    v[e] = MODE == 1 ? gelu_fast(x) : x;
+                for (int e = 0; e < 4; e += 2) {
+                    f32x2v x = {acc[i][j][4 * q + e] + bv[j][q][e], acc[i][j][4 * q + e + 1] + bv[j][q][e + 1]};
+                    if (MODE == 1) x = gelu_fast2(x);
+                    v[e] = x.x; v[e + 1] = x.y;
                 }
                 uint2 pk;
                 pk.x = pack2<F16>(v[0], v[1]);
@@ -504,8 +505,9 @@ __device__ __forceinline__ void v3_store_batch(const GemmArgs& g, const unsigned
             const float h0 = to_f32<F16>((bf16_t)(a.x & 0xFFFF)), h1 = to_f32<F16>((bf16_t)(a.x >> 16));
             const float h2 = to_f32<F16>((bf16_t)(a.y & 0xFFFF)), h3 = to_f32<F16>((bf16_t)(a.y >> 16));
             uint2 pk;
-            pk.x = pack2<F16>(v.x * gelu_fast_grad(h0), v.y * gelu_fast_grad(h1));
-            pk.y = pack2<F16>(v.z * gelu_fast_grad(h2), v.w * gelu_fast_grad(h3));
+            const f32x2v ga = gelu_fast_grad2(f32x2v{h0, h1}), gb = gelu_fast_grad2(f32x2v{h2, h3});
+            pk.x = pack2<F16>(v.x * ga.x, v.y * ga.y);
+            pk.y = pack2<F16>(v.z * gb.x, v.w * gb.y);
             v3_st<uint2>(g.outH + o, pk);
         }
     }
