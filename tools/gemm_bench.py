@@ -8,6 +8,7 @@ from transformer4sed_amd.ops import gemm_nt, F16, BF16
 dev = "cuda"
 shapes = [("fc1 stu", 38080, 3072, 768, ops.EPI_GELU), ("fc2 stu", 38080, 768, 3072, ops.EPI_F32_RESID),
           ("proj stu", 38080, 768, 768, ops.EPI_F32_RESID), ("fc1 win", 211904, 3072, 768, ops.EPI_GELU),
+          ("proj win", 211904, 768, 768, ops.EPI_F32_RESID), ("fc2 win", 211904, 768, 3072, ops.EPI_F32_RESID),
           ("plain f32 out", 38080, 3072, 768, ops.EPI_F32), ("plain f16 out", 38080, 3072, 768, ops.EPI_BF16),
           ("dX fc1 (bf16)", 38080, 768, 3072, ops.EPI_F32), ("square 8k", 8192, 8192, 8192, ops.EPI_BF16)]
 reps = int(os.environ.get("REPS", "5"))
