@@ -201,15 +201,23 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # debugging aid for boxes with a single GPU: SED_BENCH_BACKEND=gloo SED_BENCH_ONE_GPU=1 runs every rank on cuda:0 with
+        # host-staged collectives, which exercises the whole N > 1 control flow (RCCL itself refuses two ranks on one device)
+        backend = os.environ.get("SED_BENCH_BACKEND", "nccl")
+        if os.environ.get("SED_BENCH_ONE_GPU") == "1":
+            local = 0           # (LOCAL_RANK still decides who builds)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
     import __graft_entry__
     if world > 1:
         # one builder per node: concurrent hipcc runs writing the same libsed_hip.so would corrupt it
-        if local == 0:
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
             __graft_entry__.build()
         dist.barrier()
     __graft_entry__.build()   # up to date by now: dlopen + symbol check only
