@@ -125,8 +125,9 @@ int sed_mlm_apply(const float* x, const float* mask_token, const uint8_t* action
                   int rows, hipStream_t stream);
 int sed_mlm_apply_bwd(const float* dout, const uint8_t* action, const int* src_idx, float* dx_zeroed, float* dtoken,
                       int rows, hipStream_t stream);
-int sed_masked_mse(const float* pred, const float* target, const uint8_t* mask, int n_masked_rows, float* loss_zeroed,
-                   float* dpred, float* dtarget, int rows, hipStream_t stream);
+/* n_masked_rows_dev (nullable): the row count as a device int, read by the kernel instead of n_masked_rows (no host sync) */
+int sed_masked_mse(const float* pred, const float* target, const uint8_t* mask, int n_masked_rows, const int* n_masked_rows_dev,
+                   float* loss_zeroed, float* dpred, float* dtarget, int rows, hipStream_t stream);
 /* classifier + sigmoid(x/temp) + pad mask + linear-softmax pooling (passt_sed.py:285-296) */
 int sed_head_fwd(const float* x, const float* W, const float* bias, float temp, const uint8_t* pad_mask, float* strong,
                  float* weak, float* sums, int B, int T, int C, hipStream_t stream);
@@ -213,9 +214,11 @@ int sed_lora_grad(const float* dW, const float* A, const float* Bm, float scalin
                   int r, hipStream_t stream);
 /* prototype-similarity BCE of the PMAM trainer (recipes/desed/pmam/train.py:82-87, 100-106): loss[0] += mean BCE over the
  * `sel`ected frames x C classes; dlogit [B*T, 768] (nullable) = d loss / d logit; post [B*T, C] (nullable) = posteriors.
- * protos [C, 768] are the row-normalised GMM means (train.py:31); labels [B, C, T]. */
+ * protos [C, 768] are the row-normalised GMM means (train.py:31); labels [B, C, T].  n_selected_dev (nullable): the number of
+ * selected frames as a device int, read by the kernel instead of n_selected (no host sync). */
 int sed_proto_bce(const float* logit, const float* protos, const float* labels, const uint8_t* sel, int n_selected,
-                  float temperature, float* loss, float* dlogit, float* post, int B, int T, int C, int D, hipStream_t stream);
+                  const int* n_selected_dev, float temperature, float* loss, float* dlogit, float* post, int B, int T, int C, int D,
+                  hipStream_t stream);
 
 #ifdef __cplusplus
 }

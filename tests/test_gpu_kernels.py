@@ -492,10 +492,14 @@ def test_mlm_mse_adamw():
     mask = (action != 0)
     nm = int(mask.sum())
     loss = torch.zeros(1, device=DEV); dp = torch.empty(rows, 768, device=DEV); dt = torch.empty(rows, 768, device=DEV)
-    call("sed_masked_mse", pred, tgt, mask.to(torch.uint8), nm, loss, dp, dt, rows)
+    call("sed_masked_mse", pred, tgt, mask.to(torch.uint8), nm, None, loss, dp, dt, rows)
     pp = pred.clone().requires_grad_(True); tt = tgt.clone().requires_grad_(True)
     lref = torch.nn.functional.mse_loss(tt[mask], pp[mask]); lref.backward()
     assert abs(float(loss) - float(lref)) < 1e-5 * float(lref) + 1e-6
+    # same with the row count read from device memory (the trainers' sync-free form)
+    loss2 = torch.zeros(1, device=DEV); dp2 = torch.empty(rows, 768, device=DEV)
+    call("sed_masked_mse", pred, tgt, mask.to(torch.uint8), 0, torch.tensor([nm], dtype=torch.int32, device=DEV), loss2, dp2, None, rows)
+    assert abs(float(loss2) - float(loss)) < 1e-5 * float(loss) and torch.equal(dp2, dp)   # loss: atomic summation order
     assert maxerr(dp, pp.grad) < 1e-9 + 1e-6 * float(pp.grad.abs().max()) and maxerr(dt, tt.grad) < 1e-9 + 1e-6 * float(tt.grad.abs().max())
     n = 4096 * 3
     p = rnd(n, seed=115); gr = rnd(n, seed=116); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)

@@ -507,9 +507,10 @@ extern "C" int sed_mlm_apply_bwd(const float* dout, const uint8_t* action, const
 // loss = mean over masked rows x D of (target - pred)^2 ; dpred = 2 (pred - target) / n, dtarget = -dpred.
 __global__ __launch_bounds__(256) void masked_mse_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                                          const unsigned char* __restrict__ mask, float inv_n,
-                                                         float* __restrict__ loss, float* __restrict__ dpred,
-                                                         float* __restrict__ dtarget, int rows) {
+                                                         const int* __restrict__ n_dev, float* __restrict__ loss,
+                                                         float* __restrict__ dpred, float* __restrict__ dtarget, int rows) {
     __shared__ float red[4];
+    if (n_dev != nullptr) inv_n = 1.0f / (fmaxf((float)n_dev[0], 1.0f) * (float)DM);   // count produced on the device: no host sync
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float acc = 0.f;
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
@@ -535,12 +536,13 @@ __global__ __launch_bounds__(256) void masked_mse_kernel(const float* __restrict
     if (threadIdx.x == 0) unsafeAtomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_n);
 }
 extern "C" int sed_masked_mse(const float* pred, const float* target, const uint8_t* mask, int n_masked_rows,
-                              float* loss_zeroed, float* dpred, float* dtarget, int rows, hipStream_t stream) {
+                              const int* n_masked_rows_dev, float* loss_zeroed, float* dpred, float* dtarget, int rows,
+                              hipStream_t stream) {
     (void)hipGetLastError();
-    if (n_masked_rows <= 0) return SED_ERR_ARG;
-    const float inv_n = 1.0f / ((float)n_masked_rows * (float)DM);
-    hipLaunchKernelGGL(masked_mse_kernel, dim3(512), dim3(256), 0, stream, pred, target, mask, inv_n, loss_zeroed, dpred,
-                       dtarget, rows);
+    if (n_masked_rows <= 0 && n_masked_rows_dev == nullptr) return SED_ERR_ARG;
+    const float inv_n = n_masked_rows > 0 ? 1.0f / ((float)n_masked_rows * (float)DM) : 0.f;
+    hipLaunchKernelGGL(masked_mse_kernel, dim3(512), dim3(256), 0, stream, pred, target, mask, inv_n, n_masked_rows_dev, loss_zeroed,
+                       dpred, dtarget, rows);
     return sed_check_launch();
 }
 

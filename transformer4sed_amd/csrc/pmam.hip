@@ -433,26 +433,37 @@ extern "C" int sed_ln_bwd_any(const float* dy, const float* x, const float* mean
 }
 
 // backward of sed_mlm_apply_c: dx (zero-initialised) receives kept rows and the scatter of 'copy' rows, dtoken the 'mask' rows
-__global__ void mlm_apply_bwd_c_kernel(const float* __restrict__ dout, const unsigned char* __restrict__ action,
-                                       const int* __restrict__ src_idx, float* __restrict__ dx, float* __restrict__ dtoken, int rows,
-                                       int C) {
-    const size_t total = (size_t)rows * C;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int d = (int)(idx % C);
-        const int row = (int)(idx / C);
+__global__ __launch_bounds__(256) void mlm_apply_bwd_c_kernel(const float* __restrict__ dout, const unsigned char* __restrict__ action,
+                                                              const int* __restrict__ src_idx, float* __restrict__ dx,
+                                                              float* __restrict__ dtoken, int rows, int C) {
+    // a workgroup walks a slab of rows with one thread per column (C <= 1024): the 'mask' rows (most of the masked frames) are summed
+    // in registers and leave as ONE atomic per column and workgroup instead of one per element on the same C addresses
+    float tok[4] = {0.f, 0.f, 0.f, 0.f};
+    const int per = (rows + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+    for (int row = r0; row < r1; ++row) {
         const unsigned char a = action[row];
-        const float g = dout[idx];
-        if (a == 0) unsafeAtomicAdd(&dx[idx], g);
-        else if (a == 1) unsafeAtomicAdd(&dtoken[d], g);
-        else unsafeAtomicAdd(&dx[(size_t)src_idx[row] * C + d], g);
+        const int src = a == 2 ? src_idx[row] : row;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int d = threadIdx.x + 256 * u;
+            if (d >= C) break;
+            const float g = dout[(size_t)row * C + d];
+            if (a == 1) tok[u] += g;
+            else unsafeAtomicAdd(&dx[(size_t)src * C + d], g);   // 'copy' rows scatter onto rows that also keep their own gradient
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int d = threadIdx.x + 256 * u;
+        if (d < C && tok[u] != 0.f) unsafeAtomicAdd(&dtoken[d], tok[u]);
     }
 }
 extern "C" int sed_mlm_apply_bwd_c(const float* dout, const uint8_t* action, const int* src_idx, float* dx_zeroed, float* dtoken,
                                    int rows, int C, hipStream_t stream) {
     (void)hipGetLastError();
-    if (rows <= 0 || C <= 0) return SED_ERR_ARG;
-    hipLaunchKernelGGL(mlm_apply_bwd_c_kernel, dim3(grid_for((size_t)rows * C)), dim3(256), 0, stream, dout, action, src_idx, dx_zeroed,
-                       dtoken, rows, C);
+    if (rows <= 0 || C <= 0 || C > 1024) return SED_ERR_ARG;
+    int blocks = rows < 2048 ? rows : 2048;
+    hipLaunchKernelGGL(mlm_apply_bwd_c_kernel, dim3(blocks), dim3(256), 0, stream, dout, action, src_idx, dx_zeroed, dtoken, rows, C);
     return sed_check_launch();
 }
 
@@ -767,9 +778,11 @@ extern "C" int sed_lora_grad(const float* dW, const float* A, const float* Bm, f
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void proto_bce_kernel(const float* __restrict__ logit, const float* __restrict__ protos,
                                                         const float* __restrict__ labels, const unsigned char* __restrict__ sel,
-                                                        float inv_count, float inv_temp, float* __restrict__ loss,
-                                                        float* __restrict__ dlogit, float* __restrict__ post, int rows, int T, int C) {
+                                                        float inv_count, const int* __restrict__ n_dev, float inv_temp,
+                                                        float* __restrict__ loss, float* __restrict__ dlogit, float* __restrict__ post,
+                                                        int rows, int T, int C) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (n_dev != nullptr) inv_count = 1.0f / (fmaxf((float)n_dev[0], 1.0f) * (float)C);   // count produced on the device: no host sync
     float lsum = 0.f;
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         float4 x[3], gacc[3];
@@ -829,14 +842,16 @@ __global__ __launch_bounds__(256) void proto_bce_kernel(const float* __restrict_
     if (lane == 0 && lsum != 0.f) unsafeAtomicAdd(loss, lsum * inv_count);
 }
 extern "C" int sed_proto_bce(const float* logit, const float* protos, const float* labels, const uint8_t* sel, int n_selected,
-                             float temperature, float* loss, float* dlogit, float* post, int B, int T, int C, int D,
-                             hipStream_t stream) {
+                             const int* n_selected_dev, float temperature, float* loss, float* dlogit, float* post, int B, int T,
+                             int C, int D, hipStream_t stream) {
     (void)hipGetLastError();
-    if (B <= 0 || T <= 0 || C <= 0 || C > 64 || D != 768 || n_selected <= 0 || temperature <= 0.f) return SED_ERR_ARG;
+    if (B <= 0 || T <= 0 || C <= 0 || C > 64 || D != 768 || (n_selected <= 0 && n_selected_dev == nullptr) || temperature <= 0.f)
+        return SED_ERR_ARG;
     const int rows = B * T;
     int blocks = cdiv(rows, 4);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(proto_bce_kernel, dim3(blocks), dim3(256), 0, stream, logit, protos, labels, sel, 1.0f / ((float)n_selected * (float)C),
-                       1.0f / temperature, loss, dlogit, post, rows, T, C);
+    hipLaunchKernelGGL(proto_bce_kernel, dim3(blocks), dim3(256), 0, stream, logit, protos, labels, sel,
+                       n_selected > 0 ? 1.0f / ((float)n_selected * (float)C) : 0.f, n_selected_dev, 1.0f / temperature, loss, dlogit, post,
+                       rows, T, C);
     return sed_check_launch();
 }

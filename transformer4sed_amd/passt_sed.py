@@ -338,13 +338,12 @@ class PaSST_SED(SEDModel):
         s0, s1 = cfg["mask_style"][0], cfg["mask_style"][1]
         mm = flat & (probs < s0)
         rm = flat & (probs >= s0) & (probs < s0 + s1)
-        nr = int(rm.sum().item())
-        ridx = dr["rand_idx"].to(dev) if dr else torch.randint(0, B * T, (nr,), device=dev)
-        action = torch.zeros(B * T, dtype=torch.uint8, device=dev)
-        action[mm] = 1
-        action[rm] = 2
-        src = torch.zeros(B * T, dtype=torch.int32, device=dev)
-        src[rm] = ridx.to(torch.int32)
+        action = mm.to(torch.uint8) + 2 * rm.to(torch.uint8)
+        if dr:   # injected draws (tests): one index per 'random' row, in row order like mask.py:79
+            src = torch.zeros(B * T, dtype=torch.int32, device=dev)
+            src[rm] = dr["rand_idx"].to(dev).to(torch.int32)
+        else:    # one draw per row, used where the row is a 'random' one: no count has to travel to the host
+            src = torch.where(rm, torch.randint(0, B * T, (B * T,), device=dev, dtype=torch.int32), 0)
         # Reference quirk: the in-place masking only takes effect when the sequence is contiguous
         # (sliding windows) or B == 1; otherwise the decoder sees the unmasked sequence.
         eff = bool(encoder_win) or B == 1 or getattr(self, "_mask_always_effective", False)

@@ -78,11 +78,12 @@ class ProtoBCE(torch.autograd.Function):
     def forward(ctx, logit, protos, labels, sel, temperature):
         B, T, Dm = logit.shape
         C = protos.shape[0]
-        n = int(sel.sum().item())
+        sel8 = sel.to(torch.uint8).contiguous()
+        n_dev = sel8.sum(dtype=torch.int32).reshape(1)    # stays on the device: a .item() here would stall the host every step
         loss = torch.zeros(1, dtype=torch.float32, device=logit.device)
         dlogit = torch.empty_like(logit)
-        call("sed_proto_bce", logit.contiguous(), protos.contiguous(), labels.contiguous().float(), sel.to(torch.uint8).contiguous(), n,
-             float(temperature), loss, dlogit, None, B, T, C, Dm)
+        call("sed_proto_bce", logit.contiguous(), protos.contiguous(), labels.contiguous().float(), sel8, 0, n_dev, float(temperature),
+             loss, dlogit, None, B, T, C, Dm)
         ctx.save_for_backward(dlogit)
         return loss[0]
 
@@ -100,7 +101,7 @@ def prototype_posteriors(logit, protos, temperature=0.1):
     sel = torch.ones(B * T, dtype=torch.uint8, device=logit.device)
     lab = torch.zeros(B, C, T, dtype=torch.float32, device=logit.device)
     loss = torch.zeros(1, dtype=torch.float32, device=logit.device)
-    call("sed_proto_bce", logit.contiguous(), protos.contiguous(), lab, sel, B * T, float(temperature), loss, None, post, B, T, C, Dm)
+    call("sed_proto_bce", logit.contiguous(), protos.contiguous(), lab, sel, B * T, None, float(temperature), loss, None, post, B, T, C, Dm)
     return post
 
 

@@ -231,11 +231,11 @@ class MaskedMSE(torch.autograd.Function):
     def forward(ctx, target, pred, mask):
         rows = mask.numel()
         m8 = mask.reshape(-1).to(torch.uint8).contiguous()
-        n = int(mask.sum().item())
+        n_dev = m8.sum(dtype=torch.int32).reshape(1)      # stays on the device: a .item() here would stall the host every step
         loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
         dp = torch.empty_like(pred, memory_format=torch.contiguous_format)
         dt = torch.empty_like(pred, memory_format=torch.contiguous_format)
-        call("sed_masked_mse", pred.contiguous(), target.contiguous(), m8, n, loss, dp, dt, rows)
+        call("sed_masked_mse", pred.contiguous(), target.contiguous(), m8, 0, n_dev, loss, dp, dt, rows)
         ctx.save_for_backward(dp, dt)
         return loss[0]
 
