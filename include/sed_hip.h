@@ -51,6 +51,12 @@ int sed_median_filter(const float* in, float* out, const int* sizes, const float
 int sed_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi, const float* bias,
                 const float* resF, float* outF, void* outH, void* outH2, const void* auxH, int ldc, float alpha,
                 int ksplit, int f16, hipStream_t stream);
+/* sed_gemm_nt with a narrow result: A / B are padded to N (a multiple of 128, not of 256) but only the first ncols (multiple of 4)
+ * output columns exist in memory -- bias [ncols], residual and outputs [M, ldc] with ldc >= ncols.  The 16/32/64-filter layers of
+ * the PMAM CNN branch (src/models/cnn/base.py:62-70) produce their [pixels, filters] matrices this way. */
+int sed_gemm_nt_cols(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi, const float* bias,
+                     const float* resF, float* outF, void* outH, void* outH2, const void* auxH, int ldc, float alpha, int f16,
+                     int ncols, hipStream_t stream);
 /* Weight gradient in TN form: dW[M,N] (fp32, ldc) += dY[T,M]^T . X[T,N], both operands row-major [token][feature] as the forward /
  * backward left them (dY bf16, X bf16 or IEEE half) -- the autograd of F.linear's weight (same reference lines as sed_gemm_nt).
  * T % 64 == 0, M % 256 == 0, N % 256 == 0; split-K over tokens chosen by the library.  `workspace` (caller-owned, optional):

@@ -47,6 +47,7 @@ struct GemmArgs {
     int seq, seq_pad, heads;
     int bwd_bf16; // f16 runs only: tensors that only the (bf16) backward consumes are written as bf16 straight away
     int stagger;  // v3: first-round workgroups start phase * stagger wall-clock ticks (10 ns) late, phase = 0..7
+    int ncols;    // 128^2 kernel: output columns >= ncols are computed but not written (operands padded to the tile width)
 };
 
 #define TILE 128
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * lg;
+                if (n >= g.ncols) continue;
                 const float v4[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
                 epilogue_quad<EPI, F16>(g, m, n, v4);
             }
@@ -1614,12 +1616,13 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
     return sed_check_launch();
 }
 
-extern "C" int sed_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi,
-                           const float* bias, const float* resF, float* outF, void* outH, void* outH2,
-                           const void* auxH, int ldc, float alpha, int ksplit, int f16, hipStream_t stream) {
+static int gemm_nt_impl(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi, const float* bias,
+                        const float* resF, float* outF, void* outH, void* outH2, const void* auxH, int ldc, float alpha,
+                        int ksplit, int f16, int ncols, hipStream_t stream) {
     (void)hipGetLastError();
     GemmArgs g = {};
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B;
+    g.ncols = ncols;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ksplit = ksplit > 0 ? ksplit : 1;
     g.alpha = alpha; g.bias = bias; g.resF = resF; g.outF = outF; g.outH = (bf16_t*)outH; g.outH2 = (bf16_t*)outH2;
     g.auxH = (const bf16_t*)auxH;
@@ -1638,6 +1641,19 @@ extern "C" int sed_gemm_nt(const void* A, const void* B, int M, int N, int K, in
         default: return SED_ERR_ARG;
     }
 }
+extern "C" int sed_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi,
+                           const float* bias, const float* resF, float* outF, void* outH, void* outH2,
+                           const void* auxH, int ldc, float alpha, int ksplit, int f16, hipStream_t stream) {
+    return gemm_nt_impl(A, B, M, N, K, lda, ldb, epi, bias, resF, outF, outH, outH2, auxH, ldc, alpha, ksplit, f16, N, stream);
+}
+// same GEMM with a narrow result: the operands are padded to N (multiple of 128) but only the first ncols (multiple of 4) output
+// columns exist in memory (row stride ldc >= ncols); bias / residual / outputs are indexed like the narrow matrix.  128^2 kernel only.
+extern "C" int sed_gemm_nt_cols(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi,
+                                const float* bias, const float* resF, float* outF, void* outH, void* outH2,
+                                const void* auxH, int ldc, float alpha, int f16, int ncols, hipStream_t stream) {
+    if (ncols <= 0 || ncols > N || (ncols % 4) || N % 256 == 0 || epi == EPI_ATOMIC) return SED_ERR_ARG;
+    return gemm_nt_impl(A, B, M, N, K, lda, ldb, epi, bias, resF, outF, outH, outH2, auxH, ldc, alpha, 1, f16, ncols, stream);
+}
 
 extern "C" int sed_gemm_qkv(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq,
                             int seq_pad, void* q, void* k, void* v, void* qt, void* kt, void* vt, void* q2,
@@ -1646,6 +1662,7 @@ extern "C" int sed_gemm_qkv(const void* A, const void* W, const float* bias, int
     GemmArgs g = {};
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)W;
     g.M = M; g.N = 3 * heads * 64; g.K = K; g.lda = K; g.ldb = K; g.ldc = g.N; g.ksplit = 1; g.alpha = 1.f;
+    g.ncols = g.N;
     g.bias = bias;
     g.q = (bf16_t*)q; g.k = (bf16_t*)k; g.v = (bf16_t*)v; g.qt = (bf16_t*)qt; g.kt = (bf16_t*)kt; g.vt = (bf16_t*)vt;
     g.q2 = (bf16_t*)q2; g.q2t = (bf16_t*)q2t; g.pu = pos_u; g.pv = pos_v;

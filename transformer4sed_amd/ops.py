@@ -128,6 +128,13 @@ def gemm_nt(A, B, epi, M=None, bias=None, res=None, outF=None, outH=None, outH2=
          float(alpha), ksplit, 3 if pre_bf16 else is_f16(A))
 
 
+def gemm_nt_cols(A, B, epi, ncols, bias=None, res=None, outF=None, outH=None, ldc=None):
+    """gemm_nt whose result has only `ncols` (< B.shape[0], the padded operand width) columns in memory; see sed_gemm_nt_cols."""
+    N, K = B.shape
+    call("sed_gemm_nt_cols", A, B, A.shape[0], N, K, A.shape[1], K, epi, bias, res, outF, outH, None, None, ldc or ncols, 1.0,
+         is_f16(A), ncols)
+
+
 def dw_ksplit(n_out, k_in, mpad):
     tiles = ((n_out + 127) // 128) * (k_in // 128)
     ks = max(1, min((640 + tiles - 1) // tiles, mpad // 256))

@@ -18,7 +18,7 @@ import math
 import torch
 
 from .engine import SedEngine, _W, D, H
-from .ops import BF16, F16, F32, call, h2d, gemm_nt, gemm_dw, pad64, transpose_bf16, split3, is_f16, to_bf16_, o_kind
+from .ops import BF16, F16, F32, call, h2d, gemm_nt, gemm_nt_cols, gemm_dw, pad64, transpose_bf16, split3, is_f16, to_bf16_, o_kind
 from .ops import EPI_F32, EPI_F32_RESID, EPI_BF16, EPI_GELU32
 
 HD_PAD = 64          # head width the attention kernels are built for
@@ -184,13 +184,17 @@ class PmamEngine(SedEngine):
                 call("sed_conv0_im2col", mel, col, B, T, f16)
             else:
                 call("sed_conv3x3_im2col", X, col, B, Hc, Wc, cin, max(64, cin), Kp)
-            Y = E(Mi, Np)
-            gemm_nt(col, W[f"cnn.cnn.conv{i}.weight"].w, EPI_F32, bias=aux["bias"], outF=Y)
+            ldy = co if co < Np else Np     # 16 / 32 / 64 filters: the GEMM writes only the valid columns of its 128-wide tile
+            Y = E(Mi, ldy)
+            if ldy < Np:
+                gemm_nt_cols(col, W[f"cnn.cnn.conv{i}.weight"].w, EPI_F32, co, bias=aux["bias"], outF=Y)
+            else:
+                gemm_nt(col, W[f"cnn.cnn.conv{i}.weight"].w, EPI_F32, bias=aux["bias"], outF=Y)
             bn = f"cnn.cnn.batchnorm{i}."
             g, bt = self.P(bn + "weight").detach(), self.P(bn + "bias").detach()
             if train:
                 s1, s2 = torch.zeros(co, device=dev), torch.zeros(co, device=dev)
-                call("sed_colstats", Y, Np, None, 0, None, None, s1, s2, Mi, co, 0)
+                call("sed_colstats", Y, ldy, None, 0, None, None, s1, s2, Mi, co, 0)
                 mean = s1 / Mi
                 var = (s2 / Mi - mean * mean).clamp_(min=0)
                 rm, rv = m._buffer_by_name[bn + "running_mean"], m._buffer_by_name[bn + "running_var"]
@@ -203,9 +207,12 @@ class PmamEngine(SedEngine):
             a = (g * rstd).contiguous()
             b = (bt - mean * a).contiguous()
             Z = E(Mi, Cp, dt=self.act)
-            call("sed_bn_act", Y, Np, a, b, Z, Mi, co, Cp, f16)
-            L = E(Mi, Np)
-            gemm_nt(Z, W[f"cnn.cnn.cg{i}.linear.weight"].w, EPI_F32, bias=aux["gbias"], outF=L)
+            call("sed_bn_act", Y, ldy, a, b, Z, Mi, co, Cp, f16)
+            L = E(Mi, ldy)
+            if ldy < Np:
+                gemm_nt_cols(Z, W[f"cnn.cnn.cg{i}.linear.weight"].w, EPI_F32, co, bias=aux["gbias"], outF=L)
+            else:
+                gemm_nt(Z, W[f"cnn.cnn.cg{i}.linear.weight"].w, EPI_F32, bias=aux["gbias"], outF=L)
             ph, pw = m.cnn_pooling[i]
             last = i + 1 == len(self.cnn_aux)
             Cpo = max(64, co)
@@ -217,10 +224,10 @@ class PmamEngine(SedEngine):
             if train and m.conv_dropout > 0:
                 mask = drop_masks[i] if drop_masks is not None else (torch.rand(Mi, co, device=dev) >= m.conv_dropout).to(torch.uint8)
                 scale = 1.0 / (1.0 - m.conv_dropout)
-            call("sed_cg_pool", Y, Np, a, b, L, Np, mask, float(scale), Xn, feat, B, Hc, Wc, co, Cpo, ph, pw, f16)
+            call("sed_cg_pool", Y, ldy, a, b, L, ldy, mask, float(scale), Xn, feat, B, Hc, Wc, co, Cpo, ph, pw, f16)
             if save:
                 layers.append(dict(col=col, Y=Y, a=a, b=b, ah=rstd.contiguous(), bh=(-mean * rstd).contiguous(), Z=Z, L=L, mask=mask,
-                                   scale=scale, H=Hc, W=Wc))
+                                   scale=scale, H=Hc, W=Wc, ldy=ldy))
             X = Xn
             Hc, Wc = Hc // ph, Wc // pw
         assert Wc == 1
@@ -415,24 +422,28 @@ class PmamEngine(SedEngine):
             Hc, Wc = L["H"], L["W"]
             Mi = B * Hc * Wc
             ph, pw = m.cnn_pooling[i]
-            dz = E(Mi, Np)
+            ldy = L["ldy"]
+            dz = E(Mi, ldy)
             dL16 = E(Mi, Np, dt=BF16)
-            call("sed_cg_pool_bwd", dout, L["Y"], Np, L["a"], L["b"], L["L"], Np, L["mask"], float(L["scale"]), dz, Np, dL16, Np, B, Hc,
+            call("sed_cg_pool_bwd", dout, L["Y"], ldy, L["a"], L["b"], L["L"], ldy, L["mask"], float(L["scale"]), dz, ldy, dL16, Np, B, Hc,
                  Wc, co, ph, pw)
             gWT, gb = self._dw_swapped(dL16, L["Z"], Mi, co, co)
             cg = f"cnn.cnn.cg{i}.linear."
             if G(cg + "weight") is not None:
                 G(cg + "weight").add_(gWT[:co, :co].t())
                 G(cg + "bias").add_(gb[:co])
-            gemm_nt(dL16, aux["wtg"], EPI_F32_RESID, res=dz, outF=dz)      # dz += dL W_gate
+            if ldy < Np:      # dz += dL W_gate
+                gemm_nt_cols(dL16, aux["wtg"], EPI_F32_RESID, co, res=dz, outF=dz)
+            else:
+                gemm_nt(dL16, aux["wtg"], EPI_F32_RESID, res=dz, outF=dz)
             s1, s2 = torch.zeros(co, device=dev), torch.zeros(co, device=dev)
-            call("sed_colstats", dz, Np, L["Y"], Np, L["ah"], L["bh"], s1, s2, Mi, co, 1)
+            call("sed_colstats", dz, ldy, L["Y"], ldy, L["ah"], L["bh"], s1, s2, Mi, co, 1)
             bn = f"cnn.cnn.batchnorm{i}."
             if G(bn + "weight") is not None:
                 G(bn + "weight").add_(s2)
                 G(bn + "bias").add_(s1)
             dY16 = E(Mi, Np, dt=BF16)
-            call("sed_bn_bwd", dz, Np, L["Y"], Np, L["ah"], L["bh"], self.P(bn + "weight"), s1, s2, dY16, Np, Mi, co)
+            call("sed_bn_bwd", dz, ldy, L["Y"], ldy, L["ah"], L["bh"], self.P(bn + "weight"), s1, s2, dY16, Np, Mi, co)
             del dz, dL16
             cWT, cb = self._dw_swapped(dY16, L["col"], Mi, co, 9 * cin)
             cv = f"cnn.cnn.conv{i}."
