@@ -226,6 +226,12 @@ int sed_proto_bce(const float* logit, const float* protos, const float* labels, 
                   const int* n_selected_dev, float temperature, float* loss, float* dlogit, float* post, int B, int T, int C, int D,
                   hipStream_t stream);
 
+/* transpose of a narrow 16-bit matrix (bf16 or, in_f16 != 0, IEEE half): in [R, ldin] with C = 8, 16, 24 or 32 valid columns
+ * -> outT bf16 [C, Rpad] (rows R..Rpad-1 zero) + optional fp32 column sums (+=): the weight-gradient operands of the 16/32-filter
+ * CNN layers (src/models/cnn/base.py:62-70) */
+int sed_transpose_narrow(const void* in, int in_f16, int R, int C, int ldin, void* outT, int Rpad, float* colsum,
+                         hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -404,9 +404,17 @@ class PmamEngine(SedEngine):
         Mpad = pad64(M)
         gT = torch.empty(n, Mpad, dtype=BF16, device=dev)
         csum = torch.zeros(n, device=dev)
-        transpose_bf16(dy16, M, n_eff, gT, colsum=csum, ld=n)
+        pad8 = lambda v: (v + 7) // 8 * 8
+
+        def tr(src, valid, eff, dst, colsum):
+            if pad8(valid) <= 32 and src.dtype in (BF16, F16):     # 16 / 32 data columns in a 64+ wide row: row-per-thread kernel
+                call("sed_transpose_narrow", src, is_f16(src), M, pad8(valid), src.shape[1], dst, Mpad, colsum)
+            else:
+                transpose_bf16(src, M, eff, dst, colsum=colsum, ld=src.shape[1])
+
+        tr(dy16, n_valid, n_eff, gT, csum)
         xT = torch.empty(k, Mpad, dtype=BF16, device=dev)
-        transpose_bf16(x, M, k_eff, xT, ld=k)
+        tr(x, k_valid, k_eff, xT, None)
         gWT = torch.zeros(k, n, device=dev)
         gemm_dw(xT, gT, gWT)
         return gWT, csum
