@@ -1,0 +1,214 @@
+"""Per-kernel parity tests of the PMAM entry points (csrc/pmam.hip + sed_gemm_nt_cols / sed_weight_images): every op called through
+the C ABI against a plain PyTorch fp32 reference of the same op (needs an MI355X)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from transformer4sed_amd.ops import call, gemm_nt_cols, BF16, F16, F32, EPI_F32, EPI_F32_RESID  # noqa: E402
+from test_gpu_kernels import rnd, maxerr, r16, report  # noqa: E402
+
+DEV = "cuda"
+
+
+def test_lora_merge_and_grad():
+    n, k, r, s = 2304, 768, 8, 0.125
+    W, A, Bm = rnd(n, k, seed=1), rnd(r, k, seed=2), rnd(n, r, seed=3)
+    out = torch.empty_like(W)
+    call("sed_lora_merge", W, A, Bm, s, out, n, k, r)
+    assert maxerr(out, W + s * (Bm @ A)) < 2e-5
+    dW = rnd(n, k, seed=4)
+    dA, dB = torch.zeros(r, k, device=DEV), torch.zeros(n, r, device=DEV)
+    call("sed_lora_grad", dW, A, Bm, s, dA, dB, n, k, r)
+    assert maxerr(dB, s * dW @ A.t()) < 2e-3 and maxerr(dA, s * Bm.t() @ dW) < 2e-3
+
+
+@pytest.mark.parametrize("D", [384, 768])
+def test_layernorm_any_width(D):
+    M = 1003
+    x, g, b = rnd(M, D, seed=5), 1 + 0.1 * rnd(D, seed=6), rnd(D, seed=7)
+    y32 = torch.empty(M, D, device=DEV); y16 = torch.empty(M, D, dtype=F16, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    call("sed_ln_fwd_any", x, g, b, 1e-5, 2.5, y16, y32, mean, rstd, M, D, 1)
+    xr = (2.5 * x).clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (D,), g, b, 1e-5)
+    assert maxerr(y32, ref) < 2e-5 and maxerr(y16.float(), ref) < 4e-3
+    dy = rnd(M, D, seed=8)
+    gp, bp = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    xr2 = x.clone().requires_grad_(True)
+    F.layer_norm(2.5 * xr2, (D,), gp, bp, 1e-5).backward(dy)
+    dx = torch.ones(M, D, device=DEV)
+    dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    call("sed_ln_bwd_any", dy, x, mean, rstd, g, 2.5, dx, 1, dg, db, M, D)
+    assert maxerr(dx - 1, xr2.grad) < 5e-5 and maxerr(dg, gp.grad) < 2e-3 and maxerr(db, bp.grad) < 2e-3
+
+
+def test_cnn_branch_kernels_one_layer():
+    """im2col + narrow GEMM + BatchNorm affine + gate + dropout + pooling, forward and backward, against torch ops (16 filters)."""
+    B, H, W, ci, co, Cp, Np = 2, 20, 16, 16, 16, 64, 128
+    Kp = 256
+    x = r16(rnd(B, H, W, ci, seed=9))
+    X = torch.zeros(B, H, W, Cp, dtype=F16, device=DEV); X[..., :ci] = x.to(F16)
+    col = torch.empty(B * H * W, Kp, dtype=F16, device=DEV)
+    call("sed_conv3x3_im2col", X, col, B, H, W, ci, Cp, Kp)
+    ref_col = F.unfold(X[..., :ci].float().permute(0, 3, 1, 2), 3, padding=1).view(B, ci, 9, H * W).permute(0, 3, 2, 1).reshape(B * H * W, 9 * ci)
+    assert maxerr(col[:, :9 * ci].float(), ref_col) == 0.0 and float(col[:, 9 * ci:].abs().max()) == 0.0
+    wc = rnd(co, ci, 3, 3, scale=0.1, seed=10)
+    img = torch.zeros(Np, Kp, device=DEV); img[:co, :9 * ci] = wc.permute(0, 2, 3, 1).reshape(co, 9 * ci)
+    img16 = img.to(F16)
+    bias = torch.zeros(Np, device=DEV); bias[:co] = rnd(co, seed=11)
+    M = B * H * W
+    Y = torch.empty(M, co, device=DEV)
+    gemm_nt_cols(col, img16, EPI_F32, co, bias=bias, outF=Y)
+    conv_ref = F.conv2d(X[..., :ci].float().permute(0, 3, 1, 2), img16[:co, :9 * ci].float().view(co, 3, 3, ci).permute(0, 3, 1, 2), bias[:co],
+                        padding=1).permute(0, 2, 3, 1).reshape(M, co)
+    assert maxerr(Y, conv_ref) < 2e-3
+    # batch statistics
+    s1, s2 = torch.zeros(co, device=DEV), torch.zeros(co, device=DEV)
+    call("sed_colstats", Y, co, None, 0, None, None, s1, s2, M, co, 0)
+    assert maxerr(s1 / M, Y.mean(0)) < 1e-4 and maxerr(s2 / M, (Y * Y).mean(0)) < 1e-3
+    a, b = 0.5 + rnd(co, seed=12).abs(), rnd(co, seed=13)
+    Z = torch.empty(M, Cp, dtype=F16, device=DEV)
+    call("sed_bn_act", Y, co, a, b, Z, M, co, Cp, 1)
+    z = Y * a + b
+    assert maxerr(Z[:, :co].float(), z) < 6e-3 and float(Z[:, co:].abs().max()) == 0.0
+    L = rnd(M, co, seed=14)
+    mask = (torch.rand(M, co, device=DEV) > 0.5).to(torch.uint8)
+    out32 = torch.empty(B * (H // 2) * (W // 2), co, device=DEV)
+    out16 = torch.empty(B, H // 2, W // 2, Cp, dtype=F16, device=DEV)
+    call("sed_cg_pool", Y, co, a, b, L, co, mask, 2.0, out16, out32, B, H, W, co, Cp, 2, 2, 1)
+    gated = (z * torch.sigmoid(L) * mask * 2.0).view(B, H, W, co).permute(0, 3, 1, 2)
+    ref_pool = F.avg_pool2d(gated, 2).permute(0, 2, 3, 1).reshape(-1, co)
+    assert maxerr(out32, ref_pool) < 1e-5 and maxerr(out16[..., :co].float().reshape(-1, co), ref_pool) < 4e-3
+    # backward of gate * dropout * pooling
+    dout = rnd(B * (H // 2) * (W // 2), co, seed=15)
+    zz, LL = z.clone().requires_grad_(True), L.clone().requires_grad_(True)
+    (F.avg_pool2d((zz * torch.sigmoid(LL) * mask * 2.0).view(B, H, W, co).permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).reshape(-1, co) * dout).sum().backward()
+    dzd = torch.empty(M, co, device=DEV); dL16 = torch.empty(M, Np, dtype=BF16, device=DEV)
+    call("sed_cg_pool_bwd", dout, Y, co, a, b, L, co, mask, 2.0, dzd, co, dL16, Np, B, H, W, co, 2, 2)
+    assert maxerr(dzd, zz.grad) < 1e-5 and maxerr(dL16[:, :co].float(), LL.grad) < 5e-3 * max(1.0, float(LL.grad.abs().max())) and float(dL16[:, co:].float().abs().max()) == 0.0
+    # BatchNorm backward with batch statistics
+    mean, var = Y.mean(0), Y.var(0, unbiased=False)
+    rstd = torch.rsqrt(var + 1e-3)
+    gam = 1 + 0.1 * rnd(co, seed=16)
+    Yr = Y.clone().requires_grad_(True)
+    dz = rnd(M, co, seed=17)
+    (((Yr - Yr.mean(0)) * torch.rsqrt(Yr.var(0, unbiased=False) + 1e-3)) * gam).backward(dz)
+    ah, bh = rstd.contiguous(), (-mean * rstd).contiguous()
+    t1, t2 = torch.zeros(co, device=DEV), torch.zeros(co, device=DEV)
+    call("sed_colstats", dz, co, Y, co, ah, bh, t1, t2, M, co, 1)
+    dY16 = torch.empty(M, Np, dtype=BF16, device=DEV)
+    call("sed_bn_bwd", dz, co, Y, co, ah, bh, gam, t1, t2, dY16, Np, M, co)
+    assert maxerr(dY16[:, :co].float(), Yr.grad) < 2e-2 * float(Yr.grad.abs().max())
+    # col2im = transpose of the gather
+    dcol = r16(rnd(M, Kp, seed=18)).to(BF16)
+    dX = torch.empty(B, H, W, ci, device=DEV)
+    call("sed_col2im3x3", dcol, Kp, dX, B, H, W, ci)
+    ref_dx = F.fold(dcol[:, :9 * ci].float().view(B, H * W, 9, ci).permute(0, 3, 2, 1).reshape(B, ci * 9, H * W), (H, W), 3, padding=1)
+    assert maxerr(dX, ref_dx.permute(0, 2, 3, 1)) < 1e-4
+    # narrow transpose (+ column sums)
+    outT = torch.full((16, 704), 7.0, dtype=BF16, device=DEV)
+    cs = torch.zeros(16, device=DEV)
+    call("sed_transpose_narrow", dL16, 0, M, 16, Np, outT, 704, cs)
+    assert torch.equal(outT[:, :M], dL16[:, :16].t()) and float(outT[:, M:].float().abs().max()) == 0.0
+    assert maxerr(cs, dL16[:, :16].float().sum(0)) < 1e-2
+
+
+def test_conv0_im2col_and_fpool_attention_and_merge():
+    B, T = 2, 40
+    mel = rnd(B, 128, T, seed=19)
+    col = torch.empty(B * T * 128, 64, dtype=F16, device=DEV)
+    call("sed_conv0_im2col", mel, col, B, T, 1)
+    ref = F.unfold(mel.transpose(1, 2).unsqueeze(1), 3, padding=1).transpose(1, 2).reshape(B * T * 128, 9)
+    assert maxerr(col[:, :9].float(), ref.to(F16).float()) == 0.0 and float(col[:, 9:].abs().max()) == 0.0
+    # attention pooling over the 12 frequency tokens (6 heads of 128)
+    tp = 7
+    N = 2 + 12 * tp
+    kv = r16(rnd(B * N, 1536, seed=20)).to(F16)
+    q = rnd(768, seed=21)
+    out32 = torch.empty(B * tp, 768, device=DEV); probs = torch.empty(B * tp, 6, 12, device=DEV)
+    call("sed_fpool_attn_fwd", kv, q, None, out32, probs, B, N, tp, 1)
+    kvf = kv.float().view(B, N, 1536)[:, 2:].reshape(B, 12, tp, 1536).permute(0, 2, 1, 3).requires_grad_(True)      # [B, tp, 12, 1536]
+    qq = q.clone().requires_grad_(True)
+    k, v = kvf[..., :768].reshape(B, tp, 12, 6, 128), kvf[..., 768:].reshape(B, tp, 12, 6, 128)
+    sc = torch.einsum("hd,btfhd->bthf", qq.view(6, 128), k) / math.sqrt(128)
+    pr = torch.softmax(sc, -1)
+    ref = torch.einsum("bthf,btfhd->bthd", pr, v).reshape(B * tp, 768)
+    assert maxerr(out32, ref) < 1e-4 and maxerr(probs, pr.reshape(B * tp, 6, 12)) < 1e-5
+    dout = rnd(B * tp, 768, seed=22)
+    (ref * dout).sum().backward()
+    dkv = torch.empty(B * N, 1536, dtype=BF16, device=DEV); dq = torch.zeros(768, device=DEV)
+    call("sed_fpool_attn_bwd", kv, q, probs, dout, dkv, dq, B, N, tp, 1)
+    got = dkv.float().view(B, N, 1536)
+    assert float(got[:, :2].abs().max()) == 0.0
+    want = kvf.grad.permute(0, 2, 1, 3).reshape(B, 12 * tp, 1536)
+    assert maxerr(got[:, 2:], want) < 1e-2 * float(want.abs().max()) + 1e-3 and maxerr(dq, qq.grad) < 2e-3
+    # projector merge
+    C, tp1, tp2 = 384, 99, 250
+    P1, P2, mw = rnd(B, tp1, C, seed=23).requires_grad_(True), rnd(B, tp2, C, seed=24).requires_grad_(True), torch.tensor([0.7], device=DEV, requires_grad=True)
+    out = torch.empty(B, 1000, C, device=DEV)
+    call("sed_pmam_merge", P1.detach(), P2.detach(), mw.detach(), out, B, tp1, 1, 10, tp2, 4, C)
+    up = lambda t, n: F.interpolate(t.transpose(1, 2), size=n, mode="linear").transpose(1, 2)
+    ref = up(torch.cat([P1, P1[:, -1:]], 1), 1000) + mw * up(P2, 1000)
+    assert maxerr(out, ref) < 1e-5
+    g = rnd(B, 1000, C, seed=25)
+    (ref * g).sum().backward()
+    d1, d2, dm = torch.empty(B, tp1, C, device=DEV), torch.empty(B, tp2, C, device=DEV), torch.zeros(1, device=DEV)
+    call("sed_pmam_merge_bwd", g, P2.detach(), mw.detach(), d1, d2, dm, B, tp1, 1, 10, tp2, 4, C)
+    assert maxerr(d1, P1.grad) < 1e-4 and maxerr(d2, P2.grad) < 1e-4 and abs(float(dm) - float(mw.grad)) < 2e-2 * abs(float(mw.grad)) + 1e-2
+
+
+def test_proto_bce_and_mlm_apply_c():
+    B, T, C, D = 2, 50, 30, 768
+    logit = rnd(B, T, D, seed=26).requires_grad_(True)
+    protos = F.normalize(rnd(C, D, seed=27) + 0.3 * logit.detach()[0, :C], dim=-1)     # some prototypes aligned with some frames
+    labels = (torch.rand(B, C, T, device=DEV) > 0.7).float()
+    sel = torch.rand(B * T, device=DEV) > 0.3
+    z = F.leaky_relu(F.normalize(logit, dim=-1) @ protos.t(), 0.2) * 2 - 1
+    p = torch.sigmoid(z / 0.1)
+    ref = F.binary_cross_entropy(p.view(B * T, C)[sel], labels.transpose(1, 2).reshape(B * T, C)[sel])
+    ref.backward()
+    loss, dl, post = torch.zeros(1, device=DEV), torch.empty(B, T, D, device=DEV), torch.empty(B * T, C, device=DEV)
+    n_dev = sel.sum(dtype=torch.int32).reshape(1)
+    call("sed_proto_bce", logit.detach(), protos, labels, sel.to(torch.uint8), 0, n_dev, 0.1, loss, dl, post, B, T, C, D)
+    assert abs(float(loss) - float(ref)) < 2e-5 * float(ref) + 1e-6
+    assert maxerr(post[sel], p.view(B * T, C)[sel].detach()) < 2e-5 and float(post[~sel].abs().max()) == 0.0
+    assert maxerr(dl, logit.grad) < 2e-3 * float(logit.grad.abs().max()) + 1e-8
+    # masking rows of width 384
+    rows, Cw = 300, 384
+    x, tok = rnd(rows, Cw, seed=28), rnd(Cw, seed=29)
+    action = torch.randint(0, 3, (rows,), device=DEV, dtype=torch.uint8)
+    src = torch.randint(0, rows, (rows,), device=DEV, dtype=torch.int32)
+    out = torch.empty(rows, Cw, device=DEV)
+    call("sed_mlm_apply_c", x, tok, action, src, out, rows, Cw)
+    ref = x.clone(); ref[action == 1] = tok; ref[action == 2] = x[src.long()[action == 2]]
+    assert torch.equal(out, ref)
+    dout = rnd(rows, Cw, seed=30)
+    dx, dtok = torch.zeros(rows, Cw, device=DEV), torch.zeros(Cw, device=DEV)
+    call("sed_mlm_apply_bwd_c", dout, action, src, dx, dtok, rows, Cw)
+    dref = torch.zeros(rows, Cw, device=DEV); dref[action == 0] = dout[action == 0]
+    dref.index_add_(0, src.long()[action == 2], dout[action == 2])
+    assert maxerr(dx, dref) < 1e-5 and maxerr(dtok, dout[action == 1].sum(0)) < 2e-3
+
+
+def test_weight_images_one_launch():
+    """sed_weight_images = per-weight transpose / cast / split-precision images, for several weights at once."""
+    from transformer4sed_amd.ops import h2d, split3, transpose_bf16
+    shapes = [(768, 256), (2304, 768), (384, 1152), (48, 64)]
+    ws = [rnd(n, k, scale=0.3, seed=31 + i) for i, (n, k) in enumerate(shapes)]
+    rows, outs, tiles = [], [], 0
+    for w in ws:
+        n, k = w.shape
+        wt, wsr, wsp = torch.empty(k, n, dtype=BF16, device=DEV), torch.empty(n, k, dtype=F16, device=DEV), torch.empty(n, 3 * k, dtype=F16, device=DEV)
+        outs.append((wt, wsr, wsp))
+        rows.append([w.data_ptr(), wt.data_ptr(), wsr.data_ptr(), wsp.data_ptr(), n, k, 2, tiles])
+        tiles += ((n + 63) // 64) * (k // 64)
+    desc = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    call("sed_weight_images", desc, len(rows), tiles)
+    for w, (wt, wsr, wsp) in zip(ws, outs):
+        n, k = w.shape
+        assert torch.equal(wsr, w.to(F16)) and torch.equal(wt, w.t().to(BF16))
+        assert torch.equal(wsp, split3(w, n, k, weight=True))

@@ -2,6 +2,7 @@
 // pooling + x10 linear interpolation (+ sliding-window merge), classifier/pooling heads, attention-pooling
 // AT head, MLM masking and loss, fused AdamW + EMA.  All fp32 math; bf16 only as GEMM-operand outputs.
 // Wave64: one wavefront per 768-wide row, 12 channels per lane held as 3 x float4, shuffle reductions.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/sed_hip.h"
 
@@ -38,35 +39,40 @@ __device__ __forceinline__ const float& f4(const float4& v, int c) { return rein
 // load -> 2 wave reductions -> store).  A persistent grid-stride variant (gamma / beta fetched once per wave) looked 2x faster in
 // a warm-cache loop but is slower on cold input (70 vs 56 us at M = 38080, tools/ln_bench.py) -- in the step the input was just
 // written with non-temporal stores, so the one-shot grid below is what ships.
+template <int RW>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, float in_scale,
                                                             bf16_t* __restrict__ y16, float* __restrict__ y32,
                                                             float* __restrict__ mean, float* __restrict__ rstd, int M, int f16) {
     const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
     if (row0 >= M) return;
-    const bool two = row0 + 1 < M;
-    Row r[2], g, b;
-    row_load(r[0], x + (size_t)row0 * DM, lane);
-    row_load(r[1], x + (size_t)(two ? row0 + 1 : row0) * DM, lane);
+    Row r[RW], g, b;
+#pragma unroll
+    for (int k = 0; k < RW; ++k) row_load(r[k], x + (size_t)(row0 + k < M ? row0 + k : row0) * DM, lane);
     row_load(g, gamma, lane);
     row_load(b, beta, lane);
-    float s[2] = {0.f, 0.f};
+    float s[RW], mu[RW], q[RW], rs[RW];
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < RW; ++k) {
+        s[k] = 0.f;
 #pragma unroll
         ROW_FOREACH(i, c) { f4(r[k].v[i], c) *= in_scale; s[k] += f4(r[k].v[i], c); }
-    const float mu[2] = {wave_sum(s[0]) * (1.0f / DM), wave_sum(s[1]) * (1.0f / DM)};
-    float q[2] = {0.f, 0.f};
+    }
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < RW; ++k) mu[k] = wave_sum(s[k]) * (1.0f / DM);
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+        q[k] = 0.f;
 #pragma unroll
         ROW_FOREACH(i, c) { const float d = f4(r[k].v[i], c) - mu[k]; q[k] += d * d; }
-    const float rs[2] = {rsqrtf(wave_sum(q[0]) * (1.0f / DM) + eps), rsqrtf(wave_sum(q[1]) * (1.0f / DM) + eps)};
+    }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        if (k == 1 && !two) break;
+    for (int k = 0; k < RW; ++k) rs[k] = rsqrtf(wave_sum(q[k]) * (1.0f / DM) + eps);
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
         const int row = row0 + k;
+        if (row >= M) break;
 #pragma unroll
         ROW_FOREACH(i, c) f4(r[k].v[i], c) = (f4(r[k].v[i], c) - mu[k]) * rs[k] * f4(g.v[i], c) + f4(b.v[i], c);
         if (y16 != nullptr) row_store_bf16(r[k], y16 + (size_t)row * DM, lane, f16);
@@ -79,8 +85,16 @@ extern "C" int sed_layernorm_fwd(const float* x, const float* gamma, const float
                                  void* y_bf16, float* y_f32, float* mean, float* rstd, int M, int D, int f16, hipStream_t stream) {
     (void)hipGetLastError();
     if (D != DM || M <= 0) return SED_ERR_ARG;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(M, 8)), dim3(256), 0, stream, x, gamma, beta, eps, in_scale,
-                       (bf16_t*)y_bf16, y_f32, mean, rstd, M, f16);
+    static const int rw = []() { const char* e = getenv("SED_LN_RW"); return e ? atoi(e) : 2; }();
+    if (rw == 4)
+        hipLaunchKernelGGL(layernorm_fwd_kernel<4>, dim3(cdiv(M, 16)), dim3(256), 0, stream, x, gamma, beta, eps, in_scale,
+                           (bf16_t*)y_bf16, y_f32, mean, rstd, M, f16);
+    else if (rw == 1)
+        hipLaunchKernelGGL(layernorm_fwd_kernel<1>, dim3(cdiv(M, 4)), dim3(256), 0, stream, x, gamma, beta, eps, in_scale,
+                           (bf16_t*)y_bf16, y_f32, mean, rstd, M, f16);
+    else
+        hipLaunchKernelGGL(layernorm_fwd_kernel<2>, dim3(cdiv(M, 8)), dim3(256), 0, stream, x, gamma, beta, eps, in_scale,
+                           (bf16_t*)y_bf16, y_f32, mean, rstd, M, f16);
     return sed_check_launch();
 }
 
