@@ -57,6 +57,14 @@ def _eval_vs_golden(golden, tag, depth, fl, B):
     close(other["at_out"], g["ev_at_out"], 1e-3, what="AT head")
     close(pred[S], g["ev_pred_s"], 8e-3, 2e-3, what="MLM logits")
     gmm = torch.from_numpy(synth.det_normal("pmam/gmm_means", (30, 768)))
+    # validation loss of the PMAM trainer (masked and not padded frames), HIP loss kernel vs the reference's value
+    from transformer4sed_amd.pmam_trainer import PmamTrainer
+    tr = PmamTrainer(net, None, None, gmm, {})
+    pm = torch.zeros(B, 1000, dtype=torch.bool)
+    pm[0, 900:] = True
+    labels = torch.from_numpy(synth.synth_strong_labels(B, n_classes=30, seed=500)).cuda()
+    vloss = float(tr.validation_loss(pred, other, labels, pm.cuda()))
+    assert abs(vloss - float(g["ev_val_loss"])) < 2e-3 * float(g["ev_val_loss"]), (vloss, float(g["ev_val_loss"]))
     strong = PO.prototype_posteriors(pred.cpu(), gmm)
     err = float((strong[:, ::25] - torch.from_numpy(g["ev_strong_s"])).abs().max())
     print(f"{tag}: prototype posterior max err {err:.2e}")

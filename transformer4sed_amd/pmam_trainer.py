@@ -128,6 +128,19 @@ class PmamTrainer:
             loss_weak = self.bce(other["at_out"], (labels.sum(-1) >= 1).float())
         return loss_strong, loss_weak, loss_strong + tr["w_AT"] * loss_weak
 
+    @torch.no_grad()
+    def validation_step(self, wav, labels, pad_mask):
+        """Per-batch body of `Trainer.validation` (pmam/train.py:145-159): eval-mode frontend and model, prototype BCE over the
+        frames that are masked AND not padded.  Returns the batch loss (device tensor)."""
+        self.net.eval()
+        mel = self.net.get_feature_extractor().logmel(wav)
+        logit, other = self.net(mel, pad_mask=pad_mask, **self.cfg[self.net.get_model_name()]["val_kwargs"])
+        return self.validation_loss(logit, other, labels, pad_mask)
+
+    def validation_loss(self, logit, other, labels, pad_mask):
+        sel = torch.logical_and(torch.logical_not(pad_mask.to(logit.device)), other["mask_id_seq"])
+        return ProtoBCE.apply(logit, self.protos, labels, sel.reshape(-1), 0.1)
+
     def step(self, wav, labels):
         """One optimisation step (pmam/train.py:96-132; its clip_grad_norm_ before backward acts on cleared grads: a no-op)."""
         self.net.train()
