@@ -266,10 +266,11 @@ class PmamEngine(SedEngine):
             qu, k = [E(B * H, T, 64, dt=A16) for _ in range(2)]
             v = E(B * H, T, 64, dt=B16)
             qv = E(B * H, T, 64, dt=A16)
-            vt = torch.zeros(B * H, 64, Tpad, dtype=A16, device=dev)
+            use_pool = getattr(self, "_lease_ok", False) or not save
+            vt = self._zeros(("dec_vt", li, B, Tpad), (B * H, 64, Tpad), A16, dev, use_pool)
             qut = kt = qvt = None
             if save:
-                qut, kt, qvt = [torch.zeros(B * H, 64, Tpad, dtype=B16, device=dev) for _ in range(3)]
+                qut, kt, qvt = [self._zeros(("dec", li, j, B, Tpad), (B * H, 64, Tpad), B16, dev, use_pool) for j in range(3)]
             call("sed_gemm_qkv", yop, W[p + "attn.in_proj.weight"].ws, aux["bin"], M, 3 * Dd, H, T, Tpad, qu, k, v, qut, kt, vt, qv, qvt,
                  aux["u"], aux["v"], 3 if save else 1)
             o32 = E(M, Dp)
@@ -304,6 +305,7 @@ class PmamEngine(SedEngine):
         assert Fm == 128 and T == 1000
         Dd = m.decoder_dim
         W = self._weights(need_t=save)
+        lease = self._lease(save)
         E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
         out = {}
         tp = 99
@@ -389,7 +391,8 @@ class PmamEngine(SedEngine):
         ctx = None
         if save:
             ctx = dict(B=B, T=T, tp=tp, Tdec=Tdec, ectx=ectx, dctx=dctx, actx=actx, cctx=cctx, xd=xd, W=W, pooled=pooled, feat=feat, P1=P1,
-                       P2=P2, hctx=hctx, mlm_plan=plan if (plan is not None and plan["effective"]) else None)
+                       P2=P2, hctx=hctx, mlm_plan=plan if (plan is not None and plan["effective"]) else None, lease=lease)
+        self._lease_ok = False
         return out, ctx
 
     # ==================================================================== backward
@@ -496,7 +499,7 @@ class PmamEngine(SedEngine):
             Dtmp = E(B * H, T)
             dOh = E(B * H, T, 64, dt=BF16)
             dOt = E(B * H, 64, Tpad, dt=BF16)
-            dSt = Z(B * H, Tpad, Tpad, dt=BF16)
+            dSt = self._zeros(("dSt", B, Tpad), (B * H, Tpad, Tpad), BF16, dev)
             dP = Z(Rpad, Dp)
             duv = Z(2, Dp)
             call("sed_relpos_attn_bwd", L["qu"], to_bf16_(L["qut"]), L["qv"], to_bf16_(L["qvt"]), L["k"], to_bf16_(L["kt"]),
