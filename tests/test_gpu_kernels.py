@@ -169,10 +169,14 @@ def test_gemm_dw_tn(T, M, N, XDT):
     dW = rnd(M, N, seed=23).contiguous()
     # a half-precision X is rounded to bf16 in registers (the gradient-side MFMA is bf16): the reference does the same rounding
     want = dW + dY.float().t() @ X.float().to(BF16).float()
-    ops.gemm_dw_tn(dY, X, dW)
+    db = rnd(M, seed=24).contiguous()
+    want_b = db + dY.float().sum(0)
+    ops.gemm_dw_tn(dY, X, dW, dbias=db)      # the bias gradient (column sums of dY) comes out of the same launch
     e = float(((dW - want).abs() / (want.abs() + 1.0)).max())
     report(f"gemm_dw_tn T={T} M={M} N={N} X={'f16' if XDT == F16 else 'bf16'}", e)
     assert e < 1e-3 * (T / 1024) ** 0.5 + 1e-4
+    eb = float(((db - want_b).abs() / (want_b.abs() + 1.0)).max())
+    assert eb < 2e-4 * (T / 1024) ** 0.5 + 1e-5, eb
 
 
 @pytest.mark.parametrize("B,N", [(2, 70), (2, 602)])   # 128^2 kernel (M < 1024) and the 256^2 kernel with its staged epilogue

@@ -1336,6 +1336,7 @@ struct TnArgs {
     const bf16_t* B;  // X  [T, ldb]  bf16 or f16
     float* C;         // dW [M, ldc]  fp32 (accumulated)
     float* ws;        // optional split-K workspace [ksplit][M][N] fp32 (plain stores + a reduce pass instead of atomics)
+    float* dbias;     // optional: dbias[m] += sum_t dY[t, m] (the bias gradient of the same linear), taken from the dY fragments
     int M, N, T, lda, ldb, ldc, ksplit, b_f16;
 };
 template <int OFF>
@@ -1407,6 +1408,10 @@ __global__ __launch_bounds__(512) void gemm_tn_dw_kernel(const TnArgs g) {
         const int col = wn * 64 + j * 32 + (G & 1) * 16 + 4 * (a & 3);
         baddr[j] = lbase + 32768 + (8 * kg + (a >> 2)) * 512 + (((col >> 5) ^ (a >> 2)) << 6) + (col & 31) * 2;
     }
+    // bias gradient: the workgroups of the first N tile also sum their dY fragments over the tokens -- wave (wm, wn) owns the 32
+    // features of fragment i = wn (a lane holds 8 tokens of one feature); VALU work that rides under the MFMAs
+    const bool do_bias = g.dbias != nullptr && n0 == 0;
+    float colacc = 0.f;
     if (nk > 0) { TN_DMA(0, 0); }
     for (int it = 0; it < nk; ++it) {
         const int stage = it & 1;
@@ -1432,6 +1437,15 @@ __global__ __launch_bounds__(512) void gemm_tn_dw_kernel(const TnArgs g) {
             _Pragma("unroll") for (int j = 0; j < 2; ++j) bf_[j] = tn_frag(bl[j], bh[j], !BF16_B);                         \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mfma32t<false>(bf_[j], af[i], acc[i][j]);        \
+            if (do_bias) {                                                                                                 \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
+                    if (wn == i) {                                                                                         \
+                        unsigned w4[4];                                                                                    \
+                        __builtin_memcpy(w4, &af[i], 16);                                                                  \
+                        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                      \
+                            colacc += __uint_as_float(w4[e] << 16) + __uint_as_float(w4[e] & 0xffff0000u);                 \
+                    }                                                                                                      \
+            }                                                                                                              \
         }
         // fragment reads run one k-step ahead of the MFMAs (12 transposing reads per k-step; lgkmcnt counts them in order)
         unsigned long long pal[4], pah[4], pbl[2], pbh[2], qal[4], qah[4], qbl[2], qbh[2];
@@ -1450,6 +1464,10 @@ __global__ __launch_bounds__(512) void gemm_tn_dw_kernel(const TnArgs g) {
 #undef TN_READS
 #undef TN_WAIT
 #undef TN_MFMA
+    }
+    if (do_bias) {
+        colacc += __shfl_xor(colacc, 32, 64);      // the two token halves of the fragment
+        if (lane < 32) unsafeAtomicAdd(&g.dbias[m0 + wm * 128 + wn * 32 + lane], colacc);
     }
     __builtin_amdgcn_s_barrier();
     // Split-K partial sums.  With a workspace: plain coalesced stores of the tile into ws[split] (a reduce pass adds the splits
@@ -1503,11 +1521,11 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 }
 
 extern "C" int sed_gemm_dw_tn(const void* dY, const void* X, int x_f16, int T, int M, int N, int ldy, int ldx, float* dW,
-                              int ldc, float* workspace, int64_t workspace_bytes, hipStream_t stream) {
+                              int ldc, float* dbias, float* workspace, int64_t workspace_bytes, hipStream_t stream) {
     (void)hipGetLastError();
     if (T <= 0 || (T % BK) || (M % V3_T) || (N % V3_T) || (ldy % 8) || (ldx % 8) || (ldc % 4) || M <= 0 || N <= 0) return SED_ERR_ARG;
     TnArgs g;
-    g.A = (const bf16_t*)dY; g.B = (const bf16_t*)X; g.C = dW;
+    g.A = (const bf16_t*)dY; g.B = (const bf16_t*)X; g.C = dW; g.dbias = dbias;
     g.M = M; g.N = N; g.T = T; g.lda = ldy; g.ldb = ldx; g.ldc = ldc; g.b_f16 = x_f16;
     const int tiles = (M / V3_T) * (N / V3_T), ktiles = T / BK;
     // one workgroup per CU and ONE round: tiles * ks <= 256 (rounding the split count up instead costs a second, nearly empty

@@ -583,11 +583,14 @@ class SedEngine:
         tn = self.dw_tn and Mt >= 1024 and dw_tn_ok(Mt, n_out, k_in) and x.dtype in (F16, BF16)
         if tn:
             g16 = E(M, n_out, dt=BF16) if dy.dtype == F32 else None
-            if g16 is not None or bias is not None:
+            # bias gradient: with a 16-bit dy the TN kernel sums its own dY fragments (no extra pass over dy); an fp32 dy needs the
+            # cast pass anyway, which also yields the column sums
+            bias_in_gemm = g16 is None and bias is not None and gW is not None and Mt == M and os.environ.get("SED_TN_BIAS", "1") != "0"
+            if g16 is not None or (bias is not None and not bias_in_gemm):
                 transpose_bf16(dy, M, n_out, None, out_s=g16, colsum=bias)   # cast and/or column sums only, one pass
             dy16 = g16 if g16 is not None else dy
             if gW is not None:
-                gemm_dw_tn(dy16, x, gW, tokens=Mt)
+                gemm_dw_tn(dy16, x, gW, tokens=Mt, dbias=bias if bias_in_gemm else None)
                 if Mt < M:
                     gT, xT = E(n_out, 64, dt=BF16), E(k_in, 64, dt=BF16)
                     transpose_bf16(dy16[Mt:], M - Mt, n_out, gT)
