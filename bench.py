@@ -337,11 +337,16 @@ def main():
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("avg_bytes_per_launch")
             traffic_src = "profiles/r1_gemm_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE passes over this command)"
+        mpath = os.path.join(ROOT, "profiles", "r1_gemm_mfma_busy.json")   # PMC pass (tools/mfma_util.py), offline
+        mfma_busy = json.load(open(mpath)).get("family_busy_fraction") if os.path.exists(mpath) else None
         line["roofline"] = {"kernel": "gemm_nt_v3_kernel<EPI,F16> / gemm_tn_dw_kernel / gemm_nt_kernel (all GEMM launches of the step: "
                                       "linears, qkv, dX, split-K dW)",
                             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
-                            "traffic_source": traffic_src, "alg_bytes_per_launch": round(by / max(1, n)),
+                            "traffic_source": traffic_src,
+                            "mfma_pipe_busy": mfma_busy, "mfma_pipe_busy_source": "profiles/r1_gemm_mfma_busy.json (rocprofv3 "
+                            "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) over this command, at the running clock)",
+                            "alg_bytes_per_launch": round(by / max(1, n)),
                             "launches_per_step": n // timed_steps_with_events, "avg_launch_ms": round(ms / max(1, n), 4),
                             "instrumented_steps": f"{timed_steps_with_events} of the {a.steps} timed steps",
                             "gemm_share_of_step": round(ms / timed_steps_with_events / (1000 * dt / a.steps), 3),
