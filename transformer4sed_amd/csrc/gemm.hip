@@ -1206,6 +1206,112 @@ __device__ __forceinline__ void v5_epilogue(const GemmArgs& g, const f32x16_t (&
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// v8 (experiment, SED_GEMM_V8=1): TWO workgroups per CU.  The 256 x 256 / 8-wave kernel above owns its CU alone (246 VGPRs x 2 waves
+// per SIMD, 128 KB of LDS), so a tile's epilogue -- stores, GELU, residual reads -- never overlaps another tile's MFMAs; MFMA-pipe
+// busy is 34 % on the K = 768 shapes.  Here a workgroup is 4 waves (one per SIMD) on a 128 x 256 tile with the same 128 x 64
+// accumulator block per wave and the same staged epilogue; one 48 KB operand stage (A 128 rows | B 256 rows of 128 B) that doubles
+// as the epilogue staging area (4 x 17 KB) keeps the footprint at 68 KB, so two workgroups are co-resident and cover each other's
+// DMA waits, barriers and epilogues.
+// ---------------------------------------------------------------------------------------------------------------------
+#define V8_LDS (4 * V3_WLDS)
+template <int EPI, bool F16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_v8_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave;
+    const int ntn = g.N / V3_T, ntm = (g.M + 127) / 128, nwg = ntm * ntn;
+    if (g.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+        // the second workgroup of every CU starts late, so that the two co-resident workgroups are in different phases (one in its
+        // K loop while the other stores): launched together they would run in lock step and reach their epilogues together
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (unsigned long long)g.stagger) __builtin_amdgcn_s_sleep(32);
+    }
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int group_size = 8 * ntn, gid = t / group_size, first_m = gid * 8;
+    const int gm = (ntm - first_m) < 8 ? (ntm - first_m) : 8;
+    const int tin = t - gid * group_size;
+    const int m0 = (first_m + tin % gm) * 128, n0 = (tin / gm) * V3_T;
+    const int nk = g.K / BK;
+    // DMA: 16 (A) + 32 (B) pieces of 8 rows x 128 B; wave w owns pieces 12 w .. 12 w + 11
+    const int prow = lane >> 3, pch = lane & 7;
+    const bf16_t* src[12];
+    int dst[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int p = wave * 12 + i;
+        const bool isB = p >= 16;
+        const int q = isB ? p - 16 : p;
+        const int row = q * 8 + prow;
+        const int cl = pch ^ ((row >> 1) & 7);
+        int am = m0 + row;
+        am = am < g.M ? am : g.M - 1;
+        src[i] = isB ? g.B + (size_t)(n0 + row) * g.ldb + cl * 8 : g.A + (size_t)am * g.lda + cl * 8;
+        dst[i] = (isB ? 16384 : 0) + q * 1024;
+    }
+#define V8_DMA(kt)                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 12; ++i)                                                                        \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)(kt) * BK),     \
+                                         (__attribute__((address_space(3))) void*)(lds3 + dst[i]), 16, 0, 0);
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int lr = lane & 31, lg = lane >> 5;
+    int aoff[4], boff[2], aswz[4], bswz[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int r = i * 32 + lr; aoff[i] = r * 128; aswz[i] = (r >> 1) & 7; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int r = wn * 64 + j * 32 + lr; boff[j] = 16384 + r * 128; bswz[j] = (r >> 1) & 7; }
+    V3Consts<EPI> cc;
+    v3_load_consts<EPI>(cc, g, n0 + wn * 64, lane);
+    s16x8_t af[2][4], bfr[2][2];
+#define V8_FRAGS(SET, KS)                                                                                                 \
+    {                                                                                                                     \
+        const int ch_ = 2 * (KS) + lg;                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                     \
+            af[SET][i] = *reinterpret_cast<const s16x8_t*>(lds3 + aoff[i] + ((ch_ ^ aswz[i]) << 4));                      \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                     \
+            bfr[SET][j] = *reinterpret_cast<const s16x8_t*>(lds3 + boff[j] + ((ch_ ^ bswz[j]) << 4));                     \
+    }
+    if (nk > 0) {
+        V8_DMA(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        V8_FRAGS(0, 0);
+    }
+    for (int it = 0; it < nk; ++it) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s < 3) {
+                V8_FRAGS(nxt, s + 1);
+            } else if (it + 1 < nk) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my last fragments of this tile are in registers
+                __builtin_amdgcn_s_barrier();                         // ... and everybody's: the stage can be overwritten
+                V8_DMA(it + 1);                                       // lands under the 8 MFMAs below (and the other workgroup)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32t<F16>(bfr[cur][j], af[cur][i], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s == 3 && it + 1 < nk) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                V8_FRAGS(nxt, 0);
+            }
+        }
+    }
+#undef V8_FRAGS
+#undef V8_DMA
+    __builtin_amdgcn_s_barrier();  // every wave is done reading the operand stage: LDS becomes the per-wave C staging area
+    v3_epilogue<EPI, F16>(g, acc, cc, lds3 + wave * V3_WLDS, m0, n0 + wn * 64, lane);
+}
+
 template <int EPI, bool F16>
 __global__ __launch_bounds__(512) void gemm_nt_v5_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
@@ -1583,6 +1689,23 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
         const bool fits32 = (long long)g.M * g.lda < (1LL << 31) && (long long)g.N * g.ldb < (1LL << 31);
         // 4-wave / 128x128-per-wave / four 32-deep stages: measured slower than v3 (1009 vs 1089 TFLOP/s at 8192^3, fc1 0.344 vs
         // 0.301 ms): neither fewer LDS fragment reads nor two K tiles in flight move the ~2 us per 256x256x64 step.  Opt-in.
+        static const int v8 = []() { const char* e = getenv("SED_GEMM_V8"); return (e != nullptr && e[0] == '1') ? 1 : 0; }();
+        if (v8 && EPI != EPI_ATOMIC && (long long)g.M * g.lda < (1LL << 31) && (long long)g.N * g.ldb < (1LL << 31)) {
+            dim3 grid8(cdiv(g.M, 128) * (g.N / V3_T));
+            static bool attr8[2] = {false, false};
+            static const float st8 = []() { const char* e = getenv("SED_V8_STAGGER_US"); return e ? (float)atof(e) : 0.f; }();
+            GemmArgs g8 = g;
+            g8.stagger = (int)(st8 * 100.f);     // wall-clock ticks of 10 ns
+            const GemmArgs& g = g8;
+            if (f16) {
+                if (!attr8[1]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v8_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V8_LDS); attr8[1] = true; }
+                hipLaunchKernelGGL((gemm_nt_v8_kernel<EPI, true>), grid8, dim3(256), V8_LDS, s, g);
+            } else {
+                if (!attr8[0]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v8_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, V8_LDS); attr8[0] = true; }
+                hipLaunchKernelGGL((gemm_nt_v8_kernel<EPI, false>), grid8, dim3(256), V8_LDS, s, g);
+            }
+            return sed_check_launch();
+        }
         static const int v7 = []() { const char* e = getenv("SED_GEMM_V7"); return (e != nullptr && e[0] == '1') ? 1 : 0; }();
         if (v7 && fits32) {
             static bool attr7[2] = {false, false};
