@@ -82,53 +82,73 @@ class PmamEngine(SedEngine):
             if n.startswith("mlm_mlp") and not m.mlm:
                 continue
             self._image(n, self.P(n).detach(), split=True)
-        # context network: heads zero-padded from hd to 64 in the images
+        # context network: heads zero-padded from hd to 64 in the images; CNN branch: conv weight [co, ci, 3, 3] -> [pad128(co), Kp]
+        # with column = tap * ci + c, gate weight [co, co] -> [pad128(co), Cp].  Every padded image is a gather of the fp32 master with
+        # a per-element scale (0 on the padding, sqrt(2) on the K / P rows): the (index, scale) pair is derived ONCE by running the
+        # padding expression on an enumeration of the source elements, after which an image costs two launches per step.
         def rows(w, scale=1.0):      # [H*hd, K] -> [H*64, K]
             o = w.new_zeros(H, HD_PAD, w.shape[1])
             o[:, :hd] = w.view(H, hd, -1) * scale
             return o.view(H * HD_PAD, -1)
+
         def vec(b, scale=1.0):
             o = b.new_zeros(H, HD_PAD)
             o[:, :hd] = b.view(H, hd) * scale
             return o.view(-1)
+
+        def pad2(w, R, C):
+            o = w.new_zeros(R, C)
+            o[:w.shape[0], :w.shape[1]] = w
+            return o
+
+        exprs = {
+            "win": lambda w, k: torch.cat([rows(w[:Dd]), rows(w[Dd:2 * Dd], k), rows(w[2 * Dd:])], 0),
+            "bin": lambda b, k: torch.cat([vec(b[:Dd]), vec(b[Dd:2 * Dd], k), vec(b[2 * Dd:])], 0),
+            "wout": lambda w, k: pad2(w.view(Dd * H, hd), Dd * H, HD_PAD).view(Dd, H * HD_PAD),
+            "wpos": lambda w, k: rows(w, k),
+            "uv": lambda b, k: vec(b).view(H, HD_PAD),
+        }
+
+        def image_of(tag, kind, src, fn=None):
+            """Padded fp32 image of `src` through expression `kind` (or `fn`), via the cached (index, scale) plan."""
+            plans = self.__dict__.setdefault("_pad_plans", {})
+            key = (tag, tuple(src.shape), str(src.device))
+            if key not in plans:
+                f = fn if fn is not None else exprs[kind]
+                ids = torch.arange(1, src.numel() + 1, dtype=torch.float32, device=src.device).view(src.shape)
+                mapped = f(ids, 1.0)
+                scale = f(torch.ones_like(src, dtype=torch.float32), SQRT2)
+                plans[key] = ((mapped.reshape(-1).long() - 1).clamp_(min=0), scale.reshape(-1).contiguous(), tuple(mapped.shape))
+            idx, scale, shape = plans[key]
+            return torch.index_select(src.reshape(-1), 0, idx).mul_(scale).view(shape)
+
         self.dec_aux = []
         for i in range(m.decoder_layer_num):
             p = f"decoder.encoder_blocks.{i}."
-            w = self.P(p + "attn.in_proj.weight").detach()
-            b = self.P(p + "attn.in_proj.bias").detach()
-            win = torch.cat([rows(w[:Dd]), rows(w[Dd:2 * Dd], SQRT2), rows(w[2 * Dd:])], 0)
-            bin_ = torch.cat([vec(b[:Dd]), vec(b[Dd:2 * Dd], SQRT2), vec(b[2 * Dd:])], 0)
-            self._image(p + "attn.in_proj.weight", win, split=True)
-            wo = self.P(p + "attn.out_proj.weight").detach()
-            wop = wo.new_zeros(Dd, H, HD_PAD)
-            wop[:, :, :hd] = wo.view(Dd, H, hd)
-            self._image(p + "attn.out_proj.weight", wop.view(Dd, H * HD_PAD), split=True)
-            self._image(p + "attn.linear_pos.weight", rows(self.P(p + "attn.linear_pos.weight").detach(), SQRT2), split=True)
+            self._image(p + "attn.in_proj.weight", image_of("win", "win", self.P(p + "attn.in_proj.weight").detach()), split=True)
+            self._image(p + "attn.out_proj.weight", image_of("wout", "wout", self.P(p + "attn.out_proj.weight").detach()), split=True)
+            self._image(p + "attn.linear_pos.weight", image_of("wpos", "wpos", self.P(p + "attn.linear_pos.weight").detach()), split=True)
             self._image(p + "mlp.fc1.weight", self.P(p + "mlp.fc1.weight").detach(), split=True)
             self._image(p + "mlp.fc2.weight", self.P(p + "mlp.fc2.weight").detach(), split=True)
-            self.dec_aux.append(dict(bin=bin_.contiguous(), u=vec(self.P(p + "attn.pos_bias_u").detach()).view(H, HD_PAD).contiguous(),
-                                     v=vec(self.P(p + "attn.pos_bias_v").detach()).view(H, HD_PAD).contiguous()))
-        # CNN branch: conv weight [co, ci, 3, 3] -> [pad128(co), Kp] with column = tap * ci + c; gate weight [co, co] -> [pad128(co), Cp]
+            self.dec_aux.append(dict(bin=image_of("bin", "bin", self.P(p + "attn.in_proj.bias").detach()),
+                                     u=image_of("uv", "uv", self.P(p + "attn.pos_bias_u").detach()),
+                                     v=image_of("uv", "uv", self.P(p + "attn.pos_bias_v").detach())))
         self.cnn_aux = []
         cin = 1
         for i, co in enumerate(m.cnn_filters):
             Np = pad128(co)
             Kp = 64 if i == 0 else pad128(9 * cin)
-            wc = self.P(f"cnn.cnn.conv{i}.weight").detach()
-            img = wc.new_zeros(Np, Kp)
-            img[:co, :9 * cin] = wc.permute(0, 2, 3, 1).reshape(co, 9 * cin)
-            self._image(f"cnn.cnn.conv{i}.weight", img)
             Cp = max(64, co)
+            wc = self.P(f"cnn.cnn.conv{i}.weight").detach()
             wg = self.P(f"cnn.cnn.cg{i}.linear.weight").detach()
-            gimg = wg.new_zeros(Np, Cp)
-            gimg[:co, :co] = wg
-            self._image(f"cnn.cnn.cg{i}.linear.weight", gimg)
+            img = image_of(("conv", Np, Kp), None, wc, fn=lambda w, k, Np=Np, Kp=Kp: pad2(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1), Np, Kp))
+            self._image(f"cnn.cnn.conv{i}.weight", img)
+            self._image(f"cnn.cnn.cg{i}.linear.weight", image_of(("gate", Np, Cp), None, wg, fn=lambda w, k, Np=Np, Cp=Cp: pad2(w, Np, Cp)))
             wtg = None
             if need_t:      # backward operand of the gate GEMM: [Np (N), Np (K)] = W_gate^T, zero padded
-                wtg = torch.zeros(Np, Np, dtype=BF16, device=dev)
-                wtg[:co, :co] = wg.t().to(BF16)
-            bc = wc.new_zeros(Np); bc[:co] = self.P(f"cnn.cnn.conv{i}.bias").detach()
-            bg = wc.new_zeros(Np); bg[:co] = self.P(f"cnn.cnn.cg{i}.linear.bias").detach()
+                wtg = image_of(("gateT", Np), None, wg, fn=lambda w, k, Np=Np: pad2(w.t(), Np, Np)).to(BF16)
+            bc = image_of(("b", Np), None, self.P(f"cnn.cnn.conv{i}.bias").detach(), fn=lambda b, k, Np=Np: pad2(b.view(1, -1), 1, Np).view(-1))
+            bg = image_of(("b", Np), None, self.P(f"cnn.cnn.cg{i}.linear.bias").detach(), fn=lambda b, k, Np=Np: pad2(b.view(1, -1), 1, Np).view(-1))
             self.cnn_aux.append(dict(Np=Np, Kp=Kp, Cp=Cp, cin=cin, co=co, bias=bc, gbias=bg, wtg=wtg))
             cin = co
         return self.cache
