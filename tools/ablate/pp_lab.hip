@@ -1,0 +1,545 @@
+// Developer tool (not part of the product library): main-loop laboratory for the 256 x 256 x 64 "ping-pong" GEMM.
+// Stand-alone program (no torch): builds variants of the K loop as template instances, checks each against a naive reference on
+// sampled outputs and times it on random data.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ablate/pp_lab.hip -o gpurun_out/pp_lab && gpurun_out/pp_lab
+// Variant parameters:
+//   SCHED 0: four quadrant phases per K tile, reads 12/4/8/0   1: quadrant phases, B0 of the next tile prefetched in P4 (8/4/8/4)
+//         2: two half-tile phases per K tile (16 MFMAs per section, reads 16/8)
+//         3: one phase per K tile (32 MFMAs per section, all 24 fragment reads up front)
+//   ABL bit0: no DMA after the prologue   bit1: fragment reads only in the first K tile   bit2: no barriers   (timing only)
+//   PRIO: s_setprio 1 around the MFMA sections      PREWAIT: lgkmcnt(0) before the first barrier instead of after it
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "../../transformer4sed_amd/csrc/common.h"
+
+#define BK 64
+#define T256 256
+#define LDS_BYTES (128 * 1024)
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+__device__ unsigned long long* g_trace = nullptr;
+__device__ unsigned long long g_clk[4];
+template <int SCHED, int ABL, bool PRIO, bool PREWAIT, int TRACE = 0>
+__global__ __launch_bounds__(512) void pp_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C,
+                                                 int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntn = N / T256, ntm = (M + T256 - 1) / T256, nwg = ntm * ntn;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int group_size = 4 * ntn, gid = t / group_size, first_m = gid * 4;
+    const int gm = (ntm - first_m) < 4 ? (ntm - first_m) : 4;
+    const int tin = t - gid * group_size;
+    const int m0 = (first_m + tin % gm) * T256, n0 = (tin / gm) * T256;
+    const int nk = K / BK;
+    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = wall_clock64();
+    const int rows_a = (M - m0) < T256 ? (M - m0) : T256;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * K), 0, rows_a * K * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(B + (size_t)n0 * K), 0, T256 * K * 2, 0x00020000);
+    // DMA slots (16 pieces of 8 rows x 128 B each, 2 per wave): 0 = A rows of half 0, 1 = B block-0 rows (SCHED 1: rows with
+    // bit 5 clear; otherwise rows 0-127), 2 = the other B rows, 3 = A rows of half 1
+    const int prow = lane >> 3, pch = lane & 7;
+    int vo[4][2], ld_[4][2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int p = 2 * wave + e;
+        const int ra0 = (p >> 3) * 128 + (p & 7) * 8, ra1 = ra0 + 64;
+        int rb0, rb1;
+        if (SCHED == 1) { rb0 = (p >> 2) * 64 + (p & 3) * 8; rb1 = rb0 + 32; }
+        else { rb0 = p * 8; rb1 = 128 + p * 8; }
+        const int rows[4] = {ra0, rb0, rb1, ra1};
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            const int row = rows[sl] + prow;
+            const int cl = pch ^ ((row >> 1) & 7);
+            const bool is_b = (sl == 1 || sl == 2);
+            vo[sl][e] = row * K * 2 + cl * 16;
+            ld_[sl][e] = (is_b ? 65536 : 0) + rows[sl] * 128;
+        }
+    }
+#define PP_DMA(SL, KT)                                                                                                    \
+    if (!(ABL & 1)) {                                                                                                     \
+        const int so_ = (KT) * (BK * 2), st_ = ((KT) & 1) << 15;                                                          \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? rb : ra, (lds_ptr_t)(lds3 + st_ + ld_[SL][0]), 16, vo[SL][0], so_, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? rb : ra, (lds_ptr_t)(lds3 + st_ + ld_[SL][1]), 16, vo[SL][1], so_, 0, 0); \
+    }
+#define PP_DMA_ALWAYS(SL, KT)                                                                                             \
+    {                                                                                                                     \
+        const int so_ = (KT) * (BK * 2), st_ = ((KT) & 1) << 15;                                                          \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? rb : ra, (lds_ptr_t)(lds3 + st_ + ld_[SL][0]), 16, vo[SL][0], so_, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? rb : ra, (lds_ptr_t)(lds3 + st_ + ld_[SL][1]), 16, vo[SL][1], so_, 0, 0); \
+    }
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int lr = lane & 31, lg = lane >> 5, sw = (lr >> 1) & 7;
+    int aaddr[4], baddr[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int c = ((2 * ks + lg) ^ sw) << 4;
+        aaddr[ks] = wm * 16384 + lr * 128 + c;
+        baddr[ks] = 65536 + wn * 8192 + lr * 128 + c;
+    }
+    s16x8_t fa[SCHED == 3 ? 4 : 2][4], fb[2][4];
+    unsigned long long stamp[17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) stamp[i] = 0;
+    const bool rd_on = !(ABL & 2);
+    bool trace_on = false;
+#define PP_RD_A(IH) PP_RD_A_T(IH, it)
+#define PP_RD_A_T(IH, T_)                                                                                                 \
+    if (rd_on || (T_) == 0) {                                                                                               \
+        _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)                                                                  \
+            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                              \
+                fa[(SCHED == 3 ? 2 * (IH) : 0) + ii][ks] = *reinterpret_cast<const s16x8_t*>(lds3 + aaddr[ks] + (2 * (IH) + ii) * 4096); \
+    }
+#define PP_RD_B(J, XOR) PP_RD_B_T(J, J, XOR, it)
+#define PP_RD_B_T(BR, JR, XOR, T_)                                                                                        \
+    if (rd_on || (T_) == 0) {                                                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                  \
+            fb[BR][ks] = *reinterpret_cast<const s16x8_t*>(lds3 + (baddr[ks] ^ (XOR)) + (JR) * 4096);                     \
+    }
+#define PP_BAR() if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+#define PP_STAMP(I_) if (TRACE && trace_on) { stamp[I_] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#define PP_SYNC_IN() PP_SYNC_IN_P(0)
+#define PP_SYNC_IN_P(PH_)                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    if (TRACE & 2) PP_STAMP(4 * (PH_) + 1)                                                                             \
+    if (PREWAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+    PP_BAR()                                                                                                              \
+    if (!PREWAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    PP_STAMP(4 * (PH_) + 2)                                                                                            \
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
+#define PP_SYNC_OUT() PP_SYNC_OUT_P(0)
+#define PP_SYNC_OUT_P(PH_)                                                                                                \
+    if (PRIO) __builtin_amdgcn_s_setprio(0);                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    PP_STAMP(4 * (PH_) + 3)                                                                                            \
+    PP_BAR()                                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    PP_STAMP(4 * (PH_) + 4)
+#define PP_MFMA_Q(IH, J) PP_MFMA_QB(IH, J, J)
+#define PP_MFMA_QB(IH, J, BR) PP_MFMA_QBP(IH, J, BR, 0)
+#define PP_MFMA_QBP(IH, J, BR, PH_)                                                                                       \
+    PP_SYNC_IN_P(PH_)                                                                                                          \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                      \
+        _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)                                                                  \
+            acc[2 * (IH) + ii][J] = mfma32t<true>(fb[BR][ks], fa[(SCHED == 3 ? 2 * (IH) : 0) + ii][ks], acc[2 * (IH) + ii][J]); \
+    PP_SYNC_OUT_P(PH_)
+#define PP_MFMA_H(IH)                                                                                                     \
+    PP_SYNC_IN()                                                                                                          \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                      \
+        _Pragma("unroll") for (int ii = 0; ii < 2; ++ii)                                                                  \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
+                acc[2 * (IH) + ii][j] = mfma32t<true>(fb[j][ks], fa[(SCHED == 3 ? 2 * (IH) : 0) + ii][ks], acc[2 * (IH) + ii][j]); \
+    PP_SYNC_OUT()
+#define PP_FLIP() _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) { aaddr[ks] ^= 0x8000; baddr[ks] ^= 0x8000; }
+
+    if (SCHED == 0) {
+        PP_DMA_ALWAYS(0, 0) PP_DMA_ALWAYS(1, 0) PP_DMA_ALWAYS(2, 0) PP_DMA_ALWAYS(3, 0)
+        if (nk > 1 && !(ABL & 1)) { PP_DMA(0, 1) PP_DMA(1, 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) PP_BAR()
+        for (int it = 0; it < nk; ++it) {
+            if (it + 1 < nk) PP_DMA(2, it + 1)
+            PP_RD_A(0) PP_RD_B(0, 0)
+            PP_MFMA_Q(0, 0)
+            if (it + 1 < nk) PP_DMA(3, it + 1)
+            PP_RD_B(1, 0)
+            PP_MFMA_Q(0, 1)
+            if (it + 2 < nk) PP_DMA(0, it + 2)
+            PP_RD_A(1)
+            PP_MFMA_Q(1, 1)
+            if (it + 2 < nk && !(ABL & 1)) { PP_DMA(1, it + 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            PP_MFMA_Q(1, 0)
+            if (!(ABL & 1)) PP_FLIP()
+        }
+        if (wm == 0) PP_BAR()
+    } else if (SCHED == 1) {
+        // balanced reads 8/4/8/4: the next tile's B0 fragments are read in P4 into the registers B1 vacated after P3, so the
+        // two B register sets swap roles every tile (two tiles per loop trip; nk even).  Slots of tile t+1: B0 at P2(t-1), A0 at
+        // P3(t-1), B1 at P4(t-1), A1 at P1(t); retired by vmcnt(4) at P3(t); first read (B0) at P4(t).
+#define PP_TILE1(T_, X, Y)                                                                                                \
+        if ((T_) + 1 < nk) PP_DMA(3, (T_) + 1)                                                                            \
+        PP_RD_A_T(0, T_)                                                                                                  \
+        PP_MFMA_QBP(0, 0, X, 0)                                                                                               \
+        if ((T_) + 2 < nk) PP_DMA(1, (T_) + 2)                                                                            \
+        PP_RD_B_T(Y, 1, 0, T_)                                                                                            \
+        PP_MFMA_QBP(0, 1, Y, 1)                                                                                               \
+        if ((T_) + 2 < nk && !(ABL & 1)) { PP_DMA(0, (T_) + 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }         \
+        else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                                                         \
+        PP_RD_A_T(1, T_)                                                                                                  \
+        PP_MFMA_QBP(1, 1, Y, 2)                                                                                               \
+        if ((T_) + 2 < nk) PP_DMA(2, (T_) + 2)                                                                            \
+        if ((T_) + 1 < nk) { PP_RD_B_T(Y, 0, (ABL & 1) ? 0 : 0x8000, (rd_on ? 0 : 1)) }                                   \
+        PP_MFMA_QBP(1, 0, X, 3)                                                                                               \
+        if (!(ABL & 1)) PP_FLIP()
+        PP_DMA_ALWAYS(1, 0) PP_DMA_ALWAYS(0, 0) PP_DMA_ALWAYS(2, 0) PP_DMA_ALWAYS(3, 0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (nk > 1) { PP_DMA(1, 1) PP_DMA(0, 1) PP_DMA(2, 1) }
+        if (wm == 1) PP_BAR()
+        PP_RD_B_T(0, 0, 0, 0)
+        for (int it = 0; it < nk; it += 2) {
+            trace_on = TRACE && (it == 4);
+            PP_STAMP(0)
+            PP_TILE1(it, 0, 1)
+            trace_on = false;
+            PP_TILE1(it + 1, 1, 0)
+        }
+        if (wm == 0) PP_BAR()
+    } else if (SCHED == 2) {
+        // tile t+1: B slots (1, 2) issued at H2(t-1), A slots (0, 3) at H1(t); retired at H2(t) (4 younger pieces = B of t+2)
+        PP_DMA_ALWAYS(0, 0) PP_DMA_ALWAYS(1, 0) PP_DMA_ALWAYS(2, 0) PP_DMA_ALWAYS(3, 0)
+        if (nk > 1 && !(ABL & 1)) { PP_DMA(1, 1) PP_DMA(2, 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) PP_BAR()
+        for (int it = 0; it < nk; ++it) {
+            if (it + 1 < nk) { PP_DMA(0, it + 1) PP_DMA(3, it + 1) }
+            PP_RD_A(0) PP_RD_B(0, 0) PP_RD_B(1, 0)
+            PP_MFMA_H(0)
+            if (it + 2 < nk && !(ABL & 1)) { PP_DMA(1, it + 2) PP_DMA(2, it + 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            PP_RD_A(1)
+            PP_MFMA_H(1)
+            if (!(ABL & 1)) PP_FLIP()
+        }
+        if (wm == 0) PP_BAR()
+    } else {
+        // SCHED 3: all fragments of a K tile are read in one section (24 reads, 32 MFMAs per section).  Tile it+1 is issued at the
+        // top of tile it's load section (its stage was last read one section earlier by both wave rows: PREWAIT) and retired at
+        // the end of the MFMA section, ahead of the barrier that precedes its first read.
+        PP_DMA_ALWAYS(0, 0) PP_DMA_ALWAYS(1, 0) PP_DMA_ALWAYS(2, 0) PP_DMA_ALWAYS(3, 0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) PP_BAR()
+        for (int it = 0; it < nk; ++it) {
+            if (it + 1 < nk) { PP_DMA(0, it + 1) PP_DMA(1, it + 1) PP_DMA(2, it + 1) PP_DMA(3, it + 1) }
+            PP_RD_A(0) PP_RD_A(1) PP_RD_B(0, 0) PP_RD_B(1, 0)
+            PP_SYNC_IN()
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma32t<true>(fb[j][ks], fa[i][ks], acc[i][j]);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PP_BAR()
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(ABL & 1)) PP_FLIP()
+        }
+        if (wm == 0) PP_BAR()
+    }
+    if (blockIdx.x == 17 && tid == 0) { g_clk[0] = __builtin_readcyclecounter() - clk0; g_clk[1] = wall_clock64() - rt0; }
+    if (TRACE && g_trace != nullptr && lane == 0 && blockIdx.x < 512) {
+#pragma unroll
+        for (int i = 0; i < 17; ++i) g_trace[((size_t)blockIdx.x * 8 + wave) * 17 + i] = stamp[i];
+    }
+    // plain epilogue: accumulator block (i, j) holds C^T -- lane = row, register quad q = columns 8 q + 4 lg .. + 3
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 128 + i * 32 + lr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * lg;
+                uint2 pk;
+                pk.x = pack2<true>(acc[i][j][4 * q], acc[i][j][4 * q + 1]);
+                pk.y = pack2<true>(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                *reinterpret_cast<uint2*>(C + (size_t)m * N + n) = pk;
+            }
+    }
+}
+
+
+// ---- the same ping-pong loop (SCHED 1: balanced quadrant phases) on v_mfma_f32_16x16x32_f16 -------------------------------------
+// wave tile 128 x 64 = 8 x 4 blocks of 16 x 16 (f32x4 accumulators, C^T: lane & 15 = row, register r = column 4 (lane >> 4) + r);
+// a K tile is two 32-deep k-steps; fragment (16 rows, 32 k): lane reads row (lane & 15), 16-byte chunk 4 ks + (lane >> 4).
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+template <int ABL, bool PRIO>
+__global__ __launch_bounds__(512) void pp16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C,
+                                                   int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntn = N / T256, ntm = (M + T256 - 1) / T256, nwg = ntm * ntn;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int group_size = 4 * ntn, gid = t / group_size, first_m = gid * 4;
+    const int gm = (ntm - first_m) < 4 ? (ntm - first_m) : 4;
+    const int tin = t - gid * group_size;
+    const int m0 = (first_m + tin % gm) * T256, n0 = (tin / gm) * T256;
+    const int nk = K / BK;
+    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = wall_clock64();
+    const int rows_a = (M - m0) < T256 ? (M - m0) : T256;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * K), 0, rows_a * K * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(B + (size_t)n0 * K), 0, T256 * K * 2, 0x00020000);
+    const int prow = lane >> 3, pch = lane & 7;
+    int vo[4][2], ld_[4][2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int p = 2 * wave + e;
+        const int ra0 = (p >> 3) * 128 + (p & 7) * 8, ra1 = ra0 + 64;
+        const int rb0 = (p >> 2) * 64 + (p & 3) * 8, rb1 = rb0 + 32;
+        const int rows[4] = {ra0, rb0, rb1, ra1};
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            const int row = rows[sl] + prow;
+            const int cl = pch ^ ((row >> 1) & 7);
+            const bool is_b = (sl == 1 || sl == 2);
+            vo[sl][e] = row * K * 2 + cl * 16;
+            ld_[sl][e] = (is_b ? 65536 : 0) + rows[sl] * 128;
+        }
+    }
+#define Q_DMA(SL, KT)                                                                                                     \
+    if (!(ABL & 1)) {                                                                                                     \
+        const int so_ = (KT) * (BK * 2), st_ = ((KT) & 1) << 15;                                                          \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? rb : ra, (lds_ptr_t)(lds3 + st_ + ld_[SL][0]), 16, vo[SL][0], so_, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? rb : ra, (lds_ptr_t)(lds3 + st_ + ld_[SL][1]), 16, vo[SL][1], so_, 0, 0); \
+    }
+#define Q_DMA_ALWAYS(SL, KT)                                                                                              \
+    {                                                                                                                     \
+        const int so_ = (KT) * (BK * 2), st_ = ((KT) & 1) << 15;                                                          \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? rb : ra, (lds_ptr_t)(lds3 + st_ + ld_[SL][0]), 16, vo[SL][0], so_, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? rb : ra, (lds_ptr_t)(lds3 + st_ + ld_[SL][1]), 16, vo[SL][1], so_, 0, 0); \
+    }
+    f32x4v acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const int l15 = lane & 15, lq = lane >> 4, sw = (l15 >> 1) & 7;
+    int aaddr[2], baddr[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int c = ((4 * ks + lq) ^ sw) << 4;
+        aaddr[ks] = wm * 16384 + l15 * 128 + c;
+        baddr[ks] = 65536 + wn * 8192 + l15 * 128 + c;
+    }
+    // rows of fragment block i: 16 i + l15 -> swizzle ((16 i + l15) >> 1) & 7 = sw ^ ... no: 16 i adds 8 to (row >> 1): & 7 unchanged
+    f16x8_t fa[4][2], fb[2][2][2];   // fa[ii][ks]: 4 row blocks of the current half; fb[set][jj][ks]: 2 column blocks
+    const bool rd_on = !(ABL & 2);
+#define Q_RD_A(IH, T_)                                                                                                    \
+    if (rd_on || (T_) == 0) {                                                                                             \
+        _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                                  \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
+                fa[ii][ks] = *reinterpret_cast<const f16x8_t*>(lds3 + aaddr[ks] + (4 * (IH) + ii) * 2048);                \
+    }
+#define Q_RD_B(SET, JH, XOR, T_)                                                                                          \
+    if (rd_on || (T_) == 0) {                                                                                             \
+        _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                                  \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
+                fb[SET][jj][ks] = *reinterpret_cast<const f16x8_t*>(lds3 + (baddr[ks] ^ (XOR)) + (2 * (JH) + jj) * 2048); \
+    }
+#define Q_BAR() if (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+#define Q_MFMA(IH, JH, SET)                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    Q_BAR()                                                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    if (PRIO) __builtin_amdgcn_s_setprio(1);                                                                              \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                      \
+        _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                                  \
+            _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                              \
+                acc[4 * (IH) + ii][2 * (JH) + jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[SET][jj][ks], fa[ii][ks], acc[4 * (IH) + ii][2 * (JH) + jj], 0, 0, 0); \
+    if (PRIO) __builtin_amdgcn_s_setprio(0);                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    Q_BAR()                                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);
+#define Q_FLIP() _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { aaddr[ks] ^= 0x8000; baddr[ks] ^= 0x8000; }
+#define Q_TILE(T_, X, Y)                                                                                                  \
+    if ((T_) + 1 < nk) Q_DMA(3, (T_) + 1)                                                                                 \
+    Q_RD_A(0, T_)                                                                                                         \
+    Q_MFMA(0, 0, X)                                                                                                       \
+    if ((T_) + 2 < nk) Q_DMA(1, (T_) + 2)                                                                                 \
+    Q_RD_B(Y, 1, 0, T_)                                                                                                   \
+    Q_MFMA(0, 1, Y)                                                                                                       \
+    if ((T_) + 2 < nk && !(ABL & 1)) { Q_DMA(0, (T_) + 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }              \
+    else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                                                             \
+    Q_RD_A(1, T_)                                                                                                         \
+    Q_MFMA(1, 1, Y)                                                                                                       \
+    if ((T_) + 2 < nk) Q_DMA(2, (T_) + 2)                                                                                 \
+    if ((T_) + 1 < nk) { Q_RD_B(Y, 0, (ABL & 1) ? 0 : 0x8000, (rd_on ? 0 : 1)) }                                          \
+    Q_MFMA(1, 0, X)                                                                                                       \
+    if (!(ABL & 1)) Q_FLIP()
+    Q_DMA_ALWAYS(1, 0) Q_DMA_ALWAYS(0, 0) Q_DMA_ALWAYS(2, 0) Q_DMA_ALWAYS(3, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (nk > 1) { Q_DMA(1, 1) Q_DMA(0, 1) Q_DMA(2, 1) }
+    if (wm == 1) Q_BAR()
+    Q_RD_B(0, 0, 0, 0)
+    for (int it = 0; it < nk; it += 2) {
+        Q_TILE(it, 0, 1)
+        Q_TILE(it + 1, 1, 0)
+    }
+    if (wm == 0) Q_BAR()
+    if (blockIdx.x == 17 && tid == 0) { g_clk[0] = __builtin_readcyclecounter() - clk0; g_clk[1] = wall_clock64() - rt0; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wm * 128 + i * 16 + l15;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + 4 * lq;
+            uint2 pk;
+            pk.x = pack2<true>(acc[i][j][0], acc[i][j][1]);
+            pk.y = pack2<true>(acc[i][j][2], acc[i][j][3]);
+            *reinterpret_cast<uint2*>(C + (size_t)m * N + n) = pk;
+        }
+    }
+}
+
+__global__ void fill_kernel(bf16_t* p, size_t n, unsigned seed, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)(i * 2654435761u) ^ seed;
+        h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12; h *= 0x297a2d39u; h ^= h >> 15;
+        p[i] = f2h(((h & 0xffff) / 32768.0f - 1.0f) * scale);
+    }
+}
+__global__ void ref_kernel(const bf16_t* A, const bf16_t* B, const int* mm, const int* nn, float* out, int K, int ns) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ns) return;
+    const bf16_t* a = A + (size_t)mm[s] * K;
+    const bf16_t* b = B + (size_t)nn[s] * K;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc += h2f(a[k]) * h2f(b[k]);
+    out[s] = acc;
+}
+__global__ void gather_kernel(const bf16_t* C, const int* mm, const int* nn, float* out, int N, int ns) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < ns) out[s] = h2f(C[(size_t)mm[s] * N + nn[s]]);
+}
+
+typedef void (*kern_t)(const bf16_t*, const bf16_t*, bf16_t*, int, int, int);
+struct Variant { const char* name; kern_t k; bool check; };
+
+int main(int argc, char** argv) {
+    const int reps = argc > 1 ? atoi(argv[1]) : 10;
+    std::vector<Variant> vs = {
+        {"S0 quad 12/4/8/0 prio postwait", pp_kernel<0, 0, true, false>, true},
+        {"S0 quad prio PREWAIT          ", pp_kernel<0, 0, true, true>, true},
+        {"S0 quad noprio                ", pp_kernel<0, 0, false, false>, true},
+        {"S1 quad 8/4/8/4 prio postwait ", pp_kernel<1, 0, true, false>, true},
+        {"S1 quad 8/4/8/4 prio prewait  ", pp_kernel<1, 0, true, true>, true},
+        {"S1 with mfma 16x16x32 prio    ", pp16_kernel<0, true>, true},
+        {"S1 with mfma 16x16x32 noprio  ", pp16_kernel<0, false>, true},
+        {"S1/16x16 ABL noDMA            ", pp16_kernel<1, true>, false},
+        {"S1/16x16 ABL noDMA noRD       ", pp16_kernel<3, true>, false},
+        {"S2 half 16/8 prio prewait     ", pp_kernel<2, 0, true, true>, true},
+        {"S2 half 16/8 prio postwait    ", pp_kernel<2, 0, true, false>, true},
+        {"S2 half noprio prewait        ", pp_kernel<2, 0, false, true>, true},
+        {"S3 tile 24 prio prewait       ", pp_kernel<3, 0, true, true>, true},
+        {"S3 tile noprio prewait        ", pp_kernel<3, 0, false, true>, true},
+        {"S0 ABL noDMA                  ", pp_kernel<0, 1, true, false>, false},
+        {"S0 ABL noDMA noRD             ", pp_kernel<0, 3, true, false>, false},
+        {"S0 ABL noDMA noRD noBAR       ", pp_kernel<0, 7, true, false>, false},
+        {"S0 ABL noRD                   ", pp_kernel<0, 2, true, false>, false},
+        {"S2 ABL noDMA                  ", pp_kernel<2, 1, true, true>, false},
+        {"S2 ABL noDMA noRD             ", pp_kernel<2, 3, true, true>, false},
+        {"S2 ABL noDMA noRD noBAR       ", pp_kernel<2, 7, true, true>, false},
+        {"S3 ABL noDMA                  ", pp_kernel<3, 1, true, true>, false},
+        {"S3 ABL noDMA noRD             ", pp_kernel<3, 3, true, true>, false},
+    };
+    {
+        unsigned long long* dtr;
+        CHECK(hipMalloc(&dtr, 512 * 8 * 17 * 8));
+        CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &dtr, sizeof(dtr)));
+        const int M = 8192, N = 8192, K = 8192;
+        bf16_t *A, *B, *C;
+        CHECK(hipMalloc(&A, (size_t)M * K * 2)); CHECK(hipMalloc(&B, (size_t)N * K * 2)); CHECK(hipMalloc(&C, (size_t)M * N * 2));
+        fill_kernel<<<2048, 256>>>(A, (size_t)M * K, 0x1234u, 1.0f);
+        fill_kernel<<<2048, 256>>>(B, (size_t)N * K, 0x9876u, 0.05f);
+        for (int mode = 0; mode < 2; ++mode) {
+            kern_t k = mode == 0 ? (kern_t)pp_kernel<1, 0, true, false, 1> : (kern_t)pp_kernel<1, 0, true, false, 3>;
+            CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+            CHECK(hipMemset(dtr, 0, 512 * 8 * 17 * 8));
+            k<<<dim3(32 * 32), 512, LDS_BYTES>>>(A, B, C, M, N, K);
+            CHECK(hipDeviceSynchronize());
+            std::vector<unsigned long long> h(512 * 8 * 17);
+            CHECK(hipMemcpy(h.data(), dtr, h.size() * 8, hipMemcpyDeviceToHost));
+            printf("trace mode %d (S1, 8192^3, K tile 4): per phase [start->load issued->mfma start->mfma end->next start], cycles\n", mode);
+            for (int blk : {0, 100, 300}) for (int w : {0, 4}) {
+                const unsigned long long* st = &h[((size_t)blk * 8 + w) * 17];
+                printf("  blk %3d wave %d:", blk, w);
+                for (int ph = 0; ph < 4; ++ph) {
+                    const long long s0 = st[4 * ph], s1 = st[4 * ph + 1], s2 = st[4 * ph + 2], s3 = st[4 * ph + 3];
+                    const long long nx = (long long)st[4 * ph + 4];
+                    printf("  P%d: ld %lld bar %lld mfma %lld out %lld |", ph + 1, s1 ? s1 - s0 : -1, s1 ? s2 - s1 : s2 - s0, s3 - s2, nx ? nx - s3 : -1);
+                }
+                printf("\n");
+            }
+        }
+        CHECK(hipFree(A)); CHECK(hipFree(B)); CHECK(hipFree(C));
+        dtr = nullptr;
+        CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &dtr, sizeof(dtr)));
+    }
+    const int shapes[][3] = {{8192, 8192, 8192}, {38080, 3072, 768}, {38080, 768, 3072}, {211904, 768, 768}};
+    for (auto& v : vs) CHECK(hipFuncSetAttribute((const void*)v.k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    for (const auto& sh : shapes) {
+        const int M = sh[0], N = sh[1], K = sh[2];
+        bf16_t *A, *B, *C;
+        CHECK(hipMalloc(&A, (size_t)M * K * 2)); CHECK(hipMalloc(&B, (size_t)N * K * 2)); CHECK(hipMalloc(&C, (size_t)M * N * 2));
+        fill_kernel<<<2048, 256>>>(A, (size_t)M * K, 0x1234u, 1.0f);
+        fill_kernel<<<2048, 256>>>(B, (size_t)N * K, 0x9876u, 0.05f);
+        const int ns = 8192;
+        std::vector<int> hm(ns), hn(ns);
+        srand(7);
+        for (int s = 0; s < ns; ++s) { hm[s] = (s < 512) ? (M - 1 - (s & 255)) : rand() % M; hn[s] = rand() % N; }
+        int *dm, *dn; float *dref, *dout;
+        CHECK(hipMalloc(&dm, ns * 4)); CHECK(hipMalloc(&dn, ns * 4)); CHECK(hipMalloc(&dref, ns * 4)); CHECK(hipMalloc(&dout, ns * 4));
+        CHECK(hipMemcpy(dm, hm.data(), ns * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dn, hn.data(), ns * 4, hipMemcpyHostToDevice));
+        ref_kernel<<<(ns + 255) / 256, 256>>>(A, B, dm, dn, dref, K, ns);
+        std::vector<float> href(ns), hout(ns);
+        CHECK(hipMemcpy(href.data(), dref, ns * 4, hipMemcpyDeviceToHost));
+        const dim3 grid(((M + 255) / 256) * (N / 256));
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        for (auto& v : vs) {
+            CHECK(hipMemset(C, 0, (size_t)M * N * 2));
+            v.k<<<grid, 512, LDS_BYTES>>>(A, B, C, M, N, K);
+            CHECK(hipDeviceSynchronize());
+            double maxerr = -1.0;
+            if (v.check) {
+                gather_kernel<<<(ns + 255) / 256, 256>>>(C, dm, dn, dout, N, ns);
+                CHECK(hipMemcpy(hout.data(), dout, ns * 4, hipMemcpyDeviceToHost));
+                maxerr = 0.0;
+                for (int s = 0; s < ns; ++s) {
+                    const double e = fabs((double)hout[s] - href[s]) / (1.0 + fabs((double)href[s]));
+                    if (e > maxerr) maxerr = e;
+                }
+            }
+            v.k<<<grid, 512, LDS_BYTES>>>(A, B, C, M, N, K);
+            CHECK(hipEventRecord(e0));
+            for (int r = 0; r < reps; ++r) v.k<<<grid, 512, LDS_BYTES>>>(A, B, C, M, N, K);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float ms;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            ms /= reps;
+            unsigned long long hc[4];
+            CHECK(hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_clk), sizeof(hc)));
+            printf("M%-6d N%-5d K%-5d %s %8.3f ms %8.1f TF/s  err %s%.2e  clk %.2f GHz (blk 17: %llu cyc)\n", M, N, K, v.name, ms, 2.0 * M * N * K / ms / 1e9,
+                   (v.check && maxerr > 2e-2) ? "FAIL " : "", maxerr, hc[1] ? (double)hc[0] / ((double)hc[1] * 10.0) : 0.0, hc[0]);
+            fflush(stdout);
+        }
+        CHECK(hipFree(A)); CHECK(hipFree(B)); CHECK(hipFree(C)); CHECK(hipFree(dm)); CHECK(hipFree(dn)); CHECK(hipFree(dref)); CHECK(hipFree(dout));
+    }
+    return 0;
+}

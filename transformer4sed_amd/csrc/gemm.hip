@@ -46,7 +46,6 @@ struct GemmArgs {
     const float *pu, *pv;
     int seq, seq_pad, heads;
     int bwd_bf16; // f16 runs only: tensors that only the (bf16) backward consumes are written as bf16 straight away
-    int stagger;  // v3: first-round workgroups start phase * stagger wall-clock ticks (10 ns) late, phase = 0..7
     int ncols;    // 128^2 kernel: output columns >= ncols are computed but not written (operands padded to the tile width)
 };
 
@@ -193,7 +192,7 @@ __device__ __forceinline__ void mfma_tile(const unsigned char* la, const unsigne
     }
 }
 
-template <int EPI, bool F16, bool GLDS>
+template <int EPI, bool F16>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][TILE * BK * 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -210,49 +209,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
     const int ktiles = g.K / BK;
     const int kt_begin = (int)(((long long)blockIdx.y * ktiles) / g.ksplit);
     const int kt_end = (int)(((long long)(blockIdx.y + 1) * ktiles) / g.ksplit);
-
-    // staging: thread -> 16-B chunk c of rows r0 + 32 i (i = 0..3) of both operand tiles.  Named registers (not arrays
-    // captured by lambdas): arrays end up in scratch and every prefetch then stalls on vmcnt(0) + scratch_store.
-    const int c = tid & 7, r0 = tid >> 3;
-    const int am_last = g.M - 1;
-    const int am0 = (m0 + r0) < g.M ? (m0 + r0) : am_last, am1 = (m0 + r0 + 32) < g.M ? (m0 + r0 + 32) : am_last;
-    const int am2 = (m0 + r0 + 64) < g.M ? (m0 + r0 + 64) : am_last, am3 = (m0 + r0 + 96) < g.M ? (m0 + r0 + 96) : am_last;
-    const bf16_t* ap0 = g.A + (size_t)am0 * g.lda + c * 8;
-    const bf16_t* ap1 = g.A + (size_t)am1 * g.lda + c * 8;
-    const bf16_t* ap2 = g.A + (size_t)am2 * g.lda + c * 8;
-    const bf16_t* ap3 = g.A + (size_t)am3 * g.lda + c * 8;
-    const bf16_t* bp0 = g.B + (size_t)(n0 + r0) * g.ldb + c * 8;
-    const bf16_t* bp1 = bp0 + (size_t)32 * g.ldb;
-    const bf16_t* bp2 = bp0 + (size_t)64 * g.ldb;
-    const bf16_t* bp3 = bp0 + (size_t)96 * g.ldb;
-    const int lo0 = r0 * 128 + ((c ^ ((r0 >> 1) & 7)) << 4);
-    const int lo1 = (r0 + 32) * 128 + ((c ^ (((r0 + 32) >> 1) & 7)) << 4);
-    const int lo2 = (r0 + 64) * 128 + ((c ^ (((r0 + 64) >> 1) & 7)) << 4);
-    const int lo3 = (r0 + 96) * 128 + ((c ^ (((r0 + 96) >> 1) & 7)) << 4);
-    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define GEMM_GLOAD(kt)                                                          \
-    {                                                                           \
-        const size_t ko = (size_t)(kt) * BK;                                    \
-        ra0 = *reinterpret_cast<const uint4*>(ap0 + ko);                        \
-        ra1 = *reinterpret_cast<const uint4*>(ap1 + ko);                        \
-        ra2 = *reinterpret_cast<const uint4*>(ap2 + ko);                        \
-        ra3 = *reinterpret_cast<const uint4*>(ap3 + ko);                        \
-        rb0 = *reinterpret_cast<const uint4*>(bp0 + ko);                        \
-        rb1 = *reinterpret_cast<const uint4*>(bp1 + ko);                        \
-        rb2 = *reinterpret_cast<const uint4*>(bp2 + ko);                        \
-        rb3 = *reinterpret_cast<const uint4*>(bp3 + ko);                        \
-    }
-#define GEMM_LSTORE(buf)                                                        \
-    {                                                                           \
-        *reinterpret_cast<uint4*>(&lds[buf][0][lo0]) = ra0;                     \
-        *reinterpret_cast<uint4*>(&lds[buf][0][lo1]) = ra1;                     \
-        *reinterpret_cast<uint4*>(&lds[buf][0][lo2]) = ra2;                     \
-        *reinterpret_cast<uint4*>(&lds[buf][0][lo3]) = ra3;                     \
-        *reinterpret_cast<uint4*>(&lds[buf][1][lo0]) = rb0;                     \
-        *reinterpret_cast<uint4*>(&lds[buf][1][lo1]) = rb1;                     \
-        *reinterpret_cast<uint4*>(&lds[buf][1][lo2]) = rb2;                     \
-        *reinterpret_cast<uint4*>(&lds[buf][1][lo3]) = rb3;                     \
-    }
 
     f32x16_t acc[2][2];
 #pragma unroll
@@ -274,23 +230,22 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
 // split-K weight gradients keep the un-swapped accumulator layout (lane = output column): their atomics then hit 2 cache
 // lines per instruction instead of 64
 #define GEMM_COMPUTE(buf) mfma_tile<F16, EPI != EPI_ATOMIC>(lds[buf][0], lds[buf][1], arow, brow, lg, acc)
-    if (GLDS) {
-        // Direct-to-LDS staging (global_load_lds_dwordx4): each wave-instruction DMAs 64 x 16 B = 8 tile rows straight
-        // into LDS (lane-linear destination), no VGPR round trip and no ds_write pass.  The XOR swizzle therefore moves to
-        // the per-lane SOURCE address: lane l fills physical chunk l & 7 of row 8 p + (l >> 3) with logical chunk
-        // (l & 7) ^ ((row >> 1) & 7) -- the same involution the fragment reads apply.  Wave w owns pieces 4 w .. 4 w + 3.
-        const int prow = lane >> 3, pch = lane & 7;
-        const bf16_t* asrc[4];
-        const bf16_t* bsrc[4];
+    // Direct-to-LDS staging (global_load_lds_dwordx4): each wave-instruction DMAs 64 x 16 B = 8 tile rows straight into LDS
+    // (lane-linear destination), no VGPR round trip and no ds_write pass.  The XOR swizzle therefore sits on the per-lane SOURCE
+    // address: lane l fills physical chunk l & 7 of row 8 p + (l >> 3) with logical chunk (l & 7) ^ ((row >> 1) & 7) -- the same
+    // involution the fragment reads apply.  Wave w owns pieces 4 w .. 4 w + 3.
+    const int prow = lane >> 3, pch = lane & 7;
+    const bf16_t* asrc[4];
+    const bf16_t* bsrc[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (wave * 4 + i) * 8 + prow;
-            const int cl = pch ^ ((row >> 1) & 7);
-            int am = m0 + row;
-            am = am < g.M ? am : g.M - 1;
-            asrc[i] = g.A + (size_t)am * g.lda + cl * 8;
-            bsrc[i] = g.B + (size_t)(n0 + row) * g.ldb + cl * 8;
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + prow;
+        const int cl = pch ^ ((row >> 1) & 7);
+        int am = m0 + row;
+        am = am < g.M ? am : g.M - 1;
+        asrc[i] = g.A + (size_t)am * g.lda + cl * 8;
+        bsrc[i] = g.B + (size_t)(n0 + row) * g.ldb + cl * 8;
+    }
 #define GEMM_DMA(kt, buf)                                                                                                \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                      \
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (size_t)(kt) * BK),   \
@@ -300,32 +255,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
                                          (__attribute__((address_space(3))) void*)(&lds[buf][1][(wave * 4 + i) * 1024]), \
                                          16, 0, 0);                                                                      \
     }
-        if (kt_begin < kt_end) GEMM_DMA(kt_begin, 0);
-        __syncthreads();  // (drains the LDS-DMA: hipcc emits vmcnt(0) before a barrier while one is in flight)
-        for (int kt = kt_begin; kt < kt_end; ++kt) {
-            const int buf = (kt - kt_begin) & 1;
-            if (kt + 1 < kt_end) GEMM_DMA(kt + 1, buf ^ 1);
-            GEMM_COMPUTE(buf);
-            __syncthreads();
-        }
-    } else {
-        if (kt_begin < kt_end) {
-            GEMM_GLOAD(kt_begin);
-            GEMM_LSTORE(0);
-        }
+    if (kt_begin < kt_end) GEMM_DMA(kt_begin, 0);
+    __syncthreads();  // (drains the LDS-DMA: hipcc emits vmcnt(0) before a barrier while one is in flight)
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) GEMM_DMA(kt + 1, buf ^ 1);
+        GEMM_COMPUTE(buf);
         __syncthreads();
-        for (int kt = kt_begin; kt < kt_end; ++kt) {
-            const int buf = (kt - kt_begin) & 1;
-            // register-staged variant: prefetch -> MFMA -> LDS store, pinned so the loads are not sunk to their ds_writes
-            GEMM_GLOAD(kt + 1 < kt_end ? kt + 1 : kt);
-            __builtin_amdgcn_sched_barrier(0);
-            GEMM_COMPUTE(buf);
-            __builtin_amdgcn_sched_barrier(0);
-            GEMM_LSTORE(buf ^ 1);
-            __syncthreads();
-        }
     }
-
     if (EPI == EPI_ATOMIC) {  // un-swapped: column = lane & 31, rows from the register index
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -358,65 +295,88 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// v3: 256 x 256 x 64 workgroup tile, 8 waves (2 x 4), 128 x 64 per wave (4 x 2 MFMA 32x32x16 blocks, 128 accumulator
-// registers), two 64-KiB LDS stages filled by direct-to-LDS DMA one K tile ahead.
-// Why (tools/ablate, MI355X): with 64x64 per-wave tiles the LDS is the shared bottleneck -- DMA fills and fragment reads
-// together take as long as the MFMAs (MFMA-only 1571 TFLOP/s, DMA-only about the same, combined ~900).  This geometry
-// needs 27 % fewer LDS read bytes and 50 % fewer LDS write bytes per FLOP and 6 ds_read_b128 per 8 MFMAs, and one K tile
-// of MFMA work per wave pair (~2k cycles) covers the DMA latency.
+// 256 x 256 x 64 workgroup tile, 8 waves (2 x 4), 128 x 64 per wave, "ping-pong" K loop on v_mfma_f32_16x16x32.
+//
+// Why this shape of loop (measured on MI355X, tools/ablate/pp_lab.hip, mfma_bench.hip, dma_bench.hip):
+//  * The chip is POWER-limited in a dense GEMM on real data: the clock settles at 1.35-1.65 GHz (2.4 GHz on all-zero
+//    operands), so TFLOP/s is set by energy per FLOP, not by issue slots.  v_mfma_f32_16x16x32 sustains ~1800 TFLOP/s on
+//    random operands, v_mfma_f32_32x32x16 ~1550 (twice the accumulator read/write traffic per FLOP): the whole kernel moved
+//    from 1270 to 1440 TFLOP/s at 8192^3 by changing the MFMA shape alone.  Fragment reads cost ~6 %, the DMA ~13 % of the energy.
+//  * The two wave rows run half a phase apart.  A K tile is four phases; in each, a wave computes one 64 x 32 quadrant of its
+//    sub-tile (4 x 2 blocks x 2 k-steps = 16 back-to-back MFMAs) between two workgroup barriers, and before the first of them
+//    does its memory work: 2 direct-to-LDS DMA pieces of a later K tile and the fragment reads the coming quadrant needs (A half:
+//    8 ds_read_b128, B half: 4).  Waves 4-7 execute one extra barrier up front, so on every SIMD one wave is in its MFMA section
+//    while its partner issues DMA / LDS reads: 92 % MFMA-pipe occupancy in cycles, against two waves that stall on the same
+//    `s_waitcnt lgkmcnt(0)` at the same time in a lock-step loop.
+//  * Reads per phase are balanced 8/4/8/4: the next tile's B half 0 is read in P4 into the registers that B half 1 vacated after
+//    P3, so the two B register sets swap roles every K tile (two tiles per loop trip).
+// DMA plan for K tile t+1 (16 pieces of 8 rows x 128 B per slot, 2 per wave): B half-0 rows at P2(t-1), A half-0 rows at P3(t-1),
+// B half-1 rows at P4(t-1), A half-1 rows at P1(t) -- each at least two barriers after the last read of the region it overwrites --
+// retired by ONE counted `s_waitcnt vmcnt(4)` at P3(t) ahead of that phase's first barrier (the 4 youngest pieces belong to tile
+// t+2); the first read of tile t+1 (its B half 0) is a phase later, in P4(t).
+// Operands come through buffer descriptors: rows past M read as zeros, 32-bit lane offsets + an SGPR K offset.
+// LDS: A stage s at s * 32 KiB, B stage s at 64 KiB + s * 32 KiB -> every fragment read is `vaddr + imm16`; the address registers
+// flip bit 15 per K tile.  128-byte rows, 16-B chunk c of row r stored at chunk c ^ ((r >> 1) & 7) (applied on the DMA source
+// address): conflict-free for the 16 x 32 fragment reads (lane & 15 = row, lane >> 4 = chunk inside the k-step).
+// Accumulators: acc[i][j], i = 0..7 (16-row blocks), j = 0..3 (16-column blocks); the MFMA operands are issued swapped (B fragment
+// first), so a block holds C^T: lane & 15 = row, register r = column 4 (lane >> 4) + r -> a lane owns 4 CONSECUTIVE columns of
+// one row per block (16-byte fp32 / 8-byte 16-bit staging writes).
 // ---------------------------------------------------------------------------------------------------------------------
-// ---- v3 staged epilogue ------------------------------------------------------------------------------------------------
-// After the K loop each wave owns a private 17 KiB LDS region.  The accumulators (C^T layout: lane = row, register quad = 4
-// columns) are written there as a row-major [rows][64] sub-tile (padded row stride: conflict-free), then read back so that
-// 8 (16-bit) or 16 (fp32) consecutive lanes cover one full output row: every global store / residual load is a run of whole
-// 128- / 256-byte rows instead of 64 different cache lines per instruction.
+// ---- staged epilogue ---------------------------------------------------------------------------------------------------
+// After the K loop each wave owns a private 17 KiB LDS region.  The accumulators are written there as a row-major [rows][64]
+// sub-tile (padded row stride), then read back so that 8 (16-bit) or 16 (fp32) consecutive lanes cover one full output row: every
+// global store / residual load is a run of whole 128- / 256-byte rows instead of 64 different cache lines per instruction.
 #define V3_WLDS 17408          // per-wave bytes: 128 rows x 136 B (16-bit) or 64 rows x 264 B (fp32, two passes)
 #define V3_RS16 136
 #define V3_RS32 264
+#define V3_T 256
+#define V3_STAGE (64 * 1024)
+#define V3_LDS (8 * V3_WLDS > 2 * V3_STAGE ? 8 * V3_WLDS : 2 * V3_STAGE)
 
-// Per-lane column constants (bias, plus the rel-pos u / v vector for the q projection) for the 32 columns a lane owns in
-// the C^T accumulator layout: fetched ONCE, before any store -- the output pointers may alias them as far as the compiler
-// knows, so a load placed between stores costs a full `s_waitcnt vmcnt(0)` round trip each time (measured: 8 us / tile).
-__device__ __forceinline__ void v3_col_consts(float (&bv)[2][4][4], const float* bias_n, const float* extra, int lg) {
+// Per-lane column constants (bias, plus the rel-pos u / v vector for the q projection) for the 16 columns a lane owns: fetched ONCE,
+// before any store -- the output pointers may alias them as far as the compiler knows, so a load placed between stores costs a full
+// `s_waitcnt vmcnt(0)` round trip each time (measured: 8 us / tile).
+__device__ __forceinline__ void pp_col_consts(float (&bv)[4][4], const float* bias_n, const float* extra, int lq) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int col = j * 32 + 8 * q + 4 * lg;
-            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (bias_n != nullptr) b = *reinterpret_cast<const float4*>(bias_n + col);
-            if (extra != nullptr) {
-                const float4 x = *reinterpret_cast<const float4*>(extra + col);
-                b.x += x.x; b.y += x.y; b.z += x.z; b.w += x.w;
-            }
-            bv[j][q][0] = b.x; bv[j][q][1] = b.y; bv[j][q][2] = b.z; bv[j][q][3] = b.w;
+    for (int j = 0; j < 4; ++j) {
+        const int col = j * 16 + 4 * lq;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias_n != nullptr) b = *reinterpret_cast<const float4*>(bias_n + col);
+        if (extra != nullptr) {
+            const float4 x = *reinterpret_cast<const float4*>(extra + col);
+            b.x += x.x; b.y += x.y; b.z += x.z; b.w += x.w;
         }
+        bv[j][0] = b.x; bv[j][1] = b.y; bv[j][2] = b.z; bv[j][3] = b.w;
+    }
 }
 
 template <bool F16, int MODE>
-__device__ __forceinline__ void v3_stage16(unsigned char* wl, const f32x16_t (&acc)[4][2], const float (&bv)[2][4][4], int lr, int lg) {
+__device__ __forceinline__ void pp_stage16(unsigned char* wl, const f32x4_t (&acc)[8][4], const float (&bv)[4][4], int l15, int lq) {
     // mode 0: acc + column constant   1: gelu_fast(acc + column constant)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int col = j * 32 + 8 * q + 4 * lg;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; e += 2) {
-                    f32x2v x = {acc[i][j][4 * q + e] + bv[j][q][e], acc[i][j][4 * q + e + 1] + bv[j][q][e + 1]};
-                    if (MODE == 1) x = gelu_fast2(x);
-                    v[e] = x.x; v[e + 1] = x.y;
-                }
-                uint2 pk;
-                pk.x = pack2<F16>(v[0], v[1]);
-                pk.y = pack2<F16>(v[2], v[3]);
-                *reinterpret_cast<uint2*>(wl + (i * 32 + lr) * V3_RS16 + col * 2) = pk;
-            }
+        for (int j = 0; j < 4; ++j) {
+            f32x2v x0 = {acc[i][j][0] + bv[j][0], acc[i][j][1] + bv[j][1]};
+            f32x2v x1 = {acc[i][j][2] + bv[j][2], acc[i][j][3] + bv[j][3]};
+            if (MODE == 1) { x0 = gelu_fast2(x0); x1 = gelu_fast2(x1); }
+            uint2 pk;
+            pk.x = pack2<F16>(x0.x, x0.y);
+            pk.y = pack2<F16>(x1.x, x1.y);
+            *reinterpret_cast<uint2*>(wl + (i * 16 + l15) * V3_RS16 + (j * 16 + 4 * lq) * 2) = pk;
+        }
 }
-// 64 staged rows (accumulator blocks i0, i0 + 1) as fp32
+// 64 staged rows (accumulator blocks 4 p .. 4 p + 3) as fp32
+__device__ __forceinline__ void pp_stage32(unsigned char* wl, const f32x4_t (&acc)[8][4], int p, int l15, int lq) {
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4_t& a = acc[4 * p + ii][j];
+            *reinterpret_cast<float4*>(wl + (ii * 16 + l15) * V3_RS32 + (j * 16 + 4 * lq) * 4) = make_float4(a[0], a[1], a[2], a[3]);
+        }
+}
+// (32 x 32 accumulator blocks: the TN weight-gradient kernel)
 __device__ __forceinline__ void v3_stage32(unsigned char* wl, const f32x16_t (&acc)[4][2], int i0, int lr, int lg) {
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
@@ -431,17 +391,12 @@ __device__ __forceinline__ void v3_stage32(unsigned char* wl, const f32x16_t (&a
             }
 }
 
-// C-tile stores of the 256^2 kernel are non-temporal: the tile is not re-read by this kernel, and write-allocating it evicts
-// the A/B panels that the neighbouring column tiles still need from the 4 MB L2 (+2..4 % on the model's shapes, 156 -> 154 ms
-// per step; -DV3_NT_STORE=0 restores plain stores).
-#ifndef V3_NT_STORE
-#define V3_NT_STORE 1
-#endif
+// C-tile stores of the 256^2 kernels are non-temporal: the tile is not re-read by this kernel, and write-allocating it evicts
+// the A/B panels that the neighbouring column tiles still need from the 4 MB L2 (+2..4 % on the model's shapes).
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 template <class T>
 __device__ __forceinline__ void v3_st(void* p, const T& v) {
-#if V3_NT_STORE
     if constexpr (sizeof(T) == 16) {
         u32x4_t t;
         __builtin_memcpy(&t, &v, 16);
@@ -451,9 +406,6 @@ __device__ __forceinline__ void v3_st(void* p, const T& v) {
         __builtin_memcpy(&t, &v, 8);
         __builtin_nontemporal_store(t, reinterpret_cast<u32x2_t*>(p));
     }
-#else
-    *reinterpret_cast<T*>(p) = v;
-#endif
 }
 
 // Side input of one batch (8 rows per lane, rows m0 + 4 u + lane/16): residual rows (fp32) or saved pre-activations (16-bit)
@@ -517,43 +469,35 @@ __device__ __forceinline__ void v3_store_batch(const GemmArgs& g, const unsigned
 
 template <int EPI>
 struct V3Consts {  // per-lane bias values, fetched before the K loop so their latency is off the epilogue's critical path
-    static constexpr bool kStaged16 = (EPI == EPI_BF16 || EPI == EPI_GELU);  // QKV is at the VGPR cap: it loads late
-    float bv[kStaged16 ? 2 : 1][kStaged16 ? 4 : 1][4];
+    static constexpr bool kStaged16 = (EPI == EPI_BF16 || EPI == EPI_GELU);
+    float bv[kStaged16 ? 4 : 1][4];
 };
 template <int EPI>
 __device__ __forceinline__ void v3_load_consts(V3Consts<EPI>& c, const GemmArgs& g, int nb, int lane) {
-    if (EPI == EPI_QKV) {
-        c.bv[0][0][0] = 0.f;
-    } else if (V3Consts<EPI>::kStaged16) {
-        float t[2][4][4];
-        v3_col_consts(t, g.bias != nullptr ? g.bias + nb : nullptr, nullptr, lane >> 5);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) c.bv[V3Consts<EPI>::kStaged16 ? j : 0][V3Consts<EPI>::kStaged16 ? q : 0][e] = t[j][q][e];
+    if constexpr (EPI == EPI_QKV) {
+        c.bv[0][0] = 0.f;
+    } else if constexpr (V3Consts<EPI>::kStaged16) {
+        pp_col_consts(c.bv, g.bias != nullptr ? g.bias + nb : nullptr, nullptr, lane >> 4);
     } else {
         float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
         if (g.bias != nullptr) b = *reinterpret_cast<const float4*>(g.bias + nb + (lane & 15) * 4);
-        c.bv[0][0][0] = b.x; c.bv[0][0][1] = b.y; c.bv[0][0][2] = b.z; c.bv[0][0][3] = b.w;
+        c.bv[0][0] = b.x; c.bv[0][1] = b.y; c.bv[0][2] = b.z; c.bv[0][3] = b.w;
     }
 }
 
 template <int EPI, bool F16>
-__device__ __forceinline__ void v3_epilogue(const GemmArgs& g, const f32x16_t (&acc)[4][2], const V3Consts<EPI>& cc,
+__device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&acc)[8][4], const V3Consts<EPI>& cc,
                                             unsigned char* wl, int mb, int nb, int lane) {
     // mb = first row of this wave's 128 x 64 sub-tile, nb = its first column
-    const int lr = lane & 31, lg = lane >> 5;
+    const int l15 = lane & 15, lq = lane >> 4;
     if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
-        const float (&bv)[2][4][4] = cc.bv;
 #pragma unroll
         for (int pass = 0; pass < (EPI == EPI_GELU ? 2 : 1); ++pass) {
             bf16_t* out = (EPI == EPI_GELU && pass == 1) ? g.outH2 : g.outH;
             if (out == nullptr) continue;
-            if (EPI == EPI_GELU && pass == 1) v3_stage16<F16, 1>(wl, acc, bv, lr, lg);
-            else if (EPI == EPI_GELU && F16 && g.bwd_bf16) v3_stage16<false, 0>(wl, acc, bv, lr, lg);  // pre-activation for the bf16 backward
-            else v3_stage16<F16, 0>(wl, acc, bv, lr, lg);
+            if (EPI == EPI_GELU && pass == 1) pp_stage16<F16, 1>(wl, acc, cc.bv, l15, lq);
+            else if (EPI == EPI_GELU && F16 && g.bwd_bf16) pp_stage16<false, 0>(wl, acc, cc.bv, l15, lq);  // pre-activation for the bf16 backward
+            else pp_stage16<F16, 0>(wl, acc, cc.bv, l15, lq);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int rb = 0; rb < 16; rb += 8) {
@@ -581,9 +525,9 @@ __device__ __forceinline__ void v3_epilogue(const GemmArgs& g, const f32x16_t (&
             if (which == 0 && g.pu != nullptr) extra = (pass == 0 ? g.pu : g.pv) + h * 64;
             bf16_t* rd = pass == 0 ? row_dst : g.q2;
             bf16_t* td = pass == 0 ? tr_dst : g.q2t;
-            float bv[2][4][4];
-            v3_col_consts(bv, g.bias != nullptr ? g.bias + nb : nullptr, extra, lg);
-            v3_stage16<F16, 0>(wl, acc, bv, lr, lg);
+            float bv[4][4];
+            pp_col_consts(bv, g.bias != nullptr ? g.bias + nb : nullptr, extra, lq);
+            pp_stage16<F16, 0>(wl, acc, bv, l15, lq);
             // Tensors that only the bf16 backward reads (row-major V; Q^T, K^T, (q+v)^T) are emitted as bf16 when g.bwd_bf16 is
             // set: converted from the staged f16 tile on the way out (same double rounding as a later in-place conversion,
             // without the extra pass over HBM); V^T and the row-major q / k stay f16.
@@ -648,39 +592,22 @@ __device__ __forceinline__ void v3_epilogue(const GemmArgs& g, const f32x16_t (&
         }
         return;
     }
-    if constexpr (EPI == EPI_ATOMIC) {
-        // split-K weight gradients: stage the tile row-major, then one atomic per lane with the 64 lanes on 64 consecutive
-        // columns (256 contiguous bytes per instruction)
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            v3_stage32(wl, acc, 2 * pass, lr, lg);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll 8
-            for (int row = 0; row < 64; ++row) {
-                const int m = mb + pass * 64 + row;
-                const float v = *reinterpret_cast<const float*>(wl + row * V3_RS32 + lane * 4);
-                if (m < g.M) unsafeAtomicAdd(&g.outF[(size_t)m * g.ldc + nb + lane], v * g.alpha);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        return;
-    }
     // fp32-staged epilogues (two passes of 64 rows): EPI_F32, EPI_F32_RESID, EPI_F32_BF16, EPI_GELU32, EPI_DGELU
     // 16 lanes x 16 B = one 256-B fp32 row; the lane's 4 columns (and so its bias) are the same for every row.  Four batches
     // of 8 rows-per-lane; the residual / saved pre-activation of batch k+1 is requested before batch k is stored, so its
-    // latency hides under the stores (loads placed between stores would each cost a full wait, see v3_col_consts).
+    // latency hides under the stores (loads placed between stores would each cost a full wait, see pp_col_consts).
     const int c4 = lane & 15, n = nb + c4 * 4;
-    const float4 b = make_float4(cc.bv[0][0][0], cc.bv[0][0][1], cc.bv[0][0][2], cc.bv[0][0][3]);
+    const float4 b = make_float4(cc.bv[0][0], cc.bv[0][1], cc.bv[0][2], cc.bv[0][3]);
     V3Side<EPI> s0, s1;
     v3_side_load<EPI>(s0, g, mb, n, lane);
-    v3_stage32(wl, acc, 0, lr, lg);
+    pp_stage32(wl, acc, 0, l15, lq);
     __builtin_amdgcn_wave_barrier();
     v3_side_load<EPI>(s1, g, mb + 32, n, lane);
     v3_store_batch<EPI, F16>(g, wl, s0, b, mb, 0, n, c4, lane);
     v3_side_load<EPI>(s0, g, mb + 64, n, lane);
     v3_store_batch<EPI, F16>(g, wl, s1, b, mb + 32, 32, n, c4, lane);
     __builtin_amdgcn_wave_barrier();
-    v3_stage32(wl, acc, 2, lr, lg);
+    pp_stage32(wl, acc, 1, l15, lq);
     __builtin_amdgcn_wave_barrier();
     v3_side_load<EPI>(s1, g, mb + 96, n, lane);
     v3_store_batch<EPI, F16>(g, wl, s0, b, mb + 64, 0, n, c4, lane);
@@ -688,740 +615,131 @@ __device__ __forceinline__ void v3_epilogue(const GemmArgs& g, const f32x16_t (&
     __builtin_amdgcn_wave_barrier();
 }
 
-#define V3_T 256
-#define V3_STAGE (64 * 1024)
-#ifdef SED_GEMM_TRACE  // developer build only (tools/ablate/trace_v3.py): per-workgroup phase timestamps
-__device__ unsigned long long* sed_trace_buf = nullptr;
-__device__ int sed_trace_wave = 0;   // which wave of the workgroup reports its per-K-tile waits
-extern "C" int sed_debug_set_gemm_trace(unsigned long long* p) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(sed_trace_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+template <bool F16> __device__ __forceinline__ f32x4_t mfma16t(s16x8_t a, s16x8_t b, f32x4_t c) {
+    if (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
-extern "C" int sed_debug_set_gemm_trace_wave(int w) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(sed_trace_wave), &w, sizeof(w)) == hipSuccess ? 0 : -1;
-}
-#define V3_TRACE(slot) do { if (tid == 0 && sed_trace_buf != nullptr) sed_trace_buf[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
-#else
-#define V3_TRACE(slot) do {} while (0)
-#endif
-#define V3_LDS (8 * V3_WLDS > 2 * V3_STAGE ? 8 * V3_WLDS : 2 * V3_STAGE)
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 template <int EPI, bool F16>
-__global__ __launch_bounds__(512) void gemm_nt_v3_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    V3_TRACE(0);
-#ifdef SED_GEMM_TRACE
-    if (tid == 0 && sed_trace_buf != nullptr) {
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        sed_trace_buf[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hw;
-    }
-#endif
-    const int ntn = g.N / V3_T, ntm = (g.M + V3_T - 1) / V3_T, nwg = ntm * ntn;
-    if (g.stagger > 0 && blockIdx.x < 256) {
-        // De-phase the first round: identical workgroups launched together reach their epilogues together and the
-        // whole chip's C tiles hit HBM in one burst (measured: 8-25 us of store issue per tile vs ~2 us alone).
-        const unsigned long long wait = (unsigned long long)(((blockIdx.x >> 3) & 7) * g.stagger);
-        const unsigned long long t0 = wall_clock64();
-        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-    }
-    const int t = xcd_remap(blockIdx.x, nwg);
-    const int group_size = 4 * ntn, gid = t / group_size, first_m = gid * 4;
-    const int gm = (ntm - first_m) < 4 ? (ntm - first_m) : 4;
-    const int tin = t - gid * group_size;
-    const int m0 = (first_m + tin % gm) * V3_T, n0 = (tin / gm) * V3_T;
-    const int ktiles = g.K / BK;
-    const int kt_begin = (int)(((long long)blockIdx.y * ktiles) / g.ksplit);
-    const int kt_end = (int)(((long long)(blockIdx.y + 1) * ktiles) / g.ksplit);
-    const int nk = kt_end - kt_begin;
-
-    // DMA: 32 (A) + 32 (B) pieces of 8 rows x 128 B per stage; wave w owns pieces 8 w .. 8 w + 7 (waves 0-3: A, 4-7: B)
-    const int prow = lane >> 3, pch = lane & 7;
-    const bf16_t* src[8];
-    int dst[8];
-    const bool isB = wave >= 4;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int piece = (wave & 3) * 8 + i;
-        const int row = piece * 8 + prow;
-        const int cl = pch ^ ((row >> 1) & 7);
-        int am = m0 + row;
-        am = am < g.M ? am : g.M - 1;
-        src[i] = isB ? g.B + (size_t)(n0 + row) * g.ldb + cl * 8 : g.A + (size_t)am * g.lda + cl * 8;
-        dst[i] = (isB ? 32768 : 0) + piece * 1024;
-    }
-#define V3_DMA(kt, stage)                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                         \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)(kt) * BK),     \
-                                         (__attribute__((address_space(3))) void*)(lds3 + (stage) * V3_STAGE + dst[i]),   \
-                                         16, 0, 0);
-#define V3_DMA2(kt, stage, I0)                                                                                            \
-    _Pragma("unroll") for (int i = (I0); i < (I0) + 2; ++i)                                                               \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)(kt) * BK),     \
-                                         (__attribute__((address_space(3))) void*)(lds3 + (stage) * V3_STAGE + dst[i]),   \
-                                         16, 0, 0);
-    f32x16_t acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int lr = lane & 31, lg = lane >> 5;
-    int aoff[4], boff[2], aswz[4], bswz[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const int r = wm * 128 + i * 32 + lr; aoff[i] = r * 128; aswz[i] = (r >> 1) & 7; }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { const int r = wn * 64 + j * 32 + lr; boff[j] = 32768 + r * 128; bswz[j] = (r >> 1) & 7; }
-
-    V3Consts<EPI> cc;
-    v3_load_consts<EPI>(cc, g, n0 + wn * 64, lane);
-#ifndef V3_XBAR
-#define V3_XBAR 1
-#endif
-#ifndef V3_DMA_SPREAD
-#define V3_DMA_SPREAD 1   // +4-5 % on every shape of tools/gemm_bench.py (ablation: the DMA's LDS writes cost the loop 22 %, the fragment reads 11 %)
-#endif
-#if V3_XBAR
-    // The per-K-tile barrier sits BEFORE the last k-step's MFMAs instead of at the top of the tile: by then every wave has
-    // finished reading the current stage (its k-step-3 fragments are in registers), so right after the barrier the stage can be
-    // handed to the DMA of tile it+2, and the first fragments of tile it+1 (landed: vmcnt(0) + barrier) are requested from the
-    // other stage -- both latencies run under the 8 MFMAs of k-step 3 instead of stalling the top of the next tile (a phase trace
-    // showed the waves never wait for DMA data; they idle ~400 cycles per tile between barrier and first MFMA).
-#ifdef SED_GEMM_TRACE
-    unsigned long long tw = 0, tb = 0;   // (per-wave wait accounting exists for the V3_XBAR=0 loop only)
-#endif
-    s16x8_t af[2][4], bfr[2][2];
-#define V3_FRAGS(SET, BASE, KS)                                                                                           \
-    {                                                                                                                     \
-        const int ch_ = 2 * (KS) + lg;                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                     \
-            af[SET][i] = *reinterpret_cast<const s16x8_t*>((BASE) + aoff[i] + ((ch_ ^ aswz[i]) << 4));                    \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                     \
-            bfr[SET][j] = *reinterpret_cast<const s16x8_t*>((BASE) + boff[j] + ((ch_ ^ bswz[j]) << 4));                   \
-    }
-    if (nk > 0) {
-        V3_DMA(kt_begin, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        V3_TRACE(1);
-#if V3_DMA_SPREAD
-        if (nk > 1) { V3_DMA2(kt_begin + 1, 1, 0); }
-#else
-        if (nk > 1) { V3_DMA(kt_begin + 1, 1); }
-#endif
-        V3_FRAGS(0, lds3, 0);
-#ifdef V3_ABLATE
-        V3_FRAGS(1, lds3, 1);
-#endif
-    }
-    for (int it = 0; it < nk; ++it) {
-        const unsigned char* base = lds3 + (it & 1) * V3_STAGE;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int cur = s & 1, nxt = cur ^ 1;
-#ifdef V3_ABLATE   // timing experiments only (results are wrong): bit 0 = no DMA, bit 1 = no fragment reads, bit 2 = no barrier
-            if (s < 3) {
-                if (!(V3_ABLATE & 2)) { V3_FRAGS(nxt, base, s + 1); }
-            } else if (it + 1 < nk) {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                if (!(V3_ABLATE & 4)) __builtin_amdgcn_s_barrier();
-                if (!(V3_ABLATE & 1) && it + 2 < nk) { V3_DMA(kt_begin + it + 2, it & 1); }
-                if (!(V3_ABLATE & 2)) { V3_FRAGS(nxt, lds3 + ((it + 1) & 1) * V3_STAGE, 0); }
-            }
-            if (V3_ABLATE & 2) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(af[nxt][i]));
-#pragma unroll
-                for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(bfr[nxt][j]));
-            }
-#else
-            if (s < 3) {
-#if V3_DMA_SPREAD
-                // the DMA of tile it+1 is spread over the k-steps (2 of this wave's 8 pieces each) instead of one burst of 64 KiB
-                // into the LDS right when every wave starts reading fragments
-                if (it + 1 < nk) { V3_DMA2(kt_begin + it + 1, (it + 1) & 1, 2 * s + 2); }
-#endif
-                V3_FRAGS(nxt, base, s + 1);
-            } else if (it + 1 < nk) {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // next tile landed; my reads of this stage are done
-                __builtin_amdgcn_s_barrier();                                 // ... for every wave
-#if V3_DMA_SPREAD
-                if (it + 2 < nk) { V3_DMA2(kt_begin + it + 2, it & 1, 0); }
-#else
-                if (it + 2 < nk) { V3_DMA(kt_begin + it + 2, it & 1); }       // this stage is free again
-#endif
-                V3_FRAGS(nxt, lds3 + ((it + 1) & 1) * V3_STAGE, 0);
-            }
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32t<F16>(bfr[cur][j], af[cur][i], acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#undef V3_FRAGS
-#else
-    if (nk > 0) { V3_DMA(kt_begin, 0); }
-#ifdef SED_GEMM_TRACE
-    unsigned long long tw = 0, tb = 0;
-#endif
-    for (int it = 0; it < nk; ++it) {
-        const int stage = it & 1;
-#ifdef SED_GEMM_TRACE
-        const unsigned long long c0 = __builtin_readcyclecounter();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long c1 = __builtin_readcyclecounter();
-        __builtin_amdgcn_s_barrier();
-        const unsigned long long c2 = __builtin_readcyclecounter();
-        if (it > 0) { tw += c1 - c0; tb += c2 - c1; }
-#else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // tile `it` landed (all waves); the other stage is no longer being read
-#endif
-        if (it == 0) V3_TRACE(1);
-        if (it + 1 < nk) { V3_DMA(kt_begin + it + 1, stage ^ 1); }
-        const unsigned char* base = lds3 + stage * V3_STAGE;
-        s16x8_t af[2][4], bfr[2][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[0][i] = *reinterpret_cast<const s16x8_t*>(base + aoff[i] + ((lg ^ aswz[i]) << 4));
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bfr[0][j] = *reinterpret_cast<const s16x8_t*>(base + boff[j] + ((lg ^ bswz[j]) << 4));
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int cur = s & 1, nxt = cur ^ 1;
-            if (s < 3) {
-                const int ch = 2 * (s + 1) + lg;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    af[nxt][i] = *reinterpret_cast<const s16x8_t*>(base + aoff[i] + ((ch ^ aswz[i]) << 4));
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    bfr[nxt][j] = *reinterpret_cast<const s16x8_t*>(base + boff[j] + ((ch ^ bswz[j]) << 4));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32t<F16>(bfr[cur][j], af[cur][i], acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#endif
-    __builtin_amdgcn_s_barrier();  // every wave is done reading the operand stages: LDS becomes the per-wave C staging area
-    V3_TRACE(2);
-#ifdef SED_GEMM_TRACE
-    if (lane == 0 && wave == sed_trace_wave && sed_trace_buf != nullptr) { sed_trace_buf[(size_t)blockIdx.x * 8 + 5] = tw; sed_trace_buf[(size_t)blockIdx.x * 8 + 6] = tb; }
-#endif
-    v3_epilogue<EPI, F16>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * 128, n0 + wn * 64, lane);
-    V3_TRACE(3);
-#ifdef SED_GEMM_TRACE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    V3_TRACE(4);
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// v7: 256 x 256 workgroup tile, FOUR waves (2 x 2) with 128 x 128 per wave (16 MFMA blocks = 256 accumulator registers in the
-// AGPR half of the unified file, one wave per SIMD), K consumed in 32-deep tiles through FOUR 32 KiB LDS stages.
-// Why: v3 keeps one K tile in flight, so an iteration can never be shorter than one DMA round trip (~2 us under load = its
-// measured iteration time; halving the LDS fragment traffic alone -- the same 4-wave geometry at BK = 64 -- changed nothing).
-// Here two tiles are in flight while two have landed: tile it is being multiplied, tile it+1 is already visible (its first
-// fragments are pre-read under tile it's MFMAs, so no LDS latency is exposed after the barrier), tiles it+2 and it+3 fly.
-// Counted `s_waitcnt vmcnt(8)` (8 DMA instructions per wave per tile) + raw s_barrier per tile.
-// LDS rows are 64 B: 16-B chunk c of row r is stored at chunk c ^ ((r >> 2) & 3) (conflict-free for the ds_read_b128 lane groups).
-// ---------------------------------------------------------------------------------------------------------------------
-#define V7_BK 32
-#define V7_STAGE (32 * 1024)
-#define V7_NST 4
-#define V7_LDS (V7_NST * V7_STAGE)
-template <int EPI, bool F16>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_v7_kernel(const GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
     const int ntn = g.N / V3_T, ntm = (g.M + V3_T - 1) / V3_T, nwg = ntm * ntn;
     const int t = xcd_remap(blockIdx.x, nwg);
     const int group_size = 4 * ntn, gid = t / group_size, first_m = gid * 4;
     const int gm = (ntm - first_m) < 4 ? (ntm - first_m) : 4;
     const int tin = t - gid * group_size;
     const int m0 = (first_m + tin % gm) * V3_T, n0 = (tin / gm) * V3_T;
-    const int ktiles = g.K / V7_BK;
-    const int kt_begin = (int)(((long long)blockIdx.y * ktiles) / g.ksplit);
-    const int kt_end = (int)(((long long)(blockIdx.y + 1) * ktiles) / g.ksplit);
-    const int nk = kt_end - kt_begin;
-
-    // DMA: 16 (A) + 16 (B) pieces of 16 rows x 64 B per stage; waves 0,1 fetch A pieces, waves 2,3 B pieces (8 each)
-    const int prow = lane >> 2, pch = lane & 3;
-    const bool isB = wave >= 2;
-    const bf16_t* const opbase = isB ? g.B : g.A;
-    unsigned src[8];  // element offsets (the launcher checks they fit 32 bits)
-    const int dst0 = (isB ? 16384 : 0) + (wave & 1) * 8 * 1024;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = ((wave & 1) * 8 + i) * 16 + prow;
-        const int cl = pch ^ ((row >> 2) & 3);
-        int am = m0 + row;
-        am = am < g.M ? am : g.M - 1;
-        src[i] = (unsigned)((isB ? (n0 + row) * g.ldb : am * g.lda) + cl * 8 + kt_begin * V7_BK);
-    }
-#define V7_DMA(kt)                                                                                                        \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                         \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(opbase + src[i] + (kt) * V7_BK), \
-                                         (__attribute__((address_space(3))) void*)(lds3 + ((kt) & 3) * V7_STAGE + dst0 + i * 1024), \
-                                         16, 0, 0);
-    f32x16_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int lr = lane & 31, lg = lane >> 5;
-    int aoff[4], boff[4], aswz[4], bswz[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const int r = wm * 128 + i * 32 + lr; aoff[i] = r * 64; aswz[i] = (r >> 2) & 3; }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const int r = wn * 128 + j * 32 + lr; boff[j] = 16384 + r * 64; bswz[j] = (r >> 2) & 3; }
-#define V7_FRAGS(dstA, dstB, kt, s)                                                                                       \
-    {                                                                                                                     \
-        const unsigned char* fb = lds3 + ((kt) & 3) * V7_STAGE;                                                           \
-        const int ch = 2 * (s) + lg;                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) dstA[i] = *reinterpret_cast<const s16x8_t*>(fb + aoff[i] + ((ch ^ aswz[i]) << 4)); \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) dstB[j] = *reinterpret_cast<const s16x8_t*>(fb + boff[j] + ((ch ^ bswz[j]) << 4)); \
-    }
-#define V7_MFMA(fa, fb_)                                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                         \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mfma32t<F16>(fb_[j], fa[i], acc[i][j]);
-
-    s16x8_t a0[4], b0[4], a1[4], b1[4];
-    if (nk > 0) {
-        V7_DMA(0);
-        if (nk > 1) { V7_DMA(1); }
-        if (nk > 2) { V7_DMA(2); }
-        if (nk > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        V7_FRAGS(a0, b0, 0, 0);
-    }
-    for (int it = 0; it < nk; ++it) {
-        // tile it + 1 must be visible before this iteration pre-reads its first fragments; tile it + 2 may stay in flight
-        if (it + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // ... for every wave's pieces; also: nobody still reads stage (it - 1) & 3
-        if (it + 3 < nk) { V7_DMA(it + 3); }
-        V7_FRAGS(a1, b1, it, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        V7_MFMA(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (it + 1 < nk) { V7_FRAGS(a0, b0, it + 1, 0); }
-        __builtin_amdgcn_sched_barrier(0);
-        V7_MFMA(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    __builtin_amdgcn_s_barrier();  // every wave is done reading the operand stages: LDS becomes the per-wave C staging area
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int nb = n0 + wn * 128 + h * 64;
-        V3Consts<EPI> cc;
-        v3_load_consts<EPI>(cc, g, nb, lane);
-        f32x16_t a2[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { a2[i][0] = acc[i][2 * h]; a2[i][1] = acc[i][2 * h + 1]; }
-        v3_epilogue<EPI, F16>(g, a2, cc, lds3 + wave * V3_WLDS, m0 + wm * 128, nb, lane);
-    }
-#undef V7_DMA
-#undef V7_FRAGS
-#undef V7_MFMA
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// v5 = v3's main loop as a PERSISTENT kernel (one workgroup per CU walks its XCD's share of the tiles).  What it buys: the next
-// tile's first K-tile DMA is issued right after the last MFMA of the current tile, BEFORE the epilogue, so the ~3 us DMA
-// prologue that every short-K tile paid (K = 768: 22 us main loop) runs under the epilogue's LDS staging and stores.  The
-// epilogue therefore may only use LDS outside stage 0: per-wave staging shrinks to 8.5 KiB (64 rows of 16-bit / 32 rows of
-// fp32 per pass) placed on stage 1 and the 27 KiB above the stages.
-// ---------------------------------------------------------------------------------------------------------------------
-#define V5_WLDS 8704
-#define V5_LDS (V3_STAGE + 8 * V5_WLDS)
-template <bool F16, int MODE>
-__device__ __forceinline__ void v5_stage16(unsigned char* wl, const f32x16_t (&acc)[4][2], const float (&bv)[2][4][4], int p, int lr,
-                                           int lg) {
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int col = j * 32 + 8 * q + 4 * lg;
-                const f32x16_t& a = p == 0 ? acc[ii][j] : acc[2 + ii][j];
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float x = a[4 * q + e] + bv[j][q][e];
-                    v[e] = MODE == 1 ? gelu_fast(x) : x;
-                }
-                uint2 pk;
-                pk.x = pack2<F16>(v[0], v[1]);
-                pk.y = pack2<F16>(v[2], v[3]);
-                *reinterpret_cast<uint2*>(wl + (ii * 32 + lr) * V3_RS16 + col * 2) = pk;
-            }
-}
-__device__ __forceinline__ void v5_stage32(unsigned char* wl, const f32x16_t (&a2)[2], int lr, int lg) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int col = j * 32 + 8 * q + 4 * lg;
-            *reinterpret_cast<float4*>(wl + lr * V3_RS32 + col * 4) =
-                make_float4(a2[j][4 * q], a2[j][4 * q + 1], a2[j][4 * q + 2], a2[j][4 * q + 3]);
-        }
-}
-
-template <int EPI, bool F16>
-__device__ __forceinline__ void v5_epilogue(const GemmArgs& g, const f32x16_t (&acc)[4][2], const V3Consts<EPI>& cc,
-                                            unsigned char* wl, int mb, int nb, int lane) {
-    const int lr = lane & 31, lg = lane >> 5;
-    if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
-        const float (&bv)[2][4][4] = cc.bv;
-#pragma unroll
-        for (int pass = 0; pass < (EPI == EPI_GELU ? 2 : 1); ++pass) {
-            bf16_t* out = (EPI == EPI_GELU && pass == 1) ? g.outH2 : g.outH;
-            if (out == nullptr) continue;
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                if (EPI == EPI_GELU && pass == 1) v5_stage16<F16, 1>(wl, acc, bv, p, lr, lg);
-                else v5_stage16<F16, 0>(wl, acc, bv, p, lr, lg);
-                __builtin_amdgcn_wave_barrier();
-                uint4 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint4*>(wl + (u * 8 + (lane >> 3)) * V3_RS16 + (lane & 7) * 16);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int m = mb + p * 64 + u * 8 + (lane >> 3);
-                    if (m < g.M) v3_st<uint4>(out + (size_t)m * g.ldc + nb + (lane & 7) * 8, v[u]);
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        return;
-    }
-    if constexpr (EPI == EPI_QKV) {
-        const int D = g.heads * 64;
-        const int which = nb / D, h = (nb - which * D) >> 6;
-        bf16_t* row_dst = which == 0 ? g.q : (which == 1 ? g.k : g.v);
-        bf16_t* tr_dst = which == 0 ? g.qt : (which == 1 ? g.kt : g.vt);
-        const int npass = (which == 0 && g.q2 != nullptr) ? 2 : 1;
-        for (int pass = 0; pass < npass; ++pass) {
-            const float* extra = nullptr;
-            if (which == 0 && g.pu != nullptr) extra = (pass == 0 ? g.pu : g.pv) + h * 64;
-            bf16_t* rd = pass == 0 ? row_dst : g.q2;
-            bf16_t* td = pass == 0 ? tr_dst : g.q2t;
-            float bv[2][4][4];
-            v3_col_consts(bv, g.bias != nullptr ? g.bias + nb : nullptr, extra, lg);
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                v5_stage16<F16, 0>(wl, acc, bv, p, lr, lg);
-                __builtin_amdgcn_wave_barrier();
-                if (rd != nullptr) {  // (the row-major V is only needed by the backward: inference passes v = NULL)
-#pragma unroll
-                    for (int ub = 0; ub < 8; ub += 4) {  // batches of 4: this epilogue sits at the VGPR cap
-                        uint4 v[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            v[u] = *reinterpret_cast<const uint4*>(wl + ((ub + u) * 8 + (lane >> 3)) * V3_RS16 + (lane & 7) * 16);
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int m = mb + p * 64 + (ub + u) * 8 + (lane >> 3);
-                            if (m < g.M) {
-                                const int bidx = m / g.seq, tt = m - bidx * g.seq;
-                                v3_st<uint4>(rd + ((size_t)(bidx * g.heads + h) * g.seq + tt) * 64 + (lane & 7) * 8, v[u]);
-                            }
-                        }
-                    }
-                }
-                if (td != nullptr && (g.seq & 1) == 0) {
-                    // transposed copy [bh][d][seq_pad]: a lane owns a PAIR of consecutive tokens (same clip: seq is even, the
-                    // pair starts on an even row) and one of two interleaved d columns -> 4-byte stores, 32 lanes = 128 B
-                    const int pr = (lane & 31) * 2, dsel = lane >> 5;
-                    const int m = mb + p * 64 + pr;
-                    if (m < g.M) {
-                        const int bidx = m / g.seq, t = m - bidx * g.seq;
-                        bf16_t* base = td + (size_t)(bidx * g.heads + h) * 64 * g.seq_pad + t;
-                        const unsigned short* s0 = reinterpret_cast<const unsigned short*>(wl + pr * V3_RS16);
-                        const unsigned short* s1 = reinterpret_cast<const unsigned short*>(wl + (pr + 1) * V3_RS16);
-#pragma unroll 8
-                        for (int dd = 0; dd < 32; ++dd) {
-                            const int d = dd * 2 + dsel;
-                            *reinterpret_cast<unsigned*>(base + (size_t)d * g.seq_pad) = (unsigned)s0[d] | ((unsigned)s1[d] << 16);
-                        }
-                    }
-                } else if (td != nullptr) {
-                    const int m = mb + p * 64 + lane;
-                    if (m < g.M) {
-                        const int bidx = m / g.seq, t = m - bidx * g.seq;
-                        bf16_t* base = td + (size_t)(bidx * g.heads + h) * 64 * g.seq_pad + t;
-                        const unsigned short* src = reinterpret_cast<const unsigned short*>(wl + lane * V3_RS16);
-#pragma unroll 8
-                        for (int d = 0; d < 64; ++d) base[(size_t)d * g.seq_pad] = src[d];
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        return;
-    }
-    if constexpr (EPI == EPI_ATOMIC) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v5_stage32(wl, acc[i], lr, lg);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll 8
-            for (int row = 0; row < 32; ++row) {
-                const int m = mb + i * 32 + row;
-                const float v = *reinterpret_cast<const float*>(wl + row * V3_RS32 + lane * 4);
-                if (m < g.M) unsafeAtomicAdd(&g.outF[(size_t)m * g.ldc + nb + lane], v * g.alpha);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        return;
-    }
-    // fp32-staged epilogues, four passes of 32 rows; the side input of pass i + 1 is requested before pass i is stored
-    const int c4 = lane & 15, n = nb + c4 * 4;
-    const float4 b = make_float4(cc.bv[0][0][0], cc.bv[0][0][1], cc.bv[0][0][2], cc.bv[0][0][3]);
-    V3Side<EPI> s0, s1;
-    v3_side_load<EPI>(s0, g, mb, n, lane);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        v5_stage32(wl, acc[i], lr, lg);
-        __builtin_amdgcn_wave_barrier();
-        if (i < 3) v3_side_load<EPI>((i & 1) ? s0 : s1, g, mb + 32 * (i + 1), n, lane);
-        v3_store_batch<EPI, F16>(g, wl, (i & 1) ? s1 : s0, b, mb + 32 * i, 0, n, c4, lane);
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// v8 (experiment, SED_GEMM_V8=1): TWO workgroups per CU.  The 256 x 256 / 8-wave kernel above owns its CU alone (246 VGPRs x 2 waves
-// per SIMD, 128 KB of LDS), so a tile's epilogue -- stores, GELU, residual reads -- never overlaps another tile's MFMAs; MFMA-pipe
-// busy is 34 % on the K = 768 shapes.  Here a workgroup is 4 waves (one per SIMD) on a 128 x 256 tile with the same 128 x 64
-// accumulator block per wave and the same staged epilogue; one 48 KB operand stage (A 128 rows | B 256 rows of 128 B) that doubles
-// as the epilogue staging area (4 x 17 KB) keeps the footprint at 68 KB, so two workgroups are co-resident and cover each other's
-// DMA waits, barriers and epilogues.
-// ---------------------------------------------------------------------------------------------------------------------
-#define V8_LDS (4 * V3_WLDS)
-template <int EPI, bool F16>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_nt_v8_kernel(const GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave;
-    const int ntn = g.N / V3_T, ntm = (g.M + 127) / 128, nwg = ntm * ntn;
-    if (g.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
-        // the second workgroup of every CU starts late, so that the two co-resident workgroups are in different phases (one in its
-        // K loop while the other stores): launched together they would run in lock step and reach their epilogues together
-        const unsigned long long t0 = wall_clock64();
-        while (wall_clock64() - t0 < (unsigned long long)g.stagger) __builtin_amdgcn_s_sleep(32);
-    }
-    const int t = xcd_remap(blockIdx.x, nwg);
-    const int group_size = 8 * ntn, gid = t / group_size, first_m = gid * 8;
-    const int gm = (ntm - first_m) < 8 ? (ntm - first_m) : 8;
-    const int tin = t - gid * group_size;
-    const int m0 = (first_m + tin % gm) * 128, n0 = (tin / gm) * V3_T;
     const int nk = g.K / BK;
-    // DMA: 16 (A) + 32 (B) pieces of 8 rows x 128 B; wave w owns pieces 12 w .. 12 w + 11
+
+    const int rows_a = (g.M - m0) < V3_T ? (g.M - m0) : V3_T;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)m0 * g.lda), 0, rows_a * g.lda * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(g.B + (size_t)n0 * g.ldb), 0, V3_T * g.ldb * 2, 0x00020000);
+    // DMA pieces of this wave: slot piece index p = 2 wave + e.  Slot 0 = A rows of half 0 (wave-row * 128 + 0..63), slot 3 = A rows
+    // of half 1, slot 1 = B rows of half 0 (wave-column * 64 + 0..31), slot 2 = B rows of half 1
     const int prow = lane >> 3, pch = lane & 7;
-    const bf16_t* src[12];
-    int dst[12];
+    int vo[4][2];      // lane byte offsets into the A / B row panels, [slot][e]
+    int ld_[4][2];     // LDS byte offsets (stage bit 15 added at issue)
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        const int p = wave * 12 + i;
-        const bool isB = p >= 16;
-        const int q = isB ? p - 16 : p;
-        const int row = q * 8 + prow;
-        const int cl = pch ^ ((row >> 1) & 7);
-        int am = m0 + row;
-        am = am < g.M ? am : g.M - 1;
-        src[i] = isB ? g.B + (size_t)(n0 + row) * g.ldb + cl * 8 : g.A + (size_t)am * g.lda + cl * 8;
-        dst[i] = (isB ? 16384 : 0) + q * 1024;
+    for (int e = 0; e < 2; ++e) {
+        const int p = 2 * wave + e;
+        const int ra0 = (p >> 3) * 128 + (p & 7) * 8, ra1 = ra0 + 64;
+        const int rb0 = (p >> 2) * 64 + (p & 3) * 8, rb1 = rb0 + 32;
+        const int rows[4] = {ra0, rb0, rb1, ra1};
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            const int row = rows[sl] + prow;
+            const int cl = pch ^ ((row >> 1) & 7);
+            const bool is_b = (sl == 1 || sl == 2);
+            vo[sl][e] = row * (is_b ? g.ldb : g.lda) * 2 + cl * 16;
+            ld_[sl][e] = (is_b ? 65536 : 0) + rows[sl] * 128;
+        }
     }
-#define V8_DMA(kt)                                                                                                        \
-    _Pragma("unroll") for (int i = 0; i < 12; ++i)                                                                        \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)(kt) * BK),     \
-                                         (__attribute__((address_space(3))) void*)(lds3 + dst[i]), 16, 0, 0);
-    f32x16_t acc[4][2];
+#define PP_DMA(SL, KT)                                                                                                    \
+    {                                                                                                                     \
+        const int so_ = (KT) * (BK * 2), st_ = ((KT) & 1) << 15;                                                          \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? rb : ra, (lds_ptr_t)(lds3 + st_ + ld_[SL][0]), 16, vo[SL][0], so_, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? rb : ra, (lds_ptr_t)(lds3 + st_ + ld_[SL][1]), 16, vo[SL][1], so_, 0, 0); \
+    }
+    f32x4_t acc[8][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // fragment addresses: every block's rows are (lane & 15) + a multiple of 16, so one swizzle serves all of them
+    const int l15 = lane & 15, lq = lane >> 4, sw = (l15 >> 1) & 7;
+    int aaddr[2], baddr[2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int lr = lane & 31, lg = lane >> 5;
-    int aoff[4], boff[2], aswz[4], bswz[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const int r = i * 32 + lr; aoff[i] = r * 128; aswz[i] = (r >> 1) & 7; }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { const int r = wn * 64 + j * 32 + lr; boff[j] = 16384 + r * 128; bswz[j] = (r >> 1) & 7; }
+    for (int ks = 0; ks < 2; ++ks) {
+        const int c = ((4 * ks + lq) ^ sw) << 4;
+        aaddr[ks] = wm * 16384 + l15 * 128 + c;
+        baddr[ks] = 65536 + wn * 8192 + l15 * 128 + c;
+    }
     V3Consts<EPI> cc;
     v3_load_consts<EPI>(cc, g, n0 + wn * 64, lane);
-    s16x8_t af[2][4], bfr[2][2];
-#define V8_FRAGS(SET, KS)                                                                                                 \
-    {                                                                                                                     \
-        const int ch_ = 2 * (KS) + lg;                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                     \
-            af[SET][i] = *reinterpret_cast<const s16x8_t*>(lds3 + aoff[i] + ((ch_ ^ aswz[i]) << 4));                      \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                     \
-            bfr[SET][j] = *reinterpret_cast<const s16x8_t*>(lds3 + boff[j] + ((ch_ ^ bswz[j]) << 4));                     \
-    }
-    if (nk > 0) {
-        V8_DMA(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        V8_FRAGS(0, 0);
-    }
-    for (int it = 0; it < nk; ++it) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int cur = s & 1, nxt = cur ^ 1;
-            if (s < 3) {
-                V8_FRAGS(nxt, s + 1);
-            } else if (it + 1 < nk) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my last fragments of this tile are in registers
-                __builtin_amdgcn_s_barrier();                         // ... and everybody's: the stage can be overwritten
-                V8_DMA(it + 1);                                       // lands under the 8 MFMAs below (and the other workgroup)
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32t<F16>(bfr[cur][j], af[cur][i], acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (s == 3 && it + 1 < nk) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                V8_FRAGS(nxt, 0);
-            }
-        }
-    }
-#undef V8_FRAGS
-#undef V8_DMA
-    __builtin_amdgcn_s_barrier();  // every wave is done reading the operand stage: LDS becomes the per-wave C staging area
-    v3_epilogue<EPI, F16>(g, acc, cc, lds3 + wave * V3_WLDS, m0, n0 + wn * 64, lane);
-}
 
-template <int EPI, bool F16>
-__global__ __launch_bounds__(512) void gemm_nt_v5_kernel(const GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
-    const int ntn = g.N / V3_T, ntm = (g.M + V3_T - 1) / V3_T, nwg = ntm * ntn;
-    // workgroup w sits on XCD w % 8 (round-robin dispatch) and walks that XCD's contiguous share of the tile list, so the 32
-    // workgroups of an XCD work on neighbouring tiles (4 tile-rows x 8 tile-columns) at any time
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-    const int tpx = (nwg + 7) >> 3;
-    const int t_hi = (xcd + 1) * tpx < nwg ? (xcd + 1) * tpx : nwg;
-    int t = xcd * tpx + slot;
-    if (t >= t_hi) return;
-    const int ktiles = g.K / BK;
-    const int kt_begin = (int)(((long long)blockIdx.y * ktiles) / g.ksplit);
-    const int kt_end = (int)(((long long)(blockIdx.y + 1) * ktiles) / g.ksplit);
-    const int nk = kt_end - kt_begin;
-    const int group_size = 4 * ntn;
-    const int prow = lane >> 3, pch = lane & 7;
-    const bool isB = wave >= 4;
-    unsigned src[8];  // element offsets from the operand base (32-bit: the launcher checks the operands are < 2^31 elements)
-    const bf16_t* const opbase = isB ? g.B : g.A;
-    int dst[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dst[i] = (isB ? 32768 : 0) + ((wave & 3) * 8 + i) * 1024;
-    int m0, n0;
-#define V5_TILE(tt)                                                                                                        \
-    {                                                                                                                      \
-        const int gid = (tt) / group_size, first_m = gid * 4;                                                              \
-        const int gm = (ntm - first_m) < 4 ? (ntm - first_m) : 4;                                                          \
-        const int tin = (tt) - gid * group_size;                                                                           \
-        m0 = (first_m + tin % gm) * V3_T;                                                                                  \
-        n0 = (tin / gm) * V3_T;                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                    \
-            const int row = ((wave & 3) * 8 + i) * 8 + prow;                                                               \
-            const int cl = pch ^ ((row >> 1) & 7);                                                                         \
-            int am = m0 + row;                                                                                             \
-            am = am < g.M ? am : g.M - 1;                                                                                  \
-            src[i] = (unsigned)((isB ? (n0 + row) * g.ldb : am * g.lda) + cl * 8 + kt_begin * BK);                         \
-        }                                                                                                                  \
-    }
-#define V5_DMA(kt, stage)                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                         \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(opbase + src[i] + (kt) * BK),    \
-                                         (__attribute__((address_space(3))) void*)(lds3 + (stage) * V3_STAGE + dst[i]),   \
-                                         16, 0, 0);
-    const int lr = lane & 31, lg = lane >> 5;
-    int aoff[4], boff[2], aswz[4], bswz[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const int r = wm * 128 + i * 32 + lr; aoff[i] = r * 128; aswz[i] = (r >> 1) & 7; }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { const int r = wn * 64 + j * 32 + lr; boff[j] = 32768 + r * 128; bswz[j] = (r >> 1) & 7; }
+    s16x8_t fa[4][2], fb[2][2][2];   // fa[ii][ks]: 4 row blocks of the current A half; fb[set][jj][ks]: 2 column blocks of a B half
+#define PP_RD_A(IH)                                                                                                       \
+    _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                                      \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                  \
+            fa[ii][ks] = *reinterpret_cast<const s16x8_t*>(lds3 + aaddr[ks] + (4 * (IH) + ii) * 2048);
+#define PP_RD_B(SET, JH, XOR)                                                                                             \
+    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                                      \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                  \
+            fb[SET][jj][ks] = *reinterpret_cast<const s16x8_t*>(lds3 + (baddr[ks] ^ (XOR)) + (2 * (JH) + jj) * 2048);
+#define PP_MFMA(IH, JH, SET)                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    __builtin_amdgcn_s_barrier();                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                      \
+        _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                                  \
+            _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                              \
+                acc[4 * (IH) + ii][2 * (JH) + jj] = mfma16t<F16>(fb[SET][jj][ks], fa[ii][ks], acc[4 * (IH) + ii][2 * (JH) + jj]); \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    __builtin_amdgcn_s_barrier();                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);
+    // one K tile; X = B register set holding this tile's half 0, Y = the other set
+#define PP_TILE(T_, X, Y)                                                                                                 \
+    if ((T_) + 1 < nk) PP_DMA(3, (T_) + 1)                                                                                \
+    PP_RD_A(0)                                                                                                            \
+    PP_MFMA(0, 0, X)                                                                                                      \
+    if ((T_) + 2 < nk) PP_DMA(1, (T_) + 2)                                                                                \
+    PP_RD_B(Y, 1, 0)                                                                                                      \
+    PP_MFMA(0, 1, Y)                                                                                                      \
+    if ((T_) + 2 < nk) { PP_DMA(0, (T_) + 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }                           \
+    else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                                                             \
+    PP_RD_A(1)                                                                                                            \
+    PP_MFMA(1, 1, Y)                                                                                                      \
+    if ((T_) + 2 < nk) PP_DMA(2, (T_) + 2)                                                                                \
+    if ((T_) + 1 < nk) { PP_RD_B(Y, 0, 0x8000) }                                                                          \
+    PP_MFMA(1, 0, X)                                                                                                      \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { aaddr[ks] ^= 0x8000; baddr[ks] ^= 0x8000; }
 
-    V5_TILE(t);
-    if (nk > 0) { V5_DMA(0, 0); }
-    while (true) {
-        f32x16_t acc[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int it = 0; it < nk; ++it) {
-            const int stage = it & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // tile `it` landed (all waves); the other stage (and the C staging) is idle
-            if (it + 1 < nk) { V5_DMA(it + 1, stage ^ 1); }
-            const unsigned char* base = lds3 + stage * V3_STAGE;
-            s16x8_t af[2][4], bfr[2][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[0][i] = *reinterpret_cast<const s16x8_t*>(base + aoff[i] + ((lg ^ aswz[i]) << 4));
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bfr[0][j] = *reinterpret_cast<const s16x8_t*>(base + boff[j] + ((lg ^ bswz[j]) << 4));
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int cur = s & 1, nxt = cur ^ 1;
-                if (s < 3) {
-                    const int ch = 2 * (s + 1) + lg;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        af[nxt][i] = *reinterpret_cast<const s16x8_t*>(base + aoff[i] + ((ch ^ aswz[i]) << 4));
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        bfr[nxt][j] = *reinterpret_cast<const s16x8_t*>(base + boff[j] + ((ch ^ bswz[j]) << 4));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma32t<F16>(bfr[cur][j], af[cur][i], acc[i][j]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        const int mb = m0 + wm * 128, nb = n0 + wn * 64;
-        V3Consts<EPI> cc;  // bias values: requested once the operand fragments are dead, they land during the barrier + DMA issue
-        v3_load_consts<EPI>(cc, g, nb, lane);
-        __builtin_amdgcn_s_barrier();  // every wave is done reading the operand stages
-        const int tn = t + nslots;
-        const bool more = tn < t_hi;
-        if (more) {
-            V5_TILE(tn);
-            if (nk > 0) { V5_DMA(0, 0); }  // next tile's first K tile flies under this tile's epilogue
-        }
-        v5_epilogue<EPI, F16>(g, acc, cc, lds3 + V3_STAGE + wave * V5_WLDS, mb, nb, lane);
-        if (!more) break;
-        t = tn;
+    // prologue: all of tile 0; then the three slots of tile 1 that the steady state would have issued during tile -1
+    PP_DMA(1, 0) PP_DMA(0, 0) PP_DMA(2, 0) PP_DMA(3, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (nk > 1) { PP_DMA(1, 1) PP_DMA(0, 1) PP_DMA(2, 1) }
+    if (wm == 1) __builtin_amdgcn_s_barrier();   // second wave row: half a phase behind
+    PP_RD_B(0, 0, 0)
+    int it = 0;
+    for (; it + 1 < nk; it += 2) {
+        PP_TILE(it, 0, 1)
+        PP_TILE(it + 1, 1, 0)
     }
-#undef V5_TILE
-#undef V5_DMA
+    if (it < nk) { PP_TILE(it, 0, 1) }
+    if (wm == 0) __builtin_amdgcn_s_barrier();   // pairs with the last barrier of waves 4-7: nobody reads the stages any more
+#undef PP_DMA
+#undef PP_RD_A
+#undef PP_RD_B
+#undef PP_MFMA
+#undef PP_TILE
+    pp_epilogue<EPI, F16>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1662,98 +980,24 @@ template <int EPI>
 static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
     if (g.M <= 0 || g.N % TILE != 0 || g.K % BK != 0 || g.ksplit < 1) return SED_ERR_ARG;
     if ((g.lda % 8) || (g.ldb % 8) || (g.ldc % 4)) return SED_ERR_ARG;
-    dim3 grid(cdiv(g.M, TILE) * (g.N / TILE), g.ksplit);
-    static const int glds = []() { const char* e = getenv("SED_GEMM_GLDS"); return (e == nullptr || e[0] != '0') ? 1 : 0; }();
-    static const int v3 = []() { const char* e = getenv("SED_GEMM_V3"); return (e == nullptr || e[0] != '0') ? 1 : 0; }();
-    // split-K dW through the 256^2 kernel measured slower in the train step (178 vs 171 ms): one workgroup per CU leaves the
-    // long atomic epilogue uncovered, whereas the 128^2 kernel keeps a second workgroup's MFMAs running under it.  Opt-in.
-    static const int v3dw = []() { const char* e = getenv("SED_GEMM_V3_DW"); return (e != nullptr && e[0] == '1') ? 1 : 0; }();
-    const bool v3_ok = EPI == EPI_ATOMIC ? (v3dw && g.M >= 512 && g.K >= 32 * BK) : (g.M >= 1024 && g.ksplit == 1);
-    if (v3 && g.N % V3_T == 0 && v3_ok) {
-        int ks3 = 1;
-        if (EPI == EPI_ATOMIC) {  // split-K weight gradients: one workgroup per CU, at least 16 K tiles per split
-            const int tiles3 = cdiv(g.M, V3_T) * (g.N / V3_T), ktiles = g.K / BK;
-            ks3 = 256 / tiles3;  // one round of workgroups (see sed_gemm_dw_tn)
-            if (ks3 > ktiles / 16) ks3 = ktiles / 16;
-            if (ks3 < 1) ks3 = 1;
-        }
-        dim3 grid3(cdiv(g.M, V3_T) * (g.N / V3_T), ks3);
-        static const float stagger_us = []() { const char* e = getenv("SED_GEMM_STAGGER_US"); return e ? (float)atof(e) : 0.f; }();
-        GemmArgs gs = g;
-        gs.ksplit = ks3;
-        gs.stagger = (int)(stagger_us * 100.f / 8.f);
-        const GemmArgs& g = gs;
-        // persistent variant: measured no better than the per-tile launch (fc1 0.303 vs 0.290 ms, step 151.1 vs 149.2 ms) -- the
-        // hidden 3 us prologue is paid back by the smaller staging passes and the loss of dynamic tile balancing.  Opt-in.
-        static const int v5 = []() { const char* e = getenv("SED_GEMM_V5"); return (e != nullptr && e[0] == '1') ? 1 : 0; }();
-        const bool fits32 = (long long)g.M * g.lda < (1LL << 31) && (long long)g.N * g.ldb < (1LL << 31);
-        // 4-wave / 128x128-per-wave / four 32-deep stages: measured slower than v3 (1009 vs 1089 TFLOP/s at 8192^3, fc1 0.344 vs
-        // 0.301 ms): neither fewer LDS fragment reads nor two K tiles in flight move the ~2 us per 256x256x64 step.  Opt-in.
-        static const int v8 = []() { const char* e = getenv("SED_GEMM_V8"); return (e != nullptr && e[0] == '1') ? 1 : 0; }();
-        if (v8 && EPI != EPI_ATOMIC && (long long)g.M * g.lda < (1LL << 31) && (long long)g.N * g.ldb < (1LL << 31)) {
-            dim3 grid8(cdiv(g.M, 128) * (g.N / V3_T));
-            static bool attr8[2] = {false, false};
-            static const float st8 = []() { const char* e = getenv("SED_V8_STAGGER_US"); return e ? (float)atof(e) : 0.f; }();
-            GemmArgs g8 = g;
-            g8.stagger = (int)(st8 * 100.f);     // wall-clock ticks of 10 ns
-            const GemmArgs& g = g8;
-            if (f16) {
-                if (!attr8[1]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v8_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V8_LDS); attr8[1] = true; }
-                hipLaunchKernelGGL((gemm_nt_v8_kernel<EPI, true>), grid8, dim3(256), V8_LDS, s, g);
-            } else {
-                if (!attr8[0]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v8_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, V8_LDS); attr8[0] = true; }
-                hipLaunchKernelGGL((gemm_nt_v8_kernel<EPI, false>), grid8, dim3(256), V8_LDS, s, g);
-            }
-            return sed_check_launch();
-        }
-        static const int v7 = []() { const char* e = getenv("SED_GEMM_V7"); return (e != nullptr && e[0] == '1') ? 1 : 0; }();
-        if (v7 && fits32) {
-            static bool attr7[2] = {false, false};
-            if (f16) {
-                if (!attr7[1]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v7_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V7_LDS); attr7[1] = true; }
-                hipLaunchKernelGGL((gemm_nt_v7_kernel<EPI, true>), grid3, dim3(256), V7_LDS, s, g);
-            } else {
-                if (!attr7[0]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v7_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, V7_LDS); attr7[0] = true; }
-                hipLaunchKernelGGL((gemm_nt_v7_kernel<EPI, false>), grid3, dim3(256), V7_LDS, s, g);
-            }
-            return sed_check_launch();
-        }
-        if (v5 && fits32 && !g.bwd_bf16) {
-            static const int ncu = []() {
-                int dev = 0, n = 0;
-                (void)hipGetDevice(&dev);
-                (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-                return n >= 8 ? (n & ~7) : 256;
-            }();
-            const int nwg3 = (int)grid3.x;
-            dim3 grid5(nwg3 < ncu ? ((nwg3 + 7) & ~7) : ncu, ks3);
-            static bool attr5[2] = {false, false};
-            if (f16) {
-                if (!attr5[1]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v5_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V5_LDS); attr5[1] = true; }
-                hipLaunchKernelGGL((gemm_nt_v5_kernel<EPI, true>), grid5, dim3(512), V5_LDS, s, g);
-            } else {
-                if (!attr5[0]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v5_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, V5_LDS); attr5[0] = true; }
-                hipLaunchKernelGGL((gemm_nt_v5_kernel<EPI, false>), grid5, dim3(512), V5_LDS, s, g);
-            }
-            return sed_check_launch();
-        }
-        static bool attr3[2] = {false, false};
+    // 256^2 kernel: every forward / dX GEMM of the model (N % 256 == 0, M >= 1024).  The split-K weight-gradient GEMMs of the NT
+    // form stay on the 128^2 kernel (two workgroups per CU cover its atomic epilogue).
+    if constexpr (EPI != EPI_ATOMIC) if (g.N % V3_T == 0 && g.M >= 1024 && g.ksplit == 1) {
+        dim3 grid3(cdiv(g.M, V3_T) * (g.N / V3_T), 1);
+        if ((long long)g.lda * 2 * V3_T >= (1LL << 31) || (long long)g.ldb * 2 * V3_T >= (1LL << 31)) return SED_ERR_ARG;  // 32-bit panel offsets
+        static bool attrp[2] = {false, false};
         if (f16) {
-            if (!attr3[1]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr3[1] = true; }
-            hipLaunchKernelGGL((gemm_nt_v3_kernel<EPI, true>), grid3, dim3(512), V3_LDS, s, g);
+            if (!attrp[1]) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attrp[1] = true; }
+            hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true>), grid3, dim3(512), V3_LDS, s, g);
         } else {
-            if (!attr3[0]) { (void)hipFuncSetAttribute((const void*)gemm_nt_v3_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr3[0] = true; }
-            hipLaunchKernelGGL((gemm_nt_v3_kernel<EPI, false>), grid3, dim3(512), V3_LDS, s, g);
+            if (!attrp[0]) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attrp[0] = true; }
+            hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, false>), grid3, dim3(512), V3_LDS, s, g);
         }
         return sed_check_launch();
     }
-    if (glds) {
-        if (f16) hipLaunchKernelGGL((gemm_nt_kernel<EPI, true, true>), grid, dim3(256), 0, s, g);
-        else hipLaunchKernelGGL((gemm_nt_kernel<EPI, false, true>), grid, dim3(256), 0, s, g);
-    } else {
-        if (f16) hipLaunchKernelGGL((gemm_nt_kernel<EPI, true, false>), grid, dim3(256), 0, s, g);
-        else hipLaunchKernelGGL((gemm_nt_kernel<EPI, false, false>), grid, dim3(256), 0, s, g);
-    }
+    dim3 grid(cdiv(g.M, TILE) * (g.N / TILE), g.ksplit);
+    if (f16) hipLaunchKernelGGL((gemm_nt_kernel<EPI, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_nt_kernel<EPI, false>), grid, dim3(256), 0, s, g);
     return sed_check_launch();
 }
 
