@@ -406,6 +406,122 @@ __global__ __launch_bounds__(512) void pp16_kernel(const bf16_t* __restrict__ A,
     }
 }
 
+
+// ---- "dual": two independent 4-wave workgroups per CU, 128 x 256 tile each (wave = 128 x 64), BK = 32, three 24-KiB stages ------
+// Purpose: let one workgroup's epilogue overlap the other's K loop (the 8-wave kernel leaves the matrix pipe idle for the whole
+// epilogue: 9-30 us per tile at K = 768).  Single-stream software pipeline per wave: DMA of step s+2, fragment reads of step s+1,
+// MFMAs of step s; one barrier per 32-deep step.  64-byte LDS rows, chunk c of row r stored at c ^ ((3 * (r >> 2)) & 3).
+#define D_STAGE 24576
+#define D_LDS (3 * D_STAGE)
+template <int EPI_SPIN>
+__global__ __launch_bounds__(256, 2) void dual_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C,
+                                                      int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntn = N / 256, ntm = (M + 127) / 128, nwg = ntm * ntn;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int group_size = 8 * ntn, gid = t / group_size, first_m = gid * 8;
+    const int gm = (ntm - first_m) < 8 ? (ntm - first_m) : 8;
+    const int tin = t - gid * group_size;
+    const int m0 = (first_m + tin % gm) * 128, n0 = (tin / gm) * 256;
+    const int ns = K / 32;
+    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = wall_clock64();
+    const int rows_a = (M - m0) < 128 ? (M - m0) : 128;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * K), 0, rows_a * K * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(B + (size_t)n0 * K), 0, 256 * K * 2, 0x00020000);
+    // DMA pieces (16 rows x 64 B): wave w fetches A pieces 2w, 2w+1 and B pieces 4w .. 4w+3 (its own 64 B rows)
+    const int prow = lane >> 2, pc = lane & 3;
+    const int lchunk = pc ^ ((3 * (prow >> 2)) & 3);
+    int voa[2], vob[4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) voa[e] = ((2 * wn + e) * 16 + prow) * K * 2 + lchunk * 16;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vob[e] = ((4 * wn + e) * 16 + prow) * K * 2 + lchunk * 16;
+#define D_DMA(S_, STG_)                                                                                                   \
+    {                                                                                                                     \
+        const int so_ = (S_) * 64, sb_ = (STG_) * D_STAGE;                                                                \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                                     \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(lds3 + sb_ + (2 * wn + e) * 1024), 16, voa[e], so_, 0, 0); \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                     \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(lds3 + sb_ + 8192 + (4 * wn + e) * 1024), 16, vob[e], so_, 0, 0); \
+    }
+    f32x4v acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int cswz = (lq ^ ((3 * (l15 >> 2)) & 3)) << 4;
+    const unsigned lbase = (unsigned)(size_t)lds3;
+    const unsigned abase = lbase + l15 * 64 + cswz, bbase = lbase + 8192 + (wn * 64 + l15) * 64 + cswz;
+    f16x8_t fa[2][4], fb[2][4];   // fa[h]: the 4 row blocks of A half h of the current step; fb[set]: the 4 column blocks of a step
+#define D_RD1(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+#define D_READ_A(H, STG_)                                                                                                 \
+    {                                                                                                                     \
+        const unsigned aa_ = abase + (STG_) * D_STAGE;                                                                    \
+        D_RD1(fa[H][0], aa_, (H) * 4096); D_RD1(fa[H][1], aa_, (H) * 4096 + 1024); D_RD1(fa[H][2], aa_, (H) * 4096 + 2048); D_RD1(fa[H][3], aa_, (H) * 4096 + 3072); \
+    }
+#define D_READ_B(SET, STG_)                                                                                               \
+    {                                                                                                                     \
+        const unsigned bb_ = bbase + (STG_) * D_STAGE;                                                                    \
+        D_RD1(fb[SET][0], bb_, 0); D_RD1(fb[SET][1], bb_, 1024); D_RD1(fb[SET][2], bb_, 2048); D_RD1(fb[SET][3], bb_, 3072); \
+    }
+    // counted LDS wait; ties the fragment registers it covers to the wait so that no consumer is scheduled above it
+#define D_WAIT_AB(CNT, H, SET)                                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                            \
+                 : "+v"(fa[H][0]), "+v"(fa[H][1]), "+v"(fa[H][2]), "+v"(fa[H][3]), "+v"(fb[SET][0]), "+v"(fb[SET][1]), "+v"(fb[SET][2]), "+v"(fb[SET][3]) \
+                 :: "memory");
+#define D_WAIT_A(CNT, H)                                                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(fa[H][0]), "+v"(fa[H][1]), "+v"(fa[H][2]), "+v"(fa[H][3]) :: "memory");
+#define D_MFMA(H, SET)                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                     \
+            acc[4 * (H) + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[SET][j], fa[H][i], acc[4 * (H) + i][j], 0, 0, 0);
+    // one 32-deep step S_ (B fragments in set X; the next step's go to set Y); stage indices st0 (this step), st1, st2 in SGPRs
+#define D_STEP(S_, X, Y)                                                                                                  \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                      \
+    __builtin_amdgcn_s_barrier();                                                                                         \
+    if ((S_) + 2 < ns) D_DMA((S_) + 2, st2)                                                                               \
+    D_READ_A(1, st0)                                                                                                      \
+    D_WAIT_AB(4, 0, X)                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    D_MFMA(0, X)                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    if ((S_) + 1 < ns) { D_READ_B(Y, st1) D_READ_A(0, st1) D_WAIT_A(8, 1) } else { D_WAIT_A(0, 1) }                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    D_MFMA(1, X)                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    { const int t_ = st0; st0 = st1; st1 = st2; st2 = t_; }
+    int st0 = 0, st1 = 1, st2 = 2;
+    D_DMA(0, 0)
+    if (ns > 1) { D_DMA(1, 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __builtin_amdgcn_s_barrier();
+    D_READ_B(0, 0) D_READ_A(0, 0)
+    for (int s_ = 0; s_ < ns; s_ += 2) {
+        D_STEP(s_, 0, 1)
+        D_STEP(s_ + 1, 1, 0)
+    }
+    if (blockIdx.x == 17 && tid == 0) { g_clk[0] = __builtin_readcyclecounter() - clk0; g_clk[1] = wall_clock64() - rt0; }
+    if (EPI_SPIN > 0) {   // stand-in for a long epilogue: EPI_SPIN x 1000 cycles of VALU-free waiting
+        const unsigned long long e0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - e0 < (unsigned long long)EPI_SPIN * 1000) __builtin_amdgcn_s_sleep(8);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + i * 16 + l15;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + 4 * lq;
+            uint2 pk;
+            pk.x = pack2<true>(acc[i][j][0], acc[i][j][1]);
+            pk.y = pack2<true>(acc[i][j][2], acc[i][j][3]);
+            *reinterpret_cast<uint2*>(C + (size_t)m * N + n) = pk;
+        }
+    }
+}
+
 __global__ void fill_kernel(bf16_t* p, size_t n, unsigned seed, float scale) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         unsigned h = (unsigned)(i * 2654435761u) ^ seed;
@@ -428,7 +544,7 @@ __global__ void gather_kernel(const bf16_t* C, const int* mm, const int* nn, flo
 }
 
 typedef void (*kern_t)(const bf16_t*, const bf16_t*, bf16_t*, int, int, int);
-struct Variant { const char* name; kern_t k; bool check; };
+struct Variant { const char* name; kern_t k; bool check; int threads = 512; int lds = LDS_BYTES; int tm = 256; };
 
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 10;
@@ -442,6 +558,8 @@ int main(int argc, char** argv) {
         {"S1 with mfma 16x16x32 noprio  ", pp16_kernel<0, false>, true},
         {"S1/16x16 ABL noDMA            ", pp16_kernel<1, true>, false},
         {"S1/16x16 ABL noDMA noRD       ", pp16_kernel<3, true>, false},
+        {"DUAL 2x(4 waves,128x256,BK32) ", dual_kernel<0>, true, 256, D_LDS, 128},
+        {"DUAL + 10k-cycle fake epilogue", dual_kernel<10>, true, 256, D_LDS, 128},
         {"S2 half 16/8 prio prewait     ", pp_kernel<2, 0, true, true>, true},
         {"S2 half 16/8 prio postwait    ", pp_kernel<2, 0, true, false>, true},
         {"S2 half noprio prewait        ", pp_kernel<2, 0, false, true>, true},
@@ -491,7 +609,7 @@ int main(int argc, char** argv) {
         CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &dtr, sizeof(dtr)));
     }
     const int shapes[][3] = {{8192, 8192, 8192}, {38080, 3072, 768}, {38080, 768, 3072}, {211904, 768, 768}};
-    for (auto& v : vs) CHECK(hipFuncSetAttribute((const void*)v.k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    for (auto& v : vs) CHECK(hipFuncSetAttribute((const void*)v.k, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds));
     for (const auto& sh : shapes) {
         const int M = sh[0], N = sh[1], K = sh[2];
         bf16_t *A, *B, *C;
@@ -508,12 +626,12 @@ int main(int argc, char** argv) {
         ref_kernel<<<(ns + 255) / 256, 256>>>(A, B, dm, dn, dref, K, ns);
         std::vector<float> href(ns), hout(ns);
         CHECK(hipMemcpy(href.data(), dref, ns * 4, hipMemcpyDeviceToHost));
-        const dim3 grid(((M + 255) / 256) * (N / 256));
         hipEvent_t e0, e1;
         CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
         for (auto& v : vs) {
             CHECK(hipMemset(C, 0, (size_t)M * N * 2));
-            v.k<<<grid, 512, LDS_BYTES>>>(A, B, C, M, N, K);
+            const dim3 grid(((M + v.tm - 1) / v.tm) * (N / 256));
+            v.k<<<grid, v.threads, v.lds>>>(A, B, C, M, N, K);
             CHECK(hipDeviceSynchronize());
             double maxerr = -1.0;
             if (v.check) {
@@ -525,9 +643,9 @@ int main(int argc, char** argv) {
                     if (e > maxerr) maxerr = e;
                 }
             }
-            v.k<<<grid, 512, LDS_BYTES>>>(A, B, C, M, N, K);
+            v.k<<<grid, v.threads, v.lds>>>(A, B, C, M, N, K);
             CHECK(hipEventRecord(e0));
-            for (int r = 0; r < reps; ++r) v.k<<<grid, 512, LDS_BYTES>>>(A, B, C, M, N, K);
+            for (int r = 0; r < reps; ++r) v.k<<<grid, v.threads, v.lds>>>(A, B, C, M, N, K);
             CHECK(hipEventRecord(e1));
             CHECK(hipEventSynchronize(e1));
             float ms;

@@ -31,7 +31,12 @@ class GradBucketReducer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.min_elems = min_bytes // 4
         self.ranges = {}
+        # Only slices that can receive a gradient take part: frozen parameters and PaSST's unused classification heads
+        # (`backbone.head*`: never on the MAT-SED path, their arena slices stay zero) are excluded statically.
+        trainable = {n for n, p in net.named_parameters() if p.requires_grad} if hasattr(net, "named_parameters") else None
         for n, o, k in optimizer.layout:
+            if n.startswith("backbone.head") or (trainable is not None and n not in trainable):
+                continue
             st = stage_of(n, getattr(net, "depth", 12))
             self.ranges.setdefault(st, []).append([o, o + (k + 63) // 64 * 64])
         for st, rs in self.ranges.items():  # merge adjacent slices
@@ -45,6 +50,7 @@ class GradBucketReducer:
             self.ranges[st] = merged
         self.pending = []
         self.fired = set()
+        self.order = []       # stages in the order their hooks fired during the current backward
         self.force = False  # issue the collectives even at world size 1 (single-GPU check of the RCCL path)
         net._grad_ready_hook = self.on_stage
         self.use_avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
@@ -62,8 +68,19 @@ class GradBucketReducer:
         """Called by the engine as soon as every gradient of `stage` is final."""
         arena = self.net._last_grad_arena
         self.fired.add(stage)
+        self.order.append(stage)
         for a, b in self.ranges.get(stage, []):
             self._reduce(arena[a:b])
+
+    def wait_pending(self):
+        """Block the compute stream on every collective issued so far (the averaged slices are final afterwards)."""
+        for w in self.pending:
+            if isinstance(w, tuple):
+                w[0].wait()
+                w[1].div_(self.world)
+            else:
+                w.wait()
+        self.pending = []
 
     def allreduce_grads(self, net=None):
         """After backward: reduce whatever no stage hook covered (frozen stages never fire), then wait."""
@@ -72,11 +89,6 @@ class GradBucketReducer:
             if st not in self.fired:
                 for a, b in rs:
                     self._reduce(arena[a:b])
-        for w in self.pending:
-            if isinstance(w, tuple):
-                w[0].wait()
-                w[1].div_(self.world)
-            else:
-                w.wait()
-        self.pending = []
+        self.wait_pending()
         self.fired = set()
+        self.order = []

@@ -202,14 +202,22 @@ class _SedFunction(torch.autograd.Function):
             for n, p in live:
                 views[n] = arena[off:off + p.numel()].view(p.shape)
                 off += (p.numel() + 63) // 64 * 64
+        # a second backward before zero_grad() accumulates (autograd semantics): the arena the optimiser / all-reduce read is the sum
+        prev = getattr(module, "_last_grad_arena", None)
+        accumulate = prev is not None and prev.numel() == arena.numel() and any(p.grad is not None for _, p in live)
         module._last_grad_arena = arena
-        module.engine.backward(ctx.ectx, grads, lambda n: views.get(n), hook=getattr(module, "_grad_ready_hook", None))
+        hook = getattr(module, "_grad_ready_hook", None)
+        module.engine.backward(ctx.ectx, grads, lambda n: views.get(n), hook=hook)
         ctx.ectx = None
+        if accumulate:
+            owner = getattr(hook, "__self__", None)
+            if owner is not None and hasattr(owner, "wait_pending"):
+                owner.wait_pending()      # the slices being averaged must be final before the earlier (already averaged) sum is added
+            arena.add_(prev)
         touched = module._grad_names()
         for n, p in live:
-            if n in touched:
-                v = views[n]
-                p.grad = v if p.grad is None else p.grad + v     # autograd's accumulate semantics
+            if n in touched or (accumulate and p.grad is not None):
+                p.grad = views[n]
         return None, None, None, None
 
 

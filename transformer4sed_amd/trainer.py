@@ -117,6 +117,7 @@ class FusedAdamWEMA:
         for p in self.net.parameters():
             p.grad = None
         self.grad_arena = None
+        self.net._last_grad_arena = None
 
     # ---- optimiser state (the reference saves weights only, recipes/desed/finetune/passt/main.py:82-87; this is the state a true
     # resume additionally needs).  Keyed by parameter NAME, so it survives a different grouping / arena layout.
