@@ -1,40 +1,47 @@
-"""CPU baseline leg for bench.py: one MAT-SED finetune2-style train step computed by the ORACLE (torch CPU fp32,
-autograd) -- frontend + student forward/backward + sliding-window teacher forward + losses + AdamW + EMA.
+"""CPU baseline leg for bench.py: MAT-SED finetune2 train steps computed by the ORACLE (torch CPU fp32, autograd) through
+`OracleFinetuneTrainer.step` -- the reference's whole step (train-mode frontend, frame_shift, mixup draw, frequency warp +
+FilterAugment for both views, student forward/backward, 11-window teacher forward, six losses, AdamW, ExponentialDown, EMA).
 TEST/BENCH INFRASTRUCTURE ONLY (reported as `cpu_baseline`, kind "port"); never on the product path."""
+import json
+import random
+import sys
 import time
 
+import numpy as np
 import torch
 
-from . import matsed_oracle as O
+from .train_step import OracleFinetuneTrainer
 
 
-def finetune2_step_seconds(sd_np, wav_np, labels_np, strong_n, weak_n, depth=12, feature_layer=10, threads=None,
-                           win_param=(512, 49)):
+def finetune2_steps(sd_np, wav_np, labels_np, cfg, depth=12, feature_layer=10, threads=None, warmup=1, steps=3, stream=None):
+    """Runs `warmup` untimed + `steps` timed steps on the same inputs; returns the timed seconds.  Every finished step is also
+    written to `stream` as a JSON line, so a caller that has to cut the run short still has the completed samples."""
     if threads:
         torch.set_num_threads(threads)
-    sd = {k: torch.from_numpy(v).clone().requires_grad_(not k.startswith("backbone.head")) for k, v in sd_np.items()}
-    ema = {k: v.detach().clone() for k, v in sd.items()}
-    wav = torch.from_numpy(wav_np)
-    labels = torch.from_numpy(labels_np)
-    t0 = time.perf_counter()
-    mel = O.logmel(wav, 3.0, 15400.0)
-    mel = O.frame_shift(mel, [7] * mel.shape[0])
-    k, lam = O.freq_warp_table(128, 0.01, 0.3)
-    lam_t = torch.from_numpy(lam).float().view(1, -1, 1)
-    view = lambda m: (1 - lam_t) * m[:, k] + lam_t * m[:, k + 1]
-    stu_in, tch_in = view(mel), view(mel)
-    stu = O.passt_sed_forward(sd, stu_in, depth=depth, feature_layer=feature_layer)
-    with torch.no_grad():
-        tch = O.passt_sed_forward(ema, tch_in, depth=depth, feature_layer=feature_layer, encoder_win=True,
-                                  win_param=win_param)
-    lw = O.weak_labels_from(labels, strong_n, weak_n)
-    L = O.finetune_losses(stu, tch, labels, lw, strong_n, weak_n, w_cons=1.0)
-    L["loss_total"].backward()
-    with torch.no_grad():
-        for name, p in sd.items():
-            if p.grad is None:
-                continue
-            newp, _, _ = O.adamw_reference_step(p, p.grad, torch.zeros_like(p), torch.zeros_like(p), 1, 1e-4, 1e-4)
-            p.copy_(newp)
-            ema[name].mul_(0.999).add_(p, alpha=0.001)
-    return time.perf_counter() - t0
+    random.seed(1); np.random.seed(1); torch.manual_seed(1)
+    sched = {"n_epochs": 30, "n_epochs_cut": 15, "exponent": -1, "warmup_epochs": 1, "warmup_rate": 0.1, "epoch_len": 1000}
+    tr = OracleFinetuneTrainer(sd_np, cfg, sched, depth, feature_layer)
+    out = []
+    for i in range(warmup + steps):
+        t0 = time.perf_counter()
+        tr.step(wav_np, labels_np)
+        dt = time.perf_counter() - t0
+        if i >= warmup:
+            out.append(dt)
+        if stream is not None:
+            stream.write(json.dumps({"step": i, "warmup": i < warmup, "sec": dt}) + "\n")
+            stream.flush()
+    return out
+
+
+if __name__ == "__main__":   # python -m oracle.cpu_step <batch> <depth> <threads>: used by bench.py's cpu_baseline leg
+    from transformer4sed_amd import synth
+    B, depth, threads = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    cfg = json.loads(sys.argv[4])
+    sn = (B + 2) // 3
+    wn = (B + 1) // 3
+    un = B - sn - wn
+    cfg["training"]["batch_size"] = [sn, 0, wn, un]
+    sd = synth.matsed_state_dict_np(tag="w768", depth=12)
+    finetune2_steps(sd, synth.synth_wav(B, seed=1), synth.synth_batch_labels(sn, wn, un, seed=1), cfg, depth=depth,
+                    feature_layer=min(10, depth), threads=threads, stream=sys.stdout)

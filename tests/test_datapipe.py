@@ -81,3 +81,33 @@ def test_resample_filter_matches_scipy_definition():
         half = 10 * max(u, d)
         want = signal.firwin(2 * half + 1, 1.0 / max(u, d), window=("kaiser", 5.0)) * u
         assert np.abs(h - want).max() < 1e-6 and n_pre_pad == d - half % d and n_pre_remove == (half + n_pre_pad) // d
+
+
+def test_framewise_labeled_dataset_items(tmp_path):
+    """FrameWiseLabeledDataset (src/preprocess/dataset.py:198-230, used by all four sets of recipes/desed/pmam/setting.py:46-70): one tsv per
+    clip whose columns from the third on are the frame-wise labels; item = [wav, label[n_class, n_frames], pad_mask, idx(, name, path)]."""
+    import pandas as pd
+    from datapipe_files import write_pcm16
+    from transformer4sed_amd.evaluation import Encoder
+    tsv_dir, wav_dir = tmp_path / "tsv", tmp_path / "wav"
+    tsv_dir.mkdir(); wav_dir.mkdir()
+    enc = Encoder([f"c{i}" for i in range(30)], audio_len=10, frame_len=1024, frame_hop=320, net_pooling=1, sr=32000)
+    rng = np.random.RandomState(3)
+    want = {}
+    for name, seconds in (("a", 10.0), ("b", 4.5)):
+        frames = rng.rand(1000, 30).astype(np.float32).round(3)
+        df = pd.DataFrame(np.concatenate([np.arange(1000)[:, None] * 0.01, np.arange(1, 1001)[:, None] * 0.01, frames], 1),
+                          columns=["onset", "offset"] + [f"c{i}" for i in range(30)])
+        df.to_csv(tsv_dir / f"{name}.tsv", sep="\t", index=False)
+        write_pcm16(str(wav_dir / f"{name}.wav"), rng.uniform(-0.5, 0.5, int(seconds * 32000)), 32000)
+        want[f"{name}.wav"] = pd.read_csv(tsv_dir / f"{name}.tsv", sep="\t").to_numpy()[:, 2:].T
+    (tsv_dir / "notes.txt").write_text("ignored")
+    ds = data.FrameWiseLabeledDataset(str(tsv_dir), str(wav_dir), True, enc)
+    assert len(ds) == 2
+    for i in range(2):
+        wav, label, pad_mask, idx, filename, path = ds[i]
+        assert idx == i and path == str(wav_dir / filename) and wav.shape == (320000,)
+        assert label.shape == (30, 1000) and label.dtype == torch.float32
+        assert np.array_equal(label.numpy(), want[filename].astype(np.float32))
+        assert bool(pad_mask.any()) == (filename == "b.wav")
+    assert len(data.FrameWiseLabeledDataset(str(tsv_dir), str(wav_dir), False, enc)[0]) == 4

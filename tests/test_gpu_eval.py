@@ -160,3 +160,11 @@ def test_bench_json_contract():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # algorithmic FLOPs (split-precision GEMMs at their logical K) never exceed the issued ones; PMC-derived fields carry the file they
+    # came from (keyed by mode) or are null -- never another workload's numbers
+    assert r["achieved_issued"] >= r["achieved"] > 0
+    assert (r["traffic"] is None) == (r["traffic_source"] is None)
+    assert r["traffic_source"] is None or r["traffic_source"].endswith("_finetune2.json")
+    assert (r["mfma_pipe_busy"] is None) == (r["mfma_pipe_busy_source"] is None)
+    g = line["step_gflop_per_clip"]
+    assert g["executed"] < g["reference_schedule"] and line["step_mfma_frac"] < line["step_mfma_frac_reference_flops"]

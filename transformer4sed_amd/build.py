@@ -7,11 +7,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsed_hip.so")
 SOURCES = ["gemm.hip", "attention.hip", "relpos_attention.hip", "norm_elem.hip", "frontend.hip", "pmam.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
-         "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# -ffast-math (re-association, approximate division / sqrt) only where MFMA operand rounding dominates the error anyway: the GEMM
+# epilogues, the attention softmax and the PMAM branch (16-bit NHWC activations).  The fp32 LayerNorm / pooling / loss / optimizer
+# kernels (norm_elem.hip) and the frontend are built with IEEE semantics (NaN / inf are meaningful on those paths: a fully padded
+# clip yields a NaN weak output like the reference).
+FAST = ["-ffast-math", "-fno-finite-math-only"]
 # attention kernels: MFMA accumulators stay in (unified-file) VGPRs -- the AGPR form costs a v_accvgpr_read/write per softmax
 # operand.  The GEMM file is left to the compiler: its 128x128-per-wave kernel needs the AGPR half for its 256 accumulators.
-FILE_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "relpos_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+FILE_FLAGS = {"pmam.hip": FAST,
+              "gemm.hip": FAST, "attention.hip": FAST + ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+              "relpos_attention.hip": FAST + ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc():

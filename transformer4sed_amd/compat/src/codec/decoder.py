@@ -12,6 +12,8 @@ _ref = None
 
 def __getattr__(name):
     global _ref
+    if name.startswith("__"):      # the import machinery probes __path__ / __spec__ ...: that must not load the reference module
+        raise AttributeError(name)
     if _ref is None:
         here = os.path.abspath(__file__)
         for p in sys.path:

@@ -6,6 +6,15 @@ import sys
 
 import yaml
 
+# hot-path overrides first (scheduler.py here), then the reference's own src/utils (log.py, statistics/, ...): the recipes import
+# `src.utils.log` (finetune/passt/main.py:17) and `src.utils.statistics.model_statistic` (pmam/main.py:26) as sub-modules
+__path__ = [os.path.dirname(os.path.abspath(__file__))]
+_rel = __name__.replace(".", os.sep)
+for _p in sys.path:
+    _cand = os.path.join(_p, _rel)
+    if os.path.isdir(_cand) and os.path.abspath(_cand) != __path__[0]:
+        __path__.append(os.path.abspath(_cand))
+
 from transformer4sed_amd.scheduler import ExponentialDown, update_ema  # noqa: F401
 
 
@@ -39,6 +48,8 @@ def count_parameters(model):
 
 def __getattr__(name):
     """Logger / BestModels live in the reference's src/utils/log.py (not on the hot path): load them lazily from there."""
+    if name.startswith("__"):
+        raise AttributeError(name)
     if name in ("Logger", "BestModels"):
         for p in sys.path:
             cand = os.path.join(p, "src", "utils", "log.py")

@@ -376,21 +376,6 @@ __device__ __forceinline__ void pp_stage32(unsigned char* wl, const f32x4_t (&ac
             *reinterpret_cast<float4*>(wl + (ii * 16 + l15) * V3_RS32 + (j * 16 + 4 * lq) * 4) = make_float4(a[0], a[1], a[2], a[3]);
         }
 }
-// (32 x 32 accumulator blocks: the TN weight-gradient kernel)
-__device__ __forceinline__ void v3_stage32(unsigned char* wl, const f32x16_t (&acc)[4][2], int i0, int lr, int lg) {
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int col = j * 32 + 8 * q + 4 * lg;
-                const f32x16_t& a = acc[i0 + ii][j];
-                *reinterpret_cast<float4*>(wl + (ii * 32 + lr) * V3_RS32 + col * 4) =
-                    make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
-            }
-}
-
 // C-tile stores of the 256^2 kernels are non-temporal: the tile is not re-read by this kernel, and write-allocating it evicts
 // the A/B panels that the neighbouring column tiles still need from the 4 MB L2 (+2..4 % on the model's shapes).
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -745,14 +730,16 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
 // ---------------------------------------------------------------------------------------------------------------------
 // Weight-gradient GEMM in TN form: dW[m, n] += sum_t dY[t, m] * X[t, n] with BOTH operands read in their natural row-major
 // [token][feature] layout -- no transposed operand copies in HBM (the NT kernels need dY^T and X^T: 6.4 ms/step of transposes).
-// The contraction index is the slow dimension of both tiles, so the MFMA fragments (8 consecutive k per lane) are columns of the
-// LDS image: read with `ds_read_b64_tr_b16`.  Semantics measured on gfx950 (tools/ablate/trread.hip): the 16 lanes of a group
+// The contraction index is the slow dimension of both tiles, so the MFMA fragments (8 consecutive tokens per lane) are columns of
+// the LDS image: read with `ds_read_b64_tr_b16`.  Semantics measured on gfx950 (tools/ablate/trread.hip): the 16 lanes of a group
 // supply 16 addresses of 8-byte chunks, taken as a [4 rows r = a>>2][4 chunks c = a&3] grid = a 4 x 16 halfword matrix M;
 // lane i of the group receives column i: {M[0][i], M[1][i], M[2][i], M[3][i]}.  With rows = 4 consecutive tokens and columns =
-// 16 consecutive features, two such reads give the 8-token fragment of one feature per lane.
-// LDS stage = [64 tokens][256 features] per operand (512-B rows), filled by DMA; 64-B unit u of token row k is stored at unit
-// u ^ (k & 3), so that the four rows of a transposing read hit four different bank quarters.
-// Same 256 x 256 x 64 tiling / 8 waves (128 x 64 per wave) / two stages as v3; split-K over the tokens, atomic accumulate.
+// 16 consecutive features, two such reads give the 8-token slice of one feature per lane -- exactly the v_mfma_f32_16x16x32
+// operand (lane & 15 = feature, lane >> 4 = token group of 8): lane group G reads tokens 8 G .. 8 G + 7 of the 32-token k-step.
+// LDS stage = [64 tokens][256 features] per operand (512-B rows), filled by DMA; the 64-B unit u of token row k is stored at unit
+// u ^ (k & 3) and its 32-B halves are swapped when (k >> 3) & 1, so that the 32 lanes of a read cycle (groups G, G + 1: token rows
+// 8 G + r and 8 G + 8 + r, r = 0..3, 32 bytes each) cover four whole 64-B units = all 64 banks.
+// Same 256 x 256 x 64 tiling / 8 waves (128 x 64 per wave) / two stages as the NT kernel; split-K over the tokens.
 // X may be IEEE half (saved forward activation): converted to bf16 in registers (the gradient-side MFMA is bf16).
 // ---------------------------------------------------------------------------------------------------------------------
 struct TnArgs {
@@ -800,7 +787,8 @@ __global__ __launch_bounds__(512) void gemm_tn_dw_kernel(const TnArgs g) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int piece = (wave & 3) * 8 + i, k = piece * 2 + krow;
-            const int col = (((pc >> 2) ^ (k & 3)) * 4 + (pc & 3)) * 8;   // logical feature offset stored at physical chunk pc
+            // logical feature offset stored at physical 16-B chunk pc of token row k (unit swizzle + half swap, see above)
+            const int col = (((pc >> 2) ^ (k & 3)) * 4 + ((pc & 3) ^ (((k >> 3) & 1) << 1))) * 8;
             src[i] = (isB ? g.B + (size_t)k * g.ldb + n0 : g.A + (size_t)k * g.lda + m0) + col + (size_t)kt_begin * BK * (isB ? g.ldb : g.lda);
             dst[i] = (isB ? 32768 : 0) + piece * 1024;
         }
@@ -811,31 +799,30 @@ __global__ __launch_bounds__(512) void gemm_tn_dw_kernel(const TnArgs g) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)(kt) * kstride), \
                                          (__attribute__((address_space(3))) void*)(lds3 + (stage) * V3_STAGE + dst[i]),   \
                                          16, 0, 0);
-    f32x16_t acc[4][2];
+    f32x4_t acc[8][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // transposing-read lane addresses: group G = lane >> 4 (k half g = G >> 1, 16-feature half = G & 1), a = lane & 15
-    const int a = lane & 15, G = lane >> 4, kg = G >> 1;
-    unsigned aaddr[4], baddr[2];
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // transposing-read lane addresses: group G = lane >> 4 reads token rows 8 G + (a >> 2) (+ 4 for the second read), a = lane & 15
+    const int a = lane & 15, G = lane >> 4;
+    unsigned aaddr[8], baddr[4];
     const unsigned lbase = (unsigned)(size_t)lds3;
+    const unsigned rowoff = (unsigned)((8 * G + (a >> 2)) * 512);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int col = wm * 128 + i * 32 + (G & 1) * 16 + 4 * (a & 3);
-        aaddr[i] = lbase + (8 * kg + (a >> 2)) * 512 + (((col >> 5) ^ (a >> 2)) << 6) + (col & 31) * 2;
+    for (int i = 0; i < 8; ++i) {
+        const int col = wm * 128 + i * 16 + 4 * (a & 3);
+        aaddr[i] = lbase + rowoff + ((((col >> 5) ^ (a >> 2)) & 7) << 6) + ((((col >> 4) & 1) ^ (G & 1)) << 5) + (col & 15) * 2;
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = wn * 64 + j * 32 + (G & 1) * 16 + 4 * (a & 3);
-        baddr[j] = lbase + 32768 + (8 * kg + (a >> 2)) * 512 + (((col >> 5) ^ (a >> 2)) << 6) + (col & 31) * 2;
+    for (int j = 0; j < 4; ++j) {
+        const int col = wn * 64 + j * 16 + 4 * (a & 3);
+        baddr[j] = lbase + 32768 + rowoff + ((((col >> 5) ^ (a >> 2)) & 7) << 6) + ((((col >> 4) & 1) ^ (G & 1)) << 5) + (col & 15) * 2;
     }
-    // bias gradient: the workgroups of the first N tile also sum their dY fragments over the tokens -- wave (wm, wn) owns the 32
-    // features of fragment i = wn (a lane holds 8 tokens of one feature); VALU work that rides under the MFMAs
+    // bias gradient: the workgroups of the first N tile also sum their dY fragments over the tokens -- wave (wm, wn) owns the two
+    // 16-feature blocks i = 2 wn, 2 wn + 1 (a lane holds 8 tokens of one feature); VALU work that rides under the MFMAs
     const bool do_bias = g.dbias != nullptr && n0 == 0;
-    float colacc = 0.f;
+    float colacc[2] = {0.f, 0.f};
     if (nk > 0) { TN_DMA(0, 0); }
     for (int it = 0; it < nk; ++it) {
         const int stage = it & 1;
@@ -843,66 +830,73 @@ __global__ __launch_bounds__(512) void gemm_tn_dw_kernel(const TnArgs g) {
         __builtin_amdgcn_s_barrier();
         if (it + 1 < nk) { TN_DMA(it + 1, stage ^ 1); }
         const unsigned so = stage * V3_STAGE;
-#define TN_READS(S, al, ah, bl, bh)                                                                                       \
-        {                                                                                                                  \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) { al[i] = lds_tr<(S) * 8192>(aaddr[i] + so); ah[i] = lds_tr<(S) * 8192 + 2048>(aaddr[i] + so); } \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) { bl[j] = lds_tr<(S) * 8192>(baddr[j] + so); bh[j] = lds_tr<(S) * 8192 + 2048>(baddr[j] + so); } \
+        // fragment reads: B (4 column blocks) of k-step S, A half H (row blocks 4 H .. 4 H + 3) of k-step S -- 8 reads each
+#define TN_RB(S, bl, bh)                                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) { bl[j] = lds_tr<(S) * 16384>(baddr[j] + so); bh[j] = lds_tr<(S) * 16384 + 2048>(baddr[j] + so); }
+#define TN_RA(S, H, al, ah)                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) { al[i] = lds_tr<(S) * 16384>(aaddr[4 * (H) + i] + so); ah[i] = lds_tr<(S) * 16384 + 2048>(aaddr[4 * (H) + i] + so); }
+        // the compiler does not know the asm results are still in flight: every consumer is tied to a counted wait (lgkmcnt <= 15)
+#define TN_WAIT4(CNT, xl, xh)                                                                                             \
+        asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                        \
+                     : "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xl[3]), "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]) :: "memory");
+#define TN_MFMA(H, al, ah, bf_)                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                   \
+            const s16x8_t af = tn_frag(al[i], ah[i], false);                                                              \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[4 * (H) + i][j] = mfma16t<false>(bf_[j], af, acc[4 * (H) + i][j]); \
+            if (do_bias && ((4 * (H) + i) >> 1) == wn) {                                                                  \
+                unsigned w4[4];                                                                                           \
+                __builtin_memcpy(w4, &af, 16);                                                                            \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                             \
+                    colacc[i & 1] += __uint_as_float(w4[e] << 16) + __uint_as_float(w4[e] & 0xffff0000u);                 \
+            }                                                                                                             \
         }
-        /* the compiler does not know the asm results are still in flight: every consumer is tied to the counted wait */       \
-#define TN_WAIT(CNT, al, ah, bl, bh)                                                                                       \
-        asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                         \
-                     : "+v"(al[0]), "+v"(al[1]), "+v"(al[2]), "+v"(al[3]), "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3]), \
-                       "+v"(bl[0]), "+v"(bl[1]), "+v"(bh[0]), "+v"(bh[1])                                                  \
-                     :: "memory");
-#define TN_MFMA(al, ah, bl, bh)                                                                                            \
-        {                                                                                                                  \
-            s16x8_t af[4], bf_[2];                                                                                         \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) af[i] = tn_frag(al[i], ah[i], false);                            \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) bf_[j] = tn_frag(bl[j], bh[j], !BF16_B);                         \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mfma32t<false>(bf_[j], af[i], acc[i][j]);        \
-            if (do_bias) {                                                                                                 \
-                _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                              \
-                    if (wn == i) {                                                                                         \
-                        unsigned w4[4];                                                                                    \
-                        __builtin_memcpy(w4, &af[i], 16);                                                                  \
-                        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                      \
-                            colacc += __uint_as_float(w4[e] << 16) + __uint_as_float(w4[e] & 0xffff0000u);                 \
-                    }                                                                                                      \
-            }                                                                                                              \
-        }
-        // fragment reads run one k-step ahead of the MFMAs (12 transposing reads per k-step; lgkmcnt counts them in order)
-        unsigned long long pal[4], pah[4], pbl[2], pbh[2], qal[4], qah[4], qbl[2], qbh[2];
-        TN_READS(0, pal, pah, pbl, pbh)
-        TN_READS(1, qal, qah, qbl, qbh)
-        TN_WAIT(12, pal, pah, pbl, pbh)
-        TN_MFMA(pal, pah, pbl, pbh)
-        TN_READS(2, pal, pah, pbl, pbh)
-        TN_WAIT(12, qal, qah, qbl, qbh)
-        TN_MFMA(qal, qah, qbl, qbh)
-        TN_READS(3, qal, qah, qbl, qbh)
-        TN_WAIT(12, pal, pah, pbl, pbh)
-        TN_MFMA(pal, pah, pbl, pbh)
-        TN_WAIT(0, qal, qah, qbl, qbh)
-        TN_MFMA(qal, qah, qbl, qbh)
-#undef TN_READS
-#undef TN_WAIT
+        // two 32-token k-steps, each in two halves of 16 MFMAs; the reads run 8-16 operations ahead of their consumers
+        unsigned long long b0l[4], b0h[4], b1l[4], b1h[4], pal[4], pah[4], qal[4], qah[4];
+        s16x8_t bf0[4], bf1[4];
+        TN_RB(0, b0l, b0h)
+        TN_RA(0, 0, pal, pah)
+        TN_RA(0, 1, qal, qah)
+        TN_WAIT4(8, b0l, b0h)
+        TN_WAIT4(8, pal, pah)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf0[j] = tn_frag(b0l[j], b0h[j], !BF16_B);
+        TN_MFMA(0, pal, pah, bf0)
+        TN_RB(1, b1l, b1h)
+        TN_WAIT4(8, qal, qah)
+        TN_RA(1, 0, pal, pah)
+        TN_MFMA(1, qal, qah, bf0)
+        TN_RA(1, 1, qal, qah)
+        TN_WAIT4(8, b1l, b1h)
+        TN_WAIT4(8, pal, pah)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf1[j] = tn_frag(b1l[j], b1h[j], !BF16_B);
+        TN_MFMA(0, pal, pah, bf1)
+        TN_WAIT4(0, qal, qah)
+        TN_MFMA(1, qal, qah, bf1)
+#undef TN_RB
+#undef TN_RA
+#undef TN_WAIT4
 #undef TN_MFMA
     }
     if (do_bias) {
-        colacc += __shfl_xor(colacc, 32, 64);      // the two token halves of the fragment
-        if (lane < 32) unsafeAtomicAdd(&g.dbias[m0 + wm * 128 + wn * 32 + lane], colacc);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float c = colacc[e];
+            c += __shfl_xor(c, 16, 64);      // the four 8-token groups of the fragment
+            c += __shfl_xor(c, 32, 64);
+            if (lane < 16) unsafeAtomicAdd(&g.dbias[m0 + wm * 128 + (2 * wn + e) * 16 + lane], c);
+        }
     }
     __builtin_amdgcn_s_barrier();
     // Split-K partial sums.  With a workspace: plain coalesced stores of the tile into ws[split] (a reduce pass adds the splits
     // into dW) -- one workgroup per CU cannot hide 64 Ki device-scope atomics behind anything (measured ~150-200 us per GEMM,
     // as long as the whole K loop).  Without: atomics straight into dW.
     unsigned char* wl = lds3 + wave * V3_WLDS;
-    const int lr = lane & 31, lg = lane >> 5;
+    const int l15 = lane & 15, lq = lane >> 4;
     const int mb = m0 + wm * 128, nb = n0 + wn * 64;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-        v3_stage32(wl, acc, 2 * pass, lr, lg);
+        pp_stage32(wl, acc, pass, l15, lq);
         __builtin_amdgcn_wave_barrier();
         if (g.ws != nullptr) {
             float* dstp = g.ws + ((size_t)blockIdx.y * g.M + mb + pass * 64) * g.N + nb + (lane & 15) * 4;

@@ -364,7 +364,8 @@ extern "C" int sed_fpool_bwd(const float* dpooled, const float* x, const float* 
 // in [B, tin, D] (+ `pad` replicated frames at the end) -> out [B, ratio (tin + pad), D]
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void interp_coeff(int j, int ratio, int tlen, int tin, int& i0, int& i1, float& lam) {
-    float src = ((float)j + 0.5f) / (float)ratio - 0.5f;
+    // torch's area_pixel_compute_source_index: scale * (dst + 0.5) - 0.5 with scale = (float)(1.0 / scale_factor)
+    float src = (float)(1.0 / (double)ratio) * ((float)j + 0.5f) - 0.5f;
     src = src < 0.f ? 0.f : src;
     i0 = (int)src;
     i1 = i0 + 1 < tlen ? i0 + 1 : tlen - 1;

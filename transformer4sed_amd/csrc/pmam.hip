@@ -323,7 +323,7 @@ extern "C" int sed_fpool_attn_fwd(const void* kv, const float* q, void* out16, f
 // align_corners=False) index arithmetic as in sed_interp_fwd.  P1 [B, tp1, C] is extended by `pad1` copies of its last frame.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void lerp_idx(int j, int ratio, int tin, int& i0, int& i1, float& lam) {
-    float src = ((float)j + 0.5f) / (float)ratio - 0.5f;
+    float src = (float)(1.0 / (double)ratio) * ((float)j + 0.5f) - 0.5f;   // torch: scale * (dst + 0.5) - 0.5, scale = (float)(1 / scale_factor)
     src = src < 0.f ? 0.f : src;
     i0 = (int)src;
     i1 = i0 + 1 < tin ? i0 + 1 : tin - 1;

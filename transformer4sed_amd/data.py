@@ -146,17 +146,31 @@ def waveform_modification(filepath, pad_to, encoder, resample_device=None):
 
 # ----------------------------------------------------------------------------------------------------------------- datasets
 class _ClipDataset(Dataset):
+    """One record per clip: (file name, path, label source).  Subclasses build `self.records` and turn a label source into the
+    [n_class, n_frames] tensor; the item contract `[wav, label, pad_mask, idx(, filename, path)]` of the reference's four dataset
+    classes (src/preprocess/dataset.py:15-230) lives here once."""
+
     def __init__(self, dataset_dir, return_name, encoder, resample_device=None):
         self.dataset_dir, self.return_name, self.encoder = dataset_dir, return_name, encoder
         self.pad_to = encoder.audio_len * encoder.sr
         self.resample_device = resample_device
+        self.records = []
 
-    def _item(self, path, filename, label, idx):
+    def _blank(self):
+        return torch.zeros(self.encoder.n_frames, len(self.encoder.labels))
+
+    def _label(self, source):
+        raise NotImplementedError
+
+    def __len__(self):
+        return len(self.records)
+
+    def __getitem__(self, idx):
+        idx = idx.tolist() if torch.is_tensor(idx) else idx
+        filename, path, source = self.records[idx]
         wav, pad_mask = waveform_modification(path, self.pad_to, self.encoder, self.resample_device)
-        out = [wav, label, pad_mask, idx]
-        if self.return_name:
-            out.extend([filename, path])
-        return out
+        item = [wav, self._label(source), pad_mask, idx]
+        return item + [filename, path] if self.return_name else item
 
 
 class StronglyLabeledDataset(_ClipDataset):
@@ -164,26 +178,14 @@ class StronglyLabeledDataset(_ClipDataset):
 
     def __init__(self, tsv_read, dataset_dir, return_name, encoder, resample_device=None):
         super().__init__(dataset_dir, return_name, encoder, resample_device)
-        self.clips = {}
         for filename, group in tsv_read.groupby("filename"):
-            self.clips[filename] = {"path": os.path.join(dataset_dir, filename),
-                                    "events": [{"event_label": r["event_label"], "onset": r["onset"], "offset": r["offset"]}
-                                               for _, r in group.iterrows()]}
-        self.clip_list = list(self.clips.keys())
+            events = group[["event_label", "onset", "offset"]].to_dict("records")
+            self.records.append((filename, os.path.join(dataset_dir, filename), events))
 
-    def __len__(self):
-        return len(self.clip_list)
-
-    def __getitem__(self, idx):
-        if torch.is_tensor(idx):
-            idx = idx.tolist()
-        filename = self.clip_list[idx]
-        clip = self.clips[filename]
-        if not len(clip["events"]):
-            label = torch.zeros(self.encoder.n_frames, len(self.encoder.labels)).float()
-        else:
-            label = torch.from_numpy(self.encoder.encode_strong_df(pd.DataFrame(clip["events"]))).float()
-        return self._item(clip["path"], filename, label.transpose(0, 1), idx)
+    def _label(self, events):
+        if not events:
+            return self._blank().float().transpose(0, 1)
+        return torch.from_numpy(self.encoder.encode_strong_df(pd.DataFrame(events))).float().transpose(0, 1)
 
 
 class WeaklyLabeledDataset(_ClipDataset):
@@ -191,25 +193,15 @@ class WeaklyLabeledDataset(_ClipDataset):
 
     def __init__(self, tsv_read, dataset_dir, return_name, encoder, resample_device=None):
         super().__init__(dataset_dir, return_name, encoder, resample_device)
-        self.clips = {}
-        for _, row in tsv_read.iterrows():
-            if row["filename"] not in self.clips:
-                self.clips[row["filename"]] = {"path": os.path.join(dataset_dir, row["filename"]),
-                                               "events": row["event_labels"].split(",")}
-        self.clip_list = list(self.clips.keys())
+        first = tsv_read.drop_duplicates("filename")            # a repeated file keeps its first row, like the reference's dict
+        for filename, tags in zip(first["filename"], first["event_labels"]):
+            self.records.append((filename, os.path.join(dataset_dir, filename), tags.split(",")))
 
-    def __len__(self):
-        return len(self.clip_list)
-
-    def __getitem__(self, idx):
-        if torch.is_tensor(idx):
-            idx = idx.tolist()
-        filename = self.clip_list[idx]
-        clip = self.clips[filename]
-        label = torch.zeros(self.encoder.n_frames, len(self.encoder.labels))
-        if len(clip["events"]):
-            label[0, :] = torch.from_numpy(self.encoder.encode_weak(clip["events"])).float()
-        return self._item(clip["path"], filename, label.transpose(0, 1), idx)
+    def _label(self, tags):
+        label = self._blank()
+        if tags:
+            label[0, :] = torch.from_numpy(self.encoder.encode_weak(tags)).float()
+        return label.transpose(0, 1)
 
 
 class UnlabeledDataset(_ClipDataset):
@@ -217,47 +209,55 @@ class UnlabeledDataset(_ClipDataset):
 
     def __init__(self, dataset_dir, return_name, encoder, resample_device=None):
         super().__init__(dataset_dir, return_name, encoder, resample_device)
-        self.clips = glob(os.path.join(dataset_dir, "*.wav"))
+        self.records = [(os.path.split(path)[-1], path, None) for path in glob(os.path.join(dataset_dir, "*.wav"))]
 
-    def __len__(self):
-        return len(self.clips)
+    def _label(self, _):
+        return self._blank().float().transpose(0, 1)
 
-    def __getitem__(self, idx):
-        if torch.is_tensor(idx):
-            idx = idx.tolist()
-        path = self.clips[idx]
-        label = torch.zeros(self.encoder.n_frames, len(self.encoder.labels)).float().transpose(0, 1)
-        return self._item(path, os.path.split(path)[-1], label, idx)
+
+class FrameWiseLabeledDataset(_ClipDataset):
+    """dataset.py:198-230 (the PMAM recipes, recipes/desed/pmam/setting.py:46-70): one tsv per clip in `tsv_dir`, its columns from the
+    third on are the frame-wise (pseudo) labels; label = those columns transposed to [n_class, n_frames]; the wav of `x.tsv` is
+    `dataset_dir/x.wav`."""
+
+    def __init__(self, tsv_dir, dataset_dir, return_name, encoder, resample_device=None):
+        super().__init__(dataset_dir, return_name, encoder, resample_device)
+        for tsv_name in os.listdir(tsv_dir):
+            if not tsv_name.endswith(".tsv"):
+                continue
+            table = pd.read_csv(os.path.join(tsv_dir, tsv_name), sep="\t").to_numpy()
+            wav_name = tsv_name.replace(".tsv", ".wav")
+            self.records.append((wav_name, os.path.join(dataset_dir, wav_name), torch.Tensor(table[:, 2:]).T))
+
+    def _label(self, frames):
+        return frames
 
 
 class ConcatDatasetBatchSampler(Sampler):
-    """dataset.py:156-196: one batch = batch_sizes[0] indices of dataset 0, then batch_sizes[1] of dataset 1, ... (offsets into the
-    ConcatDataset); an epoch ends with the first sampler that cannot fill its share."""
+    """dataset.py:156-196: one batch = batch_sizes[0] indices of dataset 0, then batch_sizes[1] of dataset 1, ... (as offsets into the
+    ConcatDataset); an epoch has as many batches as the scarcest dataset can fill."""
 
     def __init__(self, samplers, batch_sizes, epoch=0):
-        self.batch_sizes, self.samplers = batch_sizes, samplers
-        self.offsets = [0] + np.cumsum([len(x) for x in self.samplers]).tolist()[:-1]
+        self.samplers, self.batch_sizes = samplers, batch_sizes
+        sizes = [len(x) for x in samplers]
+        self.offsets = [sum(sizes[:i]) for i in range(len(sizes))]
         self.epoch = epoch
-        self.set_epoch(self.epoch)
+        self.set_epoch(epoch)
 
     def set_epoch(self, epoch):
         if hasattr(self.samplers[0], "epoch"):
-            for s in self.samplers:
-                s.set_epoch(epoch)
-
-    def __iter__(self):
-        iterators = [iter(i) for i in self.samplers]
-        for _ in range(len(self)):
-            tot_batch = []
-            for samp_idx in range(len(self.samplers)):
-                c_batch = []
-                while len(c_batch) < self.batch_sizes[samp_idx]:
-                    c_batch.append(self.offsets[samp_idx] + next(iterators[samp_idx]))
-                tot_batch.extend(c_batch)
-            yield tot_batch
+            for sampler in self.samplers:
+                sampler.set_epoch(epoch)
 
     def __len__(self):
-        return min(len(s) // self.batch_sizes[i] for i, s in enumerate(self.samplers))
+        return min(len(sampler) // size for sampler, size in zip(self.samplers, self.batch_sizes))
+
+    def __iter__(self):
+        def shifted(sampler, off):        # (a function, not a nested generator expression: `off` must be bound per stream)
+            return (off + i for i in sampler)
+        streams = [shifted(sampler, off) for sampler, off in zip(self.samplers, self.offsets)]
+        for _ in range(len(self)):
+            yield [next(stream) for stream, size in zip(streams, self.batch_sizes) for _ in range(size)]
 
 
 class DevicePrefetcher:

@@ -296,6 +296,13 @@ class SedEngine:
         ctx = dict(B=B, T=T, Tpad=Tpad, Rpad=Rpad, layers=[])
         cur = x
         SP = self.split
+        if SP and not getattr(self, "_in_split", False):   # every GEMM of this forward runs on split-precision operands (3x K issued)
+            self._in_split = True
+            try:
+                with ops.split_precision():
+                    return self._decoder_fwd(W, x, save)
+            finally:
+                self._in_split = False
         for li in range(m.decoder_layer_num):
             p = f"decoder.encoder_blocks.{li}."
             in_scale = math.sqrt(D) if li == 0 else 1.0
@@ -424,9 +431,10 @@ class SedEngine:
             if self.split:
                 xd16 = xd.view(M, D)
                 act = E(M, D)
-                gemm_nt(split3(xd16, M, D), W["mlm_mlp.0.weight"].ws, EPI_GELU32, bias=self.P("mlm_mlp.0.bias"), outH=hpre,
-                        outF=act)
-                gemm_nt(split3(act, M, D), W["mlm_mlp.2.weight"].ws, EPI_F32, bias=self.P("mlm_mlp.2.bias"), outF=pred)
+                with ops.split_precision():
+                    gemm_nt(split3(xd16, M, D), W["mlm_mlp.0.weight"].ws, EPI_GELU32, bias=self.P("mlm_mlp.0.bias"), outH=hpre,
+                            outF=act)
+                    gemm_nt(split3(act, M, D), W["mlm_mlp.2.weight"].ws, EPI_F32, bias=self.P("mlm_mlp.2.bias"), outF=pred)
             else:
                 xd16 = E(M, D, dt=self.act)
                 call("sed_cast_f32_bf16", xd, xd16, M * D, is_f16(xd16))

@@ -81,22 +81,37 @@ class KernelTimer:
 
     def recycle(self):
         """Drop the records, keep their events for the next instrumented step."""
-        for _, e0, e1, _, _ in self.records:
+        for _, e0, e1, _, _, _ in self.records:
             self.pool += [e0, e1]
         self.records = []
 
     def summarize(self):
         out = {}
-        for name, e0, e1, fl, by in self.records:
-            d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        for name, e0, e1, fl, by, fi in self.records:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, flops_issued=0.0))
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["flops"] += fl
+            d["flops_issued"] += fi
             d["bytes"] += by
         return out
 
 
 TIMER = None
+ALG_K_SCALE = 1.0     # set by `split_precision()` around a GEMM whose K is the 3x concatenated split-precision reduction dim
+
+
+class split_precision:
+    """Marks the GEMM launches inside the block as split-precision (operands [hi|lo|hi] x [hi|hi|lo]): the kernel timer credits them
+    with their logical 2 M N K, a third of the MFMA FLOPs they issue."""
+
+    def __enter__(self):
+        global ALG_K_SCALE
+        ALG_K_SCALE = 1.0 / 3.0
+
+    def __exit__(self, *exc):
+        global ALG_K_SCALE
+        ALG_K_SCALE = 1.0
 
 
 def _flops_of(name, args):
@@ -153,7 +168,8 @@ def call(name, *args):
         e0.record()
         lib().call(name, *conv, _stream_of(dev))
         e1.record()
-        TIMER.records.append((name, e0, e1, _flops_of(name, args), _bytes_of(name, args)))
+        fi = _flops_of(name, args)
+        TIMER.records.append((name, e0, e1, fi * ALG_K_SCALE, _bytes_of(name, args), fi))
         return
     lib().call(name, *conv, _stream_of(dev))
 

@@ -401,6 +401,11 @@ class PaSST_SED(SEDModel):
             return o["mlm_pred"], other
         return o["strong"], o["weak"], other
 
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._param_generation = getattr(self, "_param_generation", 0) + 1   # cached operand images of frozen tensors are stale now
+        return out
+
     def get_feature_extractor(self):
         return self.mel_trans
 

@@ -17,6 +17,8 @@ import math
 
 import torch
 
+from . import ops
+
 from .engine import SedEngine, _W, D, H
 from .ops import BF16, F16, F32, call, h2d, gemm_nt, gemm_nt_cols, gemm_dw, pad64, transpose_bf16, split3, is_f16, to_bf16_, o_kind
 from .ops import EPI_F32, EPI_F32_RESID, EPI_BF16, EPI_GELU32
@@ -60,8 +62,11 @@ class PmamEngine(SedEngine):
                 n = f"backbone.blocks.{i}.{sub}"
                 wp = self.P(n + ".weight")
                 parts = [wp] + ([self.P(n + ".lora_A"), self.P(n + ".lora_B")] if m.lora_r else [])
-                # frozen operands (the blocks below `freeze_layer`, cnn_trans/setting.py:66-82) keep their images across steps
-                key = (merged, wp.data_ptr(), wp._version) if not any(p.requires_grad for p in parts) else None
+                # Frozen operands (the blocks below `freeze_layer`, cnn_trans/setting.py:66-82) keep their images across steps.  A tensor
+                # without requires_grad is not necessarily constant: the EMA teacher's masters are rewritten through raw pointers
+                # (fused AdamW + EMA kernel) or `.data` in-place ops (update_ema), neither of which moves `_version` -- so the key
+                # carries the module's parameter generation, bumped by every such writer and by load_state_dict.
+                key = (merged, wp.data_ptr(), getattr(m, "_param_generation", 0)) if not any(p.requires_grad for p in parts) else None
                 ent = self.cache.get(n + ".weight")
                 if key is not None and ent is not None and getattr(self, "_static_keys", {}).get(n) == key:
                     continue
@@ -266,6 +271,13 @@ class PmamEngine(SedEngine):
         A16 = self.act
         ctx = dict(B=B, T=T, Tpad=Tpad, Rpad=Rpad, layers=[])
         cur = x
+        if not getattr(self, "_in_split", False):   # every GEMM of this forward runs on split-precision operands (3x K issued)
+            self._in_split = True
+            try:
+                with ops.split_precision():
+                    return self._decoder_fwd(W, x, save)
+            finally:
+                self._in_split = False
         for li in range(m.decoder_layer_num):
             p = f"decoder.encoder_blocks.{li}."
             aux = self.dec_aux[li]
@@ -335,7 +347,8 @@ class PmamEngine(SedEngine):
         Tc = cctx["Tc"]
         Cl = feat.shape[1]
         P2 = E(B * Tc, Dd)
-        gemm_nt(split3(feat, B * Tc, Cl), W["cnn_projector.weight"].ws, EPI_F32, bias=self.P("cnn_projector.bias"), outF=P2)
+        with ops.split_precision():
+            gemm_nt(split3(feat, B * Tc, Cl), W["cnn_projector.weight"].ws, EPI_F32, bias=self.P("cnn_projector.bias"), outF=P2)
         assert Tdec % Tc == 0
         xg = E(B, Tdec, Dd)
         if encoder_win:
@@ -364,14 +377,16 @@ class PmamEngine(SedEngine):
             i32 = lambda v: h2d(v, torch.int32, dev)
             call("sed_window_mix", packed, i32(lefts), i32(tps), i32(offs), len(starts), x768, float(mix_rate), B, Tdec, m.decode_ratio)
             P1 = E(B * Tdec, Dd)
-            gemm_nt(split3(x768.view(B * Tdec, D), B * Tdec, D), W["transformer_projector.weight"].ws, EPI_F32,
-                    bias=self.P("transformer_projector.bias"), outF=P1)
+            with ops.split_precision():
+                gemm_nt(split3(x768.view(B * Tdec, D), B * Tdec, D), W["transformer_projector.weight"].ws, EPI_F32,
+                        bias=self.P("transformer_projector.bias"), outF=P1)
             call("sed_pmam_merge", P1, P2, self.P("merge_weight"), xg, B, Tdec, 0, 1, Tc, Tdec // Tc, Dd)
         else:
             # transformer_projector / cnn_projector before the interpolations
             P1 = E(B * tp, Dd)
-            gemm_nt(split3(pooled.view(B * tp, D), B * tp, D), W["transformer_projector.weight"].ws, EPI_F32,
-                    bias=self.P("transformer_projector.bias"), outF=P1)
+            with ops.split_precision():
+                gemm_nt(split3(pooled.view(B * tp, D), B * tp, D), W["transformer_projector.weight"].ws, EPI_F32,
+                        bias=self.P("transformer_projector.bias"), outF=P1)
             call("sed_pmam_merge", P1, P2, self.P("merge_weight"), xg, B, tp, 1, m.decode_ratio, Tc, Tdec // Tc, Dd)
         out["frame_before_mask"] = xg
         dec_in = xg
@@ -390,9 +405,11 @@ class PmamEngine(SedEngine):
         if m.mlm:
             hpre = E(M, Dd, dt=BF16 if save else self.act)
             act = E(M, Dd)
-            gemm_nt(split3(xd.view(M, Dd), M, Dd), W["mlm_mlp.0.weight"].ws, EPI_GELU32, bias=self.P("mlm_mlp.0.bias"), outH=hpre, outF=act)
+            with ops.split_precision():
+                gemm_nt(split3(xd.view(M, Dd), M, Dd), W["mlm_mlp.0.weight"].ws, EPI_GELU32, bias=self.P("mlm_mlp.0.bias"), outH=hpre, outF=act)
             pred = E(B, Tdec, m.mlm_out)
-            gemm_nt(split3(act, M, Dd), W["mlm_mlp.2.weight"].ws, EPI_F32, bias=self.P("mlm_mlp.2.bias"), outF=pred.view(M, m.mlm_out))
+            with ops.split_precision():
+                gemm_nt(split3(act, M, Dd), W["mlm_mlp.2.weight"].ws, EPI_F32, bias=self.P("mlm_mlp.2.bias"), outF=pred.view(M, m.mlm_out))
             out["mlm_pred"] = pred
             hctx = dict(xd=xd, hpre=hpre, act=act)
         else:

@@ -53,6 +53,7 @@ def update_ema(net, ema_net, step, ema_factor):
     with torch.no_grad():
         for ema_params, params in zip(ema_net.parameters(), net.parameters()):
             ema_params.data.mul_(alpha).add_(params.data, alpha=1 - alpha)
+    ema_net._param_generation = getattr(ema_net, "_param_generation", 0) + 1     # `.data` writes do not move `_version`
     return ema_net
 
 

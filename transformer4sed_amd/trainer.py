@@ -208,6 +208,9 @@ class FusedAdamWEMA:
                      float(ema_alpha_value) if ema_alpha_value is not None else 0.0, 1)
                 done.append((s, e))
         if self.ema_arena is not None and ema_alpha_value is not None:
+            # the teacher's masters change behind torch's back (raw-pointer kernel): engines that cache operand images of frozen
+            # tensors key them on this counter
+            self.ema_net._param_generation = getattr(self.ema_net, "_param_generation", 0) + 1
             done.sort()
             pos = 0
             for s, e in done + [(self.total, self.total)]:
@@ -268,7 +271,11 @@ class MatSedTrainer:
         return {"net": {k: v.detach().cpu().clone() for k, v in self.net.state_dict().items()},
                 "ema_net": None if self.ema_net is None else {k: v.detach().cpu().clone() for k, v in self.ema_net.state_dict().items()},
                 "optimizer": self.optimizer.state_dict(), "scheduler": {"step_num": self.scheduler.step_num},
-                "rng": {"python": _r.getstate(), "numpy": np.random.get_state(), "torch": torch.get_rng_state()}}
+                # the MLM mask plan and the dropout masks draw from the DEVICE generator: without it a resumed pretrain / PMAM run
+                # diverges from an uninterrupted one (one state per rank under DDP: every rank saves its own checkpoint shard)
+                "rng": {"python": _r.getstate(), "numpy": np.random.get_state(), "torch": torch.get_rng_state(),
+                        "cuda": torch.cuda.get_rng_state(next(self.net.parameters()).device)
+                        if next(self.net.parameters()).is_cuda else None}}
 
     def load_state_dict(self, sd, restore_rng=True):
         import random as _r
@@ -279,6 +286,8 @@ class MatSedTrainer:
         self.scheduler.step_num = int(sd["scheduler"]["step_num"])
         if restore_rng and "rng" in sd:
             _r.setstate(sd["rng"]["python"]); np.random.set_state(sd["rng"]["numpy"]); torch.set_rng_state(sd["rng"]["torch"])
+            if sd["rng"].get("cuda") is not None and next(self.net.parameters()).is_cuda:
+                torch.cuda.set_rng_state(sd["rng"]["cuda"], next(self.net.parameters()).device)
 
     def save_weights(self, folder):
         """best_student.pt / best_teacher.pt exactly as the reference writes them (weights-only state_dicts, log.py:86-89)."""
