@@ -127,6 +127,10 @@ int sed_interp_bwd(const float* dout, float* din, int B, int tin, int pad, int r
 /* EncoderSlideWindow merge + global/local mix (src/models/encoder_slide_window.py:16-36; passt_sed.py:266-271) */
 int sed_window_mix(const float* pooled_win, const int* lefts, const int* tps, const int* offs, int nW, float* x,
                    float mix, int B, int T, int ratio, hipStream_t stream);
+/* its backward (autograd of encoder_slide_window.py:16-36 + the mix of passt_sed.py:266-271, student with encoder_win=True):
+   dx [B, T, 768] -> dpooled_win (same packed layout as pooled_win, `rows` rows in all) and dglobal = (1 - mix) dx */
+int sed_window_mix_bwd(const float* dx, const int* lefts, const int* tps, const int* offs, int nW, float* dpooled_win,
+                       float* dglobal, float mix, int B, int T, int ratio, int rows, hipStream_t stream);
 /* MlmModule.setence_mask application (src/models/transformer/mask.py:62-85) and masked MSE (mlm_passt/train.py:36-38) */
 int sed_mlm_apply(const float* x, const float* mask_token, const uint8_t* action, const int* src_idx, float* out,
                   int rows, hipStream_t stream);

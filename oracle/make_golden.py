@@ -537,7 +537,7 @@ TRAINSTEP_PROBES = ["backbone.patch_embed.proj.weight", "backbone.blocks.1.attn.
                     "classifier.weight", "at_adpater.0.mha.in_proj_weight", "at_adpater.1.bias"]
 
 
-def gen_trainstep():
+def gen_trainstep(tag="trainstep", depth=2, feature_layer=2, n_steps=3, sizes=(2, 2, 2), extra_probes=()):
     """Three consecutive optimisation steps of the REFERENCE trainer itself (recipes/desed/finetune/train.py:Trainer.train,
     finetune2 settings: global student, sliding-window EMA teacher in train mode, AdamW groups from
     recipes/desed/finetune/passt/setting.py:get_params, ExponentialDown, update_ema), each run as a one-batch epoch so the
@@ -549,8 +549,9 @@ def gen_trainstep():
     from recipes.desed.finetune.passt.setting import get_params
     from src.utils.scheduler import ExponentialDown
     cfg = json.loads(json.dumps(TRAINSTEP_CFG))
-    net = build_reference_model(768, False, 2, 2)
-    probes = [n for n in TRAINSTEP_PROBES if n in dict(net.named_parameters())]
+    cfg["training"]["batch_size"] = [sizes[0] - sizes[0] // 2, sizes[0] // 2, sizes[1], sizes[2]]
+    net = build_reference_model(768, False, depth, feature_layer)
+    probes = [n for n in list(TRAINSTEP_PROBES) + list(extra_probes) if n in dict(net.named_parameters())]
     assert len(probes) >= 10, [n for n in TRAINSTEP_PROBES if n not in probes]
     ema_net = deepcopy(net)
     for prm in ema_net.parameters():
@@ -577,10 +578,9 @@ def gen_trainstep():
     random.seed(TRAINSTEP_SEEDS[0]); np.random.seed(TRAINSTEP_SEEDS[1]); torch.manual_seed(TRAINSTEP_SEEDS[2])
     out = dict(probe_names=np.array(probes))
     name2p = lambda m: dict(m.named_parameters())
-    n_steps = 3
     for step in range(n_steps):
-        wav = torch.from_numpy(synth.synth_wav(6, seed=2000 + step))
-        labels = torch.from_numpy(synth.synth_batch_labels(2, 2, 2, seed=300 + step))
+        wav = torch.from_numpy(synth.synth_wav(sum(sizes), seed=2000 + step))
+        labels = torch.from_numpy(synth.synth_batch_labels(*sizes, seed=300 + step))
         tr.train_loader = [(wav, labels, None, None)]
         if hasattr(tr, "_train_epoch_len"):
             del tr._train_epoch_len
@@ -599,10 +599,96 @@ def gen_trainstep():
             out[f"s{step}_ema{i}"] = t2n(ep[n]).reshape(-1)[:512].astype(np.float32).copy()
         print(f"   step {step}: " + " ".join(f"{k}={v:.6f}" for k, v in scalars[-1].items()), flush=True)
     out["n_steps"] = np.int64(n_steps)
-    out["config_json"] = np.array(json.dumps(dict(cfg=TRAINSTEP_CFG, sched=TRAINSTEP_SCHED, seeds=TRAINSTEP_SEEDS,
-                                                  wav_seed0=2000, label_seed0=300, groups=[2, 2, 2])))
+    out["config_json"] = np.array(json.dumps(dict(cfg=cfg, sched=TRAINSTEP_SCHED, seeds=TRAINSTEP_SEEDS,
+                                                  wav_seed0=2000, label_seed0=300, groups=list(sizes), depth=depth,
+                                                  feature_layer=feature_layer)))
     out["group_sizes"] = np.array([len(g["params"]) for g in opt.param_groups])
-    save("trainstep", **out)
+    save(tag, **out)
+
+
+def gen_trainstep12():
+    """One optimisation step of the reference trainer at the REAL depth (12 blocks, feature layer 10, 11 teacher windows), 4 clips."""
+    gen_trainstep(tag="trainstep12", depth=12, feature_layer=10, n_steps=1, sizes=(2, 1, 1),
+                  extra_probes=("backbone.blocks.11.attn.qkv.weight", "backbone.blocks.5.mlp.fc1.weight", "backbone.blocks.9.norm1.weight"))
+
+
+def _grad_digest(net, out, prefix):
+    names, norms, heads = [], [], []
+    for k, p in net.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(k)
+        norms.append(float(p.grad.double().norm()))
+        heads.append(t2n(p.grad.reshape(-1)[:8]))
+    out[prefix + "grad_names"] = np.asarray(names)
+    out[prefix + "grad_norms"] = np.asarray(norms)
+    out[prefix + "grad_heads"] = np.stack(heads)
+
+
+def _weighted_loss(tag, strong, weak, at):
+    wgt_s = torch.from_numpy(synth.det_uniform(f"{tag}/gs", tuple(strong.shape)))
+    wgt_w = torch.from_numpy(synth.det_uniform(f"{tag}/gw", tuple(weak.shape)))
+    wgt_a = torch.from_numpy(synth.det_uniform(f"{tag}/ga", tuple(at.shape)))
+    return (strong * wgt_s).sum() + (weak * wgt_w).sum() + (at * wgt_a).sum()
+
+
+def gen_full12_train():
+    """Real depth (12 blocks, feature layer 10), B = 2: loss and per-tensor gradient digests of a train-mode forward/backward, the
+    parameter set that recipes/desed/finetune/passt/setting.py:get_params leaves trainable at freeze_layer = 8, and the eval forward
+    with the 11 sliding windows of the finetune2 teacher."""
+    import logging
+    from recipes.desed.finetune.passt.setting import get_params
+    tag = "model_d768_l12_train"
+    B = 2
+    out = {}
+    mel = torch.from_numpy(synth.det_uniform(f"{tag}/mel", (B, 128, 1000), -1.2, 1.2))
+    net = build_reference_model(768, False, 12, 10)
+    net.train()
+    for p in net.parameters():
+        p.requires_grad_(True)
+    strong, weak, other = net(mel, encoder_win=False, temp_w=1)
+    loss = _weighted_loss(tag, strong, weak, other["at_out"])
+    loss.backward()
+    out["ft_loss"] = t2n(loss)
+    out["strong_train"] = t2n(strong)
+    _grad_digest(net, out, "ft_")
+    cfg = json.loads(json.dumps(TRAINSTEP_CFG))
+    cfg["opt"]["param_groups"]["encoder"]["freeze_layer"] = 8
+    get_params(net, cfg, logging.getLogger("golden"))
+    out["freeze8_trainable"] = np.asarray([k for k, p in net.named_parameters() if p.requires_grad])
+    net.eval()
+    with torch.no_grad():
+        s3, w3, o3 = net(mel, encoder_win=True, mix_rate=0.5, win_param=[512, 49], temp_w=1)
+    S = (slice(None), slice(None, None, 25), slice(None, None, 16))
+    out["strong_win49"] = t2n(s3)
+    out["weak_win49"] = t2n(w3)
+    out["at_win49"] = t2n(o3["at_out"])
+    out["fbm_win49_s"] = t2n(o3["frame_before_mask"][S])
+    save(tag, **out)
+
+
+def gen_winbwd():
+    """Student gradient THROUGH the sliding-window path (src/models/encoder_slide_window.py:16-36, passt_sed.py:266-271): depth-2 encoder,
+    train mode (one random time-embedding offset per window, recorded), weighted loss, gradient digests of every tensor."""
+    tag = "model_d768_l2_winbwd"
+    B = 2
+    out = {}
+    mel = torch.from_numpy(synth.det_uniform(f"{tag}/mel", (B, 128, 1000), -1.2, 1.2))
+    net = build_reference_model(768, False, 2, 2)
+    net.train()
+    for p in net.parameters():
+        p.requires_grad_(True)
+    torch.manual_seed(53)
+    rec = DrawRecorder()
+    with rec.recording():
+        strong, weak, other = net(mel, encoder_win=True, mix_rate=0.5, win_param=[512, 49], temp_w=1)
+    out["toffsets"] = np.asarray([int(x.item()) for x in rec.of("randint")])
+    loss = _weighted_loss(tag, strong, weak, other["at_out"])
+    loss.backward()
+    out["loss"] = t2n(loss)
+    out["strong"] = t2n(strong)
+    _grad_digest(net, out, "")
+    save(tag, **out)
 
 
 def gen_evalpath():
@@ -910,7 +996,7 @@ def gen_pmamft():
 
 
 GENS = dict(frontend=gen_frontend, augment=gen_augment, micro=gen_micro, full=gen_full, full12=gen_full12,
-            schedule=gen_schedule, postprocess=gen_postprocess, losses=gen_losses, trainstep=gen_trainstep, evalpath=gen_evalpath, datapipe=gen_datapipe, pmam=gen_pmam, pmamstep=gen_pmamstep, pmamft=gen_pmamft)
+            schedule=gen_schedule, postprocess=gen_postprocess, losses=gen_losses, trainstep=gen_trainstep, trainstep12=gen_trainstep12, full12train=gen_full12_train, winbwd=gen_winbwd, evalpath=gen_evalpath, datapipe=gen_datapipe, pmam=gen_pmam, pmamstep=gen_pmamstep, pmamft=gen_pmamft)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

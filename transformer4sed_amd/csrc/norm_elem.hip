@@ -470,6 +470,55 @@ extern "C" int sed_window_mix(const float* pooled_win, const int* lefts, const i
     return sed_check_launch();
 }
 
+// backward of the merge: every packed source row (window w, clip b, pooled frame i) gathers the output frames its two interpolation
+// taps reach, weighted by mix / cnt_j; the global branch gets (1 - mix) dx.  No atomics: one thread owns one (row, 4 channels).
+__global__ void window_mix_bwd_kernel(const float* __restrict__ dx, const int* __restrict__ lefts, const int* __restrict__ tps,
+                                      const int* __restrict__ offs, int nW, float* __restrict__ dpooled, float* __restrict__ dglobal,
+                                      float mix, int B, int T, int ratio, int rows) {
+    const size_t total = (size_t)rows * (DM / 4);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int d4 = (int)(idx % (DM / 4));
+        const int row = (int)(idx / (DM / 4));
+        int w = 0;
+        for (int k = 1; k < nW; ++k) w = (row >= offs[k]) ? ((offs[k] >= offs[w]) ? k : w) : w;   // the window whose row range holds `row`
+        const int tpw = tps[w], rel = row - offs[w], b = rel / tpw, i = rel - b * tpw, left = lefts[w];
+        int jlo = (i - 1) * ratio - ratio, jhi = (i + 1) * ratio + ratio;
+        jlo = jlo < 0 ? 0 : jlo;
+        jhi = jhi > tpw * ratio - 1 ? tpw * ratio - 1 : jhi;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int jj = jlo; jj <= jhi; ++jj) {
+            const int j = left + jj;
+            if (j >= T) break;
+            int i0, i1; float lam;
+            interp_coeff(jj, ratio, tpw, tpw, i0, i1, lam);
+            float wgt = 0.f;
+            if (i0 == i) wgt += 1.f - lam;
+            if (i1 == i) wgt += lam;
+            if (wgt == 0.f) continue;
+            int cnt = 0;
+            for (int k = 0; k < nW; ++k) { const int q = j - lefts[k]; cnt += (q >= 0 && q < tps[k] * ratio) ? 1 : 0; }
+            wgt *= mix / (float)cnt;
+            const float4 g = reinterpret_cast<const float4*>(dx)[((size_t)b * T + j) * (DM / 4) + d4];
+            acc.x += wgt * g.x; acc.y += wgt * g.y; acc.z += wgt * g.z; acc.w += wgt * g.w;
+        }
+        reinterpret_cast<float4*>(dpooled)[idx] = acc;
+    }
+    const size_t tot2 = (size_t)B * T * (DM / 4);
+    const float s = 1.f - mix;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot2; idx += (size_t)gridDim.x * blockDim.x) {
+        const float4 g = reinterpret_cast<const float4*>(dx)[idx];
+        reinterpret_cast<float4*>(dglobal)[idx] = make_float4(s * g.x, s * g.y, s * g.z, s * g.w);
+    }
+}
+extern "C" int sed_window_mix_bwd(const float* dx, const int* lefts, const int* tps, const int* offs, int nW, float* dpooled_win,
+                                  float* dglobal, float mix, int B, int T, int ratio, int rows, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (nW <= 0 || rows <= 0) return SED_ERR_ARG;
+    hipLaunchKernelGGL(window_mix_bwd_kernel, dim3(2048), dim3(256), 0, stream, dx, lefts, tps, offs, nW, dpooled_win, dglobal, mix, B,
+                       T, ratio, rows);
+    return sed_check_launch();
+}
+
 // ---------------------------------------------------------------------------------------------------
 // MLM masking (mask.py:62-85) and masked MSE (mlm_passt/train.py:36-38)
 // ---------------------------------------------------------------------------------------------------

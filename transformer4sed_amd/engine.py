@@ -384,10 +384,8 @@ class SedEngine:
         assert Tdec == 1000, "MAT-SED expects 1000 decoder frames (passt_sed.py:260)"
         xg = E(B, Tdec, D)
         call("sed_interp_fwd", pooled, xg, B, tp, pad, ratio)
+        wctx = None
         if encoder_win:
-            if save:
-                raise NotImplementedError("gradient through the sliding-window path is not needed by any MAT-SED "
-                                          "config (only the no-grad teacher / validation use it)")
             win, step = win_param
             starts = window_starts(T, win, step)
             if toffsets is None:
@@ -399,17 +397,21 @@ class SedEngine:
                 width = min(left + win, T) - left
                 groups.setdefault((width - 16) // 10 + 1, []).append(wi)
             lefts, tps, offs, chunks, row = [0] * len(starts), [0] * len(starts), [0] * len(starts), [], 0
+            wgroups = []
             for tpw, wis in groups.items():
-                pw, _, _ = self._encoder_fwd(W, mel, [starts[w] for w in wis], tpw, [toffsets[w] for w in wis], False,
-                                             want_frame=False)
+                pw, _, gctx = self._encoder_fwd(W, mel, [starts[w] for w in wis], tpw, [toffsets[w] for w in wis], save,
+                                                want_frame=False)
                 chunks.append(pw.view(-1, D))
+                wgroups.append(dict(ectx=gctx, row0=row, rows=len(wis) * B * tpw))
                 for k, w in enumerate(wis):
                     lefts[w], tps[w], offs[w] = round(starts[w] * (Tdec / T)), tpw, row + k * B * tpw
                 row += len(wis) * B * tpw
             packed = chunks[0] if len(chunks) == 1 else torch.cat(chunks, 0)
             i32 = lambda v: h2d(v, torch.int32, dev)
-            call("sed_window_mix", packed, i32(lefts), i32(tps), i32(offs), len(starts), xg, float(mix_rate), B, Tdec,
-                 ratio)
+            wl, wt, wo = i32(lefts), i32(tps), i32(offs)
+            call("sed_window_mix", packed, wl, wt, wo, len(starts), xg, float(mix_rate), B, Tdec, ratio)
+            if save:
+                wctx = dict(groups=wgroups, lefts=wl, tps=wt, offs=wo, n=len(starts), mix=float(mix_rate), rows=row)
         out["frame_before_mask"] = xg
         dec_in = xg
         if m.mlm and mlm_plan is not None:
@@ -459,7 +461,7 @@ class SedEngine:
         if save:
             ctx = dict(B=B, T=T, tp=tp, Tdec=Tdec, ectx=ectx, dctx=dctx, actx=actx, hctx=hctx, xd=xd, W=W,
                        mlm_plan=mlm_plan if (m.mlm and mlm_plan is not None and mlm_plan["effective"]) else None,
-                       pooled=pooled, lease=lease)
+                       pooled=pooled, lease=lease, wctx=wctx)
         self._lease_ok = False
         return out, ctx
 
@@ -536,45 +538,80 @@ class SedEngine:
         dfbm = grads.get("frame_before_mask")
         if dfbm is not None:
             g = g + dfbm.contiguous().float()
-        # ---------------- interp + f_pool -> encoder layer `feature_layer`
+        # ---------------- sliding windows (student with encoder_win=True): x = (1 - mix) global + mix * local
         ectx = ctx["ectx"]
         tp = ctx["tp"]
+        wctx = ctx.get("wctx")
+        if wctx is not None:
+            dpacked = E(wctx["rows"], D)
+            gglob = E(B, Tdec, D)
+            call("sed_window_mix_bwd", g.contiguous(), wctx["lefts"], wctx["tps"], wctx["offs"], wctx["n"], dpacked, gglob,
+                 wctx["mix"], B, Tdec, m.decode_ratio, wctx["rows"])
+            g = gglob
+            for grp in wctx["groups"]:       # every window group: f_pool -> blocks -> patch embedding, no stage hooks yet
+                gctx = grp["ectx"]
+                self._encoder_bwd(W, gctx, None, dpacked[grp["row0"]:grp["row0"] + grp["rows"]].view(gctx["B"], gctx["tp"], D), G, None)
+        # ---------------- interp + f_pool -> encoder layer `feature_layer`
         dpooled = E(B, tp, D)
         call("sed_interp_bwd", g, dpooled, B, tp, 1, m.decode_ratio)
-        enc_trainable = G("backbone.blocks.0.attn.qkv.weight") is not None
-        N = ectx["N"]
-        Me = B * N
+        lo, embed_train = self._lowest_trainable(G, len(ectx["layers"]))
         genc = None  # gradient of the encoder residual stream, built from the top
         if m.has_at and grads.get("at_out") is not None:
-            genc = self._at_bwd(W, ctx["actx"], ectx, grads["at_out"].contiguous().float(), G, need_dx=enc_trainable)
-        need_pool_dx = enc_trainable
+            genc = self._at_bwd(W, ctx["actx"], ectx, grads["at_out"].contiguous().float(), G, need_dx=lo < len(ectx["layers"]))
+        self._encoder_bwd(W, ectx, genc, dpooled, G, hook)
+
+    def _lowest_trainable(self, G, depth):
+        """Index of the lowest encoder block with a trainable tensor (`depth` if none; 0 when the patch embedding / position tables train:
+        recipes/desed/finetune/passt/setting.py:44-60 freezes everything below `freeze_layer` except the final norm)."""
+        embed_train = G("backbone.patch_embed.proj.weight") is not None or G("backbone.time_new_pos_embed") is not None
+        if embed_train:
+            return 0, True
+        for i in range(depth):
+            if G(f"backbone.blocks.{i}.attn.qkv.weight") is not None or G(f"backbone.blocks.{i}.norm1.weight") is not None:
+                return i, False
+        return depth, False
+
+    def _encoder_bwd(self, W, ectx, genc, dpooled, G, hook):
+        """Backward of one encoder pass (the global one, or a group of sliding windows folded into the batch): f_pool at the tapped
+        layer, the blocks from the top saved one down to the lowest trainable one, then the patch embedding.  `genc` is the gradient
+        arriving at the top of the stack (AT head) or None; gradients accumulate into the arena views."""
+        m = self.m
+        B, N, tp = ectx["B"], ectx["N"], ectx["tp"]
+        dev = dpooled.device
+        E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
+        Z = lambda *s, dt=F32: torch.zeros(*s, dtype=dt, device=dev)
         depth = len(ectx["layers"])
+        lo, embed_train = self._lowest_trainable(G, depth)
+        tap = m.passt_feature_layer - 1                      # f_pool reads the output of block `tap`
+        need_pool_dx = lo <= tap
         gpool = Z(B, N, D) if need_pool_dx else None
         dtok_tmp = E(B, N, D)
-        # out_norm grads (+ dx into the stream at the feature layer)
-        pool_dx = gpool if need_pool_dx else E(B, N, D)
-        if not need_pool_dx:
-            pool_dx.zero_()
-        call("sed_fpool_bwd", dpooled, ectx["pool_x"], ectx["pool_mean"], ectx["pool_rstd"], self.P("out_norm.weight"),
+        pool_dx = gpool if need_pool_dx else Z(B, N, D)
+        call("sed_fpool_bwd", dpooled.contiguous(), ectx["pool_x"], ectx["pool_mean"], ectx["pool_rstd"], self.P("out_norm.weight"),
              dtok_tmp, pool_dx, G("out_norm.weight"), G("out_norm.bias"), B, tp)
         if hook is not None:
             hook("heads")  # AT head, out_norm (and backbone.norm) gradients are final
-        if not enc_trainable:
+        if lo >= depth:
             return
         if genc is None:
             genc = Z(B, N, D)
-        for li in range(depth - 1, -1, -1):
-            if li + 1 == m.passt_feature_layer:
+        for li in range(depth - 1, lo - 1, -1):
+            if li == tap:
                 genc.add_(gpool)
             genc = self._enc_layer_bwd(W, ectx, li, genc, G)
             if hook is not None:
                 hook(("block", li))
-        # patch embedding + positional tables
-        dconv16 = E(B * 12 * tp, D, dt=BF16)
-        toff = int(ectx["toffsets"][0])
-        call("sed_assemble_tokens_bwd", genc, dconv16, G("backbone.cls_token"), G("backbone.dist_token"),
-             G("backbone.new_pos_embed"), G("backbone.freq_new_pos_embed"), G("backbone.time_new_pos_embed"), toff, B, tp)
+        if not embed_train:
+            return
+        # patch embedding + positional tables (one slab of the batch per window / time offset)
+        nS = ectx["nS"]
+        Bs = B // nS
         Mp = B * 12 * tp
+        dconv16 = E(Mp, D, dt=BF16)
+        for sidx in range(nS):
+            call("sed_assemble_tokens_bwd", genc[sidx * Bs:(sidx + 1) * Bs], dconv16[sidx * Bs * 12 * tp:(sidx + 1) * Bs * 12 * tp],
+                 G("backbone.cls_token"), G("backbone.dist_token"), G("backbone.new_pos_embed"), G("backbone.freq_new_pos_embed"),
+                 G("backbone.time_new_pos_embed"), int(ectx["toffsets"][sidx]), Bs, tp)
         self._dw_accum(dconv16, ectx["cols"], Mp, G("backbone.patch_embed.proj.weight"), G("backbone.patch_embed.proj.bias"))
         if hook is not None:
             hook("embed")
