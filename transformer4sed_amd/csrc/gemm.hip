@@ -46,6 +46,7 @@ struct GemmArgs {
     const float *pu, *pv;
     int seq, seq_pad, heads;
     int bwd_bf16; // f16 runs only: tensors that only the (bf16) backward consumes are written as bf16 straight away
+    int group_m;  // 256^2 kernel: tile rows per L2 group (see gemm_nt_pp_kernel)
     int ncols;    // 128^2 kernel: output columns >= ncols are computed but not written (operands padded to the tile width)
 };
 
@@ -615,8 +616,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     const int wm = wave >> 2, wn = wave & 3;
     const int ntn = g.N / V3_T, ntm = (g.M + V3_T - 1) / V3_T, nwg = ntm * ntn;
     const int t = xcd_remap(blockIdx.x, nwg);
-    const int group_size = 4 * ntn, gid = t / group_size, first_m = gid * 4;
-    const int gm = (ntm - first_m) < 4 ? (ntm - first_m) : 4;
+    const int GM = g.group_m;
+    const int group_size = GM * ntn, gid = t / group_size, first_m = gid * GM;
+    const int gm = (ntm - first_m) < GM ? (ntm - first_m) : GM;
     const int tin = t - gid * group_size;
     const int m0 = (first_m + tin % gm) * V3_T, n0 = (tin / gm) * V3_T;
     const int nk = g.K / BK;
@@ -979,6 +981,13 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
     if constexpr (EPI != EPI_ATOMIC) if (g.N % V3_T == 0 && g.M >= 1024 && g.ksplit == 1) {
         dim3 grid3(cdiv(g.M, V3_T) * (g.N / V3_T), 1);
         if ((long long)g.lda * 2 * V3_T >= (1LL << 31) || (long long)g.ldb * 2 * V3_T >= (1LL << 31)) return SED_ERR_ARG;  // 32-bit panel offsets
+        // L2 grouping: 4 tile rows x all tile columns per group, groups XCD-contiguous.  Swept 2..32 on the model's shapes
+        // (tools/gemm_l2.py): fabric reads stay at 1.4-2.3x (N = 768) / ~5x (N = 3072) of the algorithmic operand bytes for every
+        // height -- column tiles of one row panel drift apart by more than the ~2 K-steps a line survives in the 4 MB L2 and re-read it
+        // from the Infinity Cache -- while the time is best at 4 (fc2 1186 vs 998 TFLOP/s at 2): the counter does not track the time.
+        GemmArgs gg = g;
+        gg.group_m = 4;
+        const GemmArgs& g = gg;
         static bool attrp[2] = {false, false};
         if (f16) {
             if (!attrp[1]) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attrp[1] = true; }
