@@ -139,6 +139,17 @@ int sed_mlm_apply_bwd(const float* dout, const uint8_t* action, const int* src_i
 /* n_masked_rows_dev (nullable): the row count as a device int, read by the kernel instead of n_masked_rows (no host sync) */
 int sed_masked_mse(const float* pred, const float* target, const uint8_t* mask, int n_masked_rows, const int* n_masked_rows_dev,
                    float* loss_zeroed, float* dpred, float* dtarget, int rows, hipStream_t stream);
+/* The six mean-teacher loss terms of Trainer.train and their gradients in one call (recipes/desed/finetune/train.py:160-191):
+   l_strong = BCE(s_strong[:strong_n], labels[:strong_n]), l_weak = BCE(s_weak[ws], labels_weak[ws]), l_at = BCE(s_at[ws], labels_weak[ws]),
+   lc_strong = MSE(s_strong, t_strong), lc_weak = MSE(s_weak, t_at), lc_at = MSE(s_at, t_at)   (ws = clips weak_lo .. weak_lo + weak_n - 1),
+   total = l_strong + w_weak l_weak + w_at l_at + w_cons (lc_strong + w_weak_cons lc_weak + w_at lc_at); torch.nn.BCELoss / MSELoss
+   semantics (mean reduction, log clamped at -100, BCE gradient denominator clamped at 1e-12).
+   out[8] = {total, l_strong, l_weak, l_at, lc_strong, lc_weak, lc_at, 0}; scratch[8] is zeroed by the call;
+   d_strong [B,C,T], d_weak [B,C], d_at [B,C] = d total / d (student outputs). */
+int sed_sed_losses(const float* s_strong, const float* s_weak, const float* s_at, const float* t_strong, const float* t_at,
+                   const float* labels, const float* labels_weak, int B, int C, int T, int strong_n, int weak_lo, int weak_n,
+                   float w_weak, float w_weak_cons, float w_at, float w_cons, float* scratch, float* out, float* d_strong,
+                   float* d_weak, float* d_at, hipStream_t stream);
 /* classifier + sigmoid(x/temp) + pad mask + linear-softmax pooling (passt_sed.py:285-296) */
 int sed_head_fwd(const float* x, const float* W, const float* bias, float temp, const uint8_t* pad_mask, float* strong,
                  float* weak, float* sums, int B, int T, int C, hipStream_t stream);

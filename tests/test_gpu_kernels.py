@@ -517,3 +517,43 @@ def test_mlm_mse_adamw():
         e_ref = e_ref * alpha + pt.detach() * (1 - alpha)
         call("sed_adamw_ema", p, (gr * step).contiguous(), m, v, ema, n, 1e-3, 1e-4, 0.9, 0.999, 1e-8, step, alpha, 1)
         assert maxerr(p, pt.detach()) < 2e-6 and maxerr(ema, e_ref) < 2e-6
+
+
+def test_fused_sed_losses_vs_torch_modules():
+    """sed_sed_losses == the six torch.nn.BCELoss / MSELoss terms of Trainer.train (recipes/desed/finetune/train.py:160-191) and their
+    autograd gradients, including saturated posteriors (log clamp at -100, gradient clamp 1e-12) and an empty strong set."""
+    from transformer4sed_amd.trainer import FusedSedLosses
+    torch.manual_seed(5)
+    B, C, T = 7, 10, 1000
+    for strong_n, weak_n in ((3, 2), (0, 4)):
+        mk = lambda *s: torch.rand(*s, device=DEV)
+        ss, sw, sa = mk(B, C, T).requires_grad_(True), mk(B, C).requires_grad_(True), mk(B, C).requires_grad_(True)
+        with torch.no_grad():
+            ss[0, 0, :5] = 0.0; ss[0, 1, :5] = 1.0; sw[strong_n, 0] = 1.0; sa[strong_n, 1] = 0.0
+        ts, ta = mk(B, C, T), mk(B, C)
+        y = (mk(B, C, T) < 0.3).float(); yw = (mk(B, C) < 0.5).float()
+        w = dict(w_weak=0.5, w_weak_cons=0.5, w_at=2.0, w_cons=13.7)
+        total, terms = FusedSedLosses.apply(ss, sw, sa, ts, ta, y, yw, strong_n, strong_n, weak_n, w["w_weak"], w["w_weak_cons"], w["w_at"], w["w_cons"])
+        (total * 1.5).backward()
+        got = [t.grad.clone() for t in (ss, sw, sa)]
+        for t in (ss, sw, sa):
+            t.grad = None
+        bce, mse = torch.nn.BCELoss(), torch.nn.MSELoss()
+        ws = slice(strong_n, strong_n + weak_n)
+        l_at, lc_at = bce(sa[ws], yw[ws]), mse(sa, ta)
+        l_strong, l_weak = bce(ss[:strong_n], y[:strong_n]), bce(sw[ws], yw[ws])
+        lc_strong, lc_weak = mse(ss, ts), mse(sw, ta)
+        ref_total = l_strong + w["w_weak"] * l_weak + (lc_strong + w["w_weak_cons"] * lc_weak + w["w_at"] * lc_at) * w["w_cons"] + l_at * w["w_at"]
+        refs = [ref_total, l_strong, l_weak, l_at, lc_strong, lc_weak, lc_at]
+        for k, r in enumerate(refs):
+            a, b = float(terms[k]), float(r)
+            if np.isnan(b):
+                assert np.isnan(a), (k, a)
+            else:
+                assert abs(a - b) <= 2e-6 * max(1.0, abs(b)), (strong_n, k, a, b)
+        if strong_n > 0:
+            (ref_total * 1.5).backward()
+            for g, t, nm in zip(got, (ss, sw, sa), ("strong", "weak", "at")):
+                e = maxerr(g, t.grad)
+                sc = float(t.grad.abs().max())
+                report(f"fused losses d{nm}", e); assert e <= 1e-6 * max(1.0, sc), (nm, e, sc)

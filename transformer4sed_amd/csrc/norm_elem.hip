@@ -611,6 +611,96 @@ extern "C" int sed_masked_mse(const float* pred, const float* target, const uint
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The six loss terms of the mean-teacher step and their gradients (recipes/desed/finetune/train.py:160-191) in one pass over the
+// posteriors: torch.nn.BCELoss (log clamped at -100; gradient (p - y) / max(p (1 - p), 1e-12)) and MSELoss, mean reductions.
+// sums[0..5] = un-normalised {bce_strong, bce_weak, bce_at, se_strong, se_weak, se_at}; a one-thread kernel turns them into the
+// seven scalars the trainer logs.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bce_term(float p, float y) {
+    const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.f - p), -100.f);
+    return -(y * lp + (1.f - y) * lq);
+}
+__device__ __forceinline__ float bce_grad(float p, float y) { return (p - y) / fmaxf((1.f - p) * p, 1e-12f); }
+__global__ void zero8_kernel(float* p) { if (threadIdx.x < 8) p[threadIdx.x] = 0.f; }
+__global__ __launch_bounds__(256) void sed_losses_kernel(const float* __restrict__ ss, const float* __restrict__ sw, const float* __restrict__ sa,
+                                                         const float* __restrict__ ts, const float* __restrict__ ta,
+                                                         const float* __restrict__ y, const float* __restrict__ yw, int B, int C, int T,
+                                                         int strong_n, int weak_lo, int weak_n, float w_weak, float w_weak_cons, float w_at,
+                                                         float w_cons, float* __restrict__ sums, float* __restrict__ ds,
+                                                         float* __restrict__ dw, float* __restrict__ da) {
+    __shared__ float red[4][6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const size_t per_clip = (size_t)C * T, total = (size_t)B * per_clip;
+    const float g_bce_s = strong_n > 0 ? 1.f / ((float)strong_n * (float)C * (float)T) : 0.f;
+    const float g_mse_s = 2.f * w_cons / ((float)B * (float)C * (float)T);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / per_clip);
+        const float p = ss[i], q = ts[i];
+        float g = g_mse_s * (p - q);
+        acc[3] += (p - q) * (p - q);
+        if (b < strong_n) {
+            const float t = y[i];
+            acc[0] += bce_term(p, t);
+            g += g_bce_s * bce_grad(p, t);
+        }
+        ds[i] = g;
+    }
+    if (blockIdx.x == 0) {       // clip-level terms: B x C values
+        const float g_bce_w = weak_n > 0 ? 1.f / ((float)weak_n * (float)C) : 0.f, g_mse_w = 2.f * w_cons / ((float)B * (float)C);
+        for (int i = threadIdx.x; i < B * C; i += blockDim.x) {
+            const int b = i / C;
+            const bool in_w = b >= weak_lo && b < weak_lo + weak_n;
+            const float pw = sw[i], pa = sa[i], qa = ta[i];
+            float gw = g_mse_w * w_weak_cons * (pw - qa), ga = g_mse_w * w_at * (pa - qa);
+            acc[4] += (pw - qa) * (pw - qa);
+            acc[5] += (pa - qa) * (pa - qa);
+            if (in_w) {
+                const float t = yw[i];
+                acc[1] += bce_term(pw, t);
+                acc[2] += bce_term(pa, t);
+                gw += w_weak * g_bce_w * bce_grad(pw, t);
+                ga += w_at * g_bce_w * bce_grad(pa, t);
+            }
+            dw[i] = gw;
+            da[i] = ga;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float v = wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) unsafeAtomicAdd(&sums[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void sed_losses_final_kernel(const float* __restrict__ sums, float* __restrict__ out, int B, int C, int T, int strong_n,
+                                        int weak_n, float w_weak, float w_weak_cons, float w_at, float w_cons) {
+    if (threadIdx.x != 0) return;
+    const float nan = __int_as_float(0x7fc00000);     // torch: the mean over an empty selection is NaN
+    const float l_strong = strong_n > 0 ? sums[0] / ((float)strong_n * C * T) : nan;
+    const float l_weak = weak_n > 0 ? sums[1] / ((float)weak_n * C) : nan, l_at = weak_n > 0 ? sums[2] / ((float)weak_n * C) : nan;
+    const float lc_strong = sums[3] / ((float)B * C * T), lc_weak = sums[4] / ((float)B * C), lc_at = sums[5] / ((float)B * C);
+    out[0] = l_strong + w_weak * l_weak + (lc_strong + w_weak_cons * lc_weak + w_at * lc_at) * w_cons + l_at * w_at;
+    out[1] = l_strong; out[2] = l_weak; out[3] = l_at; out[4] = lc_strong; out[5] = lc_weak; out[6] = lc_at; out[7] = 0.f;
+}
+extern "C" int sed_sed_losses(const float* s_strong, const float* s_weak, const float* s_at, const float* t_strong, const float* t_at,
+                              const float* labels, const float* labels_weak, int B, int C, int T, int strong_n, int weak_lo, int weak_n,
+                              float w_weak, float w_weak_cons, float w_at, float w_cons, float* scratch, float* out, float* d_strong,
+                              float* d_weak, float* d_at, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (B <= 0 || C <= 0 || T <= 0 || strong_n < 0 || strong_n > B || weak_lo < 0 || weak_n < 0 || weak_lo + weak_n > B) return SED_ERR_ARG;
+    hipLaunchKernelGGL(zero8_kernel, dim3(1), dim3(64), 0, stream, scratch);
+    int blocks = cdiv((int64_t)B * C * T, 256 * 4);
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    hipLaunchKernelGGL(sed_losses_kernel, dim3(blocks), dim3(256), 0, stream, s_strong, s_weak, s_at, t_strong, t_at, labels, labels_weak, B, C,
+                       T, strong_n, weak_lo, weak_n, w_weak, w_weak_cons, w_at, w_cons, scratch, d_strong, d_weak, d_at);
+    hipLaunchKernelGGL(sed_losses_final_kernel, dim3(1), dim3(64), 0, stream, scratch, out, B, C, T, strong_n, weak_n, w_weak, w_weak_cons,
+                       w_at, w_cons);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // SED head (passt_sed.py:285-296): logits = W x + b, s = sigmoid(logit / temp), pad mask, linear-softmax pooling
 // ---------------------------------------------------------------------------------------------------
 #define NCLS_MAX 16

@@ -249,6 +249,31 @@ class MaskedMSE(torch.autograd.Function):
         return dt * g, dp * g, None
 
 
+class FusedSedLosses(torch.autograd.Function):
+    """The six loss terms of Trainer.train (recipes/desed/finetune/train.py:160-191) and d total / d (student outputs) in ONE C-ABI call
+    (`sed_sed_losses`) instead of ~30 element-wise / reduction launches.  Returns (total, terms[8]); only `total` is differentiable."""
+
+    @staticmethod
+    def forward(ctx, s_strong, s_weak, s_at, t_strong, t_at, labels, labels_weak, strong_n, weak_lo, weak_n, w_weak, w_weak_cons, w_at,
+                w_cons):
+        B, C, T = s_strong.shape
+        f = lambda t: t.detach().contiguous().float()
+        dev = s_strong.device
+        scratch = torch.empty(8, dtype=torch.float32, device=dev)
+        out = torch.empty(8, dtype=torch.float32, device=dev)
+        ds, dw, da = torch.empty(B, C, T, device=dev), torch.empty(B, C, device=dev), torch.empty(B, C, device=dev)
+        call("sed_sed_losses", f(s_strong), f(s_weak), f(s_at), f(t_strong), f(t_at), f(labels), f(labels_weak), B, C, T, int(strong_n),
+             int(weak_lo), int(weak_n), float(w_weak), float(w_weak_cons), float(w_at), float(w_cons), scratch, out, ds, dw, da)
+        ctx.save_for_backward(ds, dw, da)
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, g_total, _g_terms):
+        ds, dw, da = ctx.saved_tensors
+        return (ds * g_total, dw * g_total, da * g_total) + (None,) * 11
+
+
 class MatSedTrainer:
     def __init__(self, net, ema_net, optimizer, scheduler, config, epoch_len, net_pooling=1, ddp=None):
         self.net, self.ema_net = net, ema_net
@@ -261,6 +286,7 @@ class MatSedTrainer:
         self.mse = torch.nn.MSELoss()
         import os
         self.overlap_teacher = os.environ.get("SED_OVERLAP_TEACHER", "0") == "1"
+        self.fused_losses = os.environ.get("SED_FUSED_LOSSES", "1") != "0"      # 0: the torch BCELoss / MSELoss modules (A/B reference)
         self._side = None
 
     # ---- checkpoint / resume.  Weights use the reference's state_dict keys, so `best_student.pt` /
@@ -342,14 +368,24 @@ class MatSedTrainer:
                 tch_strong, tch_weak, tch_other = self.ema_net(tch_feat, **kw["train_tch_kwargs"])
         at_s, at_t = stu_other["at_out"], tch_other["at_out"].detach()
         ws = slice(strong_n, strong_n + weak_n)
+        w_cons = cons_weight(self.scheduler.step_num, tr["self_loss_warmup"] * self.epoch_len, tr["cons_scheduler_name"],
+                             tr["w_cons_max"], tr["w_cons_min"])
+        if self.fused_losses and stu_strong.is_cuda:
+            loss_total, terms = FusedSedLosses.apply(stu_strong, stu_weak, at_s, tch_strong.detach(), at_t, labels, labels_weak, strong_n,
+                                                     strong_n, weak_n, tr["w_weak"], tr["w_weak_cons"], tr["w_AT"], w_cons)
+            loss_total.backward()
+            if self.ddp is not None:
+                self.ddp.allreduce_grads(self.net)
+            self.optimizer.step(ema_alpha(self.scheduler.step_num + 1, tr["ema_factor"]))
+            self.scheduler.step()
+            return dict(loss_total=loss_total.detach(), loss_class_strong=terms[1], loss_class_weak=terms[2], loss_class_at_specific=terms[3],
+                        loss_cons_strong=terms[4], loss_cons_weak=terms[5], loss_cons_at_specific=terms[6], w_cons=w_cons)
         l_at = self.bce(at_s[ws], labels_weak[ws])
         lc_at = self.mse(at_s, at_t)
         l_strong = self.bce(stu_strong[:strong_n], labels[:strong_n])
         l_weak = self.bce(stu_weak[ws], labels_weak[ws])
         lc_strong = self.mse(stu_strong, tch_strong.detach())
         lc_weak = self.mse(stu_weak, at_t)
-        w_cons = cons_weight(self.scheduler.step_num, tr["self_loss_warmup"] * self.epoch_len, tr["cons_scheduler_name"],
-                             tr["w_cons_max"], tr["w_cons_min"])
         self_loss = (lc_strong + tr["w_weak_cons"] * lc_weak + tr["w_AT"] * lc_at) * w_cons
         loss_total = l_strong + tr["w_weak"] * l_weak + self_loss + l_at * tr["w_AT"]
         loss_total.backward()  # (the reference's clip_grad_norm before backward is a no-op)
