@@ -768,39 +768,61 @@ __device__ __forceinline__ s16x8_t tn_frag(unsigned long long lo, unsigned long 
     __builtin_memcpy(&f, w, 16);
     return f;
 }
+// LDS stage: per operand four PANELS of [64 tokens][64 features] (128-byte rows, 8 KiB each) -- a DMA piece is 8 token rows of one
+// panel, so pieces (and the DMA slots built from them) follow the feature halves the ping-pong phases consume, exactly like the row
+// halves of the NT kernel.  Inside a row the 32-byte block b (16 features) of token row r sits at block b ^ (r & 3) ^ ((r >> 3) & 1):
+// the 32 lanes of one transposing-read cycle (two 16-lane groups: token rows 8 G + r and 8 G + 8 + r, r = 0..3, 32 bytes each) then
+// cover all 64 banks.  A stage s at s * 32 KiB, B stage s at 64 KiB + s * 32 KiB.
+// K loop: the ping-pong schedule of gemm_nt_pp_kernel (two wave rows half a phase apart, four 64 x 32 quadrant phases per 64-token
+// K tile, B half 0 of the next tile read in P4).  DMA slots (2 pieces per wave each): A0 = A panels {0, 2}, A1 = {1, 3}, B01, B23.
+// A piece spans both feature halves of the waves that read it, so a B slot is free only after P2 and the issue order differs from the
+// NT kernel: P1(t): B23(t+1), P2(t): A1(t+1), P3(t): A0(t+2), P4(t): B01(t+2); `vmcnt(4)` at P3(t) retires A0 / B01 / B23 of tile
+// t+1 one phase ahead of their first read (B half 0 in P4(t)), `vmcnt(6)` at P1(t) retires A1(t) two phases ahead of its read.
 template <bool BF16_B>
 __global__ __launch_bounds__(512) void gemm_tn_dw_kernel(const TnArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int ntn = g.N / V3_T, ntm = g.M / V3_T, nwg = ntm * ntn;
-    const int t = xcd_remap(blockIdx.x, nwg);
+    // One linear workgroup index, split-major and XCD-contiguous: the tiles of one token split run side by side on ONE XCD, so the
+    // split's dY / X rows go through that L2 once for all of them (9 x 3 tiles: fabric reads 663 -> ~250 MB per launch; with the tile
+    // index spread over the XCDs every dY panel was fetched by three L2s and every X panel by up to nine).
+    const int ntn = g.N / V3_T, ntm = g.M / V3_T, ntiles = ntm * ntn;
+    const int L = xcd_remap(blockIdx.x, ntiles * g.ksplit);
+    const int split = L / ntiles, t = L - split * ntiles;
     const int m0 = (t % ntm) * V3_T, n0 = (t / ntm) * V3_T;
     const int ktiles = g.T / BK;
-    const int kt_begin = (int)(((long long)blockIdx.y * ktiles) / g.ksplit);
-    const int kt_end = (int)(((long long)(blockIdx.y + 1) * ktiles) / g.ksplit);
+    const int kt_begin = (int)(((long long)split * ktiles) / g.ksplit);
+    const int kt_end = (int)(((long long)(split + 1) * ktiles) / g.ksplit);
     const int nk = kt_end - kt_begin;
-    // DMA: per operand 32 pieces of 2 token rows x 512 B; waves 0-3 fetch dY pieces, 4-7 X pieces (8 each)
-    const bool isB = wave >= 4;
-    const bf16_t* src[8];
-    int dst[8];
-    {
-        const int krow = lane >> 5, pc = lane & 31;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)kt_begin * BK * g.lda + m0), 0,
+                                                                        (nk * BK - 1) * g.lda * 2 + V3_T * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(g.B + (size_t)kt_begin * BK * g.ldb + n0), 0,
+                                                                        (nk * BK - 1) * g.ldb * 2 + V3_T * 2, 0x00020000);
+    // DMA pieces of this wave: slot piece index pi = 2 wave + e -> panel list[pi >> 3], token rows 8 (pi & 7) .. + 7
+    const int prow = lane >> 3, pc = lane & 7;
+    int vo[4][2], ld_[4][2];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int piece = (wave & 3) * 8 + i, k = piece * 2 + krow;
-            // logical feature offset stored at physical 16-B chunk pc of token row k (unit swizzle + half swap, see above)
-            const int col = (((pc >> 2) ^ (k & 3)) * 4 + ((pc & 3) ^ (((k >> 3) & 1) << 1))) * 8;
-            src[i] = (isB ? g.B + (size_t)k * g.ldb + n0 : g.A + (size_t)k * g.lda + m0) + col + (size_t)kt_begin * BK * (isB ? g.ldb : g.lda);
-            dst[i] = (isB ? 32768 : 0) + piece * 1024;
+    for (int e = 0; e < 2; ++e) {
+        const int pi = 2 * wave + e, q = pi & 7, hi = pi >> 3;
+        const int panels[4] = {2 * hi, hi, 2 + hi, 2 * hi + 1};      // slots: A0 {0,2}, B01 {0,1}, B23 {2,3}, A1 {1,3}
+        const int r = 8 * q + prow;
+        const int lc = ((((pc >> 1) ^ (r & 3) ^ ((r >> 3) & 1)) & 3) << 1) | (pc & 1);      // logical 16-B chunk held by physical chunk pc
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            const bool is_b = (sl == 1 || sl == 2);
+            vo[sl][e] = r * (is_b ? g.ldb : g.lda) * 2 + (panels[sl] * 64 + lc * 8) * 2;
+            ld_[sl][e] = (is_b ? 65536 : 0) + panels[sl] * 8192 + q * 1024;
         }
     }
-    const size_t kstride = (size_t)BK * (isB ? g.ldb : g.lda);
-#define TN_DMA(kt, stage)                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                         \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)(kt) * kstride), \
-                                         (__attribute__((address_space(3))) void*)(lds3 + (stage) * V3_STAGE + dst[i]),   \
-                                         16, 0, 0);
+    const int kstride_a = BK * g.lda * 2, kstride_b = BK * g.ldb * 2;
+#define TN_DMA(SL, KT)                                                                                                    \
+    {                                                                                                                     \
+        const bool b_ = ((SL) == 1 || (SL) == 2);                                                                         \
+        const int so_ = (KT) * (b_ ? kstride_b : kstride_a), st_ = ((KT) & 1) << 15;                                      \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_ ? rb : ra, (lds_ptr_t)(lds3 + st_ + ld_[SL][0]), 16, vo[SL][0], so_, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_ ? rb : ra, (lds_ptr_t)(lds3 + st_ + ld_[SL][1]), 16, vo[SL][1], so_, 0, 0); \
+    }
     f32x4_t acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -808,78 +830,104 @@ __global__ __launch_bounds__(512) void gemm_tn_dw_kernel(const TnArgs g) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     // transposing-read lane addresses: group G = lane >> 4 reads token rows 8 G + (a >> 2) (+ 4 for the second read), a = lane & 15
     const int a = lane & 15, G = lane >> 4;
-    unsigned aaddr[8], baddr[4];
     const unsigned lbase = (unsigned)(size_t)lds3;
-    const unsigned rowoff = (unsigned)((8 * G + (a >> 2)) * 512);
+    const unsigned rowb = (unsigned)((8 * G + (a >> 2)) * 128 + 8 * (a & 3));
+    const int sx = ((a >> 2) & 3) ^ (G & 1);
+    unsigned aaddr[4], baddr[4];        // one per 32-byte block (16 features) of a 64-feature panel
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int col = wm * 128 + i * 16 + 4 * (a & 3);
-        aaddr[i] = lbase + rowoff + ((((col >> 5) ^ (a >> 2)) & 7) << 6) + ((((col >> 4) & 1) ^ (G & 1)) << 5) + (col & 15) * 2;
+    for (int u = 0; u < 4; ++u) {
+        aaddr[u] = lbase + (2 * wm) * 8192 + rowb + ((u ^ sx) << 5);
+        baddr[u] = lbase + 65536 + wn * 8192 + rowb + ((u ^ sx) << 5);
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = wn * 64 + j * 16 + 4 * (a & 3);
-        baddr[j] = lbase + 32768 + rowoff + ((((col >> 5) ^ (a >> 2)) & 7) << 6) + ((((col >> 4) & 1) ^ (G & 1)) << 5) + (col & 15) * 2;
-    }
-    // bias gradient: the workgroups of the first N tile also sum their dY fragments over the tokens -- wave (wm, wn) owns the two
-    // 16-feature blocks i = 2 wn, 2 wn + 1 (a lane holds 8 tokens of one feature); VALU work that rides under the MFMAs
     const bool do_bias = g.dbias != nullptr && n0 == 0;
     float colacc[2] = {0.f, 0.f};
-    if (nk > 0) { TN_DMA(0, 0); }
-    for (int it = 0; it < nk; ++it) {
-        const int stage = it & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (it + 1 < nk) { TN_DMA(it + 1, stage ^ 1); }
-        const unsigned so = stage * V3_STAGE;
-        // fragment reads: B (4 column blocks) of k-step S, A half H (row blocks 4 H .. 4 H + 3) of k-step S -- 8 reads each
-#define TN_RB(S, bl, bh)                                                                                                  \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) { bl[j] = lds_tr<(S) * 16384>(baddr[j] + so); bh[j] = lds_tr<(S) * 16384 + 2048>(baddr[j] + so); }
-#define TN_RA(S, H, al, ah)                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) { al[i] = lds_tr<(S) * 16384>(aaddr[4 * (H) + i] + so); ah[i] = lds_tr<(S) * 16384 + 2048>(aaddr[4 * (H) + i] + so); }
-        // the compiler does not know the asm results are still in flight: every consumer is tied to a counted wait (lgkmcnt <= 15)
-#define TN_WAIT4(CNT, xl, xh)                                                                                             \
-        asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                        \
-                     : "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xl[3]), "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]) :: "memory");
-#define TN_MFMA(H, al, ah, bf_)                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                   \
-            const s16x8_t af = tn_frag(al[i], ah[i], false);                                                              \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[4 * (H) + i][j] = mfma16t<false>(bf_[j], af, acc[4 * (H) + i][j]); \
-            if (do_bias && ((4 * (H) + i) >> 1) == wn) {                                                                  \
-                unsigned w4[4];                                                                                           \
-                __builtin_memcpy(w4, &af, 16);                                                                            \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                             \
-                    colacc[i & 1] += __uint_as_float(w4[e] << 16) + __uint_as_float(w4[e] & 0xffff0000u);                 \
-            }                                                                                                             \
-        }
-        // two 32-token k-steps, each in two halves of 16 MFMAs; the reads run 8-16 operations ahead of their consumers
-        unsigned long long b0l[4], b0h[4], b1l[4], b1h[4], pal[4], pah[4], qal[4], qah[4];
-        s16x8_t bf0[4], bf1[4];
-        TN_RB(0, b0l, b0h)
-        TN_RA(0, 0, pal, pah)
-        TN_RA(0, 1, qal, qah)
-        TN_WAIT4(8, b0l, b0h)
-        TN_WAIT4(8, pal, pah)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bf0[j] = tn_frag(b0l[j], b0h[j], !BF16_B);
-        TN_MFMA(0, pal, pah, bf0)
-        TN_RB(1, b1l, b1h)
-        TN_WAIT4(8, qal, qah)
-        TN_RA(1, 0, pal, pah)
-        TN_MFMA(1, qal, qah, bf0)
-        TN_RA(1, 1, qal, qah)
-        TN_WAIT4(8, b1l, b1h)
-        TN_WAIT4(8, pal, pah)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bf1[j] = tn_frag(b1l[j], b1h[j], !BF16_B);
-        TN_MFMA(0, pal, pah, bf1)
-        TN_WAIT4(0, qal, qah)
-        TN_MFMA(1, qal, qah, bf1)
-#undef TN_RB
-#undef TN_RA
-#undef TN_WAIT4
-#undef TN_MFMA
+    unsigned long long al[4][2], ah[4][2], bl[2][2][2], bh[2][2][2];   // A half: [ii][ks]; B: [set][jj][ks]; lo / hi = tokens +0..3 / +4..7
+#define TN_RD_A(H)                                                                                                        \
+    _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) {                                                                    \
+        al[ii][0] = lds_tr<(H) * 8192>(aaddr[ii]); ah[ii][0] = lds_tr<(H) * 8192 + 512>(aaddr[ii]);                       \
+        al[ii][1] = lds_tr<(H) * 8192 + 4096>(aaddr[ii]); ah[ii][1] = lds_tr<(H) * 8192 + 4608>(aaddr[ii]);               \
     }
+#define TN_RD_B(SET, JH, XOR)                                                                                             \
+    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                                    \
+        bl[SET][jj][0] = lds_tr<0>(baddr[2 * (JH) + jj] ^ (XOR)); bh[SET][jj][0] = lds_tr<512>(baddr[2 * (JH) + jj] ^ (XOR)); \
+        bl[SET][jj][1] = lds_tr<4096>(baddr[2 * (JH) + jj] ^ (XOR)); bh[SET][jj][1] = lds_tr<4608>(baddr[2 * (JH) + jj] ^ (XOR)); \
+    }
+    // the compiler does not know the asm read results are in flight: the fragments are tied to the wait that retires them
+#define TN_TIE_A() asm volatile("" : "+v"(al[0][0]), "+v"(al[0][1]), "+v"(al[1][0]), "+v"(al[1][1]), "+v"(al[2][0]), "+v"(al[2][1]), "+v"(al[3][0]), "+v"(al[3][1]), \
+                                   "+v"(ah[0][0]), "+v"(ah[0][1]), "+v"(ah[1][0]), "+v"(ah[1][1]), "+v"(ah[2][0]), "+v"(ah[2][1]), "+v"(ah[3][0]), "+v"(ah[3][1]) :: "memory");
+#define TN_TIE_B(SET) asm volatile("" : "+v"(bl[SET][0][0]), "+v"(bl[SET][0][1]), "+v"(bl[SET][1][0]), "+v"(bl[SET][1][1]), \
+                                        "+v"(bh[SET][0][0]), "+v"(bh[SET][0][1]), "+v"(bh[SET][1][0]), "+v"(bh[SET][1][1]) :: "memory");
+#define TN_SYNC_IN()                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    __builtin_amdgcn_s_barrier();                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#define TN_MFMA(IH, JH, SET, BIAS)                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    {                                                                                                                     \
+        s16x8_t bf_[2][2];                                                                                                \
+        _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                                  \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) bf_[jj][ks] = tn_frag(bl[SET][jj][ks], bh[SET][jj][ks], !BF16_B); \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                  \
+            _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) {                                                            \
+                const s16x8_t af = tn_frag(al[ii][ks], ah[ii][ks], false);                                                \
+                _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                          \
+                    acc[4 * (IH) + ii][2 * (JH) + jj] = mfma16t<false>(bf_[jj][ks], af, acc[4 * (IH) + ii][2 * (JH) + jj]); \
+                if ((BIAS) && do_bias && ((4 * (IH) + ii) >> 1) == wn) {                                                  \
+                    unsigned w4[4];                                                                                       \
+                    __builtin_memcpy(w4, &af, 16);                                                                        \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                         \
+                        colacc[ii & 1] += __uint_as_float(w4[e] << 16) + __uint_as_float(w4[e] & 0xffff0000u);            \
+                }                                                                                                         \
+            }                                                                                                             \
+    }                                                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    __builtin_amdgcn_s_barrier();                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);
+    // one K tile; X = B register set holding this tile's half 0, Y = the other set
+#define TN_TILE(T_, X, Y)                                                                                                 \
+    if ((T_) + 1 < nk) { TN_DMA(2, (T_) + 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }                           \
+    else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                                                             \
+    TN_RD_A(0)                                                                                                            \
+    TN_SYNC_IN() TN_TIE_A() TN_TIE_B(X)                                                                                   \
+    TN_MFMA(0, 0, X, true)                                                                                                \
+    if ((T_) + 1 < nk) TN_DMA(3, (T_) + 1)                                                                                \
+    TN_RD_B(Y, 1, 0)                                                                                                      \
+    TN_SYNC_IN() TN_TIE_B(Y)                                                                                              \
+    TN_MFMA(0, 1, Y, false)                                                                                               \
+    if ((T_) + 2 < nk) { TN_DMA(0, (T_) + 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }                           \
+    else if ((T_) + 1 < nk) { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }                                          \
+    TN_RD_A(1)                                                                                                            \
+    TN_SYNC_IN() TN_TIE_A()                                                                                               \
+    TN_MFMA(1, 1, Y, true)                                                                                                \
+    if ((T_) + 2 < nk) TN_DMA(1, (T_) + 2)                                                                                \
+    if ((T_) + 1 < nk) { TN_RD_B(Y, 0, 0x8000) }                                                                          \
+    TN_SYNC_IN() TN_TIE_B(Y)                                                                                              \
+    TN_MFMA(1, 0, X, false)                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) { aaddr[u] ^= 0x8000; baddr[u] ^= 0x8000; }
+
+    if (nk > 0) {
+        TN_DMA(0, 0) TN_DMA(1, 0) TN_DMA(2, 0) TN_DMA(3, 0)
+        if (nk > 1) { TN_DMA(0, 1) TN_DMA(1, 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();   // second wave row: half a phase behind
+    if (nk > 0) { TN_RD_B(0, 0, 0) }
+    int it = 0;
+    for (; it + 1 < nk; it += 2) {
+        TN_TILE(it, 0, 1)
+        TN_TILE(it + 1, 1, 0)
+    }
+    if (it < nk) { TN_TILE(it, 0, 1) }
+    if (wm == 0) __builtin_amdgcn_s_barrier();   // pairs with the last barrier of waves 4-7
+#undef TN_DMA
+#undef TN_RD_A
+#undef TN_RD_B
+#undef TN_TIE_A
+#undef TN_TIE_B
+#undef TN_SYNC_IN
+#undef TN_MFMA
+#undef TN_TILE
     if (do_bias) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -889,7 +937,7 @@ __global__ __launch_bounds__(512) void gemm_tn_dw_kernel(const TnArgs g) {
             if (lane < 16) unsafeAtomicAdd(&g.dbias[m0 + wm * 128 + (2 * wn + e) * 16 + lane], c);
         }
     }
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();    // both wave rows are past their last operand read: LDS becomes the per-wave staging area
     // Split-K partial sums.  With a workspace: plain coalesced stores of the tile into ws[split] (a reduce pass adds the splits
     // into dW) -- one workgroup per CU cannot hide 64 Ki device-scope atomics behind anything (measured ~150-200 us per GEMM,
     // as long as the whole K loop).  Without: atomics straight into dW.
@@ -901,14 +949,14 @@ __global__ __launch_bounds__(512) void gemm_tn_dw_kernel(const TnArgs g) {
         pp_stage32(wl, acc, pass, l15, lq);
         __builtin_amdgcn_wave_barrier();
         if (g.ws != nullptr) {
-            float* dstp = g.ws + ((size_t)blockIdx.y * g.M + mb + pass * 64) * g.N + nb + (lane & 15) * 4;
+            float* dstp = g.ws + ((size_t)split * g.M + mb + pass * 64) * g.N + nb + (lane & 15) * 4;
 #pragma unroll
-            for (int rb = 0; rb < 16; rb += 8) {
+            for (int rb2 = 0; rb2 < 16; rb2 += 8) {
                 float4 v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(wl + ((rb + u) * 4 + (lane >> 4)) * V3_RS32 + (lane & 15) * 16);
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(wl + ((rb2 + u) * 4 + (lane >> 4)) * V3_RS32 + (lane & 15) * 16);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v3_st<float4>(dstp + (size_t)((rb + u) * 4 + (lane >> 4)) * g.N, v[u]);
+                for (int u = 0; u < 8; ++u) v3_st<float4>(dstp + (size_t)((rb2 + u) * 4 + (lane >> 4)) * g.N, v[u]);
             }
         } else {
 #pragma unroll 8
@@ -919,7 +967,6 @@ __global__ __launch_bounds__(512) void gemm_tn_dw_kernel(const TnArgs g) {
         }
         __builtin_amdgcn_wave_barrier();
     }
-#undef TN_DMA
 }
 
 // dW[m, n] += sum_s ws[s][m][n]
@@ -951,12 +998,13 @@ extern "C" int sed_gemm_dw_tn(const void* dY, const void* X, int x_f16, int T, i
     // one workgroup per CU and ONE round: tiles * ks <= 256 (rounding the split count up instead costs a second, nearly empty
     // round -- 36 tiles x 8 splits = 288 workgroups took twice the time of 36 x 7)
     int ks = 256 / tiles;
+    if (ks >= 8) ks &= ~7;        // whole splits per XCD (the kernel lays the splits out XCD-contiguously)
     if (ks > ktiles / 16) ks = ktiles / 16;
     if (ks < 1) ks = 1;
     g.ksplit = ks;
     g.ws = (workspace != nullptr && workspace_bytes >= (int64_t)ks * M * N * 4) ? workspace : nullptr;
     static bool attr[2] = {false, false};
-    dim3 grid(tiles, ks);
+    dim3 grid(tiles * ks);
     if (x_f16) {
         if (!attr[1]) { (void)hipFuncSetAttribute((const void*)gemm_tn_dw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr[1] = true; }
         hipLaunchKernelGGL((gemm_tn_dw_kernel<false>), grid, dim3(512), V3_LDS, stream, g);
