@@ -84,8 +84,9 @@ int sed_small_linear_bwd(const float* a, const float* w, const float* out, const
                          float* db, int M, int N, int K, int act, hipStream_t stream);
 
 /* ------------------------------------------------------------------ attention */
-/* encoder MHSA (src/models/passt/passt.py:335-341), flash style; O [B,N,768] bf16, LSE [B*H,N] (log2 domain) */
-int sed_mhsa_fwd(const void* Q, const void* K, const void* Vt, void* O, float* LSE, int B, int H, int N, int Npad,
+/* encoder MHSA (src/models/passt/passt.py:335-341), flash style; Q, K, V head-split [B*H, N, 64] 16-bit (V row-major: the kernel takes
+   V^T out of its LDS tile with transposing reads); O [B,N,768] 16-bit, LSE [B*H,N] (log2 domain) */
+int sed_mhsa_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int Npad,
                  int f16, hipStream_t stream);
 int sed_mhsa_bwd_prep(const void* dO, const void* O, float* Dtmp, void* dOh, void* dOt, int B, int H, int N, int Npad,
                       int o_f16, hipStream_t stream);

@@ -238,7 +238,7 @@ def test_mhsa_fwd_bwd(B, N, DT):
     q, k, v, qt, kt, vt, Npad = _split(B, N, 20, scale=1.3, dt=DT)
     O = torch.empty(B, N, 768, dtype=DT, device=DEV)
     lse = torch.empty(B * Hh, N, device=DEV)
-    call("sed_mhsa_fwd", q.to(DT), k.to(DT), vt, O, lse, B, Hh, N, Npad, f16)
+    call("sed_mhsa_fwd", q.to(DT), k.to(DT), v.to(DT), O, lse, B, Hh, N, Npad, f16)    # V row-major: transposed inside the kernel
     qq, kk, vv = [t.clone().requires_grad_(True) for t in (q, k, v)]
     s = (qq @ kk.transpose(1, 2)) * 0.125
     p = torch.softmax(s, dim=-1)

@@ -10,11 +10,10 @@ for name, B, H, N in (("global 1190", 32, 12, 1190), ("window 602", 352, 12, 602
     Npad = (N + 63) // 64 * 64
     q = (torch.randn(B * H, N, 64, device=dev) * 0.5).half()
     k = (torch.randn(B * H, N, 64, device=dev) * 0.5).half()
-    vt = torch.zeros(B * H, 64, Npad, device=dev, dtype=torch.half)
-    vt[:, :, :N] = torch.randn(B * H, 64, N, device=dev).half()
+    v = torch.randn(B * H, N, 64, device=dev).half()
     o = torch.empty(B, N, H * 64, device=dev, dtype=torch.half)
     lse = torch.empty(B * H, N, device=dev)
-    f = lambda: call("sed_mhsa_fwd", q, k, vt, o, lse, B, H, N, Npad, 1)
+    f = lambda: call("sed_mhsa_fwd", q, k, v, o, lse, B, H, N, Npad, 1)
     f(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

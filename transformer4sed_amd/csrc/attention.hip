@@ -5,11 +5,12 @@
 // (1190 tokens for the global pass, 602 for the 512-frame windows).
 //
 // Inputs come head-split from the qkv GEMM epilogue (gemm.hip, EPI_QKV):
-//   Q, K, V : [B*H, N, 64] bf16,   Qt, Kt, Vt : [B*H, 64, Npad] bf16 (zero padded to a multiple of 64)
+//   Q, K, V : [B*H, N, 64] 16-bit,   Qt, Kt : [B*H, 64, Npad] (zero padded to a multiple of 64; backward only)
 //
 // Forward ("swapped" form so that a lane owns one query column of every accumulator):
 //   S^T[key, q] = K . Q^T   -> online softmax along registers (+1 cross-half shuffle) ->
-//   O^T[d, q]  += V^T[d, key] . P^T[key, q]     with P^T taken straight from the S^T accumulator registers
+//   O^T[d, q]  += V^T[d, key] . P^T[key, q]     with P^T taken straight from the S^T accumulator registers and the V^T fragments
+//   read out of the ROW-major V tile with ds_read_b64_tr_b16 (no transposed copy of V in HBM)
 //   (the MFMA k-index permutation is chosen to match the accumulator row pattern, so no cross-lane traffic).
 // 4 waves x 32 queries per workgroup, 64-key tiles, K and V^T tiles double buffered in XOR-swizzled LDS,
 // next tile's global loads in flight during the MFMA phase.
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     const int q0 = q_begin + blockIdx.x * (128 * NQ) + wave * (32 * NQ);
     const bf16_t* Qb = Q + (size_t)bh * N * HD;
     const bf16_t* Kb = K + (size_t)bh * N * HD;
-    const bf16_t* Vtb = Vt + (size_t)bh * HD * Npad;
+    const bf16_t* Vb = Vt + (size_t)bh * N * HD;      // V row-major [N][64]: its transpose is taken by the LDS reads
 
     s16x8_t qf[NQ][4];
 #pragma unroll
@@ -106,9 +107,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     const int ntiles = (N + KVB - 1) / KVB;
     TileRegs rk, rv;
     tile_gload(rk, Kb, 0, N, HD, 0, tid);
-    tile_gload(rv, Vtb, 0, HD, Npad, 0, tid);
+    tile_gload(rv, Vb, 0, N, HD, 0, tid);
     tile_lstore_rows(rk, lds[0][0], tid);
-    tile_lstore_cols(rv, lds[0][1], tid);
+    tile_lstore_vrows(rv, lds[0][1], tid);
 #pragma unroll
     for (int u = 0; u < NQ; ++u) pin_frags(qf[u]);
     __syncthreads();
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         const int buf = t & 1, j0 = t * KVB;
         if (t + 1 < ntiles) {
             tile_gload(rk, Kb, j0 + KVB, N, HD, 0, tid);
-            tile_gload(rv, Vtb, 0, HD, Npad, j0 + KVB, tid);
+            tile_gload(rv, Vb, j0 + KVB, N, HD, 0, tid);
         }
         const unsigned char* lk = lds[buf][0];
         const unsigned char* lv = lds[buf][1];
@@ -146,14 +147,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 for (int u = 0; u < NQ; ++u) pf[u] = pack_frag_t<F16>(st[u][kb], s);
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    const s16x8_t vfr = lds_frag_cols(lv, 32 * db + lr, 8 * kb + 4 * s + lg);
+                    const s16x8_t vfr = lds_frag_vt(lv, db, 8 * kb + 4 * s + lg, lane);
 #pragma unroll
                     for (int u = 0; u < NQ; ++u) o[u][db] = mfma32t<F16>(vfr, pf[u], o[u][db]);
                 }
             }
         if (t + 1 < ntiles) {
             tile_lstore_rows(rk, lds[buf ^ 1][0], tid);
-            tile_lstore_cols(rv, lds[buf ^ 1][1], tid);
+            tile_lstore_vrows(rv, lds[buf ^ 1][1], tid);
         }
         __syncthreads();
     }
@@ -177,137 +178,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     }
 }
 
-// Software-pipelined forward: the K . Q^T MFMAs of tile t+1 are issued BEFORE the softmax of tile t, so within one wave the
-// matrix pipe works under the VALU-bound softmax (a wave issues in order: without this the MFMA pipe idles during every softmax
-// and the VALU idles during every MFMA burst unless another wave happens to be in the opposite phase).  K therefore runs one
-// tile ahead of V^T in LDS: iteration t reads K(t+1) and V^T(t), and stages K(t+2) and V^T(t+1).  +32 VGPRs (second S tile).
-#ifndef MHSA_PIPE_WPE
-#define MHSA_PIPE_WPE 2
-#endif
-template <bool F16>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MHSA_PIPE_WPE, MHSA_PIPE_WPE)))
-void mhsa_fwd_pipe_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
-                          bf16_t* __restrict__ O, float* __restrict__ LSE, int N, int Npad, int H) {
-    __shared__ __attribute__((aligned(16))) unsigned char ldk[2][KVB * 128];
-    __shared__ __attribute__((aligned(16))) unsigned char ldv[2][KVB * 128];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
-    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
-    const int q0 = blockIdx.x * 128 + wave * 32;
-    const bf16_t* Qb = Q + (size_t)bh * N * HD;
-    const bf16_t* Kb = K + (size_t)bh * N * HD;
-    const bf16_t* Vtb = Vt + (size_t)bh * HD * Npad;
-    s16x8_t qf[4];
-    {
-        int qrow = q0 + lr;
-        qrow = qrow < N ? qrow : N - 1;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const s16x8_t*>(Qb + (size_t)qrow * HD + 16 * s + 8 * lg);
-    }
-    f32x16_t o[2];
-    float m_run = -1e30f, l_run = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    const int ntiles = (N + KVB - 1) / KVB;
-    TileRegs rk, rv;
-    tile_gload(rk, Kb, 0, N, HD, 0, tid);
-    tile_gload(rv, Vtb, 0, HD, Npad, 0, tid);
-    tile_lstore_rows(rk, ldk[0], tid);
-    tile_lstore_cols(rv, ldv[0], tid);
-    if (ntiles > 1) {
-        tile_gload(rk, Kb, KVB, N, HD, 0, tid);
-        tile_lstore_rows(rk, ldk[1], tid);
-    }
-    pin_frags(qf);
-    __syncthreads();
-    f32x16_t sc[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) sc[kb] = mfma32t<F16>(lds_frag_rows(ldk[0], 32 * kb + lr, 2 * s + lg), qf[s], s == 0 ? zero16 : sc[kb]);
-
-    // Tiles that have a successor: one straight-line block per tile (no branches, so the scheduler may interleave the S(t+1)
-    // MFMAs with the softmax of S(t)); tile indices past the end are clamped -- the redundant copies land in buffers nobody
-    // reads any more.  None of these tiles is the masked tail.
-    for (int t = 0; t + 1 < ntiles; ++t) {
-        const int tk = (t + 2 < ntiles ? t + 2 : ntiles - 1) * KVB;
-        tile_gload(rk, Kb, tk, N, HD, 0, tid);
-        tile_gload(rv, Vtb, 0, HD, Npad, (t + 1) * KVB, tid);
-        f32x16_t sn[2];
-        const unsigned char* lk = ldk[(t + 1) & 1];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                sn[kb] = mfma32t<F16>(lds_frag_rows(lk, 32 * kb + lr, 2 * s + lg), qf[s], s == 0 ? zero16 : sn[kb]);
-        softmax_tile<false>(sc, o, m_run, l_run, t * KVB, N, lg);
-        const unsigned char* lv = ldv[t & 1];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const s16x8_t pf = pack_frag_t<F16>(sc[kb], s);
-#pragma unroll
-                for (int db = 0; db < 2; ++db) o[db] = mfma32t<F16>(lds_frag_cols(lv, 32 * db + lr, 8 * kb + 4 * s + lg), pf, o[db]);
-            }
-        tile_lstore_rows(rk, ldk[t & 1], tid);        // K(t) was last read during iteration t - 1
-        tile_lstore_cols(rv, ldv[(t + 1) & 1], tid);  // V^T(t - 1) likewise
-        __syncthreads();
-        sc[0] = sn[0];
-        sc[1] = sn[1];
-    }
-    {   // last tile (the only one that can hold keys >= N)
-        const int t = ntiles - 1, j0 = t * KVB;
-        if (j0 + KVB > N) softmax_tile<true>(sc, o, m_run, l_run, j0, N, lg);
-        else softmax_tile<false>(sc, o, m_run, l_run, j0, N, lg);
-        const unsigned char* lv = ldv[t & 1];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const s16x8_t pf = pack_frag_t<F16>(sc[kb], s);
-#pragma unroll
-                for (int db = 0; db < 2; ++db) o[db] = mfma32t<F16>(lds_frag_cols(lv, 32 * db + lr, 8 * kb + 4 * s + lg), pf, o[db]);
-            }
-    }
-    const int q = q0 + lr;
-    if (q < N) {
-        const float inv = 1.0f / l_run;
-        bf16_t* orow = O + ((size_t)b * N + q) * (H * HD) + h * HD;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                uint2 pk;
-                pk.x = pack2<F16>(o[db][4 * qd] * inv, o[db][4 * qd + 1] * inv);
-                pk.y = pack2<F16>(o[db][4 * qd + 2] * inv, o[db][4 * qd + 3] * inv);
-                *reinterpret_cast<uint2*>(orow + 32 * db + 8 * qd + 4 * lg) = pk;
-            }
-        if (lg == 0 && LSE != nullptr) LSE[(size_t)bh * N + q] = m_run + log2f(l_run);  // log2 domain
-    }
-}
-
 template <bool F16>
 static void launch_mhsa_fwd(const void* Q, const void* K, const void* Vt, void* O, float* LSE, int B, int H, int N, int Npad,
                             hipStream_t stream) {
     // NQ = 2 (256-query workgroups) halves LDS traffic per MFMA but drops to one wave per SIMD (202 VGPRs) and measured
     // slower on MI355X (24.9 vs 20.8 ms/step); NQ = 1 (two waves per SIMD) is the shipped configuration.
-#ifdef MHSA_PIPE
-    hipLaunchKernelGGL((mhsa_fwd_pipe_kernel<F16>), dim3(cdiv(N, 128), B * H), dim3(256), 0, stream, (const bf16_t*)Q,
-                       (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, LSE, N, Npad, H);
-#else
     hipLaunchKernelGGL((mhsa_fwd_kernel<F16, 1>), dim3(cdiv(N, 128), B * H), dim3(256), 0, stream, (const bf16_t*)Q,
                        (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, LSE, N, Npad, H, 0);
-#endif
 }
 
-extern "C" int sed_mhsa_fwd(const void* Q, const void* K, const void* Vt, void* O, float* LSE, int B, int H, int N,
+extern "C" int sed_mhsa_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N,
                             int Npad, int f16, hipStream_t stream) {
     (void)hipGetLastError();
     if (N <= 0 || Npad % 64 || Npad < N) return SED_ERR_ARG;
-    if (f16) launch_mhsa_fwd<true>(Q, K, Vt, O, LSE, B, H, N, Npad, stream);
-    else launch_mhsa_fwd<false>(Q, K, Vt, O, LSE, B, H, N, Npad, stream);
+    if (f16) launch_mhsa_fwd<true>(Q, K, V, O, LSE, B, H, N, Npad, stream);
+    else launch_mhsa_fwd<false>(Q, K, V, O, LSE, B, H, N, Npad, stream);
     return sed_check_launch();
 }
 

@@ -24,6 +24,24 @@ __device__ __forceinline__ s16x8_t lds_frag_cols(const unsigned char* base, int 
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
 }
+// Row-major V tile [64 keys][64 d] (128-B rows) read through the transposing LDS load: 16-B chunk c of key row r sits at chunk
+// c ^ (((r >> 1) & 1) << 2), so the four key rows of one read cycle (32 lanes = 4 rows x 64 B) fall on four different bank quarters.
+__device__ __forceinline__ int v_off(int row, int ch16) { return row * 128 + ((ch16 ^ (((row >> 1) & 1) << 2)) << 4); }
+// V^T operand fragment for the 32 d rows of block db and the 8 keys {c..c+3, c+8..c+11}, c = 4 ch8 (the same key pattern as
+// lds_frag_cols: it matches the accumulator rows the P^T operand comes from).  ds_read_b64_tr_b16: the 16 lanes of a group supply the
+// addresses of a [4 key rows][4 x 8 B] block and lane i receives column i -- 4 consecutive keys of d = 16 (group & 1) + i.
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x8_t lds_frag_vt(const unsigned char* base, int db, int ch8, int lane) {
+    const int a = lane & 15, g16 = (lane >> 4) & 1;
+    const int row = 4 * ch8 + (a >> 2);                       // (row >> 1) & 1 == (a >> 3): the key blocks start on multiples of 4
+    const unsigned char* p = base + row * 128 + ((db ^ (a >> 3)) << 6) + g16 * 32 + 8 * (a & 3);
+    const s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)p);
+    const s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)(p + 8 * 128));
+    s16x8_t r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
 template <bool F16>
 __device__ __forceinline__ s16x8_t pack_frag_t(const f32x16_t& p, int s) {  // registers 8s..8s+7 -> 8 x 16-bit
     s16x8_t r;
@@ -51,6 +69,11 @@ __device__ __forceinline__ void tile_lstore_rows(const TileRegs& t, unsigned cha
     const int r = tid >> 3, c = tid & 7;
     *reinterpret_cast<uint4*>(dst + k_off(r, c)) = t.a;
     *reinterpret_cast<uint4*>(dst + k_off(r + 32, c)) = t.b;
+}
+__device__ __forceinline__ void tile_lstore_vrows(const TileRegs& t, unsigned char* dst, int tid) {
+    const int r = tid >> 3, c = tid & 7;
+    *reinterpret_cast<uint4*>(dst + v_off(r, c)) = t.a;
+    *reinterpret_cast<uint4*>(dst + v_off(r + 32, c)) = t.b;
 }
 __device__ __forceinline__ void tile_lstore_cols(const TileRegs& t, unsigned char* dst, int tid) {
     const int r = tid >> 3, c = tid & 7;

@@ -517,7 +517,8 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
             // Tensors that only the bf16 backward reads (row-major V; Q^T, K^T, (q+v)^T) are emitted as bf16 when g.bwd_bf16 is
             // set: converted from the staged f16 tile on the way out (same double rounding as a later in-place conversion,
             // without the extra pass over HBM); V^T and the row-major q / k stay f16.
-            const bool row_bf = F16 && g.bwd_bf16 && which == 2 && pass == 0;
+            // (a row-major V that the forward itself consumes -- no V^T requested: the encoder's attention transposes it in LDS -- stays f16)
+            const bool row_bf = F16 && g.bwd_bf16 && which == 2 && pass == 0 && g.vt != nullptr;
             const bool tr_bf = F16 && g.bwd_bf16 && !(which == 2 && pass == 0);
             __builtin_amdgcn_wave_barrier();
             if (rd != nullptr) {  // (the row-major V is only needed by the backward: inference passes v = NULL)

@@ -212,9 +212,10 @@ class SedEngine:
         # tensors that only the backward reads (row-major V, Q^T, K^T, GELU pre-activation) are produced as bf16 right away
         B16 = BF16 if save else A16
         qkv_flag = 3 if (save and f16) else f16
-        mk_qkv = lambda: [E(Bx * H, N, 64, dt=A16), E(Bx * H, N, 64, dt=A16), E(Bx * H, N, 64, dt=B16)]
+        # V stays f16 and row-major: the attention forward takes its transpose in LDS (ds_read_b64_tr_b16), the backward converts it in place
+        mk_qkv = lambda: [E(Bx * H, N, 64, dt=A16), E(Bx * H, N, 64, dt=A16), E(Bx * H, N, 64, dt=A16)]
         use_pool = getattr(self, "_lease_ok", False) or not save
-        mk_t = lambda li: [self._zeros(("enc", li, j, Bx, Npad), (Bx * H, 64, Npad), B16 if j < 2 else A16, dev, use_pool) for j in range(3)]
+        mk_t = lambda li: [self._zeros(("enc", li, j, Bx, Npad), (Bx * H, 64, Npad), B16, dev, use_pool) for j in range(2)]
         scratch = None
         pooled = None
         for li in range(m.depth):
@@ -223,23 +224,23 @@ class SedEngine:
             if save or scratch is None:
                 h16 = E(M, D, dt=A16)
                 q, k, v = mk_qkv()
-                qt, kt, vt = mk_t(li) if save else (None, None, self._zeros(("enc_vt", Bx, Npad), (Bx * H, 64, Npad), A16, dev))
+                qt, kt = mk_t(li) if save else (None, None)
                 o16 = E(M, D, dt=A16)
                 lse = E(Bx * H, N)
                 h2 = E(M, D, dt=A16)
                 hpre = E(M, 4 * D, dt=B16)
                 act = E(M, 4 * D, dt=A16)
                 mean1, rstd1, mean2, rstd2 = (E(M), E(M), E(M), E(M)) if save else (None, None, None, None)
-                scratch = (h16, q, k, v, qt, kt, vt, o16, lse, h2, hpre, act)
+                scratch = (h16, q, k, v, qt, kt, o16, lse, h2, hpre, act)
             else:
-                h16, q, k, v, qt, kt, vt, o16, lse, h2, hpre, act = scratch
+                h16, q, k, v, qt, kt, o16, lse, h2, hpre, act = scratch
                 mean1 = rstd1 = mean2 = rstd2 = None
             x_in = x
             call("sed_layernorm_fwd", x_in, self.P(p + "norm1.weight"), self.P(p + "norm1.bias"), 1e-6, 1.0, h16, None,
                  mean1, rstd1, M, D, f16)
             call("sed_gemm_qkv", h16, W[p + "attn.qkv.weight"].w, self.P(p + "attn.qkv.bias"), M, D, H, N, Npad, q, k,
-                 v if save else None, qt, kt, vt, None, None, None, None, qkv_flag)  # row-major V is a backward-only operand
-            call("sed_mhsa_fwd", q, k, vt, o16, lse, Bx, H, N, Npad, f16)
+                 v, qt, kt, None, None, None, None, None, qkv_flag)
+            call("sed_mhsa_fwd", q, k, v, o16, lse, Bx, H, N, Npad, f16)
             x_mid = E(Bx, N, D) if save else x_in
             gemm_nt(o16, W[p + "attn.proj.weight"].w, EPI_F32_RESID, bias=self.P(p + "attn.proj.bias"), res=x_in,
                     outF=x_mid)
