@@ -407,8 +407,14 @@ __device__ __forceinline__ void v3_side_load(V3Side<EPI>& sd, const GemmArgs& g,
         for (int u = 0; u < 8; ++u) {
             const int m = m0 + u * 4 + (lane >> 4);
             const size_t o = (size_t)(m < g.M ? m : g.M - 1) * g.ldc + n;
-            if constexpr (EPI == EPI_F32_RESID) sd.r[u] = *reinterpret_cast<const float4*>(g.resF + o);
-            else sd.a[u] = *reinterpret_cast<const uint2*>(g.auxH + o);
+            // read-once side inputs: non-temporal, like the tile stores
+            if constexpr (EPI == EPI_F32_RESID) {
+                const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(g.resF + o));
+                sd.r[u] = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                const u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(g.auxH + o));
+                sd.a[u] = make_uint2(v[0], v[1]);
+            }
         }
     }
 }
