@@ -160,7 +160,8 @@ def cpu_baseline(depth, batch=4, budget_s=330):
     (train-mode frontend, full augmentation, student fwd+bwd, 11-window teacher fwd, losses, AdamW, EMA) at batch `batch`,
     one warm-up step then the median of three timed steps on the same inputs."""
     import subprocess
-    cores = os.cpu_count() or 1
+    from transformer4sed_amd.hostcpu import usable_cpus
+    cores = usable_cpus()           # affinity mask and cgroup CPU quota: more threads than that only buys throttling
     threads = min(cores, 64)
     cmd = [sys.executable, "-m", "oracle.cpu_step", str(batch), str(depth), str(threads), json.dumps(FINETUNE2)]
     env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))

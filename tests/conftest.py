@@ -9,8 +9,16 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The test processes also run the CPU oracle (torch fp32): give it every CPU the container may really use (affinity / cgroup quota)
+# instead of the product's host-thread cap (transformer4sed_amd/hostcpu.py) or torch's default of half the visible cores.
+os.environ.setdefault("SED_HOST_THREADS", "0")
+
 
 def pytest_configure(config):
+    import torch
+    from transformer4sed_amd.hostcpu import usable_cpus
+    if "OMP_NUM_THREADS" not in os.environ:
+        torch.set_num_threads(min(torch.get_num_threads(), usable_cpus()))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
