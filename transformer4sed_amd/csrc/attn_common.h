@@ -44,10 +44,9 @@ __device__ __forceinline__ s16x8_t lds_frag_vt(const unsigned char* base, int db
 }
 template <bool F16>
 __device__ __forceinline__ s16x8_t pack_frag_t(const f32x16_t& p, int s) {  // registers 8s..8s+7 -> 8 x 16-bit
-    s16x8_t r;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] = (short)to_16<F16>(p[8 * s + e]);
-    return r;
+    const uint4 r = make_uint4(pack2<F16>(p[8 * s], p[8 * s + 1]), pack2<F16>(p[8 * s + 2], p[8 * s + 3]),
+                               pack2<F16>(p[8 * s + 4], p[8 * s + 5]), pack2<F16>(p[8 * s + 6], p[8 * s + 7]));
+    return __builtin_bit_cast(s16x8_t, r);
 }
 __device__ __forceinline__ s16x8_t pack_frag(const f32x16_t& p, int s) { return pack_frag_t<false>(p, s); }
 

@@ -15,12 +15,20 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even (inputs are finite here)
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// fp32 -> 16-bit conversions on the gfx950 packed converters (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, round-to-nearest-even): one VALU
+// instruction per PAIR instead of the 4-instruction integer rounding sequence per element
+typedef __attribute__((ext_vector_type(2))) float f32x2v_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2v_t;
+__device__ __forceinline__ unsigned pack2bf(float a, float b) {
+    const f32x2v_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v_t));
 }
-__device__ __forceinline__ unsigned pack2bf(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+__device__ __forceinline__ unsigned pack2h(float a, float b) {
+    const f32x2v_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2v_t));
+}
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 __device__ __forceinline__ float h2f(bf16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
@@ -29,9 +37,7 @@ __device__ __forceinline__ bf16_t f2h(float f) { return __builtin_bit_cast(bf16_
 // the frame posteriors within 1e-3 of the fp32 reference), otherwise bf16 (gradient operands: fp32 exponent range).
 template <bool F16> __device__ __forceinline__ float to_f32(bf16_t h) { return F16 ? h2f(h) : bf2f(h); }
 template <bool F16> __device__ __forceinline__ bf16_t to_16(float f) { return F16 ? f2h(f) : f2bf(f); }
-template <bool F16> __device__ __forceinline__ unsigned pack2(float a, float b) {
-    return (unsigned)to_16<F16>(a) | ((unsigned)to_16<F16>(b) << 16);
-}
+template <bool F16> __device__ __forceinline__ unsigned pack2(float a, float b) { return F16 ? pack2h(a, b) : pack2bf(a, b); }
 template <bool F16> __device__ __forceinline__ f32x16_t mfma32t(s16x8_t a, s16x8_t b, f32x16_t c) {
     if (F16)
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);

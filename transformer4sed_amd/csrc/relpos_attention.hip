@@ -391,6 +391,11 @@ __global__ __launch_bounds__(256) void relpos_bwd_dkdv_kernel(
 // backward kernel 2: dQ (= dQu + dQv), per-head sums for pos_bias_u / pos_bias_v, and dS^T for the dP kernel.
 // workgroup = 128 queries; loops over 64-key tiles; lane owns a query column (as in forward).
 // ---------------------------------------------------------------------------------------------------
+#ifdef RPX_NOBAR
+#define RPX_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+#else
+#define RPX_SYNC() __syncthreads()
+#endif
 template <bool SF16>
 __global__ __launch_bounds__(256) void relpos_bwd_dq_kernel(
     const bf16_t* __restrict__ Qu, const bf16_t* __restrict__ Qv, const bf16_t* __restrict__ K,
@@ -471,7 +476,7 @@ __global__ __launch_bounds__(256) void relpos_bwd_dq_kernel(
                 dp[kb] = mfma32(lds_frag_rows(lds[1], 32 * kb + lr, 2 * s + lg), dof[s], s == 0 ? zero16 : dp[kb]);
             }
         }
-        __syncthreads();
+        RPX_SYNC();
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(256) void relpos_bwd_dq_kernel(
                 p = (qvalid && (j0 + jj < T)) ? p : 0.f;
                 dp[kb][r] = p * (dp[kb][r] - dd);  // dS^T[key, q]
             }
-        __syncthreads();  // everyone has read G^T before it is overwritten with dG^T
+        RPX_SYNC();  // everyone has read G^T before it is overwritten with dG^T
         // dS^T -> global (for the dP kernel) and -> skewed LDS image dG^T[rho, q]
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -489,7 +494,9 @@ __global__ __launch_bounds__(256) void relpos_bwd_dq_kernel(
             for (int r = 0; r < 16; ++r) {
                 const int jj = 32 * kb + mfma32_row(r, lg);
                 gs[(jj - lr + 31) * 32 + lr] = dp[kb][r];
+                #ifndef RPX_NOSTORE
                 if (qvalid && (j0 + jj < T)) dSt[((size_t)bh * Tpad + j0 + jj) * Tpad + q0 + lr] = f2bf(dp[kb][r]);
+#endif
             }
         // dQu^T[d, q] += K^T[d, key] dS^T[key, q]
 #pragma unroll
@@ -501,7 +508,7 @@ __global__ __launch_bounds__(256) void relpos_bwd_dq_kernel(
                 for (int db = 0; db < 2; ++db)
                     dqu[db] = mfma32(lds_frag_cols(lds[2], 32 * db + lr, 8 * kb + 4 * s + lg), dsf, dqu[db]);
             }
-        __syncthreads();
+        RPX_SYNC();
         // dQv^T[d, q] += P_band^T[d, rho] dG^T[rho, q]   (rho = 16 s + 8 g + e, natural k order)
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
