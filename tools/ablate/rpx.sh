@@ -1,5 +1,4 @@
 mkdir -p gpurun_out/r2; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d gpurun_out/r2/rpx_pmc1 -o p -- python tools/relpos_bench.py > gpurun_out/r2/rpx_pmc1.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_MFMA --kernel-trace --output-format csv -d gpurun_out/r2/rpx_pmc2 -o p -- python tools/relpos_bench.py > gpurun_out/r2/rpx_pmc2.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/r2/rpx_pmc3 -o p -- python tools/relpos_bench.py > gpurun_out/r2/rpx_pmc3.log 2>&1
-ls gpurun_out/r2/rpx_pmc*
+python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "relpos or rel_pos or decoder or xl" 2>&1 | grep -E "passed|failed|Error|error" | tail -5
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2/rpx_new -o p -- python tools/relpos_bench.py > /dev/null 2>&1
+rm -f gpurun_out/r2/rpx_new/p_kernel_trace.csv

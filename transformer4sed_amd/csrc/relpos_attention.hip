@@ -391,11 +391,6 @@ __global__ __launch_bounds__(256) void relpos_bwd_dkdv_kernel(
 // backward kernel 2: dQ (= dQu + dQv), per-head sums for pos_bias_u / pos_bias_v, and dS^T for the dP kernel.
 // workgroup = 128 queries; loops over 64-key tiles; lane owns a query column (as in forward).
 // ---------------------------------------------------------------------------------------------------
-#ifdef RPX_NOBAR
-#define RPX_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
-#else
-#define RPX_SYNC() __syncthreads()
-#endif
 template <bool SF16>
 __global__ __launch_bounds__(256) void relpos_bwd_dq_kernel(
     const bf16_t* __restrict__ Qu, const bf16_t* __restrict__ Qv, const bf16_t* __restrict__ K,
@@ -424,7 +419,7 @@ __global__ __launch_bounds__(256) void relpos_bwd_dq_kernel(
         qvf[s] = *reinterpret_cast<const s16x8_t*>(Qv + hb + (size_t)qrow * HD + 16 * s + 8 * lg);
         dof[s] = *reinterpret_cast<const s16x8_t*>(dOh + hb + (size_t)qrow * HD + 16 * s + 8 * lg);
     }
-    const float l2 = LSE[(size_t)bh * T + qrow], dd = Dv[(size_t)bh * T + qrow];
+    const float l2 = qvalid ? LSE[(size_t)bh * T + qrow] : __builtin_inff(), dd = Dv[(size_t)bh * T + qrow];
     f32x16_t dqu[2], dqv[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -476,28 +471,38 @@ __global__ __launch_bounds__(256) void relpos_bwd_dq_kernel(
                 dp[kb] = mfma32(lds_frag_rows(lds[1], 32 * kb + lr, 2 * s + lg), dof[s], s == 0 ? zero16 : dp[kb]);
             }
         }
-        RPX_SYNC();
+        __syncthreads();
+        // all 32 skewed reads are issued before the first use (a load inside a conditional expression is compiled into a branch
+        // with its own s_waitcnt: 32 serialised LDS round trips per tile)
+        float gv[2][16];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gv[kb][r] = gs[(32 * kb + mfma32_row(r, lg) - lr + 31) * 32 + lr];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int jj = 32 * kb + mfma32_row(r, lg);
-                float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r] + gs[(jj - lr + 31) * 32 + lr], SCALE_LOG2E, -l2));
-                p = (qvalid && (j0 + jj < T)) ? p : 0.f;
+                float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r] + gv[kb][r], SCALE_LOG2E, -l2));  // invalid query: l2 = +inf
+                if (j0 + KVB > T) p = (j0 + 32 * kb + mfma32_row(r, lg) < T) ? p : 0.f;                      // last tile only
                 dp[kb][r] = p * (dp[kb][r] - dd);  // dS^T[key, q]
             }
-        RPX_SYNC();  // everyone has read G^T before it is overwritten with dG^T
-        // dS^T -> global (for the dP kernel) and -> skewed LDS image dG^T[rho, q]
+        // dS^T -> global (for the dP kernel; rows / columns up to Tpad exist, the values there are exact zeros) and -> skewed LDS
+        // image dG^T[rho, q] (wave-private buffer: the wave's own reads above have completed)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int jj = 32 * kb + mfma32_row(r, lg);
                 gs[(jj - lr + 31) * 32 + lr] = dp[kb][r];
-                #ifndef RPX_NOSTORE
-                if (qvalid && (j0 + jj < T)) dSt[((size_t)bh * Tpad + j0 + jj) * Tpad + q0 + lr] = f2bf(dp[kb][r]);
-#endif
             }
+        if (q0 + lr < Tpad) {   // one lane predicate around all 32 stores (the query blocks of 128 can overhang Tpad, a multiple of 64)
+            bf16_t* dcol = dSt + ((size_t)bh * Tpad + j0) * Tpad + q0 + lr;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dcol[(size_t)(32 * kb + mfma32_row(r, lg)) * Tpad] = f2bf(dp[kb][r]);
+        }
         // dQu^T[d, q] += K^T[d, key] dS^T[key, q]
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -508,17 +513,20 @@ __global__ __launch_bounds__(256) void relpos_bwd_dq_kernel(
                 for (int db = 0; db < 2; ++db)
                     dqu[db] = mfma32(lds_frag_cols(lds[2], 32 * db + lr, 8 * kb + 4 * s + lg), dsf, dqu[db]);
             }
-        RPX_SYNC();
+        __syncthreads();
         // dQv^T[d, q] += P_band^T[d, rho] dG^T[rho, q]   (rho = 16 s + 8 g + e, natural k order)
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
-            s16x8_t gf;
+            float ge[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ge[e] = gs[(16 * s + 8 * lg + e) * 32 + lr];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int rho = 16 * s + 8 * lg + e, jj = rho + lr - 31;
-                const float v = (jj >= 0 && jj < 64) ? gs[rho * 32 + lr] : 0.f;
-                gf[e] = (short)f2bf(v);
+                const int jj = 16 * s + 8 * lg + e + lr - 31;
+                ge[e] = (jj >= 0 && jj < 64) ? ge[e] : 0.f;
             }
+            const uint4 gp = make_uint4(pack2bf(ge[0], ge[1]), pack2bf(ge[2], ge[3]), pack2bf(ge[4], ge[5]), pack2bf(ge[6], ge[7]));
+            const s16x8_t gf = __builtin_bit_cast(s16x8_t, gp);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 const int row = 32 * db + lr, ch = (band_row0 >> 3) + 2 * s + lg;
