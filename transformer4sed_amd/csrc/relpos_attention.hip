@@ -12,6 +12,7 @@
 //   Qu = q+u, Qv = q+v : [B*H, T, 64]      K, V : [B*H, T, 64]       Kt, Vt, Qut, Qvt : [B*H, 64, Tpad]
 //   P  = linear_pos(pos_emb) head-split : [H, Rpad, 64],   Pt : [H, 64, Rpad]      (R = 2T-1 rows, Rpad % 64 == 0)
 // Requires T % 8 == 0 (band columns of Pt are then 16-byte aligned); T = 1000 in MAT-SED.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/sed_hip.h"
 
@@ -575,6 +576,250 @@ __global__ __launch_bounds__(256) void relpos_bwd_dq_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
+// backward kernel 2, second generation: the same outputs on v_mfma_f32_16x16x32 with 8 waves (2 per SIMD) per workgroup.
+//   workgroup = 128 queries, wave = 16 queries x 64-key tiles, lane = (query column c = lane & 15, row group g = lane >> 4).
+//   ~130 VGPRs per wave instead of 441 (the first generation ran one wave per SIMD and had to park its register prefetch in AGPRs
+//   behind an s_waitcnt vmcnt(0) right after issuing it), and the positional band never passes through registers:
+//     * P rows (score recompute, S type) live in a 256-row LDS ring, P^T columns (bf16, dQv) in four 64-column panels; the 64 new
+//       rows / columns a tile needs are DMA'd (buffer_load ... lds) into the slot the previous tile retired, one 1-KiB piece per wave
+//     * K rows, V rows and K^T (64 d x 64 keys) are single-buffered and prefetched through 12 VGPRs per lane
+//     * wave-private LDS: G^T [80 rho][16 q] fp32 for the skew, dG^T [16 q][96 rho] bf16 (zero outside the band, set once)
+//   k-slot order of the dQu contraction: lane group g owns keys {32 ks + 4 g + e} and {32 ks + 16 + 4 g + e}, e < 4 -- exactly the
+//   accumulator rows the lane already holds for the two 16-key blocks, so dS^T goes from accumulators to the B operand without
+//   leaving the lane; the A operand reads K^T with the same slot order (two 8-byte reads).
+// ---------------------------------------------------------------------------------------------------
+template <bool F16> __device__ __forceinline__ f32x4_t mfma16x(s16x8_t a, s16x8_t b, f32x4_t c) {
+    if (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+typedef __attribute__((address_space(3))) void* rp_lds_ptr_t;
+#define zero4 (f32x4_t{0.f, 0.f, 0.f, 0.f})
+
+#define DQ16_LDS (24576 + 65536 + 65536)
+template <bool SF16>
+__global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
+    const bf16_t* __restrict__ Qu, const bf16_t* __restrict__ Qv, const bf16_t* __restrict__ K,
+    const bf16_t* __restrict__ Kt, const bf16_t* __restrict__ V, const bf16_t* __restrict__ P,
+    const bf16_t* __restrict__ Pt, const bf16_t* __restrict__ dOh, const float* __restrict__ LSE,
+    const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, bf16_t* __restrict__ dSt, float* __restrict__ du,
+    float* __restrict__ dvb, int T, int Tpad, int H, int Rpad) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds_dq[];
+    unsigned char (*lds_kv)[KVB * 128] = reinterpret_cast<unsigned char (*)[KVB * 128]>(lds_dq);                    // K rows, V rows, K^T rows (d)
+    unsigned char* lds_band = lds_dq + 3 * KVB * 128;                                                               // ring of P rows, slot = n & 255
+    unsigned char (*lds_bandT)[64 * 128] = reinterpret_cast<unsigned char (*)[64 * 128]>(lds_dq + 24576 + 32768);  // P^T panels [64 d][64 rho]
+    unsigned char (*lds_w)[8192] = reinterpret_cast<unsigned char (*)[8192]>(lds_dq + 24576 + 65536);              // per wave: G^T fp32 + dG^T bf16
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int I0 = blockIdx.x * 128, q0 = I0 + wave * 16;
+    const int R = 2 * T - 1;
+    const size_t hb = (size_t)bh * T * HD, hbt = (size_t)bh * HD * Tpad;
+    const int RB0 = T - 128 - I0;          // global P row of band index n = 0 (multiple of 8: T % 8 == 0)
+    // rows outside [0, R) of the head's P slab read as zeros, columns of P^T outside the slab likewise (inside it they are finite
+    // and only ever multiply exact zeros of dG^T)
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(P + (size_t)h * Rpad * HD), 0, R * HD * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rpt = __builtin_amdgcn_make_buffer_rsrc((void*)(Pt + (size_t)h * HD * Rpad), 0, HD * Rpad * 2, 0x00020000);
+    const int prow = lane >> 3, pch = lane & 7;
+    // band piece of this wave for band rows n0 .. n0 + 7 (n0 % 8 == 0) and P^T piece for d rows 8 wave .. + 7, columns n0 .. n0 + 63
+    auto dma_band = [&](int n0) {
+        const int slot = (n0 & 255) + prow;
+        const int vo = (RB0 + n0 + prow) * (HD * 2) + ((pch ^ ((slot >> 1) & 7)) << 4);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (rp_lds_ptr_t)(lds_band + (n0 & 255) * 128), 16, vo, 0, 0, 0);
+    };
+    auto dma_bandT = [&](int n0) {
+        const int d = 8 * wave + prow;
+        const int vo = (d * Rpad + RB0 + n0) * 2 + ((pch ^ ((d >> 1) & 7)) << 4);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rpt, (rp_lds_ptr_t)(lds_bandT[(n0 >> 6) & 3] + 8 * wave * 128), 16, vo, 0, 0, 0);
+    };
+    // ---- prologue: the whole ring (256 rows / 4 panels), tile 0 of K / V / K^T, query-side fragments
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        dma_band(64 * i + 8 * wave);
+        dma_bandT(64 * i);
+    }
+    const int trow = tid >> 3, tch = tid & 7;   // this thread's 16-byte chunk of a [64][64] tile
+    uint4 pk, pv, pkt;
+    auto gload = [&](int t) {
+        const int j0 = t * KVB;
+        int kr = j0 + trow;
+        kr = kr < T ? kr : T - 1;
+        pk = *reinterpret_cast<const uint4*>(K + hb + (size_t)kr * HD + tch * 8);
+        pv = *reinterpret_cast<const uint4*>(V + hb + (size_t)kr * HD + tch * 8);
+        pkt = *reinterpret_cast<const uint4*>(Kt + hbt + (size_t)trow * Tpad + j0 + tch * 8);
+    };
+    auto lstore = [&]() {
+        const int off = k_off(trow, tch);
+        *reinterpret_cast<uint4*>(lds_kv[0] + off) = pk;
+        *reinterpret_cast<uint4*>(lds_kv[1] + off) = pv;
+        *reinterpret_cast<uint4*>(lds_kv[2] + off) = pkt;
+    };
+    gload(0);
+    int qrow = q0 + c;
+    const bool qvalid = qrow < T;
+    qrow = qvalid ? qrow : T - 1;
+    s16x8_t quf[2], qvf[2], dof[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        quf[ks] = *reinterpret_cast<const s16x8_t*>(Qu + hb + (size_t)qrow * HD + 32 * ks + 8 * g);
+        qvf[ks] = *reinterpret_cast<const s16x8_t*>(Qv + hb + (size_t)qrow * HD + 32 * ks + 8 * g);
+        dof[ks] = *reinterpret_cast<const s16x8_t*>(dOh + hb + (size_t)qrow * HD + 32 * ks + 8 * g);
+    }
+    const float l2 = qvalid ? LSE[(size_t)bh * T + qrow] : __builtin_inff(), dd = Dv[(size_t)bh * T + qrow];
+    unsigned char* wl = lds_w[wave];
+    float* gs = reinterpret_cast<float*>(wl);                      // G^T [80][16]
+    unsigned char* dgl = wl + 5120;                                // dG^T [16 q][96 rho] bf16
+#pragma unroll
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<uint4*>(dgl + (i * 64 + lane) * 16) = make_uint4(0, 0, 0, 0);
+    lstore();
+    f32x4_t dqu[4], dqv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dqu[i] = zero4; dqv[i] = zero4; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // tell the compiler's waitcnt pass that the prologue loads have arrived (it would otherwise wait for them at their first use
+    // inside the loop, behind -- and therefore also for -- the tile prefetch issued at the top of the iteration)
+    asm volatile("" ::"v"(quf[0]), "v"(quf[1]), "v"(qvf[0]), "v"(qvf[1]), "v"(dof[0]), "v"(dof[1]), "v"(l2), "v"(dd));
+    __syncthreads();
+    const int ntiles = (T + KVB - 1) / KVB;
+    // dS^T slab of this (batch, head): [Tpad keys][Tpad queries] bf16; the 128-query block can overhang Tpad (a multiple of 64)
+    const __amdgpu_buffer_rsrc_t rds = __builtin_amdgcn_make_buffer_rsrc((void*)(dSt + (size_t)bh * Tpad * Tpad), 0, Tpad * Tpad * 2, 0x00020000);
+    const int dvo = (q0 + c < Tpad) ? (4 * g * Tpad + q0 + c) * 2 : 0x7ffffff0;
+    for (int t = 0; t < ntiles; ++t) {
+        const int j0 = t * KVB;
+        const bool more = t + 1 < ntiles;
+        if (more) {   // tile t + 1: band rows / P^T columns n in [64 t + 192, 64 t + 256) replace the slot tile t - 1 retired
+            dma_band(64 * t + 192 + 8 * wave);
+            dma_bandT(64 * t + 192);
+            gload(t + 1);
+        }
+        const int nb = 64 * t + 16 * (7 - wave);    // this wave's band base
+        // ---- G^T[rho, q] = P_band[rho, :] . Qv[q, :]  (5 blocks of 16 rho) -> wave-private LDS
+#pragma unroll
+        for (int blk = 0; blk < 5; ++blk) {
+            const int slot = ((nb + 16 * blk) & 255) + c;
+            const unsigned char* rowp = lds_band + slot * 128;
+            const int sw = (slot >> 1) & 7;
+            f32x4_t gacc = zero4;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                gacc = mfma16x<SF16>(*reinterpret_cast<const s16x8_t*>(rowp + (((4 * ks + g) ^ sw) << 4)), qvf[ks], gacc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gs[(16 * blk + 4 * g + r) * 16 + c] = gacc[r];
+        }
+        // ---- S^T = K Qu^T + skew(G^T) (the skewed band term enters as the accumulator input), dP^T = V dO^T
+        f32x4_t st[4], dp[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[kb][r] = gs[(16 * kb + 4 * g + r - c + 15) * 16 + c];
+        const int swc = (c >> 1) & 7;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const unsigned char* kp = lds_kv[0] + (16 * kb + c) * 128;
+            const unsigned char* vp = lds_kv[1] + (16 * kb + c) * 128;
+            dp[kb] = zero4;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                st[kb] = mfma16x<SF16>(*reinterpret_cast<const s16x8_t*>(kp + (((4 * ks + g) ^ swc) << 4)), quf[ks], st[kb]);
+                dp[kb] = mfma16x<false>(*reinterpret_cast<const s16x8_t*>(vp + (((4 * ks + g) ^ swc) << 4)), dof[ks], dp[kb]);
+            }
+        }
+        // ---- P = exp2(S c - LSE), dS^T = P (dP^T - D)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], SCALE_LOG2E, -l2));   // invalid query: LSE = +inf
+                if (j0 + KVB > T) p = (j0 + 16 * kb + 4 * g + r < T) ? p : 0.f;                  // last tile only
+                dp[kb][r] = p * (dp[kb][r] - dd);
+            }
+        // ---- dS^T -> skewed dG^T image (wave-private) and -> global for the dP kernel
+        {
+            unsigned short* dg16 = reinterpret_cast<unsigned short*>(dgl) + c * 96 + 15 - c + 4 * g;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const unsigned p01 = pack2bf(dp[kb][0], dp[kb][1]), p23 = pack2bf(dp[kb][2], dp[kb][3]);
+                dg16[16 * kb + 0] = (unsigned short)(p01 & 0xffffu);
+                dg16[16 * kb + 1] = (unsigned short)(p01 >> 16);
+                dg16[16 * kb + 2] = (unsigned short)(p23 & 0xffffu);
+                dg16[16 * kb + 3] = (unsigned short)(p23 >> 16);
+                // branch-free: a lane whose query column does not exist in the [Tpad][Tpad] slab stores out of the buffer's bounds
+                const int so = (j0 + 16 * kb) * Tpad * 2;
+                __builtin_amdgcn_raw_buffer_store_b16((short)(p01 & 0xffffu), rds, dvo, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b16((short)(p01 >> 16), rds, dvo, so + Tpad * 2, 0);
+                __builtin_amdgcn_raw_buffer_store_b16((short)(p23 & 0xffffu), rds, dvo, so + Tpad * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b16((short)(p23 >> 16), rds, dvo, so + Tpad * 6, 0);
+            }
+        }
+        // ---- dQu^T[d, q] += K^T[d, key] dS^T[key, q]
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint4 dsu = make_uint4(pack2bf(dp[2 * ks][0], dp[2 * ks][1]), pack2bf(dp[2 * ks][2], dp[2 * ks][3]),
+                                         pack2bf(dp[2 * ks + 1][0], dp[2 * ks + 1][1]), pack2bf(dp[2 * ks + 1][2], dp[2 * ks + 1][3]));
+            const s16x8_t dsf = __builtin_bit_cast(s16x8_t, dsu);
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const unsigned char* rowp = lds_kv[2] + (16 * db + c) * 128;   // (row >> 1) & 7 == swc for every 16-row block
+                const int ch8a = 8 * ks + g, ch8b = 8 * ks + 4 + g;
+                const uint2 lo = *reinterpret_cast<const uint2*>(rowp + ((((ch8a >> 1) ^ swc) << 4) | ((ch8a & 1) << 3)));
+                const uint2 hi = *reinterpret_cast<const uint2*>(rowp + ((((ch8b >> 1) ^ swc) << 4) | ((ch8b & 1) << 3)));
+                const uint4 au = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                dqu[db] = mfma16x<false>(__builtin_bit_cast(s16x8_t, au), dsf, dqu[db]);
+            }
+        }
+        // ---- dQv^T[d, q] += P^T[d, rho] dG^T[rho, q]   (96 rho slots, the last 16 and the cells outside the band are zeros)
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const s16x8_t gf = *reinterpret_cast<const s16x8_t*>(dgl + c * 192 + 64 * ks + 16 * g);
+            const int n = nb + 32 * ks + 8 * g;
+            const unsigned char* pan = lds_bandT[(n >> 6) & 3];
+            const int ch = (n & 63) >> 3;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+                dqv[db] = mfma16x<false>(*reinterpret_cast<const s16x8_t*>(pan + (16 * db + c) * 128 + ((ch ^ swc) << 4)), gf, dqv[db]);
+        }
+        if (more) {
+            __syncthreads();                                   // every wave is done with K / V / K^T of tile t
+            lstore();
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // this wave's band pieces have landed (only the 16 dS^T stores are younger)
+            __syncthreads();
+        }
+    }
+    // ---- outputs: dq rows (lane = query, 4 consecutive d per block) and the pos_bias_u / pos_bias_v column sums
+    if (qvalid) {
+        bf16_t* row = dqkv + ((size_t)b * T + q0 + c) * (3 * H * HD) + h * HD + 4 * g;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            uint2 o;
+            o.x = pack2bf((dqu[db][0] + dqv[db][0]) * SCALE, (dqu[db][1] + dqv[db][1]) * SCALE);
+            o.y = pack2bf((dqu[db][2] + dqv[db][2]) * SCALE, (dqu[db][3] + dqv[db][3]) * SCALE);
+            *reinterpret_cast<uint2*>(row + 16 * db) = o;
+        }
+    }
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float su = dqu[db][r] * SCALE, sv = dqv[db][r] * SCALE;   // invalid queries contributed exact zeros
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                su += __shfl_xor(su, o, 64);
+                sv += __shfl_xor(sv, o, 64);
+            }
+            dqu[db][r] = su; dqv[db][r] = sv;
+        }
+    if (c == 0) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                unsafeAtomicAdd(&du[h * HD + 16 * db + 4 * g + r], dqu[db][r]);
+                unsafeAtomicAdd(&dvb[h * HD + 16 * db + 4 * g + r], dqv[db][r]);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // backward kernel 3: dP[r, h*64 + d] += scale * sum_{b, i} dS_b[i, i + r - (T-1)] * Qv_b[i, d]
 //   grid (Rpad/64, H, Bsplit); each workgroup: one 64-row block of r, loops over its batch slice and all i tiles.
 //   dS^T tile staged with a 33-word row stride so that the diagonal gather is bank-conflict free.
@@ -650,11 +895,17 @@ extern "C" int sed_relpos_attn_bwd(const void* Qu, const void* Qut, const void* 
     int rc = sed_mhsa_bwd_prep(dO, O, Dtmp, dOh, dOt, B, H, T, Tpad, o_kind, stream);
     if (rc) return rc;
     dim3 grid(cdiv(T, 128), B * H);
+    static const bool use_old_dq = getenv("SED_RP_OLD_DQ") != nullptr;   // developer A/B switch
 #define SED_LAUNCH_RP(F)                                                                                               \
     hipLaunchKernelGGL(relpos_bwd_dkdv_kernel<F>, grid, dim3(256), 0, stream, (const bf16_t*)Qu, (const bf16_t*)Qut,   \
                        (const bf16_t*)Qv, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)P, (const bf16_t*)dOh,    \
                        (const bf16_t*)dOt, LSE, Dtmp, (bf16_t*)dqkv, T, Tpad, H, Rpad);                                \
+    if (use_old_dq)                                                                                                    \
     hipLaunchKernelGGL(relpos_bwd_dq_kernel<F>, grid, dim3(256), 0, stream, (const bf16_t*)Qu, (const bf16_t*)Qv,      \
+                       (const bf16_t*)K, (const bf16_t*)Kt, (const bf16_t*)V, (const bf16_t*)P, (const bf16_t*)Pt,     \
+                       (const bf16_t*)dOh, LSE, Dtmp, (bf16_t*)dqkv, (bf16_t*)dSt, du, dv, T, Tpad, H, Rpad);          \
+    else                                                                                                               \
+    hipLaunchKernelGGL(relpos_bwd_dq16_kernel<F>, grid, dim3(512), DQ16_LDS, stream, (const bf16_t*)Qu, (const bf16_t*)Qv,    \
                        (const bf16_t*)K, (const bf16_t*)Kt, (const bf16_t*)V, (const bf16_t*)P, (const bf16_t*)Pt,     \
                        (const bf16_t*)dOh, LSE, Dtmp, (bf16_t*)dqkv, (bf16_t*)dSt, du, dv, T, Tpad, H, Rpad);
     if (f16) { SED_LAUNCH_RP(true) } else { SED_LAUNCH_RP(false) }
