@@ -611,6 +611,9 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
     unsigned char (*lds_w)[8192] = reinterpret_cast<unsigned char (*)[8192]>(lds_dq + 24576 + 65536);              // per wave: G^T fp32 + dG^T bf16
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // grid (query blocks, batch x head): with 8 query blocks the hardware's round-robin puts query block i of every head on XCD i, so
+    // one L2 serves a fixed slice of the positional table (an XCD-contiguous order that keeps a head's K / V in one L2 instead
+    // measured 18 % slower)
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
     const int I0 = blockIdx.x * 128, q0 = I0 + wave * 16;
     const int R = 2 * T - 1;
@@ -826,50 +829,75 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void relpos_bwd_dp_kernel(const bf16_t* __restrict__ dSt, const bf16_t* __restrict__ Qvt,
                                                             float* __restrict__ dP, int B, int T, int Tpad, int H,
-                                                            int ldp) {
-    __shared__ __attribute__((aligned(16))) unsigned int lds_s[128 * 33];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_q[KVB * 128];
+                                                            int ldp, int nrb, int bsplit) {
+    __shared__ __attribute__((aligned(16))) unsigned int lds_s[2][128 * 33];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_q[2][KVB * 128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
-    const int R0 = blockIdx.x * 64, h = blockIdx.y;
+    // XCD-contiguous order with the r block fastest: neighbouring r blocks of one (head, batch slice) read overlapping key rows of the
+    // same dS^T tiles (128 rows for 64 diagonals), so they should share an L2
+    const int L = xcd_remap(blockIdx.x, nrb * H * bsplit);
+    const int xb = L % nrb, h = (L / nrb) % H, zb = L / (nrb * H);
+    const int R0 = xb * 64;
     const int rb = wave >> 1, db = wave & 1;
-    const int bper = (B + gridDim.z - 1) / gridDim.z;
-    const int b_begin = blockIdx.z * bper, b_end = min(B, b_begin + bper);
+    const int bper = (B + bsplit - 1) / bsplit;
+    const int b_begin = zb * bper, b_end = min(B, b_begin + bper);
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // query tiles whose key rows jbase .. jbase + 127 (jbase = 64 t + R0 - (T - 1)) touch the score matrix: a contiguous range of t
     const int ntiles = (T + 63) / 64;
-    const unsigned short* ls16 = reinterpret_cast<const unsigned short*>(lds_s);
-    for (int b = b_begin; b < b_end; ++b) {
-        const int bh = b * H + h;
-        for (int t = 0; t < ntiles; ++t) {
-            const int i0 = t * 64;
-            const int jbase = i0 + R0 - (T - 1);
-            if (jbase + 127 < 0 || jbase >= T) continue;  // whole tile outside the score matrix (block-uniform)
-            // stage dS^T rows j = jbase + jl (jl 0..127), columns i0..i0+63
+    int t_lo = (T - 1 - R0 - 127 + 63) >> 6, t_hi = (2 * T - 2 - R0) >> 6;   // jbase + 127 >= 0, jbase <= T - 1
+    t_lo = t_lo < 0 ? 0 : t_lo;
+    t_hi = t_hi > ntiles - 1 ? ntiles - 1 : t_hi;
+    const int nt = t_hi - t_lo + 1;
+    const int total = (nt > 0 && b_end > b_begin) ? nt * (b_end - b_begin) : 0;
+    // the next (batch, query tile) pair travels HBM -> registers while the current one is multiplied, registers -> the other LDS stage
+    // afterwards (one barrier per pair; the first version loaded, stored and multiplied in sequence and spent 77 % of its wave
+    // cycles waiting)
+    uint4 pv[4];
+    TileRegs rq;
+    auto gload = [&](int it) {
+        const int bb = it / nt, t = t_lo + (it - bb * nt);
+        const int bh = (b_begin + bb) * H + h, i0 = t * 64, jbase = i0 + R0 - (T - 1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int jl = (tid >> 3) + 32 * i, c = tid & 7, j = jbase + jl;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (j >= 0 && j < T) v = *reinterpret_cast<const uint4*>(dSt + ((size_t)bh * Tpad + j) * Tpad + i0 + c * 8);
-                unsigned int* d = &lds_s[jl * 33 + c * 4];
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-            }
-            TileRegs rq;
-            tile_gload(rq, Qvt + (size_t)bh * HD * Tpad, 0, HD, Tpad, i0, tid);
-            tile_lstore_rows(rq, lds_q, tid);
-            __syncthreads();
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                s16x8_t af;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int ii = 16 * s + 8 * lg + e, rr = 32 * rb + lr;
-                    af[e] = (short)ls16[(ii + rr) * 66 + ii];
-                }
-                acc = mfma32(af, lds_frag_rows(lds_q, 32 * db + lr, 2 * s + lg), acc);
-            }
-            __syncthreads();
+        for (int i = 0; i < 4; ++i) {
+            const int j = jbase + (tid >> 3) + 32 * i;
+            const int jc = j < 0 ? 0 : (j < T ? j : T - 1);
+            const uint4 v = *reinterpret_cast<const uint4*>(dSt + ((size_t)bh * Tpad + jc) * Tpad + i0 + (tid & 7) * 8);
+            const bool ok = j >= 0 && j < T;
+            pv[i] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
         }
+        tile_gload(rq, Qvt + (size_t)bh * HD * Tpad, 0, HD, Tpad, i0, tid);
+    };
+    auto lstore = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned int* d = &lds_s[st][((tid >> 3) + 32 * i) * 33 + (tid & 7) * 4];
+            d[0] = pv[i].x; d[1] = pv[i].y; d[2] = pv[i].z; d[3] = pv[i].w;
+        }
+        tile_lstore_rows(rq, lds_q[st], tid);
+    };
+    if (total > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < total; ++it) {
+        const int st = it & 1;
+        if (it + 1 < total) gload(it + 1);
+        const unsigned short* ls16 = reinterpret_cast<const unsigned short*>(lds_s[st]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            s16x8_t af;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ii = 16 * s + 8 * lg + e, rr = 32 * rb + lr;
+                af[e] = (short)ls16[(ii + rr) * 66 + ii];
+            }
+            acc = mfma32(af, lds_frag_rows(lds_q[st], 32 * db + lr, 2 * s + lg), acc);
+        }
+        if (it + 1 < total) lstore(st ^ 1);
+        __syncthreads();
     }
     const int R = 2 * T - 1;
 #pragma unroll
@@ -912,8 +940,8 @@ extern "C" int sed_relpos_attn_bwd(const void* Qu, const void* Qut, const void* 
 #undef SED_LAUNCH_RP
     if (need_param_grads) {
         int bsplit = B < 8 ? B : 8;
-        hipLaunchKernelGGL(relpos_bwd_dp_kernel, dim3(Rpad / 64, H, bsplit), dim3(256), 0, stream, (const bf16_t*)dSt,
-                           (const bf16_t*)Qvt, dP, B, T, Tpad, H, H * HD);
+        hipLaunchKernelGGL(relpos_bwd_dp_kernel, dim3((Rpad / 64) * H * bsplit), dim3(256), 0, stream, (const bf16_t*)dSt,
+                           (const bf16_t*)Qvt, dP, B, T, Tpad, H, H * HD, Rpad / 64, bsplit);
     }
     return sed_check_launch();
 }
