@@ -583,10 +583,11 @@ __global__ __launch_bounds__(256) void relpos_bwd_dq_kernel(
 //     * P rows (score recompute, S type) live in a 256-row LDS ring, P^T columns (bf16, dQv) in four 64-column panels; the 64 new
 //       rows / columns a tile needs are DMA'd (buffer_load ... lds) into the slot the previous tile retired, one 1-KiB piece per wave
 //     * K rows, V rows and K^T (64 d x 64 keys) are single-buffered and prefetched through 12 VGPRs per lane
-//     * wave-private LDS: G^T [80 rho][16 q] fp32 for the skew, dG^T [16 q][96 rho] bf16 (zero outside the band, set once)
-//   k-slot order of the dQu contraction: lane group g owns keys {32 ks + 4 g + e} and {32 ks + 16 + 4 g + e}, e < 4 -- exactly the
-//   accumulator rows the lane already holds for the two 16-key blocks, so dS^T goes from accumulators to the B operand without
-//   leaving the lane; the A operand reads K^T with the same slot order (two 8-byte reads).
+//     * wave-private LDS: G [16 q][85] fp32 for the skew (read back as aligned 16-byte rows), dG^T [16 q][96 rho] bf16 (zero outside
+//       the band, set once)
+//   K / V rows are permuted inside each 32-key group so that lane group g's accumulator rows of two neighbouring 16-key blocks are the
+//   8 consecutive keys 32 ks + 8 g .. + 7: dS^T goes from the accumulators to the B operand of the dQu contraction without leaving
+//   the lane, and its A operand is one 16-byte read of the K^T tile.
 // ---------------------------------------------------------------------------------------------------
 template <bool F16> __device__ __forceinline__ f32x4_t mfma16x(s16x8_t a, s16x8_t b, f32x4_t c) {
     if (F16)
@@ -596,7 +597,8 @@ template <bool F16> __device__ __forceinline__ f32x4_t mfma16x(s16x8_t a, s16x8_
 typedef __attribute__((address_space(3))) void* rp_lds_ptr_t;
 #define zero4 (f32x4_t{0.f, 0.f, 0.f, 0.f})
 
-#define DQ16_LDS (24576 + 65536 + 65536)
+#define DQ16_WL 8576                      // per-wave LDS: G [16 q][85] fp32 (5440 B) + dG^T [16 q][96 rho] bf16 (3072 B)
+#define DQ16_LDS (24576 + 65536 + 8 * DQ16_WL)
 template <bool SF16>
 __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
     const bf16_t* __restrict__ Qu, const bf16_t* __restrict__ Qv, const bf16_t* __restrict__ K,
@@ -608,7 +610,7 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
     unsigned char (*lds_kv)[KVB * 128] = reinterpret_cast<unsigned char (*)[KVB * 128]>(lds_dq);                    // K rows, V rows, K^T rows (d)
     unsigned char* lds_band = lds_dq + 3 * KVB * 128;                                                               // ring of P rows, slot = n & 255
     unsigned char (*lds_bandT)[64 * 128] = reinterpret_cast<unsigned char (*)[64 * 128]>(lds_dq + 24576 + 32768);  // P^T panels [64 d][64 rho]
-    unsigned char (*lds_w)[8192] = reinterpret_cast<unsigned char (*)[8192]>(lds_dq + 24576 + 65536);              // per wave: G^T fp32 + dG^T bf16
+    unsigned char (*lds_w)[DQ16_WL] = reinterpret_cast<unsigned char (*)[DQ16_WL]>(lds_dq + 24576 + 65536);        // per wave: G fp32 + dG^T bf16
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // grid (query blocks, batch x head): with 8 query blocks the hardware's round-robin puts query block i of every head on XCD i, so
@@ -651,10 +653,14 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
         pv = *reinterpret_cast<const uint4*>(V + hb + (size_t)kr * HD + tch * 8);
         pkt = *reinterpret_cast<const uint4*>(Kt + hbt + (size_t)trow * Tpad + j0 + tch * 8);
     };
+    // K / V rows sit in LDS in the order the 16-row MFMA blocks want them: block kb = 2 (key >> 5) + ((key >> 2) & 1) holds the keys
+    // 32 (kb >> 1) + 8 G + 4 (kb & 1) + r at row 4 G + r, so that lane group G's accumulator rows of blocks 2 ks and 2 ks + 1 together
+    // are the 8 consecutive keys 32 ks + 8 G .. + 7 -- the K^T operand of the dQu contraction is then ONE 16-byte read per lane
+    const int krow_lds = (trow & 32) + (((trow >> 2) & 1) << 4) + (((trow >> 3) & 3) << 2) + (trow & 3);
     auto lstore = [&]() {
-        const int off = k_off(trow, tch);
-        *reinterpret_cast<uint4*>(lds_kv[0] + off) = pk;
-        *reinterpret_cast<uint4*>(lds_kv[1] + off) = pv;
+        const int off = k_off(trow, tch), offp = k_off(krow_lds, tch);
+        *reinterpret_cast<uint4*>(lds_kv[0] + offp) = pk;
+        *reinterpret_cast<uint4*>(lds_kv[1] + offp) = pv;
         *reinterpret_cast<uint4*>(lds_kv[2] + off) = pkt;
     };
     gload(0);
@@ -670,8 +676,10 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
     }
     const float l2 = qvalid ? LSE[(size_t)bh * T + qrow] : __builtin_inff(), dd = Dv[(size_t)bh * T + qrow];
     unsigned char* wl = lds_w[wave];
-    float* gs = reinterpret_cast<float*>(wl);                      // G^T [80][16]
-    unsigned char* dgl = wl + 5120;                                // dG^T [16 q][96 rho] bf16
+    // G[q][rho] fp32 at word 85 q + 1 + rho: the four band values a lane adds to one accumulator (rho = jj - q + 15 .. + 3) start at
+    // word 84 q + 16 + jj, a multiple of 4 -> one aligned 16-byte read
+    float* gs = reinterpret_cast<float*>(wl);
+    unsigned char* dgl = wl + 5440;                                // dG^T [16 q][96 rho] bf16
 #pragma unroll
     for (int i = 0; i < 3; ++i) *reinterpret_cast<uint4*>(dgl + (i * 64 + lane) * 16) = make_uint4(0, 0, 0, 0);
     lstore();
@@ -686,7 +694,7 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
     const int ntiles = (T + KVB - 1) / KVB;
     // dS^T slab of this (batch, head): [Tpad keys][Tpad queries] bf16; the 128-query block can overhang Tpad (a multiple of 64)
     const __amdgpu_buffer_rsrc_t rds = __builtin_amdgcn_make_buffer_rsrc((void*)(dSt + (size_t)bh * Tpad * Tpad), 0, Tpad * Tpad * 2, 0x00020000);
-    const int dvo = (q0 + c < Tpad) ? (4 * g * Tpad + q0 + c) * 2 : 0x7ffffff0;
+    const int dvo = (q0 + c < Tpad) ? (8 * g * Tpad + q0 + c) * 2 : 0x7ffffff0;
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * KVB;
         const bool more = t + 1 < ntiles;
@@ -707,14 +715,12 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
             for (int ks = 0; ks < 2; ++ks)
                 gacc = mfma16x<SF16>(*reinterpret_cast<const s16x8_t*>(rowp + (((4 * ks + g) ^ sw) << 4)), qvf[ks], gacc);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gs[(16 * blk + 4 * g + r) * 16 + c] = gacc[r];
+            for (int r = 0; r < 4; ++r) gs[85 * c + 1 + 16 * blk + 4 * g + r] = gacc[r];
         }
         // ---- S^T = K Qu^T + skew(G^T) (the skewed band term enters as the accumulator input), dP^T = V dO^T
-        f32x4_t st[4], dp[4];
+        f32x4_t st[4], dp[4];   // block kb, register r <-> key jj = 32 (kb >> 1) + 4 (kb & 1) + 8 g + r
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) st[kb][r] = gs[(16 * kb + 4 * g + r - c + 15) * 16 + c];
+        for (int kb = 0; kb < 4; ++kb) st[kb] = *reinterpret_cast<const f32x4_t*>(gs + 84 * c + 16 + 32 * (kb >> 1) + 4 * (kb & 1) + 8 * g);
         const int swc = (c >> 1) & 7;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
@@ -733,21 +739,22 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], SCALE_LOG2E, -l2));   // invalid query: LSE = +inf
-                if (j0 + KVB > T) p = (j0 + 16 * kb + 4 * g + r < T) ? p : 0.f;                  // last tile only
+                if (j0 + KVB > T) p = (j0 + 32 * (kb >> 1) + 4 * (kb & 1) + 8 * g + r < T) ? p : 0.f;   // last tile only
                 dp[kb][r] = p * (dp[kb][r] - dd);
             }
         // ---- dS^T -> skewed dG^T image (wave-private) and -> global for the dP kernel
         {
-            unsigned short* dg16 = reinterpret_cast<unsigned short*>(dgl) + c * 96 + 15 - c + 4 * g;
+            unsigned short* dg16 = reinterpret_cast<unsigned short*>(dgl) + c * 96 + 15 - c + 8 * g;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
                 const unsigned p01 = pack2bf(dp[kb][0], dp[kb][1]), p23 = pack2bf(dp[kb][2], dp[kb][3]);
-                dg16[16 * kb + 0] = (unsigned short)(p01 & 0xffffu);
-                dg16[16 * kb + 1] = (unsigned short)(p01 >> 16);
-                dg16[16 * kb + 2] = (unsigned short)(p23 & 0xffffu);
-                dg16[16 * kb + 3] = (unsigned short)(p23 >> 16);
+                const int jb = 32 * (kb >> 1) + 4 * (kb & 1);
+                dg16[jb + 0] = (unsigned short)(p01 & 0xffffu);
+                dg16[jb + 1] = (unsigned short)(p01 >> 16);
+                dg16[jb + 2] = (unsigned short)(p23 & 0xffffu);
+                dg16[jb + 3] = (unsigned short)(p23 >> 16);
                 // branch-free: a lane whose query column does not exist in the [Tpad][Tpad] slab stores out of the buffer's bounds
-                const int so = (j0 + 16 * kb) * Tpad * 2;
+                const int so = (j0 + jb) * Tpad * 2;
                 __builtin_amdgcn_raw_buffer_store_b16((short)(p01 & 0xffffu), rds, dvo, so, 0);
                 __builtin_amdgcn_raw_buffer_store_b16((short)(p01 >> 16), rds, dvo, so + Tpad * 2, 0);
                 __builtin_amdgcn_raw_buffer_store_b16((short)(p23 & 0xffffu), rds, dvo, so + Tpad * 4, 0);
@@ -763,11 +770,7 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
                 const unsigned char* rowp = lds_kv[2] + (16 * db + c) * 128;   // (row >> 1) & 7 == swc for every 16-row block
-                const int ch8a = 8 * ks + g, ch8b = 8 * ks + 4 + g;
-                const uint2 lo = *reinterpret_cast<const uint2*>(rowp + ((((ch8a >> 1) ^ swc) << 4) | ((ch8a & 1) << 3)));
-                const uint2 hi = *reinterpret_cast<const uint2*>(rowp + ((((ch8b >> 1) ^ swc) << 4) | ((ch8b & 1) << 3)));
-                const uint4 au = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                dqu[db] = mfma16x<false>(__builtin_bit_cast(s16x8_t, au), dsf, dqu[db]);
+                dqu[db] = mfma16x<false>(*reinterpret_cast<const s16x8_t*>(rowp + (((4 * ks + g) ^ swc) << 4)), dsf, dqu[db]);
             }
         }
         // ---- dQv^T[d, q] += P^T[d, rho] dG^T[rho, q]   (96 rho slots, the last 16 and the cells outside the band are zeros)
