@@ -657,12 +657,12 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
     // 32 (kb >> 1) + 8 G + 4 (kb & 1) + r at row 4 G + r, so that lane group G's accumulator rows of blocks 2 ks and 2 ks + 1 together
     // are the 8 consecutive keys 32 ks + 8 G .. + 7 -- the K^T operand of the dQu contraction is then ONE 16-byte read per lane
     const int krow_lds = (trow & 32) + (((trow >> 2) & 1) << 4) + (((trow >> 3) & 3) << 2) + (trow & 3);
-    auto lstore = [&]() {
-        const int off = k_off(trow, tch), offp = k_off(krow_lds, tch);
+    auto lstore_kv = [&]() {
+        const int offp = k_off(krow_lds, tch);
         *reinterpret_cast<uint4*>(lds_kv[0] + offp) = pk;
         *reinterpret_cast<uint4*>(lds_kv[1] + offp) = pv;
-        *reinterpret_cast<uint4*>(lds_kv[2] + off) = pkt;
     };
+    auto lstore_kt = [&]() { *reinterpret_cast<uint4*>(lds_kv[2] + k_off(trow, tch)) = pkt; };
     gload(0);
     int qrow = q0 + c;
     const bool qvalid = qrow < T;
@@ -682,7 +682,8 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
     unsigned char* dgl = wl + 5440;                                // dG^T [16 q][96 rho] bf16
 #pragma unroll
     for (int i = 0; i < 3; ++i) *reinterpret_cast<uint4*>(dgl + (i * 64 + lane) * 16) = make_uint4(0, 0, 0, 0);
-    lstore();
+    lstore_kv();
+    lstore_kt();
     f32x4_t dqu[4], dqv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { dqu[i] = zero4; dqv[i] = zero4; }
@@ -699,12 +700,17 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
         const int j0 = t * KVB;
         const bool more = t + 1 < ntiles;
         if (more) {   // tile t + 1: band rows / P^T columns n in [64 t + 192, 64 t + 256) replace the slot tile t - 1 retired
+#ifndef DQX_NO_DMA
             dma_band(64 * t + 192 + 8 * wave);
             dma_bandT(64 * t + 192);
+#endif
+#ifndef DQX_NO_GLOAD
             gload(t + 1);
+#endif
         }
         const int nb = 64 * t + 16 * (7 - wave);    // this wave's band base
         // ---- G^T[rho, q] = P_band[rho, :] . Qv[q, :]  (5 blocks of 16 rho) -> wave-private LDS
+#ifndef DQX_NO_G
 #pragma unroll
         for (int blk = 0; blk < 5; ++blk) {
             const int slot = ((nb + 16 * blk) & 255) + c;
@@ -717,6 +723,7 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) gs[85 * c + 1 + 16 * blk + 4 * g + r] = gacc[r];
         }
+#endif
         // ---- S^T = K Qu^T + skew(G^T) (the skewed band term enters as the accumulator input), dP^T = V dO^T
         f32x4_t st[4], dp[4];   // block kb, register r <-> key jj = 32 (kb >> 1) + 4 (kb & 1) + 8 g + r
 #pragma unroll
@@ -732,6 +739,13 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
                 st[kb] = mfma16x<SF16>(*reinterpret_cast<const s16x8_t*>(kp + (((4 * ks + g) ^ swc) << 4)), quf[ks], st[kb]);
                 dp[kb] = mfma16x<false>(*reinterpret_cast<const s16x8_t*>(vp + (((4 * ks + g) ^ swc) << 4)), dof[ks], dp[kb]);
             }
+        }
+        // Two barriers per tile, half a tile apart: A -- every wave has read K / V of tile t, the prefetched K / V rows go to LDS;
+        // B (end of tile) -- every wave has read K^T of tile t and the band pieces of tile t + 1 have landed, K^T goes to LDS and is
+        // first read after the next A.
+        if (more) {
+            __syncthreads();
+            lstore_kv();
         }
         // ---- P = exp2(S c - LSE), dS^T = P (dP^T - D)
 #pragma unroll
@@ -754,14 +768,17 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
                 dg16[jb + 2] = (unsigned short)(p23 & 0xffffu);
                 dg16[jb + 3] = (unsigned short)(p23 >> 16);
                 // branch-free: a lane whose query column does not exist in the [Tpad][Tpad] slab stores out of the buffer's bounds
+#ifndef DQX_NO_STORE
                 const int so = (j0 + jb) * Tpad * 2;
                 __builtin_amdgcn_raw_buffer_store_b16((short)(p01 & 0xffffu), rds, dvo, so, 0);
                 __builtin_amdgcn_raw_buffer_store_b16((short)(p01 >> 16), rds, dvo, so + Tpad * 2, 0);
                 __builtin_amdgcn_raw_buffer_store_b16((short)(p23 & 0xffffu), rds, dvo, so + Tpad * 4, 0);
                 __builtin_amdgcn_raw_buffer_store_b16((short)(p23 >> 16), rds, dvo, so + Tpad * 6, 0);
+#endif
             }
         }
         // ---- dQu^T[d, q] += K^T[d, key] dS^T[key, q]
+#ifndef DQX_NO_DQU
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const uint4 dsu = make_uint4(pack2bf(dp[2 * ks][0], dp[2 * ks][1]), pack2bf(dp[2 * ks][2], dp[2 * ks][3]),
@@ -773,7 +790,9 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
                 dqu[db] = mfma16x<false>(*reinterpret_cast<const s16x8_t*>(rowp + (((4 * ks + g) ^ swc) << 4)), dsf, dqu[db]);
             }
         }
+#endif
         // ---- dQv^T[d, q] += P^T[d, rho] dG^T[rho, q]   (96 rho slots, the last 16 and the cells outside the band are zeros)
+#ifndef DQX_NO_DQV
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
             const s16x8_t gf = *reinterpret_cast<const s16x8_t*>(dgl + c * 192 + 64 * ks + 16 * g);
@@ -784,11 +803,16 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
             for (int db = 0; db < 4; ++db)
                 dqv[db] = mfma16x<false>(*reinterpret_cast<const s16x8_t*>(pan + (16 * db + c) * 128 + ((ch ^ swc) << 4)), gf, dqv[db]);
         }
+#endif
         if (more) {
-            __syncthreads();                                   // every wave is done with K / V / K^T of tile t
-            lstore();
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // this wave's band pieces have landed (only the 16 dS^T stores are younger)
+#ifdef DQX_NO_STORE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#endif
+            // this wave's band pieces have landed (only the 16 dS^T stores are younger)
             __syncthreads();
+            lstore_kt();
         }
     }
     // ---- outputs: dq rows (lane = query, 4 consecutive d per block) and the pos_bias_u / pos_bias_v column sums
