@@ -389,197 +389,12 @@ __global__ __launch_bounds__(256) void relpos_bwd_dkdv_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
-// backward kernel 2: dQ (= dQu + dQv), per-head sums for pos_bias_u / pos_bias_v, and dS^T for the dP kernel.
-// workgroup = 128 queries; loops over 64-key tiles; lane owns a query column (as in forward).
-// ---------------------------------------------------------------------------------------------------
-template <bool SF16>
-__global__ __launch_bounds__(256) void relpos_bwd_dq_kernel(
-    const bf16_t* __restrict__ Qu, const bf16_t* __restrict__ Qv, const bf16_t* __restrict__ K,
-    const bf16_t* __restrict__ Kt, const bf16_t* __restrict__ V, const bf16_t* __restrict__ P,
-    const bf16_t* __restrict__ Pt, const bf16_t* __restrict__ dOh, const float* __restrict__ LSE,
-    const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, bf16_t* __restrict__ dSt, float* __restrict__ du,
-    float* __restrict__ dvb, int T, int Tpad, int H, int Rpad) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[3][KVB * 128];  // K rows, V rows, K^T
-    __shared__ __attribute__((aligned(16))) unsigned char lds_band[BAND_ROWS * 128];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_bandT[64 * 384];
-    __shared__ __attribute__((aligned(16))) float lds_g[4][96 * 32];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
-    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
-    const int I0 = blockIdx.x * 128, q0 = I0 + wave * 32;
-    const int R = 2 * T - 1;
-    const size_t hb = (size_t)bh * T * HD, hbt = (size_t)bh * HD * Tpad;
-    const bf16_t* Ph = P + (size_t)h * Rpad * HD;
-    const bf16_t* Pth = Pt + (size_t)h * HD * Rpad;
-    int qrow = q0 + lr;
-    const bool qvalid = qrow < T;
-    qrow = qvalid ? qrow : T - 1;
-    s16x8_t quf[4], qvf[4], dof[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        quf[s] = *reinterpret_cast<const s16x8_t*>(Qu + hb + (size_t)qrow * HD + 16 * s + 8 * lg);
-        qvf[s] = *reinterpret_cast<const s16x8_t*>(Qv + hb + (size_t)qrow * HD + 16 * s + 8 * lg);
-        dof[s] = *reinterpret_cast<const s16x8_t*>(dOh + hb + (size_t)qrow * HD + 16 * s + 8 * lg);
-    }
-    const float l2 = qvalid ? LSE[(size_t)bh * T + qrow] : __builtin_inff(), dd = Dv[(size_t)bh * T + qrow];
-    f32x16_t dqu[2], dqv[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dqu[i][r] = 0.f; dqv[i][r] = 0.f; }
-    float* gs = lds_g[wave];
-    const int band_row0 = 32 * (3 - wave);
-    const int ntiles = (T + KVB - 1) / KVB;
-    // next tile's operands travel HBM -> registers while the current tile is being consumed, registers -> LDS afterwards
-    TileRegs r0, r1, r2;
-    BandRegs rb, rbt;
-    auto gload = [&](int t) {
-        const int j0 = t * KVB;
-        const int RB = j0 - I0 - 127 + T - 1;  // multiple of 8 because T % 8 == 0
-        tile_gload(r0, K + hb, j0, T, HD, 0, tid);
-        tile_gload(r1, V + hb, j0, T, HD, 0, tid);
-        tile_gload(r2, Kt + hbt, 0, HD, Tpad, j0, tid);
-        band_gload(rb, Ph, RB, R, tid);
-        bandT_gload(rbt, Pth, RB, Rpad, tid);
-    };
-    auto lstore = [&]() {
-        tile_lstore_rows(r0, lds[0], tid);
-        tile_lstore_rows(r1, lds[1], tid);
-        tile_lstore_cols(r2, lds[2], tid);
-        band_lstore(rb, lds_band, tid);
-        bandT_lstore(rbt, lds_bandT, tid);
-    };
-    gload(0);
-    lstore();
-    __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        const int j0 = t * KVB;
-        if (t + 1 < ntiles) gload(t + 1);
-#pragma unroll
-        for (int blk = 0; blk < 3; ++blk) {
-            f32x16_t g;
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                g = mfma32t<SF16>(lds_frag_rows(lds_band, band_row0 + 32 * blk + lr, 2 * s + lg), qvf[s], s == 0 ? zero16 : g);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) gs[(32 * blk + mfma32_row(r, lg)) * 32 + lr] = g[r];
-        }
-        f32x16_t st[2], dp[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                st[kb] = mfma32t<SF16>(lds_frag_rows(lds[0], 32 * kb + lr, 2 * s + lg), quf[s], s == 0 ? zero16 : st[kb]);
-                dp[kb] = mfma32(lds_frag_rows(lds[1], 32 * kb + lr, 2 * s + lg), dof[s], s == 0 ? zero16 : dp[kb]);
-            }
-        }
-        __syncthreads();
-        // all 32 skewed reads are issued before the first use (a load inside a conditional expression is compiled into a branch
-        // with its own s_waitcnt: 32 serialised LDS round trips per tile)
-        float gv[2][16];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) gv[kb][r] = gs[(32 * kb + mfma32_row(r, lg) - lr + 31) * 32 + lr];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r] + gv[kb][r], SCALE_LOG2E, -l2));  // invalid query: l2 = +inf
-                if (j0 + KVB > T) p = (j0 + 32 * kb + mfma32_row(r, lg) < T) ? p : 0.f;                      // last tile only
-                dp[kb][r] = p * (dp[kb][r] - dd);  // dS^T[key, q]
-            }
-        // dS^T -> global (for the dP kernel; rows / columns up to Tpad exist, the values there are exact zeros) and -> skewed LDS
-        // image dG^T[rho, q] (wave-private buffer: the wave's own reads above have completed)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int jj = 32 * kb + mfma32_row(r, lg);
-                gs[(jj - lr + 31) * 32 + lr] = dp[kb][r];
-            }
-        if (q0 + lr < Tpad) {   // one lane predicate around all 32 stores (the query blocks of 128 can overhang Tpad, a multiple of 64)
-            bf16_t* dcol = dSt + ((size_t)bh * Tpad + j0) * Tpad + q0 + lr;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dcol[(size_t)(32 * kb + mfma32_row(r, lg)) * Tpad] = f2bf(dp[kb][r]);
-        }
-        // dQu^T[d, q] += K^T[d, key] dS^T[key, q]
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const s16x8_t dsf = pack_frag(dp[kb], s);
-#pragma unroll
-                for (int db = 0; db < 2; ++db)
-                    dqu[db] = mfma32(lds_frag_cols(lds[2], 32 * db + lr, 8 * kb + 4 * s + lg), dsf, dqu[db]);
-            }
-        __syncthreads();
-        // dQv^T[d, q] += P_band^T[d, rho] dG^T[rho, q]   (rho = 16 s + 8 g + e, natural k order)
-#pragma unroll
-        for (int s = 0; s < 6; ++s) {
-            float ge[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ge[e] = gs[(16 * s + 8 * lg + e) * 32 + lr];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int jj = 16 * s + 8 * lg + e + lr - 31;
-                ge[e] = (jj >= 0 && jj < 64) ? ge[e] : 0.f;
-            }
-            const uint4 gp = make_uint4(pack2bf(ge[0], ge[1]), pack2bf(ge[2], ge[3]), pack2bf(ge[4], ge[5]), pack2bf(ge[6], ge[7]));
-            const s16x8_t gf = __builtin_bit_cast(s16x8_t, gp);
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const int row = 32 * db + lr, ch = (band_row0 >> 3) + 2 * s + lg;
-                const s16x8_t pf = *reinterpret_cast<const s16x8_t*>(lds_bandT + bt_off(row, ch));
-                dqv[db] = mfma32(pf, gf, dqv[db]);
-            }
-        }
-        __syncthreads();
-        if (t + 1 < ntiles) {
-            lstore();
-            __syncthreads();
-        }
-    }
-    // outputs
-    if (qvalid) {
-        bf16_t* row = dqkv + ((size_t)b * T + q0 + lr) * (3 * H * HD) + h * HD;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                float v0 = (dqu[db][4 * qd] + dqv[db][4 * qd]) * SCALE, v1 = (dqu[db][4 * qd + 1] + dqv[db][4 * qd + 1]) * SCALE;
-                float v2 = (dqu[db][4 * qd + 2] + dqv[db][4 * qd + 2]) * SCALE, v3 = (dqu[db][4 * qd + 3] + dqv[db][4 * qd + 3]) * SCALE;
-                uint2 pk;
-                pk.x = pack2bf(v0, v1);
-                pk.y = pack2bf(v2, v3);
-                *reinterpret_cast<uint2*>(row + 32 * db + 8 * qd + 4 * lg) = pk;
-            }
-    }
-    // pos_bias grads: sum over the wave's 32 queries (invalid queries contributed exact zeros)
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float su = dqu[db][r] * SCALE, sv = dqv[db][r] * SCALE;
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) {
-                su += __shfl_xor(su, o, 64);
-                sv += __shfl_xor(sv, o, 64);
-            }
-            if (lr == 0) {
-                const int d = 32 * db + mfma32_row(r, lg);
-                unsafeAtomicAdd(&du[h * HD + d], su);
-                unsafeAtomicAdd(&dvb[h * HD + d], sv);
-            }
-        }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// backward kernel 2, second generation: the same outputs on v_mfma_f32_16x16x32 with 8 waves (2 per SIMD) per workgroup.
+// backward kernel 2: dQ (= dQu + dQv), per-head sums for pos_bias_u / pos_bias_v, and dS^T for the dP kernel, on
+// v_mfma_f32_16x16x32 with 8 waves (2 per SIMD) per workgroup.
 //   workgroup = 128 queries, wave = 16 queries x 64-key tiles, lane = (query column c = lane & 15, row group g = lane >> 4).
-//   ~130 VGPRs per wave instead of 441 (the first generation ran one wave per SIMD and had to park its register prefetch in AGPRs
-//   behind an s_waitcnt vmcnt(0) right after issuing it), and the positional band never passes through registers:
+//   146 VGPRs per wave (the first version, 4 waves x 32 queries on 32x32x16 MFMAs, needed 441, ran one wave per SIMD and had to park
+//   its register prefetch in AGPRs behind an s_waitcnt vmcnt(0) right after issuing it); the positional band never passes through
+//   registers:
 //     * P rows (score recompute, S type) live in a 256-row LDS ring, P^T columns (bf16, dQv) in four 64-column panels; the 64 new
 //       rows / columns a tile needs are DMA'd (buffer_load ... lds) into the slot the previous tile retired, one 1-KiB piece per wave
 //     * K rows, V rows and K^T (64 d x 64 keys) are single-buffered and prefetched through 12 VGPRs per lane
@@ -600,7 +415,7 @@ typedef __attribute__((address_space(3))) void* rp_lds_ptr_t;
 #define DQ16_WL 8576                      // per-wave LDS: G [16 q][85] fp32 (5440 B) + dG^T [16 q][96 rho] bf16 (3072 B)
 #define DQ16_LDS (24576 + 65536 + 8 * DQ16_WL)
 template <bool SF16>
-__global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
+__global__ __launch_bounds__(512) void relpos_bwd_dq_kernel(
     const bf16_t* __restrict__ Qu, const bf16_t* __restrict__ Qv, const bf16_t* __restrict__ K,
     const bf16_t* __restrict__ Kt, const bf16_t* __restrict__ V, const bf16_t* __restrict__ P,
     const bf16_t* __restrict__ Pt, const bf16_t* __restrict__ dOh, const float* __restrict__ LSE,
@@ -700,17 +515,12 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
         const int j0 = t * KVB;
         const bool more = t + 1 < ntiles;
         if (more) {   // tile t + 1: band rows / P^T columns n in [64 t + 192, 64 t + 256) replace the slot tile t - 1 retired
-#ifndef DQX_NO_DMA
             dma_band(64 * t + 192 + 8 * wave);
             dma_bandT(64 * t + 192);
-#endif
-#ifndef DQX_NO_GLOAD
             gload(t + 1);
-#endif
         }
         const int nb = 64 * t + 16 * (7 - wave);    // this wave's band base
         // ---- G^T[rho, q] = P_band[rho, :] . Qv[q, :]  (5 blocks of 16 rho) -> wave-private LDS
-#ifndef DQX_NO_G
 #pragma unroll
         for (int blk = 0; blk < 5; ++blk) {
             const int slot = ((nb + 16 * blk) & 255) + c;
@@ -723,7 +533,6 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) gs[85 * c + 1 + 16 * blk + 4 * g + r] = gacc[r];
         }
-#endif
         // ---- S^T = K Qu^T + skew(G^T) (the skewed band term enters as the accumulator input), dP^T = V dO^T
         f32x4_t st[4], dp[4];   // block kb, register r <-> key jj = 32 (kb >> 1) + 4 (kb & 1) + 8 g + r
 #pragma unroll
@@ -768,17 +577,14 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
                 dg16[jb + 2] = (unsigned short)(p23 & 0xffffu);
                 dg16[jb + 3] = (unsigned short)(p23 >> 16);
                 // branch-free: a lane whose query column does not exist in the [Tpad][Tpad] slab stores out of the buffer's bounds
-#ifndef DQX_NO_STORE
                 const int so = (j0 + jb) * Tpad * 2;
                 __builtin_amdgcn_raw_buffer_store_b16((short)(p01 & 0xffffu), rds, dvo, so, 0);
                 __builtin_amdgcn_raw_buffer_store_b16((short)(p01 >> 16), rds, dvo, so + Tpad * 2, 0);
                 __builtin_amdgcn_raw_buffer_store_b16((short)(p23 & 0xffffu), rds, dvo, so + Tpad * 4, 0);
                 __builtin_amdgcn_raw_buffer_store_b16((short)(p23 >> 16), rds, dvo, so + Tpad * 6, 0);
-#endif
             }
         }
         // ---- dQu^T[d, q] += K^T[d, key] dS^T[key, q]
-#ifndef DQX_NO_DQU
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const uint4 dsu = make_uint4(pack2bf(dp[2 * ks][0], dp[2 * ks][1]), pack2bf(dp[2 * ks][2], dp[2 * ks][3]),
@@ -790,9 +596,7 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
                 dqu[db] = mfma16x<false>(*reinterpret_cast<const s16x8_t*>(rowp + (((4 * ks + g) ^ swc) << 4)), dsf, dqu[db]);
             }
         }
-#endif
         // ---- dQv^T[d, q] += P^T[d, rho] dG^T[rho, q]   (96 rho slots, the last 16 and the cells outside the band are zeros)
-#ifndef DQX_NO_DQV
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
             const s16x8_t gf = *reinterpret_cast<const s16x8_t*>(dgl + c * 192 + 64 * ks + 16 * g);
@@ -803,13 +607,8 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq16_kernel(
             for (int db = 0; db < 4; ++db)
                 dqv[db] = mfma16x<false>(*reinterpret_cast<const s16x8_t*>(pan + (16 * db + c) * 128 + ((ch ^ swc) << 4)), gf, dqv[db]);
         }
-#endif
         if (more) {
-#ifdef DQX_NO_STORE
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
             asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-#endif
             // this wave's band pieces have landed (only the 16 dS^T stores are younger)
             __syncthreads();
             lstore_kt();
@@ -950,17 +749,11 @@ extern "C" int sed_relpos_attn_bwd(const void* Qu, const void* Qut, const void* 
     int rc = sed_mhsa_bwd_prep(dO, O, Dtmp, dOh, dOt, B, H, T, Tpad, o_kind, stream);
     if (rc) return rc;
     dim3 grid(cdiv(T, 128), B * H);
-    static const bool use_old_dq = getenv("SED_RP_OLD_DQ") != nullptr;   // developer A/B switch
 #define SED_LAUNCH_RP(F)                                                                                               \
     hipLaunchKernelGGL(relpos_bwd_dkdv_kernel<F>, grid, dim3(256), 0, stream, (const bf16_t*)Qu, (const bf16_t*)Qut,   \
                        (const bf16_t*)Qv, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)P, (const bf16_t*)dOh,    \
                        (const bf16_t*)dOt, LSE, Dtmp, (bf16_t*)dqkv, T, Tpad, H, Rpad);                                \
-    if (use_old_dq)                                                                                                    \
-    hipLaunchKernelGGL(relpos_bwd_dq_kernel<F>, grid, dim3(256), 0, stream, (const bf16_t*)Qu, (const bf16_t*)Qv,      \
-                       (const bf16_t*)K, (const bf16_t*)Kt, (const bf16_t*)V, (const bf16_t*)P, (const bf16_t*)Pt,     \
-                       (const bf16_t*)dOh, LSE, Dtmp, (bf16_t*)dqkv, (bf16_t*)dSt, du, dv, T, Tpad, H, Rpad);          \
-    else                                                                                                               \
-    hipLaunchKernelGGL(relpos_bwd_dq16_kernel<F>, grid, dim3(512), DQ16_LDS, stream, (const bf16_t*)Qu, (const bf16_t*)Qv,    \
+    hipLaunchKernelGGL(relpos_bwd_dq_kernel<F>, grid, dim3(512), DQ16_LDS, stream, (const bf16_t*)Qu, (const bf16_t*)Qv,    \
                        (const bf16_t*)K, (const bf16_t*)Kt, (const bf16_t*)V, (const bf16_t*)P, (const bf16_t*)Pt,     \
                        (const bf16_t*)dOh, LSE, Dtmp, (bf16_t*)dqkv, (bf16_t*)dSt, du, dv, T, Tpad, H, Rpad);
     if (f16) { SED_LAUNCH_RP(true) } else { SED_LAUNCH_RP(false) }
