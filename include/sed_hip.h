@@ -91,10 +91,10 @@ int sed_mhsa_fwd(const void* Q, const void* K, const void* V, void* O, float* LS
 int sed_mhsa_bwd_prep(const void* dO, const void* O, float* Dtmp, void* dOh, void* dOt, int B, int H, int N, int Npad,
                       int o_f16, hipStream_t stream);
 /* dqkv [B*N, 3*768] bf16 (dq | dk | dv).  f16 != 0: Q, K, O are IEEE half (as the f16 forward wrote them, used for the
- * score recompute), all gradient-side operands (Qt, Kt, V, dO) are bf16. */
-int sed_mhsa_bwd(const void* Q, const void* Qt, const void* K, const void* Kt, const void* V, const void* O,
-                 const void* dO, const float* LSE, float* Dtmp, void* dOh, void* dOt, void* dqkv, int B, int H, int N,
-                 int Npad, int f16, hipStream_t stream);
+ * score recompute), the gradient-side operands V, dO are bf16.  Transposed operands are taken out of row-major LDS tiles with
+ * transposing reads: no Q^T / K^T / dO^T copies (sed_mhsa_bwd_prep accepts dOt == NULL). */
+int sed_mhsa_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, float* Dtmp,
+                 void* dOh, void* dqkv, int B, int H, int N, int Npad, int f16, hipStream_t stream);
 /* Transformer-XL rel-pos attention (src/models/transformer/transformerXL.py:493-576 incl. rel_shift 254-297) */
 int sed_relpos_attn_fwd(const void* Qu, const void* Qv, const void* K, const void* Vt, const void* P, void* O,
                         float* LSE, int B, int H, int T, int Tpad, int Rpad, int f16, int o_f32, hipStream_t stream);

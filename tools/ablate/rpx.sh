@@ -1,6 +1,4 @@
 mkdir -p gpurun_out/r2; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-for v in s_ilp s_agpr s_iter s_mem; do
-  export SED_HIP_LIB=$GRAFT_REPO_ROOT/tools/ablate/variants/$v.so
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2/rpx_$v -o p -- python tools/relpos_bench.py > /dev/null 2>&1
-  rm -f gpurun_out/r2/rpx_$v/p_kernel_trace.csv
-done
+python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|error|assert" | tail -8
+python tools/attn_bench.py 2>&1 | grep mhsa
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-200

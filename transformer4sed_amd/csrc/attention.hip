@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_prep_kernel(const bf16_t* __rest
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
         const int d = ty * 16 + i, t = t0 + tx;
-        if (t < Npad) dOt[((size_t)bh * HD + d) * Npad + t] = (t < N) ? tile[tx][d] : (bf16_t)0;
+        if (dOt != nullptr && t < Npad) dOt[((size_t)bh * HD + d) * Npad + t] = (t < N) ? tile[tx][d] : (bf16_t)0;
     }
 }
 
@@ -236,24 +236,27 @@ __global__ __launch_bounds__(256) void mhsa_bwd_prep_kernel(const bf16_t* __rest
 // backward kernel 1: dK, dV.  Workgroup = 128 keys (4 waves x 32), loops over 64-query tiles.
 //   S[q, key]  = Q . K^T  (A = Q rows from LDS, B = K fragments in registers)  -> lane owns a key column
 //   P = exp2(S c - L2[q]);  dP[q, key] = dO . V^T ;  dS = P (dP - D[q])
-//   dV[key, d] += P^T[key, q] dO[q, d]   (A from the P registers, B = dO^T tile)
-//   dK[key, d] += dS^T[key, q] Q[q, d] * scale   (B = Q^T tile)
+//   dV[key, d] += P^T[key, q] dO[q, d]   (A from the P registers, B = dO^T fragments)
+//   dK[key, d] += dS^T[key, q] Q[q, d] * scale   (B = Q^T fragments)
+// The transposed operands come out of ROW-major LDS tiles through ds_read_b64_tr_b16 (round 2): no Q^T / dO^T copies in HBM or LDS
+// (the first version staged them as separate column-swizzled tiles -- a third of its LDS cycles were bank conflicts).  Q is saved as
+// IEEE half for the score recompute while the gradient-side MFMA is bf16: the bf16 image of the Q tile is made on the way into LDS.
 // ---------------------------------------------------------------------------------------------------
 template <bool SF16>
 __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_kernel(
-    const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Qt, const bf16_t* __restrict__ K,
-    const bf16_t* __restrict__ V, const bf16_t* __restrict__ dOh, const bf16_t* __restrict__ dOt,
-    const float* __restrict__ LSE, const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, int N, int Npad, int H) {
-    // LDS per stage: Q rows [64][64], dO rows [64][64], Q^T [64 d][64 q], dO^T [64 d][64 q], L2[64], D[64]
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][4][KVB * 128];
+    const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+    const bf16_t* __restrict__ dOh, const float* __restrict__ LSE, const float* __restrict__ Dv,
+    bf16_t* __restrict__ dqkv, int N, int Npad, int H) {
+    // LDS per stage: Q rows (S type, row fragments), Q rows bf16 (transposing reads; the same tile when the forward ran in bf16),
+    // dO rows bf16 (dual use: row fragments for dP, transposing reads for dV), L2[64], D[64]
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][3][KVB * 128];
     __shared__ __attribute__((aligned(16))) float lstat[2][2][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
     const int key0 = blockIdx.x * 128 + wave * 32;
-    const size_t hb = (size_t)bh * N * HD, hbt = (size_t)bh * HD * Npad;
+    const size_t hb = (size_t)bh * N * HD;
 
     int krow = key0 + lr;
-    const bool key_valid_lane = krow < N;
     krow = krow < N ? krow : N - 1;
     s16x8_t kf[4], vf[4];
 #pragma unroll
@@ -268,14 +271,12 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_kernel(
         for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
 
     const int ntiles = (N + 63) / 64;
-    TileRegs rq, rdo, rqt, rdot;
+    TileRegs rq, rdo;
     float rs = 0.f;
     auto gload = [&](int t) {
         const int i0 = t * 64;
         tile_gload(rq, Q + hb, i0, N, HD, 0, tid);
         tile_gload(rdo, dOh + hb, i0, N, HD, 0, tid);
-        tile_gload(rqt, Qt + hbt, 0, HD, Npad, i0, tid);
-        tile_gload(rdot, dOt + hbt, 0, HD, Npad, i0, tid);
         if (tid < 128) {
             const int qi = i0 + (tid & 63);
             const float* src = (tid < 64) ? LSE : Dv;
@@ -283,10 +284,16 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_kernel(
         }
     };
     auto lstore = [&](int buf) {
-        tile_lstore_rows(rq, lds[buf][0], tid);
-        tile_lstore_rows(rdo, lds[buf][1], tid);
-        tile_lstore_cols(rqt, lds[buf][2], tid);
-        tile_lstore_cols(rdot, lds[buf][3], tid);
+        if (SF16) {
+            tile_lstore_rows(rq, lds[buf][0], tid);
+            TileRegs rb;
+            rb.a = h8_to_bf8(rq.a);
+            rb.b = h8_to_bf8(rq.b);
+            tile_lstore_drows(rb, lds[buf][1], tid);
+        } else {
+            tile_lstore_drows(rq, lds[buf][1], tid);
+        }
+        tile_lstore_drows(rdo, lds[buf][2], tid);
         if (tid < 128) lstat[buf][tid >> 6][tid & 63] = rs;
     };
     gload(0);
@@ -297,13 +304,16 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_kernel(
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         if (t + 1 < ntiles) gload(t + 1);
+        const unsigned char* lq = lds[buf][1];
+        const unsigned char* ldo = lds[buf][2];
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {  // 32-query sub-blocks of the tile
             f32x16_t s_, dp;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                s_ = mfma32t<SF16>(lds_frag_rows(lds[buf][0], 32 * qb + lr, 2 * s + lg), kf[s], s == 0 ? zero16 : s_);
-                dp = mfma32(lds_frag_rows(lds[buf][1], 32 * qb + lr, 2 * s + lg), vf[s], s == 0 ? zero16 : dp);
+                const s16x8_t qfr = SF16 ? lds_frag_rows(lds[buf][0], 32 * qb + lr, 2 * s + lg) : lds_frag_rows_d(lq, 32 * qb + lr, 2 * s + lg);
+                s_ = mfma32t<SF16>(qfr, kf[s], s == 0 ? zero16 : s_);
+                dp = mfma32(lds_frag_rows_d(ldo, 32 * qb + lr, 2 * s + lg), vf[s], s == 0 ? zero16 : dp);
             }
             // rows of the accumulators are queries 32 qb + mfma32_row(r, lg); column = this lane's key.  A lane whose key is
             // >= N needs no masking here: its P / dS columns only feed the dK / dV rows of that key, which are never stored
@@ -330,8 +340,8 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_kernel(
                 const s16x8_t pf = pack_frag(s_, s), dsf = pack_frag(dp, s);
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    dv[db] = mfma32(pf, lds_frag_cols(lds[buf][3], 32 * db + lr, 8 * qb + 4 * s + lg), dv[db]);
-                    dk[db] = mfma32(dsf, lds_frag_cols(lds[buf][2], 32 * db + lr, 8 * qb + 4 * s + lg), dk[db]);
+                    dv[db] = mfma32(pf, lds_frag_vt_d(ldo, db, 8 * qb + 4 * s + lg, lane), dv[db]);
+                    dk[db] = mfma32(dsf, lds_frag_vt_d(lq, db, 8 * qb + 4 * s + lg, lane), dk[db]);
                 }
             }
         }
@@ -356,19 +366,19 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_kernel(
 // ---------------------------------------------------------------------------------------------------
 // backward kernel 2: dQ.  Workgroup = 128 queries, loops over 64-key tiles (swapped form as in forward).
 //   S^T[key, q] = K . Q^T ; dP^T[key, q] = V . dO^T ; dS^T = P^T (dP^T - D[q])
-//   dQ^T[d, q] += K^T[d, key] dS^T[key, q]
+//   dQ^T[d, q] += K^T[d, key] dS^T[key, q]      (K^T fragments by transposing reads of the bf16 image of the K rows tile)
 // ---------------------------------------------------------------------------------------------------
 template <bool SF16>
 __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                          const bf16_t* __restrict__ Kt, const bf16_t* __restrict__ V,
+                                                          const bf16_t* __restrict__ V,
                                                           const bf16_t* __restrict__ dOh, const float* __restrict__ LSE,
                                                           const float* __restrict__ Dv, bf16_t* __restrict__ dqkv,
                                                           int N, int Npad, int H) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][3][KVB * 128];  // K rows, V rows, K^T
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][3][KVB * 128];  // K rows (S type), V rows, K rows bf16 (dual use)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
     const int q0 = blockIdx.x * 128 + wave * 32;
-    const size_t hb = (size_t)bh * N * HD, hbt = (size_t)bh * HD * Npad;
+    const size_t hb = (size_t)bh * N * HD;
     int qrow = q0 + lr;
     const bool qvalid = qrow < N;
     qrow = qvalid ? qrow : N - 1;
@@ -385,16 +395,22 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
     const int ntiles = (N + KVB - 1) / KVB;
-    TileRegs rk, rv, rkt;
+    TileRegs rk, rv;
     auto gload = [&](int t) {
         tile_gload(rk, K + hb, t * KVB, N, HD, 0, tid);
         tile_gload(rv, V + hb, t * KVB, N, HD, 0, tid);
-        tile_gload(rkt, Kt + hbt, 0, HD, Npad, t * KVB, tid);
     };
     auto lstore = [&](int buf) {
-        tile_lstore_rows(rk, lds[buf][0], tid);
+        if (SF16) {
+            tile_lstore_rows(rk, lds[buf][0], tid);
+            TileRegs rb;
+            rb.a = h8_to_bf8(rk.a);
+            rb.b = h8_to_bf8(rk.b);
+            tile_lstore_drows(rb, lds[buf][2], tid);
+        } else {
+            tile_lstore_drows(rk, lds[buf][2], tid);
+        }
         tile_lstore_rows(rv, lds[buf][1], tid);
-        tile_lstore_cols(rkt, lds[buf][2], tid);
     };
     gload(0);
     lstore(0);
@@ -409,7 +425,8 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const bf16_t* __restri
             f32x16_t st, dp;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                st = mfma32t<SF16>(lds_frag_rows(lds[buf][0], 32 * kb + lr, 2 * s + lg), qf[s], s == 0 ? zero16 : st);
+                const s16x8_t kfr = SF16 ? lds_frag_rows(lds[buf][0], 32 * kb + lr, 2 * s + lg) : lds_frag_rows_d(lds[buf][2], 32 * kb + lr, 2 * s + lg);
+                st = mfma32t<SF16>(kfr, qf[s], s == 0 ? zero16 : st);
                 dp = mfma32(lds_frag_rows(lds[buf][1], 32 * kb + lr, 2 * s + lg), dof[s], s == 0 ? zero16 : dp);
             }
             const f32x2_t c2 = {SCALE_LOG2E, SCALE_LOG2E}, nl = {-l2, -l2}, nd = {-dd, -dd};
@@ -431,7 +448,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const bf16_t* __restri
                 const s16x8_t dsf = pack_frag(dp, s);
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
-                    dq[db] = mfma32(lds_frag_cols(lds[buf][2], 32 * db + lr, 8 * kb + 4 * s + lg), dsf, dq[db]);
+                    dq[db] = mfma32(lds_frag_vt_d(lds[buf][2], db, 8 * kb + 4 * s + lg, lane), dsf, dq[db]);
             }
         }
         if (t + 1 < ntiles) lstore(buf ^ 1);
@@ -460,21 +477,19 @@ extern "C" int sed_mhsa_bwd_prep(const void* dO, const void* O, float* Dtmp, voi
     return sed_check_launch();
 }
 
-extern "C" int sed_mhsa_bwd(const void* Q, const void* Qt, const void* K, const void* Kt, const void* V,
-                            const void* O, const void* dO, const float* LSE, float* Dtmp, void* dOh, void* dOt,
-                            void* dqkv, int B, int H, int N, int Npad, int f16, hipStream_t stream) {
+extern "C" int sed_mhsa_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                            float* Dtmp, void* dOh, void* dqkv, int B, int H, int N, int Npad, int f16, hipStream_t stream) {
     (void)hipGetLastError();
-    // f16 != 0: Q, K (score recompute) and O are IEEE half as written by the forward; Qt, Kt, V, dO are bf16.
+    // f16 != 0: Q, K (score recompute) and O are IEEE half as written by the forward; V, dO are bf16.
     if (N <= 0 || Npad % 64 || Npad < N) return SED_ERR_ARG;
-    int rc = sed_mhsa_bwd_prep(dO, O, Dtmp, dOh, dOt, B, H, N, Npad, f16, stream);
+    int rc = sed_mhsa_bwd_prep(dO, O, Dtmp, dOh, nullptr, B, H, N, Npad, f16, stream);
     if (rc) return rc;
     dim3 grid(cdiv(N, 128), B * H);
 #define SED_LAUNCH_BWD(F)                                                                                              \
-    hipLaunchKernelGGL(mhsa_bwd_dkdv_kernel<F>, grid, dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)Qt,       \
-                       (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dOh, (const bf16_t*)dOt, LSE, Dtmp,          \
-                       (bf16_t*)dqkv, N, Npad, H);                                                                     \
+    hipLaunchKernelGGL(mhsa_bwd_dkdv_kernel<F>, grid, dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,        \
+                       (const bf16_t*)V, (const bf16_t*)dOh, LSE, Dtmp, (bf16_t*)dqkv, N, Npad, H);                    \
     hipLaunchKernelGGL(mhsa_bwd_dq_kernel<F>, grid, dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,          \
-                       (const bf16_t*)Kt, (const bf16_t*)V, (const bf16_t*)dOh, LSE, Dtmp, (bf16_t*)dqkv, N, Npad, H);
+                       (const bf16_t*)V, (const bf16_t*)dOh, LSE, Dtmp, (bf16_t*)dqkv, N, Npad, H);
     if (f16) { SED_LAUNCH_BWD(true) } else { SED_LAUNCH_BWD(false) }
 #undef SED_LAUNCH_BWD
     return sed_check_launch();

@@ -42,6 +42,32 @@ __device__ __forceinline__ s16x8_t lds_frag_vt(const unsigned char* base, int db
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
 }
+// Dual-use row-major tile [64 rows][64 x 16 bit]: the SAME LDS image serves 16-byte row fragments (A / B operand with the tile's rows
+// as MFMA rows) and transposing reads (operand with the tile's COLUMNS as MFMA rows).  16-byte chunk c of row r sits at chunk
+// c ^ fd(r), fd(r) = (((r >> 1) & 1) << 2) | ((r >> 2) & 3): a bit permutation of (r >> 1) & 7, so the 16 rows of one ds_read_b128
+// lane group still hit 16 different bank quads, while the four rows of one transposing read differ in the 64-byte half exactly as in
+// v_off (PMC: zero bank conflicts for both kinds of read).
+__device__ __forceinline__ int fd_sw(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ int d_off(int row, int ch16) { return row * 128 + ((ch16 ^ fd_sw(row)) << 4); }
+__device__ __forceinline__ s16x8_t lds_frag_rows_d(const unsigned char* base, int row, int ch16) {
+    return *reinterpret_cast<const s16x8_t*>(base + d_off(row, ch16));
+}
+// transposed fragment (same contract as lds_frag_vt) out of a dual-use tile: rows 4 ch8 + (a >> 2) (+ 8 for the second read)
+__device__ __forceinline__ s16x8_t lds_frag_vt_d(const unsigned char* base, int db, int ch8, int lane) {
+    const int a = lane & 15, g16 = (lane >> 4) & 1;
+    const int row = 4 * ch8 + (a >> 2);
+    const int cl = 2 * g16 + ((a & 3) >> 1), half = (a & 3) & 1;          // 16-byte chunk inside the 64-byte half, 8-byte half of it
+    const int hi64 = db ^ ((a >> 3) & 1);                                 // (row >> 1) & 1 == (a >> 3) & 1
+    const int m0 = ch8 & 3, m1 = (ch8 + 2) & 3;                           // (row >> 2) & 3 for the two reads
+    const unsigned char* p0 = base + row * 128 + (((4 * hi64) | (cl ^ m0)) << 4) + half * 8;
+    const unsigned char* p1 = base + (row + 8) * 128 + (((4 * hi64) | (cl ^ m1)) << 4) + half * 8;
+    const s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)p0);
+    const s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)p1);
+    s16x8_t r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
 template <bool F16>
 __device__ __forceinline__ s16x8_t pack_frag_t(const f32x16_t& p, int s) {  // registers 8s..8s+7 -> 8 x 16-bit
     const uint4 r = make_uint4(pack2<F16>(p[8 * s], p[8 * s + 1]), pack2<F16>(p[8 * s + 2], p[8 * s + 3]),
@@ -73,6 +99,20 @@ __device__ __forceinline__ void tile_lstore_vrows(const TileRegs& t, unsigned ch
     const int r = tid >> 3, c = tid & 7;
     *reinterpret_cast<uint4*>(dst + v_off(r, c)) = t.a;
     *reinterpret_cast<uint4*>(dst + v_off(r + 32, c)) = t.b;
+}
+__device__ __forceinline__ void tile_lstore_drows(const TileRegs& t, unsigned char* dst, int tid) {
+    const int r = tid >> 3, c = tid & 7;
+    *reinterpret_cast<uint4*>(dst + d_off(r, c)) = t.a;
+    *reinterpret_cast<uint4*>(dst + d_off(r + 32, c)) = t.b;
+}
+// IEEE half -> bf16 of one 16-byte chunk (the score recompute reads the saved f16 operand, the gradient-side MFMA wants bf16)
+__device__ __forceinline__ uint4 h8_to_bf8(uint4 v) {
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    unsigned o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        o[i] = pack2bf(h2f((bf16_t)(w[i] & 0xffffu)), h2f((bf16_t)(w[i] >> 16)));
+    return make_uint4(o[0], o[1], o[2], o[3]);
 }
 __device__ __forceinline__ void tile_lstore_cols(const TileRegs& t, unsigned char* dst, int tid) {
     const int r = tid >> 3, c = tid & 7;

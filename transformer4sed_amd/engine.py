@@ -209,13 +209,11 @@ class SedEngine:
         if save:
             ctx["cols"] = cols
         # per-call scratch (reused across layers when not saving)
-        # tensors that only the backward reads (row-major V, Q^T, K^T, GELU pre-activation) are produced as bf16 right away
+        # tensors that only the backward reads (GELU pre-activation) are produced as bf16 right away
         B16 = BF16 if save else A16
-        qkv_flag = 3 if (save and f16) else f16
-        # V stays f16 and row-major: the attention forward takes its transpose in LDS (ds_read_b64_tr_b16), the backward converts it in place
+        # q, k, v stay row-major: the attention forward and backward take every transposed operand out of their LDS tiles
+        # (ds_read_b64_tr_b16); the backward converts V in place and makes the bf16 images of the Q / K tiles on the way into LDS
         mk_qkv = lambda: [E(Bx * H, N, 64, dt=A16), E(Bx * H, N, 64, dt=A16), E(Bx * H, N, 64, dt=A16)]
-        use_pool = getattr(self, "_lease_ok", False) or not save
-        mk_t = lambda li: [self._zeros(("enc", li, j, Bx, Npad), (Bx * H, 64, Npad), B16, dev, use_pool) for j in range(2)]
         scratch = None
         pooled = None
         for li in range(m.depth):
@@ -224,22 +222,21 @@ class SedEngine:
             if save or scratch is None:
                 h16 = E(M, D, dt=A16)
                 q, k, v = mk_qkv()
-                qt, kt = mk_t(li) if save else (None, None)
                 o16 = E(M, D, dt=A16)
                 lse = E(Bx * H, N)
                 h2 = E(M, D, dt=A16)
                 hpre = E(M, 4 * D, dt=B16)
                 act = E(M, 4 * D, dt=A16)
                 mean1, rstd1, mean2, rstd2 = (E(M), E(M), E(M), E(M)) if save else (None, None, None, None)
-                scratch = (h16, q, k, v, qt, kt, o16, lse, h2, hpre, act)
+                scratch = (h16, q, k, v, o16, lse, h2, hpre, act)
             else:
-                h16, q, k, v, qt, kt, o16, lse, h2, hpre, act = scratch
+                h16, q, k, v, o16, lse, h2, hpre, act = scratch
                 mean1 = rstd1 = mean2 = rstd2 = None
             x_in = x
             call("sed_layernorm_fwd", x_in, self.P(p + "norm1.weight"), self.P(p + "norm1.bias"), 1e-6, 1.0, h16, None,
                  mean1, rstd1, M, D, f16)
             call("sed_gemm_qkv", h16, W[p + "attn.qkv.weight"].w, self.P(p + "attn.qkv.bias"), M, D, H, N, Npad, q, k,
-                 v, qt, kt, None, None, None, None, None, qkv_flag)
+                 v, None, None, None, None, None, None, None, f16)
             call("sed_mhsa_fwd", q, k, v, o16, lse, Bx, H, N, Npad, f16)
             x_mid = E(Bx, N, D) if save else x_in
             gemm_nt(o16, W[p + "attn.proj.weight"].w, EPI_F32_RESID, bias=self.P(p + "attn.proj.bias"), res=x_in,
@@ -252,7 +249,7 @@ class SedEngine:
             gemm_nt(act, W[p + "mlp.fc2.weight"].w, EPI_F32_RESID, bias=self.P(p + "mlp.fc2.bias"), res=x_mid,
                     outF=x_out)
             if save:
-                L.update(x_in=x_in, h16=h16, q=q, k=k, v=v, qt=qt, kt=kt, o16=o16, lse=lse, x_mid=x_mid, h2=h2,
+                L.update(x_in=x_in, h16=h16, q=q, k=k, v=v, o16=o16, lse=lse, x_mid=x_mid, h2=h2,
                          hpre=hpre, act=act, mean1=mean1, rstd1=rstd1, mean2=mean2, rstd2=rstd2)
                 ctx["layers"].append(L)
             x = x_out
@@ -697,11 +694,9 @@ class SedEngine:
         dqkv = E(M, 3 * D, dt=BF16)
         Dtmp = E(B * H, N)
         dOh = E(B * H, N, 64, dt=BF16)
-        dOt = E(B * H, 64, Npad, dt=BF16)
         f16 = is_f16(L["q"])
-        call("sed_mhsa_bwd", L["q"], to_bf16_(L["qt"]), L["k"], to_bf16_(L["kt"]), to_bf16_(L["v"]), L["o16"], do16,
-             L["lse"], Dtmp, dOh, dOt, dqkv, B, H, N, Npad, f16)
-        del dOh, dOt, do16
+        call("sed_mhsa_bwd", L["q"], L["k"], to_bf16_(L["v"]), L["o16"], do16, L["lse"], Dtmp, dOh, dqkv, B, H, N, Npad, f16)
+        del dOh, do16
         self._dw_accum(dqkv, L["h16"], M, G(p + "attn.qkv.weight"), G(p + "attn.qkv.bias"))
         dln = E(M, D)
         gemm_nt(dqkv, W[p + "attn.qkv.weight"].wt, EPI_F32, outF=dln)
