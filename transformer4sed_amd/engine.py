@@ -81,6 +81,13 @@ class SedEngine:
         self.split = os.environ.get("SED_DECODER_SPLIT", "1") != "0" and self.act == F16
         # weight gradients: TN kernel on the operands as they lie (default) or transposed copies + NT split-K kernel
         self.dw_tn = os.environ.get("SED_DW_TN", "1") != "0"
+        # weight-gradient (TN) GEMMs on a side stream: they depend only on dY and the saved operand, nothing in the backward chain
+        # reads their result, so they fill the partially occupied last rounds of the dX GEMMs and run under the HBM-bound
+        # LayerNorm / cast passes.  Joined before every stage hook and at the end of backward.  Off while the kernel timer
+        # instruments a step (interleaved kernels inflate every per-launch duration).
+        self.dw_side = os.environ.get("SED_DW_STREAM", "1") != "0"
+        self._dw_stream = None
+        self._dw_pending = False
 
     def __deepcopy__(self, memo):
         return None  # `ema_net = deepcopy(net)` (finetune/passt/setting.py:8-15): the copy rebuilds its engine lazily
@@ -488,7 +495,26 @@ class SedEngine:
         return dict(q=q, kv16=kv16, pooled=pooled, probs=probs, att=att, at_out=at_out)
 
     # ==================================================================== backward
+    def _join_dw(self):
+        """Make the current stream wait for the weight-gradient GEMMs issued on the side stream so far."""
+        if self._dw_pending:
+            torch.cuda.current_stream().wait_stream(self._dw_stream)
+            self._dw_pending = False
+
     def backward(self, ctx, grads, garena, hook=None):
+        """Backward of the whole model (see `_backward_impl`); gradients in the arena are complete when it returns, and the ones of a
+        stage are complete when its hook fires."""
+        h = hook
+        if hook is not None:
+            def h(stage):
+                self._join_dw()
+                hook(stage)
+        try:
+            return self._backward_impl(ctx, grads, garena, h)
+        finally:
+            self._join_dw()
+
+    def _backward_impl(self, ctx, grads, garena, hook=None):
         """grads: dict of upstream gradients (strong / weak / at_out / mlm_pred / frame_before_mask, any may be None).
         garena: callable name -> fp32 gradient view (zero-initialised) or None when the parameter is frozen."""
         m = self.m
@@ -633,12 +659,25 @@ class SedEngine:
                 transpose_bf16(dy, M, n_out, None, out_s=g16, colsum=bias)   # cast and/or column sums only, one pass
             dy16 = g16 if g16 is not None else dy
             if gW is not None:
-                gemm_dw_tn(dy16, x, gW, tokens=Mt, dbias=bias if bias_in_gemm else None)
-                if Mt < M:
-                    gT, xT = E(n_out, 64, dt=BF16), E(k_in, 64, dt=BF16)
-                    transpose_bf16(dy16[Mt:], M - Mt, n_out, gT)
-                    transpose_bf16(x[Mt:], M - Mt, k_in, xT)
-                    gemm_dw(gT, xT, gW)
+                def run():
+                    gemm_dw_tn(dy16, x, gW, tokens=Mt, dbias=bias if bias_in_gemm else None)
+                    if Mt < M:
+                        gT, xT = E(n_out, 64, dt=BF16), E(k_in, 64, dt=BF16)
+                        transpose_bf16(dy16[Mt:], M - Mt, n_out, gT)
+                        transpose_bf16(x[Mt:], M - Mt, k_in, xT)
+                        gemm_dw(gT, xT, gW)
+                if self.dw_side and ops.TIMER is None and dy16.is_cuda:
+                    if self._dw_stream is None:
+                        self._dw_stream = torch.cuda.Stream(device=dev)
+                    main = torch.cuda.current_stream(dev)
+                    self._dw_stream.wait_stream(main)        # dY, the saved operand and the zeroed arena are ready
+                    with torch.cuda.stream(self._dw_stream):
+                        run()
+                    dy16.record_stream(self._dw_stream)      # the caching allocator must not hand these out again before the
+                    x.record_stream(self._dw_stream)         # side stream has read them
+                    self._dw_pending = True
+                else:
+                    run()
             return dy16
         Mpad = pad64(M)
         g16 = E(M, n_out, dt=BF16) if dy.dtype == F32 else None

@@ -595,7 +595,7 @@ class PmamEngine(SedEngine):
              gpool.view(M, D), 0, G("out_norm.weight"), G("out_norm.bias"), M, D)
         return gpool
 
-    def backward(self, ctx, grads, garena, hook=None):
+    def _backward_impl(self, ctx, grads, garena, hook=None):
         m = self.m
         W = ctx["W"]
         B, Tdec, tp = ctx["B"], ctx["Tdec"], ctx["tp"]
