@@ -76,7 +76,7 @@ class KernelTimer:
 
     def __init__(self, names):
         self.names = set(names)
-        self.records = []  # (name, start_event, end_event, flops, algorithmic bytes)
+        self.records = []  # (name, start_event, end_event, algorithmic flops, algorithmic bytes, issued flops, shape key)
         self.pool = []     # recycled events: creating ~600 HIP events inside a timed step costs tens of ms of host time
 
     def event(self):
@@ -84,13 +84,13 @@ class KernelTimer:
 
     def recycle(self):
         """Drop the records, keep their events for the next instrumented step."""
-        for _, e0, e1, _, _, _ in self.records:
+        for _, e0, e1, *_ in self.records:
             self.pool += [e0, e1]
         self.records = []
 
     def summarize(self):
         out = {}
-        for name, e0, e1, fl, by, fi in self.records:
+        for name, e0, e1, fl, by, fi, _ in self.records:
             d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, flops_issued=0.0))
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
@@ -125,6 +125,17 @@ def _flops_of(name, args):
     if name == "sed_gemm_dw_tn":
         return 2.0 * args[3] * args[4] * args[5]
     return 0.0
+
+
+def _shape_of(name, args):
+    """(M, N, K, epilogue / output count) of one GEMM launch, for per-shape tables (tools/gemm_shapes.py)."""
+    if name == "sed_gemm_nt":
+        return (args[2], args[3], args[4], "epi%d" % args[7])
+    if name == "sed_gemm_qkv":
+        return (args[3], 3 * args[5] * 64, args[4], "qkv%d" % sum(a is not None for a in args[8:16]))
+    if name == "sed_gemm_dw_tn":
+        return (args[4], args[5], args[3], "tn")
+    return None
 
 
 def _bytes_of(name, args):
@@ -172,7 +183,7 @@ def call(name, *args):
         lib().call(name, *conv, _stream_of(dev))
         e1.record()
         fi = _flops_of(name, args)
-        TIMER.records.append((name, e0, e1, fi * ALG_K_SCALE, _bytes_of(name, args), fi))
+        TIMER.records.append((name, e0, e1, fi * ALG_K_SCALE, _bytes_of(name, args), fi, _shape_of(name, args)))
         return
     lib().call(name, *conv, _stream_of(dev))
 
