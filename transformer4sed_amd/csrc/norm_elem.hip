@@ -884,7 +884,7 @@ __global__ __launch_bounds__(256) void sed_head_bwd_kernel(const float* __restri
     // 2048 waves onto the same addresses were the whole 0.38 ms of this kernel)
     __shared__ float red[4][DM];
     __shared__ float redb[4][HEAD_C];
-#pragma unroll 1
+#pragma unroll   // fully unrolled: a runtime index into pw[] would put the 10 partial rows into scratch memory
     for (int c = 0; c < HEAD_C; ++c) {
         row_store(pw[c], red[wave], lane);
         if (lane == 0) redb[wave][c] = pb[c];
