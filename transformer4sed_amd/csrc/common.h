@@ -89,16 +89,19 @@ __device__ __forceinline__ f32x2v gelu_half_tail2(f32x2v x) {   // 0.5 * (1 - er
     p = p * p; p = p * p; p = p * p; p = p * p;     // overflows to +inf for |x| > ~17: rcp(inf) = 0, the exact limit
     return f32x2v{0.5f * __builtin_amdgcn_rcpf(p.x), 0.5f * __builtin_amdgcn_rcpf(p.y)};
 }
+// x Phi(x) = 0.5 x + |x| (0.5 - tail(|x|)): no compare / select per element, three packed operations after the reciprocal
 __device__ __forceinline__ f32x2v gelu_fast2(f32x2v x) {
     const f32x2v h = gelu_half_tail2(x);
-    return f32x2v{x.x * (x.x >= 0.f ? 1.0f - h.x : h.x), x.y * (x.y >= 0.f ? 1.0f - h.y : h.y)};
+    const f32x2v ax = {fabsf(x.x), fabsf(x.y)};
+    return ax * (0.5f - h) + 0.5f * x;
 }
 __device__ __forceinline__ float gelu_fast(float x) { return gelu_fast2(f32x2v{x, x}).x; }
-__device__ __forceinline__ f32x2v gelu_fast_grad2(f32x2v x) {    // Phi(x) + x phi(x)
-    const f32x2v h = gelu_half_tail2(x);
-    const f32x2v e = {__expf(-0.5f * x.x * x.x), __expf(-0.5f * x.y * x.y)};
-    return f32x2v{(x.x >= 0.f ? 1.0f - h.x : h.x) + x.x * 0.39894228040143268f * e.x,
-                  (x.y >= 0.f ? 1.0f - h.y : h.y) + x.y * 0.39894228040143268f * e.y};
+__device__ __forceinline__ f32x2v gelu_fast_grad2(f32x2v x) {    // Phi(x) + x phi(x), Phi(x) = 0.5 + sign(x) (0.5 - tail(|x|))
+    const f32x2v d = 0.5f - gelu_half_tail2(x);
+    const f32x2v sd = {__builtin_copysignf(d.x, x.x), __builtin_copysignf(d.y, x.y)};
+    const f32x2v q = x * x * -0.72134752044448170f;                 // -0.5 x^2 log2(e)
+    const f32x2v e = {__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+    return (x * 0.39894228040143268f) * e + sd + 0.5f;
 }
 __device__ __forceinline__ float gelu_fast_grad(float x) { return gelu_fast_grad2(f32x2v{x, x}).x; }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }

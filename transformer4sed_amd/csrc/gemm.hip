@@ -479,7 +479,7 @@ __device__ __forceinline__ void v3_load_consts(V3Consts<EPI>& c, const GemmArgs&
 
 template <int EPI, bool F16>
 __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&acc)[8][4], const V3Consts<EPI>& cc,
-                                            unsigned char* wl, int mb, int nb, int lane) {
+                                            unsigned char* wl, int mb, int nb, int lane, unsigned long long* gxt = nullptr) {
     // mb = first row of this wave's 128 x 64 sub-tile, nb = its first column
     const int l15 = lane & 15, lq = lane >> 4;
     if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
@@ -491,6 +491,10 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
             else if (EPI == EPI_GELU && F16 && g.bwd_bf16) pp_stage16<false, 0>(wl, acc, cc.bv, l15, lq);  // pre-activation for the bf16 backward
             else pp_stage16<F16, 0>(wl, acc, cc.bv, l15, lq);
             __builtin_amdgcn_wave_barrier();
+#ifdef GX_TRACE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (gxt != nullptr) gxt[4] = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
             for (int rb = 0; rb < 16; rb += 8) {
                 uint4 v[8];
@@ -714,10 +718,18 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     PP_MFMA(1, 0, X)                                                                                                      \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { aaddr[ks] ^= 0x8000; baddr[ks] ^= 0x8000; }
 
+#ifdef GX_TRACE
+    unsigned long long gx_t[8];
+    gx_t[0] = __builtin_amdgcn_s_memrealtime();
+#define GX_STAMP(i) gx_t[i] = __builtin_amdgcn_s_memrealtime();
+#else
+#define GX_STAMP(i)
+#endif
     // prologue: all of tile 0; then the three slots of tile 1 that the steady state would have issued during tile -1
     PP_DMA(1, 0) PP_DMA(0, 0) PP_DMA(2, 0) PP_DMA(3, 0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    GX_STAMP(1)
     if (nk > 1) { PP_DMA(1, 1) PP_DMA(0, 1) PP_DMA(2, 1) }
     if (wm == 1) __builtin_amdgcn_s_barrier();   // second wave row: half a phase behind
     PP_RD_B(0, 0, 0)
@@ -727,13 +739,31 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
         PP_TILE(it + 1, 1, 0)
     }
     if (it < nk) { PP_TILE(it, 0, 1) }
+    GX_STAMP(2)
     if (wm == 0) __builtin_amdgcn_s_barrier();   // pairs with the last barrier of waves 4-7: nobody reads the stages any more
+    GX_STAMP(3)
 #undef PP_DMA
 #undef PP_RD_A
 #undef PP_RD_B
 #undef PP_MFMA
 #undef PP_TILE
+#ifdef GX_TRACE
+    pp_epilogue<EPI, F16>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * 128, n0 + wn * 64, lane, gx_t);
+    GX_STAMP(5)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GX_STAMP(6)
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
+        // developer trace: stamps of every wave of workgroups 0, 100 and 300 behind the output matrix (tools/epi_trace.py)
+        const int slot = blockIdx.x == 0 ? 0 : (blockIdx.x == 100 ? 1 : (blockIdx.x == 300 ? 2 : -1));
+        if (slot >= 0 && lane == 0) {
+            unsigned long long* tr = reinterpret_cast<unsigned long long*>((EPI == EPI_GELU ? g.outH2 : g.outH) + (size_t)g.M * g.ldc) + (slot * 8 + wave) * 8;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) tr[i] = gx_t[i];
+        }
+    }
+#else
     pp_epilogue<EPI, F16>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * 128, n0 + wn * 64, lane);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
