@@ -47,6 +47,7 @@ struct GemmArgs {
     int seq, seq_pad, heads;
     int bwd_bf16; // f16 runs only: tensors that only the (bf16) backward consumes are written as bf16 straight away
     int group_m;  // 256^2 kernel: tile rows per L2 group (see gemm_nt_pp_kernel)
+    int persist;  // 256^2 kernel: one workgroup per CU walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ...
     int ncols;    // 128^2 kernel: output columns >= ncols are computed but not written (operands padded to the tile width)
 };
 
@@ -622,11 +623,20 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 template <int EPI, bool F16>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+#ifdef GX_TRACE
+    const unsigned long long gx_top = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int ntn = g.N / V3_T, ntm = (g.M + V3_T - 1) / V3_T, nwg = ntm * ntn;
-    const int t = xcd_remap(blockIdx.x, nwg);
+    // Persistent form: gridDim.x = number of CUs, every workgroup walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x is
+    // a multiple of 8, so a workgroup's tiles stay on its XCD and the L2 grouping below is unchanged).  Measured per 256^2 tile with
+    // one launch per tile: 1.6 us between the last store of a workgroup and the first instruction of the next one on that CU plus
+    // 0.5 us of kernel-argument / address setup (tools/epi_gaps.py) against a 17 us K = 768 main loop.
+    const int tstep = g.persist ? (int)gridDim.x : nwg;
+    for (int tl = blockIdx.x; tl < nwg; tl += tstep) {
+    const int t = xcd_remap(tl, nwg);
     const int GM = g.group_m;
     const int group_size = GM * ntn, gid = t / group_size, first_m = gid * GM;
     const int gm = (ntm - first_m) < GM ? (ntm - first_m) : GM;
@@ -760,10 +770,21 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 7; ++i) tr[i] = gx_t[i];
         }
+        // every workgroup: (hardware id, first instruction, entry stamp, last store acknowledged) of wave 0 -> occupancy gaps per CU
+        if (wave == 0 && lane == 0) {
+            unsigned long long* wr = reinterpret_cast<unsigned long long*>((EPI == EPI_GELU ? g.outH2 : g.outH) + (size_t)g.M * g.ldc) + 256 + 4 * blockIdx.x;
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            wr[0] = ((unsigned long long)xcc << 32) | hw;
+            wr[1] = gx_top; wr[2] = gx_t[0]; wr[3] = gx_t[6];
+        }
     }
 #else
     pp_epilogue<EPI, F16>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * 128, n0 + wn * 64, lane);
 #endif
+    if (tl + tstep < nwg) __syncthreads();   // the staging areas overlap the operand stages the next tile's DMA is about to fill
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1072,6 +1093,16 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
         // from the Infinity Cache -- while the time is best at 4 (fc2 1186 vs 998 TFLOP/s at 2): the counter does not track the time.
         GemmArgs gg = g;
         gg.group_m = 4;
+        static const int persist_env = getenv("SED_GEMM_PERSIST") ? atoi(getenv("SED_GEMM_PERSIST")) : 1;
+        static int ncu = 0;
+        if (ncu == 0) {
+            int dev = 0, n = 0;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+            ncu = n & ~7;   // whole XCD rounds: blockIdx.x & 7 must stay the XCD of every tile a workgroup walks
+        }
+        gg.persist = (persist_env && (int)grid3.x > ncu) ? 1 : 0;
+        if (gg.persist) grid3.x = ncu;
         const GemmArgs& g = gg;
         static bool attrp[2] = {false, false};
         if (f16) {
