@@ -2,7 +2,9 @@
 import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1]
-flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffast-math", "-fno-finite-math-only", "-I" + os.path.join(root, "include")] + sys.argv[2:]
+sys.path.insert(0, root)
+from transformer4sed_amd.build import FLAGS, FILE_FLAGS   # the flags the library itself is built with (per file)
+flags = [f for f in FLAGS if f != "-fPIC"] + FILE_FLAGS.get(os.path.basename(src), []) + ["-I" + os.path.join(root, "include")] + sys.argv[2:]
 asm = subprocess.run(["/opt/rocm/bin/hipcc", *flags, "-S", "--cuda-device-only", src, "-o", "-"], capture_output=True, text=True).stdout
 cur = {}
 
