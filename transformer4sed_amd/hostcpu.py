@@ -48,8 +48,12 @@ def cap_torch_threads():
         return
     import torch
     if want is not None:
-        if int(want) > 0:
-            torch.set_num_threads(int(want))
+        try:
+            n = int(want)
+        except ValueError:
+            raise ValueError(f"SED_HOST_THREADS must be an integer (0 = leave torch's thread pool alone), got {want!r}") from None
+        if n > 0:
+            torch.set_num_threads(n)
         return
     cap = max(1, usable_cpus() // 4)
     if torch.get_num_threads() > cap:
