@@ -92,7 +92,8 @@ int sed_mhsa_bwd_prep(const void* dO, const void* O, float* Dtmp, void* dOh, voi
                       int o_f16, hipStream_t stream);
 /* dqkv [B*N, 3*768] bf16 (dq | dk | dv).  f16 != 0: Q, K, O are IEEE half (as the f16 forward wrote them, used for the
  * score recompute), the gradient-side operands V, dO are bf16.  Transposed operands are taken out of row-major LDS tiles with
- * transposing reads: no Q^T / K^T / dO^T copies (sed_mhsa_bwd_prep accepts dOt == NULL). */
+ * transposing reads (no Q^T / K^T / dO^T copies); dO and O are read in their token-major [B, N, 768] layout and D = rowsum(dO * O)
+ * is produced by the dQ kernel into Dtmp [B*H, N] -- no pre-pass; dOh is unused (may be NULL). */
 int sed_mhsa_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, float* Dtmp,
                  void* dOh, void* dqkv, int B, int H, int N, int Npad, int f16, hipStream_t stream);
 /* Transformer-XL rel-pos attention (src/models/transformer/transformerXL.py:493-576 incl. rel_shift 254-297) */

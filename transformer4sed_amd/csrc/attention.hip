@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_prep_kernel(const bf16_t* __rest
 template <bool SF16>
 __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
-    const bf16_t* __restrict__ dOh, const float* __restrict__ LSE, const float* __restrict__ Dv,
+    const bf16_t* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ Dv,
     bf16_t* __restrict__ dqkv, int N, int Npad, int H) {
     // LDS per stage: Q rows (S type, row fragments), Q rows bf16 (transposing reads; the same tile when the forward ran in bf16),
     // dO rows bf16 (dual use: row fragments for dP, transposing reads for dV), L2[64], D[64]
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_kernel(
     auto gload = [&](int t) {
         const int i0 = t * 64;
         tile_gload(rq, Q + hb, i0, N, HD, 0, tid);
-        tile_gload(rdo, dOh + hb, i0, N, HD, 0, tid);
+        tile_gload(rdo, dO + (size_t)b * N * (H * HD), i0, N, H * HD, h * HD, tid);   // token-major dO [B, N, H * 64]: no head-split copy
         if (tid < 128) {
             const int qi = i0 + (tid & 63);
             const float* src = (tid < 64) ? LSE : Dv;
@@ -371,8 +371,9 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_kernel(
 template <bool SF16>
 __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                           const bf16_t* __restrict__ V,
-                                                          const bf16_t* __restrict__ dOh, const float* __restrict__ LSE,
-                                                          const float* __restrict__ Dv, bf16_t* __restrict__ dqkv,
+                                                          const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O,
+                                                          const float* __restrict__ LSE,
+                                                          float* __restrict__ Dv, bf16_t* __restrict__ dqkv,
                                                           int N, int Npad, int H) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][3][KVB * 128];  // K rows (S type), V rows, K rows bf16 (dual use)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
@@ -382,13 +383,22 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const bf16_t* __restri
     int qrow = q0 + lr;
     const bool qvalid = qrow < N;
     qrow = qvalid ? qrow : N - 1;
+    // dO and O rows of this lane's query straight from the token-major [B, N, H * 64] tensors (the pre-pass that made head-split
+    // copies and D = rowsum(dO * O) is gone: D is one shuffle away here, and the dK/dV kernel, launched afterwards, reads it)
+    const size_t trow = ((size_t)b * N + qrow) * (H * HD) + h * HD;
     s16x8_t qf[4], dof[4];
+    float dd = 0.f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         qf[s] = *reinterpret_cast<const s16x8_t*>(Q + hb + (size_t)qrow * HD + 16 * s + 8 * lg);
-        dof[s] = *reinterpret_cast<const s16x8_t*>(dOh + hb + (size_t)qrow * HD + 16 * s + 8 * lg);
+        dof[s] = *reinterpret_cast<const s16x8_t*>(dO + trow + 16 * s + 8 * lg);
+        const s16x8_t of = *reinterpret_cast<const s16x8_t*>(O + trow + 16 * s + 8 * lg);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dd += bf2f((bf16_t)dof[s][e]) * to_f32<SF16>((bf16_t)of[e]);
     }
-    const float l2 = LSE[(size_t)bh * N + qrow], dd = Dv[(size_t)bh * N + qrow];
+    dd += __shfl_xor(dd, 32, 64);
+    if (lg == 0 && qvalid) Dv[(size_t)bh * N + qrow] = dd;
+    const float l2 = LSE[(size_t)bh * N + qrow];
     f32x16_t dq[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -480,16 +490,17 @@ extern "C" int sed_mhsa_bwd_prep(const void* dO, const void* O, float* Dtmp, voi
 extern "C" int sed_mhsa_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
                             float* Dtmp, void* dOh, void* dqkv, int B, int H, int N, int Npad, int f16, hipStream_t stream) {
     (void)hipGetLastError();
-    // f16 != 0: Q, K (score recompute) and O are IEEE half as written by the forward; V, dO are bf16.
+    // f16 != 0: Q, K (score recompute) and O are IEEE half as written by the forward; V, dO are bf16.  dOh is unused since the kernels
+    // read dO / O in their token-major layout (kept in the signature for ABI stability; may be NULL).
+    (void)dOh;
     if (N <= 0 || Npad % 64 || Npad < N) return SED_ERR_ARG;
-    int rc = sed_mhsa_bwd_prep(dO, O, Dtmp, dOh, nullptr, B, H, N, Npad, f16, stream);
-    if (rc) return rc;
     dim3 grid(cdiv(N, 128), B * H);
+    // dQ first: it also produces D = rowsum(dO * O), which the dK/dV kernel reads
 #define SED_LAUNCH_BWD(F)                                                                                              \
-    hipLaunchKernelGGL(mhsa_bwd_dkdv_kernel<F>, grid, dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,        \
-                       (const bf16_t*)V, (const bf16_t*)dOh, LSE, Dtmp, (bf16_t*)dqkv, N, Npad, H);                    \
     hipLaunchKernelGGL(mhsa_bwd_dq_kernel<F>, grid, dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,          \
-                       (const bf16_t*)V, (const bf16_t*)dOh, LSE, Dtmp, (bf16_t*)dqkv, N, Npad, H);
+                       (const bf16_t*)V, (const bf16_t*)dO, (const bf16_t*)O, LSE, Dtmp, (bf16_t*)dqkv, N, Npad, H);   \
+    hipLaunchKernelGGL(mhsa_bwd_dkdv_kernel<F>, grid, dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,        \
+                       (const bf16_t*)V, (const bf16_t*)dO, LSE, Dtmp, (bf16_t*)dqkv, N, Npad, H);
     if (f16) { SED_LAUNCH_BWD(true) } else { SED_LAUNCH_BWD(false) }
 #undef SED_LAUNCH_BWD
     return sed_check_launch();

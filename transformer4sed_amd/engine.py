@@ -732,10 +732,9 @@ class SedEngine:
         gemm_nt(g16, W[p + "attn.proj.weight"].wt, EPI_BF16, outH=do16)
         dqkv = E(M, 3 * D, dt=BF16)
         Dtmp = E(B * H, N)
-        dOh = E(B * H, N, 64, dt=BF16)
         f16 = is_f16(L["q"])
-        call("sed_mhsa_bwd", L["q"], L["k"], to_bf16_(L["v"]), L["o16"], do16, L["lse"], Dtmp, dOh, dqkv, B, H, N, Npad, f16)
-        del dOh, do16
+        call("sed_mhsa_bwd", L["q"], L["k"], to_bf16_(L["v"]), L["o16"], do16, L["lse"], Dtmp, None, dqkv, B, H, N, Npad, f16)
+        del do16
         self._dw_accum(dqkv, L["h16"], M, G(p + "attn.qkv.weight"), G(p + "attn.qkv.bias"))
         dln = E(M, D)
         gemm_nt(dqkv, W[p + "attn.qkv.weight"].wt, EPI_F32, outF=dln)
