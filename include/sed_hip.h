@@ -91,11 +91,12 @@ int sed_mhsa_fwd(const void* Q, const void* K, const void* V, void* O, float* LS
 int sed_mhsa_bwd_prep(const void* dO, const void* O, float* Dtmp, void* dOh, void* dOt, int B, int H, int N, int Npad,
                       int o_f16, hipStream_t stream);
 /* dqkv [B*N, 3*768] bf16 (dq | dk | dv).  f16 != 0: Q, K, O are IEEE half (as the f16 forward wrote them, used for the
- * score recompute), the gradient-side operands V, dO are bf16.  Transposed operands are taken out of row-major LDS tiles with
+ * score recompute), the gradient-side operand dO is bf16; V is bf16, or with v_f16 != 0 the IEEE half tensor the forward saved (its bf16
+ * operand image is made inside the kernels).  Transposed operands are taken out of row-major LDS tiles with
  * transposing reads (no Q^T / K^T / dO^T copies); dO and O are read in their token-major [B, N, 768] layout and D = rowsum(dO * O)
  * is produced by the dQ kernel into Dtmp [B*H, N] -- no pre-pass; dOh is unused (may be NULL). */
 int sed_mhsa_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, float* Dtmp,
-                 void* dOh, void* dqkv, int B, int H, int N, int Npad, int f16, hipStream_t stream);
+                 void* dOh, void* dqkv, int B, int H, int N, int Npad, int f16, int v_f16, hipStream_t stream);
 /* Transformer-XL rel-pos attention (src/models/transformer/transformerXL.py:493-576 incl. rel_shift 254-297) */
 int sed_relpos_attn_fwd(const void* Qu, const void* Qv, const void* K, const void* Vt, const void* P, void* O,
                         float* LSE, int B, int H, int T, int Tpad, int Rpad, int f16, int o_f32, hipStream_t stream);

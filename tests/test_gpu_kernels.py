@@ -254,7 +254,7 @@ def test_mhsa_fwd_bwd(B, N, DT):
     Dt = torch.empty(B * Hh, N, device=DEV)
     dOh = torch.empty(B * Hh, N, 64, dtype=BF16, device=DEV)
     dOt = torch.empty(B * Hh, 64, Npad, dtype=BF16, device=DEV)
-    call("sed_mhsa_bwd", q.to(DT), k.to(DT), v.to(BF16), O, dO.to(BF16), lse, Dt, dOh, dqkv, B, Hh, N, Npad, f16)
+    call("sed_mhsa_bwd", q.to(DT), k.to(DT), v.to(DT), O, dO.to(BF16), lse, Dt, None, dqkv, B, Hh, N, Npad, f16, f16)   # V as the forward saved it
     g = dqkv.float().view(B, N, 3, Hh, 64).permute(2, 0, 3, 1, 4).reshape(3, B * Hh, N, 64)
     for i, (ref, nm) in enumerate(((qq.grad, "dq"), (kk.grad, "dk"), (vv.grad, "dv"))):
         e = maxerr(g[i], ref); sc = float(ref.abs().max()); report(f"mhsa bwd {nm} N={N} {DT}", e, sc)

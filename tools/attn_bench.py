@@ -36,7 +36,7 @@ call("sed_mhsa_fwd", q, k, v.half(), o, lse, B, H, N, Npad, 1)
 do = (torch.randn(B, N, H * 64, device=dev) * 0.1).to(BF)
 Dt = torch.empty(B * H, N, device=dev); dOh = torch.empty(B * H, N, 64, dtype=BF, device=dev)
 dOt = torch.zeros(B * H, 64, Npad, dtype=BF, device=dev); dqkv = torch.empty(B * N, 3 * H * 64, dtype=BF, device=dev)
-fb = lambda: call("sed_mhsa_bwd", q, k, v, o, do, lse, Dt, dOh, dqkv, B, H, N, Npad, 1)
+fb = lambda: call("sed_mhsa_bwd", q, k, v, o, do, lse, Dt, None, dqkv, B, H, N, Npad, 1, 0)
 fb(); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()

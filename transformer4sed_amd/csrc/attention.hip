@@ -246,7 +246,7 @@ template <bool SF16>
 __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
     const bf16_t* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ Dv,
-    bf16_t* __restrict__ dqkv, int N, int Npad, int H) {
+    bf16_t* __restrict__ dqkv, int N, int Npad, int H, int v_is_f16) {
     // LDS per stage: Q rows (S type, row fragments), Q rows bf16 (transposing reads; the same tile when the forward ran in bf16),
     // dO rows bf16 (dual use: row fragments for dP, transposing reads for dV), L2[64], D[64]
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][3][KVB * 128];
@@ -262,7 +262,8 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_kernel(
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         kf[s] = *reinterpret_cast<const s16x8_t*>(K + hb + (size_t)krow * HD + 16 * s + 8 * lg);
-        vf[s] = *reinterpret_cast<const s16x8_t*>(V + hb + (size_t)krow * HD + 16 * s + 8 * lg);
+        const uint4 vraw = *reinterpret_cast<const uint4*>(V + hb + (size_t)krow * HD + 16 * s + 8 * lg);
+        vf[s] = __builtin_bit_cast(s16x8_t, (SF16 && v_is_f16) ? h8_to_bf8(vraw) : vraw);   // saved V is f16: bf16 operand made here
     }
     f32x16_t dk[2], dv[2];
 #pragma unroll
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O,
                                                           const float* __restrict__ LSE,
                                                           float* __restrict__ Dv, bf16_t* __restrict__ dqkv,
-                                                          int N, int Npad, int H) {
+                                                          int N, int Npad, int H, int v_is_f16) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][3][KVB * 128];  // K rows (S type), V rows, K rows bf16 (dual use)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
@@ -420,7 +421,14 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const bf16_t* __restri
         } else {
             tile_lstore_drows(rk, lds[buf][2], tid);
         }
-        tile_lstore_rows(rv, lds[buf][1], tid);
+        if (SF16 && v_is_f16) {   // the saved V is IEEE half: its bf16 operand image is made on the way into LDS
+            TileRegs vb;
+            vb.a = h8_to_bf8(rv.a);
+            vb.b = h8_to_bf8(rv.b);
+            tile_lstore_rows(vb, lds[buf][1], tid);
+        } else {
+            tile_lstore_rows(rv, lds[buf][1], tid);
+        }
     };
     gload(0);
     lstore(0);
@@ -488,9 +496,11 @@ extern "C" int sed_mhsa_bwd_prep(const void* dO, const void* O, float* Dtmp, voi
 }
 
 extern "C" int sed_mhsa_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
-                            float* Dtmp, void* dOh, void* dqkv, int B, int H, int N, int Npad, int f16, hipStream_t stream) {
+                            float* Dtmp, void* dOh, void* dqkv, int B, int H, int N, int Npad, int f16, int v_f16,
+                            hipStream_t stream) {
     (void)hipGetLastError();
-    // f16 != 0: Q, K (score recompute) and O are IEEE half as written by the forward; V, dO are bf16.  dOh is unused since the kernels
+    // f16 != 0: Q, K (score recompute) and O are IEEE half as written by the forward; dO is bf16; V is bf16, or IEEE half as saved by
+    // the forward when v_f16 != 0 (converted inside the kernels).  dOh is unused since the kernels
     // read dO / O in their token-major layout (kept in the signature for ABI stability; may be NULL).
     (void)dOh;
     if (N <= 0 || Npad % 64 || Npad < N) return SED_ERR_ARG;
@@ -498,9 +508,10 @@ extern "C" int sed_mhsa_bwd(const void* Q, const void* K, const void* V, const v
     // dQ first: it also produces D = rowsum(dO * O), which the dK/dV kernel reads
 #define SED_LAUNCH_BWD(F)                                                                                              \
     hipLaunchKernelGGL(mhsa_bwd_dq_kernel<F>, grid, dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,          \
-                       (const bf16_t*)V, (const bf16_t*)dO, (const bf16_t*)O, LSE, Dtmp, (bf16_t*)dqkv, N, Npad, H);   \
+                       (const bf16_t*)V, (const bf16_t*)dO, (const bf16_t*)O, LSE, Dtmp, (bf16_t*)dqkv, N, Npad, H,   \
+                       v_f16);                                                                                         \
     hipLaunchKernelGGL(mhsa_bwd_dkdv_kernel<F>, grid, dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,        \
-                       (const bf16_t*)V, (const bf16_t*)dO, LSE, Dtmp, (bf16_t*)dqkv, N, Npad, H);
+                       (const bf16_t*)V, (const bf16_t*)dO, LSE, Dtmp, (bf16_t*)dqkv, N, Npad, H, v_f16);
     if (f16) { SED_LAUNCH_BWD(true) } else { SED_LAUNCH_BWD(false) }
 #undef SED_LAUNCH_BWD
     return sed_check_launch();

@@ -733,7 +733,7 @@ class SedEngine:
         dqkv = E(M, 3 * D, dt=BF16)
         Dtmp = E(B * H, N)
         f16 = is_f16(L["q"])
-        call("sed_mhsa_bwd", L["q"], L["k"], to_bf16_(L["v"]), L["o16"], do16, L["lse"], Dtmp, None, dqkv, B, H, N, Npad, f16)
+        call("sed_mhsa_bwd", L["q"], L["k"], L["v"], L["o16"], do16, L["lse"], Dtmp, None, dqkv, B, H, N, Npad, f16, is_f16(L["v"]))
         del do16
         self._dw_accum(dqkv, L["h16"], M, G(p + "attn.qkv.weight"), G(p + "attn.qkv.bias"))
         dln = E(M, D)
