@@ -204,10 +204,32 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     a = ap.parse_args()
 
+    one_gpu = os.environ.get("SED_BENCH_ONE_GPU") == "1"
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # `python bench.py --gpus N` on its own: become N ranks (one process per GPU) through torch.distributed.run, exactly the
+        # command the driver would have used; the children take the branch below
+        have = torch.cuda.device_count()
+        if have < a.gpus and not one_gpu:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: only {have} HIP device(s) visible (one rank per GPU; nothing was measured)")
+        import socket
+        import subprocess
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")))
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus} was started with WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(torch.distributed.run --nproc-per-node {a.gpus}) or drop the launcher and let --gpus start the ranks")
+    if world > 1 and not one_gpu and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} HIP device(s) visible")
     force_ddp = os.environ.get("SED_DDP_FORCE") == "1"   # exercise the RCCL gradient path on a single rank (debugging aid)
     if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -218,23 +240,30 @@ def main():
         # debugging aid for boxes with a single GPU: SED_BENCH_BACKEND=gloo SED_BENCH_ONE_GPU=1 runs every rank on cuda:0 with
         # host-staged collectives, which exercises the whole N > 1 control flow (RCCL itself refuses two ranks on one device)
         backend = os.environ.get("SED_BENCH_BACKEND", "nccl")
-        if os.environ.get("SED_BENCH_ONE_GPU") == "1":
+        if one_gpu:
             local = 0           # (LOCAL_RANK still decides who builds)
         torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != world:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, expected {world}")
+        world = dist.get_world_size()      # n_gpus / global_batch below come from the LIVE group, not from the flag
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    import __graft_entry__
+    # the product library only: the benchmark process never imports the checker (oracle/); the cpu_baseline leg runs it in a child
+    from transformer4sed_amd import build as _build, hostcpu
+    from transformer4sed_amd import _lib as _L
     if world > 1:
         # one builder per node: concurrent hipcc runs writing the same libsed_hip.so would corrupt it
         if int(os.environ.get("LOCAL_RANK", "0")) == 0:
-            __graft_entry__.build()
+            _build.build(verbose=False)
         dist.barrier()
-    __graft_entry__.build()   # up to date by now: dlopen + symbol check only
+    _build.build(verbose=False)   # up to date by now
+    _L.lib()                      # dlopen + every symbol of include/sed_hip.h
+    hostcpu.cap_torch_threads()   # entry points opt in to the host-thread cap; importing the package does not
     from transformer4sed_amd import ops, synth
     from transformer4sed_amd.ddp import GradBucketReducer
     import random
@@ -328,7 +357,8 @@ def main():
                    "val": "clips/sec (10 s clips) MAT-SED validation step (student + teacher, 17 windows, score tables + events)",
                    "pmam": "clips/sec (10 s clips) PMAM post-pretrain step (PaSST_CNN: LoRA encoder + CNN branch, prototype BCE)"}[a.mode],
         "value": round(value, 3), "unit": "clips/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * dt / a.steps, 3),
+        "n_gpus": world, "ranks": dist.get_world_size() if dist.is_initialized() else 1,
+        "collective_backend": (dist.get_backend() if dist.is_initialized() else None), "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * dt / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16 fwd / bf16 bwd MFMA operands, fp32 accumulate + residual stream",
         "data": "synthetic (DESED-shaped 320000-sample clips @32 kHz, deterministic synthetic weights)",
@@ -356,9 +386,15 @@ def main():
         by = sum(v["bytes"] for v in summ.values())
         # PMC figures (separate rocprofv3 passes over this command, tools/gemm_traffic.py / tools/mfma_util.py) are keyed by mode:
         # a mode without a committed profile reports null, never another workload's numbers
+        # ... and only for the configuration the profile was taken on (depth 12, the mode's default per-GPU batch)
         def prof(kind):
-            path = os.path.join(ROOT, "profiles", f"r2_gemm_{kind}_{a.mode}.json")
-            return (json.load(open(path)), os.path.relpath(path, ROOT)) if os.path.exists(path) else (None, None)
+            if a.depth != 12 or a.batch is not None:
+                return None, None
+            for rnd in ("r3", "r2"):
+                path = os.path.join(ROOT, "profiles", f"{rnd}_gemm_{kind}_{a.mode}.json")
+                if os.path.exists(path):
+                    return json.load(open(path)), os.path.relpath(path, ROOT)
+            return None, None
         tj, tsrc = prof("traffic")
         mj, msrc = prof("mfma_busy")
         line["roofline"] = {"kernel": "gemm_nt_pp_kernel<EPI,F16> / gemm_tn_dw_kernel / gemm_nt_kernel (all GEMM launches of the step: "

@@ -114,3 +114,138 @@ def test_param_groups_and_optimizer_runs_cpu():
     assert len(runs) == 2 and all(a % 64 == 0 and b % 64 == 0 for a, b in runs)
     assert net._flat_layout is opt and opt.arena.numel() == opt.total
     assert net.classifier.weight.data_ptr() == opt.arena[opt.offset["classifier.weight"][0]:].data_ptr()
+
+
+class _P:
+    def __init__(self, rg=True):
+        self.requires_grad = rg
+
+
+class _FakeNet2(_FakeNet):
+    def __init__(self):
+        self.params = {n: _P() for n in NAMES}
+
+    def named_parameters(self):
+        return list(self.params.items())
+
+
+def test_small_stages_are_carried_and_merged(monkeypatch):
+    """`min_bytes`: a stage smaller than the threshold does not get a collective of its own -- it rides with the next stage (adjacent
+    slices merged) or with the end-of-backward flush; nothing is dropped and nothing is reduced twice."""
+    from transformer4sed_amd.ddp import GradBucketReducer
+    stages = ["decoder", "heads", ("block", 1), ("block", 0), "embed"]
+
+    def run(min_bytes):
+        net, opt = _FakeNet2(), _FakeOpt(_layout())
+        red = GradBucketReducer(net, opt, min_bytes=min_bytes)
+        red.force = True
+        calls, at_hook = [], []
+        monkeypatch.setattr(red, "_reduce", lambda t: calls.append((t.data_ptr(), t.numel())))
+        net._last_grad_arena = torch.zeros(opt.total)
+        base = net._last_grad_arena.data_ptr()
+        for st in stages:
+            red.on_stage(st)
+            at_hook.append(len(calls))
+        red.allreduce_grads()
+        spans = sorted(((p - base) // 4, (p - base) // 4 + k) for p, k in calls)
+        pos = 0
+        for a, b in spans:          # a partition of the arena: complete, no overlap
+            assert a == pos
+            pos = b
+        assert pos == opt.total
+        assert red.carry == [] and red.fired == set()
+        return at_hook, len(calls)
+    eager, n_eager = run(0)
+    lazy, n_lazy = run(4 * 2500)
+    assert eager[0] > 0 and lazy[0] == 0          # the first (small) stage waits for company
+    assert n_lazy < n_eager                        # carried slices merge with their arena neighbours
+
+
+def test_ranges_follow_requires_grad_changes(monkeypatch):
+    """Layer-wise unfreezing: a parameter un-frozen after the reducer was built must join the exchange."""
+    from transformer4sed_amd.ddp import GradBucketReducer
+    net, opt = _FakeNet2(), _FakeOpt(_layout())
+    net.params["backbone.blocks.0.attn.qkv.weight"].requires_grad = False
+    net.params["backbone.blocks.0.mlp.fc1.weight"].requires_grad = False
+    red = GradBucketReducer(net, opt, min_bytes=0)
+    assert ("block", 0) not in red.ranges
+    net.params["backbone.blocks.0.mlp.fc1.weight"].requires_grad = True
+    net._last_grad_arena = torch.zeros(opt.total)
+    red.force = True
+    calls = []
+    monkeypatch.setattr(red, "_reduce", lambda t: calls.append(t.numel()))
+    red.on_stage("decoder")
+    assert ("block", 0) in red.ranges and len(red.ranges[("block", 0)]) == 1
+    red.allreduce_grads()
+    o, k = [(o, k) for n, o, k in opt.layout if n == "backbone.blocks.0.mlp.fc1.weight"][0]
+    assert any(a <= o and o + k <= b for a, b in red.last_issued)
+
+
+def test_rank_sharded_batch_sampler():
+    """Per-rank batch stream (SURVEY 8(e) 'Partitioning'): disjoint indices, the reference's strong | weak | unlabeled order on every
+    rank, equal group sizes, and the union over ranks of batch i == the reference sampler's batch i."""
+    from torch.utils.data import RandomSampler, SequentialSampler
+    from transformer4sed_amd.data import ConcatDatasetBatchSampler, RankShardedBatchSampler
+    sizes, bs, world = [40, 24, 64], [4, 4, 8], 2
+
+    def samplers(seq):
+        return [SequentialSampler(range(n)) if seq else RandomSampler(range(n)) for n in sizes]
+    ref = list(ConcatDatasetBatchSampler(samplers(True), bs))
+    ranks = [list(RankShardedBatchSampler(samplers(True), bs, rank=r, world=world)) for r in range(world)]
+    assert len(ranks[0]) == len(ref) == 6
+    offs = [0, 40, 64, 128]
+    for i, gb in enumerate(ref):
+        parts = [ranks[r][i] for r in range(world)]
+        assert all(len(p) == sum(bs) // world for p in parts)
+        assert not set(parts[0]) & set(parts[1])
+        pos = 0
+        for g, size in enumerate(bs):       # group by group: rank-major concatenation of the shares = the global group
+            per = size // world
+            share = [p[pos // world: pos // world + per] for p in parts]
+            assert share[0] + share[1] == gb[pos:pos + size]
+            assert all(offs[g] <= j < offs[g + 1] for sh in share for j in sh)
+            pos += size
+    # shuffled samplers: the same permutation on every rank (seeded per epoch), a different one next epoch
+    r0 = RankShardedBatchSampler(samplers(False), bs, rank=0, world=world, seed=7)
+    r1 = RankShardedBatchSampler(samplers(False), bs, rank=1, world=world, seed=7)
+    e0 = [list(r0), list(r1)]
+    seen = [j for b0, b1 in zip(*e0) for j in b0 + b1]
+    assert len(seen) == len(set(seen))
+    r0.set_epoch(1); r1.set_epoch(1)
+    e1 = [list(r0), list(r1)]
+    assert e1[0] != e0[0]
+    seen = [j for b0, b1 in zip(*e1) for j in b0 + b1]
+    assert len(seen) == len(set(seen))
+    with pytest.raises(ValueError):
+        RankShardedBatchSampler(samplers(True), [3, 4, 8], rank=0, world=2)
+
+
+def _bn_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from transformer4sed_amd.ddp import broadcast_buffers
+    net = torch.nn.Sequential(torch.nn.Conv2d(1, 4, 3), torch.nn.BatchNorm2d(4))
+    torch.manual_seed(10 + rank)
+    net.train()
+    for _ in range(rank + 2):       # ranks see different data and even different step counts
+        net(torch.randn(3, 1, 8, 8))
+    mine = {k: v.clone() for k, v in net.named_buffers()}
+    n = broadcast_buffers(net, src=0)
+    assert n == 3
+    got = torch.cat([b.reshape(-1).double() for _, b in net.named_buffers()])
+    both = [torch.empty_like(got) for _ in range(world)]
+    dist.all_gather(both, got)
+    assert torch.equal(both[0], both[1])
+    if rank == 0:       # rank 0 keeps its own statistics bit for bit, num_batches_tracked included
+        assert all(torch.equal(mine[k], v) for k, v in net.named_buffers())
+    else:
+        assert int(net[1].num_batches_tracked) == 2 and net[1].num_batches_tracked.dtype == torch.int64
+    dist.destroy_process_group()
+
+
+def test_batchnorm_buffers_follow_rank0():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_bn_worker, args=(2, port), nprocs=2, join=True)

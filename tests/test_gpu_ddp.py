@@ -187,3 +187,120 @@ def test_rccl_collectives_run_beside_the_compute_stream():
         torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ whole trainers under two ranks
+def _gather_equal(t, world):
+    import torch.distributed as dist
+    mine = t.detach().cpu()
+    both = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    return all(torch.equal(both[0], b) for b in both[1:])
+
+
+def _trainer_worker(rank, world, port, kind, q):
+    """Two ranks on cuda:0 (gloo): the REAL train step -- frontend, augmentation with rank-specific draws, student forward / backward
+    with stage hooks + side-stream weight gradients, teacher windows on the second stream, reducer, fused AdamW + EMA -- twice; then
+    parameters, EMA and Adam moments must be bit-identical on both ranks although every rank saw different clips."""
+    try:
+        import json
+        import random
+        import sys
+        import numpy as np
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        from transformer4sed_amd import synth
+        from transformer4sed_amd.ddp import GradBucketReducer
+        random.seed(50 + rank); np.random.seed(50 + rank); torch.manual_seed(50 + rank)
+        if kind == "matsed":
+            B = 6
+            net, ema_net, opt, trainer, _ = bench.build(B, DEPTH, dev, "finetune2")
+            trainer.cfg = json.loads(json.dumps(bench.FINETUNE2))
+            trainer.cfg["training"]["batch_size"] = [2, 0, 2, 2]
+            labels = torch.from_numpy(synth.synth_batch_labels(2, 2, 2, seed=60 + rank)).to(dev)
+            step = lambda wav: trainer.finetune_step(wav, labels.clone())
+            assert trainer.overlap_teacher      # the teacher's windows run on the second stream (and the dW GEMMs on the side stream)
+        else:
+            B = 4
+            net, opt, trainer = bench.build_pmam(DEPTH, dev)
+            ema_net = None
+            labels = torch.from_numpy(synth.synth_strong_labels(B, n_classes=30, seed=60 + rank)).to(dev)
+            step = lambda wav: trainer.step(wav, labels.clone())
+        trainer.ddp = GradBucketReducer(net, opt)
+        start = opt.arena.detach().clone()
+        assert _gather_equal(opt.arena, world), "replicas must start from the same weights"
+        losses = []
+        for it in range(2):
+            wav = torch.from_numpy(synth.synth_wav(B, seed=70 + 10 * it + rank)).to(dev)
+            out = step(wav)
+            losses.append(float(out["loss_total"]))
+            assert trainer.ddp.last_issued, "no gradient slice was exchanged"
+        torch.cuda.synchronize()
+        assert all(np.isfinite(losses))
+        both = [None] * world
+        dist.all_gather_object(both, losses)
+        assert both[0] != both[1], "the ranks were meant to see different clips"
+        assert not torch.equal(start, opt.arena)
+        for name, t in (("parameters", opt.arena), ("adam m", opt.m), ("adam v", opt.v)) + ((("EMA", opt.ema_arena),) if ema_net is not None else ()):
+            assert _gather_equal(t, world), f"{name} differ between the ranks after two steps"
+        if kind == "pmam":
+            # BatchNorm running statistics are per rank while training ...
+            rm = dict(net.named_buffers())["cnn.cnn.batchnorm0.running_mean"]
+            assert not _gather_equal(rm, world)
+            # ... and rank 0's become the model's as soon as something reads the model (validation / checkpoint)
+            mine0 = rm.detach().clone()
+            pm = torch.zeros(B, 1000, dtype=torch.bool, device=dev)
+            trainer.cfg.setdefault("PaSST_CNN", {}).setdefault("val_kwargs", {"encoder_win": False, "temp_w": 1})
+            trainer.validation_step(torch.from_numpy(synth.synth_wav(B, seed=99)).to(dev), labels.clone(), pm)
+            for n, b in net.named_buffers():
+                assert _gather_equal(b, world), n
+            if rank == 0:
+                assert torch.equal(mine0, rm)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok", losses))
+    except Exception:
+        import traceback
+        q.put((rank, "fail", traceback.format_exc()))
+        raise
+
+
+@pytest.mark.parametrize("kind", ["matsed", "pmam"])
+def test_two_rank_trainer_steps_keep_replicas_identical(kind):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, kind, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+    res = [q.get(timeout=10) for _ in procs]
+    assert all(r[1] == "ok" for r in res), res
+
+
+def test_bench_gpus2_starts_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it becomes two ranks (here both on cuda:0 over gloo -- RCCL refuses two ranks
+    per device) and reports the LIVE world size; asking for more GPUs than the box has fails loudly instead of measuring one."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    args = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--depth", "2", "--batch", "6", "--steps", "2", "--warmup", "1",
+            "--no-cpu-baseline"]
+    out = subprocess.run(args, capture_output=True, text=True, timeout=900, cwd=root,
+                         env=dict(env, SED_BENCH_BACKEND="gloo", SED_BENCH_ONE_GPU="1"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["config"]["global_batch"] == 12 and line["config"]["parallelism"] == "dp2"
+    assert line["value"] > 0 and abs(line["value"] - 12 * 2 / (line["ms_per_step"] * 2 / 1000)) < 1e-2 * line["value"]
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run(args, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+        assert out.returncode != 0 and "HIP device" in (out.stderr + out.stdout)

@@ -282,8 +282,10 @@ __global__ void assemble_tokens_bwd_kernel(const float* __restrict__ dx, bf16_t*
             a += dx[((size_t)b * N) * DM + d];
             c += dx[((size_t)b * N + 1) * DM + d];
         }
-        unsafeAtomicAdd(&dcls[d], a); unsafeAtomicAdd(&ddist[d], c);
-        unsafeAtomicAdd(&dnew_pos[d], a); unsafeAtomicAdd(&dnew_pos[DM + d], c);
+        // every table may be frozen on its own (null = no gradient wanted)
+        if (dcls != nullptr) unsafeAtomicAdd(&dcls[d], a);
+        if (ddist != nullptr) unsafeAtomicAdd(&ddist[d], c);
+        if (dnew_pos != nullptr) { unsafeAtomicAdd(&dnew_pos[d], a); unsafeAtomicAdd(&dnew_pos[DM + d], c); }
     } else if (job <= 12) {
         const int f = job - 1;
         float a = 0.f;
@@ -293,9 +295,10 @@ __global__ void assemble_tokens_bwd_kernel(const float* __restrict__ dx, bf16_t*
                 a += v;
                 dconv[((size_t)b * 12 * tp + f * tp + t) * DM + d] = f2bf(v);
             }
-        unsafeAtomicAdd(&dfreq[d * 12 + f], a);
+        if (dfreq != nullptr) unsafeAtomicAdd(&dfreq[d * 12 + f], a);
     } else {
         const int t = job - 13;
+        if (dtime == nullptr) return;
         float a = 0.f;
         for (int b = b0; b < b1; ++b)
             for (int f = 0; f < 12; ++f) a += dx[((size_t)b * N + 2 + f * tp + t) * DM + d];

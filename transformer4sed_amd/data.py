@@ -260,6 +260,53 @@ class ConcatDatasetBatchSampler(Sampler):
             yield [next(stream) for stream, size in zip(streams, self.batch_sizes) for _ in range(size)]
 
 
+class RankShardedBatchSampler(ConcatDatasetBatchSampler):
+    """The data-parallel batch stream of one rank (one process per GPU) -- replaces nn.DataParallel's positional scatter of the global
+    batch (recipes/desed/finetune/passt/main.py:31-33) and the divisibility assert recipes/desed/setting.py:200-202.
+
+    `batch_sizes` are the GLOBAL group sizes of the config ([strong, synth, weak, unlabeled] / [synth, weak, unlabeled]).  Every rank
+    walks the SAME global batch stream (the samplers must draw identically on all ranks: `seed` reseeds torch `RandomSampler`s per
+    epoch) and keeps, from every group g, its own contiguous `batch_sizes[g] / world` indices -- in the reference's group order, so
+    the trainer's positional `[:strong_n]`, `[strong_n:strong_n + weak_n]` slicing holds on a rank as it does on the global batch.
+    The union over ranks of batch i is exactly the reference's batch i; ranks never share an index.  Every group must divide by the
+    world size (the reference only asserts the sum): the losses are per-group means, and the mean over ranks of per-rank means equals
+    the global mean only for equal group sizes."""
+
+    def __init__(self, samplers, batch_sizes, rank=None, world=None, epoch=0, seed=None):
+        import torch.distributed as dist
+        if world is None:
+            world = dist.get_world_size() if dist.is_initialized() else 1
+        if rank is None:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        if not 0 <= rank < world:
+            raise ValueError(f"rank {rank} outside world size {world}")
+        bad = [b for b in batch_sizes if b % world]
+        if bad:
+            raise ValueError(f"every group of training.batch_size {list(batch_sizes)} must be a multiple of the number of GPUs (= {world}): "
+                             "each rank takes an equal share of every group")
+        self.rank, self.world, self.seed = rank, world, seed
+        self.local_batch_sizes = [b // world for b in batch_sizes]
+        super().__init__(samplers, batch_sizes, epoch)
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+        super().set_epoch(epoch)
+        if self.seed is not None:      # same permutation on every rank, a new one per epoch
+            for i, sampler in enumerate(self.samplers):
+                if hasattr(sampler, "generator"):
+                    g = torch.Generator()
+                    g.manual_seed(self.seed + 1000003 * epoch + i)
+                    sampler.generator = g
+
+    def __iter__(self):
+        for batch in super().__iter__():
+            mine, pos = [], 0
+            for size, per in zip(self.batch_sizes, self.local_batch_sizes):
+                mine += batch[pos + self.rank * per: pos + (self.rank + 1) * per]
+                pos += size
+            yield mine
+
+
 class DevicePrefetcher:
     """Wraps a DataLoader: tensors of batch i+1 are staged in pinned memory and copied on a side stream while batch i is in use."""
 

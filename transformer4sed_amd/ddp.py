@@ -25,35 +25,90 @@ def stage_of(name, depth):
     return "embed"
 
 
+def broadcast_buffers(net, src=0, group=None):
+    """BatchNorm running statistics (PaSST_CNN's CNN branch, src/models/cnn/base.py:75) under one process per GPU.
+
+    POLICY: rank `src`'s buffers are the model's.  `nn.DataParallel` (recipes/desed/pmam/main.py:165) gives the same answer: every
+    replica normalises its own slice with its own batch statistics, and only replica 0 -- which shares storage with the wrapped module
+    -- keeps its running-statistics update, so the checkpointed / validated model carries the statistics of GPU 0's share of every
+    batch.  Here each rank's buffers drift apart during training (batch statistics stay per rank, as in the reference); before anything
+    reads them as "the model" (validation, checkpoint) every rank takes rank 0's, in ONE collective over a flat staging tensor."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0
+    bufs = [b for _, b in net.named_buffers() if b is not None and b.numel() > 0]
+    if not bufs:
+        return 0
+    flat = torch.cat([b.detach().reshape(-1).to(torch.float64) for b in bufs])   # float64 carries num_batches_tracked (int64) exactly
+    if dist.get_backend(group) == "nccl":
+        dist.broadcast(flat, src=src, group=group)
+    else:
+        host = flat.cpu()
+        dist.broadcast(host, src=src, group=group)
+        flat = host.to(flat.device)
+    off = 0
+    with torch.no_grad():
+        for b in bufs:
+            b.copy_(flat[off:off + b.numel()].view(b.shape).to(b.dtype))
+            off += b.numel()
+    if hasattr(net, "_param_generation"):
+        net._param_generation += 1
+    return len(bufs)
+
+
 class GradBucketReducer:
     def __init__(self, net, optimizer, group=None, min_bytes=8 << 20):
         self.net, self.opt, self.group = net, optimizer, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # a stage whose slices are smaller than this is not worth a collective of its own: it is carried to the next stage hook (or
+        # to the end of backward) and merged with adjacent slices there
         self.min_elems = min_bytes // 4
         self.ranges = {}
-        # Only slices that can receive a gradient take part: frozen parameters and PaSST's unused classification heads
-        # (`backbone.head*`: never on the MAT-SED path, their arena slices stay zero) are excluded statically.
+        self._flags = None
+        self._build_ranges()
+        self.pending = []
+        self.carry = []
+        self.fired = set()
+        self.order = []       # stages in the order their hooks fired during the current backward
+        self.issued = []      # [start, end) arena ranges of the collectives of the current backward, in issue order
+        self.force = False  # issue the collectives even at world size 1 (single-GPU check of the RCCL path)
+        net._grad_ready_hook = self.on_stage
+        self.use_avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
+
+    def _trainable_flags(self):
+        return tuple(p.requires_grad for _, p in self.net.named_parameters()) if hasattr(self.net, "named_parameters") else None
+
+    def _build_ranges(self):
+        """Arena slices per backward stage.  Only slices that can receive a gradient take part: frozen parameters and PaSST's unused
+        classification heads (`backbone.head*`: never on the MAT-SED path, their arena slices stay zero) are excluded.  Rebuilt when
+        the set of trainable parameters changes (layer-wise unfreezing), see `_refresh`."""
+        net = self.net
+        self._flags = self._trainable_flags()
         trainable = {n for n, p in net.named_parameters() if p.requires_grad} if hasattr(net, "named_parameters") else None
-        for n, o, k in optimizer.layout:
+        self.ranges = {}
+        for n, o, k in self.opt.layout:
             if n.startswith("backbone.head") or (trainable is not None and n not in trainable):
                 continue
             st = stage_of(n, getattr(net, "depth", 12))
             self.ranges.setdefault(st, []).append([o, o + (k + 63) // 64 * 64])
-        for st, rs in self.ranges.items():  # merge adjacent slices
-            rs.sort()
-            merged = [rs[0]]
-            for a, b in rs[1:]:
-                if a == merged[-1][1]:
-                    merged[-1][1] = b
-                else:
-                    merged.append([a, b])
-            self.ranges[st] = merged
-        self.pending = []
-        self.fired = set()
-        self.order = []       # stages in the order their hooks fired during the current backward
-        self.force = False  # issue the collectives even at world size 1 (single-GPU check of the RCCL path)
-        net._grad_ready_hook = self.on_stage
-        self.use_avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        for st, rs in self.ranges.items():
+            self.ranges[st] = self._merge(rs)
+
+    @staticmethod
+    def _merge(rs):
+        rs = sorted(rs)
+        merged = [list(rs[0])]
+        for a, b in rs[1:]:
+            if a == merged[-1][1]:
+                merged[-1][1] = b
+            else:
+                merged.append([a, b])
+        return merged
+
+    def _refresh(self):
+        """A parameter un-frozen (or frozen) since the ranges were built would otherwise silently drop out of (or stay in) the
+        exchange and let the ranks diverge: compare the requires_grad flags (220 booleans) once per backward."""
+        if not self.fired and not self.carry and self._trainable_flags() != self._flags:
+            self._build_ranges()
 
     def _reduce(self, t):
         if self.world == 1 and not self.force:
@@ -64,13 +119,24 @@ class GradBucketReducer:
             w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self.pending.append((w, t))
 
+    def _issue(self, ranges):
+        arena = self.net._last_grad_arena
+        for a, b in self._merge(ranges):
+            self.issued.append((a, b))
+            self._reduce(arena[a:b])
+
     def on_stage(self, stage):
         """Called by the engine as soon as every gradient of `stage` is final."""
-        arena = self.net._last_grad_arena
+        self._refresh()
         self.fired.add(stage)
         self.order.append(stage)
-        for a, b in self.ranges.get(stage, []):
-            self._reduce(arena[a:b])
+        todo = self.carry + [list(r) for r in self.ranges.get(stage, [])]
+        if sum(b - a for a, b in todo) < self.min_elems:
+            self.carry = todo
+            return
+        self.carry = []
+        if todo:
+            self._issue(todo)
 
     def wait_pending(self):
         """Block the compute stream on every collective issued so far (the averaged slices are final afterwards)."""
@@ -83,12 +149,20 @@ class GradBucketReducer:
         self.pending = []
 
     def allreduce_grads(self, net=None):
-        """After backward: reduce whatever no stage hook covered (frozen stages never fire), then wait."""
-        arena = self.net._last_grad_arena
+        """After backward: reduce whatever no stage hook covered (frozen stages never fire) and what was carried, then wait."""
+        self._refresh()
+        todo = self.carry
+        self.carry = []
         for st, rs in self.ranges.items():
             if st not in self.fired:
-                for a, b in rs:
-                    self._reduce(arena[a:b])
+                todo = todo + [list(r) for r in rs]
+        if todo:
+            self._issue(todo)
         self.wait_pending()
         self.fired = set()
         self.order = []
+        self.last_issued, self.issued = self.issued, []
+
+    def sync_buffers(self, src=0):
+        """Rank `src`'s BatchNorm running statistics become every rank's (see `broadcast_buffers` for the policy)."""
+        return broadcast_buffers(self.net, src=src, group=self.group)

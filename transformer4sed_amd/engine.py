@@ -219,7 +219,7 @@ class SedEngine:
         # tensors that only the backward reads (GELU pre-activation) are produced as bf16 right away
         B16 = BF16 if save else A16
         # q, k, v stay row-major: the attention forward and backward take every transposed operand out of their LDS tiles
-        # (ds_read_b64_tr_b16); the backward converts V in place and makes the bf16 images of the Q / K tiles on the way into LDS
+        # (ds_read_b64_tr_b16); the backward makes the bf16 images of the saved f16 Q / K / V tiles on the way into LDS
         mk_qkv = lambda: [E(Bx * H, N, 64, dt=A16), E(Bx * H, N, 64, dt=A16), E(Bx * H, N, 64, dt=A16)]
         scratch = None
         pooled = None
@@ -513,6 +513,7 @@ class SedEngine:
             return self._backward_impl(ctx, grads, garena, h)
         finally:
             self._join_dw()
+            self._lo_cache = None
 
     def _backward_impl(self, ctx, grads, garena, hook=None):
         """grads: dict of upstream gradients (strong / weak / at_out / mlm_pred / frame_before_mask, any may be None).
@@ -587,13 +588,24 @@ class SedEngine:
     def _lowest_trainable(self, G, depth):
         """Index of the lowest encoder block with a trainable tensor (`depth` if none; 0 when the patch embedding / position tables train:
         recipes/desed/finetune/passt/setting.py:44-60 freezes everything below `freeze_layer` except the final norm)."""
-        embed_train = G("backbone.patch_embed.proj.weight") is not None or G("backbone.time_new_pos_embed") is not None
-        if embed_train:
-            return 0, True
-        for i in range(depth):
-            if G(f"backbone.blocks.{i}.attn.qkv.weight") is not None or G(f"backbone.blocks.{i}.norm1.weight") is not None:
-                return i, False
-        return depth, False
+        key = (id(G), depth)
+        hit = getattr(self, "_lo_cache", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        embed = ("backbone.patch_embed.proj.weight", "backbone.patch_embed.proj.bias", "backbone.cls_token", "backbone.dist_token",
+                 "backbone.new_pos_embed", "backbone.freq_new_pos_embed", "backbone.time_new_pos_embed")
+        block = ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias", "norm2.weight",
+                 "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
+        res = (depth, False)
+        if any(G(n) is not None for n in embed):           # ANY tensor of a stage makes the stage (and everything above it) run
+            res = (0, True)
+        else:
+            for i in range(depth):
+                if any(G(f"backbone.blocks.{i}.{t}") is not None for t in block):
+                    res = (i, False)
+                    break
+        self._lo_cache = (key, res, G)      # (G kept alive so that its id cannot be recycled while cached)
+        return res
 
     def _encoder_bwd(self, W, ectx, genc, dpooled, G, hook):
         """Backward of one encoder pass (the global one, or a group of sliding windows folded into the batch): f_pool at the tapped
@@ -686,6 +698,9 @@ class SedEngine:
         if gW is not None:
             xT = E(k_in, Mpad, dt=BF16)
             transpose_bf16(x, M, k_in, xT)
+            # this path adds into gW with atomics on the CURRENT stream; TN work still pending on the side stream adds its split-K
+            # workspace into the same gW with a plain read-modify-write (a window group of another M may have taken that path): order them
+            self._join_dw()
             gemm_dw(gT, xT, gW)
         return g16 if g16 is not None else dy
 

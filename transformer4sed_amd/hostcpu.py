@@ -3,9 +3,14 @@ here: 256 hardware threads visible, quota 16) torch sizes its intra-op OpenMP po
 host-side tensor op above the parallel grain then wakes 128 spinning threads, the cgroup burns its quota in a few milliseconds and
 the kernel throttles the WHOLE process for the rest of the 100 ms period -- the Python thread that feeds the GPU included.  Measured
 on the masked-reconstruction step: host issue time 37-118 ms/step with the default pool, 7.8 ms/step with one thread (the GPU needs
-33 ms).  The host side of this package only touches tiny tensors (a 128 x 513 filter bank, a 32 x 128 gain table), so the pool is
-capped once at import; SED_HOST_THREADS overrides (0 = leave torch's setting alone), and an explicit OMP_NUM_THREADS is respected."""
+33 ms).  The host side of this package only touches tiny tensors (a 128 x 513 filter bank, a 32 x 128 gain table), so the TRAINING
+ENTRY POINTS (`MatSedTrainer`, `PmamTrainer`, `bench.py`) cap the pool when they are constructed -- importing the package, building a
+model or running inference / evaluation never touches the host process's threading.  SED_HOST_THREADS overrides (0 = leave torch's
+setting alone), an explicit OMP_NUM_THREADS is respected, and the value chosen is logged once."""
+import logging
 import os
+
+log = logging.getLogger("transformer4sed_amd")
 
 
 def usable_cpus():
@@ -54,7 +59,10 @@ def cap_torch_threads():
             raise ValueError(f"SED_HOST_THREADS must be an integer (0 = leave torch's thread pool alone), got {want!r}") from None
         if n > 0:
             torch.set_num_threads(n)
+            log.info("host threads: torch intra-op pool set to %d (SED_HOST_THREADS)", n)
         return
     cap = max(1, usable_cpus() // 4)
     if torch.get_num_threads() > cap:
+        log.info("host threads: torch intra-op pool %d -> %d (usable CPUs %d; SED_HOST_THREADS=0 keeps torch's setting)",
+                 torch.get_num_threads(), cap, usable_cpus())
         torch.set_num_threads(cap)

@@ -5,9 +5,6 @@ import os
 import torch
 
 from ._lib import lib
-from .hostcpu import cap_torch_threads
-
-cap_torch_threads()
 
 BF16 = torch.bfloat16
 F16 = torch.float16

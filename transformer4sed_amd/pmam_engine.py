@@ -66,7 +66,10 @@ class PmamEngine(SedEngine):
                 # without requires_grad is not necessarily constant: the EMA teacher's masters are rewritten through raw pointers
                 # (fused AdamW + EMA kernel) or `.data` in-place ops (update_ema), neither of which moves `_version` -- so the key
                 # carries the module's parameter generation, bumped by every such writer and by load_state_dict.
-                key = (merged, wp.data_ptr(), getattr(m, "_param_generation", 0)) if not any(p.requires_grad for p in parts) else None
+                # ... and `_version`, which catches what the generation cannot: sub-module load_state_dict, nn.DataParallel(net)
+                # .load_state_dict, p.copy_ under no_grad.
+                key = ((merged, wp.data_ptr(), tuple(p._version for p in parts), getattr(m, "_param_generation", 0))
+                       if not any(p.requires_grad for p in parts) else None)
                 ent = self.cache.get(n + ".weight")
                 if key is not None and ent is not None and getattr(self, "_static_keys", {}).get(n) == key:
                     continue

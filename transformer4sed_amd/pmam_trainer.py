@@ -110,6 +110,8 @@ class PmamTrainer:
         self.net, self.optimizer, self.scheduler, self.cfg, self.net_pooling, self.ddp = net, optimizer, scheduler, config, net_pooling, ddp
         self.protos = torch.nn.functional.normalize(gmm_means.float(), dim=-1).to(next(net.parameters()).device)   # train.py:31
         self.bce = torch.nn.BCELoss()
+        from .hostcpu import cap_torch_threads
+        cap_torch_threads()     # training entry point: see hostcpu.py (SED_HOST_THREADS=0 opts out)
 
     def preprocess(self, wav, label):
         ext = self.net.get_feature_extractor()
@@ -132,6 +134,8 @@ class PmamTrainer:
     def validation_step(self, wav, labels, pad_mask):
         """Per-batch body of `Trainer.validation` (pmam/train.py:145-159): eval-mode frontend and model, prototype BCE over the
         frames that are masked AND not padded.  Returns the batch loss (device tensor)."""
+        if self.net.training and self.ddp is not None:
+            self.ddp.sync_buffers()      # first validation batch after training: rank 0's BatchNorm statistics are the model's (ddp.py)
         self.net.eval()
         mel = self.net.get_feature_extractor().logmel(wav)
         logit, other = self.net(mel, pad_mask=pad_mask, **self.cfg[self.net.get_model_name()]["val_kwargs"])

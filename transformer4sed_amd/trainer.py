@@ -285,6 +285,8 @@ class MatSedTrainer:
         self.bce = torch.nn.BCELoss()
         self.mse = torch.nn.MSELoss()
         import os
+        from .hostcpu import cap_torch_threads
+        cap_torch_threads()     # a training loop is the one place where the host-thread cap matters (hostcpu.py); opt out: SED_HOST_THREADS=0
         # the no-grad teacher forward runs on a second HIP stream beside the student forward (+1.4 % clips/s); SED_OVERLAP_TEACHER=0 serialises
         self.overlap_teacher = os.environ.get("SED_OVERLAP_TEACHER", "1") != "0"
         self.fused_losses = os.environ.get("SED_FUSED_LOSSES", "1") != "0"      # 0: the torch BCELoss / MSELoss modules (A/B reference)
@@ -293,8 +295,18 @@ class MatSedTrainer:
     # ---- checkpoint / resume.  Weights use the reference's state_dict keys, so `best_student.pt` /
     # `best_teacher.pt` written by either side load into the other (recipes/desed/finetune/passt/main.py:60-71,82-96); optimiser,
     # scheduler step and RNG state are what the reference does not keep and a bit-faithful resume needs.
+    def _sync_buffers(self):
+        """Under data parallelism rank 0's BatchNorm running statistics are the model's (ddp.broadcast_buffers; PaSST_CNN only -- MAT-SED
+        has no buffers that training changes)."""
+        if self.ddp is not None:
+            from .ddp import broadcast_buffers
+            self.ddp.sync_buffers()
+            if self.ema_net is not None:
+                broadcast_buffers(self.ema_net, group=self.ddp.group)
+
     def state_dict(self):
         import random as _r
+        self._sync_buffers()
         return {"net": {k: v.detach().cpu().clone() for k, v in self.net.state_dict().items()},
                 "ema_net": None if self.ema_net is None else {k: v.detach().cpu().clone() for k, v in self.ema_net.state_dict().items()},
                 "optimizer": self.optimizer.state_dict(), "scheduler": {"step_num": self.scheduler.step_num},
@@ -319,6 +331,7 @@ class MatSedTrainer:
     def save_weights(self, folder):
         """best_student.pt / best_teacher.pt exactly as the reference writes them (weights-only state_dicts, log.py:86-89)."""
         import os
+        self._sync_buffers()
         os.makedirs(folder, exist_ok=True)
         torch.save({k: v.detach().cpu() for k, v in self.net.state_dict().items()}, os.path.join(folder, "best_student.pt"))
         if self.ema_net is not None:
