@@ -219,7 +219,7 @@ def gen_augment():
 
 
 # ------------------------------------------------------------------------------------------------
-def build_reference_model(embed_dim, mlm, depth, feature_layer):
+def build_reference_model(embed_dim, mlm, depth, feature_layer, tag=None):
     """PaSST_SED from the reference with synth weights; encoder truncated to `depth` blocks
     (discrepancy 2).  torch.load is patched because the PaSST checkpoint is unavailable."""
     from src.models.passt.passt_sed import PaSST_SED
@@ -234,7 +234,7 @@ def build_reference_model(embed_dim, mlm, depth, feature_layer):
         net = PaSST_SED(**kw)
     finally:
         torch.load = o_load
-    sd_np = synth.matsed_state_dict_np(tag=f"w{embed_dim}", embed_dim=embed_dim, depth=12, mlm=mlm)
+    sd_np = synth.matsed_state_dict_np(tag=tag or f"w{embed_dim}", embed_dim=embed_dim, depth=12, mlm=mlm)
     missing, unexpected = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
     assert not missing and not unexpected
     # state_dict contract check: every key/shape we generate is exactly what the reference owns
@@ -993,9 +993,34 @@ def gen_pmamft():
         heads.append(t2n(torch.cat([g, g.new_zeros(8)])[:8]))
     out["tr_grad_names"], out["tr_grad_norms"], out["tr_grad_heads"] = np.asarray(names), np.asarray(norms), np.stack(heads)
     save(tag, **out)
+def gen_val12():
+    """The REAL validation configuration at the REAL depth (config/mat-sed/base/finetune2.yaml:80-86 `val_kwargs`: 17 windows of 512
+    frames, step 31, mix 0.5, temperature 0.5) through the per-batch body of Trainer.validation (recipes/desed/finetune/train.py:
+    296-321): eval frontend + normalize (`preprocess_eval`, :216-219), student and EMA teacher with the batch's pad mask.  This is
+    the path every PSDS number comes from.  The teacher carries its own weights (an EMA teacher differs from its student)."""
+    B = 2
+    wav = torch.from_numpy(synth.synth_wav(B, seed=811))
+    pm = torch.zeros(B, 1000, dtype=torch.bool)
+    pm[1, 800:] = True                                     # a 8 s clip padded to 10 s
+    val_kwargs = dict(encoder_win=True, win_param=[512, 31], mix_rate=0.5, temp_w=0.5)
+    out = {"pad_mask": pm.numpy(), "val_kwargs_json": np.asarray(json.dumps(val_kwargs)), "wav_seed": np.asarray(811),
+           "teacher_tag": np.asarray("w768t")}
+    for who, tag in (("stu", None), ("tch", "w768t")):
+        net = build_reference_model(768, False, 12, 10, tag=tag)
+        net.eval()
+        with torch.no_grad():
+            ext = net.get_feature_extractor()
+            feat = ext.normalize(ext(wav))
+            strong, weak, other = net(feat, pad_mask=pm, **val_kwargs)
+        out[f"{who}_strong"] = t2n(strong)
+        out[f"{who}_weak"] = t2n(weak)
+        out[f"{who}_at_out"] = t2n(other["at_out"])
+        if who == "stu":
+            out["feat_s"] = t2n(feat[:, ::4, ::5])
+    save("val12", **out)
 
 
-GENS = dict(frontend=gen_frontend, augment=gen_augment, micro=gen_micro, full=gen_full, full12=gen_full12,
+GENS = dict(val12=gen_val12, frontend=gen_frontend, augment=gen_augment, micro=gen_micro, full=gen_full, full12=gen_full12,
             schedule=gen_schedule, postprocess=gen_postprocess, losses=gen_losses, trainstep=gen_trainstep, trainstep12=gen_trainstep12, full12train=gen_full12_train, winbwd=gen_winbwd, evalpath=gen_evalpath, datapipe=gen_datapipe, pmam=gen_pmam, pmamstep=gen_pmamstep, pmamft=gen_pmamft)
 
 if __name__ == "__main__":
