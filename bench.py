@@ -320,7 +320,7 @@ def main():
         step()
     # HIP events bracket every GEMM launch of the FIRST timed step only: the event packets cost ~8 us of stream time per launch
     # (2.5 ms on a 138 ms step when every step is instrumented), which would otherwise be charged to `value`
-    timer = None if a.no_kernel_timer else ops.KernelTimer(["sed_gemm_nt", "sed_gemm_qkv", "sed_gemm_dw_tn"])
+    timer = None if a.no_kernel_timer else ops.KernelTimer(["sed_gemm_nt", "sed_gemm_qkv", "sed_gemm_dw_tn", "sed_gemm_nt_gb", "sed_gemm_qkv_gb"])
     timed_steps_with_events = 1
     if timer is not None:       # one untimed instrumented step creates the event objects; the timed step reuses them
         ops.TIMER = timer

@@ -51,6 +51,19 @@ int sed_median_filter(const float* in, float* out, const int* sizes, const float
 int sed_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi, const float* bias,
                 const float* resF, float* outF, void* outH, void* outH2, const void* auxH, int ldc, float alpha,
                 int ksplit, int f16, hipStream_t stream);
+/* sed_gemm_nt / sed_gemm_qkv with a ROW-GROUP bias: row m additionally gets gbias[(m / gb_rows) * N + n] (fp32 [M / gb_rows, N]; gb_rows =
+ * tokens per clip >= 128, M % gb_rows == 0; epilogues 0-3, 7, 8).  Carries the weight-rounding correction of the evaluation-mode encoder:
+ * mean_t(x) . (W - f16(W))^T per clip, added to the F.linear results of src/models/passt/passt.py:332,342 and timm Mlp fc1 / fc2
+ * (same reference lines as sed_gemm_nt) so that frame posteriors stay inside BASELINE.json's 1e-3 at the validation temperature. */
+int sed_gemm_nt_gb(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi, const float* bias,
+                   const float* resF, float* outF, void* outH, void* outH2, const void* auxH, int ldc, float alpha, int f16,
+                   const float* gbias, int gb_rows, hipStream_t stream);
+int sed_gemm_qkv_gb(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq, int seq_pad, void* q,
+                    void* k, void* v, int f16, const float* gbias, int gb_rows, hipStream_t stream);
+/* operands of that correction: per-clip token means of a 16-bit activation x [groups * rows, K] -> [groups, K] (K % 256 == 0), and
+ * the f16 image of scale * (w - f16(w)) for an fp32 weight of n (multiple of 4) elements */
+int sed_group_colmean(const void* x, void* out, int groups, int rows, int K, int f16, hipStream_t stream);
+int sed_weight_residual_f16(const float* w, void* out, int64_t n, float scale, hipStream_t stream);
 /* sed_gemm_nt with a narrow result: A / B are padded to N (a multiple of 128, not of 256) but only the first ncols (multiple of 4)
  * output columns exist in memory -- bias [ncols], residual and outputs [M, ldc] with ldc >= ncols.  The 16/32/64-filter layers of
  * the PMAM CNN branch (src/models/cnn/base.py:62-70) produce their [pixels, filters] matrices this way. */

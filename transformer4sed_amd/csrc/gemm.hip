@@ -49,6 +49,11 @@ struct GemmArgs {
     int group_m;  // 256^2 kernel: tile rows per L2 group (see gemm_nt_pp_kernel)
     int persist;  // 256^2 kernel: one workgroup per CU walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ...
     int ncols;    // 128^2 kernel: output columns >= ncols are computed but not written (operands padded to the tile width)
+    // Row-group bias (nullable): row m additionally gets gbias[(m / gb_rows) * N + n] -- one bias row per clip (gb_rows = tokens per
+    // clip, M % gb_rows == 0, gb_rows >= 128).  Carries the weight-rounding correction of the evaluation-mode encoder (engine.py
+    // `_wcorr_bias`): mean activation of the clip x the part of the fp32 weight its f16 image dropped.
+    const float* gbias;
+    int gb_rows;
 };
 
 #define TILE 128
@@ -70,6 +75,10 @@ __device__ __forceinline__ void epilogue_quad(const GemmArgs& g, int m, int n, c
     if (g.bias != nullptr) {
         const float4 bb = *reinterpret_cast<const float4*>(g.bias + n);
         b[0] = bb.x; b[1] = bb.y; b[2] = bb.z; b[3] = bb.w;
+    }
+    if (g.gbias != nullptr) {
+        const float4 bb = *reinterpret_cast<const float4*>(g.gbias + (size_t)(m / g.gb_rows) * g.N + n);
+        b[0] += bb.x; b[1] += bb.y; b[2] += bb.z; b[3] += bb.w;
     }
     if (EPI == EPI_QKV) {
         const int D = g.heads * 64;
@@ -352,6 +361,41 @@ __device__ __forceinline__ void pp_col_consts(float (&bv)[4][4], const float* bi
     }
 }
 
+// Row-group bias of a wave's 128-row sub-tile (rows mb .. mb + 127): with gb_rows >= 128 it touches at most two groups; rows below
+// `bnd` (relative to mb) belong to the first, the rest to the second.
+__device__ __forceinline__ int gb_split(const GemmArgs& g, int mb, const float*& rowA, const float*& rowB) {
+    const int last = g.M / g.gb_rows - 1;
+    int gA = mb / g.gb_rows;
+    gA = gA < last ? gA : last;
+    const int gB = gA < last ? gA + 1 : last;
+    rowA = g.gbias + (size_t)gA * g.N;
+    rowB = g.gbias + (size_t)gB * g.N;
+    return (gA + 1) * g.gb_rows - mb;
+}
+// staging with a per-row choice between two sets of column constants (bv + group-bias row A for rows < bnd, + row B otherwise);
+// the two rows are fetched per 16-column block (8 registers live at a time: this variant must fit beside the 128 accumulators)
+template <bool F16, int MODE>
+__device__ __forceinline__ void pp_stage16_gb(unsigned char* wl, const f32x4_t (&acc)[8][4], const float (&bv)[4][4], const float* rowA,
+                                              const float* rowB, int bnd, int l15, int lq) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 a4 = *reinterpret_cast<const float4*>(rowA + j * 16 + 4 * lq), b4 = *reinterpret_cast<const float4*>(rowB + j * 16 + 4 * lq);
+        const float cA[4] = {bv[j][0] + a4.x, bv[j][1] + a4.y, bv[j][2] + a4.z, bv[j][3] + a4.w};
+        const float cB[4] = {bv[j][0] + b4.x, bv[j][1] + b4.y, bv[j][2] + b4.z, bv[j][3] + b4.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool second = i * 16 + l15 >= bnd;
+            f32x2v x0 = {acc[i][j][0] + (second ? cB[0] : cA[0]), acc[i][j][1] + (second ? cB[1] : cA[1])};
+            f32x2v x1 = {acc[i][j][2] + (second ? cB[2] : cA[2]), acc[i][j][3] + (second ? cB[3] : cA[3])};
+            if (MODE == 1) { x0 = gelu_fast2(x0); x1 = gelu_fast2(x1); }
+            uint2 pk;
+            pk.x = pack2<F16>(x0.x, x0.y);
+            pk.y = pack2<F16>(x1.x, x1.y);
+            *reinterpret_cast<uint2*>(wl + (i * 16 + l15) * V3_RS16 + (j * 16 + 4 * lq) * 2) = pk;
+        }
+    }
+}
+
 template <bool F16, int MODE>
 __device__ __forceinline__ void pp_stage16(unsigned char* wl, const f32x4_t (&acc)[8][4], const float (&bv)[4][4], int l15, int lq) {
     // mode 0: acc + column constant   1: gelu_fast(acc + column constant)
@@ -421,8 +465,10 @@ __device__ __forceinline__ void v3_side_load(V3Side<EPI>& sd, const GemmArgs& g,
 }
 // rows m0 .. m0 + 31 of the output = staged rows srow0 .. srow0 + 31
 template <int EPI, bool F16>
-__device__ __forceinline__ void v3_store_batch(const GemmArgs& g, const unsigned char* wl, const V3Side<EPI>& sd, const float4 b,
-                                               int m0, int srow0, int n, int c4, int lane) {
+__device__ __forceinline__ void v3_store_batch(const GemmArgs& g, const unsigned char* wl, const V3Side<EPI>& sd, const float4 b0,
+                                               int m0, int srow0, int n, int c4, int lane, const float4 bB = make_float4(0.f, 0.f, 0.f, 0.f),
+                                               int mbnd = 0x7fffffff) {
+    // (b0 already contains the first group's row-group bias; rows m >= mbnd take bB instead -- see pp_epilogue)
     float4 vv[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) vv[u] = *reinterpret_cast<const float4*>(wl + (srow0 + u * 4 + (lane >> 4)) * V3_RS32 + c4 * 16);
@@ -431,6 +477,7 @@ __device__ __forceinline__ void v3_store_batch(const GemmArgs& g, const unsigned
         const int m = m0 + u * 4 + (lane >> 4);
         if (m >= g.M) continue;
         float4 v = vv[u];
+        const float4 b = m >= mbnd ? bB : b0;
         const size_t o = (size_t)m * g.ldc + n;
         if constexpr (EPI == EPI_F32) {
             v3_st<float4>(g.outF + o, make_float4(v.x * g.alpha + b.x, v.y * g.alpha + b.y, v.z * g.alpha + b.z, v.w * g.alpha + b.w));
@@ -478,7 +525,7 @@ __device__ __forceinline__ void v3_load_consts(V3Consts<EPI>& c, const GemmArgs&
     }
 }
 
-template <int EPI, bool F16>
+template <int EPI, bool F16, bool GB>
 __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&acc)[8][4], const V3Consts<EPI>& cc,
                                             unsigned char* wl, int mb, int nb, int lane, unsigned long long* gxt = nullptr) {
     // mb = first row of this wave's 128 x 64 sub-tile, nb = its first column
@@ -488,6 +535,12 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
         for (int pass = 0; pass < (EPI == EPI_GELU ? 2 : 1); ++pass) {
             bf16_t* out = (EPI == EPI_GELU && pass == 1) ? g.outH2 : g.outH;
             if (out == nullptr) continue;
+            if constexpr (GB) {      // evaluation-mode encoder only (no saved pre-activation: one pass)
+                const float *rA, *rB;
+                const int bnd = gb_split(g, mb, rA, rB);
+                if (EPI == EPI_GELU && pass == 1) pp_stage16_gb<F16, 1>(wl, acc, cc.bv, rA + nb, rB + nb, bnd, l15, lq);
+                else pp_stage16_gb<F16, 0>(wl, acc, cc.bv, rA + nb, rB + nb, bnd, l15, lq);
+            } else
             if (EPI == EPI_GELU && pass == 1) pp_stage16<F16, 1>(wl, acc, cc.bv, l15, lq);
             else if (EPI == EPI_GELU && F16 && g.bwd_bf16) pp_stage16<false, 0>(wl, acc, cc.bv, l15, lq);  // pre-activation for the bf16 backward
             else pp_stage16<F16, 0>(wl, acc, cc.bv, l15, lq);
@@ -524,7 +577,13 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
             bf16_t* td = pass == 0 ? tr_dst : g.q2t;
             float bv[4][4];
             pp_col_consts(bv, g.bias != nullptr ? g.bias + nb : nullptr, extra, lq);
-            pp_stage16<F16, 0>(wl, acc, bv, l15, lq);
+            if constexpr (GB) {
+                const float *rA, *rB;
+                const int bnd = gb_split(g, mb, rA, rB);
+                pp_stage16_gb<F16, 0>(wl, acc, bv, rA + nb, rB + nb, bnd, l15, lq);
+            } else {
+                pp_stage16<F16, 0>(wl, acc, bv, l15, lq);
+            }
             // Tensors that only the bf16 backward reads (row-major V; Q^T, K^T, (q+v)^T) are emitted as bf16 when g.bwd_bf16 is
             // set: converted from the staged f16 tile on the way out (same double rounding as a later in-place conversion,
             // without the extra pass over HBM); V^T and the row-major q / k stay f16.
@@ -595,21 +654,30 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
     // of 8 rows-per-lane; the residual / saved pre-activation of batch k+1 is requested before batch k is stored, so its
     // latency hides under the stores (loads placed between stores would each cost a full wait, see pp_col_consts).
     const int c4 = lane & 15, n = nb + c4 * 4;
-    const float4 b = make_float4(cc.bv[0][0], cc.bv[0][1], cc.bv[0][2], cc.bv[0][3]);
+    float4 b = make_float4(cc.bv[0][0], cc.bv[0][1], cc.bv[0][2], cc.bv[0][3]);
+    float4 bB = b;
+    int mbnd = 0x7fffffff;
+    if constexpr (GB) {
+        const float *rA, *rB;
+        mbnd = mb + gb_split(g, mb, rA, rB);
+        const float4 xa = *reinterpret_cast<const float4*>(rA + n), xb = *reinterpret_cast<const float4*>(rB + n);
+        bB = make_float4(b.x + xb.x, b.y + xb.y, b.z + xb.z, b.w + xb.w);
+        b = make_float4(b.x + xa.x, b.y + xa.y, b.z + xa.z, b.w + xa.w);
+    }
     V3Side<EPI> s0, s1;
     v3_side_load<EPI>(s0, g, mb, n, lane);
     pp_stage32(wl, acc, 0, l15, lq);
     __builtin_amdgcn_wave_barrier();
     v3_side_load<EPI>(s1, g, mb + 32, n, lane);
-    v3_store_batch<EPI, F16>(g, wl, s0, b, mb, 0, n, c4, lane);
+    v3_store_batch<EPI, F16>(g, wl, s0, b, mb, 0, n, c4, lane, bB, mbnd);
     v3_side_load<EPI>(s0, g, mb + 64, n, lane);
-    v3_store_batch<EPI, F16>(g, wl, s1, b, mb + 32, 32, n, c4, lane);
+    v3_store_batch<EPI, F16>(g, wl, s1, b, mb + 32, 32, n, c4, lane, bB, mbnd);
     __builtin_amdgcn_wave_barrier();
     pp_stage32(wl, acc, 1, l15, lq);
     __builtin_amdgcn_wave_barrier();
     v3_side_load<EPI>(s1, g, mb + 96, n, lane);
-    v3_store_batch<EPI, F16>(g, wl, s0, b, mb + 64, 0, n, c4, lane);
-    v3_store_batch<EPI, F16>(g, wl, s1, b, mb + 96, 32, n, c4, lane);
+    v3_store_batch<EPI, F16>(g, wl, s0, b, mb + 64, 0, n, c4, lane, bB, mbnd);
+    v3_store_batch<EPI, F16>(g, wl, s1, b, mb + 96, 32, n, c4, lane, bB, mbnd);
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -620,7 +688,7 @@ template <bool F16> __device__ __forceinline__ f32x4_t mfma16t(s16x8_t a, s16x8_
 }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-template <int EPI, bool F16>
+template <int EPI, bool F16, bool GB = false>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
 #ifdef GX_TRACE
@@ -758,7 +826,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
 #undef PP_MFMA
 #undef PP_TILE
 #ifdef GX_TRACE
-    pp_epilogue<EPI, F16>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * 128, n0 + wn * 64, lane, gx_t);
+    pp_epilogue<EPI, F16, GB>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * 128, n0 + wn * 64, lane, gx_t);
     GX_STAMP(5)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GX_STAMP(6)
@@ -781,7 +849,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
         }
     }
 #else
-    pp_epilogue<EPI, F16>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * 128, n0 + wn * 64, lane);
+    pp_epilogue<EPI, F16, GB>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * 128, n0 + wn * 64, lane);
 #endif
     if (tl + tstep < nwg) __syncthreads();   // the staging areas overlap the operand stages the next tile's DMA is about to fill
     }
@@ -1104,6 +1172,18 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
         gg.persist = (persist_env && (int)grid3.x > ncu) ? 1 : 0;
         if (gg.persist) grid3.x = ncu;
         const GemmArgs& g = gg;
+        if (g.gbias != nullptr) {
+            // row-group bias: evaluation-mode encoder GEMMs only (f16 operands; residual, fused-GELU and head-split epilogues)
+            if constexpr (EPI == EPI_F32_RESID || EPI == EPI_GELU || EPI == EPI_QKV) {
+                if (!f16) return SED_ERR_ARG;
+                static bool attrg = false;
+                if (!attrg) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attrg = true; }
+                hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true, true>), grid3, dim3(512), V3_LDS, s, g);
+                return sed_check_launch();
+            } else {
+                return SED_ERR_ARG;
+            }
+        }
         static bool attrp[2] = {false, false};
         if (f16) {
             if (!attrp[1]) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attrp[1] = true; }
@@ -1122,9 +1202,11 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
 
 static int gemm_nt_impl(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi, const float* bias,
                         const float* resF, float* outF, void* outH, void* outH2, const void* auxH, int ldc, float alpha,
-                        int ksplit, int f16, int ncols, hipStream_t stream) {
+                        int ksplit, int f16, int ncols, hipStream_t stream, const float* gbias = nullptr, int gb_rows = 0) {
     (void)hipGetLastError();
     GemmArgs g = {};
+    if (gbias != nullptr && (gb_rows < 128 || M % gb_rows || epi == EPI_ATOMIC || epi == EPI_DGELU)) return SED_ERR_ARG;
+    g.gbias = gbias; g.gb_rows = gb_rows;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B;
     g.ncols = ncols;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ksplit = ksplit > 0 ? ksplit : 1;
@@ -1150,6 +1232,11 @@ extern "C" int sed_gemm_nt(const void* A, const void* B, int M, int N, int K, in
                            const void* auxH, int ldc, float alpha, int ksplit, int f16, hipStream_t stream) {
     return gemm_nt_impl(A, B, M, N, K, lda, ldb, epi, bias, resF, outF, outH, outH2, auxH, ldc, alpha, ksplit, f16, N, stream);
 }
+extern "C" int sed_gemm_nt_gb(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi,
+                              const float* bias, const float* resF, float* outF, void* outH, void* outH2,
+                              const void* auxH, int ldc, float alpha, int f16, const float* gbias, int gb_rows, hipStream_t stream) {
+    return gemm_nt_impl(A, B, M, N, K, lda, ldb, epi, bias, resF, outF, outH, outH2, auxH, ldc, alpha, 1, f16, N, stream, gbias, gb_rows);
+}
 // same GEMM with a narrow result: the operands are padded to N (multiple of 128) but only the first ncols (multiple of 4) output
 // columns exist in memory (row stride ldc >= ncols); bias / residual / outputs are indexed like the narrow matrix.  128^2 kernel only.
 extern "C" int sed_gemm_nt_cols(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi,
@@ -1159,11 +1246,26 @@ extern "C" int sed_gemm_nt_cols(const void* A, const void* B, int M, int N, int 
     return gemm_nt_impl(A, B, M, N, K, lda, ldb, epi, bias, resF, outF, outH, outH2, auxH, ldc, alpha, 1, f16, ncols, stream);
 }
 
+static int gemm_qkv_impl(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq,
+                         int seq_pad, void* q, void* k, void* v, void* qt, void* kt, void* vt, void* q2,
+                         void* q2t, const float* pos_u, const float* pos_v, int f16, const float* gbias, int gb_rows, hipStream_t stream);
 extern "C" int sed_gemm_qkv(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq,
                             int seq_pad, void* q, void* k, void* v, void* qt, void* kt, void* vt, void* q2,
                             void* q2t, const float* pos_u, const float* pos_v, int f16, hipStream_t stream) {
+    return gemm_qkv_impl(A, W, bias, M, K, heads, seq, seq_pad, q, k, v, qt, kt, vt, q2, q2t, pos_u, pos_v, f16, nullptr, 0, stream);
+}
+extern "C" int sed_gemm_qkv_gb(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq,
+                               int seq_pad, void* q, void* k, void* v, int f16, const float* gbias, int gb_rows, hipStream_t stream) {
+    return gemm_qkv_impl(A, W, bias, M, K, heads, seq, seq_pad, q, k, v, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, f16,
+                         gbias, gb_rows, stream);
+}
+static int gemm_qkv_impl(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq,
+                         int seq_pad, void* q, void* k, void* v, void* qt, void* kt, void* vt, void* q2,
+                         void* q2t, const float* pos_u, const float* pos_v, int f16, const float* gbias, int gb_rows, hipStream_t stream) {
     (void)hipGetLastError();
     GemmArgs g = {};
+    if (gbias != nullptr && (gb_rows < 128 || M % gb_rows)) return SED_ERR_ARG;
+    g.gbias = gbias; g.gb_rows = gb_rows;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)W;
     g.M = M; g.N = 3 * heads * 64; g.K = K; g.lda = K; g.ldb = K; g.ldc = g.N; g.ksplit = 1; g.alpha = 1.f;
     g.ncols = g.N;
@@ -1376,6 +1478,67 @@ extern "C" int sed_weight_images(const int64_t* desc, int n_desc, int total_tile
     (void)hipGetLastError();
     if (n_desc <= 0 || total_tiles <= 0) return SED_ERR_ARG;
     hipLaunchKernelGGL(weight_images_kernel, dim3(total_tiles), dim3(256), 0, stream, (const long long*)desc, n_desc);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight-rounding correction of the evaluation-mode encoder (engine.py `_wcorr_bias`).  The f16 image of an fp32 weight drops
+// W_lo = W - f16(W); the dropped product x . W_lo^T has a part that is the SAME for every token of a clip -- mean_t(x) . W_lo^T -- which
+// no later averaging (frequency pooling, attention) reduces, and which is most of the posterior error the image costs (measured
+// with tools/err_sim.py: logit error of the f16 weight images 1.6e-3 -> 0.7e-3).  It is a [clips, K] x [K, N] product: the two kernels
+// below make its operands (per-clip token means of the 16-bit activation; f16 image of 2^11 W_lo), the ordinary GEMM forms it and
+// the main GEMM adds it as a row-group bias.
+// x [groups * rows, K] 16-bit -> mean [groups, K] 16-bit (same kind); one workgroup per (group, 256-column chunk), fp32 sums
+template <bool F16>
+__global__ __launch_bounds__(256) void group_colmean_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int rows, int K) {
+    __shared__ float part[8][256];
+    const int grp = blockIdx.x, c0 = blockIdx.y * 256;
+    // thread = (row slice of 8, 32 column groups of 8 columns = 16 bytes)
+    const int cg = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bf16_t* base = x + (size_t)grp * rows * K + c0 + cg * 8;
+    for (int r = sl; r < rows; r += 8) {
+        const uint4 u = *reinterpret_cast<const uint4*>(base + (size_t)r * K);
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[2 * e] += to_f32<F16>((bf16_t)(w[e] & 0xFFFF));
+            a[2 * e + 1] += to_f32<F16>((bf16_t)(w[e] >> 16));
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[sl][cg * 8 + e] = a[e];
+    __syncthreads();
+    const int c = threadIdx.x;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += part[i][c];
+    out[(size_t)grp * K + c0 + c] = to_16<F16>(s / (float)rows);
+}
+extern "C" int sed_group_colmean(const void* x, void* out, int groups, int rows, int K, int f16, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (groups <= 0 || rows <= 0 || K % 256) return SED_ERR_ARG;
+    if (f16) hipLaunchKernelGGL(group_colmean_kernel<true>, dim3(groups, K / 256), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)out, rows, K);
+    else hipLaunchKernelGGL(group_colmean_kernel<false>, dim3(groups, K / 256), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)out, rows, K);
+    return sed_check_launch();
+}
+// out = f16(scale * (w - f16(w)))  -- what the straight f16 image of an fp32 weight dropped (scale 2^11 keeps it a normal number)
+__global__ void weight_residual_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, size_t n4, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(w)[i];
+        uint2 p;
+        p.x = (unsigned)f2h(scale * (v.x - h2f(f2h(v.x)))) | ((unsigned)f2h(scale * (v.y - h2f(f2h(v.y)))) << 16);
+        p.y = (unsigned)f2h(scale * (v.z - h2f(f2h(v.z)))) | ((unsigned)f2h(scale * (v.w - h2f(f2h(v.w)))) << 16);
+        reinterpret_cast<uint2*>(out)[i] = p;
+    }
+}
+extern "C" int sed_weight_residual_f16(const float* w, void* out, int64_t n, float scale, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n <= 0 || n % 4) return SED_ERR_ARG;
+    const size_t n4 = n / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    blocks = blocks > 4096 ? 4096 : blocks;
+    hipLaunchKernelGGL(weight_residual_kernel, dim3(blocks), dim3(256), 0, stream, w, (bf16_t*)out, n4, scale);
     return sed_check_launch();
 }
 

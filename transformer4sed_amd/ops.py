@@ -115,9 +115,9 @@ class split_precision:
 
 
 def _flops_of(name, args):
-    if name == "sed_gemm_nt":
+    if name in ("sed_gemm_nt", "sed_gemm_nt_gb"):
         return 2.0 * args[2] * args[3] * args[4]
-    if name == "sed_gemm_qkv":
+    if name in ("sed_gemm_qkv", "sed_gemm_qkv_gb"):
         return 2.0 * args[3] * args[4] * (3 * args[5] * 64)
     if name == "sed_gemm_dw_tn":
         return 2.0 * args[3] * args[4] * args[5]
@@ -126,8 +126,10 @@ def _flops_of(name, args):
 
 def _shape_of(name, args):
     """(M, N, K, epilogue / output count) of one GEMM launch, for per-shape tables (tools/gemm_shapes.py)."""
-    if name == "sed_gemm_nt":
-        return (args[2], args[3], args[4], "epi%d" % args[7])
+    if name in ("sed_gemm_nt", "sed_gemm_nt_gb"):
+        return (args[2], args[3], args[4], "epi%d" % args[7] + ("gb" if name.endswith("_gb") else ""))
+    if name == "sed_gemm_qkv_gb":
+        return (args[3], 3 * args[5] * 64, args[4], "qkv3gb")
     if name == "sed_gemm_qkv":
         return (args[3], 3 * args[5] * 64, args[4], "qkv%d" % sum(a is not None for a in args[8:16]))
     if name == "sed_gemm_dw_tn":
@@ -137,7 +139,10 @@ def _shape_of(name, args):
 
 def _bytes_of(name, args):
     """Algorithmic HBM bytes of one GEMM launch: operands once + every output / side input once."""
-    if name == "sed_gemm_nt":
+    if name == "sed_gemm_qkv_gb":
+        M, K, D = args[3], args[4], args[5] * 64
+        return 2.0 * K * (M + 3 * D) + 2.0 * M * D * 3
+    if name in ("sed_gemm_nt", "sed_gemm_nt_gb"):
         M, N, K, epi = args[2], args[3], args[4], args[7]
         out = {0: 4, 1: 8, 2: 2, 3: 2 * ((args[11] is not None) + (args[12] is not None)), 4: 4, 5: 8, 7: 6, 8: 6}.get(epi, 4)
         return 2.0 * K * (M + N) + float(out) * M * N
@@ -190,10 +195,16 @@ def pad64(n):
 
 
 def gemm_nt(A, B, epi, M=None, bias=None, res=None, outF=None, outH=None, outH2=None, aux=None, alpha=1.0, ksplit=1,
-            lda=None, ldb=None, ldc=None):
-    """C[M,N] = A[M,K] . B[N,K]^T (bf16 operands) with fused epilogue; see include/sed_hip.h."""
+            lda=None, ldb=None, ldc=None, gbias=None, gb_rows=0):
+    """C[M,N] = A[M,K] . B[N,K]^T (bf16 operands) with fused epilogue; see include/sed_hip.h.  `gbias` [M / gb_rows, N]: row-group bias."""
     M = A.shape[0] if M is None else M
     N, K = B.shape[0], B.shape[1]
+    if gbias is not None:
+        if A.dtype != B.dtype:
+            raise RuntimeError("gemm_nt: operand types differ")
+        call("sed_gemm_nt_gb", A, B, M, N, K, lda or A.shape[1], ldb or K, epi, bias, res, outF, outH, outH2, aux, ldc or N, float(alpha),
+             is_f16(A), gbias, int(gb_rows))
+        return
     # the saved pre-activation of a GELU GEMM (epi 3 / 8) is consumed only by the bf16 backward: it may be bf16 in an f16 GEMM
     pre_bf16 = epi in (EPI_GELU, EPI_GELU32) and outH is not None and outH.dtype == BF16 and A.dtype == F16
     if A.dtype != B.dtype or any(t is not None and t.dtype != A.dtype for t in ((None if pre_bf16 else outH), outH2, aux)):
