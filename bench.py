@@ -84,7 +84,10 @@ PMAM = {
 }
 MODE_CFG = {"finetune2": FINETUNE2, "val": FINETUNE2, "finetune1": FINETUNE1, "pretrain": PRETRAIN, "pmam": PMAM}
 MODE_GFLOP = {"finetune2": (2463.16, 21.22), "finetune1": (649.13, 14.15), "pretrain": (383.68, 14.15), "val": (2 * 2264.3, 2 * 7.07),
-              "pmam": (None, None)}
+              # PMAM post-pretrain step: FlopCounterMode on the reference's own PaSST_CNN (depth 12, LoRA r = 8, freeze_layer 8, forward + loss +
+              # backward) at B = 1, 2 -- oracle/make_golden.py gen_pmamflops.  (The reference never forms the full dW of a LoRA layer; this
+              # build does, as an intermediate of dA / dB: those FLOPs are not credited.)
+              "pmam": (433.06, 3.54)}
 GFLOP_PER_CLIP = 2463.16      # finetune2 step, algorithmic GEMM+conv FLOPs per clip of the REFERENCE's schedule (a-term)
 GFLOP_PER_BATCH = 21.22       # batch-shared linear_pos GEMMs (b-term)
 # What this build does not execute: the teacher's 11 sliding windows stop after the tapped block 10 (blocks 11-12 of a window feed
@@ -92,6 +95,8 @@ GFLOP_PER_BATCH = 21.22       # batch-shared linear_pos GEMMs (b-term)
 # 10 windows of 602 tokens + one of 590 -> 2 x (10 x 9.635 + 9.421) = 211.5 GFLOP per clip.
 GFLOP_SKIPPED = {"finetune2": 211.5, "val": 2 * 17 / 11 * 211.5 * 0.0}   # (val: not priced -- its line carries no MFMA fraction)
 PEAK_BF16_TFLOPS = 2500.0     # dense 16-bit MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0         # HBM3E peak, MI355X_MICROARCH.md
+GEMM_KERNELS = ["sed_gemm_nt", "sed_gemm_qkv", "sed_gemm_dw_tn", "sed_gemm_nt_gb", "sed_gemm_qkv_gb"]
 
 
 def build(per_gpu_batch, depth, device, mode="finetune2"):
@@ -320,7 +325,7 @@ def main():
         step()
     # HIP events bracket every GEMM launch of the FIRST timed step only: the event packets cost ~8 us of stream time per launch
     # (2.5 ms on a 138 ms step when every step is instrumented), which would otherwise be charged to `value`
-    timer = None if a.no_kernel_timer else ops.KernelTimer(["sed_gemm_nt", "sed_gemm_qkv", "sed_gemm_dw_tn", "sed_gemm_nt_gb", "sed_gemm_qkv_gb"])
+    timer = None if a.no_kernel_timer else ops.KernelTimer(GEMM_KERNELS + list(ops.HBM_KERNELS))
     timed_steps_with_events = 1
     if timer is not None:       # one untimed instrumented step creates the event objects; the timed step reuses them
         ops.TIMER = timer
@@ -377,7 +382,18 @@ def main():
                                        "skipped": "blocks 11-12 of the 11 teacher windows (their output is never read)" if skipped else None}
         line["step_mfma_frac_reference_flops"] = round(value / world * (gflop_clip + gflop_batch / B) / 1000.0 / PEAK_BF16_TFLOPS, 4)
     if rank == 0 and timer is not None:
-        summ = timer.summarize()
+        summ_all = timer.summarize()
+        summ = {k: v for k, v in summ_all.items() if k in GEMM_KERNELS}
+        # HBM-bound kernels of the same instrumented step (SURVEY 8(d) "report both"): algorithmic bytes / HIP-event duration vs 8 TB/s
+        what = {"sed_logmel_fwd": "log-mel frontend (wav_absmax + logmel kernels; 1.28 MB read + 0.512 MB written per clip)",
+                "sed_adamw_ema": "fused AdamW + EMA sweeps (28 B / trainable parameter + 8-12 B / EMA parameter)",
+                "sed_layernorm_fwd": "LayerNorm forward (fp32 in -> 16-bit / fp32 out + statistics)",
+                "sed_layernorm_bwd": "LayerNorm backward (dy, x in; dx out / accumulated; gamma / beta gradients)"}
+        line["roofline_hbm"] = [
+            {"kernel": k, "what": what[k], "launches": v["launches"], "bytes": round(v["bytes"]), "us": round(1000 * v["ms"], 1),
+             "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "peak_GB/s": PEAK_HBM_GBS,
+             "frac_of_8TB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+            for k, v in summ_all.items() if k in what and v["ms"] > 0]
         ms = sum(v["ms"] for v in summ.values())
         fl = sum(v["flops"] for v in summ.values())
         n = sum(v["launches"] for v in summ.values())

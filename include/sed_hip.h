@@ -60,9 +60,9 @@ int sed_gemm_nt_gb(const void* A, const void* B, int M, int N, int K, int lda, i
                    const float* gbias, int gb_rows, hipStream_t stream);
 int sed_gemm_qkv_gb(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq, int seq_pad, void* q,
                     void* k, void* v, int f16, const float* gbias, int gb_rows, hipStream_t stream);
-/* operands of that correction: per-clip token means of a 16-bit activation x [groups * rows, K] -> [groups, K] (K % 256 == 0), and
- * the f16 image of scale * (w - f16(w)) for an fp32 weight of n (multiple of 4) elements */
-int sed_group_colmean(const void* x, void* out, int groups, int rows, int K, int f16, hipStream_t stream);
+/* operands of that correction: per-clip token means of a 16-bit activation x [groups * rows, K] -> [groups, K] (K % 256 == 0; every
+ * step-th token), and the f16 image of scale * (w - f16(w)) for an fp32 weight of n (multiple of 4) elements */
+int sed_group_colmean(const void* x, void* out, int groups, int rows, int K, int step, int f16, hipStream_t stream);
 int sed_weight_residual_f16(const float* w, void* out, int64_t n, float scale, hipStream_t stream);
 /* sed_gemm_nt with a narrow result: A / B are padded to N (a multiple of 128, not of 256) but only the first ncols (multiple of 4)
  * output columns exist in memory -- bias [ncols], residual and outputs [M, ldc] with ldc >= ncols.  The 16/32/64-filter layers of

@@ -954,6 +954,37 @@ def gen_pmamstep():
     save("pmamstep", **out)
 
 
+def gen_pmamflops():
+    """Algorithmic GEMM + conv FLOPs of one PMAM post-pretrain step of the REFERENCE (what `bench.py --mode pmam` prices its step at):
+    `torch.utils.flop_counter.FlopCounterMode` around forward + loss + backward of the reference's own PaSST_CNN at the real depth with
+    the recipe's freezing (`mark_only_lora_as_trainable`, `get_param_lr` with freeze_layer 8), at B = 1 and B = 2 -> F(B) = a + b / B as
+    BASELINE.md section 2 does for the MAT-SED steps.  Prints the two coefficients (kept as constants in bench.py)."""
+    import logging
+    from torch.utils.flop_counter import FlopCounterMode
+    from recipes.desed.finetune.cnn_trans.setting import get_param_lr
+    from src.models.lora import mark_only_lora_as_trainable
+    cfg = json.loads(json.dumps(PMAMSTEP_CFG))
+    cfg["opt"]["param_groups"]["passt"].update(lr=5.0e-6, freeze_layer=8)      # config/pmam/post_pretrain.yaml:105-122
+    gmm = torch.nn.functional.normalize(torch.from_numpy(synth.det_normal(PMAM_SYNTH["gmm_name"], (30, 768))), dim=-1)
+    tot = {}
+    for B in (1, 2):
+        net = build_reference_pmam(12, 10, conv_dropout=0.5)
+        mark_only_lora_as_trainable(net.backbone)
+        get_param_lr(net, cfg, logging.getLogger("golden"))
+        net.train()
+        mel = torch.from_numpy(synth.det_uniform("pmamflops/mel", (B, 128, 1000), -1.2, 1.2))
+        with FlopCounterMode(display=False) as fc:
+            pred, other = net(mel, encoder_win=False)
+            sim = torch.nn.functional.normalize(pred, dim=-1) @ gmm.t()
+            loss = sim.mean() + other["at_out"].mean()
+            loss.backward()
+        tot[B] = fc.get_total_flops() / 1e9
+        print(f"   B={B}: {tot[B]:.2f} GFLOP per step, {tot[B] / B:.2f} per clip", flush=True)
+    b = 2 * (tot[1] - tot[2] / 2)
+    a = tot[1] - b
+    print(f"   PMAM post-pretrain step: a = {a:.2f} GFLOP/clip, b = {b:.2f} GFLOP/batch")
+
+
 def gen_pmamft():
     """PMAM finetune stage (config/pmam/finetune1.yaml / finetune2.yaml: PaSST_CNN with mlm False, no LoRA, 10 classes): eval forward
     with the validation temperature and a pad mask, sliding windows (step 49 / 31, eval offsets), train-mode gradients (dropout 0)."""
@@ -1020,7 +1051,7 @@ def gen_val12():
     save("val12", **out)
 
 
-GENS = dict(val12=gen_val12, frontend=gen_frontend, augment=gen_augment, micro=gen_micro, full=gen_full, full12=gen_full12,
+GENS = dict(val12=gen_val12, pmamflops=gen_pmamflops, frontend=gen_frontend, augment=gen_augment, micro=gen_micro, full=gen_full, full12=gen_full12,
             schedule=gen_schedule, postprocess=gen_postprocess, losses=gen_losses, trainstep=gen_trainstep, trainstep12=gen_trainstep12, full12train=gen_full12_train, winbwd=gen_winbwd, evalpath=gen_evalpath, datapipe=gen_datapipe, pmam=gen_pmam, pmamstep=gen_pmamstep, pmamft=gen_pmamft)
 
 if __name__ == "__main__":

@@ -24,95 +24,173 @@ __global__ void zero_u32_kernel(unsigned* __restrict__ p, int n) {
     if (i < n) p[i] = 0u;
 }
 
-__global__ void wav_absmax_kernel(const float* __restrict__ wav, unsigned* __restrict__ maxbits, int L) {
+// |max| per clip: 16-byte loads, 8 independent loads in flight per lane (the scalar 4-byte version ran at 0.55 TB/s)
+__global__ __launch_bounds__(256) void wav_absmax_kernel(const float* __restrict__ wav, unsigned* __restrict__ maxbits, int L) {
     const int b = blockIdx.y;
     const float* w = wav + (size_t)b * L;
     float m = 0.f;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L; i += gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
+    const int lead = (int)((16 - ((size_t)w & 15)) & 15) >> 2;       // scalar elements before the first 16-byte boundary (odd L)
+    const int L4 = (L - lead) >> 2;
+    const f32x4_t* w4 = reinterpret_cast<const f32x4_t*>(w + lead);
+    const int stride = gridDim.x * blockDim.x;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 7 * stride < L4; i += 8 * stride) {
+        f32x4_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = w4[i + u * stride];      // plain loads: the log-mel kernel re-reads the clip from the caches
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u][0]), fabsf(v[u][1]))), fmaxf(fabsf(v[u][2]), fabsf(v[u][3])));
+    }
+    for (; i < L4; i += stride) {
+        const f32x4_t v = w4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    if (blockIdx.x == 0) {      // the unaligned head and the < 4-element tail
+        if ((int)threadIdx.x < lead) m = fmaxf(m, fabsf(w[threadIdx.x]));
+        const int t0 = lead + 4 * L4;
+        if (t0 + (int)threadIdx.x < L) m = fmaxf(m, fabsf(w[t0 + threadIdx.x]));
+    }
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) atomicMax(&maxbits[b], __float_as_uint(m));  // non-negative floats order as uints
 }
 
-// pre-emphasised, reflect-padded signal sample n of the padded axis (n = 0 .. Ly + 1023), Ly = L - 1
-__device__ __forceinline__ float ypad_at(const float* __restrict__ w, int n, int Ly, float inv) {
+// pre-emphasised, reflect-padded signal sample n of the padded axis (n = 0 .. Ly + 1023), Ly = L - 1, from the raw samples
+// (the 1 / (max + 1e-10) normalisation is applied by the caller: it commutes with the pre-emphasis up to rounding)
+__device__ __forceinline__ int ypad_index(int n, int Ly) {
     int m = n - NFFT / 2;
     m = m < 0 ? -m : m;
-    m = m > Ly - 1 ? 2 * (Ly - 1) - m : m;
-    return w[m + 1] / inv - 0.97f * (w[m] / inv);
+    return m > Ly - 1 ? 2 * (Ly - 1) - m : m;
 }
 
+#define MEL_CSR_CAP 1280      // non-zero filterbank weights held in LDS (every bin lies under at most two triangles: <= 1026 + edges)
+// complex helpers on packed fp32 pairs (v_pk_mul / v_pk_fma / v_pk_add): (re, im)
+__device__ __forceinline__ f32x2v cmul_tw(f32x2v z, f32x2v tw, f32x2v twp) {   // z * tw, twp = (-tw.y, tw.x)
+    return f32x2v{z.x, z.x} * tw + f32x2v{z.y, z.y} * twp;
+}
+__device__ __forceinline__ f32x2v mul_neg_i(f32x2v d) { return f32x2v{d.y, -d.x}; }
+
+// One workgroup = 8 frames as 4 pairs; a pair of real frames is one 1024-point complex radix-4 Stockham FFT in LDS.  Everything a
+// pair needs besides its samples lives on chip for the whole workgroup: the window taps and the 12 twiddle factors of a lane in
+// registers, the non-zero filterbank weights as a CSR image in LDS; the samples of the next pair are requested before the current
+// pair's FFT.  The arithmetic is packed fp32 on (re, im) pairs.
 __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ wav, const unsigned* __restrict__ maxbits,
                                                      const float* __restrict__ window,  // [800] symmetric Hann
                                                      const float2* __restrict__ twiddle,  // [1024] exp(-2 pi i k / 1024)
                                                      const float* __restrict__ melw,      // [128, 513] dense
                                                      const int* __restrict__ mel_range,   // [128, 2] first bin, end bin
                                                      float* __restrict__ out, int L, int T, int do_log) {
-    __shared__ float xr[2][NFFT], xi[2][NFFT];
+    __shared__ f32x2v z[2][NFFT];
     __shared__ float pw[2][NBIN + 3];
     __shared__ float ostage[NMEL][FR_PER_WG];
+    __shared__ float wcsr[MEL_CSR_CAP];
+    __shared__ int moff[NMEL + 1];
     const int tid = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * FR_PER_WG;
     const float* w = wav + (size_t)b * L;
-    const float denom = __uint_as_float(maxbits[b]) + 1e-10f;
+    const float rinv = 1.0f / (__uint_as_float(maxbits[b]) + 1e-10f);
     const int Ly = L - 1;
-    for (int pair = 0; pair < FR_PER_WG / 2; ++pair) {
-        const int ta = t0 + 2 * pair, tb = ta + 1;
-        // windowed frames -> complex input (zero outside the 800-sample window support)
-        for (int n = tid; n < NFFT; n += 256) {
-            float a = 0.f, c = 0.f;
-            if (n >= WINOFF && n < WINOFF + WINLEN) {
-                const float wn = window[n - WINOFF];
-                if (ta < T) a = wn * ypad_at(w, HOP * ta + n, Ly, denom);
-                if (tb < T) c = wn * ypad_at(w, HOP * tb + n, Ly, denom);
-            }
-            xr[0][n] = a;
-            xi[0][n] = c;
+    // ---- per-lane constants
+    float wv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = tid + 256 * q;
+        wv[q] = (n >= WINOFF && n < WINOFF + WINLEN) ? window[n - WINOFF] * rinv : 0.f;     // window tap x clip normalisation
+    }
+    f32x2v tw[4][3], twp[4][3];      // stages Ns = 4, 16, 64, 256 (the first stage has none)
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const int Ns = 4 << (2 * st), k = tid & (Ns - 1);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const float2 t = twiddle[q * k * (256 / Ns)];
+            tw[st][q - 1] = f32x2v{t.x, t.y};
+            twp[st][q - 1] = f32x2v{-t.y, t.x};
         }
+    }
+    // ---- filterbank as CSR in LDS
+    const int mm = tid & 127, which = tid >> 7;
+    const int k0 = mel_range[2 * mm], k1 = mel_range[2 * mm + 1];
+    if (tid < NMEL) moff[tid + 1] = k1 - k0;
+    if (tid == 0) moff[0] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 1; i <= NMEL; ++i) { run += moff[i]; moff[i] = run; }
+    }
+    __syncthreads();
+    const int off = moff[mm], nnz = moff[NMEL];
+    const bool csr = nnz <= MEL_CSR_CAP;
+    if (csr)
+        for (int k = k0 + which; k < k1; k += 2) wcsr[off + k - k0] = melw[(size_t)mm * NBIN + k];
+    // ---- samples of pair 0
+    float sa[4][2], sb[4][2];        // [q][x[m], x[m + 1]] of frames a and b
+    auto fetch = [&](int pair) {
+        const int ta = t0 + 2 * pair, tb = ta + 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = tid + 256 * q;
+            sa[q][0] = sa[q][1] = sb[q][0] = sb[q][1] = 0.f;
+            if (n >= WINOFF && n < WINOFF + WINLEN) {
+                if (ta < T) { const int m = ypad_index(HOP * ta + n, Ly); sa[q][0] = w[m]; sa[q][1] = w[m + 1]; }
+                if (tb < T) { const int m = ypad_index(HOP * tb + n, Ly); sb[q][0] = w[m]; sb[q][1] = w[m + 1]; }
+            }
+        }
+    };
+    fetch(0);
+    for (int pair = 0; pair < FR_PER_WG / 2; ++pair) {
+        // windowed, pre-emphasised frames -> complex input (frame a real part, frame b imaginary part)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            z[0][tid + 256 * q] = f32x2v{wv[q] * (sa[q][1] - 0.97f * sa[q][0]), wv[q] * (sb[q][1] - 0.97f * sb[q][0])};
         __syncthreads();
+        if (pair + 1 < FR_PER_WG / 2) fetch(pair + 1);       // in flight during the FFT
         int cur = 0;
 #pragma unroll
-        for (int Ns = 1; Ns < NFFT; Ns *= 4) {
+        for (int st = 0; st < 5; ++st) {
+            const int Ns = 1 << (2 * st);
             const int j = tid, k = j & (Ns - 1);
-            float ur[4], ui[4];
+            f32x2v u[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float re = xr[cur][j + q * 256], im = xi[cur][j + q * 256];
-                if (q == 0 || Ns == 1) { ur[q] = re; ui[q] = im; }
-                else {
-                    const float2 tw = twiddle[q * k * (256 / Ns)];
-                    ur[q] = re * tw.x - im * tw.y;
-                    ui[q] = re * tw.y + im * tw.x;
-                }
+            for (int q = 0; q < 4; ++q) u[q] = z[cur][j + q * 256];
+            if (st > 0) {
+#pragma unroll
+                for (int q = 1; q < 4; ++q) u[q] = cmul_tw(u[q], tw[st > 0 ? st - 1 : 0][q - 1], twp[st > 0 ? st - 1 : 0][q - 1]);
             }
-            const float v0r = ur[0] + ur[2], v0i = ui[0] + ui[2], v1r = ur[0] - ur[2], v1i = ui[0] - ui[2];
-            const float v2r = ur[1] + ur[3], v2i = ui[1] + ui[3];
-            const float v3r = ui[1] - ui[3], v3i = -(ur[1] - ur[3]);  // (u1 - u3) * (-i)
+            const f32x2v v0 = u[0] + u[2], v1 = u[0] - u[2], v2 = u[1] + u[3], v3 = mul_neg_i(u[1] - u[3]);
             const int j0 = ((j / Ns) * Ns * 4) + k;
             const int nxt = cur ^ 1;
-            xr[nxt][j0] = v0r + v2r;          xi[nxt][j0] = v0i + v2i;
-            xr[nxt][j0 + Ns] = v1r + v3r;     xi[nxt][j0 + Ns] = v1i + v3i;
-            xr[nxt][j0 + 2 * Ns] = v0r - v2r; xi[nxt][j0 + 2 * Ns] = v0i - v2i;
-            xr[nxt][j0 + 3 * Ns] = v1r - v3r; xi[nxt][j0 + 3 * Ns] = v1i - v3i;
+            z[nxt][j0] = v0 + v2;
+            z[nxt][j0 + Ns] = v1 + v3;
+            z[nxt][j0 + 2 * Ns] = v0 - v2;
+            z[nxt][j0 + 3 * Ns] = v1 - v3;
             __syncthreads();
             cur = nxt;
         }
         // split the two real spectra: Xa = (Z[k] + conj Z[N-k]) / 2, Xb = (Z[k] - conj Z[N-k]) / (2i); power
         for (int k = tid; k < NBIN; k += 256) {
             const int kn = (NFFT - k) & (NFFT - 1);
-            const float zr = xr[cur][k], zi = xi[cur][k], yr = xr[cur][kn], yi = -xi[cur][kn];
-            const float ar = 0.5f * (zr + yr), ai = 0.5f * (zi + yi);
-            const float dr = zr - yr, di = zi - yi;           // (Z - conj Zn)
+            const f32x2v zk = z[cur][k], zn = z[cur][kn];
+            const float yr = zn.x, yi = -zn.y;
+            const float ar = 0.5f * (zk.x + yr), ai = 0.5f * (zk.y + yi);
+            const float dr = zk.x - yr, di = zk.y - yi;       // (Z - conj Zn)
             const float br = 0.5f * di, bi = -0.5f * dr;      // divided by 2i
             pw[0][k] = ar * ar + ai * ai;
             pw[1][k] = br * br + bi * bi;
         }
         __syncthreads();
         {
-            const int m = tid & 127, which = tid >> 7;
-            const int k0 = mel_range[2 * m], k1 = mel_range[2 * m + 1];
-            const float* wrow = melw + (size_t)m * NBIN;
             float acc = 0.f;
-            for (int k = k0; k < k1; ++k) acc += wrow[k] * pw[which][k];
-            ostage[m][2 * pair + which] = do_log ? (__logf(acc + 1e-5f) + 4.5f) / 5.0f : acc;
+            if (csr) {
+                const float* wr = wcsr + off;
+                const float* pp = pw[which] + k0;
+                const int n = k1 - k0;
+                int i = 0;
+                for (; i + 3 < n; i += 4) acc += wr[i] * pp[i] + wr[i + 1] * pp[i + 1] + wr[i + 2] * pp[i + 2] + wr[i + 3] * pp[i + 3];
+                for (; i < n; ++i) acc += wr[i] * pp[i];
+            } else {
+                const float* wrow = melw + (size_t)mm * NBIN;
+                for (int k = k0; k < k1; ++k) acc += wrow[k] * pw[which][k];
+            }
+            ostage[mm][2 * pair + which] = do_log ? (__logf(acc + 1e-5f) + 4.5f) / 5.0f : acc;
         }
         __syncthreads();
     }
@@ -135,7 +213,13 @@ extern "C" int sed_logmel_fwd(const float* wav, float* out, uint32_t* maxbits_tm
     (void)hipGetLastError();
     if (B <= 0 || T != 1 + (L - 1) / HOP || L < NFFT) return SED_ERR_ARG;
     hipLaunchKernelGGL(zero_u32_kernel, dim3(cdiv(B, 256)), dim3(256), 0, stream, maxbits_tmp, B);
-    hipLaunchKernelGGL(wav_absmax_kernel, dim3(64, B), dim3(256), 0, stream, wav, maxbits_tmp, L);
+    {
+        // ~16 KiB of samples per workgroup and at least ~1024 workgroups on the 256 CUs
+        int bx = cdiv(L, 4096);
+        if (bx * B < 1024) bx = cdiv(1024, B);
+        if (bx > cdiv(L, 1024)) bx = cdiv(L, 1024);
+        hipLaunchKernelGGL(wav_absmax_kernel, dim3(bx, B), dim3(256), 0, stream, wav, maxbits_tmp, L);
+    }
     hipLaunchKernelGGL(logmel_kernel, dim3(cdiv(T, FR_PER_WG), B), dim3(256), 0, stream, wav, maxbits_tmp, window,
                        (const float2*)twiddle, melw, mel_range, out, L, T, do_log);
     return sed_check_launch();

@@ -1489,15 +1489,18 @@ extern "C" int sed_weight_images(const int64_t* desc, int n_desc, int total_tile
 // below make its operands (per-clip token means of the 16-bit activation; f16 image of 2^11 W_lo), the ordinary GEMM forms it and
 // the main GEMM adds it as a row-group bias.
 // x [groups * rows, K] 16-bit -> mean [groups, K] 16-bit (same kind); one workgroup per (group, 256-column chunk), fp32 sums
+// `step` > 1: every step-th token only -- an estimate of the mean (the correction needs it to a few per cent; the part of the dropped
+// product that varies from token to token is left uncorrected anyway), for 1 / step of the extra pass over the activation
 template <bool F16>
-__global__ __launch_bounds__(256) void group_colmean_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int rows, int K) {
+__global__ __launch_bounds__(256) void group_colmean_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int rows, int K, int step) {
     __shared__ float part[8][256];
     const int grp = blockIdx.x, c0 = blockIdx.y * 256;
     // thread = (row slice of 8, 32 column groups of 8 columns = 16 bytes)
     const int cg = threadIdx.x & 31, sl = threadIdx.x >> 5;
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bf16_t* base = x + (size_t)grp * rows * K + c0 + cg * 8;
-    for (int r = sl; r < rows; r += 8) {
+    const int nvis = (rows + step - 1) / step;
+    for (int r = sl * step; r < rows; r += 8 * step) {
         const uint4 u = *reinterpret_cast<const uint4*>(base + (size_t)r * K);
         const unsigned w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
@@ -1513,13 +1516,13 @@ __global__ __launch_bounds__(256) void group_colmean_kernel(const bf16_t* __rest
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += part[i][c];
-    out[(size_t)grp * K + c0 + c] = to_16<F16>(s / (float)rows);
+    out[(size_t)grp * K + c0 + c] = to_16<F16>(s / (float)nvis);
 }
-extern "C" int sed_group_colmean(const void* x, void* out, int groups, int rows, int K, int f16, hipStream_t stream) {
+extern "C" int sed_group_colmean(const void* x, void* out, int groups, int rows, int K, int step, int f16, hipStream_t stream) {
     (void)hipGetLastError();
-    if (groups <= 0 || rows <= 0 || K % 256) return SED_ERR_ARG;
-    if (f16) hipLaunchKernelGGL(group_colmean_kernel<true>, dim3(groups, K / 256), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)out, rows, K);
-    else hipLaunchKernelGGL(group_colmean_kernel<false>, dim3(groups, K / 256), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)out, rows, K);
+    if (groups <= 0 || rows <= 0 || K % 256 || step < 1) return SED_ERR_ARG;
+    if (f16) hipLaunchKernelGGL(group_colmean_kernel<true>, dim3(groups, K / 256), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)out, rows, K, step);
+    else hipLaunchKernelGGL(group_colmean_kernel<false>, dim3(groups, K / 256), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)out, rows, K, step);
     return sed_check_launch();
 }
 // out = f16(scale * (w - f16(w)))  -- what the straight f16 image of an fp32 weight dropped (scale 2^11 keeps it a normal number)

@@ -95,6 +95,7 @@ class SedEngine:
         # averages; removing it halves the error at the validation temperature for ~2 % of an inference pass.  Training-mode passes
         # (student, and the teacher inside the train step) do not pay for it.  SED_ENC_WCORR=0 off, =all every no-grad pass.
         self.wcorr = os.environ.get("SED_ENC_WCORR", "eval") if self.act == F16 else "0"
+        self.wcorr_step = int(os.environ.get("SED_ENC_WCORR_STEP", "8"))     # clip means from every 8th token (1/8 of the extra read)
 
     def _wcorr_on(self, save):
         if self.wcorr == "0" or save:
@@ -122,7 +123,7 @@ class SedEngine:
         wlo = self._wlo_image(W, name)
         K = x16.shape[-1]
         mean = torch.empty(groups, K, dtype=x16.dtype, device=x16.device)
-        call("sed_group_colmean", x16, mean, groups, rows, K, is_f16(x16))
+        call("sed_group_colmean", x16, mean, groups, rows, K, self.wcorr_step, is_f16(x16))
         out = torch.empty(groups, wlo.shape[0], dtype=F32, device=x16.device)
         gemm_nt(mean, wlo, EPI_F32, outF=out, alpha=1.0 / 2048.0)
         return out

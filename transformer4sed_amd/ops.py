@@ -156,6 +156,25 @@ def _bytes_of(name, args):
     return 0.0
 
 
+def _hbm_bytes_of(name, args):
+    """Algorithmic HBM bytes of one launch of an HBM-bound kernel (operands once, outputs once)."""
+    if name == "sed_logmel_fwd":                 # (wav, out, tmp, window, twiddle, melw, mel_range, B, L, T, do_log)
+        B, L, T = args[7], args[8], args[9]
+        return 4.0 * B * (L + 128 * T)
+    if name == "sed_adamw_ema":                  # (p, g, m, v, ema, n, ..., do_adam)
+        n, ema, adam = args[5], args[4] is not None, bool(args[13])
+        return float(n) * ((28 + (8 if ema else 0)) if adam else 12)
+    if name == "sed_layernorm_fwd":              # (x, gamma, beta, eps, scale, y16, y32, mean, rstd, M, D, f16)
+        M, D = args[9], args[10]
+        return float(M) * (D * (4 + (2 if args[5] is not None else 0) + (4 if args[6] is not None else 0)) + (8 if args[7] is not None else 0))
+    if name == "sed_layernorm_bwd":              # (dy, x, mean, rstd, gamma, scale, dx, accumulate, dgamma, dbeta, M, D)
+        M, D = args[10], args[11]
+        return float(M) * (D * (12 + (4 if args[7] else 0)) + 8)
+    return 0.0
+
+
+HBM_KERNELS = ("sed_logmel_fwd", "sed_adamw_ema", "sed_layernorm_fwd", "sed_layernorm_bwd")
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # the current stream's handle without building a Stream object
 
 
@@ -185,7 +204,8 @@ def call(name, *args):
         lib().call(name, *conv, _stream_of(dev))
         e1.record()
         fi = _flops_of(name, args)
-        TIMER.records.append((name, e0, e1, fi * ALG_K_SCALE, _bytes_of(name, args), fi, _shape_of(name, args)))
+        by = _hbm_bytes_of(name, args) if name in HBM_KERNELS else _bytes_of(name, args)
+        TIMER.records.append((name, e0, e1, fi * ALG_K_SCALE, by, fi, _shape_of(name, args)))
         return
     lib().call(name, *conv, _stream_of(dev))
 
