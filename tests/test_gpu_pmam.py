@@ -302,10 +302,12 @@ def test_pmam_finetune_stage_vs_reference(golden):
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/pmam_errors.log", "a") as f:
         f.write("PMAM finetune-stage posterior errors (SED_ENC_WCORR=%s): %s\n" % (os.environ.get("SED_ENC_WCORR", "eval"), {k: f"{v:.2e}" for k, v in errs.items()}))
-    # 1e-3 everywhere except the validation-temperature case without windows: sigmoid(logit / 0.5) doubles the logit error of the f16
-    # encoder; measured 0.92e-3 .. 1.10e-3 depending on the accumulation order of the GEMM build (the window cases average it down)
-    assert max(v for k, v in errs.items() if k != "strong_t05_pad") < 1e-3, errs
-    assert errs["strong_t05_pad"] < 1.25e-3, errs
+    # BASELINE north_star: 1e-3 on every frame posterior, the validation temperature included (sigmoid(logit / 0.5) doubles the logit
+    # error).  Measured with the evaluation-mode weight-rounding correction (engine.py `_wcorr_bias`): 7.2e-4 at temp 0.5, 7.7e-4 / 7.9e-4
+    # with windows (8.9e-4 / 8.0e-4 / 8.3e-4 without it); the rest is per-token f16 rounding of the encoder activations, which the
+    # attention pooling of this model does not average down the way MAT-SED's mean pooling does (tools/err_sim_pmam.py: the CNN branch
+    # contributes 2e-5).
+    assert max(errs.values()) < 1e-3, errs
     # gradients
     net = build_ft(dropout=0.0)
     net.train()
