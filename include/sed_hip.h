@@ -64,10 +64,6 @@ int sed_gemm_qkv_gb(const void* A, const void* W, const float* bias, int M, int 
  * step-th token), and the f16 image of scale * (w - f16(w)) for an fp32 weight of n (multiple of 4) elements */
 int sed_group_colmean(const void* x, void* out, int groups, int rows, int K, int step, int f16, hipStream_t stream);
 int sed_weight_residual_f16(const float* w, void* out, int64_t n, float scale, hipStream_t stream);
-/* Kernel selection switch of the GEMM family (A/B measurements and the bit-exactness test of the two forward kernels): bit e of `mask`
- * allows epilogue code e to run on the drain-pipelined 256 x 128 kernel (epilogue of tile i under the K loop of tile i + 1) instead of
- * the 256 x 256 one; mask < 0 only queries.  Returns the previous mask (never an error code).  Default: every supported epilogue. */
-int sed_gemm_dp_mask(int mask);
 /* sed_gemm_nt with a narrow result: A / B are padded to N (a multiple of 128, not of 256) but only the first ncols (multiple of 4)
  * output columns exist in memory -- bias [ncols], residual and outputs [M, ldc] with ldc >= ncols.  The 16/32/64-filter layers of
  * the PMAM CNN branch (src/models/cnn/base.py:62-70) produce their [pixels, filters] matrices this way. */
@@ -123,7 +119,9 @@ int sed_relpos_attn_bwd(const void* Qu, const void* Qut, const void* Qv, const v
                         int H, int T, int Tpad, int Rpad, int need_param_grads, int f16, int o_kind, hipStream_t stream);
 
 /* ------------------------------------------------------------------ norms / glue / heads / optimiser */
-/* nn.LayerNorm over D=768 (passt.py:361-362,580; passt_sed.py:128; timm Block norms); y = LN(in_scale*x) */
+/* nn.LayerNorm over D=768 (passt.py:361-362,580; passt_sed.py:128; timm Block norms); y = LN(in_scale*x).
+ * f16: 0 bf16 / 1 IEEE-half y_bf16 [M, D]; 4: y_bf16 is the split-precision operand image [M, 3 D] = [hi | lo | hi] f16 of the result
+ * (the context-network GEMMs' A operand, transformerXL.py:31-35 -- what sed_split3_f16 would make from y_f32 in a second pass) */
 int sed_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float in_scale, void* y_bf16,
                       float* y_f32, float* mean, float* rstd, int M, int D, int f16, hipStream_t stream);
 int sed_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,

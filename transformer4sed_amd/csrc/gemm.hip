@@ -856,417 +856,6 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Drain-pipelined GEMM ("dp"): the epilogue of tile i runs UNDER the K loop of tile i + 1.
-//
-// Why: on the model's short-K shapes the 256^2 kernel above pays its epilogue in sequence with its main loop -- 8.6 us (16-bit
-// output) to 24-31 us (fp32 residual read-modify-write) per tile against a 17.3 us K = 768 loop -- because one 8-wave workgroup owns
-// the CU (246 VGPRs, 128 KiB LDS) and a CU moves its output at ~12 B / clk no matter how idle HBM is.  Here a wave owns a 64 x 64
-// sub-tile of a 256 x 128 tile = 64 accumulator VGPRs, and keeps TWO such sets: while set X accumulates tile i + 1, set Y (tile i,
-// finished) is drained one 2-KiB chunk per K tile: accumulators -> (bias / GELU / GELU') -> wave-private LDS staging -> read back row-major
-// -> 16-byte global stores, with the residual (or saved pre-activation) of the next chunk requested one K tile ahead.  The drain's
-// handful of instructions per K tile sit in the wave's load segment, beside the partner wave's MFMA segment.
-//  * 8 waves = 2 groups of 4 (the ping-pong halves, half a phase apart as in gemm_nt_pp_kernel), wave (grp, w): rows 64 (2 grp + w / 2),
-//    columns 64 (w & 1).  A K tile (BK = 64) is two phases, one per 32-deep k-step: 4 A + 4 B fragment reads, 16 MFMAs.
-//  * LDS: three operand stages of 48 KiB (A 256 rows, B 128 rows, 128-byte rows, chunk ^ ((row >> 1) & 7) swizzle on the DMA source
-//    address) + 8 x 2 KiB staging = 160 KiB.  K tile g + 2 is DMA'd during K tile g (3 pieces per wave per phase) into the stage K tile
-//    g - 1 used; every wave retires its fragment reads BEFORE the phase's first barrier, so one barrier separates the last read of a
-//    stage from the first DMA into it.  ONE counted wait per K tile (`vmcnt(6)` after the second phase's pieces are issued) retires
-//    K tile g + 1's pieces -- read from the next phase on -- and, being older, every drain load / store of the previous K tile.
-//  * The K-tile stream runs across tiles (persistent workgroups): the pieces of the next tile's first K tiles are in flight during the
-//    current tile's last ones; operands come through whole-matrix buffer descriptors (rows past M read zeros), tile origin in the SGPR offset.
-//  * Drain loads go through inline asm: the compiler does not count them, so it cannot answer a loop-carried prefetch with a
-//    `vmcnt(0)` in the loop; the registers are tied to the counted wait instead.
-#define DP_TM 256
-#define DP_TN 128
-#define DP_STAGE 49152
-#define DP_STG_OFF (3 * DP_STAGE)
-#define DP_WSTG 2048
-#define DP_LDS (DP_STG_OFF + 8 * DP_WSTG)
-
-__device__ __forceinline__ f32x4_t dp_load16(const void* p) {
-    f32x4_t v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ f32x4_t dp_load16_nt(const void* p) {
-    f32x4_t v;
-    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2_t dp_load8_nt(const void* p) {
-    f32x2_t v;
-    asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-
-template <int EPI>
-struct DpTraits {
-    static constexpr bool k16 = (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_QKV || EPI == EPI_DGELU);   // 16-bit staged
-    // chunks per 64 x 64 sub-tile, 2 KiB each: 16 rows x 64 columns (16-bit) or 16 rows x 32 columns (fp32); the fused GELU has two
-    // 16-bit outputs (pre-activation kept for the backward, activation): chunk = 2 * row block + pass, the even ones skipped when no
-    // pre-activation is wanted
-    static constexpr int nch = (EPI == EPI_GELU) ? 8 : (k16 ? 4 : 8);
-};
-
-template <int EPI, bool F16>
-__global__ __launch_bounds__(512) void gemm_nt_dp_kernel(const GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
-    using TR = DpTraits<EPI>;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, w4 = wave & 3;
-    const int wr = grp * 2 + (w4 >> 1), wc = w4 & 1;
-    const int ntn = g.N / DP_TN, ntm = (g.M + DP_TM - 1) / DP_TM, nwg = ntm * ntn;
-    const int nk = g.K / BK;
-    const int l15 = lane & 15, lq = lane >> 4, sw = (l15 >> 1) & 7;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)(((size_t)(g.M - 1) * g.lda + g.K) * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, (int)(((size_t)(g.N - 1) * g.ldb + g.K) * 2), 0x00020000);
-    // ---- DMA pieces of this wave: A pieces 4 wave + e (rows 8 p .. 8 p + 7 of the tile), B pieces 2 wave + e
-    const int prow = lane >> 3, pch = lane & 7;
-    int voA[4], voB[2];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int row = (4 * wave + e) * 8 + prow;
-        voA[e] = row * g.lda * 2 + ((pch ^ ((row >> 1) & 7)) << 4);
-    }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int row = (2 * wave + e) * 8 + prow;
-        voB[e] = row * g.ldb * 2 + ((pch ^ ((row >> 1) & 7)) << 4);
-    }
-    const int ldsA = wave * 4096, ldsB = 32768 + wave * 2048;
-    // ---- tile walk (persistent): tile tl -> origin, XCD-contiguous and grouped for the L2 as in gemm_nt_pp_kernel
-    auto tile_origin = [&](int tl, int& m0, int& n0) {
-        const int t = xcd_remap(tl, nwg);
-        const int GM = g.group_m;
-        const int group_size = GM * ntn, gid = t / group_size, first_m = gid * GM;
-        const int gm = (ntm - first_m) < GM ? (ntm - first_m) : GM;
-        const int tin = t - gid * group_size;
-        m0 = (first_m + tin % gm) * DP_TM;
-        n0 = (tin / gm) * DP_TN;
-    };
-    // DMA cursor: the next K tile to fetch (two ahead of the one being multiplied)
-    int d_tl = blockIdx.x, d_kt = 0, d_stage = 0;
-    bool d_live = d_tl < nwg;
-    unsigned d_baseA = 0, d_baseB = 0;
-    {
-        int m0 = 0, n0 = 0;
-        if (d_live) tile_origin(d_tl, m0, n0);
-        d_baseA = (unsigned)m0 * (unsigned)g.lda * 2u;
-        d_baseB = (unsigned)n0 * (unsigned)g.ldb * 2u;
-    }
-    // (the tile's row offset goes into the VGPR offset: only that one is range-checked against the descriptor -- rows past M must
-    //  read zeros, not whatever lies behind the matrix; the K offset rides in the SGPR offset)
-#define DP_DMA_A(E)                                                                                                        \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(lds3 + d_stage * DP_STAGE + ldsA + (E) * 1024), 16,           \
-                                             (int)((unsigned)voA[E] + d_baseA), d_kt * (BK * 2), 0, 0);
-#define DP_DMA_B(E)                                                                                                        \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(lds3 + d_stage * DP_STAGE + ldsB + (E) * 1024), 16,           \
-                                             (int)((unsigned)voB[E] + d_baseB), d_kt * (BK * 2), 0, 0);
-#define DP_DMA_FIRST()  { DP_DMA_A(0) DP_DMA_A(1) DP_DMA_B(0) }
-#define DP_DMA_SECOND() { DP_DMA_A(2) DP_DMA_A(3) DP_DMA_B(1) }
-#define DP_ADVANCE()                                                                                                       \
-    {                                                                                                                      \
-        d_stage = d_stage == 2 ? 0 : d_stage + 1;                                                                          \
-        if (++d_kt == nk) {                                                                                                \
-            d_kt = 0;                                                                                                      \
-            d_tl += (int)gridDim.x;                                                                                        \
-            d_live = d_tl < nwg;                                                                                           \
-            if (d_live) {                                                                                                  \
-                int m0_, n0_;                                                                                              \
-                tile_origin(d_tl, m0_, n0_);                                                                               \
-                d_baseA = (unsigned)m0_ * (unsigned)g.lda * 2u;                                                            \
-                d_baseB = (unsigned)n0_ * (unsigned)g.ldb * 2u;                                                            \
-            }                                                                                                              \
-        }                                                                                                                  \
-    }
-    // ---- fragment addresses (stage base added per K tile)
-    int aaddr[2], baddr[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const int c = ((4 * ks + lq) ^ sw) << 4;
-        aaddr[ks] = wr * 8192 + l15 * 128 + c;
-        baddr[ks] = 32768 + wc * 8192 + l15 * 128 + c;
-    }
-    s16x8_t fa[4], fb[4];
-#define DP_RD(KS, SB)                                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                        \
-        fa[i] = *reinterpret_cast<const s16x8_t*>(lds3 + (SB) + aaddr[KS] + i * 2048);                                     \
-        fb[i] = *reinterpret_cast<const s16x8_t*>(lds3 + (SB) + baddr[KS] + i * 2048);                                     \
-    }
-#define DP_MFMA(ACC)                                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                          \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) ACC[i][j] = mfma16t<F16>(fb[j], fa[i], ACC[i][j]);
-    // ---- drain state of the finished sub-tile (plain locals: everything must stay in registers)
-    unsigned char* wl = lds3 + DP_STG_OFF + wave * DP_WSTG;
-    constexpr int NB = TR::k16 ? 4 : 2;                                  // bias quads: 16-bit path columns j * 16 + 4 lq .. + 3; fp32 path jh * 32 + 4 rch .. + 3
-    constexpr int NS = (EPI == EPI_F32_RESID || EPI == EPI_DGELU) ? 2 : 1;   // side input of the NEXT chunk
-    constexpr int NR = 2;                                                // read-back of the current chunk (row-major 16-byte pieces)
-    const int d_first = (EPI == EPI_GELU && g.outH == nullptr) ? 1 : 0, d_step = (EPI == EPI_GELU && g.outH == nullptr) ? 2 : 1;
-    int d_mw = 0, d_nw = 0, d_chunk = TR::nch;
-    f32x4_t dbias[NB], dside[NS], drb[NR];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) dbias[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < NS; ++i) dside[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < NR; ++i) drb[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const int rrow = lane >> 3, rch = lane & 7;      // read-back: row rrow (+ 8 for the second piece), 16-byte chunk rch
-    // request the side input of chunk C (residual rows in read-back layout / saved pre-activation in accumulator layout)
-#define DP_SIDE(C)                                                                                                         \
-    if constexpr (EPI == EPI_F32_RESID) {                                                                                  \
-        _Pragma("unroll") for (int r = 0; r < 2; ++r) {                                                                    \
-            int m_ = d_mw + ((C) >> 1) * 16 + rrow + 8 * r;                                                                \
-            m_ = m_ < g.M ? m_ : g.M - 1;                                                                                  \
-            dside[r] = dp_load16_nt(g.resF + (size_t)m_ * g.ldc + d_nw + ((C) & 1) * 32 + 4 * rch);                        \
-        }                                                                                                                  \
-    } else if constexpr (EPI == EPI_DGELU) {                                                                               \
-        int m_ = d_mw + (C) * 16 + l15;                                                                                    \
-        m_ = m_ < g.M ? m_ : g.M - 1;                                                                                      \
-        const bf16_t* rowp_ = g.auxH + (size_t)m_ * g.ldc + d_nw + 4 * lq;                                                 \
-        const f32x2_t a0_ = dp_load8_nt(rowp_), a1_ = dp_load8_nt(rowp_ + 16), a2_ = dp_load8_nt(rowp_ + 32), a3_ = dp_load8_nt(rowp_ + 48); \
-        dside[0] = f32x4_t{a0_.x, a0_.y, a1_.x, a1_.y};                                                                    \
-        dside[NS - 1] = f32x4_t{a2_.x, a2_.y, a3_.x, a3_.y};                                                               \
-    }
-    // a tile has just finished at (MW, NW): constants and the first chunk's side input
-#define DP_DRAIN_BEGIN(MW, NW)                                                                                             \
-    {                                                                                                                      \
-        d_mw = (MW); d_nw = (NW); d_chunk = d_first;                                                                       \
-        if (g.bias != nullptr) {                                                                                           \
-            _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_)                                                              \
-                dbias[i_] = dp_load16(g.bias + d_nw + (TR::k16 ? i_ * 16 + 4 * lq : i_ * 32 + 4 * rch));                   \
-        }                                                                                                                  \
-        DP_SIDE(0)                                                                                                         \
-    }
-#define DP_SWZ16(ROW, U) ((ROW) * 128 + (((((U) >> 1) ^ ((ROW) & 7))) << 4) + ((((U) & 1) ^ (((ROW) >> 3) & 1)) << 3))
-#define DP_STAGE16(ACC, I, MODE, BF)                                                                                       \
-    {                                                                                                                      \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                    \
-            f32x2v x0 = {ACC[I][j][0] + dbias[j % NB][0], ACC[I][j][1] + dbias[j % NB][1]};                                \
-            f32x2v x1 = {ACC[I][j][2] + dbias[j % NB][2], ACC[I][j][3] + dbias[j % NB][3]};                                \
-            if ((MODE) == 1) { x0 = gelu_fast2(x0); x1 = gelu_fast2(x1); }                                                 \
-            if ((MODE) == 2) {                                                                                             \
-                const unsigned a_lo = __float_as_uint(dside[(j >> 1) % NS][2 * (j & 1)]), a_hi = __float_as_uint(dside[(j >> 1) % NS][2 * (j & 1) + 1]); \
-                const f32x2v h0 = {to_f32<F16>((bf16_t)(a_lo & 0xFFFF)), to_f32<F16>((bf16_t)(a_lo >> 16))};               \
-                const f32x2v h1 = {to_f32<F16>((bf16_t)(a_hi & 0xFFFF)), to_f32<F16>((bf16_t)(a_hi >> 16))};               \
-                x0 = x0 * gelu_fast_grad2(h0); x1 = x1 * gelu_fast_grad2(h1);                                              \
-            }                                                                                                              \
-            uint2 pk;                                                                                                      \
-            pk.x = (BF) ? pack2<false>(x0.x, x0.y) : pack2<F16>(x0.x, x0.y);                                               \
-            pk.y = (BF) ? pack2<false>(x1.x, x1.y) : pack2<F16>(x1.x, x1.y);                                               \
-            *reinterpret_cast<uint2*>(wl + DP_SWZ16(l15, j * 4 + lq)) = pk;                                                \
-            if ((MODE) != 0) __builtin_amdgcn_sched_barrier(0);   /* one column block at a time: the GELU temporaries of four would spill */ \
-        }                                                                                                                  \
-    }
-    // rows 8..15 of the 16-bit staging hold the 8-byte halves of every 16-byte piece swapped (bank spreading of the 8-byte writes)
-#define DP_READBACK16(K0)                                                                                                  \
-    {                                                                                                                      \
-        drb[(K0) % NR] = *reinterpret_cast<const f32x4_t*>(wl + rrow * 128 + ((rch ^ (rrow & 7)) << 4));                   \
-        const f32x4_t t_ = *reinterpret_cast<const f32x4_t*>(wl + (rrow + 8) * 128 + ((rch ^ (rrow & 7)) << 4));           \
-        drb[((K0) + 1) % NR] = f32x4_t{t_[2], t_[3], t_[0], t_[1]};                                                        \
-    }
-#define DP_LDS16(ACC, C)                                                                                                   \
-    {                                                                                                                      \
-        if constexpr (EPI == EPI_GELU) {                                                                                   \
-            if (((C) & 1) == 0) { DP_STAGE16(ACC, (C) >> 1, 0, (F16 && g.bwd_bf16)) }                                      \
-            else { DP_STAGE16(ACC, (C) >> 1, 1, false) }                                                                   \
-        } else if constexpr (EPI == EPI_DGELU) {                                                                           \
-            DP_STAGE16(ACC, (C) & 3, 2, false)                                                                             \
-        } else {                                                                                                           \
-            DP_STAGE16(ACC, (C) & 3, 0, false)                                                                             \
-        }                                                                                                                  \
-        DP_READBACK16(0)                                                                                                   \
-    }
-#define DP_LDS32(ACC, C)                                                                                                   \
-    {                                                                                                                      \
-        _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                                   \
-            *reinterpret_cast<f32x4_t*>(wl + l15 * 128 + (((jj * 4 + lq) ^ (l15 & 7)) << 4)) = ACC[(C) >> 1][2 * ((C) & 1) + jj]; \
-        _Pragma("unroll") for (int r = 0; r < 2; ++r)                                                                      \
-            drb[r] = *reinterpret_cast<const f32x4_t*>(wl + (rrow + 8 * r) * 128 + ((rch ^ ((rrow + 8 * r) & 7)) << 4));   \
-    }
-    // LDS half of one drain step: chunk d_chunk of accumulator set ACC -> staging -> read-back registers
-#define DP_DRAIN_LDS(ACC)                                                                                                  \
-    if (d_chunk < TR::nch) {                                                                                               \
-        if constexpr (TR::k16) {                                                                                           \
-            switch (d_chunk) {                                                                                             \
-                case 0: DP_LDS16(ACC, 0) break;                                                                            \
-                case 1: DP_LDS16(ACC, 1) break;                                                                            \
-                case 2: DP_LDS16(ACC, 2) break;                                                                            \
-                case 3: DP_LDS16(ACC, 3) break;                                                                            \
-                case 4: DP_LDS16(ACC, (TR::nch == 8 ? 4 : 0)) break;                                                       \
-                case 5: DP_LDS16(ACC, (TR::nch == 8 ? 5 : 1)) break;                                                       \
-                case 6: DP_LDS16(ACC, (TR::nch == 8 ? 6 : 2)) break;                                                       \
-                default: DP_LDS16(ACC, (TR::nch == 8 ? 7 : 3)) break;                                                      \
-            }                                                                                                              \
-        } else {                                                                                                           \
-            switch (d_chunk) {                                                                                             \
-                case 0: DP_LDS32(ACC, 0) break;                                                                            \
-                case 1: DP_LDS32(ACC, 1) break;                                                                            \
-                case 2: DP_LDS32(ACC, 2) break;                                                                            \
-                case 3: DP_LDS32(ACC, 3) break;                                                                            \
-                case 4: DP_LDS32(ACC, 4) break;                                                                            \
-                case 5: DP_LDS32(ACC, 5) break;                                                                            \
-                case 6: DP_LDS32(ACC, 6) break;                                                                            \
-                default: DP_LDS32(ACC, 7) break;                                                                           \
-            }                                                                                                              \
-        }                                                                                                                  \
-    }
-    // memory half of the step: stores of the chunk just read back, side request for the next one
-#define DP_DRAIN_MEM()                                                                                                     \
-    if (d_chunk < TR::nch) {                                                                                               \
-        if constexpr (TR::k16) {                                                                                           \
-            const int rblk_ = EPI == EPI_GELU ? (d_chunk >> 1) : d_chunk;                                                  \
-            _Pragma("unroll") for (int r = 0; r < 2; ++r) {                                                                \
-                const int m_ = d_mw + rblk_ * 16 + rrow + 8 * r;                                                           \
-                if (m_ < g.M) {                                                                                            \
-                    if constexpr (EPI == EPI_QKV) {                                                                        \
-                        const int D_ = g.heads * 64;                                                                       \
-                        const int which_ = d_nw / D_, h_ = (d_nw - which_ * D_) >> 6;                                      \
-                        bf16_t* dst_ = which_ == 0 ? g.q : (which_ == 1 ? g.k : g.v);                                      \
-                        const int bidx_ = m_ / g.seq, t_ = m_ - bidx_ * g.seq;                                             \
-                        v3_st<f32x4_t>(dst_ + ((size_t)(bidx_ * g.heads + h_) * g.seq + t_) * 64 + rch * 8, drb[r]);       \
-                    } else if constexpr (EPI == EPI_GELU) {                                                                \
-                        v3_st<f32x4_t>(((d_chunk & 1) ? g.outH2 : g.outH) + (size_t)m_ * g.ldc + d_nw + rch * 8, drb[r]);  \
-                    } else {                                                                                               \
-                        v3_st<f32x4_t>(g.outH + (size_t)m_ * g.ldc + d_nw + rch * 8, drb[r]);                              \
-                    }                                                                                                      \
-                }                                                                                                          \
-            }                                                                                                              \
-        } else {                                                                                                           \
-            const f32x4_t b_ = dbias[(d_chunk & 1) % NB];                                                                  \
-            _Pragma("unroll") for (int r = 0; r < 2; ++r) {                                                                \
-                const int m_ = d_mw + (d_chunk >> 1) * 16 + rrow + 8 * r;                                                  \
-                if (m_ < g.M) {                                                                                            \
-                    f32x4_t v_ = drb[r];                                                                                   \
-                    if constexpr (EPI == EPI_F32) v_ = v_ * g.alpha + b_;                                                  \
-                    else v_ = v_ + b_ + dside[r % NS];                                                                     \
-                    v3_st<f32x4_t>(g.outF + (size_t)m_ * g.ldc + d_nw + (d_chunk & 1) * 32 + 4 * rch, v_);                 \
-                }                                                                                                          \
-            }                                                                                                              \
-        }                                                                                                                  \
-        d_chunk += d_step;                                                                                                 \
-        if (d_chunk < TR::nch) { DP_SIDE(d_chunk) }                                                                        \
-    }
-    // every register a drain load may still be writing is tied to the wait that retires it
-#define DP_TIE()                                                                                                           \
-    {                                                                                                                      \
-        _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_) asm volatile("" : "+v"(dbias[i_]) :: "memory");                  \
-        _Pragma("unroll") for (int i_ = 0; i_ < NS; ++i_) asm volatile("" : "+v"(dside[i_]) :: "memory");                  \
-    }
-
-    f32x4_t accX[4][4], accY[4][4];
-#define DP_ZERO(ACC)                                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) ACC[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    // one tile: accumulate into ACC while DRN (the previous tile's set) drains
-#define DP_TILE(ACC, DRN)                                                                                                  \
-    {                                                                                                                      \
-        DP_ZERO(ACC)                                                                                                       \
-        for (int kt = 0; kt < nk; ++kt) {                                                                                  \
-            const int sb = c_stage * DP_STAGE;                                                                             \
-            /* ---- phase 1 */                                                                                             \
-            if (d_live) DP_DMA_FIRST()                                                                                     \
-            DP_RD(0, sb)                                                                                                   \
-            __builtin_amdgcn_sched_barrier(0);                                                                             \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
-            __builtin_amdgcn_s_barrier();                                                                                  \
-            __builtin_amdgcn_sched_barrier(0);                                                                             \
-            DP_MFMA(ACC)                                                                                                   \
-            __builtin_amdgcn_sched_barrier(0);                                                                             \
-            __builtin_amdgcn_s_barrier();                                                                                  \
-            __builtin_amdgcn_sched_barrier(0);                                                                             \
-            /* ---- phase 2 */                                                                                             \
-            if (d_live) { DP_DMA_SECOND() asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }                               \
-            else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                                                      \
-            DP_TIE()                                                                                                       \
-            DP_ADVANCE()                                                                                                   \
-            DP_DRAIN_LDS(DRN)      /* before the fragment reads: their 32 registers are free while the chunk is converted */ \
-            __builtin_amdgcn_sched_barrier(0);                                                                             \
-            DP_RD(1, sb)                                                                                                   \
-            __builtin_amdgcn_sched_barrier(0);                                                                             \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
-            __builtin_amdgcn_s_barrier();                                                                                  \
-            __builtin_amdgcn_sched_barrier(0);                                                                             \
-            DP_DRAIN_MEM()                                                                                                   \
-            DP_MFMA(ACC)                                                                                                   \
-            __builtin_amdgcn_sched_barrier(0);                                                                             \
-            __builtin_amdgcn_s_barrier();                                                                                  \
-            __builtin_amdgcn_sched_barrier(0);                                                                             \
-            c_stage = c_stage == 2 ? 0 : c_stage + 1;                                                                      \
-        }                                                                                                                  \
-        /* whatever the K loop was too short to drain goes out now (wave-private: no barrier needed) */                    \
-        while (d_chunk < TR::nch) {                                                                                       \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
-            DP_TIE()                                                                                                       \
-            DP_DRAIN_LDS(DRN)                                                                                              \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
-            DP_DRAIN_MEM()                                                                                                   \
-        }                                                                                                                  \
-    }
-
-    if (!d_live) return;
-    // prologue: K tiles 0 and 1 of the stream; the second wave group starts half a phase behind
-    DP_DMA_FIRST() DP_DMA_SECOND() DP_ADVANCE()
-    if (d_live) { DP_DMA_FIRST() DP_DMA_SECOND() asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); DP_ADVANCE() }
-    else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();
-    int c_stage = 0;
-    int tl = blockIdx.x;
-    while (true) {
-        int m0, n0;
-        tile_origin(tl, m0, n0);
-        DP_TILE(accX, accY)
-        DP_DRAIN_BEGIN(m0 + wr * 64, n0 + wc * 64)
-        tl += (int)gridDim.x;
-        if (tl >= nwg) {        // last tile of this workgroup: nothing left to hide its drain under
-            while (d_chunk < TR::nch) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                DP_TIE()
-                DP_DRAIN_LDS(accX)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                DP_DRAIN_MEM()
-            }
-            break;
-        }
-        tile_origin(tl, m0, n0);
-        DP_TILE(accY, accX)
-        DP_DRAIN_BEGIN(m0 + wr * 64, n0 + wc * 64)
-        tl += (int)gridDim.x;
-        if (tl >= nwg) {
-            while (d_chunk < TR::nch) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                DP_TIE()
-                DP_DRAIN_LDS(accY)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                DP_DRAIN_MEM()
-            }
-            break;
-        }
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();   // pairs with the second group's last barrier
-#undef DP_DMA_A
-#undef DP_DMA_B
-#undef DP_DMA_FIRST
-#undef DP_DMA_SECOND
-#undef DP_ADVANCE
-#undef DP_RD
-#undef DP_MFMA
-#undef DP_SWZ16
-#undef DP_STAGE16
-#undef DP_READBACK16
-#undef DP_LDS16
-#undef DP_LDS32
-#undef DP_DRAIN_LDS
-#undef DP_TIE
-#undef DP_SIDE
-#undef DP_DRAIN_BEGIN
-#undef DP_DRAIN_MEM
-#undef DP_ZERO
-#undef DP_TILE
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // Weight-gradient GEMM in TN form: dW[m, n] += sum_t dY[t, m] * X[t, n] with BOTH operands read in their natural row-major
 // [token][feature] layout -- no transposed operand copies in HBM (the NT kernels need dY^T and X^T: 6.4 ms/step of transposes).
 // The contraction index is the slow dimension of both tiles, so the MFMA fragments (8 consecutive tokens per lane) are columns of
@@ -1557,55 +1146,12 @@ extern "C" int sed_gemm_dw_tn(const void* dY, const void* X, int x_f16, int T, i
     return sed_check_launch();
 }
 
-// which epilogue codes may take the drain-pipelined kernel: SED_GEMM_DP (bit mask, default all), or sed_gemm_dp_mask() at run time
-static int g_dp_mask = -2;
-static int dp_mask_value() {
-    if (g_dp_mask == -2) g_dp_mask = getenv("SED_GEMM_DP") ? (int)strtol(getenv("SED_GEMM_DP"), nullptr, 0) : 0x7fffffff;
-    return g_dp_mask;
-}
-extern "C" int sed_gemm_dp_mask(int mask) {
-    const int old = dp_mask_value();
-    if (mask >= 0) g_dp_mask = mask;
-    return old < 0 ? 0x7fffffff : old;
-}
-
 template <int EPI>
 static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
     if (g.M <= 0 || g.N % TILE != 0 || g.K % BK != 0 || g.ksplit < 1) return SED_ERR_ARG;
     if ((g.lda % 8) || (g.ldb % 8) || (g.ldc % 4)) return SED_ERR_ARG;
     // 256^2 kernel: every forward / dX GEMM of the model (N % 256 == 0, M >= 1024).  The split-K weight-gradient GEMMs of the NT
     // form stay on the 128^2 kernel (two workgroups per CU cover its atomic epilogue).
-    // drain-pipelined kernel (epilogue of tile i under the K loop of tile i + 1): the forward / dX GEMMs with 16-bit, fused-GELU,
-    // GELU', head-split (row-major q, k, v only), fp32 and fp32-residual epilogues.  SED_GEMM_DP: bit mask of epilogue codes (default all).
-    if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_QKV || EPI == EPI_DGELU || EPI == EPI_F32 || EPI == EPI_F32_RESID) {
-        bool ok = ((dp_mask_value() >> EPI) & 1) && g.gbias == nullptr && g.N % DP_TN == 0 && g.M >= 1024 && g.ksplit == 1 && g.K >= 2 * BK &&
-                  ((size_t)g.M + DP_TM) * g.lda * 2 < (1ull << 32) && ((size_t)g.N + DP_TN) * g.ldb * 2 < (1ull << 32);
-        if (EPI == EPI_QKV) ok = ok && g.qt == nullptr && g.kt == nullptr && g.vt == nullptr && g.q2 == nullptr && g.q2t == nullptr &&
-                                 g.pu == nullptr && g.pv == nullptr && g.q != nullptr && g.k != nullptr && g.v != nullptr && !g.bwd_bf16;
-        if (EPI == EPI_F32_RESID) ok = ok && g.resF != nullptr;
-        if (ok) {
-            static int ncu_dp = 0;
-            if (ncu_dp == 0) {
-                int dev = 0, n = 0;
-                (void)hipGetDevice(&dev);
-                if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-                ncu_dp = n & ~7;
-            }
-            GemmArgs gg = g;
-            gg.group_m = 4;
-            const int tiles = cdiv(g.M, DP_TM) * (g.N / DP_TN);
-            dim3 gridp(tiles < ncu_dp ? tiles : ncu_dp);
-            static bool attrd[2] = {false, false};
-            if (f16) {
-                if (!attrd[1]) { (void)hipFuncSetAttribute((const void*)gemm_nt_dp_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS); attrd[1] = true; }
-                hipLaunchKernelGGL((gemm_nt_dp_kernel<EPI, true>), gridp, dim3(512), DP_LDS, s, gg);
-            } else {
-                if (!attrd[0]) { (void)hipFuncSetAttribute((const void*)gemm_nt_dp_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS); attrd[0] = true; }
-                hipLaunchKernelGGL((gemm_nt_dp_kernel<EPI, false>), gridp, dim3(512), DP_LDS, s, gg);
-            }
-            return sed_check_launch();
-        }
-    }
     if constexpr (EPI != EPI_ATOMIC) if (g.N % V3_T == 0 && g.M >= 1024 && g.ksplit == 1) {
         dim3 grid3(cdiv(g.M, V3_T) * (g.N / V3_T), 1);
         if ((long long)g.lda * 2 * V3_T >= (1LL << 31) || (long long)g.ldb * 2 * V3_T >= (1LL << 31)) return SED_ERR_ARG;  // 32-bit panel offsets

@@ -55,6 +55,23 @@ __device__ __forceinline__ void row_store_bf16_nt(const Row& r, bf16_t* p, int l
         __builtin_nontemporal_store(pk, reinterpret_cast<u32x2nt*>(p) + lane + 64 * i);
     }
 }
+// split-precision operand image of a row: [hi | lo | hi] f16 over 3 * DM columns (what sed_split3_f16 makes in a pass of its own)
+__device__ __forceinline__ void row_store_split3_nt(const Row& r, bf16_t* p, int lane) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float v[4] = {r.v[i].x, r.v[i].y, r.v[i].z, r.v[i].w};
+        bf16_t h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h[e] = f2h(v[e]); l[e] = f2h(v[e] - h2f(h[e])); }
+        u32x2nt hi, lo;
+        hi[0] = (unsigned)h[0] | ((unsigned)h[1] << 16); hi[1] = (unsigned)h[2] | ((unsigned)h[3] << 16);
+        lo[0] = (unsigned)l[0] | ((unsigned)l[1] << 16); lo[1] = (unsigned)l[2] | ((unsigned)l[3] << 16);
+        u32x2nt* q = reinterpret_cast<u32x2nt*>(p) + lane + 64 * i;
+        __builtin_nontemporal_store(hi, q);
+        __builtin_nontemporal_store(lo, q + DM / 4);
+        __builtin_nontemporal_store(hi, q + 2 * (DM / 4));
+    }
+}
 #define ROW_FOREACH(i, c) for (int i = 0; i < NV; ++i) for (int c = 0; c < 4; ++c)
 __device__ __forceinline__ float& f4(float4& v, int c) { return reinterpret_cast<float*>(&v)[c]; }
 __device__ __forceinline__ const float& f4(const float4& v, int c) { return reinterpret_cast<const float*>(&v)[c]; }
@@ -102,7 +119,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         if (row >= M) break;
 #pragma unroll
         ROW_FOREACH(i, c) f4(r[k].v[i], c) = (f4(r[k].v[i], c) - mu[k]) * rs[k] * f4(g.v[i], c) + f4(b.v[i], c);
-        if (y16 != nullptr) row_store_bf16_nt(r[k], y16 + (size_t)row * DM, lane, f16);
+        if (y16 != nullptr) {
+            if (f16 == 4) row_store_split3_nt(r[k], y16 + (size_t)row * 3 * DM, lane);
+            else row_store_bf16_nt(r[k], y16 + (size_t)row * DM, lane, f16);
+        }
         if (y32 != nullptr) row_store_nt(r[k], y32 + (size_t)row * DM, lane);
         if (lane == 0 && mean != nullptr) { mean[row] = mu[k]; rstd[row] = rs[k]; }
     }

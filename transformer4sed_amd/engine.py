@@ -374,12 +374,12 @@ class SedEngine:
             in_scale = math.sqrt(D) if li == 0 else 1.0
             wk = (lambda n: W[n].ws) if SP else (lambda n: W[n].w)   # forward operand image of a decoder weight
             KD = 3 * D if SP else D
-            y16 = None if SP else E(M, D, dt=A16)
+            y16 = E(M, 3 * D, dt=F16) if SP else E(M, D, dt=A16)      # split precision: the LayerNorm writes the [hi | lo | hi] image itself
             y32 = E(B, T, D)
             mean1, rstd1 = (E(M), E(M)) if save else (None, None)
             call("sed_layernorm_fwd", cur, self.P(p + "norm1.weight"), self.P(p + "norm1.bias"), 1e-5, in_scale, y16,
-                 y32, mean1, rstd1, M, D, f16)
-            yop = split3(y32, M, D) if SP else y16
+                 y32, mean1, rstd1, M, D, 4 if SP else f16)
+            yop = y16
             # p = linear_pos(pos_emb), head-split [H, Rpad, 64] (+ transposed [H, 64, Rpad] for backward)
             Ph = E(H, Rpad, 64, dt=A16)
             Pt = torch.zeros(H, 64, Rpad, dtype=A16, device=dev) if save else None
@@ -407,13 +407,15 @@ class SedEngine:
             gemm_nt(split3(o16, M, D) if SP else o16, wk(p + "attn.out_proj.weight"), EPI_F32_RESID,
                     bias=self.P(p + "attn.out_proj.bias"), res=y32, outF=x1)
             h2 = E(M, D, dt=F32 if SP else A16)
+            h2s = E(M, 3 * D, dt=F16) if SP else None
             mean2, rstd2 = (E(M), E(M)) if save else (None, None)
+            # (the fp32 h2 is only needed by the backward: weight gradient of fc1)
             call("sed_layernorm_fwd", x1, self.P(p + "norm2.weight"), self.P(p + "norm2.bias"), 1e-5, 1.0,
-                 None if SP else h2, h2 if SP else None, mean2, rstd2, M, D, f16)
+                 h2s if SP else h2, (h2 if save else None) if SP else None, mean2, rstd2, M, D, 4 if SP else f16)
             hpre = E(M, D, dt=B16)
             if SP:
                 act = E(M, D)
-                gemm_nt(split3(h2, M, D), wk(p + "mlp.fc1.weight"), EPI_GELU32, bias=self.P(p + "mlp.fc1.bias"), outH=hpre,
+                gemm_nt(h2s, wk(p + "mlp.fc1.weight"), EPI_GELU32, bias=self.P(p + "mlp.fc1.bias"), outH=hpre,
                         outF=act)
             else:
                 act = E(M, D, dt=A16)
