@@ -71,89 +71,59 @@ __device__ __forceinline__ int ypad_index(int n, int Ly) {
 
 #define MEL_CSR_CAP 1280      // non-zero filterbank weights held in LDS (every bin lies under at most two triangles: <= 1026 + edges)
 // complex helpers on packed fp32 pairs (v_pk_mul / v_pk_fma / v_pk_add): (re, im)
-typedef f32x2v cpx;
-__device__ __forceinline__ cpx cmul(cpx z, cpx w) { return cpx{z.x, z.x} * w + cpx{z.y, z.y} * cpx{-w.y, w.x}; }
-__device__ __forceinline__ cpx mul_neg_i(cpx d) { return cpx{d.y, -d.x}; }
-__device__ __forceinline__ cpx mul_pos_i(cpx d) { return cpx{-d.y, d.x}; }
-// Y[q] = sum_a x[a] (-i)^(a q)
-__device__ __forceinline__ void radix4(cpx x0, cpx x1, cpx x2, cpx x3, cpx& y0, cpx& y1, cpx& y2, cpx& y3) {
-    const cpx e0 = x0 + x2, e1 = x0 - x2, o0 = x1 + x3, o1 = mul_neg_i(x1 - x3);
-    y0 = e0 + o0; y2 = e0 - o0; y1 = e1 + o1; y3 = e1 - o1;
+__device__ __forceinline__ f32x2v cmul_tw(f32x2v z, f32x2v tw, f32x2v twp) {   // z * tw, twp = (-tw.y, tw.x)
+    return f32x2v{z.x, z.x} * tw + f32x2v{z.y, z.y} * twp;
 }
-// in-register 16-point DFT, natural order in and out: out[k] = sum_n v[n] exp(-2 pi i n k / 16).  n = 4 a + c, k = q + 4 s:
-// t[c][q] = radix-4 over a, times exp(-2 pi i c q / 16), then radix-4 over c.
-__device__ __forceinline__ void dft16(cpx (&v)[16]) {
-    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
-    cpx t[4][4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) radix4(v[c], v[c + 4], v[c + 8], v[c + 12], t[c][0], t[c][1], t[c][2], t[c][3]);
-    // twiddles W16^(c q), W16^m = (cos(pi m / 8), -sin(pi m / 8)):  m = 1: (C1,-S1)  2: (R2,-R2)  3: (S1,-C1)  4: (0,-1)  6: (-R2,-R2)  9: (-C1, S1)
-    t[1][1] = cmul(t[1][1], cpx{C1, -S1});
-    t[1][2] = cmul(t[1][2], cpx{R2, -R2});
-    t[1][3] = cmul(t[1][3], cpx{S1, -C1});
-    t[2][1] = cmul(t[2][1], cpx{R2, -R2});
-    t[2][2] = mul_neg_i(t[2][2]);
-    t[2][3] = cmul(t[2][3], cpx{-R2, -R2});
-    t[3][1] = cmul(t[3][1], cpx{S1, -C1});
-    t[3][2] = cmul(t[3][2], cpx{-R2, -R2});
-    t[3][3] = cmul(t[3][3], cpx{-C1, S1});
-#pragma unroll
-    for (int q = 0; q < 4; ++q) radix4(t[0][q], t[1][q], t[2][q], t[3][q], v[q], v[q + 4], v[q + 8], v[q + 12]);
-}
-// value of the quad neighbour lane ^ 1 / lane ^ 2 (DPP quad_perm: no LDS traffic)
-__device__ __forceinline__ float quad_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); }   // [1,0,3,2]
-__device__ __forceinline__ float quad_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)); }   // [2,3,0,1]
+__device__ __forceinline__ f32x2v mul_neg_i(f32x2v d) { return f32x2v{d.y, -d.x}; }
 
-#define FE_TSTRIDE 68                      // float2 row stride of the 16 x 64 transpose image (conflict-free both ways)
-#define FE_WAVE_LDS (16 * FE_TSTRIDE * 8)   // 8704 B per wave: transpose image, then the spectrum in natural order, then the two power spectra
-#define FE_SPAN (HOP * (FR_PER_WG - 1) + WINLEN)   // pre-emphasised samples one workgroup's 8 frames touch (3040)
-
-// One WAVE = one pair of frames = one 1024-point complex FFT (frame a real part, frame b imaginary part), with no workgroup barrier
-// inside: 1024 = 16 x 16 x 4 -- a 16-point DFT in registers over n1 (lane = n2, n = 64 n1 + n2), twiddle, a 16 x 64 transpose through
-// the wave's own LDS image, a 16-point DFT in registers over j (lane = (k1, r), n2 = 4 j + r), twiddle, and the last radix-4 across
-// the four lanes of a quad with DPP moves.  The workgroup (4 waves = 8 frames) shares the pre-emphasised, reflect-padded samples of
-// its span (read from HBM once, 16-byte-friendly, instead of 2.5 x 2 times), the window taps and the non-zero filterbank weights in
-// LDS; two workgroup barriers in all (after the shared tables, before the 128 x 8 output tile is written).
-// (The 256-thread-per-FFT version this replaces spent its time at 36 workgroup barriers per 8 frames with 4 waves per SIMD:
-//  111 us for 32 clips against ~12 us of packed-fp32 arithmetic.)
+// One workgroup = 8 frames as 4 pairs; a pair of real frames is one 1024-point complex radix-4 Stockham FFT in LDS.  Everything a
+// pair needs besides its samples lives on chip for the whole workgroup: the window taps and the 12 twiddle factors of a lane in
+// registers, the non-zero filterbank weights as a CSR image in LDS; the samples of the next pair are requested before the current
+// pair's FFT.  The arithmetic is packed fp32 on (re, im) pairs.
 __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ wav, const unsigned* __restrict__ maxbits,
                                                      const float* __restrict__ window,  // [800] symmetric Hann
                                                      const float2* __restrict__ twiddle,  // [1024] exp(-2 pi i k / 1024)
                                                      const float* __restrict__ melw,      // [128, 513] dense
                                                      const int* __restrict__ mel_range,   // [128, 2] first bin, end bin
                                                      float* __restrict__ out, int L, int T, int do_log) {
-    __shared__ float ybuf[FE_SPAN + 16];
-    __shared__ float wwin[WINLEN];
+    __shared__ f32x2v z[2][NFFT];
+    __shared__ float pw[2][NBIN + 3];
+    __shared__ float ostage[NMEL][FR_PER_WG];
     __shared__ float wcsr[MEL_CSR_CAP];
     __shared__ int moff[NMEL + 1];
-    __shared__ float ostage[NMEL][FR_PER_WG];
-    __shared__ __attribute__((aligned(16))) unsigned char wbuf[4][FE_WAVE_LDS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, t0 = blockIdx.x * FR_PER_WG;
+    const int tid = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * FR_PER_WG;
     const float* w = wav + (size_t)b * L;
     const float rinv = 1.0f / (__uint_as_float(maxbits[b]) + 1e-10f);
     const int Ly = L - 1;
-    // ---- twiddles of this lane, requested first (consumed after the first in-register DFT)
-    cpx twA[15];
+    // ---- per-lane constants
+    float wv[4];
 #pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) { const float2 t = twiddle[lane * k1]; twA[k1 - 1] = cpx{t.x, t.y}; }
-    // ---- shared tables: pre-emphasised samples of the span (x rinv), window taps, filterbank CSR
-    const int mbase = HOP * t0 + WINOFF - NFFT / 2;           // padded-axis sample of ybuf[0], minus the centre offset
-    for (int i = tid; i < FE_SPAN; i += 256) {
-        int m = ypad_index(mbase + i + NFFT / 2, Ly);
-        m = m < 0 ? 0 : (m > Ly - 1 ? Ly - 1 : m);      // (only frames past T, whose columns are never written, can land outside)
-        ybuf[i] = (w[m + 1] - 0.97f * w[m]) * rinv;
+    for (int q = 0; q < 4; ++q) {
+        const int n = tid + 256 * q;
+        wv[q] = (n >= WINOFF && n < WINOFF + WINLEN) ? window[n - WINOFF] * rinv : 0.f;     // window tap x clip normalisation
     }
-    for (int i = tid; i < WINLEN; i += 256) wwin[i] = window[i];
-    const int mm = tid & 127, half = tid >> 7;
-    const int k0 = mel_range[2 * mm], k1r = mel_range[2 * mm + 1];
+    f32x2v tw[4][3], twp[4][3];      // stages Ns = 4, 16, 64, 256 (the first stage has none)
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const int Ns = 4 << (2 * st), k = tid & (Ns - 1);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            const float2 t = twiddle[q * k * (256 / Ns)];
+            tw[st][q - 1] = f32x2v{t.x, t.y};
+            twp[st][q - 1] = f32x2v{-t.y, t.x};
+        }
+    }
+    // ---- filterbank as CSR in LDS
+    const int mm = tid & 127, which = tid >> 7;
+    const int k0 = mel_range[2 * mm], k1 = mel_range[2 * mm + 1];
     {   // exclusive prefix sum of the 128 band widths: inclusive shuffle scan inside waves 0 and 1, wave 1 adds wave 0's total
-        int incl = k1r - k0;
+        int incl = k1 - k0;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int up = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += up;
+            if ((tid & 63) >= o) incl += up;
         }
-        if (tid == 63) moff[NMEL] = incl;
+        if (tid == 63) moff[NMEL] = incl;          // total of the first 64 bands, parked in the last slot for a moment
         __syncthreads();
         const int base = (tid >= 64 && tid < NMEL) ? moff[NMEL] : 0;
         __syncthreads();
@@ -161,114 +131,92 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
         if (tid == 0) moff[0] = 0;
         __syncthreads();
     }
-    const int nnz = moff[NMEL];
+    const int off = moff[mm], nnz = moff[NMEL];
     const bool csr = nnz <= MEL_CSR_CAP;
-    if (csr) {
-        const int off = moff[mm];
-        for (int k = k0 + half; k < k1r; k += 2) wcsr[off + k - k0] = melw[(size_t)mm * NBIN + k];
-    }
-    __syncthreads();
-    // ---- this wave's pair
-    const int ta = t0 + 2 * wave, tb = ta + 1;
-    cpx* tr = reinterpret_cast<cpx*>(wbuf[wave]);
-    cpx v[16];
+    if (csr)
+        for (int k = k0 + which; k < k1; k += 2) wcsr[off + k - k0] = melw[(size_t)mm * NBIN + k];
+    // ---- samples of pair 0
+    float sa[4][2], sb[4][2];        // [q][x[m], x[m + 1]] of frames a and b
+    auto fetch = [&](int pair) {
+        const int ta = t0 + 2 * pair, tb = ta + 1;
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) {
-        const int n = 64 * n1 + lane;
-        float a = 0.f, c = 0.f;
-        if (n >= WINOFF && n < WINOFF + WINLEN) {
-            const float wn = wwin[n - WINOFF];
-            const int i = HOP * (ta - t0) + n - WINOFF;
-            a = ta < T ? wn * ybuf[i] : 0.f;
-            c = tb < T ? wn * ybuf[i + HOP] : 0.f;
+        for (int q = 0; q < 4; ++q) {
+            const int n = tid + 256 * q;
+            sa[q][0] = sa[q][1] = sb[q][0] = sb[q][1] = 0.f;
+            if (n >= WINOFF && n < WINOFF + WINLEN) {
+                if (ta < T) { const int m = ypad_index(HOP * ta + n, Ly); sa[q][0] = w[m]; sa[q][1] = w[m + 1]; }
+                if (tb < T) { const int m = ypad_index(HOP * tb + n, Ly); sb[q][0] = w[m]; sb[q][1] = w[m + 1]; }
+            }
         }
-        v[n1] = cpx{a, c};
-    }
-    dft16(v);                                               // over n1 -> k1
+    };
+    fetch(0);
+    for (int pair = 0; pair < FR_PER_WG / 2; ++pair) {
+        // windowed, pre-emphasised frames -> complex input (frame a real part, frame b imaginary part)
 #pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmul(v[k1], twA[k1 - 1]);
+        for (int q = 0; q < 4; ++q)
+            z[0][tid + 256 * q] = f32x2v{wv[q] * (sa[q][1] - 0.97f * sa[q][0]), wv[q] * (sb[q][1] - 0.97f * sb[q][0])};
+        __syncthreads();
+        if (pair + 1 < FR_PER_WG / 2) fetch(pair + 1);       // in flight during the FFT
+        int cur = 0;
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) tr[k1 * FE_TSTRIDE + lane] = v[k1];
-    const int k1l = lane >> 2, r = lane & 3;
-    cpx twB[15];
+        for (int st = 0; st < 5; ++st) {
+            const int Ns = 1 << (2 * st);
+            const int j = tid, k = j & (Ns - 1);
+            f32x2v u[4];
 #pragma unroll
-    for (int k2a = 1; k2a < 16; ++k2a) { const float2 t = twiddle[16 * r * k2a]; twB[k2a - 1] = cpx{t.x, t.y}; }
+            for (int q = 0; q < 4; ++q) u[q] = z[cur][j + q * 256];
+            if (st > 0) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = tr[k1l * FE_TSTRIDE + 4 * j + r];
-    dft16(v);                                               // over j -> k2a
-#pragma unroll
-    for (int k2a = 1; k2a < 16; ++k2a) v[k2a] = cmul(v[k2a], twB[k2a - 1]);
-    // radix-4 over r across the quad: lanes 0..3 end up with k2b = 0, 2, 1, 3
-#pragma unroll
-    for (int k2a = 0; k2a < 16; ++k2a) {
-        const cpx p2 = cpx{quad_xor2(v[k2a].x), quad_xor2(v[k2a].y)};
-        const cpx s = (r & 2) ? p2 - v[k2a] : v[k2a] + p2;          // lanes 0, 1: V0 + V2, V1 + V3;  lanes 2, 3: V0 - V2, V1 - V3
-        const cpx p1 = cpx{quad_xor1(s.x), quad_xor1(s.y)};
-        cpx o;
-        if (r == 0) o = s + p1;                                     // (V0 + V2) + (V1 + V3)          k2b = 0
-        else if (r == 1) o = p1 - s;                                // (V0 + V2) - (V1 + V3)          k2b = 2
-        else if (r == 2) o = s + mul_neg_i(p1);                     // (V0 - V2) - i (V1 - V3)        k2b = 1
-        else o = p1 + mul_pos_i(s);                                 // (V0 - V2) + i (V1 - V3)        k2b = 3
-        v[k2a] = o;
-    }
-    // spectrum to LDS in natural order (8 float2 of padding per 256 keep the four quad lanes on different banks)
-    const int k2b = (r == 1) ? 2 : (r == 2 ? 1 : r);
-#pragma unroll
-    for (int k2a = 0; k2a < 16; ++k2a) {
-        const int k = k1l + 16 * k2a + 256 * k2b;
-        tr[k + 8 * k2b] = v[k2a];
-    }
-    // split the two real spectra: Xa = (Z[k] + conj Z[N-k]) / 2, Xb = (Z[k] - conj Z[N-k]) / (2i); power; all reads before the writes
-    float pa[9], pb[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const int k = lane + 64 * i;
-        pa[i] = pb[i] = 0.f;
-        if (k < NBIN) {
+                for (int q = 1; q < 4; ++q) u[q] = cmul_tw(u[q], tw[st > 0 ? st - 1 : 0][q - 1], twp[st > 0 ? st - 1 : 0][q - 1]);
+            }
+            const f32x2v v0 = u[0] + u[2], v1 = u[0] - u[2], v2 = u[1] + u[3], v3 = mul_neg_i(u[1] - u[3]);
+            const int j0 = ((j / Ns) * Ns * 4) + k;
+            const int nxt = cur ^ 1;
+            z[nxt][j0] = v0 + v2;
+            z[nxt][j0 + Ns] = v1 + v3;
+            z[nxt][j0 + 2 * Ns] = v0 - v2;
+            z[nxt][j0 + 3 * Ns] = v1 - v3;
+            __syncthreads();
+            cur = nxt;
+        }
+        // split the two real spectra: Xa = (Z[k] + conj Z[N-k]) / 2, Xb = (Z[k] - conj Z[N-k]) / (2i); power
+        for (int k = tid; k < NBIN; k += 256) {
             const int kn = (NFFT - k) & (NFFT - 1);
-            const cpx zk = tr[k + 8 * (k >> 8)], zn = tr[kn + 8 * (kn >> 8)];
+            const f32x2v zk = z[cur][k], zn = z[cur][kn];
             const float yr = zn.x, yi = -zn.y;
             const float ar = 0.5f * (zk.x + yr), ai = 0.5f * (zk.y + yi);
             const float dr = zk.x - yr, di = zk.y - yi;       // (Z - conj Zn)
             const float br = 0.5f * di, bi = -0.5f * dr;      // divided by 2i
-            pa[i] = ar * ar + ai * ai;
-            pb[i] = br * br + bi * bi;
+            pw[0][k] = ar * ar + ai * ai;
+            pw[1][k] = br * br + bi * bi;
         }
-    }
-    asm volatile("" ::: "memory");     // the power spectra overwrite the spectrum image: keep every read above this line
-    float* pw = reinterpret_cast<float*>(wbuf[wave]);          // [2][NBIN + 3]
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const int k = lane + 64 * i;
-        if (k < NBIN) { pw[k] = pa[i]; pw[NBIN + 3 + k] = pb[i]; }
-    }
-    // filterbank: lane -> mel bins lane, lane + 64 of both frames
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int m = lane + 64 * h;
-        const int q0 = mel_range[2 * m], q1 = mel_range[2 * m + 1], n = q1 - q0;
-        float acc_a = 0.f, acc_b = 0.f;
-        if (csr) {
-            const float* wr = wcsr + moff[m];
-            const float* ppa = pw + q0;
-            const float* ppb = pw + NBIN + 3 + q0;
-            for (int i = 0; i < n; ++i) { const float wt = wr[i]; acc_a += wt * ppa[i]; acc_b += wt * ppb[i]; }
-        } else {
-            const float* wrow = melw + (size_t)m * NBIN;
-            for (int k = q0; k < q1; ++k) { const float wt = wrow[k]; acc_a += wt * pw[k]; acc_b += wt * pw[NBIN + 3 + k]; }
+        __syncthreads();
+        {
+            float acc = 0.f;
+            if (csr) {
+                const float* wr = wcsr + off;
+                const float* pp = pw[which] + k0;
+                const int n = k1 - k0;
+                int i = 0;
+                for (; i + 3 < n; i += 4) acc += wr[i] * pp[i] + wr[i + 1] * pp[i + 1] + wr[i + 2] * pp[i + 2] + wr[i + 3] * pp[i + 3];
+                for (; i < n; ++i) acc += wr[i] * pp[i];
+            } else {
+                const float* wrow = melw + (size_t)mm * NBIN;
+                for (int k = k0; k < k1; ++k) acc += wrow[k] * pw[which][k];
+            }
+            ostage[mm][2 * pair + which] = do_log ? (__logf(acc + 1e-5f) + 4.5f) / 5.0f : acc;
         }
-        ostage[m][2 * wave] = do_log ? (__logf(acc_a + 1e-5f) + 4.5f) / 5.0f : acc_a;
-        ostage[m][2 * wave + 1] = do_log ? (__logf(acc_b + 1e-5f) + 4.5f) / 5.0f : acc_b;
+        __syncthreads();
     }
-    __syncthreads();
     // 128 x 8 tile -> global: thread (m, half) writes 4 consecutive frames
     {
-        const int m = tid >> 1, hf = tid & 1, t = t0 + 4 * hf;
+        const int m = tid >> 1, half = tid & 1, t = t0 + 4 * half;
         float* dst = out + ((size_t)b * NMEL + m) * T + t;
         if (t + 3 < T && (T & 3) == 0) {
-            *reinterpret_cast<float4*>(dst) = make_float4(ostage[m][4 * hf], ostage[m][4 * hf + 1], ostage[m][4 * hf + 2], ostage[m][4 * hf + 3]);
+            *reinterpret_cast<float4*>(dst) = make_float4(ostage[m][4 * half], ostage[m][4 * half + 1],
+                                                          ostage[m][4 * half + 2], ostage[m][4 * half + 3]);
         } else {
-            for (int i = 0; i < 4; ++i) if (t + i < T) dst[i] = ostage[m][4 * hf + i];
+            for (int i = 0; i < 4; ++i) if (t + i < T) dst[i] = ostage[m][4 * half + i];
         }
     }
 }
