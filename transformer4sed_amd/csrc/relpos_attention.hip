@@ -77,176 +77,231 @@ __device__ __forceinline__ void bandT_lstore(const BandRegs& b, unsigned char* d
 }
 
 // ---------------------------------------------------------------------------------------------------
-// forward
+// forward, on v_mfma_f32_16x16x32 with 8 waves (2 per SIMD) per workgroup -- the structure of the dQ kernel below:
+//   workgroup = 128 queries, wave = 16 queries x 64-key tiles, lane = (query column c = lane & 15, row group g = lane >> 4).
+//   (The first version -- 4 waves x 32 queries on 32x32x16, 238 VGPRs and 128 KiB of LDS, i.e. ONE wave per SIMD with nothing to
+//   hide its LDS round trips behind, G^T scattered with 48 ds_write_b32 and gathered with 32 ds_read_b32 per lane per tile -- ran at
+//   0.11 of the MFMA peak.)
+//   * P rows of the band live in a 256-row LDS ring filled by DMA (one 1-KiB piece per wave per tile), K rows and the V^T tile
+//     ([64 d][64 keys], from the zero-padded transposed copy the in_proj epilogue writes) are single-buffered and prefetched
+//     through 8 VGPRs per lane
+//   * G [16 q][85] fp32 per wave: the band product of a tile; the four values a lane adds to one score accumulator are one aligned
+//     16-byte read that enters the K Qu^T MFMA as its C operand -- the skew costs no VALU
+//   * K rows are permuted inside each 32-key group (see the dQ kernel) so that lane group g's accumulator rows of two neighbouring
+//     16-key blocks are the 8 consecutive keys 32 ks + 8 g .. + 7: P^T goes from the accumulators into the B operand of the
+//     V^T P^T product without leaving the lane, its A operand is one 16-byte read of the V^T tile
 // ---------------------------------------------------------------------------------------------------
-template <bool F16, bool O32>
-__global__ __launch_bounds__(256) void relpos_fwd_kernel(const bf16_t* __restrict__ Qu, const bf16_t* __restrict__ Qv,
+template <bool F16> __device__ __forceinline__ f32x4_t mfma16x(s16x8_t a, s16x8_t b, f32x4_t c) {
+    if (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+typedef __attribute__((address_space(3))) void* rp_lds_ptr_t;
+#define zero4 (f32x4_t{0.f, 0.f, 0.f, 0.f})
+
+#define FW16_WL 5440                       // per-wave LDS: G [16 q][85] fp32
+// NW waves (16 NW queries) per workgroup; the ring holds the 16 NW + 63 band rows a tile touches plus the 64 the next one adds
+#define FW16_RING(NW) (16 * (NW) + 128)
+#define FW16_LDS(NW) (16384 + FW16_RING(NW) * 128 + (NW) * FW16_WL)
+template <bool F16, bool O32, int NW>
+__global__ __launch_bounds__(64 * NW) void relpos_fwd_kernel(const bf16_t* __restrict__ Qu, const bf16_t* __restrict__ Qv,
                                                          const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
                                                          const bf16_t* __restrict__ P, bf16_t* __restrict__ O,
                                                          float* __restrict__ LSE, int T, int Tpad, int H, int Rpad) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_kv[2][2][KVB * 128];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_band[2][BAND_ROWS * 128];
-    __shared__ __attribute__((aligned(16))) float lds_g[4][96 * 32];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds_fw[];
+    unsigned char* lds_k = lds_fw;                      // K rows of the tile (permuted, see above)
+    unsigned char* lds_vt = lds_fw + 8192;              // V^T tile [64 d][64 keys]
+    unsigned char* lds_band = lds_fw + 16384;           // ring of P rows, slot = n & 255
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int RING = FW16_RING(NW);
+    float* gs = reinterpret_cast<float*>(lds_fw + 16384 + RING * 128 + wave * FW16_WL);
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
-    const int I0 = blockIdx.x * 128, q0 = I0 + wave * 32;
+    const int I0 = blockIdx.x * (16 * NW), q0 = I0 + wave * 16;
     const int R = 2 * T - 1;
-    const size_t hb = (size_t)bh * T * HD;
-    const bf16_t* Vtb = Vt + (size_t)bh * HD * Tpad;
-    const bf16_t* Ph = P + (size_t)h * Rpad * HD;
-
-    int qrow = q0 + lr;
-    qrow = qrow < T ? qrow : T - 1;
-    s16x8_t quf[4], qvf[4];
+    const size_t hb = (size_t)bh * T * HD, hbt = (size_t)bh * HD * Tpad;
+    const int RB0 = T - 16 * NW - I0;      // global P row of band index n = 0 (multiple of 8: T % 8 == 0)
+    // rows outside [0, R) of the head's P slab read as zeros (they only meet pairs that do not exist)
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(P + (size_t)h * Rpad * HD), 0, R * HD * 2, 0x00020000);
+    const int prow = lane >> 3, pch = lane & 7;
+    auto dma_band = [&](int n0) {          // band rows n0 .. n0 + 7 (n0 % 8 == 0) -> ring
+        const int s0 = n0 % RING;
+        const int slot = s0 + prow;
+        const int vo = (RB0 + n0 + prow) * (HD * 2) + ((pch ^ ((slot >> 1) & 7)) << 4);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (rp_lds_ptr_t)(lds_band + s0 * 128), 16, vo, 0, 0, 0);
+    };
+    for (int n0 = 8 * wave; n0 < 16 * NW + 64; n0 += 8 * NW) dma_band(n0);      // rows tile 0 touches
+    const int trow = (tid >> 3) & 63, tch = tid & 7;   // this thread's 16-byte chunk of a [64][64] tile (threads 0..511)
+    const bool loader = tid < 512;
+    uint4 pk = make_uint4(0, 0, 0, 0), pvt = make_uint4(0, 0, 0, 0);
+    auto gload = [&](int t) {
+        if (!loader) return;
+        const int j0 = t * KVB;
+        int kr = j0 + trow;
+        kr = kr < T ? kr : T - 1;
+        pk = *reinterpret_cast<const uint4*>(K + hb + (size_t)kr * HD + tch * 8);
+        pvt = *reinterpret_cast<const uint4*>(Vt + hbt + (size_t)trow * Tpad + j0 + tch * 8);
+    };
+    const int krow_lds = (trow & 32) + (((trow >> 2) & 1) << 4) + (((trow >> 3) & 3) << 2) + (trow & 3);
+    gload(0);
+    int qrow = q0 + c;
+    const bool qvalid = qrow < T;
+    qrow = qvalid ? qrow : T - 1;
+    s16x8_t quf[2], qvf[2];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        quf[s] = *reinterpret_cast<const s16x8_t*>(Qu + hb + (size_t)qrow * HD + 16 * s + 8 * lg);
-        qvf[s] = *reinterpret_cast<const s16x8_t*>(Qv + hb + (size_t)qrow * HD + 16 * s + 8 * lg);
+    for (int ks = 0; ks < 2; ++ks) {
+        quf[ks] = *reinterpret_cast<const s16x8_t*>(Qu + hb + (size_t)qrow * HD + 32 * ks + 8 * g);
+        qvf[ks] = *reinterpret_cast<const s16x8_t*>(Qv + hb + (size_t)qrow * HD + 32 * ks + 8 * g);
     }
-    f32x16_t o[2];
+    if (loader) {
+        *reinterpret_cast<uint4*>(lds_k + k_off(krow_lds, tch)) = pk;
+        *reinterpret_cast<uint4*>(lds_vt + k_off(trow, tch)) = pvt;
+    }
+    f32x4_t o[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    for (int i = 0; i < 4; ++i) o[i] = zero4;
     float m_run = -1e30f, l_run = 0.f;
-    float* gs = lds_g[wave];
-    const int band_row0 = 32 * (3 - wave);
-
-    const int ntiles = (T + KVB - 1) / KVB;
-    TileRegs rk, rv;
-    BandRegs rb;
-    tile_gload(rk, K + hb, 0, T, HD, 0, tid);
-    tile_gload(rv, Vtb, 0, HD, Tpad, 0, tid);
-    band_gload(rb, Ph, 0 - I0 - 127 + T - 1, R, tid);
-    tile_lstore_rows(rk, lds_kv[0][0], tid);
-    tile_lstore_cols(rv, lds_kv[0][1], tid);
-    band_lstore(rb, lds_band[0], tid);
-    pin_frags(quf);
-    pin_frags(qvf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::"v"(quf[0]), "v"(quf[1]), "v"(qvf[0]), "v"(qvf[1]));   // (arrived: no compiler wait inside the loop)
     __syncthreads();
-
+    const int ntiles = (T + KVB - 1) / KVB;
+    const int swc = (c >> 1) & 7;
     for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1, j0 = t * KVB;
-        if (t + 1 < ntiles) {
-            tile_gload(rk, K + hb, j0 + KVB, T, HD, 0, tid);
-            tile_gload(rv, Vtb, 0, HD, Tpad, j0 + KVB, tid);
-            band_gload(rb, Ph, j0 + KVB - I0 - 127 + T - 1, R, tid);
+        const int j0 = t * KVB;
+        const bool more = t + 1 < ntiles;
+        if (more) {   // tile t + 1: the 64 band rows it adds replace the slots tile t - 1 retired (one piece per wave 0..7)
+            if (wave < 8) dma_band(64 * t + 16 * NW + 64 + 8 * wave);
+            gload(t + 1);
         }
-        const unsigned char* lk = lds_kv[buf][0];
-        const unsigned char* lv = lds_kv[buf][1];
-        const unsigned char* lb = lds_band[buf];
-        // band product G^T[rho, q] -> wave-private LDS
+        const int nb = 64 * t + 16 * (NW - 1 - wave);    // this wave's band base
+        // ---- G^T[rho, q] = P_band[rho, :] . Qv[q, :]  (5 blocks of 16 rho) -> wave-private LDS
 #pragma unroll
-        for (int blk = 0; blk < 3; ++blk) {
-            f32x16_t g;
+        for (int blk = 0; blk < 5; ++blk) {
+            const int slot = ((nb + 16 * blk) % RING) + c;
+            const unsigned char* rowp = lds_band + slot * 128;
+            const int sw = (slot >> 1) & 7;
+            f32x4_t gacc = zero4;
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-                g = mfma32t<F16>(lds_frag_rows(lb, band_row0 + 32 * blk + lr, 2 * s + lg), qvf[s], s == 0 ? zero16 : g);
+            for (int ks = 0; ks < 2; ++ks)
+                gacc = mfma16x<F16>(*reinterpret_cast<const s16x8_t*>(rowp + (((4 * ks + g) ^ sw) << 4)), qvf[ks], gacc);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) gs[(32 * blk + mfma32_row(r, lg)) * 32 + lr] = g[r];
+            for (int r = 0; r < 4; ++r) gs[85 * c + 1 + 16 * blk + 4 * g + r] = gacc[r];
         }
-        f32x16_t st[2];
+        // ---- S^T = K Qu^T + skew(G^T): block kb, register r <-> key jj = 32 (kb >> 1) + 4 (kb & 1) + 8 g + r
+        f32x4_t st[4];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 4; ++kb) st[kb] = *reinterpret_cast<const f32x4_t*>(gs + 84 * c + 16 + 32 * (kb >> 1) + 4 * (kb & 1) + 8 * g);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-                st[kb] = mfma32t<F16>(lds_frag_rows(lk, 32 * kb + lr, 2 * s + lg), quf[s], s == 0 ? zero16 : st[kb]);
+        for (int kb = 0; kb < 4; ++kb) {
+            const unsigned char* kp = lds_k + (16 * kb + c) * 128;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                st[kb] = mfma16x<F16>(*reinterpret_cast<const s16x8_t*>(kp + (((4 * ks + g) ^ swc) << 4)), quf[ks], st[kb]);
         }
-        __syncthreads();  // G^T visible (wave-private buffer, but keep it simple and safe)
-        // raw score = AC + skewed BD; max on raw scores, scale + max-subtract as one packed FMA, raw v_exp_f32
-        float mloc = -1e30f;
+        // barrier A: every wave has read the K rows of tile t -> the prefetched K rows go to LDS
+        if (more) {
+            __syncthreads();
+            if (loader) *reinterpret_cast<uint4*>(lds_k + k_off(krow_lds, tch)) = pk;
+        }
+        // ---- online softmax of the lane's query over its 16 keys, combined over the four lane groups
+        if (j0 + KVB > T) {   // keys >= T exist only in the last tile
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const int jj = 32 * kb + mfma32_row(r, lg);
-                float s0 = st[kb][r] + gs[(jj - lr + 31) * 32 + lr], s1 = st[kb][r + 1] + gs[(jj - lr + 32) * 32 + lr];
-                if (j0 + KVB > T) {  // keys >= T exist only in the last tile
-                    s0 = (j0 + jj < T) ? s0 : -1e30f;
-                    s1 = (j0 + jj + 1 < T) ? s1 : -1e30f;
-                }
-                st[kb][r] = s0; st[kb][r + 1] = s1;
-                mloc = max3_raw(mloc, s0, s1);
-            }
+                for (int r = 0; r < 4; ++r)
+                    st[kb][r] = (j0 + 32 * (kb >> 1) + 4 * (kb & 1) + 8 * g + r < T) ? st[kb][r] : -1e30f;
+        }
+        float mloc = max3_raw(st[0][0], st[0][1], st[0][2]);
+        mloc = max3_raw(mloc, st[0][3], st[1][0]);
+        mloc = max3_raw(mloc, st[1][1], st[1][2]);
+        mloc = max3_raw(mloc, st[1][3], st[2][0]);
+        mloc = max3_raw(mloc, st[2][1], st[2][2]);
+        mloc = max3_raw(mloc, st[2][3], st[3][0]);
+        mloc = max3_raw(mloc, st[3][1], st[3][2]);
+        mloc = fmaxf(mloc, st[3][3]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float m_new = fmaxf(m_run, mloc * SCALE_LOG2E);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        const f32x2_t c2 = {SCALE_LOG2E, SCALE_LOG2E}, nm2 = {-m_new, -m_new};
-        f32x2_t ps2 = {0.f, 0.f};
+        float psum = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                f32x2_t x = {st[kb][r], st[kb][r + 1]};
-                x = __builtin_elementwise_fma(x, c2, nm2);
-                const f32x2_t pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
-                st[kb][r] = pv.x; st[kb][r + 1] = pv.y;
-                ps2 += pv;
+            for (int r = 0; r < 4; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], SCALE_LOG2E, -m_new));
+                st[kb][r] = pv;
+                psum += pv;
             }
-        float psum = ps2.x + ps2.y;
+        psum += __shfl_xor(psum, 16, 64);
         psum += __shfl_xor(psum, 32, 64);
         l_run = l_run * alpha + psum;
         m_run = m_new;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int db = 0; db < 4; ++db) o[db] *= alpha;
+        // ---- O^T[d, q] += V^T[d, key] P^T[key, q]
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint4 pu = make_uint4(pack2<F16>(st[2 * ks][0], st[2 * ks][1]), pack2<F16>(st[2 * ks][2], st[2 * ks][3]),
+                                        pack2<F16>(st[2 * ks + 1][0], st[2 * ks + 1][1]), pack2<F16>(st[2 * ks + 1][2], st[2 * ks + 1][3]));
+            const s16x8_t pf = __builtin_bit_cast(s16x8_t, pu);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const s16x8_t pf = pack_frag_t<F16>(st[kb], s);
-#pragma unroll
-                for (int db = 0; db < 2; ++db)
-                    o[db] = mfma32t<F16>(lds_frag_cols(lv, 32 * db + lr, 8 * kb + 4 * s + lg), pf, o[db]);
+            for (int db = 0; db < 4; ++db) {
+                const unsigned char* rowp = lds_vt + (16 * db + c) * 128;   // (row >> 1) & 7 == swc for every 16-row block
+                o[db] = mfma16x<F16>(*reinterpret_cast<const s16x8_t*>(rowp + (((4 * ks + g) ^ swc) << 4)), pf, o[db]);
             }
-        if (t + 1 < ntiles) {
-            tile_lstore_rows(rk, lds_kv[buf ^ 1][0], tid);
-            tile_lstore_cols(rv, lds_kv[buf ^ 1][1], tid);
-            band_lstore(rb, lds_band[buf ^ 1], tid);
         }
-        __syncthreads();
+        // barrier B: every wave has read V^T of tile t and this wave's band piece of tile t + 1 has landed
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (loader) *reinterpret_cast<uint4*>(lds_vt + k_off(trow, tch)) = pvt;
+        }
     }
-    const int q = q0 + lr;
-    if (q < T) {
+    if (qvalid) {
         const float inv = 1.0f / l_run;
+        const int q = q0 + c;
         if (O32) {
-            float* orow = reinterpret_cast<float*>(O) + ((size_t)b * T + q) * (H * HD) + h * HD;
+            float* orow = reinterpret_cast<float*>(O) + ((size_t)b * T + q) * (H * HD) + h * HD + 4 * g;
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd)
-                    *reinterpret_cast<float4*>(orow + 32 * db + 8 * qd + 4 * lg) =
-                        make_float4(o[db][4 * qd] * inv, o[db][4 * qd + 1] * inv, o[db][4 * qd + 2] * inv, o[db][4 * qd + 3] * inv);
+            for (int db = 0; db < 4; ++db)
+                *reinterpret_cast<float4*>(orow + 16 * db) = make_float4(o[db][0] * inv, o[db][1] * inv, o[db][2] * inv, o[db][3] * inv);
         } else {
-            bf16_t* orow = O + ((size_t)b * T + q) * (H * HD) + h * HD;
+            bf16_t* orow = O + ((size_t)b * T + q) * (H * HD) + h * HD + 4 * g;
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    uint2 pk;
-                    pk.x = pack2<F16>(o[db][4 * qd] * inv, o[db][4 * qd + 1] * inv);
-                    pk.y = pack2<F16>(o[db][4 * qd + 2] * inv, o[db][4 * qd + 3] * inv);
-                    *reinterpret_cast<uint2*>(orow + 32 * db + 8 * qd + 4 * lg) = pk;
-                }
+            for (int db = 0; db < 4; ++db) {
+                uint2 pk2;
+                pk2.x = pack2<F16>(o[db][0] * inv, o[db][1] * inv);
+                pk2.y = pack2<F16>(o[db][2] * inv, o[db][3] * inv);
+                *reinterpret_cast<uint2*>(orow + 16 * db) = pk2;
+            }
         }
-        if (lg == 0 && LSE != nullptr) LSE[(size_t)bh * T + q] = m_run + log2f(l_run);
+        if (g == 0 && LSE != nullptr) LSE[(size_t)bh * T + q] = m_run + log2f(l_run);
     }
 }
 
+template <bool F16, bool O32, int NW>
+static void launch_relpos_fwd(const void* Qu, const void* Qv, const void* K, const void* Vt, const void* P, void* O, float* LSE, int B, int H,
+                              int T, int Tpad, int Rpad, hipStream_t stream) {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)relpos_fwd_kernel<F16, O32, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, FW16_LDS(NW)); attr = true; }
+    hipLaunchKernelGGL((relpos_fwd_kernel<F16, O32, NW>), dim3(cdiv(T, 16 * NW), B * H), dim3(64 * NW), FW16_LDS(NW), stream, (const bf16_t*)Qu,
+                       (const bf16_t*)Qv, (const bf16_t*)K, (const bf16_t*)Vt, (const bf16_t*)P, (bf16_t*)O, LSE, T, Tpad, H, Rpad);
+}
 extern "C" int sed_relpos_attn_fwd(const void* Qu, const void* Qv, const void* K, const void* Vt, const void* P,
                                    void* O, float* LSE, int B, int H, int T, int Tpad, int Rpad, int f16, int o_f32,
                                    hipStream_t stream) {
     (void)hipGetLastError();
     if (T <= 0 || (T % 8) || Tpad % 64 || Tpad < T || Rpad % 64 || Rpad < 2 * T - 1) return SED_ERR_ARG;
-    dim3 grid(cdiv(T, 128), B * H);
-#define SED_RP_FWD(F, O32)                                                                                            \
-    hipLaunchKernelGGL((relpos_fwd_kernel<F, O32>), grid, dim3(256), 0, stream, (const bf16_t*)Qu, (const bf16_t*)Qv, \
-                       (const bf16_t*)K, (const bf16_t*)Vt, (const bf16_t*)P, (bf16_t*)O, LSE, T, Tpad, H, Rpad)
-    if (f16 && o_f32) SED_RP_FWD(true, true);
-    else if (f16) SED_RP_FWD(true, false);
-    else if (o_f32) SED_RP_FWD(false, true);
-    else SED_RP_FWD(false, false);
+    // 16 waves (256 queries) per workgroup when the sequence is long enough to fill them: four waves per SIMD, K / V^T tiles staged once per
+    // 256 queries; SED_RELPOS_FWD_NW=8 selects the 8-wave form (A/B)
+    static const int nw_env = getenv("SED_RELPOS_FWD_NW") ? atoi(getenv("SED_RELPOS_FWD_NW")) : 16;
+    const bool big = nw_env == 16 && T > 128;
+#define SED_RP_FWD(F, O32) { if (big) launch_relpos_fwd<F, O32, 16>(Qu, Qv, K, Vt, P, O, LSE, B, H, T, Tpad, Rpad, stream); \
+                             else launch_relpos_fwd<F, O32, 8>(Qu, Qv, K, Vt, P, O, LSE, B, H, T, Tpad, Rpad, stream); }
+    if (f16 && o_f32) SED_RP_FWD(true, true)
+    else if (f16) SED_RP_FWD(true, false)
+    else if (o_f32) SED_RP_FWD(false, true)
+    else SED_RP_FWD(false, false)
 #undef SED_RP_FWD
     return sed_check_launch();
 }
@@ -404,13 +459,6 @@ __global__ __launch_bounds__(256) void relpos_bwd_dkdv_kernel(
 //   8 consecutive keys 32 ks + 8 g .. + 7: dS^T goes from the accumulators to the B operand of the dQu contraction without leaving
 //   the lane, and its A operand is one 16-byte read of the K^T tile.
 // ---------------------------------------------------------------------------------------------------
-template <bool F16> __device__ __forceinline__ f32x4_t mfma16x(s16x8_t a, s16x8_t b, f32x4_t c) {
-    if (F16)
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-typedef __attribute__((address_space(3))) void* rp_lds_ptr_t;
-#define zero4 (f32x4_t{0.f, 0.f, 0.f, 0.f})
 
 #define DQ16_WL 8576                      // per-wave LDS: G [16 q][85] fp32 (5440 B) + dG^T [16 q][96 rho] bf16 (3072 B)
 #define DQ16_LDS (24576 + 65536 + 8 * DQ16_WL)
