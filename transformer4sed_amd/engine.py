@@ -404,14 +404,18 @@ class SedEngine:
             lse = E(B * H, T)
             call("sed_relpos_attn_fwd", qu, qv, k, vt, Ph, o16, lse, B, H, T, Tpad, Rpad, f16, 1 if SP else 0)
             x1 = E(B, T, D)
-            gemm_nt(split3(o16, M, D) if SP else o16, wk(p + "attn.out_proj.weight"), EPI_F32_RESID,
+            o16s = split3(o16, M, D) if SP else None
+            gemm_nt(o16s if SP else o16, wk(p + "attn.out_proj.weight"), EPI_F32_RESID,
                     bias=self.P(p + "attn.out_proj.bias"), res=y32, outF=x1)
             h2 = E(M, D, dt=F32 if SP else A16)
             h2s = E(M, 3 * D, dt=F16) if SP else None
             mean2, rstd2 = (E(M), E(M)) if save else (None, None)
-            # (the fp32 h2 is only needed by the backward: weight gradient of fc1)
+            # (split precision: the [hi | lo | hi] image is the only form of LN2's output anybody reads -- the fc1 GEMM now, the weight
+            #  gradient of fc1 later through its first third)
             call("sed_layernorm_fwd", x1, self.P(p + "norm2.weight"), self.P(p + "norm2.bias"), 1e-5, 1.0,
-                 h2s if SP else h2, (h2 if save else None) if SP else None, mean2, rstd2, M, D, 4 if SP else f16)
+                 h2s if SP else h2, None, mean2, rstd2, M, D, 4 if SP else f16)
+            if SP:
+                h2 = h2s
             hpre = E(M, D, dt=B16)
             if SP:
                 act = E(M, D)
@@ -421,12 +425,15 @@ class SedEngine:
                 act = E(M, D, dt=A16)
                 gemm_nt(h2, wk(p + "mlp.fc1.weight"), EPI_GELU, bias=self.P(p + "mlp.fc1.bias"), outH=hpre, outH2=act)
             x2 = E(B, T, D)
-            gemm_nt(split3(act, M, D) if SP else act, wk(p + "mlp.fc2.weight"), EPI_F32_RESID,
+            if SP:
+                act = split3(act, M, D)     # the fp32 activation is not read again: forward operand and (first third) dW operand of fc2
+            gemm_nt(act, wk(p + "mlp.fc2.weight"), EPI_F32_RESID,
                     bias=self.P(p + "mlp.fc2.bias"), res=x1, outF=x2)
             if save:
-                ctx["layers"].append(dict(x_in=cur, in_scale=in_scale, y16=y32.view(M, D) if SP else y16, mean1=mean1,
+                # split precision: y16 / h2 / act / o16s are [M, 3 D] images whose first third is the f16 operand of the weight gradients
+                ctx["layers"].append(dict(x_in=cur, in_scale=in_scale, y16=y16, mean1=mean1,
                                           rstd1=rstd1, Ph=Ph, Pt=Pt, qu=qu, qut=qut, qv=qv, qvt=qvt, k=k, kt=kt, v=v,
-                                          o16=o16, lse=lse, x1=x1, h2=h2, mean2=mean2, rstd2=rstd2, hpre=hpre, act=act))
+                                          o16=o16, o16s=o16s, lse=lse, x1=x1, h2=h2, mean2=mean2, rstd2=rstd2, hpre=hpre, act=act))
             cur = x2
         return cur, ctx
 
@@ -502,9 +509,11 @@ class SedEngine:
                 xd16 = xd.view(M, D)
                 act = E(M, D)
                 with ops.split_precision():
-                    gemm_nt(split3(xd16, M, D), W["mlm_mlp.0.weight"].ws, EPI_GELU32, bias=self.P("mlm_mlp.0.bias"), outH=hpre,
+                    xd16 = split3(xd16, M, D)
+                    gemm_nt(xd16, W["mlm_mlp.0.weight"].ws, EPI_GELU32, bias=self.P("mlm_mlp.0.bias"), outH=hpre,
                             outF=act)
-                    gemm_nt(split3(act, M, D), W["mlm_mlp.2.weight"].ws, EPI_F32, bias=self.P("mlm_mlp.2.bias"), outF=pred)
+                    act = split3(act, M, D)
+                    gemm_nt(act, W["mlm_mlp.2.weight"].ws, EPI_F32, bias=self.P("mlm_mlp.2.bias"), outF=pred)
             else:
                 xd16 = E(M, D, dt=self.act)
                 call("sed_cast_f32_bf16", xd, xd16, M * D, is_f16(xd16))
@@ -721,7 +730,10 @@ class SedEngine:
         dX GEMM that follows).  TN kernel on the operands as they lie when the shapes allow it (tokens % 64, features % 256);
         otherwise transposed copies + the NT split-K kernel."""
         dev = dy.device
-        n_out, k_in = dy.shape[1], x.shape[1]
+        n_out, ldx = dy.shape[1], x.shape[1]
+        # a saved split-precision image [M, 3 k_in] = [hi | lo | hi] (context network, MLM head) serves as the f16 operand through its
+        # first third: the weight gradient sees the activation at the precision the encoder's gradients see theirs
+        k_in = gW.shape[1] if (gW is not None and x.dtype == F16 and ldx == 3 * gW.shape[1]) else ldx
         E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
         Mt = M // 64 * 64      # the TN kernel walks the tokens in steps of 64: a ragged tail goes through the NT kernel
         tn = self.dw_tn and Mt >= 1024 and dw_tn_ok(Mt, n_out, k_in) and x.dtype in (F16, BF16)
@@ -735,11 +747,11 @@ class SedEngine:
             dy16 = g16 if g16 is not None else dy
             if gW is not None:
                 def run():
-                    gemm_dw_tn(dy16, x, gW, tokens=Mt, dbias=bias if bias_in_gemm else None)
+                    gemm_dw_tn(dy16, x, gW, tokens=Mt, dbias=bias if bias_in_gemm else None, k_in=k_in)
                     if Mt < M:
                         gT, xT = E(n_out, 64, dt=BF16), E(k_in, 64, dt=BF16)
                         transpose_bf16(dy16[Mt:], M - Mt, n_out, gT)
-                        transpose_bf16(x[Mt:], M - Mt, k_in, xT)
+                        transpose_bf16(x[Mt:], M - Mt, k_in, xT, ld=ldx)
                         gemm_dw(gT, xT, gW)
                 if self.dw_side and ops.TIMER is None and dy16.is_cuda:
                     if self._dw_stream is None:
@@ -760,7 +772,7 @@ class SedEngine:
         transpose_bf16(dy, M, n_out, gT, out_s=g16, colsum=bias)
         if gW is not None:
             xT = E(k_in, Mpad, dt=BF16)
-            transpose_bf16(x, M, k_in, xT)
+            transpose_bf16(x, M, k_in, xT, ld=ldx)
             # this path adds into gW with atomics on the CURRENT stream; TN work still pending on the side stream adds its split-K
             # workspace into the same gW with a plain read-modify-write (a window group of another M may have taken that path): order them
             self._join_dw()
@@ -842,8 +854,8 @@ class SedEngine:
                  Gl(p + "norm2.weight"), Gl(p + "norm2.bias"), M, D)
             del dln
             # attention branch: x1 = y + out_proj(relattn(y)),  y = LN1(in_scale * x_in)
-            g16 = self._dw_accum(g2, L["o16"], M, G(p + "attn.out_proj.weight") if trainable else None,
-                                 Gl(p + "attn.out_proj.bias"))
+            g16 = self._dw_accum(g2, L["o16s"] if L.get("o16s") is not None else L["o16"], M,
+                                 G(p + "attn.out_proj.weight") if trainable else None, Gl(p + "attn.out_proj.bias"))
             do16 = E(M, D, dt=BF16)
             gemm_nt(g16, W[p + "attn.out_proj.weight"].wt, EPI_BF16, outH=do16)
             dqkv = E(M, 3 * D, dt=BF16)

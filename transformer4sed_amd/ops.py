@@ -253,13 +253,14 @@ def gemm_dw(dYt, Xt, dW, n_out=None):
     gemm_nt(dYt, Xt, EPI_ATOMIC, M=n_out, outF=dW, ksplit=dw_ksplit(n_out, k_in, mpad), ldc=k_in)
 
 
-def gemm_dw_tn(dY, X, dW, tokens=None, ldc=None, dbias=None):
+def gemm_dw_tn(dY, X, dW, tokens=None, ldc=None, dbias=None, k_in=None):
     """dW[n_out, k_in] (fp32) += dY[tokens, n_out]^T . X[tokens, k_in]; both operands in their row-major [token][feature] layout
-    (dY bf16, X bf16 or f16).  Needs tokens % 64 == 0 and both feature counts % 256 == 0 (see `dw_tn_ok`)."""
+    (dY bf16, X bf16 or f16).  Needs tokens % 64 == 0 and both feature counts % 256 == 0 (see `dw_tn_ok`).  `k_in` < X.shape[1]: only the
+    first k_in columns of X's rows are the operand (the `hi` third of a split-precision image [tokens, 3 k_in])."""
     T = dY.shape[0] if tokens is None else tokens
     ws = _dw_workspace(dY.device)
-    call("sed_gemm_dw_tn", dY, X, is_f16(X), T, dY.shape[1], X.shape[1], dY.shape[1], X.shape[1], dW, ldc or X.shape[1], dbias, ws,
-         ws.numel() * 4)
+    k = X.shape[1] if k_in is None else k_in
+    call("sed_gemm_dw_tn", dY, X, is_f16(X), T, dY.shape[1], k, dY.shape[1], X.shape[1], dW, ldc or k, dbias, ws, ws.numel() * 4)
 
 
 _DW_WS = {}
