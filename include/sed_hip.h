@@ -110,8 +110,10 @@ int sed_mhsa_bwd_prep(const void* dO, const void* O, float* Dtmp, void* dOh, voi
  * is produced by the dQ kernel into Dtmp [B*H, N] -- no pre-pass; dOh is unused (may be NULL). */
 int sed_mhsa_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE, float* Dtmp,
                  void* dOh, void* dqkv, int B, int H, int N, int Npad, int f16, int v_f16, hipStream_t stream);
-/* Transformer-XL rel-pos attention (src/models/transformer/transformerXL.py:493-576 incl. rel_shift 254-297) */
-int sed_relpos_attn_fwd(const void* Qu, const void* Qv, const void* K, const void* Vt, const void* P, void* O,
+/* Transformer-XL rel-pos attention (src/models/transformer/transformerXL.py:493-576 incl. rel_shift 254-297).  O [B, T, H 64] 16-bit, or
+ * fp32 with o_f32; O_split (nullable, fp32 mode only): the [hi | lo | hi] f16 split-precision image [B T, 3 H 64] of the same values --
+ * out_proj's A operand (transformerXL.py:584), written here instead of by a sed_split3_f16 pass over O */
+int sed_relpos_attn_fwd(const void* Qu, const void* Qv, const void* K, const void* Vt, const void* P, void* O, void* O_split,
                         float* LSE, int B, int H, int T, int Tpad, int Rpad, int f16, int o_f32, hipStream_t stream);
 int sed_relpos_attn_bwd(const void* Qu, const void* Qut, const void* Qv, const void* Qvt, const void* K, const void* Kt,
                         const void* V, const void* P, const void* Pt, const void* O, const void* dO, const float* LSE,

@@ -292,10 +292,13 @@ def test_relpos_fwd_bwd(B, T, DT):
     Pt = torch.zeros(Hh, 64, Rpad, dtype=BF16, device=DEV); Pt[:, :, :R] = P.to(BF16).transpose(1, 2)
     O = torch.empty(B, T, 768, dtype=DT, device=DEV)
     lse = torch.empty(B * Hh, T, device=DEV)
-    call("sed_relpos_attn_fwd", qu.to(DT), qv.to(DT), k.to(DT), vt, Pp, O, lse, B, Hh, T, Tpad, Rpad, f16, 0)
+    call("sed_relpos_attn_fwd", qu.to(DT), qv.to(DT), k.to(DT), vt, Pp, O, None, lse, B, Hh, T, Tpad, Rpad, f16, 0)
     O32 = torch.empty(B, T, 768, device=DEV)
-    call("sed_relpos_attn_fwd", qu.to(DT), qv.to(DT), k.to(DT), vt, Pp, O32, None, B, Hh, T, Tpad, Rpad, f16, 1)
+    Osp = torch.empty(B * T, 3 * 768, dtype=F16, device=DEV)
+    call("sed_relpos_attn_fwd", qu.to(DT), qv.to(DT), k.to(DT), vt, Pp, O32, Osp, None, B, Hh, T, Tpad, Rpad, f16, 1)
     assert maxerr(O32.to(DT).float(), O.float()) == 0
+    # the split-precision image the kernel writes beside the fp32 output == what sed_split3_f16 makes of that output
+    assert torch.equal(Osp, ops.split3(O32.view(B * T, 768), B * T, 768))
     leaves = [t.clone().requires_grad_(True) for t in (qu, qv, k, v, P)]
     o, s = _relpos_ref(*leaves, T)
     oref = o.view(B, Hh, T, 64).permute(0, 2, 1, 3).reshape(B, T, 768)

@@ -22,7 +22,7 @@ dqkv = torch.empty(B * T, 2304, dtype=BF16, device=dev); Dt = torch.empty(B * H,
 dOh = torch.empty(B * H, T, 64, dtype=BF16, device=dev); dOt = torch.empty(B * H, 64, Tpad, dtype=BF16, device=dev)
 dSt = torch.zeros(B * H, Tpad, Tpad, dtype=BF16, device=dev); dP = torch.zeros(Rpad, 768, device=dev)
 du = torch.zeros(H, 64, device=dev); dv = torch.zeros(H, 64, device=dev)
-def fwd(): call("sed_relpos_attn_fwd", qu, qv, k, vt, P, O, lse, B, H, T, Tpad, Rpad, 1, 0)
+def fwd(): call("sed_relpos_attn_fwd", qu, qv, k, vt, P, O, None, lse, B, H, T, Tpad, Rpad, 1, 0)
 def bwd(): call("sed_relpos_attn_bwd", qu, qut, qv, qvt, k, kt, v.to(BF16), P, Pt, O, dO, lse, Dt, dOh, dOt, dqkv, dSt, dP, du, dv, B, H, T, Tpad, Rpad, 1, 1, 1)
 for name, f in (("fwd", fwd), ("bwd", bwd)):
     f(); torch.cuda.synchronize()

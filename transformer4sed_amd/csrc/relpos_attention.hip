@@ -107,7 +107,7 @@ template <bool F16, bool O32, int NW>
 __global__ __launch_bounds__(64 * NW) void relpos_fwd_kernel(const bf16_t* __restrict__ Qu, const bf16_t* __restrict__ Qv,
                                                          const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt,
                                                          const bf16_t* __restrict__ P, bf16_t* __restrict__ O,
-                                                         float* __restrict__ LSE, int T, int Tpad, int H, int Rpad) {
+                                                         bf16_t* __restrict__ Osplit, float* __restrict__ LSE, int T, int Tpad, int H, int Rpad) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds_fw[];
     unsigned char* lds_k = lds_fw;                      // K rows of the tile (permuted, see above)
     unsigned char* lds_vt = lds_fw + 8192;              // V^T tile [64 d][64 keys]
@@ -265,6 +265,21 @@ __global__ __launch_bounds__(64 * NW) void relpos_fwd_kernel(const bf16_t* __res
 #pragma unroll
             for (int db = 0; db < 4; ++db)
                 *reinterpret_cast<float4*>(orow + 16 * db) = make_float4(o[db][0] * inv, o[db][1] * inv, o[db][2] * inv, o[db][3] * inv);
+            if (Osplit != nullptr) {    // split-precision operand image of the same values, [hi | lo | hi] over 3 H 64 columns (out_proj's A operand)
+                const int Dm = H * HD;
+                bf16_t* srow = Osplit + ((size_t)b * T + q) * (3 * Dm) + h * HD + 4 * g;
+#pragma unroll
+                for (int db = 0; db < 4; ++db) {
+                    bf16_t hh[4], ll[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float v = o[db][e] * inv; hh[e] = f2h(v); ll[e] = f2h(v - h2f(hh[e])); }
+                    const uint2 hi = make_uint2((unsigned)hh[0] | ((unsigned)hh[1] << 16), (unsigned)hh[2] | ((unsigned)hh[3] << 16));
+                    const uint2 lo = make_uint2((unsigned)ll[0] | ((unsigned)ll[1] << 16), (unsigned)ll[2] | ((unsigned)ll[3] << 16));
+                    *reinterpret_cast<uint2*>(srow + 16 * db) = hi;
+                    *reinterpret_cast<uint2*>(srow + Dm + 16 * db) = lo;
+                    *reinterpret_cast<uint2*>(srow + 2 * Dm + 16 * db) = hi;
+                }
+            }
         } else {
             bf16_t* orow = O + ((size_t)b * T + q) * (H * HD) + h * HD + 4 * g;
 #pragma unroll
@@ -280,24 +295,24 @@ __global__ __launch_bounds__(64 * NW) void relpos_fwd_kernel(const bf16_t* __res
 }
 
 template <bool F16, bool O32, int NW>
-static void launch_relpos_fwd(const void* Qu, const void* Qv, const void* K, const void* Vt, const void* P, void* O, float* LSE, int B, int H,
-                              int T, int Tpad, int Rpad, hipStream_t stream) {
+static void launch_relpos_fwd(const void* Qu, const void* Qv, const void* K, const void* Vt, const void* P, void* O, void* Os, float* LSE, int B,
+                              int H, int T, int Tpad, int Rpad, hipStream_t stream) {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)relpos_fwd_kernel<F16, O32, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, FW16_LDS(NW)); attr = true; }
     hipLaunchKernelGGL((relpos_fwd_kernel<F16, O32, NW>), dim3(cdiv(T, 16 * NW), B * H), dim3(64 * NW), FW16_LDS(NW), stream, (const bf16_t*)Qu,
-                       (const bf16_t*)Qv, (const bf16_t*)K, (const bf16_t*)Vt, (const bf16_t*)P, (bf16_t*)O, LSE, T, Tpad, H, Rpad);
+                       (const bf16_t*)Qv, (const bf16_t*)K, (const bf16_t*)Vt, (const bf16_t*)P, (bf16_t*)O, (bf16_t*)Os, LSE, T, Tpad, H, Rpad);
 }
 extern "C" int sed_relpos_attn_fwd(const void* Qu, const void* Qv, const void* K, const void* Vt, const void* P,
-                                   void* O, float* LSE, int B, int H, int T, int Tpad, int Rpad, int f16, int o_f32,
+                                   void* O, void* O_split, float* LSE, int B, int H, int T, int Tpad, int Rpad, int f16, int o_f32,
                                    hipStream_t stream) {
     (void)hipGetLastError();
-    if (T <= 0 || (T % 8) || Tpad % 64 || Tpad < T || Rpad % 64 || Rpad < 2 * T - 1) return SED_ERR_ARG;
+    if (T <= 0 || (T % 8) || Tpad % 64 || Tpad < T || Rpad % 64 || Rpad < 2 * T - 1 || (O_split != nullptr && !o_f32)) return SED_ERR_ARG;
     // 16 waves (256 queries) per workgroup when the sequence is long enough to fill them: four waves per SIMD, K / V^T tiles staged once per
     // 256 queries; SED_RELPOS_FWD_NW=8 selects the 8-wave form (A/B)
     static const int nw_env = getenv("SED_RELPOS_FWD_NW") ? atoi(getenv("SED_RELPOS_FWD_NW")) : 16;
     const bool big = nw_env == 16 && T > 128;
-#define SED_RP_FWD(F, O32) { if (big) launch_relpos_fwd<F, O32, 16>(Qu, Qv, K, Vt, P, O, LSE, B, H, T, Tpad, Rpad, stream); \
-                             else launch_relpos_fwd<F, O32, 8>(Qu, Qv, K, Vt, P, O, LSE, B, H, T, Tpad, Rpad, stream); }
+#define SED_RP_FWD(F, O32) { if (big) launch_relpos_fwd<F, O32, 16>(Qu, Qv, K, Vt, P, O, O_split, LSE, B, H, T, Tpad, Rpad, stream); \
+                             else launch_relpos_fwd<F, O32, 8>(Qu, Qv, K, Vt, P, O, O_split, LSE, B, H, T, Tpad, Rpad, stream); }
     if (f16 && o_f32) SED_RP_FWD(true, true)
     else if (f16) SED_RP_FWD(true, false)
     else if (o_f32) SED_RP_FWD(false, true)

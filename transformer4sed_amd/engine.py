@@ -402,9 +402,9 @@ class SedEngine:
                  3 if (save and f16) else f16)
             o16 = E(M, D, dt=F32 if SP else A16)
             lse = E(B * H, T)
-            call("sed_relpos_attn_fwd", qu, qv, k, vt, Ph, o16, lse, B, H, T, Tpad, Rpad, f16, 1 if SP else 0)
+            o16s = E(M, 3 * D, dt=F16) if SP else None      # split-precision image of the attention output, written by the kernel itself
+            call("sed_relpos_attn_fwd", qu, qv, k, vt, Ph, o16, o16s, lse, B, H, T, Tpad, Rpad, f16, 1 if SP else 0)
             x1 = E(B, T, D)
-            o16s = split3(o16, M, D) if SP else None
             gemm_nt(o16s if SP else o16, wk(p + "attn.out_proj.weight"), EPI_F32_RESID,
                     bias=self.P(p + "attn.out_proj.bias"), res=y32, outF=x1)
             h2 = E(M, D, dt=F32 if SP else A16)

@@ -310,9 +310,10 @@ class PmamEngine(SedEngine):
                  aux["u"], aux["v"], 3 if save else 1)
             o32 = E(M, Dp)
             lse = E(B * H, T)
-            call("sed_relpos_attn_fwd", qu, qv, k, vt, Ph, o32, lse, B, H, T, Tpad, Rpad, 1, 1)
+            o32s = E(M, 3 * Dp, dt=F16)
+            call("sed_relpos_attn_fwd", qu, qv, k, vt, Ph, o32, o32s, lse, B, H, T, Tpad, Rpad, 1, 1)
             x1 = E(B, T, Dd)
-            gemm_nt(split3(o32, M, Dp), W[p + "attn.out_proj.weight"].ws, EPI_F32_RESID, bias=self.P(p + "attn.out_proj.bias"), res=y32,
+            gemm_nt(o32s, W[p + "attn.out_proj.weight"].ws, EPI_F32_RESID, bias=self.P(p + "attn.out_proj.bias"), res=y32,
                     outF=x1)
             h2 = E(M, Dd)
             mean2, rstd2 = (E(M), E(M)) if save else (None, None)
