@@ -646,9 +646,26 @@ def gen_full12_train():
     net.train()
     for p in net.parameters():
         p.requires_grad_(True)
+    # The rel-pos biases enter as `q + pos_bias_u` with q [batch, time, head, d] (transformerXL.py:497-503): for this one backward each
+    # of them is swapped for its own broadcast [B, T, H, d] as a leaf -- the forward is bit-identical, and the leaf's gradient holds the
+    # per-(clip, frame) TERMS whose sum is the parameter's gradient.  sum |terms| is what bounds the rounding error of that (heavily
+    # cancelling) sum in any reduced-precision implementation; the tests hold the HIP gradients to it.
+    swapped = {}
+    for i, blk in enumerate(net.decoder.encoder_blocks):
+        for nm in ("pos_bias_u", "pos_bias_v"):
+            p0 = blk.attn._parameters[nm]
+            swapped[(i, nm)] = p0
+            blk.attn._parameters[nm] = torch.nn.Parameter(p0.detach().expand(B, 1000, *p0.shape).clone())
     strong, weak, other = net(mel, encoder_win=False, temp_w=1)
     loss = _weighted_loss(tag, strong, weak, other["at_out"])
     loss.backward()
+    for (i, nm), p0 in swapped.items():
+        att = net.decoder.encoder_blocks[i].attn
+        terms = att._parameters[nm].grad
+        att._parameters[nm] = p0
+        p0.grad = terms.sum(dim=(0, 1))
+        out[f"posbias{i}_{nm}_grad"] = t2n(p0.grad)
+        out[f"posbias{i}_{nm}_abs"] = t2n(terms.abs().sum(dim=(0, 1)))
     out["ft_loss"] = t2n(loss)
     out["strong_train"] = t2n(strong)
     _grad_digest(net, out, "ft_")
