@@ -79,6 +79,57 @@ def test_gemm_epilogues(M, N, K, DT):
     e = maxerr(acc, ref); report(f"gemm atomic split-K {M}x{N}x{K}", e); assert e < tol
 
 
+@pytest.mark.parametrize("DT", [F16, BF16])
+# ragged last tile (2380 = 2 x 1190: 11 tiles of 224 rows, the last one 140 rows), many tiles per workgroup with the model's token count
+# (38080 x 2304: 1530 tiles on 256 CUs), long K, a token count that is not a multiple of 16
+@pytest.mark.parametrize("M,N,K", [(2380, 768, 768), (38080, 2304, 768), (4760, 3072, 768), (2380, 768, 3072), (17997, 1024, 256)])
+def test_gemm_224_row_tiles_are_bit_identical_to_256_row_tiles(M, N, K, DT, monkeypatch):
+    """The 224-row form of the 256^2 kernel (seven 16-row blocks per wave row instead of eight, chosen when it fills the last round of
+    workgroups better) accumulates every output over K in the same order on the same MFMA shape: every epilogue must agree BIT FOR BIT
+    with the 256-row form -- a wrong row mapping of the A panel, a stale or unmasked eighth block or a mis-sized last tile shows here."""
+    A = rnd(M, K, seed=21).to(DT)
+    B = rnd(N, K, scale=0.05, seed=22).to(DT)
+    bias, res = rnd(N, seed=23), rnd(M, N, seed=24)
+    aux = rnd(M, N, seed=25).to(DT)
+
+    def run():
+        out = {}
+        o = torch.full((M, N), 7.0, device=DEV); gemm_nt(A, B, ops.EPI_F32, bias=bias, outF=o, alpha=0.5); out["f32"] = o
+        o = torch.full((M, N), 7.0, device=DEV); gemm_nt(A, B, ops.EPI_F32_RESID, bias=bias, res=res, outF=o); out["resid"] = o
+        o = res.clone(); gemm_nt(A, B, ops.EPI_F32_RESID, bias=bias, res=o, outF=o); out["resid_inplace"] = o
+        o = torch.full((M, N), 3.0, dtype=DT, device=DEV); gemm_nt(A, B, ops.EPI_BF16, bias=bias, outH=o); out["h16"] = o
+        h = torch.full((M, N), 3.0, dtype=DT, device=DEV); a = torch.full((M, N), 3.0, dtype=DT, device=DEV)
+        gemm_nt(A, B, ops.EPI_GELU, bias=bias, outH=h, outH2=a); out["gelu_pre"], out["gelu_act"] = h, a
+        o = torch.full((M, N), 3.0, dtype=DT, device=DEV); gemm_nt(A, B, ops.EPI_DGELU, outH=o, aux=aux); out["dgelu"] = o
+        f = torch.full((M, N), 7.0, device=DEV); h = torch.full((M, N), 3.0, dtype=DT, device=DEV)
+        gemm_nt(A, B, ops.EPI_F32_BF16, bias=bias, outF=f, outH=h); out["f32_16_f"], out["f32_16_h"] = f, h
+        if N % 192 == 0 and M % 1190 == 0:      # head-split q / k / v with transposed copies and biased queries (the context net's call)
+            Hh, seq = N // 192, 1190
+            Npad = pad64(seq)
+            mk = lambda: torch.full((M // seq * Hh, seq, 64), 3.0, dtype=DT, device=DEV)
+            mkt = lambda: torch.zeros(M // seq * Hh, 64, Npad, dtype=DT, device=DEV)
+            q, k, v, q2 = mk(), mk(), mk(), mk()
+            qt, kt, vt, q2t = mkt(), mkt(), mkt(), mkt()
+            u, w = rnd(Hh, 64, seed=10), rnd(Hh, 64, seed=11)
+            call("sed_gemm_qkv", A, B, bias, M, K, Hh, seq, Npad, q, k, v, qt, kt, vt, q2, q2t, u, w, 1 if DT == F16 else 0)
+            out.update(q=q, k=k, v=v, q2=q2, qt=qt, kt=kt, vt=vt, q2t=q2t)
+        torch.cuda.synchronize()
+        return out
+    monkeypatch.setenv("SED_GEMM_RB", "8")
+    ref = run()
+    monkeypatch.setenv("SED_GEMM_RB", "7")
+    got = run()
+    for name in ref:
+        if not torch.equal(ref[name], got[name]):
+            d = (ref[name].float() - got[name].float()).abs()
+            bad = torch.nonzero(d > 0)
+            raise AssertionError(f"{name}: {bad.shape[0]} of {d.numel()} elements differ, max {float(d.max()):.3e}, first at {bad[0].tolist()}, "
+                                 f"rows {int(bad[:, 0].min())}..{int(bad[:, 0].max())}")
+    # and against fp32 torch, so that 'identical' cannot mean 'identically wrong'
+    e = maxerr(got["f32"], 0.5 * (A.float() @ B.float().t()) + bias)
+    assert e < 2e-3 * math.sqrt(K / 64) * (1 if DT == F16 else 8), e
+
+
 def test_split_precision_gemm():
     """[A_hi|A_lo|A_hi] . [W_hi|W_hi|W_lo]^T through the ordinary f16 GEMM ~ fp32 product (context-network path)."""
     from transformer4sed_amd.ops import split3

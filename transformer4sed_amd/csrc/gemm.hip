@@ -396,11 +396,11 @@ __device__ __forceinline__ void pp_stage16_gb(unsigned char* wl, const f32x4_t (
     }
 }
 
-template <bool F16, int MODE>
+template <bool F16, int MODE, int RB = 8>
 __device__ __forceinline__ void pp_stage16(unsigned char* wl, const f32x4_t (&acc)[8][4], const float (&bv)[4][4], int l15, int lq) {
     // mode 0: acc + column constant   1: gelu_fast(acc + column constant)
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x2v x0 = {acc[i][j][0] + bv[j][0], acc[i][j][1] + bv[j][1]};
@@ -413,11 +413,13 @@ __device__ __forceinline__ void pp_stage16(unsigned char* wl, const f32x4_t (&ac
         }
 }
 // 64 staged rows (accumulator blocks 4 p .. 4 p + 3) as fp32
+template <int RB = 8>
 __device__ __forceinline__ void pp_stage32(unsigned char* wl, const f32x4_t (&acc)[8][4], int p, int l15, int lq) {
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            if (4 * p + ii >= RB) continue;
             const f32x4_t& a = acc[4 * p + ii][j];
             *reinterpret_cast<float4*>(wl + (ii * 16 + l15) * V3_RS32 + (j * 16 + 4 * lq) * 4) = make_float4(a[0], a[1], a[2], a[3]);
         }
@@ -467,7 +469,7 @@ __device__ __forceinline__ void v3_side_load(V3Side<EPI>& sd, const GemmArgs& g,
 template <int EPI, bool F16>
 __device__ __forceinline__ void v3_store_batch(const GemmArgs& g, const unsigned char* wl, const V3Side<EPI>& sd, const float4 b0,
                                                int m0, int srow0, int n, int c4, int lane, const float4 bB = make_float4(0.f, 0.f, 0.f, 0.f),
-                                               int mbnd = 0x7fffffff) {
+                                               int mbnd = 0x7fffffff, int mend = 0x7fffffff) {
     // (b0 already contains the first group's row-group bias; rows m >= mbnd take bB instead -- see pp_epilogue)
     float4 vv[8];
 #pragma unroll
@@ -475,7 +477,7 @@ __device__ __forceinline__ void v3_store_batch(const GemmArgs& g, const unsigned
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int m = m0 + u * 4 + (lane >> 4);
-        if (m >= g.M) continue;
+        if (m >= g.M || m >= mend) continue;      // (mend: first row past a 112-row wave sub-tile)
         float4 v = vv[u];
         const float4 b = m >= mbnd ? bB : b0;
         const size_t o = (size_t)m * g.ldc + n;
@@ -525,7 +527,7 @@ __device__ __forceinline__ void v3_load_consts(V3Consts<EPI>& c, const GemmArgs&
     }
 }
 
-template <int EPI, bool F16, bool GB>
+template <int EPI, bool F16, bool GB, int RB = 8>
 __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&acc)[8][4], const V3Consts<EPI>& cc,
                                             unsigned char* wl, int mb, int nb, int lane, unsigned long long* gxt = nullptr) {
     // mb = first row of this wave's 128 x 64 sub-tile, nb = its first column
@@ -557,7 +559,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int row = (rb + u) * 8 + (lane >> 3);
-                    if (mb + row < g.M) v3_st<uint4>(out + (size_t)(mb + row) * g.ldc + nb + (lane & 7) * 8, v[u]);
+                    if (mb + row < g.M && row < 16 * RB) v3_st<uint4>(out + (size_t)(mb + row) * g.ldc + nb + (lane & 7) * 8, v[u]);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -582,7 +584,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
                 const int bnd = gb_split(g, mb, rA, rB);
                 pp_stage16_gb<F16, 0>(wl, acc, bv, rA + nb, rB + nb, bnd, l15, lq);
             } else {
-                pp_stage16<F16, 0>(wl, acc, bv, l15, lq);
+                pp_stage16<F16, 0, RB>(wl, acc, bv, l15, lq);
             }
             // Tensors that only the bf16 backward reads (row-major V; Q^T, K^T, (q+v)^T) are emitted as bf16 when g.bwd_bf16 is
             // set: converted from the staged f16 tile on the way out (same double rounding as a later in-place conversion,
@@ -604,7 +606,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int m = mb + (rb + u) * 8 + (lane >> 3);
-                        if (m < g.M) {
+                        if (m < g.M && (rb + u) * 8 + (lane >> 3) < 16 * RB) {
                             const int bidx = m / g.seq, t = m - bidx * g.seq;
                             v3_st<uint4>(rd + ((size_t)(bidx * g.heads + h) * g.seq + t) * 64 + (lane & 7) * 8, v[u]);
                         }
@@ -618,7 +620,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int row = half * 64 + pr, m = mb + row;
-                    if (m < g.M) {
+                    if (m < g.M && row < 16 * RB) {
                         const int bidx = m / g.seq, t = m - bidx * g.seq;
                         bf16_t* base = td + (size_t)(bidx * g.heads + h) * 64 * g.seq_pad + t;
                         const unsigned short* s0 = reinterpret_cast<const unsigned short*>(wl + row * V3_RS16);
@@ -636,7 +638,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int row = half * 64 + lane, m = mb + row;
-                    if (m < g.M) {
+                    if (m < g.M && row < 16 * RB) {
                         const int bidx = m / g.seq, t = m - bidx * g.seq;
                         bf16_t* base = td + (size_t)(bidx * g.heads + h) * 64 * g.seq_pad + t;
                         const unsigned short* src = reinterpret_cast<const unsigned short*>(wl + row * V3_RS16);
@@ -664,20 +666,21 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
         bB = make_float4(b.x + xb.x, b.y + xb.y, b.z + xb.z, b.w + xb.w);
         b = make_float4(b.x + xa.x, b.y + xa.y, b.z + xa.z, b.w + xa.w);
     }
+    const int mend = mb + 16 * RB;
     V3Side<EPI> s0, s1;
     v3_side_load<EPI>(s0, g, mb, n, lane);
-    pp_stage32(wl, acc, 0, l15, lq);
+    pp_stage32<RB>(wl, acc, 0, l15, lq);
     __builtin_amdgcn_wave_barrier();
     v3_side_load<EPI>(s1, g, mb + 32, n, lane);
-    v3_store_batch<EPI, F16>(g, wl, s0, b, mb, 0, n, c4, lane, bB, mbnd);
+    v3_store_batch<EPI, F16>(g, wl, s0, b, mb, 0, n, c4, lane, bB, mbnd, mend);
     v3_side_load<EPI>(s0, g, mb + 64, n, lane);
-    v3_store_batch<EPI, F16>(g, wl, s1, b, mb + 32, 32, n, c4, lane, bB, mbnd);
+    v3_store_batch<EPI, F16>(g, wl, s1, b, mb + 32, 32, n, c4, lane, bB, mbnd, mend);
     __builtin_amdgcn_wave_barrier();
-    pp_stage32(wl, acc, 1, l15, lq);
+    pp_stage32<RB>(wl, acc, 1, l15, lq);
     __builtin_amdgcn_wave_barrier();
     v3_side_load<EPI>(s1, g, mb + 96, n, lane);
-    v3_store_batch<EPI, F16>(g, wl, s0, b, mb + 64, 0, n, c4, lane, bB, mbnd);
-    v3_store_batch<EPI, F16>(g, wl, s1, b, mb + 96, 32, n, c4, lane, bB, mbnd);
+    v3_store_batch<EPI, F16>(g, wl, s0, b, mb + 64, 0, n, c4, lane, bB, mbnd, mend);
+    v3_store_batch<EPI, F16>(g, wl, s1, b, mb + 96, 32, n, c4, lane, bB, mbnd, mend);
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -688,8 +691,13 @@ template <bool F16> __device__ __forceinline__ f32x4_t mfma16t(s16x8_t a, s16x8_
 }
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-template <int EPI, bool F16, bool GB = false>
+// RB = 16-row blocks per wave row: 8 -> 256-row tiles; 7 -> 224-row tiles (the eighth block's reads, MFMAs and stores are skipped; its
+// LDS rows are still filled so that every wave keeps the same DMA count for the counted waits).  With M = 38080 tokens on 256 CUs the
+// N = 768 / 2304 GEMMs are 447 / 1341 tiles of 256 rows = 1.75 / 5.24 rounds, i.e. 2 / 6 rounds with 13 % of the last ones empty; as
+// 510 / 1530 tiles of 224 rows they are 1.99 / 5.98 rounds of tiles that are 12.5 % shorter -- launch_gemm picks the cheaper height.
+template <int EPI, bool F16, bool GB = false, int RB = 8>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
+    constexpr int TM = 32 * RB;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
 #ifdef GX_TRACE
     const unsigned long long gx_top = __builtin_amdgcn_s_memrealtime();
@@ -697,7 +705,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int ntn = g.N / V3_T, ntm = (g.M + V3_T - 1) / V3_T, nwg = ntm * ntn;
+    const int ntn = g.N / V3_T, ntm = (g.M + TM - 1) / TM, nwg = ntm * ntn;
     // Persistent form: gridDim.x = number of CUs, every workgroup walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x is
     // a multiple of 8, so a workgroup's tiles stay on its XCD and the L2 grouping below is unchanged).  Measured per 256^2 tile with
     // one launch per tile: 1.6 us between the last store of a workgroup and the first instruction of the next one on that CU plus
@@ -709,10 +717,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     const int group_size = GM * ntn, gid = t / group_size, first_m = gid * GM;
     const int gm = (ntm - first_m) < GM ? (ntm - first_m) : GM;
     const int tin = t - gid * group_size;
-    const int m0 = (first_m + tin % gm) * V3_T, n0 = (tin / gm) * V3_T;
+    const int m0 = (first_m + tin % gm) * TM, n0 = (tin / gm) * V3_T;
     const int nk = g.K / BK;
 
-    const int rows_a = (g.M - m0) < V3_T ? (g.M - m0) : V3_T;
+    const int rows_a = (g.M - m0) < TM ? (g.M - m0) : TM;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)m0 * g.lda), 0, rows_a * g.lda * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(g.B + (size_t)n0 * g.ldb), 0, V3_T * g.ldb * 2, 0x00020000);
     // DMA pieces of this wave: slot piece index p = 2 wave + e.  Slot 0 = A rows of half 0 (wave-row * 128 + 0..63), slot 3 = A rows
@@ -731,7 +739,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
             const int row = rows[sl] + prow;
             const int cl = pch ^ ((row >> 1) & 7);
             const bool is_b = (sl == 1 || sl == 2);
-            vo[sl][e] = row * (is_b ? g.ldb : g.lda) * 2 + cl * 16;
+            // LDS row wm * 128 + r of the A stage holds tile row wm * 16 RB + r (r >= 16 RB: a row nobody reads)
+            const int grow = is_b ? row : (row >> 7) * (16 * RB) + (row & 127);
+            vo[sl][e] = grow * (is_b ? g.ldb : g.lda) * 2 + cl * 16;
             ld_[sl][e] = (is_b ? 65536 : 0) + rows[sl] * 128;
         }
     }
@@ -760,7 +770,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
 
     s16x8_t fa[4][2], fb[2][2][2];   // fa[ii][ks]: 4 row blocks of the current A half; fb[set][jj][ks]: 2 column blocks of a B half
 #define PP_RD_A(IH)                                                                                                       \
-    _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                                      \
+    _Pragma("unroll") for (int ii = 0; ii < ((IH) == 1 ? RB - 4 : 4); ++ii)                                               \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                  \
             fa[ii][ks] = *reinterpret_cast<const s16x8_t*>(lds3 + aaddr[ks] + (4 * (IH) + ii) * 2048);
 #define PP_RD_B(SET, JH, XOR)                                                                                             \
@@ -773,7 +783,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                                    \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                      \
-        _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                                  \
+        _Pragma("unroll") for (int ii = 0; ii < ((IH) == 1 ? RB - 4 : 4); ++ii)                                           \
             _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                              \
                 acc[4 * (IH) + ii][2 * (JH) + jj] = mfma16t<F16>(fb[SET][jj][ks], fa[ii][ks], acc[4 * (IH) + ii][2 * (JH) + jj]); \
     __builtin_amdgcn_sched_barrier(0);                                                                                    \
@@ -826,7 +836,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
 #undef PP_MFMA
 #undef PP_TILE
 #ifdef GX_TRACE
-    pp_epilogue<EPI, F16, GB>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * 128, n0 + wn * 64, lane, gx_t);
+    pp_epilogue<EPI, F16, GB, RB>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * (16 * RB), n0 + wn * 64, lane, gx_t);
     GX_STAMP(5)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GX_STAMP(6)
@@ -849,7 +859,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
         }
     }
 #else
-    pp_epilogue<EPI, F16, GB>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * 128, n0 + wn * 64, lane);
+    pp_epilogue<EPI, F16, GB, RB>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * (16 * RB), n0 + wn * 64, lane);
 #endif
     if (tl + tstep < nwg) __syncthreads();   // the staging areas overlap the operand stages the next tile's DMA is about to fill
     }
@@ -1153,7 +1163,6 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
     // 256^2 kernel: every forward / dX GEMM of the model (N % 256 == 0, M >= 1024).  The split-K weight-gradient GEMMs of the NT
     // form stay on the 128^2 kernel (two workgroups per CU cover its atomic epilogue).
     if constexpr (EPI != EPI_ATOMIC) if (g.N % V3_T == 0 && g.M >= 1024 && g.ksplit == 1) {
-        dim3 grid3(cdiv(g.M, V3_T) * (g.N / V3_T), 1);
         if ((long long)g.lda * 2 * V3_T >= (1LL << 31) || (long long)g.ldb * 2 * V3_T >= (1LL << 31)) return SED_ERR_ARG;  // 32-bit panel offsets
         // L2 grouping: 4 tile rows x all tile columns per group, groups XCD-contiguous.  Swept 2..32 on the model's shapes
         // (tools/gemm_l2.py): fabric reads stay at 1.4-2.3x (N = 768) / ~5x (N = 3072) of the algorithmic operand bytes for every
@@ -1162,6 +1171,8 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
         GemmArgs gg = g;
         gg.group_m = 4;
         static const int persist_env = getenv("SED_GEMM_PERSIST") ? atoi(getenv("SED_GEMM_PERSIST")) : 1;
+        const char* rb_s = getenv("SED_GEMM_RB");      // 7 / 8 force a tile height (A/B and the bit-exactness test; read per launch), else choose
+        const int rb_env = rb_s ? atoi(rb_s) : 0;
         static int ncu = 0;
         if (ncu == 0) {
             int dev = 0, n = 0;
@@ -1169,6 +1180,13 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
             if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
             ncu = n & ~7;   // whole XCD rounds: blockIdx.x & 7 must stay the XCD of every tile a workgroup walks
         }
+        // Tile height: rounds of workgroups x rows per tile is what the launch costs; 224-row tiles win when they fill the last round
+        // that 256-row tiles leave mostly empty (M = 38080: 2 x 256 vs 2 x 224 for N = 768, 6 x 256 vs 6 x 224 for N = 2304).
+        const int ntn = g.N / V3_T;
+        const long long t8 = (long long)cdiv(g.M, 256) * ntn, t7 = (long long)cdiv(g.M, 224) * ntn;
+        const long long c8 = ((t8 + ncu - 1) / ncu) * 256, c7 = ((t7 + ncu - 1) / ncu) * 224;
+        const bool use7 = g.gbias == nullptr && (rb_env == 7 || (rb_env == 0 && c7 * 100 < c8 * 97));
+        dim3 grid3((unsigned)(use7 ? t7 : t8), 1);
         gg.persist = (persist_env && (int)grid3.x > ncu) ? 1 : 0;
         if (gg.persist) grid3.x = ncu;
         const GemmArgs& g = gg;
@@ -1184,14 +1202,18 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
                 return SED_ERR_ARG;
             }
         }
-        static bool attrp[2] = {false, false};
-        if (f16) {
-            if (!attrp[1]) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attrp[1] = true; }
-            hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true>), grid3, dim3(512), V3_LDS, s, g);
-        } else {
-            if (!attrp[0]) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attrp[0] = true; }
-            hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, false>), grid3, dim3(512), V3_LDS, s, g);
+        static bool attrp[2][2] = {{false, false}, {false, false}};
+#define SED_PP_LAUNCH(F, RBV)                                                                                              \
+        {                                                                                                                  \
+            if (!attrp[F][RBV - 7]) {                                                                                      \
+                (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, F, false, RBV>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); \
+                attrp[F][RBV - 7] = true;                                                                                  \
+            }                                                                                                              \
+            hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, F, false, RBV>), grid3, dim3(512), V3_LDS, s, g);                   \
         }
+        if (f16) { if (use7) SED_PP_LAUNCH(true, 7) else SED_PP_LAUNCH(true, 8) }
+        else { if (use7) SED_PP_LAUNCH(false, 7) else SED_PP_LAUNCH(false, 8) }
+#undef SED_PP_LAUNCH
         return sed_check_launch();
     }
     dim3 grid(cdiv(g.M, TILE) * (g.N / TILE), g.ksplit);
