@@ -249,3 +249,19 @@ def test_batchnorm_buffers_follow_rank0():
     port = s.getsockname()[1]
     s.close()
     mp.spawn(_bn_worker, args=(2, port), nprocs=2, join=True)
+
+
+def test_bench_refuses_to_measure_fewer_ranks_than_asked(tmp_path):
+    """`bench.py --gpus N` never reports a one-rank number as an N-GPU one: without enough HIP devices it stops before any work, and a
+    launcher that started a different number of ranks than `--gpus` says is an error (missing item 1)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SED_BENCH_ONE_GPU")}
+    env.update(CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0 and "HIP device" in (r.stderr + r.stdout) and "{" not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout) and "{" not in r.stdout
