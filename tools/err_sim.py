@@ -15,7 +15,7 @@ depth = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 fl = min(10, depth)
 torch.set_num_threads(16)
-sd = O.to_torch_sd(synth.matsed_state_dict_np(tag="w768", depth=12))
+sd = O.to_torch_sd(synth.matsed_state_dict_np(tag=os.environ.get("SIM_TAG", "w768"), depth=12))
 mel = torch.from_numpy(synth.det_uniform("model_d768_l2/mel", (B, 128, 1000), -1.2, 1.2))
 H = 12
 
