@@ -96,7 +96,7 @@ GFLOP_PER_BATCH = 21.22       # batch-shared linear_pos GEMMs (b-term)
 GFLOP_SKIPPED = {"finetune2": 211.5, "val": 2 * 17 / 11 * 211.5 * 0.0}   # (val: not priced -- its line carries no MFMA fraction)
 PEAK_BF16_TFLOPS = 2500.0     # dense 16-bit MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0         # HBM3E peak, MI355X_MICROARCH.md
-GEMM_KERNELS = ["sed_gemm_nt", "sed_gemm_qkv", "sed_gemm_dw_tn", "sed_gemm_nt_gb", "sed_gemm_qkv_gb"]
+GEMM_KERNELS = ["sed_gemm_nt", "sed_gemm_qkv", "sed_gemm_dw_tn", "sed_gemm_nt_gb", "sed_gemm_qkv_gb", "sed_gemm_nt_w2", "sed_gemm_qkv_w2"]
 
 
 def build(per_gpu_batch, depth, device, mode="finetune2"):
@@ -419,7 +419,7 @@ def main():
                             "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                             "achieved_issued": round(fl_issued / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, 2),
                             "achieved_note": "achieved = algorithmic 2MNK (split-precision GEMMs counted at their logical K); "
-                                             "achieved_issued = MFMA FLOPs actually issued (3x K for the split-precision GEMMs)",
+                                             "achieved_issued = MFMA FLOPs actually issued (3x K for the split-precision GEMMs, 2x K for the two-term-weight GEMMs of evaluation passes)",
                             "traffic": None if tj is None else tj.get("avg_bytes_per_launch"), "traffic_unit": "HBM bytes per launch",
                             "traffic_source": tsrc, "mfma_pipe_busy": None if mj is None else mj.get("family_busy_fraction"),
                             "mfma_pipe_busy_source": msrc,

@@ -60,6 +60,13 @@ int sed_gemm_nt_gb(const void* A, const void* B, int M, int N, int K, int lda, i
                    const float* gbias, int gb_rows, hipStream_t stream);
 int sed_gemm_qkv_gb(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq, int seq_pad, void* q,
                     void* k, void* v, int f16, const float* gbias, int gb_rows, hipStream_t stream);
+/* The same F.linear calls with TWO-TERM weights (evaluation-mode encoder, default): A [M, K] f16 against B [N, 2K] =
+ * [f16(W) | f16(W - f16(W))] (sed_split3_f16 mode 2); the A panel is walked twice, so the result carries the fp32 weight to ~2^-19 at the
+ * cost of twice the MFMA work.  256^2 kernel only: N % 256 == 0, M >= 1024, f16; epi 1 (fp32 + residual) or 3 (GELU, outH nullable). */
+int sed_gemm_nt_w2(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi, const float* bias,
+                   const float* resF, float* outF, void* outH, void* outH2, int ldc, int f16, hipStream_t stream);
+int sed_gemm_qkv_w2(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq, int seq_pad, void* q,
+                    void* k, void* v, int f16, hipStream_t stream);
 /* operands of that correction: per-clip token means of a 16-bit activation x [groups * rows, K] -> [groups, K] (K % 256 == 0; every
  * step-th token), and the f16 image of scale * (w - f16(w)) for an fp32 weight of n (multiple of 4) elements */
 int sed_group_colmean(const void* x, void* out, int groups, int rows, int K, int step, int f16, hipStream_t stream);
@@ -84,7 +91,8 @@ int sed_gemm_qkv(const void* A, const void* W, const float* bias, int M, int K, 
                  const float* pos_v, int f16, hipStream_t stream);
 int sed_cast_f32_bf16(const float* in, void* out, int64_t n, int f16, hipStream_t stream);
 int sed_f16_to_bf16_inplace(void* p, int64_t n, hipStream_t stream);
-/* split-precision operand image: fp32 [M,K] -> f16 [M,3K]; mode 0 [hi|lo|hi] (activations), 1 [hi|hi|lo] (weights) */
+/* split-precision operand image: fp32 [M,K] -> f16 [M,3K]; mode 0 [hi|lo|hi] (activations), 1 [hi|hi|lo] (weights);
+ * mode 2: f16 [M,2K] = [hi|lo], the two-term weight image of sed_gemm_nt_w2 / sed_gemm_qkv_w2 */
 int sed_split3_f16(const float* in, void* out, int64_t M, int K, int mode, hipStream_t stream);
 /* in [R,C] -> outT [C,Rpad] (zero padded; nullable), optional straight 16-bit copy and fp32 column sums (+=).
  * kinds: 0 bf16, 1 f32 (input only), 2 f16 */

@@ -152,6 +152,66 @@ def test_split_precision_gemm():
     assert maxerr(act, torch.nn.functional.gelu(ref)) < 5e-5 and maxerr(h16.float(), ref) < 2e-3 * float(ref.abs().max())
 
 
+def test_gemm_two_term_weights_and_row_group_bias():
+    """Evaluation-mode encoder GEMMs (engine.py `_encoder_fwd`): (a) two-term weights -- A [M, K] against [f16(W) | f16(W - f16(W))] with the
+    A panel walked twice -- are bit-identical to the ordinary GEMM over a materialised [A | A], and reproduce the fp32-weight product far
+    better than the f16 weight does; (b) the row-group bias lands on the rows of its clip (ragged last tile, groups straddling tiles)."""
+    from transformer4sed_amd.ops import two_term_weight
+    for M, N, K, rows in ((2380, 768, 768, 1190), (1204 * 3, 3072, 768, 602), (2408, 768, 3072, 602)):
+        A = rnd(M, K, seed=31).to(F16)
+        W = rnd(N, K, scale=0.03, seed=32)
+        bias, res = rnd(N, seed=33), rnd(M, N, seed=34)
+        W2 = two_term_weight(W)
+        hi = W.to(F16)
+        assert torch.equal(W2[:, :K], hi) and torch.equal(W2[:, K:], (W - hi.float()).to(F16))
+        out = torch.empty(M, N, device=DEV)
+        gemm_nt(A, W2, ops.EPI_F32_RESID, bias=bias, res=res, outF=out, two_term=True)
+        AA = torch.cat([A, A], dim=1).contiguous()
+        mat = torch.empty(M, N, device=DEV)
+        gemm_nt(AA, W2, ops.EPI_F32_RESID, bias=bias, res=res, outF=mat)
+        assert torch.equal(out, mat)
+        ref = (A.double() @ W.double().t() + bias.double() + res.double()).float()
+        e2 = maxerr(out, ref)
+        one = torch.empty(M, N, device=DEV)
+        gemm_nt(A, hi, ops.EPI_F32_RESID, bias=bias, res=res, outF=one)
+        e1 = maxerr(one, ref)
+        report(f"two-term weights {M}x{N}x{K} (f16 weight: {e1:.2e})", e2, float(ref.abs().max()))
+        assert e2 < 2e-5 * math.sqrt(K / 768) and e1 > 10 * e2
+        act = torch.empty(M, N, dtype=F16, device=DEV); actm = torch.empty(M, N, dtype=F16, device=DEV)
+        gemm_nt(A, W2, ops.EPI_GELU, bias=bias, outH=None, outH2=act, two_term=True)
+        gemm_nt(AA, W2, ops.EPI_GELU, bias=bias, outH=None, outH2=actm)
+        assert torch.equal(act, actm)
+        # row-group bias
+        G = M // rows
+        gb = rnd(G, N, seed=35)
+        got = torch.empty(M, N, device=DEV)
+        gemm_nt(A, hi, ops.EPI_F32_RESID, bias=bias, res=res, outF=got, gbias=gb, gb_rows=rows)
+        want = one + gb.repeat_interleave(rows, dim=0)
+        e = maxerr(got, want); report(f"row-group bias {M}x{N}x{K}", e); assert e < 1e-5
+        gotg = torch.empty(M, N, dtype=F16, device=DEV)
+        gemm_nt(A, hi, ops.EPI_GELU, bias=bias, outH=None, outH2=gotg, gbias=gb, gb_rows=rows)
+        pre = (A.float() @ hi.float().t() + bias + gb.repeat_interleave(rows, dim=0))
+        assert maxerr(gotg.float(), torch.nn.functional.gelu(pre)) < 4e-3 * float(pre.abs().max())
+    # head-split form
+    B, Ntok, Hh = 2, 602, 12
+    M = B * Ntok
+    x = rnd(M, 768, seed=36).to(F16); W = rnd(2304, 768, scale=0.03, seed=37); b = rnd(2304, seed=38)
+    W2 = two_term_weight(W)
+    mk = lambda: torch.empty(B * Hh, Ntok, 64, dtype=F16, device=DEV)
+    q, k, v = mk(), mk(), mk()
+    call("sed_gemm_qkv_w2", x, W2, b, M, 768, Hh, Ntok, pad64(Ntok), q, k, v, 1)
+    q1, k1, v1 = mk(), mk(), mk()
+    call("sed_gemm_qkv", torch.cat([x, x], 1).contiguous(), W2, b, M, 1536, Hh, Ntok, pad64(Ntok), q1, k1, v1, None, None, None, None, None, None, None, 1)
+    assert torch.equal(q, q1) and torch.equal(k, k1) and torch.equal(v, v1)
+    ref = (x.double() @ W.double().t() + b.double()).float().view(B, Ntok, 3, Hh, 64).permute(2, 0, 3, 1, 4)
+    for got, i in ((q, 0), (k, 1), (v, 2)):
+        want = ref[i].reshape(B * Hh, Ntok, 64)
+        assert maxerr(got.float(), want) < 1.1 * 2 ** -11 * float(want.abs().max())     # the f16 output rounding and nothing else
+    # outside the 256^2 kernel's domain the two-term form refuses instead of computing something else
+    with pytest.raises(RuntimeError):
+        gemm_nt(x[:512], W2[:768], ops.EPI_F32_RESID, bias=b[:768], res=torch.zeros(512, 768, device=DEV), outF=torch.zeros(512, 768, device=DEV), two_term=True)
+
+
 def test_gemm_asymmetric_identity():
     """A = I with an asymmetric B catches transposed C writes (guide rule 16)."""
     K = 128

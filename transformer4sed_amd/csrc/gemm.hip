@@ -54,6 +54,9 @@ struct GemmArgs {
     // `_wcorr_bias`): mean activation of the clip x the part of the fp32 weight its f16 image dropped.
     const float* gbias;
     int gb_rows;
+    // Two-term weights (256^2 kernel, evaluation-mode encoder): B rows are [f16(W) | f16(W - f16(W))] over K = 2 * k_wrap * 64 and the
+    // A panel (k_wrap K tiles wide) is walked twice -- the fp32 weight to ~2^-19 against the same f16 activations.  0 = off.
+    int k_wrap;
 };
 
 #define TILE 128
@@ -527,10 +530,11 @@ __device__ __forceinline__ void v3_load_consts(V3Consts<EPI>& c, const GemmArgs&
     }
 }
 
-template <int EPI, bool F16, bool GB, int RB = 8>
+template <int EPI, bool F16, int GBM, int RB = 8>
 __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&acc)[8][4], const V3Consts<EPI>& cc,
                                             unsigned char* wl, int mb, int nb, int lane, unsigned long long* gxt = nullptr) {
     // mb = first row of this wave's 128 x 64 sub-tile, nb = its first column
+    constexpr bool GB = GBM == 1;   // 1: row-group bias, 2: two-term weights (plain epilogue)
     const int l15 = lane & 15, lq = lane >> 4;
     if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
 #pragma unroll
@@ -695,7 +699,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // LDS rows are still filled so that every wave keeps the same DMA count for the counted waits).  With M = 38080 tokens on 256 CUs the
 // N = 768 / 2304 GEMMs are 447 / 1341 tiles of 256 rows = 1.75 / 5.24 rounds, i.e. 2 / 6 rounds with 13 % of the last ones empty; as
 // 510 / 1530 tiles of 224 rows they are 1.99 / 5.98 rounds of tiles that are 12.5 % shorter -- launch_gemm picks the cheaper height.
-template <int EPI, bool F16, bool GB = false, int RB = 8>
+template <int EPI, bool F16, int GB = 0, int RB = 8>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     constexpr int TM = 32 * RB;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
@@ -747,7 +751,8 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     }
 #define PP_DMA(SL, KT)                                                                                                    \
     {                                                                                                                     \
-        const int so_ = (KT) * (BK * 2), st_ = ((KT) & 1) << 15;                                                          \
+        const int kt_ = (GB == 2 && ((SL) == 0 || (SL) == 3) && (KT) >= g.k_wrap) ? (KT) - g.k_wrap : (KT);              \
+        const int so_ = kt_ * (BK * 2), st_ = ((KT) & 1) << 15;                                                           \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? rb : ra, (lds_ptr_t)(lds3 + st_ + ld_[SL][0]), 16, vo[SL][0], so_, 0, 0); \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? rb : ra, (lds_ptr_t)(lds3 + st_ + ld_[SL][1]), 16, vo[SL][1], so_, 0, 0); \
     }
@@ -1185,18 +1190,23 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
         const int ntn = g.N / V3_T;
         const long long t8 = (long long)cdiv(g.M, 256) * ntn, t7 = (long long)cdiv(g.M, 224) * ntn;
         const long long c8 = ((t8 + ncu - 1) / ncu) * 256, c7 = ((t7 + ncu - 1) / ncu) * 224;
-        const bool use7 = g.gbias == nullptr && (rb_env == 7 || (rb_env == 0 && c7 * 100 < c8 * 97));
+        const bool use7 = g.gbias == nullptr && g.k_wrap == 0 && (rb_env == 7 || (rb_env == 0 && c7 * 100 < c8 * 97));
         dim3 grid3((unsigned)(use7 ? t7 : t8), 1);
         gg.persist = (persist_env && (int)grid3.x > ncu) ? 1 : 0;
         if (gg.persist) grid3.x = ncu;
         const GemmArgs& g = gg;
-        if (g.gbias != nullptr) {
-            // row-group bias: evaluation-mode encoder GEMMs only (f16 operands; residual, fused-GELU and head-split epilogues)
+        if (g.gbias != nullptr || g.k_wrap != 0) {
+            // row-group bias / two-term weights: evaluation-mode encoder GEMMs only (f16 operands; residual, fused-GELU and head-split epilogues)
             if constexpr (EPI == EPI_F32_RESID || EPI == EPI_GELU || EPI == EPI_QKV) {
-                if (!f16) return SED_ERR_ARG;
-                static bool attrg = false;
-                if (!attrg) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attrg = true; }
-                hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true, true>), grid3, dim3(512), V3_LDS, s, g);
+                if (!f16 || (g.gbias != nullptr && g.k_wrap != 0)) return SED_ERR_ARG;
+                static bool attrg[2] = {false, false};
+                if (g.k_wrap != 0) {
+                    if (!attrg[1]) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attrg[1] = true; }
+                    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true, 2>), grid3, dim3(512), V3_LDS, s, g);
+                } else {
+                    if (!attrg[0]) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attrg[0] = true; }
+                    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true, 1>), grid3, dim3(512), V3_LDS, s, g);
+                }
                 return sed_check_launch();
             } else {
                 return SED_ERR_ARG;
@@ -1206,16 +1216,17 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
 #define SED_PP_LAUNCH(F, RBV)                                                                                              \
         {                                                                                                                  \
             if (!attrp[F][RBV - 7]) {                                                                                      \
-                (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, F, false, RBV>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); \
+                (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, F, 0, RBV>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); \
                 attrp[F][RBV - 7] = true;                                                                                  \
             }                                                                                                              \
-            hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, F, false, RBV>), grid3, dim3(512), V3_LDS, s, g);                   \
+            hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, F, 0, RBV>), grid3, dim3(512), V3_LDS, s, g);                   \
         }
         if (f16) { if (use7) SED_PP_LAUNCH(true, 7) else SED_PP_LAUNCH(true, 8) }
         else { if (use7) SED_PP_LAUNCH(false, 7) else SED_PP_LAUNCH(false, 8) }
 #undef SED_PP_LAUNCH
         return sed_check_launch();
     }
+    if (g.k_wrap != 0) return SED_ERR_ARG;   // two-term weights exist in the 256^2 kernel only (N % 256 == 0, M >= 1024)
     dim3 grid(cdiv(g.M, TILE) * (g.N / TILE), g.ksplit);
     if (f16) hipLaunchKernelGGL((gemm_nt_kernel<EPI, true>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm_nt_kernel<EPI, false>), grid, dim3(256), 0, s, g);
@@ -1224,9 +1235,14 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
 
 static int gemm_nt_impl(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi, const float* bias,
                         const float* resF, float* outF, void* outH, void* outH2, const void* auxH, int ldc, float alpha,
-                        int ksplit, int f16, int ncols, hipStream_t stream, const float* gbias = nullptr, int gb_rows = 0) {
+                        int ksplit, int f16, int ncols, hipStream_t stream, const float* gbias = nullptr, int gb_rows = 0, int two_term = 0) {
     (void)hipGetLastError();
     GemmArgs g = {};
+    if (two_term) {      // A [M, K] against B [N, 2K]
+        if (K % BK || epi == EPI_ATOMIC || epi == EPI_DGELU || gbias != nullptr || ksplit > 1) return SED_ERR_ARG;
+        g.k_wrap = K / BK;
+        K *= 2;
+    }
     if (gbias != nullptr && (gb_rows < 128 || M % gb_rows || epi == EPI_ATOMIC || epi == EPI_DGELU)) return SED_ERR_ARG;
     g.gbias = gbias; g.gb_rows = gb_rows;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B;
@@ -1259,6 +1275,14 @@ extern "C" int sed_gemm_nt_gb(const void* A, const void* B, int M, int N, int K,
                               const void* auxH, int ldc, float alpha, int f16, const float* gbias, int gb_rows, hipStream_t stream) {
     return gemm_nt_impl(A, B, M, N, K, lda, ldb, epi, bias, resF, outF, outH, outH2, auxH, ldc, alpha, 1, f16, N, stream, gbias, gb_rows);
 }
+// Two-term weights: A [M, K] (f16) against B [N, 2K] = [f16(W) | f16(W - f16(W))] (sed_weight_two_term_f16); A is read twice, the
+// result is A . W^T with W good to ~2^-19 relative.  256^2 kernel only (N % 256 == 0, M >= 1024), epilogues EPI_F32_RESID / EPI_GELU.
+extern "C" int sed_gemm_nt_w2(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi,
+                              const float* bias, const float* resF, float* outF, void* outH, void* outH2,
+                              int ldc, int f16, hipStream_t stream) {
+    if (!(f16 & 1) || N % 256 || M < 1024) return SED_ERR_ARG;
+    return gemm_nt_impl(A, B, M, N, K, lda, ldb, epi, bias, resF, outF, outH, outH2, nullptr, ldc, 1.f, 1, f16, N, stream, nullptr, 0, 1);
+}
 // same GEMM with a narrow result: the operands are padded to N (multiple of 128) but only the first ncols (multiple of 4) output
 // columns exist in memory (row stride ldc >= ncols); bias / residual / outputs are indexed like the narrow matrix.  128^2 kernel only.
 extern "C" int sed_gemm_nt_cols(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi,
@@ -1270,7 +1294,7 @@ extern "C" int sed_gemm_nt_cols(const void* A, const void* B, int M, int N, int 
 
 static int gemm_qkv_impl(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq,
                          int seq_pad, void* q, void* k, void* v, void* qt, void* kt, void* vt, void* q2,
-                         void* q2t, const float* pos_u, const float* pos_v, int f16, const float* gbias, int gb_rows, hipStream_t stream);
+                         void* q2t, const float* pos_u, const float* pos_v, int f16, const float* gbias, int gb_rows, hipStream_t stream, int two_term = 0);
 extern "C" int sed_gemm_qkv(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq,
                             int seq_pad, void* q, void* k, void* v, void* qt, void* kt, void* vt, void* q2,
                             void* q2t, const float* pos_u, const float* pos_v, int f16, hipStream_t stream) {
@@ -1281,15 +1305,26 @@ extern "C" int sed_gemm_qkv_gb(const void* A, const void* W, const float* bias, 
     return gemm_qkv_impl(A, W, bias, M, K, heads, seq, seq_pad, q, k, v, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, f16,
                          gbias, gb_rows, stream);
 }
+// two-term weights (see sed_gemm_nt_w2): W is [3 * heads * 64, 2K]; inference outputs only
+extern "C" int sed_gemm_qkv_w2(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq,
+                               int seq_pad, void* q, void* k, void* v, int f16, hipStream_t stream) {
+    if (!(f16 & 1) || M < 1024) return SED_ERR_ARG;
+    return gemm_qkv_impl(A, W, bias, M, K, heads, seq, seq_pad, q, k, v, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, f16,
+                         nullptr, 0, stream, 1);
+}
 static int gemm_qkv_impl(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq,
                          int seq_pad, void* q, void* k, void* v, void* qt, void* kt, void* vt, void* q2,
-                         void* q2t, const float* pos_u, const float* pos_v, int f16, const float* gbias, int gb_rows, hipStream_t stream) {
+                         void* q2t, const float* pos_u, const float* pos_v, int f16, const float* gbias, int gb_rows, hipStream_t stream, int two_term) {
     (void)hipGetLastError();
     GemmArgs g = {};
     if (gbias != nullptr && (gb_rows < 128 || M % gb_rows)) return SED_ERR_ARG;
     g.gbias = gbias; g.gb_rows = gb_rows;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)W;
     g.M = M; g.N = 3 * heads * 64; g.K = K; g.lda = K; g.ldb = K; g.ldc = g.N; g.ksplit = 1; g.alpha = 1.f;
+    if (two_term) {
+        if (K % BK || gbias != nullptr) return SED_ERR_ARG;
+        g.k_wrap = K / BK; g.K = 2 * K; g.ldb = 2 * K;
+    }
     g.ncols = g.N;
     g.bias = bias;
     g.q = (bf16_t*)q; g.k = (bf16_t*)k; g.v = (bf16_t*)v; g.qt = (bf16_t*)qt; g.kt = (bf16_t*)kt; g.vt = (bf16_t*)vt;
@@ -1570,7 +1605,8 @@ extern "C" int sed_weight_residual_f16(const float* w, void* out, int64_t n, flo
 // Split-precision operand images (f16 hi + f16 lo carries ~22 significand bits): a GEMM over the concatenated reduction
 // dimension [A_hi | A_lo | A_hi] . [W_hi | W_hi | W_lo]^T accumulates A_hi W_hi + A_lo W_hi + A_hi W_lo in fp32 inside the
 // ordinary MFMA kernel.  Used for the context-network GEMMs, whose operand rounding dominates the posterior error.
-// in fp32 [M, K] -> out f16 [M, 3K]; mode 0: [hi | lo | hi] (activations), mode 1: [hi | hi | lo] (weights)
+// in fp32 [M, K] -> out f16 [M, 3K]; mode 0: [hi | lo | hi] (activations), mode 1: [hi | hi | lo] (weights);
+// mode 2: out f16 [M, 2K] = [hi | lo], the two-term weight image of sed_gemm_nt_w2 / sed_gemm_qkv_w2
 __global__ void split3_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t M, int K, int mode) {
     const size_t total = M * (size_t)(K / 2);
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -1580,15 +1616,15 @@ __global__ void split3_kernel(const float* __restrict__ in, bf16_t* __restrict__
         const bf16_t h0 = f2h(v.x), h1 = f2h(v.y);
         const bf16_t l0 = f2h(v.x - h2f(h0)), l1 = f2h(v.y - h2f(h1));
         const unsigned hi = (unsigned)h0 | ((unsigned)h1 << 16), lo = (unsigned)l0 | ((unsigned)l1 << 16);
-        unsigned* row = reinterpret_cast<unsigned*>(out + m * (size_t)(3 * K));
+        unsigned* row = reinterpret_cast<unsigned*>(out + m * (size_t)((mode == 2 ? 2 : 3) * K));
         row[k / 2] = hi;
-        row[(K + k) / 2] = mode == 0 ? lo : hi;
-        row[(2 * K + k) / 2] = mode == 0 ? hi : lo;
+        row[(K + k) / 2] = mode == 1 ? hi : lo;
+        if (mode != 2) row[(2 * K + k) / 2] = mode == 0 ? hi : lo;
     }
 }
 extern "C" int sed_split3_f16(const float* in, void* out, int64_t M, int K, int mode, hipStream_t stream) {
     (void)hipGetLastError();
-    if (K % 2 || M <= 0) return SED_ERR_ARG;
+    if (K % 2 || M <= 0 || mode < 0 || mode > 2) return SED_ERR_ARG;
     size_t total = (size_t)M * (K / 2);
     int blocks = (int)((total + 255) / 256);
     blocks = blocks > 4096 ? 4096 : blocks;

@@ -16,7 +16,7 @@ import torch
 from . import ops
 import os
 
-from .ops import BF16, F16, F32, call, h2d, gemm_nt, gemm_dw, gemm_dw_tn, dw_tn_ok, pad64, transpose_bf16, to_bf16_, is_f16, split3, o_kind
+from .ops import BF16, F16, F32, call, h2d, gemm_nt, gemm_dw, gemm_dw_tn, dw_tn_ok, pad64, transpose_bf16, to_bf16_, is_f16, split3, o_kind, two_term_weight
 from .ops import EPI_F32, EPI_F32_RESID, EPI_BF16, EPI_GELU, EPI_DGELU, EPI_F32_BF16, EPI_GELU32
 
 D = 768
@@ -45,11 +45,12 @@ def rel_pos_table(T, Dm=D):
 
 class _W:
     """bf16 operand images of one fp32 weight matrix [n_out, k_in]."""
-    __slots__ = ("w", "wt", "ws", "wlo", "wlo_key")
+    __slots__ = ("w", "wt", "ws", "wlo", "wlo_key", "w2", "w2_key")
 
     def __init__(self, w, wt):
         self.w, self.wt, self.ws = w, wt, None
-        self.wlo, self.wlo_key = None, None      # f16 image of 2^11 (W - f16(W)) (evaluation-mode correction) and what it was built from
+        self.wlo, self.wlo_key = None, None      # f16 image of 2^11 (W - f16(W)) (evaluation-mode mean correction) and what it was built from
+        self.w2, self.w2_key = None, None        # two-term image [f16(W) | f16(W - f16(W))] (evaluation-mode encoder)
 
 
 class _PoolLease:
@@ -89,20 +90,40 @@ class SedEngine:
         self.dw_side = os.environ.get("SED_DW_STREAM", "1") != "0"
         self._dw_stream = None
         self._dw_pending = False
-        # Evaluation-mode encoder: add mean_t(x) . (W - f16(W))^T per clip to every encoder GEMM (`_wcorr_bias`).  The f16 weight
-        # images are the largest single term of the posterior error (tools/err_sim.py: logit error 1.6e-3 of 2.0e-3 in total), and
-        # the part of it that is common to all tokens of a clip is the part that survives the frequency pooling and the attention
-        # averages; removing it halves the error at the validation temperature for ~2 % of an inference pass.  Training-mode passes
-        # (student, and the teacher inside the train step) do not pay for it.  SED_ENC_WCORR=0 off, =all every no-grad pass.
-        self.wcorr = os.environ.get("SED_ENC_WCORR", "eval") if self.act == F16 else "0"
-        self.wcorr_step = int(os.environ.get("SED_ENC_WCORR_STEP", "8"))     # clip means from every 8th token (1/8 of the extra read)
+        # Evaluation-mode encoder.  The f16 weight images are the largest single term of the posterior error (tools/err_sim.py: logit
+        # error 1.6e-3 of 2.0e-3 in total), so passes whose posteriors are SCORED (module in eval mode: validation, test, inference)
+        # do not round the weights:
+        #   exact (default)  two-term weights [f16(W) | f16(W - f16(W))], the activation panel walked twice (sed_gemm_*_w2): the fp32
+        #                    weight to ~2^-19 for twice the encoder GEMM work of an inference pass;
+        #   mean             f16 weights + mean_t(x) . (W - f16(W))^T per clip as a row-group bias (`_wcorr_bias`): the part of the
+        #                    rounding that is common to all tokens of a clip, ~2 % of an inference pass, about a third of the gain;
+        #   0                off.
+        # Training-mode passes (student, and the teacher inside the train step) never pay for it; SED_ENC_WCORR_ALL=1 extends it to
+        # every no-grad pass.
+        self.wcorr = os.environ.get("SED_ENC_WCORR", "exact") if self.act == F16 else "0"
+        if self.wcorr == "eval":
+            self.wcorr = "mean"
+        if self.wcorr not in ("0", "mean", "exact"):
+            raise ValueError(f"SED_ENC_WCORR={self.wcorr!r}: expected 0, mean or exact")
+        self.wcorr_all = os.environ.get("SED_ENC_WCORR_ALL", "0") != "0"
+        self.wcorr_step = int(os.environ.get("SED_ENC_WCORR_STEP", "8"))     # mean: clip means from every 8th token (1/8 of the extra read)
 
     def _wcorr_on(self, save):
         if self.wcorr == "0" or save:
             return False
         if getattr(self.m, "lora_r", 0) and not getattr(self.m, "lora_merged", False):
             return False        # PaSST_CNN in train mode: the GEMM operand is W + s B A, not the master the residual image is taken from
-        return self.wcorr == "all" or not self.m.training
+        return self.wcorr_all or not self.m.training
+
+    def _w2_image(self, W, name):
+        """Two-term f16 image [n_out, 2 k_in] of an fp32 weight, cached per weight like `_wlo_image`."""
+        ent = W[name]
+        p = self.P(name)
+        key = (p.data_ptr(), p._version, getattr(self.m, "_param_generation", 0))
+        if ent.w2 is None or ent.w2_key != key or ent.w2.device != ent.w.device:
+            ent.w2 = two_term_weight(p.detach().reshape(ent.w.shape))
+            ent.w2_key = key
+        return ent.w2
 
     def _wlo_image(self, W, name, w32=None):
         """f16 image of 2^11 (W - f16(W)), cached per weight: rebuilt when the fp32 master changed (in-place writes move `_version`,
@@ -263,6 +284,7 @@ class SedEngine:
         scratch = None
         pooled = None
         wc = self._wcorr_on(save) and N >= 128
+        w2 = wc and self.wcorr == "exact" and M >= 1024      # (the 256^2 kernel's domain; tiny inputs take the mean correction)
         for li in range(m.depth):
             p = f"backbone.blocks.{li}."
             L = {}
@@ -282,7 +304,24 @@ class SedEngine:
             x_in = x
             call("sed_layernorm_fwd", x_in, self.P(p + "norm1.weight"), self.P(p + "norm1.bias"), 1e-6, 1.0, h16, None,
                  mean1, rstd1, M, D, f16)
-            if wc:      # evaluation mode: every GEMM carries its per-clip weight-rounding correction as a row-group bias
+            if w2:      # evaluation mode: every encoder GEMM against the two-term weight image
+                call("sed_gemm_qkv_w2", h16, self._w2_image(W, p + "attn.qkv.weight"), self.P(p + "attn.qkv.bias"), M, D, H, N, Npad, q, k, v, f16)
+                call("sed_mhsa_fwd", q, k, v, o16, lse, Bx, H, N, Npad, f16)
+                gemm_nt(o16, self._w2_image(W, p + "attn.proj.weight"), EPI_F32_RESID, bias=self.P(p + "attn.proj.bias"), res=x_in, outF=x_in,
+                        two_term=True)
+                call("sed_layernorm_fwd", x_in, self.P(p + "norm2.weight"), self.P(p + "norm2.bias"), 1e-6, 1.0, h2, None,
+                     mean2, rstd2, M, D, f16)
+                gemm_nt(h2, self._w2_image(W, p + "mlp.fc1.weight"), EPI_GELU, bias=self.P(p + "mlp.fc1.bias"), outH=None, outH2=act,
+                        two_term=True)
+                gemm_nt(act, self._w2_image(W, p + "mlp.fc2.weight"), EPI_F32_RESID, bias=self.P(p + "mlp.fc2.bias"), res=x_in, outF=x_in,
+                        two_term=True)
+                x = x_in
+                if li + 1 == m.passt_feature_layer:
+                    pooled = self._fpool_fwd(W, x, Bx, tp, save, ctx)
+                    if not want_frame:
+                        break
+                continue
+            if wc:      # (mean mode) every GEMM carries its per-clip weight-rounding correction as a row-group bias
                 gb = lambda nm, xin: self._wcorr_bias(W, p + nm, xin, Bx, N)
                 call("sed_gemm_qkv_gb", h16, W[p + "attn.qkv.weight"].w, self.P(p + "attn.qkv.bias"), M, D, H, N, Npad, q, k, v, f16,
                      gb("attn.qkv.weight", h16), N)

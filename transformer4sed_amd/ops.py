@@ -115,9 +115,9 @@ class split_precision:
 
 
 def _flops_of(name, args):
-    if name in ("sed_gemm_nt", "sed_gemm_nt_gb"):
+    if name in ("sed_gemm_nt", "sed_gemm_nt_gb", "sed_gemm_nt_w2"):       # (w2: the logical 2 M N K, half of the MFMA FLOPs issued)
         return 2.0 * args[2] * args[3] * args[4]
-    if name in ("sed_gemm_qkv", "sed_gemm_qkv_gb"):
+    if name in ("sed_gemm_qkv", "sed_gemm_qkv_gb", "sed_gemm_qkv_w2"):
         return 2.0 * args[3] * args[4] * (3 * args[5] * 64)
     if name == "sed_gemm_dw_tn":
         return 2.0 * args[3] * args[4] * args[5]
@@ -128,8 +128,10 @@ def _shape_of(name, args):
     """(M, N, K, epilogue / output count) of one GEMM launch, for per-shape tables (tools/gemm_shapes.py)."""
     if name in ("sed_gemm_nt", "sed_gemm_nt_gb"):
         return (args[2], args[3], args[4], "epi%d" % args[7] + ("gb" if name.endswith("_gb") else ""))
-    if name == "sed_gemm_qkv_gb":
-        return (args[3], 3 * args[5] * 64, args[4], "qkv3gb")
+    if name in ("sed_gemm_qkv_gb", "sed_gemm_qkv_w2"):
+        return (args[3], 3 * args[5] * 64, args[4], "qkv3" + name[-2:])
+    if name == "sed_gemm_nt_w2":
+        return (args[2], args[3], args[4], "epi%dw2" % args[7])
     if name == "sed_gemm_qkv":
         return (args[3], 3 * args[5] * 64, args[4], "qkv%d" % sum(a is not None for a in args[8:16]))
     if name == "sed_gemm_dw_tn":
@@ -139,9 +141,13 @@ def _shape_of(name, args):
 
 def _bytes_of(name, args):
     """Algorithmic HBM bytes of one GEMM launch: operands once + every output / side input once."""
-    if name == "sed_gemm_qkv_gb":
+    if name in ("sed_gemm_qkv_gb", "sed_gemm_qkv_w2"):
         M, K, D = args[3], args[4], args[5] * 64
-        return 2.0 * K * (M + 3 * D) + 2.0 * M * D * 3
+        return 2.0 * K * (M + 3 * D * (2 if name.endswith("w2") else 1)) + 2.0 * M * D * 3
+    if name == "sed_gemm_nt_w2":
+        M, N, K, epi = args[2], args[3], args[4], args[7]
+        out = {1: 8, 3: 2 * ((args[11] is not None) + (args[12] is not None))}.get(epi, 4)
+        return 2.0 * K * (M + 2 * N) + float(out) * M * N
     if name in ("sed_gemm_nt", "sed_gemm_nt_gb"):
         M, N, K, epi = args[2], args[3], args[4], args[7]
         out = {0: 4, 1: 8, 2: 2, 3: 2 * ((args[11] is not None) + (args[12] is not None)), 4: 4, 5: 8, 7: 6, 8: 6}.get(epi, 4)
@@ -205,7 +211,8 @@ def call(name, *args):
         e1.record()
         fi = _flops_of(name, args)
         by = _hbm_bytes_of(name, args) if name in HBM_KERNELS else _bytes_of(name, args)
-        TIMER.records.append((name, e0, e1, fi * ALG_K_SCALE, by, fi, _shape_of(name, args)))
+        issued = fi * (2.0 if name.endswith("_w2") else 1.0)      # two-term weights: the A panel is multiplied twice
+        TIMER.records.append((name, e0, e1, fi * ALG_K_SCALE, by, issued, _shape_of(name, args)))
         return
     lib().call(name, *conv, _stream_of(dev))
 
@@ -215,10 +222,16 @@ def pad64(n):
 
 
 def gemm_nt(A, B, epi, M=None, bias=None, res=None, outF=None, outH=None, outH2=None, aux=None, alpha=1.0, ksplit=1,
-            lda=None, ldb=None, ldc=None, gbias=None, gb_rows=0):
-    """C[M,N] = A[M,K] . B[N,K]^T (bf16 operands) with fused epilogue; see include/sed_hip.h.  `gbias` [M / gb_rows, N]: row-group bias."""
+            lda=None, ldb=None, ldc=None, gbias=None, gb_rows=0, two_term=False):
+    """C[M,N] = A[M,K] . B[N,K]^T (bf16 operands) with fused epilogue; see include/sed_hip.h.  `gbias` [M / gb_rows, N]: row-group bias.
+    `two_term`: B is the [N, 2K] image [f16(W) | f16(W - f16(W))] over an A of K columns."""
     M = A.shape[0] if M is None else M
     N, K = B.shape[0], B.shape[1]
+    if two_term:
+        if A.dtype != F16 or B.dtype != F16 or K != 2 * A.shape[1]:
+            raise RuntimeError("gemm_nt: two-term weights take an f16 A [M, K] and an f16 B [N, 2K]")
+        call("sed_gemm_nt_w2", A, B, M, N, K // 2, lda or A.shape[1], ldb or K, epi, bias, res, outF, outH, outH2, ldc or N, 1)
+        return
     if gbias is not None:
         if A.dtype != B.dtype:
             raise RuntimeError("gemm_nt: operand types differ")
@@ -298,6 +311,14 @@ def split3(x32, rows, cols, weight=False):
     (weights); a GEMM over the concatenated K accumulates hi*hi + lo*hi + hi*lo in fp32."""
     out = torch.empty(rows, 3 * cols, dtype=F16, device=x32.device)
     call("sed_split3_f16", x32, out, rows, cols, 1 if weight else 0)
+    return out
+
+
+def two_term_weight(w32):
+    """fp32 weight [N, K] -> f16 [N, 2K] = [f16(W) | f16(W - f16(W))] for gemm_nt(two_term=True) / sed_gemm_qkv_w2."""
+    N, K = w32.shape
+    out = torch.empty(N, 2 * K, dtype=F16, device=w32.device)
+    call("sed_split3_f16", w32.contiguous(), out, N, K, 2)
     return out
 
 
