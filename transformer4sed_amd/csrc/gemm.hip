@@ -57,6 +57,9 @@ struct GemmArgs {
     // Two-term weights (256^2 kernel, evaluation-mode encoder): B rows are [f16(W) | f16(W - f16(W))] over K = 2 * k_wrap * 64 and the
     // A panel (k_wrap K tiles wide) is walked twice -- the fp32 weight to ~2^-19 against the same f16 activations.  0 = off.
     int k_wrap;
+    // Persistent 256^2 kernel: workgroups with an odd (blockIdx.x >> 3) start `stagger` ticks of the 100 MHz real-time counter late, so
+    // that their store phases fall into the other half's main loops instead of all 256 CUs hitting HBM in lock-step.  0 = off.
+    int stagger;
 };
 
 #define TILE 128
@@ -715,6 +718,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     // one launch per tile: 1.6 us between the last store of a workgroup and the first instruction of the next one on that CU plus
     // 0.5 us of kernel-argument / address setup (tools/epi_gaps.py) against a 17 us K = 768 main loop.
     const int tstep = g.persist ? (int)gridDim.x : nwg;
+    if (g.stagger > 0 && ((blockIdx.x >> 3) & 1)) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)g.stagger) __builtin_amdgcn_s_sleep(16);
+    }
     for (int tl = blockIdx.x; tl < nwg; tl += tstep) {
     const int t = xcd_remap(tl, nwg);
     const int GM = g.group_m;
@@ -1194,6 +1201,10 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
         dim3 grid3((unsigned)(use7 ? t7 : t8), 1);
         gg.persist = (persist_env && (int)grid3.x > ncu) ? 1 : 0;
         if (gg.persist) grid3.x = ncu;
+        {
+            const char* st_s = getenv("SED_GEMM_STAGGER");      // experiment: start delay of every other workgroup, in 10 ns ticks
+            gg.stagger = (gg.persist && st_s) ? atoi(st_s) : 0;
+        }
         const GemmArgs& g = gg;
         if (g.gbias != nullptr || g.k_wrap != 0) {
             // row-group bias / two-term weights: evaluation-mode encoder GEMMs only (f16 operands; residual, fused-GELU and head-split epilogues)
