@@ -79,8 +79,9 @@ int sed_gemm_nt_cols(const void* A, const void* B, int M, int N, int K, int lda,
                      int ncols, hipStream_t stream);
 /* Weight gradient in TN form: dW[M,N] (fp32, ldc) += dY[T,M]^T . X[T,N], both operands row-major [token][feature] as the forward /
  * backward left them (dY bf16, X bf16 or IEEE half) -- the autograd of F.linear's weight (same reference lines as sed_gemm_nt).
- * T % 64 == 0, M % 256 == 0, N % 256 == 0; split-K over tokens chosen by the library.  `workspace` (caller-owned, optional):
- * with >= (256 / tiles) * M * N * 4 bytes (tiles = M/256 * N/256) the splits are stored there and reduced by a second launch; otherwise atomics.
+ * T % 64 == 0, M % 64 == 0, N % 64 == 0 (256 x 256 tiles; a partly valid last tile computes on whatever lies behind its rows and stores
+ * only its valid part); split-K over tokens chosen by the library.  `workspace` (caller-owned, optional): with >= (256 / tiles) * M * N * 4
+ * bytes (tiles = ceil(M/256) * ceil(N/256)) the splits are stored there and reduced by a second launch; otherwise atomics.
  * dbias (nullable): dbias[M] += column sums of dY over the T tokens, i.e. the bias gradient of the same linear, for free. */
 int sed_gemm_dw_tn(const void* dY, const void* X, int x_f16, int T, int M, int N, int ldy, int ldx, float* dW, int ldc,
                    float* dbias, float* workspace, int64_t workspace_bytes, hipStream_t stream);

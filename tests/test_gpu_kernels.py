@@ -273,7 +273,10 @@ def test_gemm_qkv_split(DT):
 
 
 @pytest.mark.parametrize("XDT", [BF16, F16])
-@pytest.mark.parametrize("T,M,N", [(1024, 256, 256), (2432, 768, 512), (38080, 768, 768)])
+# 64-multiples that are not 256-multiples (PMAM's 384-wide context network, its 64 / 128-column CNN operands): the last tile of a dimension
+# is partly valid
+@pytest.mark.parametrize("T,M,N", [(1024, 256, 256), (2432, 768, 512), (38080, 768, 768), (1024, 128, 128), (24000, 384, 384), (24000, 1152, 384),
+                                   (2432, 384, 1536), (4096, 64, 128), (4096, 192, 64), (8192, 320, 576)])
 def test_gemm_dw_tn(T, M, N, XDT):
     """TN weight-gradient GEMM (transposing LDS reads, split-K atomics) against fp32 torch; accumulates into dW."""
     dY = r16(rnd(T, M, scale=0.3, seed=21)).to(BF16)
@@ -289,6 +292,26 @@ def test_gemm_dw_tn(T, M, N, XDT):
     assert e < 1e-3 * (T / 1024) ** 0.5 + 1e-4
     eb = float(((db - want_b).abs() / (want_b.abs() + 1.0)).max())
     assert eb < 2e-4 * (T / 1024) ** 0.5 + 1e-5, eb
+
+
+def test_gemm_dw_tn_half_valid_tiles_ignore_what_lies_behind_the_rows():
+    """A half-valid 256-wide tile of the TN kernel multiplies whatever follows its rows in memory; none of it may reach dW or the bias
+    gradient -- checked with NaNs in the padding columns of wider rows (ld 512 for 384 features)."""
+    T, M, N = 4096, 384, 384
+    dYw = torch.full((T, 512), float("nan"), device=DEV).to(BF16)
+    Xw = torch.full((T, 512), float("nan"), device=DEV).to(F16)
+    dY = r16(rnd(T, M, scale=0.3, seed=41)).to(BF16); X = rnd(T, N, seed=42).to(F16)
+    dYw[:, :M] = dY; Xw[:, :N] = X
+    dW = torch.zeros(M, N, device=DEV); db = torch.zeros(M, device=DEV)
+    ws = torch.empty(24 << 20, dtype=F32, device=DEV)
+    call("sed_gemm_dw_tn", dYw, Xw, 1, T, M, N, 512, 512, dW, N, db, ws, ws.numel() * 4)
+    want = dY.float().t() @ X.float().to(BF16).float()
+    assert bool(torch.isfinite(dW).all()) and bool(torch.isfinite(db).all())
+    assert float(((dW - want).abs() / (want.abs() + 1.0)).max()) < 2e-3
+    assert float((db - dY.float().sum(0)).abs().max()) < 2e-3
+    dW2 = torch.zeros(M, N, device=DEV)
+    call("sed_gemm_dw_tn", dYw, Xw, 1, T, M, N, 512, 512, dW2, N, None, None, 0)      # atomics instead of the workspace
+    assert bool(torch.isfinite(dW2).all()) and float((dW2 - dW).abs().max()) < 1e-3 * float(want.abs().max())
 
 
 @pytest.mark.parametrize("B,N", [(2, 70), (2, 602)])   # 128^2 kernel (M < 1024) and the 256^2 kernel with its staged epilogue

@@ -935,7 +935,10 @@ __global__ __launch_bounds__(512) void gemm_tn_dw_kernel(const TnArgs g) {
     // One linear workgroup index, split-major and XCD-contiguous: the tiles of one token split run side by side on ONE XCD, so the
     // split's dY / X rows go through that L2 once for all of them (9 x 3 tiles: fabric reads 663 -> ~250 MB per launch; with the tile
     // index spread over the XCDs every dY panel was fetched by three L2s and every X panel by up to nine).
-    const int ntn = g.N / V3_T, ntm = g.M / V3_T, ntiles = ntm * ntn;
+    // M, N multiples of 64: the last tile of a dimension may be partly valid.  Its out-of-range operand columns are whatever lies behind
+    // them in memory (the next token's row; nothing past the buffer end) -- an output element depends on its own operand columns only,
+    // and the out-of-range rows / columns of the tile are not stored.
+    const int ntn = (g.N + V3_T - 1) / V3_T, ntm = (g.M + V3_T - 1) / V3_T, ntiles = ntm * ntn;
     const int L = xcd_remap(blockIdx.x, ntiles * g.ksplit);
     const int split = L / ntiles, t = L - split * ntiles;
     const int m0 = (t % ntm) * V3_T, n0 = (t / ntm) * V3_T;
@@ -943,10 +946,11 @@ __global__ __launch_bounds__(512) void gemm_tn_dw_kernel(const TnArgs g) {
     const int kt_begin = (int)(((long long)split * ktiles) / g.ksplit);
     const int kt_end = (int)(((long long)(split + 1) * ktiles) / g.ksplit);
     const int nk = kt_end - kt_begin;
+    const int mw = (g.M - m0) < V3_T ? (g.M - m0) : V3_T, nw = (g.N - n0) < V3_T ? (g.N - n0) : V3_T;     // valid tile extent
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)kt_begin * BK * g.lda + m0), 0,
-                                                                        (nk * BK - 1) * g.lda * 2 + V3_T * 2, 0x00020000);
+                                                                        (nk * BK - 1) * g.lda * 2 + mw * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(g.B + (size_t)kt_begin * BK * g.ldb + n0), 0,
-                                                                        (nk * BK - 1) * g.ldb * 2 + V3_T * 2, 0x00020000);
+                                                                        (nk * BK - 1) * g.ldb * 2 + nw * 2, 0x00020000);
     // DMA pieces of this wave: slot piece index pi = 2 wave + e -> panel list[pi >> 3], token rows 8 (pi & 7) .. + 7
     const int prow = lane >> 3, pc = lane & 7;
     int vo[4][2], ld_[4][2];
@@ -1082,7 +1086,7 @@ __global__ __launch_bounds__(512) void gemm_tn_dw_kernel(const TnArgs g) {
             float c = colacc[e];
             c += __shfl_xor(c, 16, 64);      // the four 8-token groups of the fragment
             c += __shfl_xor(c, 32, 64);
-            if (lane < 16) unsafeAtomicAdd(&g.dbias[m0 + wm * 128 + (2 * wn + e) * 16 + lane], c);
+            if (lane < 16 && wm * 128 + (2 * wn + e) * 16 + lane < mw) unsafeAtomicAdd(&g.dbias[m0 + wm * 128 + (2 * wn + e) * 16 + lane], c);
         }
     }
     __builtin_amdgcn_s_barrier();    // both wave rows are past their last operand read: LDS becomes the per-wave staging area
@@ -1092,8 +1096,10 @@ __global__ __launch_bounds__(512) void gemm_tn_dw_kernel(const TnArgs g) {
     unsigned char* wl = lds3 + wave * V3_WLDS;
     const int l15 = lane & 15, lq = lane >> 4;
     const int mb = m0 + wm * 128, nb = n0 + wn * 64;
+    if (mb >= g.M || nb >= g.N) return;      // (64-granular validity: each 64 x 64 pass of a wave's sub-tile is entirely in or entirely out)
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
+        if (mb + pass * 64 >= g.M) break;
         pp_stage32(wl, acc, pass, l15, lq);
         __builtin_amdgcn_wave_barrier();
         if (g.ws != nullptr) {
@@ -1138,11 +1144,11 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 extern "C" int sed_gemm_dw_tn(const void* dY, const void* X, int x_f16, int T, int M, int N, int ldy, int ldx, float* dW,
                               int ldc, float* dbias, float* workspace, int64_t workspace_bytes, hipStream_t stream) {
     (void)hipGetLastError();
-    if (T <= 0 || (T % BK) || (M % V3_T) || (N % V3_T) || (ldy % 8) || (ldx % 8) || (ldc % 4) || M <= 0 || N <= 0) return SED_ERR_ARG;
+    if (T <= 0 || (T % BK) || (M % 64) || (N % 64) || (ldy % 8) || (ldx % 8) || (ldc % 4) || M <= 0 || N <= 0) return SED_ERR_ARG;
     TnArgs g;
     g.A = (const bf16_t*)dY; g.B = (const bf16_t*)X; g.C = dW; g.dbias = dbias;
     g.M = M; g.N = N; g.T = T; g.lda = ldy; g.ldb = ldx; g.ldc = ldc; g.b_f16 = x_f16;
-    const int tiles = (M / V3_T) * (N / V3_T), ktiles = T / BK;
+    const int tiles = cdiv(M, V3_T) * cdiv(N, V3_T), ktiles = T / BK;
     // one workgroup per CU and ONE round: tiles * ks <= 256 (rounding the split count up instead costs a second, nearly empty
     // round -- 36 tiles x 8 splits = 288 workgroups took twice the time of 36 x 7)
     int ks = 256 / tiles;

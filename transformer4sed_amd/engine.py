@@ -775,7 +775,12 @@ class SedEngine:
         k_in = gW.shape[1] if (gW is not None and x.dtype == F16 and ldx == 3 * gW.shape[1]) else ldx
         E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
         Mt = M // 64 * 64      # the TN kernel walks the tokens in steps of 64: a ragged tail goes through the NT kernel
-        tn = self.dw_tn and Mt >= 1024 and dw_tn_ok(Mt, n_out, k_in) and x.dtype in (F16, BF16)
+        tn = self.dw_tn and Mt >= 1024 and dw_tn_ok(Mt, n_out, k_in) and x.dtype in (F16, BF16, F32)
+        if tn and x.dtype == F32 and gW is not None:
+            # an fp32 saved operand (projector / pooling inputs): one cast pass to bf16 instead of a transposing pass, then the TN kernel
+            x16 = E(M, ldx, dt=BF16)
+            transpose_bf16(x, M, ldx, None, out_s=x16)
+            x = x16
         if tn:
             g16 = E(M, n_out, dt=BF16) if dy.dtype == F32 else None
             # bias gradient: with a 16-bit dy the TN kernel sums its own dY fragments (no extra pass over dy); an fp32 dy needs the

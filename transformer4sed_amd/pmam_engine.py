@@ -20,7 +20,7 @@ import torch
 from . import ops
 
 from .engine import SedEngine, _W, D, H
-from .ops import BF16, F16, F32, call, h2d, gemm_nt, gemm_nt_cols, gemm_dw, pad64, transpose_bf16, split3, is_f16, to_bf16_, o_kind
+from .ops import BF16, F16, F32, call, h2d, gemm_nt, gemm_nt_cols, gemm_dw, gemm_dw_tn, dw_tn_ok, pad64, transpose_bf16, split3, is_f16, to_bf16_, o_kind
 from .ops import EPI_F32, EPI_F32_RESID, EPI_BF16, EPI_GELU32
 
 HD_PAD = 64          # head width the attention kernels are built for
@@ -320,12 +320,16 @@ class PmamEngine(SedEngine):
             call("sed_ln_fwd_any", x1, self.P(p + "norm2.weight"), self.P(p + "norm2.bias"), 1e-5, 1.0, None, h2, mean2, rstd2, M, Dd, 1)
             hpre = E(M, Dd, dt=B16)
             act = E(M, Dd)
-            gemm_nt(split3(h2, M, Dd), W[p + "mlp.fc1.weight"].ws, EPI_GELU32, bias=self.P(p + "mlp.fc1.bias"), outH=hpre, outF=act)
+            h2 = split3(h2, M, Dd)
+            gemm_nt(h2, W[p + "mlp.fc1.weight"].ws, EPI_GELU32, bias=self.P(p + "mlp.fc1.bias"), outH=hpre, outF=act)
             x2 = E(B, T, Dd)
-            gemm_nt(split3(act, M, Dd), W[p + "mlp.fc2.weight"].ws, EPI_F32_RESID, bias=self.P(p + "mlp.fc2.bias"), res=x1, outF=x2)
+            act = split3(act, M, act.shape[1])
+            gemm_nt(act, W[p + "mlp.fc2.weight"].ws, EPI_F32_RESID, bias=self.P(p + "mlp.fc2.bias"), res=x1, outF=x2)
             if save:
-                ctx["layers"].append(dict(x_in=cur, in_scale=in_scale, y16=y32.view(M, Dd), mean1=mean1, rstd1=rstd1, Ph=Ph, Pt=Pt, qu=qu,
-                                          qut=qut, qv=qv, qvt=qvt, k=k, kt=kt, v=v, o16=o32, lse=lse, x1=x1, h2=h2, mean2=mean2,
+                # y16 / h2 / act / o16s are the [M, 3 K] split-precision images the forward GEMMs consumed; their first third is the f16
+                # operand of the weight gradients (TN kernel, engine.py `_dw_accum`) -- no fp32 copies saved, no transposes in the backward
+                ctx["layers"].append(dict(x_in=cur, in_scale=in_scale, y16=yop, mean1=mean1, rstd1=rstd1, Ph=Ph, Pt=Pt, qu=qu,
+                                          qut=qut, qv=qv, qvt=qvt, k=k, kt=kt, v=v, o16=o32, o16s=o32s, lse=lse, x1=x1, h2=h2, mean2=mean2,
                                           rstd2=rstd2, hpre=hpre, act=act))
             cur = x2
         return cur, ctx
@@ -409,13 +413,15 @@ class PmamEngine(SedEngine):
         if m.mlm:
             hpre = E(M, Dd, dt=BF16 if save else self.act)
             act = E(M, Dd)
+            xds = split3(xd.view(M, Dd), M, Dd)
             with ops.split_precision():
-                gemm_nt(split3(xd.view(M, Dd), M, Dd), W["mlm_mlp.0.weight"].ws, EPI_GELU32, bias=self.P("mlm_mlp.0.bias"), outH=hpre, outF=act)
+                gemm_nt(xds, W["mlm_mlp.0.weight"].ws, EPI_GELU32, bias=self.P("mlm_mlp.0.bias"), outH=hpre, outF=act)
             pred = E(B, Tdec, m.mlm_out)
+            acts = split3(act, M, Dd)
             with ops.split_precision():
-                gemm_nt(split3(act, M, Dd), W["mlm_mlp.2.weight"].ws, EPI_F32, bias=self.P("mlm_mlp.2.bias"), outF=pred.view(M, m.mlm_out))
+                gemm_nt(acts, W["mlm_mlp.2.weight"].ws, EPI_F32, bias=self.P("mlm_mlp.2.bias"), outF=pred.view(M, m.mlm_out))
             out["mlm_pred"] = pred
-            hctx = dict(xd=xd, hpre=hpre, act=act)
+            hctx = dict(xd=xds, hpre=hpre, act=acts)       # split images: first third = weight-gradient operand
         else:
             # classifier + sigmoid + linear-softmax pooling (passt_cnn.py:74-86) on the 768-wide head kernel: decoder output and
             # classifier weight zero-padded from Dd to 768 columns (the dot products are unchanged)
@@ -444,6 +450,12 @@ class PmamEngine(SedEngine):
         transposed images stay uninitialised and only feed output elements nobody reads."""
         dev = dy16.device
         n, k = dy16.shape[1], x.shape[1]
+        if self.dw_tn and M % 64 == 0 and M >= 1024 and dw_tn_ok(M, n, k) and dy16.dtype == BF16 and x.dtype in (F16, BF16):
+            # TN kernel on the operands as they lie: dW [n, k] = dy^T x and the column sums of dy from the same launch.  Padding columns
+            # of either operand only reach output elements outside [:n_valid, :k_valid], which nobody reads.
+            gW, csum = torch.zeros(n, k, device=dev), torch.zeros(n, device=dev)
+            gemm_dw_tn(dy16, x, gW, dbias=csum)
+            return gW.t(), csum
         n_eff, k_eff = min(n, pad64(n_valid)), min(k, pad64(k_valid))
         Mpad = pad64(M)
         gT = torch.empty(n, Mpad, dtype=BF16, device=dev)
@@ -531,8 +543,9 @@ class PmamEngine(SedEngine):
                  Gl(p + "norm2.bias"), M, Dd)
             del dln
             gwo = Z(Dd, Dp) if trainable else None
-            g16 = self._dw_accum(g2, L["o16"], M, gwo, Gl(p + "attn.out_proj.bias"))
+            g16 = self._dw_accum(g2, L["o16s"], M, gwo, Gl(p + "attn.out_proj.bias"))
             if trainable:
+                self._join_dw()      # gwo was filled on the weight-gradient side stream
                 G(p + "attn.out_proj.weight").add_(gwo.view(Dd, H, HD_PAD)[:, :, :hd].reshape(Dd, Dd))
             do16 = E(M, Dp, dt=BF16)
             gemm_nt(g16, W[p + "attn.out_proj.weight"].wt, EPI_BF16, outH=do16)
@@ -557,6 +570,7 @@ class PmamEngine(SedEngine):
                 G(p + "attn.linear_pos.weight").add_(unrows(gwp, SQRT2))
                 gwi, gbi = Z(3 * Dp, Dd), Z(3 * Dp)
                 self._dw_accum(dqkv, L["y16"], M, gwi, gbi)
+                self._join_dw()      # gwi / gbi likewise
                 gw, gb = G(p + "attn.in_proj.weight"), G(p + "attn.in_proj.bias")
                 for s_, sc in ((0, 1.0), (1, SQRT2), (2, 1.0)):
                     gw[s_ * Dd:(s_ + 1) * Dd].add_(unrows(gwi[s_ * Dp:(s_ + 1) * Dp], sc))
@@ -615,7 +629,7 @@ class PmamEngine(SedEngine):
             if dpred is None:
                 g = Z(B, Tdec, Dd)
             else:
-                g = self._mlp_bwd(W, "mlm_mlp.0", "mlm_mlp.2", dpred.contiguous().float().view(M, m.mlm_out), hc["xd"].view(M, Dd),
+                g = self._mlp_bwd(W, "mlm_mlp.0", "mlm_mlp.2", dpred.contiguous().float().view(M, m.mlm_out), hc["xd"],
                                   hc["hpre"], hc["act"], M, G, residual=None).view(B, Tdec, Dd)
         else:
             ds, dw = grads.get("strong"), grads.get("weak")
@@ -692,6 +706,8 @@ class PmamEngine(SedEngine):
                     return tmp[name]
                 return G(name)
             genc = self._enc_layer_bwd(W, ectx, li, genc, Gl)
+            if tmp:
+                self._join_dw()      # the full dW_eff scratch of a LoRA layer comes from the side stream; sed_lora_grad reads it here
             for name, dW in tmp.items():
                 base = name[:-7]
                 call("sed_lora_grad", dW, self.P(base + ".lora_A").detach(), self.P(base + ".lora_B").detach(), s, G(base + ".lora_A"),
