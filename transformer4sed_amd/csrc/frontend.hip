@@ -162,9 +162,14 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
         for (int st = 0; st < 5; ++st) {
             const int Ns = 1 << (2 * st);
             const int j = tid, k = j & (Ns - 1);
+            // LDS slot swizzle of the stage buffers: a stage's scattered writes (index bits: low 2 st bits from j, then q, then the
+            // rest of j) put only 3-4 of a half-wave's 5 varying lane bits into the 5 bank-selecting index bits; the missing ones sit in
+            // index bits >= 5 and are XORed back in.  The next stage reads linearly (j + 256 q), for which any XOR by bits >= 5 stays
+            // conflict-free.  g(i) for the buffer WRITTEN by stage st: st 0: (i >> 5) & 3; st 1: ((i >> 5) & 3) << 2; st 2: ((i >> 6) & 1) << 4.
+#define FFT_SWZ(ST, I) ((ST) == 0 ? ((I) ^ (((I) >> 5) & 3)) : (ST) == 1 ? ((I) ^ ((((I) >> 5) & 3) << 2)) : (ST) == 2 ? ((I) ^ ((((I) >> 6) & 1) << 4)) : (I))
             f32x2v u[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) u[q] = z[cur][j + q * 256];
+            for (int q = 0; q < 4; ++q) u[q] = st == 0 ? z[cur][j + q * 256] : z[cur][FFT_SWZ(st - 1, j + q * 256)];
             if (st > 0) {
 #pragma unroll
                 for (int q = 1; q < 4; ++q) u[q] = cmul_tw(u[q], tw[st > 0 ? st - 1 : 0][q - 1], twp[st > 0 ? st - 1 : 0][q - 1]);
@@ -172,10 +177,10 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
             const f32x2v v0 = u[0] + u[2], v1 = u[0] - u[2], v2 = u[1] + u[3], v3 = mul_neg_i(u[1] - u[3]);
             const int j0 = ((j / Ns) * Ns * 4) + k;
             const int nxt = cur ^ 1;
-            z[nxt][j0] = v0 + v2;
-            z[nxt][j0 + Ns] = v1 + v3;
-            z[nxt][j0 + 2 * Ns] = v0 - v2;
-            z[nxt][j0 + 3 * Ns] = v1 - v3;
+            z[nxt][FFT_SWZ(st, j0)] = v0 + v2;
+            z[nxt][FFT_SWZ(st, j0 + Ns)] = v1 + v3;
+            z[nxt][FFT_SWZ(st, j0 + 2 * Ns)] = v0 - v2;
+            z[nxt][FFT_SWZ(st, j0 + 3 * Ns)] = v1 - v3;
             __syncthreads();
             cur = nxt;
         }
