@@ -126,8 +126,11 @@ int sed_relpos_attn_fwd(const void* Qu, const void* Qv, const void* K, const voi
                         float* LSE, int B, int H, int T, int Tpad, int Rpad, int f16, int o_f32, hipStream_t stream);
 int sed_relpos_attn_bwd(const void* Qu, const void* Qut, const void* Qv, const void* Qvt, const void* K, const void* Kt,
                         const void* V, const void* P, const void* Pt, const void* O, const void* dO, const float* LSE,
-                        float* Dtmp, void* dOh, void* dOt, void* dqkv, void* dSt, float* dP, float* du, float* dv, int B,
+                        float* Dtmp, void* dOh, void* dOt, void* dqkv, void* dSt, void* Pst, float* dP, float* du, float* dv, int B,
                         int H, int T, int Tpad, int Rpad, int need_param_grads, int f16, int o_kind, hipStream_t stream);
+/* (dSt, Pst: [B H, Tpad, Tpad] bf16 scratch slabs, ZERO outside the region the kernels write -- rows = keys, columns = queries.  The dQ
+ *  kernel stores dS^T there for the positional-table gradient and, when Pst is given, P^T as well: dK and dV are then two contractions
+ *  over the stored slabs (a streaming kernel) instead of a second recomputation of the scores; Pst = NULL keeps the recomputing kernel.) */
 
 /* ------------------------------------------------------------------ norms / glue / heads / optimiser */
 /* nn.LayerNorm over D=768 (passt.py:361-362,580; passt_sed.py:128; timm Block norms); y = LN(in_scale*x).

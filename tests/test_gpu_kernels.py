@@ -447,8 +447,19 @@ def test_relpos_fwd_bwd(B, T, DT):
     dSt = torch.zeros(B * Hh, Tpad, Tpad, dtype=BF16, device=DEV)
     dP = torch.zeros(Rpad, 768, device=DEV)
     du = torch.zeros(Hh, 64, device=DEV); dv = torch.zeros(Hh, 64, device=DEV)
+    Pst = torch.zeros(B * Hh, Tpad, Tpad, dtype=BF16, device=DEV)
     call("sed_relpos_attn_bwd", qu.to(DT), qut, qv.to(DT), qvt, k.to(DT), kt, v.to(BF16), Pp, Pt, O, dO.to(BF16),
-         lse, Dt, dOh, dOt, dqkv, dSt, dP, du, dv, B, Hh, T, Tpad, Rpad, 1, f16, f16)
+         lse, Dt, dOh, dOt, dqkv, dSt, Pst, dP, du, dv, B, Hh, T, Tpad, Rpad, 1, f16, f16)
+    # the same backward with dK / dV from the score-recomputing kernel (no P^T slab): same dQ bits, dK / dV to bf16 rounding
+    dqkv_r = torch.empty_like(dqkv)
+    call("sed_relpos_attn_bwd", qu.to(DT), qut, qv.to(DT), qvt, k.to(DT), kt, v.to(BF16), Pp, Pt, O, dO.to(BF16),
+         lse, Dt, dOh, dOt, dqkv_r, torch.zeros_like(dSt), None, torch.zeros_like(dP), torch.zeros_like(du), torch.zeros_like(dv), B, Hh, T, Tpad, Rpad, 1, f16, f16)
+    assert torch.equal(dqkv_r[:, :768], dqkv[:, :768])
+    e = maxerr(dqkv_r[:, 768:].float(), dqkv[:, 768:].float()); report(f"relpos bwd dk|dv stream vs recompute T={T}", e)
+    assert e < 0.02 * float(dqkv[:, 768:].float().abs().max()) + 2e-3
+    # the slabs: P^T rows sum to the softmax mass their keys received; nothing outside [T, T] is touched
+    assert float(Pst[:, T:, :].float().abs().max()) == 0 and float(Pst[:, :, T:].float().abs().max()) == 0
+    assert maxerr(Pst[:, :T, :T].float().sum(1), torch.ones(B * Hh, T, device=DEV)) < 2e-2
     g = dqkv.float().view(B, T, 3, Hh, 64).permute(2, 0, 3, 1, 4).reshape(3, B * Hh, T, 64)
     dq_ref = leaves[0].grad + leaves[1].grad
     for got, ref, nm in ((g[0], dq_ref, "dq"), (g[1], leaves[2].grad, "dk"), (g[2], leaves[3].grad, "dv")):

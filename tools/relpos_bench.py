@@ -23,8 +23,11 @@ dOh = torch.empty(B * H, T, 64, dtype=BF16, device=dev); dOt = torch.empty(B * H
 dSt = torch.zeros(B * H, Tpad, Tpad, dtype=BF16, device=dev); dP = torch.zeros(Rpad, 768, device=dev)
 du = torch.zeros(H, 64, device=dev); dv = torch.zeros(H, 64, device=dev)
 def fwd(): call("sed_relpos_attn_fwd", qu, qv, k, vt, P, O, None, lse, B, H, T, Tpad, Rpad, 1, 0)
-def bwd(): call("sed_relpos_attn_bwd", qu, qut, qv, qvt, k, kt, v.to(BF16), P, Pt, O, dO, lse, Dt, dOh, dOt, dqkv, dSt, dP, du, dv, B, H, T, Tpad, Rpad, 1, 1, 1)
-for name, f in (("fwd", fwd), ("bwd", bwd)):
+Pst = torch.zeros(B * H, Tpad, Tpad, dtype=BF16, device=dev)
+vb = v.to(BF16)
+def bwd(): call("sed_relpos_attn_bwd", qu, qut, qv, qvt, k, kt, vb, P, Pt, O, dO, lse, Dt, dOh, dOt, dqkv, dSt, Pst, dP, du, dv, B, H, T, Tpad, Rpad, 1, 1, 1)
+def bwd_rc(): call("sed_relpos_attn_bwd", qu, qut, qv, qvt, k, kt, vb, P, Pt, O, dO, lse, Dt, dOh, dOt, dqkv, dSt, None, dP, du, dv, B, H, T, Tpad, Rpad, 1, 1, 1)
+for name, f in (("fwd", fwd), ("bwd (dK / dV streamed from the stored slabs)", bwd), ("bwd (dK / dV recomputed)", bwd_rc)):
     f(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -482,7 +482,7 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq_kernel(
     const bf16_t* __restrict__ Qu, const bf16_t* __restrict__ Qv, const bf16_t* __restrict__ K,
     const bf16_t* __restrict__ Kt, const bf16_t* __restrict__ V, const bf16_t* __restrict__ P,
     const bf16_t* __restrict__ Pt, const bf16_t* __restrict__ dOh, const float* __restrict__ LSE,
-    const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, bf16_t* __restrict__ dSt, float* __restrict__ du,
+    const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, bf16_t* __restrict__ dSt, bf16_t* __restrict__ Pst, float* __restrict__ du,
     float* __restrict__ dvb, int T, int Tpad, int H, int Rpad) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds_dq[];
     unsigned char (*lds_kv)[KVB * 128] = reinterpret_cast<unsigned char (*)[KVB * 128]>(lds_dq);                    // K rows, V rows, K^T rows (d)
@@ -573,7 +573,15 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq_kernel(
     const int ntiles = (T + KVB - 1) / KVB;
     // dS^T slab of this (batch, head): [Tpad keys][Tpad queries] bf16; the 128-query block can overhang Tpad (a multiple of 64)
     const __amdgpu_buffer_rsrc_t rds = __builtin_amdgcn_make_buffer_rsrc((void*)(dSt + (size_t)bh * Tpad * Tpad), 0, Tpad * Tpad * 2, 0x00020000);
-    const int dvo = (q0 + c < Tpad) ? (8 * g * Tpad + q0 + c) * 2 : 0x7ffffff0;
+    // P^T slab, same layout (nullable): with it the dK / dV of this layer are two plain contractions over the queries of the stored
+    // dS^T and P^T (relpos_bwd_dkdv_stream_kernel) instead of a second recomputation of the scores
+    const bool store_p = Pst != nullptr;
+    const __amdgpu_buffer_rsrc_t rps = __builtin_amdgcn_make_buffer_rsrc((void*)((store_p ? Pst : dSt) + (size_t)bh * Tpad * Tpad), 0,
+                                                                        store_p ? Tpad * Tpad * 2 : 0, 0x00020000);
+    // slab stores: neighbouring query lanes (c, c ^ 1) trade halves so that every lane stores 4-byte words (two queries of one key row):
+    // the even lane takes key rows r = 0, 1 of a block, the odd lane rows 2, 3 -- half the store instructions of 2-byte stores
+    const bool odd = c & 1;
+    const int dvo = (q0 + c < Tpad) ? ((8 * g + (odd ? 2 : 0)) * Tpad + q0 + (c & ~1)) * 2 : 0x7ffffff0;     // (Tpad is even: a pair is in or out together)
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * KVB;
         const bool more = t + 1 < ntiles;
@@ -627,6 +635,7 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq_kernel(
                 float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], SCALE_LOG2E, -l2));   // invalid query: LSE = +inf
                 if (j0 + KVB > T) p = (j0 + 32 * (kb >> 1) + 4 * (kb & 1) + 8 * g + r < T) ? p : 0.f;   // last tile only
                 dp[kb][r] = p * (dp[kb][r] - dd);
+                st[kb][r] = p;
             }
         // ---- dS^T -> skewed dG^T image (wave-private) and -> global for the dP kernel
         {
@@ -641,10 +650,19 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq_kernel(
                 dg16[jb + 3] = (unsigned short)(p23 >> 16);
                 // branch-free: a lane whose query column does not exist in the [Tpad][Tpad] slab stores out of the buffer's bounds
                 const int so = (j0 + jb) * Tpad * 2;
-                __builtin_amdgcn_raw_buffer_store_b16((short)(p01 & 0xffffu), rds, dvo, so, 0);
-                __builtin_amdgcn_raw_buffer_store_b16((short)(p01 >> 16), rds, dvo, so + Tpad * 2, 0);
-                __builtin_amdgcn_raw_buffer_store_b16((short)(p23 & 0xffffu), rds, dvo, so + Tpad * 4, 0);
-                __builtin_amdgcn_raw_buffer_store_b16((short)(p23 >> 16), rds, dvo, so + Tpad * 6, 0);
+                {
+                    const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? p01 : p23), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                    const unsigned lo = odd ? recv : p01, hi = odd ? p23 : recv;      // the even query's pair of keys, the odd query's
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(hi, lo, 0x05040100u), rds, dvo, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(hi, lo, 0x07060302u), rds, dvo, so + Tpad * 2, 0);
+                }
+                {   // (without a P^T slab the resource has zero records: every lane stores out of bounds)
+                    const unsigned q01 = pack2bf(st[kb][0], st[kb][1]), q23 = pack2bf(st[kb][2], st[kb][3]);
+                    const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? q01 : q23), 0xB1, 0xF, 0xF, true);
+                    const unsigned lo = odd ? recv : q01, hi = odd ? q23 : recv;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(hi, lo, 0x05040100u), rps, dvo, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(hi, lo, 0x07060302u), rps, dvo, so + Tpad * 2, 0);
+                }
             }
         }
         // ---- dQu^T[d, q] += K^T[d, key] dS^T[key, q]
@@ -672,7 +690,7 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq_kernel(
         }
         if (more) {
             asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            // this wave's band pieces have landed (only the 16 dS^T stores are younger)
+            // this wave's band pieces have landed (only the 8 dS^T and 8 P^T stores are younger)
             __syncthreads();
             lstore_kt();
         }
@@ -708,6 +726,83 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq_kernel(
                 unsafeAtomicAdd(&du[h * HD + 16 * db + 4 * g + r], dqu[db][r]);
                 unsafeAtomicAdd(&dvb[h * HD + 16 * db + 4 * g + r], dqv[db][r]);
             }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward kernel 1' (round 3): dK and dV from the dS^T / P^T slabs the dQ kernel stored -- two contractions over the queries,
+//   dK^T[d, key] = scale * sum_q Qu^T[d, q] dS^T[key, q]        dV^T[d, key] = sum_q dO^T[d, q] P^T[key, q]
+// with nothing recomputed (the first-generation kernel above recomputes the content scores, the band product, its skew, the
+// exponentials and dP a second time: 796 us, 286 VGPRs).  A streaming kernel: per (batch, head) it reads the two [Tpad][Tpad] bf16 slabs
+// once (1.6 GB per layer at B = 32) and is bound by that.
+//   workgroup = 8 waves x 16 keys; MFMA rows = d (Qu^T / dO^T tiles [64 d][64 q] in LDS, shared by the waves), MFMA columns = keys:
+//   lane (c, g) reads the 16 bytes q = 32 ks + 8 g .. + 7 of its key's slab row straight from global memory into the B operand, one
+//   tile ahead.  Output lane = key column, 4 consecutive d per block -> 8-byte stores.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void relpos_bwd_dkdv_stream_kernel(const bf16_t* __restrict__ Qut, const bf16_t* __restrict__ dOt,
+                                                                     const bf16_t* __restrict__ dSt, const bf16_t* __restrict__ Pst,
+                                                                     bf16_t* __restrict__ dqkv, int T, int Tpad, int H) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][64 * 128];     // [stage][Qu^T | dO^T][d rows x 64 q]
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int key = blockIdx.x * 128 + wave * 16 + c;
+    const int krow = key < Tpad ? key : Tpad - 1;          // (a key block may overhang Tpad; keys >= T are not stored)
+    const size_t hbt = (size_t)bh * HD * Tpad, sb = (size_t)bh * Tpad * Tpad + (size_t)krow * Tpad + 8 * g;
+    const int trow = tid >> 3, tch = tid & 7;              // this thread's 16-byte chunk of a [64 d][64 q] tile
+    const int ntiles = Tpad / 64;
+    uint4 ta, tb;
+    s16x8_t fs[2], fp[2];
+    // (one tile of slab rows in flight per wave; two were slower: 424 vs 402 us)
+    auto gload = [&](int t) {
+        ta = *reinterpret_cast<const uint4*>(Qut + hbt + (size_t)trow * Tpad + 64 * t + 8 * tch);
+        tb = *reinterpret_cast<const uint4*>(dOt + hbt + (size_t)trow * Tpad + 64 * t + 8 * tch);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            fs[ks] = __builtin_nontemporal_load(reinterpret_cast<const s16x8_t*>(dSt + sb + 64 * t + 32 * ks));
+            fp[ks] = __builtin_nontemporal_load(reinterpret_cast<const s16x8_t*>(Pst + sb + 64 * t + 32 * ks));
+        }
+    };
+    f32x4_t dk[4], dv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dk[i] = zero4; dv[i] = zero4; }
+    gload(0);
+    *reinterpret_cast<uint4*>(lds[0][0] + k_off(trow, tch)) = ta;
+    *reinterpret_cast<uint4*>(lds[0][1] + k_off(trow, tch)) = tb;
+    __syncthreads();
+    const int swc = (c >> 1) & 7;
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        s16x8_t bs[2], bp[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { bs[ks] = fs[ks]; bp[ks] = fp[ks]; }
+        if (t + 1 < ntiles) gload(t + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const int ro = (16 * db + c) * 128 + (((4 * ks + g) ^ swc) << 4);
+                dk[db] = mfma16x<false>(*reinterpret_cast<const s16x8_t*>(lds[cur][0] + ro), bs[ks], dk[db]);
+                dv[db] = mfma16x<false>(*reinterpret_cast<const s16x8_t*>(lds[cur][1] + ro), bp[ks], dv[db]);
+            }
+        if (t + 1 < ntiles) {
+            *reinterpret_cast<uint4*>(lds[cur ^ 1][0] + k_off(trow, tch)) = ta;     // the other stage: last read before the previous barrier
+            *reinterpret_cast<uint4*>(lds[cur ^ 1][1] + k_off(trow, tch)) = tb;
+            __syncthreads();
+        }
+    }
+    if (key < T) {
+        bf16_t* row = dqkv + ((size_t)b * T + key) * (3 * H * HD) + h * HD + 4 * g;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            uint2 o;
+            o.x = pack2bf(dk[db][0] * SCALE, dk[db][1] * SCALE);
+            o.y = pack2bf(dk[db][2] * SCALE, dk[db][3] * SCALE);
+            *reinterpret_cast<uint2*>(row + H * HD + 16 * db) = o;
+            o.x = pack2bf(dv[db][0], dv[db][1]);
+            o.y = pack2bf(dv[db][2], dv[db][3]);
+            *reinterpret_cast<uint2*>(row + 2 * H * HD + 16 * db) = o;
+        }
     }
 }
 
@@ -803,7 +898,7 @@ extern "C" int sed_mhsa_bwd_prep(const void* dO, const void* O, float* Dtmp, voi
 extern "C" int sed_relpos_attn_bwd(const void* Qu, const void* Qut, const void* Qv, const void* Qvt, const void* K,
                                    const void* Kt, const void* V, const void* P, const void* Pt, const void* O,
                                    const void* dO, const float* LSE, float* Dtmp, void* dOh, void* dOt, void* dqkv,
-                                   void* dSt, float* dP, float* du, float* dv, int B, int H, int T, int Tpad,
+                                   void* dSt, void* Pst, float* dP, float* du, float* dv, int B, int H, int T, int Tpad,
                                    int Rpad, int need_param_grads, int f16, int o_kind, hipStream_t stream) {
     (void)hipGetLastError();
     // f16 != 0: Qu, Qv, K, P (score recompute) are IEEE half; Qut, Qvt, Kt, V, Pt, dO are bf16.
@@ -812,15 +907,21 @@ extern "C" int sed_relpos_attn_bwd(const void* Qu, const void* Qut, const void* 
     int rc = sed_mhsa_bwd_prep(dO, O, Dtmp, dOh, dOt, B, H, T, Tpad, o_kind, stream);
     if (rc) return rc;
     dim3 grid(cdiv(T, 128), B * H);
+    // Pst (nullable): a second [B H, Tpad, Tpad] bf16 slab, zero outside its valid region like dSt.  With it the dQ kernel also stores
+    // P^T and dK / dV come from the streaming kernel; without it the first-generation kernel recomputes the scores for them.
 #define SED_LAUNCH_RP(F)                                                                                               \
-    hipLaunchKernelGGL(relpos_bwd_dkdv_kernel<F>, grid, dim3(256), 0, stream, (const bf16_t*)Qu, (const bf16_t*)Qut,   \
-                       (const bf16_t*)Qv, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)P, (const bf16_t*)dOh,    \
-                       (const bf16_t*)dOt, LSE, Dtmp, (bf16_t*)dqkv, T, Tpad, H, Rpad);                                \
+    if (Pst == nullptr)                                                                                                \
+        hipLaunchKernelGGL(relpos_bwd_dkdv_kernel<F>, grid, dim3(256), 0, stream, (const bf16_t*)Qu, (const bf16_t*)Qut, \
+                           (const bf16_t*)Qv, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)P, (const bf16_t*)dOh, \
+                           (const bf16_t*)dOt, LSE, Dtmp, (bf16_t*)dqkv, T, Tpad, H, Rpad);                            \
     hipLaunchKernelGGL(relpos_bwd_dq_kernel<F>, grid, dim3(512), DQ16_LDS, stream, (const bf16_t*)Qu, (const bf16_t*)Qv,    \
                        (const bf16_t*)K, (const bf16_t*)Kt, (const bf16_t*)V, (const bf16_t*)P, (const bf16_t*)Pt,     \
-                       (const bf16_t*)dOh, LSE, Dtmp, (bf16_t*)dqkv, (bf16_t*)dSt, du, dv, T, Tpad, H, Rpad);
+                       (const bf16_t*)dOh, LSE, Dtmp, (bf16_t*)dqkv, (bf16_t*)dSt, (bf16_t*)Pst, du, dv, T, Tpad, H, Rpad);
     if (f16) { SED_LAUNCH_RP(true) } else { SED_LAUNCH_RP(false) }
 #undef SED_LAUNCH_RP
+    if (Pst != nullptr)
+        hipLaunchKernelGGL(relpos_bwd_dkdv_stream_kernel, grid, dim3(512), 0, stream, (const bf16_t*)Qut, (const bf16_t*)dOt,
+                           (const bf16_t*)dSt, (const bf16_t*)Pst, (bf16_t*)dqkv, T, Tpad, H);
     if (need_param_grads) {
         int bsplit = B < 8 ? B : 8;
         hipLaunchKernelGGL(relpos_bwd_dp_kernel, dim3((Rpad / 64) * H * bsplit), dim3(256), 0, stream, (const bf16_t*)dSt,

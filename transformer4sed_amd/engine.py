@@ -88,6 +88,8 @@ class SedEngine:
         # LayerNorm / cast passes.  Joined before every stage hook and at the end of backward.  Off while the kernel timer
         # instruments a step (interleaved kernels inflate every per-launch duration).
         self.dw_side = os.environ.get("SED_DW_STREAM", "1") != "0"
+        # rel-pos backward: dK / dV from the dS^T / P^T slabs the dQ kernel stores (streaming kernel) instead of recomputing the scores
+        self.relpos_stream = os.environ.get("SED_RELPOS_DKDV", "stream") != "recompute"
         self._dw_stream = None
         self._dw_pending = False
         # Evaluation-mode encoder.  The f16 weight images are the largest single term of the posterior error (tools/err_sim.py: logit
@@ -907,6 +909,8 @@ class SedEngine:
             dOh = E(B * H, T, 64, dt=BF16)
             dOt = E(B * H, 64, Tpad, dt=BF16)
             dSt = self._zeros(("dSt", B, Tpad), (B * H, Tpad, Tpad), BF16, dev)      # scratch of this call: one buffer for all layers
+            # P^T slab beside it: dK / dV as contractions over the two stored slabs (SED_RELPOS_DKDV=recompute: the score-recomputing kernel)
+            Pst = self._zeros(("Pst", B, Tpad), (B * H, Tpad, Tpad), BF16, dev) if self.relpos_stream else None
             dP = Z(Rpad, D)
             du = Gl(p + "attn.pos_bias_u")
             dv = Gl(p + "attn.pos_bias_v")
@@ -914,9 +918,9 @@ class SedEngine:
             f16 = is_f16(L["qu"])
             call("sed_relpos_attn_bwd", L["qu"], to_bf16_(L["qut"]), L["qv"], to_bf16_(L["qvt"]), L["k"],
                  to_bf16_(L["kt"]), to_bf16_(L["v"]), L["Ph"], to_bf16_(L["Pt"]), L["o16"], do16, L["lse"], Dtmp, dOh, dOt,
-                 dqkv, dSt, dP, du if du is not None else scratch_uv[0], dv if dv is not None else scratch_uv[1], B, H, T,
+                 dqkv, dSt, Pst, dP, du if du is not None else scratch_uv[0], dv if dv is not None else scratch_uv[1], B, H, T,
                  Tpad, Rpad, 1 if trainable else 0, f16, o_kind(L["o16"]))
-            del dSt, dOh, dOt, do16
+            del dSt, Pst, dOh, dOt, do16
             if trainable:
                 dPT = E(D, Rpad, dt=BF16)
                 transpose_bf16(dP, Rpad, D, dPT)

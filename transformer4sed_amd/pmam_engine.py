@@ -554,12 +554,13 @@ class PmamEngine(SedEngine):
             dOh = E(B * H, T, 64, dt=BF16)
             dOt = E(B * H, 64, Tpad, dt=BF16)
             dSt = self._zeros(("dSt", B, Tpad), (B * H, Tpad, Tpad), BF16, dev)
+            Pst = self._zeros(("Pst", B, Tpad), (B * H, Tpad, Tpad), BF16, dev) if self.relpos_stream else None
             dP = Z(Rpad, Dp)
             duv = Z(2, Dp)
             call("sed_relpos_attn_bwd", L["qu"], to_bf16_(L["qut"]), L["qv"], to_bf16_(L["qvt"]), L["k"], to_bf16_(L["kt"]),
-                 to_bf16_(L["v"]), L["Ph"], to_bf16_(L["Pt"]), L["o16"], do16, L["lse"], Dtmp, dOh, dOt, dqkv, dSt, dP, duv[0], duv[1], B, H,
+                 to_bf16_(L["v"]), L["Ph"], to_bf16_(L["Pt"]), L["o16"], do16, L["lse"], Dtmp, dOh, dOt, dqkv, dSt, Pst, dP, duv[0], duv[1], B, H,
                  T, Tpad, Rpad, 1 if trainable else 0, 1, o_kind(L["o16"]))
-            del dSt, dOh, dOt, do16
+            del dSt, Pst, dOh, dOt, do16
             if trainable:
                 G(p + "attn.pos_bias_u").add_(duv[0].view(H, HD_PAD)[:, :hd])
                 G(p + "attn.pos_bias_v").add_(duv[1].view(H, HD_PAD)[:, :hd])
