@@ -67,6 +67,25 @@ int sed_gemm_nt_w2(const void* A, const void* B, int M, int N, int K, int lda, i
                    const float* resF, float* outF, void* outH, void* outH2, int ldc, int f16, hipStream_t stream);
 int sed_gemm_qkv_w2(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq, int seq_pad, void* q,
                     void* k, void* v, int f16, hipStream_t stream);
+/* LayerNorm FOLDED into the two Linear layers around it -- timm Block.forward `x = x + attn(norm1(x))`, `x = x + mlp(norm2(x))`
+ * (src/models/passt/passt.py:360-363 with the F.linear calls of :332,342 and Mlp fc1 / fc2) for no-grad f16 passes (teacher, inference), so
+ * that the normalised tensor never exists in memory:
+ *   sed_gemm_nt_lnp   the residual Linear (proj / fc2): outF = resF + A . B^T + bias (fp32, may alias resF) AND x16 = its f16 image AND
+ *                     rowpart [M][N / 64][2] = per-row (sum, sum of squares) of every 64-column slice
+ *   sed_ln_fold_stats rowpart -> rowstat [M][2] = (mean, 1 / sqrt(var + eps)) over D = 64 S columns
+ *   sed_ln_fold_weight W16 [N, K] = f16(gamma[k] W[n, k]), colS[n] = sum_k W16[n, k], colC[n] = sum_k beta[k] W[n, k] + bias[n]
+ *   sed_gemm_nt_lnc / sed_gemm_qkv_lnc  the Linear AFTER the LayerNorm (fc1 + GELU; qkv with the head split), fed with x16 (the RAW
+ *                     stream) and W16: out[m, n] = f(rstd[m] * (acc[m, n] - mean[m] * colS[n]) + colC[n])  ==  f(Linear(LayerNorm(x)))
+ * 256^2 kernel only: N % 256 == 0, M >= 1024, K % 64 == 0, f16 operands. */
+int sed_gemm_nt_lnp(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* bias, const float* resF,
+                    float* outF, void* x16, float* rowpart, int ldc, hipStream_t stream);
+int sed_ln_fold_stats(const float* rowpart, float* rowstat, int M, int S, int D, float eps, hipStream_t stream);
+int sed_ln_fold_weight(const float* W, const float* gamma, const float* beta, const float* bias, void* W16, float* colS, float* colC,
+                       int N, int K, hipStream_t stream);
+int sed_gemm_nt_lnc(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* colC, const float* colS,
+                    const float* rowstat, void* outH2, int ldc, hipStream_t stream);
+int sed_gemm_qkv_lnc(const void* A, const void* W, const float* colC, const float* colS, const float* rowstat, int M, int K, int heads,
+                     int seq, int seq_pad, void* q, void* k, void* v, hipStream_t stream);
 /* operands of that correction: per-clip token means of a 16-bit activation x [groups * rows, K] -> [groups, K] (K % 256 == 0; every
  * step-th token), and the f16 image of scale * (w - f16(w)) for an fp32 weight of n (multiple of 4) elements */
 int sed_group_colmean(const void* x, void* out, int groups, int rows, int K, int step, int f16, hipStream_t stream);

@@ -212,6 +212,68 @@ def test_gemm_two_term_weights_and_row_group_bias():
         gemm_nt(x[:512], W2[:768], ops.EPI_F32_RESID, bias=b[:768], res=torch.zeros(512, 768, device=DEV), outF=torch.zeros(512, 768, device=DEV), two_term=True)
 
 
+def test_gemm_layernorm_fold():
+    """LayerNorm folded into the GEMMs around it (sed_gemm_nt_lnp -> sed_ln_fold_stats -> sed_gemm_nt_lnc / sed_gemm_qkv_lnc with
+    sed_ln_fold_weight images) against Linear(LayerNorm(x)) in fp64, and against the unfolded HIP path (LayerNorm kernel -> f16 -> GEMM):
+    the fold must be as accurate.  The stream carries a per-row offset and outlier channels like a ViT residual stream does."""
+    M, D, Hd = 2 * 1190, 768, 3072
+    a16 = rnd(M, D, seed=71).to(F16)
+    Wp = rnd(D, D, scale=0.03, seed=72); bp = rnd(D, seed=73) * 0.1
+    res = rnd(M, D, scale=1.5, seed=74) + 0.7 * rnd(M, 1, seed=75)
+    res[:, ::97] *= 12.0
+    gam = 1.0 + 0.3 * rnd(D, seed=76); bet = 0.2 * rnd(D, seed=77)
+    W1 = rnd(Hd, D, scale=0.03, seed=78); b1 = rnd(Hd, seed=79) * 0.1
+    # ---- producer
+    x = torch.empty(M, D, device=DEV); x16 = torch.empty(M, D, dtype=F16, device=DEV)
+    part = torch.full((M, D // 64, 2), float("nan"), device=DEV)
+    call("sed_gemm_nt_lnp", a16, Wp.to(F16), M, D, D, D, D, bp, res, x, x16, part, D)
+    plain = torch.empty(M, D, device=DEV)
+    gemm_nt(a16, Wp.to(F16), ops.EPI_F32_RESID, bias=bp, res=res, outF=plain)
+    assert torch.equal(x, plain) and torch.equal(x16, x.to(F16))
+    sl = x.view(M, D // 64, 64)
+    assert maxerr(part[:, :, 0], sl.sum(-1)) < 2e-3 and maxerr(part[:, :, 1], (sl * sl).sum(-1)) < 2e-3 * float((sl * sl).sum(-1).max())
+    inplace = res.clone()
+    call("sed_gemm_nt_lnp", a16, Wp.to(F16), M, D, D, D, D, bp, inplace, inplace, x16, part, D)
+    assert torch.equal(inplace, x)
+    stat = torch.empty(M, 2, device=DEV)
+    call("sed_ln_fold_stats", part, stat, M, D // 64, D, 1e-6)
+    xd = x.double()
+    mu, var = xd.mean(-1), xd.var(-1, unbiased=False)
+    assert maxerr(stat[:, 0], mu) < 1e-5 and float(((stat[:, 1].double() - (var + 1e-6).rsqrt()).abs() * (var + 1e-6).sqrt()).max()) < 2e-5
+    # ---- weight side
+    W16 = torch.empty(Hd, D, dtype=F16, device=DEV); cS = torch.empty(Hd, device=DEV); cC = torch.empty(Hd, device=DEV)
+    call("sed_ln_fold_weight", W1, gam, bet, b1, W16, cS, cC, Hd, D)
+    assert torch.equal(W16, (W1 * gam).to(F16)) and maxerr(cS, W16.float().sum(-1)) < 1e-4
+    assert maxerr(cC, (W1.double() @ bet.double() + b1.double())) < 1e-5
+    # ---- consumer (fc1 + GELU) vs fp64 and vs the unfolded path
+    act = torch.empty(M, Hd, dtype=F16, device=DEV)
+    call("sed_gemm_nt_lnc", x16, W16, M, Hd, D, D, D, cC, cS, stat, act, Hd)
+    truth = torch.nn.functional.gelu(torch.nn.functional.layer_norm(xd, (D,), gam.double(), bet.double(), 1e-6) @ W1.double().t() + b1.double())
+    h16 = torch.empty(M, D, dtype=F16, device=DEV)
+    call("sed_layernorm_fwd", x, gam, bet, 1e-6, 1.0, h16, None, None, None, M, D, 1)
+    act0 = torch.empty(M, Hd, dtype=F16, device=DEV)
+    gemm_nt(h16, W1.to(F16), ops.EPI_GELU, bias=b1, outH=None, outH2=act0)
+    e_fold, e_plain = maxerr(act.float(), truth), maxerr(act0.float(), truth)
+    rms = lambda t: float(((t.double() - truth) ** 2).mean().sqrt())
+    report(f"LN fold fc1+GELU: max {e_fold:.2e} (unfolded {e_plain:.2e}), rms {rms(act):.2e} (unfolded {rms(act0):.2e})", e_fold, float(truth.abs().max()))
+    assert e_fold < 1.5 * e_plain + 1e-3 and rms(act) < 1.3 * rms(act0)
+    # ---- consumer (qkv, head split)
+    Hh, Ntok = 12, 1190
+    Wq = rnd(2304, D, scale=0.03, seed=80); bq = rnd(2304, seed=81) * 0.1
+    Wq16 = torch.empty(2304, D, dtype=F16, device=DEV); qS = torch.empty(2304, device=DEV); qC = torch.empty(2304, device=DEV)
+    call("sed_ln_fold_weight", Wq, gam, bet, bq, Wq16, qS, qC, 2304, D)
+    mk = lambda: torch.empty(2 * Hh, Ntok, 64, dtype=F16, device=DEV)
+    q, k, v = mk(), mk(), mk()
+    call("sed_gemm_qkv_lnc", x16, Wq16, qC, qS, stat, M, D, Hh, Ntok, pad64(Ntok), q, k, v)
+    q0, k0, v0 = mk(), mk(), mk()
+    call("sed_gemm_qkv", h16, Wq.to(F16), bq, M, D, Hh, Ntok, pad64(Ntok), q0, k0, v0, None, None, None, None, None, None, None, 1)
+    tq = (torch.nn.functional.layer_norm(xd, (D,), gam.double(), bet.double(), 1e-6) @ Wq.double().t() + bq.double()).view(2, Ntok, 3, Hh, 64).permute(2, 0, 3, 1, 4)
+    for got, got0, i in ((q, q0, 0), (k, k0, 1), (v, v0, 2)):
+        want = tq[i].reshape(2 * Hh, Ntok, 64)
+        ef, ep = maxerr(got.float(), want), maxerr(got0.float(), want)
+        assert ef < 1.5 * ep + 1e-3, (i, ef, ep)
+
+
 def test_gemm_asymmetric_identity():
     """A = I with an asymmetric B catches transposed C writes (guide rule 16)."""
     K = 128

@@ -60,6 +60,15 @@ struct GemmArgs {
     // Persistent 256^2 kernel: workgroups with an odd (blockIdx.x >> 3) start `stagger` ticks of the 100 MHz real-time counter late, so
     // that their store phases fall into the other half's main loops instead of all 256 CUs hitting HBM in lock-step.  0 = off.
     int stagger;
+    // LayerNorm folded into the GEMMs around it (256^2 kernel, no-grad f16 passes; engine.py `_encoder_fwd`):
+    //   producer (EPI_F32_RESID): besides the fp32 residual stream it writes the f16 image of the new stream to outH and, per row and
+    //     64-column slice, the partial sums (sum x, sum x^2) to rowpart [M][N / 64][2];
+    //   consumer (EPI_QKV / EPI_GELU): A is that f16 image of the RAW stream, B the f16 image of gamma (.) W; row m of the result is
+    //     rstd[m] * (acc - mean[m] * colS[n]) + bias[n] with rowstat [M][2] = (mean, rstd), colS[n] = sum_k B[n, k], and `bias` already
+    //     holding beta . W^T + b  ->  exactly Linear(LayerNorm(x)) without the normalised tensor ever existing.
+    float* rowpart;
+    const float* rowstat;
+    const float* colS;
 };
 
 #define TILE 128
@@ -402,6 +411,68 @@ __device__ __forceinline__ void pp_stage16_gb(unsigned char* wl, const f32x4_t (
     }
 }
 
+// LayerNorm-folded staging: x = rstd[row] * (acc - mean[row] * sv[col]) + bv[col]  (rows mb + 16 i + l15, statistics clipped to the last row)
+// (BVP: the column constants are fetched per 16-column block from `bias_n` instead of living in 16 registers -- the head-split epilogue
+//  has no room for them beside the accumulators)
+template <bool F16, int MODE, bool BVP = false>
+__device__ __forceinline__ void pp_stage16_ln(unsigned char* wl, const f32x4_t (&acc)[8][4], const float (&bv)[4][4], const float* colS_n,
+                                              const float* rowstat, int mb, int M, int l15, int lq, const float* bias_n = nullptr) {
+    // every global load of the epilogue is issued up front (8 row statistics, 4 + 4 column vectors): one exposed round trip instead of
+    // one per 16-column block -- the K loop's fragment registers are free by now
+    float2 st[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = mb + i * 16 + l15;
+        st[i] = *reinterpret_cast<const float2*>(rowstat + 2 * (size_t)(m < M ? m : M - 1));
+    }
+    if constexpr (BVP) {      // head-split epilogue (tight on registers): column vectors one 16-column block ahead, blocks outermost
+        float rs[8], tm[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { rs[i] = st[i].y; tm[i] = -st[i].x * st[i].y; }
+        float4 sn = *reinterpret_cast<const float4*>(colS_n + 4 * lq), bn = *reinterpret_cast<const float4*>(bias_n + 4 * lq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 sc = sn, bc = bn;
+            if (j < 3) {
+                sn = *reinterpret_cast<const float4*>(colS_n + (j + 1) * 16 + 4 * lq);
+                bn = *reinterpret_cast<const float4*>(bias_n + (j + 1) * 16 + 4 * lq);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                uint2 pk;
+                pk.x = pack2<F16>(__builtin_fmaf(acc[i][j][0], rs[i], __builtin_fmaf(tm[i], sc.x, bc.x)),
+                                  __builtin_fmaf(acc[i][j][1], rs[i], __builtin_fmaf(tm[i], sc.y, bc.y)));
+                pk.y = pack2<F16>(__builtin_fmaf(acc[i][j][2], rs[i], __builtin_fmaf(tm[i], sc.z, bc.z)),
+                                  __builtin_fmaf(acc[i][j][3], rs[i], __builtin_fmaf(tm[i], sc.w, bc.w)));
+                *reinterpret_cast<uint2*>(wl + (i * 16 + l15) * V3_RS16 + (j * 16 + 4 * lq) * 2) = pk;
+            }
+        }
+        return;
+    }
+    float4 s4[4], b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s4[j] = *reinterpret_cast<const float4*>(colS_n + j * 16 + 4 * lq);
+        b4[j] = make_float4(bv[j][0], bv[j][1], bv[j][2], bv[j][3]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float rs = st[i].y, tm = -st[i].x * st[i].y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x2v x0 = {__builtin_fmaf(acc[i][j][0], rs, __builtin_fmaf(tm, s4[j].x, b4[j].x)),
+                         __builtin_fmaf(acc[i][j][1], rs, __builtin_fmaf(tm, s4[j].y, b4[j].y))};
+            f32x2v x1 = {__builtin_fmaf(acc[i][j][2], rs, __builtin_fmaf(tm, s4[j].z, b4[j].z)),
+                         __builtin_fmaf(acc[i][j][3], rs, __builtin_fmaf(tm, s4[j].w, b4[j].w))};
+            if (MODE == 1) { x0 = gelu_fast2(x0); x1 = gelu_fast2(x1); }
+            uint2 pk;
+            pk.x = pack2<F16>(x0.x, x0.y);
+            pk.y = pack2<F16>(x1.x, x1.y);
+            *reinterpret_cast<uint2*>(wl + (i * 16 + l15) * V3_RS16 + (j * 16 + 4 * lq) * 2) = pk;
+        }
+    }
+}
+
 template <bool F16, int MODE, int RB = 8>
 __device__ __forceinline__ void pp_stage16(unsigned char* wl, const f32x4_t (&acc)[8][4], const float (&bv)[4][4], int l15, int lq) {
     // mode 0: acc + column constant   1: gelu_fast(acc + column constant)
@@ -472,7 +543,15 @@ __device__ __forceinline__ void v3_side_load(V3Side<EPI>& sd, const GemmArgs& g,
     }
 }
 // rows m0 .. m0 + 31 of the output = staged rows srow0 .. srow0 + 31
-template <int EPI, bool F16>
+// 16-lane (one staged row) sum through DPP: quad butterflies, then the two mirrors
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
+template <int EPI, bool F16, bool LNP = false>
 __device__ __forceinline__ void v3_store_batch(const GemmArgs& g, const unsigned char* wl, const V3Side<EPI>& sd, const float4 b0,
                                                int m0, int srow0, int n, int c4, int lane, const float4 bB = make_float4(0.f, 0.f, 0.f, 0.f),
                                                int mbnd = 0x7fffffff, int mend = 0x7fffffff) {
@@ -491,7 +570,16 @@ __device__ __forceinline__ void v3_store_batch(const GemmArgs& g, const unsigned
             v3_st<float4>(g.outF + o, make_float4(v.x * g.alpha + b.x, v.y * g.alpha + b.y, v.z * g.alpha + b.z, v.w * g.alpha + b.w));
         } else if constexpr (EPI == EPI_F32_RESID) {
             const float4 r = sd.r[u];
-            v3_st<float4>(g.outF + o, make_float4(r.x + v.x + b.x, r.y + v.y + b.y, r.z + v.z + b.z, r.w + v.w + b.w));
+            const float4 x = make_float4(r.x + v.x + b.x, r.y + v.y + b.y, r.z + v.z + b.z, r.w + v.w + b.w);
+            v3_st<float4>(g.outF + o, x);
+            if constexpr (LNP) {      // LayerNorm-fold producer: f16 image of the stream + this 64-column slice's (sum, sum of squares) per row
+                uint2 pk; pk.x = pack2<true>(x.x, x.y); pk.y = pack2<true>(x.z, x.w);
+                *reinterpret_cast<uint2*>(g.outH + o) = pk;      // (a plain store: the next GEMM reads this image right away)
+                // (all 16 lanes of a row take this path together: m is uniform across them)
+                const float s1 = row16_sum((x.x + x.y) + (x.z + x.w));
+                const float s2 = row16_sum((x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w));
+                if (c4 == 0) *reinterpret_cast<float2*>(g.rowpart + ((size_t)m * (g.N >> 6) + (n >> 6)) * 2) = make_float2(s1, s2);
+            }
         } else if constexpr (EPI == EPI_F32_BF16) {
             v = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
             v3_st<float4>(g.outF + o, v);
@@ -537,7 +625,8 @@ template <int EPI, bool F16, int GBM, int RB = 8>
 __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&acc)[8][4], const V3Consts<EPI>& cc,
                                             unsigned char* wl, int mb, int nb, int lane, unsigned long long* gxt = nullptr) {
     // mb = first row of this wave's 128 x 64 sub-tile, nb = its first column
-    constexpr bool GB = GBM == 1;   // 1: row-group bias, 2: two-term weights (plain epilogue)
+    constexpr bool GB = GBM == 1;   // 1: row-group bias, 2: two-term weights (plain epilogue), 3: folded LayerNorm (producer / consumer by EPI)
+    constexpr bool LN = GBM == 3;
     const int l15 = lane & 15, lq = lane >> 4;
     if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
 #pragma unroll
@@ -549,6 +638,9 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
                 const int bnd = gb_split(g, mb, rA, rB);
                 if (EPI == EPI_GELU && pass == 1) pp_stage16_gb<F16, 1>(wl, acc, cc.bv, rA + nb, rB + nb, bnd, l15, lq);
                 else pp_stage16_gb<F16, 0>(wl, acc, cc.bv, rA + nb, rB + nb, bnd, l15, lq);
+            } else if constexpr (LN) {      // consumer: Linear(LayerNorm(x)) from the raw stream's product (no saved pre-activation either)
+                if (EPI == EPI_GELU && pass == 1) pp_stage16_ln<F16, 1>(wl, acc, cc.bv, g.colS + nb, g.rowstat, mb, g.M, l15, lq);
+                else pp_stage16_ln<F16, 0>(wl, acc, cc.bv, g.colS + nb, g.rowstat, mb, g.M, l15, lq);
             } else
             if (EPI == EPI_GELU && pass == 1) pp_stage16<F16, 1>(wl, acc, cc.bv, l15, lq);
             else if (EPI == EPI_GELU && F16 && g.bwd_bf16) pp_stage16<false, 0>(wl, acc, cc.bv, l15, lq);  // pre-activation for the bf16 backward
@@ -585,11 +677,13 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
             bf16_t* rd = pass == 0 ? row_dst : g.q2;
             bf16_t* td = pass == 0 ? tr_dst : g.q2t;
             float bv[4][4];
-            pp_col_consts(bv, g.bias != nullptr ? g.bias + nb : nullptr, extra, lq);
+            if constexpr (!LN) pp_col_consts(bv, g.bias != nullptr ? g.bias + nb : nullptr, extra, lq);
             if constexpr (GB) {
                 const float *rA, *rB;
                 const int bnd = gb_split(g, mb, rA, rB);
                 pp_stage16_gb<F16, 0>(wl, acc, bv, rA + nb, rB + nb, bnd, l15, lq);
+            } else if constexpr (LN) {
+                pp_stage16_ln<F16, 0, true>(wl, acc, bv, g.colS + nb, g.rowstat, mb, g.M, l15, lq, g.bias + nb);
             } else {
                 pp_stage16<F16, 0, RB>(wl, acc, bv, l15, lq);
             }
@@ -679,15 +773,15 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
     pp_stage32<RB>(wl, acc, 0, l15, lq);
     __builtin_amdgcn_wave_barrier();
     v3_side_load<EPI>(s1, g, mb + 32, n, lane);
-    v3_store_batch<EPI, F16>(g, wl, s0, b, mb, 0, n, c4, lane, bB, mbnd, mend);
+    v3_store_batch<EPI, F16, LN && EPI == EPI_F32_RESID>(g, wl, s0, b, mb, 0, n, c4, lane, bB, mbnd, mend);
     v3_side_load<EPI>(s0, g, mb + 64, n, lane);
-    v3_store_batch<EPI, F16>(g, wl, s1, b, mb + 32, 32, n, c4, lane, bB, mbnd, mend);
+    v3_store_batch<EPI, F16, LN && EPI == EPI_F32_RESID>(g, wl, s1, b, mb + 32, 32, n, c4, lane, bB, mbnd, mend);
     __builtin_amdgcn_wave_barrier();
     pp_stage32<RB>(wl, acc, 1, l15, lq);
     __builtin_amdgcn_wave_barrier();
     v3_side_load<EPI>(s1, g, mb + 96, n, lane);
-    v3_store_batch<EPI, F16>(g, wl, s0, b, mb + 64, 0, n, c4, lane, bB, mbnd, mend);
-    v3_store_batch<EPI, F16>(g, wl, s1, b, mb + 96, 32, n, c4, lane, bB, mbnd, mend);
+    v3_store_batch<EPI, F16, LN && EPI == EPI_F32_RESID>(g, wl, s0, b, mb + 64, 0, n, c4, lane, bB, mbnd, mend);
+    v3_store_batch<EPI, F16, LN && EPI == EPI_F32_RESID>(g, wl, s1, b, mb + 96, 32, n, c4, lane, bB, mbnd, mend);
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -1203,7 +1297,7 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
         const int ntn = g.N / V3_T;
         const long long t8 = (long long)cdiv(g.M, 256) * ntn, t7 = (long long)cdiv(g.M, 224) * ntn;
         const long long c8 = ((t8 + ncu - 1) / ncu) * 256, c7 = ((t7 + ncu - 1) / ncu) * 224;
-        const bool use7 = g.gbias == nullptr && g.k_wrap == 0 && (rb_env == 7 || (rb_env == 0 && c7 * 100 < c8 * 97));
+        const bool use7 = g.gbias == nullptr && g.k_wrap == 0 && g.rowpart == nullptr && g.rowstat == nullptr && (rb_env == 7 || (rb_env == 0 && c7 * 100 < c8 * 97));
         dim3 grid3((unsigned)(use7 ? t7 : t8), 1);
         gg.persist = (persist_env && (int)grid3.x > ncu) ? 1 : 0;
         if (gg.persist) grid3.x = ncu;
@@ -1212,6 +1306,21 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
             gg.stagger = (gg.persist && st_s) ? atoi(st_s) : 0;
         }
         const GemmArgs& g = gg;
+        if (g.rowpart != nullptr || g.rowstat != nullptr) {
+            // folded LayerNorm: producer (residual epilogue) or consumer (head-split / fused-GELU epilogue); f16, no other special mode
+            if constexpr (EPI == EPI_F32_RESID || EPI == EPI_GELU || EPI == EPI_QKV) {
+                constexpr bool producer = EPI == EPI_F32_RESID;
+                if (!f16 || g.gbias != nullptr || g.k_wrap != 0 || (g.N & 63)) return SED_ERR_ARG;
+                if (producer ? (g.rowpart == nullptr || g.outH == nullptr || g.rowstat != nullptr)
+                             : (g.rowstat == nullptr || g.colS == nullptr || g.rowpart != nullptr)) return SED_ERR_ARG;
+                static bool attrl = false;
+                if (!attrl) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attrl = true; }
+                hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true, 3>), grid3, dim3(512), V3_LDS, s, g);
+                return sed_check_launch();
+            } else {
+                return SED_ERR_ARG;
+            }
+        }
         if (g.gbias != nullptr || g.k_wrap != 0) {
             // row-group bias / two-term weights: evaluation-mode encoder GEMMs only (f16 operands; residual, fused-GELU and head-split epilogues)
             if constexpr (EPI == EPI_F32_RESID || EPI == EPI_GELU || EPI == EPI_QKV) {
@@ -1243,7 +1352,7 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
 #undef SED_PP_LAUNCH
         return sed_check_launch();
     }
-    if (g.k_wrap != 0) return SED_ERR_ARG;   // two-term weights exist in the 256^2 kernel only (N % 256 == 0, M >= 1024)
+    if (g.k_wrap != 0 || g.rowpart != nullptr || g.rowstat != nullptr) return SED_ERR_ARG;   // 256^2-kernel-only modes (N % 256 == 0, M >= 1024)
     dim3 grid(cdiv(g.M, TILE) * (g.N / TILE), g.ksplit);
     if (f16) hipLaunchKernelGGL((gemm_nt_kernel<EPI, true>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm_nt_kernel<EPI, false>), grid, dim3(256), 0, s, g);
@@ -1300,6 +1409,31 @@ extern "C" int sed_gemm_nt_w2(const void* A, const void* B, int M, int N, int K,
     if (!(f16 & 1) || N % 256 || M < 1024) return SED_ERR_ARG;
     return gemm_nt_impl(A, B, M, N, K, lda, ldb, epi, bias, resF, outF, outH, outH2, nullptr, ldc, 1.f, 1, f16, N, stream, nullptr, 0, 1);
 }
+// LayerNorm folded into the two GEMMs around it (no-grad f16 passes; 256^2 kernel only: N % 256 == 0, M >= 1024).
+// producer = sed_gemm_nt with EPI_F32_RESID that ALSO writes x16 [M, N] (f16 image of the new residual stream) and rowpart [M][N / 64][2]
+// (per-row partial sum / sum of squares of each 64-column slice); sed_ln_fold_stats turns rowpart into rowstat [M][2] = (mean, rstd);
+// consumer = EPI_GELU GEMM whose A operand is x16 (the RAW stream), B the f16 image of gamma (.) W (sed_ln_fold_weight), with
+// out[m, n] = act(rstd[m] * (acc - mean[m] * colS[n]) + colC[n]).
+extern "C" int sed_gemm_nt_lnp(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* bias, const float* resF,
+                               float* outF, void* x16, float* rowpart, int ldc, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (N % 256 || M < 1024 || K % BK || x16 == nullptr || rowpart == nullptr || ldc != N) return SED_ERR_ARG;
+    GemmArgs g = {};
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.ncols = N;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ksplit = 1; g.alpha = 1.f;
+    g.bias = bias; g.resF = resF; g.outF = outF; g.outH = (bf16_t*)x16; g.rowpart = rowpart;
+    return launch_gemm<EPI_F32_RESID>(g, 1, stream);
+}
+extern "C" int sed_gemm_nt_lnc(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* colC, const float* colS,
+                               const float* rowstat, void* outH2, int ldc, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (N % 256 || M < 1024 || K % BK || colS == nullptr || rowstat == nullptr || outH2 == nullptr) return SED_ERR_ARG;
+    GemmArgs g = {};
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.ncols = N;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ksplit = 1; g.alpha = 1.f;
+    g.bias = colC; g.outH2 = (bf16_t*)outH2; g.colS = colS; g.rowstat = rowstat;
+    return launch_gemm<EPI_GELU>(g, 1, stream);
+}
 // same GEMM with a narrow result: the operands are padded to N (multiple of 128) but only the first ncols (multiple of 4) output
 // columns exist in memory (row stride ldc >= ncols); bias / residual / outputs are indexed like the narrow matrix.  128^2 kernel only.
 extern "C" int sed_gemm_nt_cols(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi,
@@ -1321,6 +1455,19 @@ extern "C" int sed_gemm_qkv_gb(const void* A, const void* W, const float* bias, 
                                int seq_pad, void* q, void* k, void* v, int f16, const float* gbias, int gb_rows, hipStream_t stream) {
     return gemm_qkv_impl(A, W, bias, M, K, heads, seq, seq_pad, q, k, v, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, f16,
                          gbias, gb_rows, stream);
+}
+// folded-LayerNorm consumer (see sed_gemm_nt_lnc): A = f16 image of the raw stream, W = f16 image of gamma (.) W_qkv; inference outputs only
+extern "C" int sed_gemm_qkv_lnc(const void* A, const void* W, const float* colC, const float* colS, const float* rowstat, int M, int K,
+                                int heads, int seq, int seq_pad, void* q, void* k, void* v, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (M < 1024 || K % BK || colS == nullptr || rowstat == nullptr || seq <= 0 || (seq_pad % 64) || M % seq) return SED_ERR_ARG;
+    GemmArgs g = {};
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)W;
+    g.M = M; g.N = 3 * heads * 64; g.K = K; g.lda = K; g.ldb = K; g.ldc = g.N; g.ksplit = 1; g.alpha = 1.f; g.ncols = g.N;
+    g.bias = colC; g.colS = colS; g.rowstat = rowstat;
+    g.q = (bf16_t*)q; g.k = (bf16_t*)k; g.v = (bf16_t*)v;
+    g.seq = seq; g.seq_pad = seq_pad; g.heads = heads;
+    return launch_gemm<EPI_QKV>(g, 1, stream);
 }
 // two-term weights (see sed_gemm_nt_w2): W is [3 * heads * 64, 2K]; inference outputs only
 extern "C" int sed_gemm_qkv_w2(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq,
@@ -1616,6 +1763,58 @@ extern "C" int sed_weight_residual_f16(const float* w, void* out, int64_t n, flo
     int blocks = (int)((n4 + 255) / 256);
     blocks = blocks > 4096 ? 4096 : blocks;
     hipLaunchKernelGGL(weight_residual_kernel, dim3(blocks), dim3(256), 0, stream, w, (bf16_t*)out, n4, scale);
+    return sed_check_launch();
+}
+
+// rowpart [M][S][2] (per-row partial sums of S column slices) -> rowstat [M][2] = (mean, 1 / sqrt(var + eps)) over D columns
+__global__ void ln_fold_stats_kernel(const float* __restrict__ rowpart, float* __restrict__ rowstat, int M, int S, float invD, float eps) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < S; ++i) {
+        const float2 p = *reinterpret_cast<const float2*>(rowpart + ((size_t)m * S + i) * 2);
+        s1 += p.x; s2 += p.y;
+    }
+    const float mean = s1 * invD;
+    float var = s2 * invD - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    *reinterpret_cast<float2*>(rowstat + 2 * (size_t)m) = make_float2(mean, 1.0f / sqrtf(var + eps));
+}
+extern "C" int sed_ln_fold_stats(const float* rowpart, float* rowstat, int M, int S, int D, float eps, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (M <= 0 || S <= 0 || D <= 0) return SED_ERR_ARG;
+    hipLaunchKernelGGL(ln_fold_stats_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, rowpart, rowstat, M, S, 1.0f / (float)D, eps);
+    return sed_check_launch();
+}
+// Weight side of the fold: W16[n, k] = f16(gamma[k] W[n, k]); colS[n] = sum_k W16[n, k] (of the ROUNDED values: the mean component the
+// GEMM accumulates is then cancelled exactly); colC[n] = sum_k beta[k] W[n, k] + bias[n].  One wave per output row.
+__global__ __launch_bounds__(256) void ln_fold_weight_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ bias,
+                                                             bf16_t* __restrict__ W16, float* __restrict__ colS, float* __restrict__ colC,
+                                                             int N, int K) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float s = 0.f, c = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const float4 w = *reinterpret_cast<const float4*>(W + (size_t)n * K + k), gm = *reinterpret_cast<const float4*>(gamma + k),
+                     bt = *reinterpret_cast<const float4*>(beta + k);
+        const bf16_t h0 = f2h(w.x * gm.x), h1 = f2h(w.y * gm.y), h2 = f2h(w.z * gm.z), h3 = f2h(w.w * gm.w);
+        uint2 pk;
+        pk.x = (unsigned)h0 | ((unsigned)h1 << 16);
+        pk.y = (unsigned)h2 | ((unsigned)h3 << 16);
+        *reinterpret_cast<uint2*>(W16 + (size_t)n * K + k) = pk;
+        s += (h2f(h0) + h2f(h1)) + (h2f(h2) + h2f(h3));
+        c += (bt.x * w.x + bt.y * w.y) + (bt.z * w.z + bt.w * w.w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); c += __shfl_xor(c, o, 64); }
+    if (lane == 0) { colS[n] = s; colC[n] = c + (bias != nullptr ? bias[n] : 0.f); }
+}
+extern "C" int sed_ln_fold_weight(const float* W, const float* gamma, const float* beta, const float* bias, void* W16, float* colS,
+                                  float* colC, int N, int K, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (N <= 0 || K <= 0 || (K % 4)) return SED_ERR_ARG;
+    hipLaunchKernelGGL(ln_fold_weight_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, W, gamma, beta, bias, (bf16_t*)W16, colS, colC, N, K);
     return sed_check_launch();
 }
 

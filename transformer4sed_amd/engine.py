@@ -45,12 +45,13 @@ def rel_pos_table(T, Dm=D):
 
 class _W:
     """bf16 operand images of one fp32 weight matrix [n_out, k_in]."""
-    __slots__ = ("w", "wt", "ws", "wlo", "wlo_key", "w2", "w2_key")
+    __slots__ = ("w", "wt", "ws", "wlo", "wlo_key", "w2", "w2_key", "lnf", "lnf_key")
 
     def __init__(self, w, wt):
         self.w, self.wt, self.ws = w, wt, None
         self.wlo, self.wlo_key = None, None      # f16 image of 2^11 (W - f16(W)) (evaluation-mode mean correction) and what it was built from
         self.w2, self.w2_key = None, None        # two-term image [f16(W) | f16(W - f16(W))] (evaluation-mode encoder)
+        self.lnf, self.lnf_key = None, None      # LayerNorm-folded image (f16(gamma . W), colS, colC) (no-grad encoder passes)
 
 
 class _PoolLease:
@@ -90,6 +91,7 @@ class SedEngine:
         self.dw_side = os.environ.get("SED_DW_STREAM", "1") != "0"
         # rel-pos backward: dK / dV from the dS^T / P^T slabs the dQ kernel stores (streaming kernel) instead of recomputing the scores
         self.relpos_stream = os.environ.get("SED_RELPOS_DKDV", "stream") != "recompute"
+        self.ln_fold = os.environ.get("SED_LN_FOLD", "1") != "0"
         self._dw_stream = None
         self._dw_pending = False
         # Evaluation-mode encoder.  The f16 weight images are the largest single term of the posterior error (tools/err_sim.py: logit
@@ -116,6 +118,21 @@ class SedEngine:
         if getattr(self.m, "lora_r", 0) and not getattr(self.m, "lora_merged", False):
             return False        # PaSST_CNN in train mode: the GEMM operand is W + s B A, not the master the residual image is taken from
         return self.wcorr_all or not self.m.training
+
+    def _lnf_image(self, W, wname, bname, gname, btname):
+        """(f16(gamma (.) W), colS, colC) of a Linear that follows a LayerNorm (sed_ln_fold_weight), cached per weight: rebuilt when
+        any of the four masters changed."""
+        ent = W[wname]
+        ps = [self.P(n) for n in (wname, bname, gname, btname)]
+        key = tuple((p.data_ptr(), p._version) for p in ps) + (getattr(self.m, "_param_generation", 0),)
+        if ent.lnf is None or ent.lnf_key != key or ent.lnf[0].device != ent.w.device:
+            n_out, k_in = ent.w.shape
+            w16 = torch.empty(n_out, k_in, dtype=F16, device=ent.w.device)
+            cs, cc = torch.empty(n_out, device=ent.w.device), torch.empty(n_out, device=ent.w.device)
+            call("sed_ln_fold_weight", ps[0].detach().reshape(n_out, k_in).contiguous(), ps[2].detach(), ps[3].detach(), ps[1].detach(),
+                 w16, cs, cc, n_out, k_in)
+            ent.lnf, ent.lnf_key = (w16, cs, cc), key
+        return ent.lnf
 
     def _w2_image(self, W, name):
         """Two-term f16 image [n_out, 2 k_in] of an fp32 weight, cached per weight like `_wlo_image`."""
@@ -287,6 +304,14 @@ class SedEngine:
         pooled = None
         wc = self._wcorr_on(save) and N >= 128
         w2 = wc and self.wcorr == "exact" and M >= 1024      # (the 256^2 kernel's domain; tiny inputs take the mean correction)
+        # No-grad f16 passes that are not scored (the teacher inside the train step, frozen encoders): LayerNorm folded into the GEMMs around
+        # it -- the residual GEMM writes the f16 image of the new stream + per-row partial sums, the next GEMM consumes the RAW image against
+        # gamma-scaled weights and normalises in its epilogue (csrc/gemm.hip, GemmArgs.rowpart / rowstat).  Two passes over the stream less
+        # per block.  SED_LN_FOLD=0 keeps the LayerNorm kernels.
+        fold = self.ln_fold and not save and not wc and self.act == F16 and M >= 1024 and not getattr(m, "lora_r", 0)
+        if fold:
+            x16f, partf, statf = E(M, D, dt=F16), E(M, D // 64, 2), E(M, 2)
+            have_stat = False       # statistics of the current stream available (false before the first residual GEMM)
         for li in range(m.depth):
             p = f"backbone.blocks.{li}."
             L = {}
@@ -304,8 +329,36 @@ class SedEngine:
                 h16, q, k, v, o16, lse, h2, hpre, act = scratch
                 mean1 = rstd1 = mean2 = rstd2 = None
             x_in = x
-            call("sed_layernorm_fwd", x_in, self.P(p + "norm1.weight"), self.P(p + "norm1.bias"), 1e-6, 1.0, h16, None,
-                 mean1, rstd1, M, D, f16)
+            if not (fold and have_stat):
+                call("sed_layernorm_fwd", x_in, self.P(p + "norm1.weight"), self.P(p + "norm1.bias"), 1e-6, 1.0, h16, None,
+                     mean1, rstd1, M, D, f16)
+            if fold:
+                last = li + 1 == m.depth or (li + 1 == m.passt_feature_layer and not want_frame)
+                if have_stat:
+                    wq, sq, cq = self._lnf_image(W, p + "attn.qkv.weight", p + "attn.qkv.bias", p + "norm1.weight", p + "norm1.bias")
+                    call("sed_gemm_qkv_lnc", x16f, wq, cq, sq, statf, M, D, H, N, Npad, q, k, v)
+                else:       # first block: its LayerNorm ran above (the stream comes from the token assembly, not from a GEMM)
+                    call("sed_gemm_qkv", h16, W[p + "attn.qkv.weight"].w, self.P(p + "attn.qkv.bias"), M, D, H, N, Npad, q, k,
+                         v, None, None, None, None, None, None, None, f16)
+                call("sed_mhsa_fwd", q, k, v, o16, lse, Bx, H, N, Npad, f16)
+                call("sed_gemm_nt_lnp", o16, W[p + "attn.proj.weight"].w, M, D, D, D, D, self.P(p + "attn.proj.bias"), x_in, x_in, x16f,
+                     partf, D)
+                call("sed_ln_fold_stats", partf, statf, M, D // 64, D, 1e-6)
+                w1, s1, c1 = self._lnf_image(W, p + "mlp.fc1.weight", p + "mlp.fc1.bias", p + "norm2.weight", p + "norm2.bias")
+                call("sed_gemm_nt_lnc", x16f, w1, M, 4 * D, D, D, D, c1, s1, statf, act, 4 * D)
+                if last:
+                    gemm_nt(act, W[p + "mlp.fc2.weight"].w, EPI_F32_RESID, bias=self.P(p + "mlp.fc2.bias"), res=x_in, outF=x_in)
+                else:
+                    call("sed_gemm_nt_lnp", act, W[p + "mlp.fc2.weight"].w, M, D, 4 * D, 4 * D, 4 * D, self.P(p + "mlp.fc2.bias"), x_in, x_in,
+                         x16f, partf, D)
+                    call("sed_ln_fold_stats", partf, statf, M, D // 64, D, 1e-6)
+                    have_stat = True
+                x = x_in
+                if li + 1 == m.passt_feature_layer:
+                    pooled = self._fpool_fwd(W, x, Bx, tp, save, ctx)
+                    if not want_frame:
+                        break
+                continue
             if w2:      # evaluation mode: every encoder GEMM against the two-term weight image
                 call("sed_gemm_qkv_w2", h16, self._w2_image(W, p + "attn.qkv.weight"), self.P(p + "attn.qkv.bias"), M, D, H, N, Npad, q, k, v, f16)
                 call("sed_mhsa_fwd", q, k, v, o16, lse, Bx, H, N, Npad, f16)

@@ -115,8 +115,10 @@ class split_precision:
 
 
 def _flops_of(name, args):
-    if name in ("sed_gemm_nt", "sed_gemm_nt_gb", "sed_gemm_nt_w2"):       # (w2: the logical 2 M N K, half of the MFMA FLOPs issued)
+    if name in ("sed_gemm_nt", "sed_gemm_nt_gb", "sed_gemm_nt_w2", "sed_gemm_nt_lnp", "sed_gemm_nt_lnc"):       # (w2: the logical 2 M N K, half of the MFMA FLOPs issued)
         return 2.0 * args[2] * args[3] * args[4]
+    if name == "sed_gemm_qkv_lnc":
+        return 2.0 * args[5] * args[6] * (3 * args[7] * 64)
     if name in ("sed_gemm_qkv", "sed_gemm_qkv_gb", "sed_gemm_qkv_w2"):
         return 2.0 * args[3] * args[4] * (3 * args[5] * 64)
     if name == "sed_gemm_dw_tn":
@@ -132,6 +134,10 @@ def _shape_of(name, args):
         return (args[3], 3 * args[5] * 64, args[4], "qkv3" + name[-2:])
     if name == "sed_gemm_nt_w2":
         return (args[2], args[3], args[4], "epi%dw2" % args[7])
+    if name in ("sed_gemm_nt_lnp", "sed_gemm_nt_lnc"):
+        return (args[2], args[3], args[4], "epi1lnp" if name.endswith("p") else "epi3lnc")
+    if name == "sed_gemm_qkv_lnc":
+        return (args[5], 3 * args[7] * 64, args[6], "qkv3lnc")
     if name == "sed_gemm_qkv":
         return (args[3], 3 * args[5] * 64, args[4], "qkv%d" % sum(a is not None for a in args[8:16]))
     if name == "sed_gemm_dw_tn":
@@ -144,6 +150,15 @@ def _bytes_of(name, args):
     if name in ("sed_gemm_qkv_gb", "sed_gemm_qkv_w2"):
         M, K, D = args[3], args[4], args[5] * 64
         return 2.0 * K * (M + 3 * D * (2 if name.endswith("w2") else 1)) + 2.0 * M * D * 3
+    if name == "sed_gemm_nt_lnp":      # operands + fp32 read-modify-write + the f16 image
+        M, N, K = args[2], args[3], args[4]
+        return 2.0 * K * (M + N) + 10.0 * M * N
+    if name == "sed_gemm_nt_lnc":
+        M, N, K = args[2], args[3], args[4]
+        return 2.0 * K * (M + N) + 2.0 * M * N
+    if name == "sed_gemm_qkv_lnc":
+        M, K, D = args[5], args[6], args[7] * 64
+        return 2.0 * K * (M + 3 * D) + 2.0 * M * D * 3
     if name == "sed_gemm_nt_w2":
         M, N, K, epi = args[2], args[3], args[4], args[7]
         out = {1: 8, 3: 2 * ((args[11] is not None) + (args[12] is not None))}.get(epi, 4)
