@@ -627,6 +627,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
     // mb = first row of this wave's 128 x 64 sub-tile, nb = its first column
     constexpr bool GB = GBM == 1;   // 1: row-group bias, 2: two-term weights (plain epilogue), 3: folded LayerNorm (producer / consumer by EPI)
     constexpr bool LN = GBM == 3;
+    constexpr bool ROWS_ONLY = GBM >= 3;      // head-split epilogue: row-major q / k / v only (3: folded LayerNorm, 4: the plain encoder form)
     const int l15 = lane & 15, lq = lane >> 4;
     if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
 #pragma unroll
@@ -670,7 +671,9 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
         const int which = nb / D, h = (nb - which * D) >> 6;
         bf16_t* row_dst = which == 0 ? g.q : (which == 1 ? g.k : g.v);
         bf16_t* tr_dst = which == 0 ? g.qt : (which == 1 ? g.kt : g.vt);
-        const int npass = (which == 0 && g.q2 != nullptr) ? 2 : 1;
+        // (folded-LayerNorm consumer: inference outputs only -- no second biased q, no transposed copies; compiled out to keep the
+        //  epilogue's registers under the limit: a spilled register reloaded between the tile stores waits for every store before it)
+        const int npass = (!ROWS_ONLY && which == 0 && g.q2 != nullptr) ? 2 : 1;
         for (int pass = 0; pass < npass; ++pass) {
             const float* extra = nullptr;
             if (which == 0 && g.pu != nullptr) extra = (pass == 0 ? g.pu : g.pv) + h * 64;
@@ -714,6 +717,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
                     }
                 }
             }
+            if constexpr (ROWS_ONLY) { __builtin_amdgcn_wave_barrier(); continue; }
             if (td != nullptr && (g.seq & 1) == 0) {
                 // transposed copy [bh][d][seq_pad]: a lane owns a PAIR of consecutive tokens (same clip: seq is even and
                 // the pair starts on an even row) and one of two interleaved d columns -> 4-byte stores, 32 lanes = 128 B
@@ -1336,6 +1340,25 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
                 return sed_check_launch();
             } else {
                 return SED_ERR_ARG;
+            }
+        }
+        if constexpr (EPI == EPI_QKV) {
+            // the encoder's form of the head split -- row-major q / k / v, no biased second q, no transposed copies (its attention kernels
+            // transpose in LDS): a kernel without those paths (mode 4), 3 % faster than carrying them as run-time branches
+            if (g.qt == nullptr && g.kt == nullptr && g.vt == nullptr && g.q2 == nullptr && g.q2t == nullptr && g.pu == nullptr) {
+                static bool attrq[2][2] = {{false, false}, {false, false}};
+#define SED_PP_LAUNCH_Q(F, RBV)                                                                                            \
+                {                                                                                                          \
+                    if (!attrq[F][RBV - 7]) {                                                                              \
+                        (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, F, 4, RBV>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); \
+                        attrq[F][RBV - 7] = true;                                                                          \
+                    }                                                                                                      \
+                    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, F, 4, RBV>), grid3, dim3(512), V3_LDS, s, g);               \
+                }
+                if (f16) { if (use7) SED_PP_LAUNCH_Q(true, 7) else SED_PP_LAUNCH_Q(true, 8) }
+                else { if (use7) SED_PP_LAUNCH_Q(false, 7) else SED_PP_LAUNCH_Q(false, 8) }
+#undef SED_PP_LAUNCH_Q
+                return sed_check_launch();
             }
         }
         static bool attrp[2][2] = {{false, false}, {false, false}};
