@@ -1,7 +1,7 @@
 # Round-end measurement set (run through gpurun): GPU tests, smoke, the full bench line, the other modes, rocprofv3 kernel stats and the
-# PMC passes (separate runs, counters only).  Everything lands in gpurun_out/r3f; the summaries to keep are copied to profiles/ by hand.
-mkdir -p gpurun_out/r3f; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/r3f
+# PMC passes (separate runs, counters only).  Everything lands in gpurun_out/r3h; the summaries to keep are copied to profiles/ by hand.
+mkdir -p gpurun_out/r3h; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r3h
 python -m pytest tests -m gpu -q > $O/gpu_tests.txt 2>&1; grep -E "passed|failed|error" $O/gpu_tests.txt | tail -2
 python __graft_entry__.py smoke > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
 python bench.py > $O/bench_line.json 2> $O/bench_err.txt; cut -c1-200 $O/bench_line.json
