@@ -419,7 +419,10 @@ def main():
                             "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                             "achieved_issued": round(fl_issued / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, 2),
                             "achieved_note": "achieved = algorithmic 2MNK (split-precision GEMMs counted at their logical K); "
-                                             "achieved_issued = MFMA FLOPs actually issued (3x K for the split-precision GEMMs, 2x K for the two-term-weight GEMMs of evaluation passes)",
+                                             "achieved_issued = MFMA FLOPs actually issued (3x K for the split-precision GEMMs, 2x K for the two-term-weight GEMMs of evaluation passes); "
+                                             "the GEMM launches of no-grad encoder passes also carry that block's LayerNorm (row statistics in the residual epilogue, "
+                                             "normalisation in the next GEMM's epilogue; SED_LN_FOLD=0 separates them again): their time counts here, the LayerNorm passes "
+                                             "they replace do not exist any more",
                             "traffic": None if tj is None else tj.get("avg_bytes_per_launch"), "traffic_unit": "HBM bytes per launch",
                             "traffic_source": tsrc, "mfma_pipe_busy": None if mj is None else mj.get("family_busy_fraction"),
                             "mfma_pipe_busy_source": msrc,
