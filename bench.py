@@ -388,7 +388,8 @@ def main():
         what = {"sed_logmel_fwd": "log-mel frontend (wav_absmax + logmel kernels; 1.28 MB read + 0.512 MB written per clip)",
                 "sed_adamw_ema": "fused AdamW + EMA sweeps (28 B / trainable parameter + 8-12 B / EMA parameter)",
                 "sed_layernorm_fwd": "LayerNorm forward (fp32 in -> 16-bit / fp32 out + statistics)",
-                "sed_layernorm_bwd": "LayerNorm backward (dy, x in; dx out / accumulated; gamma / beta gradients)"}
+                "sed_layernorm_bwd": "LayerNorm backward (dy, x in; dx out / accumulated; gamma / beta gradients)",
+                "sed_layernorm_bwd_x16": "LayerNorm backward that also writes the bf16 image of the gradient stream (the next GEMMs' dY operand)"}
         line["roofline_hbm"] = [
             {"kernel": k, "what": what[k], "launches": v["launches"], "bytes": round(v["bytes"]), "us": round(1000 * v["ms"], 1),
              "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "peak_GB/s": PEAK_HBM_GBS,

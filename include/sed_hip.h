@@ -160,6 +160,11 @@ int sed_layernorm_fwd(const float* x, const float* gamma, const float* beta, flo
 int sed_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                       float in_scale, float* dx, int accumulate, float* dgamma, float* dbeta, int M, int D,
                       hipStream_t stream);
+/* the same backward, also writing dx16 [M, D] = bf16 image of the residual-stream gradient it leaves in dx: the dY operand of the
+ * weight-gradient and dX GEMMs of the block below (autograd of timm Block.forward, passt.py:360-363) without a separate cast pass */
+int sed_layernorm_bwd_x16(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                          float in_scale, float* dx, int accumulate, float* dgamma, float* dbeta, void* dx16, int M, int D,
+                          hipStream_t stream);
 /* patch embedding plumbing (passt.py:302-315, 503-569) */
 int sed_im2col(const float* mel, void* cols, int B, int T, int tstart, int tp, int f16, hipStream_t stream);
 int sed_assemble_tokens(const float* conv, const float* cls, const float* dist, const float* new_pos,

@@ -560,6 +560,11 @@ def test_layernorm_fwd_bwd():
         st = torch.empty(M, 768, device=DEV)
         call("sed_layernorm_bwd", dy, x, mu, rs, g, in_scale, st, 0, None, None, M, 768)
         assert maxerr(st, xx.grad) < 1e-4 * sc + 1e-5
+        # the variant that also leaves the bf16 image of the stream it updated: same dx bits, image == bf16(dx)
+        acc2 = base.clone(); dx16 = torch.empty(M, 768, dtype=BF16, device=DEV)
+        dg2 = torch.zeros(768, device=DEV); db2 = torch.zeros(768, device=DEV)
+        call("sed_layernorm_bwd_x16", dy, x, mu, rs, g, in_scale, acc2, 1, dg2, db2, dx16, M, 768)
+        assert torch.equal(acc2, acc) and torch.equal(dx16, acc.to(BF16))
 
 
 def test_patch_tokens_fpool_interp():

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma, float in_scale,
                                                             float* __restrict__ dx_acc, int accumulate,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
-                                                            float dy_scale) {
+                                                            float dy_scale, bf16_t* __restrict__ dx16 = nullptr) {
     __shared__ float red[4][DM];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     Row g, pg, pb;
@@ -189,6 +189,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             f4(o.v[i], c) = accumulate ? f4(o.v[i], c) + v : v;
         }
         row_store_nt(o, out, lane);
+        // bf16 image of the updated residual-stream gradient: the dY operand of the weight-gradient / dX GEMMs of the block below
+        if (dx16 != nullptr) row_store_bf16(o, dx16 + (size_t)row * DM, lane, 0);
     }
     if (dgamma == nullptr) return;
 #pragma unroll
@@ -212,7 +214,19 @@ extern "C" int sed_layernorm_bwd(const float* dy, const float* x, const float* m
     int blocks = cdiv(M, 4);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, stream, dy, x, mean, rstd, gamma, in_scale, dx,
-                       accumulate, dgamma, dbeta, M, 1.0f);
+                       accumulate, dgamma, dbeta, M, 1.0f, (bf16_t*)nullptr);
+    return sed_check_launch();
+}
+// the same backward that also writes dx16 [M, D] = bf16 image of the dx it leaves in `dx` (after the accumulation)
+extern "C" int sed_layernorm_bwd_x16(const float* dy, const float* x, const float* mean, const float* rstd,
+                                     const float* gamma, float in_scale, float* dx, int accumulate, float* dgamma,
+                                     float* dbeta, void* dx16, int M, int D, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (D != DM || M <= 0 || dx16 == nullptr) return SED_ERR_ARG;
+    int blocks = cdiv(M, 4);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, stream, dy, x, mean, rstd, gamma, in_scale, dx,
+                       accumulate, dgamma, dbeta, M, 1.0f, (bf16_t*)dx16);
     return sed_check_launch();
 }
 

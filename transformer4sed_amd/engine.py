@@ -92,6 +92,8 @@ class SedEngine:
         # rel-pos backward: dK / dV from the dS^T / P^T slabs the dQ kernel stores (streaming kernel) instead of recomputing the scores
         self.relpos_stream = os.environ.get("SED_RELPOS_DKDV", "stream") != "recompute"
         self.ln_fold = os.environ.get("SED_LN_FOLD", "1") != "0"
+        self.ln_bwd16 = os.environ.get("SED_LN_BWD16", "1") != "0"
+        self._genc16 = None
         self._dw_stream = None
         self._dw_pending = False
         # Evaluation-mode encoder.  The f16 weight images are the largest single term of the posterior error (tools/err_sim.py: logit
@@ -818,12 +820,20 @@ class SedEngine:
         if hook is not None:
             hook("embed")
 
-    def _dw_accum(self, dy, x, M, gW, bias=None):
+    def _g16_take(self, g):
+        """bf16 image of the residual-stream gradient `g` if the LayerNorm backward that last wrote `g` left one (and nobody touched `g`
+        through torch since); consumed by the call."""
+        t, self._genc16 = getattr(self, "_genc16", None), None
+        return t[1] if (t is not None and t[0] is g and t[2] == g._version) else None
+
+    def _dw_accum(self, dy, x, M, gW, bias=None, dy16=None):
         """gW += dy^T x (weight gradient), bias += column sums of dy.  dy [M, n_out] f32 or bf16, x [M, k_in] (saved forward
         operand, 16-bit or f32); gW / bias are arena views or None.  Returns dy as a bf16 [M, n_out] tensor (operand of the
         dX GEMM that follows).  TN kernel on the operands as they lie when the shapes allow it (tokens % 64, features % 256);
         otherwise transposed copies + the NT split-K kernel."""
         dev = dy.device
+        if dy16 is not None:      # the producer of dy already wrote its bf16 image (sed_layernorm_bwd_x16): no cast pass, bias sums in the TN kernel
+            dy = dy16
         n_out, ldx = dy.shape[1], x.shape[1]
         # a saved split-precision image [M, 3 k_in] = [hi | lo | hi] (context network, MLM head) serves as the f16 operand through its
         # first third: the weight gradient sees the activation at the precision the encoder's gradients see theirs
@@ -878,7 +888,7 @@ class SedEngine:
             gemm_dw(gT, xT, gW)
         return g16 if g16 is not None else dy
 
-    def _mlp_bwd(self, W, n1, n2, dy, x16, hpre, act, M, G, residual):
+    def _mlp_bwd(self, W, n1, n2, dy, x16, hpre, act, M, G, residual, dy16=None):
         """Backward of y = fc2(gelu(fc1(x))) given dy [M, n_out] f32.  Returns dx f32 [M, D] (new tensor), or adds
         into `residual` (f32 [M, D]) when given.  Weight/bias grads go to the arena when trainable."""
         dev = dy.device
@@ -889,7 +899,7 @@ class SedEngine:
         n_out = w2.w.shape[0]
         train = G(n1 + ".weight") is not None
         hpre = to_bf16_(hpre)
-        g16 = self._dw_accum(dy, act, M, G(n2 + ".weight") if train else None, G(n2 + ".bias") if train else None)
+        g16 = self._dw_accum(dy, act, M, G(n2 + ".weight") if train else None, G(n2 + ".bias") if train else None, dy16=dy16)
         dh16 = E(M, hid, dt=BF16)
         gemm_nt(g16, w2.wt, EPI_DGELU, outH=dh16, aux=hpre)
         if train:
@@ -910,13 +920,22 @@ class SedEngine:
         dev = g.device
         E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
         g2 = g.view(M, D)
+        # The LayerNorm backward kernels leave the bf16 image of the residual-stream gradient they just updated: it is the dY operand of the
+        # next weight-gradient / dX GEMMs (no cast pass over the fp32 stream; the bias gradient comes out of the TN kernel).  SED_LN_BWD16=0 off.
+        x16_on = self.ln_bwd16 and self.dw_tn
+        gin16 = self._g16_take(g)
         # ---- MLP branch: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
-        dln = self._mlp_bwd(W, p + "mlp.fc1", p + "mlp.fc2", g2, L["h2"], L["hpre"], L["act"], M, G, residual=None)
-        call("sed_layernorm_bwd", dln, L["x_mid"], L["mean2"], L["rstd2"], self.P(p + "norm2.weight"), 1.0, g2, 1,
-             G(p + "norm2.weight"), G(p + "norm2.bias"), M, D)
+        dln = self._mlp_bwd(W, p + "mlp.fc1", p + "mlp.fc2", g2, L["h2"], L["hpre"], L["act"], M, G, residual=None, dy16=gin16)
+        gmid16 = E(M, D, dt=BF16) if x16_on else None
+        if gmid16 is not None:
+            call("sed_layernorm_bwd_x16", dln, L["x_mid"], L["mean2"], L["rstd2"], self.P(p + "norm2.weight"), 1.0, g2, 1,
+                 G(p + "norm2.weight"), G(p + "norm2.bias"), gmid16, M, D)
+        else:
+            call("sed_layernorm_bwd", dln, L["x_mid"], L["mean2"], L["rstd2"], self.P(p + "norm2.weight"), 1.0, g2, 1,
+                 G(p + "norm2.weight"), G(p + "norm2.bias"), M, D)
         del dln
         # ---- attention branch: x_mid = x_in + proj(attn(LN1(x_in)))
-        g16 = self._dw_accum(g2, L["o16"], M, G(p + "attn.proj.weight"), G(p + "attn.proj.bias"))
+        g16 = self._dw_accum(g2, L["o16"], M, G(p + "attn.proj.weight"), G(p + "attn.proj.bias"), dy16=gmid16)
         do16 = E(M, D, dt=BF16)
         gemm_nt(g16, W[p + "attn.proj.weight"].wt, EPI_BF16, outH=do16)
         dqkv = E(M, 3 * D, dt=BF16)
@@ -927,8 +946,14 @@ class SedEngine:
         self._dw_accum(dqkv, L["h16"], M, G(p + "attn.qkv.weight"), G(p + "attn.qkv.bias"))
         dln = E(M, D)
         gemm_nt(dqkv, W[p + "attn.qkv.weight"].wt, EPI_F32, outF=dln)
-        call("sed_layernorm_bwd", dln, L["x_in"], L["mean1"], L["rstd1"], self.P(p + "norm1.weight"), 1.0, g2, 1,
-             G(p + "norm1.weight"), G(p + "norm1.bias"), M, D)
+        gout16 = E(M, D, dt=BF16) if x16_on else None
+        if gout16 is not None:
+            call("sed_layernorm_bwd_x16", dln, L["x_in"], L["mean1"], L["rstd1"], self.P(p + "norm1.weight"), 1.0, g2, 1,
+                 G(p + "norm1.weight"), G(p + "norm1.bias"), gout16, M, D)
+            self._genc16 = (g, gout16, g._version)      # for the block below (`_g16_take`)
+        else:
+            call("sed_layernorm_bwd", dln, L["x_in"], L["mean1"], L["rstd1"], self.P(p + "norm1.weight"), 1.0, g2, 1,
+                 G(p + "norm1.weight"), G(p + "norm1.bias"), M, D)
         ectx["layers"][li] = None  # free saved activations
         return g
 

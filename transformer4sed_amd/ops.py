@@ -191,10 +191,13 @@ def _hbm_bytes_of(name, args):
     if name == "sed_layernorm_bwd":              # (dy, x, mean, rstd, gamma, scale, dx, accumulate, dgamma, dbeta, M, D)
         M, D = args[10], args[11]
         return float(M) * (D * (12 + (4 if args[7] else 0)) + 8)
+    if name == "sed_layernorm_bwd_x16":          # (..., dbeta, dx16, M, D): + the bf16 image
+        M, D = args[11], args[12]
+        return float(M) * (D * (14 + (4 if args[7] else 0)) + 8)
     return 0.0
 
 
-HBM_KERNELS = ("sed_logmel_fwd", "sed_adamw_ema", "sed_layernorm_fwd", "sed_layernorm_bwd")
+HBM_KERNELS = ("sed_logmel_fwd", "sed_adamw_ema", "sed_layernorm_fwd", "sed_layernorm_bwd", "sed_layernorm_bwd_x16")
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # the current stream's handle without building a Stream object
 
