@@ -720,21 +720,48 @@ extern "C" int sed_fpool_attn_bwd(const void* kv, const float* q, const float* p
 }
 
 // LoRA gradients from the gradient of the merged weight (dW [n_out, k_in] fp32):  dB += s dW A^T  [n_out, r],
-// dA += s B^T dW  [r, k_in]   (r <= 16).  grid.y 0: one wave per row of dW (dB); grid.y 1: one thread per column (dA), row slabs.
+// dA += s B^T dW  [r, k_in]   (r <= 16).  grid.y 0: one wave per row of dW (dB); grid.y 1: one thread per column (dA), 32-row slabs.
 __global__ __launch_bounds__(256) void lora_grad_kernel(const float* __restrict__ dW, const float* __restrict__ A,
                                                         const float* __restrict__ Bm, float s, float* __restrict__ dA,
                                                         float* __restrict__ dB, int n_out, int k_in, int r) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (blockIdx.y == 0) {
-        for (int n = blockIdx.x * 4 + wave; n < n_out; n += gridDim.x * 4) {
+        // dB: one wave per row of dW; the row's loads are issued eight at a time (both halves of this kernel were latency-bound loops of
+        // dependent loads: 86 us per launch in the step for 2-9 MB of dW)
+        // (wide rows, k_in > 1024: the four waves of a block share ONE row, a quarter of its columns each)
+        __shared__ float part[4][16];
+        const bool wide = k_in > 1024;
+        const int kq = wide ? ((k_in / 4 + 63) / 64) * 64 : k_in, kb = wide ? wave * kq : 0, ke = wide ? (kb + kq < k_in ? kb + kq : k_in) : k_in;
+        for (int n = wide ? blockIdx.x : blockIdx.x * 4 + wave; n < n_out; n += wide ? gridDim.x : gridDim.x * 4) {
             float acc[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-            for (int k = lane; k < k_in; k += 64) {
-                const float g = dW[(size_t)n * k_in + k];
+            const float* row = dW + (size_t)n * k_in;
+            for (int k0 = kb; k0 < ke; k0 += 512) {
+                float g[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int k = k0 + 64 * u + lane; g[u] = k < ke ? row[k] : 0.f; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + 64 * u + lane;
+                    if (k < ke) {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j)
+                            if (j < r) acc[j] = fmaf(g[u], A[(size_t)j * k_in + k], acc[j]);
+                    }
+                }
+            }
+            if (wide) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
-                    if (j < r) acc[j] = fmaf(g, A[(size_t)j * k_in + k], acc[j]);
+                    if (j < r) {
+                        const float v = wave_sum(acc[j]);
+                        if (lane == 0) part[wave][j] = v;
+                    }
+                __syncthreads();
+                if (threadIdx.x < r) dB[(size_t)n * r + threadIdx.x] += s * (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+                __syncthreads();
+                continue;
             }
 #pragma unroll
             for (int j = 0; j < 16; ++j)
@@ -744,29 +771,38 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const float* __restrict_
                 }
         }
     } else {
-        const int slabs = gridDim.x, rows_per = (n_out + slabs - 1) / slabs;
-        const int n0 = blockIdx.x * rows_per, n1 = n0 + rows_per < n_out ? n0 + rows_per : n_out;
-        for (int k = threadIdx.x; k < k_in; k += 256) {
-            float acc[16];
+        // dA: block = (slab of 32 dW rows, 256 columns); a thread owns one column, walks the slab's rows eight loads at a time (coalesced
+        // across the block) and adds its r partial sums with one atomic each
+        const int cblocks = (k_in + 255) / 256;
+        const int slab = blockIdx.x / cblocks, k = (blockIdx.x - slab * cblocks) * 256 + threadIdx.x;
+        const int n0 = slab * 32;
+        if (k >= k_in || n0 >= n_out) return;
+        float acc[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-            for (int n = n0; n < n1; ++n) {
-                const float g = dW[(size_t)n * k_in + k];
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        for (int nn = n0; nn < n0 + 32; nn += 8) {
+            float g[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g[u] = nn + u < n_out ? dW[(size_t)(nn + u) * k_in + k] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int n = nn + u < n_out ? nn + u : n_out - 1;
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
-                    if (j < r) acc[j] = fmaf(g, Bm[(size_t)n * r + j], acc[j]);
+                    if (j < r) acc[j] = fmaf(g[u], Bm[(size_t)n * r + j], acc[j]);
             }
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (j < r) unsafeAtomicAdd(&dA[(size_t)j * k_in + k], s * acc[j]);
         }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < r) unsafeAtomicAdd(&dA[(size_t)j * k_in + k], s * acc[j]);
     }
 }
 extern "C" int sed_lora_grad(const float* dW, const float* A, const float* Bm, float scaling, float* dA, float* dB, int n_out,
                              int k_in, int r, hipStream_t stream) {
     (void)hipGetLastError();
     if (n_out <= 0 || k_in <= 0 || r <= 0 || r > 16) return SED_ERR_ARG;
-    hipLaunchKernelGGL(lora_grad_kernel, dim3(256, 2), dim3(256), 0, stream, dW, A, Bm, scaling, dA, dB, n_out, k_in, r);
+    const int nb_a = ((n_out + 31) / 32) * ((k_in + 255) / 256), nb_b = k_in > 1024 ? n_out : (n_out + 3) / 4;
+    hipLaunchKernelGGL(lora_grad_kernel, dim3(nb_a > nb_b ? nb_a : nb_b, 2), dim3(256), 0, stream, dW, A, Bm, scaling, dA, dB, n_out, k_in, r);
     return sed_check_launch();
 }
 
