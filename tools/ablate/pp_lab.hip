@@ -543,6 +543,148 @@ __global__ void gather_kernel(const bf16_t* C, const int* mm, const int* nn, flo
     if (s < ns) out[s] = h2f(C[(size_t)mm[s] * N + nn[s]]);
 }
 
+
+// ---- "quad": ONE 4-wave workgroup per CU, wave tile 128 x 128 (8 x 8 blocks of 16 x 16: 256 accumulator registers), one wave per SIMD
+// with the 512-register budget.  Per 64-deep K tile a wave reads 32 fragments (16 per 32-deep k-step) for 128 MFMAs -- two thirds of
+// the LDS fragment traffic of the 8-wave kernel per FLOP.  Single-stream software pipeline: fragments of step s + 1 are read while the
+// MFMAs of step s issue; tile t + 1 is DMA'd while tile t is consumed; two workgroup barriers per K tile.
+template <int ABL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void quad_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                                                          bf16_t* __restrict__ C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = N / T256, ntm = (M + T256 - 1) / T256, nwg = ntm * ntn;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int group_size = 4 * ntn, gid = t / group_size, first_m = gid * 4;
+    const int gm = (ntm - first_m) < 4 ? (ntm - first_m) : 4;
+    const int tin = t - gid * group_size;
+    const int m0 = (first_m + tin % gm) * T256, n0 = (tin / gm) * T256;
+    const int nk = K / BK;
+    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = wall_clock64();
+    const int rows_a = (M - m0) < T256 ? (M - m0) : T256;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * K), 0, rows_a * K * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(B + (size_t)n0 * K), 0, T256 * K * 2, 0x00020000);
+    // DMA: 32 A pieces + 32 B pieces of 8 rows per K tile; wave w fetches A pieces 8 w .. 8 w + 7 and B pieces 8 w .. 8 w + 7
+    const int prow = lane >> 3, pch = lane & 7;
+    int voa[8], vob[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int row = (8 * wave + e) * 8 + prow;
+        const int cl = pch ^ ((row >> 1) & 7);
+        voa[e] = row * K * 2 + cl * 16;
+        vob[e] = row * K * 2 + cl * 16;
+    }
+#define QD_DMA(KT)                                                                                                        \
+    {                                                                                                                     \
+        const int so_ = (KT) * (BK * 2), st_ = ((KT) & 1) << 15;                                                          \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                                   \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(lds3 + st_ + (8 * wave + e) * 1024), 16, voa[e], so_, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(lds3 + 65536 + st_ + (8 * wave + e) * 1024), 16, vob[e], so_, 0, 0); \
+        }                                                                                                                 \
+    }
+    f32x4v acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const int l15 = lane & 15, lq = lane >> 4, sw = (l15 >> 1) & 7;
+    // fragment (block b of 16 rows, k-step ks): row 16 b + l15, 16-byte chunk (4 ks + lq) ^ sw
+    const unsigned lbase = (unsigned)(size_t)lds3;
+    unsigned aaddr[2], baddr[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int c = ((4 * ks + lq) ^ sw) << 4;
+        aaddr[ks] = lbase + wm * 16384 + l15 * 128 + c;
+        baddr[ks] = lbase + 65536 + wn * 16384 + l15 * 128 + c;
+    }
+    f16x8_t fa[2][8], fb[2][8];      // [register set][block]
+    // LDS reads as asm (the compiler's own wait insertion would serialise the sets at the loop back edge); explicit waits + ties
+#define QD_RD1(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+#define QD_READ(SET, KS, STG)                                                                                             \
+    {                                                                                                                     \
+        QD_RD1(fa[SET][0], aaddr[KS], ((STG) << 15) + 0 * 2048); QD_RD1(fb[SET][0], baddr[KS], ((STG) << 15) + 0 * 2048); \
+        QD_RD1(fa[SET][1], aaddr[KS], ((STG) << 15) + 1 * 2048); QD_RD1(fb[SET][1], baddr[KS], ((STG) << 15) + 1 * 2048); \
+        QD_RD1(fa[SET][2], aaddr[KS], ((STG) << 15) + 2 * 2048); QD_RD1(fb[SET][2], baddr[KS], ((STG) << 15) + 2 * 2048); \
+        QD_RD1(fa[SET][3], aaddr[KS], ((STG) << 15) + 3 * 2048); QD_RD1(fb[SET][3], baddr[KS], ((STG) << 15) + 3 * 2048); \
+        QD_RD1(fa[SET][4], aaddr[KS], ((STG) << 15) + 4 * 2048); QD_RD1(fb[SET][4], baddr[KS], ((STG) << 15) + 4 * 2048); \
+        QD_RD1(fa[SET][5], aaddr[KS], ((STG) << 15) + 5 * 2048); QD_RD1(fb[SET][5], baddr[KS], ((STG) << 15) + 5 * 2048); \
+        QD_RD1(fa[SET][6], aaddr[KS], ((STG) << 15) + 6 * 2048); QD_RD1(fb[SET][6], baddr[KS], ((STG) << 15) + 6 * 2048); \
+        QD_RD1(fa[SET][7], aaddr[KS], ((STG) << 15) + 7 * 2048); QD_RD1(fb[SET][7], baddr[KS], ((STG) << 15) + 7 * 2048); \
+    }
+#define QD_TIE(SET)                                                                                                       \
+    asm volatile("" : "+v"(fa[SET][0]), "+v"(fa[SET][1]), "+v"(fa[SET][2]), "+v"(fa[SET][3]), "+v"(fa[SET][4]), "+v"(fa[SET][5]), \
+                      "+v"(fa[SET][6]), "+v"(fa[SET][7]), "+v"(fb[SET][0]), "+v"(fb[SET][1]), "+v"(fb[SET][2]), "+v"(fb[SET][3]), \
+                      "+v"(fb[SET][4]), "+v"(fb[SET][5]), "+v"(fb[SET][6]), "+v"(fb[SET][7]) :: "memory");
+#define QD_MFMA(SET)                                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                     \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[SET][j], fa[SET][i], acc[i][j], 0, 0, 0);
+    // one K tile whose operands sit in stage STG (compile-time): set 0 holds its k-step 0 on entry.  Memory instructions are sprinkled
+    // between the rows of MFMAs (8 per row, 128 matrix-pipe cycles): a lone wave per SIMD issues in order, so a block of 16 reads /
+    // 16 DMA instructions in front of a batch would idle the pipe for their whole issue time.  Reads end two rows before the batch
+    // that consumes them.  Tiles past the end are fetched out of the buffer's range (zeros) and never consumed: no branches.
+#define QD_TILE(T_, STG) \
+    { \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); QD_TIE(0) __builtin_amdgcn_sched_barrier(0); \
+    QD_RD1(fb[1][0], baddr[1], ((STG) << 15) + 0 * 2048); QD_RD1(fb[1][1], baddr[1], ((STG) << 15) + 1 * 2048); QD_RD1(fb[1][2], baddr[1], ((STG) << 15) + 2 * 2048); __builtin_amdgcn_sched_barrier(0); \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[0][j]) : "v"(fb[0][j]), "v"(fa[0][0])); __builtin_amdgcn_sched_barrier(0); \
+    QD_RD1(fb[1][3], baddr[1], ((STG) << 15) + 3 * 2048); QD_RD1(fb[1][4], baddr[1], ((STG) << 15) + 4 * 2048); QD_RD1(fb[1][5], baddr[1], ((STG) << 15) + 5 * 2048); __builtin_amdgcn_sched_barrier(0); \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[1][j]) : "v"(fb[0][j]), "v"(fa[0][1])); __builtin_amdgcn_sched_barrier(0); \
+    QD_RD1(fb[1][6], baddr[1], ((STG) << 15) + 6 * 2048); QD_RD1(fb[1][7], baddr[1], ((STG) << 15) + 7 * 2048); QD_RD1(fa[1][0], aaddr[1], ((STG) << 15) + 0 * 2048); __builtin_amdgcn_sched_barrier(0); \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[2][j]) : "v"(fb[0][j]), "v"(fa[0][2])); __builtin_amdgcn_sched_barrier(0); \
+    QD_RD1(fa[1][1], aaddr[1], ((STG) << 15) + 1 * 2048); QD_RD1(fa[1][2], aaddr[1], ((STG) << 15) + 2 * 2048); QD_RD1(fa[1][3], aaddr[1], ((STG) << 15) + 3 * 2048); __builtin_amdgcn_sched_barrier(0); \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[3][j]) : "v"(fb[0][j]), "v"(fa[0][3])); __builtin_amdgcn_sched_barrier(0); \
+    QD_RD1(fa[1][4], aaddr[1], ((STG) << 15) + 4 * 2048); QD_RD1(fa[1][5], aaddr[1], ((STG) << 15) + 5 * 2048); __builtin_amdgcn_sched_barrier(0); \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[4][j]) : "v"(fb[0][j]), "v"(fa[0][4])); __builtin_amdgcn_sched_barrier(0); \
+    QD_RD1(fa[1][6], aaddr[1], ((STG) << 15) + 6 * 2048); QD_RD1(fa[1][7], aaddr[1], ((STG) << 15) + 7 * 2048); __builtin_amdgcn_sched_barrier(0); \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[5][j]) : "v"(fb[0][j]), "v"(fa[0][5])); __builtin_amdgcn_sched_barrier(0); \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[6][j]) : "v"(fb[0][j]), "v"(fa[0][6])); __builtin_amdgcn_sched_barrier(0); \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[7][j]) : "v"(fb[0][j]), "v"(fa[0][7])); __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); QD_TIE(1) __builtin_amdgcn_sched_barrier(0); \
+    const int so2_ = ((T_) + 2) * (BK * 2), st2_ = (STG) << 15; \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[0][j]) : "v"(fb[1][j]), "v"(fa[1][0])); __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); \
+    QD_RD1(fb[0][0], baddr[0], (((STG) ^ 1) << 15) + 0 * 2048); QD_RD1(fb[0][1], baddr[0], (((STG) ^ 1) << 15) + 1 * 2048); QD_RD1(fb[0][2], baddr[0], (((STG) ^ 1) << 15) + 2 * 2048); __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(lds3 + st2_ + (8 * wave + 0) * 1024), 16, voa[0], so2_, 0, 0); __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(lds3 + st2_ + (8 * wave + 1) * 1024), 16, voa[1], so2_, 0, 0); __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(lds3 + st2_ + (8 * wave + 2) * 1024), 16, voa[2], so2_, 0, 0); __builtin_amdgcn_sched_barrier(0); \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[1][j]) : "v"(fb[1][j]), "v"(fa[1][1])); __builtin_amdgcn_sched_barrier(0); \
+    QD_RD1(fb[0][3], baddr[0], (((STG) ^ 1) << 15) + 3 * 2048); QD_RD1(fb[0][4], baddr[0], (((STG) ^ 1) << 15) + 4 * 2048); QD_RD1(fb[0][5], baddr[0], (((STG) ^ 1) << 15) + 5 * 2048); __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(lds3 + st2_ + (8 * wave + 3) * 1024), 16, voa[3], so2_, 0, 0); __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(lds3 + st2_ + (8 * wave + 4) * 1024), 16, voa[4], so2_, 0, 0); __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(lds3 + st2_ + (8 * wave + 5) * 1024), 16, voa[5], so2_, 0, 0); __builtin_amdgcn_sched_barrier(0); \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[2][j]) : "v"(fb[1][j]), "v"(fa[1][2])); __builtin_amdgcn_sched_barrier(0); \
+    QD_RD1(fb[0][6], baddr[0], (((STG) ^ 1) << 15) + 6 * 2048); QD_RD1(fb[0][7], baddr[0], (((STG) ^ 1) << 15) + 7 * 2048); QD_RD1(fa[0][0], aaddr[0], (((STG) ^ 1) << 15) + 0 * 2048); __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(lds3 + st2_ + (8 * wave + 6) * 1024), 16, voa[6], so2_, 0, 0); __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(lds3 + st2_ + (8 * wave + 7) * 1024), 16, voa[7], so2_, 0, 0); __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(lds3 + 65536 + st2_ + (8 * wave + 0) * 1024), 16, vob[0], so2_, 0, 0); __builtin_amdgcn_sched_barrier(0); \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[3][j]) : "v"(fb[1][j]), "v"(fa[1][3])); __builtin_amdgcn_sched_barrier(0); \
+    QD_RD1(fa[0][1], aaddr[0], (((STG) ^ 1) << 15) + 1 * 2048); QD_RD1(fa[0][2], aaddr[0], (((STG) ^ 1) << 15) + 2 * 2048); QD_RD1(fa[0][3], aaddr[0], (((STG) ^ 1) << 15) + 3 * 2048); __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(lds3 + 65536 + st2_ + (8 * wave + 1) * 1024), 16, vob[1], so2_, 0, 0); __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(lds3 + 65536 + st2_ + (8 * wave + 2) * 1024), 16, vob[2], so2_, 0, 0); __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(lds3 + 65536 + st2_ + (8 * wave + 3) * 1024), 16, vob[3], so2_, 0, 0); __builtin_amdgcn_sched_barrier(0); \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[4][j]) : "v"(fb[1][j]), "v"(fa[1][4])); __builtin_amdgcn_sched_barrier(0); \
+    QD_RD1(fa[0][4], aaddr[0], (((STG) ^ 1) << 15) + 4 * 2048); QD_RD1(fa[0][5], aaddr[0], (((STG) ^ 1) << 15) + 5 * 2048); __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(lds3 + 65536 + st2_ + (8 * wave + 4) * 1024), 16, vob[4], so2_, 0, 0); __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(lds3 + 65536 + st2_ + (8 * wave + 5) * 1024), 16, vob[5], so2_, 0, 0); __builtin_amdgcn_sched_barrier(0); \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[5][j]) : "v"(fb[1][j]), "v"(fa[1][5])); __builtin_amdgcn_sched_barrier(0); \
+    QD_RD1(fa[0][6], aaddr[0], (((STG) ^ 1) << 15) + 6 * 2048); QD_RD1(fa[0][7], aaddr[0], (((STG) ^ 1) << 15) + 7 * 2048); __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(lds3 + 65536 + st2_ + (8 * wave + 6) * 1024), 16, vob[6], so2_, 0, 0); __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(lds3 + 65536 + st2_ + (8 * wave + 7) * 1024), 16, vob[7], so2_, 0, 0); __builtin_amdgcn_sched_barrier(0); \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[6][j]) : "v"(fb[1][j]), "v"(fa[1][6])); __builtin_amdgcn_sched_barrier(0); \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[7][j]) : "v"(fb[1][j]), "v"(fa[1][7])); __builtin_amdgcn_sched_barrier(0); \
+    }
+    QD_DMA(0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (nk > 1) QD_DMA(1)
+    QD_READ(0, 0, 0)
+    for (int it = 0; it < nk; it += 2) {       // (nk even)
+        QD_TILE(it, 0)
+        QD_TILE(it + 1, 1)
+    }
+    if (blockIdx.x == 17 && tid == 0) { g_clk[0] = __builtin_readcyclecounter() - clk0; g_clk[1] = wall_clock64() - rt0; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wm * 128 + i * 16 + l15;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int n = n0 + wn * 128 + j * 16 + 4 * lq;
+            uint2 pk;
+            pk.x = pack2<true>(acc[i][j][0], acc[i][j][1]);
+            pk.y = pack2<true>(acc[i][j][2], acc[i][j][3]);
+            *reinterpret_cast<uint2*>(C + (size_t)m * N + n) = pk;
+        }
+    }
+}
+
 typedef void (*kern_t)(const bf16_t*, const bf16_t*, bf16_t*, int, int, int);
 struct Variant { const char* name; kern_t k; bool check; int threads = 512; int lds = LDS_BYTES; int tm = 256; };
 
@@ -558,6 +700,7 @@ int main(int argc, char** argv) {
         {"S1 with mfma 16x16x32 noprio  ", pp16_kernel<0, false>, true},
         {"S1/16x16 ABL noDMA            ", pp16_kernel<1, true>, false},
         {"S1/16x16 ABL noDMA noRD       ", pp16_kernel<3, true>, false},
+        {"QUAD 4 waves x 128x128, 512 reg", quad_kernel<0>, true, 256, LDS_BYTES, 256},
         {"DUAL 2x(4 waves,128x256,BK32) ", dual_kernel<0>, true, 256, D_LDS, 128},
         {"DUAL + 10k-cycle fake epilogue", dual_kernel<10>, true, 256, D_LDS, 128},
         {"S2 half 16/8 prio prewait     ", pp_kernel<2, 0, true, true>, true},
