@@ -414,21 +414,21 @@ __device__ __forceinline__ void pp_stage16_gb(unsigned char* wl, const f32x4_t (
 // LayerNorm-folded staging: x = rstd[row] * (acc - mean[row] * sv[col]) + bv[col]  (rows mb + 16 i + l15, statistics clipped to the last row)
 // (BVP: the column constants are fetched per 16-column block from `bias_n` instead of living in 16 registers -- the head-split epilogue
 //  has no room for them beside the accumulators)
-template <bool F16, int MODE, bool BVP = false>
+template <bool F16, int MODE, bool BVP = false, int RB = 8>
 __device__ __forceinline__ void pp_stage16_ln(unsigned char* wl, const f32x4_t (&acc)[8][4], const float (&bv)[4][4], const float* colS_n,
                                               const float* rowstat, int mb, int M, int l15, int lq, const float* bias_n = nullptr) {
     // every global load of the epilogue is issued up front (8 row statistics, 4 + 4 column vectors): one exposed round trip instead of
     // one per 16-column block -- the K loop's fragment registers are free by now
     float2 st[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < RB; ++i) {
         const int m = mb + i * 16 + l15;
         st[i] = *reinterpret_cast<const float2*>(rowstat + 2 * (size_t)(m < M ? m : M - 1));
     }
     if constexpr (BVP) {      // head-split epilogue (tight on registers): column vectors one 16-column block ahead, blocks outermost
         float rs[8], tm[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { rs[i] = st[i].y; tm[i] = -st[i].x * st[i].y; }
+        for (int i = 0; i < RB; ++i) { rs[i] = st[i].y; tm[i] = -st[i].x * st[i].y; }
         float4 sn = *reinterpret_cast<const float4*>(colS_n + 4 * lq), bn = *reinterpret_cast<const float4*>(bias_n + 4 * lq);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -438,7 +438,7 @@ __device__ __forceinline__ void pp_stage16_ln(unsigned char* wl, const f32x4_t (
                 bn = *reinterpret_cast<const float4*>(bias_n + (j + 1) * 16 + 4 * lq);
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < RB; ++i) {
                 uint2 pk;
                 pk.x = pack2<F16>(__builtin_fmaf(acc[i][j][0], rs[i], __builtin_fmaf(tm[i], sc.x, bc.x)),
                                   __builtin_fmaf(acc[i][j][1], rs[i], __builtin_fmaf(tm[i], sc.y, bc.y)));
@@ -456,7 +456,7 @@ __device__ __forceinline__ void pp_stage16_ln(unsigned char* wl, const f32x4_t (
         b4[j] = make_float4(bv[j][0], bv[j][1], bv[j][2], bv[j][3]);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < RB; ++i) {
         const float rs = st[i].y, tm = -st[i].x * st[i].y;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -640,8 +640,8 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
                 if (EPI == EPI_GELU && pass == 1) pp_stage16_gb<F16, 1>(wl, acc, cc.bv, rA + nb, rB + nb, bnd, l15, lq);
                 else pp_stage16_gb<F16, 0>(wl, acc, cc.bv, rA + nb, rB + nb, bnd, l15, lq);
             } else if constexpr (LN) {      // consumer: Linear(LayerNorm(x)) from the raw stream's product (no saved pre-activation either)
-                if (EPI == EPI_GELU && pass == 1) pp_stage16_ln<F16, 1>(wl, acc, cc.bv, g.colS + nb, g.rowstat, mb, g.M, l15, lq);
-                else pp_stage16_ln<F16, 0>(wl, acc, cc.bv, g.colS + nb, g.rowstat, mb, g.M, l15, lq);
+                if (EPI == EPI_GELU && pass == 1) pp_stage16_ln<F16, 1, false, RB>(wl, acc, cc.bv, g.colS + nb, g.rowstat, mb, g.M, l15, lq);
+                else pp_stage16_ln<F16, 0, false, RB>(wl, acc, cc.bv, g.colS + nb, g.rowstat, mb, g.M, l15, lq);
             } else
             if (EPI == EPI_GELU && pass == 1) pp_stage16<F16, 1>(wl, acc, cc.bv, l15, lq);
             else if (EPI == EPI_GELU && F16 && g.bwd_bf16) pp_stage16<false, 0>(wl, acc, cc.bv, l15, lq);  // pre-activation for the bf16 backward
@@ -686,7 +686,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
                 const int bnd = gb_split(g, mb, rA, rB);
                 pp_stage16_gb<F16, 0>(wl, acc, bv, rA + nb, rB + nb, bnd, l15, lq);
             } else if constexpr (LN) {
-                pp_stage16_ln<F16, 0, true>(wl, acc, bv, g.colS + nb, g.rowstat, mb, g.M, l15, lq, g.bias + nb);
+                pp_stage16_ln<F16, 0, true, RB>(wl, acc, bv, g.colS + nb, g.rowstat, mb, g.M, l15, lq, g.bias + nb);
             } else {
                 pp_stage16<F16, 0, RB>(wl, acc, bv, l15, lq);
             }
@@ -1287,8 +1287,11 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
         GemmArgs gg = g;
         gg.group_m = 4;
         static const int persist_env = getenv("SED_GEMM_PERSIST") ? atoi(getenv("SED_GEMM_PERSIST")) : 1;
-        const char* rb_s = getenv("SED_GEMM_RB");      // 7 / 8 force a tile height (A/B and the bit-exactness test; read per launch), else choose
-        const int rb_env = rb_s ? atoi(rb_s) : 0;
+        // SED_GEMM_RB (read per launch): 7 / 8 force a tile height (A/B and the bit-exactness test), 0 = choose by the round count below.
+        // Default 8: alone on the GPU the 224-row form wins 3-4 % on the N = 768 shapes, but inside the train step the teacher's and the
+        // weight-gradient streams fill the last round's idle CUs anyway and the shorter tiles cost 0.25 % (104.03 vs 103.77 ms, 3 A/B pairs).
+        const char* rb_s = getenv("SED_GEMM_RB");
+        const int rb_env = rb_s ? atoi(rb_s) : 8;
         static int ncu = 0;
         if (ncu == 0) {
             int dev = 0, n = 0;
@@ -1301,7 +1304,7 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
         const int ntn = g.N / V3_T;
         const long long t8 = (long long)cdiv(g.M, 256) * ntn, t7 = (long long)cdiv(g.M, 224) * ntn;
         const long long c8 = ((t8 + ncu - 1) / ncu) * 256, c7 = ((t7 + ncu - 1) / ncu) * 224;
-        const bool use7 = g.gbias == nullptr && g.k_wrap == 0 && g.rowpart == nullptr && g.rowstat == nullptr && (rb_env == 7 || (rb_env == 0 && c7 * 100 < c8 * 97));
+        const bool use7 = g.gbias == nullptr && g.k_wrap == 0 && (rb_env == 7 || (rb_env == 0 && c7 * 100 < c8 * 97));
         dim3 grid3((unsigned)(use7 ? t7 : t8), 1);
         gg.persist = (persist_env && (int)grid3.x > ncu) ? 1 : 0;
         if (gg.persist) grid3.x = ncu;
@@ -1317,9 +1320,14 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
                 if (!f16 || g.gbias != nullptr || g.k_wrap != 0 || (g.N & 63)) return SED_ERR_ARG;
                 if (producer ? (g.rowpart == nullptr || g.outH == nullptr || g.rowstat != nullptr)
                              : (g.rowstat == nullptr || g.colS == nullptr || g.rowpart != nullptr)) return SED_ERR_ARG;
-                static bool attrl = false;
-                if (!attrl) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attrl = true; }
-                hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true, 3>), grid3, dim3(512), V3_LDS, s, g);
+                static bool attrl[2] = {false, false};
+                if (use7) {
+                    if (!attrl[0]) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true, 3, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attrl[0] = true; }
+                    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true, 3, 7>), grid3, dim3(512), V3_LDS, s, g);
+                } else {
+                    if (!attrl[1]) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true, 3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attrl[1] = true; }
+                    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true, 3, 8>), grid3, dim3(512), V3_LDS, s, g);
+                }
                 return sed_check_launch();
             } else {
                 return SED_ERR_ARG;
