@@ -345,6 +345,25 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ops.TIMER = None
+    # one more UNTIMED instrumented step with the LayerNorm fold switched off: the GEMM family on its own, for the roofline note (the
+    # timed steps above ran the product's default, where the no-grad GEMM launches also carry their block's LayerNorm)
+    summ_unfolded = None
+    if world == 1 and timer is not None and a.mode in ("finetune2", "finetune1", "pretrain"):      # (a step is collective: single rank only)
+        engs = [e for e in (getattr(net, "engine", None), getattr(getattr(trainer, "ema_net", None), "engine", None)) if e is not None]
+        if engs and all(getattr(e, "ln_fold", False) for e in engs):
+            t2 = ops.KernelTimer(GEMM_KERNELS)
+            for e in engs:
+                e.ln_fold = False
+            try:
+                ops.TIMER = t2
+                step()
+                ops.TIMER = None
+                torch.cuda.synchronize()
+                summ_unfolded = t2.summarize()
+            finally:
+                ops.TIMER = None
+                for e in engs:
+                    e.ln_fold = True
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -427,6 +446,10 @@ def main():
                             "traffic": None if tj is None else tj.get("avg_bytes_per_launch"), "traffic_unit": "HBM bytes per launch",
                             "traffic_source": tsrc, "mfma_pipe_busy": None if mj is None else mj.get("family_busy_fraction"),
                             "mfma_pipe_busy_source": msrc,
+                            "achieved_ln_unfolded": None if not summ_unfolded else round(
+                                sum(v["flops"] for v in summ_unfolded.values()) / (sum(v["ms"] for v in summ_unfolded.values()) * 1e-3) / 1e12, 2),
+                            "achieved_ln_unfolded_note": "the same GEMM launches in one extra untimed step with SED_LN_FOLD=0 (LayerNorm as separate kernels): "
+                                                         "the family's own rate; `achieved` / `frac` are the timed configuration",
                             "alg_bytes_per_launch": round(by / max(1, n)),
                             "launches_per_step": n // timed_steps_with_events, "avg_launch_ms": round(ms / max(1, n), 4),
                             "instrumented_steps": f"{timed_steps_with_events} of the {a.steps} timed steps",
