@@ -112,6 +112,7 @@ class SedEngine:
         if self.wcorr not in ("0", "mean", "exact"):
             raise ValueError(f"SED_ENC_WCORR={self.wcorr!r}: expected 0, mean or exact")
         self.wcorr_all = os.environ.get("SED_ENC_WCORR_ALL", "0") != "0"
+        self.wcorr_fc1 = os.environ.get("SED_ENC_WCORR_FC1", "1") != "0"
         self.wcorr_step = int(os.environ.get("SED_ENC_WCORR_STEP", "8"))     # mean: clip means from every 8th token (1/8 of the extra read)
 
     def _wcorr_on(self, save):
@@ -368,8 +369,11 @@ class SedEngine:
                         two_term=True)
                 call("sed_layernorm_fwd", x_in, self.P(p + "norm2.weight"), self.P(p + "norm2.bias"), 1e-6, 1.0, h2, None,
                      mean2, rstd2, M, D, f16)
-                gemm_nt(h2, self._w2_image(W, p + "mlp.fc1.weight"), EPI_GELU, bias=self.P(p + "mlp.fc1.bias"), outH=None, outH2=act,
-                        two_term=True)
+                if self.wcorr_fc1:
+                    gemm_nt(h2, self._w2_image(W, p + "mlp.fc1.weight"), EPI_GELU, bias=self.P(p + "mlp.fc1.bias"), outH=None, outH2=act,
+                            two_term=True)
+                else:       # (experiment: fc1 is the weight whose rounding matters least)
+                    gemm_nt(h2, W[p + "mlp.fc1.weight"].w, EPI_GELU, bias=self.P(p + "mlp.fc1.bias"), outH=None, outH2=act)
                 gemm_nt(act, self._w2_image(W, p + "mlp.fc2.weight"), EPI_F32_RESID, bias=self.P(p + "mlp.fc2.bias"), res=x_in, outF=x_in,
                         two_term=True)
                 x = x_in
