@@ -299,7 +299,9 @@ class SedEngine:
             ctx["cols"] = cols
         # per-call scratch (reused across layers when not saving)
         # tensors that only the backward reads (GELU pre-activation) are produced as bf16 right away
-        B16 = BF16 if save else A16
+        # Blocks below the lowest one with a trainable tensor are never walked by the backward (frozen encoder of the pretrain / finetune1
+        # stages, `freeze_layer`): they run like a no-grad pass -- nothing saved, in place, LayerNorms folded -- even inside a pass that saves.
+        lo_f = self._lowest_trainable_fwd(m.depth) if save else m.depth
         # q, k, v stay row-major: the attention forward and backward take every transposed operand out of their LDS tiles
         # (ds_read_b64_tr_b16); the backward makes the bf16 images of the saved f16 Q / K / V tiles on the way into LDS
         mk_qkv = lambda: [E(Bx * H, N, 64, dt=A16), E(Bx * H, N, 64, dt=A16), E(Bx * H, N, 64, dt=A16)]
@@ -311,14 +313,17 @@ class SedEngine:
         # it -- the residual GEMM writes the f16 image of the new stream + per-row partial sums, the next GEMM consumes the RAW image against
         # gamma-scaled weights and normalises in its epilogue (csrc/gemm.hip, GemmArgs.rowpart / rowstat).  Two passes over the stream less
         # per block.  SED_LN_FOLD=0 keeps the LayerNorm kernels.
-        fold = self.ln_fold and not save and not wc and self.act == F16 and M >= 1024 and not getattr(m, "lora_r", 0)
-        if fold:
+        fold_ok = self.ln_fold and not wc and self.act == F16 and M >= 1024 and not getattr(m, "lora_r", 0) and (not save or lo_f > 0)
+        have_stat = False       # statistics of the current stream available (false before the first residual GEMM)
+        if fold_ok:
             x16f, partf, statf = E(M, D, dt=F16), E(M, D // 64, 2), E(M, 2)
-            have_stat = False       # statistics of the current stream available (false before the first residual GEMM)
         for li in range(m.depth):
             p = f"backbone.blocks.{li}."
             L = {}
-            if save or scratch is None:
+            sv = save and li >= lo_f          # this block's activations are read by a backward
+            fold = fold_ok and not sv
+            B16 = BF16 if sv else A16
+            if sv or scratch is None:
                 h16 = E(M, D, dt=A16)
                 q, k, v = mk_qkv()
                 o16 = E(M, D, dt=A16)
@@ -326,7 +331,7 @@ class SedEngine:
                 h2 = E(M, D, dt=A16)
                 hpre = E(M, 4 * D, dt=B16)
                 act = E(M, 4 * D, dt=A16)
-                mean1, rstd1, mean2, rstd2 = (E(M), E(M), E(M), E(M)) if save else (None, None, None, None)
+                mean1, rstd1, mean2, rstd2 = (E(M), E(M), E(M), E(M)) if sv else (None, None, None, None)
                 scratch = (h16, q, k, v, o16, lse, h2, hpre, act)
             else:
                 h16, q, k, v, o16, lse, h2, hpre, act = scratch
@@ -336,7 +341,7 @@ class SedEngine:
                 call("sed_layernorm_fwd", x_in, self.P(p + "norm1.weight"), self.P(p + "norm1.bias"), 1e-6, 1.0, h16, None,
                      mean1, rstd1, M, D, f16)
             if fold:
-                last = li + 1 == m.depth or (li + 1 == m.passt_feature_layer and not want_frame)
+                last = li + 1 == m.depth or (li + 1 == m.passt_feature_layer and not want_frame) or (save and li + 1 >= lo_f)
                 if have_stat:
                     wq, sq, cq = self._lnf_image(W, p + "attn.qkv.weight", p + "attn.qkv.bias", p + "norm1.weight", p + "norm1.bias")
                     call("sed_gemm_qkv_lnc", x16f, wq, cq, sq, statf, M, D, H, N, Npad, q, k, v)
@@ -361,6 +366,10 @@ class SedEngine:
                     pooled = self._fpool_fwd(W, x, Bx, tp, save, ctx)
                     if not want_frame:
                         break
+                    if save:
+                        x = x.clone()       # f_pool's backward reads the tensor it was given; the blocks above keep updating in place
+                if save:
+                    ctx["layers"].append(None)
                 continue
             if w2:      # evaluation mode: every encoder GEMM against the two-term weight image
                 call("sed_gemm_qkv_w2", h16, self._w2_image(W, p + "attn.qkv.weight"), self.P(p + "attn.qkv.bias"), M, D, H, N, Npad, q, k, v, f16)
@@ -406,25 +415,29 @@ class SedEngine:
             call("sed_gemm_qkv", h16, W[p + "attn.qkv.weight"].w, self.P(p + "attn.qkv.bias"), M, D, H, N, Npad, q, k,
                  v, None, None, None, None, None, None, None, f16)
             call("sed_mhsa_fwd", q, k, v, o16, lse, Bx, H, N, Npad, f16)
-            x_mid = E(Bx, N, D) if save else x_in
+            x_mid = E(Bx, N, D) if sv else x_in
             gemm_nt(o16, W[p + "attn.proj.weight"].w, EPI_F32_RESID, bias=self.P(p + "attn.proj.bias"), res=x_in,
                     outF=x_mid)
             call("sed_layernorm_fwd", x_mid, self.P(p + "norm2.weight"), self.P(p + "norm2.bias"), 1e-6, 1.0, h2, None,
                  mean2, rstd2, M, D, f16)
-            gemm_nt(h2, W[p + "mlp.fc1.weight"].w, EPI_GELU, bias=self.P(p + "mlp.fc1.bias"), outH=hpre if save else None,
+            gemm_nt(h2, W[p + "mlp.fc1.weight"].w, EPI_GELU, bias=self.P(p + "mlp.fc1.bias"), outH=hpre if sv else None,
                     outH2=act)
-            x_out = E(Bx, N, D) if save else x_mid
+            x_out = E(Bx, N, D) if sv else x_mid
             gemm_nt(act, W[p + "mlp.fc2.weight"].w, EPI_F32_RESID, bias=self.P(p + "mlp.fc2.bias"), res=x_mid,
                     outF=x_out)
-            if save:
+            if sv:
                 L.update(x_in=x_in, h16=h16, q=q, k=k, v=v, o16=o16, lse=lse, x_mid=x_mid, h2=h2,
                          hpre=hpre, act=act, mean1=mean1, rstd1=rstd1, mean2=mean2, rstd2=rstd2)
                 ctx["layers"].append(L)
+            elif save:
+                ctx["layers"].append(None)      # (a frozen block below the lowest trainable one: index kept, nothing saved)
             x = x_out
             if li + 1 == m.passt_feature_layer:
                 pooled = self._fpool_fwd(W, x, Bx, tp, save, ctx)
                 if not want_frame:
                     break  # later blocks only feed the AT head (`frame`); windows never need them
+                if save and not (li + 1 >= lo_f):
+                    x = x.clone()           # the in-place blocks that follow must not touch the tensor f_pool's backward reads
         frame16 = None
         if want_frame:
             frame16 = E(M, D, dt=A16)
@@ -756,6 +769,24 @@ class SedEngine:
         if m.has_at and grads.get("at_out") is not None:
             genc = self._at_bwd(W, ctx["actx"], ectx, grads["at_out"].contiguous().float(), G, need_dx=lo < len(ectx["layers"]))
         self._encoder_bwd(W, ectx, genc, dpooled, G, hook)
+
+    def _lowest_trainable_fwd(self, depth):
+        """The forward's view of `_lowest_trainable` (requires_grad flags instead of gradient views): index of the first encoder block
+        whose activations a backward can need -- 0 when the patch embedding / position tables train, `depth` when nothing below the
+        pooling does."""
+        pbn = self.m._param_by_name
+        cache = getattr(self, "_blk_params", None)
+        if cache is None or cache[0] is not pbn:
+            embed = [p_ for n, p_ in pbn.items() if n.startswith("backbone.") and not n.startswith("backbone.blocks.") and
+                     not n.startswith("backbone.norm.") and not n.startswith("backbone.head")]
+            blocks = [[p_ for n, p_ in pbn.items() if n.startswith(f"backbone.blocks.{i}.")] for i in range(depth)]
+            cache = self._blk_params = (pbn, embed, blocks)
+        if any(p_.requires_grad for p_ in cache[1]):
+            return 0
+        for i, ps in enumerate(cache[2][:depth]):
+            if any(p_.requires_grad for p_ in ps):
+                return i
+        return depth
 
     def _lowest_trainable(self, G, depth):
         """Index of the lowest encoder block with a trainable tensor (`depth` if none; 0 when the patch embedding / position tables train:
