@@ -608,7 +608,8 @@ class SedEngine:
                 dec_in = E(B, Tdec, D)
                 call("sed_mlm_apply", xg, self.P("mask_token").reshape(D), mlm_plan["action"], mlm_plan["src_idx"],
                      dec_in, B * Tdec)
-        xd, dctx = self._decoder_fwd(W, dec_in, save)
+        # (heads-only training -- the finetune1 stage: nothing at or below the context network learns, its backward is never walked)
+        xd, dctx = self._decoder_fwd(W, dec_in, save and self._walks_decoder_fwd())
         actx = None
         if m.has_at:
             actx = self._at_fwd(W, frame16, ectx, save)
@@ -733,6 +734,15 @@ class SedEngine:
                 dw = None if dw is None else dw.contiguous().float()
                 call("sed_head_bwd", ctx["xd"], self.P("classifier.weight"), hc["strong"], hc["sums"], ds, dw, hc["temp"],
                      g, G("classifier.weight"), G("classifier.bias"), B, Tdec, m.class_num)
+        # ---------------- nothing at or below the context network learns (finetune1: heads only): neither it nor the encoder is walked
+        if not self._walks_decoder(G, len(ctx["ectx"]["layers"])) and grads.get("frame_before_mask") is None:
+            if hook is not None:
+                hook("decoder")
+            if m.has_at and grads.get("at_out") is not None:
+                self._at_bwd(W, ctx["actx"], ctx["ectx"], grads["at_out"].contiguous().float(), G, need_dx=False)
+            if hook is not None:
+                hook("heads")
+            return
         # ---------------- context network
         dec_trainable = G("decoder.encoder_blocks.0.attn.in_proj.weight") is not None
         g = self._decoder_bwd(W, ctx["dctx"], g, G, dec_trainable)
@@ -770,17 +780,37 @@ class SedEngine:
             genc = self._at_bwd(W, ctx["actx"], ectx, grads["at_out"].contiguous().float(), G, need_dx=lo < len(ectx["layers"]))
         self._encoder_bwd(W, ectx, genc, dpooled, G, hook)
 
+    _BELOW_HEADS = ("decoder.", "out_norm.", "mask_token", "f_pool_module.")
+
+    def _walks_decoder_fwd(self):
+        """Will a backward have to pass through the context network?  Yes when one of its own tensors trains, or anything under it: the
+        f_pool normalisation, the MLM mask token, an encoder block, the patch embedding (requires_grad flags; `_walks_decoder` is the
+        backward's twin on gradient views)."""
+        pbn = self.m._param_by_name
+        inert = getattr(self.m, "_inert_param_names", ())
+        if any(p_.requires_grad for n, p_ in pbn.items() if n.startswith(self._BELOW_HEADS) and n not in inert):
+            return True
+        return self._lowest_trainable_fwd(self.m.depth) < self.m.depth
+
+    def _walks_decoder(self, G, depth):
+        names = [n for n in self.m._param_by_name if n.startswith(self._BELOW_HEADS)]
+        if any(G(n) is not None for n in names):
+            return True
+        lo, embed = self._lowest_trainable(G, depth)
+        return embed or lo < depth
+
     def _lowest_trainable_fwd(self, depth):
         """The forward's view of `_lowest_trainable` (requires_grad flags instead of gradient views): index of the first encoder block
         whose activations a backward can need -- 0 when the patch embedding / position tables train, `depth` when nothing below the
         pooling does."""
         pbn = self.m._param_by_name
+        inert = getattr(self.m, "_inert_param_names", ())      # (lr-0 groups: FusedAdamWEMA; no gradient is computed for them)
         cache = getattr(self, "_blk_params", None)
-        if cache is None or cache[0] is not pbn:
+        if cache is None or cache[0] is not pbn or cache[3] is not inert:
             embed = [p_ for n, p_ in pbn.items() if n.startswith("backbone.") and not n.startswith("backbone.blocks.") and
-                     not n.startswith("backbone.norm.") and not n.startswith("backbone.head")]
-            blocks = [[p_ for n, p_ in pbn.items() if n.startswith(f"backbone.blocks.{i}.")] for i in range(depth)]
-            cache = self._blk_params = (pbn, embed, blocks)
+                     not n.startswith("backbone.norm.") and not n.startswith("backbone.head") and n not in inert]
+            blocks = [[p_ for n, p_ in pbn.items() if n.startswith(f"backbone.blocks.{i}.") and n not in inert] for i in range(depth)]
+            cache = self._blk_params = (pbn, embed, blocks, inert)
         if any(p_.requires_grad for p_ in cache[1]):
             return 0
         for i, ps in enumerate(cache[2][:depth]):

@@ -187,7 +187,8 @@ class _SedFunction(torch.autograd.Function):
         grads = {k: g for k, g in zip(ctx.keys, gouts)}
         names = module._param_names
         params = [module._param_by_name[n] for n in names]
-        live = [(n, p) for n, p in zip(names, params) if p.requires_grad and not n.startswith("backbone.head")]
+        inert = getattr(module, "_inert_param_names", ())      # groups the optimiser will never move (lr 0): no gradient is computed for them
+        live = [(n, p) for n, p in zip(names, params) if p.requires_grad and not n.startswith("backbone.head") and n not in inert]
         flat = getattr(module, "_flat_layout", None)
         views = {}
         if flat is not None:  # optimiser-owned layout: gradient arena offsets == parameter arena offsets
@@ -385,7 +386,8 @@ class PaSST_SED(SEDModel):
             kw["mlm_plan"] = self._mlm_plan(B, (99 + 1) * self.decode_ratio, input.device, encoder_win)
         if getattr(self, "_drop_masks", None) is not None:
             kw["drop_masks"] = self._drop_masks
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._param_by_name.values())
+        inert = getattr(self, "_inert_param_names", ())
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for n, p in self._param_by_name.items() if n not in inert)
         kw["save"] = need_grad
         anchor = getattr(self, "_anchor", None)
         if anchor is None or anchor.device != input.device:

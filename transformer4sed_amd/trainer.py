@@ -67,7 +67,12 @@ class FusedAdamWEMA:
     """Flat-arena AdamW (+ optional EMA teacher).  `param_groups` exposes 'lr' like torch optimisers so that
     `ExponentialDown` can drive it unchanged."""
 
-    def __init__(self, net, groups, ema_net=None, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, net, groups, ema_net=None, betas=(0.9, 0.999), eps=1e-8, skip_zero_lr_groups=True):
+        """`skip_zero_lr_groups`: a group constructed with lr = 0 (the recipes' way of freezing the encoder / the context network in the
+        finetune1 stage, recipes/desed/finetune/passt/setting.py:28-103 -- its LayerNorm tensors even keep requires_grad) can never move
+        under a multiplicative schedule, so the model does not compute gradients for it at all: its backward stops above the frozen
+        stack.  The parameter trajectory is the reference's; what differs is that those tensors' `.grad` stays None and their Adam moments
+        stay zero.  `step()` raises if such a group is later given a non-zero lr."""
         self.net, self.ema_net = net, ema_net
         self.betas, self.eps = betas, eps
         self.step_count = 0
@@ -112,6 +117,8 @@ class FusedAdamWEMA:
                     p.data = self.ema_arena[o:o + k].view(p.shape)
         net._flat_layout = self  # the model's backward lays its gradient arena out identically
         self.grad_arena = None
+        self.inert_names = frozenset(n for g in self.param_groups if skip_zero_lr_groups and float(g["lr"]) == 0.0 for n in g["names"])
+        net._inert_param_names = self.inert_names
 
     def zero_grad(self, set_to_none=True):
         for p in self.net.parameters():
@@ -196,6 +203,9 @@ class FusedAdamWEMA:
         garena = getattr(net, "_last_grad_arena", None)
         if garena is None or garena.numel() != self.total:
             raise RuntimeError("FusedAdamWEMA.step(): no flat gradient arena (call loss.backward() on the model output first)")
+        if self.inert_names and any(float(g["lr"]) != 0.0 and g["names"] and g["names"][0] in self.inert_names for g in self.param_groups):
+            raise RuntimeError("FusedAdamWEMA: a parameter group built with lr = 0 now has a non-zero lr, but no gradients were computed "
+                               "for it (construct the optimiser with skip_zero_lr_groups=False to train it later)")
         self.step_count += 1
         touched = {n for n, p in net.named_parameters() if p.grad is not None}
         b1, b2 = self.betas
