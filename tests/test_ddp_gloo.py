@@ -181,6 +181,21 @@ def test_ranges_follow_requires_grad_changes(monkeypatch):
     assert any(a <= o and o + k <= b for a, b in red.last_issued)
 
 
+def test_inert_lr0_groups_stay_out_of_the_exchange():
+    """Parameters of lr-0 groups (FusedAdamWEMA marks them inert: no gradient is computed for them) are not all-reduced, and joining /
+    leaving that set rebuilds the ranges like a requires_grad change does."""
+    from transformer4sed_amd.ddp import GradBucketReducer
+    net, opt = _FakeNet2(), _FakeOpt(_layout())
+    net._inert_param_names = frozenset(n for n in NAMES if n.startswith("backbone.blocks.0."))
+    red = GradBucketReducer(net, opt, min_bytes=0)
+    assert ("block", 0) not in red.ranges and ("block", 1) in red.ranges
+    net._inert_param_names = frozenset()
+    net._last_grad_arena = torch.zeros(opt.total)
+    red.on_stage("decoder")
+    assert ("block", 0) in red.ranges
+    red.allreduce_grads()
+
+
 def test_rank_sharded_batch_sampler():
     """Per-rank batch stream (SURVEY 8(e) 'Partitioning'): disjoint indices, the reference's strong | weak | unlabeled order on every
     rank, equal group sizes, and the union over ranks of batch i == the reference sampler's batch i."""

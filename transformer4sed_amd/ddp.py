@@ -75,7 +75,9 @@ class GradBucketReducer:
         self.use_avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
 
     def _trainable_flags(self):
-        return tuple(p.requires_grad for _, p in self.net.named_parameters()) if hasattr(self.net, "named_parameters") else None
+        # (parameters of lr-0 groups are inert: the model computes no gradient for them, see FusedAdamWEMA.skip_zero_lr_groups)
+        inert = getattr(self.net, "_inert_param_names", ())
+        return tuple(p.requires_grad and n not in inert for n, p in self.net.named_parameters()) if hasattr(self.net, "named_parameters") else None
 
     def _build_ranges(self):
         """Arena slices per backward stage.  Only slices that can receive a gradient take part: frozen parameters and PaSST's unused
@@ -83,7 +85,8 @@ class GradBucketReducer:
         the set of trainable parameters changes (layer-wise unfreezing), see `_refresh`."""
         net = self.net
         self._flags = self._trainable_flags()
-        trainable = {n for n, p in net.named_parameters() if p.requires_grad} if hasattr(net, "named_parameters") else None
+        inert = getattr(net, "_inert_param_names", ())
+        trainable = {n for n, p in net.named_parameters() if p.requires_grad and n not in inert} if hasattr(net, "named_parameters") else None
         self.ranges = {}
         for n, o, k in self.opt.layout:
             if n.startswith("backbone.head") or (trainable is not None and n not in trainable):
