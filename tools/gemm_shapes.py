@@ -18,7 +18,7 @@ labels = torch.from_numpy(synth.synth_batch_labels(sn, wn, un, seed=1000)).to(de
 step = (lambda: trainer.pretrain_step(wav)) if mode == "pretrain" else (lambda: trainer.finetune_step(wav, labels.clone()))
 for _ in range(3):
     step()
-timer = ops.KernelTimer(["sed_gemm_nt", "sed_gemm_qkv", "sed_gemm_dw_tn"])
+timer = ops.KernelTimer(bench.GEMM_KERNELS)
 ops.TIMER = timer
 step(); torch.cuda.synchronize(); timer.recycle()
 step(); torch.cuda.synchronize()
