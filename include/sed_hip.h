@@ -70,7 +70,7 @@ int sed_gemm_qkv_w2(const void* A, const void* W, const float* bias, int M, int 
 /* LayerNorm FOLDED into the two Linear layers around it -- timm Block.forward `x = x + attn(norm1(x))`, `x = x + mlp(norm2(x))`
  * (src/models/passt/passt.py:360-363 with the F.linear calls of :332,342 and Mlp fc1 / fc2) for no-grad f16 passes (teacher, inference), so
  * that the normalised tensor never exists in memory:
- *   sed_gemm_nt_lnp   the residual Linear (proj / fc2): outF = resF + A . B^T + bias (fp32, may alias resF) AND x16 = its f16 image AND
+ *   sed_gemm_nt_lnp   the residual Linear (proj / fc2): outF = residual + A . B^T + bias (fp32, may alias resF) AND x16 = its f16 image AND
  *                     rowpart [M][N / 64][2] = per-row (sum, sum of squares) of every 64-column slice
  *   sed_ln_fold_stats rowpart -> rowstat [M][2] = (mean, 1 / sqrt(var + eps)) over D = 64 S columns
  *   sed_ln_fold_weight W16 [N, K] = f16(gamma[k] W[n, k]), colS[n] = sum_k W16[n, k], colC[n] = sum_k beta[k] W[n, k] + bias[n]
@@ -78,7 +78,11 @@ int sed_gemm_qkv_w2(const void* A, const void* W, const float* bias, int M, int 
  *                     stream) and W16: out[m, n] = f(rstd[m] * (acc[m, n] - mean[m] * colS[n]) + colC[n])  ==  f(Linear(LayerNorm(x)))
  * 256^2 kernel only: N % 256 == 0, M >= 1024, K % 64 == 0, f16 operands. */
 int sed_gemm_nt_lnp(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* bias, const float* resF,
-                    float* outF, void* x16, float* rowpart, int ldc, hipStream_t stream);
+                    const void* res_hi, const void* res_lo, float* outF, void* x16, void* out_lo, float* rowpart, int ldc,
+                    hipStream_t stream);
+/* (sed_gemm_nt_lnp, split-plane stream: between two folded blocks the residual stream can live as two f16 planes hi + lo instead of fp32
+ *  -- res_hi / res_lo != NULL: the residual is read as hi + lo instead of resF; out_lo != NULL: the result is written as x16 (hi) + out_lo
+ *  and outF is left alone.  The hi plane is the next GEMM's A operand, so a producer moves 8 instead of 10 bytes per element.) */
 int sed_ln_fold_stats(const float* rowpart, float* rowstat, int M, int S, int D, float eps, hipStream_t stream);
 int sed_ln_fold_weight(const float* W, const float* gamma, const float* beta, const float* bias, void* W16, float* colS, float* colC,
                        int N, int K, hipStream_t stream);

@@ -226,15 +226,28 @@ def test_gemm_layernorm_fold():
     # ---- producer
     x = torch.empty(M, D, device=DEV); x16 = torch.empty(M, D, dtype=F16, device=DEV)
     part = torch.full((M, D // 64, 2), float("nan"), device=DEV)
-    call("sed_gemm_nt_lnp", a16, Wp.to(F16), M, D, D, D, D, bp, res, x, x16, part, D)
+    call("sed_gemm_nt_lnp", a16, Wp.to(F16), M, D, D, D, D, bp, res, None, None, x, x16, None, part, D)
     plain = torch.empty(M, D, device=DEV)
     gemm_nt(a16, Wp.to(F16), ops.EPI_F32_RESID, bias=bp, res=res, outF=plain)
     assert torch.equal(x, plain) and torch.equal(x16, x.to(F16))
     sl = x.view(M, D // 64, 64)
     assert maxerr(part[:, :, 0], sl.sum(-1)) < 2e-3 and maxerr(part[:, :, 1], (sl * sl).sum(-1)) < 2e-3 * float((sl * sl).sum(-1).max())
     inplace = res.clone()
-    call("sed_gemm_nt_lnp", a16, Wp.to(F16), M, D, D, D, D, bp, inplace, inplace, x16, part, D)
+    call("sed_gemm_nt_lnp", a16, Wp.to(F16), M, D, D, D, D, bp, inplace, None, None, inplace, x16, None, part, D)
     assert torch.equal(inplace, x)
+    # split-plane stream: fp32 in -> planes out; planes in -> planes out (in place); planes in -> fp32 out
+    hi = torch.empty(M, D, dtype=F16, device=DEV); lo = torch.empty(M, D, dtype=F16, device=DEV); part2 = torch.empty_like(part)
+    call("sed_gemm_nt_lnp", a16, Wp.to(F16), M, D, D, D, D, bp, res, None, None, None, hi, lo, part2, D)
+    assert torch.equal(hi, x16) and torch.equal(lo, (x - x16.float()).to(F16)) and torch.equal(part2, part)
+    assert maxerr(hi.float() + lo.float(), x) < 2e-6 * float(x.abs().max())
+    x2 = torch.empty(M, D, device=DEV)
+    gemm_nt(a16, Wp.to(F16), ops.EPI_F32_RESID, bias=bp, res=hi.float() + lo.float(), outF=x2)      # what a second block adds on top
+    hi2, lo2 = hi.clone(), lo.clone()
+    call("sed_gemm_nt_lnp", a16, Wp.to(F16), M, D, D, D, D, bp, None, hi2, lo2, None, hi2, lo2, part2, D)
+    assert torch.equal(hi2, x2.to(F16)) and maxerr(hi2.float() + lo2.float(), x2) < 2e-6 * float(x2.abs().max())
+    back = torch.empty(M, D, device=DEV); h3 = torch.empty(M, D, dtype=F16, device=DEV)
+    call("sed_gemm_nt_lnp", a16, Wp.to(F16), M, D, D, D, D, bp, None, hi, lo, back, h3, None, part2, D)
+    assert torch.equal(back, x2) and torch.equal(h3, x2.to(F16))
     stat = torch.empty(M, 2, device=DEV)
     call("sed_ln_fold_stats", part, stat, M, D // 64, D, 1e-6)
     xd = x.double()

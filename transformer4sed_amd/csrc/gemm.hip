@@ -69,6 +69,12 @@ struct GemmArgs {
     float* rowpart;
     const float* rowstat;
     const float* colS;
+    // producer, split-plane residual stream: the stream lives as two f16 planes hi + lo (~22 significand bits) instead of fp32 -- the hi
+    // plane IS the next GEMM's A operand, so the producer moves 8 bytes per element (read hi, lo; write hi, lo) instead of 10 (fp32
+    // read-modify-write + the f16 image).  res_lo != NULL: the residual comes as auxH (hi) + res_lo; out_lo != NULL: the result leaves as
+    // outH (hi) + out_lo and outF is not written.
+    const bf16_t* res_lo;
+    bf16_t* out_lo;
 };
 
 #define TILE 128
@@ -524,9 +530,23 @@ struct V3Side {
     float4 r[EPI == EPI_F32_RESID ? 8 : 1];
     uint2 a[EPI == EPI_DGELU ? 8 : 1];
 };
-template <int EPI>
+template <int EPI, bool LNP = false>
 __device__ __forceinline__ void v3_side_load(V3Side<EPI>& sd, const GemmArgs& g, int m0, int n, int lane) {
     if constexpr (EPI == EPI_F32_RESID || EPI == EPI_DGELU) {
+        if constexpr (LNP) {
+            if (g.res_lo != nullptr) {      // split-plane residual: hi + lo (f16 each)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int m = m0 + u * 4 + (lane >> 4);
+                    const size_t o = (size_t)(m < g.M ? m : g.M - 1) * g.ldc + n;
+                    const u32x2_t h = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(g.auxH + o));
+                    const u32x2_t l = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(g.res_lo + o));
+                    sd.r[u] = make_float4(h2f((bf16_t)(h[0] & 0xFFFF)) + h2f((bf16_t)(l[0] & 0xFFFF)), h2f((bf16_t)(h[0] >> 16)) + h2f((bf16_t)(l[0] >> 16)),
+                                          h2f((bf16_t)(h[1] & 0xFFFF)) + h2f((bf16_t)(l[1] & 0xFFFF)), h2f((bf16_t)(h[1] >> 16)) + h2f((bf16_t)(l[1] >> 16)));
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int m = m0 + u * 4 + (lane >> 4);
@@ -571,9 +591,17 @@ __device__ __forceinline__ void v3_store_batch(const GemmArgs& g, const unsigned
         } else if constexpr (EPI == EPI_F32_RESID) {
             const float4 r = sd.r[u];
             const float4 x = make_float4(r.x + v.x + b.x, r.y + v.y + b.y, r.z + v.z + b.z, r.w + v.w + b.w);
-            v3_st<float4>(g.outF + o, x);
+            if constexpr (!LNP) v3_st<float4>(g.outF + o, x);
             if constexpr (LNP) {      // LayerNorm-fold producer: f16 image of the stream + this 64-column slice's (sum, sum of squares) per row
                 uint2 pk; pk.x = pack2<true>(x.x, x.y); pk.y = pack2<true>(x.z, x.w);
+                if (g.out_lo != nullptr) {      // split-plane stream: lo = f16(x - hi)
+                    uint2 pl;
+                    pl.x = pack2<true>(x.x - h2f((bf16_t)(pk.x & 0xFFFF)), x.y - h2f((bf16_t)(pk.x >> 16)));
+                    pl.y = pack2<true>(x.z - h2f((bf16_t)(pk.y & 0xFFFF)), x.w - h2f((bf16_t)(pk.y >> 16)));
+                    v3_st<uint2>(g.out_lo + o, pl);
+                } else {
+                    v3_st<float4>(g.outF + o, x);
+                }
                 *reinterpret_cast<uint2*>(g.outH + o) = pk;      // (a plain store: the next GEMM reads this image right away)
                 // (all 16 lanes of a row take this path together: m is uniform across them)
                 const float s1 = row16_sum((x.x + x.y) + (x.z + x.w));
@@ -773,17 +801,17 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
     }
     const int mend = mb + 16 * RB;
     V3Side<EPI> s0, s1;
-    v3_side_load<EPI>(s0, g, mb, n, lane);
+    v3_side_load<EPI, LN && EPI == EPI_F32_RESID>(s0, g, mb, n, lane);
     pp_stage32<RB>(wl, acc, 0, l15, lq);
     __builtin_amdgcn_wave_barrier();
-    v3_side_load<EPI>(s1, g, mb + 32, n, lane);
+    v3_side_load<EPI, LN && EPI == EPI_F32_RESID>(s1, g, mb + 32, n, lane);
     v3_store_batch<EPI, F16, LN && EPI == EPI_F32_RESID>(g, wl, s0, b, mb, 0, n, c4, lane, bB, mbnd, mend);
-    v3_side_load<EPI>(s0, g, mb + 64, n, lane);
+    v3_side_load<EPI, LN && EPI == EPI_F32_RESID>(s0, g, mb + 64, n, lane);
     v3_store_batch<EPI, F16, LN && EPI == EPI_F32_RESID>(g, wl, s1, b, mb + 32, 32, n, c4, lane, bB, mbnd, mend);
     __builtin_amdgcn_wave_barrier();
     pp_stage32<RB>(wl, acc, 1, l15, lq);
     __builtin_amdgcn_wave_barrier();
-    v3_side_load<EPI>(s1, g, mb + 96, n, lane);
+    v3_side_load<EPI, LN && EPI == EPI_F32_RESID>(s1, g, mb + 96, n, lane);
     v3_store_batch<EPI, F16, LN && EPI == EPI_F32_RESID>(g, wl, s0, b, mb + 64, 0, n, c4, lane, bB, mbnd, mend);
     v3_store_batch<EPI, F16, LN && EPI == EPI_F32_RESID>(g, wl, s1, b, mb + 96, 32, n, c4, lane, bB, mbnd, mend);
     __builtin_amdgcn_wave_barrier();
@@ -1446,13 +1474,17 @@ extern "C" int sed_gemm_nt_w2(const void* A, const void* B, int M, int N, int K,
 // consumer = EPI_GELU GEMM whose A operand is x16 (the RAW stream), B the f16 image of gamma (.) W (sed_ln_fold_weight), with
 // out[m, n] = act(rstd[m] * (acc - mean[m] * colS[n]) + colC[n]).
 extern "C" int sed_gemm_nt_lnp(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* bias, const float* resF,
-                               float* outF, void* x16, float* rowpart, int ldc, hipStream_t stream) {
+                               const void* res_hi, const void* res_lo, float* outF, void* x16, void* out_lo, float* rowpart, int ldc,
+                               hipStream_t stream) {
     (void)hipGetLastError();
     if (N % 256 || M < 1024 || K % BK || x16 == nullptr || rowpart == nullptr || ldc != N) return SED_ERR_ARG;
+    // residual: fp32 resF, or the planes res_hi + res_lo; result: fp32 outF + f16 image x16, or the planes x16 (hi) + out_lo
+    if ((res_lo != nullptr) != (res_hi != nullptr) || (res_lo == nullptr && resF == nullptr) || (out_lo == nullptr && outF == nullptr)) return SED_ERR_ARG;
     GemmArgs g = {};
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.ncols = N;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ksplit = 1; g.alpha = 1.f;
     g.bias = bias; g.resF = resF; g.outF = outF; g.outH = (bf16_t*)x16; g.rowpart = rowpart;
+    g.auxH = (const bf16_t*)res_hi; g.res_lo = (const bf16_t*)res_lo; g.out_lo = (bf16_t*)out_lo;
     return launch_gemm<EPI_F32_RESID>(g, 1, stream);
 }
 extern "C" int sed_gemm_nt_lnc(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* colC, const float* colS,

@@ -93,6 +93,7 @@ class SedEngine:
         self.relpos_stream = os.environ.get("SED_RELPOS_DKDV", "stream") != "recompute"
         self.ln_fold = os.environ.get("SED_LN_FOLD", "1") != "0"
         self.ln_bwd16 = os.environ.get("SED_LN_BWD16", "1") != "0"
+        self.ln_planes = os.environ.get("SED_LN_PLANES", "1") != "0"      # folded blocks: residual stream as two f16 planes between producers
         self._genc16 = None
         self._dw_stream = None
         self._dw_pending = False
@@ -316,7 +317,10 @@ class SedEngine:
         fold_ok = self.ln_fold and not wc and self.act == F16 and M >= 1024 and not getattr(m, "lora_r", 0) and (not save or lo_f > 0)
         have_stat = False       # statistics of the current stream available (false before the first residual GEMM)
         if fold_ok:
-            x16f, partf, statf = E(M, D, dt=F16), E(M, D // 64, 2), E(M, 2)
+            # between folded blocks the residual stream lives as two f16 planes (x16f = hi, which is also the consumers' A operand, + xlo)
+            # instead of fp32: a producer then moves 8 bytes per element instead of 10 (csrc/gemm.hip, GemmArgs.res_lo / out_lo)
+            x16f, xlo, partf, statf = E(M, D, dt=F16), E(M, D, dt=F16), E(M, D // 64, 2), E(M, 2)
+        planes = False              # the current stream value is in (x16f, xlo) rather than in the fp32 tensor
         for li in range(m.depth):
             p = f"backbone.blocks.{li}."
             L = {}
@@ -349,18 +353,26 @@ class SedEngine:
                     call("sed_gemm_qkv", h16, W[p + "attn.qkv.weight"].w, self.P(p + "attn.qkv.bias"), M, D, H, N, Npad, q, k,
                          v, None, None, None, None, None, None, None, f16)
                 call("sed_mhsa_fwd", q, k, v, o16, lse, Bx, H, N, Npad, f16)
-                call("sed_gemm_nt_lnp", o16, W[p + "attn.proj.weight"].w, M, D, D, D, D, self.P(p + "attn.proj.bias"), x_in, x_in, x16f,
-                     partf, D)
+                sp = self.ln_planes
+                call("sed_gemm_nt_lnp", o16, W[p + "attn.proj.weight"].w, M, D, D, D, D, self.P(p + "attn.proj.bias"),
+                     None if planes else x_in, x16f if planes else None, xlo if planes else None,
+                     None if sp else x_in, x16f, xlo if sp else None, partf, D)
+                planes = sp
                 call("sed_ln_fold_stats", partf, statf, M, D // 64, D, 1e-6)
                 w1, s1, c1 = self._lnf_image(W, p + "mlp.fc1.weight", p + "mlp.fc1.bias", p + "norm2.weight", p + "norm2.bias")
                 call("sed_gemm_nt_lnc", x16f, w1, M, 4 * D, D, D, D, c1, s1, statf, act, 4 * D)
-                if last:
+                # the block's output has an fp32 reader (f_pool, the final norm, a saving block) -> fp32 out; otherwise it stays in planes
+                f32_out = last or li + 1 == m.passt_feature_layer or not sp
+                if last and not planes:
                     gemm_nt(act, W[p + "mlp.fc2.weight"].w, EPI_F32_RESID, bias=self.P(p + "mlp.fc2.bias"), res=x_in, outF=x_in)
                 else:
-                    call("sed_gemm_nt_lnp", act, W[p + "mlp.fc2.weight"].w, M, D, 4 * D, 4 * D, 4 * D, self.P(p + "mlp.fc2.bias"), x_in, x_in,
-                         x16f, partf, D)
-                    call("sed_ln_fold_stats", partf, statf, M, D // 64, D, 1e-6)
-                    have_stat = True
+                    call("sed_gemm_nt_lnp", act, W[p + "mlp.fc2.weight"].w, M, D, 4 * D, 4 * D, 4 * D, self.P(p + "mlp.fc2.bias"),
+                         None if planes else x_in, x16f if planes else None, xlo if planes else None,
+                         x_in if f32_out else None, x16f, None if f32_out else xlo, partf, D)
+                    planes = not f32_out
+                    if not last:
+                        call("sed_ln_fold_stats", partf, statf, M, D // 64, D, 1e-6)
+                        have_stat = True
                 x = x_in
                 if li + 1 == m.passt_feature_layer:
                     pooled = self._fpool_fwd(W, x, Bx, tp, save, ctx)

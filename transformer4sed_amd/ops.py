@@ -150,9 +150,9 @@ def _bytes_of(name, args):
     if name in ("sed_gemm_qkv_gb", "sed_gemm_qkv_w2"):
         M, K, D = args[3], args[4], args[5] * 64
         return 2.0 * K * (M + 3 * D * (2 if name.endswith("w2") else 1)) + 2.0 * M * D * 3
-    if name == "sed_gemm_nt_lnp":      # operands + fp32 read-modify-write + the f16 image
+    if name == "sed_gemm_nt_lnp":      # operands + the residual read (4 B either way) + fp32 and f16 image (6 B) or the two f16 planes (4 B)
         M, N, K = args[2], args[3], args[4]
-        return 2.0 * K * (M + N) + 10.0 * M * N
+        return 2.0 * K * (M + N) + (8.0 if args[13] is not None else 10.0) * M * N
     if name == "sed_gemm_nt_lnc":
         M, N, K = args[2], args[3], args[4]
         return 2.0 * K * (M + N) + 2.0 * M * N
