@@ -40,6 +40,12 @@ int sed_warp_filt(const float* in, float* out, const int* kidx, const float* lam
  * src/codec/decoder.py:91,94 (modes 1, 2); optional per-(clip,class) weak-mask multiplier (decoder.py:22-23,80) */
 int sed_median_filter(const float* in, float* out, const int* sizes, const float* scale, int B, int T, int C, int mode,
                       hipStream_t stream);
+/* the same filters with the caller's bound `max_size` on the window sizes (which live on the device): with it, windows of 24 frames and more
+ * (the evaluation path filters with 32 / 128 frames, recipes/desed/finetune/train.py:221-227) take an order-statistics kernel -- global
+ * ranks of the padded column once, windows as bitmaps over ranks -- instead of the O(k^2) rank search; same element selected, bit-exact.
+ * A window larger than max_size traps. */
+int sed_median_filter_k(const float* in, float* out, const int* sizes, const float* scale, int B, int T, int C, int mode,
+                        int max_size, hipStream_t stream);
 
 /* ------------------------------------------------------------------ GEMM family (nn.Linear / conv / autograd GEMMs) */
 /* C[M,N] = A[M,K] . B[N,K]^T, bf16 operands, fp32 accumulate, fused epilogue `epi`:

@@ -21,7 +21,7 @@ def _run(x, sizes, mode, scale=None):
         raise ValueError("scipy-semantics filter: window longer than the sequence is outside the reproduced domain")
     sz = h2d(list(sizes), torch.int32, x.device)
     sc = None if scale is None else scale.contiguous().float()
-    call("sed_median_filter", x, out, sz, sc, B, T, C, mode)
+    call("sed_median_filter_k", x, out, sz, sc, B, T, C, mode, max(int(s) for s in sizes))     # (the bound selects the long-window kernel)
     return out
 
 
