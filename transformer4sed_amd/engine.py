@@ -720,6 +720,7 @@ class SedEngine:
         finally:
             self._join_dw()
             self._lo_cache = None
+            self._genc16 = None       # (the bf16 gradient image handed from block to block does not outlive the backward)
 
     def _backward_impl(self, ctx, grads, garena, hook=None):
         """grads: dict of upstream gradients (strong / weak / at_out / mlm_pred / frame_before_mask, any may be None).
