@@ -16,9 +16,17 @@
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
+/* ABI version.  Bumped whenever an EXISTING entry point changes its argument list (new entry points alone do not bump it; a changed
+ * one normally gets a new suffixed name instead, like sed_median_filter_k).  History: 3 = round 3 (sed_relpos_attn_fwd gained O_split,
+ * sed_relpos_attn_bwd gained Pst, both in place); 4 = round 4.  A binding compares sed_abi_version() with the header it was written
+ * against before the first call (transformer4sed_amd/_lib.py does). */
+#define SED_HIP_ABI_VERSION 4
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+int sed_abi_version(int reserved);
 
 /* ------------------------------------------------------------------ frontend / augment / post-process */
 /* PasstFeatureExtractor.forward + .normalize (src/models/passt/passt_feature_extraction.py:46-94).

@@ -226,11 +226,14 @@ def test_rank_sharded_batch_sampler():
     e0 = [list(r0), list(r1)]
     seen = [j for b0, b1 in zip(*e0) for j in b0 + b1]
     assert len(seen) == len(set(seen))
-    r0.set_epoch(1); r1.set_epoch(1)
-    e1 = [list(r0), list(r1)]
+    e1 = [list(r0), list(r1)]         # a second pass WITHOUT set_epoch (the reference loop never calls it) is a new epoch on every rank
     assert e1[0] != e0[0]
     seen = [j for b0, b1 in zip(*e1) for j in b0 + b1]
     assert len(seen) == len(set(seen))
+    r0.set_epoch(0); r1.set_epoch(0)
+    assert [list(r0), list(r1)] == e0
+    with pytest.raises(ValueError):      # shuffling samplers without a shared seed: every rank would draw its own permutation
+        RankShardedBatchSampler(samplers(False), bs, rank=0, world=world)
     with pytest.raises(ValueError):
         RankShardedBatchSampler(samplers(True), [3, 4, 8], rank=0, world=2)
 

@@ -57,6 +57,11 @@ class _Lib:
             fn.restype = ctypes.c_int
             fn.argtypes = [t for t, _ in args]
             setattr(self, "_raw_" + name, fn)
+        want = int(re.search(r"#define\s+SED_HIP_ABI_VERSION\s+(\d+)", open(HEADER_PATH).read()).group(1))
+        have = self._dll.sed_abi_version(0)
+        if have != want:
+            raise ImportError(f"libsed_hip.so implements ABI version {have}, include/sed_hip.h declares {want}: rebuild the library "
+                              "(python -m transformer4sed_amd.build --force)")
 
     def call(self, name, *args):
         rc = getattr(self, "_raw_" + name)(*args)

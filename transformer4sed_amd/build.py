@@ -41,11 +41,17 @@ def build(force=False, verbose=True):
     objs = []
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    # headers every source includes: a newer header rebuilds everything, otherwise only the sources newer than their object
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "sed_hip.h"),
+                                                                                     os.path.abspath(__file__)]
+    hdr_t = max(os.path.getmtime(h) for h in hdrs)
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(os.path.join(CSRC, src))):
+            continue
         cmd = [_hipcc(), *FLAGS, *FILE_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:

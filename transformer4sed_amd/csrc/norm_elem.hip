@@ -6,6 +6,8 @@
 #include "common.h"
 #include "../../include/sed_hip.h"
 
+extern "C" int sed_abi_version(int) { return SED_HIP_ABI_VERSION; }
+
 #define DM 768
 #define NV 3  // float4 per lane per row
 

@@ -284,8 +284,15 @@ class RankShardedBatchSampler(ConcatDatasetBatchSampler):
         if bad:
             raise ValueError(f"every group of training.batch_size {list(batch_sizes)} must be a multiple of the number of GPUs (= {world}): "
                              "each rank takes an equal share of every group")
+        # Random samplers draw from the process-global torch RNG unless they carry a generator: across ranks that gives every rank its
+        # own permutation, i.e. overlapping / missing shares of the global batch.  A shared `seed` is therefore mandatory for them.
+        from torch.utils.data import RandomSampler
+        if world > 1 and seed is None and any(isinstance(s_, RandomSampler) and s_.generator is None for s_ in samplers):
+            raise ValueError("RankShardedBatchSampler: shuffling samplers need a `seed` shared by all ranks (every rank must walk the "
+                             "same global batch stream); pass seed=... or samplers with identically seeded generators")
         self.rank, self.world, self.seed = rank, world, seed
         self.local_batch_sizes = [b // world for b in batch_sizes]
+        self._auto_epoch = True       # the reference loop never calls set_epoch: every pass over the sampler is a new epoch
         super().__init__(samplers, batch_sizes, epoch)
 
     def set_epoch(self, epoch):
@@ -299,6 +306,14 @@ class RankShardedBatchSampler(ConcatDatasetBatchSampler):
                     sampler.generator = g
 
     def __iter__(self):
+        if self.seed is not None:
+            self.set_epoch(self.epoch)          # (re)seed for THIS pass: identical on every rank
+        for batch in self._global_batches():
+            yield batch
+        if self._auto_epoch:
+            self.epoch += 1                     # the next pass reshuffles even if nobody calls set_epoch
+
+    def _global_batches(self):
         for batch in super().__iter__():
             mine, pos = [], 0
             for size, per in zip(self.batch_sizes, self.local_batch_sizes):

@@ -35,7 +35,10 @@ def broadcast_buffers(net, src=0, group=None):
     reads them as "the model" (validation, checkpoint) every rank takes rank 0's, in ONE collective over a flat staging tensor."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return 0
-    bufs = [b for _, b in net.named_buffers() if b is not None and b.numel() > 0]
+    # only buffers that training mutates: the running statistics / batch counters of BatchNorm layers (constant tables -- the
+    # frontend's window / twiddles -- are identical on every rank by construction and stay out of the collective)
+    bufs = [b for mod in net.modules() if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm)
+            for b in mod.buffers(recurse=False) if b is not None and b.numel() > 0]
     if not bufs:
         return 0
     flat = torch.cat([b.detach().reshape(-1).to(torch.float64) for b in bufs])   # float64 carries num_batches_tracked (int64) exactly

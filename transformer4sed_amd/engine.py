@@ -912,7 +912,7 @@ class SedEngine:
         t, self._genc16 = getattr(self, "_genc16", None), None
         return t[1] if (t is not None and t[0] is g and t[2] == g._version) else None
 
-    def _dw_accum(self, dy, x, M, gW, bias=None, dy16=None):
+    def _dw_accum(self, dy, x, M, gW, bias=None, dy16=None, k_in=None):
         """gW += dy^T x (weight gradient), bias += column sums of dy.  dy [M, n_out] f32 or bf16, x [M, k_in] (saved forward
         operand, 16-bit or f32); gW / bias are arena views or None.  Returns dy as a bf16 [M, n_out] tensor (operand of the
         dX GEMM that follows).  TN kernel on the operands as they lie when the shapes allow it (tokens % 64, features % 256);
@@ -923,7 +923,9 @@ class SedEngine:
         n_out, ldx = dy.shape[1], x.shape[1]
         # a saved split-precision image [M, 3 k_in] = [hi | lo | hi] (context network, MLM head) serves as the f16 operand through its
         # first third: the weight gradient sees the activation at the precision the encoder's gradients see theirs
-        k_in = gW.shape[1] if (gW is not None and x.dtype == F16 and ldx == 3 * gW.shape[1]) else ldx
+        # (callers that hold split images pass `k_in`; otherwise it is inferred from the gradient view)
+        if k_in is None:
+            k_in = gW.shape[1] if (gW is not None and x.dtype == F16 and ldx == 3 * gW.shape[1]) else ldx
         E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
         Mt = M // 64 * 64      # the TN kernel walks the tokens in steps of 64: a ragged tail goes through the NT kernel
         tn = self.dw_tn and Mt >= 1024 and dw_tn_ok(Mt, n_out, k_in) and x.dtype in (F16, BF16, F32)
@@ -975,6 +977,7 @@ class SedEngine:
         return g16 if g16 is not None else dy
 
     def _mlp_bwd(self, W, n1, n2, dy, x16, hpre, act, M, G, residual, dy16=None):
+        # (operand widths of the two weight gradients come from the weight images: a saved split image [M, 3 k] serves through its first third)
         """Backward of y = fc2(gelu(fc1(x))) given dy [M, n_out] f32.  Returns dx f32 [M, D] (new tensor), or adds
         into `residual` (f32 [M, D]) when given.  Weight/bias grads go to the arena when trainable."""
         dev = dy.device
@@ -985,11 +988,12 @@ class SedEngine:
         n_out = w2.w.shape[0]
         train = G(n1 + ".weight") is not None
         hpre = to_bf16_(hpre)
-        g16 = self._dw_accum(dy, act, M, G(n2 + ".weight") if train else None, G(n2 + ".bias") if train else None, dy16=dy16)
+        g16 = self._dw_accum(dy, act, M, G(n2 + ".weight") if train else None, G(n2 + ".bias") if train else None, dy16=dy16,
+                             k_in=w2.w.shape[1])
         dh16 = E(M, hid, dt=BF16)
         gemm_nt(g16, w2.wt, EPI_DGELU, outH=dh16, aux=hpre)
         if train:
-            self._dw_accum(dh16, x16, M, G(n1 + ".weight"), G(n1 + ".bias"))
+            self._dw_accum(dh16, x16, M, G(n1 + ".weight"), G(n1 + ".bias"), k_in=w1.w.shape[1])
         if residual is not None:
             gemm_nt(dh16, w1.wt, EPI_F32_RESID, res=residual, outF=residual)
             return residual
@@ -1065,7 +1069,7 @@ class SedEngine:
             del dln
             # attention branch: x1 = y + out_proj(relattn(y)),  y = LN1(in_scale * x_in)
             g16 = self._dw_accum(g2, L["o16s"] if L.get("o16s") is not None else L["o16"], M,
-                                 G(p + "attn.out_proj.weight") if trainable else None, Gl(p + "attn.out_proj.bias"))
+                                 G(p + "attn.out_proj.weight") if trainable else None, Gl(p + "attn.out_proj.bias"), k_in=D)
             do16 = E(M, D, dt=BF16)
             gemm_nt(g16, W[p + "attn.out_proj.weight"].wt, EPI_BF16, outH=do16)
             dqkv = E(M, 3 * D, dt=BF16)
@@ -1089,7 +1093,7 @@ class SedEngine:
                 dPT = E(D, Rpad, dt=BF16)
                 transpose_bf16(dP, Rpad, D, dPT)
                 gemm_dw(dPT, posT16, G(p + "attn.linear_pos.weight"))
-                self._dw_accum(dqkv, L["y16"], M, G(p + "attn.in_proj.weight"), G(p + "attn.in_proj.bias"))
+                self._dw_accum(dqkv, L["y16"], M, G(p + "attn.in_proj.weight"), G(p + "attn.in_proj.bias"), k_in=D)
             # dy = g (residual from the normalised input) + dqkv @ W_in
             gemm_nt(dqkv, W[p + "attn.in_proj.weight"].wt, EPI_F32_RESID, res=g2, outF=g2)
             gnew = E(B, T, D)

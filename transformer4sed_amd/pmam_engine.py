@@ -454,6 +454,9 @@ class PmamEngine(SedEngine):
             # TN kernel on the operands as they lie: dW [n, k] = dy^T x and the column sums of dy from the same launch.  Padding columns
             # of either operand only reach output elements outside [:n_valid, :k_valid], which nobody reads.
             gW, csum = torch.zeros(n, k, device=dev), torch.zeros(n, device=dev)
+            # this launch runs on the CURRENT stream and uses the per-device split-K workspace that weight-gradient GEMMs still pending on
+            # the side stream (`_dw_accum`: the cnn_projector's dW was issued just before the CNN backward) are writing / reducing: order them
+            self._join_dw()
             gemm_dw_tn(dy16, x, gW, dbias=csum)
             return gW.t(), csum
         n_eff, k_eff = min(n, pad64(n_valid)), min(k, pad64(k_valid))

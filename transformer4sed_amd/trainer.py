@@ -217,6 +217,10 @@ class FusedAdamWEMA:
                      float(g["weight_decay"]), b1, b2, self.eps, self.step_count,
                      float(ema_alpha_value) if ema_alpha_value is not None else 0.0, 1)
                 done.append((s, e))
+        if done:
+            # the student's masters were rewritten through raw pointers too (neither `_version` nor `data_ptr` moves): the cached
+            # evaluation-mode images of its weights (two-term / residual / LayerNorm-folded, engine.py) key on this counter
+            net._param_generation = getattr(net, "_param_generation", 0) + 1
         if self.ema_arena is not None and ema_alpha_value is not None:
             # the teacher's masters change behind torch's back (raw-pointer kernel): engines that cache operand images of frozen
             # tensors key them on this counter
@@ -306,9 +310,11 @@ class MatSedTrainer:
     # `best_teacher.pt` written by either side load into the other (recipes/desed/finetune/passt/main.py:60-71,82-96); optimiser,
     # scheduler step and RNG state are what the reference does not keep and a bit-faithful resume needs.
     def _sync_buffers(self):
-        """Under data parallelism rank 0's BatchNorm running statistics are the model's (ddp.broadcast_buffers; PaSST_CNN only -- MAT-SED
-        has no buffers that training changes)."""
-        if self.ddp is not None:
+        """Under data parallelism rank 0's BatchNorm running statistics are the model's (ddp.broadcast_buffers).  Only a model WITH
+        BatchNorm layers (PaSST_CNN) has buffers that training changes: for MAT-SED this is a no-op, so `state_dict()` /
+        `save_weights()` carry no collective and may be called from one rank (`if rank == 0: trainer.save_weights(...)`).  For a
+        BatchNorm model EVERY rank must call them (the broadcast is a collective)."""
+        if self.ddp is not None and any(isinstance(mod, torch.nn.modules.batchnorm._BatchNorm) for mod in self.net.modules()):
             from .ddp import broadcast_buffers
             self.ddp.sync_buffers()
             if self.ema_net is not None:
