@@ -44,6 +44,14 @@ int sed_roll_mix(const float* in, float* out, const int* shift, const int* perm,
 /* freq_nonlinear (gather-lerp table) + filt_aug additive term (data_aug.py:150-192, 207-222) */
 int sed_warp_filt(const float* in, float* out, const int* kidx, const float* lam, const float* add, int B, int F, int T,
                   hipStream_t stream);
+/* In-place box fill x[:, f0:f1, t0:t1] = value on x [B,F,T]: time_mask (src/preprocess/data_aug.py:93-108: features 0 / 1e-4 and labels 0
+ * over a time range) and torchaudio's FrequencyMasking as called at data_aug.py:136-140 (a frequency range, all clips, value 0).  An empty
+ * range is a no-op (python slice semantics are resolved by the caller). */
+int sed_mask_box(float* x, int B, int F, int T, int f0, int f1, int t0, int t1, float value, hipStream_t stream);
+/* add_noise (data_aug.py:195-204): out[b] = x[b] + noise[b] * std(x[b]) / snr_lin[b], std unbiased over the n = F*T elements of a clip
+ * (torch.std over dims (1,2)), snr_lin = 10^(snr_dB/20); noise = the caller's standard-normal draws.  part: scratch fp32 [B, 64, 3]. */
+int sed_add_noise(const float* x, const float* noise, const float* snr_lin, float* part, float* out, int B, int n,
+                  hipStream_t stream);
 /* median_filter_torch (src/postprocess/filter.py:4-36, mode 0); scipy median / max filter as called at
  * src/codec/decoder.py:91,94 (modes 1, 2); optional per-(clip,class) weak-mask multiplier (decoder.py:22-23,80) */
 int sed_median_filter(const float* in, float* out, const int* sizes, const float* scale, int B, int T, int C, int mode,

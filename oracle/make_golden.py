@@ -218,6 +218,96 @@ def gen_augment():
     save("augment", **out)
 
 
+def gen_augment2():
+    """The augmentation branches no shipped config turns on (SURVEY 8(a) rows 6-8 'unused-by-config'): time_mask, FilterAugment
+    'linear', FrequencyMasking (torchaudio stand-in, oracle/ref_shims) and add_noise, with every draw recorded; add_noise's randn tensor
+    is replaced by a synth.py tensor (3 MB of normal draws would not be a small fixture) -- the arithmetic under test is the same."""
+    from src.preprocess import data_aug
+    B = 4
+    mel = torch.from_numpy(synth.det_uniform("aug2/mel", (B, 128, 1000), -1.5, 1.5))
+    label = torch.from_numpy(synth.synth_strong_labels(B, seed=78))
+    out = {}
+    # time_mask without labels (features zeroed over [t_low, t_low + t_width))
+    torch.manual_seed(31)
+    rec = DrawRecorder()
+    with rec.recording():
+        tm = data_aug.time_mask(mel.clone())
+    ri = rec.of("randint")
+    out["tm_width_low"] = np.asarray([int(ri[0]), int(ri[1])])
+    out["tm_mel_colsum"] = t2n(tm.sum(1))
+    # time_mask with labels, net_pooling 4 on a 250-frame label (the feature range is bounded by len(features) = B, as written)
+    torch.manual_seed(32)
+    rec = DrawRecorder()
+    with rec.recording():
+        tm2, tl2 = data_aug.time_mask(mel.clone(), label[:, :, :250].clone(), net_pooling=4)
+    ri = rec.of("randint")
+    out["tml_width_low"] = np.asarray([int(ri[0]), int(ri[1])])
+    out["tml_mel_colsum"] = t2n(tm2.sum(1))
+    out["tml_label_colsum"] = t2n(tl2.sum(1))
+    # a case where the feature slice is NOT empty: tiny n_frame so that t_low * net_pooling < len(features)
+    big = torch.from_numpy(synth.det_uniform("aug2/mel16", (16, 8, 40), -1.0, 1.0))
+    lab = torch.ones(16, 3, 40)
+    torch.manual_seed(5)
+    for seed in range(200):
+        torch.manual_seed(seed)
+        rec = DrawRecorder()
+        with rec.recording():
+            f3, l3 = data_aug.time_mask(big.clone(), lab.clone(), net_pooling=1)
+        ri = rec.of("randint")
+        if int(ri[1]) < 14:
+            out["tms_seed"] = np.asarray(seed)
+            out["tms_width_low"] = np.asarray([int(ri[0]), int(ri[1])])
+            out["tms_mel"] = t2n(f3)
+            out["tms_label_colsum"] = t2n(l3.sum(1))
+            break
+    # FilterAugment 'linear' (dB draws used as they are: negative -> NaN, reproduced)
+    torch.manual_seed(41)
+    rec = DrawRecorder()
+    with rec.recording():
+        fl = data_aug.filt_aug(mel, db_range=[-26, 26], n_band=[2, 5], min_bw=4, filter_type="linear", log=True, norm_std=5.0)
+    ri = rec.of("randint")
+    nb = int(ri[0].item())
+    out["lin_bounds"] = np.asarray([0] + (torch.sort(ri[1])[0] + torch.arange(1, nb) * 4).tolist() + [128])
+    out["lin_band_db"] = t2n(rec.of("rand")[0] * 52.0 + (-26.0))
+    out["lin_mel_s"] = t2n(fl[:, :, ::13])
+    # the same with a positive dB range: finite everywhere
+    torch.manual_seed(42)
+    rec = DrawRecorder()
+    with rec.recording():
+        fl = data_aug.filt_aug(mel, db_range=[1, 27], n_band=[3, 6], min_bw=6, filter_type="linear", log=True, norm_std=5.0)
+    ri = rec.of("randint")
+    nb = int(ri[0].item())
+    out["linp_bounds"] = np.asarray([0] + (torch.sort(ri[1])[0] + torch.arange(1, nb) * 6).tolist() + [128])
+    out["linp_band_db"] = t2n(rec.of("rand")[0] * 26.0 + 1.0)
+    out["linp_mel_s"] = t2n(fl[:, :, ::13])
+    # add_noise with the normal draws injected
+    noise = torch.from_numpy(synth.det_uniform("aug2/noise", (B, 128, 1000), -1.7320508, 1.7320508))
+    o_randn = torch.randn
+    torch.randn = lambda *a, **k: noise.clone()
+    try:
+        torch.manual_seed(51)
+        rec = DrawRecorder()
+        with rec.recording():
+            an = data_aug.add_noise(mel, snrs=(15, 30))
+        out["noise_snr_u"] = t2n(rec.of("rand")[0])
+        out["noise_mel_s"] = t2n(an[:, ::2, ::13])
+        out["noise_scalar_mel_s"] = t2n(data_aug.add_noise(mel, snrs=20)[:, ::2, ::13])
+        # the whole dispatcher with every branch on: draws in call order
+        random.seed(61)
+        torch.manual_seed(62)
+        rec = DrawRecorder()
+        with rec.recording():
+            views = data_aug.feature_transformation(mel, n_transform=2, choice=[1, 1, 1, 1], filter_db_range=[-26, 26],
+                                                    filter_bands=[2, 5], filter_minimum_bandwidth=4, filter_type="step",
+                                                    freq_mask_ratio=16, noise_snrs=(15, 30), log=True, norm_std=5.0)
+    finally:
+        torch.randn = o_randn
+    for v in range(2):
+        out[f"all{v}_mel_s"] = t2n(views[v][:, ::2, ::13])
+    out["all_n_rand"] = np.asarray(len(rec.of("rand")))
+    save("augment2", **out)
+
+
 # ------------------------------------------------------------------------------------------------
 def build_reference_model(embed_dim, mlm, depth, feature_layer, tag=None):
     """PaSST_SED from the reference with synth weights; encoder truncated to `depth` blocks
@@ -1068,7 +1158,7 @@ def gen_val12():
     save("val12", **out)
 
 
-GENS = dict(val12=gen_val12, pmamflops=gen_pmamflops, frontend=gen_frontend, augment=gen_augment, micro=gen_micro, full=gen_full, full12=gen_full12,
+GENS = dict(val12=gen_val12, augment2=gen_augment2, pmamflops=gen_pmamflops, frontend=gen_frontend, augment=gen_augment, micro=gen_micro, full=gen_full, full12=gen_full12,
             schedule=gen_schedule, postprocess=gen_postprocess, losses=gen_losses, trainstep=gen_trainstep, trainstep12=gen_trainstep12, full12train=gen_full12_train, winbwd=gen_winbwd, evalpath=gen_evalpath, datapipe=gen_datapipe, pmam=gen_pmam, pmamstep=gen_pmamstep, pmamft=gen_pmamft)
 
 if __name__ == "__main__":

@@ -152,6 +152,53 @@ def filt_aug_step(mel: torch.Tensor, bounds, band_db: torch.Tensor, norm_std: fl
     return mel + torch.log(filt + 0.00001) / norm_std
 
 
+def time_mask(mel, t_width: int, t_low: int, labels=None, net_pooling=None):
+    """data_aug.py:93-108 with its two randint draws given.  With labels the feature slice ends at
+    min((t_low + t_width) * net_pooling, len(features)) -- the BATCH size, as the reference writes it -- and is filled with 1e-4."""
+    mel = mel.clone()
+    if labels is not None:
+        labels = labels.clone()
+        mel[:, :, int(t_low * net_pooling):min(int((t_low + t_width) * net_pooling), len(mel))] = 1e-4
+        labels[:, :, t_low:t_low + t_width] = 0
+        return mel, labels
+    mel[:, :, t_low:t_low + t_width] = 0
+    return mel
+
+
+def filt_aug_linear(mel: torch.Tensor, bounds, band_db: torch.Tensor, norm_std: float = 5.0) -> torch.Tensor:
+    """data_aug.py:176-185, 'linear' type, log=True: band_db [B, n_band + 1] are the dB draws at the band edges; the reference
+    interpolates them with torch.linspace and takes ln(. + 1e-5) / norm_std of the dB numbers themselves (no 10^(./20) in this branch),
+    so negative values give NaN -- kept."""
+    B, Fb, _ = mel.shape
+    filt = torch.ones((B, Fb, 1), dtype=mel.dtype)
+    for i in range(len(bounds) - 1):
+        for j in range(B):
+            filt[j, bounds[i]:bounds[i + 1], :] = torch.linspace(band_db[j, i], band_db[j, i + 1],
+                                                                 bounds[i + 1] - bounds[i]).unsqueeze(-1)
+    return mel + torch.log(filt + 0.00001) / norm_std
+
+
+def frequency_mask_band(n_freq: int, mask_param: int, u_value: float, u_min: float):
+    """torchaudio 2.0.1 functional.mask_along_axis on axis 1 (FrequencyMasking at data_aug.py:136-140; 3-D input: one band for the
+    batch) from its two uniform draws: [long(min_value), long(min_value) + long(value)).  THIRD-PARTY, restated from the published
+    definition: parity unpinned (torchaudio is not installed in the authoring container)."""
+    value = np.float32(u_value) * np.float32(mask_param)
+    min_value = np.float32(u_min) * (np.float32(n_freq) - value)
+    start = int(min_value)
+    return start, start + int(value)
+
+
+def add_noise(mel: torch.Tensor, snr_u, noise: torch.Tensor, snrs=(15, 30)) -> torch.Tensor:
+    """data_aug.py:195-204 with the uniform SNR draws `snr_u` [B] and the standard-normal tensor `noise` given."""
+    if isinstance(snrs, (list, tuple)):
+        snr = (snrs[0] - snrs[1]) * torch.as_tensor(snr_u, dtype=mel.dtype).reshape(-1, 1, 1) + snrs[1]
+    else:
+        snr = snrs
+    snr = 10 ** (snr / 20)
+    sigma = torch.std(mel, dim=(1, 2), keepdim=True) / snr
+    return mel + noise * sigma
+
+
 # =====================================================================================================
 # PaSST encoder  (src/models/passt/passt.py:257-596)
 # =====================================================================================================

@@ -314,6 +314,91 @@ extern "C" int sed_warp_filt(const float* in, float* out, const int* kidx, const
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The augmentation branches no shipped config turns on (choice[1], choice[2], time_mask), HBM-bound like the rest:
+//  mask_box : x[b, f0:f1, t0:t1] = value in place            (time_mask data_aug.py:93-108; FrequencyMasking :136-140)
+//  add_noise: out = x + noise * std_b(x) / snr_b            (data_aug.py:195-204; std over (F, T) per clip, unbiased like torch.std)
+// ---------------------------------------------------------------------------------------------------
+__global__ void mask_box_kernel(float* __restrict__ x, int B, int F, int T, int f0, int f1, int t0, int t1, float value) {
+    const int wf = f1 - f0, wt = t1 - t0;
+    const size_t total = (size_t)B * wf * wt;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(idx % wt);
+        const size_t r = idx / wt;
+        const int f = (int)(r % wf), b = (int)(r / wf);
+        x[((size_t)b * F + f0 + f) * T + t0 + t] = value;
+    }
+}
+extern "C" int sed_mask_box(float* x, int B, int F, int T, int f0, int f1, int t0, int t1, float value, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (f0 < 0 || f1 > F || t0 < 0 || t1 > T) return SED_ERR_ARG;
+    if (f1 <= f0 || t1 <= t0 || B <= 0) return SED_OK;      // an empty slice, like the reference's python slicing
+    const size_t total = (size_t)B * (f1 - f0) * (t1 - t0);
+    hipLaunchKernelGGL(mask_box_kernel, dim3((unsigned)min((size_t)2048, (total + 255) / 256)), dim3(256), 0, stream, x, B, F, T, f0, f1,
+                       t0, t1, value);
+    return sed_check_launch();
+}
+
+#define NOISE_CHUNKS 64
+// per (clip, chunk): count, mean and M2 = sum (x - mean)^2 of the chunk (two passes over registers: no cancellation)
+__global__ __launch_bounds__(256) void clip_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int n) {
+    const int b = blockIdx.y, c = blockIdx.x;
+    const int per = (n + NOISE_CHUNKS - 1) / NOISE_CHUNKS;
+    const int lo = c * per, hi = min(n, lo + per);
+    const float* xb = x + (size_t)b * n;
+    __shared__ float red[8];
+    float s = 0.f;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) s += xb[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const int cnt = max(hi - lo, 0);
+    const float mean = cnt > 0 ? (red[0] + red[1] + red[2] + red[3]) / (float)cnt : 0.f;
+    float m2 = 0.f;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) { const float d = xb[i] - mean; m2 += d * d; }
+    m2 = wave_sum(m2);
+    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = m2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* o = part + ((size_t)b * NOISE_CHUNKS + c) * 3;
+        o[0] = (float)cnt; o[1] = mean; o[2] = red[4] + red[5] + red[6] + red[7];
+    }
+}
+__global__ __launch_bounds__(256) void add_noise_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+                                                        const float* __restrict__ snr_lin, const float* __restrict__ part,
+                                                        float* __restrict__ out, int n) {
+    const int b = blockIdx.y;
+    // Chan's pairwise combination of the chunk statistics, in double (64 terms; every thread does it: no barrier)
+    double cn = 0.0, cm = 0.0, cM2 = 0.0;
+    for (int c = 0; c < NOISE_CHUNKS; ++c) {
+        const float* p = part + ((size_t)b * NOISE_CHUNKS + c) * 3;
+        const double k = p[0], mu = p[1], m2 = p[2];
+        if (k > 0.0) {
+            const double d = mu - cm, tot = cn + k;
+            cM2 += m2 + d * d * cn * k / tot;
+            cm += d * k / tot;
+            cn = tot;
+        }
+    }
+    const float sigma = (float)sqrt(cM2 / (cn - 1.0)) / snr_lin[b];
+    const size_t base = (size_t)b * n;
+    const int n4 = n / 4;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4*>(x + base)[i], z = reinterpret_cast<const float4*>(noise + base)[i];
+        float4 o;
+        o.x = a.x + z.x * sigma; o.y = a.y + z.y * sigma; o.z = a.z + z.z * sigma; o.w = a.w + z.w * sigma;
+        reinterpret_cast<float4*>(out + base)[i] = o;
+    }
+}
+extern "C" int sed_add_noise(const float* x, const float* noise, const float* snr_lin, float* part, float* out, int B, int n,
+                             hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n % 4 || n < 2 || B <= 0) return SED_ERR_ARG;
+    hipLaunchKernelGGL(clip_stats_kernel, dim3(NOISE_CHUNKS, B), dim3(256), 0, stream, x, part, n);
+    hipLaunchKernelGGL(add_noise_kernel, dim3(64, B), dim3(256), 0, stream, x, noise, snr_lin, part, out, n);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Median / max filter along time per class, both reference semantics, bit-exact (compare/select only).
 //   mode 0: src/postprocess/filter.py:4-36   even size -> size+1, replicate padding, true median
 //   mode 1: scipy.ndimage.median_filter as called at src/codec/decoder.py:91: window [i - k/2, i - k/2 + k),
