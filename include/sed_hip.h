@@ -73,6 +73,14 @@ int sed_median_filter_k(const float* in, float* out, const int* sizes, const flo
 int sed_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi, const float* bias,
                 const float* resF, float* outF, void* outH, void* outH2, const void* auxH, int ldc, float alpha,
                 int ksplit, int f16, hipStream_t stream);
+/* Number of CUs the persistent GEMM kernels (256 x 256 tiles: every forward / dX GEMM; the TN weight-gradient kernel's split count)
+ * size their grids for; 0 = all (default; the environment variable SED_GEMM_CUS is read when nothing was set).  The one process-wide
+ * setting of the library: a data-parallel job whose RCCL kernels run beside the backward leaves their CUs out (ddp.py).  The persistent
+ * kernels walk their tiles dynamically (per-XCD counters), so a workgroup that starts late only shortens the others' share. */
+int sed_gemm_set_cu_budget(int n_cus);
+/* Measurement aid: n_cus single-wave workgroups (one per CU) that idle for `usec` microseconds on `stream` -- the stand-in for
+ * communication kernels in tools/cu_steal.py (profiles/r4_cu_steal.txt).  Not used by the product path. */
+int sed_debug_hold_cus(int n_cus, int usec, hipStream_t stream);
 /* sed_gemm_nt / sed_gemm_qkv with a ROW-GROUP bias: row m additionally gets gbias[(m / gb_rows) * N + n] (fp32 [M / gb_rows, N]; gb_rows =
  * tokens per clip >= 128, M % gb_rows == 0; epilogues 0-3, 7, 8).  Carries the weight-rounding correction of the evaluation-mode encoder:
  * mean_t(x) . (W - f16(W))^T per clip, added to the F.linear results of src/models/passt/passt.py:332,342 and timm Mlp fc1 / fc2

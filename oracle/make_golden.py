@@ -627,7 +627,7 @@ TRAINSTEP_PROBES = ["backbone.patch_embed.proj.weight", "backbone.blocks.1.attn.
                     "classifier.weight", "at_adpater.0.mha.in_proj_weight", "at_adpater.1.bias"]
 
 
-def gen_trainstep(tag="trainstep", depth=2, feature_layer=2, n_steps=3, sizes=(2, 2, 2), extra_probes=()):
+def gen_trainstep(tag="trainstep", depth=2, feature_layer=2, n_steps=3, sizes=(2, 2, 2), extra_probes=(), probe_steps=None):
     """Three consecutive optimisation steps of the REFERENCE trainer itself (recipes/desed/finetune/train.py:Trainer.train,
     finetune2 settings: global student, sliding-window EMA teacher in train mode, AdamW groups from
     recipes/desed/finetune/passt/setting.py:get_params, ExponentialDown, update_ema), each run as a one-batch epoch so the
@@ -685,6 +685,8 @@ def gen_trainstep(tag="trainstep", depth=2, feature_layer=2, n_steps=3, sizes=(2
         out[f"s{step}_draw_kinds"] = np.array([k for k, _ in rec.log])
         sp, ep = name2p(tr.net.module if hasattr(tr.net, "module") else tr.net), name2p(tr.ema_net.module if hasattr(tr.ema_net, "module") else tr.ema_net)
         for i, n in enumerate(probes):
+            if probe_steps is not None and step not in probe_steps:
+                continue
             out[f"s{step}_stu{i}"] = t2n(sp[n]).reshape(-1)[:512].astype(np.float32).copy()
             out[f"s{step}_ema{i}"] = t2n(ep[n]).reshape(-1)[:512].astype(np.float32).copy()
         print(f"   step {step}: " + " ".join(f"{k}={v:.6f}" for k, v in scalars[-1].items()), flush=True)
@@ -694,6 +696,17 @@ def gen_trainstep(tag="trainstep", depth=2, feature_layer=2, n_steps=3, sizes=(2
                                                   feature_layer=feature_layer)))
     out["group_sizes"] = np.array([len(g["params"]) for g in opt.param_groups])
     save(tag, **out)
+
+
+def gen_trajectory():
+    """Thirty consecutive steps of the reference's own Trainer.train at depth 2 (recipes/desed/finetune/train.py:129-213): the six loss
+    terms, w_cons and the learning rates of every step, student / EMA probe parameters after steps 10, 20 and 30.  Same seeds, batches and
+    schedule as `trainstep` (whose three steps are the first three of this run)."""
+    gen_trainstep(tag="trajectory", n_steps=30, probe_steps=(9, 19, 29))
+    g = dict(np.load(os.path.join(GOLD, "trajectory.npz"), allow_pickle=False))
+    out = {k: v for k, v in g.items() if not k.endswith("_draw_kinds")}     # (the draw-kind lists of 30 steps are 60 % of the file)
+    out["probe_steps"] = np.asarray([9, 19, 29])
+    save("trajectory", **out)
 
 
 def gen_trainstep12():
@@ -1158,7 +1171,7 @@ def gen_val12():
     save("val12", **out)
 
 
-GENS = dict(val12=gen_val12, augment2=gen_augment2, pmamflops=gen_pmamflops, frontend=gen_frontend, augment=gen_augment, micro=gen_micro, full=gen_full, full12=gen_full12,
+GENS = dict(val12=gen_val12, augment2=gen_augment2, trajectory=gen_trajectory, pmamflops=gen_pmamflops, frontend=gen_frontend, augment=gen_augment, micro=gen_micro, full=gen_full, full12=gen_full12,
             schedule=gen_schedule, postprocess=gen_postprocess, losses=gen_losses, trainstep=gen_trainstep, trainstep12=gen_trainstep12, full12train=gen_full12_train, winbwd=gen_winbwd, evalpath=gen_evalpath, datapipe=gen_datapipe, pmam=gen_pmam, pmamstep=gen_pmamstep, pmamft=gen_pmamft)
 
 if __name__ == "__main__":

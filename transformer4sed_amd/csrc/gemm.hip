@@ -14,6 +14,7 @@
 // timm Mlp fc1/fc2 in the context blocks; the conv2d of passt.py:307 (as im2col GEMM);
 // src/models/passt/passt_sed.py:196 (mlm_mlp) and their autograd backward GEMMs.
 #include <stdlib.h>
+#include <atomic>
 
 #include "common.h"
 #include "../../include/sed_hip.h"
@@ -75,6 +76,11 @@ struct GemmArgs {
     // outH (hi) + out_lo and outF is not written.
     const bf16_t* res_lo;
     bf16_t* out_lo;
+    // Persistent 256^2 kernel, dynamic tile walk: 8 per-XCD tile counters + 1 exit counter, one 64-byte line each (int index 16 x).  A
+    // workgroup takes the next tile of ITS XCD's contiguous tile range from counter blockIdx.x & 7 (so the L2 grouping of the static walk
+    // is kept) instead of the fixed blockIdx.x + k gridDim.x: a workgroup that becomes resident late -- or only after the others have
+    // drained the range, when communication kernels hold CUs -- costs nothing instead of a whole column of tiles.  NULL = static walk.
+    int* tile_ctr;
 };
 
 #define TILE 128
@@ -662,6 +668,10 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
         for (int pass = 0; pass < (EPI == EPI_GELU ? 2 : 1); ++pass) {
             bf16_t* out = (EPI == EPI_GELU && pass == 1) ? g.outH2 : g.outH;
             if (out == nullptr) continue;
+            // (opaque to the optimiser: otherwise `out + lane column` is hoisted out of the persistent tile loop as a 64-bit per-lane value,
+            //  spilled around it in the register-tight variants and reloaded -- behind a vmcnt(0) -- at every tile's store phase)
+            int lc8 = (lane & 7) * 8;
+            asm volatile("" : "+v"(lc8));
             if constexpr (GB) {      // evaluation-mode encoder only (no saved pre-activation: one pass)
                 const float *rA, *rB;
                 const int bnd = gb_split(g, mb, rA, rB);
@@ -687,7 +697,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int row = (rb + u) * 8 + (lane >> 3);
-                    if (mb + row < g.M && row < 16 * RB) v3_st<uint4>(out + (size_t)(mb + row) * g.ldc + nb + (lane & 7) * 8, v[u]);
+                    if (mb + row < g.M && row < 16 * RB) v3_st<uint4>(out + (size_t)(mb + row) * g.ldc + nb + lc8, v[u]);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -848,7 +858,18 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)g.stagger) __builtin_amdgcn_s_sleep(16);
     }
-    for (int tl = blockIdx.x; tl < nwg; tl += tstep) {
+    // Dynamic walk (g.tile_ctr): the logical tiles tl with tl & 7 == x are XCD x's contiguous range (xcd_remap); index k of that range
+    // comes from the per-XCD counter.  The counter for tile i + 1 is read at the top of tile i (one lane) and handed to the other waves
+    // through one LDS word after the prologue barrier, so the ~1 us of a device-scope atomic is never waited for.
+    __shared__ int s_next_tile;
+    int* const dyn_ctr = g.tile_ctr != nullptr ? g.tile_ctr + 16 * (blockIdx.x & 7) : nullptr;
+    int tl = blockIdx.x;
+    if (dyn_ctr != nullptr) {
+        if (tid == 0) s_next_tile = atomicAdd(dyn_ctr, 1);
+        __syncthreads();
+        tl = __builtin_amdgcn_readfirstlane(s_next_tile) * 8 + (blockIdx.x & 7);
+    }
+    while (tl < nwg) {
     const int t = xcd_remap(tl, nwg);
     const int GM = g.group_m;
     const int group_size = GM * ntn, gid = t / group_size, first_m = gid * GM;
@@ -952,9 +973,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
 #define GX_STAMP(i)
 #endif
     // prologue: all of tile 0; then the three slots of tile 1 that the steady state would have issued during tile -1
+    int dyn_nxt = 0;
+    if (dyn_ctr != nullptr && tid == 0) dyn_nxt = atomicAdd(dyn_ctr, 1);     // next tile's index: returns under the prologue's DMA
     PP_DMA(1, 0) PP_DMA(0, 0) PP_DMA(2, 0) PP_DMA(3, 0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (dyn_ctr != nullptr && tid == 0) s_next_tile = dyn_nxt;     // (everybody read the previous value before this barrier; read again after the tile's last one)
     GX_STAMP(1)
     if (nk > 1) { PP_DMA(1, 1) PP_DMA(0, 1) PP_DMA(2, 1) }
     if (wm == 1) __builtin_amdgcn_s_barrier();   // second wave row: half a phase behind
@@ -999,7 +1023,21 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
 #else
     pp_epilogue<EPI, F16, GB, RB>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * (16 * RB), n0 + wn * 64, lane);
 #endif
-    if (tl + tstep < nwg) __syncthreads();   // the staging areas overlap the operand stages the next tile's DMA is about to fill
+    if (dyn_ctr != nullptr) {
+        __syncthreads();                     // (also orders the epilogue's staging reads before the next tile's DMA)
+        tl = __builtin_amdgcn_readfirstlane(s_next_tile) * 8 + (blockIdx.x & 7);
+    } else {
+        tl += tstep;
+        if (tl < nwg) __syncthreads();       // the staging areas overlap the operand stages the next tile's DMA is about to fill
+    }
+    }
+    if (dyn_ctr != nullptr && tid == 0) {
+        // last workgroup out re-arms the slot for its next user (every tile-counter atomic of a workgroup has returned before its exit atomic)
+        int* const base = g.tile_ctr;
+        if (atomicAdd(base + 16 * 8, 1) == (int)gridDim.x - 1) {
+#pragma unroll
+            for (int x = 0; x <= 8; ++x) atomicExch(base + 16 * x, 0);
+        }
     }
 }
 
@@ -1267,6 +1305,59 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     }
 }
 
+// Counter slots of the dynamic tile walk: a ring in device memory (zero at module load, every launch leaves its slot zeroed again), one
+// slot per launch so that GEMMs running concurrently on different streams never share counters.  A slot comes round again after
+// DYN_SLOTS launches -- far more than a stream queue holds.
+#define DYN_SLOTS 2048
+#define DYN_SLOT_INTS (16 * 9)
+__device__ int g_tile_counters[DYN_SLOTS * DYN_SLOT_INTS];
+static int* dyn_counter_slot() {
+    static int* base[64] = {};
+    static std::atomic<unsigned> next{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (base[dev] == nullptr) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tile_counters)) != hipSuccess) return nullptr;
+        base[dev] = (int*)p;
+    }
+    return base[dev] + (size_t)(next.fetch_add(1) % DYN_SLOTS) * DYN_SLOT_INTS;
+}
+// Number of CUs the persistent GEMM kernels size their grids for.  Default: all of them.  A data-parallel job whose collectives run
+// beside the backward (ddp.py) reserves the communication kernels' CUs by lowering it (sed_gemm_set_cu_budget / SED_GEMM_CUS): a
+// persistent workgroup that cannot become resident beside a communication kernel would otherwise start only after another one has exited.
+static std::atomic<int> g_cu_budget{0};
+static int cu_budget(int ncu_device) {
+    int b = g_cu_budget.load();
+    if (b <= 0) {
+        const char* e = getenv("SED_GEMM_CUS");
+        b = e ? atoi(e) : 0;
+    }
+    if (b <= 0 || b > ncu_device) b = ncu_device;
+    return b < 8 ? 8 : b;
+}
+// Measurement aid (tools/cu_steal.py): `n` single-wave workgroups, one per CU (81 KiB of LDS each: two cannot share a CU), that hold their
+// CUs for `usec` microseconds doing nothing -- a stand-in for the RCCL kernels of a data-parallel step, whose workgroups keep a persistent
+// GEMM workgroup (the whole register file of a CU) from becoming resident next to them.
+__global__ __launch_bounds__(64) void hold_cus_kernel(unsigned long long ticks, int* sink) {
+    extern __shared__ unsigned char hold_lds[];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    if (sink != nullptr && threadIdx.x == 1000) sink[0] = hold_lds[0];
+}
+extern "C" int sed_debug_hold_cus(int n_cus, int usec, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n_cus <= 0 || usec <= 0) return SED_ERR_ARG;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)hold_cus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 81 * 1024); attr = true; }
+    hipLaunchKernelGGL(hold_cus_kernel, dim3(n_cus), dim3(64), 81 * 1024, stream, (unsigned long long)usec * 100ull, (int*)nullptr);
+    return sed_check_launch();
+}
+extern "C" int sed_gemm_set_cu_budget(int n_cus) {
+    g_cu_budget.store(n_cus > 0 ? n_cus : 0);
+    return SED_OK;
+}
+
 extern "C" int sed_gemm_dw_tn(const void* dY, const void* X, int x_f16, int T, int M, int N, int ldy, int ldx, float* dW,
                               int ldc, float* dbias, float* workspace, int64_t workspace_bytes, hipStream_t stream) {
     (void)hipGetLastError();
@@ -1277,7 +1368,14 @@ extern "C" int sed_gemm_dw_tn(const void* dY, const void* X, int x_f16, int T, i
     const int tiles = cdiv(M, V3_T) * cdiv(N, V3_T), ktiles = T / BK;
     // one workgroup per CU and ONE round: tiles * ks <= 256 (rounding the split count up instead costs a second, nearly empty
     // round -- 36 tiles x 8 splits = 288 workgroups took twice the time of 36 x 7)
-    int ks = 256 / tiles;
+    static int ncu_dev_tn = 0;
+    if (ncu_dev_tn == 0) {
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        ncu_dev_tn = n;
+    }
+    int ks = cu_budget(ncu_dev_tn) / tiles;      // (the CUs a data-parallel job leaves to the GEMMs: see cu_budget)
     if (ks >= 8) ks &= ~7;        // whole splits per XCD (the kernel lays the splits out XCD-contiguously)
     if (ks > ktiles / 16) ks = ktiles / 16;
     if (ks < 1) ks = 1;
@@ -1320,13 +1418,15 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
         // weight-gradient streams fill the last round's idle CUs anyway and the shorter tiles cost 0.25 % (104.03 vs 103.77 ms, 3 A/B pairs).
         const char* rb_s = getenv("SED_GEMM_RB");
         const int rb_env = rb_s ? atoi(rb_s) : 8;
-        static int ncu = 0;
-        if (ncu == 0) {
+        static int ncu_probe = 0;
+        if (ncu_probe == 0) {
             int dev = 0, n = 0;
             (void)hipGetDevice(&dev);
             if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-            ncu = n & ~7;   // whole XCD rounds: blockIdx.x & 7 must stay the XCD of every tile a workgroup walks
+            ncu_probe = n;
         }
+        const int ncu_dev = ncu_probe;
+        const int ncu = cu_budget(ncu_dev) & ~7;   // whole XCD rounds: blockIdx.x & 7 must stay the XCD of every tile a workgroup walks
         // Tile height: rounds of workgroups x rows per tile is what the launch costs; 224-row tiles win when they fill the last round
         // that 256-row tiles leave mostly empty (M = 38080: 2 x 256 vs 2 x 224 for N = 768, 6 x 256 vs 6 x 224 for N = 2304).
         const int ntn = g.N / V3_T;
@@ -1336,6 +1436,11 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
         dim3 grid3((unsigned)(use7 ? t7 : t8), 1);
         gg.persist = (persist_env && (int)grid3.x > ncu) ? 1 : 0;
         if (gg.persist) grid3.x = ncu;
+        {
+            // SED_GEMM_DYN (read per launch; default 1): dynamic tile walk of the persistent form, 0 = the static walk (bit-identical results)
+            const char* dy = getenv("SED_GEMM_DYN");
+            gg.tile_ctr = (gg.persist && !(dy && atoi(dy) == 0)) ? dyn_counter_slot() : nullptr;
+        }
         {
             const char* st_s = getenv("SED_GEMM_STAGGER");      // experiment: start delay of every other workgroup, in 10 ns ticks
             gg.stagger = (gg.persist && st_s) ? atoi(st_s) : 0;
