@@ -81,6 +81,8 @@ int sed_gemm_set_cu_budget(int n_cus);
 /* Measurement aid: n_cus single-wave workgroups (one per CU) that idle for `usec` microseconds on `stream` -- the stand-in for
  * communication kernels in tools/cu_steal.py (profiles/r4_cu_steal.txt).  Not used by the product path. */
 int sed_debug_hold_cus(int n_cus, int usec, hipStream_t stream);
+/* Test aid: synchronises the device and returns the number of non-zero words in the dynamic-walk counter ring (0 when idle). */
+int sed_debug_tile_counters_dirty(int reserved);
 /* sed_gemm_nt / sed_gemm_qkv with a ROW-GROUP bias: row m additionally gets gbias[(m / gb_rows) * N + n] (fp32 [M / gb_rows, N]; gb_rows =
  * tokens per clip >= 128, M % gb_rows == 0; epilogues 0-3, 7, 8).  Carries the weight-rounding correction of the evaluation-mode encoder:
  * mean_t(x) . (W - f16(W))^T per clip, added to the F.linear results of src/models/passt/passt.py:332,342 and timm Mlp fc1 / fc2

@@ -130,6 +130,58 @@ def test_gemm_224_row_tiles_are_bit_identical_to_256_row_tiles(M, N, K, DT, monk
     assert e < 2e-3 * math.sqrt(K / 64) * (1 if DT == F16 else 8), e
 
 
+@pytest.mark.parametrize("M,N,K", [(38080, 768, 768), (38080, 2304, 768), (211904, 768, 768), (17997, 1024, 256)])
+def test_gemm_dynamic_tile_walk_is_bit_identical_to_the_static_walk(M, N, K, monkeypatch):
+    """The persistent 256^2 kernel takes its tiles from per-XCD counters (csrc/gemm.hip `tile_ctr`) instead of blockIdx.x + k gridDim.x.
+    Which workgroup computes a tile cannot change its value: every epilogue agrees BIT FOR BIT with the static walk -- alone on the GPU,
+    with 8 / 32 CUs held by another kernel for the whole launch (the stand-in for RCCL's kernels: late workgroups find the range drained),
+    with a reduced CU budget, and with two GEMMs running concurrently on two streams (one counter slot per launch); afterwards the whole
+    counter ring is zero again (every launch re-arms its slot)."""
+    from transformer4sed_amd._lib import lib
+    DT = F16
+    A = rnd(M, K, seed=31).to(DT)
+    B = rnd(N, K, scale=0.05, seed=32).to(DT)
+    bias, res = rnd(N, seed=33), rnd(M, N, seed=34)
+
+    def run():
+        out = {}
+        o = torch.full((M, N), 7.0, device=DEV); gemm_nt(A, B, ops.EPI_F32_RESID, bias=bias, res=res, outF=o); out["resid"] = o
+        h = torch.full((M, N), 3.0, dtype=DT, device=DEV); a = torch.full((M, N), 3.0, dtype=DT, device=DEV)
+        gemm_nt(A, B, ops.EPI_GELU, bias=bias, outH=h, outH2=a); out["gelu_pre"], out["gelu_act"] = h, a
+        o = torch.full((M, N), 3.0, dtype=DT, device=DEV); gemm_nt(A, B, ops.EPI_BF16, bias=bias, outH=o); out["h16"] = o
+        return out
+
+    def same(ref, got, what):
+        for name in ref:
+            assert torch.equal(ref[name], got[name]), (what, name, float((ref[name].float() - got[name].float()).abs().max()))
+    monkeypatch.setenv("SED_GEMM_DYN", "0")
+    ref = run(); torch.cuda.synchronize()
+    monkeypatch.setenv("SED_GEMM_DYN", "1")
+    same(ref, run(), "alone")
+    side = torch.cuda.Stream()
+    for held in (8, 32):
+        with torch.cuda.stream(side):
+            call("sed_debug_hold_cus", held, 20000)          # 20 ms: longer than the three GEMMs
+        torch.cuda._sleep(2_000_000)                          # (let the holders become resident first)
+        same(ref, run(), f"{held} CUs held")
+        torch.cuda.synchronize()
+    call("sed_gemm_set_cu_budget", 200)
+    try:
+        same(ref, run(), "CU budget 200")
+    finally:
+        call("sed_gemm_set_cu_budget", 0)
+    # two launches at once on two streams
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        got_side = run()
+    got_main = run()
+    torch.cuda.synchronize()
+    same(ref, got_side, "side stream"); same(ref, got_main, "main stream beside it")
+    assert lib()._raw_sed_debug_tile_counters_dirty(0) == 0
+    e = maxerr(got_main["resid"], A.float() @ B.float().t() + bias + res)
+    assert e < 2e-3 * math.sqrt(K / 64), e
+
+
 def test_split_precision_gemm():
     """[A_hi|A_lo|A_hi] . [W_hi|W_hi|W_lo]^T through the ordinary f16 GEMM ~ fp32 product (context-network path)."""
     from transformer4sed_amd.ops import split3

@@ -65,6 +65,8 @@ class _Lib:
 
     def call(self, name, *args):
         rc = getattr(self, "_raw_" + name)(*args)
+        if rc > 0 and name.startswith("sed_debug_"):
+            return rc           # (test aids return counts)
         if rc != 0:
             what = "bad argument" if rc == -1 else (f"HIP error {-rc - 1000}" if rc <= -1000 else "HIP launch failure")
             raise SedHipError(f"{name} failed with code {rc} ({what})")

@@ -1353,6 +1353,17 @@ extern "C" int sed_debug_hold_cus(int n_cus, int usec, hipStream_t stream) {
     hipLaunchKernelGGL(hold_cus_kernel, dim3(n_cus), dim3(64), 81 * 1024, stream, (unsigned long long)usec * 100ull, (int*)nullptr);
     return sed_check_launch();
 }
+// Test aid: number of non-zero words in the counter ring of the current device after a device synchronisation (must be 0 whenever no GEMM
+// is in flight: every launch re-arms its slot).  Returns the count (>= 0) or a negative error code.
+extern "C" int sed_debug_tile_counters_dirty(int reserved) {
+    (void)reserved;
+    if (hipDeviceSynchronize() != hipSuccess) return SED_ERR_LAUNCH;
+    static int host[DYN_SLOTS * DYN_SLOT_INTS];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tile_counters), sizeof(host)) != hipSuccess) return SED_ERR_LAUNCH;
+    int dirty = 0;
+    for (int i = 0; i < DYN_SLOTS * DYN_SLOT_INTS; ++i) dirty += host[i] != 0;
+    return dirty;
+}
 extern "C" int sed_gemm_set_cu_budget(int n_cus) {
     g_cu_budget.store(n_cus > 0 ? n_cus : 0);
     return SED_OK;
