@@ -392,6 +392,12 @@ def main():
                    "global_batch": B * world, "per_gpu_batch": B, "seq_len": "1190 encoder tokens / 1000 decoder frames",
                    "parallelism": f"dp{world}", "final_loss": loss},
     }
+    if getattr(trainer, "ddp", None) is not None:
+        st = trainer.ddp.last_stats
+        line["grad_exchange"] = {"dtype": str(trainer.ddp.comm_dtype).replace("torch.", ""), "collectives_per_step": st["collectives"],
+                                 "MB_per_step": round(st["bytes"] / 1e6, 1), "reserved_cus": trainer.ddp.reserve_cus,
+                                 "note": "stage-triggered all-reduce(AVG) of contiguous gradient-arena slices on the collective stream while "
+                                         "the backward continues (ddp.py); SED_DDP_COMM_DTYPE=bf16 halves the bytes"}
     if gflop_clip is not None and a.mode != "val":
         # fraction of the dense 16-bit MFMA peak over the whole step, on the FLOPs this build executes (algorithmic: no credit for the
         # 3x K of the split-precision GEMMs or for padded columns); the same on the reference's own schedule is reported beside it

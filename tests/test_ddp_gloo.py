@@ -37,12 +37,12 @@ def _layout():
     return out
 
 
-def _worker(rank, world, port, frozen_encoder):
+def _worker(rank, world, port, frozen_encoder, comm_dtype=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from transformer4sed_amd.ddp import GradBucketReducer
     net, opt = _FakeNet(), _FakeOpt(_layout())
-    red = GradBucketReducer(net, opt, min_bytes=0)
+    red = GradBucketReducer(net, opt, min_bytes=0, comm_dtype=comm_dtype)
     torch.manual_seed(rank)
     arena = torch.randn(opt.total)
     mine = arena.clone()
@@ -58,7 +58,20 @@ def _worker(rank, world, port, frozen_encoder):
     gathered = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine)
     want = sum(gathered) / world
-    assert torch.allclose(arena, want, atol=1e-6), (rank, float((arena - want).abs().max()))
+    if comm_dtype == torch.bfloat16:
+        # the exchange carries bf16 images: every rank's slice is rounded once (2^-9 relative), the mean once more; untouched padding /
+        # excluded slices keep their fp32 values, and every rank ends with the SAME numbers (bit-identical replicas)
+        img = sum(g.to(torch.bfloat16).float() for g in gathered) / world
+        err = (arena - img).abs()
+        assert float((err / (img.abs() + 1e-3)).max()) < 2 ** -7, float((err / (img.abs() + 1e-3)).max())
+        assert float((arena - want).abs().max()) < 2 ** -6 * float(want.abs().max())
+        both = [torch.zeros_like(arena) for _ in range(world)]
+        dist.all_gather(both, arena)
+        assert torch.equal(both[0], both[1])
+        assert red.last_stats["bytes"] == 2 * sum(b - a for a, b in red.last_issued) and red.last_stats["collectives"] == len(red.last_issued)
+    else:
+        assert torch.allclose(arena, want, atol=1e-6), (rank, float((arena - want).abs().max()))
+        assert red.last_stats["bytes"] == 4 * sum(b - a for a, b in red.last_issued) and red.last_stats["collectives"] == len(red.last_issued)
     dist.destroy_process_group()
 
 
@@ -69,6 +82,16 @@ def test_bucketed_allreduce_mean_world2(frozen_encoder):
     port = s.getsockname()[1]
     s.close()
     mp.spawn(_worker, args=(2, port, frozen_encoder), nprocs=2, join=True)
+
+
+def test_bucketed_allreduce_bf16_exchange_world2():
+    """Optional bf16 gradient exchange (half the bytes per step): same stage / slice logic, the collective runs on a bf16
+    image of each slice and the fp32 arena receives the mean -- within bf16 rounding of the fp32 exchange, identical on every rank."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, False, torch.bfloat16), nprocs=2, join=True)
 
 
 def test_stage_partition_covers_arena_once():

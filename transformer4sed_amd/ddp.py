@@ -59,9 +59,33 @@ def broadcast_buffers(net, src=0, group=None):
 
 
 class GradBucketReducer:
-    def __init__(self, net, optimizer, group=None, min_bytes=8 << 20):
+    def __init__(self, net, optimizer, group=None, min_bytes=8 << 20, comm_dtype=None, reserve_cus=None):
+        """`comm_dtype`: torch.float32 (default) exchanges the fp32 arena slices in place; torch.bfloat16 exchanges a bf16 image of every
+        slice -- half the bytes on the xGMI links (200 MB instead of 400 MB per finetune2 step) for one rounding of the
+        summed gradient to 8 significand bits, the precision its MFMA operands had anyway.  The image is cast on the compute stream when
+        the stage fires, reduced on the collective stream, and written back into the fp32 arena before the optimiser reads it.
+        Environment default: SED_DDP_COMM_DTYPE=bf16|fp32.
+        `reserve_cus`: CUs left to the communication kernels while this reducer lives (sed_gemm_set_cu_budget(total - reserve); default
+        SED_DDP_RESERVE_CUS or 0).  With the dynamic tile walk of the persistent GEMMs a reserve is not needed for correctness of the
+        overlap -- a late workgroup costs nothing (profiles/r4_cu_steal.txt) -- it only avoids queueing workgroups that will find no tile."""
+        import os
         self.net, self.opt, self.group = net, optimizer, group
+        if comm_dtype is None:
+            comm_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[os.environ.get("SED_DDP_COMM_DTYPE", "fp32")]
+        if comm_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("comm_dtype must be torch.float32 or torch.bfloat16")
+        self.comm_dtype = comm_dtype
+        self._stage = None            # bf16 staging arena (same offsets as the gradient arena), allocated on first use
+        self.stats = dict(collectives=0, bytes=0)        # of the current backward; `last_stats` = of the last finished one
+        self.last_stats = dict(collectives=0, bytes=0)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if reserve_cus is None:
+            reserve_cus = int(os.environ.get("SED_DDP_RESERVE_CUS", "0"))
+        self.reserve_cus = int(reserve_cus)
+        if self.reserve_cus > 0 and self.world > 1 and torch.cuda.is_available():
+            from .ops import call
+            total = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+            call("sed_gemm_set_cu_budget", max(8, total - self.reserve_cus))
         # a stage whose slices are smaller than this is not worth a collective of its own: it is carried to the next stage hook (or
         # to the end of backward) and merged with adjacent slices there
         self.min_elems = min_bytes // 4
@@ -116,20 +140,32 @@ class GradBucketReducer:
         if not self.fired and not self.carry and self._trainable_flags() != self._flags:
             self._build_ranges()
 
-    def _reduce(self, t):
+    def _reduce(self, t, back=None):
+        """all-reduce (mean) of `t` in place; `back` = (fp32 arena slice) when `t` is its bf16 image: written back after the wait."""
+        self.stats["collectives"] += 1
+        self.stats["bytes"] += t.numel() * t.element_size()
         if self.world == 1 and not self.force:
+            if back is not None:
+                back.copy_(t)
             return
         if self.use_avg:
-            self.pending.append(dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+            self.pending.append((dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None, t, back))
         else:
             w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self.pending.append((w, t))
+            self.pending.append((w, self.world, t, back))
 
     def _issue(self, ranges):
         arena = self.net._last_grad_arena
         for a, b in self._merge(ranges):
             self.issued.append((a, b))
-            self._reduce(arena[a:b])
+            if self.comm_dtype == torch.float32:
+                self._reduce(arena[a:b])
+            else:
+                if self._stage is None or self._stage.numel() != arena.numel() or self._stage.device != arena.device:
+                    self._stage = torch.empty(arena.numel(), dtype=self.comm_dtype, device=arena.device)
+                img = self._stage[a:b]
+                img.copy_(arena[a:b])                 # cast on the compute stream, behind the kernels that produced the slice
+                self._reduce(img, back=arena[a:b])
 
     def on_stage(self, stage):
         """Called by the engine as soon as every gradient of `stage` is final."""
@@ -146,12 +182,12 @@ class GradBucketReducer:
 
     def wait_pending(self):
         """Block the compute stream on every collective issued so far (the averaged slices are final afterwards)."""
-        for w in self.pending:
-            if isinstance(w, tuple):
-                w[0].wait()
-                w[1].div_(self.world)
-            else:
-                w.wait()
+        for w, div, t, back in self.pending:
+            w.wait()
+            if div is not None:
+                t.div_(div)
+            if back is not None:
+                back.copy_(t)                         # bf16 image -> fp32 arena (what the optimiser reads)
         self.pending = []
 
     def allreduce_grads(self, net=None):
@@ -168,6 +204,7 @@ class GradBucketReducer:
         self.fired = set()
         self.order = []
         self.last_issued, self.issued = self.issued, []
+        self.last_stats, self.stats = self.stats, dict(collectives=0, bytes=0)
 
     def sync_buffers(self, src=0):
         """Rank `src`'s BatchNorm running statistics become every rank's (see `broadcast_buffers` for the policy)."""
