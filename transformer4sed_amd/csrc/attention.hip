@@ -27,6 +27,17 @@
 // resource of this kernel (16 MFMAs = 512 matrix-pipe cycles per tile against 4 cycles per VALU instruction), so: max on the
 // raw scores (v_max3), scale and max-subtract in one packed FMA, raw v_exp_f32, packed row sums, masking only when MASKED.
 
+// single-instruction fp32 helpers the SLP vectoriser cannot fuse into v_pk_* forms
+#ifdef ATT_PLAIN
+__device__ __forceinline__ float sfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float sadd(float a, float b) { return a + b; }
+__device__ __forceinline__ float smul(float a, float b) { return a * b; }
+#else
+__device__ __forceinline__ float sfma(float a, float b, float c) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ float sadd(float a, float b) { float d; asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float smul(float a, float b) { float d; asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+#endif
+
 template <bool MASKED>
 __device__ __forceinline__ void softmax_tile(f32x16_t (&st)[2], f32x16_t (&o)[2], float& m_run, float& l_run, int j0, int N, int lg) {
     if (MASKED) {
@@ -38,6 +49,36 @@ __device__ __forceinline__ void softmax_tile(f32x16_t (&st)[2], f32x16_t (&o)[2]
                 st[kb][r] = key < N ? st[kb][r] : -1e30f;
             }
     }
+#ifdef ATT_ABL
+    // timing ablations (results are NOT a softmax): 1 = no running max / rescale, 2 = also no exp, 3 = no vector work at all
+    {
+#if ATT_ABL == 3
+        return;
+#else
+        const f32x2_t c2a = {SCALE_LOG2E, SCALE_LOG2E}, nm2a = {-8.f, -8.f};
+        f32x2_t ps2a = {0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f32x2_t x = {st[kb][r], st[kb][r + 1]};
+                x = __builtin_elementwise_fma(x, c2a, nm2a);
+#if ATT_ABL == 1
+                f32x2_t pv = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+#else
+                f32x2_t pv = x;
+#endif
+                st[kb][r] = pv.x; st[kb][r + 1] = pv.y;
+                ps2a += pv;
+            }
+        float psa = ps2a.x + ps2a.y;
+        psa += __shfl_xor(psa, 32, 64);
+        l_run += psa;
+        m_run = 8.f;
+        return;
+#endif
+    }
+#endif
     float mloc = -1e30f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -46,6 +87,21 @@ __device__ __forceinline__ void softmax_tile(f32x16_t (&st)[2], f32x16_t (&o)[2]
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float m_new = fmaxf(m_run, mloc * SCALE_LOG2E);   // SCALE_LOG2E > 0: max(c s) = c max(s)
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#ifdef ATT_SCALAR
+    // scalar (one element per instruction) form of the same arithmetic: packed fp32 operations issued beside MFMAs of other waves cost
+    // more than their own issue time (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
+    float psum = 0.f, psum1 = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float p0 = __builtin_amdgcn_exp2f(sfma(st[kb][r], SCALE_LOG2E, -m_new));
+            const float p1 = __builtin_amdgcn_exp2f(sfma(st[kb][r + 1], SCALE_LOG2E, -m_new));
+            st[kb][r] = p0; st[kb][r + 1] = p1;
+            psum = sadd(psum, p0); psum1 = sadd(psum1, p1);
+        }
+    psum = sadd(psum, psum1);
+#else
     const f32x2_t c2 = {SCALE_LOG2E, SCALE_LOG2E}, nm2 = {-m_new, -m_new};
     f32x2_t ps2 = {0.f, 0.f};
 #pragma unroll
@@ -59,14 +115,22 @@ __device__ __forceinline__ void softmax_tile(f32x16_t (&st)[2], f32x16_t (&o)[2]
             ps2 += pv;
         }
     float psum = ps2.x + ps2.y;
+#endif
     psum += __shfl_xor(psum, 32, 64);
     l_run = l_run * alpha + psum;
     m_run = m_new;
     // (a wave-uniform "max did not move" skip costs more in register copies at the join than the 16 packed multiplies)
+#ifdef ATT_SCALAR
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = smul(o[i][r], alpha);
+#else
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+#endif
 }
 
 // NQ = query blocks (of 32) per wave: 2 for the bulk of the sequence (256 queries per workgroup: every K / V^T fragment
@@ -123,6 +187,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         const unsigned char* lk = lds[buf][0];
         const unsigned char* lv = lds[buf][1];
         f32x16_t st[NQ][2];
+#ifdef ATT_QKIL
+        // the two key blocks' accumulator chains interleaved: consecutive MFMAs never depend on each other
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const s16x8_t kfr = lds_frag_rows(lk, 32 * kb + lr, 2 * s + lg);
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) st[u][kb] = mfma32t<F16>(kfr, qf[u][s], s == 0 ? zero16 : st[u][kb]);
+            }
+#else
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -131,6 +206,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
                 for (int u = 0; u < NQ; ++u) st[u][kb] = mfma32t<F16>(kfr, qf[u][s], s == 0 ? zero16 : st[u][kb]);  // C = inline 0
             }
+#endif
         // online softmax per query block (log2 domain); keys >= N are masked on the last tile only
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
