@@ -85,15 +85,34 @@ def enc_blocks(x, R):
     return layers
 
 
+def dgemm(a, w, name, R):
+    """One context-network GEMM a @ w^T under the operand-term mode R["dec_mode"][name] (default: R["dec_gemm"]):
+    exact | half (a_hi w_hi) | split (a_hi w_hi + a_lo w_hi + a_hi w_lo) | a2 (a_hi w_hi + a_lo w_hi: weight lo term dropped) |
+    w2 (a_hi w_hi + a_hi w_lo: activation lo term dropped)."""
+    mode = R.get("dec_mode", {}).get(name, R["dec_gemm"])
+    if mode == "exact":
+        return a @ w.t()
+    ah, wh = a.half().float(), w.half().float()
+    if mode == "half":
+        return ah @ wh.t()
+    al, wl = (a - ah).half().float(), (w - wh).half().float()
+    out = ah @ wh.t()
+    if mode in ("split", "a2"):
+        out = out + al @ wh.t()
+    if mode in ("split", "w2"):
+        out = out + ah @ wl.t()
+    return out
+
+
 def relpos(y, pos, p, R):
     Bx, T, D = y.shape
     sp = lambda t: split(t, R["dec_split_is_split"]) if R["dec_gemm"] == "split" else h(t, R["dec_gemm"] == "half")
-    qkv = sp(y) @ sp(sd[p + "in_proj.weight"]).t() + sd[p + "in_proj.bias"]
+    qkv = dgemm(y, sd[p + "in_proj.weight"], "in_proj", R) + sd[p + "in_proj.bias"]
     q, k, v = qkv.chunk(3, dim=-1)
     q = q.reshape(Bx, T, H, 64)
     k = h(k, R["dec_qk"]).reshape(Bx, T, H, 64).permute(0, 2, 1, 3)
     v = h(v, R["dec_v"]).reshape(Bx, T, H, 64).permute(0, 2, 1, 3)
-    pe = h(sp(pos) @ sp(sd[p + "linear_pos.weight"]).t(), R["dec_qk"]).reshape(-1, H, 64).permute(1, 0, 2)
+    pe = h(dgemm(pos, sd[p + "linear_pos.weight"], "linear_pos", R), R["dec_qk"]).reshape(-1, H, 64).permute(1, 0, 2)
     qu = h(q + sd[p + "pos_bias_u"], R["dec_qk"]).permute(0, 2, 1, 3)
     qv = h(q + sd[p + "pos_bias_v"], R["dec_qk"]).permute(0, 2, 1, 3)
     ac = qu @ k.transpose(-2, -1)
@@ -106,7 +125,7 @@ def relpos(y, pos, p, R):
     pexp = torch.exp(s - m)
     o = (h(pexp, R["dec_p"]) @ v) / pexp.sum(-1, keepdim=True)
     o = o.permute(0, 2, 1, 3).reshape(Bx, T, D)
-    return sp(o) @ sp(sd[p + "out_proj.weight"]).t() + sd[p + "out_proj.bias"]
+    return dgemm(o, sd[p + "out_proj.weight"], "out_proj", R) + sd[p + "out_proj.bias"]
 
 
 def decoder(x, R):
@@ -119,8 +138,8 @@ def decoder(x, R):
         y = O._ln(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5)
         x = y + relpos(y, pos, p + "attn.", R)
         hh = O._ln(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5)
-        a = F.gelu(sp(hh) @ sp(sd[p + "mlp.fc1.weight"]).t() + sd[p + "mlp.fc1.bias"])
-        x = x + (sp(a) @ sp(sd[p + "mlp.fc2.weight"]).t() + sd[p + "mlp.fc2.bias"])
+        a = F.gelu(dgemm(hh, sd[p + "mlp.fc1.weight"], "fc1", R) + sd[p + "mlp.fc1.bias"])
+        x = x + (dgemm(a, sd[p + "mlp.fc2.weight"], "fc2", R) + sd[p + "mlp.fc2.bias"])
     return x
 
 
@@ -166,6 +185,19 @@ with torch.no_grad():
         "PRODUCT + per-clip mean correction": dict(enc_w=ALLW, wcorr="mean", enc_act=True, enc_qkv=True, enc_p=True, dec_gemm="split", dec_qk=True, dec_v=True, dec_p=True),
         "PRODUCT": dict(enc_w=ALLW, enc_act=True, enc_qkv=True, enc_p=True, dec_gemm="split", dec_qk=True, dec_v=True, dec_p=True),
     }
+    if os.environ.get("SIM_DEC_TERMS"):
+        # which operand terms the five context-network GEMMs need: each GEMM alone with one term dropped, against the full split
+        DEC = dict(dec_gemm="split", dec_qk=True, dec_v=True, dec_p=True)
+        cases = {"DECODER product (all GEMMs 3 terms)": DEC}
+        for g_ in ("in_proj", "linear_pos", "out_proj", "fc1", "fc2"):
+            for m_ in ("a2", "w2", "half"):
+                cases[f"decoder, {g_}: {m_}"] = {**DEC, "dec_mode": {g_: m_}}
+        for m_ in ("a2", "w2"):
+            cases[f"decoder, ALL GEMMs: {m_}"] = {**DEC, "dec_mode": {g_: m_ for g_ in ("in_proj", "linear_pos", "out_proj", "fc1", "fc2")}}
+        ENC = dict(enc_w=ALLW, enc_act=True, enc_qkv=True, enc_p=True)
+        cases["PRODUCT (train mode: f16 encoder weights)"] = {**ENC, **DEC}
+        for m_ in ("a2", "w2"):
+            cases[f"PRODUCT, ALL decoder GEMMs: {m_}"] = {**ENC, **DEC, "dec_mode": {g_: m_ for g_ in ("in_proj", "linear_pos", "out_proj", "fc1", "fc2")}}
     for name, ch in cases.items():
         z = run({**BASE, **ch}, x0)
         e1 = float((torch.sigmoid(z) - torch.sigmoid(ref)).abs().max())

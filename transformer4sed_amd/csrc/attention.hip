@@ -14,6 +14,8 @@
 //   (the MFMA k-index permutation is chosen to match the accumulator row pattern, so no cross-lane traffic).
 // 4 waves x 32 queries per workgroup, 64-key tiles, K and V^T tiles double buffered in XOR-swizzled LDS,
 // next tile's global loads in flight during the MFMA phase.
+#include <stdlib.h>
+#include <string.h>
 #include "common.h"
 #include "../../include/sed_hip.h"
 
@@ -254,11 +256,168 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// forward, K / V tiles staged by LDS-DMA (round 4).  Same arithmetic, tile images and fragment reads as mhsa_fwd_kernel; what changes is how
+// a tile reaches LDS: `buffer_load ... lds` (1 KiB = 8 rows per wave-instruction, 4 per wave and tile) instead of global -> 16 VGPRs ->
+// ds_write_b128.  The register path cost the LDS as much as the fragment reads did (a ds_write_b128 moves its 5 source dwords at 2
+// cycles each: ~13 cycles per KiB against 4 for a read) and its 16 staging registers.  The DMA writes lane l's 16 bytes at piece base
+// + 16 l, so the XOR swizzles of the K image (chunk ^ (row >> 1) & 7) and of the V image (chunk ^ ((row >> 1) & 1) << 2) are applied on the
+// SOURCE address; rows past the sequence end read zeros through the buffer descriptor (no clamped duplicates).
+// ---------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* att_lds_ptr_t;
+template <int OFF>
+__device__ __forceinline__ unsigned long long att_tr(unsigned addr) {
+    unsigned long long v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ s16x8_t att_frag(unsigned long long lo, unsigned long long hi) {
+    const unsigned w[4] = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+    s16x8_t f;
+    __builtin_memcpy(&f, w, 16);
+    return f;
+}
+#ifndef WPE_DMA
+#define WPE_DMA 3
+#endif
+
+template <bool F16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE_DMA, WPE_DMA))) void mhsa_fwd_dma_kernel(
+    const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
+    float* __restrict__ LSE, int N, int H) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][KVB * 128];  // [buf][K | V]
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const bf16_t* Qb = Q + (size_t)bh * N * HD;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(K + (size_t)bh * N * HD), 0, N * HD * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(V + (size_t)bh * N * HD), 0, N * HD * 2, 0x00020000);
+    // this wave's two pieces of a tile: rows 8 p .. 8 p + 7, p = 2 wave + e; lane -> (row, stored chunk slot)
+    int vok[2], vov[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int row = 8 * (2 * wave + e) + (lane >> 3), cs = lane & 7;
+        vok[e] = row * 128 + ((cs ^ ((row >> 1) & 7)) << 4);
+        vov[e] = row * 128 + ((cs ^ (((row >> 1) & 1) << 2)) << 4);
+    }
+#define ATT_DMA(T_, BUF_)                                                                                                            \
+    {                                                                                                                                \
+        const int so_ = (T_) * (KVB * 128);                                                                                          \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                                              \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (att_lds_ptr_t)(lds[BUF_][0] + (2 * wave + e) * 1024), 16, vok[e], so_, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (att_lds_ptr_t)(lds[BUF_][1] + (2 * wave + e) * 1024), 16, vov[e], so_, 0, 0); \
+        }                                                                                                                            \
+    }
+    s16x8_t qf[4];
+    {
+        int qrow = q0 + lr;
+        qrow = qrow < N ? qrow : N - 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const s16x8_t*>(Qb + (size_t)qrow * HD + 16 * s + 8 * lg);
+    }
+    f32x16_t o[2];
+    float m_run = -1e30f, l_run = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    const int ntiles = (N + KVB - 1) / KVB;
+    // lane part of the V^T fragment address (lds_frag_vt): key row 4 lg + (a >> 2) of a 16-key block, d block 0 (block 1: ^ 64)
+    const unsigned vaddr = (unsigned)(size_t)&lds[0][0][0] + (4 * lg + ((lane & 15) >> 2)) * 128 + (((lane & 15) >> 3) << 6) + ((lane >> 4) & 1) * 32 +
+                           8 * (lane & 3);
+    ATT_DMA(0, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pin_frags(qf);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1, j0 = t * KVB;
+        if (t + 1 < ntiles) {
+            if (buf) ATT_DMA(t + 1, 0) else ATT_DMA(t + 1, 1)
+        }
+        const unsigned char* lk = lds[buf][0];
+        const unsigned char* lv = lds[buf][1];
+        f32x16_t st[2];
+#ifndef ATT_NO_KPRE
+        {   // all eight K fragments requested before the first MFMA: their LDS latency is paid once per tile, not once per MFMA
+            s16x8_t kf[2][4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) kf[kb][s] = lds_frag_rows(lk, 32 * kb + lr, 2 * s + lg);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) st[kb] = mfma32t<F16>(kf[kb][s], qf[s], s == 0 ? zero16 : st[kb]);
+        }
+#else
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                st[kb] = mfma32t<F16>(lds_frag_rows(lk, 32 * kb + lr, 2 * s + lg), qf[s], s == 0 ? zero16 : st[kb]);
+#endif
+        if (j0 + KVB > N) softmax_tile<true>(st, o, m_run, l_run, j0, N, lg);
+        else softmax_tile<false>(st, o, m_run, l_run, j0, N, lg);
+        // V^T fragments by transposing reads issued as inline asm: through the builtin the compiler's wait-count pass assumes a read may
+        // alias the LDS-DMA in flight and puts `s_waitcnt vmcnt(0)` -- the NEXT tile's arrival -- in front of the first one.  Two fragment
+        // sets, four steps (key blocks of 16): reads of step j + 2 are issued behind the MFMAs of step j, counted lgkmcnt waits.
+        {
+            const unsigned va = vaddr ^ (buf << 14);
+            unsigned long long vl[2][2], vh[2][2];
+#define ATT_RDV(SET, J)                                                                                                   \
+            vl[SET][0] = att_tr<8192 + (J) * 2048>(va); vh[SET][0] = att_tr<8192 + (J) * 2048 + 1024>(va);                \
+            vl[SET][1] = att_tr<8192 + (J) * 2048>(va ^ 64); vh[SET][1] = att_tr<8192 + (J) * 2048 + 1024>(va ^ 64);
+#define ATT_PV(SET, J, WAIT)                                                                                              \
+            {                                                                                                             \
+                const s16x8_t pf = pack_frag_t<F16>(st[(J) >> 1], (J) & 1);                                               \
+                asm volatile("s_waitcnt lgkmcnt(" #WAIT ")" : "+v"(vl[SET][0]), "+v"(vh[SET][0]), "+v"(vl[SET][1]), "+v"(vh[SET][1]) :: "memory"); \
+                _Pragma("unroll") for (int db = 0; db < 2; ++db) o[db] = mfma32t<F16>(att_frag(vl[SET][db], vh[SET][db]), pf, o[db]); \
+            }
+            ATT_RDV(0, 0) ATT_RDV(1, 1)
+            ATT_PV(0, 0, 4)
+            ATT_RDV(0, 2)
+            ATT_PV(1, 1, 4)
+            ATT_RDV(1, 3)
+            ATT_PV(0, 2, 4)
+            ATT_PV(1, 3, 0)
+#undef ATT_RDV
+#undef ATT_PV
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile t + 1 have landed ...
+        __syncthreads();                                      // ... and everybody's; nobody reads tile t any more
+    }
+#undef ATT_DMA
+    const int q = q0 + lr;
+    if (q < N) {
+        const float inv = 1.0f / l_run;
+        bf16_t* orow = O + ((size_t)b * N + q) * (H * HD) + h * HD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                uint2 pk;
+                pk.x = pack2<F16>(o[db][4 * qd] * inv, o[db][4 * qd + 1] * inv);
+                pk.y = pack2<F16>(o[db][4 * qd + 2] * inv, o[db][4 * qd + 3] * inv);
+                *reinterpret_cast<uint2*>(orow + 32 * db + 8 * qd + 4 * lg) = pk;
+            }
+        if (lg == 0 && LSE != nullptr) LSE[(size_t)bh * N + q] = m_run + log2f(l_run);  // log2 domain
+    }
+}
+
 template <bool F16>
 static void launch_mhsa_fwd(const void* Q, const void* K, const void* Vt, void* O, float* LSE, int B, int H, int N, int Npad,
                             hipStream_t stream) {
     // NQ = 2 (256-query workgroups) halves LDS traffic per MFMA but drops to one wave per SIMD (202 VGPRs) and measured
     // slower on MI355X (24.9 vs 20.8 ms/step); NQ = 1 (two waves per SIMD) is the shipped configuration.
+    // SED_MHSA_FWD=reg: the register-staged kernel (A/B, tests); default: K / V tiles by LDS-DMA (needs N * 128 B < 2 GiB per head: always)
+    static const bool reg_path = getenv("SED_MHSA_FWD") && !strcmp(getenv("SED_MHSA_FWD"), "reg");
+    if (!reg_path) {
+        hipLaunchKernelGGL((mhsa_fwd_dma_kernel<F16>), dim3(cdiv(N, 128), B * H), dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,
+                           (const bf16_t*)Vt, (bf16_t*)O, LSE, N, H);
+        return;
+    }
     hipLaunchKernelGGL((mhsa_fwd_kernel<F16, 1>), dim3(cdiv(N, 128), B * H), dim3(256), 0, stream, (const bf16_t*)Q,
                        (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, LSE, N, Npad, H, 0);
 }
