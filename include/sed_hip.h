@@ -73,6 +73,12 @@ int sed_median_filter_k(const float* in, float* out, const int* sizes, const flo
 int sed_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi, const float* bias,
                 const float* resF, float* outF, void* outH, void* outH2, const void* auxH, int ldc, float alpha,
                 int ksplit, int f16, hipStream_t stream);
+/* sed_gemm_qkv (all its outputs) on two of the three split-precision terms: A plain f16 [M, K], Wsplit the split weight image [N, 3K] =
+ * [hi | hi | lo]; result A . (hi + lo)^T.  The context network's in_proj (src/models/transformer/transformerXL.py:382-384), whose output is
+ * insensitive to the activation's lo part (tools/err_sim.py).  256 x 256 kernel: M >= 1024. */
+int sed_gemm_qkv_w2s(const void* A, const void* Wsplit, const float* bias, int M, int K, int heads, int seq, int seq_pad, void* q,
+                     void* k, void* v, void* qt, void* kt, void* vt, void* q2, void* q2t, const float* pos_u, const float* pos_v,
+                     int f16, hipStream_t stream);
 /* Number of CUs the persistent GEMM kernels (256 x 256 tiles: every forward / dX GEMM; the TN weight-gradient kernel's split count)
  * size their grids for; 0 = all (default; the environment variable SED_GEMM_CUS is read when nothing was set).  The one process-wide
  * setting of the library: a data-parallel job whose RCCL kernels run beside the backward leaves their CUs out (ddp.py).  The persistent

@@ -375,6 +375,44 @@ def test_transpose_and_dw():
     e = maxerr(dW, ref); report("dW gemm", e, float(ref.abs().max())); assert e < 2e-2
 
 
+def test_gemm_qkv_two_of_three_split_terms():
+    """sed_gemm_qkv_w2s (the context network's in_proj): plain f16 activations against the split weight image [hi | hi | lo], the B walk
+    skipping the middle third -> A . (hi + lo)^T.  Bit-identical to the three-term head-split GEMM fed an activation image whose lo part
+    is zero (same products, same order, the extra third adds exact zeros at the end), all eight outputs, and within f16 output rounding of
+    the fp32 product with the UNROUNDED weight."""
+    from transformer4sed_amd.ops import split3
+    B, N, Hh = 3, 1000, 12            # M = 3000: the 256 x 256 kernel's domain, ragged last tile
+    Npad = pad64(N)
+    M = B * N
+    x32 = rnd(M, 768, seed=7)
+    x = x32.half()
+    W32 = rnd(2304, 768, scale=0.05, seed=8)
+    b = rnd(2304, seed=9)
+    u, v = rnd(Hh, 64, seed=10), rnd(Hh, 64, seed=11)
+    Ws = split3(W32, 2304, 768, weight=True)                     # [hi | hi | lo]
+    x3 = torch.cat([x, torch.zeros_like(x), x], dim=1).contiguous()    # activation image [hi | 0 | hi]
+    outs = []
+    for which in range(2):
+        mk = lambda: torch.full((B * Hh, N, 64), 9.0, dtype=F16, device=DEV)
+        mkt = lambda: torch.zeros(B * Hh, 64, Npad, dtype=F16, device=DEV)
+        q, k, vv, q2 = mk(), mk(), mk(), mk()
+        qt, kt, vt, q2t = mkt(), mkt(), mkt(), mkt()
+        if which == 0:
+            call("sed_gemm_qkv_w2s", x, Ws, b, M, 768, Hh, N, Npad, q, k, vv, qt, kt, vt, q2, q2t, u, v, 1)
+        else:
+            call("sed_gemm_qkv", x3, Ws, b, M, 3 * 768, Hh, N, Npad, q, k, vv, qt, kt, vt, q2, q2t, u, v, 1)
+        outs.append((q, k, vv, q2, qt, kt, vt, q2t))
+    for a_, b_, nm in zip(outs[0], outs[1], ("q", "k", "v", "q2", "qt", "kt", "vt", "q2t")):
+        assert torch.equal(a_, b_), (nm, float((a_.float() - b_.float()).abs().max()))
+    ref = (x.float() @ W32.t() + b).view(B, N, 3, Hh, 64).permute(2, 0, 3, 1, 4)
+    uu = u.view(1, Hh, 1, 64).expand(B, Hh, N, 64)
+    e = maxerr(outs[0][0], (ref[0] + uu).reshape(B * Hh, N, 64)); report("qkv two-of-three terms: q + u", e); assert e < 4e-3
+    e = maxerr(outs[0][1], ref[1].reshape(B * Hh, N, 64)); report("qkv two-of-three terms: k", e); assert e < 4e-3
+    # ... and the point of the weight's lo term: against the f16-rounded weight alone the same check is an order of magnitude off the weight error
+    e_half = float((x.float() @ (W32.half().float() - W32).t()).abs().max())
+    report("qkv: what the weight's lo term carries (max |x . (f16(W) - W)^T|)", e_half)
+
+
 @pytest.mark.parametrize("DT", [BF16, F16])
 def test_gemm_qkv_split(DT):
     BF16 = DT

@@ -58,6 +58,10 @@ struct GemmArgs {
     // Two-term weights (256^2 kernel, evaluation-mode encoder): B rows are [f16(W) | f16(W - f16(W))] over K = 2 * k_wrap * 64 and the
     // A panel (k_wrap K tiles wide) is walked twice -- the fp32 weight to ~2^-19 against the same f16 activations.  0 = off.
     int k_wrap;
+    // ... and, when the B rows are a split-precision weight image [hi | hi | lo] over 3 * k_wrap K tiles (context network), the number of B
+    // K tiles to skip once the A panel has wrapped: the walk then multiplies A . hi^T and A . lo^T (b_skip = k_wrap), dropping the a_lo
+    // term of the three-term product.
+    int b_skip;
     // Persistent 256^2 kernel: workgroups with an odd (blockIdx.x >> 3) start `stagger` ticks of the 100 MHz real-time counter late, so
     // that their store phases fall into the other half's main loops instead of all 256 CUs hitting HBM in lock-step.  0 = off.
     int stagger;
@@ -905,7 +909,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     }
 #define PP_DMA(SL, KT)                                                                                                    \
     {                                                                                                                     \
-        const int kt_ = (GB == 2 && ((SL) == 0 || (SL) == 3) && (KT) >= g.k_wrap) ? (KT) - g.k_wrap : (KT);              \
+        const int kt_ = (GB == 2 && (KT) >= g.k_wrap) ? (((SL) == 0 || (SL) == 3) ? (KT) - g.k_wrap : (KT) + g.b_skip) : (KT); \
         const int so_ = kt_ * (BK * 2), st_ = ((KT) & 1) << 15;                                                           \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? rb : ra, (lds_ptr_t)(lds3 + st_ + ld_[SL][0]), 16, vo[SL][0], so_, 0, 0); \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? rb : ra, (lds_ptr_t)(lds3 + st_ + ld_[SL][1]), 16, vo[SL][1], so_, 0, 0); \
@@ -1625,6 +1629,16 @@ extern "C" int sed_gemm_nt_cols(const void* A, const void* B, int M, int N, int 
 static int gemm_qkv_impl(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq,
                          int seq_pad, void* q, void* k, void* v, void* qt, void* kt, void* vt, void* q2,
                          void* q2t, const float* pos_u, const float* pos_v, int f16, const float* gbias, int gb_rows, hipStream_t stream, int two_term = 0);
+// the context network's in_proj on TWO of the three split-precision terms: A = plain f16 activations [M, K], W = the split weight image
+// [N, 3K] = [hi | hi | lo] (sed_weight_images); computes A . (hi + lo)^T -- the weight to ~2^-22, the activation rounded once.  Which terms
+// the posteriors need per GEMM: tools/err_sim.py (SIM_DEC_TERMS=1): in_proj is insensitive to the activation's lo part (logit error
+// 3.96e-4 -> 5.4e-4) and sensitive to the weight's (1.9e-3).  All outputs of sed_gemm_qkv.
+extern "C" int sed_gemm_qkv_w2s(const void* A, const void* Wsplit, const float* bias, int M, int K, int heads, int seq, int seq_pad, void* q,
+                                void* k, void* v, void* qt, void* kt, void* vt, void* q2, void* q2t, const float* pos_u, const float* pos_v,
+                                int f16, hipStream_t stream) {
+    if (!(f16 & 1) || M < 1024) return SED_ERR_ARG;
+    return gemm_qkv_impl(A, Wsplit, bias, M, K, heads, seq, seq_pad, q, k, v, qt, kt, vt, q2, q2t, pos_u, pos_v, f16, nullptr, 0, stream, 2);
+}
 extern "C" int sed_gemm_qkv(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq,
                             int seq_pad, void* q, void* k, void* v, void* qt, void* kt, void* vt, void* q2,
                             void* q2t, const float* pos_u, const float* pos_v, int f16, hipStream_t stream) {
@@ -1667,6 +1681,7 @@ static int gemm_qkv_impl(const void* A, const void* W, const float* bias, int M,
     if (two_term) {
         if (K % BK || gbias != nullptr) return SED_ERR_ARG;
         g.k_wrap = K / BK; g.K = 2 * K; g.ldb = 2 * K;
+        if (two_term == 2) { g.ldb = 3 * K; g.b_skip = K / BK; }      // W = [hi | hi | lo]: walk hi, then lo
     }
     g.ncols = g.N;
     g.bias = bias;

@@ -94,6 +94,11 @@ class SedEngine:
         self.ln_fold = os.environ.get("SED_LN_FOLD", "1") != "0"
         self.ln_bwd16 = os.environ.get("SED_LN_BWD16", "1") != "0"
         self.ln_planes = os.environ.get("SED_LN_PLANES", "1") != "0"      # folded blocks: residual stream as two f16 planes between producers
+        # Context-network GEMMs that do not need all three split-precision terms (tools/err_sim.py SIM_DEC_TERMS=1: logit error of the whole
+        # decoder 3.96e-4 with three terms everywhere): in_proj without the activation's lo part (5.4e-4; the weight's lo part is the one that
+        # matters there: 1.9e-3 without it) -> two K passes instead of three on the largest decoder GEMM, and its LayerNorm writes a plain f16
+        # image; linear_pos on plain f16 operands (5.3e-4).  out_proj / fc1 / fc2 keep three terms.  SED_DEC_TERMS=3 restores three everywhere.
+        self.dec_terms2 = os.environ.get("SED_DEC_TERMS", "2") != "3"
         self._genc16 = None
         self._dw_stream = None
         self._dw_pending = False
@@ -256,7 +261,7 @@ class SedEngine:
         call("sed_weight_images", self._wimg_desc, self._wimg_n, self._wimg_tiles)
         return self.cache
 
-    def _pos(self, T, dev, Dm=D):
+    def _pos(self, T, dev, Dm=D, want_plain=True):
         key = (T, str(dev), Dm)
         if key not in self.pos_cache:
             R = 2 * T - 1
@@ -267,10 +272,11 @@ class SedEngine:
             pos16 = tab.to(self.act).contiguous()
             posT16 = torch.empty(Dm, Rpad, dtype=BF16, device=dev)
             transpose_bf16(tab, Rpad, Dm, posT16)
-            if self.split:
-                pos16 = split3(tab, Rpad, Dm)
-            self.pos_cache[key] = (pos16, posT16, Rpad)
-        return self.pos_cache[key]
+            pos16s = split3(tab, Rpad, Dm) if self.split else None
+            self.pos_cache[key] = (pos16, posT16, Rpad, pos16s)
+        ent = self.pos_cache[key]
+        # (pos16: split image [hi | lo | hi] when the split-precision linear_pos GEMM reads it, the plain f16 table for `dec_terms2`)
+        return (ent[3] if (self.split and not (self.dec_terms2 and want_plain)) else ent[0]), ent[1], ent[2]
 
     # ------------------------------------------------------------------ encoder
     def _encoder_fwd(self, W, mel, tstarts, tp, toffsets, save, want_frame):
@@ -488,7 +494,7 @@ class SedEngine:
         B, T, _ = x.shape
         Tpad = pad64(T)
         M = B * T
-        pos16, posT16, Rpad = self._pos(T, dev)
+        pos16, posT16, Rpad = self._pos(T, dev, want_plain=M >= 1024)
         E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
         A16 = self.act
         f16 = 1 if A16 == F16 else 0
@@ -507,17 +513,23 @@ class SedEngine:
             in_scale = math.sqrt(D) if li == 0 else 1.0
             wk = (lambda n: W[n].ws) if SP else (lambda n: W[n].w)   # forward operand image of a decoder weight
             KD = 3 * D if SP else D
-            y16 = E(M, 3 * D, dt=F16) if SP else E(M, D, dt=A16)      # split precision: the LayerNorm writes the [hi | lo | hi] image itself
+            T2 = SP and self.dec_terms2 and M >= 1024       # in_proj / linear_pos on fewer terms (see `dec_terms2`; the 256^2 kernel's domain)
+            # split precision: the LayerNorm writes the [hi | lo | hi] image itself (two-term in_proj: the plain f16 image is all it reads)
+            y16 = E(M, 3 * D, dt=F16) if (SP and not T2) else E(M, D, dt=A16)
             y32 = E(B, T, D)
             mean1, rstd1 = (E(M), E(M)) if save else (None, None)
             call("sed_layernorm_fwd", cur, self.P(p + "norm1.weight"), self.P(p + "norm1.bias"), 1e-5, in_scale, y16,
-                 y32, mean1, rstd1, M, D, 4 if SP else f16)
+                 y32, mean1, rstd1, M, D, 4 if (SP and not T2) else f16)
             yop = y16
             # p = linear_pos(pos_emb), head-split [H, Rpad, 64] (+ transposed [H, 64, Rpad] for backward)
             Ph = E(H, Rpad, 64, dt=A16)
             Pt = torch.zeros(H, 64, Rpad, dtype=A16, device=dev) if save else None
             ptmp = E(Rpad, D, dt=A16)
-            gemm_nt(pos16, wk(p + "attn.linear_pos.weight"), EPI_BF16, outH=ptmp)
+            if T2:
+                with ops.plain_precision():
+                    gemm_nt(pos16, W[p + "attn.linear_pos.weight"].w, EPI_BF16, outH=ptmp)
+            else:
+                gemm_nt(pos16, wk(p + "attn.linear_pos.weight"), EPI_BF16, outH=ptmp)
             Ph.copy_(ptmp.view(Rpad, H, 64).permute(1, 0, 2))
             if save:
                 Pt.copy_(ptmp.view(Rpad, H, 64).permute(1, 2, 0))
@@ -530,9 +542,13 @@ class SedEngine:
             qut = kt = qvt = None
             if save:
                 qut, kt, qvt = [self._zeros(("dec", li, j, B, Tpad), (B * H, 64, Tpad), B16, dev, use_pool) for j in range(3)]
-            call("sed_gemm_qkv", yop, wk(p + "attn.in_proj.weight"), self.P(p + "attn.in_proj.bias"), M, KD, H, T, Tpad,
-                 qu, k, v, qut, kt, vt, qv, qvt, self.P(p + "attn.pos_bias_u"), self.P(p + "attn.pos_bias_v"),
-                 3 if (save and f16) else f16)
+            if T2:
+                call("sed_gemm_qkv_w2s", yop, W[p + "attn.in_proj.weight"].ws, self.P(p + "attn.in_proj.bias"), M, D, H, T, Tpad,
+                     qu, k, v, qut, kt, vt, qv, qvt, self.P(p + "attn.pos_bias_u"), self.P(p + "attn.pos_bias_v"), 3 if save else 1)
+            else:
+                call("sed_gemm_qkv", yop, wk(p + "attn.in_proj.weight"), self.P(p + "attn.in_proj.bias"), M, KD, H, T, Tpad,
+                     qu, k, v, qut, kt, vt, qv, qvt, self.P(p + "attn.pos_bias_u"), self.P(p + "attn.pos_bias_v"),
+                     3 if (save and f16) else f16)
             o16 = E(M, D, dt=F32 if SP else A16)
             lse = E(B * H, T)
             o16s = E(M, 3 * D, dt=F16) if SP else None      # split-precision image of the attention output, written by the kernel itself

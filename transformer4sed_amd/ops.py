@@ -114,12 +114,24 @@ class split_precision:
         ALG_K_SCALE = 1.0
 
 
+class plain_precision:
+    """Inside a split_precision() block: the GEMM launches in THIS block run on plain operands again (logical K = issued K)."""
+
+    def __enter__(self):
+        global ALG_K_SCALE
+        self.prev, ALG_K_SCALE = ALG_K_SCALE, 1.0
+
+    def __exit__(self, *exc):
+        global ALG_K_SCALE
+        ALG_K_SCALE = self.prev
+
+
 def _flops_of(name, args):
     if name in ("sed_gemm_nt", "sed_gemm_nt_gb", "sed_gemm_nt_w2", "sed_gemm_nt_lnp", "sed_gemm_nt_lnc"):       # (w2: the logical 2 M N K, half of the MFMA FLOPs issued)
         return 2.0 * args[2] * args[3] * args[4]
     if name == "sed_gemm_qkv_lnc":
         return 2.0 * args[5] * args[6] * (3 * args[7] * 64)
-    if name in ("sed_gemm_qkv", "sed_gemm_qkv_gb", "sed_gemm_qkv_w2"):
+    if name in ("sed_gemm_qkv", "sed_gemm_qkv_gb", "sed_gemm_qkv_w2", "sed_gemm_qkv_w2s"):
         return 2.0 * args[3] * args[4] * (3 * args[5] * 64)
     if name == "sed_gemm_dw_tn":
         return 2.0 * args[3] * args[4] * args[5]
@@ -138,8 +150,8 @@ def _shape_of(name, args):
         return (args[2], args[3], args[4], "epi1lnp" if name.endswith("p") else "epi3lnc")
     if name == "sed_gemm_qkv_lnc":
         return (args[5], 3 * args[7] * 64, args[6], "qkv3lnc")
-    if name == "sed_gemm_qkv":
-        return (args[3], 3 * args[5] * 64, args[4], "qkv%d" % sum(a is not None for a in args[8:16]))
+    if name in ("sed_gemm_qkv", "sed_gemm_qkv_w2s"):
+        return (args[3], 3 * args[5] * 64, args[4], "qkv%d" % sum(a is not None for a in args[8:16]) + ("w2s" if name.endswith("w2s") else ""))
     if name == "sed_gemm_dw_tn":
         return (args[4], args[5], args[3], "tn")
     return None
@@ -167,10 +179,10 @@ def _bytes_of(name, args):
         M, N, K, epi = args[2], args[3], args[4], args[7]
         out = {0: 4, 1: 8, 2: 2, 3: 2 * ((args[11] is not None) + (args[12] is not None)), 4: 4, 5: 8, 7: 6, 8: 6}.get(epi, 4)
         return 2.0 * K * (M + N) + float(out) * M * N
-    if name == "sed_gemm_qkv":
+    if name in ("sed_gemm_qkv", "sed_gemm_qkv_w2s"):
         M, K, D = args[3], args[4], args[5] * 64
         nout = sum(a is not None for a in args[8:16])
-        return 2.0 * K * (M + 3 * D) + 2.0 * M * D * nout
+        return 2.0 * K * (M + 3 * D * (2 if name.endswith("w2s") else 1)) + 2.0 * M * D * nout
     if name == "sed_gemm_dw_tn":
         T, M, N = args[3], args[4], args[5]
         return 2.0 * T * (M + N) + 8.0 * M * N
@@ -229,8 +241,10 @@ def call(name, *args):
         e1.record()
         fi = _flops_of(name, args)
         by = _hbm_bytes_of(name, args) if name in HBM_KERNELS else _bytes_of(name, args)
-        issued = fi * (2.0 if name.endswith("_w2") else 1.0)      # two-term weights: the A panel is multiplied twice
-        TIMER.records.append((name, e0, e1, fi * ALG_K_SCALE, by, issued, _shape_of(name, args)))
+        two = name.endswith("_w2") or name.endswith("_w2s")
+        issued = fi * (2.0 if two else 1.0)      # two-term weights: the A panel is multiplied twice
+        # (a two-term launch is given its LOGICAL K: no split-precision scaling even inside a split_precision() block)
+        TIMER.records.append((name, e0, e1, fi * (1.0 if two else ALG_K_SCALE), by, issued, _shape_of(name, args)))
         return
     lib().call(name, *conv, _stream_of(dev))
 

@@ -36,6 +36,7 @@ class PmamEngine(SedEngine):
         super().__init__(module)
         if not self.split:
             raise RuntimeError("the PMAM path runs its 384-wide context network in split precision (SED_DECODER_SPLIT=1, f16 forward)")
+        self.dec_terms2 = False      # (its own context-network schedule below keeps three terms in every GEMM)
 
     # ------------------------------------------------------------------ operand images
     def _image(self, name, w32, split=False):
