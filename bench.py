@@ -93,7 +93,9 @@ GFLOP_PER_BATCH = 21.22       # batch-shared linear_pos GEMMs (b-term)
 # What this build does not execute: the teacher's 11 sliding windows stop after the tapped block 10 (blocks 11-12 of a window feed
 # nothing, engine._encoder_fwd).  Per block and window of N tokens: 14.156 MFLOP/token of GEMMs + 4 N^2 768 of attention;
 # 10 windows of 602 tokens + one of 590 -> 2 x (10 x 9.635 + 9.421) = 211.5 GFLOP per clip.
-GFLOP_SKIPPED = {"finetune2": 211.5, "val": 2 * 17 / 11 * 211.5 * 0.0}   # (val: not priced -- its line carries no MFMA fraction)
+# validation: student AND teacher run the 17 windows of val_kwargs, each stopping after block 10: 2 nets x (16 windows of 602 tokens + one
+# of 590) x 2 blocks = 2 x 2 x (16 x 9.635 + 9.421) = 654.3 GFLOP per clip never executed
+GFLOP_SKIPPED = {"finetune2": 211.5, "val": 654.3}
 PEAK_BF16_TFLOPS = 2500.0     # dense 16-bit MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0         # HBM3E peak, MI355X_MICROARCH.md
 GEMM_KERNELS = ["sed_gemm_nt", "sed_gemm_qkv", "sed_gemm_qkv_w2s", "sed_gemm_dw_tn", "sed_gemm_nt_gb", "sed_gemm_qkv_gb", "sed_gemm_nt_w2", "sed_gemm_qkv_w2", "sed_gemm_nt_lnp", "sed_gemm_nt_lnc", "sed_gemm_qkv_lnc"]
@@ -398,13 +400,13 @@ def main():
                                  "MB_per_step": round(st["bytes"] / 1e6, 1), "reserved_cus": trainer.ddp.reserve_cus,
                                  "note": "stage-triggered all-reduce(AVG) of contiguous gradient-arena slices on the collective stream while "
                                          "the backward continues (ddp.py); SED_DDP_COMM_DTYPE=bf16 halves the bytes"}
-    if gflop_clip is not None and a.mode != "val":
+    if gflop_clip is not None:
         # fraction of the dense 16-bit MFMA peak over the whole step, on the FLOPs this build executes (algorithmic: no credit for the
         # 3x K of the split-precision GEMMs or for padded columns); the same on the reference's own schedule is reported beside it
         skipped = GFLOP_SKIPPED.get(a.mode, 0.0)
         line["step_mfma_frac"] = round(value / world * (gflop_clip - skipped + gflop_batch / B) / 1000.0 / PEAK_BF16_TFLOPS, 4)
         line["step_gflop_per_clip"] = {"executed": round(gflop_clip - skipped, 1), "reference_schedule": gflop_clip,
-                                       "skipped": "blocks 11-12 of the 11 teacher windows (their output is never read)" if skipped else None}
+                                       "skipped": (("blocks 11-12 of the 17 windows of student and teacher" if a.mode == "val" else "blocks 11-12 of the 11 teacher windows") + " (their output is never read)") if skipped else None}
         line["step_mfma_frac_reference_flops"] = round(value / world * (gflop_clip + gflop_batch / B) / 1000.0 / PEAK_BF16_TFLOPS, 4)
     if rank == 0 and timer is not None:
         summ_all = timer.summarize()
