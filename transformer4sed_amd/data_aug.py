@@ -33,6 +33,52 @@ def roll_mix(x, shifts, perm=None, c=None, clamp01=False):
     return out
 
 
+def roll_mix_dev(x, sh, pm=None, cm=None, clamp01=False):
+    """`roll_mix` on draw tables that are already on the device (int32 shifts [B], int32 perm [B], fp32 cmix [B, 2])."""
+    x = x.contiguous().float()
+    B, Fd, T = x.shape
+    out = torch.empty_like(x)
+    call("sed_roll_mix", x, out, sh, pm, cm, B, Fd, T, 1 if clamp01 else 0)
+    return out
+
+
+def warp_filt_dev(features, k=None, lam=None, add=None):
+    """`warp_filt` on device-resident tables."""
+    x = features.contiguous().float()
+    B, Fd, T = x.shape
+    out = torch.empty_like(x)
+    call("sed_warp_filt", x, out, k, lam, add, B, Fd, T)
+    return out
+
+
+def transformation_draws(B, Fd, n_transform, choice, filter_db_range, filter_bands, filter_minimum_bandwidth, filter_type, freq_mask_ratio=None,
+                         noise_snrs=None, norm_std=5, log=False):
+    """The draws of `feature_transformation` for the (default) branches choice = [filt, 0, 0, warp], in its call order: per view
+    (warp table or None, additive table or None) as host arrays."""
+    if choice[1] or choice[2]:
+        raise ValueError("transformation_draws covers the FilterAugment / frequency-warp branches; use feature_transformation for the others")
+    if choice[0] and filter_type not in ("step", "linear"):
+        raise Exception("Unkonwn filter augment type")
+    if choice[0] and not log:
+        raise NotImplementedError("[DEBUG] Don't support filter augumentation after log operation")
+    views = []
+    for _ in range(n_transform):
+        warp = add = None
+        if choice[3]:
+            bias = 0.03 * random.random()
+            phi = random.random()
+            warp = freq_warp_table(Fd, bias, phi)
+        if choice[0]:
+            if filter_type == "step":
+                dr = filt_aug_draws(B, Fd, filter_db_range, filter_bands, filter_minimum_bandwidth)
+                add = None if dr is None else filt_add_table(dr[0], dr[1], Fd, norm_std)
+            else:
+                dr = filt_aug_draws_linear(B, Fd, filter_db_range, filter_bands, filter_minimum_bandwidth)
+                add = None if dr is None else filt_add_table_linear(dr[0], dr[1], Fd, norm_std)
+        views.append((warp, add))
+    return views
+
+
 def frame_shift(features, label=None, net_pooling=None, max_shift_frame=90):
     B = features.shape[0]
     shifts = [int(random.gauss(0, max_shift_frame)) for _ in range(B)]

@@ -635,8 +635,8 @@ class SedEngine:
                     lefts[w], tps[w], offs[w] = round(starts[w] * (Tdec / T)), tpw, row + k * B * tpw
                 row += len(wis) * B * tpw
             packed = chunks[0] if len(chunks) == 1 else torch.cat(chunks, 0)
-            i32 = lambda v: h2d(v, torch.int32, dev)
-            wl, wt, wo = i32(lefts), i32(tps), i32(offs)
+            wdesc = h2d([lefts, tps, offs], torch.int32, dev)       # one upload for the three window tables
+            wl, wt, wo = wdesc[0], wdesc[1], wdesc[2]
             call("sed_window_mix", packed, wl, wt, wo, len(starts), xg, float(mix_rate), B, Tdec, ratio)
             if save:
                 wctx = dict(groups=wgroups, lefts=wl, tps=wt, offs=wo, n=len(starts), mix=float(mix_rate), rows=row)

@@ -68,23 +68,51 @@ class PasstFeatureExtractor(nn.Module):
         """wav [B, L] -> raw mel power [B, 128, T] (the reference applies `.normalize` separately)."""
         return self._run(x, fmin_fmax, do_log=0)
 
-    def logmel(self, x, fmin_fmax=None):
-        """Fused `normalize(forward(x))` in one kernel (what the trainers in this package use)."""
-        return self._run(x, fmin_fmax, do_log=1)
+    def logmel(self, x, fmin_fmax=None, bank=None):
+        """Fused `normalize(forward(x))` in one kernel (what the trainers in this package use).  `bank` = (melw, range) device tensors of
+        an already drawn `fmin_fmax` (a caller that batches its uploads; no draws happen then)."""
+        return self._run(x, fmin_fmax, do_log=1, bank=bank)
 
-    def _run(self, x, fmin_fmax, do_log):
-        # same RNG call order as the reference (passt_feature_extraction.py:66-71): always draw, use only in train
+    def draw_fmin_fmax(self):
+        """The two draws of one call (passt_feature_extraction.py:66-71): always drawn, used only in train mode."""
         fmin = self.fmin + torch.randint(self.fmin_aug_range, (1,)).item()
         fmax = self.fmax + self.fmax_aug_range // 2 - torch.randint(self.fmax_aug_range, (1,)).item()
         if not self.training:
             fmin, fmax = self.fmin, self.fmax
-        if fmin_fmax is not None:
+        return fmin, fmax
+
+    def bank_host(self, fmin, fmax, dev):
+        """(cached device bank or None, host arrays or None): lets a caller put a missing bank into its own upload block."""
+        key = (float(fmin), float(fmax), str(dev))
+        if key in self._banks:
+            return self._banks[key], None
+        w = kaldi_mel_banks(fmin, fmax)
+        nz = (w > 0).numpy()
+        rng = np.zeros((self.n_mels, 2), dtype=np.int32)
+        for m in range(self.n_mels):
+            idx = np.nonzero(nz[m])[0]
+            if len(idx):
+                rng[m] = (idx[0], idx[-1] + 1)
+        return None, (key, w, rng)
+
+    def bank_store(self, key, melw_dev, rng_dev):
+        if len(self._banks) > 64:
+            self._banks.clear()
+        self._banks[key] = (melw_dev, rng_dev)
+
+    def _run(self, x, fmin_fmax, do_log, bank=None):
+        # same RNG call order as the reference (passt_feature_extraction.py:66-71): always draw, use only in train
+        if bank is None:
+            fmin, fmax = self.draw_fmin_fmax()
+            if fmin_fmax is not None:
+                fmin, fmax = fmin_fmax
+        else:
             fmin, fmax = fmin_fmax
         self.last_fmin_fmax = (fmin, fmax)
         x = x.contiguous().float()
         B, L = x.shape
         T = 1 + (L - 1) // self.hopsize
-        melw, rng = self._bank(fmin, fmax, x.device)
+        melw, rng = bank if bank is not None else self._bank(fmin, fmax, x.device)
         out = torch.empty(B, self.n_mels, T, dtype=torch.float32, device=x.device)
         tmp = torch.empty(B, dtype=torch.int32, device=x.device)
         call("sed_logmel_fwd", x, out, tmp, self.window, self.twiddle, melw, rng, B, L, T, do_log)

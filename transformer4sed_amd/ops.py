@@ -58,6 +58,38 @@ def h2d(x, dtype, dev):
     return out
 
 
+class UploadBlock:
+    """Several small host arrays -> ONE pinned staging block -> ONE asynchronous H2D copy; the arrays come back as typed views of the device
+    copy.  A train step used to issue ~25 separate small uploads (shift / permutation / mixing tables, warp and filter tables, the mel
+    filterbank, window descriptors), each a pinned copy + a blit kernel; everything the step's preprocessing draws on the host now travels
+    in one (trainer.MatSedTrainer.preprocess)."""
+
+    def __init__(self, dev):
+        self.dev, self.parts, self.size = dev, [], 0
+
+    def add(self, arr, dtype):
+        """Stage `arr` (array-like) as `dtype` (torch.int32 / torch.float32); returns a handle for `view` after `commit`."""
+        import numpy as np
+        t = arr if isinstance(arr, torch.Tensor) else torch.as_tensor(np.asarray(arr))
+        t = t.to(dtype).contiguous()
+        off = (self.size + 15) // 16 * 16
+        self.parts.append((off, t))
+        self.size = off + t.numel() * t.element_size()
+        return len(self.parts) - 1
+
+    def commit(self):
+        cap = max(4096, 1 << (self.size - 1).bit_length())        # few distinct capacities -> few pinned rings
+        host = torch.zeros(cap, dtype=torch.uint8)
+        for off, t in self.parts:
+            host[off:off + t.numel() * t.element_size()] = t.reshape(-1).view(torch.uint8)
+        self.block = h2d(host, torch.uint8, self.dev)
+        return self
+
+    def view(self, handle):
+        off, t = self.parts[handle]
+        return self.block[off:off + t.numel() * t.element_size()].view(t.dtype).view(t.shape)
+
+
 def _ptr(t):
     if t is None:
         return None

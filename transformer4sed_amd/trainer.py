@@ -8,6 +8,7 @@ plus `FusedAdamWEMA`: torch.optim.AdamW semantics (recipes/desed/setting.py:254-
 parameter arena.  The gradient arena produced by the model's backward uses the same layout, so the optimiser (and the
 data-parallel all-reduce, ddp.py) work on contiguous slices -- no per-tensor launches.
 """
+import os
 import random
 import re
 
@@ -355,6 +356,63 @@ class MatSedTrainer:
 
     # ---- recipes/desed/finetune/train.py:69-88
     def preprocess(self, wav, label, strong_n, weak_n):
+        """extractor -> frame_shift -> mixup (w.p. 0.5, strong and weak groups) -> two augmented views -> weak labels.
+        Every random draw of the reference happens first, on the host, in the reference's order (same generators, same call sequence: the
+        trainstep goldens pin it); the tables they produce travel to the device in ONE upload; then five launches: log-mel, roll + mix of
+        the features and of the labels (frame shift and mixup of both groups are one `sed_roll_mix` pass each: per-clip shift, partner and
+        mixing weights), and one warp + filter pass per view."""
+        tr = self.cfg["training"]
+        if tr["transform"]["choice"][1] or tr["transform"]["choice"][2] or not wav.is_cuda or os.environ.get("SED_PREPROCESS_BATCHED", "1") == "0":
+            return self._preprocess_calls(wav, label, strong_n, weak_n)
+        from .ops import UploadBlock
+        ext = self.net.get_feature_extractor()
+        B, dev = wav.shape[0], wav.device
+        ub = UploadBlock(dev)
+        # --- draws, reference order
+        fmin, fmax = ext.draw_fmin_fmax()                                            # passt_feature_extraction.py:66-71
+        bank, miss = ext.bank_host(fmin, fmax, dev)
+        shifts = [int(random.gauss(0, 90)) for _ in range(B)]                        # frame_shift, data_aug.py:14
+        perm, cmix = list(range(B)), [[1.0, 0.0]] * B
+        mixed = random.random() < 0.5                                                # train.py:76
+        if mixed:
+            cmix = [list(c) for c in cmix]
+            for lo, hi in ((0, strong_n), (strong_n, strong_n + weak_n)):
+                c = np.random.beta(10, 0.5)                                          # train.py:78-80
+                pg = torch.randperm(hi - lo).tolist()                                # data_aug.py:58
+                for i in range(hi - lo):
+                    perm[lo + i] = lo + pg[i]
+                    cmix[lo + i] = [float(c), 1.0 - float(c)]
+        views = data_aug.transformation_draws(B, 128, log=True, norm_std=5.0, **tr["transform"])
+        # --- one upload
+        h_sh = ub.add(shifts, torch.int32)
+        h_ls = ub.add([data_aug.label_shift_of(s, self.net_pooling) for s in shifts], torch.int32)
+        h_pm = ub.add(perm, torch.int32) if mixed else None
+        h_cm = ub.add(cmix, torch.float32) if mixed else None
+        h_v = [(None if w is None else (ub.add(w[0], torch.int32), ub.add(w[1], torch.float32)), None if a is None else ub.add(a, torch.float32))
+               for w, a in views]
+        h_bank = None if miss is None else (ub.add(miss[1], torch.float32), ub.add(miss[2], torch.int32))
+        ub.commit()
+        if miss is not None:
+            bank = (ub.view(h_bank[0]), ub.view(h_bank[1]))
+            ext.bank_store(miss[0], *bank)
+        # --- launches
+        mel = ext.logmel(wav, fmin_fmax=(fmin, fmax), bank=bank)
+        pm, cm = (ub.view(h_pm), ub.view(h_cm)) if mixed else (None, None)
+        mel = data_aug.roll_mix_dev(mel, ub.view(h_sh), pm, cm)
+        label = data_aug.roll_mix_dev(label, ub.view(h_ls), pm, cm, clamp01=mixed)
+        outs = []
+        for hw, ha in h_v:
+            k, lam = (ub.view(hw[0]), ub.view(hw[1])) if hw is not None else (None, None)
+            outs.append(data_aug.warp_filt_dev(mel, k, lam, None if ha is None else ub.view(ha)))
+        stu_mel, tch_mel = outs
+        label_weak = torch.zeros((label.shape[0], label.shape[1]), device=label.device)
+        label_weak[strong_n:strong_n + weak_n] = torch.sum(label[strong_n:strong_n + weak_n], -1)
+        label_weak[:strong_n] = pool_strong_labels(label[:strong_n])
+        return stu_mel, tch_mel, label, label_weak
+
+    def _preprocess_calls(self, wav, label, strong_n, weak_n):
+        """The same through the public per-function API (one upload per table): the A/B reference of `preprocess` and the path for the
+        augmentation branches no shipped config uses."""
         tr = self.cfg["training"]
         ext = self.net.get_feature_extractor()
         mel = ext.logmel(wav)
