@@ -434,7 +434,7 @@ def main():
         def prof(kind):
             if a.depth != 12 or a.batch is not None:
                 return None, None
-            for rnd in ("r3", "r2"):
+            for rnd in ("r4", "r3", "r2"):
                 path = os.path.join(ROOT, "profiles", f"{rnd}_gemm_{kind}_{a.mode}.json")
                 if os.path.exists(path):
                     return json.load(open(path)), os.path.relpath(path, ROOT)
@@ -454,6 +454,7 @@ def main():
                             "traffic": None if tj is None else tj.get("avg_bytes_per_launch"), "traffic_unit": "HBM bytes per launch",
                             "traffic_source": tsrc, "mfma_pipe_busy": None if mj is None else mj.get("family_busy_fraction"),
                             "mfma_pipe_busy_source": msrc,
+                            "pmc_collected_on_commit": None if tj is None else tj.get("commit"),
                             "achieved_ln_unfolded": None if not summ_unfolded else round(
                                 sum(v["flops"] for v in summ_unfolded.values()) / (sum(v["ms"] for v in summ_unfolded.values()) * 1e-3) / 1e12, 2),
                             "achieved_ln_unfolded_note": "the same GEMM launches in one extra untimed step with SED_LN_FOLD=0 (LayerNorm as separate kernels): "

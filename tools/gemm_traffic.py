@@ -32,5 +32,6 @@ for k in sorted(set(f) | set(w)):
     tot_b += n * (rd + wr)
 out["launches"] = tot_l
 out["avg_bytes_per_launch"] = round(tot_b / max(1, tot_l))
+out["commit"] = sys.argv[4] if len(sys.argv) > 4 else None      # the tree the counters were collected on
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))

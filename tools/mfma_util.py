@@ -25,5 +25,6 @@ for k in sorted(per):
     tb += b
     tg += g
 out["family_busy_fraction"] = round(tb / (128.0 * tg), 4) if tg else None
+out["commit"] = sys.argv[3] if len(sys.argv) > 3 else None      # the tree the counters were collected on
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 print(json.dumps(out, indent=1))
