@@ -137,12 +137,22 @@ class SedEngine:
             return False        # PaSST_CNN in train mode: the GEMM operand is W + s B A, not the master the residual image is taken from
         return self.wcorr_all or not self.m.training
 
+    def _gen(self, *names):
+        """Cache-key component for images of the fp32 masters `names`: the module's parameter generation (bumped by the raw-pointer
+        writers: fused AdamW on the student, the EMA sweep on the teacher) -- but only when one of them can actually be written: frozen
+        (`requires_grad` off) and inert (lr-0 group) tensors never change under the optimiser, so their images survive its steps."""
+        inert = getattr(self.m, "_inert_param_names", ())
+        ema_written = getattr(self.m, "_ema_written", False)      # the EMA sweep rewrites EVERY tensor of a teacher
+        if ema_written or any(self.P(n).requires_grad and n not in inert for n in names):
+            return getattr(self.m, "_param_generation", 0)
+        return 0
+
     def _lnf_image(self, W, wname, bname, gname, btname):
         """(f16(gamma (.) W), colS, colC) of a Linear that follows a LayerNorm (sed_ln_fold_weight), cached per weight: rebuilt when
         any of the four masters changed."""
         ent = W[wname]
         ps = [self.P(n) for n in (wname, bname, gname, btname)]
-        key = tuple((p.data_ptr(), p._version) for p in ps) + (getattr(self.m, "_param_generation", 0),)
+        key = tuple((p.data_ptr(), p._version) for p in ps) + (self._gen(wname, bname, gname, btname),)
         if ent.lnf is None or ent.lnf_key != key or ent.lnf[0].device != ent.w.device:
             n_out, k_in = ent.w.shape
             w16 = torch.empty(n_out, k_in, dtype=F16, device=ent.w.device)
@@ -156,7 +166,7 @@ class SedEngine:
         """Two-term f16 image [n_out, 2 k_in] of an fp32 weight, cached per weight like `_wlo_image`."""
         ent = W[name]
         p = self.P(name)
-        key = (p.data_ptr(), p._version, getattr(self.m, "_param_generation", 0))
+        key = (p.data_ptr(), p._version, self._gen(name))
         if ent.w2 is None or ent.w2_key != key or ent.w2.device != ent.w.device:
             ent.w2 = two_term_weight(p.detach().reshape(ent.w.shape))
             ent.w2_key = key
@@ -167,7 +177,7 @@ class SedEngine:
         raw-pointer writers -- fused AdamW / EMA -- bump the module's parameter generation)."""
         ent = W[name]
         p = self.P(name)
-        key = (p.data_ptr(), p._version, getattr(self.m, "_param_generation", 0), id(w32) if w32 is not None else 0)
+        key = (p.data_ptr(), p._version, self._gen(name), id(w32) if w32 is not None else 0)
         if ent.wlo is None or ent.wlo_key != key or ent.wlo.device != ent.w.device:
             src = (w32 if w32 is not None else p.detach()).reshape(ent.w.shape).contiguous()
             if ent.wlo is None or ent.wlo.shape != ent.w.shape or ent.wlo.device != ent.w.device:

@@ -54,6 +54,7 @@ def update_ema(net, ema_net, step, ema_factor):
         for ema_params, params in zip(ema_net.parameters(), net.parameters()):
             ema_params.data.mul_(alpha).add_(params.data, alpha=1 - alpha)
     ema_net._param_generation = getattr(ema_net, "_param_generation", 0) + 1     # `.data` writes do not move `_version`
+    ema_net._ema_written = True                 # (engine._gen: every tensor of the teacher is rewritten, whatever its requires_grad says)
     return ema_net
 
 

@@ -226,6 +226,7 @@ class FusedAdamWEMA:
             # the teacher's masters change behind torch's back (raw-pointer kernel): engines that cache operand images of frozen
             # tensors key them on this counter
             self.ema_net._param_generation = getattr(self.ema_net, "_param_generation", 0) + 1
+            self.ema_net._ema_written = True          # (every tensor of the teacher moves with the sweep, whatever its requires_grad says)
             done.sort()
             pos = 0
             for s, e in done + [(self.total, self.total)]:
