@@ -592,33 +592,60 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq_kernel(
         }
         const int nb = 64 * t + 16 * (7 - wave);    // this wave's band base
         // ---- G^T[rho, q] = P_band[rho, :] . Qv[q, :]  (5 blocks of 16 rho) -> wave-private LDS
+        // (round 4: the operand fragments of a whole phase are requested before its first MFMA.  With two waves per SIMD -- the LDS footprint
+        //  allows no more -- a read issued right before the MFMA that consumes it exposed the LDS latency ~30 times per tile; at this
+        //  occupancy the kernel has 110 registers of headroom: 146 -> 217 VGPRs, 881 -> 852 us per launch)
+        {
+            s16x8_t bfr[5][2];
 #pragma unroll
-        for (int blk = 0; blk < 5; ++blk) {
-            const int slot = ((nb + 16 * blk) & 255) + c;
-            const unsigned char* rowp = lds_band + slot * 128;
-            const int sw = (slot >> 1) & 7;
-            f32x4_t gacc = zero4;
+            for (int blk = 0; blk < 5; ++blk) {
+                const int slot = ((nb + 16 * blk) & 255) + c;
+                const unsigned char* rowp = lds_band + slot * 128;
+                const int sw = (slot >> 1) & 7;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                gacc = mfma16x<SF16>(*reinterpret_cast<const s16x8_t*>(rowp + (((4 * ks + g) ^ sw) << 4)), qvf[ks], gacc);
+                for (int ks = 0; ks < 2; ++ks) bfr[blk][ks] = *reinterpret_cast<const s16x8_t*>(rowp + (((4 * ks + g) ^ sw) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4_t gacc[5];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gs[85 * c + 1 + 16 * blk + 4 * g + r] = gacc[r];
+            for (int blk = 0; blk < 5; ++blk) {
+                gacc[blk] = mfma16x<SF16>(bfr[blk][0], qvf[0], zero4);
+                gacc[blk] = mfma16x<SF16>(bfr[blk][1], qvf[1], gacc[blk]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int blk = 0; blk < 5; ++blk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gs[85 * c + 1 + 16 * blk + 4 * g + r] = gacc[blk][r];
         }
         // ---- S^T = K Qu^T + skew(G^T) (the skewed band term enters as the accumulator input), dP^T = V dO^T
         f32x4_t st[4], dp[4];   // block kb, register r <-> key jj = 32 (kb >> 1) + 4 (kb & 1) + 8 g + r
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) st[kb] = *reinterpret_cast<const f32x4_t*>(gs + 84 * c + 16 + 32 * (kb >> 1) + 4 * (kb & 1) + 8 * g);
         const int swc = (c >> 1) & 7;
+        {
+            s16x8_t kfr[4][2], vfr[4][2];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            const unsigned char* kp = lds_kv[0] + (16 * kb + c) * 128;
-            const unsigned char* vp = lds_kv[1] + (16 * kb + c) * 128;
-            dp[kb] = zero4;
+            for (int kb = 0; kb < 4; ++kb) {
+                const unsigned char* kp = lds_kv[0] + (16 * kb + c) * 128;
+                const unsigned char* vp = lds_kv[1] + (16 * kb + c) * 128;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                st[kb] = mfma16x<SF16>(*reinterpret_cast<const s16x8_t*>(kp + (((4 * ks + g) ^ swc) << 4)), quf[ks], st[kb]);
-                dp[kb] = mfma16x<false>(*reinterpret_cast<const s16x8_t*>(vp + (((4 * ks + g) ^ swc) << 4)), dof[ks], dp[kb]);
+                for (int ks = 0; ks < 2; ++ks) {
+                    kfr[kb][ks] = *reinterpret_cast<const s16x8_t*>(kp + (((4 * ks + g) ^ swc) << 4));
+                    vfr[kb][ks] = *reinterpret_cast<const s16x8_t*>(vp + (((4 * ks + g) ^ swc) << 4));
+                }
             }
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) st[kb] = *reinterpret_cast<const f32x4_t*>(gs + 84 * c + 16 + 32 * (kb >> 1) + 4 * (kb & 1) + 8 * g);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                dp[kb] = zero4;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    st[kb] = mfma16x<SF16>(kfr[kb][ks], quf[ks], st[kb]);
+                    dp[kb] = mfma16x<false>(vfr[kb][ks], dof[ks], dp[kb]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // Two barriers per tile, half a tile apart: A -- every wave has read K / V of tile t, the prefetched K / V rows go to LDS;
         // B (end of tile) -- every wave has read K^T of tile t and the band pieces of tile t + 1 have landed, K^T goes to LDS and is
@@ -627,6 +654,22 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq_kernel(
             __syncthreads();
             lstore_kv();
         }
+        // K^T (dQu) and P^T-panel (dQv) fragments of this tile: requested now, they arrive under the exponentials
+        s16x8_t ktf[2][4], ptf[3][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+                ktf[ks][db] = *reinterpret_cast<const s16x8_t*>(lds_kv[2] + (16 * db + c) * 128 + (((4 * ks + g) ^ swc) << 4));
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int n = nb + 32 * ks + 8 * g;
+            const unsigned char* pan = lds_bandT[(n >> 6) & 3];
+            const int ch = (n & 63) >> 3;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) ptf[ks][db] = *reinterpret_cast<const s16x8_t*>(pan + (16 * db + c) * 128 + ((ch ^ swc) << 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // ---- P = exp2(S c - LSE), dS^T = P (dP^T - D)
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
@@ -672,21 +715,14 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq_kernel(
                                          pack2bf(dp[2 * ks + 1][0], dp[2 * ks + 1][1]), pack2bf(dp[2 * ks + 1][2], dp[2 * ks + 1][3]));
             const s16x8_t dsf = __builtin_bit_cast(s16x8_t, dsu);
 #pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                const unsigned char* rowp = lds_kv[2] + (16 * db + c) * 128;   // (row >> 1) & 7 == swc for every 16-row block
-                dqu[db] = mfma16x<false>(*reinterpret_cast<const s16x8_t*>(rowp + (((4 * ks + g) ^ swc) << 4)), dsf, dqu[db]);
-            }
+            for (int db = 0; db < 4; ++db) dqu[db] = mfma16x<false>(ktf[ks][db], dsf, dqu[db]);      // ((row >> 1) & 7 == swc for every 16-row block)
         }
         // ---- dQv^T[d, q] += P^T[d, rho] dG^T[rho, q]   (96 rho slots, the last 16 and the cells outside the band are zeros)
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
             const s16x8_t gf = *reinterpret_cast<const s16x8_t*>(dgl + c * 192 + 64 * ks + 16 * g);
-            const int n = nb + 32 * ks + 8 * g;
-            const unsigned char* pan = lds_bandT[(n >> 6) & 3];
-            const int ch = (n & 63) >> 3;
 #pragma unroll
-            for (int db = 0; db < 4; ++db)
-                dqv[db] = mfma16x<false>(*reinterpret_cast<const s16x8_t*>(pan + (16 * db + c) * 128 + ((ch ^ swc) << 4)), gf, dqv[db]);
+            for (int db = 0; db < 4; ++db) dqv[db] = mfma16x<false>(ptf[ks][db], gf, dqv[db]);
         }
         if (more) {
             asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
