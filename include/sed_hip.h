@@ -20,7 +20,7 @@
  * one normally gets a new suffixed name instead, like sed_median_filter_k).  History: 3 = round 3 (sed_relpos_attn_fwd gained O_split,
  * sed_relpos_attn_bwd gained Pst, both in place); 4 = round 4.  A binding compares sed_abi_version() with the header it was written
  * against before the first call (transformer4sed_amd/_lib.py does). */
-#define SED_HIP_ABI_VERSION 4
+#define SED_HIP_ABI_VERSION 5
 
 #ifdef __cplusplus
 extern "C" {
@@ -140,8 +140,8 @@ int sed_gemm_nt_cols(const void* A, const void* B, int M, int N, int K, int lda,
                      int ncols, hipStream_t stream);
 /* Weight gradient in TN form: dW[M,N] (fp32, ldc) += dY[T,M]^T . X[T,N], both operands row-major [token][feature] as the forward /
  * backward left them (dY bf16, X bf16 or IEEE half) -- the autograd of F.linear's weight (same reference lines as sed_gemm_nt).
- * T % 64 == 0, M % 64 == 0, N % 64 == 0 (256 x 256 tiles; a partly valid last tile computes on whatever lies behind its rows and stores
- * only its valid part); split-K over tokens chosen by the library.  `workspace` (caller-owned, optional): with >= (256 / tiles) * M * N * 4
+ * M % 64 == 0, N % 64 == 0, any T > 0 (256 x 256 tiles; a partly valid last tile computes on whatever lies behind its rows and stores
+ * only its valid part; token rows past T read as zeros); split-K over tokens chosen by the library.  `workspace` (caller-owned, optional): with >= (256 / tiles) * M * N * 4
  * bytes (tiles = ceil(M/256) * ceil(N/256)) the splits are stored there and reduced by a second launch; otherwise atomics.
  * dbias (nullable): dbias[M] += column sums of dY over the T tokens, i.e. the bias gradient of the same linear, for free. */
 int sed_gemm_dw_tn(const void* dY, const void* X, int x_f16, int T, int M, int N, int ldy, int ldx, float* dW, int ldc,
@@ -264,9 +264,12 @@ int sed_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, int6
                   float beta2, float eps, int step, float ema_alpha, int do_adam, hipStream_t stream);
 
 /* every weight image of a model in one launch (what sed_transpose_to_bf16 + sed_split3_f16 produce per weight): desc is a device
- * table of n_desc x 8 int64 {fp32 master [R, C], transposed bf16 image [C, R] or 0, straight 16-bit image [R, C] or 0,
+ * table of n_desc x 16 int64 {fp32 master, transposed bf16 image [C, R] or 0, straight 16-bit image [R, C] or 0,
  * split-precision f16 image [R, 3C] = [hi | hi | lo] or 0, R (multiple of 16), C (multiple of 64), straight-image kind
- * (0 bf16, 2 f16), index of the weight's first 64 x 64 tile}; total_tiles = sum of ceil(R / 64) * (C / 64). */
+ * (0 bf16, 2 f16), index of the weight's first 64 x 64 tile, gather plan int32 [R, C] or 0 (image element -> master element; without
+ * one the master IS [R, C]), scale plan fp32 [R, C] or 0, LoRA A fp32 [r, C] or 0, LoRA B fp32 [R, r], r, LoRA scaling as float bits,
+ * 0, 0}; image = gather(master) * scale + s B A (src/models/lora/layers.py:148-151: the train-mode LoRA linear W x + s B (A x) as one
+ * weight; the plans: zero-padded context-network / CNN images of the PMAM model); total_tiles = sum of ceil(R / 64) * (C / 64). */
 int sed_weight_images(const int64_t* desc, int n_desc, int total_tiles, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------------------
@@ -313,6 +316,18 @@ int sed_mlm_apply_bwd_c(const float* dout, const uint8_t* action, const int* src
 /* dP1 / dP2 / d merge_weight of sed_pmam_merge (dmw += , nullable) */
 int sed_pmam_merge_bwd(const float* g, const float* P2, const float* mw, float* dP1, float* dP2, float* dmw, int B, int tp1,
                        int pad1, int r1, int tp2, int r2, int C, hipStream_t stream);
+/* BatchNorm2d(eps, momentum) batch statistics -> per-channel affines (src/models/cnn/base.py:72-75, torch BatchNorm semantics):
+ * s1 / s2 = sed_colstats(mode 0) sums over the M rows (train: running_mean / running_var updated in place, unbiased variance) or
+ * nullptr (eval: the running statistics are used); a = gamma rstd, b = beta - mean a, ah = rstd, bh = -mean rstd. */
+int sed_bn_finalize(const float* s1, const float* s2, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                    int64_t M, int C, double momentum, double eps, float* a, float* b, float* ah, float* bh, hipStream_t stream);
+/* batched small gathers / scatter-adds between fp32 masters and the padded images the kernels use; desc n_desc x 8 int64, one
+ * workgroup per 256 elements (first block per descriptor in field 5):
+ *   gather       {src, plan int32 [n], scale fp32 [n] or 0, dst [n], n, first block, 0, 0}:  dst[e] = src[plan[e]] * scale[e]
+ *   scatter_add  {gimg, plan int32 [n] or 0, scale fp32 [n] or 0, gmaster, n, first block, C | ld_i << 32, ld_j}:
+ *                gmaster[plan[e]] += scale[e] * gimg[(e / C) ld_i + (e % C) ld_j] where scale[e] != 0 (plans are injective there) */
+int sed_gather_f32(const int64_t* desc, int n_desc, int total_blocks, hipStream_t stream);
+int sed_scatter_add_f32(const int64_t* desc, int n_desc, int total_blocks, hipStream_t stream);
 /* column sums over the M rows (+= into s1, s2): mode 0: sum A, sum A^2 (BatchNorm batch statistics, base.py:72-75 in train mode);
  * mode 1: sum A, sum A * (Bm * a + b) (BatchNorm backward sums with xhat = Y * a + b) */
 int sed_colstats(const float* A, int lda, const float* Bm, int ldb, const float* a, const float* b, float* s1, float* s2,

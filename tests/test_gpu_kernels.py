@@ -441,11 +441,16 @@ def test_gemm_qkv_split(DT):
 # 64-multiples that are not 256-multiples (PMAM's 384-wide context network, its 64 / 128-column CNN operands): the last tile of a dimension
 # is partly valid
 @pytest.mark.parametrize("T,M,N", [(1024, 256, 256), (2432, 768, 512), (38080, 768, 768), (1024, 128, 128), (24000, 384, 384), (24000, 1152, 384),
-                                   (2432, 384, 1536), (4096, 64, 128), (4096, 192, 64), (8192, 320, 576)])
+                                   (2432, 384, 1536), (4096, 64, 128), (4096, 192, 64), (8192, 320, 576),
+                                   # token counts that are not multiples of the 64-token K tile (24 clips x 1190 tokens; a tail of one row):
+                                   # the last tile's missing rows read as zeros, NaNs placed behind the operands must not get in
+                                   (28560, 768, 768), (1025, 256, 128), (4159, 384, 320)])
 def test_gemm_dw_tn(T, M, N, XDT):
     """TN weight-gradient GEMM (transposing LDS reads, split-K atomics) against fp32 torch; accumulates into dW."""
-    dY = r16(rnd(T, M, scale=0.3, seed=21)).to(BF16)
-    X = rnd(T, N, seed=22).to(XDT)
+    dYb, Xb = torch.full((T + 64, M), float("nan"), dtype=BF16, device=DEV), torch.full((T + 64, N), float("nan"), dtype=XDT, device=DEV)
+    dYb[:T] = r16(rnd(T, M, scale=0.3, seed=21)).to(BF16)
+    Xb[:T] = rnd(T, N, seed=22).to(XDT)
+    dY, X = dYb[:T], Xb[:T]
     dW = rnd(M, N, seed=23).contiguous()
     # a half-precision X is rounded to bf16 in registers (the gradient-side MFMA is bf16): the reference does the same rounding
     want = dW + dY.float().t() @ X.float().to(BF16).float()

@@ -204,7 +204,7 @@ def test_weight_images_one_launch():
         n, k = w.shape
         wt, wsr, wsp = torch.empty(k, n, dtype=BF16, device=DEV), torch.empty(n, k, dtype=F16, device=DEV), torch.empty(n, 3 * k, dtype=F16, device=DEV)
         outs.append((wt, wsr, wsp))
-        rows.append([w.data_ptr(), wt.data_ptr(), wsr.data_ptr(), wsp.data_ptr(), n, k, 2, tiles])
+        rows.append([w.data_ptr(), wt.data_ptr(), wsr.data_ptr(), wsp.data_ptr(), n, k, 2, tiles] + [0] * 8)
         tiles += ((n + 63) // 64) * (k // 64)
     desc = torch.tensor(rows, dtype=torch.int64, device=DEV)
     call("sed_weight_images", desc, len(rows), tiles)
@@ -212,3 +212,93 @@ def test_weight_images_one_launch():
         n, k = w.shape
         assert torch.equal(wsr, w.to(F16)) and torch.equal(wt, w.t().to(BF16))
         assert torch.equal(wsp, split3(w, n, k, weight=True))
+
+
+def test_weight_images_gather_plan_and_lora_term():
+    """The two image sources round 4 added to sed_weight_images: a padded image as gather(master) * scale (context-network heads padded
+    from 32 to 64 dims with sqrt(2) on the K rows; a permuted + padded convolution weight) and the train-mode LoRA weight W + s B A
+    (lora/layers.py:148-151) -- bit-equal to the per-weight launches they replace (index_select + mul; sed_lora_merge)."""
+    from transformer4sed_amd.ops import split3
+    g = torch.Generator(device="cpu").manual_seed(5)
+    # (a) padded heads: master [12 * 32, 384] -> image [12 * 64, 384], rows 32..63 of every head zero, everything * sqrt(2)
+    w = rnd(384, 384, scale=0.3, seed=41)
+    img = torch.zeros(12, 64, 384, device=DEV)
+    img[:, :32] = w.view(12, 32, 384) * math.sqrt(2.0)
+    img = img.view(768, 384)
+    ids = torch.arange(384 * 384, device=DEV, dtype=torch.float32).view(384, 384) + 1
+    mp = torch.zeros(12, 64, 384, device=DEV); mp[:, :32] = ids.view(12, 32, 384)
+    plan = (mp.reshape(-1).long() - 1).clamp_(min=0).to(torch.int32)
+    sc = torch.zeros(12, 64, 384, device=DEV); sc[:, :32] = math.sqrt(2.0)
+    sc = sc.reshape(-1).contiguous()
+    # (b) LoRA: W [768, 256], A [8, 256], B [768, 8]
+    W, A, Bm = rnd(768, 256, scale=0.3, seed=42), rnd(8, 256, scale=0.3, seed=43), rnd(768, 8, scale=0.3, seed=44)
+    eff = torch.empty_like(W)
+    call("sed_lora_merge", W, A, Bm, 0.125, eff, 768, 256, 8)
+    sbits = int(torch.tensor(0.125, dtype=torch.float32).view(torch.int32))
+    o = lambda *s, dt: torch.empty(*s, dtype=dt, device=DEV)
+    a_t, a_s, a_p = o(384, 768, dt=BF16), o(768, 384, dt=F16), o(768, 3 * 384, dt=F16)
+    b_t, b_s = o(256, 768, dt=BF16), o(768, 256, dt=BF16)
+    rows = [[w.data_ptr(), a_t.data_ptr(), a_s.data_ptr(), a_p.data_ptr(), 768, 384, 2, 0, plan.data_ptr(), sc.data_ptr(), 0, 0, 0, 0, 0, 0],
+            [W.data_ptr(), b_t.data_ptr(), b_s.data_ptr(), 0, 768, 256, 0, 12 * 6, 0, 0, A.data_ptr(), Bm.data_ptr(), 8, sbits, 0, 0]]
+    call("sed_weight_images", torch.tensor(rows, dtype=torch.int64, device=DEV), 2, 12 * 6 + 12 * 4)
+    ref = torch.index_select(w.reshape(-1), 0, plan.long()).mul_(sc).view(768, 384)
+    assert torch.equal(ref, img)
+    assert torch.equal(a_s, img.to(F16)) and torch.equal(a_t, img.t().to(BF16)) and torch.equal(a_p, split3(img.contiguous(), 768, 384, weight=True))
+    assert torch.equal(b_s, eff.to(BF16)) and torch.equal(b_t, eff.t().to(BF16))
+
+
+def test_gather_scatter_f32_tables():
+    """sed_gather_f32 / sed_scatter_add_f32: padded fp32 vectors out of the masters and gradient images back into the masters'
+    gradients (strided image, sqrt(2) rows, padding skipped), several descriptors per launch."""
+    b = rnd(3 * 384, seed=51)
+    mp = torch.zeros(3, 12, 64, device=DEV); mp[:, :, :32] = (torch.arange(3 * 384, device=DEV, dtype=torch.float32) + 1).view(3, 12, 32)
+    plan = (mp.reshape(-1).long() - 1).clamp_(min=0).to(torch.int32)
+    sc = torch.zeros(3, 12, 64, device=DEV); sc[:, :, :32] = 1.0; sc[1, :, :32] = math.sqrt(2.0)
+    sc = sc.reshape(-1).contiguous()
+    u = rnd(12 * 32, seed=52)
+    up = torch.zeros(12, 64, device=DEV); up[:, :32] = (torch.arange(384, device=DEV, dtype=torch.float32) + 1).view(12, 32)
+    uplan = (up.reshape(-1).long() - 1).clamp_(min=0).to(torch.int32)
+    usc = (up > 0).float().reshape(-1).contiguous()
+    d1, d2 = torch.empty(2304, device=DEV), torch.empty(768, device=DEV)
+    rows = [[b.data_ptr(), plan.data_ptr(), sc.data_ptr(), d1.data_ptr(), 2304, 0, 0, 0],
+            [u.data_ptr(), uplan.data_ptr(), usc.data_ptr(), d2.data_ptr(), 768, 9, 0, 0]]
+    call("sed_gather_f32", torch.tensor(rows, dtype=torch.int64, device=DEV), 2, 9 + 3)
+    assert torch.equal(d1, b[plan.long()] * sc) and torch.equal(d2, u[uplan.long()] * usc)
+    # scatter: a [64, 128] gradient image stored transposed ([128, 64]) into a [40, 100] master through a padding plan; an identity vector
+    gm = rnd(40, 100, seed=53); gm0 = gm.clone()
+    gimgT = rnd(128, 64, seed=54)
+    mp = torch.zeros(64, 128, device=DEV); mp[:40, :100] = (torch.arange(4000, device=DEV, dtype=torch.float32) + 1).view(40, 100)
+    splan = (mp.reshape(-1).long() - 1).clamp_(min=0).to(torch.int32)
+    ssc = ((mp > 0).float() * 1.5).reshape(-1).contiguous()
+    gv = rnd(37, seed=55); gv0 = gv.clone()
+    src = rnd(37, seed=56)
+    rows = [[gimgT.data_ptr(), splan.data_ptr(), ssc.data_ptr(), gm.data_ptr(), 64 * 128, 0, 128 | (1 << 32), 64],
+            [src.data_ptr(), 0, 0, gv.data_ptr(), 37, 32, 37, 1]]
+    call("sed_scatter_add_f32", torch.tensor(rows, dtype=torch.int64, device=DEV), 2, 33)
+    assert torch.allclose(gm, gm0 + 1.5 * gimgT.t()[:40, :100], rtol=0, atol=1e-6)
+    assert torch.allclose(gv, gv0 + src, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_bn_finalize_vs_torch_batchnorm(train):
+    """sed_bn_finalize against torch.nn.BatchNorm2d(eps 1e-3, momentum 0.99) (src/models/cnn/base.py:72-75): the affine it yields
+    reproduces the module's output and the running statistics move as the module's do."""
+    C, M = 32, 4096
+    y = rnd(M, C, scale=2.0, seed=61) + 0.5
+    bn = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.99).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(rnd(C, seed=62) + 1.0); bn.bias.copy_(rnd(C, seed=63))
+        bn.running_mean.copy_(rnd(C, seed=64) * 0.1); bn.running_var.copy_(rnd(C, seed=65).abs() + 0.5)
+    rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+    bn.train(train)
+    with torch.no_grad():
+        ref = bn(y.t().reshape(1, C, M, 1)).reshape(C, M).t()
+    a, b, ah, bh = (torch.empty(C, device=DEV) for _ in range(4))
+    s1 = s2 = None
+    if train:
+        s1, s2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        call("sed_colstats", y, C, None, 0, None, None, s1, s2, M, C, 0)
+    call("sed_bn_finalize", s1, s2, bn.weight.detach(), bn.bias.detach(), rm, rv, M, C, 0.99, 1e-3, a, b, ah, bh)
+    assert maxerr(y * a + b, ref) < 2e-5
+    assert maxerr((y * ah + bh) * bn.weight.detach() + bn.bias.detach(), ref) < 2e-5
+    assert maxerr(rm, bn.running_mean) < 1e-6 and maxerr(rv, bn.running_var) < 1e-5

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsed_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sed_hip.h")
 
-_CTYPES = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "hipStream_t": ctypes.c_void_p}
+_CTYPES = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "double": ctypes.c_double, "hipStream_t": ctypes.c_void_p}
 
 
 def parse_header(path=HEADER_PATH):

@@ -1110,15 +1110,18 @@ __global__ __launch_bounds__(512) void gemm_tn_dw_kernel(const TnArgs g) {
     const int L = xcd_remap(blockIdx.x, ntiles * g.ksplit);
     const int split = L / ntiles, t = L - split * ntiles;
     const int m0 = (t % ntm) * V3_T, n0 = (t / ntm) * V3_T;
-    const int ktiles = g.T / BK;
+    const int ktiles = (g.T + BK - 1) / BK;
     const int kt_begin = (int)(((long long)split * ktiles) / g.ksplit);
     const int kt_end = (int)(((long long)(split + 1) * ktiles) / g.ksplit);
     const int nk = kt_end - kt_begin;
     const int mw = (g.M - m0) < V3_T ? (g.M - m0) : V3_T, nw = (g.N - n0) < V3_T ? (g.N - n0) : V3_T;     // valid tile extent
+    // token rows of this split; a ragged last K tile (T not a multiple of 64) ends the buffer descriptors at the last real token, the
+    // rows behind it read as zeros and add nothing to dW or to the bias sums (round 4: the tail used to be two transposes + an NT GEMM)
+    const int trows = (g.T - kt_begin * BK) < nk * BK ? (g.T - kt_begin * BK) : nk * BK;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)kt_begin * BK * g.lda + m0), 0,
-                                                                        (nk * BK - 1) * g.lda * 2 + mw * 2, 0x00020000);
+                                                                        (trows - 1) * g.lda * 2 + mw * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(g.B + (size_t)kt_begin * BK * g.ldb + n0), 0,
-                                                                        (nk * BK - 1) * g.ldb * 2 + nw * 2, 0x00020000);
+                                                                        (trows - 1) * g.ldb * 2 + nw * 2, 0x00020000);
     // DMA pieces of this wave: slot piece index pi = 2 wave + e -> panel list[pi >> 3], token rows 8 (pi & 7) .. + 7
     const int prow = lane >> 3, pc = lane & 7;
     int vo[4][2], ld_[4][2];
@@ -1376,11 +1379,11 @@ extern "C" int sed_gemm_set_cu_budget(int n_cus) {
 extern "C" int sed_gemm_dw_tn(const void* dY, const void* X, int x_f16, int T, int M, int N, int ldy, int ldx, float* dW,
                               int ldc, float* dbias, float* workspace, int64_t workspace_bytes, hipStream_t stream) {
     (void)hipGetLastError();
-    if (T <= 0 || (T % BK) || (M % 64) || (N % 64) || (ldy % 8) || (ldx % 8) || (ldc % 4) || M <= 0 || N <= 0) return SED_ERR_ARG;
+    if (T <= 0 || (M % 64) || (N % 64) || (ldy % 8) || (ldx % 8) || (ldc % 4) || M <= 0 || N <= 0) return SED_ERR_ARG;
     TnArgs g;
     g.A = (const bf16_t*)dY; g.B = (const bf16_t*)X; g.C = dW; g.dbias = dbias;
     g.M = M; g.N = N; g.T = T; g.lda = ldy; g.ldb = ldx; g.ldc = ldc; g.b_f16 = x_f16;
-    const int tiles = cdiv(M, V3_T) * cdiv(N, V3_T), ktiles = T / BK;
+    const int tiles = cdiv(M, V3_T) * cdiv(N, V3_T), ktiles = cdiv(T, BK);
     // one workgroup per CU and ONE round: tiles * ks <= 256 (rounding the split count up instead costs a second, nearly empty
     // round -- 36 tiles x 8 splits = 288 workgroups took twice the time of 36 x 7)
     static int ncu_dev_tn = 0;
@@ -1817,16 +1820,21 @@ extern "C" int sed_transpose_to_bf16(const void* in, int in_kind, int R, int C, 
 
 // All weight images of a model in ONE launch.  Per step the engine rebuilds, from the fp32 masters, the straight 16-bit image of
 // every GEMM weight, its transposed bf16 image (backward operand) and, for the split-precision layers, the [hi | hi | lo] f16
-// image: ~130 launches of 5-20 us for student + teacher.  desc: n_desc x 8 int64 {in fp32 [R, C], outT bf16 [C, R] or 0,
-// outS [R, C] or 0, split f16 [R, 3C] or 0, R, C, outS kind (0 bf16 / 2 f16), first tile index}; one workgroup per 64 x 64 tile.
+// image: ~130 launches of 5-20 us for student + teacher.  desc: n_desc x 16 int64 {in fp32, outT bf16 [C, R] or 0,
+// outS [R, C] or 0, split f16 [R, 3C] or 0, R, C, outS kind (0 bf16 / 2 f16), first tile index, gather plan int32 [R, C] or 0,
+// scale plan fp32 [R, C] or 0, LoRA A fp32 [r, C] or 0, LoRA B fp32 [R, r], r, LoRA scaling (float bits), 0, 0}; one workgroup per
+// 64 x 64 tile.  Image element (i, j) = in[plan ? plan[i C + j] : i C + j] * (scale ? scale[i C + j] : 1) + s sum_k B[i, k] A[k, j]:
+// the PMAM model's padded context-network / CNN images (a gather of the master with zeros on the padding, round 4) and its merged
+// LoRA weights W + s B A (src/models/lora/layers.py:148-151) without an fp32 copy of either.
+#define WIMG_DESC 16
 __global__ __launch_bounds__(256) void weight_images_kernel(const long long* __restrict__ desc, int n_desc) {
     __shared__ float tile[64][65];
     int lo = 0, hi = n_desc - 1;
     while (lo < hi) {   // last descriptor whose first tile <= blockIdx.x
         const int mid = (lo + hi + 1) >> 1;
-        if (desc[(size_t)mid * 8 + 7] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+        if (desc[(size_t)mid * WIMG_DESC + 7] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
     }
-    const long long* d = desc + (size_t)lo * 8;
+    const long long* d = desc + (size_t)lo * WIMG_DESC;
     const float* in = reinterpret_cast<const float*>(d[0]);
     bf16_t* outT = reinterpret_cast<bf16_t*>(d[1]);
     bf16_t* outS = reinterpret_cast<bf16_t*>(d[2]);
@@ -1834,14 +1842,53 @@ __global__ __launch_bounds__(256) void weight_images_kernel(const long long* __r
     const int R = (int)d[4], C = (int)d[5], skind = (int)d[6];
     const int tl = blockIdx.x - (int)d[7], tx = C / 64;
     const int c0 = (tl % tx) * 64, r0 = (tl / tx) * 64;
+    const int* gplan = reinterpret_cast<const int*>(d[8]);
+    const float* gscale = reinterpret_cast<const float*>(d[9]);
+    const float* la = reinterpret_cast<const float*>(d[10]);
+    const float* lb = reinterpret_cast<const float*>(d[11]);
+    const int lr = (int)d[12];
+    const float ls = __int_as_float((int)d[13]);
     const int t = threadIdx.x;
     {
         const int row = t >> 2, cg = (t & 3) * 16, r = r0 + row;
         float v[16];
         if (r < R) {
-            const float4* src = reinterpret_cast<const float4*>(in + (size_t)r * C + c0 + cg);
+            const size_t e0 = (size_t)r * C + c0 + cg;
+            if (gplan != nullptr) {      // (uniform per workgroup)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const float4 f = src[k]; v[4 * k] = f.x; v[4 * k + 1] = f.y; v[4 * k + 2] = f.z; v[4 * k + 3] = f.w; }
+                for (int k = 0; k < 4; ++k) {
+                    const int4 ix = reinterpret_cast<const int4*>(gplan + e0)[k];
+                    v[4 * k] = in[ix.x]; v[4 * k + 1] = in[ix.y]; v[4 * k + 2] = in[ix.z]; v[4 * k + 3] = in[ix.w];
+                }
+            } else {
+                const float4* src = reinterpret_cast<const float4*>(in + e0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float4 f = src[k]; v[4 * k] = f.x; v[4 * k + 1] = f.y; v[4 * k + 2] = f.z; v[4 * k + 3] = f.w; }
+            }
+            if (gscale != nullptr) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 f = reinterpret_cast<const float4*>(gscale + e0)[k];
+                    v[4 * k] *= f.x; v[4 * k + 1] *= f.y; v[4 * k + 2] *= f.z; v[4 * k + 3] *= f.w;
+                }
+            }
+            if (la != nullptr) {         // + s B A, accumulated as sed_lora_merge does (k ascending, one fma with s at the end)
+                float acc[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                for (int k = 0; k < lr; ++k) {
+                    const float bv = lb[(size_t)r * lr + k];
+                    const float4* arow = reinterpret_cast<const float4*>(la + (size_t)k * C + c0 + cg);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 a = arow[q];
+                        acc[4 * q] = fmaf(bv, a.x, acc[4 * q]); acc[4 * q + 1] = fmaf(bv, a.y, acc[4 * q + 1]);
+                        acc[4 * q + 2] = fmaf(bv, a.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(bv, a.w, acc[4 * q + 3]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = fmaf(ls, acc[e], v[e]);
+            }
             if (outS != nullptr) {
                 unsigned pk[8];
 #pragma unroll

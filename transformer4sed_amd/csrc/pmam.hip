@@ -948,3 +948,106 @@ extern "C" int sed_transpose_narrow(const void* in, int in_f16, int R, int C, in
 #undef SED_TN
     return sed_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Batched small-tensor plumbing of the PMAM step (round 4).  The padded fp32 vectors the kernels read (in_proj bias / pos_bias_u / v with
+// 32-wide heads sitting in 64-wide slots, convolution and gate biases in 128-wide tiles) are gathers of the masters, and the gradients of
+// every padded image go back to the masters through the same plan: ~230 torch index_select / mul / add_ launches per step as one launch
+// each way.  desc: n_desc x 8 int64.
+//   sed_gather_f32      {src fp32, plan int32 [n] (image element -> source element), scale fp32 [n] or 0, dst fp32 [n], n, first block, 0, 0}
+//                       dst[e] = src[plan[e]] * scale[e]
+//   sed_scatter_add_f32 {gimg fp32, plan int32 [n] or 0 (identity), scale fp32 [n] or 0, gmaster fp32, n, first block, C | ld_i << 32, ld_j}
+//                       image element e = (i, j) = (e / C, e % C) read at gimg[i ld_i + j ld_j];  gmaster[plan[e]] += scale[e] * value
+//                       for every e with scale[e] != 0 (the padding has scale 0; a plan is injective on the rest: no atomics)
+// one workgroup per 256 elements.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ const long long* small_desc(const long long* desc, int n_desc) {
+    int lo = 0, hi = n_desc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[(size_t)mid * 8 + 5] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    return desc + (size_t)lo * 8;
+}
+__global__ __launch_bounds__(256) void gather_f32_kernel(const long long* __restrict__ desc, int n_desc) {
+    const long long* d = small_desc(desc, n_desc);
+    const float* src = reinterpret_cast<const float*>(d[0]);
+    const int* plan = reinterpret_cast<const int*>(d[1]);
+    const float* scale = reinterpret_cast<const float*>(d[2]);
+    float* dst = reinterpret_cast<float*>(d[3]);
+    const long long e = (long long)(blockIdx.x - (int)d[5]) * 256 + threadIdx.x;
+    if (e >= d[4]) return;
+    const float v = src[plan[e]];
+    dst[e] = scale != nullptr ? v * scale[e] : v;
+}
+extern "C" int sed_gather_f32(const int64_t* desc, int n_desc, int total_blocks, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n_desc <= 0 || total_blocks <= 0) return SED_ERR_ARG;
+    hipLaunchKernelGGL(gather_f32_kernel, dim3(total_blocks), dim3(256), 0, stream, (const long long*)desc, n_desc);
+    return sed_check_launch();
+}
+__global__ __launch_bounds__(256) void scatter_add_f32_kernel(const long long* __restrict__ desc, int n_desc) {
+    const long long* d = small_desc(desc, n_desc);
+    const float* gimg = reinterpret_cast<const float*>(d[0]);
+    const int* plan = reinterpret_cast<const int*>(d[1]);
+    const float* scale = reinterpret_cast<const float*>(d[2]);
+    float* gm = reinterpret_cast<float*>(d[3]);
+    const long long e = (long long)(blockIdx.x - (int)d[5]) * 256 + threadIdx.x;
+    if (e >= d[4]) return;
+    float sc = 1.0f;
+    if (scale != nullptr) {
+        sc = scale[e];
+        if (sc == 0.0f) return;
+    }
+    const int C = (int)(d[6] & 0xffffffffll);
+    const long long ld_i = d[6] >> 32, ld_j = d[7];
+    const long long i = e / C, j = e - i * C;
+    gm[plan != nullptr ? (long long)plan[e] : e] += sc * gimg[i * ld_i + j * ld_j];
+}
+extern "C" int sed_scatter_add_f32(const int64_t* desc, int n_desc, int total_blocks, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n_desc <= 0 || total_blocks <= 0) return SED_ERR_ARG;
+    hipLaunchKernelGGL(scatter_add_f32_kernel, dim3(total_blocks), dim3(256), 0, stream, (const long long*)desc, n_desc);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// BatchNorm2d statistics -> the per-channel affines the CNN kernels use (src/models/cnn/base.py:72-75; torch BatchNorm semantics).
+//   train (s1 / s2 = column sums of Y and Y^2 over the M rows, sed_colstats mode 0):  mean = s1 / M, var = max(s2 / M - mean^2, 0);
+//         running_mean = (1 - mom) running_mean + mom mean,  running_var = (1 - mom) running_var + mom var M / (M - 1)
+//   eval  (s1 == nullptr): mean / var = the running statistics, left untouched
+//   a = gamma rstd, b = beta - mean a   (Z = Y a + b);   ah = rstd, bh = -mean rstd   (xhat = Y ah + bh, backward)
+// replaces eleven single-purpose torch launches per layer.
+// ---------------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ s1, const float* __restrict__ s2, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ run_mean, float* __restrict__ run_var, float inv_m,
+                                   float unbias, float mom, float keep, float eps, float* __restrict__ a, float* __restrict__ b, float* __restrict__ ah,
+                                   float* __restrict__ bh, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mean, var;
+    if (s1 != nullptr) {
+        mean = s1[c] * inv_m;
+        var = fmaxf(s2[c] * inv_m - mean * mean, 0.f);
+        run_mean[c] = run_mean[c] * keep + mom * mean;
+        run_var[c] = run_var[c] * keep + mom * (var * unbias);
+    } else {
+        mean = run_mean[c];
+        var = run_var[c];
+    }
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float av = gamma[c] * rstd;
+    a[c] = av;
+    b[c] = beta[c] - mean * av;
+    ah[c] = rstd;
+    bh[c] = -mean * rstd;
+}
+extern "C" int sed_bn_finalize(const float* s1, const float* s2, const float* gamma, const float* beta, float* run_mean, float* run_var,
+                               int64_t M, int C, double momentum, double eps, float* a, float* b, float* ah, float* bh, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (C <= 0 || M <= 1 || (s1 == nullptr) != (s2 == nullptr)) return SED_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, stream, s1, s2, gamma, beta, run_mean, run_var,
+                       (float)(1.0 / (double)M), (float)((double)M / (double)(M - 1)), (float)momentum, (float)(1.0 - momentum), (float)eps, a, b,
+                       ah, bh, C);
+    return sed_check_launch();
+}

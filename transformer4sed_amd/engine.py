@@ -268,7 +268,7 @@ class SedEngine:
                 if want_split and (ent.ws is None or ent.ws.device != w32.device):
                     ent.ws = torch.empty(n_out, 3 * k_in, dtype=F16, device=w32.device)
                 rows.append([w32.data_ptr(), ent.wt.data_ptr() if need_t else 0, ent.w.data_ptr(), ent.ws.data_ptr() if want_split else 0,
-                             n_out, k_in, 2 if self.act == F16 else 0, tiles])
+                             n_out, k_in, 2 if self.act == F16 else 0, tiles, 0, 0, 0, 0, 0, 0, 0, 0])   # (no gather plan, no LoRA term)
                 tiles += ((n_out + 63) // 64) * (k_in // 64)
             self._wimg_desc = h2d(rows, torch.int64, self.P(names[0]).device)
             self._wimg_n, self._wimg_tiles, self._wimg_key = len(rows), tiles, ptrs
@@ -957,7 +957,7 @@ class SedEngine:
         if k_in is None:
             k_in = gW.shape[1] if (gW is not None and x.dtype == F16 and ldx == 3 * gW.shape[1]) else ldx
         E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
-        Mt = M // 64 * 64      # the TN kernel walks the tokens in steps of 64: a ragged tail goes through the NT kernel
+        Mt = M                 # (the TN kernel masks a ragged last 64-token tile itself; rounds 1-3 sent the tail through the NT kernel)
         tn = self.dw_tn and Mt >= 1024 and dw_tn_ok(Mt, n_out, k_in) and x.dtype in (F16, BF16, F32)
         if tn and x.dtype == F32 and gW is not None:
             # an fp32 saved operand (projector / pooling inputs): one cast pass to bf16 instead of a transposing pass, then the TN kernel

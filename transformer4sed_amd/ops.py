@@ -332,7 +332,7 @@ def gemm_dw(dYt, Xt, dW, n_out=None):
 
 def gemm_dw_tn(dY, X, dW, tokens=None, ldc=None, dbias=None, k_in=None):
     """dW[n_out, k_in] (fp32) += dY[tokens, n_out]^T . X[tokens, k_in]; both operands in their row-major [token][feature] layout
-    (dY bf16, X bf16 or f16).  Needs tokens % 64 == 0 and both feature counts % 64 == 0 (see `dw_tn_ok`).  `k_in` < X.shape[1]: only the
+    (dY bf16, X bf16 or f16).  Needs both feature counts % 64 == 0 (see `dw_tn_ok`); any token count.  `k_in` < X.shape[1]: only the
     first k_in columns of X's rows are the operand (the `hi` third of a split-precision image [tokens, 3 k_in])."""
     T = dY.shape[0] if tokens is None else tokens
     ws = _dw_workspace(dY.device)
@@ -352,7 +352,7 @@ def _dw_workspace(dev):
 
 
 def dw_tn_ok(tokens, n_out, k_in):
-    return tokens % 64 == 0 and n_out % 64 == 0 and k_in % 64 == 0
+    return n_out % 64 == 0 and k_in % 64 == 0
 
 
 def transpose_bf16(x, rows, cols, out_t, out_s=None, colsum=None, ld=None):

@@ -39,62 +39,35 @@ class PmamEngine(SedEngine):
         self.dec_terms2 = False      # (its own context-network schedule below keeps three terms in every GEMM)
 
     # ------------------------------------------------------------------ operand images
-    def _image(self, name, w32, split=False):
-        """16-bit images of one fp32 weight [n_out, k_in]: straight (forward operand), transposed bf16 (backward operand) and, for
-        the split-precision GEMMs, the [hi | hi | lo] image."""
-        n_out, k_in = w32.shape
-        ent = self.cache.get(name)
-        if ent is None or ent.w.device != w32.device or ent.w.shape != (n_out, k_in):
-            ent = _W(torch.empty(n_out, k_in, dtype=self.act, device=w32.device), torch.empty(k_in, n_out, dtype=BF16, device=w32.device))
-            self.cache[name] = ent
-        transpose_bf16(w32, n_out, k_in, ent.wt, out_s=ent.w)
-        if split:
-            ent.ws = split3(w32, n_out, k_in, weight=True)
-        return ent
+    def _plan(self, tag, src_shape, dev, fn):
+        """(plan int32, scale fp32, image shape) of a padded image: `fn(w, k)` is the padding expression on a tensor of the master's
+        shape (k: the scale of the sqrt(2) rows); it is run ONCE on an enumeration of the master's elements and on ones, after which the
+        image -- and the way its gradient returns to the master -- is a gather / scatter with a per-element scale (0 on the padding)."""
+        plans = self.__dict__.setdefault("_pad_plans", {})
+        key = (tag, tuple(src_shape), str(dev))
+        if key not in plans:
+            if fn is None:
+                raise RuntimeError(f"padding plan {tag} requested before the forward built it")
+            n = 1
+            for v in src_shape:
+                n *= v
+            ids = torch.arange(1, n + 1, dtype=torch.float32, device=dev).view(src_shape)
+            mapped = fn(ids, 1.0)
+            scale = fn(torch.ones(src_shape, dtype=torch.float32, device=dev), SQRT2)
+            plans[key] = ((mapped.reshape(-1).long() - 1).clamp_(min=0).to(torch.int32), scale.reshape(-1).contiguous(), tuple(mapped.shape))
+        return plans[key]
 
-    def _weights(self, need_t):
+    def _image_specs(self, dev):
+        """Every 16-bit operand image of the model as (cache name, master name, R, C, plan or None, LoRA base or None, split?, kind)
+        -- kind 'act': straight image in the activation type + transposed bf16; 'bf16': straight bf16 image only -- and every padded
+        fp32 vector as (slot, master name, plan).  Shapes only: built once per device."""
+        key = ("specs", str(dev))
+        if getattr(self, "_specs_key", None) == key:
+            return self._specs
         m = self.m
-        dev = self.P("out_norm.weight").device
         Dd, hd = m.decoder_dim, m.decoder_dim // H
-        self._image("backbone.patch_embed.proj.weight", self.P("backbone.patch_embed.proj.weight").detach().reshape(D, 256))
-        merged = m.lora_merged or not m.lora_r
-        for i in range(m.depth):
-            for sub in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"):
-                n = f"backbone.blocks.{i}.{sub}"
-                wp = self.P(n + ".weight")
-                parts = [wp] + ([self.P(n + ".lora_A"), self.P(n + ".lora_B")] if m.lora_r else [])
-                # Frozen operands (the blocks below `freeze_layer`, cnn_trans/setting.py:66-82) keep their images across steps.  A tensor
-                # without requires_grad is not necessarily constant: the EMA teacher's masters are rewritten through raw pointers
-                # (fused AdamW + EMA kernel) or `.data` in-place ops (update_ema), neither of which moves `_version` -- so the key
-                # carries the module's parameter generation, bumped by every such writer and by load_state_dict.
-                # ... and `_version`, which catches what the generation cannot: sub-module load_state_dict, nn.DataParallel(net)
-                # .load_state_dict, p.copy_ under no_grad.
-                key = ((merged, wp.data_ptr(), tuple(p._version for p in parts), getattr(m, "_param_generation", 0))
-                       if not any(p.requires_grad for p in parts) else None)
-                ent = self.cache.get(n + ".weight")
-                if key is not None and ent is not None and getattr(self, "_static_keys", {}).get(n) == key:
-                    continue
-                w = wp.detach()
-                if not merged:      # train mode: the reference adds s * B (A x) to the frozen W x (lora/layers.py:148-151)
-                    eff = torch.empty_like(w)
-                    call("sed_lora_merge", w, parts[1].detach(), parts[2].detach(), float(m.lora_scaling), eff, w.shape[0], w.shape[1],
-                         m.lora_r)
-                    w = eff
-                self._image(n + ".weight", w)
-                if not hasattr(self, "_static_keys"):
-                    self._static_keys = {}
-                self._static_keys[n] = key
-        for n in ("at_adpater.0.frequency_att.in_proj_weight", "f_pool_module.frequency_att.in_proj_weight",
-                  "f_pool_module.frequency_att.out_proj.weight"):
-            self._image(n, self.P(n).detach())
-        for n in ("transformer_projector.weight", "cnn_projector.weight", "mlm_mlp.0.weight", "mlm_mlp.2.weight"):
-            if n.startswith("mlm_mlp") and not m.mlm:
-                continue
-            self._image(n, self.P(n).detach(), split=True)
-        # context network: heads zero-padded from hd to 64 in the images; CNN branch: conv weight [co, ci, 3, 3] -> [pad128(co), Kp]
-        # with column = tap * ci + c, gate weight [co, co] -> [pad128(co), Cp].  Every padded image is a gather of the fp32 master with
-        # a per-element scale (0 on the padding, sqrt(2) on the K / P rows): the (index, scale) pair is derived ONCE by running the
-        # padding expression on an enumeration of the source elements, after which an image costs two launches per step.
+        P = lambda n: self.P(n)
+
         def rows(w, scale=1.0):      # [H*hd, K] -> [H*64, K]
             o = w.new_zeros(H, HD_PAD, w.shape[1])
             o[:, :hd] = w.view(H, hd, -1) * scale
@@ -110,56 +83,155 @@ class PmamEngine(SedEngine):
             o[:w.shape[0], :w.shape[1]] = w
             return o
 
-        exprs = {
-            "win": lambda w, k: torch.cat([rows(w[:Dd]), rows(w[Dd:2 * Dd], k), rows(w[2 * Dd:])], 0),
-            "bin": lambda b, k: torch.cat([vec(b[:Dd]), vec(b[Dd:2 * Dd], k), vec(b[2 * Dd:])], 0),
-            "wout": lambda w, k: pad2(w.view(Dd * H, hd), Dd * H, HD_PAD).view(Dd, H * HD_PAD),
-            "wpos": lambda w, k: rows(w, k),
-            "uv": lambda b, k: vec(b).view(H, HD_PAD),
-        }
+        win = lambda w, k: torch.cat([rows(w[:Dd]), rows(w[Dd:2 * Dd], k), rows(w[2 * Dd:])], 0)
+        binf = lambda b, k: torch.cat([vec(b[:Dd]), vec(b[Dd:2 * Dd], k), vec(b[2 * Dd:])], 0)
+        wout = lambda w, k: pad2(w.view(Dd * H, hd), Dd * H, HD_PAD).view(Dd, H * HD_PAD)
+        wpos = lambda w, k: rows(w, k)
+        uv = lambda b, k: vec(b).view(H, HD_PAD)
+        mats, vecs = [], []
 
-        def image_of(tag, kind, src, fn=None):
-            """Padded fp32 image of `src` through expression `kind` (or `fn`), via the cached (index, scale) plan."""
-            plans = self.__dict__.setdefault("_pad_plans", {})
-            key = (tag, tuple(src.shape), str(src.device))
-            if key not in plans:
-                f = fn if fn is not None else exprs[kind]
-                ids = torch.arange(1, src.numel() + 1, dtype=torch.float32, device=src.device).view(src.shape)
-                mapped = f(ids, 1.0)
-                scale = f(torch.ones_like(src, dtype=torch.float32), SQRT2)
-                plans[key] = ((mapped.reshape(-1).long() - 1).clamp_(min=0), scale.reshape(-1).contiguous(), tuple(mapped.shape))
-            idx, scale, shape = plans[key]
-            return torch.index_select(src.reshape(-1), 0, idx).mul_(scale).view(shape)
+        def mat(name, master, plan=None, lora=None, split=False, kind="act", shape=None):
+            if plan is not None:
+                R, C = plan[2]
+            else:
+                R = shape[0] if shape else P(master).shape[0]
+                C = P(master).numel() // R
+            mats.append((name, master, R, C, plan, lora, split, kind))
 
-        self.dec_aux = []
+        mat("backbone.patch_embed.proj.weight", "backbone.patch_embed.proj.weight")
+        for i in range(m.depth):
+            for sub in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2"):
+                n = f"backbone.blocks.{i}.{sub}"
+                mat(n + ".weight", n + ".weight", lora=n if m.lora_r else None)
+        for n in ("at_adpater.0.frequency_att.in_proj_weight", "f_pool_module.frequency_att.in_proj_weight",
+                  "f_pool_module.frequency_att.out_proj.weight"):
+            mat(n, n)
+        for n in ("transformer_projector.weight", "cnn_projector.weight", "mlm_mlp.0.weight", "mlm_mlp.2.weight"):
+            if n.startswith("mlm_mlp") and not m.mlm:
+                continue
+            mat(n, n, split=True)
+        # context network: heads zero-padded from hd to 64 in the images; CNN branch: conv weight [co, ci, 3, 3] -> [pad128(co), Kp]
+        # with column = tap * ci + c, gate weight [co, co] -> [pad128(co), Cp]
         for i in range(m.decoder_layer_num):
             p = f"decoder.encoder_blocks.{i}."
-            self._image(p + "attn.in_proj.weight", image_of("win", "win", self.P(p + "attn.in_proj.weight").detach()), split=True)
-            self._image(p + "attn.out_proj.weight", image_of("wout", "wout", self.P(p + "attn.out_proj.weight").detach()), split=True)
-            self._image(p + "attn.linear_pos.weight", image_of("wpos", "wpos", self.P(p + "attn.linear_pos.weight").detach()), split=True)
-            self._image(p + "mlp.fc1.weight", self.P(p + "mlp.fc1.weight").detach(), split=True)
-            self._image(p + "mlp.fc2.weight", self.P(p + "mlp.fc2.weight").detach(), split=True)
-            self.dec_aux.append(dict(bin=image_of("bin", "bin", self.P(p + "attn.in_proj.bias").detach()),
-                                     u=image_of("uv", "uv", self.P(p + "attn.pos_bias_u").detach()),
-                                     v=image_of("uv", "uv", self.P(p + "attn.pos_bias_v").detach())))
-        self.cnn_aux = []
+            for sub, tag, fn in (("attn.in_proj.weight", "win", win), ("attn.out_proj.weight", "wout", wout), ("attn.linear_pos.weight", "wpos", wpos)):
+                mat(p + sub, p + sub, plan=self._plan(tag, P(p + sub).shape, dev, fn), split=True)
+            mat(p + "mlp.fc1.weight", p + "mlp.fc1.weight", split=True)
+            mat(p + "mlp.fc2.weight", p + "mlp.fc2.weight", split=True)
+            vecs.append((("dec", i, "bin"), p + "attn.in_proj.bias", self._plan("bin", P(p + "attn.in_proj.bias").shape, dev, binf)))
+            vecs.append((("dec", i, "u"), p + "attn.pos_bias_u", self._plan("uv", P(p + "attn.pos_bias_u").shape, dev, uv)))
+            vecs.append((("dec", i, "v"), p + "attn.pos_bias_v", self._plan("uv", P(p + "attn.pos_bias_v").shape, dev, uv)))
+        geo = []
         cin = 1
         for i, co in enumerate(m.cnn_filters):
             Np = pad128(co)
             Kp = 64 if i == 0 else pad128(9 * cin)
             Cp = max(64, co)
-            wc = self.P(f"cnn.cnn.conv{i}.weight").detach()
-            wg = self.P(f"cnn.cnn.cg{i}.linear.weight").detach()
-            img = image_of(("conv", Np, Kp), None, wc, fn=lambda w, k, Np=Np, Kp=Kp: pad2(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1), Np, Kp))
-            self._image(f"cnn.cnn.conv{i}.weight", img)
-            self._image(f"cnn.cnn.cg{i}.linear.weight", image_of(("gate", Np, Cp), None, wg, fn=lambda w, k, Np=Np, Cp=Cp: pad2(w, Np, Cp)))
-            wtg = None
-            if need_t:      # backward operand of the gate GEMM: [Np (N), Np (K)] = W_gate^T, zero padded
-                wtg = image_of(("gateT", Np), None, wg, fn=lambda w, k, Np=Np: pad2(w.t(), Np, Np)).to(BF16)
-            bc = image_of(("b", Np), None, self.P(f"cnn.cnn.conv{i}.bias").detach(), fn=lambda b, k, Np=Np: pad2(b.view(1, -1), 1, Np).view(-1))
-            bg = image_of(("b", Np), None, self.P(f"cnn.cnn.cg{i}.linear.bias").detach(), fn=lambda b, k, Np=Np: pad2(b.view(1, -1), 1, Np).view(-1))
-            self.cnn_aux.append(dict(Np=Np, Kp=Kp, Cp=Cp, cin=cin, co=co, bias=bc, gbias=bg, wtg=wtg))
+            cw, gw = f"cnn.cnn.conv{i}.weight", f"cnn.cnn.cg{i}.linear.weight"
+            mat(cw, cw, plan=self._plan(("conv", Np, Kp), P(cw).shape, dev,
+                                        lambda w, k, Np=Np, Kp=Kp: pad2(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1), Np, Kp)))
+            mat(gw, gw, plan=self._plan(("gate", Np, Cp), P(gw).shape, dev, lambda w, k, Np=Np, Cp=Cp: pad2(w, Np, Cp)))
+            # backward operand of the gate GEMM: [Np (N), Np (K)] = W_gate^T, zero padded, bf16
+            mat(gw + "#T", gw, plan=self._plan(("gateT", Np), P(gw).shape, dev, lambda w, k, Np=Np: pad2(w.t(), Np, Np)), kind="bf16")
+            bplan = lambda n, Np=Np: self._plan(("b", Np), P(n).shape, dev, lambda b, k: pad2(b.view(1, -1), 1, Np).view(-1))
+            vecs.append((("cnn", i, "bias"), f"cnn.cnn.conv{i}.bias", bplan(f"cnn.cnn.conv{i}.bias")))
+            vecs.append((("cnn", i, "gbias"), f"cnn.cnn.cg{i}.linear.bias", bplan(f"cnn.cnn.cg{i}.linear.bias")))
+            geo.append(dict(Np=Np, Kp=Kp, Cp=Cp, cin=cin, co=co))
             cin = co
+        self._specs, self._specs_key = (mats, vecs, geo), key
+        return self._specs
+
+    def _weights(self, need_t):
+        """Operand images of every GEMM weight and the padded fp32 vectors, from the fp32 masters: one `sed_weight_images` launch for
+        what can change between steps, one for whichever frozen images went stale (normally none), one `sed_gather_f32`.  The LoRA
+        linears' train-mode weight W + s B A (lora/layers.py:148-151) is formed inside the image kernel."""
+        m = self.m
+        dev = self.P("out_norm.weight").device
+        mats, vecs, geo = self._image_specs(dev)
+        merged = m.lora_merged or not m.lora_r
+        kind_act = 2 if self.act == F16 else 0
+        sbits = int(torch.tensor(float(m.lora_scaling), dtype=torch.float32).view(torch.int32)) if m.lora_r else 0
+        statics = self.__dict__.setdefault("_static_keys", {})
+
+        def entry(name, R, C, split, kind):
+            ent = self.cache.get(name)
+            if ent is None or ent.w.device != dev or ent.w.shape != (R, C):
+                wdt = BF16 if kind == "bf16" else self.act
+                ent = _W(torch.empty(R, C, dtype=wdt, device=dev), torch.empty(C, R, dtype=BF16, device=dev) if kind == "act" else None)
+                self.cache[name] = ent
+            if split and (ent.ws is None or ent.ws.device != dev):
+                ent.ws = torch.empty(R, 3 * C, dtype=F16, device=dev)
+            return ent
+
+        def row(spec, tiles):
+            name, master, R, C, plan, lora, split, kind = spec
+            ent = entry(name, R, C, split, kind)
+            use_lora = lora is not None and not merged
+            return [self.P(master).data_ptr(), ent.wt.data_ptr() if (kind == "act" and need_t) else 0, ent.w.data_ptr(),
+                    ent.ws.data_ptr() if split else 0, R, C, kind_act if kind == "act" else 0, tiles,
+                    plan[0].data_ptr() if plan is not None else 0, plan[1].data_ptr() if plan is not None else 0,
+                    self.P(lora + ".lora_A").data_ptr() if use_lora else 0, self.P(lora + ".lora_B").data_ptr() if use_lora else 0,
+                    m.lora_r if use_lora else 0, sbits if use_lora else 0, 0, 0]
+
+        # Frozen operands (the blocks below `freeze_layer`, cnn_trans/setting.py:66-82) keep their images across steps.  A tensor without
+        # requires_grad is not necessarily constant: the EMA teacher's masters are rewritten through raw pointers (fused AdamW + EMA
+        # kernel) or `.data` in-place ops (update_ema), neither of which moves `_version` -- so the key carries the module's parameter
+        # generation (`_gen`: bumped by every such writer and by load_state_dict; it only counts for tensors the optimiser or the EMA
+        # sweep can reach, a frozen master of the student is not re-imaged after every step) -- and `_version`, which catches the rest:
+        # sub-module load_state_dict, nn.DataParallel(net).load_state_dict, p.copy_ under no_grad.
+        live, stale = [], []
+        for spec in mats:
+            name, master, R, C, plan, lora, split, kind = spec
+            if not (name.startswith("backbone.blocks.") and lora is not None):
+                live.append(spec)
+                continue
+            parts = [self.P(master), self.P(lora + ".lora_A"), self.P(lora + ".lora_B")]
+            if any(p.requires_grad for p in parts):
+                live.append(spec)
+                continue
+            key = (merged, bool(need_t), self.act, tuple(p.data_ptr() for p in parts), tuple(p._version for p in parts),
+                   self._gen(master, lora + ".lora_A", lora + ".lora_B"))
+            if statics.get(name) != key or name not in self.cache:
+                stale.append(spec)
+                statics[name] = key
+        for specs, cached in ((stale, False), (live, True)):
+            if not specs:
+                continue
+            ptrs = tuple(self.P(sp[1]).data_ptr() for sp in specs) + tuple(self.P(sp[5] + ".lora_A").data_ptr() for sp in specs if sp[5]) + \
+                (bool(need_t), merged, self.act, len(specs))
+            if cached and getattr(self, "_wimg_key", None) == ptrs:
+                desc, n, tiles = self._wimg_desc
+            else:
+                rows_, tiles = [], 0
+                for sp in specs:
+                    if sp[2] % 16 or sp[3] % 64 or not self.P(sp[1]).is_contiguous():
+                        raise RuntimeError(f"weight {sp[0]}: unsupported shape / layout for the operand images")
+                    rows_.append(row(sp, tiles))
+                    tiles += ((sp[2] + 63) // 64) * (sp[3] // 64)
+                desc, n = h2d(rows_, torch.int64, dev), len(rows_)
+                if cached:
+                    self._wimg_desc, self._wimg_key = (desc, n, tiles), ptrs
+            call("sed_weight_images", desc, n, tiles)
+        # padded fp32 vectors
+        vkey = tuple(self.P(mn).data_ptr() for _, mn, _ in vecs)
+        if getattr(self, "_vimg_key", None) != vkey:
+            total = sum(pl[0].numel() for _, _, pl in vecs)
+            buf = torch.empty(total, dtype=F32, device=dev)
+            rows_, off, blocks, views = [], 0, 0, {}
+            for slot, mn, pl in vecs:
+                nel = pl[0].numel()
+                dst = buf[off:off + nel]
+                rows_.append([self.P(mn).data_ptr(), pl[0].data_ptr(), pl[1].data_ptr(), dst.data_ptr(), nel, blocks, 0, 0])
+                views[slot] = dst.view(pl[2])
+                off += nel
+                blocks += (nel + 255) // 256
+            self._vimg = (h2d(rows_, torch.int64, dev), len(rows_), blocks, buf, views)
+            self._vimg_key = vkey
+        vdesc, vn, vblocks, _, views = self._vimg
+        call("sed_gather_f32", vdesc, vn, vblocks)
+        self.dec_aux = [dict(bin=views[("dec", i, "bin")], u=views[("dec", i, "u")], v=views[("dec", i, "v")]) for i in range(m.decoder_layer_num)]
+        self.cnn_aux = [dict(g, bias=views[("cnn", i, "bias")], gbias=views[("cnn", i, "gbias")],
+                             wtg=self.cache[f"cnn.cnn.cg{i}.linear.weight#T"].w if need_t else None) for i, g in enumerate(geo)]
         return self.cache
 
     # ------------------------------------------------------------------ attention frequency pooling
@@ -205,6 +277,12 @@ class PmamEngine(SedEngine):
         X = None
         layers = []
         feat = None
+        nl = len(self.cnn_aux)
+        cmax = max(a_["co"] for a_ in self.cnn_aux)
+        sums = torch.zeros(nl, 2, cmax, device=dev) if train else None      # batch-statistics sums of every layer: one fill
+        aff = E(nl, 4, cmax)                                                # a | b | ah | bh of every layer (saved for the backward)
+        if train:
+            torch._foreach_add_([m._buffer_by_name[f"cnn.cnn.batchnorm{i}.num_batches_tracked"] for i in range(nl)], 1)
         for i, aux in enumerate(self.cnn_aux):
             co, Np, Kp, Cp, cin = aux["co"], aux["Np"], aux["Kp"], aux["Cp"], aux["cin"]
             Mi = B * Hc * Wc
@@ -221,20 +299,13 @@ class PmamEngine(SedEngine):
                 gemm_nt(col, W[f"cnn.cnn.conv{i}.weight"].w, EPI_F32, bias=aux["bias"], outF=Y)
             bn = f"cnn.cnn.batchnorm{i}."
             g, bt = self.P(bn + "weight").detach(), self.P(bn + "bias").detach()
-            if train:
-                s1, s2 = torch.zeros(co, device=dev), torch.zeros(co, device=dev)
+            s1 = s2 = None
+            if train:   # batch statistics; running statistics updated with torch's BatchNorm rule (momentum 0.99, unbiased variance)
+                s1, s2 = sums[i, 0], sums[i, 1]
                 call("sed_colstats", Y, ldy, None, 0, None, None, s1, s2, Mi, co, 0)
-                mean = s1 / Mi
-                var = (s2 / Mi - mean * mean).clamp_(min=0)
-                rm, rv = m._buffer_by_name[bn + "running_mean"], m._buffer_by_name[bn + "running_var"]
-                rm.mul_(1 - 0.99).add_(mean, alpha=0.99)
-                rv.mul_(1 - 0.99).add_(var * (Mi / (Mi - 1)), alpha=0.99)
-                m._buffer_by_name[bn + "num_batches_tracked"].add_(1)
-            else:
-                mean, var = m._buffer_by_name[bn + "running_mean"], m._buffer_by_name[bn + "running_var"]
-            rstd = torch.rsqrt(var + 1e-3)
-            a = (g * rstd).contiguous()
-            b = (bt - mean * a).contiguous()
+            a, b, ah, bh = aff[i, 0], aff[i, 1], aff[i, 2], aff[i, 3]
+            call("sed_bn_finalize", s1, s2, g, bt, m._buffer_by_name[bn + "running_mean"], m._buffer_by_name[bn + "running_var"], Mi, co,
+                 0.99, 1e-3, a, b, ah, bh)
             Z = E(Mi, Cp, dt=self.act)
             call("sed_bn_act", Y, ldy, a, b, Z, Mi, co, Cp, f16)
             L = E(Mi, ldy)
@@ -255,8 +326,7 @@ class PmamEngine(SedEngine):
                 scale = 1.0 / (1.0 - m.conv_dropout)
             call("sed_cg_pool", Y, ldy, a, b, L, ldy, mask, float(scale), Xn, feat, B, Hc, Wc, co, Cpo, ph, pw, f16)
             if save:
-                layers.append(dict(col=col, Y=Y, a=a, b=b, ah=rstd.contiguous(), bh=(-mean * rstd).contiguous(), Z=Z, L=L, mask=mask,
-                                   scale=scale, H=Hc, W=Wc, ldy=ldy))
+                layers.append(dict(col=col, Y=Y, a=a, b=b, ah=ah, bh=bh, Z=Z, L=L, mask=mask, scale=scale, H=Hc, W=Wc, ldy=ldy))
             X = Xn
             Hc, Wc = Hc // ph, Wc // pw
         assert Wc == 1
@@ -444,17 +514,25 @@ class PmamEngine(SedEngine):
         return out, ctx
 
     # ==================================================================== backward
-    def _dw_swapped(self, dy16, x, M, n_valid, k_valid):
+    def _dw_swapped_tn(self, M, n, k):
+        """Does `_dw_swapped` run the TN kernel for these shapes (gradient image laid out [n, k]) or the transposed-copy path ([k, n])?"""
+        return bool(self.dw_tn and M >= 1024 and dw_tn_ok(M, n, k))
+
+    def _dw_swapped(self, dy16, x, M, n_valid, k_valid, out=None):
         """(dy^T x)^T = x^T dy for operand widths that are not multiples of 128 on the x side: returns fp32 [k, n] and the fp32 column
         sums of dy; only [:k_valid, :n_valid] / [:n_valid] are meaningful.  The operands are zero padded to GEMM-friendly widths
         (16 filters sit in 128 columns): only the 64-column groups that hold valid data are transposed, the other rows of the
-        transposed images stay uninitialised and only feed output elements nobody reads."""
+        transposed images stay uninitialised and only feed output elements nobody reads.  `out` = (zeroed flat fp32 [n k], zeroed
+        fp32 [n]): the gradient-image slots of `_grad_slots` (accumulated into; nothing is allocated or filled here)."""
         dev = dy16.device
         n, k = dy16.shape[1], x.shape[1]
-        if self.dw_tn and M % 64 == 0 and M >= 1024 and dw_tn_ok(M, n, k) and dy16.dtype == BF16 and x.dtype in (F16, BF16):
+        tn = self._dw_swapped_tn(M, n, k) and dy16.dtype == BF16 and x.dtype in (F16, BF16)
+        if out is not None and tn != self._dw_swapped_tn(M, n, k):
+            raise RuntimeError("gradient-image slot laid out for the TN kernel, operands are not 16-bit")
+        if tn:
             # TN kernel on the operands as they lie: dW [n, k] = dy^T x and the column sums of dy from the same launch.  Padding columns
             # of either operand only reach output elements outside [:n_valid, :k_valid], which nobody reads.
-            gW, csum = torch.zeros(n, k, device=dev), torch.zeros(n, device=dev)
+            gW, csum = (torch.zeros(n, k, device=dev), torch.zeros(n, device=dev)) if out is None else (out[0].view(n, k), out[1])
             # this launch runs on the CURRENT stream and uses the per-device split-K workspace that weight-gradient GEMMs still pending on
             # the side stream (`_dw_accum`: the cnn_projector's dW was issued just before the CNN backward) are writing / reducing: order them
             self._join_dw()
@@ -463,7 +541,7 @@ class PmamEngine(SedEngine):
         n_eff, k_eff = min(n, pad64(n_valid)), min(k, pad64(k_valid))
         Mpad = pad64(M)
         gT = torch.empty(n, Mpad, dtype=BF16, device=dev)
-        csum = torch.zeros(n, device=dev)
+        csum = torch.zeros(n, device=dev) if out is None else out[1]
         pad8 = lambda v: (v + 7) // 8 * 8
 
         def tr(src, valid, eff, dst, colsum):
@@ -475,11 +553,75 @@ class PmamEngine(SedEngine):
         tr(dy16, n_valid, n_eff, gT, csum)
         xT = torch.empty(k, Mpad, dtype=BF16, device=dev)
         tr(x, k_valid, k_eff, xT, None)
-        gWT = torch.zeros(k, n, device=dev)
+        gWT = torch.zeros(k, n, device=dev) if out is None else out[0].view(k, n)
         gemm_dw(xT, gT, gWT)
         return gWT, csum
 
-    def _cnn_bwd(self, W, cctx, dfeat, B, G):
+    def _grad_slots(self, B, dev, G, dec_train, cnn_train):
+        """Gradient images of every padded weight / vector of one backward, as views of ONE zeroed fp32 arena, and the two
+        `sed_scatter_add_f32` tables (context network, CNN branch) that return them to the masters' gradients through the forward
+        plans -- scale sqrt(2) on the K / P rows, nothing from the padding.  Replaces a `zeros` per image and an `add_` of a sliced /
+        permuted view per master (~190 launches per step) by one fill and two launches."""
+        m = self.m
+        mats, vecs, geo = self._image_specs(dev)
+        Dd = m.decoder_dim
+        Dp = H * HD_PAD
+        items = []       # (group, slot, numel, master grad name, plan or None, n, C, ld_i, ld_j)
+        if dec_train:
+            for li in range(m.decoder_layer_num):
+                p = f"decoder.encoder_blocks.{li}."
+                pl = lambda tag, n: self._plan(tag, self.P(n).shape, dev, None)
+                items += [("dec", ("gwo", li), Dd * Dp, p + "attn.out_proj.weight", pl("wout", p + "attn.out_proj.weight"), Dd * Dp, Dp, Dp, 1),
+                          ("dec", ("gwp", li), Dp * Dd, p + "attn.linear_pos.weight", pl("wpos", p + "attn.linear_pos.weight"), Dp * Dd, Dd, Dd, 1),
+                          ("dec", ("gwi", li), 3 * Dp * Dd, p + "attn.in_proj.weight", pl("win", p + "attn.in_proj.weight"), 3 * Dp * Dd, Dd, Dd, 1),
+                          ("dec", ("gbi", li), 3 * Dp, p + "attn.in_proj.bias", pl("bin", p + "attn.in_proj.bias"), 3 * Dp, 3 * Dp, 0, 1),
+                          ("dec", ("du", li), Dp, p + "attn.pos_bias_u", pl("uv", p + "attn.pos_bias_u"), Dp, Dp, 0, 1),
+                          ("dec", ("dv", li), Dp, p + "attn.pos_bias_v", pl("uv", p + "attn.pos_bias_v"), Dp, Dp, 0, 1)]
+        if cnn_train:
+            Hc, Wc = 1000, 128
+            for i, g in enumerate(geo):
+                co, Np, Kp, Cp, cin = g["co"], g["Np"], g["Kp"], g["Cp"], g["cin"]
+                Mi = B * Hc * Wc
+                cw, gw = f"cnn.cnn.conv{i}.weight", f"cnn.cnn.cg{i}.linear.weight"
+                bplan = self._plan(("b", Np), self.P(f"cnn.cnn.conv{i}.bias").shape, dev, None)
+                for slot, master, plan, k in ((("gate", i), gw, self._plan(("gate", Np, Cp), self.P(gw).shape, dev, None), Cp),
+                                              (("conv", i), cw, self._plan(("conv", Np, Kp), self.P(cw).shape, dev, None), Kp)):
+                    tn = self._dw_swapped_tn(Mi, Np, k)      # image element (i, j) of [Np, k] sits at i k + j (TN) or j Np + i
+                    items.append(("cnn", slot, Np * k, master, plan, Np * k, k, k if tn else 1, 1 if tn else Np))
+                items += [("cnn", ("gate_b", i), Np, f"cnn.cnn.cg{i}.linear.bias", bplan, Np, Np, 0, 1),
+                          ("cnn", ("conv_b", i), Np, f"cnn.cnn.conv{i}.bias", bplan, Np, Np, 0, 1),
+                          ("cnn", ("bn_s1", i), co, f"cnn.cnn.batchnorm{i}.bias", None, co, co, 0, 1),
+                          ("cnn", ("bn_s2", i), co, f"cnn.cnn.batchnorm{i}.weight", None, co, co, 0, 1)]
+                ph, pw = m.cnn_pooling[i]
+                Hc, Wc = Hc // ph, Wc // pw
+        if not items:
+            return {}, {}
+        gp = lambda n: G(n).data_ptr() if G(n) is not None else 0      # (a master without a gradient slot: its image is formed and dropped)
+        key = (B, str(dev), dec_train, cnn_train, tuple(gp(it[3]) for it in items))
+        if getattr(self, "_gslot_key", None) != key:
+            total = sum((it[2] + 63) // 64 * 64 for it in items)
+            arena = torch.empty(total, dtype=F32, device=dev)
+            views, tables, off = {}, {}, 0
+            rows_ = {"dec": [], "cnn": []}
+            blocks = {"dec": 0, "cnn": 0}
+            for grp, slot, numel, master, plan, n, C, ld_i, ld_j in items:
+                v = arena[off:off + numel]
+                views[slot] = v
+                off += (numel + 63) // 64 * 64
+                if not gp(master):
+                    continue
+                rows_[grp].append([v.data_ptr(), plan[0].data_ptr() if plan is not None else 0, plan[1].data_ptr() if plan is not None else 0,
+                                   gp(master), n, blocks[grp], C | (ld_i << 32), ld_j])
+                blocks[grp] += (n + 255) // 256
+            for grp in ("dec", "cnn"):
+                if rows_[grp]:
+                    tables[grp] = (h2d(rows_[grp], torch.int64, dev), len(rows_[grp]), blocks[grp])
+            self._gslot_key, self._gslot = key, (arena, views, tables)
+        arena, views, tables = self._gslot
+        arena.zero_()
+        return views, tables
+
+    def _cnn_bwd(self, W, cctx, dfeat, B, G, slots):
         m = self.m
         dev = dfeat.device
         E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
@@ -495,29 +637,20 @@ class PmamEngine(SedEngine):
             dL16 = E(Mi, Np, dt=BF16)
             call("sed_cg_pool_bwd", dout, L["Y"], ldy, L["a"], L["b"], L["L"], ldy, L["mask"], float(L["scale"]), dz, ldy, dL16, Np, B, Hc,
                  Wc, co, ph, pw)
-            gWT, gb = self._dw_swapped(dL16, L["Z"], Mi, co, co)
-            cg = f"cnn.cnn.cg{i}.linear."
-            if G(cg + "weight") is not None:
-                G(cg + "weight").add_(gWT[:co, :co].t())
-                G(cg + "bias").add_(gb[:co])
+            # weight / bias gradient images land in the zeroed slots; `sed_scatter_add_f32` returns them to the masters after the loop
+            self._dw_swapped(dL16, L["Z"], Mi, co, co, out=(slots[("gate", i)], slots[("gate_b", i)]))
             if ldy < Np:      # dz += dL W_gate
                 gemm_nt_cols(dL16, aux["wtg"], EPI_F32_RESID, co, res=dz, outF=dz)
             else:
                 gemm_nt(dL16, aux["wtg"], EPI_F32_RESID, res=dz, outF=dz)
-            s1, s2 = torch.zeros(co, device=dev), torch.zeros(co, device=dev)
+            s1, s2 = slots[("bn_s1", i)], slots[("bn_s2", i)]
             call("sed_colstats", dz, ldy, L["Y"], ldy, L["ah"], L["bh"], s1, s2, Mi, co, 1)
             bn = f"cnn.cnn.batchnorm{i}."
-            if G(bn + "weight") is not None:
-                G(bn + "weight").add_(s2)
-                G(bn + "bias").add_(s1)
             dY16 = E(Mi, Np, dt=BF16)
             call("sed_bn_bwd", dz, ldy, L["Y"], ldy, L["ah"], L["bh"], self.P(bn + "weight"), s1, s2, dY16, Np, Mi, co)
             del dz, dL16
-            cWT, cb = self._dw_swapped(dY16, L["col"], Mi, co, 9 * cin)
+            self._dw_swapped(dY16, L["col"], Mi, co, 9 * cin, out=(slots[("conv", i)], slots[("conv_b", i)]))
             cv = f"cnn.cnn.conv{i}."
-            if G(cv + "weight") is not None:
-                G(cv + "weight").add_(cWT[:9 * cin, :co].t().reshape(co, 3, 3, cin).permute(0, 3, 1, 2))
-                G(cv + "bias").add_(cb[:co])
             if i > 0:
                 dcol = E(Mi, Kp, dt=BF16)
                 gemm_nt(dY16, W[cv + "weight"].wt, EPI_BF16, outH=dcol)
@@ -525,7 +658,7 @@ class PmamEngine(SedEngine):
                 call("sed_col2im3x3", dcol, Kp, dout, B, Hc, Wc, cin)
             cctx["layers"][i] = None
 
-    def _decoder_bwd(self, W, dctx, g, G, trainable):
+    def _decoder_bwd(self, W, dctx, g, G, trainable, slots):
         m = self.m
         B, T, Tpad, Rpad = dctx["B"], dctx["T"], dctx["Tpad"], dctx["Rpad"]
         Dd, hd = m.decoder_dim, m.decoder_dim // H
@@ -535,7 +668,6 @@ class PmamEngine(SedEngine):
         E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
         Z = lambda *s, dt=F32: torch.zeros(*s, dtype=dt, device=dev)
         pos16, posT16, _ = self._pos(T, dev, Dd)
-        unrows = lambda gp, sc=1.0: gp.view(H, HD_PAD, -1)[:, :hd].reshape(H * hd, -1) * sc
         g = g.contiguous()
         for li in range(m.decoder_layer_num - 1, -1, -1):
             p = f"decoder.encoder_blocks.{li}."
@@ -546,11 +678,8 @@ class PmamEngine(SedEngine):
             call("sed_ln_bwd_any", dln, L["x1"], L["mean2"], L["rstd2"], self.P(p + "norm2.weight"), 1.0, g2, 1, Gl(p + "norm2.weight"),
                  Gl(p + "norm2.bias"), M, Dd)
             del dln
-            gwo = Z(Dd, Dp) if trainable else None
+            gwo = slots[("gwo", li)].view(Dd, Dp) if trainable else None
             g16 = self._dw_accum(g2, L["o16s"], M, gwo, Gl(p + "attn.out_proj.bias"))
-            if trainable:
-                self._join_dw()      # gwo was filled on the weight-gradient side stream
-                G(p + "attn.out_proj.weight").add_(gwo.view(Dd, H, HD_PAD)[:, :, :hd].reshape(Dd, Dd))
             do16 = E(M, Dp, dt=BF16)
             gemm_nt(g16, W[p + "attn.out_proj.weight"].wt, EPI_BF16, outH=do16)
             dqkv = E(M, 3 * Dp, dt=BF16)
@@ -560,26 +689,17 @@ class PmamEngine(SedEngine):
             dSt = self._zeros(("dSt", B, Tpad), (B * H, Tpad, Tpad), BF16, dev)
             Pst = self._zeros(("Pst", B, Tpad), (B * H, Tpad, Tpad), BF16, dev) if self.relpos_stream else None
             dP = Z(Rpad, Dp)
-            duv = Z(2, Dp)
+            du, dv = (slots[("du", li)], slots[("dv", li)]) if trainable else (Z(Dp), Z(Dp))
             call("sed_relpos_attn_bwd", L["qu"], to_bf16_(L["qut"]), L["qv"], to_bf16_(L["qvt"]), L["k"], to_bf16_(L["kt"]),
-                 to_bf16_(L["v"]), L["Ph"], to_bf16_(L["Pt"]), L["o16"], do16, L["lse"], Dtmp, dOh, dOt, dqkv, dSt, Pst, dP, duv[0], duv[1], B, H,
+                 to_bf16_(L["v"]), L["Ph"], to_bf16_(L["Pt"]), L["o16"], do16, L["lse"], Dtmp, dOh, dOt, dqkv, dSt, Pst, dP, du, dv, B, H,
                  T, Tpad, Rpad, 1 if trainable else 0, 1, o_kind(L["o16"]))
             del dSt, Pst, dOh, dOt, do16
             if trainable:
-                G(p + "attn.pos_bias_u").add_(duv[0].view(H, HD_PAD)[:, :hd])
-                G(p + "attn.pos_bias_v").add_(duv[1].view(H, HD_PAD)[:, :hd])
+                # gradient images (padded heads) in the zeroed slots of `_grad_slots`; one scatter launch after the loop un-pads them
                 dPT = E(Dp, Rpad, dt=BF16)
                 transpose_bf16(dP, Rpad, Dp, dPT)
-                gwp = Z(Dp, Dd)
-                gemm_dw(dPT, posT16, gwp)
-                G(p + "attn.linear_pos.weight").add_(unrows(gwp, SQRT2))
-                gwi, gbi = Z(3 * Dp, Dd), Z(3 * Dp)
-                self._dw_accum(dqkv, L["y16"], M, gwi, gbi)
-                self._join_dw()      # gwi / gbi likewise
-                gw, gb = G(p + "attn.in_proj.weight"), G(p + "attn.in_proj.bias")
-                for s_, sc in ((0, 1.0), (1, SQRT2), (2, 1.0)):
-                    gw[s_ * Dd:(s_ + 1) * Dd].add_(unrows(gwi[s_ * Dp:(s_ + 1) * Dp], sc))
-                    gb[s_ * Dd:(s_ + 1) * Dd].add_(unrows(gbi[s_ * Dp:(s_ + 1) * Dp].view(-1, 1), sc).view(-1))
+                gemm_dw(dPT, posT16, slots[("gwp", li)].view(Dp, Dd))
+                self._dw_accum(dqkv, L["y16"], M, slots[("gwi", li)].view(3 * Dp, Dd), slots[("gbi", li)])
             gemm_nt(dqkv, W[p + "attn.in_proj.weight"].wt, EPI_F32_RESID, res=g2, outF=g2)
             gnew = E(B, T, Dd)
             call("sed_ln_bwd_any", g2, L["x_in"], L["mean1"], L["rstd1"], self.P(p + "norm1.weight"), L["in_scale"], gnew.view(M, Dd), 0,
@@ -650,7 +770,14 @@ class PmamEngine(SedEngine):
                 if G("classifier.weight") is not None:
                     G("classifier.weight").add_(gw_pad[:, :Dd])
                 g = g_pad[:, :, :Dd].contiguous()
-        g = self._decoder_bwd(W, ctx["dctx"], g, G, G("decoder.encoder_blocks.0.attn.in_proj.weight") is not None)
+        dec_train = G("decoder.encoder_blocks.0.attn.in_proj.weight") is not None
+        cnn_train = G("cnn.cnn.conv0.weight") is not None
+        slots, scatter = self._grad_slots(B, dev, G, dec_train, cnn_train)
+        g = self._decoder_bwd(W, ctx["dctx"], g, G, dec_train, slots)
+        if dec_train:
+            self._join_dw()      # out_proj / in_proj gradient images were filled on the weight-gradient side stream
+            if "dec" in scatter:
+                call("sed_scatter_add_f32", *scatter["dec"])
         if ctx["mlm_plan"] is not None:
             plan = ctx["mlm_plan"]
             gx = Z(B, Tdec, Dd)
@@ -670,9 +797,10 @@ class PmamEngine(SedEngine):
         g16 = self._dw_accum(dP2, ctx["feat"], B * Tc, G("cnn_projector.weight"), G("cnn_projector.bias"))
         dfeat = E(B * Tc, ctx["feat"].shape[1])
         gemm_nt(g16, W["cnn_projector.weight"].wt, EPI_F32, outF=dfeat)
-        cnn_train = G("cnn.cnn.conv0.weight") is not None
         if cnn_train:
-            self._cnn_bwd(W, ctx["cctx"], dfeat, B, G)
+            self._cnn_bwd(W, ctx["cctx"], dfeat, B, G, slots)
+            if "cnn" in scatter:
+                call("sed_scatter_add_f32", *scatter["cnn"])
         g16 = self._dw_accum(dP1, ctx["pooled"].view(B * tp, D), B * tp, G("transformer_projector.weight"), G("transformer_projector.bias"))
         dpooled = E(B * tp, D)
         gemm_nt(g16, W["transformer_projector.weight"].wt, EPI_F32, outF=dpooled)
