@@ -316,6 +316,18 @@ int sed_mlm_apply_bwd_c(const float* dout, const uint8_t* action, const int* src
 /* dP1 / dP2 / d merge_weight of sed_pmam_merge (dmw += , nullable) */
 int sed_pmam_merge_bwd(const float* g, const float* P2, const float* mw, float* dP1, float* dP2, float* dmw, int B, int tp1,
                        int pad1, int r1, int tp2, int r2, int C, hipStream_t stream);
+/* LoRA gradients by skinny products (src/models/lora/layers.py:148-151: y = x W^T + s (x A^T) B^T, A [r, in], B [out, r]; autograd:
+ * dB = s dy^T (x A^T), dA = (s dy B)^T x) -- one pass over x or dy each, the gradient of the merged weight is never formed:
+ *   rowproj    out[M, r] fp32 = scale * X[M, K] (16-bit, row stride ldx) . Wm, Wm fp32 [r, K] (w_kxr 0) or [K, r] (1); K % 32 == 0, r <= 16
+ *   colreduce  G += scale * sum_m P[m, j] Y[m, c], P fp32 [M, r], Y 16-bit [M, C] (row stride ldy); G fp32 [C, r] (g_cxr 1) or [r, C] (0);
+ *              C % 4 == 0, r <= 8 */
+int sed_lora_rowproj(const void* X, int x_f16, int M, int K, int ldx, const float* Wm, int w_kxr, int r, float scale, float* out,
+                     hipStream_t stream);
+int sed_lora_colreduce(const void* Y, int y_f16, int M, int C, int ldy, const float* P, int r, float scale, float* G, int g_cxr,
+                       hipStream_t stream);
+/* keep-masks of nn.Dropout(p) (src/models/cnn/base.py:88-89): mask[e] = 1 with probability 1 - p (resolved to 2^-16), n % 4 == 0;
+ * counter-based generator keyed by `seed` (the values differ from torch's Philox stream; only the distribution belongs to the model) */
+int sed_dropout_mask(uint8_t* mask, int64_t n, float p, int64_t seed, hipStream_t stream);
 /* BatchNorm2d(eps, momentum) batch statistics -> per-channel affines (src/models/cnn/base.py:72-75, torch BatchNorm semantics):
  * s1 / s2 = sed_colstats(mode 0) sums over the M rows (train: running_mean / running_var updated in place, unbiased variance) or
  * nullptr (eval: the running statistics are used); a = gamma rstd, b = beta - mean a, ah = rstd, bh = -mean rstd. */

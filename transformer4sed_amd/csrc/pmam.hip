@@ -477,7 +477,7 @@ __global__ void pmam_merge_bwd_kernel(const float* __restrict__ g, const float* 
     const int tin = second ? tp2 : tp1, ratio = second ? r2 : r1, tlen = second ? tp2 : tp1 + pad1;
     const size_t total = (size_t)B * tin * C4;
     const float w = mw[0];
-    float dw_part = 0.f;
+    double dw_part = 0.0;      // (the merge weight's gradient is a sum of ~10^6 products that cancel to ~10^-5 of their size: fp64 partials)
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int d4 = (int)(idx % C4);
         const int i = (int)((idx / C4) % tin);
@@ -502,7 +502,7 @@ __global__ void pmam_merge_bwd_kernel(const float* __restrict__ g, const float* 
         }
         if (second) {
             const float4 p = reinterpret_cast<const float4*>(P2)[idx];
-            dw_part += acc.x * p.x + acc.y * p.y + acc.z * p.z + acc.w * p.w;    // sum_j g lerp(P2) = sum_i (lerp^T g)_i P2_i
+            dw_part += ((double)acc.x * p.x + (double)acc.y * p.y) + ((double)acc.z * p.z + (double)acc.w * p.w);    // sum_j g lerp(P2) = sum_i (lerp^T g)_i P2_i
             acc.x *= w; acc.y *= w; acc.z *= w; acc.w *= w;
             reinterpret_cast<float4*>(dP2)[idx] = acc;
         } else {
@@ -510,8 +510,12 @@ __global__ void pmam_merge_bwd_kernel(const float* __restrict__ g, const float* 
         }
     }
     if (second && dmw != nullptr) {
-        dw_part = wave_sum(dw_part);
-        if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(dmw, dw_part);
+        __shared__ double wsum[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dw_part += __shfl_xor(dw_part, o, 64);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = dw_part;
+        __syncthreads();
+        if (threadIdx.x == 0) unsafeAtomicAdd(dmw, (float)((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])));
     }
 }
 extern "C" int sed_pmam_merge_bwd(const float* g, const float* P2, const float* mw, float* dP1, float* dP2, float* dmw, int B,
@@ -1049,5 +1053,244 @@ extern "C" int sed_bn_finalize(const float* s1, const float* s2, const float* ga
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, stream, s1, s2, gamma, beta, run_mean, run_var,
                        (float)(1.0 / (double)M), (float)((double)M / (double)(M - 1)), (float)momentum, (float)(1.0 - momentum), (float)eps, a, b,
                        ah, bh, C);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LoRA gradients without the gradient of the merged weight (round 4).  For y = x W^T + s (x A^T) B^T (src/models/lora/layers.py:148-151;
+// A [r, in], B [out, r]) autograd gives  dB = s dy^T (x A^T),  dA = (s dy B)^T x:  four skinny products over the M tokens, each a single
+// pass over x or dy, instead of the full dW = dy^T x (2 M out in flops per layer, the split-K reduce and the projection of dW):
+//   sed_lora_rowproj    out[M, r] = scale * X[M, K] . Wm        (u = x A^T;  du = s dy B)       MFMA 16x16x32, X fragments straight from HBM
+//   sed_lora_colreduce  G += scale * sum_m P[m, :] (x) Y[m, :]    (dB from dy, u;  dA from x, du)  lane = 4 columns, P by scalar loads
+// ---------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) _Float16 pm_f16x8_t;
+template <bool F16> __device__ __forceinline__ f32x4_t pm_mfma16(s16x8_t a, s16x8_t b, f32x4_t c) {
+    if (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pm_f16x8_t, a), __builtin_bit_cast(pm_f16x8_t, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+// Wm fp32 [r, K] (w_kxr = 0) or [K, r] (1) -> 16-bit image in LDS, row j at j * (2 K + 16) bytes (the 16-byte skew spreads the 16 rows of
+// a fragment read over the banks); a wave owns 16 token rows at a time: A operand = lane (row l & 15, k chunk l >> 4) 16-byte loads from X.
+template <bool F16>
+__global__ __launch_bounds__(256) void lora_rowproj_kernel(const bf16_t* __restrict__ X, int ldx, const float* __restrict__ Wm, int w_kxr, int M,
+                                                           int K, int r, float scale, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pm_wl[];
+    const int rows_w = r <= 8 ? 8 : 16, stride = K * 2 + 16;
+    // W image: batches of independent loads (a load -> convert -> ds_write chain per element made this prologue, not the stream over X,
+    // the longest part of the kernel: 96 dependent round trips at K = 3072)
+    if (w_kxr && r == 8) {      // Wm [K, 8]: one thread per k, its row as two 16-byte loads
+        for (int k = threadIdx.x; k < K; k += 1024) {
+            float4 v[4][2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    v[q][h] = (k + 256 * q < K) ? reinterpret_cast<const float4*>(Wm + (size_t)(k + 256 * q) * 8)[h] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (k + 256 * q < K) {
+                    unsigned char* d = pm_wl + (k + 256 * q) * 2;
+                    *reinterpret_cast<bf16_t*>(d) = to_16<F16>(v[q][0].x);
+                    *reinterpret_cast<bf16_t*>(d + stride) = to_16<F16>(v[q][0].y);
+                    *reinterpret_cast<bf16_t*>(d + 2 * stride) = to_16<F16>(v[q][0].z);
+                    *reinterpret_cast<bf16_t*>(d + 3 * stride) = to_16<F16>(v[q][0].w);
+                    *reinterpret_cast<bf16_t*>(d + 4 * stride) = to_16<F16>(v[q][1].x);
+                    *reinterpret_cast<bf16_t*>(d + 5 * stride) = to_16<F16>(v[q][1].y);
+                    *reinterpret_cast<bf16_t*>(d + 6 * stride) = to_16<F16>(v[q][1].z);
+                    *reinterpret_cast<bf16_t*>(d + 7 * stride) = to_16<F16>(v[q][1].w);
+                }
+        }
+    } else if (w_kxr) {  // Wm [K, r]: one thread per k, its r values contiguous
+        for (int k = threadIdx.x; k < K; k += 1024) {
+            float v[4][16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[q][j] = (j < r && k + 256 * q < K) ? Wm[(size_t)(k + 256 * q) * r + j] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (k + 256 * q < K)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (j < rows_w) *reinterpret_cast<bf16_t*>(pm_wl + j * stride + (k + 256 * q) * 2) = to_16<F16>(v[q][j]);
+        }
+    } else {             // Wm [r, K]: four consecutive k per thread
+        const int nq = K / 4;
+        for (int j = 0; j < rows_w; ++j)
+            for (int q0 = threadIdx.x; q0 < nq; q0 += 2048) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = (j < r && q0 + 256 * u < nq) ? reinterpret_cast<const float4*>(Wm + (size_t)j * K)[q0 + 256 * u] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (q0 + 256 * u < nq) {
+                        uint2 pk;
+                        pk.x = pack2<F16>(v[u].x, v[u].y);
+                        pk.y = pack2<F16>(v[u].z, v[u].w);
+                        *reinterpret_cast<uint2*>(pm_wl + j * stride + (q0 + 256 * u) * 8) = pk;
+                    }
+            }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, kc = lane >> 4;
+    const bool has_w = n < rows_w;
+    // K is walked 64 columns per pair of MFMA steps: lane group kc owns columns 16 kc .. 16 kc + 15 of them (32 contiguous bytes: the four
+    // groups of a row cover one 128-byte line), the first eight in the even step, the other eight in the odd one; the W fragments follow.
+    // A workgroup owns 16 token rows at a time, its four waves a quarter of K each (one tile per wave left most waves of the grid with a
+    // single tile and K / 256 dependent memory round trips: 72 us for 175 MB); the partial tiles meet in LDS.
+    __shared__ float part[4][16][17];
+    const unsigned char* wr = pm_wl + (has_w ? n : 0) * stride + kc * 32;
+    const s16x8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int kq = ((K / 64 + 3) / 4) * 64, kb = wave * kq, ke = (kb + kq) < K ? (kb + kq) : K;
+    for (int tile = blockIdx.x; tile * 16 < M; tile += gridDim.x) {
+        const int row0 = tile * 16;
+        int row = row0 + n;
+        row = row < M ? row : M - 1;
+        const bf16_t* xr = X + (size_t)row * ldx + kc * 16;
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = kb; k0 < ke; k0 += 512) {       // sixteen 32-wide K steps per trip, their loads issued together
+            s16x8_t xa[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (k0 + 64 * (u >> 1) < ke) xa[u] = *reinterpret_cast<const s16x8_t*>(xr + k0 + 64 * (u >> 1) + 8 * (u & 1));
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (k0 + 64 * (u >> 1) < ke) {
+                    const s16x8_t wb = has_w ? *reinterpret_cast<const s16x8_t*>(wr + (k0 + 64 * (u >> 1) + 8 * (u & 1)) * 2) : zero8;
+                    acc = pm_mfma16<F16>(xa[u], wb, acc);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[wave][4 * kc + i][n] = acc[i];       // D[m = 4 (lane >> 4) + i][n = lane & 15]
+        __syncthreads();
+        {
+            const int ro = threadIdx.x >> 4, col = threadIdx.x & 15;
+            if (col < r && row0 + ro < M)
+                out[(size_t)(row0 + ro) * r + col] = scale * ((part[0][ro][col] + part[1][ro][col]) + (part[2][ro][col] + part[3][ro][col]));
+        }
+        __syncthreads();
+    }
+}
+extern "C" int sed_lora_rowproj(const void* X, int x_f16, int M, int K, int ldx, const float* Wm, int w_kxr, int r, float scale, float* out,
+                                hipStream_t stream) {
+    (void)hipGetLastError();
+    if (M <= 0 || K <= 0 || (K % 64) || (ldx % 8) || ldx < K || r <= 0 || r > 16) return SED_ERR_ARG;
+    const int lds = (r <= 8 ? 8 : 16) * (K * 2 + 16);
+    if (lds > 152 * 1024) return SED_ERR_ARG;      // (4.3 KiB of static LDS beside the W image)
+    int blocks = cdiv(M, 16);
+    if (blocks > 768) blocks = 768;      // (three 49 KiB workgroups per CU at K = 3072: the W image is built once per resident workgroup)
+    static bool attr[2] = {false, false};
+    if (x_f16) {
+        if (!attr[1]) { (void)hipFuncSetAttribute((const void*)lora_rowproj_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); attr[1] = true; }
+        hipLaunchKernelGGL((lora_rowproj_kernel<true>), dim3(blocks), dim3(256), lds, stream, (const bf16_t*)X, ldx, Wm, w_kxr, M, K, r, scale, out);
+    } else {
+        if (!attr[0]) { (void)hipFuncSetAttribute((const void*)lora_rowproj_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); attr[0] = true; }
+        hipLaunchKernelGGL((lora_rowproj_kernel<false>), dim3(blocks), dim3(256), lds, stream, (const bf16_t*)X, ldx, Wm, w_kxr, M, K, r, scale, out);
+    }
+    return sed_check_launch();
+}
+// grid (column groups of 256, token slabs); the four waves of a workgroup take every fourth token of the slab, their partial sums meet in
+// LDS and leave as coalesced atomics: G [C, r] (g_cxr = 1: dB) or [r, C] (0: dA).  r <= 8.
+template <bool F16>
+__global__ __launch_bounds__(256) void lora_colreduce_kernel(const bf16_t* __restrict__ Y, int ldy, const float* __restrict__ P, int M, int C, int r,
+                                                             float scale, float* __restrict__ G, int g_cxr, int rows_per_wg) {
+    __shared__ float red[4][8][256];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c0 = blockIdx.x * 256, c = c0 + 4 * lane;
+    const bool live = c < C;
+    const int m_begin = blockIdx.y * rows_per_wg, m_end = (m_begin + rows_per_wg) < M ? (m_begin + rows_per_wg) : M;
+    float acc[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][e] = 0.f;
+    for (int m0 = m_begin + wave; m0 < m_end; m0 += 32) {      // eight rows of this wave per trip (m0, m0 + 4, ...): 4 KiB in flight
+        uint2 y[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int m = m0 + 4 * u;
+            y[u] = (live && m < m_end) ? *reinterpret_cast<const uint2*>(Y + (size_t)m * ldy + c) : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int m = m0 + 4 * u;
+            if (m >= m_end) break;       // (wave-uniform)
+            const float* pr = P + (size_t)m * r;
+            float yv[4];
+            if (F16) {
+                yv[0] = h2f((bf16_t)(y[u].x & 0xffffu)); yv[1] = h2f((bf16_t)(y[u].x >> 16));
+                yv[2] = h2f((bf16_t)(y[u].y & 0xffffu)); yv[3] = h2f((bf16_t)(y[u].y >> 16));
+            } else {
+                yv[0] = __uint_as_float(y[u].x << 16); yv[1] = __uint_as_float(y[u].x & 0xffff0000u);
+                yv[2] = __uint_as_float(y[u].y << 16); yv[3] = __uint_as_float(y[u].y & 0xffff0000u);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < r) {
+                    const float pj = pr[j];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(pj, yv[e], acc[j][e]);
+                }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave][j][4 * lane + e] = acc[j][e];
+    __syncthreads();
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = t + 256 * i;
+        const int col = g_cxr ? (e >> 3) : (e & 255), j = g_cxr ? (e & 7) : (e >> 8);
+        if (j < r && c0 + col < C) {
+            const float v = (red[0][j][col] + red[1][j][col]) + (red[2][j][col] + red[3][j][col]);
+            unsafeAtomicAdd(G + (g_cxr ? (size_t)(c0 + col) * r + j : (size_t)j * C + c0 + col), scale * v);
+        }
+    }
+}
+extern "C" int sed_lora_colreduce(const void* Y, int y_f16, int M, int C, int ldy, const float* P, int r, float scale, float* G, int g_cxr,
+                                  hipStream_t stream) {
+    (void)hipGetLastError();
+    if (M <= 0 || C <= 0 || (C % 4) || (ldy % 4) || ldy < C || r <= 0 || r > 8) return SED_ERR_ARG;
+    const int cgs = cdiv(C, 256);
+    int slabs = 1024 / cgs;      // one round of four workgroups per CU
+    if (slabs < 1) slabs = 1;
+    int rows = cdiv(M, slabs);
+    rows = (rows + 31) / 32 * 32;
+    slabs = cdiv(M, rows);
+    if (y_f16)
+        hipLaunchKernelGGL((lora_colreduce_kernel<true>), dim3(cgs, slabs), dim3(256), 0, stream, (const bf16_t*)Y, ldy, P, M, C, r, scale, G, g_cxr, rows);
+    else
+        hipLaunchKernelGGL((lora_colreduce_kernel<false>), dim3(cgs, slabs), dim3(256), 0, stream, (const bf16_t*)Y, ldy, P, M, C, r, scale, G, g_cxr, rows);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Dropout keep-masks of the CNN branch (nn.Dropout(conv_dropout) after every ContextGating, src/models/cnn/base.py:88-89), all layers in one
+// launch: mask[e] = 1 with probability 1 - p.  Counter-based generator (splitmix64 finaliser of seed + 4-element group index, 16 bits per
+// element: p is resolved to 1 / 65536) -- torch's Philox stream cannot be reproduced from outside torch, and only the distribution is part
+// of the model.  Replaces rand -> compare -> byte cast (three launches and 9 bytes of traffic per element, per layer).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dropout_mask_kernel(unsigned char* __restrict__ mask, long long n4, unsigned thr, unsigned long long seed) {
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < n4; g += (long long)gridDim.x * 256) {
+        unsigned long long z = seed + (unsigned long long)(g + 1) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        const unsigned lo = (unsigned)z, hi = (unsigned)(z >> 32);
+        const unsigned m = ((lo & 0xffffu) >= thr ? 1u : 0u) | ((lo >> 16) >= thr ? 0x100u : 0u) | ((hi & 0xffffu) >= thr ? 0x10000u : 0u) |
+                           ((hi >> 16) >= thr ? 0x1000000u : 0u);
+        reinterpret_cast<unsigned*>(mask)[g] = m;
+    }
+}
+extern "C" int sed_dropout_mask(uint8_t* mask, int64_t n, float p, int64_t seed, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n <= 0 || (n % 4) || p < 0.f || p >= 1.f) return SED_ERR_ARG;
+    const unsigned thr = (unsigned)(p * 65536.0f + 0.5f);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for((size_t)(n / 4))), dim3(256), 0, stream, mask, (long long)(n / 4), thr,
+                       (unsigned long long)seed);
     return sed_check_launch();
 }

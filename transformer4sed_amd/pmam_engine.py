@@ -14,6 +14,7 @@ Reuses every encoder / context-network kernel of the MAT-SED engine and adds, in
     weights sum to one), which shrinks the two GEMMs from 1000 to 99 / 250 rows per clip.
 """
 import math
+import os
 
 import torch
 
@@ -31,9 +32,19 @@ def pad128(n):
     return (n + 127) // 128 * 128
 
 
+class _LoraSlot:
+    """What the encoder backward receives in place of a LoRA linear's weight-gradient view: the factors and their gradient views."""
+    __slots__ = ("A", "B", "gA", "gB", "r", "s", "shape")
+
+    def __init__(self, A, B, gA, gB, r, s):
+        self.A, self.B, self.gA, self.gB, self.r, self.s = A, B, gA, gB, r, s
+        self.shape = (B.shape[0], A.shape[1])
+
+
 class PmamEngine(SedEngine):
     def __init__(self, module):
         super().__init__(module)
+        self.lora_skinny = os.environ.get("SED_LORA_SKINNY", "1") != "0"
         if not self.split:
             raise RuntimeError("the PMAM path runs its 384-wide context network in split precision (SED_DECODER_SPLIT=1, f16 forward)")
         self.dec_terms2 = False      # (its own context-network schedule below keeps three terms in every GEMM)
@@ -283,6 +294,19 @@ class PmamEngine(SedEngine):
         aff = E(nl, 4, cmax)                                                # a | b | ah | bh of every layer (saved for the backward)
         if train:
             torch._foreach_add_([m._buffer_by_name[f"cnn.cnn.batchnorm{i}.num_batches_tracked"] for i in range(nl)], 1)
+        gen_masks = None
+        if train and m.conv_dropout > 0 and drop_masks is None:
+            # keep-masks of every layer from one launch; the seed comes from torch's CPU generator (reproducible under torch.manual_seed)
+            sizes, Hm, Wm = [], T, 128
+            for i, a_ in enumerate(self.cnn_aux):
+                sizes.append(B * Hm * Wm * a_["co"])
+                Hm, Wm = Hm // m.cnn_pooling[i][0], Wm // m.cnn_pooling[i][1]
+            flat = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
+            call("sed_dropout_mask", flat, flat.numel(), float(m.conv_dropout), int(torch.randint(0, 2 ** 62, (1,)).item()))
+            gen_masks, off = [], 0
+            for n_ in sizes:
+                gen_masks.append(flat[off:off + n_])
+                off += n_
         for i, aux in enumerate(self.cnn_aux):
             co, Np, Kp, Cp, cin = aux["co"], aux["Np"], aux["Kp"], aux["Cp"], aux["cin"]
             Mi = B * Hc * Wc
@@ -322,7 +346,7 @@ class PmamEngine(SedEngine):
             mask = None
             scale = 1.0
             if train and m.conv_dropout > 0:
-                mask = drop_masks[i] if drop_masks is not None else (torch.rand(Mi, co, device=dev) >= m.conv_dropout).to(torch.uint8)
+                mask = drop_masks[i] if drop_masks is not None else gen_masks[i].view(Mi, co)
                 scale = 1.0 / (1.0 - m.conv_dropout)
             call("sed_cg_pool", Y, ldy, a, b, L, ldy, mask, float(scale), Xn, feat, B, Hc, Wc, co, Cpo, ph, pw, f16)
             if save:
@@ -514,6 +538,40 @@ class PmamEngine(SedEngine):
         return out, ctx
 
     # ==================================================================== backward
+    def _dw_accum(self, dy, x, M, gW, bias=None, dy16=None, k_in=None):
+        """As SedEngine._dw_accum; a `_LoraSlot` in place of the weight-gradient view selects the LoRA form: dB += s dy^T (x A^T),
+        dA += (s dy B)^T x (lora/layers.py:148-151 under autograd) as two projections onto the r factors and two reductions over the
+        tokens -- each one pass over x or dy, on the weight-gradient side stream like the TN GEMM they replace."""
+        if not isinstance(gW, _LoraSlot):
+            return super()._dw_accum(dy, x, M, gW, bias, dy16=dy16, k_in=k_in)
+        sl = gW
+        n_out, kin = sl.shape
+        g16 = super()._dw_accum(dy, x, M, None, bias, dy16=dy16, k_in=kin)     # bf16 image of dy (cast pass only if there is none yet)
+        if x.dtype not in (F16, BF16) or g16.dtype != BF16:
+            raise RuntimeError("LoRA gradient products expect 16-bit saved operands")
+        dev = g16.device
+        ldx = x.shape[1]
+
+        def run():
+            u, du = torch.empty(M, sl.r, device=dev), torch.empty(M, sl.r, device=dev)
+            call("sed_lora_rowproj", x, is_f16(x), M, kin, ldx, sl.A, 0, sl.r, 1.0, u)
+            call("sed_lora_rowproj", g16, 0, M, n_out, g16.shape[1], sl.B, 1, sl.r, sl.s, du)
+            call("sed_lora_colreduce", g16, 0, M, n_out, g16.shape[1], u, sl.r, sl.s, sl.gB, 1)
+            call("sed_lora_colreduce", x, is_f16(x), M, kin, ldx, du, sl.r, 1.0, sl.gA, 0)
+
+        if self.dw_side and ops.TIMER is None and g16.is_cuda:
+            if self._dw_stream is None:
+                self._dw_stream = torch.cuda.Stream(device=dev)
+            self._dw_stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self._dw_stream):
+                run()
+            g16.record_stream(self._dw_stream)
+            x.record_stream(self._dw_stream)
+            self._dw_pending = True
+        else:
+            run()
+        return g16
+
     def _dw_swapped_tn(self, M, n, k):
         """Does `_dw_swapped` run the TN kernel for these shapes (gradient image laid out [n, k]) or the transposed-copy path ([k, n])?"""
         return bool(self.dw_tn and M >= 1024 and dw_tn_ok(M, n, k))
@@ -834,6 +892,11 @@ class PmamEngine(SedEngine):
             def Gl(name, pre=pre, tmp=tmp):
                 if name.endswith(".weight") and name[:-7] + ".lora_A" in m._param_by_name and G(name[:-7] + ".lora_A") is not None \
                         and G(name) is None:
+                    base = name[:-7]
+                    if self.lora_skinny and m.lora_r <= 8:
+                        # (`_dw_accum` below turns this into the four skinny products; the gradient of the merged weight is never formed)
+                        return _LoraSlot(self.P(base + ".lora_A").detach(), self.P(base + ".lora_B").detach(), G(base + ".lora_A"),
+                                         G(base + ".lora_B"), m.lora_r, s)
                     if name not in tmp:
                         tmp[name] = torch.zeros_like(m._param_by_name[name])
                     return tmp[name]
