@@ -338,6 +338,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE_DMA, WP
         const unsigned char* lk = lds[buf][0];
         const unsigned char* lv = lds[buf][1];
         f32x16_t st[2];
+        if (q0 < N) {        // (wave-uniform) a wave whose 32 queries all lie past the sequence end only stages tiles and joins the barriers
 #ifndef ATT_NO_KPRE
         {   // all eight K fragments requested before the first MFMA: their LDS latency is paid once per tile, not once per MFMA
             s16x8_t kf[2][4];
@@ -384,6 +385,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE_DMA, WP
             ATT_PV(1, 3, 0)
 #undef ATT_RDV
 #undef ATT_PV
+        }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile t + 1 have landed ...
         __syncthreads();                                      // ... and everybody's; nobody reads tile t any more
@@ -489,6 +491,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
     const int key0 = blockIdx.x * 128 + wave * 32;
+    const bool wave_live = __builtin_amdgcn_readfirstlane(key0) < N;
     const size_t hb = (size_t)bh * N * HD;
 
     int krow = key0 + lr;
@@ -542,6 +545,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_kernel(
         if (t + 1 < ntiles) gload(t + 1);
         const unsigned char* lq = lds[buf][1];
         const unsigned char* ldo = lds[buf][2];
+        if (wave_live)       // (wave-uniform) a wave whose 32 keys all lie past the sequence end only stages tiles and joins the barriers
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {  // 32-query sub-blocks of the tile
             f32x16_t s_, dp;
@@ -615,6 +619,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const bf16_t* __restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
     const int q0 = blockIdx.x * 128 + wave * 32;
+    const bool wave_live = __builtin_amdgcn_readfirstlane(q0) < N;
     const size_t hb = (size_t)bh * N * HD;
     int qrow = q0 + lr;
     const bool qvalid = qrow < N;
@@ -673,6 +678,7 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const bf16_t* __restri
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1, j0 = t * KVB;
         if (t + 1 < ntiles) gload(t + 1);
+        if (wave_live)       // (wave-uniform) see mhsa_bwd_dkdv_kernel
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16_t st, dp;
