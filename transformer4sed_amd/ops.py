@@ -286,11 +286,11 @@ def pad64(n):
 
 
 def gemm_nt(A, B, epi, M=None, bias=None, res=None, outF=None, outH=None, outH2=None, aux=None, alpha=1.0, ksplit=1,
-            lda=None, ldb=None, ldc=None, gbias=None, gb_rows=0, two_term=False):
+            lda=None, ldb=None, ldc=None, gbias=None, gb_rows=0, two_term=False, K=None):
     """C[M,N] = A[M,K] . B[N,K]^T (bf16 operands) with fused epilogue; see include/sed_hip.h.  `gbias` [M / gb_rows, N]: row-group bias.
     `two_term`: B is the [N, 2K] image [f16(W) | f16(W - f16(W))] over an A of K columns."""
     M = A.shape[0] if M is None else M
-    N, K = B.shape[0], B.shape[1]
+    N, K = B.shape[0], (B.shape[1] if K is None else K)      # (`K` < B.shape[1] with ldb = B.shape[1]: the first K columns of B's rows)
     if two_term:
         if A.dtype != F16 or B.dtype != F16 or K != 2 * A.shape[1]:
             raise RuntimeError("gemm_nt: two-term weights take an f16 A [M, K] and an f16 B [N, 2K]")
@@ -306,7 +306,7 @@ def gemm_nt(A, B, epi, M=None, bias=None, res=None, outF=None, outH=None, outH2=
     pre_bf16 = epi in (EPI_GELU, EPI_GELU32) and outH is not None and outH.dtype == BF16 and A.dtype == F16
     if A.dtype != B.dtype or any(t is not None and t.dtype != A.dtype for t in ((None if pre_bf16 else outH), outH2, aux)):
         raise RuntimeError("gemm_nt: all 16-bit operands/outputs of one GEMM must share one type (f16 or bf16)")
-    call("sed_gemm_nt", A, B, M, N, K, lda or A.shape[1], ldb or K, epi, bias, res, outF, outH, outH2, aux, ldc or N,
+    call("sed_gemm_nt", A, B, M, N, K, lda or A.shape[1], ldb or B.shape[1], epi, bias, res, outF, outH, outH2, aux, ldc or N,
          float(alpha), ksplit, 3 if pre_bf16 else is_f16(A))
 
 

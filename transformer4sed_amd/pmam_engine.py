@@ -142,12 +142,13 @@ class PmamEngine(SedEngine):
             mat(cw, cw, plan=self._plan(("conv", Np, Kp), P(cw).shape, dev,
                                         lambda w, k, Np=Np, Kp=Kp: pad2(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1), Np, Kp)))
             mat(gw, gw, plan=self._plan(("gate", Np, Cp), P(gw).shape, dev, lambda w, k, Np=Np, Cp=Cp: pad2(w, Np, Cp)))
-            # backward operand of the gate GEMM: [Np (N), Np (K)] = W_gate^T, zero padded, bf16
-            mat(gw + "#T", gw, plan=self._plan(("gateT", Np), P(gw).shape, dev, lambda w, k, Np=Np: pad2(w.t(), Np, Np)), kind="bf16")
+            # backward operand of the gate GEMM: [Np (N), ldg (K)] = W_gate^T, zero padded, bf16 (ldg: row width of the gradient images)
+            ldg = 64 if co <= 64 else Np
+            mat(gw + "#T", gw, plan=self._plan(("gateT", Np, ldg), P(gw).shape, dev, lambda w, k, Np=Np, ldg=ldg: pad2(w.t(), Np, ldg)), kind="bf16")
             bplan = lambda n, Np=Np: self._plan(("b", Np), P(n).shape, dev, lambda b, k: pad2(b.view(1, -1), 1, Np).view(-1))
             vecs.append((("cnn", i, "bias"), f"cnn.cnn.conv{i}.bias", bplan(f"cnn.cnn.conv{i}.bias")))
             vecs.append((("cnn", i, "gbias"), f"cnn.cnn.cg{i}.linear.bias", bplan(f"cnn.cnn.cg{i}.linear.bias")))
-            geo.append(dict(Np=Np, Kp=Kp, Cp=Cp, cin=cin, co=co))
+            geo.append(dict(Np=Np, Kp=Kp, Cp=Cp, cin=cin, co=co, ldg=ldg))
             cin = co
         self._specs, self._specs_key = (mats, vecs, geo), key
         return self._specs
@@ -638,16 +639,18 @@ class PmamEngine(SedEngine):
         if cnn_train:
             Hc, Wc = 1000, 128
             for i, g in enumerate(geo):
-                co, Np, Kp, Cp, cin = g["co"], g["Np"], g["Kp"], g["Cp"], g["cin"]
+                co, Np, Kp, Cp, cin, ldg = g["co"], g["Np"], g["Kp"], g["Cp"], g["cin"], g["ldg"]
                 Mi = B * Hc * Wc
                 cw, gw = f"cnn.cnn.conv{i}.weight", f"cnn.cnn.cg{i}.linear.weight"
                 bplan = self._plan(("b", Np), self.P(f"cnn.cnn.conv{i}.bias").shape, dev, None)
+                # the gradient images hold the first ldg of the weight images' Np rows (64 for the 16 / 32 / 64-filter layers: the bf16
+                # gradient operands are 64 columns wide there, round 4); the plans are read up to row ldg
                 for slot, master, plan, k in ((("gate", i), gw, self._plan(("gate", Np, Cp), self.P(gw).shape, dev, None), Cp),
                                               (("conv", i), cw, self._plan(("conv", Np, Kp), self.P(cw).shape, dev, None), Kp)):
-                    tn = self._dw_swapped_tn(Mi, Np, k)      # image element (i, j) of [Np, k] sits at i k + j (TN) or j Np + i
-                    items.append(("cnn", slot, Np * k, master, plan, Np * k, k, k if tn else 1, 1 if tn else Np))
-                items += [("cnn", ("gate_b", i), Np, f"cnn.cnn.cg{i}.linear.bias", bplan, Np, Np, 0, 1),
-                          ("cnn", ("conv_b", i), Np, f"cnn.cnn.conv{i}.bias", bplan, Np, Np, 0, 1),
+                    tn = self._dw_swapped_tn(Mi, ldg, k)      # image element (i, j) of [ldg, k] sits at i k + j (TN) or j ldg + i
+                    items.append(("cnn", slot, ldg * k, master, plan, ldg * k, k, k if tn else 1, 1 if tn else ldg))
+                items += [("cnn", ("gate_b", i), ldg, f"cnn.cnn.cg{i}.linear.bias", bplan, ldg, ldg, 0, 1),
+                          ("cnn", ("conv_b", i), ldg, f"cnn.cnn.conv{i}.bias", bplan, ldg, ldg, 0, 1),
                           ("cnn", ("bn_s1", i), co, f"cnn.cnn.batchnorm{i}.bias", None, co, co, 0, 1),
                           ("cnn", ("bn_s2", i), co, f"cnn.cnn.batchnorm{i}.weight", None, co, co, 0, 1)]
                 ph, pw = m.cnn_pooling[i]
@@ -691,9 +694,10 @@ class PmamEngine(SedEngine):
             Mi = B * Hc * Wc
             ph, pw = m.cnn_pooling[i]
             ldy = L["ldy"]
+            ldg = aux["ldg"]       # row width of the bf16 gradient operands: 64 columns hold the 16 / 32 / 64 filters (128 until round 4)
             dz = E(Mi, ldy)
-            dL16 = E(Mi, Np, dt=BF16)
-            call("sed_cg_pool_bwd", dout, L["Y"], ldy, L["a"], L["b"], L["L"], ldy, L["mask"], float(L["scale"]), dz, ldy, dL16, Np, B, Hc,
+            dL16 = E(Mi, ldg, dt=BF16)
+            call("sed_cg_pool_bwd", dout, L["Y"], ldy, L["a"], L["b"], L["L"], ldy, L["mask"], float(L["scale"]), dz, ldy, dL16, ldg, B, Hc,
                  Wc, co, ph, pw)
             # weight / bias gradient images land in the zeroed slots; `sed_scatter_add_f32` returns them to the masters after the loop
             self._dw_swapped(dL16, L["Z"], Mi, co, co, out=(slots[("gate", i)], slots[("gate_b", i)]))
@@ -704,14 +708,14 @@ class PmamEngine(SedEngine):
             s1, s2 = slots[("bn_s1", i)], slots[("bn_s2", i)]
             call("sed_colstats", dz, ldy, L["Y"], ldy, L["ah"], L["bh"], s1, s2, Mi, co, 1)
             bn = f"cnn.cnn.batchnorm{i}."
-            dY16 = E(Mi, Np, dt=BF16)
-            call("sed_bn_bwd", dz, ldy, L["Y"], ldy, L["ah"], L["bh"], self.P(bn + "weight"), s1, s2, dY16, Np, Mi, co)
+            dY16 = E(Mi, ldg, dt=BF16)
+            call("sed_bn_bwd", dz, ldy, L["Y"], ldy, L["ah"], L["bh"], self.P(bn + "weight"), s1, s2, dY16, ldg, Mi, co)
             del dz, dL16
             self._dw_swapped(dY16, L["col"], Mi, co, 9 * cin, out=(slots[("conv", i)], slots[("conv_b", i)]))
             cv = f"cnn.cnn.conv{i}."
             if i > 0:
                 dcol = E(Mi, Kp, dt=BF16)
-                gemm_nt(dY16, W[cv + "weight"].wt, EPI_BF16, outH=dcol)
+                gemm_nt(dY16, W[cv + "weight"].wt, EPI_BF16, outH=dcol, K=ldg)      # (the first ldg of the transposed image's Np columns)
                 dout = E(B, Hc, Wc, cin)
                 call("sed_col2im3x3", dcol, Kp, dout, B, Hc, Wc, cin)
             cctx["layers"][i] = None
