@@ -20,7 +20,7 @@
  * one normally gets a new suffixed name instead, like sed_median_filter_k).  History: 3 = round 3 (sed_relpos_attn_fwd gained O_split,
  * sed_relpos_attn_bwd gained Pst, both in place); 4 = round 4.  A binding compares sed_abi_version() with the header it was written
  * against before the first call (transformer4sed_amd/_lib.py does). */
-#define SED_HIP_ABI_VERSION 5
+#define SED_HIP_ABI_VERSION 6
 
 #ifdef __cplusplus
 extern "C" {
@@ -325,6 +325,11 @@ int sed_lora_rowproj(const void* X, int x_f16, int M, int K, int ldx, const floa
                      hipStream_t stream);
 int sed_lora_colreduce(const void* Y, int y_f16, int M, int C, int ldy, const float* P, int r, float scale, float* G, int g_cxr,
                        hipStream_t stream);
+/* weight / bias gradient of a 16- or 32-filter layer as a streaming reduction (the autograd of the CNN branch's gate Linear and 3x3
+ * convolution, src/models/cnn/base.py:19-30, 62-100, for its first layers): dW[i, j] += sum_m dY[m, i] X[m, j] (i < n in {16, 32},
+ * j < k <= 512, k % 4 == 0), dbias[i] += sum_m dY[m, i] (nullable); dY bf16 [M, ldy], X 16-bit [M, ldx], dW fp32 row stride ldw */
+int sed_small_dw(const void* dY, int ldy, int n, const void* X, int x_f16, int ldx, int k, float* dW, int ldw, float* dbias, int64_t M,
+                 hipStream_t stream);
 /* keep-masks of nn.Dropout(p) (src/models/cnn/base.py:88-89): mask[e] = 1 with probability 1 - p (resolved to 2^-16), n % 4 == 0;
  * counter-based generator keyed by `seed` (the values differ from torch's Philox stream; only the distribution belongs to the model) */
 int sed_dropout_mask(uint8_t* mask, int64_t n, float p, int64_t seed, hipStream_t stream);

@@ -355,3 +355,22 @@ def test_dropout_mask_distribution():
     x = m2 - 0.7
     assert abs(float((x[:, :-1] * x[:, 1:]).mean())) < 5 * 0.21 / math.sqrt(n)       # neighbouring elements uncorrelated
     assert abs(float((x[:-1] * x[1:]).mean())) < 5 * 0.21 / math.sqrt(n)             # neighbouring rows uncorrelated
+
+
+@pytest.mark.parametrize("n,k,ldy,ldx,xdt", [(16, 16, 64, 64, F16), (16, 12, 64, 64, F16), (16, 144, 64, 256, F16), (32, 32, 64, 64, F16),
+                                              (32, 288, 64, 384, BF16)])
+def test_small_dw_streaming_reduction(n, k, ldy, ldx, xdt):
+    """sed_small_dw: dW += dY^T X, dbias += column sums for 16 / 32-filter layers (the CNN branch's gate / convolution gradients) against
+    fp64 torch; garbage in the padding columns of either operand must not get in; accumulates."""
+    M = 100003
+    dY = torch.full((M, ldy), float("nan"), dtype=BF16, device=DEV); dY[:, :n] = rnd(M, n, scale=0.2, seed=81).to(BF16)
+    X = torch.full((M, ldx), float("nan"), dtype=xdt, device=DEV); X[:, :k] = rnd(M, k, seed=82).to(xdt)
+    dW0, db0 = rnd(64, ldx, seed=83).contiguous(), rnd(64, seed=84).contiguous()
+    dW, db = dW0.clone(), db0.clone()
+    call("sed_small_dw", dY, ldy, n, X, 1 if xdt == F16 else 0, ldx, k, dW, ldx, db, M)
+    want = dY[:, :n].double().t() @ X[:, :k].double()
+    got = (dW - dW0).double()
+    assert float((got[:n, :k] - want).abs().max() / want.abs().max()) < 2e-5
+    assert float(got[n:].abs().max()) == 0.0 and float(got[:, k:].abs().max()) == 0.0
+    wb = dY[:, :n].double().sum(0)
+    assert float(((db - db0).double()[:n] - wb).abs().max() / wb.abs().max()) < 2e-5 and float((db - db0)[n:].abs().max()) == 0.0

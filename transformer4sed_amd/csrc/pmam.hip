@@ -1294,3 +1294,133 @@ extern "C" int sed_dropout_mask(uint8_t* mask, int64_t n, float p, int64_t seed,
                        (unsigned long long)seed);
     return sed_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Weight gradient of a 16- or 32-filter layer (round 4): dW[i, j] += sum_m dY[m, i] X[m, j], dbias[i] += sum_m dY[m, i] for i < NV,
+// j < k <= 512, over millions of rows -- the gate / convolution gradients of the first CNN layers.  Through the 256 x 256-tile TN GEMM
+// such an output costs a full tile's K loop (~1.95 us per 64 rows whatever the width: 365 us + a 64 us reduce for 3 M rows, 2.2 TB/s on
+// its own operands); here it is a streaming reduction: lane = (row slot, 4 columns), the row's NV values of dY by two / four 16-byte
+// loads shared by the lanes of the slot, NV x 4 packed FMAs per row and lane, partial sums through shuffles and LDS, one round of atomics.
+// ---------------------------------------------------------------------------------------------------
+template <int NV, bool XF16>
+__global__ __launch_bounds__(256) void small_dw_kernel(const bf16_t* __restrict__ dY, int ldy, const bf16_t* __restrict__ X, int ldx, int k,
+                                                       float* __restrict__ dW, int ldw, float* __restrict__ dbias, long long M, int G,
+                                                       int rows_per_wg) {
+    extern __shared__ float sdw_red[];        // [4 waves][NV / HALVES... ][4 G]: see the combine below
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = lane & (G - 1), rs = lane / G, RS = 64 / G;
+    const int c0 = blockIdx.y * 4 * G + 4 * cg;
+    const bool col_ok = c0 < k;              // (k is a multiple of 4)
+    const long long m_begin = (long long)blockIdx.x * rows_per_wg, m_end = (m_begin + rows_per_wg) < M ? (m_begin + rows_per_wg) : M;
+    float acc[NV][4], bacc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        bacc[i] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+    }
+    const int step = 4 * RS;                 // rows per wave and trip (this wave: rows m0 + rs, + RS, ...), the four waves interleaved
+    for (long long m0 = m_begin + (long long)wave * step; m0 < m_end; m0 += 4 * step) {
+        uint2 xr[4];
+        uint4 dr[4][NV / 8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long m = m0 + u * RS + rs;
+            const bool ok = m < m_end;
+            xr[u] = (ok && col_ok) ? *reinterpret_cast<const uint2*>(X + m * ldx + c0) : make_uint2(0u, 0u);
+#pragma unroll
+            for (int q = 0; q < NV / 8; ++q) dr[u][q] = ok ? reinterpret_cast<const uint4*>(dY + m * ldy)[q] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float xv[4];
+            if (XF16) {
+                xv[0] = h2f((bf16_t)(xr[u].x & 0xffffu)); xv[1] = h2f((bf16_t)(xr[u].x >> 16));
+                xv[2] = h2f((bf16_t)(xr[u].y & 0xffffu)); xv[3] = h2f((bf16_t)(xr[u].y >> 16));
+            } else {
+                xv[0] = __uint_as_float(xr[u].x << 16); xv[1] = __uint_as_float(xr[u].x & 0xffff0000u);
+                xv[2] = __uint_as_float(xr[u].y << 16); xv[3] = __uint_as_float(xr[u].y & 0xffff0000u);
+            }
+#pragma unroll
+            for (int q = 0; q < NV / 8; ++q) {
+                const unsigned w[4] = {dr[u][q].x, dr[u][q].y, dr[u][q].z, dr[u][q].w};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float d0 = __uint_as_float(w[p] << 16), d1 = __uint_as_float(w[p] & 0xffff0000u);
+                    const int i = 8 * q + 2 * p;
+                    bacc[i] += d0; bacc[i + 1] += d1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[i][e] = fmaf(d0, xv[e], acc[i][e]);
+                        acc[i + 1][e] = fmaf(d1, xv[e], acc[i + 1][e]);
+                    }
+                }
+            }
+        }
+    }
+    // row slots of a wave -> slot 0 (lanes 0 .. G - 1)
+    for (int off = G; off < 64; off <<= 1) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            bacc[i] += __shfl_xor(bacc[i], off, 64);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][e] += __shfl_xor(acc[i][e], off, 64);
+        }
+    }
+    // the four waves of the workgroup through LDS, 8 rows of dW at a time ([4][8][4 G] floats <= 32 KiB), then one atomic per element
+    const int W4 = 4 * G;
+    for (int ib = 0; ib < NV; ib += 8) {
+        __syncthreads();
+        if (rs == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int ii = 0; ii < NV; ++ii) v = (ii == ib + i) ? acc[ii][e] : v;      // (static register indexing)
+                    sdw_red[(wave * 8 + i) * W4 + 4 * cg + e] = v;
+                }
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 8 * W4; idx += 256) {
+            const int i = idx / W4, j = idx - i * W4;
+            const int col = blockIdx.y * W4 + j;
+            if (col < k) {
+                const float v = (sdw_red[i * W4 + j] + sdw_red[(8 + i) * W4 + j]) + (sdw_red[(16 + i) * W4 + j] + sdw_red[(24 + i) * W4 + j]);
+                unsafeAtomicAdd(dW + (size_t)(ib + i) * ldw + col, v);
+            }
+        }
+    }
+    if (dbias != nullptr && blockIdx.y == 0) {
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) sdw_red[wave * NV + i] = bacc[i];
+        }
+        __syncthreads();
+        if (threadIdx.x < NV)
+            unsafeAtomicAdd(dbias + threadIdx.x, (sdw_red[threadIdx.x] + sdw_red[NV + threadIdx.x]) + (sdw_red[2 * NV + threadIdx.x] + sdw_red[3 * NV + threadIdx.x]));
+    }
+}
+extern "C" int sed_small_dw(const void* dY, int ldy, int n, const void* X, int x_f16, int ldx, int k, float* dW, int ldw, float* dbias,
+                            int64_t M, hipStream_t stream) {
+    (void)hipGetLastError();
+    if ((n != 16 && n != 32) || k <= 0 || (k % 4) || k > 512 || (ldy % 8) || ldy < n || (ldx % 4) || ldx < k || ldw < k || M <= 0) return SED_ERR_ARG;
+    int G = 1;
+    while (G < 64 && 4 * G < k) G <<= 1;           // lanes per row: 4 columns each, a power of two
+    const int cblocks = cdiv(k, 4 * G);
+    int slabs = 1024 / cblocks;                    // ~ four workgroups per CU
+    if (slabs < 1) slabs = 1;
+    const int gran = 16 * (64 / G);                // rows per workgroup and trip
+    long long rows = (M + slabs - 1) / slabs;
+    rows = (rows + gran - 1) / gran * gran;
+    slabs = (int)((M + rows - 1) / rows);
+    const size_t lds = (size_t)32 * 4 * G * sizeof(float);
+#define SED_SDW(NVV, F) hipLaunchKernelGGL((small_dw_kernel<NVV, F>), dim3(slabs, cblocks), dim3(256), lds, stream, (const bf16_t*)dY, ldy, \
+                                           (const bf16_t*)X, ldx, k, dW, ldw, dbias, (long long)M, G, (int)rows)
+    if (n == 16) { if (x_f16) SED_SDW(16, true); else SED_SDW(16, false); }
+    else { if (x_f16) SED_SDW(32, true); else SED_SDW(32, false); }
+#undef SED_SDW
+    return sed_check_launch();
+}
