@@ -349,6 +349,12 @@ int sed_scatter_add_f32(const int64_t* desc, int n_desc, int total_blocks, hipSt
  * mode 1: sum A, sum A * (Bm * a + b) (BatchNorm backward sums with xhat = Y * a + b) */
 int sed_colstats(const float* A, int lda, const float* Bm, int ldb, const float* a, const float* b, float* s1, float* s2,
                  int64_t M, int C, int mode, hipStream_t stream);
+/* sed_bn_act + the ContextGating Linear + sed_cg_pool for a 16-filter layer in one pass (base.py:19-30, 72-100): l = Wg z + bg on the fp32
+ * z = Y a + b (Wg fp32 [16, 16], bg [16]); optional side outputs for the backward: the logits Lout [pixels, 16] fp32 and the 16-bit image
+ * Zout [pixels, 16] of z; out16 NHWC with channel pad Cpo (multiple of 8) and / or out32 [rows, 16] as sed_cg_pool */
+int sed_cg_gate16_pool(const float* Y, int ldy, const float* a, const float* b, const float* Wg, const float* bg, const uint8_t* mask,
+                       float drop_scale, float* Lout, void* Zout, void* out16, float* out32, int B, int H, int W, int Cpo, int ph, int pw,
+                       int f16, hipStream_t stream);
 /* backward of sed_cg_pool: dzd [M, ldz] fp32 (direct path into the BatchNorm output; columns C..ldz-1 zero), dL16 [M, ldl16]
  * bf16 (gate logits; columns C.. zero) */
 int sed_cg_pool_bwd(const float* dout, const float* Y, int ldy, const float* a, const float* b, const float* L, int ldl,

@@ -374,3 +374,29 @@ def test_small_dw_streaming_reduction(n, k, ldy, ldx, xdt):
     assert float(got[n:].abs().max()) == 0.0 and float(got[:, k:].abs().max()) == 0.0
     wb = dY[:, :n].double().sum(0)
     assert float(((db - db0).double()[:n] - wb).abs().max() / wb.abs().max()) < 2e-5 and float((db - db0)[n:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("ph,pw,save", [(2, 2, True), (1, 1, True), (2, 2, False)])
+def test_cg_gate16_pool_equals_the_three_kernel_path(ph, pw, save):
+    """sed_cg_gate16_pool (BatchNorm affine + gate Linear + gate * dropout * pooling in one pass, 16 filters) against fp32 torch and against
+    sed_bn_act + gate GEMM + sed_cg_pool; side outputs L (logits) and Z (16-bit z image, 16 columns)."""
+    B, H, W, Cpo = 2, 20, 16, 64
+    M = B * H * W
+    Y = rnd(M, 16, scale=1.5, seed=91)
+    a, b = 0.5 + rnd(16, seed=92).abs(), rnd(16, seed=93)
+    Wg, bg = rnd(16, 16, scale=0.3, seed=94), rnd(16, seed=95)
+    mask = (torch.rand(M, 16, device=DEV) > 0.5).to(torch.uint8)
+    L = torch.empty(M, 16, device=DEV) if save else None
+    Z = torch.empty(M, 16, dtype=F16, device=DEV) if save else None
+    out16 = torch.full((B, H // ph, W // pw, Cpo), 7.0, dtype=F16, device=DEV)
+    out32 = torch.empty(B * (H // ph) * (W // pw), 16, device=DEV)
+    call("sed_cg_gate16_pool", Y, 16, a, b, Wg, bg, mask, 2.0, L, Z, out16, out32, B, H, W, Cpo, ph, pw, 1)
+    z = Y * a + b
+    l = z @ Wg.t() + bg
+    gated = (z * torch.sigmoid(l) * mask * 2.0).view(B, H, W, 16).permute(0, 3, 1, 2)
+    ref = F.avg_pool2d(gated, (ph, pw)).permute(0, 2, 3, 1).reshape(-1, 16)
+    assert maxerr(out32, ref) < 2e-5
+    half = 2.0 ** -10      # (f16 image: half an ulp relative to the largest value)
+    assert maxerr(out16[..., :16].float().reshape(-1, 16), ref) < half * float(ref.abs().max()) and float(out16[..., 16:].abs().max()) == 0.0
+    if save:
+        assert maxerr(L, l) < 2e-5 and maxerr(Z.float(), z) < half * float(z.abs().max())

@@ -269,6 +269,98 @@ extern "C" int sed_cg_pool(const float* Y, int ldy, const float* a, const float*
     return sed_check_launch();
 }
 
+// The same for a 16-filter layer with the gate Linear inside (round 4): l = W_g z + b_g by 256 FMAs per pixel on the fp32 BatchNorm output --
+// no 64-column 16-bit image of z, no [pixels x 64] . [64 -> 128] gate GEMM, no fp32 logits round trip.  One thread per OUTPUT pixel, the 16 x 16
+// weight from LDS (every lane reads the same words: broadcasts).  Optional side outputs for the backward: the logits L [pixels, 16] fp32 and
+// the 16-bit image Z [pixels, 16] of z (operand of the gate's weight gradient).
+__global__ __launch_bounds__(256) void cg_gate16_pool_kernel(const float* __restrict__ Y, int ldy, const float* __restrict__ a,
+                                                             const float* __restrict__ b, const float* __restrict__ Wg,
+                                                             const float* __restrict__ bg, const unsigned char* __restrict__ mask,
+                                                             float drop_scale, float* __restrict__ Lout, bf16_t* __restrict__ Zout,
+                                                             bf16_t* __restrict__ out16, float* __restrict__ out32, int B, int H, int W,
+                                                             int Cpo, int ph, int pw, int f16) {
+    __shared__ __attribute__((aligned(16))) float wg[16][16];
+    __shared__ float ab[3][16];
+    wg[threadIdx.x >> 4][threadIdx.x & 15] = Wg[threadIdx.x];
+    if (threadIdx.x < 16) { ab[0][threadIdx.x] = a[threadIdx.x]; ab[1][threadIdx.x] = b[threadIdx.x]; ab[2][threadIdx.x] = bg[threadIdx.x]; }
+    __syncthreads();
+    const int Ho = H / ph, Wo = W / pw;
+    const size_t total = (size_t)B * Ho * Wo;
+    const float inv = 1.0f / (float)(ph * pw);
+    for (size_t mo = (size_t)blockIdx.x * blockDim.x + threadIdx.x; mo < total; mo += (size_t)gridDim.x * blockDim.x) {
+        const int wo = (int)(mo % Wo), ho = (int)((mo / Wo) % Ho);
+        const size_t bi = mo / ((size_t)Wo * Ho);
+        float acc[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+        for (int i = 0; i < ph; ++i)
+            for (int j = 0; j < pw; ++j) {
+                const size_t m = (bi * H + (size_t)ho * ph + i) * W + (size_t)wo * pw + j;
+                float z[16], l[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 y = *reinterpret_cast<const float4*>(Y + m * ldy + 4 * q);
+                    z[4 * q] = fmaf(y.x, ab[0][4 * q], ab[1][4 * q]); z[4 * q + 1] = fmaf(y.y, ab[0][4 * q + 1], ab[1][4 * q + 1]);
+                    z[4 * q + 2] = fmaf(y.z, ab[0][4 * q + 2], ab[1][4 * q + 2]); z[4 * q + 3] = fmaf(y.w, ab[0][4 * q + 3], ab[1][4 * q + 3]);
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    float s = ab[2][c];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 w = *reinterpret_cast<const float4*>(&wg[c][4 * q]);
+                        s = fmaf(w.x, z[4 * q], s); s = fmaf(w.y, z[4 * q + 1], s); s = fmaf(w.z, z[4 * q + 2], s); s = fmaf(w.w, z[4 * q + 3], s);
+                    }
+                    l[c] = s;
+                }
+                if (Lout != nullptr) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(Lout + m * 16 + 4 * q) = make_float4(l[4 * q], l[4 * q + 1], l[4 * q + 2], l[4 * q + 3]);
+                }
+                if (Zout != nullptr) {
+                    unsigned pk[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pk[e] = (unsigned)cvt16(z[2 * e], f16) | ((unsigned)cvt16(z[2 * e + 1], f16) << 16);
+                    uint4* zd = reinterpret_cast<uint4*>(Zout + m * 16);
+                    zd[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                    zd[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+                }
+                uint4 mk4 = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+                if (mask != nullptr) mk4 = *reinterpret_cast<const uint4*>(mask + m * 16);
+                const unsigned mw[4] = {mk4.x, mk4.y, mk4.z, mk4.w};
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const float keep = ((mw[c >> 2] >> (8 * (c & 3))) & 0xffu) ? (mask != nullptr ? drop_scale : 1.0f) : 0.f;
+                    acc[c] += z[c] * sigmoidf_(l[c]) * keep;
+                }
+            }
+        if (out32 != nullptr) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(out32 + mo * 16 + 4 * q) = make_float4(acc[4 * q] * inv, acc[4 * q + 1] * inv, acc[4 * q + 2] * inv, acc[4 * q + 3] * inv);
+        }
+        if (out16 != nullptr) {
+            unsigned pk[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pk[e] = (unsigned)cvt16(acc[2 * e] * inv, f16) | ((unsigned)cvt16(acc[2 * e + 1] * inv, f16) << 16);
+            uint4* od = reinterpret_cast<uint4*>(out16 + mo * Cpo);
+            od[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            od[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+            for (int c8 = 2; c8 < Cpo / 8; ++c8) od[c8] = make_uint4(0u, 0u, 0u, 0u);       // channel padding of the NHWC operand
+        }
+    }
+}
+extern "C" int sed_cg_gate16_pool(const float* Y, int ldy, const float* a, const float* b, const float* Wg, const float* bg,
+                                  const uint8_t* mask, float drop_scale, float* Lout, void* Zout, void* out16, float* out32, int B, int H,
+                                  int W, int Cpo, int ph, int pw, int f16, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (B <= 0 || ph <= 0 || pw <= 0 || (H % ph) || (W % pw) || (Cpo % 8) || Cpo < 16 || (ldy % 4) || ldy < 16) return SED_ERR_ARG;
+    hipLaunchKernelGGL(cg_gate16_pool_kernel, dim3(grid_for((size_t)B * (H / ph) * (W / pw), 256, 16384)), dim3(256), 0, stream, Y, ldy, a, b,
+                       Wg, bg, mask, drop_scale, Lout, (bf16_t*)Zout, (bf16_t*)out16, out32, B, H, W, Cpo, ph, pw, f16);
+    return sed_check_launch();
+}
+
 // ---------------------------------------------------------------------------------------------------
 // `attention` frequency pooling (src/models/pooling.py:37-51 with 6 heads of 128, passt_sed.py:211-215): for every (clip, time
 // column) one learned query attends over the 12 frequency tokens.  kv [B*N, 1536] = (k | v) projections of the out_norm'ed tokens

@@ -46,6 +46,7 @@ class PmamEngine(SedEngine):
         super().__init__(module)
         self.lora_skinny = os.environ.get("SED_LORA_SKINNY", "1") != "0"
         self.small_dw = os.environ.get("SED_SMALL_DW", "1") != "0"
+        self.cg_fused16 = os.environ.get("SED_CG_FUSED16", "1") != "0"
         if not self.split:
             raise RuntimeError("the PMAM path runs its 384-wide context network in split precision (SED_DECODER_SPLIT=1, f16 forward)")
         self.dec_terms2 = False      # (its own context-network schedule below keeps three terms in every GEMM)
@@ -332,13 +333,17 @@ class PmamEngine(SedEngine):
             a, b, ah, bh = aff[i, 0], aff[i, 1], aff[i, 2], aff[i, 3]
             call("sed_bn_finalize", s1, s2, g, bt, m._buffer_by_name[bn + "running_mean"], m._buffer_by_name[bn + "running_var"], Mi, co,
                  0.99, 1e-3, a, b, ah, bh)
-            Z = E(Mi, Cp, dt=self.act)
-            call("sed_bn_act", Y, ldy, a, b, Z, Mi, co, Cp, f16)
-            L = E(Mi, ldy)
-            if ldy < Np:
-                gemm_nt_cols(Z, W[f"cnn.cnn.cg{i}.linear.weight"].w, EPI_F32, co, bias=aux["gbias"], outF=L)
-            else:
-                gemm_nt(Z, W[f"cnn.cnn.cg{i}.linear.weight"].w, EPI_F32, bias=aux["gbias"], outF=L)
+            # the gate Linear inside the pooling kernel (`sed_cg_gate16_pool`); its narrow z image is an operand `sed_small_dw` alone takes
+            fused16 = self.cg_fused16 and self.small_dw and self.dw_tn and co == 16 and ldy == 16 and Mi >= 1024
+            Z = L = None
+            if not fused16:
+                Z = E(Mi, Cp, dt=self.act)
+                call("sed_bn_act", Y, ldy, a, b, Z, Mi, co, Cp, f16)
+                L = E(Mi, ldy)
+                if ldy < Np:
+                    gemm_nt_cols(Z, W[f"cnn.cnn.cg{i}.linear.weight"].w, EPI_F32, co, bias=aux["gbias"], outF=L)
+                else:
+                    gemm_nt(Z, W[f"cnn.cnn.cg{i}.linear.weight"].w, EPI_F32, bias=aux["gbias"], outF=L)
             ph, pw = m.cnn_pooling[i]
             last = i + 1 == len(self.cnn_aux)
             Cpo = max(64, co)
@@ -350,7 +355,15 @@ class PmamEngine(SedEngine):
             if train and m.conv_dropout > 0:
                 mask = drop_masks[i] if drop_masks is not None else gen_masks[i].view(Mi, co)
                 scale = 1.0 / (1.0 - m.conv_dropout)
-            call("sed_cg_pool", Y, ldy, a, b, L, ldy, mask, float(scale), Xn, feat, B, Hc, Wc, co, Cpo, ph, pw, f16)
+            if fused16:
+                # 16 filters: z = Y a + b, l = W_g z + b_g (fp32, 256 FMAs per pixel), gate, dropout and pooling in one pass over Y; the
+                # backward's operands -- the logits and the 16-column 16-bit image of z -- are side outputs of a saving pass
+                if save:
+                    L, Z = E(Mi, 16), E(Mi, 16, dt=self.act)
+                call("sed_cg_gate16_pool", Y, ldy, a, b, self.P(f"cnn.cnn.cg{i}.linear.weight").detach(), self.P(f"cnn.cnn.cg{i}.linear.bias").detach(),
+                     mask, float(scale), L, Z, Xn, feat, B, Hc, Wc, Cpo, ph, pw, f16)
+            else:
+                call("sed_cg_pool", Y, ldy, a, b, L, ldy, mask, float(scale), Xn, feat, B, Hc, Wc, co, Cpo, ph, pw, f16)
             if save:
                 layers.append(dict(col=col, Y=Y, a=a, b=b, ah=ah, bh=bh, Z=Z, L=L, mask=mask, scale=scale, H=Hc, W=Wc, ldy=ldy))
             X = Xn
@@ -578,14 +591,14 @@ class PmamEngine(SedEngine):
         """Does `_dw_swapped` run the TN kernel for these shapes (gradient image laid out [n, k]) or the transposed-copy path ([k, n])?"""
         return bool(self.dw_tn and M >= 1024 and dw_tn_ok(M, n, k))
 
-    def _dw_swapped(self, dy16, x, M, n_valid, k_valid, out=None):
+    def _dw_swapped(self, dy16, x, M, n_valid, k_valid, out=None, k_img=None):
         """(dy^T x)^T = x^T dy for operand widths that are not multiples of 128 on the x side: returns fp32 [k, n] and the fp32 column
         sums of dy; only [:k_valid, :n_valid] / [:n_valid] are meaningful.  The operands are zero padded to GEMM-friendly widths
         (16 filters sit in 128 columns): only the 64-column groups that hold valid data are transposed, the other rows of the
         transposed images stay uninitialised and only feed output elements nobody reads.  `out` = (zeroed flat fp32 [n k], zeroed
         fp32 [n]): the gradient-image slots of `_grad_slots` (accumulated into; nothing is allocated or filled here)."""
         dev = dy16.device
-        n, k = dy16.shape[1], x.shape[1]
+        n, k = dy16.shape[1], (x.shape[1] if k_img is None else k_img)     # (k_img: row width of the gradient image when x is narrower than it)
         tn = self._dw_swapped_tn(M, n, k) and dy16.dtype == BF16 and x.dtype in (F16, BF16)
         if out is not None and tn != self._dw_swapped_tn(M, n, k):
             raise RuntimeError("gradient-image slot laid out for the TN kernel, operands are not 16-bit")
@@ -593,8 +606,10 @@ class PmamEngine(SedEngine):
             # 16 / 32 filters against <= 32 columns (the gate Linear, the first convolution's 9 taps): a streaming reduction instead of a
             # 256 x 256 tile's K loop (`sed_small_dw`; measured: 429 -> 165 us on layer 0, 207 -> 45 us on layer 1; the 144 / 288-column
             # convolution gradients stay on the TN kernel -- 169 / 457 us here against 164 / 201 there); same [n, k] image layout
-            call("sed_small_dw", dy16, n, n_valid, x, is_f16(x), k, (k_valid + 3) // 4 * 4, out[0], k, out[1], M)
+            call("sed_small_dw", dy16, n, n_valid, x, is_f16(x), x.shape[1], (k_valid + 3) // 4 * 4, out[0], k, out[1], M)
             return out[0].view(n, k).t(), out[1]
+        if x.shape[1] != k:
+            raise RuntimeError("weight-gradient operand narrower than its gradient image: only the streaming-reduction path takes it")
         if tn:
             # TN kernel on the operands as they lie: dW [n, k] = dy^T x and the column sums of dy from the same launch.  Padding columns
             # of either operand only reach output elements outside [:n_valid, :k_valid], which nobody reads.
@@ -707,7 +722,7 @@ class PmamEngine(SedEngine):
             call("sed_cg_pool_bwd", dout, L["Y"], ldy, L["a"], L["b"], L["L"], ldy, L["mask"], float(L["scale"]), dz, ldy, dL16, ldg, B, Hc,
                  Wc, co, ph, pw)
             # weight / bias gradient images land in the zeroed slots; `sed_scatter_add_f32` returns them to the masters after the loop
-            self._dw_swapped(dL16, L["Z"], Mi, co, co, out=(slots[("gate", i)], slots[("gate_b", i)]))
+            self._dw_swapped(dL16, L["Z"], Mi, co, co, out=(slots[("gate", i)], slots[("gate_b", i)]), k_img=Cp)
             if ldy < Np:      # dz += dL W_gate
                 gemm_nt_cols(dL16, aux["wtg"], EPI_F32_RESID, co, res=dz, outF=dz)
             else:
