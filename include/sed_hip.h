@@ -355,6 +355,10 @@ int sed_colstats(const float* A, int lda, const float* Bm, int ldb, const float*
 int sed_cg_gate16_pool(const float* Y, int ldy, const float* a, const float* b, const float* Wg, const float* bg, const uint8_t* mask,
                        float drop_scale, float* Lout, void* Zout, void* out16, float* out32, int B, int H, int W, int Cpo, int ph, int pw,
                        int f16, hipStream_t stream);
+/* backward of sed_cg_gate16_pool: dz [M, 16] fp32 = direct path + Wg^T dl (the complete gradient of z), dL16 [M, 16] bf16 = dl */
+int sed_cg_gate16_pool_bwd(const float* dout, const float* Y, int ldy, const float* a, const float* b, const float* L, const float* Wg,
+                           const uint8_t* mask, float drop_scale, float* dz, void* dL16, int B, int H, int W, int ph, int pw,
+                           hipStream_t stream);
 /* backward of sed_cg_pool: dzd [M, ldz] fp32 (direct path into the BatchNorm output; columns C..ldz-1 zero), dL16 [M, ldl16]
  * bf16 (gate logits; columns C.. zero) */
 int sed_cg_pool_bwd(const float* dout, const float* Y, int ldy, const float* a, const float* b, const float* L, int ldl,

@@ -400,3 +400,25 @@ def test_cg_gate16_pool_equals_the_three_kernel_path(ph, pw, save):
     assert maxerr(out16[..., :16].float().reshape(-1, 16), ref) < half * float(ref.abs().max()) and float(out16[..., 16:].abs().max()) == 0.0
     if save:
         assert maxerr(L, l) < 2e-5 and maxerr(Z.float(), z) < half * float(z.abs().max())
+
+
+@pytest.mark.parametrize("ph,pw", [(2, 2), (1, 1)])
+def test_cg_gate16_pool_bwd_vs_autograd(ph, pw):
+    """sed_cg_gate16_pool_bwd: gradient of z = Y a + b through gate * dropout * pooling AND through the gate Linear (dz), and the logits'
+    gradient as a 16-column bf16 image (dL16), against torch autograd of the same fp32 computation."""
+    B, H, W = 2, 20, 16
+    M = B * H * W
+    Y = rnd(M, 16, scale=1.5, seed=101)
+    a, b = 0.5 + rnd(16, seed=102).abs(), rnd(16, seed=103)
+    Wg, bg = rnd(16, 16, scale=0.3, seed=104), rnd(16, seed=105)
+    mask = (torch.rand(M, 16, device=DEV) > 0.5).to(torch.uint8)
+    dout = rnd(B * (H // ph) * (W // pw), 16, seed=106)
+    z = (Y * a + b).requires_grad_(True)
+    l = z @ Wg.t() + bg
+    l.retain_grad()
+    out = F.avg_pool2d((z * torch.sigmoid(l) * mask * 2.0).view(B, H, W, 16).permute(0, 3, 1, 2), (ph, pw)).permute(0, 2, 3, 1).reshape(-1, 16)
+    (out * dout).sum().backward()
+    dz = torch.empty(M, 16, device=DEV); dL16 = torch.empty(M, 16, dtype=BF16, device=DEV)
+    call("sed_cg_gate16_pool_bwd", dout, Y, 16, a, b, l.detach().contiguous(), Wg, mask, 2.0, dz, dL16, B, H, W, ph, pw)
+    assert maxerr(dz, z.grad) < 2e-5 * max(1.0, float(z.grad.abs().max()))
+    assert maxerr(dL16.float(), l.grad) < 2.0 ** -8 * float(l.grad.abs().max())

@@ -709,6 +709,76 @@ extern "C" int sed_cg_pool_bwd(const float* dout, const float* Y, int ldy, const
                        b, L, ldl, mask, drop_scale, dzd, ldz, (bf16_t*)dL16, ldl16, B, H, W, C, ph, pw);
     return sed_check_launch();
 }
+// backward of sed_cg_gate16_pool (16 filters): as sed_cg_pool_bwd, with the gate Linear's input gradient added in the same pass --
+// dz[m, c] = up * sigmoid(l) + sum_i dl[m, i] Wg[i, c] (fp32 dl; the NT GEMM dz += dL16 . Wg it replaces read a bf16 dl) -- and dL16 as a
+// 16-column bf16 image (operand of the gate's weight gradient, sed_small_dw).  One thread per input pixel.
+__global__ __launch_bounds__(256) void cg_gate16_pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ Y, int ldy,
+                                                                 const float* __restrict__ a, const float* __restrict__ b,
+                                                                 const float* __restrict__ L, const float* __restrict__ Wg,
+                                                                 const unsigned char* __restrict__ mask, float drop_scale,
+                                                                 float* __restrict__ dz, bf16_t* __restrict__ dL16, int B, int H, int W,
+                                                                 int ph, int pw) {
+    __shared__ __attribute__((aligned(16))) float wg[16][16];
+    __shared__ float ab[2][16];
+    wg[threadIdx.x >> 4][threadIdx.x & 15] = Wg[threadIdx.x];
+    if (threadIdx.x < 16) { ab[0][threadIdx.x] = a[threadIdx.x]; ab[1][threadIdx.x] = b[threadIdx.x]; }
+    __syncthreads();
+    const int Ho = H / ph, Wo = W / pw;
+    const size_t total = (size_t)B * H * W;
+    const float inv = 1.0f / (float)(ph * pw);
+    for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < total; m += (size_t)gridDim.x * blockDim.x) {
+        const int w = (int)(m % W), h = (int)((m / W) % H);
+        const size_t bi = m / ((size_t)W * H);
+        const size_t mo = (bi * Ho + h / ph) * Wo + w / pw;
+        uint4 mk4 = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+        if (mask != nullptr) mk4 = *reinterpret_cast<const uint4*>(mask + m * 16);
+        const unsigned mw[4] = {mk4.x, mk4.y, mk4.z, mk4.w};
+        const float kscale = mask != nullptr ? inv * drop_scale : inv;
+        float dzv[16], dl[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 g = *reinterpret_cast<const float4*>(dout + mo * 16 + 4 * q);
+            const float4 y = *reinterpret_cast<const float4*>(Y + m * ldy + 4 * q);
+            const float4 l = *reinterpret_cast<const float4*>(L + m * 16 + 4 * q);
+            const float gg[4] = {g.x, g.y, g.z, g.w}, yy[4] = {y.x, y.y, y.z, y.w}, ll[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * q + e;
+                const float keep = ((mw[q] >> (8 * e)) & 0xffu) ? kscale : 0.f;
+                const float sg = sigmoidf_(ll[e]), up = gg[e] * keep;
+                dzv[c] = up * sg;
+                dl[c] = up * fmaf(yy[e], ab[0][c], ab[1][c]) * sg * (1.f - sg);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 wv = *reinterpret_cast<const float4*>(&wg[i][4 * q]);
+                dzv[4 * q] = fmaf(dl[i], wv.x, dzv[4 * q]); dzv[4 * q + 1] = fmaf(dl[i], wv.y, dzv[4 * q + 1]);
+                dzv[4 * q + 2] = fmaf(dl[i], wv.z, dzv[4 * q + 2]); dzv[4 * q + 3] = fmaf(dl[i], wv.w, dzv[4 * q + 3]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(dz + m * 16 + 4 * q) = make_float4(dzv[4 * q], dzv[4 * q + 1], dzv[4 * q + 2], dzv[4 * q + 3]);
+        unsigned pk[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pk[e] = pack2bf(dl[2 * e], dl[2 * e + 1]);
+        uint4* dd = reinterpret_cast<uint4*>(dL16 + m * 16);
+        dd[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        dd[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+    }
+}
+extern "C" int sed_cg_gate16_pool_bwd(const float* dout, const float* Y, int ldy, const float* a, const float* b, const float* L,
+                                      const float* Wg, const uint8_t* mask, float drop_scale, float* dz, void* dL16, int B, int H, int W,
+                                      int ph, int pw, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (B <= 0 || ph <= 0 || pw <= 0 || (H % ph) || (W % pw) || (ldy % 4) || ldy < 16) return SED_ERR_ARG;
+    hipLaunchKernelGGL(cg_gate16_pool_bwd_kernel, dim3(grid_for((size_t)B * H * W, 256, 16384)), dim3(256), 0, stream, dout, Y, ldy, a, b, L, Wg,
+                       mask, drop_scale, dz, (bf16_t*)dL16, B, H, W, ph, pw);
+    return sed_check_launch();
+}
 // BatchNorm backward (batch statistics), given the column sums s1 = sum dz, s2 = sum dz * xhat (xhat = Y * ah + bh with
 // ah = rstd, bh = -mean * rstd):  dY = gamma * rstd * (dz - s1 / M - xhat * s2 / M) -> bf16 [M, ldo] (columns C.. zero).
 __global__ void bn_bwd_kernel(const float* __restrict__ dz, int ldz, const float* __restrict__ Y, int ldy, const float* __restrict__ ah,

@@ -591,14 +591,15 @@ class PmamEngine(SedEngine):
         """Does `_dw_swapped` run the TN kernel for these shapes (gradient image laid out [n, k]) or the transposed-copy path ([k, n])?"""
         return bool(self.dw_tn and M >= 1024 and dw_tn_ok(M, n, k))
 
-    def _dw_swapped(self, dy16, x, M, n_valid, k_valid, out=None, k_img=None):
+    def _dw_swapped(self, dy16, x, M, n_valid, k_valid, out=None, k_img=None, n_img=None):
         """(dy^T x)^T = x^T dy for operand widths that are not multiples of 128 on the x side: returns fp32 [k, n] and the fp32 column
         sums of dy; only [:k_valid, :n_valid] / [:n_valid] are meaningful.  The operands are zero padded to GEMM-friendly widths
         (16 filters sit in 128 columns): only the 64-column groups that hold valid data are transposed, the other rows of the
         transposed images stay uninitialised and only feed output elements nobody reads.  `out` = (zeroed flat fp32 [n k], zeroed
         fp32 [n]): the gradient-image slots of `_grad_slots` (accumulated into; nothing is allocated or filled here)."""
         dev = dy16.device
-        n, k = dy16.shape[1], (x.shape[1] if k_img is None else k_img)     # (k_img: row width of the gradient image when x is narrower than it)
+        # (n_img / k_img: rows / row width of the gradient image when the operand itself is narrower -- the 16-column images of the 16-filter layers)
+        n, k = (dy16.shape[1] if n_img is None else n_img), (x.shape[1] if k_img is None else k_img)
         tn = self._dw_swapped_tn(M, n, k) and dy16.dtype == BF16 and x.dtype in (F16, BF16)
         if out is not None and tn != self._dw_swapped_tn(M, n, k):
             raise RuntimeError("gradient-image slot laid out for the TN kernel, operands are not 16-bit")
@@ -606,9 +607,9 @@ class PmamEngine(SedEngine):
             # 16 / 32 filters against <= 32 columns (the gate Linear, the first convolution's 9 taps): a streaming reduction instead of a
             # 256 x 256 tile's K loop (`sed_small_dw`; measured: 429 -> 165 us on layer 0, 207 -> 45 us on layer 1; the 144 / 288-column
             # convolution gradients stay on the TN kernel -- 169 / 457 us here against 164 / 201 there); same [n, k] image layout
-            call("sed_small_dw", dy16, n, n_valid, x, is_f16(x), x.shape[1], (k_valid + 3) // 4 * 4, out[0], k, out[1], M)
+            call("sed_small_dw", dy16, dy16.shape[1], n_valid, x, is_f16(x), x.shape[1], (k_valid + 3) // 4 * 4, out[0], k, out[1], M)
             return out[0].view(n, k).t(), out[1]
-        if x.shape[1] != k:
+        if x.shape[1] != k or dy16.shape[1] != n:
             raise RuntimeError("weight-gradient operand narrower than its gradient image: only the streaming-reduction path takes it")
         if tn:
             # TN kernel on the operands as they lie: dW [n, k] = dy^T x and the column sums of dy from the same launch.  Padding columns
@@ -718,22 +719,32 @@ class PmamEngine(SedEngine):
             ldy = L["ldy"]
             ldg = aux["ldg"]       # row width of the bf16 gradient operands: 64 columns hold the 16 / 32 / 64 filters (128 until round 4)
             dz = E(Mi, ldy)
-            dL16 = E(Mi, ldg, dt=BF16)
-            call("sed_cg_pool_bwd", dout, L["Y"], ldy, L["a"], L["b"], L["L"], ldy, L["mask"], float(L["scale"]), dz, ldy, dL16, ldg, B, Hc,
-                 Wc, co, ph, pw)
+            fused16 = L["Z"].shape[1] == 16 and co == 16      # the forward ran `sed_cg_gate16_pool`: its backward carries the gate Linear too
+            if fused16:
+                dL16 = E(Mi, 16, dt=BF16)
+                call("sed_cg_gate16_pool_bwd", dout, L["Y"], ldy, L["a"], L["b"], L["L"], self.P(f"cnn.cnn.cg{i}.linear.weight").detach(), L["mask"],
+                     float(L["scale"]), dz, dL16, B, Hc, Wc, ph, pw)
+            else:
+                dL16 = E(Mi, ldg, dt=BF16)
+                call("sed_cg_pool_bwd", dout, L["Y"], ldy, L["a"], L["b"], L["L"], ldy, L["mask"], float(L["scale"]), dz, ldy, dL16, ldg, B, Hc,
+                     Wc, co, ph, pw)
             # weight / bias gradient images land in the zeroed slots; `sed_scatter_add_f32` returns them to the masters after the loop
-            self._dw_swapped(dL16, L["Z"], Mi, co, co, out=(slots[("gate", i)], slots[("gate_b", i)]), k_img=Cp)
-            if ldy < Np:      # dz += dL W_gate
+            self._dw_swapped(dL16, L["Z"], Mi, co, co, out=(slots[("gate", i)], slots[("gate_b", i)]), k_img=Cp, n_img=ldg)
+            if fused16:
+                pass              # (dz is already complete)
+            elif ldy < Np:      # dz += dL W_gate
                 gemm_nt_cols(dL16, aux["wtg"], EPI_F32_RESID, co, res=dz, outF=dz)
             else:
                 gemm_nt(dL16, aux["wtg"], EPI_F32_RESID, res=dz, outF=dz)
             s1, s2 = slots[("bn_s1", i)], slots[("bn_s2", i)]
             call("sed_colstats", dz, ldy, L["Y"], ldy, L["ah"], L["bh"], s1, s2, Mi, co, 1)
             bn = f"cnn.cnn.batchnorm{i}."
-            dY16 = E(Mi, ldg, dt=BF16)
-            call("sed_bn_bwd", dz, ldy, L["Y"], ldy, L["ah"], L["bh"], self.P(bn + "weight"), s1, s2, dY16, ldg, Mi, co)
+            # (first layer with 16 filters: dY only feeds the streaming weight-gradient reduction -- 16 columns are all it needs)
+            ldyo = 16 if (i == 0 and fused16) else ldg
+            dY16 = E(Mi, ldyo, dt=BF16)
+            call("sed_bn_bwd", dz, ldy, L["Y"], ldy, L["ah"], L["bh"], self.P(bn + "weight"), s1, s2, dY16, ldyo, Mi, co)
             del dz, dL16
-            self._dw_swapped(dY16, L["col"], Mi, co, 9 * cin, out=(slots[("conv", i)], slots[("conv_b", i)]))
+            self._dw_swapped(dY16, L["col"], Mi, co, 9 * cin, out=(slots[("conv", i)], slots[("conv_b", i)]), n_img=ldg)
             cv = f"cnn.cnn.conv{i}."
             if i > 0:
                 dcol = E(Mi, Kp, dt=BF16)
