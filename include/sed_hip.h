@@ -289,6 +289,11 @@ int sed_mlm_apply_c(const float* x, const float* mask_token, const uint8_t* acti
  * spectrogram [B, 128, T] (the reference's input.transpose(1, 2).unsqueeze(1), passt_cnn.py:51) into col [B*T*128, 64]
  * (9 taps + zeros); later layers read NHWC 16-bit activations X [B, H, W, Cp] into col [B*H*W, Kp], column = tap * C + c. */
 int sed_conv0_im2col(const float* mel, void* col, int B, int T, int f16, hipStream_t stream);
+/* first convolution with 16 filters, direct on the fp32 spectrogram (no patch matrix): Y [B*T*128, 16] fp32 = conv3x3(mel) + bias, Wc =
+ * conv0.weight [16, 1, 3, 3] (kernel rows over time, columns over frequency); and its weight / bias gradient from dY bf16 [pixels, ldy]:
+ * dW[c, tap] += sum dY[m, c] patch(m, tap) (row stride ldw >= 9), dbias[c] += sum dY[m, c] (nullable) */
+int sed_conv0_fwd16(const float* mel, const float* Wc, const float* bias, float* Y, int B, int T, hipStream_t stream);
+int sed_conv0_dw16(const void* dY, int ldy, const float* mel, float* dW, int ldw, float* dbias, int B, int T, hipStream_t stream);
 int sed_conv3x3_im2col(const void* X, void* col, int B, int H, int W, int C, int Cp, int Kp, hipStream_t stream);
 /* BatchNorm2d(eps 1e-3) as the per-channel affine Z = Y * a + b (base.py:72-75): 16-bit operand of the ContextGating GEMM,
  * channels C..Cp-1 zero.  Y [M, ldy] fp32 is the convolution output. */

@@ -422,3 +422,26 @@ def test_cg_gate16_pool_bwd_vs_autograd(ph, pw):
     call("sed_cg_gate16_pool_bwd", dout, Y, 16, a, b, l.detach().contiguous(), Wg, mask, 2.0, dz, dL16, B, H, W, ph, pw)
     assert maxerr(dz, z.grad) < 2e-5 * max(1.0, float(z.grad.abs().max()))
     assert maxerr(dL16.float(), l.grad) < 2.0 ** -8 * float(l.grad.abs().max())
+
+
+def test_conv0_direct_forward_and_weight_gradient():
+    """sed_conv0_fwd16 / sed_conv0_dw16 (first 3x3 convolution, 1 -> 16 filters, on the fp32 spectrogram) against F.conv2d and its autograd."""
+    B, T = 2, 203
+    mel = rnd(B, 128, T, seed=111)
+    Wc, bias = rnd(16, 1, 3, 3, scale=0.3, seed=112), rnd(16, seed=113)
+    Y = torch.empty(B * T * 128, 16, device=DEV)
+    call("sed_conv0_fwd16", mel, Wc, bias, Y, B, T)
+    x = mel.transpose(1, 2).unsqueeze(1)                                   # [B, 1, T, 128] (passt_cnn.py:51)
+    Wr = Wc.clone().requires_grad_(True); br = bias.clone().requires_grad_(True)
+    ref = F.conv2d(x, Wr, br, padding=1)                                   # [B, 16, T, 128]
+    assert maxerr(Y, ref.permute(0, 2, 3, 1).reshape(-1, 16)) < 2e-5
+    dY = rnd(B * T * 128, 16, scale=0.2, seed=114).to(BF16)
+    ref.backward(dY.float().view(B, T, 128, 16).permute(0, 3, 1, 2))
+    dYp = torch.full((B * T * 128, 64), float("nan"), dtype=BF16, device=DEV); dYp[:, :16] = dY
+    dW0, db0 = rnd(64, 64, seed=115).contiguous(), rnd(64, seed=116).contiguous()
+    dW, db = dW0.clone(), db0.clone()
+    call("sed_conv0_dw16", dYp, 64, mel, dW, 64, db, B, T)
+    got = dW - dW0
+    assert maxerr(got[:16, :9], Wr.grad.view(16, 9)) < 2e-5 * float(Wr.grad.abs().max()) + 1e-5
+    assert float(got[16:].abs().max()) == 0.0 and float(got[:, 9:].abs().max()) == 0.0
+    assert maxerr((db - db0)[:16], br.grad) < 2e-5 * float(br.grad.abs().max()) + 1e-5 and float((db - db0)[16:].abs().max()) == 0.0

@@ -158,6 +158,136 @@ extern "C" int sed_conv0_im2col(const float* mel, void* col, int B, int T, int f
     hipLaunchKernelGGL(conv0_im2col_kernel, dim3(grid_for((size_t)B * T * 128)), dim3(256), 0, stream, mel, (bf16_t*)col, B, T, f16);
     return sed_check_launch();
 }
+// layer 0 with 16 filters, direct (round 4): Y[m, c] = bias[c] + sum_tap Wc[c, tap] patch(m, tap) on the fp32 spectrogram -- 144 FMAs per
+// pixel instead of a [pixels, 64] 16-bit patch matrix (393 MB at batch 24) and a [pixels x 64] . [64 -> 128] GEMM over it.  Pixel m =
+// (b, t, f), tap = 3 (dt + 1) + (df + 1) as above; Wc = conv0.weight [16, 1, 3, 3] as it lies.
+__global__ __launch_bounds__(256) void conv0_fwd16_kernel(const float* __restrict__ mel, const float* __restrict__ Wc,
+                                                          const float* __restrict__ bias, float* __restrict__ Y, int B, int T) {
+    __shared__ float wl[9][16], bl[16];
+    if (threadIdx.x < 144) wl[threadIdx.x % 9][threadIdx.x / 9] = Wc[threadIdx.x];
+    if (threadIdx.x < 16) bl[threadIdx.x] = bias[threadIdx.x];
+    __syncthreads();
+    const size_t total = (size_t)B * T * 128;
+    for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < total; m += (size_t)gridDim.x * blockDim.x) {
+        const int f = (int)(m % 128);
+        const int t = (int)((m / 128) % T);
+        const size_t b = m / ((size_t)128 * T);
+        float acc[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = bl[c];
+#pragma unroll
+        for (int dt = -1; dt <= 1; ++dt)
+#pragma unroll
+            for (int df = -1; df <= 1; ++df) {
+                const int tt = t + dt, ff = f + df;
+                float x = 0.f;
+                if (tt >= 0 && tt < T && ff >= 0 && ff < 128) x = mel[(b * 128 + ff) * T + tt];
+                const int tap = 3 * (dt + 1) + (df + 1);
+#pragma unroll
+                for (int c = 0; c < 16; ++c) acc[c] = fmaf(wl[tap][c], x, acc[c]);
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(Y + m * 16 + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    }
+}
+extern "C" int sed_conv0_fwd16(const float* mel, const float* Wc, const float* bias, float* Y, int B, int T, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (B <= 0 || T <= 0) return SED_ERR_ARG;
+    hipLaunchKernelGGL(conv0_fwd16_kernel, dim3(grid_for((size_t)B * T * 128, 256, 16384)), dim3(256), 0, stream, mel, Wc, bias, Y, B, T);
+    return sed_check_launch();
+}
+// ... and its weight / bias gradient: dW[c, tap] += sum_m dY[m, c] patch(m, tap), dbias[c] += sum_m dY[m, c], as the streaming reduction of
+// sed_small_dw with the patches gathered from the spectrogram (lane = (pixel slot, 4 taps): four lanes per pixel, 16 pixels per wave trip).
+__global__ __launch_bounds__(256) void conv0_dw16_kernel(const bf16_t* __restrict__ dY, int ldy, const float* __restrict__ mel,
+                                                         float* __restrict__ dW, int ldw, float* __restrict__ dbias, int B, int T,
+                                                         int rows_per_wg) {
+    __shared__ float red[4][16][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = lane & 3, rs = lane >> 2;
+    const long long M = (long long)B * T * 128;
+    const long long m_begin = (long long)blockIdx.x * rows_per_wg, m_end = (m_begin + rows_per_wg) < M ? (m_begin + rows_per_wg) : M;
+    float acc[16][4], bacc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        bacc[i] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+    }
+    for (long long m0 = m_begin + (long long)wave * 32; m0 < m_end; m0 += 128) {      // two pixels per lane and trip
+        float xv[2][4];
+        uint4 dr[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long m = m0 + 16 * u + rs;
+            const bool ok = m < m_end;
+            const int f = (int)(m % 128), t = (int)((m / 128) % T);
+            const long long b = m / ((long long)128 * T);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int tap = 4 * cg + e, tt = t + tap / 3 - 1, ff = f + tap % 3 - 1;
+                xv[u][e] = (ok && tap < 9 && tt >= 0 && tt < T && ff >= 0 && ff < 128) ? mel[(b * 128 + ff) * T + tt] : 0.f;
+            }
+            dr[u][0] = ok ? reinterpret_cast<const uint4*>(dY + m * ldy)[0] : make_uint4(0u, 0u, 0u, 0u);
+            dr[u][1] = ok ? reinterpret_cast<const uint4*>(dY + m * ldy)[1] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned w[4] = {dr[u][q].x, dr[u][q].y, dr[u][q].z, dr[u][q].w};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float d0 = __uint_as_float(w[p] << 16), d1 = __uint_as_float(w[p] & 0xffff0000u);
+                    const int i = 8 * q + 2 * p;
+                    bacc[i] += d0; bacc[i + 1] += d1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[i][e] = fmaf(d0, xv[u][e], acc[i][e]);
+                        acc[i + 1][e] = fmaf(d1, xv[u][e], acc[i + 1][e]);
+                    }
+                }
+            }
+    }
+    for (int off = 4; off < 64; off <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            bacc[i] += __shfl_xor(bacc[i], off, 64);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][e] += __shfl_xor(acc[i][e], off, 64);
+        }
+    }
+    if (rs == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wave][i][4 * cg + e] = acc[i][e];
+    }
+    __syncthreads();
+    {
+        const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+        if (j < 9) unsafeAtomicAdd(dW + (size_t)i * ldw + j, (red[0][i][j] + red[1][i][j]) + (red[2][i][j] + red[3][i][j]));
+    }
+    if (dbias != nullptr) {
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[wave][0][i] = bacc[i];
+        }
+        __syncthreads();
+        if (threadIdx.x < 16) unsafeAtomicAdd(dbias + threadIdx.x, (red[0][0][threadIdx.x] + red[1][0][threadIdx.x]) + (red[2][0][threadIdx.x] + red[3][0][threadIdx.x]));
+    }
+}
+extern "C" int sed_conv0_dw16(const void* dY, int ldy, const float* mel, float* dW, int ldw, float* dbias, int B, int T, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (B <= 0 || T <= 0 || (ldy % 8) || ldy < 16 || ldw < 9) return SED_ERR_ARG;
+    const long long M = (long long)B * T * 128;
+    long long rows = (M + 1023) / 1024;
+    rows = (rows + 127) / 128 * 128;
+    const int slabs = (int)((M + rows - 1) / rows);
+    hipLaunchKernelGGL(conv0_dw16_kernel, dim3(slabs), dim3(256), 0, stream, (const bf16_t*)dY, ldy, mel, dW, ldw, dbias, B, T, (int)rows);
+    return sed_check_launch();
+}
 // generic layer: X [B, H, W, Cp] -> col [B*H*W, Kp], column tap * C + c (tap as above, c < C), zeros up to Kp; 16-byte chunks
 __global__ void conv3x3_im2col_kernel(const bf16_t* __restrict__ X, bf16_t* __restrict__ col, int B, int H, int W, int C, int Cp,
                                       int Kp) {

@@ -313,17 +313,24 @@ class PmamEngine(SedEngine):
         for i, aux in enumerate(self.cnn_aux):
             co, Np, Kp, Cp, cin = aux["co"], aux["Np"], aux["Kp"], aux["Cp"], aux["cin"]
             Mi = B * Hc * Wc
-            col = E(Mi, Kp, dt=self.act)
-            if i == 0:
-                call("sed_conv0_im2col", mel, col, B, T, f16)
-            else:
-                call("sed_conv3x3_im2col", X, col, B, Hc, Wc, cin, max(64, cin), Kp)
             ldy = co if co < Np else Np     # 16 / 32 / 64 filters: the GEMM writes only the valid columns of its 128-wide tile
             Y = E(Mi, ldy)
-            if ldy < Np:
-                gemm_nt_cols(col, W[f"cnn.cnn.conv{i}.weight"].w, EPI_F32, co, bias=aux["bias"], outF=Y)
+            # first convolution with 16 filters: direct on the fp32 spectrogram (`sed_conv0_fwd16`: no patch matrix, no GEMM); its weight
+            # gradient gathers the patches again (`sed_conv0_dw16`)
+            direct0 = i == 0 and co == 16 and self.cg_fused16 and self.small_dw and self.dw_tn and Mi >= 1024
+            col = None
+            if direct0:
+                call("sed_conv0_fwd16", mel, self.P("cnn.cnn.conv0.weight").detach(), self.P("cnn.cnn.conv0.bias").detach(), Y, B, T)
             else:
-                gemm_nt(col, W[f"cnn.cnn.conv{i}.weight"].w, EPI_F32, bias=aux["bias"], outF=Y)
+                col = E(Mi, Kp, dt=self.act)
+                if i == 0:
+                    call("sed_conv0_im2col", mel, col, B, T, f16)
+                else:
+                    call("sed_conv3x3_im2col", X, col, B, Hc, Wc, cin, max(64, cin), Kp)
+                if ldy < Np:
+                    gemm_nt_cols(col, W[f"cnn.cnn.conv{i}.weight"].w, EPI_F32, co, bias=aux["bias"], outF=Y)
+                else:
+                    gemm_nt(col, W[f"cnn.cnn.conv{i}.weight"].w, EPI_F32, bias=aux["bias"], outF=Y)
             bn = f"cnn.cnn.batchnorm{i}."
             g, bt = self.P(bn + "weight").detach(), self.P(bn + "bias").detach()
             s1 = s2 = None
@@ -365,7 +372,8 @@ class PmamEngine(SedEngine):
             else:
                 call("sed_cg_pool", Y, ldy, a, b, L, ldy, mask, float(scale), Xn, feat, B, Hc, Wc, co, Cpo, ph, pw, f16)
             if save:
-                layers.append(dict(col=col, Y=Y, a=a, b=b, ah=ah, bh=bh, Z=Z, L=L, mask=mask, scale=scale, H=Hc, W=Wc, ldy=ldy))
+                layers.append(dict(col=col, mel=mel if direct0 else None, Y=Y, a=a, b=b, ah=ah, bh=bh, Z=Z, L=L, mask=mask, scale=scale, H=Hc,
+                                   W=Wc, ldy=ldy))
             X = Xn
             Hc, Wc = Hc // ph, Wc // pw
         assert Wc == 1
@@ -744,7 +752,10 @@ class PmamEngine(SedEngine):
             dY16 = E(Mi, ldyo, dt=BF16)
             call("sed_bn_bwd", dz, ldy, L["Y"], ldy, L["ah"], L["bh"], self.P(bn + "weight"), s1, s2, dY16, ldyo, Mi, co)
             del dz, dL16
-            self._dw_swapped(dY16, L["col"], Mi, co, 9 * cin, out=(slots[("conv", i)], slots[("conv_b", i)]), n_img=ldg)
+            if L["col"] is None:      # direct first convolution: the patches come from the spectrogram again; [ldg, Kp] image as the TN kernel's
+                call("sed_conv0_dw16", dY16, ldyo, L["mel"], slots[("conv", i)], Kp, slots[("conv_b", i)], B, Hc)
+            else:
+                self._dw_swapped(dY16, L["col"], Mi, co, 9 * cin, out=(slots[("conv", i)], slots[("conv_b", i)]), n_img=ldg)
             cv = f"cnn.cnn.conv{i}."
             if i > 0:
                 dcol = E(Mi, Kp, dt=BF16)
