@@ -778,6 +778,18 @@ def test_heads_and_small_ops():
     da = torch.empty(5, 768, device=DEV); dw_ = torch.zeros(10, 768, device=DEV); db_ = torch.zeros(10, device=DEV)
     call("sed_small_linear_bwd", a, w, out, dout, da, dw_, db_, 5, 10, 768, 1)
     assert maxerr(da, aa.grad) < 1e-5 and maxerr(dw_, ww.grad) < 1e-4 and maxerr(db_, b2.grad) < 1e-5
+    # ... at the AT head's out_proj shape (32 x 768 -> 770: N not a multiple of 8, K not a multiple of 32 columns per block edge) without activation,
+    # accumulating dW / db, null outputs skipped
+    a = rnd(32, 776, seed=195); w = rnd(770, 776, scale=0.05, seed=196); dout = rnd(32, 770, seed=198)
+    aa, ww = a.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    (aa @ ww.t()).backward(dout)
+    da = torch.full((32, 776), 7.0, device=DEV); dw0 = rnd(770, 776, seed=199); db0 = rnd(770, seed=200)
+    dw_, db_ = dw0.clone(), db0.clone()
+    call("sed_small_linear_bwd", a, w, None, dout, da, dw_, db_, 32, 770, 776, 0)
+    assert maxerr(da, aa.grad) < 2e-5 and maxerr(dw_ - dw0, ww.grad) < 1e-4 and maxerr(db_ - db0, dout.sum(0)) < 1e-4
+    da2 = torch.full((32, 776), 7.0, device=DEV)
+    call("sed_small_linear_bwd", a, w, None, dout, da2, None, None, 32, 770, 776, 0)
+    assert torch.equal(da2, da)
     # attention pooling
     N, Hh = 1190, 12
     kv = r16(rnd(B, N, 1536, seed=99)); q = rnd(1, 768, seed=100)

@@ -1094,35 +1094,44 @@ __device__ __forceinline__ float slb_g(const float* dout, const float* out, size
     if (act == 1) { const float o = out[i]; g *= o * (1.f - o); }
     return g;
 }
-__global__ void small_linear_bwd_kernel(const float* __restrict__ a, const float* __restrict__ w,
-                                        const float* __restrict__ out, const float* __restrict__ dout,
-                                        float* __restrict__ da, float* __restrict__ dw, float* __restrict__ db, int M,
-                                        int N, int K, int act) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t n_dw = (size_t)N * K, n_da = (size_t)M * K;
-    if (idx < n_dw) {
-        if (dw == nullptr) return;
+__global__ __launch_bounds__(256) void small_linear_bwd_kernel(const float* __restrict__ a, const float* __restrict__ w,
+                                                               const float* __restrict__ out, const float* __restrict__ dout,
+                                                               float* __restrict__ da, float* __restrict__ dw, float* __restrict__ db, int M,
+                                                               int N, int K, int act, int nb_dw, int nb_da) {
+    // blocks [0, nb_dw): one thread per dW element; [nb_dw, nb_dw + nb_da): one block per (row m, 32 columns of da), the N-long dot products
+    // split eight ways over the block (one thread per element walked all N = 768 rows of W one dependent load after the other: 84-114 us
+    // per launch for 25 K outputs); the rest: db
+    __shared__ float red[8][32];
+    if ((int)blockIdx.x < nb_dw) {
+        const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (idx >= (size_t)N * K || dw == nullptr) return;
         const int n = (int)(idx / K), k = (int)(idx - (size_t)n * K);
         float acc = 0.f;
         for (int m = 0; m < M; ++m) acc += slb_g(dout, out, (size_t)m * N + n, act) * a[(size_t)m * K + k];
         dw[idx] += acc;
-    } else if (idx < n_dw + n_da) {
-        if (da == nullptr) return;
-        const size_t j = idx - n_dw;
-        const int m = (int)(j / K), k = (int)(j - (size_t)m * K);
+    } else if ((int)blockIdx.x < nb_dw + nb_da) {
+        const int t = blockIdx.x - nb_dw, kt = (K + 31) / 32;
+        const int m = t / kt, k = (t - m * kt) * 32 + (threadIdx.x & 31), nc = threadIdx.x >> 5;
+        const int chunk = (N + 7) / 8, n0 = nc * chunk, n1 = (n0 + chunk) < N ? (n0 + chunk) : N;
         float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-        int n = 0;
-        for (; n + 3 < N; n += 4) {
-            acc0 += slb_g(dout, out, (size_t)m * N + n, act) * w[(size_t)n * K + k];
-            acc1 += slb_g(dout, out, (size_t)m * N + n + 1, act) * w[(size_t)(n + 1) * K + k];
-            acc2 += slb_g(dout, out, (size_t)m * N + n + 2, act) * w[(size_t)(n + 2) * K + k];
-            acc3 += slb_g(dout, out, (size_t)m * N + n + 3, act) * w[(size_t)(n + 3) * K + k];
+        if (k < K) {
+            int n = n0;
+            for (; n + 3 < n1; n += 4) {
+                acc0 += slb_g(dout, out, (size_t)m * N + n, act) * w[(size_t)n * K + k];
+                acc1 += slb_g(dout, out, (size_t)m * N + n + 1, act) * w[(size_t)(n + 1) * K + k];
+                acc2 += slb_g(dout, out, (size_t)m * N + n + 2, act) * w[(size_t)(n + 2) * K + k];
+                acc3 += slb_g(dout, out, (size_t)m * N + n + 3, act) * w[(size_t)(n + 3) * K + k];
+            }
+            for (; n < n1; ++n) acc0 += slb_g(dout, out, (size_t)m * N + n, act) * w[(size_t)n * K + k];
         }
-        for (; n < N; ++n) acc0 += slb_g(dout, out, (size_t)m * N + n, act) * w[(size_t)n * K + k];
-        da[j] = (acc0 + acc1) + (acc2 + acc3);
-    } else if (idx < n_dw + n_da + N) {
-        if (db == nullptr) return;
-        const int n = (int)(idx - n_dw - n_da);
+        red[nc][threadIdx.x & 31] = (acc0 + acc1) + (acc2 + acc3);
+        __syncthreads();
+        if (nc == 0 && k < K)
+            da[(size_t)m * K + k] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) +
+                                    ((red[4][threadIdx.x] + red[5][threadIdx.x]) + (red[6][threadIdx.x] + red[7][threadIdx.x]));
+    } else {
+        const int n = (blockIdx.x - nb_dw - nb_da) * blockDim.x + threadIdx.x;
+        if (n >= N || db == nullptr) return;
         float acc = 0.f;
         for (int m = 0; m < M; ++m) acc += slb_g(dout, out, (size_t)m * N + n, act);
         db[n] += acc;
@@ -1131,9 +1140,12 @@ __global__ void small_linear_bwd_kernel(const float* __restrict__ a, const float
 extern "C" int sed_small_linear_bwd(const float* a, const float* w, const float* out, const float* dout, float* da,
                                     float* dw, float* db, int M, int N, int K, int act, hipStream_t stream) {
     (void)hipGetLastError();
-    const int64_t total = (int64_t)N * K + (int64_t)M * K + N;
-    hipLaunchKernelGGL(small_linear_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, a, w, out, dout, da, dw, db,
-                       M, N, K, act);
+    if (M <= 0 || N <= 0 || K <= 0) return SED_ERR_ARG;
+    const int nb_dw = dw != nullptr ? (int)cdiv((int64_t)N * K, 256) : 0, nb_da = da != nullptr ? M * ((K + 31) / 32) : 0;
+    const int nb_db = db != nullptr ? (int)cdiv((int64_t)N, 256) : 0;
+    if (nb_dw + nb_da + nb_db == 0) return SED_OK;
+    hipLaunchKernelGGL(small_linear_bwd_kernel, dim3(nb_dw + nb_da + nb_db), dim3(256), 0, stream, a, w, out, dout, da, dw, db,
+                       M, N, K, act, nb_dw, nb_da);
     return sed_check_launch();
 }
 
