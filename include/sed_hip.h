@@ -291,8 +291,9 @@ int sed_mlm_apply_c(const float* x, const float* mask_token, const uint8_t* acti
 int sed_conv0_im2col(const float* mel, void* col, int B, int T, int f16, hipStream_t stream);
 /* first convolution with 16 filters, direct on the fp32 spectrogram (no patch matrix): Y [B*T*128, 16] fp32 = conv3x3(mel) + bias, Wc =
  * conv0.weight [16, 1, 3, 3] (kernel rows over time, columns over frequency); and its weight / bias gradient from dY bf16 [pixels, ldy]:
- * dW[c, tap] += sum dY[m, c] patch(m, tap) (row stride ldw >= 9), dbias[c] += sum dY[m, c] (nullable) */
-int sed_conv0_fwd16(const float* mel, const float* Wc, const float* bias, float* Y, int B, int T, hipStream_t stream);
+ * dW[c, tap] += sum dY[m, c] patch(m, tap) (row stride ldw >= 9), dbias[c] += sum dY[m, c] (nullable).  s1 / s2 (nullable pair): the
+ * BatchNorm batch-statistics sums of Y (sed_colstats mode 0) accumulated by the same pass */
+int sed_conv0_fwd16(const float* mel, const float* Wc, const float* bias, float* Y, int B, int T, float* s1, float* s2, hipStream_t stream);
 int sed_conv0_dw16(const void* dY, int ldy, const float* mel, float* dW, int ldw, float* dbias, int B, int T, hipStream_t stream);
 int sed_conv3x3_im2col(const void* X, void* col, int B, int H, int W, int C, int Cp, int Kp, hipStream_t stream);
 /* BatchNorm2d(eps 1e-3) as the per-channel affine Z = Y * a + b (base.py:72-75): 16-bit operand of the ContextGating GEMM,
@@ -360,10 +361,11 @@ int sed_colstats(const float* A, int lda, const float* Bm, int ldb, const float*
 int sed_cg_gate16_pool(const float* Y, int ldy, const float* a, const float* b, const float* Wg, const float* bg, const uint8_t* mask,
                        float drop_scale, float* Lout, void* Zout, void* out16, float* out32, int B, int H, int W, int Cpo, int ph, int pw,
                        int f16, hipStream_t stream);
-/* backward of sed_cg_gate16_pool: dz [M, 16] fp32 = direct path + Wg^T dl (the complete gradient of z), dL16 [M, 16] bf16 = dl */
+/* backward of sed_cg_gate16_pool: dz [M, 16] fp32 = direct path + Wg^T dl (the complete gradient of z), dL16 [M, 16] bf16 = dl;
+ * s1 / s2 (nullable pair, with ah / bh): the BatchNorm backward sums of dz (sed_colstats mode 1) accumulated by the same pass */
 int sed_cg_gate16_pool_bwd(const float* dout, const float* Y, int ldy, const float* a, const float* b, const float* L, const float* Wg,
                            const uint8_t* mask, float drop_scale, float* dz, void* dL16, int B, int H, int W, int ph, int pw,
-                           hipStream_t stream);
+                           const float* ah, const float* bh, float* s1, float* s2, hipStream_t stream);
 /* backward of sed_cg_pool: dzd [M, ldz] fp32 (direct path into the BatchNorm output; columns C..ldz-1 zero), dL16 [M, ldl16]
  * bf16 (gate logits; columns C.. zero) */
 int sed_cg_pool_bwd(const float* dout, const float* Y, int ldy, const float* a, const float* b, const float* L, int ldl,

@@ -419,9 +419,18 @@ def test_cg_gate16_pool_bwd_vs_autograd(ph, pw):
     out = F.avg_pool2d((z * torch.sigmoid(l) * mask * 2.0).view(B, H, W, 16).permute(0, 3, 1, 2), (ph, pw)).permute(0, 2, 3, 1).reshape(-1, 16)
     (out * dout).sum().backward()
     dz = torch.empty(M, 16, device=DEV); dL16 = torch.empty(M, 16, dtype=BF16, device=DEV)
-    call("sed_cg_gate16_pool_bwd", dout, Y, 16, a, b, l.detach().contiguous(), Wg, mask, 2.0, dz, dL16, B, H, W, ph, pw)
+    ah, bh = 0.5 + rnd(16, seed=107).abs(), rnd(16, seed=108)
+    s1, s2 = rnd(16, seed=109), rnd(16, seed=110)
+    s10, s20 = s1.clone(), s2.clone()
+    call("sed_cg_gate16_pool_bwd", dout, Y, 16, a, b, l.detach().contiguous(), Wg, mask, 2.0, dz, dL16, B, H, W, ph, pw, ah, bh, s1, s2)
     assert maxerr(dz, z.grad) < 2e-5 * max(1.0, float(z.grad.abs().max()))
     assert maxerr(dL16.float(), l.grad) < 2.0 ** -8 * float(l.grad.abs().max())
+    # ... and the BatchNorm backward sums of dz (sed_colstats mode 1), accumulated into s1 / s2
+    w1, w2 = z.grad.double().sum(0), (z.grad.double() * (Y.double() * ah.double() + bh.double())).sum(0)
+    assert maxerr(s1 - s10, w1.float()) < 1e-4 * float(z.grad.abs().sum(0).max()) and maxerr(s2 - s20, w2.float()) < 1e-4 * float((z.grad.abs() * (Y * ah + bh).abs()).sum(0).max())
+    dz2 = torch.empty_like(dz)
+    call("sed_cg_gate16_pool_bwd", dout, Y, 16, a, b, l.detach().contiguous(), Wg, mask, 2.0, dz2, dL16, B, H, W, ph, pw, None, None, None, None)
+    assert torch.equal(dz2, dz)
 
 
 def test_conv0_direct_forward_and_weight_gradient():
@@ -430,7 +439,12 @@ def test_conv0_direct_forward_and_weight_gradient():
     mel = rnd(B, 128, T, seed=111)
     Wc, bias = rnd(16, 1, 3, 3, scale=0.3, seed=112), rnd(16, seed=113)
     Y = torch.empty(B * T * 128, 16, device=DEV)
-    call("sed_conv0_fwd16", mel, Wc, bias, Y, B, T)
+    s1, s2 = torch.zeros(16, device=DEV), torch.zeros(16, device=DEV)
+    call("sed_conv0_fwd16", mel, Wc, bias, Y, B, T, s1, s2)
+    assert maxerr(s1, Y.sum(0)) < 1e-4 * float(Y.abs().sum(0).max()) and maxerr(s2, (Y * Y).sum(0)) < 1e-4 * float((Y * Y).sum(0).max())
+    Y2 = torch.empty_like(Y)
+    call("sed_conv0_fwd16", mel, Wc, bias, Y2, B, T, None, None)
+    assert torch.equal(Y2, Y)
     x = mel.transpose(1, 2).unsqueeze(1)                                   # [B, 1, T, 128] (passt_cnn.py:51)
     Wr = Wc.clone().requires_grad_(True); br = bias.clone().requires_grad_(True)
     ref = F.conv2d(x, Wr, br, padding=1)                                   # [B, 16, T, 128]

@@ -162,11 +162,16 @@ extern "C" int sed_conv0_im2col(const float* mel, void* col, int B, int T, int f
 // pixel instead of a [pixels, 64] 16-bit patch matrix (393 MB at batch 24) and a [pixels x 64] . [64 -> 128] GEMM over it.  Pixel m =
 // (b, t, f), tap = 3 (dt + 1) + (df + 1) as above; Wc = conv0.weight [16, 1, 3, 3] as it lies.
 __global__ __launch_bounds__(256) void conv0_fwd16_kernel(const float* __restrict__ mel, const float* __restrict__ Wc,
-                                                          const float* __restrict__ bias, float* __restrict__ Y, int B, int T) {
+                                                          const float* __restrict__ bias, float* __restrict__ Y, int B, int T,
+                                                          float* __restrict__ s1, float* __restrict__ s2) {
     __shared__ float wl[9][16], bl[16];
+    __shared__ float sred[4][32];
     if (threadIdx.x < 144) wl[threadIdx.x % 9][threadIdx.x / 9] = Wc[threadIdx.x];
     if (threadIdx.x < 16) bl[threadIdx.x] = bias[threadIdx.x];
     __syncthreads();
+    float t1[16], t2[16];      // (s1 != nullptr: the BatchNorm batch statistics sums, sed_colstats mode 0, from the values in registers)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { t1[c] = 0.f; t2[c] = 0.f; }
     const size_t total = (size_t)B * T * 128;
     for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < total; m += (size_t)gridDim.x * blockDim.x) {
         const int f = (int)(m % 128);
@@ -189,12 +194,33 @@ __global__ __launch_bounds__(256) void conv0_fwd16_kernel(const float* __restric
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4*>(Y + m * 16 + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        if (s1 != nullptr) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { t1[c] += acc[c]; t2[c] = fmaf(acc[c], acc[c], t2[c]); }
+        }
+    }
+    if (s1 != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { t1[c] += __shfl_xor(t1[c], o, 64); t2[c] += __shfl_xor(t2[c], o, 64); }
+        }
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { sred[threadIdx.x >> 6][c] = t1[c]; sred[threadIdx.x >> 6][16 + c] = t2[c]; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const float v = (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+            unsafeAtomicAdd((threadIdx.x < 16 ? s1 : s2) + (threadIdx.x & 15), v);
+        }
     }
 }
-extern "C" int sed_conv0_fwd16(const float* mel, const float* Wc, const float* bias, float* Y, int B, int T, hipStream_t stream) {
+extern "C" int sed_conv0_fwd16(const float* mel, const float* Wc, const float* bias, float* Y, int B, int T, float* s1, float* s2,
+                               hipStream_t stream) {
     (void)hipGetLastError();
-    if (B <= 0 || T <= 0) return SED_ERR_ARG;
-    hipLaunchKernelGGL(conv0_fwd16_kernel, dim3(grid_for((size_t)B * T * 128, 256, 16384)), dim3(256), 0, stream, mel, Wc, bias, Y, B, T);
+    if (B <= 0 || T <= 0 || (s1 == nullptr) != (s2 == nullptr)) return SED_ERR_ARG;
+    hipLaunchKernelGGL(conv0_fwd16_kernel, dim3(grid_for((size_t)B * T * 128, 256, 4096)), dim3(256), 0, stream, mel, Wc, bias, Y, B, T, s1, s2);
     return sed_check_launch();
 }
 // ... and its weight / bias gradient: dW[c, tap] += sum_m dY[m, c] patch(m, tap), dbias[c] += sum_m dY[m, c], as the streaming reduction of
@@ -847,12 +873,22 @@ __global__ __launch_bounds__(256) void cg_gate16_pool_bwd_kernel(const float* __
                                                                  const float* __restrict__ L, const float* __restrict__ Wg,
                                                                  const unsigned char* __restrict__ mask, float drop_scale,
                                                                  float* __restrict__ dz, bf16_t* __restrict__ dL16, int B, int H, int W,
-                                                                 int ph, int pw) {
+                                                                 int ph, int pw, const float* __restrict__ ah, const float* __restrict__ bh,
+                                                                 float* __restrict__ s1, float* __restrict__ s2) {
     __shared__ __attribute__((aligned(16))) float wg[16][16];
-    __shared__ float ab[2][16];
+    __shared__ float ab[4][16];
+    __shared__ float sred[4][32];
     wg[threadIdx.x >> 4][threadIdx.x & 15] = Wg[threadIdx.x];
-    if (threadIdx.x < 16) { ab[0][threadIdx.x] = a[threadIdx.x]; ab[1][threadIdx.x] = b[threadIdx.x]; }
+    if (threadIdx.x < 16) {
+        ab[0][threadIdx.x] = a[threadIdx.x]; ab[1][threadIdx.x] = b[threadIdx.x];
+        ab[2][threadIdx.x] = s1 != nullptr ? ah[threadIdx.x] : 0.f; ab[3][threadIdx.x] = s1 != nullptr ? bh[threadIdx.x] : 0.f;
+    }
     __syncthreads();
+    // (s1 != nullptr: also the BatchNorm backward sums of this layer, s1[c] += sum dz, s2[c] += sum dz * xhat with xhat = Y ah + bh --
+    //  sed_colstats mode 1 -- from the values in registers)
+    float t1[16], t2[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { t1[c] = 0.f; t2[c] = 0.f; }
     const int Ho = H / ph, Wo = W / pw;
     const size_t total = (size_t)B * H * W;
     const float inv = 1.0f / (float)(ph * pw);
@@ -892,6 +928,19 @@ __global__ __launch_bounds__(256) void cg_gate16_pool_bwd_kernel(const float* __
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4*>(dz + m * 16 + 4 * q) = make_float4(dzv[4 * q], dzv[4 * q + 1], dzv[4 * q + 2], dzv[4 * q + 3]);
+        if (s1 != nullptr) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 y = *reinterpret_cast<const float4*>(Y + m * ldy + 4 * q);      // (L1 hit: read above)
+                const float yy[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 4 * q + e;
+                    t1[c] += dzv[c];
+                    t2[c] = fmaf(dzv[c], fmaf(yy[e], ab[2][c], ab[3][c]), t2[c]);
+                }
+            }
+        }
         unsigned pk[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) pk[e] = pack2bf(dl[2 * e], dl[2 * e + 1]);
@@ -899,14 +948,31 @@ __global__ __launch_bounds__(256) void cg_gate16_pool_bwd_kernel(const float* __
         dd[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         dd[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
     }
+    if (s1 != nullptr) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { t1[c] += __shfl_xor(t1[c], o, 64); t2[c] += __shfl_xor(t2[c], o, 64); }
+        }
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { sred[threadIdx.x >> 6][c] = t1[c]; sred[threadIdx.x >> 6][16 + c] = t2[c]; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const float v = (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+            unsafeAtomicAdd((threadIdx.x < 16 ? s1 : s2) + (threadIdx.x & 15), v);
+        }
+    }
 }
 extern "C" int sed_cg_gate16_pool_bwd(const float* dout, const float* Y, int ldy, const float* a, const float* b, const float* L,
                                       const float* Wg, const uint8_t* mask, float drop_scale, float* dz, void* dL16, int B, int H, int W,
-                                      int ph, int pw, hipStream_t stream) {
+                                      int ph, int pw, const float* ah, const float* bh, float* s1, float* s2, hipStream_t stream) {
     (void)hipGetLastError();
     if (B <= 0 || ph <= 0 || pw <= 0 || (H % ph) || (W % pw) || (ldy % 4) || ldy < 16) return SED_ERR_ARG;
-    hipLaunchKernelGGL(cg_gate16_pool_bwd_kernel, dim3(grid_for((size_t)B * H * W, 256, 16384)), dim3(256), 0, stream, dout, Y, ldy, a, b, L, Wg,
-                       mask, drop_scale, dz, (bf16_t*)dL16, B, H, W, ph, pw);
+    if ((s1 == nullptr) != (s2 == nullptr) || (s1 != nullptr && (ah == nullptr || bh == nullptr))) return SED_ERR_ARG;
+    hipLaunchKernelGGL(cg_gate16_pool_bwd_kernel, dim3(grid_for((size_t)B * H * W, 256, 4096)), dim3(256), 0, stream, dout, Y, ldy, a, b, L, Wg,
+                       mask, drop_scale, dz, (bf16_t*)dL16, B, H, W, ph, pw, ah, bh, s1, s2);
     return sed_check_launch();
 }
 // BatchNorm backward (batch statistics), given the column sums s1 = sum dz, s2 = sum dz * xhat (xhat = Y * ah + bh with

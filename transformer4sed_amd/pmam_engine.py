@@ -319,8 +319,9 @@ class PmamEngine(SedEngine):
             # gradient gathers the patches again (`sed_conv0_dw16`)
             direct0 = i == 0 and co == 16 and self.cg_fused16 and self.small_dw and self.dw_tn and Mi >= 1024
             col = None
-            if direct0:
-                call("sed_conv0_fwd16", mel, self.P("cnn.cnn.conv0.weight").detach(), self.P("cnn.cnn.conv0.bias").detach(), Y, B, T)
+            if direct0:      # (train: the batch-statistics sums come out of the same pass)
+                call("sed_conv0_fwd16", mel, self.P("cnn.cnn.conv0.weight").detach(), self.P("cnn.cnn.conv0.bias").detach(), Y, B, T,
+                     sums[i, 0] if train else None, sums[i, 1] if train else None)
             else:
                 col = E(Mi, Kp, dt=self.act)
                 if i == 0:
@@ -336,7 +337,8 @@ class PmamEngine(SedEngine):
             s1 = s2 = None
             if train:   # batch statistics; running statistics updated with torch's BatchNorm rule (momentum 0.99, unbiased variance)
                 s1, s2 = sums[i, 0], sums[i, 1]
-                call("sed_colstats", Y, ldy, None, 0, None, None, s1, s2, Mi, co, 0)
+                if not direct0:
+                    call("sed_colstats", Y, ldy, None, 0, None, None, s1, s2, Mi, co, 0)
             a, b, ah, bh = aff[i, 0], aff[i, 1], aff[i, 2], aff[i, 3]
             call("sed_bn_finalize", s1, s2, g, bt, m._buffer_by_name[bn + "running_mean"], m._buffer_by_name[bn + "running_var"], Mi, co,
                  0.99, 1e-3, a, b, ah, bh)
@@ -731,7 +733,7 @@ class PmamEngine(SedEngine):
             if fused16:
                 dL16 = E(Mi, 16, dt=BF16)
                 call("sed_cg_gate16_pool_bwd", dout, L["Y"], ldy, L["a"], L["b"], L["L"], self.P(f"cnn.cnn.cg{i}.linear.weight").detach(), L["mask"],
-                     float(L["scale"]), dz, dL16, B, Hc, Wc, ph, pw)
+                     float(L["scale"]), dz, dL16, B, Hc, Wc, ph, pw, L["ah"], L["bh"], slots[("bn_s1", i)], slots[("bn_s2", i)])
             else:
                 dL16 = E(Mi, ldg, dt=BF16)
                 call("sed_cg_pool_bwd", dout, L["Y"], ldy, L["a"], L["b"], L["L"], ldy, L["mask"], float(L["scale"]), dz, ldy, dL16, ldg, B, Hc,
@@ -745,7 +747,8 @@ class PmamEngine(SedEngine):
             else:
                 gemm_nt(dL16, aux["wtg"], EPI_F32_RESID, res=dz, outF=dz)
             s1, s2 = slots[("bn_s1", i)], slots[("bn_s2", i)]
-            call("sed_colstats", dz, ldy, L["Y"], ldy, L["ah"], L["bh"], s1, s2, Mi, co, 1)
+            if not fused16:      # (the fused backward accumulated the BatchNorm backward sums itself)
+                call("sed_colstats", dz, ldy, L["Y"], ldy, L["ah"], L["bh"], s1, s2, Mi, co, 1)
             bn = f"cnn.cnn.batchnorm{i}."
             # (first layer with 16 filters: dY only feeds the streaming weight-gradient reduction -- 16 columns are all it needs)
             ldyo = 16 if (i == 0 and fused16) else ldg
