@@ -1312,6 +1312,33 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     }
 }
 
+// ... for small outputs (a few thousand float4s: the [64, k] gradient images of the PMAM CNN reduce up to 256 splits with 16 blocks' worth of
+// threads, each walking all splits one dependent load after the other -- 64 us): 32 float4s per block, the splits dealt to 8 thread groups
+__global__ __launch_bounds__(256) void tn_reduce_small_kernel(const float* __restrict__ ws, int ks, int M, int N, float* __restrict__ C,
+                                                              int ldc) {
+    __shared__ float4 red[8][32];
+    const size_t total4 = (size_t)M * N / 4;
+    const size_t i = (size_t)blockIdx.x * 32 + (threadIdx.x & 31);
+    const int grp = threadIdx.x >> 5;
+    float4 a = {0.f, 0.f, 0.f, 0.f};
+    if (i < total4)
+        for (int s2 = grp; s2 < ks; s2 += 8) {
+            const float4 b = reinterpret_cast<const float4*>(ws)[(size_t)s2 * total4 + i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+    red[grp][threadIdx.x & 31] = a;
+    __syncthreads();
+    if (grp == 0 && i < total4) {
+#pragma unroll
+        for (int g2 = 1; g2 < 8; ++g2) { const float4 b = red[g2][threadIdx.x]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        const size_t e = i * 4, m = e / N, n = e - m * N;
+        float4* dst = reinterpret_cast<float4*>(C + m * ldc + n);
+        float4 c = *dst;
+        c.x += a.x; c.y += a.y; c.z += a.z; c.w += a.w;
+        *dst = c;
+    }
+}
+
 // Counter slots of the dynamic tile walk: a ring in device memory (zero at module load, every launch leaves its slot zeroed again), one
 // slot per launch so that GEMMs running concurrently on different streams never share counters.  A slot comes round again after
 // DYN_SLOTS launches -- far more than a stream queue holds.
@@ -1409,9 +1436,14 @@ extern "C" int sed_gemm_dw_tn(const void* dY, const void* X, int x_f16, int T, i
         hipLaunchKernelGGL((gemm_tn_dw_kernel<true>), grid, dim3(512), V3_LDS, stream, g);
     }
     if (g.ws != nullptr) {
-        int blocks = (int)(((size_t)M * N / 4 + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks), dim3(256), 0, stream, g.ws, ks, M, N, dW, ldc);
+        const size_t total4 = (size_t)M * N / 4;
+        if (total4 < 32768 && ks >= 16) {
+            hipLaunchKernelGGL(tn_reduce_small_kernel, dim3((unsigned)((total4 + 31) / 32)), dim3(256), 0, stream, g.ws, ks, M, N, dW, ldc);
+        } else {
+            int blocks = (int)((total4 + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks), dim3(256), 0, stream, g.ws, ks, M, N, dW, ldc);
+        }
     }
     return sed_check_launch();
 }
