@@ -5,8 +5,8 @@ cd "$(dirname "$0")/.."
 V=tools/ablate/variants
 mkdir -p $V
 FF="-ffast-math -fno-finite-math-only -mllvm -amdgpu-mfma-vgpr-form=1"
-names=(main kpre kpre_abl3)
-flags=("" "-DATT_KPRE" "-DATT_KPRE -DATT_ABL=3")
+names=(main noxcd)
+flags=("" "-DATT_NO_XCD")
 if [ "$1" = build ]; then
   for i in "${!names[@]}"; do
     ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $FF ${flags[$i]} -c transformer4sed_amd/csrc/attention.hip -o /tmp/attn_${names[$i]}.o &&
@@ -15,5 +15,5 @@ if [ "$1" = build ]; then
   done
   wait
 else
-  for n in "${names[@]}"; do echo "== $n"; SED_HIP_LIB=$PWD/$V/attn_$n.so REPS=10 python tools/attn_bench.py 2>&1 | grep mhsa_fwd; done
+  for n in "${names[@]}"; do echo "== $n"; SED_HIP_LIB=$PWD/$V/attn_$n.so REPS=10 python tools/attn_bench.py 2>&1 | grep mhsa; done
 fi

@@ -264,6 +264,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 // + 16 l, so the XOR swizzles of the K image (chunk ^ (row >> 1) & 7) and of the V image (chunk ^ ((row >> 1) & 1) << 2) are applied on the
 // SOURCE address; rows past the sequence end read zeros through the buffer descriptor (no clamped duplicates).
 // ---------------------------------------------------------------------------------------------------
+// XCD-aware order (round 4): workgroups are dispatched round-robin over the 8 XCDs in linear (x fastest) order, which puts the query / key
+// blocks of one (clip, head) on up to 8 different L2s -- its K / V (305 KB at N = 1190) fetched through each of them, ~1 GB per forward launch
+// at 220 us.  With this order XCD x walks the (clip, head) pairs = x (mod 8), all blocks of a pair back to back (needs B H % 8 == 0).
+__device__ __forceinline__ void attn_xcd_order(int& bh, int& blk) {
+    const int nq = gridDim.x, nbh = gridDim.y;
+    bh = blockIdx.y; blk = blockIdx.x;
+#ifndef ATT_NO_XCD      // (A/B build switch, tools/attn_variants.sh)
+    if ((nbh & 7) == 0) {
+        const int D = blockIdx.y * nq + blockIdx.x, slot = D >> 3;
+        bh = (slot / nq) * 8 + (D & 7);
+        blk = slot - (slot / nq) * nq;
+    }
+#endif
+}
 typedef __attribute__((address_space(3))) void* att_lds_ptr_t;
 template <int OFF>
 __device__ __forceinline__ unsigned long long att_tr(unsigned addr) {
@@ -288,8 +302,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE_DMA, WP
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][KVB * 128];  // [buf][K | V]
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    int bh, qblk;
+    attn_xcd_order(bh, qblk);
+    const int b = bh / H, h = bh - b * H;
+    const int q0 = qblk * 128 + wave * 32;
     const bf16_t* Qb = Q + (size_t)bh * N * HD;
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(K + (size_t)bh * N * HD), 0, N * HD * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(V + (size_t)bh * N * HD), 0, N * HD * 2, 0x00020000);
@@ -489,8 +505,10 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dkdv_kernel(
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][3][KVB * 128];
     __shared__ __attribute__((aligned(16))) float lstat[2][2][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
-    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
-    const int key0 = blockIdx.x * 128 + wave * 32;
+    int bh, kblk;
+    attn_xcd_order(bh, kblk);       // (the key blocks of a pair share its Q / dO tiles)
+    const int b = bh / H, h = bh - b * H;
+    const int key0 = kblk * 128 + wave * 32;
     const bool wave_live = __builtin_amdgcn_readfirstlane(key0) < N;
     const size_t hb = (size_t)bh * N * HD;
 
@@ -617,8 +635,10 @@ __global__ __launch_bounds__(256) void mhsa_bwd_dq_kernel(const bf16_t* __restri
                                                           int N, int Npad, int H, int v_is_f16) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][3][KVB * 128];  // K rows (S type), V rows, K rows bf16 (dual use)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
-    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    int bh, qblk;
+    attn_xcd_order(bh, qblk);
+    const int b = bh / H, h = bh - b * H;
+    const int q0 = qblk * 128 + wave * 32;
     const bool wave_live = __builtin_amdgcn_readfirstlane(q0) < N;
     const size_t hb = (size_t)bh * N * HD;
     int qrow = q0 + lr;
