@@ -378,10 +378,19 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
 // Per-lane column constants (bias, plus the rel-pos u / v vector for the q projection) for the 16 columns a lane owns: fetched ONCE,
 // before any store -- the output pointers may alias them as far as the compiler knows, so a load placed between stores costs a full
 // `s_waitcnt vmcnt(0)` round trip each time (measured: 8 us / tile).
+// Column order of a wave's 128 x 64 sub-tile (round 4).  MFMA block j, lane group lq = lane >> 4, register r used to be column
+// 16 j + 4 lq + r: a lane's 16 values of a row were four separate 8-byte runs, and the tile had to go through LDS to become whole rows.
+// The B operand's DMA now places weight row PP_COL(j, lq) + r at LDS row 16 j + 4 lq + r of its 64-row group (a permutation of address
+// bits 2..4 on the DMA SOURCE side; fragment reads and swizzle unchanged), so the lane holds columns 8 lq .. 8 lq + 7 (blocks 0, 1)
+// and 32 + 8 lq .. 32 + 8 lq + 7 (blocks 2, 3): two 16-byte runs of 16-bit outputs, and the four lane groups of a row make 64
+// contiguous bytes per store instruction -- the 16-bit epilogues store straight from the accumulators, no LDS round trip.
+__device__ __forceinline__ constexpr int PP_COL(int j, int lq) { return 8 * lq + 32 * (j >> 1) + 4 * (j & 1); }
+// LDS row (within the B stage) -> weight row of the tile
+__device__ __forceinline__ int pp_brow_src(int row) { return (row & ~0x1C) | ((row & 0x10) >> 2) | ((row & 0x0C) << 1); }
 __device__ __forceinline__ void pp_col_consts(float (&bv)[4][4], const float* bias_n, const float* extra, int lq) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int col = j * 16 + 4 * lq;
+        const int col = PP_COL(j, lq);
         float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
         if (bias_n != nullptr) b = *reinterpret_cast<const float4*>(bias_n + col);
         if (extra != nullptr) {
@@ -403,120 +412,6 @@ __device__ __forceinline__ int gb_split(const GemmArgs& g, int mb, const float*&
     rowB = g.gbias + (size_t)gB * g.N;
     return (gA + 1) * g.gb_rows - mb;
 }
-// staging with a per-row choice between two sets of column constants (bv + group-bias row A for rows < bnd, + row B otherwise);
-// the two rows are fetched per 16-column block (8 registers live at a time: this variant must fit beside the 128 accumulators)
-template <bool F16, int MODE>
-__device__ __forceinline__ void pp_stage16_gb(unsigned char* wl, const f32x4_t (&acc)[8][4], const float (&bv)[4][4], const float* rowA,
-                                              const float* rowB, int bnd, int l15, int lq) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float4 a4 = *reinterpret_cast<const float4*>(rowA + j * 16 + 4 * lq), b4 = *reinterpret_cast<const float4*>(rowB + j * 16 + 4 * lq);
-        const float cA[4] = {bv[j][0] + a4.x, bv[j][1] + a4.y, bv[j][2] + a4.z, bv[j][3] + a4.w};
-        const float cB[4] = {bv[j][0] + b4.x, bv[j][1] + b4.y, bv[j][2] + b4.z, bv[j][3] + b4.w};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const bool second = i * 16 + l15 >= bnd;
-            f32x2v x0 = {acc[i][j][0] + (second ? cB[0] : cA[0]), acc[i][j][1] + (second ? cB[1] : cA[1])};
-            f32x2v x1 = {acc[i][j][2] + (second ? cB[2] : cA[2]), acc[i][j][3] + (second ? cB[3] : cA[3])};
-            if (MODE == 1) { x0 = gelu_fast2(x0); x1 = gelu_fast2(x1); }
-            uint2 pk;
-            pk.x = pack2<F16>(x0.x, x0.y);
-            pk.y = pack2<F16>(x1.x, x1.y);
-            *reinterpret_cast<uint2*>(wl + (i * 16 + l15) * V3_RS16 + (j * 16 + 4 * lq) * 2) = pk;
-        }
-    }
-}
-
-// LayerNorm-folded staging: x = rstd[row] * (acc - mean[row] * sv[col]) + bv[col]  (rows mb + 16 i + l15, statistics clipped to the last row)
-// (BVP: the column constants are fetched per 16-column block from `bias_n` instead of living in 16 registers -- the head-split epilogue
-//  has no room for them beside the accumulators)
-template <bool F16, int MODE, bool BVP = false, int RB = 8>
-__device__ __forceinline__ void pp_stage16_ln(unsigned char* wl, const f32x4_t (&acc)[8][4], const float (&bv)[4][4], const float* colS_n,
-                                              const float* rowstat, int mb, int M, int l15, int lq, const float* bias_n = nullptr) {
-    // every global load of the epilogue is issued up front (8 row statistics, 4 + 4 column vectors): one exposed round trip instead of
-    // one per 16-column block -- the K loop's fragment registers are free by now
-    float2 st[8];
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        const int m = mb + i * 16 + l15;
-        st[i] = *reinterpret_cast<const float2*>(rowstat + 2 * (size_t)(m < M ? m : M - 1));
-    }
-    if constexpr (BVP) {      // head-split epilogue (tight on registers): column vectors one 16-column block ahead, blocks outermost
-        float rs[8], tm[8];
-#pragma unroll
-        for (int i = 0; i < RB; ++i) { rs[i] = st[i].y; tm[i] = -st[i].x * st[i].y; }
-        float4 sn = *reinterpret_cast<const float4*>(colS_n + 4 * lq), bn = *reinterpret_cast<const float4*>(bias_n + 4 * lq);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float4 sc = sn, bc = bn;
-            if (j < 3) {
-                sn = *reinterpret_cast<const float4*>(colS_n + (j + 1) * 16 + 4 * lq);
-                bn = *reinterpret_cast<const float4*>(bias_n + (j + 1) * 16 + 4 * lq);
-            }
-#pragma unroll
-            for (int i = 0; i < RB; ++i) {
-                uint2 pk;
-                pk.x = pack2<F16>(__builtin_fmaf(acc[i][j][0], rs[i], __builtin_fmaf(tm[i], sc.x, bc.x)),
-                                  __builtin_fmaf(acc[i][j][1], rs[i], __builtin_fmaf(tm[i], sc.y, bc.y)));
-                pk.y = pack2<F16>(__builtin_fmaf(acc[i][j][2], rs[i], __builtin_fmaf(tm[i], sc.z, bc.z)),
-                                  __builtin_fmaf(acc[i][j][3], rs[i], __builtin_fmaf(tm[i], sc.w, bc.w)));
-                *reinterpret_cast<uint2*>(wl + (i * 16 + l15) * V3_RS16 + (j * 16 + 4 * lq) * 2) = pk;
-            }
-        }
-        return;
-    }
-    float4 s4[4], b4[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        s4[j] = *reinterpret_cast<const float4*>(colS_n + j * 16 + 4 * lq);
-        b4[j] = make_float4(bv[j][0], bv[j][1], bv[j][2], bv[j][3]);
-    }
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        const float rs = st[i].y, tm = -st[i].x * st[i].y;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x2v x0 = {__builtin_fmaf(acc[i][j][0], rs, __builtin_fmaf(tm, s4[j].x, b4[j].x)),
-                         __builtin_fmaf(acc[i][j][1], rs, __builtin_fmaf(tm, s4[j].y, b4[j].y))};
-            f32x2v x1 = {__builtin_fmaf(acc[i][j][2], rs, __builtin_fmaf(tm, s4[j].z, b4[j].z)),
-                         __builtin_fmaf(acc[i][j][3], rs, __builtin_fmaf(tm, s4[j].w, b4[j].w))};
-            if (MODE == 1) { x0 = gelu_fast2(x0); x1 = gelu_fast2(x1); }
-            uint2 pk;
-            pk.x = pack2<F16>(x0.x, x0.y);
-            pk.y = pack2<F16>(x1.x, x1.y);
-            *reinterpret_cast<uint2*>(wl + (i * 16 + l15) * V3_RS16 + (j * 16 + 4 * lq) * 2) = pk;
-        }
-    }
-}
-
-template <bool F16, int MODE, int RB = 8>
-__device__ __forceinline__ void pp_stage16(unsigned char* wl, const f32x4_t (&acc)[8][4], const float (&bv)[4][4], int l15, int lq) {
-    // mode 0: acc + column constant   1: gelu_fast(acc + column constant)
-#pragma unroll
-    for (int i = 0; i < RB; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x2v x0 = {acc[i][j][0] + bv[j][0], acc[i][j][1] + bv[j][1]};
-            f32x2v x1 = {acc[i][j][2] + bv[j][2], acc[i][j][3] + bv[j][3]};
-            if (MODE == 1) { x0 = gelu_fast2(x0); x1 = gelu_fast2(x1); }
-            uint2 pk;
-            pk.x = pack2<F16>(x0.x, x0.y);
-            pk.y = pack2<F16>(x1.x, x1.y);
-            *reinterpret_cast<uint2*>(wl + (i * 16 + l15) * V3_RS16 + (j * 16 + 4 * lq) * 2) = pk;
-        }
-}
-// 64 staged rows (accumulator blocks 4 p .. 4 p + 3) as fp32
-template <int RB = 8>
-__device__ __forceinline__ void pp_stage32(unsigned char* wl, const f32x4_t (&acc)[8][4], int p, int l15, int lq) {
-#pragma unroll
-    for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (4 * p + ii >= RB) continue;
-            const f32x4_t& a = acc[4 * p + ii][j];
-            *reinterpret_cast<float4*>(wl + (ii * 16 + l15) * V3_RS32 + (j * 16 + 4 * lq) * 4) = make_float4(a[0], a[1], a[2], a[3]);
-        }
-}
 // C-tile stores of the 256^2 kernels are non-temporal: the tile is not re-read by this kernel, and write-allocating it evicts
 // the A/B panels that the neighbouring column tiles still need from the 4 MB L2 (+2..4 % on the model's shapes).
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -534,6 +429,201 @@ __device__ __forceinline__ void v3_st(void* p, const T& v) {
     }
 }
 
+// ---- 16-bit epilogue sinks: where a lane's 8 consecutive 16-bit outputs of row block i, column half k (PP_COL order: columns
+// 32 k + 8 lq .. + 7 of the wave's 64) go.  Global sinks store 16 bytes per lane straight from the accumulators; the LDS sink keeps
+// the staged form for the head-split variants that also write transposed copies.
+// A store instruction of 64 lanes x 16 B should cover 8 rows x 128 contiguous bytes (for the head-split q / k / v a wave's 128 token rows
+// of one head are ONE contiguous 16 KB run), not 16 rows x 64: lanes l15 and l15 ^ 8 of a 16-lane DPP row swap one half each
+// (`row_ror:8`), after which lanes l15 < 8 hold the low 64 bytes and lanes l15 >= 8 the high 64 bytes of rows 16 i + (l15 & 7)
+// (first store) and 16 i + 8 + (l15 & 7) (second store).  12 VALU operations per 16-row block instead of the LDS round trip.
+__device__ __forceinline__ unsigned pp_ror8(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);      // row_ror:8
+}
+__device__ __forceinline__ void pp_pair_swap(uint4& a0, uint4& a1, bool lo) {
+    // in: a0 / a1 = this lane's row, column halves 0 / 1.  out: a0 = (row l15 & 7, half l15 >> 3), a1 = (row 8 + (l15 & 7), half l15 >> 3)
+    // (component-wise selects: a conditional between the two structs becomes a pointer select into scratch memory)
+    const unsigned rx = pp_ror8(lo ? a1.x : a0.x), ry = pp_ror8(lo ? a1.y : a0.y), rz = pp_ror8(lo ? a1.z : a0.z), rw = pp_ror8(lo ? a1.w : a0.w);
+    a0 = make_uint4(lo ? a0.x : rx, lo ? a0.y : ry, lo ? a0.z : rz, lo ? a0.w : rw);
+    a1 = make_uint4(lo ? rx : a1.x, lo ? ry : a1.y, lo ? rz : a1.z, lo ? rw : a1.w);
+}
+struct PPSinkLds {
+    unsigned char* wl; int l15, lq;
+    __device__ __forceinline__ void half(int i, int k, const uint4& v) const {
+        unsigned char* d = wl + (i * 16 + l15) * V3_RS16 + (32 * k + 8 * lq) * 2;      // (136-byte rows: two 8-byte writes)
+        *reinterpret_cast<uint2*>(d) = make_uint2(v.x, v.y);
+        *reinterpret_cast<uint2*>(d + 8) = make_uint2(v.z, v.w);
+    }
+    __device__ __forceinline__ void row(int i, const uint4& a0, const uint4& a1) const { half(i, 0, a0); half(i, 1, a1); }
+};
+struct PPSinkRows {          // row-major [M][ldc] output
+    bf16_t* base;            // row mb + (l15 & 7), column nb + 32 (l15 >> 3) + 8 lq
+    bf16_t* hbase;           // row mb + l15, column nb + 8 lq   (un-swapped halves)
+    int ld8;                 // 8 * ldc
+    int mrem, hrem;          // rows left from base's / hbase's row
+    bool lo;
+    __device__ __forceinline__ void half(int i, int k, const uint4& v) const {
+        if (16 * i < hrem) v3_st<uint4>(hbase + (size_t)(2 * i) * ld8 + 32 * k, v);
+    }
+    __device__ __forceinline__ void row(int i, uint4 a0, uint4 a1) const {
+        pp_pair_swap(a0, a1, lo);
+        if (16 * i < mrem) v3_st<uint4>(base + (size_t)(2 * i) * ld8, a0);
+        if (16 * i + 8 < mrem) v3_st<uint4>(base + (size_t)(2 * i + 1) * ld8, a1);
+    }
+};
+struct PPSinkHeads {         // head-split q / k / v: [clip * heads + h][seq][64]
+    bf16_t* dst;             // + h * seq * 64 + 32 (l15 >> 3) + 8 lq already applied
+    int b0, t0, seq, hs, mrem;   // clip / token of row mb + (l15 & 7); hs = heads * seq; rows left from there
+    bool lo;
+    __device__ __forceinline__ void st(int r, const uint4& v) const {      // r = row offset from this lane's first row (a multiple of 8)
+        if (r >= mrem) return;
+        int t = t0 + r, b = b0;
+        if (seq >= 128) { if (t >= seq) { t -= seq; ++b; } }
+        else { const int q = t / seq; t -= q * seq; b += q; }
+        v3_st<uint4>(dst + ((size_t)b * hs + t) * 64, v);
+    }
+    __device__ __forceinline__ void row(int i, uint4 a0, uint4 a1) const {
+        pp_pair_swap(a0, a1, lo);
+        st(16 * i, a0);
+        st(16 * i + 8, a1);
+    }
+};
+template <bool F16, int MODE>
+__device__ __forceinline__ uint4 pp_pack8(f32x2v a0, f32x2v a1, f32x2v b0, f32x2v b1) {
+    if (MODE == 1) { a0 = gelu_fast2(a0); a1 = gelu_fast2(a1); b0 = gelu_fast2(b0); b1 = gelu_fast2(b1); }
+    return make_uint4(pack2<F16>(a0.x, a0.y), pack2<F16>(a1.x, a1.y), pack2<F16>(b0.x, b0.y), pack2<F16>(b1.x, b1.y));
+}
+
+// per-row choice between two sets of column constants (bv + group-bias row A for rows < bnd, + row B otherwise);
+// the two rows are fetched per 32-column half (16 registers live at a time: this variant must fit beside the 128 accumulators)
+template <bool F16, int MODE, class Sink>
+__device__ __forceinline__ void pp_stage16_gb(const Sink& sink, const f32x4_t (&acc)[8][4], const float (&bv)[4][4], const float* rowA,
+                                              const float* rowB, int bnd, int l15, int lq) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float cA[2][4], cB[2][4];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * k + jj;
+            const float4 a4 = *reinterpret_cast<const float4*>(rowA + PP_COL(j, lq)), b4 = *reinterpret_cast<const float4*>(rowB + PP_COL(j, lq));
+            cA[jj][0] = bv[j][0] + a4.x; cA[jj][1] = bv[j][1] + a4.y; cA[jj][2] = bv[j][2] + a4.z; cA[jj][3] = bv[j][3] + a4.w;
+            cB[jj][0] = bv[j][0] + b4.x; cB[jj][1] = bv[j][1] + b4.y; cB[jj][2] = bv[j][2] + b4.z; cB[jj][3] = bv[j][3] + b4.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool second = i * 16 + l15 >= bnd;
+            f32x2v x[2][2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const f32x4_t& a = acc[i][2 * k + jj];
+                x[jj][0] = f32x2v{a[0] + (second ? cB[jj][0] : cA[jj][0]), a[1] + (second ? cB[jj][1] : cA[jj][1])};
+                x[jj][1] = f32x2v{a[2] + (second ? cB[jj][2] : cA[jj][2]), a[3] + (second ? cB[jj][3] : cA[jj][3])};
+            }
+            sink.half(i, k, pp_pack8<F16, MODE>(x[0][0], x[0][1], x[1][0], x[1][1]));
+        }
+    }
+}
+
+// LayerNorm-folded form: x = rstd[row] * (acc - mean[row] * sv[col]) + bv[col]  (rows mb + 16 i + l15, statistics clipped to the last row)
+// (BVP: the column constants are fetched per 32-column half from `bias_n` instead of living in 16 registers -- the head-split epilogue
+//  has no room for them beside the accumulators)
+template <bool F16, int MODE, bool BVP = false, int RB = 8, class Sink>
+__device__ __forceinline__ void pp_stage16_ln(const Sink& sink, const f32x4_t (&acc)[8][4], const float (&bv)[4][4], const float* colS_n,
+                                              const float* rowstat, int mb, int M, int l15, int lq, const float* bias_n = nullptr) {
+    // every global load of the epilogue is issued up front (8 row statistics, the column vectors): one exposed round trip instead of
+    // one per column block -- the K loop's fragment registers are free by now
+    float2 st[8];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int m = mb + i * 16 + l15;
+        st[i] = *reinterpret_cast<const float2*>(rowstat + 2 * (size_t)(m < M ? m : M - 1));
+    }
+    if constexpr (BVP) {      // head-split epilogue: the bias vector comes from `bias_n` (no per-lane constants were kept over the K loop)
+        float4 sn[4], bn[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sn[j] = *reinterpret_cast<const float4*>(colS_n + PP_COL(j, lq));
+            bn[j] = *reinterpret_cast<const float4*>(bias_n + PP_COL(j, lq));
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const float rs = st[i].y, tm = -st[i].x * st[i].y;
+            uint4 o[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                f32x2v x[2][2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = 2 * k + jj;
+                    const f32x4_t& a = acc[i][j];
+                    x[jj][0] = f32x2v{__builtin_fmaf(a[0], rs, __builtin_fmaf(tm, sn[j].x, bn[j].x)), __builtin_fmaf(a[1], rs, __builtin_fmaf(tm, sn[j].y, bn[j].y))};
+                    x[jj][1] = f32x2v{__builtin_fmaf(a[2], rs, __builtin_fmaf(tm, sn[j].z, bn[j].z)), __builtin_fmaf(a[3], rs, __builtin_fmaf(tm, sn[j].w, bn[j].w))};
+                }
+                o[k] = pp_pack8<F16, MODE>(x[0][0], x[0][1], x[1][0], x[1][1]);
+            }
+            sink.row(i, o[0], o[1]);
+        }
+        return;
+    }
+    float4 s4[4], b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s4[j] = *reinterpret_cast<const float4*>(colS_n + PP_COL(j, lq));
+        b4[j] = make_float4(bv[j][0], bv[j][1], bv[j][2], bv[j][3]);
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const float rs = st[i].y, tm = -st[i].x * st[i].y;
+        uint4 o[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            f32x2v x[2][2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * k + jj;
+                x[jj][0] = f32x2v{__builtin_fmaf(acc[i][j][0], rs, __builtin_fmaf(tm, s4[j].x, b4[j].x)),
+                                  __builtin_fmaf(acc[i][j][1], rs, __builtin_fmaf(tm, s4[j].y, b4[j].y))};
+                x[jj][1] = f32x2v{__builtin_fmaf(acc[i][j][2], rs, __builtin_fmaf(tm, s4[j].z, b4[j].z)),
+                                  __builtin_fmaf(acc[i][j][3], rs, __builtin_fmaf(tm, s4[j].w, b4[j].w))};
+            }
+            o[k] = pp_pack8<F16, MODE>(x[0][0], x[0][1], x[1][0], x[1][1]);
+        }
+        sink.row(i, o[0], o[1]);
+    }
+}
+
+template <bool F16, int MODE, int RB = 8, class Sink>
+__device__ __forceinline__ void pp_stage16(const Sink& sink, const f32x4_t (&acc)[8][4], const float (&bv)[4][4]) {
+    // mode 0: acc + column constant   1: gelu_fast(acc + column constant)
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        uint4 o[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            f32x2v x[2][2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * k + jj;
+                x[jj][0] = f32x2v{acc[i][j][0] + bv[j][0], acc[i][j][1] + bv[j][1]};
+                x[jj][1] = f32x2v{acc[i][j][2] + bv[j][2], acc[i][j][3] + bv[j][3]};
+            }
+            o[k] = pp_pack8<F16, MODE>(x[0][0], x[0][1], x[1][0], x[1][1]);
+        }
+        sink.row(i, o[0], o[1]);
+    }
+}
+// 64 staged rows (accumulator blocks 4 p .. 4 p + 3) as fp32
+// (PERM: the accumulators are in PP_COL column order -- the NT ping-pong kernel; the TN kernel's are in plain order)
+template <int RB = 8, bool PERM = false>
+__device__ __forceinline__ void pp_stage32(unsigned char* wl, const f32x4_t (&acc)[8][4], int p, int l15, int lq) {
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (4 * p + ii >= RB) continue;
+            const f32x4_t& a = acc[4 * p + ii][j];
+            *reinterpret_cast<float4*>(wl + (ii * 16 + l15) * V3_RS32 + (PERM ? PP_COL(j, lq) : j * 16 + 4 * lq) * 4) = make_float4(a[0], a[1], a[2], a[3]);
+        }
+}
 // Side input of one batch (8 rows per lane, rows m0 + 4 u + lane/16): residual rows (fp32) or saved pre-activations (16-bit)
 template <int EPI>
 struct V3Side {
@@ -668,43 +758,33 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
     constexpr bool ROWS_ONLY = GBM >= 3;      // head-split epilogue: row-major q / k / v only (3: folded LayerNorm, 4: the plain encoder form)
     const int l15 = lane & 15, lq = lane >> 4;
     if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
+        // 16-byte stores straight from the accumulators (PP_COL column order): no staging, no wave barrier
 #pragma unroll
         for (int pass = 0; pass < (EPI == EPI_GELU ? 2 : 1); ++pass) {
             bf16_t* out = (EPI == EPI_GELU && pass == 1) ? g.outH2 : g.outH;
             if (out == nullptr) continue;
-            // (opaque to the optimiser: otherwise `out + lane column` is hoisted out of the persistent tile loop as a 64-bit per-lane value,
+            // (opaque to the optimiser: otherwise the per-lane output address is hoisted out of the persistent tile loop as a 64-bit value,
             //  spilled around it in the register-tight variants and reloaded -- behind a vmcnt(0) -- at every tile's store phase)
-            int lc8 = (lane & 7) * 8;
-            asm volatile("" : "+v"(lc8));
+            int lrow = l15;
+            asm volatile("" : "+v"(lrow));
+            const int r8 = lrow & 7, hk = lrow >> 3;
+            const PPSinkRows sink{out + (size_t)(mb + r8) * g.ldc + nb + 32 * hk + 8 * lq, out + (size_t)(mb + lrow) * g.ldc + nb + 8 * lq,
+                                  8 * g.ldc, g.M - mb - r8, g.M - mb - lrow, lrow < 8};
             if constexpr (GB) {      // evaluation-mode encoder only (no saved pre-activation: one pass)
                 const float *rA, *rB;
                 const int bnd = gb_split(g, mb, rA, rB);
-                if (EPI == EPI_GELU && pass == 1) pp_stage16_gb<F16, 1>(wl, acc, cc.bv, rA + nb, rB + nb, bnd, l15, lq);
-                else pp_stage16_gb<F16, 0>(wl, acc, cc.bv, rA + nb, rB + nb, bnd, l15, lq);
+                if (EPI == EPI_GELU && pass == 1) pp_stage16_gb<F16, 1>(sink, acc, cc.bv, rA + nb, rB + nb, bnd, l15, lq);
+                else pp_stage16_gb<F16, 0>(sink, acc, cc.bv, rA + nb, rB + nb, bnd, l15, lq);
             } else if constexpr (LN) {      // consumer: Linear(LayerNorm(x)) from the raw stream's product (no saved pre-activation either)
-                if (EPI == EPI_GELU && pass == 1) pp_stage16_ln<F16, 1, false, RB>(wl, acc, cc.bv, g.colS + nb, g.rowstat, mb, g.M, l15, lq);
-                else pp_stage16_ln<F16, 0, false, RB>(wl, acc, cc.bv, g.colS + nb, g.rowstat, mb, g.M, l15, lq);
+                if (EPI == EPI_GELU && pass == 1) pp_stage16_ln<F16, 1, false, RB>(sink, acc, cc.bv, g.colS + nb, g.rowstat, mb, g.M, l15, lq);
+                else pp_stage16_ln<F16, 0, false, RB>(sink, acc, cc.bv, g.colS + nb, g.rowstat, mb, g.M, l15, lq);
             } else
-            if (EPI == EPI_GELU && pass == 1) pp_stage16<F16, 1>(wl, acc, cc.bv, l15, lq);
-            else if (EPI == EPI_GELU && F16 && g.bwd_bf16) pp_stage16<false, 0>(wl, acc, cc.bv, l15, lq);  // pre-activation for the bf16 backward
-            else pp_stage16<F16, 0>(wl, acc, cc.bv, l15, lq);
-            __builtin_amdgcn_wave_barrier();
+            if (EPI == EPI_GELU && pass == 1) pp_stage16<F16, 1, RB>(sink, acc, cc.bv);
+            else if (EPI == EPI_GELU && F16 && g.bwd_bf16) pp_stage16<false, 0, RB>(sink, acc, cc.bv);  // pre-activation for the bf16 backward
+            else pp_stage16<F16, 0, RB>(sink, acc, cc.bv);
 #ifdef GX_TRACE
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (gxt != nullptr) gxt[4] = __builtin_amdgcn_s_memrealtime();
 #endif
-#pragma unroll
-            for (int rb = 0; rb < 16; rb += 8) {
-                uint4 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint4*>(wl + ((rb + u) * 8 + (lane >> 3)) * V3_RS16 + (lane & 7) * 16);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int row = (rb + u) * 8 + (lane >> 3);
-                    if (mb + row < g.M && row < 16 * RB) v3_st<uint4>(out + (size_t)(mb + row) * g.ldc + nb + lc8, v[u]);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
         }
         return;
     }
@@ -712,25 +792,41 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
         const int D = g.heads * 64;
         const int which = nb / D, h = (nb - which * D) >> 6;
         bf16_t* row_dst = which == 0 ? g.q : (which == 1 ? g.k : g.v);
+        if constexpr (ROWS_ONLY) {
+            // (folded-LayerNorm consumer / plain encoder form: row-major q / k / v only -- no second biased q, no transposed copies.)
+            // Stored straight from the accumulators: a lane's 8 columns of a half are 16 contiguous bytes of one head row.
+            if (row_dst == nullptr) return;      // (the row-major V is only needed by the backward: inference passes v = NULL)
+            int lrow = l15;
+            asm volatile("" : "+v"(lrow));
+            const int m_first = mb + (lrow & 7), b0 = m_first / g.seq;
+            const PPSinkHeads sink{row_dst + (size_t)h * g.seq * 64 + 32 * (lrow >> 3) + 8 * lq, b0, m_first - b0 * g.seq, g.seq, g.heads * g.seq,
+                                   g.M - m_first, lrow < 8};
+            if constexpr (LN) {
+                float bv[4][4];
+                pp_stage16_ln<F16, 0, true, RB>(sink, acc, bv, g.colS + nb, g.rowstat, mb, g.M, l15, lq, g.bias + nb);
+            } else {
+                float bv[4][4];
+                pp_col_consts(bv, g.bias != nullptr ? g.bias + nb : nullptr, (which == 0 && g.pu != nullptr) ? g.pu + h * 64 : nullptr, lq);
+                pp_stage16<F16, 0, RB>(sink, acc, bv);
+            }
+            return;
+        }
         bf16_t* tr_dst = which == 0 ? g.qt : (which == 1 ? g.kt : g.vt);
-        // (folded-LayerNorm consumer: inference outputs only -- no second biased q, no transposed copies; compiled out to keep the
-        //  epilogue's registers under the limit: a spilled register reloaded between the tile stores waits for every store before it)
-        const int npass = (!ROWS_ONLY && which == 0 && g.q2 != nullptr) ? 2 : 1;
+        const PPSinkLds lsink{wl, l15, lq};
+        const int npass = (which == 0 && g.q2 != nullptr) ? 2 : 1;
         for (int pass = 0; pass < npass; ++pass) {
             const float* extra = nullptr;
             if (which == 0 && g.pu != nullptr) extra = (pass == 0 ? g.pu : g.pv) + h * 64;
             bf16_t* rd = pass == 0 ? row_dst : g.q2;
             bf16_t* td = pass == 0 ? tr_dst : g.q2t;
             float bv[4][4];
-            if constexpr (!LN) pp_col_consts(bv, g.bias != nullptr ? g.bias + nb : nullptr, extra, lq);
+            pp_col_consts(bv, g.bias != nullptr ? g.bias + nb : nullptr, extra, lq);
             if constexpr (GB) {
                 const float *rA, *rB;
                 const int bnd = gb_split(g, mb, rA, rB);
-                pp_stage16_gb<F16, 0>(wl, acc, bv, rA + nb, rB + nb, bnd, l15, lq);
-            } else if constexpr (LN) {
-                pp_stage16_ln<F16, 0, true, RB>(wl, acc, bv, g.colS + nb, g.rowstat, mb, g.M, l15, lq, g.bias + nb);
+                pp_stage16_gb<F16, 0>(lsink, acc, bv, rA + nb, rB + nb, bnd, l15, lq);
             } else {
-                pp_stage16<F16, 0, RB>(wl, acc, bv, l15, lq);
+                pp_stage16<F16, 0, RB>(lsink, acc, bv);
             }
             // Tensors that only the bf16 backward reads (row-major V; Q^T, K^T, (q+v)^T) are emitted as bf16 when g.bwd_bf16 is
             // set: converted from the staged f16 tile on the way out (same double rounding as a later in-place conversion,
@@ -759,7 +855,6 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
                     }
                 }
             }
-            if constexpr (ROWS_ONLY) { __builtin_amdgcn_wave_barrier(); continue; }
             if (td != nullptr && (g.seq & 1) == 0) {
                 // transposed copy [bh][d][seq_pad]: a lane owns a PAIR of consecutive tokens (same clip: seq is even and
                 // the pair starts on an even row) and one of two interleaved d columns -> 4-byte stores, 32 lanes = 128 B
@@ -816,14 +911,14 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
     const int mend = mb + 16 * RB;
     V3Side<EPI> s0, s1;
     v3_side_load<EPI, LN && EPI == EPI_F32_RESID>(s0, g, mb, n, lane);
-    pp_stage32<RB>(wl, acc, 0, l15, lq);
+    pp_stage32<RB, true>(wl, acc, 0, l15, lq);
     __builtin_amdgcn_wave_barrier();
     v3_side_load<EPI, LN && EPI == EPI_F32_RESID>(s1, g, mb + 32, n, lane);
     v3_store_batch<EPI, F16, LN && EPI == EPI_F32_RESID>(g, wl, s0, b, mb, 0, n, c4, lane, bB, mbnd, mend);
     v3_side_load<EPI, LN && EPI == EPI_F32_RESID>(s0, g, mb + 64, n, lane);
     v3_store_batch<EPI, F16, LN && EPI == EPI_F32_RESID>(g, wl, s1, b, mb + 32, 32, n, c4, lane, bB, mbnd, mend);
     __builtin_amdgcn_wave_barrier();
-    pp_stage32<RB>(wl, acc, 1, l15, lq);
+    pp_stage32<RB, true>(wl, acc, 1, l15, lq);
     __builtin_amdgcn_wave_barrier();
     v3_side_load<EPI, LN && EPI == EPI_F32_RESID>(s1, g, mb + 96, n, lane);
     v3_store_batch<EPI, F16, LN && EPI == EPI_F32_RESID>(g, wl, s0, b, mb + 64, 0, n, c4, lane, bB, mbnd, mend);
@@ -902,7 +997,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
             const int cl = pch ^ ((row >> 1) & 7);
             const bool is_b = (sl == 1 || sl == 2);
             // LDS row wm * 128 + r of the A stage holds tile row wm * 16 RB + r (r >= 16 RB: a row nobody reads)
-            const int grow = is_b ? row : (row >> 7) * (16 * RB) + (row & 127);
+            const int grow = is_b ? pp_brow_src(row) : (row >> 7) * (16 * RB) + (row & 127);
             vo[sl][e] = grow * (is_b ? g.ldb : g.lda) * 2 + cl * 16;
             ld_[sl][e] = (is_b ? 65536 : 0) + rows[sl] * 128;
         }
