@@ -121,6 +121,12 @@ int sed_gemm_nt_lnp(const void* A, const void* B, int M, int N, int K, int lda, 
 /* (sed_gemm_nt_lnp, split-plane stream: between two folded blocks the residual stream can live as two f16 planes hi + lo instead of fp32
  *  -- res_hi / res_lo != NULL: the residual is read as hi + lo instead of resF; out_lo != NULL: the result is written as x16 (hi) + out_lo
  *  and outF is left alone.  The hi plane is the next GEMM's A operand, so a producer moves 8 instead of 10 bytes per element.) */
+/* (sed_gemm_nt_lnp8: the same with the lo plane as BYTES -- res_lo8 / out_lo8 are [M][ldc] uint8 and the stream value is
+ *  hi * (1 + (q - 128) * 2^-18): the f16 rounding residual (at most |hi| 2^-11) in 256 steps, the stream to ~2^-19 relative.  A producer
+ *  then moves 6 bytes per element.  Planes written by one entry point must be read by the same one.) */
+int sed_gemm_nt_lnp8(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* bias, const float* resF,
+                     const void* res_hi, const void* res_lo8, float* outF, void* x16, void* out_lo8, float* rowpart, int ldc,
+                     hipStream_t stream);
 int sed_ln_fold_stats(const float* rowpart, float* rowstat, int M, int S, int D, float eps, hipStream_t stream);
 int sed_ln_fold_weight(const float* W, const float* gamma, const float* beta, const float* bias, void* W16, float* colS, float* colC,
                        int N, int K, hipStream_t stream);

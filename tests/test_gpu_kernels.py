@@ -296,10 +296,35 @@ def test_gemm_layernorm_fold():
     gemm_nt(a16, Wp.to(F16), ops.EPI_F32_RESID, bias=bp, res=hi.float() + lo.float(), outF=x2)      # what a second block adds on top
     hi2, lo2 = hi.clone(), lo.clone()
     call("sed_gemm_nt_lnp", a16, Wp.to(F16), M, D, D, D, D, bp, None, hi2, lo2, None, hi2, lo2, part2, D)
-    assert torch.equal(hi2, x2.to(F16)) and maxerr(hi2.float() + lo2.float(), x2) < 2e-6 * float(x2.abs().max())
+    # (the plane-reading kernel variants may sum residual + product + bias in another order than the fp32 one (-ffast-math): the hi plane
+    #  can differ from f16(x2) by one f16 unit where x2 sits on a rounding boundary)
+    f16_ulp = lambda t: torch.maximum(t.float().abs(), torch.full_like(t.float(), 2.0 ** -14)).log2().floor().exp2() * 2.0 ** -10
+    same_f16 = lambda a, ref: bool(((a.float() - ref.to(F16).float()).abs() <= f16_ulp(ref)).all()) and float((a != ref.to(F16)).float().mean()) < 1e-3
+    assert same_f16(hi2, x2) and maxerr(hi2.float() + lo2.float(), x2) < 2e-6 * float(x2.abs().max())
     back = torch.empty(M, D, device=DEV); h3 = torch.empty(M, D, dtype=F16, device=DEV)
     call("sed_gemm_nt_lnp", a16, Wp.to(F16), M, D, D, D, D, bp, None, hi, lo, back, h3, None, part2, D)
-    assert torch.equal(back, x2) and torch.equal(h3, x2.to(F16))
+    assert maxerr(back, x2) < 1e-6 * float(x2.abs().max()) and torch.equal(h3, back.to(F16))
+    # ... with the 8-bit lo plane (sed_gemm_nt_lnp8): x = hi (1 + (q - 128) 2^-18), the stream to ~2^-19 relative per element
+    lo8 = torch.empty(M, D, dtype=torch.uint8, device=DEV); hi8 = torch.empty(M, D, dtype=F16, device=DEV)
+    dec = lambda h, q: h.float() + (q.float() - 128.0) * h.float() * 2.0 ** -18
+    call("sed_gemm_nt_lnp8", a16, Wp.to(F16), M, D, D, D, D, bp, res, None, None, None, hi8, lo8, part2, D)
+    assert torch.equal(hi8, x16) and torch.equal(part2, part)
+    # (|x| below the f16 normal range: hi is a subnormal with a fixed 2^-24 spacing, the byte cannot express more than 2^-25 absolute)
+    # (`big` = magnitude of the terms the value was summed from: two kernels that add them in different orders differ by ~2^-23 of it,
+    #  which is not small against a result that cancelled to 1e-3 of its terms)
+    lo8_ok = lambda h, q, ref, big: bool(((dec(h, q) - ref).abs() <= 2.0 ** -18 * ref.abs() + 2.0 ** -24 + 2.0 ** -22 * big.abs()).all())
+    assert lo8_ok(hi8, lo8, x, torch.zeros_like(x))
+    hi9, lo9 = hi8.clone(), lo8.clone()
+    x3 = torch.empty(M, D, device=DEV)
+    gemm_nt(a16, Wp.to(F16), ops.EPI_F32_RESID, bias=bp, res=dec(hi8, lo8), outF=x3)
+    call("sed_gemm_nt_lnp8", a16, Wp.to(F16), M, D, D, D, D, bp, None, hi9, lo9, None, hi9, lo9, part2, D)      # planes in -> planes out, in place
+    assert same_f16(hi9, x3) and lo8_ok(hi9, lo9, x3, dec(hi8, lo8))
+    part9 = part2.clone()
+    call("sed_gemm_nt_lnp8", a16, Wp.to(F16), M, D, D, D, D, bp, None, hi8, lo8, back, h3, None, part2, D)        # planes in -> fp32 out
+    assert maxerr(back, x3) < 1e-6 * float(x3.abs().max()) and torch.equal(h3, back.to(F16))
+    # row statistics of the direct (planes in -> planes out) form against the stream it wrote
+    sl9 = x3.view(M, D // 64, 64)
+    assert maxerr(part9[:, :, 0], sl9.sum(-1)) < 2e-3 and maxerr(part9[:, :, 1], (sl9 * sl9).sum(-1)) < 2e-3 * float((sl9 * sl9).sum(-1).max())
     stat = torch.empty(M, 2, device=DEV)
     call("sed_ln_fold_stats", part, stat, M, D // 64, D, 1e-6)
     xd = x.double()

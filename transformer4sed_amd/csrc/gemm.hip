@@ -80,6 +80,10 @@ struct GemmArgs {
     // outH (hi) + out_lo and outF is not written.
     const bf16_t* res_lo;
     bf16_t* out_lo;
+    // ... with an 8-bit lo plane (lo8 != 0; res_lo / out_lo then point at [M][ldc] BYTES): the stream value is hi * (1 + (q - 128) * 2^-18),
+    // q = the byte -- the f16 rounding residual |x - hi| <= ulp(hi) / 2 <= |hi| 2^-11 in steps of |hi| 2^-18, i.e. the stream to ~2^-19
+    // relative (the f16 lo plane: ~2^-22; an f16 stream: 2^-12) for 6 instead of 8 bytes per element through a producer.
+    int lo8;
     // Persistent 256^2 kernel, dynamic tile walk: 8 per-XCD tile counters + 1 exit counter, one 64-byte line each (int index 16 x).  A
     // workgroup takes the next tile of ITS XCD's contiguous tile range from counter blockIdx.x & 7 (so the L2 grouping of the static walk
     // is kept) instead of the fixed blockIdx.x + k gridDim.x: a workgroup that becomes resident late -- or only after the others have
@@ -624,25 +628,62 @@ __device__ __forceinline__ void pp_stage32(unsigned char* wl, const f32x4_t (&ac
             *reinterpret_cast<float4*>(wl + (ii * 16 + l15) * V3_RS32 + (PERM ? PP_COL(j, lq) : j * 16 + 4 * lq) * 4) = make_float4(a[0], a[1], a[2], a[3]);
         }
 }
+// 8-bit lo plane of the split residual stream (GemmArgs.lo8): x = hi + (q - 128) * hi * 2^-18 = hi * (1 + (q - 128) 2^-18)
+__device__ __forceinline__ float lo8_decode(float hf, unsigned q) {
+    return __builtin_fmaf(__builtin_fmaf((float)q, 0x1p-18f, -0x1p-11f), hf, hf);
+}
+__device__ __forceinline__ unsigned lo8_encode4(float x0, float x1, float x2, float x3, unsigned pk0, unsigned pk1) {
+    // (hi = 0: the quotient is inf / NaN and the byte arbitrary -- the decoder multiplies it by |hi| = 0)
+    const float h0 = h2f((bf16_t)(pk0 & 0xFFFF)), h1 = h2f((bf16_t)(pk0 >> 16)), h2 = h2f((bf16_t)(pk1 & 0xFFFF)), h3 = h2f((bf16_t)(pk1 >> 16));
+    const float q0 = __builtin_rintf(__builtin_fmaf((x0 - h0) * __builtin_amdgcn_rcpf(h0), 0x1p18f, 128.f));
+    const float q1 = __builtin_rintf(__builtin_fmaf((x1 - h1) * __builtin_amdgcn_rcpf(h1), 0x1p18f, 128.f));
+    const float q2 = __builtin_rintf(__builtin_fmaf((x2 - h2) * __builtin_amdgcn_rcpf(h2), 0x1p18f, 128.f));
+    const float q3 = __builtin_rintf(__builtin_fmaf((x3 - h3) * __builtin_amdgcn_rcpf(h3), 0x1p18f, 128.f));
+    unsigned r = __builtin_amdgcn_cvt_pk_u8_f32(q0, 0, 0);      // saturating float -> byte, inserted at byte 0..3
+    r = __builtin_amdgcn_cvt_pk_u8_f32(q1, 1, r);
+    r = __builtin_amdgcn_cvt_pk_u8_f32(q2, 2, r);
+    return __builtin_amdgcn_cvt_pk_u8_f32(q3, 3, r);
+}
+
 // Side input of one batch (8 rows per lane, rows m0 + 4 u + lane/16): residual rows (fp32) or saved pre-activations (16-bit)
 template <int EPI>
 struct V3Side {
     float4 r[EPI == EPI_F32_RESID ? 8 : 1];
     uint2 a[EPI == EPI_DGELU ? 8 : 1];
 };
-template <int EPI, bool LNP = false>
+// SM (side mode of the LayerNorm-fold producer): 0 = not a producer, 1 = fp32 residual, 2 = f16 hi + f16 lo planes, 3 = f16 hi + byte lo.
+// A compile-time mode (pp_epilogue dispatches on the launch's pointers): with the three load forms as run-time branches of one function
+// their results meet in register copies right behind the loads, and every batch waits for its own round trip.
+template <int EPI, int SM = 0>
 __device__ __forceinline__ void v3_side_load(V3Side<EPI>& sd, const GemmArgs& g, int m0, int n, int lane) {
+#ifdef ABL_NO_SIDE
+    if constexpr (SM >= 2) return;
+#endif
     if constexpr (EPI == EPI_F32_RESID || EPI == EPI_DGELU) {
-        if constexpr (LNP) {
-            if (g.res_lo != nullptr) {      // split-plane residual: hi + lo (f16 each)
+        if constexpr (SM >= 2) {
+            // split-plane residual: the RAW plane words are parked in sd.r and decoded where they are used (v3_residual) -- arithmetic
+            // on a loaded value right here makes the compiler wait for every row's loads before it issues the next row's (8 exposed
+            // round trips per batch: what the "HBM-saturated" 30 us producer epilogue of rounds 3-4 really was)
+            if constexpr (SM == 3) {      // f16 hi + byte lo
+                const unsigned char* lo8p = reinterpret_cast<const unsigned char*>(g.res_lo);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int m = m0 + u * 4 + (lane >> 4);
+                    const size_t o = (size_t)(m < g.M ? m : g.M - 1) * g.ldc + n;
+                    const u32x2_t h = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(g.auxH + o));
+                    const unsigned l = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(lo8p + o));
+                    sd.r[u] = make_float4(__uint_as_float(h[0]), __uint_as_float(h[1]), __uint_as_float(l), 0.f);
+                }
+                return;
+            }
+            if constexpr (SM == 2) {      // f16 hi + f16 lo
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int m = m0 + u * 4 + (lane >> 4);
                     const size_t o = (size_t)(m < g.M ? m : g.M - 1) * g.ldc + n;
                     const u32x2_t h = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(g.auxH + o));
                     const u32x2_t l = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(g.res_lo + o));
-                    sd.r[u] = make_float4(h2f((bf16_t)(h[0] & 0xFFFF)) + h2f((bf16_t)(l[0] & 0xFFFF)), h2f((bf16_t)(h[0] >> 16)) + h2f((bf16_t)(l[0] >> 16)),
-                                          h2f((bf16_t)(h[1] & 0xFFFF)) + h2f((bf16_t)(l[1] & 0xFFFF)), h2f((bf16_t)(h[1] >> 16)) + h2f((bf16_t)(l[1] >> 16)));
+                    sd.r[u] = make_float4(__uint_as_float(h[0]), __uint_as_float(h[1]), __uint_as_float(l[0]), __uint_as_float(l[1]));
                 }
                 return;
             }
@@ -671,7 +712,7 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
     return v;
 }
-template <int EPI, bool F16, bool LNP = false>
+template <int EPI, bool F16, int SM = 0>
 __device__ __forceinline__ void v3_store_batch(const GemmArgs& g, const unsigned char* wl, const V3Side<EPI>& sd, const float4 b0,
                                                int m0, int srow0, int n, int c4, int lane, const float4 bB = make_float4(0.f, 0.f, 0.f, 0.f),
                                                int mbnd = 0x7fffffff, int mend = 0x7fffffff) {
@@ -689,12 +730,37 @@ __device__ __forceinline__ void v3_store_batch(const GemmArgs& g, const unsigned
         if constexpr (EPI == EPI_F32) {
             v3_st<float4>(g.outF + o, make_float4(v.x * g.alpha + b.x, v.y * g.alpha + b.y, v.z * g.alpha + b.z, v.w * g.alpha + b.w));
         } else if constexpr (EPI == EPI_F32_RESID) {
-            const float4 r = sd.r[u];
+            float4 r = sd.r[u];
+            if constexpr (SM >= 2) {      // split-plane residual: sd.r holds the raw plane words (v3_side_load)
+                {
+                    const unsigned h0 = __float_as_uint(r.x), h1 = __float_as_uint(r.y), l0 = __float_as_uint(r.z), l1 = __float_as_uint(r.w);
+                    if constexpr (SM == 3)
+                        r = make_float4(lo8_decode(h2f((bf16_t)(h0 & 0xFFFF)), l0 & 0xFF), lo8_decode(h2f((bf16_t)(h0 >> 16)), (l0 >> 8) & 0xFF),
+                                        lo8_decode(h2f((bf16_t)(h1 & 0xFFFF)), (l0 >> 16) & 0xFF), lo8_decode(h2f((bf16_t)(h1 >> 16)), l0 >> 24));
+                    else
+                        r = make_float4(h2f((bf16_t)(h0 & 0xFFFF)) + h2f((bf16_t)(l0 & 0xFFFF)), h2f((bf16_t)(h0 >> 16)) + h2f((bf16_t)(l0 >> 16)),
+                                        h2f((bf16_t)(h1 & 0xFFFF)) + h2f((bf16_t)(l1 & 0xFFFF)), h2f((bf16_t)(h1 >> 16)) + h2f((bf16_t)(l1 >> 16)));
+                }
+            }
+            if constexpr (SM >= 2) asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));      // (the decoded value is ONE operand: no re-association into it)
+#ifdef ABL_NO_SIDE
+            r = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
             const float4 x = make_float4(r.x + v.x + b.x, r.y + v.y + b.y, r.z + v.z + b.z, r.w + v.w + b.w);
-            if constexpr (!LNP) v3_st<float4>(g.outF + o, x);
-            if constexpr (LNP) {      // LayerNorm-fold producer: f16 image of the stream + this 64-column slice's (sum, sum of squares) per row
+            if constexpr (SM == 0) v3_st<float4>(g.outF + o, x);
+            if constexpr (SM >= 1) {      // LayerNorm-fold producer: f16 image of the stream + this 64-column slice's (sum, sum of squares) per row
                 uint2 pk; pk.x = pack2<true>(x.x, x.y); pk.y = pack2<true>(x.z, x.w);
-                if (g.out_lo != nullptr) {      // split-plane stream: lo = f16(x - hi)
+#ifdef ABL_NO_LO
+                if (false) {
+#else
+                if (g.out_lo != nullptr && g.lo8) {
+#endif
+                    __builtin_nontemporal_store(lo8_encode4(x.x, x.y, x.z, x.w, pk.x, pk.y), reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(g.out_lo) + o));
+#ifdef ABL_NO_LO
+                } else if (false) {
+#else
+                } else if (g.out_lo != nullptr) {      // split-plane stream: lo = f16(x - hi)
+#endif
                     uint2 pl;
                     pl.x = pack2<true>(x.x - h2f((bf16_t)(pk.x & 0xFFFF)), x.y - h2f((bf16_t)(pk.x >> 16)));
                     pl.y = pack2<true>(x.z - h2f((bf16_t)(pk.y & 0xFFFF)), x.w - h2f((bf16_t)(pk.y >> 16)));
@@ -702,11 +768,15 @@ __device__ __forceinline__ void v3_store_batch(const GemmArgs& g, const unsigned
                 } else {
                     v3_st<float4>(g.outF + o, x);
                 }
+#ifndef ABL_NO_HI
                 *reinterpret_cast<uint2*>(g.outH + o) = pk;      // (a plain store: the next GEMM reads this image right away)
+#endif
                 // (all 16 lanes of a row take this path together: m is uniform across them)
+#ifndef ABL_NO_STATS
                 const float s1 = row16_sum((x.x + x.y) + (x.z + x.w));
                 const float s2 = row16_sum((x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w));
                 if (c4 == 0) *reinterpret_cast<float2*>(g.rowpart + ((size_t)m * (g.N >> 6) + (n >> 6)) * 2) = make_float2(s1, s2);
+#endif
             }
         } else if constexpr (EPI == EPI_F32_BF16) {
             v = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
@@ -727,6 +797,125 @@ __device__ __forceinline__ void v3_store_batch(const GemmArgs& g, const unsigned
             pk.x = pack2<F16>(v.x * ga.x, v.y * ga.y);
             pk.y = pack2<F16>(v.z * gb.x, v.w * gb.y);
             v3_st<uint2>(g.outH + o, pk);
+        }
+    }
+}
+
+// LayerNorm-fold producer on the split-plane stream with the byte lo plane, planes in -> planes out (every proj / fc2 of a folded run
+// except its first and last): straight from the accumulators, no LDS.  The staged form of this epilogue cost 33-40 us per 256^2 tile
+// against a 14 us K = 768 main loop (tools/producer_ablate.sh: no single part -- residual loads, hi stores, row sums -- was worth more
+// than 4 us of it): ~160 narrow memory instructions (4 / 8 bytes per lane) and ~80 vector instructions per lane and row.  Here a lane
+// owns 16 values of a row (PP_COL order: two runs of 8 columns), so the planes move as 16-byte (hi) / 8-byte (lo) accesses -- 72 memory
+// instructions per wave and tile --, every load is issued before the first store (a load behind a store waits for that store's
+// acknowledgement: the counter retires in order), and the row sums are one 16-value sum per lane + two cross-lane steps.
+template <int RB>
+__device__ __forceinline__ void pp_epilogue_lo8_direct(const GemmArgs& g, f32x4_t (&acc)[8][4], int mb, int nb, int lane) {
+    const int lq = lane >> 4;
+    int lrow = lane & 15;
+    asm volatile("" : "+v"(lrow));      // (see PPSinkRows: keeps the per-lane addresses out of the persistent loop's live registers)
+    const unsigned char* lo_in = reinterpret_cast<const unsigned char*>(g.res_lo);
+    unsigned char* lo_out = reinterpret_cast<unsigned char*>(g.out_lo);
+    // row blocks in four groups of two: two groups are requested before any store, the next one each time a group has been computed --
+    // its loads queue behind that group's stores, one group of arithmetic ahead of their use -- into the registers it vacated
+    // (128 accumulators leave room for two groups in flight)
+    constexpr int NG = (RB + 1) / 2;
+    u32x4_t hw[NG][2][2];
+    u32x2_t lw[NG][2][2];
+    const int mfirst = mb + lrow;
+    auto side = [&](int i, u32x4_t (&hw)[2], u32x2_t (&lw)[2]) {
+        const int m = mfirst + 16 * i;
+        const size_t o = (size_t)(m < g.M ? m : g.M - 1) * g.ldc + nb + 8 * lq;
+#ifdef ABL_NO_SIDE
+        hw[0] = hw[1] = u32x4_t{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; lw[0] = lw[1] = u32x2_t{(unsigned)o, 0x80808080u}; return;
+#endif
+        hw[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(g.auxH + o));
+        hw[1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(g.auxH + o + 32));
+        lw[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(lo_in + o));
+        lw[1] = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(lo_in + o + 32));
+    };
+    float bv[4][4];
+    pp_col_consts(bv, g.bias != nullptr ? g.bias + nb : nullptr, nullptr, lq);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) side(i, hw[0][i], lw[0][i]);
+    // bias into the accumulators while the first half's rows are in flight; its registers are free before the second half is requested
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{acc[i][j][0] + bv[j][0], acc[i][j][1] + bv[j][1], acc[i][j][2] + bv[j][2], acc[i][j][3] + bv[j][3]};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) side(2 + i, hw[1][i], lw[1][i]);
+    const bool lo = lrow < 8;
+    const int r8 = lrow & 7;
+    const size_t ocol = (size_t)nb + 32 * (lrow >> 3) + 8 * lq;
+    auto row_block = [&](int i, const u32x4_t (&hw)[2], const u32x2_t (&lw)[2]) {
+        uint4 oh[2];
+        uint2 ol[2];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned hword = hw[k][e >> 1], lword = lw[k][e >> 2];
+                const float hf = h2f((bf16_t)((e & 1) ? (hword >> 16) : (hword & 0xFFFF)));
+                float r = lo8_decode(hf, (lword >> (8 * (e & 3))) & 0xFF);
+                asm volatile("" : "+v"(r));      // (the decoded value is ONE operand, as in the staged form)
+                x[e] = r + acc[i][2 * k + (e >> 2)][e & 3];
+                s1 += x[e];
+                s2 = __builtin_fmaf(x[e], x[e], s2);
+            }
+            oh[k] = make_uint4(pack2<true>(x[0], x[1]), pack2<true>(x[2], x[3]), pack2<true>(x[4], x[5]), pack2<true>(x[6], x[7]));
+#ifdef ABL_NO_LO
+            ol[k] = make_uint2(oh[k].x, oh[k].y);
+#else
+            ol[k] = make_uint2(lo8_encode4(x[0], x[1], x[2], x[3], oh[k].x, oh[k].y), lo8_encode4(x[4], x[5], x[6], x[7], oh[k].z, oh[k].w));
+#endif
+        }
+        // this 64-column slice's (sum, sum of squares) of row 16 i + l15: the four lane groups hold 16 columns each
+#ifndef ABL_NO_STATS
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        const int mrow = mfirst + 16 * i;
+        if (lq == 0 && mrow < g.M) *reinterpret_cast<float2*>(g.rowpart + ((size_t)mrow * (g.N >> 6) + (nb >> 6)) * 2) = make_float2(s1, s2);
+#else
+        if (s1 + s2 == 12345.678f) g.rowpart[0] = s1;
+#endif
+        // lane pairs swap one half each: stores of whole 128-byte (hi) / 64-byte (lo) row segments, rows 16 i + r8 and 16 i + 8 + r8
+        pp_pair_swap(oh[0], oh[1], lo);
+        {
+            const unsigned rx = pp_ror8(lo ? ol[1].x : ol[0].x), ry = pp_ror8(lo ? ol[1].y : ol[0].y);
+            ol[0] = make_uint2(lo ? ol[0].x : rx, lo ? ol[0].y : ry);
+            ol[1] = make_uint2(lo ? rx : ol[1].x, lo ? ry : ol[1].y);
+        }
+#ifdef ABL_NO_ST
+        const int mA = (oh[0].x ^ oh[1].y ^ ol[0].x ^ ol[1].y) == 0x12345u ? mb + 16 * i + r8 : g.M;
+#else
+        const int mA = mb + 16 * i + r8;
+#endif
+        if (mA < g.M) {
+            const size_t o = (size_t)mA * g.ldc + ocol;
+            *reinterpret_cast<uint4*>(g.outH + o) = oh[0];      // (a plain store: the next GEMM reads this image right away)
+#ifndef ABL_NO_LO
+            v3_st<uint2>(lo_out + o, ol[0]);
+#endif
+        }
+        if (mA + 8 < g.M) {
+            const size_t o = (size_t)(mA + 8) * g.ldc + ocol;
+            *reinterpret_cast<uint4*>(g.outH + o) = oh[1];
+#ifndef ABL_NO_LO
+            v3_st<uint2>(lo_out + o, ol[1]);
+#endif
+        }
+    };
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (2 * gi + i < RB) row_block(2 * gi + i, hw[gi][i], lw[gi][i]);
+        if (gi + 2 < NG) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (2 * (gi + 2) + i < RB) side(2 * (gi + 2) + i, hw[gi + 2][i], lw[gi + 2][i]);
         }
     }
 }
@@ -754,7 +943,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
                                             unsigned char* wl, int mb, int nb, int lane, unsigned long long* gxt = nullptr) {
     // mb = first row of this wave's 128 x 64 sub-tile, nb = its first column
     constexpr bool GB = GBM == 1;   // 1: row-group bias, 2: two-term weights (plain epilogue), 3: folded LayerNorm (producer / consumer by EPI)
-    constexpr bool LN = GBM == 3;
+    constexpr bool LN = GBM == 3 || (GBM >= 5 && GBM <= 7);      // (5: producer reading f16 + f16 planes; 6 / 7: f16 + byte planes, writing planes / fp32)
     constexpr bool ROWS_ONLY = GBM >= 3;      // head-split epilogue: row-major q / k / v only (3: folded LayerNorm, 4: the plain encoder form)
     const int l15 = lane & 15, lq = lane >> 4;
     if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU) {
@@ -893,6 +1082,10 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
         }
         return;
     }
+    if constexpr (EPI == EPI_F32_RESID && GBM == 6) {      // byte planes in -> byte planes out: straight from the accumulators
+        pp_epilogue_lo8_direct<RB>(g, const_cast<f32x4_t (&)[8][4]>(acc), mb, nb, lane);
+        return;
+    }
     // fp32-staged epilogues (two passes of 64 rows): EPI_F32, EPI_F32_RESID, EPI_F32_BF16, EPI_GELU32, EPI_DGELU
     // 16 lanes x 16 B = one 256-B fp32 row; the lane's 4 columns (and so its bias) are the same for every row.  Four batches
     // of 8 rows-per-lane; the residual / saved pre-activation of batch k+1 is requested before batch k is stored, so its
@@ -909,20 +1102,25 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
         b = make_float4(b.x + xa.x, b.y + xa.y, b.z + xa.z, b.w + xa.w);
     }
     const int mend = mb + 16 * RB;
+    // (the producer's residual form is part of the kernel variant: GBM 3 = fp32, 5 = f16 + f16 planes, 6 = f16 + byte planes -- see v3_side_load)
+    constexpr int SM = (LN && EPI == EPI_F32_RESID) ? (GBM >= 6 ? 3 : (GBM == 5 ? 2 : 1)) : 0;
+#ifdef ABL_NO_EPI
+    if constexpr (SM >= 2) return;
+#endif
     V3Side<EPI> s0, s1;
-    v3_side_load<EPI, LN && EPI == EPI_F32_RESID>(s0, g, mb, n, lane);
+    v3_side_load<EPI, SM>(s0, g, mb, n, lane);
     pp_stage32<RB, true>(wl, acc, 0, l15, lq);
     __builtin_amdgcn_wave_barrier();
-    v3_side_load<EPI, LN && EPI == EPI_F32_RESID>(s1, g, mb + 32, n, lane);
-    v3_store_batch<EPI, F16, LN && EPI == EPI_F32_RESID>(g, wl, s0, b, mb, 0, n, c4, lane, bB, mbnd, mend);
-    v3_side_load<EPI, LN && EPI == EPI_F32_RESID>(s0, g, mb + 64, n, lane);
-    v3_store_batch<EPI, F16, LN && EPI == EPI_F32_RESID>(g, wl, s1, b, mb + 32, 32, n, c4, lane, bB, mbnd, mend);
+    v3_side_load<EPI, SM>(s1, g, mb + 32, n, lane);
+    v3_store_batch<EPI, F16, SM>(g, wl, s0, b, mb, 0, n, c4, lane, bB, mbnd, mend);
+    v3_side_load<EPI, SM>(s0, g, mb + 64, n, lane);
+    v3_store_batch<EPI, F16, SM>(g, wl, s1, b, mb + 32, 32, n, c4, lane, bB, mbnd, mend);
     __builtin_amdgcn_wave_barrier();
     pp_stage32<RB, true>(wl, acc, 1, l15, lq);
     __builtin_amdgcn_wave_barrier();
-    v3_side_load<EPI, LN && EPI == EPI_F32_RESID>(s1, g, mb + 96, n, lane);
-    v3_store_batch<EPI, F16, LN && EPI == EPI_F32_RESID>(g, wl, s0, b, mb + 64, 0, n, c4, lane, bB, mbnd, mend);
-    v3_store_batch<EPI, F16, LN && EPI == EPI_F32_RESID>(g, wl, s1, b, mb + 96, 32, n, c4, lane, bB, mbnd, mend);
+    v3_side_load<EPI, SM>(s1, g, mb + 96, n, lane);
+    v3_store_batch<EPI, F16, SM>(g, wl, s0, b, mb + 64, 0, n, c4, lane, bB, mbnd, mend);
+    v3_store_batch<EPI, F16, SM>(g, wl, s1, b, mb + 96, 32, n, c4, lane, bB, mbnd, mend);
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -953,9 +1151,12 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     // one launch per tile: 1.6 us between the last store of a workgroup and the first instruction of the next one on that CU plus
     // 0.5 us of kernel-argument / address setup (tools/epi_gaps.py) against a 17 us K = 768 main loop.
     const int tstep = g.persist ? (int)gridDim.x : nwg;
-    if (g.stagger > 0 && ((blockIdx.x >> 3) & 1)) {
+    if (g.stagger > 0) {
+        // (stagger >> 16 = number of phase groups P, default 2; workgroup i of an XCD starts (i mod P) / P * ticks late)
+        const int P = (g.stagger >> 16) ? (g.stagger >> 16) : 2, ticks = g.stagger & 0xFFFF;
+        const unsigned long long dly = (unsigned long long)(((blockIdx.x >> 3) % P) * ticks / P) * (P == 2 ? 2 : 1);
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)g.stagger) __builtin_amdgcn_s_sleep(16);
+        while (__builtin_amdgcn_s_memrealtime() - t0 < dly) __builtin_amdgcn_s_sleep(16);
     }
     // Dynamic walk (g.tile_ctr): the logical tiles tl with tl & 7 == x are XCD x's contiguous range (xcd_remap); index k of that range
     // comes from the per-XCD counter.  The counter for tile i + 1 is read at the top of tile i (one lane) and handed to the other waves
@@ -968,13 +1169,23 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
         __syncthreads();
         tl = __builtin_amdgcn_readfirstlane(s_next_tile) * 8 + (blockIdx.x & 7);
     }
+    // Epilogues that store straight from the accumulators leave the LDS alone: the next tile's first operand stage is requested BEFORE
+    // the epilogue (its DMA lands under the stores) and the end-of-tile workgroup barrier goes away.
+    constexpr bool DIRECT_EPI = (EPI == EPI_BF16 || EPI == EPI_GELU || (EPI == EPI_QKV && GB >= 3));
+    auto tile_mn = [&](int tl_, int& m0_, int& n0_) {
+        const int t = xcd_remap(tl_, nwg);
+        const int GM = g.group_m;
+        const int group_size = GM * ntn, gid = t / group_size, first_m = gid * GM;
+        const int gm = (ntm - first_m) < GM ? (ntm - first_m) : GM;
+        const int tin = t - gid * group_size;
+        m0_ = (first_m + tin % gm) * TM;
+        n0_ = (tin / gm) * V3_T;
+    };
+    bool primed = false;      // this tile's K-tile-0 DMA was issued by the previous tile
+    int m0n = 0, n0n = 0;
     while (tl < nwg) {
-    const int t = xcd_remap(tl, nwg);
-    const int GM = g.group_m;
-    const int group_size = GM * ntn, gid = t / group_size, first_m = gid * GM;
-    const int gm = (ntm - first_m) < GM ? (ntm - first_m) : GM;
-    const int tin = t - gid * group_size;
-    const int m0 = (first_m + tin % gm) * TM, n0 = (tin / gm) * V3_T;
+    int m0, n0;
+    if (primed) { m0 = m0n; n0 = n0n; } else tile_mn(tl, m0, n0);
     const int nk = g.K / BK;
 
     const int rows_a = (g.M - m0) < TM ? (g.M - m0) : TM;
@@ -1002,13 +1213,14 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
             ld_[sl][e] = (is_b ? 65536 : 0) + rows[sl] * 128;
         }
     }
-#define PP_DMA(SL, KT)                                                                                                    \
+#define PP_DMA_R(RA_, RB_, SL, KT)                                                                                        \
     {                                                                                                                     \
         const int kt_ = (GB == 2 && (KT) >= g.k_wrap) ? (((SL) == 0 || (SL) == 3) ? (KT) - g.k_wrap : (KT) + g.b_skip) : (KT); \
         const int so_ = kt_ * (BK * 2), st_ = ((KT) & 1) << 15;                                                           \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? rb : ra, (lds_ptr_t)(lds3 + st_ + ld_[SL][0]), 16, vo[SL][0], so_, 0, 0); \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? rb : ra, (lds_ptr_t)(lds3 + st_ + ld_[SL][1]), 16, vo[SL][1], so_, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? RB_ : RA_, (lds_ptr_t)(lds3 + st_ + ld_[SL][0]), 16, vo[SL][0], so_, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? RB_ : RA_, (lds_ptr_t)(lds3 + st_ + ld_[SL][1]), 16, vo[SL][1], so_, 0, 0); \
     }
+#define PP_DMA(SL, KT) PP_DMA_R(ra, rb, SL, KT)
     f32x4_t acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -1074,7 +1286,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     // prologue: all of tile 0; then the three slots of tile 1 that the steady state would have issued during tile -1
     int dyn_nxt = 0;
     if (dyn_ctr != nullptr && tid == 0) dyn_nxt = atomicAdd(dyn_ctr, 1);     // next tile's index: returns under the prologue's DMA
-    PP_DMA(1, 0) PP_DMA(0, 0) PP_DMA(2, 0) PP_DMA(3, 0)
+    if (!primed) { PP_DMA(1, 0) PP_DMA(0, 0) PP_DMA(2, 0) PP_DMA(3, 0) }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (dyn_ctr != nullptr && tid == 0) s_next_tile = dyn_nxt;     // (everybody read the previous value before this barrier; read again after the tile's last one)
@@ -1091,7 +1303,22 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     GX_STAMP(2)
     if (wm == 0) __builtin_amdgcn_s_barrier();   // pairs with the last barrier of waves 4-7: nobody reads the stages any more
     GX_STAMP(3)
+    // next tile (the K loop's last barrier is behind every wave: the operand stages are free and s_next_tile holds the next index)
+    int tl_next = tl + tstep;
+    primed = false;
+    if constexpr (DIRECT_EPI) {
+        if (dyn_ctr != nullptr) tl_next = __builtin_amdgcn_readfirstlane(s_next_tile) * 8 + (blockIdx.x & 7);
+        if (tl_next < nwg) {
+            tile_mn(tl_next, m0n, n0n);
+            const int rows_n = (g.M - m0n) < TM ? (g.M - m0n) : TM;
+            const __amdgpu_buffer_rsrc_t ran = __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)m0n * g.lda), 0, rows_n * g.lda * 2, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rbn = __builtin_amdgcn_make_buffer_rsrc((void*)(g.B + (size_t)n0n * g.ldb), 0, V3_T * g.ldb * 2, 0x00020000);
+            PP_DMA_R(ran, rbn, 1, 0) PP_DMA_R(ran, rbn, 0, 0) PP_DMA_R(ran, rbn, 2, 0) PP_DMA_R(ran, rbn, 3, 0)
+            primed = true;
+        }
+    }
 #undef PP_DMA
+#undef PP_DMA_R
 #undef PP_RD_A
 #undef PP_RD_B
 #undef PP_MFMA
@@ -1122,7 +1349,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
 #else
     pp_epilogue<EPI, F16, GB, RB>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * (16 * RB), n0 + wn * 64, lane);
 #endif
-    if (dyn_ctr != nullptr) {
+    if constexpr (DIRECT_EPI) {
+        tl = tl_next;                        // (no barrier: nothing of this tile is left in the LDS)
+    } else if (dyn_ctr != nullptr) {
         __syncthreads();                     // (also orders the epilogue's staging reads before the next tile's DMA)
         tl = __builtin_amdgcn_readfirstlane(s_next_tile) * 8 + (blockIdx.x & 7);
     } else {
@@ -1589,6 +1818,8 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
         {
             const char* st_s = getenv("SED_GEMM_STAGGER");      // experiment: start delay of every other workgroup, in 10 ns ticks
             gg.stagger = (gg.persist && st_s) ? atoi(st_s) : 0;
+            const char* sp_s = getenv("SED_GEMM_STAGGER_PHASES");
+            if (gg.stagger > 0 && sp_s) gg.stagger = (gg.stagger & 0xFFFF) | (atoi(sp_s) << 16);
         }
         const GemmArgs& g = gg;
         if (g.rowpart != nullptr || g.rowstat != nullptr) {
@@ -1598,14 +1829,21 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
                 if (!f16 || g.gbias != nullptr || g.k_wrap != 0 || (g.N & 63)) return SED_ERR_ARG;
                 if (producer ? (g.rowpart == nullptr || g.outH == nullptr || g.rowstat != nullptr)
                              : (g.rowstat == nullptr || g.colS == nullptr || g.rowpart != nullptr)) return SED_ERR_ARG;
-                static bool attrl[2] = {false, false};
-                if (use7) {
-                    if (!attrl[0]) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true, 3, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attrl[0] = true; }
-                    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true, 3, 7>), grid3, dim3(512), V3_LDS, s, g);
-                } else {
-                    if (!attrl[1]) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true, 3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attrl[1] = true; }
-                    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true, 3, 8>), grid3, dim3(512), V3_LDS, s, g);
+                static bool attrl[8] = {false, false, false, false, false, false, false, false};
+#define PP_LN_LAUNCH(GBV, RBV, SLOT)                                                                                     \
+                {                                                                                                         \
+                    if (!attrl[SLOT]) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true, GBV, RBV>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attrl[SLOT] = true; } \
+                    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true, GBV, RBV>), grid3, dim3(512), V3_LDS, s, g);          \
                 }
+                if constexpr (producer) {
+                    if (g.res_lo != nullptr && g.lo8 && g.out_lo != nullptr) { if (use7) PP_LN_LAUNCH(6, 7, 4) else PP_LN_LAUNCH(6, 8, 5) }
+                    else if (g.res_lo != nullptr && g.lo8) { if (use7) PP_LN_LAUNCH(7, 7, 6) else PP_LN_LAUNCH(7, 8, 7) }
+                    else if (g.res_lo != nullptr) { if (use7) PP_LN_LAUNCH(5, 7, 2) else PP_LN_LAUNCH(5, 8, 3) }
+                    else { if (use7) PP_LN_LAUNCH(3, 7, 0) else PP_LN_LAUNCH(3, 8, 1) }
+                } else {
+                    if (use7) PP_LN_LAUNCH(3, 7, 0) else PP_LN_LAUNCH(3, 8, 1)
+                }
+#undef PP_LN_LAUNCH
                 return sed_check_launch();
             } else {
                 return SED_ERR_ARG;
@@ -1723,9 +1961,9 @@ extern "C" int sed_gemm_nt_w2(const void* A, const void* B, int M, int N, int K,
 // (per-row partial sum / sum of squares of each 64-column slice); sed_ln_fold_stats turns rowpart into rowstat [M][2] = (mean, rstd);
 // consumer = EPI_GELU GEMM whose A operand is x16 (the RAW stream), B the f16 image of gamma (.) W (sed_ln_fold_weight), with
 // out[m, n] = act(rstd[m] * (acc - mean[m] * colS[n]) + colC[n]).
-extern "C" int sed_gemm_nt_lnp(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* bias, const float* resF,
-                               const void* res_hi, const void* res_lo, float* outF, void* x16, void* out_lo, float* rowpart, int ldc,
-                               hipStream_t stream) {
+static int gemm_nt_lnp_impl(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* bias, const float* resF,
+                            const void* res_hi, const void* res_lo, float* outF, void* x16, void* out_lo, float* rowpart, int ldc, int lo8,
+                            hipStream_t stream) {
     (void)hipGetLastError();
     if (N % 256 || M < 1024 || K % BK || x16 == nullptr || rowpart == nullptr || ldc != N) return SED_ERR_ARG;
     // residual: fp32 resF, or the planes res_hi + res_lo; result: fp32 outF + f16 image x16, or the planes x16 (hi) + out_lo
@@ -1734,8 +1972,19 @@ extern "C" int sed_gemm_nt_lnp(const void* A, const void* B, int M, int N, int K
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.ncols = N;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ksplit = 1; g.alpha = 1.f;
     g.bias = bias; g.resF = resF; g.outF = outF; g.outH = (bf16_t*)x16; g.rowpart = rowpart;
-    g.auxH = (const bf16_t*)res_hi; g.res_lo = (const bf16_t*)res_lo; g.out_lo = (bf16_t*)out_lo;
+    g.auxH = (const bf16_t*)res_hi; g.res_lo = (const bf16_t*)res_lo; g.out_lo = (bf16_t*)out_lo; g.lo8 = lo8;
     return launch_gemm<EPI_F32_RESID>(g, 1, stream);
+}
+extern "C" int sed_gemm_nt_lnp(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* bias, const float* resF,
+                               const void* res_hi, const void* res_lo, float* outF, void* x16, void* out_lo, float* rowpart, int ldc,
+                               hipStream_t stream) {
+    return gemm_nt_lnp_impl(A, B, M, N, K, lda, ldb, bias, resF, res_hi, res_lo, outF, x16, out_lo, rowpart, ldc, 0, stream);
+}
+// ... with the lo plane as bytes (GemmArgs.lo8): res_lo / out_lo are [M][ldc] uint8
+extern "C" int sed_gemm_nt_lnp8(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* bias, const float* resF,
+                                const void* res_hi, const void* res_lo8, float* outF, void* x16, void* out_lo8, float* rowpart, int ldc,
+                                hipStream_t stream) {
+    return gemm_nt_lnp_impl(A, B, M, N, K, lda, ldb, bias, resF, res_hi, res_lo8, outF, x16, out_lo8, rowpart, ldc, 1, stream);
 }
 extern "C" int sed_gemm_nt_lnc(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* colC, const float* colS,
                                const float* rowstat, void* outH2, int ldc, hipStream_t stream) {

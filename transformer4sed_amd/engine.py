@@ -93,7 +93,11 @@ class SedEngine:
         self.relpos_stream = os.environ.get("SED_RELPOS_DKDV", "stream") != "recompute"
         self.ln_fold = os.environ.get("SED_LN_FOLD", "1") != "0"
         self.ln_bwd16 = os.environ.get("SED_LN_BWD16", "1") != "0"
-        self.ln_planes = os.environ.get("SED_LN_PLANES", "1") != "0"      # folded blocks: residual stream as two f16 planes between producers
+        # folded blocks: residual stream as two planes between producers -- "8" (default): f16 hi + 8-bit lo (6 bytes per element through a
+        # producer, the stream to ~2^-19), "1": f16 hi + f16 lo (8 bytes), "0": fp32 stream + f16 image (10 bytes)
+        self.ln_planes = os.environ.get("SED_LN_PLANES", "8")
+        self.ln_lo8 = self.ln_planes == "8"
+        self.ln_planes = self.ln_planes != "0"
         # Context-network GEMMs that do not need all three split-precision terms (tools/err_sim.py SIM_DEC_TERMS=1: logit error of the whole
         # decoder 3.96e-4 with three terms everywhere): in_proj without the activation's lo part (5.4e-4; the weight's lo part is the one that
         # matters there: 1.9e-3 without it) -> two K passes instead of three on the largest decoder GEMM, and its LayerNorm writes a plain f16
@@ -344,7 +348,8 @@ class SedEngine:
         if fold_ok:
             # between folded blocks the residual stream lives as two f16 planes (x16f = hi, which is also the consumers' A operand, + xlo)
             # instead of fp32: a producer then moves 8 bytes per element instead of 10 (csrc/gemm.hip, GemmArgs.res_lo / out_lo)
-            x16f, xlo, partf, statf = E(M, D, dt=F16), E(M, D, dt=F16), E(M, D // 64, 2), E(M, 2)
+            x16f, xlo, partf, statf = E(M, D, dt=F16), E(M, D, dt=torch.uint8 if self.ln_lo8 else F16), E(M, D // 64, 2), E(M, 2)
+            lnp = "sed_gemm_nt_lnp8" if self.ln_lo8 else "sed_gemm_nt_lnp"
         planes = False              # the current stream value is in (x16f, xlo) rather than in the fp32 tensor
         for li in range(m.depth):
             p = f"backbone.blocks.{li}."
@@ -379,7 +384,7 @@ class SedEngine:
                          v, None, None, None, None, None, None, None, f16)
                 call("sed_mhsa_fwd", q, k, v, o16, lse, Bx, H, N, Npad, f16)
                 sp = self.ln_planes
-                call("sed_gemm_nt_lnp", o16, W[p + "attn.proj.weight"].w, M, D, D, D, D, self.P(p + "attn.proj.bias"),
+                call(lnp, o16, W[p + "attn.proj.weight"].w, M, D, D, D, D, self.P(p + "attn.proj.bias"),
                      None if planes else x_in, x16f if planes else None, xlo if planes else None,
                      None if sp else x_in, x16f, xlo if sp else None, partf, D)
                 planes = sp
@@ -391,7 +396,7 @@ class SedEngine:
                 if last and not planes:
                     gemm_nt(act, W[p + "mlp.fc2.weight"].w, EPI_F32_RESID, bias=self.P(p + "mlp.fc2.bias"), res=x_in, outF=x_in)
                 else:
-                    call("sed_gemm_nt_lnp", act, W[p + "mlp.fc2.weight"].w, M, D, 4 * D, 4 * D, 4 * D, self.P(p + "mlp.fc2.bias"),
+                    call(lnp, act, W[p + "mlp.fc2.weight"].w, M, D, 4 * D, 4 * D, 4 * D, self.P(p + "mlp.fc2.bias"),
                          None if planes else x_in, x16f if planes else None, xlo if planes else None,
                          x_in if f32_out else None, x16f, None if f32_out else xlo, partf, D)
                     planes = not f32_out

@@ -159,7 +159,7 @@ class plain_precision:
 
 
 def _flops_of(name, args):
-    if name in ("sed_gemm_nt", "sed_gemm_nt_gb", "sed_gemm_nt_w2", "sed_gemm_nt_lnp", "sed_gemm_nt_lnc"):       # (w2: the logical 2 M N K, half of the MFMA FLOPs issued)
+    if name in ("sed_gemm_nt", "sed_gemm_nt_gb", "sed_gemm_nt_w2", "sed_gemm_nt_lnp", "sed_gemm_nt_lnp8", "sed_gemm_nt_lnc"):       # (w2: the logical 2 M N K, half of the MFMA FLOPs issued)
         return 2.0 * args[2] * args[3] * args[4]
     if name == "sed_gemm_qkv_lnc":
         return 2.0 * args[5] * args[6] * (3 * args[7] * 64)
@@ -178,8 +178,8 @@ def _shape_of(name, args):
         return (args[3], 3 * args[5] * 64, args[4], "qkv3" + name[-2:])
     if name == "sed_gemm_nt_w2":
         return (args[2], args[3], args[4], "epi%dw2" % args[7])
-    if name in ("sed_gemm_nt_lnp", "sed_gemm_nt_lnc"):
-        return (args[2], args[3], args[4], "epi1lnp" if name.endswith("p") else "epi3lnc")
+    if name in ("sed_gemm_nt_lnp", "sed_gemm_nt_lnp8", "sed_gemm_nt_lnc"):
+        return (args[2], args[3], args[4], "epi3lnc" if name.endswith("c") else "epi1lnp")
     if name == "sed_gemm_qkv_lnc":
         return (args[5], 3 * args[7] * 64, args[6], "qkv3lnc")
     if name in ("sed_gemm_qkv", "sed_gemm_qkv_w2s"):
@@ -194,9 +194,11 @@ def _bytes_of(name, args):
     if name in ("sed_gemm_qkv_gb", "sed_gemm_qkv_w2"):
         M, K, D = args[3], args[4], args[5] * 64
         return 2.0 * K * (M + 3 * D * (2 if name.endswith("w2") else 1)) + 2.0 * M * D * 3
-    if name == "sed_gemm_nt_lnp":      # operands + the residual read (4 B either way) + fp32 and f16 image (6 B) or the two f16 planes (4 B)
+    if name in ("sed_gemm_nt_lnp", "sed_gemm_nt_lnp8"):
+        # operands + the residual read (fp32 4 B / f16 planes 4 B / f16 + byte planes 3 B) + fp32 and f16 image (6 B) or the two planes (4 B / 3 B)
         M, N, K = args[2], args[3], args[4]
-        return 2.0 * K * (M + N) + (8.0 if args[13] is not None else 10.0) * M * N
+        pl = 3.0 if name.endswith("8") else 4.0
+        return 2.0 * K * (M + N) + ((pl if args[10] is not None else 4.0) + (pl if args[13] is not None else 6.0)) * M * N
     if name == "sed_gemm_nt_lnc":
         M, N, K = args[2], args[3], args[4]
         return 2.0 * K * (M + N) + 2.0 * M * N
