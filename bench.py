@@ -98,7 +98,7 @@ GFLOP_PER_BATCH = 21.22       # batch-shared linear_pos GEMMs (b-term)
 GFLOP_SKIPPED = {"finetune2": 211.5, "val": 654.3}
 PEAK_BF16_TFLOPS = 2500.0     # dense 16-bit MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0         # HBM3E peak, MI355X_MICROARCH.md
-GEMM_KERNELS = ["sed_gemm_nt", "sed_gemm_qkv", "sed_gemm_qkv_w2s", "sed_gemm_dw_tn", "sed_gemm_nt_gb", "sed_gemm_qkv_gb", "sed_gemm_nt_w2", "sed_gemm_qkv_w2", "sed_gemm_nt_lnp", "sed_gemm_nt_lnp8", "sed_gemm_nt_lnc", "sed_gemm_qkv_lnc"]
+GEMM_KERNELS = ["sed_gemm_nt", "sed_gemm_qkv", "sed_gemm_qkv_w2s", "sed_gemm_dw_tn", "sed_gemm_nt_gb", "sed_gemm_qkv_gb", "sed_gemm_nt_w2", "sed_gemm_qkv_w2", "sed_gemm_nt_lnp", "sed_gemm_nt_lnp8", "sed_gemm_nt_lnc", "sed_gemm_qkv_lnc", "sed_gemm_nt_lnc8", "sed_gemm_qkv_lnc8"]
 
 
 def build(per_gpu_batch, depth, device, mode="finetune2"):

@@ -121,12 +121,20 @@ int sed_gemm_nt_lnp(const void* A, const void* B, int M, int N, int K, int lda, 
 /* (sed_gemm_nt_lnp, split-plane stream: between two folded blocks the residual stream can live as two f16 planes hi + lo instead of fp32
  *  -- res_hi / res_lo != NULL: the residual is read as hi + lo instead of resF; out_lo != NULL: the result is written as x16 (hi) + out_lo
  *  and outF is left alone.  The hi plane is the next GEMM's A operand, so a producer moves 8 instead of 10 bytes per element.) */
-/* (sed_gemm_nt_lnp8: the same with the lo plane as BYTES -- res_lo8 / out_lo8 are [M][ldc] uint8 and the stream value is
+/* (sed_gemm_nt_lnp8: the same with the lo plane as BYTES -- res_lo8 / out_lo8 are M * ldc uint8 in slab-major order [ldc / 64][M][64]
+ *  (a plane private to this entry point: written and read only here) and the stream value is
  *  hi * (1 + (q - 128) * 2^-18): the f16 rounding residual (at most |hi| 2^-11) in 256 steps, the stream to ~2^-19 relative.  A producer
  *  then moves 6 bytes per element.  Planes written by one entry point must be read by the same one.) */
 int sed_gemm_nt_lnp8(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* bias, const float* resF,
                      const void* res_hi, const void* res_lo8, float* outF, void* x16, void* out_lo8, float* rowpart, int ldc,
                      hipStream_t stream);
+/* (with sed_gemm_nt_lnp8 the hi plane -- res_hi in, x16 out -- is slab-major too, [ldc / 64][M][64] f16: a K tile of the consumer and a
+ *  wave's patch of the producer are contiguous runs.  sed_gemm_nt_lnc8 / sed_gemm_qkv_lnc8 are the consumers that read it: same
+ *  arguments as sed_gemm_nt_lnc / sed_gemm_qkv_lnc, lda = K.) */
+int sed_gemm_nt_lnc8(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* colC, const float* colS,
+                     const float* rowstat, void* outH2, int ldc, hipStream_t stream);
+int sed_gemm_qkv_lnc8(const void* A, const void* W, const float* colC, const float* colS, const float* rowstat, int M, int K, int heads,
+                      int seq, int seq_pad, void* q, void* k, void* v, hipStream_t stream);
 int sed_ln_fold_stats(const float* rowpart, float* rowstat, int M, int S, int D, float eps, hipStream_t stream);
 int sed_ln_fold_weight(const float* W, const float* gamma, const float* beta, const float* bias, void* W16, float* colS, float* colC,
                        int N, int K, hipStream_t stream);

@@ -306,9 +306,11 @@ def test_gemm_layernorm_fold():
     assert maxerr(back, x2) < 1e-6 * float(x2.abs().max()) and torch.equal(h3, back.to(F16))
     # ... with the 8-bit lo plane (sed_gemm_nt_lnp8): x = hi (1 + (q - 128) 2^-18), the stream to ~2^-19 relative per element
     lo8 = torch.empty(M, D, dtype=torch.uint8, device=DEV); hi8 = torch.empty(M, D, dtype=F16, device=DEV)
-    dec = lambda h, q: h.float() + (q.float() - 128.0) * h.float() * 2.0 ** -18
+    # (both planes of this entry point are slab-major: [D / 64][M][64])
+    unslab = lambda t: t.view(D // 64, M, 64).permute(1, 0, 2).reshape(M, D)
+    dec = lambda h, q: unslab(h).float() + (unslab(q).float() - 128.0) * unslab(h).float() * 2.0 ** -18
     call("sed_gemm_nt_lnp8", a16, Wp.to(F16), M, D, D, D, D, bp, res, None, None, None, hi8, lo8, part2, D)
-    assert torch.equal(hi8, x16) and torch.equal(part2, part)
+    assert torch.equal(unslab(hi8), x16) and torch.equal(part2, part)
     # (|x| below the f16 normal range: hi is a subnormal with a fixed 2^-24 spacing, the byte cannot express more than 2^-25 absolute)
     # (`big` = magnitude of the terms the value was summed from: two kernels that add them in different orders differ by ~2^-23 of it,
     #  which is not small against a result that cancelled to 1e-3 of its terms)
@@ -318,10 +320,10 @@ def test_gemm_layernorm_fold():
     x3 = torch.empty(M, D, device=DEV)
     gemm_nt(a16, Wp.to(F16), ops.EPI_F32_RESID, bias=bp, res=dec(hi8, lo8), outF=x3)
     call("sed_gemm_nt_lnp8", a16, Wp.to(F16), M, D, D, D, D, bp, None, hi9, lo9, None, hi9, lo9, part2, D)      # planes in -> planes out, in place
-    assert same_f16(hi9, x3) and lo8_ok(hi9, lo9, x3, dec(hi8, lo8))
+    assert same_f16(unslab(hi9), x3) and lo8_ok(hi9, lo9, x3, dec(hi8, lo8))
     part9 = part2.clone()
     call("sed_gemm_nt_lnp8", a16, Wp.to(F16), M, D, D, D, D, bp, None, hi8, lo8, back, h3, None, part2, D)        # planes in -> fp32 out
-    assert maxerr(back, x3) < 1e-6 * float(x3.abs().max()) and torch.equal(h3, back.to(F16))
+    assert maxerr(back, x3) < 1e-6 * float(x3.abs().max()) and torch.equal(unslab(h3), back.to(F16))
     # row statistics of the direct (planes in -> planes out) form against the stream it wrote
     sl9 = x3.view(M, D // 64, 64)
     assert maxerr(part9[:, :, 0], sl9.sum(-1)) < 2e-3 and maxerr(part9[:, :, 1], (sl9 * sl9).sum(-1)) < 2e-3 * float((sl9 * sl9).sum(-1).max())
@@ -343,6 +345,11 @@ def test_gemm_layernorm_fold():
     call("sed_layernorm_fwd", x, gam, bet, 1e-6, 1.0, h16, None, None, None, M, D, 1)
     act0 = torch.empty(M, Hd, dtype=F16, device=DEV)
     gemm_nt(h16, W1.to(F16), ops.EPI_GELU, bias=b1, outH=None, outH2=act0)
+    # the consumers of the slab-major plane are the same GEMMs with another operand addressing: bit-identical outputs
+    x16s = x16.view(M, D // 64, 64).permute(1, 0, 2).contiguous()
+    act8 = torch.empty(M, Hd, dtype=F16, device=DEV)
+    call("sed_gemm_nt_lnc8", x16s, W16, M, Hd, D, D, D, cC, cS, stat, act8, Hd)
+    assert torch.equal(act8, act)
     e_fold, e_plain = maxerr(act.float(), truth), maxerr(act0.float(), truth)
     rms = lambda t: float(((t.double() - truth) ** 2).mean().sqrt())
     report(f"LN fold fc1+GELU: max {e_fold:.2e} (unfolded {e_plain:.2e}), rms {rms(act):.2e} (unfolded {rms(act0):.2e})", e_fold, float(truth.abs().max()))
@@ -355,6 +362,9 @@ def test_gemm_layernorm_fold():
     mk = lambda: torch.empty(2 * Hh, Ntok, 64, dtype=F16, device=DEV)
     q, k, v = mk(), mk(), mk()
     call("sed_gemm_qkv_lnc", x16, Wq16, qC, qS, stat, M, D, Hh, Ntok, pad64(Ntok), q, k, v)
+    q8, k8, v8 = mk(), mk(), mk()
+    call("sed_gemm_qkv_lnc8", x16s, Wq16, qC, qS, stat, M, D, Hh, Ntok, pad64(Ntok), q8, k8, v8)
+    assert torch.equal(q8, q) and torch.equal(k8, k) and torch.equal(v8, v)
     q0, k0, v0 = mk(), mk(), mk()
     call("sed_gemm_qkv", h16, Wq.to(F16), bq, M, D, Hh, Ntok, pad64(Ntok), q0, k0, v0, None, None, None, None, None, None, None, 1)
     tq = (torch.nn.functional.layer_norm(xd, (D,), gam.double(), bet.double(), 1e-6) @ Wq.double().t() + bq.double()).view(2, Ntok, 3, Hh, 64).permute(2, 0, 3, 1, 4)

@@ -25,7 +25,7 @@ M, D = 211904, 768
 x768, x3072 = E(M, D, dt=F16), E(M, 4 * D, dt=F16)
 wproj, wfc2 = E(D, D, dt=F16) * 0.05, E(D, 4 * D, dt=F16) * 0.05
 b768 = E(D)
-x16 = E(M, D, dt=F16); xlo = (E(M, D) * 1e-3).to(F16); xlo8 = torch.randint(0, 255, (M, D), device=dev, dtype=torch.uint8)
+x16 = E(M, D, dt=F16); xlo = (E(M, D) * 1e-3).to(F16); xlo8 = torch.randint(0, 255, (M, D), device=dev, dtype=torch.uint8)      # (lnp8: both planes slab-major -- same bytes, same timing)
 part = torch.empty(M, 12, 2, device=dev)
 out = []
 for name, fn in [("proj  f16 planes", lambda: call("sed_gemm_nt_lnp", x768, wproj, M, D, D, D, D, b768, None, x16, xlo, None, x16, xlo, part, D)),

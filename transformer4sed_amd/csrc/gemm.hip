@@ -84,6 +84,10 @@ struct GemmArgs {
     // q = the byte -- the f16 rounding residual |x - hi| <= ulp(hi) / 2 <= |hi| 2^-11 in steps of |hi| 2^-18, i.e. the stream to ~2^-19
     // relative (the f16 lo plane: ~2^-22; an f16 stream: 2^-12) for 6 instead of 8 bytes per element through a producer.
     int lo8;
+    // ... and with lo8 the hi plane (outH / auxH of the producer) is slab-major as well: [ldc / 64][M][64] f16 -- a wave's 128 rows x 64
+    // columns are one contiguous 16 KB run, and for the consumer GEMMs (a_slab != 0: A is such a plane with K / 64 slabs) a K tile of
+    // 256 rows is one contiguous 32 KB run instead of 256 pieces of 128 bytes, 1536 bytes apart.
+    int a_slab;
     // Persistent 256^2 kernel, dynamic tile walk: 8 per-XCD tile counters + 1 exit counter, one 64-byte line each (int index 16 x).  A
     // workgroup takes the next tile of ITS XCD's contiguous tile range from counter blockIdx.x & 7 (so the L2 grouping of the static walk
     // is kept) instead of the fixed blockIdx.x + k gridDim.x: a workgroup that becomes resident late -- or only after the others have
@@ -628,6 +632,12 @@ __device__ __forceinline__ void pp_stage32(unsigned char* wl, const f32x4_t (&ac
             *reinterpret_cast<float4*>(wl + (ii * 16 + l15) * V3_RS32 + (PERM ? PP_COL(j, lq) : j * 16 + 4 * lq) * 4) = make_float4(a[0], a[1], a[2], a[3]);
         }
 }
+// Byte plane layout: slab-major [N / 64][M][64] -- the 64 bytes of row m in 64-column slab s sit at (s * M + m) * 64, so a wave's
+// 128 rows x 64 columns are ONE contiguous 8 KB run (row-major they are 128 pieces of 64 bytes, 768 bytes apart).  Only the producers
+// touch this plane, so the layout is theirs to choose.
+__device__ __forceinline__ size_t lo8_off(const GemmArgs& g, int m, int n) { return ((size_t)(n >> 6) * g.M + m) * 64 + (n & 63); }
+// element offset of (m, n) in a plane of the producer: slab-major with the byte lo plane (GemmArgs.lo8), row-major otherwise
+__device__ __forceinline__ size_t hi_off(const GemmArgs& g, int m, int n) { return g.lo8 ? lo8_off(g, m, n) : (size_t)m * g.ldc + n; }
 // 8-bit lo plane of the split residual stream (GemmArgs.lo8): x = hi + (q - 128) * hi * 2^-18 = hi * (1 + (q - 128) 2^-18)
 __device__ __forceinline__ float lo8_decode(float hf, unsigned q) {
     return __builtin_fmaf(__builtin_fmaf((float)q, 0x1p-18f, -0x1p-11f), hf, hf);
@@ -670,8 +680,8 @@ __device__ __forceinline__ void v3_side_load(V3Side<EPI>& sd, const GemmArgs& g,
                 for (int u = 0; u < 8; ++u) {
                     const int m = m0 + u * 4 + (lane >> 4);
                     const size_t o = (size_t)(m < g.M ? m : g.M - 1) * g.ldc + n;
-                    const u32x2_t h = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(g.auxH + o));
-                    const unsigned l = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(lo8p + o));
+                    const u32x2_t h = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(g.auxH + lo8_off(g, m < g.M ? m : g.M - 1, n)));
+                    const unsigned l = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(lo8p + lo8_off(g, m < g.M ? m : g.M - 1, n)));
                     sd.r[u] = make_float4(__uint_as_float(h[0]), __uint_as_float(h[1]), __uint_as_float(l), 0.f);
                 }
                 return;
@@ -755,7 +765,7 @@ __device__ __forceinline__ void v3_store_batch(const GemmArgs& g, const unsigned
 #else
                 if (g.out_lo != nullptr && g.lo8) {
 #endif
-                    __builtin_nontemporal_store(lo8_encode4(x.x, x.y, x.z, x.w, pk.x, pk.y), reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(g.out_lo) + o));
+                    __builtin_nontemporal_store(lo8_encode4(x.x, x.y, x.z, x.w, pk.x, pk.y), reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(g.out_lo) + lo8_off(g, m, n)));
 #ifdef ABL_NO_LO
                 } else if (false) {
 #else
@@ -769,7 +779,7 @@ __device__ __forceinline__ void v3_store_batch(const GemmArgs& g, const unsigned
                     v3_st<float4>(g.outF + o, x);
                 }
 #ifndef ABL_NO_HI
-                *reinterpret_cast<uint2*>(g.outH + o) = pk;      // (a plain store: the next GEMM reads this image right away)
+                *reinterpret_cast<uint2*>(g.outH + hi_off(g, m, n)) = pk;      // (a plain store: the next GEMM reads this image right away)
 #endif
                 // (all 16 lanes of a row take this path together: m is uniform across them)
 #ifndef ABL_NO_STATS
@@ -822,16 +832,22 @@ __device__ __forceinline__ void pp_epilogue_lo8_direct(const GemmArgs& g, f32x4_
     u32x4_t hw[NG][2][2];
     u32x2_t lw[NG][2][2];
     const int mfirst = mb + lrow;
+    const bool lo = lrow < 8;
+    const int r8 = lrow & 7;
+    const size_t ocol = (size_t)nb + 32 * (lrow >> 3) + 8 * lq;
+    // Loads in the pair-swapped layout too (rows 16 i + r8 and 16 i + 8 + r8, column half l15 >> 3): an instruction then covers 8 rows x
+    // 128 B of the hi plane / 8 rows x 64 B of the byte plane -- whole lines.  With a lane reading its own row's two halves by two
+    // instructions (16 rows x 64 / 32 B pieces) the launches fetched 1.5x their algorithmic bytes and the byte plane cost as many bytes
+    // as the f16 one (FETCH_SIZE, profiles/r4_producer_epilogue.txt).  pp_pair_swap (an involution) brings a lane's own row back.
     auto side = [&](int i, u32x4_t (&hw)[2], u32x2_t (&lw)[2]) {
-        const int m = mfirst + 16 * i;
-        const size_t o = (size_t)(m < g.M ? m : g.M - 1) * g.ldc + nb + 8 * lq;
+        const int mA = mb + 16 * i + r8, mB = mA + 8;
 #ifdef ABL_NO_SIDE
-        hw[0] = hw[1] = u32x4_t{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; lw[0] = lw[1] = u32x2_t{(unsigned)o, 0x80808080u}; return;
+        hw[0] = hw[1] = u32x4_t{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}; lw[0] = lw[1] = u32x2_t{(unsigned)mA, 0x80808080u}; return;
 #endif
-        hw[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(g.auxH + o));
-        hw[1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(g.auxH + o + 32));
-        lw[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(lo_in + o));
-        lw[1] = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(lo_in + o + 32));
+        hw[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(g.auxH + lo8_off(g, mA < g.M ? mA : g.M - 1, (int)ocol)));
+        hw[1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(g.auxH + lo8_off(g, mB < g.M ? mB : g.M - 1, (int)ocol)));
+        lw[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(lo_in + lo8_off(g, mA < g.M ? mA : g.M - 1, (int)ocol)));
+        lw[1] = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(lo_in + lo8_off(g, mB < g.M ? mB : g.M - 1, (int)ocol)));
     };
     float bv[4][4];
     pp_col_consts(bv, g.bias != nullptr ? g.bias + nb : nullptr, nullptr, lq);
@@ -844,33 +860,55 @@ __device__ __forceinline__ void pp_epilogue_lo8_direct(const GemmArgs& g, f32x4_
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{acc[i][j][0] + bv[j][0], acc[i][j][1] + bv[j][1], acc[i][j][2] + bv[j][2], acc[i][j][3] + bv[j][3]};
 #pragma unroll
     for (int i = 0; i < 2; ++i) side(2 + i, hw[1][i], lw[1][i]);
-    const bool lo = lrow < 8;
-    const int r8 = lrow & 7;
-    const size_t ocol = (size_t)nb + 32 * (lrow >> 3) + 8 * lq;
-    auto row_block = [&](int i, const u32x4_t (&hw)[2], const u32x2_t (&lw)[2]) {
+    auto row_block = [&](int i, const u32x4_t (&hws)[2], const u32x2_t (&lws)[2]) {
+        // un-swap the loaded words: this lane's own row, column halves 0 / 1
+        uint4 hw[2] = {make_uint4(hws[0][0], hws[0][1], hws[0][2], hws[0][3]), make_uint4(hws[1][0], hws[1][1], hws[1][2], hws[1][3])};
+        pp_pair_swap(hw[0], hw[1], lo);
+        uint2 lw[2];
+        {
+            const unsigned rx = pp_ror8(lo ? lws[1][0] : lws[0][0]), ry = pp_ror8(lo ? lws[1][1] : lws[0][1]);
+            lw[0] = make_uint2(lo ? lws[0][0] : rx, lo ? lws[0][1] : ry);
+            lw[1] = make_uint2(lo ? rx : lws[1][0], lo ? ry : lws[1][1]);
+        }
         uint4 oh[2];
         uint2 ol[2];
-        float s1 = 0.f, s2 = 0.f;
+        f32x2v s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             float x[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const unsigned hword = hw[k][e >> 1], lword = lw[k][e >> 2];
+                const unsigned hword = (e >> 1) == 0 ? hw[k].x : ((e >> 1) == 1 ? hw[k].y : ((e >> 1) == 2 ? hw[k].z : hw[k].w));
+                const unsigned lword = (e >> 2) == 0 ? lw[k].x : lw[k].y;
                 const float hf = h2f((bf16_t)((e & 1) ? (hword >> 16) : (hword & 0xFFFF)));
-                float r = lo8_decode(hf, (lword >> (8 * (e & 3))) & 0xFF);
-                asm volatile("" : "+v"(r));      // (the decoded value is ONE operand, as in the staged form)
-                x[e] = r + acc[i][2 * k + (e >> 2)][e & 3];
-                s1 += x[e];
-                s2 = __builtin_fmaf(x[e], x[e], s2);
+                // residual = hi (1 + (q - 128) 2^-18) = hi * (q 2^-18 + (1 - 2^-11)), added to the accumulator by the same fma
+                const float t = __builtin_fmaf((float)((lword >> (8 * (e & 3))) & 0xFF), 0x1p-18f, 1.0f - 0x1p-11f);
+                x[e] = __builtin_fmaf(hf, t, acc[i][2 * k + (e >> 2)][e & 3]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const f32x2v xv = {x[e], x[e + 1]};
+                s1v += xv;
+                s2v = xv * xv + s2v;
             }
             oh[k] = make_uint4(pack2<true>(x[0], x[1]), pack2<true>(x[2], x[3]), pack2<true>(x[4], x[5]), pack2<true>(x[6], x[7]));
 #ifdef ABL_NO_LO
             ol[k] = make_uint2(oh[k].x, oh[k].y);
 #else
-            ol[k] = make_uint2(lo8_encode4(x[0], x[1], x[2], x[3], oh[k].x, oh[k].y), lo8_encode4(x[4], x[5], x[6], x[7], oh[k].z, oh[k].w));
+            // byte of the new value: (x / hi' - 1) 2^18 + 128, with 1 - hi' / x for x / hi' - 1 (they differ by the square of a number
+            // below 2^-11: 1/16 of a step) -- one reciprocal of the fp32 value, one fma on the f16 hi' itself, one fma, round, convert
+            unsigned ob[2] = {0u, 0u};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned hword = e < 2 ? oh[k].x : (e < 4 ? oh[k].y : (e < 6 ? oh[k].z : oh[k].w));
+                const float hn = h2f((bf16_t)((e & 1) ? (hword >> 16) : (hword & 0xFFFF)));
+                const float eps = __builtin_fmaf(-hn, __builtin_amdgcn_rcpf(x[e]), 1.0f);
+                ob[e >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(eps, 0x1p18f, 128.f), e & 3, ob[e >> 2]);      // (rounds to nearest even, saturates: tools/ablate/cvt_u8_probe.hip)
+            }
+            ol[k] = make_uint2(ob[0], ob[1]);
 #endif
         }
+        float s1 = s1v.x + s1v.y, s2 = s2v.x + s2v.y;
         // this 64-column slice's (sum, sum of squares) of row 16 i + l15: the four lane groups hold 16 columns each
 #ifndef ABL_NO_STATS
         s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
@@ -893,17 +931,15 @@ __device__ __forceinline__ void pp_epilogue_lo8_direct(const GemmArgs& g, f32x4_
         const int mA = mb + 16 * i + r8;
 #endif
         if (mA < g.M) {
-            const size_t o = (size_t)mA * g.ldc + ocol;
-            *reinterpret_cast<uint4*>(g.outH + o) = oh[0];      // (a plain store: the next GEMM reads this image right away)
+            *reinterpret_cast<uint4*>(g.outH + lo8_off(g, mA, (int)ocol)) = oh[0];      // (a plain store: the next GEMM reads this image right away)
 #ifndef ABL_NO_LO
-            v3_st<uint2>(lo_out + o, ol[0]);
+            v3_st<uint2>(lo_out + lo8_off(g, mA, (int)ocol), ol[0]);
 #endif
         }
         if (mA + 8 < g.M) {
-            const size_t o = (size_t)(mA + 8) * g.ldc + ocol;
-            *reinterpret_cast<uint4*>(g.outH + o) = oh[1];
+            *reinterpret_cast<uint4*>(g.outH + lo8_off(g, mA + 8, (int)ocol)) = oh[1];
 #ifndef ABL_NO_LO
-            v3_st<uint2>(lo_out + o, ol[1]);
+            v3_st<uint2>(lo_out + lo8_off(g, mA + 8, (int)ocol), ol[1]);
 #endif
         }
     };
@@ -1189,7 +1225,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     const int nk = g.K / BK;
 
     const int rows_a = (g.M - m0) < TM ? (g.M - m0) : TM;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)m0 * g.lda), 0, rows_a * g.lda * 2, 0x00020000);
+    // (slab-major A, GemmArgs.a_slab: row pitch 128 bytes, K tile kt at kt * M * 128; rows past M read the next slab -- they only reach
+    //  accumulator rows that are never stored -- and nothing is read past the last slab's end)
+    const bool a_slab = (GB == 1 || GB == 2) ? false : g.a_slab != 0;      // (the evaluation-mode variants have no register to spare for it)
+    const int a_ld2 = a_slab ? 128 : g.lda * 2, a_kst = a_slab ? g.M * 128 : BK * 2;
+    const __amdgpu_buffer_rsrc_t ra = a_slab
+        ? __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)m0 * 64), 0, (unsigned)((size_t)(g.K / BK) * g.M * 128 - (size_t)m0 * 128), 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)m0 * g.lda), 0, rows_a * g.lda * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(g.B + (size_t)n0 * g.ldb), 0, V3_T * g.ldb * 2, 0x00020000);
     // DMA pieces of this wave: slot piece index p = 2 wave + e.  Slot 0 = A rows of half 0 (wave-row * 128 + 0..63), slot 3 = A rows
     // of half 1, slot 1 = B rows of half 0 (wave-column * 64 + 0..31), slot 2 = B rows of half 1
@@ -1209,14 +1251,14 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
             const bool is_b = (sl == 1 || sl == 2);
             // LDS row wm * 128 + r of the A stage holds tile row wm * 16 RB + r (r >= 16 RB: a row nobody reads)
             const int grow = is_b ? pp_brow_src(row) : (row >> 7) * (16 * RB) + (row & 127);
-            vo[sl][e] = grow * (is_b ? g.ldb : g.lda) * 2 + cl * 16;
+            vo[sl][e] = grow * (is_b ? g.ldb * 2 : a_ld2) + cl * 16;
             ld_[sl][e] = (is_b ? 65536 : 0) + rows[sl] * 128;
         }
     }
 #define PP_DMA_R(RA_, RB_, SL, KT)                                                                                        \
     {                                                                                                                     \
         const int kt_ = (GB == 2 && (KT) >= g.k_wrap) ? (((SL) == 0 || (SL) == 3) ? (KT) - g.k_wrap : (KT) + g.b_skip) : (KT); \
-        const int so_ = kt_ * (BK * 2), st_ = ((KT) & 1) << 15;                                                           \
+        const int so_ = kt_ * (((SL) == 1 || (SL) == 2) ? BK * 2 : a_kst), st_ = ((KT) & 1) << 15;                        \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? RB_ : RA_, (lds_ptr_t)(lds3 + st_ + ld_[SL][0]), 16, vo[SL][0], so_, 0, 0); \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? RB_ : RA_, (lds_ptr_t)(lds3 + st_ + ld_[SL][1]), 16, vo[SL][1], so_, 0, 0); \
     }
@@ -1311,7 +1353,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
         if (tl_next < nwg) {
             tile_mn(tl_next, m0n, n0n);
             const int rows_n = (g.M - m0n) < TM ? (g.M - m0n) : TM;
-            const __amdgpu_buffer_rsrc_t ran = __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)m0n * g.lda), 0, rows_n * g.lda * 2, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ran = a_slab
+                ? __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)m0n * 64), 0, (unsigned)((size_t)(g.K / BK) * g.M * 128 - (size_t)m0n * 128), 0x00020000)
+                : __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)m0n * g.lda), 0, rows_n * g.lda * 2, 0x00020000);
             const __amdgpu_buffer_rsrc_t rbn = __builtin_amdgcn_make_buffer_rsrc((void*)(g.B + (size_t)n0n * g.ldb), 0, V3_T * g.ldb * 2, 0x00020000);
             PP_DMA_R(ran, rbn, 1, 0) PP_DMA_R(ran, rbn, 0, 0) PP_DMA_R(ran, rbn, 2, 0) PP_DMA_R(ran, rbn, 3, 0)
             primed = true;
@@ -1986,15 +2030,25 @@ extern "C" int sed_gemm_nt_lnp8(const void* A, const void* B, int M, int N, int 
                                 hipStream_t stream) {
     return gemm_nt_lnp_impl(A, B, M, N, K, lda, ldb, bias, resF, res_hi, res_lo8, outF, x16, out_lo8, rowpart, ldc, 1, stream);
 }
-extern "C" int sed_gemm_nt_lnc(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* colC, const float* colS,
-                               const float* rowstat, void* outH2, int ldc, hipStream_t stream) {
+static int gemm_nt_lnc_impl(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* colC, const float* colS,
+                            const float* rowstat, void* outH2, int ldc, int a_slab, hipStream_t stream) {
     (void)hipGetLastError();
     if (N % 256 || M < 1024 || K % BK || colS == nullptr || rowstat == nullptr || outH2 == nullptr) return SED_ERR_ARG;
     GemmArgs g = {};
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.ncols = N;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ksplit = 1; g.alpha = 1.f;
-    g.bias = colC; g.outH2 = (bf16_t*)outH2; g.colS = colS; g.rowstat = rowstat;
+    g.bias = colC; g.outH2 = (bf16_t*)outH2; g.colS = colS; g.rowstat = rowstat; g.a_slab = a_slab;
+    if (a_slab && lda != K) return SED_ERR_ARG;
     return launch_gemm<EPI_GELU>(g, 1, stream);
+}
+extern "C" int sed_gemm_nt_lnc(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* colC, const float* colS,
+                               const float* rowstat, void* outH2, int ldc, hipStream_t stream) {
+    return gemm_nt_lnc_impl(A, B, M, N, K, lda, ldb, colC, colS, rowstat, outH2, ldc, 0, stream);
+}
+// ... fed with the slab-major hi plane sed_gemm_nt_lnp8 writes ([K / 64][M][64] f16)
+extern "C" int sed_gemm_nt_lnc8(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* colC, const float* colS,
+                                const float* rowstat, void* outH2, int ldc, hipStream_t stream) {
+    return gemm_nt_lnc_impl(A, B, M, N, K, lda, ldb, colC, colS, rowstat, outH2, ldc, 1, stream);
 }
 // same GEMM with a narrow result: the operands are padded to N (multiple of 128) but only the first ncols (multiple of 4) output
 // columns exist in memory (row stride ldc >= ncols); bias / residual / outputs are indexed like the narrow matrix.  128^2 kernel only.
@@ -2029,8 +2083,8 @@ extern "C" int sed_gemm_qkv_gb(const void* A, const void* W, const float* bias, 
                          gbias, gb_rows, stream);
 }
 // folded-LayerNorm consumer (see sed_gemm_nt_lnc): A = f16 image of the raw stream, W = f16 image of gamma (.) W_qkv; inference outputs only
-extern "C" int sed_gemm_qkv_lnc(const void* A, const void* W, const float* colC, const float* colS, const float* rowstat, int M, int K,
-                                int heads, int seq, int seq_pad, void* q, void* k, void* v, hipStream_t stream) {
+static int gemm_qkv_lnc_impl(const void* A, const void* W, const float* colC, const float* colS, const float* rowstat, int M, int K,
+                             int heads, int seq, int seq_pad, void* q, void* k, void* v, int a_slab, hipStream_t stream) {
     (void)hipGetLastError();
     if (M < 1024 || K % BK || colS == nullptr || rowstat == nullptr || seq <= 0 || (seq_pad % 64) || M % seq) return SED_ERR_ARG;
     GemmArgs g = {};
@@ -2038,8 +2092,16 @@ extern "C" int sed_gemm_qkv_lnc(const void* A, const void* W, const float* colC,
     g.M = M; g.N = 3 * heads * 64; g.K = K; g.lda = K; g.ldb = K; g.ldc = g.N; g.ksplit = 1; g.alpha = 1.f; g.ncols = g.N;
     g.bias = colC; g.colS = colS; g.rowstat = rowstat;
     g.q = (bf16_t*)q; g.k = (bf16_t*)k; g.v = (bf16_t*)v;
-    g.seq = seq; g.seq_pad = seq_pad; g.heads = heads;
+    g.seq = seq; g.seq_pad = seq_pad; g.heads = heads; g.a_slab = a_slab;
     return launch_gemm<EPI_QKV>(g, 1, stream);
+}
+extern "C" int sed_gemm_qkv_lnc(const void* A, const void* W, const float* colC, const float* colS, const float* rowstat, int M, int K,
+                                int heads, int seq, int seq_pad, void* q, void* k, void* v, hipStream_t stream) {
+    return gemm_qkv_lnc_impl(A, W, colC, colS, rowstat, M, K, heads, seq, seq_pad, q, k, v, 0, stream);
+}
+extern "C" int sed_gemm_qkv_lnc8(const void* A, const void* W, const float* colC, const float* colS, const float* rowstat, int M, int K,
+                                 int heads, int seq, int seq_pad, void* q, void* k, void* v, hipStream_t stream) {
+    return gemm_qkv_lnc_impl(A, W, colC, colS, rowstat, M, K, heads, seq, seq_pad, q, k, v, 1, stream);
 }
 // two-term weights (see sed_gemm_nt_w2): W is [3 * heads * 64, 2K]; inference outputs only
 extern "C" int sed_gemm_qkv_w2(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq,

@@ -349,7 +349,8 @@ class SedEngine:
             # between folded blocks the residual stream lives as two f16 planes (x16f = hi, which is also the consumers' A operand, + xlo)
             # instead of fp32: a producer then moves 8 bytes per element instead of 10 (csrc/gemm.hip, GemmArgs.res_lo / out_lo)
             x16f, xlo, partf, statf = E(M, D, dt=F16), E(M, D, dt=torch.uint8 if self.ln_lo8 else F16), E(M, D // 64, 2), E(M, 2)
-            lnp = "sed_gemm_nt_lnp8" if self.ln_lo8 else "sed_gemm_nt_lnp"
+            lnp = "sed_gemm_nt_lnp8" if self.ln_lo8 else "sed_gemm_nt_lnp"      # (lnp8: both planes slab-major, read back by the *_lnc8 consumers)
+            qkv_lnc, nt_lnc = ("sed_gemm_qkv_lnc8", "sed_gemm_nt_lnc8") if self.ln_lo8 else ("sed_gemm_qkv_lnc", "sed_gemm_nt_lnc")
         planes = False              # the current stream value is in (x16f, xlo) rather than in the fp32 tensor
         for li in range(m.depth):
             p = f"backbone.blocks.{li}."
@@ -378,7 +379,7 @@ class SedEngine:
                 last = li + 1 == m.depth or (li + 1 == m.passt_feature_layer and not want_frame) or (save and li + 1 >= lo_f)
                 if have_stat:
                     wq, sq, cq = self._lnf_image(W, p + "attn.qkv.weight", p + "attn.qkv.bias", p + "norm1.weight", p + "norm1.bias")
-                    call("sed_gemm_qkv_lnc", x16f, wq, cq, sq, statf, M, D, H, N, Npad, q, k, v)
+                    call(qkv_lnc, x16f, wq, cq, sq, statf, M, D, H, N, Npad, q, k, v)
                 else:       # first block: its LayerNorm ran above (the stream comes from the token assembly, not from a GEMM)
                     call("sed_gemm_qkv", h16, W[p + "attn.qkv.weight"].w, self.P(p + "attn.qkv.bias"), M, D, H, N, Npad, q, k,
                          v, None, None, None, None, None, None, None, f16)
@@ -390,7 +391,7 @@ class SedEngine:
                 planes = sp
                 call("sed_ln_fold_stats", partf, statf, M, D // 64, D, 1e-6)
                 w1, s1, c1 = self._lnf_image(W, p + "mlp.fc1.weight", p + "mlp.fc1.bias", p + "norm2.weight", p + "norm2.bias")
-                call("sed_gemm_nt_lnc", x16f, w1, M, 4 * D, D, D, D, c1, s1, statf, act, 4 * D)
+                call(nt_lnc, x16f, w1, M, 4 * D, D, D, D, c1, s1, statf, act, 4 * D)
                 # the block's output has an fp32 reader (f_pool, the final norm, a saving block) -> fp32 out; otherwise it stays in planes
                 f32_out = last or li + 1 == m.passt_feature_layer or not sp
                 if last and not planes:

@@ -159,9 +159,9 @@ class plain_precision:
 
 
 def _flops_of(name, args):
-    if name in ("sed_gemm_nt", "sed_gemm_nt_gb", "sed_gemm_nt_w2", "sed_gemm_nt_lnp", "sed_gemm_nt_lnp8", "sed_gemm_nt_lnc"):       # (w2: the logical 2 M N K, half of the MFMA FLOPs issued)
+    if name in ("sed_gemm_nt", "sed_gemm_nt_gb", "sed_gemm_nt_w2", "sed_gemm_nt_lnp", "sed_gemm_nt_lnp8", "sed_gemm_nt_lnc", "sed_gemm_nt_lnc8"):       # (w2: the logical 2 M N K, half of the MFMA FLOPs issued)
         return 2.0 * args[2] * args[3] * args[4]
-    if name == "sed_gemm_qkv_lnc":
+    if name in ("sed_gemm_qkv_lnc", "sed_gemm_qkv_lnc8"):
         return 2.0 * args[5] * args[6] * (3 * args[7] * 64)
     if name in ("sed_gemm_qkv", "sed_gemm_qkv_gb", "sed_gemm_qkv_w2", "sed_gemm_qkv_w2s"):
         return 2.0 * args[3] * args[4] * (3 * args[5] * 64)
@@ -178,9 +178,9 @@ def _shape_of(name, args):
         return (args[3], 3 * args[5] * 64, args[4], "qkv3" + name[-2:])
     if name == "sed_gemm_nt_w2":
         return (args[2], args[3], args[4], "epi%dw2" % args[7])
-    if name in ("sed_gemm_nt_lnp", "sed_gemm_nt_lnp8", "sed_gemm_nt_lnc"):
-        return (args[2], args[3], args[4], "epi3lnc" if name.endswith("c") else "epi1lnp")
-    if name == "sed_gemm_qkv_lnc":
+    if name in ("sed_gemm_nt_lnp", "sed_gemm_nt_lnp8", "sed_gemm_nt_lnc", "sed_gemm_nt_lnc8"):
+        return (args[2], args[3], args[4], "epi3lnc" if "lnc" in name else "epi1lnp")
+    if name in ("sed_gemm_qkv_lnc", "sed_gemm_qkv_lnc8"):
         return (args[5], 3 * args[7] * 64, args[6], "qkv3lnc")
     if name in ("sed_gemm_qkv", "sed_gemm_qkv_w2s"):
         return (args[3], 3 * args[5] * 64, args[4], "qkv%d" % sum(a is not None for a in args[8:16]) + ("w2s" if name.endswith("w2s") else ""))
@@ -199,10 +199,10 @@ def _bytes_of(name, args):
         M, N, K = args[2], args[3], args[4]
         pl = 3.0 if name.endswith("8") else 4.0
         return 2.0 * K * (M + N) + ((pl if args[10] is not None else 4.0) + (pl if args[13] is not None else 6.0)) * M * N
-    if name == "sed_gemm_nt_lnc":
+    if name in ("sed_gemm_nt_lnc", "sed_gemm_nt_lnc8"):
         M, N, K = args[2], args[3], args[4]
         return 2.0 * K * (M + N) + 2.0 * M * N
-    if name == "sed_gemm_qkv_lnc":
+    if name in ("sed_gemm_qkv_lnc", "sed_gemm_qkv_lnc8"):
         M, K, D = args[5], args[6], args[7] * 64
         return 2.0 * K * (M + 3 * D) + 2.0 * M * D * 3
     if name == "sed_gemm_nt_w2":
