@@ -130,7 +130,8 @@ int sed_gemm_nt_lnp8(const void* A, const void* B, int M, int N, int K, int lda,
                      hipStream_t stream);
 /* (with sed_gemm_nt_lnp8 the hi plane -- res_hi in, x16 out -- is slab-major too, [ldc / 64][M][64] f16: a K tile of the consumer and a
  *  wave's patch of the producer are contiguous runs.  sed_gemm_nt_lnc8 / sed_gemm_qkv_lnc8 are the consumers that read it: same
- *  arguments as sed_gemm_nt_lnc / sed_gemm_qkv_lnc, lda = K.) */
+ *  arguments as sed_gemm_nt_lnc / sed_gemm_qkv_lnc, lda = K.  sed_gemm_nt_lnc8 with ldc = 64 (N > 64) writes its output slab-major as
+ *  well, [N / 64][M][64]; sed_gemm_nt_lnp8 with lda = 64 (K > 64) reads such an A operand: the fc1 activation of a folded block.) */
 int sed_gemm_nt_lnc8(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* colC, const float* colS,
                      const float* rowstat, void* outH2, int ldc, hipStream_t stream);
 int sed_gemm_qkv_lnc8(const void* A, const void* W, const float* colC, const float* colS, const float* rowstat, int M, int K, int heads,

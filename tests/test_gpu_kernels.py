@@ -350,6 +350,17 @@ def test_gemm_layernorm_fold():
     act8 = torch.empty(M, Hd, dtype=F16, device=DEV)
     call("sed_gemm_nt_lnc8", x16s, W16, M, Hd, D, D, D, cC, cS, stat, act8, Hd)
     assert torch.equal(act8, act)
+    # ... and with ldc = 64 the fc1 activation leaves slab-major too ([Hd / 64][M][64]); the fc2 producer reads it with lda = 64
+    act8s = torch.empty(M, Hd, dtype=F16, device=DEV)
+    call("sed_gemm_nt_lnc8", x16s, W16, M, Hd, D, D, D, cC, cS, stat, act8s, 64)
+    assert torch.equal(act8s.view(Hd // 64, M, 64).permute(1, 0, 2).reshape(M, Hd), act)
+    W2 = rnd(D, Hd, scale=0.03, seed=82).to(F16); b2 = rnd(D, seed=83) * 0.1
+    outs = []
+    for a_op, lda in ((act, Hd), (act8s, 64)):
+        hi_o = torch.empty(M, D, dtype=F16, device=DEV); lo_o = torch.empty(M, D, dtype=torch.uint8, device=DEV); pt = torch.empty(M, D // 64, 2, device=DEV)
+        call("sed_gemm_nt_lnp8", a_op, W2, M, D, Hd, lda, Hd, b2, None, hi9, lo9, None, hi_o, lo_o, pt, D)
+        outs.append((hi_o, lo_o, pt))
+    assert all(torch.equal(u, w) for u, w in zip(outs[0], outs[1]))
     e_fold, e_plain = maxerr(act.float(), truth), maxerr(act0.float(), truth)
     rms = lambda t: float(((t.double() - truth) ** 2).mean().sqrt())
     report(f"LN fold fc1+GELU: max {e_fold:.2e} (unfolded {e_plain:.2e}), rms {rms(act):.2e} (unfolded {rms(act0):.2e})", e_fold, float(truth.abs().max()))

@@ -88,6 +88,9 @@ struct GemmArgs {
     // columns are one contiguous 16 KB run, and for the consumer GEMMs (a_slab != 0: A is such a plane with K / 64 slabs) a K tile of
     // 256 rows is one contiguous 32 KB run instead of 256 pieces of 128 bytes, 1536 bytes apart.
     int a_slab;
+    // ... and the 16-bit output of the fused-GELU consumer (outH2) can leave slab-major as well (c_slab != 0: [N / 64][M][64]) -- the fc1
+    // activation of a folded block is read by nobody but the fc2 producer, as its slab-major A operand.
+    int c_slab;
     // Persistent 256^2 kernel, dynamic tile walk: 8 per-XCD tile counters + 1 exit counter, one 64-byte line each (int index 16 x).  A
     // workgroup takes the next tile of ITS XCD's contiguous tile range from counter blockIdx.x & 7 (so the L2 grouping of the static walk
     // is kept) instead of the fixed blockIdx.x + k gridDim.x: a workgroup that becomes resident late -- or only after the others have
@@ -993,8 +996,11 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
             int lrow = l15;
             asm volatile("" : "+v"(lrow));
             const int r8 = lrow & 7, hk = lrow >> 3;
-            const PPSinkRows sink{out + (size_t)(mb + r8) * g.ldc + nb + 32 * hk + 8 * lq, out + (size_t)(mb + lrow) * g.ldc + nb + 8 * lq,
-                                  8 * g.ldc, g.M - mb - r8, g.M - mb - lrow, lrow < 8};
+            // (slab-major output: the wave's 64 columns are slab nb / 64, rows 128 bytes apart)
+            const int ldo = g.c_slab ? 64 : g.ldc;
+            bf16_t* const ob = g.c_slab ? out + (size_t)(nb >> 6) * g.M * 64 : out + nb;
+            const PPSinkRows sink{ob + (size_t)(mb + r8) * ldo + 32 * hk + 8 * lq, ob + (size_t)(mb + lrow) * ldo + 8 * lq,
+                                  8 * ldo, g.M - mb - r8, g.M - mb - lrow, lrow < 8};
             if constexpr (GB) {      // evaluation-mode encoder only (no saved pre-activation: one pass)
                 const float *rA, *rB;
                 const int bnd = gb_split(g, mb, rA, rB);
@@ -2017,6 +2023,7 @@ static int gemm_nt_lnp_impl(const void* A, const void* B, int M, int N, int K, i
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ksplit = 1; g.alpha = 1.f;
     g.bias = bias; g.resF = resF; g.outF = outF; g.outH = (bf16_t*)x16; g.rowpart = rowpart;
     g.auxH = (const bf16_t*)res_hi; g.res_lo = (const bf16_t*)res_lo; g.out_lo = (bf16_t*)out_lo; g.lo8 = lo8;
+    if (lo8 && lda == 64 && K > 64) { g.a_slab = 1; g.lda = K; }      // A as [K / 64][M][64] (what sed_gemm_nt_lnc8 writes with ldc = 64)
     return launch_gemm<EPI_F32_RESID>(g, 1, stream);
 }
 extern "C" int sed_gemm_nt_lnp(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* bias, const float* resF,
@@ -2039,6 +2046,7 @@ static int gemm_nt_lnc_impl(const void* A, const void* B, int M, int N, int K, i
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ksplit = 1; g.alpha = 1.f;
     g.bias = colC; g.outH2 = (bf16_t*)outH2; g.colS = colS; g.rowstat = rowstat; g.a_slab = a_slab;
     if (a_slab && lda != K) return SED_ERR_ARG;
+    if (a_slab && ldc == 64 && N > 64) { g.c_slab = 1; g.ldc = N; }      // output as [N / 64][M][64]
     return launch_gemm<EPI_GELU>(g, 1, stream);
 }
 extern "C" int sed_gemm_nt_lnc(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* colC, const float* colS,

@@ -391,13 +391,15 @@ class SedEngine:
                 planes = sp
                 call("sed_ln_fold_stats", partf, statf, M, D // 64, D, 1e-6)
                 w1, s1, c1 = self._lnf_image(W, p + "mlp.fc1.weight", p + "mlp.fc1.bias", p + "norm2.weight", p + "norm2.bias")
-                call(nt_lnc, x16f, w1, M, 4 * D, D, D, D, c1, s1, statf, act, 4 * D)
+                # (byte-plane runs: the fc1 activation goes slab-major from fc1's epilogue into fc2's A operand -- ldc / lda = 64)
+                slab_act = self.ln_lo8 and sp and not (last and not planes) and os.environ.get("SED_SLAB_ACT", "1") != "0"
+                call(nt_lnc, x16f, w1, M, 4 * D, D, D, D, c1, s1, statf, act, 64 if slab_act else 4 * D)
                 # the block's output has an fp32 reader (f_pool, the final norm, a saving block) -> fp32 out; otherwise it stays in planes
                 f32_out = last or li + 1 == m.passt_feature_layer or not sp
                 if last and not planes:
                     gemm_nt(act, W[p + "mlp.fc2.weight"].w, EPI_F32_RESID, bias=self.P(p + "mlp.fc2.bias"), res=x_in, outF=x_in)
                 else:
-                    call(lnp, act, W[p + "mlp.fc2.weight"].w, M, D, 4 * D, 4 * D, 4 * D, self.P(p + "mlp.fc2.bias"),
+                    call(lnp, act, W[p + "mlp.fc2.weight"].w, M, D, 4 * D, 64 if slab_act else 4 * D, 4 * D, self.P(p + "mlp.fc2.bias"),
                          None if planes else x_in, x16f if planes else None, xlo if planes else None,
                          x_in if f32_out else None, x16f, None if f32_out else xlo, partf, D)
                     planes = not f32_out
