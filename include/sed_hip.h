@@ -183,7 +183,8 @@ int sed_small_linear_bwd(const float* a, const float* w, const float* out, const
 
 /* ------------------------------------------------------------------ attention */
 /* encoder MHSA (src/models/passt/passt.py:335-341), flash style; Q, K, V head-split [B*H, N, 64] 16-bit (V row-major: the kernel takes
-   V^T out of its LDS tile with transposing reads); O [B,N,768] 16-bit, LSE [B*H,N] (log2 domain) */
+   V^T out of its LDS tile with transposing reads); O [B,N,768] 16-bit, LSE [B*H,N] (log2 domain).
+   f16: bit 0 = IEEE half operands (else bf16); bit 1 = O head-major [H][B*N][64] (the slab-major A operand of sed_gemm_nt_lnp8, lda = 64) */
 int sed_mhsa_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int Npad,
                  int f16, hipStream_t stream);
 int sed_mhsa_bwd_prep(const void* dO, const void* O, float* Dtmp, void* dOh, void* dOt, int B, int H, int N, int Npad,

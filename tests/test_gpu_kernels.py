@@ -590,6 +590,9 @@ def test_mhsa_fwd_bwd(B, N, DT):
     O = torch.empty(B, N, 768, dtype=DT, device=DEV)
     lse = torch.empty(B * Hh, N, device=DEV)
     call("sed_mhsa_fwd", q.to(DT), k.to(DT), v.to(DT), O, lse, B, Hh, N, Npad, f16)    # V row-major: transposed inside the kernel
+    Oh = torch.empty_like(O)      # head-major output [H][B * N][64] (f16 bit 1): the same values
+    call("sed_mhsa_fwd", q.to(DT), k.to(DT), v.to(DT), Oh, torch.empty_like(lse), B, Hh, N, Npad, f16 | 2)
+    assert torch.equal(Oh.view(Hh, B * N, 64).permute(1, 0, 2).reshape(O.shape), O)
     qq, kk, vv = [t.clone().requires_grad_(True) for t in (q, k, v)]
     s = (qq @ kk.transpose(1, 2)) * 0.125
     p = torch.softmax(s, dim=-1)

@@ -143,7 +143,7 @@ __device__ __forceinline__ void softmax_tile(f32x16_t (&st)[2], f32x16_t (&o)[2]
 template <bool F16, int NQ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void mhsa_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
-                                                       float* __restrict__ LSE, int N, int Npad, int H, int q_begin) {
+                                                       float* __restrict__ LSE, int N, int Npad, int H, int q_begin, int o_slab) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][KVB * 128];  // [buf][K | Vt]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
@@ -241,7 +241,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         const int q = q0 + 32 * u + lr;
         if (q < N) {
             const float inv = 1.0f / l_run[u];
-            bf16_t* orow = O + ((size_t)b * N + q) * (H * HD) + h * HD;
+            // (o_slab: head-major output [H][B * N][64] -- the slab-major A operand of the LayerNorm-fold proj GEMM, csrc/gemm.hip a_slab)
+            bf16_t* orow = o_slab ? O + ((size_t)h * ((int)gridDim.y / H) * N + (size_t)b * N + q) * HD : O + ((size_t)b * N + q) * (H * HD) + h * HD;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -298,7 +299,7 @@ __device__ __forceinline__ s16x8_t att_frag(unsigned long long lo, unsigned long
 template <bool F16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE_DMA, WPE_DMA))) void mhsa_fwd_dma_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, bf16_t* __restrict__ O,
-    float* __restrict__ LSE, int N, int H) {
+    float* __restrict__ LSE, int N, int H, int o_slab) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][KVB * 128];  // [buf][K | V]
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -410,7 +411,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE_DMA, WP
     const int q = q0 + lr;
     if (q < N) {
         const float inv = 1.0f / l_run;
-        bf16_t* orow = O + ((size_t)b * N + q) * (H * HD) + h * HD;
+        // (o_slab: head-major output [H][B * N][64]: a workgroup's 128 queries are one contiguous 16 KB run, and the rows are the slab-major A
+        //  operand of the LayerNorm-fold proj GEMM, csrc/gemm.hip a_slab; token-major they are 128-byte pieces 1536 bytes apart)
+        bf16_t* orow = o_slab ? O + ((size_t)h * ((int)gridDim.y / H) * N + (size_t)b * N + q) * HD : O + ((size_t)b * N + q) * (H * HD) + h * HD;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE_DMA, WP
 }
 
 template <bool F16>
-static void launch_mhsa_fwd(const void* Q, const void* K, const void* Vt, void* O, float* LSE, int B, int H, int N, int Npad,
+static void launch_mhsa_fwd(const void* Q, const void* K, const void* Vt, void* O, float* LSE, int B, int H, int N, int Npad, int o_slab,
                             hipStream_t stream) {
     // NQ = 2 (256-query workgroups) halves LDS traffic per MFMA but drops to one wave per SIMD (202 VGPRs) and measured
     // slower on MI355X (24.9 vs 20.8 ms/step); NQ = 1 (two waves per SIMD) is the shipped configuration.
@@ -433,19 +436,20 @@ static void launch_mhsa_fwd(const void* Q, const void* K, const void* Vt, void* 
     static const bool reg_path = getenv("SED_MHSA_FWD") && !strcmp(getenv("SED_MHSA_FWD"), "reg");
     if (!reg_path) {
         hipLaunchKernelGGL((mhsa_fwd_dma_kernel<F16>), dim3(cdiv(N, 128), B * H), dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,
-                           (const bf16_t*)Vt, (bf16_t*)O, LSE, N, H);
+                           (const bf16_t*)Vt, (bf16_t*)O, LSE, N, H, o_slab);
         return;
     }
     hipLaunchKernelGGL((mhsa_fwd_kernel<F16, 1>), dim3(cdiv(N, 128), B * H), dim3(256), 0, stream, (const bf16_t*)Q,
-                       (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, LSE, N, Npad, H, 0);
+                       (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, LSE, N, Npad, H, 0, o_slab);
 }
 
 extern "C" int sed_mhsa_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N,
                             int Npad, int f16, hipStream_t stream) {
     (void)hipGetLastError();
     if (N <= 0 || Npad % 64 || Npad < N) return SED_ERR_ARG;
-    if (f16) launch_mhsa_fwd<true>(Q, K, V, O, LSE, B, H, N, Npad, stream);
-    else launch_mhsa_fwd<false>(Q, K, V, O, LSE, B, H, N, Npad, stream);
+    // f16 bit 0: IEEE half operands (else bf16); bit 1: O head-major [H][B * N][64] instead of token-major [B][N][H * 64]
+    if (f16 & 1) launch_mhsa_fwd<true>(Q, K, V, O, LSE, B, H, N, Npad, (f16 >> 1) & 1, stream);
+    else launch_mhsa_fwd<false>(Q, K, V, O, LSE, B, H, N, Npad, (f16 >> 1) & 1, stream);
     return sed_check_launch();
 }
 

@@ -383,9 +383,11 @@ class SedEngine:
                 else:       # first block: its LayerNorm ran above (the stream comes from the token assembly, not from a GEMM)
                     call("sed_gemm_qkv", h16, W[p + "attn.qkv.weight"].w, self.P(p + "attn.qkv.bias"), M, D, H, N, Npad, q, k,
                          v, None, None, None, None, None, None, None, f16)
-                call("sed_mhsa_fwd", q, k, v, o16, lse, Bx, H, N, Npad, f16)
                 sp = self.ln_planes
-                call(lnp, o16, W[p + "attn.proj.weight"].w, M, D, D, D, D, self.P(p + "attn.proj.bias"),
+                # (byte-plane runs: the attention output goes head-major = slab-major into the proj GEMM's A operand)
+                slab_o = self.ln_lo8 and os.environ.get("SED_SLAB_ACT", "1") != "0"
+                call("sed_mhsa_fwd", q, k, v, o16, lse, Bx, H, N, Npad, f16 | (2 if slab_o else 0))
+                call(lnp, o16, W[p + "attn.proj.weight"].w, M, D, D, 64 if slab_o else D, D, self.P(p + "attn.proj.bias"),
                      None if planes else x_in, x16f if planes else None, xlo if planes else None,
                      None if sp else x_in, x16f, xlo if sp else None, partf, D)
                 planes = sp
