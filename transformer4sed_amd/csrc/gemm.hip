@@ -959,6 +959,49 @@ __device__ __forceinline__ void pp_epilogue_lo8_direct(const GemmArgs& g, f32x4_
     }
 }
 
+// GELU' epilogue (dX of fc2 times gelu'(saved pre-activation), student backward) straight from the accumulators: the pre-activation rows
+// are fetched up front in the pair-swapped whole-line layout (16 bytes per lane, 8 rows x 128 bytes per instruction -- the staged form
+// read and wrote 8 bytes per lane, 128 memory instructions per wave and tile instead of 32), un-swapped in registers, and the products
+// leave the same way.  No LDS.
+template <bool F16, int RB>
+__device__ __forceinline__ void pp_epilogue_dgelu_direct(const GemmArgs& g, const f32x4_t (&acc)[8][4], int mb, int nb, int lane) {
+    const int lq = lane >> 4;
+    int lrow = lane & 15;
+    asm volatile("" : "+v"(lrow));
+    const bool lo = lrow < 8;
+    const int r8 = lrow & 7;
+    const size_t ocol = (size_t)nb + 32 * (lrow >> 3) + 8 * lq;
+    u32x4_t hw[RB][2];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int mA = mb + 16 * i + r8, mB = mA + 8;
+        hw[i][0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(g.auxH + (size_t)(mA < g.M ? mA : g.M - 1) * g.ldc + ocol));
+        hw[i][1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(g.auxH + (size_t)(mB < g.M ? mB : g.M - 1) * g.ldc + ocol));
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        uint4 h[2] = {make_uint4(hw[i][0][0], hw[i][0][1], hw[i][0][2], hw[i][0][3]), make_uint4(hw[i][1][0], hw[i][1][1], hw[i][1][2], hw[i][1][3])};
+        pp_pair_swap(h[0], h[1], lo);      // -> this lane's own row, column halves 0 / 1
+        uint4 o[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            unsigned ow[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const unsigned hword = w == 0 ? h[k].x : (w == 1 ? h[k].y : (w == 2 ? h[k].z : h[k].w));
+                const f32x2v ga = gelu_fast_grad2(f32x2v{to_f32<F16>((bf16_t)(hword & 0xFFFF)), to_f32<F16>((bf16_t)(hword >> 16))});
+                const f32x4_t& a = acc[i][2 * k + (w >> 1)];
+                ow[w] = pack2<F16>(a[2 * (w & 1)] * ga.x, a[2 * (w & 1) + 1] * ga.y);
+            }
+            o[k] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+        }
+        pp_pair_swap(o[0], o[1], lo);
+        const int mA = mb + 16 * i + r8;
+        if (mA < g.M) v3_st<uint4>(g.outH + (size_t)mA * g.ldc + ocol, o[0]);
+        if (mA + 8 < g.M) v3_st<uint4>(g.outH + (size_t)(mA + 8) * g.ldc + ocol, o[1]);
+    }
+}
+
 template <int EPI>
 struct V3Consts {  // per-lane bias values, fetched before the K loop so their latency is off the epilogue's critical path
     static constexpr bool kStaged16 = (EPI == EPI_BF16 || EPI == EPI_GELU);
@@ -1122,6 +1165,10 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
             }
             __builtin_amdgcn_wave_barrier();
         }
+        return;
+    }
+    if constexpr (EPI == EPI_DGELU && GBM == 0) {
+        pp_epilogue_dgelu_direct<F16, RB>(g, acc, mb, nb, lane);
         return;
     }
     if constexpr (EPI == EPI_F32_RESID && GBM == 6) {      // byte planes in -> byte planes out: straight from the accumulators
