@@ -385,6 +385,46 @@ def test_gemm_layernorm_fold():
         assert ef < 1.5 * ep + 1e-3, (i, ef, ep)
 
 
+def test_layernorm_fold_entry_points_224_row_tiles(monkeypatch):
+    """The byte-plane / slab-major forms of the LayerNorm-fold GEMMs (direct producer epilogue, slab-major consumers) on 224-row tiles
+    (SED_GEMM_RB=7: seven row blocks per wave row, a ragged last tile) against 256-row tiles: bit-identical planes, row sums and outputs."""
+    M, D, Hd, Hh, Ntok = 2 * 1190, 768, 3072, 12, 1190
+    a16 = rnd(M, D, seed=91).to(F16)
+    Wp = rnd(D, D, scale=0.03, seed=92).to(F16); bp = rnd(D, seed=93) * 0.1
+    res = rnd(M, D, scale=1.5, seed=94)
+    W1 = rnd(Hd, D, scale=0.03, seed=95).to(F16); cS = W1.float().sum(-1).contiguous(); cC = rnd(Hd, seed=96) * 0.1
+    Wq = rnd(2304, D, scale=0.03, seed=97).to(F16); qS = Wq.float().sum(-1).contiguous(); qC = rnd(2304, seed=98) * 0.1
+    W2 = rnd(D, Hd, scale=0.03, seed=99).to(F16)
+
+    def run():
+        hi = torch.empty(M, D, dtype=F16, device=DEV); lo = torch.empty(M, D, dtype=torch.uint8, device=DEV)
+        part = torch.empty(M, D // 64, 2, device=DEV); stat = torch.empty(M, 2, device=DEV)
+        call("sed_gemm_nt_lnp8", a16, Wp, M, D, D, D, D, bp, res, None, None, None, hi, lo, part, D)          # fp32 in -> planes out (staged)
+        hi2, lo2, part2 = hi.clone(), lo.clone(), torch.empty_like(part)
+        call("sed_gemm_nt_lnp8", a16, Wp, M, D, D, D, D, bp, None, hi2, lo2, None, hi2, lo2, part2, D)       # planes -> planes (direct)
+        call("sed_ln_fold_stats", part2, stat, M, D // 64, D, 1e-6)
+        act = torch.empty(M, Hd, dtype=F16, device=DEV)
+        call("sed_gemm_nt_lnc8", hi2, W1, M, Hd, D, D, D, cC, cS, stat, act, 64)                               # slab-major in and out
+        q, k, v = [torch.empty(2 * Hh, Ntok, 64, dtype=F16, device=DEV) for _ in range(3)]
+        call("sed_gemm_qkv_lnc8", hi2, Wq, qC, qS, stat, M, D, Hh, Ntok, pad64(Ntok), q, k, v)
+        hi3, lo3, part3 = hi2.clone(), lo2.clone(), torch.empty_like(part)
+        call("sed_gemm_nt_lnp8", act, W2, M, D, Hd, 64, Hd, bp, None, hi3, lo3, None, hi3, lo3, part3, D)    # slab-major A operand
+        back = torch.empty(M, D, device=DEV); h4 = torch.empty(M, D, dtype=F16, device=DEV)
+        call("sed_gemm_nt_lnp8", act, W2, M, D, Hd, 64, Hd, bp, None, hi2, lo2, back, h4, None, part3.clone(), D)      # planes -> fp32 (staged)
+        torch.cuda.synchronize()
+        return dict(hi=hi, lo=lo, part=part, hi2=hi2, lo2=lo2, part2=part2, act=act, q=q, k=k, v=v, hi3=hi3, lo3=lo3, part3=part3, back=back, h4=h4)
+    monkeypatch.setenv("SED_GEMM_RB", "8")
+    ref = run()
+    monkeypatch.setenv("SED_GEMM_RB", "7")
+    got = run()
+    for name in ref:
+        if name.startswith("part") or name == "back":
+            # (fp32 sums: the two instantiations may add residual + product + bias in another order under -ffast-math)
+            assert torch.allclose(ref[name], got[name], rtol=2e-6, atol=2e-5), name
+        else:
+            assert torch.equal(ref[name], got[name]), name
+
+
 def test_gemm_asymmetric_identity():
     """A = I with an asymmetric B catches transposed C writes (guide rule 16)."""
     K = 128

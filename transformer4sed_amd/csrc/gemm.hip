@@ -2071,6 +2071,8 @@ static int gemm_nt_lnp_impl(const void* A, const void* B, int M, int N, int K, i
     g.bias = bias; g.resF = resF; g.outF = outF; g.outH = (bf16_t*)x16; g.rowpart = rowpart;
     g.auxH = (const bf16_t*)res_hi; g.res_lo = (const bf16_t*)res_lo; g.out_lo = (bf16_t*)out_lo; g.lo8 = lo8;
     if (lo8 && lda == 64 && K > 64) { g.a_slab = 1; g.lda = K; }      // A as [K / 64][M][64] (what sed_gemm_nt_lnc8 writes with ldc = 64)
+    // (slab-major operands are addressed through one 32-bit buffer range / K-tile offset: the whole plane has to stay below 2 GiB)
+    if (g.a_slab && (size_t)M * K * 2 >= (1ull << 31)) return SED_ERR_ARG;
     return launch_gemm<EPI_F32_RESID>(g, 1, stream);
 }
 extern "C" int sed_gemm_nt_lnp(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* bias, const float* resF,
@@ -2092,7 +2094,7 @@ static int gemm_nt_lnc_impl(const void* A, const void* B, int M, int N, int K, i
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.ncols = N;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ksplit = 1; g.alpha = 1.f;
     g.bias = colC; g.outH2 = (bf16_t*)outH2; g.colS = colS; g.rowstat = rowstat; g.a_slab = a_slab;
-    if (a_slab && lda != K) return SED_ERR_ARG;
+    if (a_slab && (lda != K || (size_t)M * K * 2 >= (1ull << 31))) return SED_ERR_ARG;
     if (a_slab && ldc == 64 && N > 64) { g.c_slab = 1; g.ldc = N; }      // output as [N / 64][M][64]
     return launch_gemm<EPI_GELU>(g, 1, stream);
 }
@@ -2148,6 +2150,7 @@ static int gemm_qkv_lnc_impl(const void* A, const void* W, const float* colC, co
     g.bias = colC; g.colS = colS; g.rowstat = rowstat;
     g.q = (bf16_t*)q; g.k = (bf16_t*)k; g.v = (bf16_t*)v;
     g.seq = seq; g.seq_pad = seq_pad; g.heads = heads; g.a_slab = a_slab;
+    if (a_slab && (size_t)M * K * 2 >= (1ull << 31)) return SED_ERR_ARG;
     return launch_gemm<EPI_QKV>(g, 1, stream);
 }
 extern "C" int sed_gemm_qkv_lnc(const void* A, const void* W, const float* colC, const float* colS, const float* rowstat, int M, int K,

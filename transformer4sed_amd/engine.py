@@ -348,9 +348,13 @@ class SedEngine:
         if fold_ok:
             # between folded blocks the residual stream lives as two f16 planes (x16f = hi, which is also the consumers' A operand, + xlo)
             # instead of fp32: a producer then moves 8 bytes per element instead of 10 (csrc/gemm.hip, GemmArgs.res_lo / out_lo)
-            x16f, xlo, partf, statf = E(M, D, dt=F16), E(M, D, dt=torch.uint8 if self.ln_lo8 else F16), E(M, D // 64, 2), E(M, 2)
-            lnp = "sed_gemm_nt_lnp8" if self.ln_lo8 else "sed_gemm_nt_lnp"      # (lnp8: both planes slab-major, read back by the *_lnc8 consumers)
-            qkv_lnc, nt_lnc = ("sed_gemm_qkv_lnc8", "sed_gemm_nt_lnc8") if self.ln_lo8 else ("sed_gemm_qkv_lnc", "sed_gemm_nt_lnc")
+            # (slab-major planes are addressed through one 32-bit buffer range: a plane has to stay below 2 GiB -- M < 1.4 M tokens for the
+            #  stream planes, M < 349 k for the fc1 activation; beyond that the f16 planes / the row-major activation)
+            lo8 = self.ln_lo8 and M * D * 2 < 2 ** 31
+            slab_ok = lo8 and os.environ.get("SED_SLAB_ACT", "1") != "0"
+            x16f, xlo, partf, statf = E(M, D, dt=F16), E(M, D, dt=torch.uint8 if lo8 else F16), E(M, D // 64, 2), E(M, 2)
+            lnp = "sed_gemm_nt_lnp8" if lo8 else "sed_gemm_nt_lnp"      # (lnp8: both planes slab-major, read back by the *_lnc8 consumers)
+            qkv_lnc, nt_lnc = ("sed_gemm_qkv_lnc8", "sed_gemm_nt_lnc8") if lo8 else ("sed_gemm_qkv_lnc", "sed_gemm_nt_lnc")
         planes = False              # the current stream value is in (x16f, xlo) rather than in the fp32 tensor
         for li in range(m.depth):
             p = f"backbone.blocks.{li}."
@@ -385,7 +389,7 @@ class SedEngine:
                          v, None, None, None, None, None, None, None, f16)
                 sp = self.ln_planes
                 # (byte-plane runs: the attention output goes head-major = slab-major into the proj GEMM's A operand)
-                slab_o = self.ln_lo8 and os.environ.get("SED_SLAB_ACT", "1") != "0"
+                slab_o = slab_ok
                 call("sed_mhsa_fwd", q, k, v, o16, lse, Bx, H, N, Npad, f16 | (2 if slab_o else 0))
                 call(lnp, o16, W[p + "attn.proj.weight"].w, M, D, D, 64 if slab_o else D, D, self.P(p + "attn.proj.bias"),
                      None if planes else x_in, x16f if planes else None, xlo if planes else None,
@@ -394,7 +398,7 @@ class SedEngine:
                 call("sed_ln_fold_stats", partf, statf, M, D // 64, D, 1e-6)
                 w1, s1, c1 = self._lnf_image(W, p + "mlp.fc1.weight", p + "mlp.fc1.bias", p + "norm2.weight", p + "norm2.bias")
                 # (byte-plane runs: the fc1 activation goes slab-major from fc1's epilogue into fc2's A operand -- ldc / lda = 64)
-                slab_act = self.ln_lo8 and sp and not (last and not planes) and os.environ.get("SED_SLAB_ACT", "1") != "0"
+                slab_act = slab_ok and sp and not (last and not planes) and M * 4 * D * 2 < 2 ** 31
                 call(nt_lnc, x16f, w1, M, 4 * D, D, D, D, c1, s1, statf, act, 64 if slab_act else 4 * D)
                 # the block's output has an fp32 reader (f_pool, the final norm, a saving block) -> fp32 out; otherwise it stays in planes
                 f32_out = last or li + 1 == m.passt_feature_layer or not sp
