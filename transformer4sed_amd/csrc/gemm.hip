@@ -1468,124 +1468,6 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// "Dual" form (round 4, experiment behind SED_GEMM_DUAL): TWO independent 4-wave workgroups per CU, 128 x 256 tile each (a wave owns all
-// 128 rows x 64 columns: the same acc[8][4] layout as the 8-wave kernel, so its LDS-free epilogues are reused as they are), BK = 32,
-// three 24 KiB operand stages (72 KiB per workgroup).  Purpose: one workgroup's epilogue runs under the other's K loop -- the 8-wave
-// kernel leaves the matrix pipe idle for the whole epilogue (8-24 us per tile at K = 768 against a 14 us K loop).  Only epilogues that
-// need no LDS fit (there is no room for the staging area): the LayerNorm-fold consumers (fused GELU, row-major head split) and the
-// planes -> planes producer.  K loop from the round-3 laboratory (tools/ablate/pp_lab.hip, since removed: 0.76x of the 8-wave loop at
-// 8192^3, 0.91-0.96x on the K = 768 shapes with a trivial epilogue): single software pipeline per wave -- DMA of step s + 2, fragment
-// reads of step s + 1, MFMAs of step s; one barrier per 32-deep step; 64-byte LDS rows, chunk c of row r at c ^ ((3 (r >> 2)) & 3).
-// ---------------------------------------------------------------------------------------------------------------------
-#define D_STAGE 24576
-#define D_LDS (3 * D_STAGE)
-template <int EPI, bool F16, int GB>
-__global__ __launch_bounds__(256, 2) void gemm_nt_dual_kernel(const GemmArgs g) {
-    static_assert((EPI == EPI_GELU && GB == 3) || (EPI == EPI_QKV && GB == 3) || (EPI == EPI_F32_RESID && GB == 6), "LDS-free epilogues only");
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntn = g.N / 256, ntm = (g.M + 127) / 128, nwg = ntm * ntn;
-    const int t = xcd_remap(blockIdx.x, nwg);
-    const int group_size = 8 * ntn, gid = t / group_size, first_m = gid * 8;
-    const int gm = (ntm - first_m) < 8 ? (ntm - first_m) : 8;
-    const int tin = t - gid * group_size;
-    const int m0 = (first_m + tin % gm) * 128, n0 = (tin / gm) * 256;
-    const int ns = g.K / 32;
-    const int rows_a = (g.M - m0) < 128 ? (g.M - m0) : 128;
-    const bool a_slab = g.a_slab != 0;
-    const int a_ld2 = a_slab ? 128 : g.lda * 2;
-    const __amdgpu_buffer_rsrc_t ra = a_slab
-        ? __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)m0 * 64), 0, (unsigned)((size_t)(g.K / BK) * g.M * 128 - (size_t)m0 * 128), 0x00020000)
-        : __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)m0 * g.lda), 0, rows_a * g.lda * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(g.B + (size_t)n0 * g.ldb), 0, 256 * g.ldb * 2, 0x00020000);
-    // DMA pieces (16 rows x 64 B): wave w fetches A pieces 2w, 2w+1 and B pieces 4w .. 4w+3 (its own 64 weight rows, in PP_COL order)
-    const int prow = lane >> 2, pc = lane & 3;
-    const int lchunk = pc ^ ((3 * (prow >> 2)) & 3);
-    int voa[2], vob[4];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) voa[e] = ((2 * wn + e) * 16 + prow) * a_ld2 + lchunk * 16;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) vob[e] = pp_brow_src((4 * wn + e) * 16 + prow) * g.ldb * 2 + lchunk * 16;
-    const int a_kst = g.M * 128;
-#define D_DMA(S_, STG_)                                                                                                   \
-    {                                                                                                                     \
-        const int sob_ = (S_) * 64, soa_ = a_slab ? ((S_) >> 1) * a_kst + ((S_) & 1) * 64 : sob_, sb_ = (STG_) * D_STAGE;  \
-        _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                                     \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(lds3 + sb_ + (2 * wn + e) * 1024), 16, voa[e], soa_, 0, 0); \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                     \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(lds3 + sb_ + 8192 + (4 * wn + e) * 1024), 16, vob[e], sob_, 0, 0); \
-    }
-    f32x4_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const int l15 = lane & 15, lq = lane >> 4;
-    const int cswz = (lq ^ ((3 * (l15 >> 2)) & 3)) << 4;
-    const unsigned lbase = (unsigned)(size_t)lds3;
-    const unsigned abase = lbase + l15 * 64 + cswz, bbase = lbase + 8192 + (wn * 64 + l15) * 64 + cswz;
-    V3Consts<EPI> cc;
-    v3_load_consts<EPI>(cc, g, n0 + wn * 64, lane);
-    s16x8_t fa[2][4], fb[2][4];   // fa[h]: the 4 row blocks of A half h of the current step; fb[set]: the 4 column blocks of a step
-#define D_RD1(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
-#define D_READ_A(H, STG_)                                                                                                 \
-    {                                                                                                                     \
-        const unsigned aa_ = abase + (STG_) * D_STAGE;                                                                    \
-        D_RD1(fa[H][0], aa_, (H) * 4096); D_RD1(fa[H][1], aa_, (H) * 4096 + 1024); D_RD1(fa[H][2], aa_, (H) * 4096 + 2048); D_RD1(fa[H][3], aa_, (H) * 4096 + 3072); \
-    }
-#define D_READ_B(SET, STG_)                                                                                               \
-    {                                                                                                                     \
-        const unsigned bb_ = bbase + (STG_) * D_STAGE;                                                                    \
-        D_RD1(fb[SET][0], bb_, 0); D_RD1(fb[SET][1], bb_, 1024); D_RD1(fb[SET][2], bb_, 2048); D_RD1(fb[SET][3], bb_, 3072); \
-    }
-    // counted LDS wait; ties the fragment registers it covers to the wait so that no consumer is scheduled above it
-#define D_WAIT_AB(CNT, H, SET)                                                                                            \
-    asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                            \
-                 : "+v"(fa[H][0]), "+v"(fa[H][1]), "+v"(fa[H][2]), "+v"(fa[H][3]), "+v"(fb[SET][0]), "+v"(fb[SET][1]), "+v"(fb[SET][2]), "+v"(fb[SET][3]) \
-                 :: "memory");
-#define D_WAIT_A(CNT, H)                                                                                                  \
-    asm volatile("s_waitcnt lgkmcnt(" #CNT ")" : "+v"(fa[H][0]), "+v"(fa[H][1]), "+v"(fa[H][2]), "+v"(fa[H][3]) :: "memory");
-#define D_MFMA(H, SET)                                                                                                    \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                         \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                     \
-            acc[4 * (H) + i][j] = mfma16t<F16>(fb[SET][j], fa[H][i], acc[4 * (H) + i][j]);
-    // one 32-deep step S_ (B fragments in set X; the next step's go to set Y); stage indices st0 (this step), st1, st2 in SGPRs
-#define D_STEP(S_, X, Y)                                                                                                  \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                      \
-    __builtin_amdgcn_s_barrier();                                                                                         \
-    if ((S_) + 2 < ns) D_DMA((S_) + 2, st2)                                                                               \
-    D_READ_A(1, st0)                                                                                                      \
-    D_WAIT_AB(4, 0, X)                                                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                                    \
-    D_MFMA(0, X)                                                                                                          \
-    __builtin_amdgcn_sched_barrier(0);                                                                                    \
-    if ((S_) + 1 < ns) { D_READ_B(Y, st1) D_READ_A(0, st1) D_WAIT_A(8, 1) } else { D_WAIT_A(0, 1) }                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                                    \
-    D_MFMA(1, X)                                                                                                          \
-    __builtin_amdgcn_sched_barrier(0);                                                                                    \
-    { const int t_ = st0; st0 = st1; st1 = st2; st2 = t_; }
-    int st0 = 0, st1 = 1, st2 = 2;
-    D_DMA(0, 0)
-    if (ns > 1) { D_DMA(1, 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); } else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    __builtin_amdgcn_s_barrier();
-    D_READ_B(0, 0) D_READ_A(0, 0)
-    for (int s_ = 0; s_ < ns; s_ += 2) {      // (ns even: K a multiple of 64)
-        D_STEP(s_, 0, 1)
-        D_STEP(s_ + 1, 1, 0)
-    }
-#undef D_DMA
-#undef D_RD1
-#undef D_READ_A
-#undef D_READ_B
-#undef D_WAIT_AB
-#undef D_WAIT_A
-#undef D_MFMA
-#undef D_STEP
-    pp_epilogue<EPI, F16, GB, 8>(g, acc, cc, nullptr, m0, n0 + wn * 64, lane);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // Weight-gradient GEMM in TN form: dW[m, n] += sum_t dY[t, m] * X[t, n] with BOTH operands read in their natural row-major
 // [token][feature] layout -- no transposed operand copies in HBM (the NT kernels need dY^T and X^T: 6.4 ms/step of transposes).
 // The contraction index is the slow dimension of both tiles, so the MFMA fragments (8 consecutive tokens per lane) are columns of
@@ -2045,22 +1927,6 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
                 if (!f16 || g.gbias != nullptr || g.k_wrap != 0 || (g.N & 63)) return SED_ERR_ARG;
                 if (producer ? (g.rowpart == nullptr || g.outH == nullptr || g.rowstat != nullptr)
                              : (g.rowstat == nullptr || g.colS == nullptr || g.rowpart != nullptr)) return SED_ERR_ARG;
-                // SED_GEMM_DUAL (experiment, read per launch; bit 0: head-split consumer, 1: planes -> planes producer, 2: fused-GELU consumer):
-                // the two-workgroups-per-CU form for the epilogues that need no LDS
-                {
-                    const char* du_s = getenv("SED_GEMM_DUAL");
-                    const int du = du_s ? atoi(du_s) : 0;
-                    constexpr int du_bit = EPI == EPI_QKV ? 1 : (EPI == EPI_F32_RESID ? 2 : 4);
-                    const bool du_ok = (du & du_bit) && (!producer || (g.res_lo != nullptr && g.lo8 && g.out_lo != nullptr)) &&
-                                       (EPI != EPI_GELU || g.outH == nullptr) && (EPI != EPI_QKV || (g.qt == nullptr && g.q2 == nullptr));
-                    if (du_ok) {
-                        static bool attrd = false;
-                        constexpr int GBD = producer ? 6 : 3;
-                        if (!attrd) { (void)hipFuncSetAttribute((const void*)gemm_nt_dual_kernel<EPI, true, GBD>, hipFuncAttributeMaxDynamicSharedMemorySize, D_LDS); attrd = true; }
-                        hipLaunchKernelGGL((gemm_nt_dual_kernel<EPI, true, GBD>), dim3((unsigned)(cdiv(g.M, 128) * (g.N / 256))), dim3(256), D_LDS, s, g);
-                        return sed_check_launch();
-                    }
-                }
                 static bool attrl[8] = {false, false, false, false, false, false, false, false};
 #define PP_LN_LAUNCH(GBV, RBV, SLOT)                                                                                     \
                 {                                                                                                         \
