@@ -62,11 +62,32 @@ def lin(a, w, on, R):
     return out
 
 
+def ln_in(x, w, b, R):
+    """The LayerNorm output as the GEMM after it sees it.  Default: f16(LayerNorm(x)) (a LayerNorm kernel writing an f16 image).
+    R["ln_fold"]: the LayerNorm folded into the GEMMs around it (csrc/gemm.hip rowpart / rowstat) -- the GEMM multiplies the f16 image of
+    the RAW stream, statistics from the fp32 values: (f16(x) - mean(x)) rstd(x) gamma + beta; R["stream"] = "lo8": the stream itself is
+    kept as f16 hi + byte lo between the blocks (hi (1 + (q - 128) 2^-18))."""
+    if not R.get("ln_fold"):
+        return h(O._ln(x, w, b, 1e-6), R["enc_act"])
+    mu = x.mean(-1, keepdim=True)
+    rstd = (x.var(-1, unbiased=False, keepdim=True) + 1e-6).rsqrt()
+    return (x.half().float() - mu) * rstd * w + b
+
+
+def stream(x, R):
+    if R.get("stream") != "lo8":
+        return x
+    hi = x.half().float()
+    q = torch.clamp(torch.round((x - hi) / hi * 2.0 ** 18), -128, 127)
+    q = torch.where(hi == 0, torch.zeros_like(q), q)
+    return hi + q * hi * 2.0 ** -18
+
+
 def enc_blocks(x, R):
     layers = []
     for i in range(depth):
         p = f"backbone.blocks.{i}."
-        hh = h(O._ln(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-6), R["enc_act"])
+        hh = ln_in(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], R)
         qkv = lin(hh, sd[p + "attn.qkv.weight"], "qkv" in R["enc_w"], R) + sd[p + "attn.qkv.bias"]
         Bx, N, D = x.shape
         qkv = h(qkv, R["enc_qkv"]).reshape(Bx, N, 3, H, 64).permute(2, 0, 3, 1, 4)
@@ -77,10 +98,10 @@ def enc_blocks(x, R):
         l = pexp.sum(-1, keepdim=True)
         o = (h(pexp, R["enc_p"]) @ v) / l
         o = h(o.permute(0, 2, 1, 3).reshape(Bx, N, D), R["enc_act"])
-        x = x + (lin(o, sd[p + "attn.proj.weight"], "proj" in R["enc_w"], R) + sd[p + "attn.proj.bias"])
-        hh = h(O._ln(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-6), R["enc_act"])
+        x = stream(x + (lin(o, sd[p + "attn.proj.weight"], "proj" in R["enc_w"], R) + sd[p + "attn.proj.bias"]), R)
+        hh = ln_in(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], R)
         a = F.gelu(lin(hh, sd[p + "mlp.fc1.weight"], "fc1" in R["enc_w"], R) + sd[p + "mlp.fc1.bias"])
-        x = x + (lin(h(a, R["enc_act"]), sd[p + "mlp.fc2.weight"], "fc2" in R["enc_w"], R) + sd[p + "mlp.fc2.bias"])
+        x = stream(x + (lin(h(a, R["enc_act"]), sd[p + "mlp.fc2.weight"], "fc2" in R["enc_w"], R) + sd[p + "mlp.fc2.bias"]), R)
         layers.append(x)
     return layers
 
@@ -185,6 +206,15 @@ with torch.no_grad():
         "PRODUCT + per-clip mean correction": dict(enc_w=ALLW, wcorr="mean", enc_act=True, enc_qkv=True, enc_p=True, dec_gemm="split", dec_qk=True, dec_v=True, dec_p=True),
         "PRODUCT": dict(enc_w=ALLW, enc_act=True, enc_qkv=True, enc_p=True, dec_gemm="split", dec_qk=True, dec_v=True, dec_p=True),
     }
+    if os.environ.get("SIM_FOLD"):
+        # would the evaluation path survive the LayerNorm fold (the GEMM reads the f16 image of the RAW stream) and the byte-plane stream?
+        EV = dict(enc_act=True, enc_qkv=True, enc_p=True, dec_gemm="split", dec_qk=True, dec_v=True, dec_p=True)      # exact (two-term) encoder weights
+        cases = {"evaluation path as it is (exact encoder weights, f16(LayerNorm(x)))": EV,
+                 "... with the LayerNorm fold (f16 of the raw stream)": {**EV, "ln_fold": True},
+                 "... with the fold and the byte-plane stream": {**EV, "ln_fold": True, "stream": "lo8"},
+                 "encoder activations alone, f16(LayerNorm(x))": dict(enc_act=True),
+                 "encoder activations alone, folded": dict(enc_act=True, ln_fold=True),
+                 "byte-plane stream alone": dict(stream="lo8")}
     if os.environ.get("SIM_DEC_TERMS"):
         # which operand terms the five context-network GEMMs need: each GEMM alone with one term dropped, against the full split
         DEC = dict(dec_gemm="split", dec_qk=True, dec_v=True, dec_p=True)
