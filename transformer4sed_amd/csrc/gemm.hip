@@ -504,11 +504,44 @@ __device__ __forceinline__ uint4 pp_pack8(f32x2v a0, f32x2v a1, f32x2v b0, f32x2
     return make_uint4(pack2<F16>(a0.x, a0.y), pack2<F16>(a1.x, a1.y), pack2<F16>(b0.x, b0.y), pack2<F16>(b1.x, b1.y));
 }
 
-// per-row choice between two sets of column constants (bv + group-bias row A for rows < bnd, + row B otherwise);
-// the two rows are fetched per 32-column half (16 registers live at a time: this variant must fit beside the 128 accumulators)
+// per-row choice between two sets of column constants (bv + group-bias row A for rows < bnd, + row B otherwise), kept as
+// base = bv + A and delta = B - A (32 registers, as many as one 32-column half of both sets used to take): all four column blocks of a
+// row block are then at hand together and the row leaves through the pair-swapped whole-row stores like every other 16-bit epilogue
 template <bool F16, int MODE, class Sink>
 __device__ __forceinline__ void pp_stage16_gb(const Sink& sink, const f32x4_t (&acc)[8][4], const float (&bv)[4][4], const float* rowA,
                                               const float* rowB, int bnd, int l15, int lq) {
+    float base[4][4], delta[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 a4 = *reinterpret_cast<const float4*>(rowA + PP_COL(j, lq)), b4 = *reinterpret_cast<const float4*>(rowB + PP_COL(j, lq));
+        base[j][0] = bv[j][0] + a4.x; base[j][1] = bv[j][1] + a4.y; base[j][2] = bv[j][2] + a4.z; base[j][3] = bv[j][3] + a4.w;
+        delta[j][0] = b4.x - a4.x; delta[j][1] = b4.y - a4.y; delta[j][2] = b4.z - a4.z; delta[j][3] = b4.w - a4.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool second = i * 16 + l15 >= bnd;
+        uint4 o[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            f32x2v x[2][2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * k + jj;
+                const f32x4_t& a = acc[i][j];
+                x[jj][0] = f32x2v{a[0] + base[j][0] + (second ? delta[j][0] : 0.f), a[1] + base[j][1] + (second ? delta[j][1] : 0.f)};
+                x[jj][1] = f32x2v{a[2] + base[j][2] + (second ? delta[j][2] : 0.f), a[3] + base[j][3] + (second ? delta[j][3] : 0.f)};
+            }
+            o[k] = pp_pack8<F16, MODE>(x[0][0], x[0][1], x[1][0], x[1][1]);
+        }
+        sink.row(i, o[0], o[1]);
+    }
+}
+
+// (the head-split epilogue's form: column constants per 32-column half -- 16 registers live at a time, it has none to spare -- halves
+//  handed to the sink one at a time)
+template <bool F16, int MODE, class Sink>
+__device__ __forceinline__ void pp_stage16_gb_k(const Sink& sink, const f32x4_t (&acc)[8][4], const float (&bv)[4][4], const float* rowA,
+                                                const float* rowB, int bnd, int l15, int lq) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         float cA[2][4], cB[2][4];
@@ -1098,7 +1131,7 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
             if constexpr (GB) {
                 const float *rA, *rB;
                 const int bnd = gb_split(g, mb, rA, rB);
-                pp_stage16_gb<F16, 0>(lsink, acc, bv, rA + nb, rB + nb, bnd, l15, lq);
+                pp_stage16_gb_k<F16, 0>(lsink, acc, bv, rA + nb, rB + nb, bnd, l15, lq);
             } else {
                 pp_stage16<F16, 0, RB>(lsink, acc, bv);
             }
