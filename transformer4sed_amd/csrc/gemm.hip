@@ -1313,7 +1313,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     const int rows_a = (g.M - m0) < TM ? (g.M - m0) : TM;
     // (slab-major A, GemmArgs.a_slab: row pitch 128 bytes, K tile kt at kt * M * 128; rows past M read the next slab -- they only reach
     //  accumulator rows that are never stored -- and nothing is read past the last slab's end)
-    const bool a_slab = (GB == 1 || GB == 2) ? false : g.a_slab != 0;      // (the evaluation-mode variants have no register to spare for it)
+    const bool a_slab = (GB == 1 || GB == 2 || GB == 8) ? false : g.a_slab != 0;      // (the evaluation-mode variants have no register to spare for it)
     const int a_ld2 = a_slab ? 128 : g.lda * 2, a_kst = a_slab ? g.M * 128 : BK * 2;
     const __amdgpu_buffer_rsrc_t ra = a_slab
         ? __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)m0 * 64), 0, (unsigned)((size_t)(g.K / BK) * g.M * 128 - (size_t)m0 * 128), 0x00020000)
@@ -1343,7 +1343,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     }
 #define PP_DMA_R(RA_, RB_, SL, KT)                                                                                        \
     {                                                                                                                     \
-        const int kt_ = (GB == 2 && (KT) >= g.k_wrap) ? (((SL) == 0 || (SL) == 3) ? (KT) - g.k_wrap : (KT) + g.b_skip) : (KT); \
+        const int kt_ = ((GB == 2 || GB == 8) && (KT) >= g.k_wrap) ? (((SL) == 0 || (SL) == 3) ? (KT) - g.k_wrap : (KT) + g.b_skip) : (KT); \
         const int so_ = kt_ * (((SL) == 1 || (SL) == 2) ? BK * 2 : a_kst), st_ = ((KT) & 1) << 15;                        \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? RB_ : RA_, (lds_ptr_t)(lds3 + st_ + ld_[SL][0]), 16, vo[SL][0], so_, 0, 0); \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? RB_ : RA_, (lds_ptr_t)(lds3 + st_ + ld_[SL][1]), 16, vo[SL][1], so_, 0, 0); \
@@ -1985,6 +1985,16 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
             if constexpr (EPI == EPI_F32_RESID || EPI == EPI_GELU || EPI == EPI_QKV) {
                 if (!f16 || (g.gbias != nullptr && g.k_wrap != 0)) return SED_ERR_ARG;
                 static bool attrg[2] = {false, false};
+                if constexpr (EPI == EPI_QKV) {
+                    // two-term weights, row-major q / k / v only (the evaluation passes of the encoder): mode 8 = the two-term K walk with the
+                    // LDS-free head-split epilogue of modes 3 / 4
+                    if (g.k_wrap != 0 && g.qt == nullptr && g.kt == nullptr && g.vt == nullptr && g.q2 == nullptr && g.q2t == nullptr && g.pu == nullptr) {
+                        static bool attr8 = false;
+                        if (!attr8) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr8 = true; }
+                        hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true, 8>), grid3, dim3(512), V3_LDS, s, g);
+                        return sed_check_launch();
+                    }
+                }
                 if (g.k_wrap != 0) {
                     if (!attrg[1]) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attrg[1] = true; }
                     hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true, 2>), grid3, dim3(512), V3_LDS, s, g);
