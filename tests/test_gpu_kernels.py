@@ -221,7 +221,14 @@ def test_gemm_two_term_weights_and_row_group_bias():
         AA = torch.cat([A, A], dim=1).contiguous()
         mat = torch.empty(M, N, device=DEV)
         gemm_nt(AA, W2, ops.EPI_F32_RESID, bias=bias, res=res, outF=mat)
-        assert torch.equal(out, mat)
+        # (the plain residual epilogue stores straight from the accumulators and adds (product + bias) + residual, the two-term variant still
+        #  stages and adds in another order: last-bit differences.  The walk itself is checked bit for bit through the fused-GELU epilogue,
+        #  which is the same code in both variants.)
+        assert maxerr(out, mat) < 2e-6 * float(mat.abs().max())
+        g2 = torch.empty(M, N, dtype=F16, device=DEV); gm = torch.empty(M, N, dtype=F16, device=DEV)
+        gemm_nt(A, W2, ops.EPI_GELU, bias=bias, outH=None, outH2=g2, two_term=True)
+        gemm_nt(AA, W2, ops.EPI_GELU, bias=bias, outH=None, outH2=gm)
+        assert torch.equal(g2, gm)
         ref = (A.double() @ W.double().t() + bias.double() + res.double()).float()
         e2 = maxerr(out, ref)
         one = torch.empty(M, N, device=DEV)
@@ -281,7 +288,7 @@ def test_gemm_layernorm_fold():
     call("sed_gemm_nt_lnp", a16, Wp.to(F16), M, D, D, D, D, bp, res, None, None, x, x16, None, part, D)
     plain = torch.empty(M, D, device=DEV)
     gemm_nt(a16, Wp.to(F16), ops.EPI_F32_RESID, bias=bp, res=res, outF=plain)
-    assert torch.equal(x, plain) and torch.equal(x16, x.to(F16))
+    assert maxerr(x, plain) < 2e-6 * float(plain.abs().max()) and torch.equal(x16, x.to(F16))      # (two kernel variants: another order of the three-term sum)
     sl = x.view(M, D // 64, 64)
     assert maxerr(part[:, :, 0], sl.sum(-1)) < 2e-3 and maxerr(part[:, :, 1], (sl * sl).sum(-1)) < 2e-3 * float((sl * sl).sum(-1).max())
     inplace = res.clone()

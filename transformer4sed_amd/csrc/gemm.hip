@@ -398,6 +398,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
 __device__ __forceinline__ constexpr int PP_COL(int j, int lq) { return 8 * lq + 32 * (j >> 1) + 4 * (j & 1); }
 // LDS row (within the B stage) -> weight row of the tile
 __device__ __forceinline__ int pp_brow_src(int row) { return (row & ~0x1C) | ((row & 0x10) >> 2) | ((row & 0x0C) << 1); }
+// Column order of the kernel variants whose epilogue stores fp32 straight from the accumulators (EPI_F32, the plain EPI_F32_RESID):
+// block j, lane group lq -> columns 32 (j & 1) + 16 (j >> 1) + 4 lq .. + 3.  After the lane-pair swap (pp_pair_swap32) a lane holds, of
+// one row, blocks 2 hk and 2 hk + 1 (hk = l15 >> 3): float4 number 4 hk + lq of the row's first and of its second 128 bytes -- each of the
+// two 16-byte stores (or residual loads) per row is then 8 lanes x 16 B = 128 contiguous bytes, 8 rows per instruction.
+__device__ __forceinline__ constexpr int PP_COL32(int j, int lq) { return 32 * (j & 1) + 16 * (j >> 1) + 4 * lq; }
+__device__ __forceinline__ int pp_brow_src32(int row) { return (row & ~0x30) | ((row & 0x10) << 1) | ((row & 0x20) >> 1); }
 __device__ __forceinline__ void pp_col_consts(float (&bv)[4][4], const float* bias_n, const float* extra, int lq) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1035,6 +1041,93 @@ __device__ __forceinline__ void pp_epilogue_dgelu_direct(const GemmArgs& g, cons
     }
 }
 
+// fp32 pair swap: a0 / a1 = this lane's row, blocks (0, 1) / (2, 3) as 8 floats each -> (row l15 & 7, blocks 2 hk, 2 hk + 1), (row 8 + (l15 & 7), same blocks)
+__device__ __forceinline__ void pp_pair_swap32(float (&a0)[8], float (&a1)[8], bool lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float r = __uint_as_float(pp_ror8(__float_as_uint(lo ? a1[e] : a0[e])));
+        a0[e] = lo ? a0[e] : r;
+        a1[e] = lo ? r : a1[e];
+    }
+}
+// fp32 output (EPI_F32: acc * alpha + bias; plain EPI_F32_RESID: residual + acc + bias, in place or not) straight from the accumulators:
+// residual rows requested two row-block groups ahead in the swapped layout, no LDS.  The staged form cost 18 (fp32 out) / 29 us (read-
+// modify-write) per 256^2 tile.
+template <int EPI, int RB>
+__device__ __forceinline__ void pp_epilogue_f32_direct(const GemmArgs& g, const f32x4_t (&acc)[8][4], int mb, int nb, int lane) {
+    constexpr bool RES = EPI == EPI_F32_RESID;
+    const int lq = lane >> 4;
+    int lrow = lane & 15;
+    asm volatile("" : "+v"(lrow));
+    const bool lo = lrow < 8;
+    const int r8 = lrow & 7;
+    const size_t ocol = (size_t)nb + 16 * (lrow >> 3) + 4 * lq;      // + 32 for the second float4
+    constexpr int NG = (RB + 1) / 2;
+    f32x4_t rw[RES ? NG : 1][2][4];      // [group][row block of the group][row A / row B x first / second float4]
+    auto side = [&](int i, f32x4_t (&r)[4]) {
+        const int mA = mb + 16 * i + r8, mB = mA + 8;
+        const float* pA = g.resF + (size_t)(mA < g.M ? mA : g.M - 1) * g.ldc + ocol;
+        const float* pB = g.resF + (size_t)(mB < g.M ? mB : g.M - 1) * g.ldc + ocol;
+        r[0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(pA));
+        r[1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(pA + 32));
+        r[2] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(pB));
+        r[3] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(pB + 32));
+    };
+    float bv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias != nullptr) b = *reinterpret_cast<const float4*>(g.bias + nb + PP_COL32(j, lq));
+        bv[j][0] = b.x; bv[j][1] = b.y; bv[j][2] = b.z; bv[j][3] = b.w;
+    }
+    if constexpr (RES) {
+#pragma unroll
+        for (int gi = 0; gi < 2 && gi < NG; ++gi)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (2 * gi + i < RB) side(2 * gi + i, rw[gi][i]);
+    }
+    const float alpha = RES ? 1.f : g.alpha;
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = 2 * gi + ii;
+            if (i >= RB) continue;
+            float a0[8], a1[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                a0[e] = __builtin_fmaf(acc[i][e >> 2][e & 3], alpha, bv[e >> 2][e & 3]);
+                a1[e] = __builtin_fmaf(acc[i][2 + (e >> 2)][e & 3], alpha, bv[2 + (e >> 2)][e & 3]);
+            }
+            pp_pair_swap32(a0, a1, lo);
+            if constexpr (RES) {      // ((product + bias) + residual: the variants that still stage add in another order -- last-bit differences)
+                const f32x4_t (&r)[4] = rw[gi][ii];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { a0[e] += r[e >> 2][e & 3]; a1[e] += r[2 + (e >> 2)][e & 3]; }
+            }
+            const int mA = mb + 16 * i + r8;
+            if (mA < g.M) {
+                float* p = g.outF + (size_t)mA * g.ldc + ocol;
+                v3_st<float4>(p, make_float4(a0[0], a0[1], a0[2], a0[3]));
+                v3_st<float4>(p + 32, make_float4(a0[4], a0[5], a0[6], a0[7]));
+            }
+            if (mA + 8 < g.M) {
+                float* p = g.outF + (size_t)(mA + 8) * g.ldc + ocol;
+                v3_st<float4>(p, make_float4(a1[0], a1[1], a1[2], a1[3]));
+                v3_st<float4>(p + 32, make_float4(a1[4], a1[5], a1[6], a1[7]));
+            }
+        }
+        if constexpr (RES) {
+            if (gi + 2 < NG) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    if (2 * (gi + 2) + i < RB) side(2 * (gi + 2) + i, rw[gi + 2][i]);
+            }
+        }
+    }
+}
+
 template <int EPI>
 struct V3Consts {  // per-lane bias values, fetched before the K loop so their latency is off the epilogue's critical path
     static constexpr bool kStaged16 = (EPI == EPI_BF16 || EPI == EPI_GELU);
@@ -1200,6 +1293,10 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
         }
         return;
     }
+    if constexpr ((EPI == EPI_F32 || EPI == EPI_F32_RESID) && GBM == 0) {
+        pp_epilogue_f32_direct<EPI, RB>(g, acc, mb, nb, lane);
+        return;
+    }
     if constexpr (EPI == EPI_DGELU && GBM == 0) {
         pp_epilogue_dgelu_direct<F16, RB>(g, acc, mb, nb, lane);
         return;
@@ -1294,6 +1391,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     // Epilogues that store straight from the accumulators leave the LDS alone: the next tile's first operand stage is requested BEFORE
     // the epilogue (its DMA lands under the stores) and the end-of-tile workgroup barrier goes away.
     constexpr bool DIRECT_EPI = (EPI == EPI_BF16 || EPI == EPI_GELU || (EPI == EPI_QKV && GB >= 3));
+    constexpr bool F32L = (EPI == EPI_F32 || EPI == EPI_F32_RESID) && GB == 0;      // fp32 straight from the accumulators: PP_COL32 column order
     auto tile_mn = [&](int tl_, int& m0_, int& n0_) {
         const int t = xcd_remap(tl_, nwg);
         const int GM = g.group_m;
@@ -1336,7 +1434,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
             const int cl = pch ^ ((row >> 1) & 7);
             const bool is_b = (sl == 1 || sl == 2);
             // LDS row wm * 128 + r of the A stage holds tile row wm * 16 RB + r (r >= 16 RB: a row nobody reads)
-            const int grow = is_b ? pp_brow_src(row) : (row >> 7) * (16 * RB) + (row & 127);
+            const int grow = is_b ? (F32L ? pp_brow_src32(row) : pp_brow_src(row)) : (row >> 7) * (16 * RB) + (row & 127);
             vo[sl][e] = grow * (is_b ? g.ldb * 2 : a_ld2) + cl * 16;
             ld_[sl][e] = (is_b ? 65536 : 0) + rows[sl] * 128;
         }
