@@ -372,10 +372,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
 // flip bit 15 per K tile.  128-byte rows, 16-B chunk c of row r stored at chunk c ^ ((r >> 1) & 7) (applied on the DMA source
 // address): conflict-free for the 16 x 32 fragment reads (lane & 15 = row, lane >> 4 = chunk inside the k-step).
 // Accumulators: acc[i][j], i = 0..7 (16-row blocks), j = 0..3 (16-column blocks); the MFMA operands are issued swapped (B fragment
-// first), so a block holds C^T: lane & 15 = row, register r = column 4 (lane >> 4) + r -> a lane owns 4 CONSECUTIVE columns of
-// one row per block (16-byte fp32 / 8-byte 16-bit staging writes).
+// first), so a block holds C^T: lane & 15 = row, register r = column 4 (lane >> 4) + r of the block's 16 weight rows -> a lane owns 4
+// CONSECUTIVE columns of one row per block.  Which 16 output columns a block's weight rows are is the DMA's choice (round 4): PP_COL /
+// PP_COL32 below place them so that a lane's blocks form 16-byte runs that the epilogues store straight from the registers.
 // ---------------------------------------------------------------------------------------------------------------------
-// ---- staged epilogue ---------------------------------------------------------------------------------------------------
+// ---- staged epilogue (what is left of it after round 4: the fp32 + 16-bit outputs, the head split with transposed copies, the
+//      LayerNorm-fold producers at the ends of a folded run, the evaluation-mode residual GEMMs; everything else is LDS-free) -----------
 // After the K loop each wave owns a private 17 KiB LDS region.  The accumulators are written there as a row-major [rows][64]
 // sub-tile (padded row stride), then read back so that 8 (16-bit) or 16 (fp32) consecutive lanes cover one full output row: every
 // global store / residual load is a run of whole 128- / 256-byte rows instead of 64 different cache lines per instruction.
