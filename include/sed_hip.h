@@ -38,6 +38,11 @@ int sed_logmel_fwd(const float* wav, float* out, uint32_t* maxbits_tmp, const fl
  * y [B,Lout], taps h [ntaps] and alignment (n_pre_pad, n_pre_remove) as scipy.signal.resample_poly defines them (host-built). */
 int sed_resample_poly(const float* x, float* y, const float* h, int B, int L, int Lout, int up, int down, int ntaps,
                       int n_pre_pad, int n_pre_remove, hipStream_t stream);
+/* The same resampler on 16-bit PCM file bodies (round 5, the batched input pipeline data.WavBatchStream -- replaces the per-file
+ * librosa.load + resample of src/preprocess/feats_extraction.py:7-12 / src/utils/resample.py:10-14): x [B,L] int16 zero padded,
+ * lens [B] real sample counts; int16 -> fp32 by 2^-15 inside; y [B,Lout] with zeros from ceil(lens[b] up / down) on (pad_wav). */
+int sed_resample_poly_pcm16(const int16_t* x, const int* lens, float* y, const float* h, int B, int L, int Lout, int up, int down,
+                            int ntaps, int n_pre_pad, int n_pre_remove, hipStream_t stream);
 /* frame_shift + mixup (src/preprocess/data_aug.py:11-28, 75-90); shift [B], perm [B] / cmix [B,2]={c,1-c} nullable */
 int sed_roll_mix(const float* in, float* out, const int* shift, const int* perm, const float* cmix, int B, int F, int T,
                  int clamp01, hipStream_t stream);

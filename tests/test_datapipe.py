@@ -111,3 +111,41 @@ def test_framewise_labeled_dataset_items(tmp_path):
         assert np.array_equal(label.numpy(), want[filename].astype(np.float32))
         assert bool(pad_mask.any()) == (filename == "b.wav")
     assert len(data.FrameWiseLabeledDataset(str(tsv_dir), str(wav_dir), False, enc)[0]) == 4
+
+
+def test_read_pcm16_into_fast_path_and_fallback(tmp_path):
+    """The batched stream's file reader: 16-bit mono bodies are copied verbatim (zero padded / trimmed); other encodings go through
+    read_wav and are requantised; the result always equals read_wav's samples times 32768."""
+    from datapipe_files import write_pcm16
+    rng = np.random.RandomState(0)
+    x = (rng.rand(5000).astype(np.float32) - 0.5)
+    write_pcm16(str(tmp_path / "a.wav"), x, 16000)
+    data.write_wav(tmp_path / "f.wav", x, 16000, float32=True)
+    write_pcm16(str(tmp_path / "st.wav"), np.stack([x, -x], 1).reshape(-1), 16000, channels=2)
+    for name, n_max in (("a.wav", 8000), ("a.wav", 3000), ("f.wav", 8000), ("st.wav", 8000)):
+        row = np.full(n_max, 7, dtype=np.int16)
+        n, sr = data.read_pcm16_into(str(tmp_path / name), row)
+        ref, sr_ref = data.read_wav(str(tmp_path / name))
+        ref = data.to_mono(ref)
+        assert sr == sr_ref == 16000 and n == min(len(ref), n_max)
+        assert np.array_equal(row[:n], np.clip(np.round(ref[:n] * 32768.0), -32768, 32767).astype(np.int16)), name
+        assert not row[n:].any()
+
+
+def test_rank_sharded_sampler_epoch_advances_at_start_and_resumes():
+    """a pass abandoned early must not replay its permutation, and the epoch survives a state_dict round trip."""
+    ds = [torch.utils.data.TensorDataset(torch.arange(12)) for _ in range(2)]
+    def make():
+        return data.RankShardedBatchSampler([torch.utils.data.RandomSampler(d) for d in ds], [2, 2], rank=0, world=1, seed=5)
+    s = make()
+    first = next(iter(s))           # abandoned after one batch
+    second = next(iter(s))
+    assert s.epoch == 2 and first != second
+    full = make()
+    e0 = list(full)
+    e1 = list(full)
+    assert e0[0] == first and e1[0] == second and e0 != e1
+    resumed = make()
+    resumed.load_state_dict(full.state_dict())
+    assert resumed.epoch == 2
+    assert list(resumed) == list(full)      # both walk epoch 2 next

@@ -141,6 +141,48 @@ def test_waveform_modification_resamples_16k_and_prefetcher(tmp_path):
         assert db[0].is_cuda and torch.equal(db[0].cpu(), hb[0]) and torch.equal(db[1].cpu(), hb[1]) and torch.equal(db[2].cpu(), hb[2])
 
 
+def test_wav_batch_stream_vs_scipy_and_item_path(tmp_path):
+    """data.WavBatchStream (pinned int16 staging -> one H2D copy -> sed_resample_poly_pcm16 on a side stream, `depth` batches in flight)
+    against scipy.signal.resample_poly of the quantised samples and against the per-item path (waveform_modification with the device
+    resampler): same clips, same pad masks, zeros past each file's end, short / exact / over-long files, a float32 file through the
+    fallback reader, more batches than ring slots."""
+    from scipy import signal
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from datapipe_files import write_pcm16
+    from transformer4sed_amd import data
+    enc = _enc()
+    rng = np.random.RandomState(11)
+    secs = [10.0, 3.21, 12.5, 0.004, 9.99, 10.0, 6.5, 1.0, 10.0, 2.0]
+    paths = []
+    for i, sec in enumerate(secs):
+        x = (0.8 * (rng.rand(int(sec * 16000)) - 0.5)).astype(np.float32)
+        pth = str(tmp_path / f"c{i}.wav")
+        if i == 6:
+            data.write_wav(pth, x, 16000, float32=True)
+        else:
+            write_pcm16(pth, x, 16000)
+        paths.append(pth)
+    batches = [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 0, 1], [2, 3, 4]]
+    stream = data.WavBatchStream(paths, batches, DEV, depth=2, workers=2, encoder=enc)
+    seen = 0
+    for (wav, pad_mask, idx), want_idx in zip(stream, batches):
+        assert idx == want_idx and wav.shape == (3, 320000) and wav.dtype == torch.float32 and pad_mask.shape == (3, 1000)
+        got = wav.cpu().numpy()
+        for j, i in enumerate(idx):
+            ref, _ = data.read_wav(paths[i])
+            q = np.clip(np.round(ref * 32768.0), -32768, 32767) / 32768.0
+            want = signal.resample_poly(q.astype(np.float64), 2, 1)[:320000]      # (resampled whole, trimmed afterwards: the reference's order)
+            n = len(want)
+            assert np.abs(got[j, :n] - want).max() < 2e-5, (i, np.abs(got[j, :n] - want).max())
+            assert not got[j, n:].any()
+            item_wav, item_pad = data.waveform_modification(paths[i], 320000, enc, resample_device=DEV)
+            assert torch.equal(item_pad, pad_mask[j]), i
+            if i != 6:      # (the float file is requantised to 16 bits by the stream's fallback reader; the item path keeps fp32)
+                assert np.abs(item_wav.numpy() - got[j]).max() < 2e-6, i
+        seen += 1
+    assert seen == len(batches)
+
+
 # ------------------------------------------------------------------------------------------------ bench.py output contract
 def test_bench_json_contract():
     """bench.py prints exactly one JSON object as its LAST stdout line with the fields the driver reads (small model / batch here)."""

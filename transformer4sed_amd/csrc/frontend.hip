@@ -573,3 +573,41 @@ extern "C" int sed_resample_poly(const float* x, float* y, const float* h, int B
                        up, down, ntaps, n_pre_pad, n_pre_remove);
     return sed_check_launch();
 }
+
+// The same filter straight from 16-bit PCM file bodies (the input pipeline's form, data.WavBatchStream): x [B, L] int16 as read from
+// the RIFF data chunks (zero padded to L by the host), lens[b] = samples the file really holds.  The int16 -> fp32 scaling by 2^-15
+// (libsndfile's convention, what the reference's reader yields) happens in the tap loop, outputs at or past ceil(lens[b] up / down) are
+// zero -- the offline tool resamples the file first and pad_wav zero-pads the result afterwards, so the filter's ringing past the
+// file's end never reaches the model.  H2D traffic is the int16 16 kHz body: a quarter of the fp32 32 kHz clip.
+__global__ __launch_bounds__(256) void resample_poly_pcm16_kernel(const short* __restrict__ x, const int* __restrict__ lens,
+                                                                  float* __restrict__ y, const float* __restrict__ h, int L, int Lout,
+                                                                  int up, int down, int ntaps, int n_pre_pad, int n_pre_remove) {
+    extern __shared__ float taps[];
+    for (int i = threadIdx.x; i < ntaps; i += blockDim.x) taps[i] = h[i] * (1.0f / 32768.0f);
+    __syncthreads();
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Lout) return;
+    int len = lens[blockIdx.y];
+    len = len < L ? len : L;
+    const long long nvalid = ((long long)len * up + down - 1) / down;
+    float acc = 0.f;
+    if (n < nvalid) {
+        const short* xb = x + (size_t)blockIdx.y * L;
+        const long long c = (long long)(n + n_pre_remove) * down - n_pre_pad;
+        long long m_hi = c / up;
+        if (m_hi > len - 1) m_hi = len - 1;
+        long long m_lo = (c - (ntaps - 1) + up - 1) / up;
+        if (c - (ntaps - 1) < 0) m_lo = 0;
+        if (m_lo < 0) m_lo = 0;
+        for (long long m = m_lo; m <= m_hi; ++m) acc += (float)xb[m] * taps[(int)(c - m * up)];
+    }
+    y[(size_t)blockIdx.y * Lout + n] = acc;
+}
+extern "C" int sed_resample_poly_pcm16(const int16_t* x, const int* lens, float* y, const float* h, int B, int L, int Lout, int up,
+                                       int down, int ntaps, int n_pre_pad, int n_pre_remove, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (B <= 0 || L <= 0 || Lout <= 0 || up < 1 || down < 1 || ntaps < 1 || ntaps > 8192) return SED_ERR_ARG;
+    hipLaunchKernelGGL(resample_poly_pcm16_kernel, dim3(cdiv(Lout, 256), B), dim3(256), ntaps * sizeof(float), stream,
+                       (const short*)x, lens, y, h, L, Lout, up, down, ntaps, n_pre_pad, n_pre_remove);
+    return sed_check_launch();
+}

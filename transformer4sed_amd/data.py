@@ -308,10 +308,20 @@ class RankShardedBatchSampler(ConcatDatasetBatchSampler):
     def __iter__(self):
         if self.seed is not None:
             self.set_epoch(self.epoch)          # (re)seed for THIS pass: identical on every rank
+        if self._auto_epoch:
+            # advanced when the pass STARTS (after seeding from the current value): a pass abandoned early (break, exception,
+            # max-steps) must not replay its permutation on the next one
+            self.epoch += 1
         for batch in self._global_batches():
             yield batch
-        if self._auto_epoch:
-            self.epoch += 1                     # the next pass reshuffles even if nobody calls set_epoch
+
+    def state_dict(self):
+        """{"epoch": next pass's epoch}: MatSedTrainer.state_dict() stores it when the trainer was given the sampler (`trainer.sampler`),
+        so a resumed run continues the batch order instead of replaying epoch 0."""
+        return {"epoch": int(self.epoch)}
+
+    def load_state_dict(self, sd):
+        self.epoch = int(sd["epoch"])
 
     def _global_batches(self):
         for batch in super().__iter__():
@@ -358,3 +368,143 @@ class DevicePrefetcher:
 
     def __len__(self):
         return len(self.loader)
+
+
+# ----------------------------------------------------------------------------------------------------------------- batched file stream
+def read_pcm16_into(path, out_row):
+    """Body of a 16-bit PCM mono RIFF file copied into `out_row` (int16 numpy view of a pinned staging row, zero padded / trimmed);
+    -> (samples copied, sample rate).  Anything else (other encodings, several channels) takes the general reader and is requantised:
+    the batched stream is the fast path for the DESED layout (16-bit mono files), not a second decoder."""
+    with open(path, "rb") as f:
+        data = f.read()
+    n_max = out_row.shape[0]
+    if data[:4] == b"RIFF" and data[8:12] == b"WAVE" and data[12:16] == b"fmt " and len(data) >= 44:
+        tag, ch, sr, _, _, bits = struct.unpack("<HHIIHH", data[20:36])
+        pos = 20 + struct.unpack("<I", data[16:20])[0]
+        while pos + 8 <= len(data) and data[pos:pos + 4] != b"data":
+            pos += 8 + struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        if tag == 1 and ch == 1 and bits == 16 and pos + 8 <= len(data):
+            size = min(struct.unpack("<I", data[pos + 4:pos + 8])[0], len(data) - pos - 8)
+            n = min(size // 2, n_max)
+            out_row[:n] = np.frombuffer(data, dtype="<i2", count=n, offset=pos + 8)
+            out_row[n:] = 0
+            return n, sr
+    x, sr = read_wav(path)
+    x = to_mono(x)
+    n = min(len(x), n_max)
+    out_row[:n] = np.clip(np.round(x[:n] * 32768.0), -32768, 32767).astype(np.int16)
+    out_row[n:] = 0
+    return n, sr
+
+
+class WavBatchStream:
+    """Files -> device clips, batch-wise: the MI355X-side replacement of the reference's per-item path (6 DataLoader workers each running
+    librosa.load + to_mono + pad_wav, dataset.py:52-74 / feats_extraction.py:7-38, over files resampled offline by src/utils/resample.py).
+
+    Per batch: reader threads copy the 16-bit PCM bodies of `batch` files into one pinned int16 staging block [batch, sr_in * seconds]
+    (zero padded) + their lengths; ONE asynchronous H2D copy of that block on a side stream (320 KB per 10 s clip at 16 kHz, a quarter
+    of the fp32 32 kHz clip the reference moves); `sed_resample_poly_pcm16` turns it into the fp32 [batch, sr_out * seconds] clip batch the
+    frontend takes (int16 scaling, polyphase 16 k -> 32 k, zero past each file's end) on the same side stream.  `depth` batches are in
+    flight, so file reading, the copy and the resampler of batches i+1.. run under the train step of batch i; the consumer's stream waits
+    on the batch's event only.  Yields (wav [batch, sr_out * seconds] fp32 on the device, pad_mask [batch, n_frames] bool on the host
+    or None, indices of the batch's files).
+    """
+
+    def __init__(self, paths, batch_indices, device, sr_in=16000, sr_out=32000, seconds=10, depth=3, workers=2, encoder=None):
+        from concurrent.futures import ThreadPoolExecutor
+        self.paths, self.batches = list(paths), batch_indices
+        self.device = torch.device(device)
+        self.sr_in, self.sr_out, self.seconds, self.depth = sr_in, sr_out, seconds, max(2, depth)
+        # (the staging rows hold a few samples more than `seconds`: an over-long file is resampled first and trimmed afterwards by the
+        #  reference, so the last output samples still see the input just past the cut)
+        g_ = math.gcd(sr_in, sr_out)
+        margin = (10 * max(sr_in, sr_out) // g_ + sr_out // g_ - 1) // (sr_out // g_) + 1      # filter half length in input samples
+        self.L, self.Lout = sr_in * seconds + margin, sr_out * seconds
+        self.encoder = encoder
+        self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
+        self.stream = torch.cuda.Stream(device=self.device)
+        up, down, h, self.n_pre_pad, self.n_pre_remove = resample_filter(sr_out, sr_in)
+        self.up, self.down, self.ntaps = up, down, len(h)
+        self.h = torch.from_numpy(h).to(self.device)
+        self._slots = []
+
+    def _slot(self, i, B):
+        while len(self._slots) <= i:
+            self._slots.append(None)
+        s = self._slots[i]
+        if s is None or s["pcm"].shape[0] != B:
+            s = self._slots[i] = {"pcm": torch.zeros(B, self.L, dtype=torch.int16).pin_memory(),
+                                  "len": torch.zeros(B, dtype=torch.int32).pin_memory(), "ev": None}
+        return s
+
+    def _produce(self, k, idx):
+        """Runs on the coordinator thread: read -> stage -> copy -> resample for batch k; returns (wav, pad_mask, idx, event)."""
+        B = len(idx)
+        s = self._slot(k % self.depth, B)
+        if s["ev"] is not None:
+            s["ev"].synchronize()           # the copy that last read this staging block has finished
+        pcm, lens = s["pcm"].numpy(), s["len"].numpy()
+
+        def load(j):
+            n, sr = read_pcm16_into(self.paths[idx[j]], pcm[j])
+            if sr != self.sr_in:
+                raise ValueError(f"{self.paths[idx[j]]}: sample rate {sr}, the stream was built for {self.sr_in}")
+            lens[j] = n
+        list(self.pool.map(load, range(B)))
+        pad_mask = None
+        if self.encoder is not None:       # pad_wav's mask (feats_extraction.py:29-38) from the file lengths, at the OUTPUT rate
+            n_out = np.minimum((lens.astype(np.int64) * self.up + self.down - 1) // self.down, self.Lout)
+            pad_idx = np.ceil([self.encoder._time_to_frame(n / self.encoder.sr) for n in n_out])
+            pad_mask = torch.arange(self.encoder.n_frames)[None, :] >= torch.from_numpy(pad_idx)[:, None]
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            d_pcm = s["pcm"].to(self.device, non_blocking=True)
+            d_len = s["len"].to(self.device, non_blocking=True)
+            wav = torch.empty(B, self.Lout, dtype=torch.float32, device=self.device)
+            call("sed_resample_poly_pcm16", d_pcm, d_len, wav, self.h, B, self.L, self.Lout, self.up, self.down, self.ntaps,
+                 self.n_pre_pad, self.n_pre_remove)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        s["ev"] = ev
+        return wav, pad_mask, idx, ev
+
+    def __iter__(self):
+        import queue
+        import threading
+        q = queue.Queue(maxsize=self.depth - 1)
+        stop = threading.Event()
+
+        def run():
+            try:
+                for k, idx in enumerate(self.batches):
+                    if stop.is_set():
+                        return
+                    item = self._produce(k, list(idx))
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.1)
+                            break
+                        except queue.Full:
+                            pass
+                q.put(None)
+            except BaseException as e:      # surfaces in the consumer
+                q.put(e)
+        thr = threading.Thread(target=run, daemon=True)
+        thr.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                wav, pad_mask, idx, ev = item
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                wav.record_stream(cur)
+                yield wav, pad_mask, idx
+        finally:
+            stop.set()
+            thr.join(timeout=10)
+
+    def __len__(self):
+        return len(self.batches)

@@ -65,13 +65,17 @@ class GradBucketReducer:
         summed gradient to 8 significand bits, the precision its MFMA operands had anyway.  The image is cast on the compute stream when
         the stage fires, reduced on the collective stream, and written back into the fp32 arena before the optimiser reads it.
         Environment default: SED_DDP_COMM_DTYPE=bf16|fp32.
-        `reserve_cus`: CUs left to the communication kernels while this reducer lives (sed_gemm_set_cu_budget(total - reserve); default
+        `reserve_cus`: CUs left to the communication kernels while this reducer lives -- until `close()` / the end of a `with` block / its
+        destruction restores the full grid (sed_gemm_set_cu_budget(total - reserve) now, (0) then; default
         SED_DDP_RESERVE_CUS or 0).  With the dynamic tile walk of the persistent GEMMs a reserve is not needed for correctness of the
         overlap -- a late workgroup costs nothing (profiles/r4_cu_steal.txt) -- it only avoids queueing workgroups that will find no tile."""
         import os
         self.net, self.opt, self.group = net, optimizer, group
         if comm_dtype is None:
-            comm_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[os.environ.get("SED_DDP_COMM_DTYPE", "fp32")]
+            name = os.environ.get("SED_DDP_COMM_DTYPE", "fp32")
+            if name not in ("bf16", "fp32"):
+                raise ValueError(f"SED_DDP_COMM_DTYPE={name!r}: expected bf16 or fp32")
+            comm_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[name]
         if comm_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("comm_dtype must be torch.float32 or torch.bfloat16")
         self.comm_dtype = comm_dtype
@@ -82,10 +86,12 @@ class GradBucketReducer:
         if reserve_cus is None:
             reserve_cus = int(os.environ.get("SED_DDP_RESERVE_CUS", "0"))
         self.reserve_cus = int(reserve_cus)
+        self._budget_set = False
         if self.reserve_cus > 0 and self.world > 1 and torch.cuda.is_available():
             from .ops import call
             total = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
             call("sed_gemm_set_cu_budget", max(8, total - self.reserve_cus))
+            self._budget_set = True
         # a stage whose slices are smaller than this is not worth a collective of its own: it is carried to the next stage hook (or
         # to the end of backward) and merged with adjacent slices there
         self.min_elems = min_bytes // 4
@@ -158,8 +164,8 @@ class GradBucketReducer:
         arena = self.net._last_grad_arena
         for a, b in self._merge(ranges):
             self.issued.append((a, b))
-            if self.comm_dtype == torch.float32:
-                self._reduce(arena[a:b])
+            if self.comm_dtype == torch.float32 or (self.world == 1 and not self.force):
+                self._reduce(arena[a:b])      # (a single rank exchanges nothing: no bf16 round trip of its own gradient either)
             else:
                 if self._stage is None or self._stage.numel() != arena.numel() or self._stage.device != arena.device:
                     self._stage = torch.empty(arena.numel(), dtype=self.comm_dtype, device=arena.device)
@@ -205,6 +211,29 @@ class GradBucketReducer:
         self.order = []
         self.last_issued, self.issued = self.issued, []
         self.last_stats, self.stats = self.stats, dict(collectives=0, bytes=0)
+
+    def close(self):
+        """Give the GEMMs their full grid back (the CU budget is process-global: a reducer that reserved CUs for the collectives must not
+        leave validation-only or single-GPU code of the same process on the reduced grid) and detach from the model."""
+        if self._budget_set:
+            from .ops import call
+            call("sed_gemm_set_cu_budget", 0)
+            self._budget_set = False
+        if getattr(self.net, "_grad_ready_hook", None) == self.on_stage:
+            self.net._grad_ready_hook = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def sync_buffers(self, src=0):
         """Rank `src`'s BatchNorm running statistics become every rank's (see `broadcast_buffers` for the policy)."""

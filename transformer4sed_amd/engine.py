@@ -122,7 +122,11 @@ class SedEngine:
             # (round 3 shipped the per-clip mean correction as a selectable whole-encoder mode; on the real validation configuration it left
             #  the teacher's posteriors at 9.3e-4 of the 1e-3 bound -- no margin -- so it is no longer a mode.  The correction itself lives on
             #  inside `exact`: fc1, and inputs too small for the 256^2 kernel.)
-            raise ValueError("SED_ENC_WCORR=mean is no longer a selectable mode (9.3e-4 on the validation configuration: no margin); use exact or 0")
+            # launch scripts of round 3 may still export it: run the mode that superseded it instead of failing at construction
+            import warnings
+            warnings.warn(f"SED_ENC_WCORR={self.wcorr} is no longer a selectable mode (9.3e-4 on the validation configuration: no margin); "
+                          "running SED_ENC_WCORR=exact", stacklevel=2)
+            self.wcorr = "exact"
         if self.wcorr not in ("0", "exact"):
             raise ValueError(f"SED_ENC_WCORR={self.wcorr!r}: expected 0 or exact")
         self.wcorr_all = os.environ.get("SED_ENC_WCORR_ALL", "0") != "0"

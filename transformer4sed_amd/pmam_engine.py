@@ -50,6 +50,15 @@ class PmamEngine(SedEngine):
         if not self.split:
             raise RuntimeError("the PMAM path runs its 384-wide context network in split precision (SED_DECODER_SPLIT=1, f16 forward)")
         self.dec_terms2 = False      # (its own context-network schedule below keeps three terms in every GEMM)
+        self._drop_gen = None
+
+    def _dropout_generator(self):
+        """Seed source of the CNN dropout masks: a generator private to this engine (seeded from torch.initial_seed() on first use), so
+        that the process-global CPU generator is advanced only by the draws the reference also makes on it (the augmentation)."""
+        if self._drop_gen is None:
+            self._drop_gen = torch.Generator()
+            self._drop_gen.manual_seed((torch.initial_seed() * 0x9E3779B1 + 0x5ED) % (1 << 63))
+        return self._drop_gen
 
     # ------------------------------------------------------------------ operand images
     def _plan(self, tag, src_shape, dev, fn):
@@ -299,13 +308,15 @@ class PmamEngine(SedEngine):
             torch._foreach_add_([m._buffer_by_name[f"cnn.cnn.batchnorm{i}.num_batches_tracked"] for i in range(nl)], 1)
         gen_masks = None
         if train and m.conv_dropout > 0 and drop_masks is None:
-            # keep-masks of every layer from one launch; the seed comes from torch's CPU generator (reproducible under torch.manual_seed)
+            # keep-masks of every layer from one launch.  The seed comes from a generator of this engine's own (seeded once from
+            # torch.initial_seed(), so runs stay reproducible under torch.manual_seed): the process-global CPU stream is consumed only
+            # where the reference consumes it (the augmentation draws, data_aug.py) -- nn.Dropout draws from the device generator there
             sizes, Hm, Wm = [], T, 128
             for i, a_ in enumerate(self.cnn_aux):
                 sizes.append(B * Hm * Wm * a_["co"])
                 Hm, Wm = Hm // m.cnn_pooling[i][0], Wm // m.cnn_pooling[i][1]
             flat = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
-            call("sed_dropout_mask", flat, flat.numel(), float(m.conv_dropout), int(torch.randint(0, 2 ** 62, (1,)).item()))
+            call("sed_dropout_mask", flat, flat.numel(), float(m.conv_dropout), int(torch.randint(0, 2 ** 62, (1,), generator=self._dropout_generator()).item()))
             gen_masks, off = [], 0
             for n_ in sizes:
                 gen_masks.append(flat[off:off + n_])

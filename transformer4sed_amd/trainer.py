@@ -328,6 +328,9 @@ class MatSedTrainer:
         return {"net": {k: v.detach().cpu().clone() for k, v in self.net.state_dict().items()},
                 "ema_net": None if self.ema_net is None else {k: v.detach().cpu().clone() for k, v in self.ema_net.state_dict().items()},
                 "optimizer": self.optimizer.state_dict(), "scheduler": {"step_num": self.scheduler.step_num},
+                # batch-order state of the rank-sharded sampler (data.RankShardedBatchSampler), when the loop handed it over as
+                # `trainer.sampler`: a resumed run continues with the next epoch's permutation
+                "sampler": self.sampler.state_dict() if getattr(self, "sampler", None) is not None and hasattr(self.sampler, "state_dict") else None,
                 # the MLM mask plan and the dropout masks draw from the DEVICE generator: without it a resumed pretrain / PMAM run
                 # diverges from an uninterrupted one (one state per rank under DDP: every rank saves its own checkpoint shard)
                 "rng": {"python": _r.getstate(), "numpy": np.random.get_state(), "torch": torch.get_rng_state(),
@@ -341,6 +344,8 @@ class MatSedTrainer:
             self.ema_net.load_state_dict(sd["ema_net"], strict=True)
         self.optimizer.load_state_dict(sd["optimizer"])
         self.scheduler.step_num = int(sd["scheduler"]["step_num"])
+        if sd.get("sampler") is not None and getattr(self, "sampler", None) is not None and hasattr(self.sampler, "load_state_dict"):
+            self.sampler.load_state_dict(sd["sampler"])
         if restore_rng and "rng" in sd:
             _r.setstate(sd["rng"]["python"]); np.random.set_state(sd["rng"]["numpy"]); torch.set_rng_state(sd["rng"]["torch"])
             if sd["rng"].get("cuda") is not None and next(self.net.parameters()).is_cuda:
