@@ -3,13 +3,11 @@
 The MI355X clocks to its power budget (MI355X_MICROARCH.md "DVFS give-back"): the MFMA-bound GEMMs of the train step run at 1.6-2.0 GHz
 of the 2.4 GHz maximum, which is what `roofline.frac` against the 2.4 GHz peak pays first.  This module puts the evidence into the bench
 line: a sampler thread reads the amdgpu hwmon files (`freq1_input` = sclk in Hz, `power1_average` / `power1_input` in microwatts) of
-the device every `period` seconds -- two small file reads, no subprocess -- and reports min / mean / max over the timed steps.  Where
-the sysfs files are not exposed it falls back to one `rocm-smi --showclocks --showpower --json` call per sample (slower: ~0.3 s each).
-Nothing here is needed by the product path; a box without either source yields `{"source": None}`."""
+the device every `period` seconds -- two small file reads, no subprocess -- and reports min / mean / max over the timed steps.  The card
+is found by the HIP device's PCI address (a node lists all its GPUs in sysfs whatever the process may use).  Nothing here is needed by
+the product path; a box without the files yields `{"source": None}`."""
 import glob
-import json
 import os
-import subprocess
 import threading
 import time
 
@@ -22,16 +20,30 @@ def _read(path):
         return None
 
 
-def _sysfs_device(index):
-    """hwmon directory of the `index`-th AMD GPU (PCI vendor 0x1002) in card order, or None."""
-    cards = []
-    for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
-        if _read(os.path.join(dev, "vendor")) == "0x1002":
-            cards.append(dev)
-    if index >= len(cards):
+def _pci_address(index):
+    """'dddd:bb:dd.f' of HIP device `index` (torch.cuda device properties), or None."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(index)
+        return "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
         return None
-    hw = sorted(glob.glob(os.path.join(cards[index], "hwmon", "hwmon*")))
-    return hw[0] if hw else None
+
+
+def _sysfs_device(index):
+    """hwmon directory of HIP device `index`: the AMD card (PCI vendor 0x1002) whose sysfs device node is the HIP device's PCI address.
+    A host exposes every GPU of the node in /sys/class/drm (plus one platform card per compute partition) even when the process sees one
+    device -- card order says nothing; without a PCI match nothing is reported rather than another GPU's idle clock."""
+    want = _pci_address(index)
+    if want is None:
+        return None
+    for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        if _read(os.path.join(dev, "vendor")) != "0x1002":
+            continue
+        if os.path.basename(os.path.realpath(dev)).lower() == want:
+            hw = sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))
+            return hw[0] if hw else None
+    return None
 
 
 class GpuSampler:
@@ -44,10 +56,8 @@ class GpuSampler:
         self.source = None
         if self.hw is not None and (_read(os.path.join(self.hw, "freq1_input")) or _read(os.path.join(self.hw, "power1_average"))
                                     or _read(os.path.join(self.hw, "power1_input"))):
-            self.source = "sysfs hwmon (" + self.hw + ")"
-        elif self._smi() is not None:
-            self.source = "rocm-smi --showclocks --showpower --json"
-            self.period = max(self.period, 0.25)
+            self.source = "sysfs hwmon of " + str(_pci_address(index)) + " (freq1_input, power1_input)"
+        # (no rocm-smi fallback: its device index is the node's, not the process's -- it would report another GPU)
 
     # one sample: (sclk MHz or None, power W or None)
     def _sysfs(self):
@@ -55,28 +65,9 @@ class GpuSampler:
         p = _read(os.path.join(self.hw, "power1_average")) or _read(os.path.join(self.hw, "power1_input"))
         return (float(f) / 1e6 if f else None, float(p) / 1e6 if p else None)
 
-    def _smi(self):
-        try:
-            out = subprocess.run(["rocm-smi", "-d", str(self.index), "--showclocks", "--showpower", "--json"], capture_output=True,
-                                 text=True, timeout=5).stdout
-            card = next(iter(json.loads(out).values()))
-        except Exception:
-            return None
-        sclk = power = None
-        for k, v in card.items():
-            kl = k.lower()
-            try:
-                if "sclk clock speed" in kl:
-                    sclk = float(str(v).strip("()").lower().replace("mhz", ""))
-                elif "power" in kl and "(w)" in kl:
-                    power = float(v)
-            except ValueError:
-                pass
-        return None if sclk is None and power is None else (sclk, power)
-
     def _loop(self):
         while not self._stop.is_set():
-            s = self._sysfs() if self.source and self.source.startswith("sysfs") else self._smi()
+            s = self._sysfs()
             if s is not None:
                 self.t.append(time.perf_counter())
                 self.sclk.append(s[0])
