@@ -416,6 +416,26 @@ int sed_proto_bce(const float* logit, const float* protos, const float* labels, 
 int sed_transpose_narrow(const void* in, int in_f16, int R, int C, int ldin, void* outT, int Rpad, float* colsum,
                          hipStream_t stream);
 
+/* ------------------------------------------------------------------ DASM query decoder + dual-stream head (round 5, forward) */
+/* fp32 GEMM on the fp32-input matrix instruction (exact fp32 products / accumulation): C[z][M,N] = act(A[z][M,K] . B[z][N,K]^T + bias[N])
+ * (+ R[z][M,N], same ldc / stride as C; nullable), z < batch with element strides (0 = shared operand); act 0 none, 1 GELU, 2 ReLU;
+ * K % 32 == 0, lda / ldb / strides % 4 == 0, 16-byte aligned A / B.  The precision-critical small linears of the DASM head: nn.Linear in
+ * src/models/detect_any_sound/detect_any_sound.py:76-78,125,138,401-416, the in_proj / out_proj / linear1 / linear2 of
+ * at_adapter.py:36-45, and the per-clip einsum('bqc,bct->bqt') of detect_any_sound.py:394. */
+int sed_gemm_f32_nt(const float* A, const float* B, const float* bias, const float* R, float* C, int M, int N, int K, int lda, int ldb,
+                    int ldc, int batch, int64_t strideA, int64_t strideB, int64_t strideC, int act, hipStream_t stream);
+/* softmax(q k^T / sqrt(head_dim) + mask) v with Nq != Nk, fp32 (torch.nn.MultiheadAttention inside nn.TransformerDecoderLayer,
+ * at_adapter.py:24-32: cross attention of the queries over the patch tokens, self attention among the queries): Q rows
+ * [b * q_batch_stride + i * ldq + h * head_dim] (q_batch_stride 0 = the same queries for every clip), K / V rows [(b * Nk + j) * ld + h *
+ * head_dim], O [B, Nq, ldo]; mask [Nq, Nk] bytes, non-zero = not allowed (nullable); head_dim 32 or 64. */
+int sed_xattn_f32_fwd(const float* Q, const float* K, const float* V, float* O, const uint8_t* mask, int B, int H, int Nq, int Nk,
+                      int head_dim, int ldq, int ldk, int ldv, int ldo, int64_t q_batch_stride, hipStream_t stream);
+/* dual-stream finish (detect_any_sound.py:317-319, 394-404): logits [B,T,Q], at_logit [B,Q], pad_mask [B,T] (nullable) ->
+ * at_out = sigmoid(at_logit) [B,Q] (nullable), strong [B,Q,T] = clamp(pad ? 0 : sigmoid(logit / temp) * at_out, 1e-7, 1),
+ * weak [B,Q] = clamp(sum_t strong^2 / sum_t strong, 1e-7, 1). */
+int sed_dasm_head_fwd(const float* logits, const float* at_logit, const uint8_t* pad_mask, float temp, float* strong, float* weak,
+                      float* at_out, int B, int T, int Q, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1174,6 +1174,80 @@ def gen_val12():
 GENS = dict(val12=gen_val12, augment2=gen_augment2, trajectory=gen_trajectory, pmamflops=gen_pmamflops, frontend=gen_frontend, augment=gen_augment, micro=gen_micro, full=gen_full, full12=gen_full12,
             schedule=gen_schedule, postprocess=gen_postprocess, losses=gen_losses, trainstep=gen_trainstep, trainstep12=gen_trainstep12, full12train=gen_full12_train, winbwd=gen_winbwd, evalpath=gen_evalpath, datapipe=gen_datapipe, pmam=gen_pmam, pmamstep=gen_pmamstep, pmamft=gen_pmamft)
 
+DASM_HEAD = dict(B=2, tdim=5, n_base=8, n_novel=4, qdim=1024, at_layers=2, cnn_t=15)
+
+
+def gen_dasm():
+    """DASM query decoder + dual-stream head (BASELINE.json config #5; src/models/detect_any_sound/detect_any_sound.py:324-399,
+    at_adapter.py:7-50) through the reference's OWN DASM.forward.  The reference's training entries for this model are broken (SURVEY
+    App. B: missing modules, no YAML, CLAP not vendored), so the configuration is this fixture's: decoder_dim 768, 12 heads, two
+    cross-attention-first decoder layers, external 1024-wide query embeddings through the query projector, out_type 'sigmoid'.
+    Case A (`dasm_head`): backbone and CNN replaced by stubs that return synthetic feature maps (6 pooled frames -> T = 60, 60 patch
+    tokens), decoder 'no' -- everything from f_pool on is reference code; inputs of the head proper (frame tokens, SED decoder
+    output) are recorded so that the HIP head can be driven alone.  Open-vocabulary call: 8 base + 4 novel queries with the demo's
+    attention mask, temp 0.5, pad mask; and the closed-set call (learned at_query, no mask, temp 0.1)."""
+    from src.models.detect_any_sound.detect_any_sound import DASM
+    from oracle import dasm_oracle
+    c = DASM_HEAD
+    B, tdim, nb, nn_, qdim = c["B"], c["tdim"], c["n_base"], c["n_novel"], c["qdim"]
+    T, P = (tdim + 1) * 10, 12 * tdim
+    tag = "dasm_head"
+    cnn = dict(n_in_channel=1, activation="cg", conv_dropout=0.5, kernel_size=[3] * 10, padding=[1] * 10, stride=[1] * 10,
+               nb_filters=list(synth.PMAM_FILTERS), pooling=[list(p) for p in synth.PMAM_POOLING])
+    sd_np = synth.dasm_state_dict_np(n_queries=nb, query_dim=qdim, at_layers=c["at_layers"])
+    net = DASM(cnn_param=cnn, backbone_param=dict(embed_dim=768, passt_feature_layer=10, pretrain_model_path=None, lora_config=None),
+               at_param=dict(at_decoder_layer=c["at_layers"], query_projector=True, query_dim=qdim, out_type="sigmoid",
+                             query=torch.from_numpy(sd_np["at_query"]).clone()),
+               decoder="no", decoder_dim=768, num_heads=12, class_num=nb)
+    own = net.state_dict()
+    for k, v in sd_np.items():
+        assert k in own and tuple(own[k].shape) == tuple(v.shape), (k, v.shape, own.get(k, torch.zeros(0)).shape)
+    missing = [k for k in own if k not in sd_np and not k.startswith(("backbone.", "cnn.", "mel_trans."))]
+    assert not missing, missing
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=False)
+    net.eval()
+    L10 = torch.from_numpy(synth.det_uniform(f"{tag}/layer10", (B, 768, P + 2), -1.5, 1.5))
+    FR = torch.from_numpy(synth.det_uniform(f"{tag}/frame", (B, 768, P + 2), -1.5, 1.5))
+    CF = torch.from_numpy(synth.det_uniform(f"{tag}/cnn", (B, 384, c["cnn_t"], 1), -1.0, 1.0))
+
+    class StubBackbone(torch.nn.Module):
+        def forward(self, x):
+            return {"layer10_out": L10, "frame": FR, "f_dim": 12, "t_dim": tdim}
+
+    class StubCnn(torch.nn.Module):
+        def forward(self, x):
+            return CF
+    net.backbone, net.cnn = StubBackbone(), StubCnn()
+    taps = {}
+    net.sed_head.register_forward_hook(lambda m, i, o: taps.__setitem__("x_dec", i[0].detach().clone()))
+    mel = torch.zeros(B, 128, 1000)
+    novel = torch.from_numpy(synth.det_normal(f"{tag}/novel", (nn_, qdim)))
+    novel = novel / novel.norm(dim=-1, keepdim=True)
+    ext = torch.cat([torch.from_numpy(sd_np["at_query"]), novel])
+    tmask = dasm_oracle.att_mask(nb + nn_, nb)
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    pad[1, T - 13:] = True
+    out = {}
+    with torch.no_grad():
+        s, w, o = net(mel, temp_w=0.5, pad_mask=pad, query=ext.clone(), query_type=None, tgt_mask=tmask)
+        out["ov_strong"], out["ov_weak"], out["ov_at"] = t2n(s), t2n(w), t2n(o["at_out"])
+        out["x_dec"] = t2n(taps["x_dec"])
+        s, w, o = net(mel, temp_w=0.1)
+        out["cs_strong"], out["cs_weak"], out["cs_at"] = t2n(s), t2n(w), t2n(o["at_out"])
+    # the checker against the same run (its pin is asserted again, from the committed fixture, by tests/test_dasm_oracle.py)
+    sd_t = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    ft = FR.transpose(1, 2)[:, 2:, :]
+    so, wo, ao, _ = dasm_oracle.dasm_head(sd_t, ft, taps["x_dec"], query=ext, tgt_mask=tmask, temp_w=0.5, pad_mask=pad, n_layers=c["at_layers"])
+    print("oracle vs reference (open vocabulary): strong %.2e weak %.2e at %.2e" % (
+        float((so - torch.from_numpy(out["ov_strong"])).abs().max()), float((wo - torch.from_numpy(out["ov_weak"])).abs().max()),
+        float((ao - torch.from_numpy(out["ov_at"])).abs().max())))
+    out["novel"] = t2n(novel)
+    save(tag, **out)
+
+
+GENS["dasm"] = gen_dasm
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")

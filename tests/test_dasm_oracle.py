@@ -1,0 +1,49 @@
+"""DASM query decoder + dual-stream head (BASELINE.json config #5): the CPU restatement oracle/dasm_oracle.py against outputs of the
+reference's own DASM.forward (tests/golden/dasm_head.npz, recorded by oracle/make_golden.py:gen_dasm).  No GPU needed."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import dasm_oracle  # noqa: E402
+from transformer4sed_amd import synth  # noqa: E402
+
+CFG = dict(B=2, tdim=5, n_base=8, n_novel=4, qdim=1024, at_layers=2)      # oracle/make_golden.py DASM_HEAD
+
+
+def head_inputs(g):
+    c = CFG
+    T, P = (c["tdim"] + 1) * 10, 12 * c["tdim"]
+    sd = {k: torch.from_numpy(v) for k, v in synth.dasm_state_dict_np(n_queries=c["n_base"], query_dim=c["qdim"], at_layers=c["at_layers"]).items()}
+    frame = torch.from_numpy(synth.det_uniform("dasm_head/frame", (c["B"], 768, P + 2), -1.5, 1.5)).transpose(1, 2)[:, 2:, :].contiguous()
+    novel = torch.from_numpy(g["novel"])
+    ext = torch.cat([sd["at_query"], novel])
+    tmask = dasm_oracle.att_mask(c["n_base"] + c["n_novel"], c["n_base"])
+    pad = torch.zeros(c["B"], T, dtype=torch.bool)
+    pad[1, T - 13:] = True
+    return sd, frame, torch.from_numpy(g["x_dec"]), ext, tmask, pad
+
+
+def test_dasm_oracle_vs_reference_forward(golden):
+    g = golden("dasm_head")
+    sd, frame, x_dec, ext, tmask, pad = head_inputs(g)
+    novel = torch.from_numpy(synth.det_normal("dasm_head/novel", (CFG["n_novel"], CFG["qdim"])))
+    assert np.allclose((novel / novel.norm(dim=-1, keepdim=True)).numpy(), g["novel"], atol=1e-7)
+    s, w, a, _ = dasm_oracle.dasm_head(sd, frame, x_dec, query=ext, tgt_mask=tmask, temp_w=0.5, pad_mask=pad, n_layers=CFG["at_layers"])
+    assert s.shape == (2, 12, 60) and w.shape == (2, 12) and a.shape == (2, 12)
+    assert float((s - torch.from_numpy(g["ov_strong"])).abs().max()) < 2e-5
+    assert float((w - torch.from_numpy(g["ov_weak"])).abs().max()) < 1e-5
+    assert float((a - torch.from_numpy(g["ov_at"])).abs().max()) < 1e-5
+    assert float(s[1, :, -13:].max()) == np.float32(1e-7)                     # padded frames: 0 -> clamp(1e-7)
+    # closed set: the learned queries, no attention mask, temperature 0.1, no pad mask
+    s, w, a, _ = dasm_oracle.dasm_head(sd, frame, x_dec, temp_w=0.1, n_layers=CFG["at_layers"])
+    assert float((s - torch.from_numpy(g["cs_strong"])).abs().max()) < 1e-4      # (temperature 0.1: logits / 0.1)
+    assert float((w - torch.from_numpy(g["cs_weak"])).abs().max()) < 2e-5
+    assert float((a - torch.from_numpy(g["cs_at"])).abs().max()) < 1e-5
+    # the novel queries do not disturb the base queries' outputs (what the demo's attention mask is for)
+    s_ov, _, a_ov, _ = dasm_oracle.dasm_head(sd, frame, x_dec, query=ext, tgt_mask=tmask, temp_w=0.1, n_layers=CFG["at_layers"])
+    assert float((a_ov[:, :8] - a).abs().max()) < 1e-5 and float((s_ov[:, :8] - s).abs().max()) < 1e-4

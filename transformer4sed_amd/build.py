@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsed_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "relpos_attention.hip", "norm_elem.hip", "frontend.hip", "pmam.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "relpos_attention.hip", "norm_elem.hip", "frontend.hip", "pmam.hip", "dasm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # -ffast-math (re-association, approximate division / sqrt) only where MFMA operand rounding dominates the error anyway: the GEMM
 # epilogues, the attention softmax and the PMAM branch (16-bit NHWC activations).  The fp32 LayerNorm / pooling / loss / optimizer

@@ -1,0 +1,274 @@
+// DASM (open-vocabulary sound event detection, BASELINE.json config #5) -- the query decoder and the dual-stream head, forward, gfx950.
+//
+// Replaces src/models/detect_any_sound/at_adapter.py:7-50 (nn.TransformerDecoder of cross-attention-first layers over the backbone's
+// patch tokens) and src/models/detect_any_sound/detect_any_sound.py:283-322, 362-389 (query projector, at_head, sed_head,
+// mask_embedding MLP, einsum('bqc,bct->bqt'), sigmoid(x / temp) * at_out, pad mask, clamp, linear-softmax pooling).
+//
+// Everything on the query side is small (Q = 10 .. a few hundred queries per clip against 1188 patch tokens / 1000 frames) and sits
+// directly in front of a sigmoid with temperature 0.1 .. 0.5, i.e. it is precision-critical, not throughput-critical: the kernels here
+// compute in fp32 throughout --
+//   * sed_gemm_f32_nt     C = act(A . B^T + bias) (+ residual), batched, on the fp32-input matrix instruction v_mfma_f32_32x32x2_f32
+//                         (exact fp32 products and accumulation at the fp32 vector rate, without one VALU instruction per FMA and
+//                         with a 64 x 64 output tile fed from LDS: MI355X_MICROARCH.md "FP32-input MFMA");
+//   * sed_xattn_f32_fwd   softmax(q k^T / sqrt(dh) + mask) v for query counts that differ from the key count (cross attention over the
+//                         patch tokens, self attention among the queries with the open-vocabulary mask), one lane per query, K / V
+//                         tiles broadcast from LDS, online softmax over 16-key chunks;
+//   * sed_dasm_head_fwd   the dual-stream finish on the [B, T, Q] logits: sigmoid / temperature, times the clip-level tagging
+//                         probability, pad mask, clamp, transposed store [B, Q, T], linear-softmax pooling.
+#include "common.h"
+#include "../../include/sed_hip.h"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 GEMM, NT form: C[z][m][n] = act(sum_k A[z][m][k] B[z][n][k] + bias[n]) (+ R[z][m][n])
+// 256 threads = 4 waves, 64 x 64 tile, wave (wm, wn) owns a 32 x 32 block = ONE accumulator tile of v_mfma_f32_32x32x2_f32;
+// K tiles of 32 staged k-major in LDS ([k][m], row pitch 65 floats: the 4-scalar transposing writes of a float4 and the 32-lane
+// fragment reads are both bank-conflict free), next tile's global loads in flight during the 16 MFMAs of the current one.
+// ---------------------------------------------------------------------------------------------------------------------
+#define F32_BK 32
+#define F32_LD 65
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int ACT>
+__global__ __launch_bounds__(256) void gemm_f32_nt_kernel(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
+                                                          const float* __restrict__ R, float* __restrict__ C, int M, int N, int K, int lda,
+                                                          int ldb, int ldc, long long sA, long long sB, long long sC) {
+    __shared__ float As[F32_BK * F32_LD], Bs[F32_BK * F32_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    A += (size_t)blockIdx.z * sA;
+    B += (size_t)blockIdx.z * sB;
+    C += (size_t)blockIdx.z * sC;
+    if (R != nullptr) R += (size_t)blockIdx.z * sC;
+    // loader: thread -> (row = tid / 8 (+ 32), k quad = tid % 8) of both operand tiles
+    const int lrow = tid >> 3, lk = (tid & 7) * 4;
+    float4 ra[2], rb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + lrow + 32 * i, n = n0 + lrow + 32 * i;
+            ra[i] = m < M ? *reinterpret_cast<const float4*>(A + (size_t)m * lda + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[i] = n < N ? *reinterpret_cast<const float4*>(B + (size_t)n * ldb + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = lrow + 32 * i;
+            As[(lk + 0) * F32_LD + r] = ra[i].x; As[(lk + 1) * F32_LD + r] = ra[i].y; As[(lk + 2) * F32_LD + r] = ra[i].z; As[(lk + 3) * F32_LD + r] = ra[i].w;
+            Bs[(lk + 0) * F32_LD + r] = rb[i].x; Bs[(lk + 1) * F32_LD + r] = rb[i].y; Bs[(lk + 2) * F32_LD + r] = rb[i].z; Bs[(lk + 3) * F32_LD + r] = rb[i].w;
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int fa = (lane >> 5) * F32_LD + wm * 32 + (lane & 31), fb = (lane >> 5) * F32_LD + wn * 32 + (lane & 31);
+    gload(0);
+    for (int k0 = 0; k0 < K; k0 += F32_BK) {
+        lstore();
+        __syncthreads();
+        if (k0 + F32_BK < K) gload(k0 + F32_BK);
+#pragma unroll
+        for (int ks = 0; ks < F32_BK; ks += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[ks * F32_LD + fa], Bs[ks * F32_LD + fb], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    const int n = n0 + wn * 32 + (lane & 31);
+    if (n >= N) return;
+    const float bn = bias != nullptr ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + mfma32_row(r, lane >> 5);
+        if (m >= M) continue;
+        float v = acc[r] + bn;
+        if (ACT == 1) v = gelu_fast(v);
+        if (ACT == 2) v = fmaxf(v, 0.f);
+        if (R != nullptr) v += R[(size_t)m * ldc + n];
+        C[(size_t)m * ldc + n] = v;
+    }
+}
+
+extern "C" int sed_gemm_f32_nt(const float* A, const float* B, const float* bias, const float* R, float* C, int M, int N, int K, int lda,
+                               int ldb, int ldc, int batch, int64_t strideA, int64_t strideB, int64_t strideC, int act,
+                               hipStream_t stream) {
+    (void)hipGetLastError();
+    if (M <= 0 || N <= 0 || K <= 0 || (K % F32_BK) != 0 || (lda & 3) || (ldb & 3) || batch < 1 || batch > 65535 || act < 0 || act > 2)
+        return SED_ERR_ARG;
+    if ((((uintptr_t)A | (uintptr_t)B) & 15) || ((strideA | strideB) & 3)) return SED_ERR_ARG;
+    const dim3 grid(cdiv(N, 64), cdiv(M, 64), batch);
+    if (act == 0)
+        hipLaunchKernelGGL(gemm_f32_nt_kernel<0>, grid, dim3(256), 0, stream, A, B, bias, R, C, M, N, K, lda, ldb, ldc, (long long)strideA,
+                           (long long)strideB, (long long)strideC);
+    else if (act == 1)
+        hipLaunchKernelGGL(gemm_f32_nt_kernel<1>, grid, dim3(256), 0, stream, A, B, bias, R, C, M, N, K, lda, ldb, ldc, (long long)strideA,
+                           (long long)strideB, (long long)strideC);
+    else
+        hipLaunchKernelGGL(gemm_f32_nt_kernel<2>, grid, dim3(256), 0, stream, A, B, bias, R, C, M, N, K, lda, ldb, ldc, (long long)strideA,
+                           (long long)strideB, (long long)strideC);
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// attention with Nq != Nk, fp32: O[b, i, h*DH + d] = sum_j softmax_j(q_i . k_j / sqrt(DH) + mask_ij) v_j[d]
+// One wave per (64 queries, head, clip): lane = query.  Per 64-key tile the K and V rows (DH floats each, row pitch DH + 4 so that the
+// 16-byte row writes of 8 lanes cover all banks) sit in LDS and are read as broadcasts (every lane the same address); the lane keeps
+// its query (pre-scaled by log2(e) / sqrt(DH)) and its output row in registers.  Online softmax over chunks of 16 keys: one rescale of
+// the output row per chunk.  Q rows / K rows / V rows are addressed through their own leading dimensions, so the packed in_proj outputs
+// ([.., 3 D] self attention, [.., 2 L D] memory projections of all layers) are read in place.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DH, bool MASK>
+__global__ __launch_bounds__(64) void xattn_f32_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ Kp, const float* __restrict__ Vp,
+                                                           float* __restrict__ O, const unsigned char* __restrict__ mask, int Nq, int Nk,
+                                                           int ldq, int ldk, int ldv, int ldo, long long q_bstride) {
+    constexpr int LDK = DH + 4;
+    __shared__ __attribute__((aligned(16))) float Ks[64 * LDK], Vs[64 * LDK];
+    const int lane = threadIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int qi = blockIdx.x * 64 + lane;
+    const int qc = qi < Nq ? qi : Nq - 1;
+    const float sc = 1.4426950408889634f * rsqrtf((float)DH);
+    float q[DH], o[DH];
+    {
+        const float* qp = Q + (size_t)b * q_bstride + (size_t)qc * ldq + h * DH;
+#pragma unroll
+        for (int d = 0; d < DH; d += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(qp + d);
+            q[d] = v.x * sc; q[d + 1] = v.y * sc; q[d + 2] = v.z * sc; q[d + 3] = v.w * sc;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < DH; ++d) o[d] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float* kb = Kp + (size_t)b * Nk * ldk + h * DH;
+    const float* vb = Vp + (size_t)b * Nk * ldv + h * DH;
+    for (int j0 = 0; j0 < Nk; j0 += 64) {
+        __syncthreads();
+        {
+            const int j = j0 + lane;
+            const bool ok = j < Nk;
+            const float* kr = kb + (size_t)(ok ? j : 0) * ldk;
+            const float* vr = vb + (size_t)(ok ? j : 0) * ldv;
+#pragma unroll
+            for (int d = 0; d < DH; d += 4) {
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(Ks + lane * LDK + d) = ok ? *reinterpret_cast<const float4*>(kr + d) : z;
+                *reinterpret_cast<float4*>(Vs + lane * LDK + d) = ok ? *reinterpret_cast<const float4*>(vr + d) : z;
+            }
+        }
+        __syncthreads();
+        const int nj = (Nk - j0) < 64 ? (Nk - j0) : 64;
+        for (int c0 = 0; c0 < nj; c0 += 16) {
+            float s[16];
+            float cmax = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                float acc = 0.f;
+#pragma unroll
+                for (int d = 0; d < DH; d += 4) {
+                    const float4 kv = *reinterpret_cast<const float4*>(Ks + (c0 + c) * LDK + d);
+                    acc = fmaf(q[d], kv.x, acc); acc = fmaf(q[d + 1], kv.y, acc); acc = fmaf(q[d + 2], kv.z, acc); acc = fmaf(q[d + 3], kv.w, acc);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // (keeps the 16 keys' LDS reads from being hoisted into 500 live registers)
+                const int j = j0 + c0 + c;
+                bool dead = j >= Nk;
+                if (MASK) dead = dead || mask[(size_t)qc * Nk + (j < Nk ? j : Nk - 1)] != 0;      // (branch-free: a select, not a jump per key)
+                s[c] = dead ? -INFINITY : acc;
+                cmax = fmaxf(cmax, s[c]);
+            }
+            const float m_new = fmaxf(m_run, cmax);
+            // (a chunk whose keys are all masked for this query leaves m_new = -inf while nothing has been seen: alpha = p = 0 then)
+            const float alpha = m_new == -INFINITY ? 1.f : exp2f(m_run - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                s[c] = m_new == -INFINITY ? 0.f : exp2f(s[c] - m_new);
+                psum += s[c];
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int d = 0; d < DH; ++d) o[d] *= alpha;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+#pragma unroll
+                for (int d = 0; d < DH; d += 4) {
+                    const float4 vv = *reinterpret_cast<const float4*>(Vs + (c0 + c) * LDK + d);
+                    o[d] = fmaf(s[c], vv.x, o[d]); o[d + 1] = fmaf(s[c], vv.y, o[d + 1]); o[d + 2] = fmaf(s[c], vv.z, o[d + 2]); o[d + 3] = fmaf(s[c], vv.w, o[d + 3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if (qi < Nq) {
+        const float inv = 1.0f / l_run;      // (a query with every key masked: 0 / 0 = NaN, like torch's softmax over an all -inf row)
+        float* op = O + ((size_t)b * Nq + qi) * ldo + h * DH;
+#pragma unroll
+        for (int d = 0; d < DH; d += 4) *reinterpret_cast<float4*>(op + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+    }
+}
+
+extern "C" int sed_xattn_f32_fwd(const float* Q, const float* K, const float* V, float* O, const uint8_t* mask, int B, int H, int Nq, int Nk,
+                                 int head_dim, int ldq, int ldk, int ldv, int ldo, int64_t q_batch_stride, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || (head_dim != 32 && head_dim != 64) || ((ldq | ldk | ldv | ldo) & 3) || B > 65535 || H > 65535)
+        return SED_ERR_ARG;
+    if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) return SED_ERR_ARG;
+    const dim3 grid(cdiv(Nq, 64), H, B);
+#define XATTN_LAUNCH(DH_, MK_) hipLaunchKernelGGL((xattn_f32_fwd_kernel<DH_, MK_>), grid, dim3(64), 0, stream, Q, K, V, O, mask, Nq, Nk, ldq, ldk, ldv, ldo, (long long)q_batch_stride)
+    if (head_dim == 64) { if (mask != nullptr) XATTN_LAUNCH(64, true); else XATTN_LAUNCH(64, false); }
+    else { if (mask != nullptr) XATTN_LAUNCH(32, true); else XATTN_LAUNCH(32, false); }
+#undef XATTN_LAUNCH
+    return sed_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dual-stream finish (detect_any_sound.py:394-404): logits [B, T, Q] -> strong [B, Q, T] = clamp(pad ? 0 : sigmoid(logit / temp) * at[b, q],
+// 1e-7, 1) through a 32 x 32 LDS transpose (coalesced on both sides), at[b, q] = sigmoid(at_logit[b, q]);
+// weak [B, Q] = clamp(sum_t s^2 / sum_t s, 1e-7, 1).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dasm_head_kernel(const float* __restrict__ logits, const float* __restrict__ at_logit,
+                                                        const unsigned char* __restrict__ pad, float inv_temp, float* __restrict__ strong,
+                                                        float* __restrict__ at_out, int T, int Qn) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.y * 32, q0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = t0 + ty + 8 * i, qn = q0 + tx;
+        float v = 0.f;
+        if (t < T && qn < Qn) {
+            const float a = sigmoidf_(at_logit[(size_t)b * Qn + qn]);
+            const bool masked = pad != nullptr && pad[(size_t)b * T + t] != 0;
+            v = masked ? 0.f : sigmoidf_(logits[((size_t)b * T + t) * Qn + qn] * inv_temp) * a;
+            v = fminf(fmaxf(v, 1e-7f), 1.0f);
+            if (t == 0 && at_out != nullptr) at_out[(size_t)b * Qn + qn] = a;
+        }
+        tile[ty + 8 * i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int qn = q0 + ty + 8 * i, t = t0 + tx;
+        if (t < T && qn < Qn) strong[((size_t)b * Qn + qn) * T + t] = tile[tx][ty + 8 * i];
+    }
+}
+__global__ __launch_bounds__(256) void dasm_weak_kernel(const float* __restrict__ strong, float* __restrict__ weak, int T) {
+    __shared__ float ra[4], rb[4];
+    const float* s = strong + (size_t)blockIdx.x * T;
+    float a = 0.f, bs = 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) { const float v = s[t]; a += v * v; bs += v; }
+    a = wave_sum(a); bs = wave_sum(bs);
+    if ((threadIdx.x & 63) == 0) { ra[threadIdx.x >> 6] = a; rb[threadIdx.x >> 6] = bs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float w = (ra[0] + ra[1] + ra[2] + ra[3]) / (rb[0] + rb[1] + rb[2] + rb[3]);
+        weak[blockIdx.x] = (w != w) ? w : fminf(fmaxf(w, 1e-7f), 1.0f);
+    }
+}
+extern "C" int sed_dasm_head_fwd(const float* logits, const float* at_logit, const uint8_t* pad_mask, float temp, float* strong, float* weak,
+                                 float* at_out, int B, int T, int Q, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (B <= 0 || T <= 0 || Q <= 0 || B > 65535 || !(temp > 0.f)) return SED_ERR_ARG;
+    hipLaunchKernelGGL(dasm_head_kernel, dim3(cdiv(Q, 32), cdiv(T, 32), B), dim3(256), 0, stream, logits, at_logit, pad_mask, 1.0f / temp, strong,
+                       at_out, T, Q);
+    hipLaunchKernelGGL(dasm_weak_kernel, dim3(B * Q), dim3(256), 0, stream, (const float*)strong, weak, T);
+    return sed_check_launch();
+}

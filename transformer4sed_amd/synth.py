@@ -242,6 +242,80 @@ def pmam_state_dict_np(tag="pmam0", **kw):
 
 
 # --------------------------------------------------------------------------------------------------
+# DASM (open-vocabulary model, BASELINE.json config #5) state_dict -- names / shapes of src/models/detect_any_sound/detect_any_sound.py:
+# 69-78 (joint layers), 80-125 (SED decoder, sed_head, mask_embedding_layer), 127-171 (query projector, learnable / external queries),
+# 173-188 (at_decoder = nn.TransformerDecoder of CrossAttentionFirstDecoderLayer, at_adapter.py:36-45; at_head); the backbone, CNN
+# branch, attention pooling and Transformer-XL decoder reuse the PaSST_CNN tensors under DASM's names (`sed_decoder.` for `decoder.`).
+# --------------------------------------------------------------------------------------------------
+def dasm_head_param_shapes(decoder_dim=768, embed_dim=768, at_layers=2, query_dim=1024, n_queries=12, expand=1):
+    Dd, D = decoder_dim, embed_dim
+    s = {"at_projector.weight": (Dd, D), "at_projector.bias": (Dd,),
+         "query_projector.0.weight": (Dd, query_dim), "query_projector.0.bias": (Dd,), "at_query": (n_queries, query_dim),
+         "sed_head.weight": (Dd, Dd), "sed_head.bias": (Dd,),
+         "at_head.layers.0.weight": (Dd, Dd), "at_head.layers.0.bias": (Dd,), "at_head.layers.1.weight": (1, Dd), "at_head.layers.1.bias": (1,)}
+    for i in range(3):
+        s[f"mask_embedding_layer.layers.{i}.weight"] = (Dd, Dd)
+        s[f"mask_embedding_layer.layers.{i}.bias"] = (Dd,)
+    for l in range(at_layers):
+        p = f"at_decoder.decoder.layers.{l}."
+        for att in ("self_attn", "multihead_attn"):
+            s[p + att + ".in_proj_weight"] = (3 * Dd, Dd)
+            s[p + att + ".in_proj_bias"] = (3 * Dd,)
+            s[p + att + ".out_proj.weight"] = (Dd, Dd)
+            s[p + att + ".out_proj.bias"] = (Dd,)
+        s[p + "linear1.weight"] = (Dd * expand, Dd)
+        s[p + "linear1.bias"] = (Dd * expand,)
+        s[p + "linear2.weight"] = (Dd, Dd * expand)
+        s[p + "linear2.bias"] = (Dd,)
+        for n in ("norm1", "norm2", "norm3"):
+            s[p + n + ".weight"] = (Dd,)
+            s[p + n + ".bias"] = (Dd,)
+    return s
+
+
+def dasm_joint_param_shapes(decoder_dim=768, embed_dim=768, cnn_dim=384):
+    Dd, D = decoder_dim, embed_dim
+    return {"norm_before_pool.weight": (D,), "norm_before_pool.bias": (D,), "norm_after_merge.weight": (Dd,), "norm_after_merge.bias": (Dd,),
+            "f_pool_module.f_att_token": (1, 1, D), "f_pool_module.frequency_att.in_proj_weight": (3 * D, D),
+            "f_pool_module.frequency_att.in_proj_bias": (3 * D,), "f_pool_module.frequency_att.out_proj.weight": (D, D),
+            "f_pool_module.frequency_att.out_proj.bias": (D,), "cnn_projector.weight": (Dd, cnn_dim), "cnn_projector.bias": (Dd,),
+            "transformer_projector.weight": (Dd, D), "transformer_projector.bias": (Dd,), "merge_weight": (1,)}
+
+
+def dasm_state_dict_np(tag="dasm0", with_joint=True, **kw):
+    """Deterministic 'active' weights of the DASM head (and, with_joint, of the joint layers in front of it): O(1) activations through
+    two decoder layers, non-trivial LayerNorm affines, attention logits of a few units, queries of CLAP-like norm (unit rows)."""
+    shapes = dasm_head_param_shapes(**kw)
+    if with_joint:
+        shapes.update(dasm_joint_param_shapes(kw.get("decoder_dim", 768), kw.get("embed_dim", 768)))
+    out = {}
+    for name, shp in shapes.items():
+        key = f"{tag}/{name}"
+        if name == "merge_weight":
+            w = np.asarray([0.5], dtype=np.float32)
+        elif name == "at_query":
+            w = det_normal(key, shp)
+            w = w / np.linalg.norm(w, axis=-1, keepdims=True)
+        elif "norm" in name and name.endswith(".weight"):
+            w = 1.0 + 0.2 * det_uniform(key, shp)
+        elif name.endswith(".bias") or name.endswith("in_proj_bias"):
+            w = 0.1 * det_uniform(key, shp)
+        elif name.endswith("_token"):
+            w = 0.5 * det_uniform(key, shp)
+        elif name == "query_projector.0.weight":
+            w = det_uniform(key, shp) * (3.0 * math.sqrt(3.0))          # unit-norm query rows -> O(1) projected components
+        elif name.startswith("mask_embedding_layer.layers.2."):
+            # the frame logits are 768-term dot products of the mask embedding with sed_head's output, divided by a temperature of
+            # 0.1 .. 0.5: a small last layer keeps them at a few units, so that the posteriors exercise the sigmoid instead of saturating
+            w = det_uniform(key, shp) * (0.1 * math.sqrt(3.0 / shp[-1]) if name.endswith("weight") else 0.01)
+        else:
+            gain = 1.6 if "in_proj" in name else 1.0
+            w = det_uniform(key, shp) * (gain * math.sqrt(3.0 / shp[-1]))
+        out[name] = np.asarray(w, dtype=np.float32)
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
 # DESED-shaped synthetic clips (SURVEY.md section 8(d) "Synthetic inputs")
 # --------------------------------------------------------------------------------------------------
 def synth_wav(n_clips: int, n_samples: int = 320000, seed: int = 1000) -> np.ndarray:
