@@ -68,10 +68,11 @@ from src.preprocess.dataset import StronglyLabeledDataset
 from src.models.lora.layers import LoRALayer
 from src.models.lora import mark_only_lora_as_trainable
 from src.models.cnn_transformer.passt_cnn import PaSST_CNN
-import transformer4sed_amd.passt_cnn as PC, transformer4sed_amd.pmam_trainer as PT
+from src.models.detect_any_sound.detect_any_sound import DASM
+import transformer4sed_amd.passt_cnn as PC, transformer4sed_amd.pmam_trainer as PT, transformer4sed_amd.dasm as DM
 out["checkout"] = [MSELoss.origin == "ref", compute_psds_from_scores() == "ref-psds", log_sedeval_metrics() == "ref-sedeval",
                    StronglyLabeledDataset.origin == "ref", Encoder.__module__ == "src.codec.encoder", LoRALayer.__module__ == "src.models.lora.layers",
-                   mark_only_lora_as_trainable is PT.mark_only_lora_as_trainable, PaSST_CNN is PC.PaSST_CNN]
+                   mark_only_lora_as_trainable is PT.mark_only_lora_as_trainable, PaSST_CNN is PC.PaSST_CNN, DASM is DM.DASM]
 out["decoder_still_lazy"] = not marked()
 import src.codec.decoder as D
 out["maestro"] = D.decode_maestro()          # any other name of the reference module: loaded from the checkout now

@@ -105,3 +105,48 @@ def test_dasm_head_full_size_vs_oracle(B, Q):
     assert s.shape == (B, Q, T)
     assert float((m.cpu() - mo).abs().max()) < 1e-4
     assert float((s.cpu() - so).abs().max()) < 1e-4 and float((w.cpu() - wo).abs().max()) < 1e-4 and float((a.cpu() - ao).abs().max()) < 1e-5
+
+
+def test_dasm_full_model_vs_reference(golden):
+    """The whole DASM model (transformer4sed_amd.dasm.DASM: PaSST + CNN trunk of the PMAM engine, norm_after_merge, Transformer-XL SED decoder,
+    query decoder, dual-stream head) against the reference class's forward (tests/golden/dasm_full.npz): open-vocabulary call with 8 base +
+    4 novel queries, the demo's attention mask, temperature 0.5, pad mask.  Loads a state_dict under the reference's key names."""
+    from oracle import dasm_oracle
+    from transformer4sed_amd.dasm import DASM
+    g = golden("dasm_full")
+    nb, nn_, qdim = 8, 4, 1024
+    cnn = dict(n_in_channel=1, activation="cg", conv_dropout=0.5, kernel_size=[3] * 10, padding=[1] * 10, stride=[1] * 10,
+               nb_filters=list(synth.PMAM_FILTERS), pooling=[list(p) for p in synth.PMAM_POOLING])
+    sd = synth.dasm_full_state_dict_np(n_queries=nb, query_dim=qdim)
+    sd["sed_head.bias"] = g["sed_head_bias"]             # the fixture's one calibrated input (oracle/make_golden.py:gen_dasm_full)
+    net = DASM(cnn_param=cnn, backbone_param=dict(embed_dim=768, passt_feature_layer=10, pretrain_model_path=None, lora_config=None),
+               at_param=dict(at_decoder_layer=2, query_projector=True, query_dim=qdim, out_type="sigmoid", query=torch.zeros(nb, qdim)),
+               decoder="transformerXL", decoder_layer_num=3, decoder_dim=768, num_heads=12, class_num=nb)
+    own = net.state_dict()
+    assert set(own) - {k for k in own if k.startswith("mel_trans.")} == set(sd), set(own) ^ set(sd)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+    net = net.to(DEV).eval()
+    mel = torch.from_numpy(synth.det_uniform("dasm_full/mel", (1, 128, 1000), -1.2, 1.2)).to(DEV)
+    ext = torch.cat([torch.from_numpy(sd["at_query"]), torch.from_numpy(g["novel"])])
+    tmask = dasm_oracle.att_mask(nb + nn_, nb)
+    pad = torch.zeros(1, 1000, dtype=torch.bool)
+    pad[0, 930:] = True
+    with torch.no_grad():
+        s, w, o = net(mel, temp_w=0.5, pad_mask=pad.to(DEV), query=ext.to(DEV), tgt_mask=tmask.to(DEV))
+    assert s.shape == (1, 12, 1000) and w.shape == (1, 12) and o["at_out"].shape == (1, 12)
+    es = float((s[:, :, ::5].cpu() - torch.from_numpy(g["strong"])).abs().max())
+    ew = float((w.cpu() - torch.from_numpy(g["weak"])).abs().max())
+    ea = float((o["at_out"].cpu() - torch.from_numpy(g["at_out"])).abs().max())
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/dasm_errors.log", "a") as f:
+        f.write(f"DASM full model vs reference: strong {es:.3e} weak {ew:.3e} at_out {ea:.3e}\n")
+    assert es < 1e-3 and ew < 1e-3 and ea < 1e-3, (es, ew, ea)      # BASELINE.json: 1e-3 on frame posteriors
+    # B = 3 with the clip repeated: batch invariance of the whole path, and the closed-set call (learned queries)
+    with torch.no_grad():
+        s3, w3, o3 = net(mel.expand(3, -1, -1).contiguous(), temp_w=0.5, pad_mask=pad.expand(3, -1).contiguous().to(DEV), query=ext.to(DEV),
+                         tgt_mask=tmask.to(DEV))
+        sc, wc, oc = net(mel, temp_w=0.5)
+    assert float((s3 - s).abs().max()) < 2e-4 and float((o3["at_out"] - o["at_out"]).abs().max()) < 2e-4
+    assert sc.shape == (1, nb, 1000) and float((oc["at_out"] - o["at_out"][:, :nb]).abs().max()) < 2e-4
+    with pytest.raises(NotImplementedError):
+        net(mel, temp_w=0.5)          # outside no_grad: the inference path refuses instead of silently dropping gradients

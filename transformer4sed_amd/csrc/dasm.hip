@@ -11,8 +11,8 @@
 //                         (exact fp32 products and accumulation at the fp32 vector rate, without one VALU instruction per FMA and
 //                         with a 64 x 64 output tile fed from LDS: MI355X_MICROARCH.md "FP32-input MFMA");
 //   * sed_xattn_f32_fwd   softmax(q k^T / sqrt(dh) + mask) v for query counts that differ from the key count (cross attention over the
-//                         patch tokens, self attention among the queries with the open-vocabulary mask), one lane per query, K / V
-//                         tiles broadcast from LDS, online softmax over 16-key chunks;
+//                         patch tokens, self attention among the queries with the open-vocabulary mask), one lane per query, four
+//                         waves splitting the key tiles, K / V tiles broadcast from LDS, online softmax over 16-key chunks;
 //   * sed_dasm_head_fwd   the dual-stream finish on the [B, T, Q] logits: sigmoid / temperature, times the clip-level tagging
 //                         probability, pad mask, clamp, transposed store [B, Q, T], linear-softmax pooling.
 #include "common.h"
@@ -109,19 +109,26 @@ extern "C" int sed_gemm_f32_nt(const float* A, const float* B, const float* bias
 
 // ---------------------------------------------------------------------------------------------------------------------
 // attention with Nq != Nk, fp32: O[b, i, h*DH + d] = sum_j softmax_j(q_i . k_j / sqrt(DH) + mask_ij) v_j[d]
-// One wave per (64 queries, head, clip): lane = query.  Per 64-key tile the K and V rows (DH floats each, row pitch DH + 4 so that the
+// One workgroup per (64 queries, head, clip): lane = query, the four waves take every fourth key tile each.  Per 64-key tile the K and V rows (DH floats each, row pitch DH + 4 so that the
 // 16-byte row writes of 8 lanes cover all banks) sit in LDS and are read as broadcasts (every lane the same address); the lane keeps
 // its query (pre-scaled by log2(e) / sqrt(DH)) and its output row in registers.  Online softmax over chunks of 16 keys: one rescale of
 // the output row per chunk.  Q rows / K rows / V rows are addressed through their own leading dimensions, so the packed in_proj outputs
 // ([.., 3 D] self attention, [.., 2 L D] memory projections of all layers) are read in place.
 // ---------------------------------------------------------------------------------------------------------------------
+#define XA_WAVES 4
 template <int DH, bool MASK>
-__global__ __launch_bounds__(64) void xattn_f32_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ Kp, const float* __restrict__ Vp,
-                                                           float* __restrict__ O, const unsigned char* __restrict__ mask, int Nq, int Nk,
-                                                           int ldq, int ldk, int ldv, int ldo, long long q_bstride) {
+__global__ __launch_bounds__(64 * XA_WAVES) void xattn_f32_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ Kp,
+                                                                      const float* __restrict__ Vp, float* __restrict__ O,
+                                                                      const unsigned char* __restrict__ mask, int Nq, int Nk, int ldq, int ldk,
+                                                                      int ldv, int ldo, long long q_bstride) {
+    // Four waves share the 64 queries of the workgroup and split the KEY tiles between them (wave w takes tiles w, w + 4, ...: with
+    // ~300 workgroups per launch a single wave per CU would leave every LDS / FMA latency exposed); their partial (max, sum, output row)
+    // triples are merged through LDS at the end -- the usual log-sum-exp combination.
     constexpr int LDK = DH + 4;
-    __shared__ __attribute__((aligned(16))) float Ks[64 * LDK], Vs[64 * LDK];
-    const int lane = threadIdx.x, h = blockIdx.y, b = blockIdx.z;
+    extern __shared__ __attribute__((aligned(16))) float xa_lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = blockIdx.y, b = blockIdx.z;
+    float* Ks = xa_lds + wave * (2 * 64 * LDK);
+    float* Vs = Ks + 64 * LDK;
     const int qi = blockIdx.x * 64 + lane;
     const int qc = qi < Nq ? qi : Nq - 1;
     const float sc = 1.4426950408889634f * rsqrtf((float)DH);
@@ -139,42 +146,45 @@ __global__ __launch_bounds__(64) void xattn_f32_fwd_kernel(const float* __restri
     float m_run = -INFINITY, l_run = 0.f;
     const float* kb = Kp + (size_t)b * Nk * ldk + h * DH;
     const float* vb = Vp + (size_t)b * Nk * ldv + h * DH;
-    for (int j0 = 0; j0 < Nk; j0 += 64) {
-        __syncthreads();
+    for (int j0 = wave * 64; j0 < Nk; j0 += 64 * XA_WAVES) {
         {
-            const int j = j0 + lane;
-            const bool ok = j < Nk;
-            const float* kr = kb + (size_t)(ok ? j : 0) * ldk;
-            const float* vr = vb + (size_t)(ok ? j : 0) * ldv;
+            // rows past the end re-read the last key (their scores are masked below, their V rows meet p = 0): plain loads, no selects
+            const int j = (j0 + lane) < Nk ? (j0 + lane) : Nk - 1;
+            const float* kr = kb + (size_t)j * ldk;
+            const float* vr = vb + (size_t)j * ldv;
+            float4 kreg[DH / 4], vreg[DH / 4];
 #pragma unroll
-            for (int d = 0; d < DH; d += 4) {
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(Ks + lane * LDK + d) = ok ? *reinterpret_cast<const float4*>(kr + d) : z;
-                *reinterpret_cast<float4*>(Vs + lane * LDK + d) = ok ? *reinterpret_cast<const float4*>(vr + d) : z;
+            for (int d = 0; d < DH / 4; ++d) { kreg[d] = reinterpret_cast<const float4*>(kr)[d]; vreg[d] = reinterpret_cast<const float4*>(vr)[d]; }
+            __builtin_amdgcn_wave_barrier();      // (the tile buffers are private to the wave: no workgroup barrier)
+#pragma unroll
+            for (int d = 0; d < DH / 4; ++d) {
+                *reinterpret_cast<float4*>(Ks + lane * LDK + 4 * d) = kreg[d];
+                *reinterpret_cast<float4*>(Vs + lane * LDK + 4 * d) = vreg[d];
             }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        __syncthreads();
         const int nj = (Nk - j0) < 64 ? (Nk - j0) : 64;
         for (int c0 = 0; c0 < nj; c0 += 16) {
             float s[16];
             float cmax = -INFINITY;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                float acc = 0.f;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;      // four independent chains: a single one is latency-bound
 #pragma unroll
                 for (int d = 0; d < DH; d += 4) {
                     const float4 kv = *reinterpret_cast<const float4*>(Ks + (c0 + c) * LDK + d);
-                    acc = fmaf(q[d], kv.x, acc); acc = fmaf(q[d + 1], kv.y, acc); acc = fmaf(q[d + 2], kv.z, acc); acc = fmaf(q[d + 3], kv.w, acc);
+                    a0 = fmaf(q[d], kv.x, a0); a1 = fmaf(q[d + 1], kv.y, a1); a2 = fmaf(q[d + 2], kv.z, a2); a3 = fmaf(q[d + 3], kv.w, a3);
                 }
                 __builtin_amdgcn_sched_barrier(0);      // (keeps the 16 keys' LDS reads from being hoisted into 500 live registers)
                 const int j = j0 + c0 + c;
                 bool dead = j >= Nk;
                 if (MASK) dead = dead || mask[(size_t)qc * Nk + (j < Nk ? j : Nk - 1)] != 0;      // (branch-free: a select, not a jump per key)
-                s[c] = dead ? -INFINITY : acc;
+                s[c] = dead ? -INFINITY : (a0 + a1) + (a2 + a3);
                 cmax = fmaxf(cmax, s[c]);
             }
             const float m_new = fmaxf(m_run, cmax);
-            // (a chunk whose keys are all masked for this query leaves m_new = -inf while nothing has been seen: alpha = p = 0 then)
+            // (a chunk whose keys are all masked for this query leaves m_new = -inf while nothing has been seen: alpha = 1, p = 0 then)
             const float alpha = m_new == -INFINITY ? 1.f : exp2f(m_run - m_new);
             float psum = 0.f;
 #pragma unroll
@@ -197,8 +207,30 @@ __global__ __launch_bounds__(64) void xattn_f32_fwd_kernel(const float* __restri
             }
         }
     }
-    if (qi < Nq) {
-        const float inv = 1.0f / l_run;      // (a query with every key masked: 0 / 0 = NaN, like torch's softmax over an all -inf row)
+    // merge the four waves' partial results: slot [wave][lane][DH + 2] in the (now idle) tile buffers
+    __syncthreads();
+    constexpr int MS = DH + 2;
+    float* mg = xa_lds + (size_t)(wave * 64 + lane) * MS;
+#pragma unroll
+    for (int d = 0; d < DH; ++d) mg[d] = o[d];
+    mg[DH] = m_run; mg[DH + 1] = l_run;
+    __syncthreads();
+    if (wave == 0 && qi < Nq) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < XA_WAVES; ++w) mx = fmaxf(mx, xa_lds[(size_t)(w * 64 + lane) * MS + DH]);
+        float l = 0.f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) o[d] = 0.f;
+#pragma unroll
+        for (int w = 0; w < XA_WAVES; ++w) {
+            const float* pw = xa_lds + (size_t)(w * 64 + lane) * MS;
+            const float f = pw[DH] == -INFINITY ? 0.f : exp2f(pw[DH] - mx);
+            l = fmaf(pw[DH + 1], f, l);
+#pragma unroll
+            for (int d = 0; d < DH; ++d) o[d] = fmaf(pw[d], f, o[d]);
+        }
+        const float inv = 1.0f / l;      // (a query with every key masked: 0 / 0 = NaN, like torch's softmax over an all -inf row)
         float* op = O + ((size_t)b * Nq + qi) * ldo + h * DH;
 #pragma unroll
         for (int d = 0; d < DH; d += 4) *reinterpret_cast<float4*>(op + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
@@ -212,9 +244,16 @@ extern "C" int sed_xattn_f32_fwd(const float* Q, const float* K, const float* V,
         return SED_ERR_ARG;
     if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) return SED_ERR_ARG;
     const dim3 grid(cdiv(Nq, 64), H, B);
-#define XATTN_LAUNCH(DH_, MK_) hipLaunchKernelGGL((xattn_f32_fwd_kernel<DH_, MK_>), grid, dim3(64), 0, stream, Q, K, V, O, mask, Nq, Nk, ldq, ldk, ldv, ldo, (long long)q_batch_stride)
-    if (head_dim == 64) { if (mask != nullptr) XATTN_LAUNCH(64, true); else XATTN_LAUNCH(64, false); }
-    else { if (mask != nullptr) XATTN_LAUNCH(32, true); else XATTN_LAUNCH(32, false); }
+#define XATTN_LAUNCH(DH_, MK_)                                                                                                   \
+    {                                                                                                                            \
+        const int lds_ = XA_WAVES * 2 * 64 * (DH_ + 4) * 4;                                                                      \
+        static bool attr_ = false;                                                                                               \
+        if (!attr_) { (void)hipFuncSetAttribute((const void*)xattn_f32_fwd_kernel<DH_, MK_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); attr_ = true; } \
+        hipLaunchKernelGGL((xattn_f32_fwd_kernel<DH_, MK_>), grid, dim3(64 * XA_WAVES), lds_, stream, Q, K, V, O, mask, Nq, Nk, ldq, ldk, ldv, ldo, \
+                           (long long)q_batch_stride);                                                                           \
+    }
+    if (head_dim == 64) { if (mask != nullptr) XATTN_LAUNCH(64, true) else XATTN_LAUNCH(64, false) }
+    else { if (mask != nullptr) XATTN_LAUNCH(32, true) else XATTN_LAUNCH(32, false) }
 #undef XATTN_LAUNCH
     return sed_check_launch();
 }

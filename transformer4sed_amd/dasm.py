@@ -137,3 +137,142 @@ class DasmHead:
         pm = None if pad_mask is None else pad_mask.to(device=dev).to(torch.uint8).contiguous()
         call("sed_dasm_head_fwd", logits, at_logit, pm, float(temp_w), strong, weak, at_out, B, T, Q)
         return strong, weak, at_out, mask_feat.view(B, Q, Dd)
+
+
+# ---------------------------------------------------------------------------------------------------------------------- whole model
+import torch.nn as nn  # noqa: E402
+
+from .passt_cnn import PaSST_CNN  # noqa: E402
+from .passt_sed import _Holder  # noqa: E402
+
+
+class _MLP(_Holder):
+    """Parameter layout of `MLP` (detect_any_sound.py:401-416)."""
+
+    def __init__(self, n_in, hidden, n_out, n_layers):
+        super().__init__()
+        h = [hidden] * (n_layers - 1)
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip([n_in] + h, h + [n_out]))
+
+
+class _AtDecoder(_Holder):
+    """Parameter layout of QueryBasedAudioTaggingDecoder (at_adapter.py:36-45): `decoder.layers.N` = nn.TransformerDecoderLayer."""
+
+    def __init__(self, n_layers, d_model, nhead, dim_ffn):
+        super().__init__()
+        layer = nn.TransformerDecoderLayer(d_model=d_model, nhead=nhead, dim_feedforward=dim_ffn, activation="gelu", batch_first=True)
+        self.decoder = nn.TransformerDecoder(layer, num_layers=n_layers)
+
+
+_RENAME = (("decoder.", "sed_decoder."), ("out_norm.", "norm_before_pool."))      # this package's trunk names -> DASM's state_dict names
+
+
+class DASM(PaSST_CNN):
+    """Drop-in for `DASM` (src/models/detect_any_sound/detect_any_sound.py:18-399), inference: same constructor arguments, forward
+    signature (`query`, `query_type`, `tgt_mask`), return values (strong [B, Q, T], weak [B, Q], {"at_out", "frame_before_mask"}) and
+    state_dict keys.  Covered configuration: PaSST backbone (optionally LoRA) + CNN branch, decoder 'transformerXL' at decoder_dim
+    768 / 12 heads / expand rate 1, `at_param` with a query projector (one modality, integer `query_dim`), out_type 'sigmoid', no MLM."""
+
+    def __init__(self, cnn_param, backbone_param=None, at_param=None, mlm_dict=None, backbone_upsample_ratio=10, decoder_dim=768, num_heads=12,
+                 decoder="gru", decoder_layer_num=2, decoder_pos_emd_len=1000, decoder_expand_rate=1, class_num=10):
+        bp = dict(embed_dim=768, passt_feature_layer=10, pretrain_model_path=None, lora_config=None)
+        bp.update(backbone_param or {})
+        ap = dict(at_decoder_layer=0, query_projector=False, query_dim=768, out_type="logit", query=None)
+        ap.update(at_param or {})
+        bad = []
+        if mlm_dict is not None: bad.append("mlm_dict (pre-training)")
+        if decoder != "transformerXL": bad.append(f"decoder={decoder!r}")
+        if decoder_dim != 768 or num_heads != 12 or decoder_expand_rate != 1: bad.append("decoder_dim / num_heads / decoder_expand_rate != 768 / 12 / 1")
+        if not ap["query_projector"] or not isinstance(ap["query_dim"], int): bad.append("at_param without a single-modality query projector")
+        if ap["out_type"] != "sigmoid": bad.append(f"out_type={ap['out_type']!r}")
+        if ap["at_decoder_layer"] < 1: bad.append("at_decoder_layer < 1")
+        if bp["pretrain_model_path"] is not None: bad.append("pretrain_model_path (load a state_dict instead)")
+        if bad:
+            raise NotImplementedError("the HIP DASM path covers the text-/audio-query inference configuration only; unsupported: " + ", ".join(bad))
+        super().__init__(passt_sed_param=dict(passt_feature_layer=bp["passt_feature_layer"], class_num=class_num, f_pool="attention",
+                                              decode_ratio=backbone_upsample_ratio, at_adapter=False, decoder="transformerXL",
+                                              decoder_layer_num=decoder_layer_num, decoder_pos_emd_len=decoder_pos_emd_len, decoder_dim=decoder_dim,
+                                              mlm=False, lora_config=bp["lora_config"], load_pretrained_model=False,
+                                              embed_dim=bp["embed_dim"]),
+                         cnn_param=cnn_param)
+        del self.classifier                       # DASM has no linear classifier: the frame logits come from the query embeddings
+        Dd, D = decoder_dim, bp["embed_dim"]
+        self.backbone_param, self.backbone_upsample_ratio, self.num_heads = bp, backbone_upsample_ratio, num_heads
+        self.at_layers = int(ap["at_decoder_layer"])
+        self.norm_after_merge = nn.LayerNorm(Dd)
+        self.at_projector = nn.Linear(D, Dd)
+        self.query_projector = nn.Sequential(nn.Linear(ap["query_dim"], Dd), nn.GELU())
+        q = ap["query"]
+        if isinstance(q, str):
+            q = torch.load(q, map_location="cpu")
+        if q is not None:
+            if not torch.is_tensor(q) or q.shape[0] != class_num:
+                raise ValueError("at_param['query'] must be a [class_num, query_dim] tensor (detect_any_sound.py:165-171)")
+            self.at_query = nn.Parameter(q.detach().clone().float())
+        else:
+            self.at_query = nn.Parameter(torch.zeros(class_num, ap["query_dim"]))
+        self.at_decoder = _AtDecoder(self.at_layers, Dd, num_heads, Dd * decoder_expand_rate)
+        self.at_head = _MLP(Dd, Dd, 1, 2)
+        self.mask_embedding_layer = _MLP(Dd, Dd, Dd, 3)
+        self.sed_head = nn.Linear(Dd, Dd)
+        self.merge_weight.requires_grad_(False)
+        self.dasm_head = None
+        self._dasm_query = self._dasm_tgt_mask = None
+        self._head_generation = -1
+        self._index_params()
+
+    # ---- state_dict under the reference's names
+    def state_dict(self, *a, **k):
+        sd = super().state_dict(*a, **k)
+        out = type(sd)()
+        for key, v in sd.items():
+            for mine, ref in _RENAME:
+                if key.startswith(mine):
+                    key = ref + key[len(mine):]
+                    break
+            out[key] = v
+        return out
+
+    def load_state_dict(self, state_dict, strict=True, **k):
+        sd = {}
+        for key, v in state_dict.items():
+            for mine, ref in _RENAME:
+                if key.startswith(ref):
+                    key = mine + key[len(ref):]
+                    break
+            sd[key] = v
+        r = super().load_state_dict(sd, strict=strict, **k)
+        self._head_generation = -1
+        return r
+
+    _HEAD_PREFIXES = ("at_projector.", "query_projector.", "at_query", "at_decoder.", "at_head.", "mask_embedding_layer.", "sed_head.")
+
+    def _ensure_head(self):
+        gen = getattr(self, "_param_generation", 0)
+        if self.dasm_head is None or self._head_generation != gen or self.dasm_head.p["sed_head.weight"].device != self.sed_head.weight.device:
+            params = {n: p for n, p in self.named_parameters() if n.startswith(self._HEAD_PREFIXES)}
+            self.dasm_head = DasmHead(params, self.at_layers, self.num_heads, self.decoder_dim)
+            self._head_generation = gen
+
+    def forward(self, input, encoder_win=False, mix_rate=0.5, win_param=[512, 49], temp_w=0.1, pad_mask=None, query=None, query_type=None,
+                tgt_mask=None):
+        if torch.is_grad_enabled():
+            raise NotImplementedError("DASM (transformer4sed_amd) is the inference path: call it under torch.no_grad()")
+        if isinstance(query, (list, tuple, nn.ParameterList)):
+            raise NotImplementedError("multi-modal query lists (detect_any_sound.py:300-309) are not covered")
+        if torch.is_tensor(query) and query.ndim == 3:      # detect_any_sound.py:366-367 (DataParallel hands the queries over per clip)
+            query = query[0]
+        if tgt_mask is not None and tgt_mask.ndim == 3:     # :373-374
+            tgt_mask = tgt_mask[0]
+        self._ensure_head()
+        self._dasm_query, self._dasm_tgt_mask = query, tgt_mask
+        try:
+            return super().forward(input, encoder_win=encoder_win, mix_rate=mix_rate, win_param=win_param, temp_w=temp_w, pad_mask=pad_mask)
+        finally:
+            self._dasm_query = self._dasm_tgt_mask = None
+
+    def get_model_name(self):
+        return "DASM"
+
+    def get_backbone_upsample_ratio(self):
+        return self.backbone_upsample_ratio

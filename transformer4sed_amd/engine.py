@@ -500,8 +500,10 @@ class SedEngine:
         if want_frame:
             frame16 = E(M, D, dt=A16)
             fm, fr = (E(M), E(M)) if save else (None, None)
+            # (DASM's head reads the tokens in fp32: the same pass writes them beside the 16-bit image)
+            self._frame32 = E(M, D) if getattr(m, "dasm_head", None) is not None else None
             call("sed_layernorm_fwd", x, self.P("backbone.norm.weight"), self.P("backbone.norm.bias"), 1e-6, 1.0,
-                 frame16, None, fm, fr, M, D, f16)
+                 frame16, self._frame32, fm, fr, M, D, f16)
             if save:
                 ctx.update(x_final=x, fmean=fm, frstd=fr, frame16=frame16)
         return pooled, frame16, ctx

@@ -397,7 +397,7 @@ class PaSST_SED(SEDModel):
         other = {"frame_before_mask": o["frame_before_mask"]}
         if self.mlm:
             other["mask_id_seq"] = self._last_mask_ids
-        if self.has_at:
+        if self.has_at or "at_out" in o:      # (DASM: the tagging stream of its head)
             other["at_out"] = o["at_out"]
         if self.mlm:
             return o["mlm_pred"], other

@@ -480,7 +480,10 @@ class PmamEngine(SedEngine):
         E = lambda *s, dt=F32: torch.empty(*s, dtype=dt, device=dev)
         out = {}
         tp = 99
-        pooled, frame16, ectx = self._encoder_fwd(W, mel, [0], tp, [0], save, want_frame=m.has_at)
+        dasm = getattr(m, "dasm_head", None)       # DASM (dasm.py): same trunk, LayerNorm after the merge, query decoder + dual-stream head
+        if dasm is not None and save:
+            raise NotImplementedError("DASM runs forward only (inference / open-vocabulary detection); call it under torch.no_grad()")
+        pooled, frame16, ectx = self._encoder_fwd(W, mel, [0], tp, [0], save, want_frame=m.has_at or dasm is not None)
         Tdec = (tp + 1) * m.decode_ratio
         feat, cctx = self._cnn_fwd(W, mel, train=m.training, save=save, drop_masks=drop_masks)
         Tc = cctx["Tc"]
@@ -527,6 +530,11 @@ class PmamEngine(SedEngine):
                 gemm_nt(split3(pooled.view(B * tp, D), B * tp, D), W["transformer_projector.weight"].ws, EPI_F32,
                         bias=self.P("transformer_projector.bias"), outF=P1)
             call("sed_pmam_merge", P1, P2, self.P("merge_weight"), xg, B, tp, 1, m.decode_ratio, Tc, Tdec // Tc, Dd)
+        if dasm is not None:      # norm_after_merge (detect_any_sound.py:361)
+            xn = E(B, Tdec, Dd)
+            call("sed_layernorm_fwd", xg.view(B * Tdec, Dd), self.P("norm_after_merge.weight"), self.P("norm_after_merge.bias"), 1e-5, 1.0,
+                 None, xn.view(B * Tdec, Dd), None, None, B * Tdec, Dd, 0)
+            xg = xn
         out["frame_before_mask"] = xg
         dec_in = xg
         plan = mlm_plan if (m.mlm and mlm_plan is not None) else None
@@ -541,7 +549,15 @@ class PmamEngine(SedEngine):
             actx = self._at_fwd(W, frame16, ectx, save)
             out["at_out"] = actx["at_out"]
         M = B * Tdec
-        if m.mlm:
+        if dasm is not None:
+            # frame tokens of the final norm without the cls / dist tokens (detect_any_sound.py:364), fp32 (engine._encoder_fwd wrote them
+            # beside the 16-bit image); the SED decoder's output goes to sed_head inside the head
+            N = 2 + 12 * tp
+            ft = self._frame32.view(B, N, D)[:, 2:, :].contiguous()
+            strong, weak, at_out, _ = dasm.forward(ft, xd, query=m._dasm_query, tgt_mask=m._dasm_tgt_mask, temp_w=float(temp_w), pad_mask=pad_mask)
+            out["strong"], out["weak"], out["at_out"] = strong, weak, at_out
+            hctx = None
+        elif m.mlm:
             hpre = E(M, Dd, dt=BF16 if save else self.act)
             act = E(M, Dd)
             xds = split3(xd.view(M, Dd), M, Dd)

@@ -315,6 +315,24 @@ def dasm_state_dict_np(tag="dasm0", with_joint=True, **kw):
     return out
 
 
+def dasm_full_state_dict_np(n_queries=8, query_dim=1024, at_layers=2, dec_layers=3):
+    """Whole DASM model under the reference's state_dict names: backbone + SED decoder from the MAT-SED weights (`w768`, the decoder
+    as `sed_decoder.`), the CNN branch from the PMAM weights, joint layers + head from `dasm_state_dict_np`."""
+    base = matsed_state_dict_np(tag="w768", depth=12, dec_layers=dec_layers)
+    pm = pmam_state_dict_np(depth=12)
+    out = {}
+    for k, v in base.items():
+        if k.startswith("backbone."):
+            out[k] = v
+        elif k.startswith("decoder."):
+            out["sed_" + k] = v
+    for k, v in pm.items():
+        if k.startswith("cnn."):
+            out[k] = v
+    out.update(dasm_state_dict_np(n_queries=n_queries, query_dim=query_dim, at_layers=at_layers, with_joint=True))
+    return out
+
+
 # --------------------------------------------------------------------------------------------------
 # DESED-shaped synthetic clips (SURVEY.md section 8(d) "Synthetic inputs")
 # --------------------------------------------------------------------------------------------------
