@@ -127,6 +127,8 @@ class PmamEngine(SedEngine):
                 mat(n + ".weight", n + ".weight", lora=n if m.lora_r else None)
         for n in ("at_adpater.0.frequency_att.in_proj_weight", "f_pool_module.frequency_att.in_proj_weight",
                   "f_pool_module.frequency_att.out_proj.weight"):
+            if n.startswith("at_adpater") and not m.has_at:      # (DASM: its tagging stream is the query decoder, dasm.py)
+                continue
             mat(n, n)
         for n in ("transformer_projector.weight", "cnn_projector.weight", "mlm_mlp.0.weight", "mlm_mlp.2.weight"):
             if n.startswith("mlm_mlp") and not m.mlm:
