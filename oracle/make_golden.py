@@ -1277,6 +1277,7 @@ def gen_dasm_full():
     taps = {}
     net.sed_head.register_forward_hook(lambda m, i, o: taps.update(xin=i[0].detach(), xs=o.detach()))
     net.mask_embedding_layer.register_forward_hook(lambda m, i, o: taps.update(emb=o.detach()))
+    net.norm_after_merge.register_forward_hook(lambda m, i, o: taps.update(nam=o.detach()))
     with torch.no_grad():
         s, w, o = net(mel, temp_w=0.5, pad_mask=pad, query=ext.clone(), tgt_mask=tmask)
     # The synthetic decoder output has a large time-constant component, which puts every frame logit at +6 (posteriors pinned to at_out:
@@ -1291,7 +1292,8 @@ def gen_dasm_full():
     print("decoder output rms %.3f  sed_head out rms %.3f  emb rms %.3f  logits mean %.3f std %.3f" % (
         float(taps["xin"].pow(2).mean().sqrt()), float(taps["xs"].pow(2).mean().sqrt()), float(taps["emb"].pow(2).mean().sqrt()),
         float(lg.mean()), float(lg.std())))
-    save(tag, strong=t2n(s[:, :, ::5]), weak=t2n(w), at_out=t2n(o["at_out"]), novel=t2n(novel), sed_head_bias=t2n(cal_bias))
+    save(tag, strong=t2n(s[:, :, ::5]), weak=t2n(w), at_out=t2n(o["at_out"]), novel=t2n(novel), sed_head_bias=t2n(cal_bias),
+         nam_s=t2n(taps["nam"][:, ::25, ::16]), xdec_s=t2n(taps["xin"][:, ::25, ::16]), xdec_mean=t2n(taps["xin"].mean(dim=(0, 1))))
 
 
 GENS["dasm_full"] = gen_dasm_full

@@ -137,9 +137,13 @@ def test_dasm_full_model_vs_reference(golden):
     es = float((s[:, :, ::5].cpu() - torch.from_numpy(g["strong"])).abs().max())
     ew = float((w.cpu() - torch.from_numpy(g["weak"])).abs().max())
     ea = float((o["at_out"].cpu() - torch.from_numpy(g["at_out"])).abs().max())
+    e_nam = float((o["frame_before_mask"][:, ::25, ::16].cpu() - torch.from_numpy(g["nam_s"])).abs().max())
+    e_xd = float((net._last_x_dec[:, ::25, ::16].cpu() - torch.from_numpy(g["xdec_s"])).abs().max())
+    e_mu = float((net._last_x_dec.mean(dim=(0, 1)).cpu() - torch.from_numpy(g["xdec_mean"])).abs().max())
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/dasm_errors.log", "a") as f:
-        f.write(f"DASM full model vs reference: strong {es:.3e} weak {ew:.3e} at_out {ea:.3e}\n")
+        f.write(f"DASM full model vs reference: strong {es:.3e} weak {ew:.3e} at_out {ea:.3e}  (norm_after_merge output {e_nam:.3e}, SED decoder "
+                f"output {e_xd:.3e} of rms {float(net._last_x_dec.pow(2).mean().sqrt()):.2f}, its time mean {e_mu:.3e})\n")
     assert es < 1e-3 and ew < 1e-3 and ea < 1e-3, (es, ew, ea)      # BASELINE.json: 1e-3 on frame posteriors
     # B = 3 with the clip repeated: batch invariance of the whole path, and the closed-set call (learned queries)
     with torch.no_grad():

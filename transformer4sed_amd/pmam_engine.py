@@ -556,6 +556,7 @@ class PmamEngine(SedEngine):
             # beside the 16-bit image); the SED decoder's output goes to sed_head inside the head
             N = 2 + 12 * tp
             ft = self._frame32.view(B, N, D)[:, 2:, :].contiguous()
+            m._last_x_dec = xd            # (kept for tests / inspection: the SED decoder's output that sed_head reads)
             strong, weak, at_out, _ = dasm.forward(ft, xd, query=m._dasm_query, tgt_mask=m._dasm_tgt_mask, temp_w=float(temp_w), pad_mask=pad_mask)
             out["strong"], out["weak"], out["at_out"] = strong, weak, at_out
             hctx = None
