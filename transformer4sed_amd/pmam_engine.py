@@ -75,7 +75,9 @@ class PmamEngine(SedEngine):
                 n *= v
             ids = torch.arange(1, n + 1, dtype=torch.float32, device=dev).view(src_shape)
             mapped = fn(ids, 1.0)
-            scale = fn(torch.ones(src_shape, dtype=torch.float32, device=dev), SQRT2)
+            # K / P rows: the attention kernels divide the scores by sqrt(64); a model head of width hd needs 1 / sqrt(hd) -- sqrt(64 / hd)
+            # on one operand (sqrt 2 for the 384-wide PMAM context net, 1 for DASM's 768-wide one)
+            scale = fn(torch.ones(src_shape, dtype=torch.float32, device=dev), math.sqrt(HD_PAD / (self.m.decoder_dim // H)))
             plans[key] = ((mapped.reshape(-1).long() - 1).clamp_(min=0).to(torch.int32), scale.reshape(-1).contiguous(), tuple(mapped.shape))
         return plans[key]
 
