@@ -33,6 +33,15 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
         if (VKIND == 10) asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(p[(i) & 3]));       \
         if (VKIND == 11) asm volatile("v_mov_b32 %0, %0" : "+v"(a[(i) & 7]));              \
         if (VKIND == 12) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(a[(i) & 7]) : "v"(a[((i) + 1) & 7]));  \
+        /* round 5: 16-bit packed arithmetic and the half-precision transcendental (could p = 2^(s - m) run on packed halves?) */ \
+        if (VKIND == 13) asm volatile("v_pk_fma_f16 %0, %0, %0, %0" : "+v"(a[(i) & 7]));   \
+        if (VKIND == 14) asm volatile("v_pk_mul_f16 %0, %0, %0" : "+v"(a[(i) & 7]));       \
+        if (VKIND == 15) asm volatile("v_pk_add_f16 %0, %0, %0" : "+v"(a[(i) & 7]));       \
+        if (VKIND == 16) asm volatile("v_exp_f16 %0, %0" : "+v"(a[(i) & 7]));              \
+        if (VKIND == 17) asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(a[(i) & 7]));          \
+        if (VKIND == 18) asm volatile("v_pk_add_u16 %0, %0, %0" : "+v"(a[(i) & 7]));       \
+        if (VKIND == 19) asm volatile("v_dot2c_f32_f16 %0, %1, %1" : "+v"(a[(i) & 7]) : "v"(a[((i) + 1) & 7]));  \
+        if (VKIND == 20) asm volatile("v_fract_f32 %0, %0" : "+v"(a[(i) & 7]));            \
     }
 #define MOP(j) { if ((j) & 1) c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, c1, 0, 0, 0); else c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, c0, 0, 0, 0); }
 
