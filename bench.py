@@ -82,12 +82,13 @@ PMAM = {
                              "passt": {"lr": 5.0e-6, "weight_decay": 1, "freeze_layer": 8, "step_lr": 0},
                              "decoder": {"lr": 1.5e-4, "weight_decay": 1.0e-4}, "head": {"lr": 2.0e-4}}},
 }
-MODE_CFG = {"finetune2": FINETUNE2, "val": FINETUNE2, "finetune1": FINETUNE1, "pretrain": PRETRAIN, "pmam": PMAM}
+MODE_CFG = {"finetune2": FINETUNE2, "val": FINETUNE2, "finetune1": FINETUNE1, "pretrain": PRETRAIN, "pmam": PMAM, "dasm": PMAM}
 MODE_GFLOP = {"finetune2": (2463.16, 21.22), "finetune1": (649.13, 14.15), "pretrain": (383.68, 14.15), "val": (2 * 2264.3, 2 * 7.07),
               # PMAM post-pretrain step: FlopCounterMode on the reference's own PaSST_CNN (depth 12, LoRA r = 8, freeze_layer 8, forward + loss +
               # backward) at B = 1, 2 -- oracle/make_golden.py gen_pmamflops.  (The reference never forms the full dW of a LoRA layer; this
               # build does, as an intermediate of dA / dB: those FLOPs are not credited.)
-              "pmam": (433.06, 3.54)}
+              "pmam": (433.06, 3.54),
+              "dasm": (None, None)}       # (no FlopCounter figure of the reference's DASM was recorded)
 GFLOP_PER_CLIP = 2463.16      # finetune2 step, algorithmic GEMM+conv FLOPs per clip of the REFERENCE's schedule (a-term)
 GFLOP_PER_BATCH = 21.22       # batch-shared linear_pos GEMMs (b-term)
 # What this build does not execute: the teacher's 11 sliding windows stop after the tapped block 10 (blocks 11-12 of a window feed
@@ -160,6 +161,32 @@ def build_pmam(depth, device):
     gmm = torch.from_numpy(synth.det_normal("pmam/gmm_means", (30, 768)))
     net.train()
     return net, opt, PmamTrainer(net, opt, sched, gmm, cfg)
+
+
+def build_dasm(depth, device, n_queries):
+    """DASM (BASELINE.json config #5) as recipes/audioset_strong/detect_any_sound/passt/main.py:24 constructs it -- PaSST backbone, the
+    PMAM CNN branch, 3-layer Transformer-XL SED decoder, 2-layer query decoder, 1024-wide external query embeddings (synthetic weights:
+    the reference ships no YAML for this model; CLAP, which makes the embeddings, is not vendored)."""
+    from transformer4sed_amd import synth
+    from transformer4sed_amd.dasm import DASM
+    cnn = {"n_in_channel": 1, "activation": "cg", "conv_dropout": 0.5, "kernel_size": [3] * 10, "padding": [1] * 10, "stride": [1] * 10,
+           "nb_filters": list(synth.PMAM_FILTERS), "pooling": [list(p) for p in synth.PMAM_POOLING]}
+    nb = max(1, n_queries // 2)
+    net = DASM(cnn_param=cnn, backbone_param={"embed_dim": 768, "passt_feature_layer": min(10, depth), "pretrain_model_path": None, "lora_config": None},
+               at_param={"at_decoder_layer": 2, "query_projector": True, "query_dim": 1024, "out_type": "sigmoid", "query": torch.zeros(nb, 1024)},
+               decoder="transformerXL", decoder_layer_num=3, decoder_dim=768, num_heads=12, class_num=nb)
+    if depth != 12:
+        raise SystemExit("--mode dasm runs the reference's depth (12): DASM builds its PaSST with depth 12 (detect_any_sound.py:222)")
+    sd = synth.dasm_full_state_dict_np(n_queries=nb, query_dim=1024)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+    net = net.to(device).eval()
+    g = torch.Generator().manual_seed(5)
+    q = torch.nn.functional.normalize(torch.randn(n_queries, 1024, generator=g), dim=-1)
+    q[:nb] = torch.from_numpy(sd["at_query"])
+    mask = torch.ones(n_queries, n_queries, dtype=torch.bool)
+    mask[:, :nb] = False
+    mask.fill_diagonal_(False)
+    return net, q.to(device), mask.to(device)
 
 
 def cpu_baseline(depth, batch=4, budget_s=330):
@@ -259,13 +286,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default 32; 24 for --mode pmam, the reference's batch)")
     ap.add_argument("--depth", type=int, default=12)
-    ap.add_argument("--mode", default="finetune2", choices=["finetune2", "finetune1", "pretrain", "val", "pmam", "pipe"],
+    ap.add_argument("--mode", default="finetune2", choices=["finetune2", "finetune1", "pretrain", "val", "pmam", "pipe", "dasm"],
                     help="finetune2 = the headline train step (default); finetune1 / pretrain = the other two training stages of "
                          "the MAT-SED recipe; val = Trainer.validation's per-batch body (student + teacher, 17 sliding windows, "
                          "score tables + event decoding), SURVEY 8(f) rank 1; pmam = the PMAM post-pretrain step (PaSST_CNN, SURVEY 8(f) rank 3)")
     ap.add_argument("--pipe-step", default="finetune2", choices=["finetune2", "pretrain"],
                     help="--mode pipe: which train step consumes the file stream (synthetic 16 kHz RIFF files -> data.WavBatchStream -> "
                          "device resampler -> step); the line reports end-to-end clips/s beside the resident-input rate of the same process")
+    ap.add_argument("--dasm-queries", type=int, default=64,
+                    help="--mode dasm: number of query embeddings per call (half of them 'base' queries, half novel ones behind the "
+                         "open-vocabulary attention mask); 407 = every AudioSet-strong class")
     ap.add_argument("--pipe-workers", type=int, default=2)
     ap.add_argument("--pipe-depth", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -340,8 +370,11 @@ def main():
     import random
     random.seed(1000 + rank); np.random.seed(1000 + rank); torch.manual_seed(1000 + rank)
 
-    B = a.batch or (24 if a.mode == "pmam" else 32)
-    if a.mode == "pmam":
+    B = a.batch or (24 if a.mode in ("pmam", "dasm") else 32)
+    if a.mode == "dasm":
+        net, dasm_q, dasm_mask = build_dasm(a.depth, dev, a.dasm_queries)
+        ema_net = opt = trainer = None
+    elif a.mode == "pmam":
         net, opt, trainer = build_pmam(a.depth, dev)
         ema_net = None
     else:
@@ -350,15 +383,16 @@ def main():
     sn = (B * 4 + 11) // 12
     wn = (B * 4 + 11) // 12
     un = B - sn - wn
-    trainer.cfg = json.loads(json.dumps(MODE_CFG[a.mode]))
-    if a.mode not in ("pretrain", "pmam"):
+    if trainer is not None:
+        trainer.cfg = json.loads(json.dumps(MODE_CFG[a.mode]))
+    if a.mode not in ("pretrain", "pmam", "dasm"):
         trainer.cfg["training"]["batch_size"] = [sn, 0, wn, un]
     wav = torch.from_numpy(synth.synth_wav(B, seed=1000 + rank)).to(dev)
     if a.mode == "pmam":   # frame-wise pseudo labels over the 30 GMM prototypes (FrameWiseLabeledDataset, pmam/setting.py:47-70)
         labels = torch.from_numpy(synth.synth_strong_labels(B, n_classes=30, seed=1000 + rank)).to(dev)
     else:
         labels = torch.from_numpy(synth.synth_batch_labels(sn, wn, un, seed=1000 + rank)).to(dev)
-    if world > 1 or force_ddp:
+    if (world > 1 or force_ddp) and trainer is not None:
         trainer.ddp = GradBucketReducer(net, opt)
         trainer.ddp.force = force_ddp
 
@@ -376,6 +410,14 @@ def main():
             ev = Evaluator(net, ema_net, enc, vcfg)
             ev.step(wav, labels, pad_mask, paths)
             return {"loss_total": torch.tensor(float(len(ev.scores.post_student)))}
+    elif a.mode == "dasm":
+        ext = net.get_feature_extractor()
+
+        def step(w=None):      # open-vocabulary inference: eval frontend -> whole model -> frame posteriors of every query
+            with torch.no_grad():
+                mel = ext.logmel(wav if w is None else w)
+                strong, weak, other = net(mel, temp_w=0.5, query=dasm_q, tgt_mask=dasm_mask)
+            return {"loss_total": weak.mean()}
     elif a.mode == "pretrain":
         def step(w=None):
             out = trainer.pretrain_step(wav if w is None else w)
@@ -391,7 +433,7 @@ def main():
         step()
     # HIP events bracket every GEMM launch of the FIRST timed step only: the event packets cost ~8 us of stream time per launch
     # (2.5 ms on a 138 ms step when every step is instrumented), which would otherwise be charged to `value`
-    timer = None if a.no_kernel_timer else ops.KernelTimer(GEMM_KERNELS + list(ops.HBM_KERNELS))
+    timer = None if a.no_kernel_timer else ops.KernelTimer(GEMM_KERNELS + list(ops.HBM_KERNELS) + (["sed_gemm_f32_nt", "sed_xattn_f32_fwd"] if a.mode == "dasm" else []))
     timed_steps_with_events = 1
     if timer is not None:       # one untimed instrumented step creates the event objects; the timed step reuses them
         ops.TIMER = timer
@@ -454,7 +496,8 @@ def main():
                    "finetune1": "clips/sec (10 s clips) MAT-SED finetune1 train step",
                    "pretrain": "clips/sec (10 s clips) MAT-SED masked-reconstruction pretrain step",
                    "val": "clips/sec (10 s clips) MAT-SED validation step (student + teacher, 17 windows, score tables + events)",
-                   "pmam": "clips/sec (10 s clips) PMAM post-pretrain step (PaSST_CNN: LoRA encoder + CNN branch, prototype BCE)"}[a.mode],
+                   "pmam": "clips/sec (10 s clips) PMAM post-pretrain step (PaSST_CNN: LoRA encoder + CNN branch, prototype BCE)",
+                   "dasm": "clips/sec (10 s clips) DASM open-vocabulary inference (frontend + PaSST + CNN + SED decoder + query decoder + dual-stream head)"}[a.mode],
         "value": round(value, 3), "unit": "clips/s",
         "n_gpus": world, "ranks": dist.get_world_size() if dist.is_initialized() else 1,
         "collective_backend": (dist.get_backend() if dist.is_initialized() else None), "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * dt / a.steps, 3),
@@ -507,6 +550,13 @@ def main():
              "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "peak_GB/s": PEAK_HBM_GBS,
              "frac_of_8TB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
             for k, v in summ_all.items() if k in what and v["ms"] > 0]
+        if a.mode == "dasm" and "sed_gemm_f32_nt" in summ_all:
+            v, x = summ_all["sed_gemm_f32_nt"], summ_all.get("sed_xattn_f32_fwd", {"ms": 0.0, "launches": 0})
+            line["roofline_f32"] = {"kernel": "gemm_f32_nt_kernel (query decoder / head linears, folded memory projection, per-clip einsum) on v_mfma_f32_32x32x2_f32",
+                                    "bound": "mfma", "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
+                                    "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / 157.3, 4), "launches": v["launches"], "ms": round(v["ms"], 3),
+                                    "xattn_f32_ms": round(x["ms"], 3), "xattn_f32_launches": x["launches"],
+                                    "note": "fp32-input MFMA peak = the fp32 vector peak (MI355X_MICROARCH.md); exact fp32 products and accumulation"}
         ms = sum(v["ms"] for v in summ.values())
         fl = sum(v["flops"] for v in summ.values())
         n = sum(v["launches"] for v in summ.values())
@@ -559,6 +609,14 @@ def main():
                                       "trainable), 10-layer CNN branch, attention frequency pooling, 384-wide context net, 80 % block mask, "
                                       "prototype-similarity BCE + 0.1 AT BCE, AdamW")
         line["config"]["model"] = f"PaSST_CNN depth {a.depth} (97.8 M params, 11.7 M trainable)"
+    if a.mode == "dasm":
+        line["config"]["workload"] = (f"DASM inference batch (src/models/detect_any_sound/detect_any_sound.py:324-399): eval frontend, PaSST depth 12 + "
+                                      f"10-layer CNN branch, attention pooling, 3-layer Transformer-XL SED decoder, 2-layer query decoder over the 1188 "
+                                      f"patch tokens, {a.dasm_queries} query embeddings ({max(1, a.dasm_queries // 2)} base + novel ones behind the "
+                                      f"open-vocabulary attention mask), temperature 0.5; forward only")
+        line["config"]["model"] = "DASM depth 12 (PaSST + CNN + Transformer-XL + query decoder, 119.7 M params), synthetic weights and query embeddings"
+        line["config"].pop("final_loss", None)
+        line["dtype"] = "f16 MFMA operands in the encoder / SED decoder (split precision there), fp32 (fp32-input MFMA) in the query decoder and head"
     if a.mode == "val":
         line["config"]["workload"] = ("MAT-SED validation batch (recipes/desed/finetune/train.py:296-366): eval frontend, student and "
                                       "EMA teacher forward with val_kwargs (17 windows of 512 frames, step 31, temp 0.5), soft-masked "

@@ -167,6 +167,8 @@ def _flops_of(name, args):
         return 2.0 * args[3] * args[4] * (3 * args[5] * 64)
     if name == "sed_gemm_dw_tn":
         return 2.0 * args[3] * args[4] * args[5]
+    if name == "sed_gemm_f32_nt":                # (A, B, bias, R, C, M, N, K, lda, ldb, ldc, batch, ...): fp32-input MFMA, its own roofline
+        return 2.0 * args[5] * args[6] * args[7] * args[11]
     return 0.0
 
 
