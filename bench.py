@@ -15,6 +15,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP initialises: see transformer4sed_amd/__init__.py
+
 import numpy as np
 import torch
 
