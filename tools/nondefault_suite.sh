@@ -3,6 +3,6 @@
 TAG=${1:-r5}; O=gpurun_out/$TAG; mkdir -p $O; OUT=$O/nondefault_suite.txt; : > $OUT
 for env in "SED_DDP_COMM_DTYPE=bf16" "SED_GEMM_DYN=0" "SED_LN_FOLD=0"; do
   echo "== $env" >> $OUT
-  env $env python -m pytest tests -m gpu -q -x 2>&1 | grep -E "passed|failed|error|Error|assert" | tail -6 >> $OUT
+  env $env python -m pytest tests -m gpu -q -x > $O/nondefault_$$.log 2>&1; grep -E "passed|failed|error|Error|assert" $O/nondefault_$$.log | tail -6 >> $OUT; rm -f $O/nondefault_$$.log
 done
 cat $OUT
