@@ -169,8 +169,25 @@ def test_pmam_loss_and_gradients_vs_reference(golden):
             continue
         # merge_weight: one scalar, the sum of B x T x 384 products that cancel almost completely -- on identical inputs its deviation moved
         # between 1.1 % and 2.3 % over eight runs (the upstream gradient carries atomic-order noise; fp64 partial sums in the kernel did not
-        # narrow it), so 2 % sat inside the run-to-run spread: 3 % for this entry, 2 % for every tensor
-        assert rel < (0.03 if n == "merge_weight" else 0.02), f"|grad {n}| off by {rel:.3f}"
+        # narrow it).  A single run therefore only has to stay inside that spread (3 %); the MEAN of five runs must meet the 2 % every
+        # other tensor meets (a 1-2 % regression of this path would otherwise hide in the single-run bound)
+        if n == "merge_weight":
+            assert rel < 0.03, f"|grad {n}| off by {rel:.3f}"
+            vals = [float(pn[n].grad.double().norm())]
+            for _ in range(4):
+                net.zero_grad()
+                net._last_grad_arena = None
+                pred_r, other_r = net(mel, encoder_win=False)
+                l_r = ProtoBCE.apply(pred_r, protos, labels, other_r["mask_id_seq"].reshape(-1), 0.1) \
+                    + 0.1 * torch.nn.functional.binary_cross_entropy(other_r["at_out"], (labels.sum(-1) >= 1).float())
+                l_r.backward()
+                vals.append(float(pn[n].grad.double().norm()))
+            ref_norm = float(dict(zip(names, g["tr_grad_norms"]))[n])
+            mrel = abs(sum(vals) / len(vals) - ref_norm) / ref_norm
+            print(f"merge_weight gradient over 5 runs: {[f'{v:.5f}' for v in vals]} mean off by {mrel:.4f}")
+            assert mrel < 0.02, (vals, ref_norm)
+            continue
+        assert rel < 0.02, f"|grad {n}| off by {rel:.3f}"
     assert sorted(h for _, h, _ in worst)[len(worst) // 2] < 0.05, "median relative error of the first gradient entries"
 
 
