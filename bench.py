@@ -515,8 +515,8 @@ def main():
     line["gpu_state"] = gpu_state
     line["host"] = {"cpus_usable": hostcpu.usable_cpus(), "affinity": len(os.sched_getaffinity(0)),
                     "issue_ms_per_step": round(1000 * host_issue_s / a.steps, 2), "cpu_ms_per_step": round(1000 * cpu_s / a.steps, 2),
-                    "note": "issue = wall time until the Python schedule of the timed steps was issued (the GPU runs behind it); cpu = process "
-                            "CPU time (all threads) per step"}
+                    "note": "issue = wall time until the Python schedule of the timed steps was issued (includes the back-pressure of the launch "
+                            "queue once it is several steps deep: an upper bound of the host's own time); cpu = process CPU time (all threads) per step"}
     if pipe_info is not None:
         # the headline of this mode is the END-TO-END rate; the resident-input rate measured above in the same process sits beside it
         line["pipe"] = dict(pipe_info, resident_value=line["value"], resident_ms_per_step=line["ms_per_step"],
@@ -571,7 +571,7 @@ def main():
         def prof(kind):
             if a.depth != 12 or a.batch is not None:
                 return None, None
-            for rnd in ("r4", "r3", "r2"):
+            for rnd in ("r5", "r4", "r3", "r2"):
                 path = os.path.join(ROOT, "profiles", f"{rnd}_gemm_{kind}_{a.mode}.json")
                 if os.path.exists(path):
                     return json.load(open(path)), os.path.relpath(path, ROOT)

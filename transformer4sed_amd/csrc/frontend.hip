@@ -516,9 +516,8 @@ static int median_filter_impl(const float* in, float* out, const int* sizes, con
                               int max_size, hipStream_t stream) {
     (void)hipGetLastError();
     if (mode < 0 || mode > 2 || T > 12288 || max_size < 0) return SED_ERR_ARG;
-    static const bool rank_on = getenv("SED_MEDIAN_RANK") ? atoi(getenv("SED_MEDIAN_RANK")) != 0 : true;
     // max_size: the caller's bound on the window sizes (they live on the device); 0 = unknown -> the rank-search kernel
-    if (rank_on && mode != 2 && max_size >= 24 && T >= 256 && T + max_size + 1 <= MEDR_MAXN) {
+    if (mode != 2 && max_size >= 24 && T >= 256 && T + max_size + 1 <= MEDR_MAXN) {
         int W = (T + max_size + 1 + 31) / 32;
         W |= 1;                                     // odd row stride: the 64 lanes' bitmap words fall into different banks
         const size_t lds = (size_t)MEDR_MAXN * (4 + 4 + 2) + (size_t)256 * W * 4;

@@ -2046,12 +2046,7 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
             const char* dy = getenv("SED_GEMM_DYN");
             gg.tile_ctr = (gg.persist && !(dy && atoi(dy) == 0)) ? dyn_counter_slot() : nullptr;
         }
-        {
-            const char* st_s = getenv("SED_GEMM_STAGGER");      // experiment: start delay of every other workgroup, in 10 ns ticks
-            gg.stagger = (gg.persist && st_s) ? atoi(st_s) : 0;
-            const char* sp_s = getenv("SED_GEMM_STAGGER_PHASES");
-            if (gg.stagger > 0 && sp_s) gg.stagger = (gg.stagger & 0xFFFF) | (atoi(sp_s) << 16);
-        }
+        gg.stagger = 0;      // (the staggered-start experiment of rounds 3 / 4 showed no effect; its environment switches are gone, the field stays reserved)
         const GemmArgs& g = gg;
         if (g.rowpart != nullptr || g.rowstat != nullptr) {
             // folded LayerNorm: producer (residual epilogue) or consumer (head-split / fused-GELU epilogue); f16, no other special mode

@@ -134,16 +134,9 @@ extern "C" int sed_layernorm_fwd(const float* x, const float* gamma, const float
                                  void* y_bf16, float* y_f32, float* mean, float* rstd, int M, int D, int f16, hipStream_t stream) {
     (void)hipGetLastError();
     if (D != DM || M <= 0) return SED_ERR_ARG;
-    static const int rw = []() { const char* e = getenv("SED_LN_RW"); return e ? atoi(e) : 2; }();
-    if (rw == 4)
-        hipLaunchKernelGGL(layernorm_fwd_kernel<4>, dim3(cdiv(M, 16)), dim3(256), 0, stream, x, gamma, beta, eps, in_scale,
-                           (bf16_t*)y_bf16, y_f32, mean, rstd, M, f16);
-    else if (rw == 1)
-        hipLaunchKernelGGL(layernorm_fwd_kernel<1>, dim3(cdiv(M, 4)), dim3(256), 0, stream, x, gamma, beta, eps, in_scale,
-                           (bf16_t*)y_bf16, y_f32, mean, rstd, M, f16);
-    else
-        hipLaunchKernelGGL(layernorm_fwd_kernel<2>, dim3(cdiv(M, 8)), dim3(256), 0, stream, x, gamma, beta, eps, in_scale,
-                           (bf16_t*)y_bf16, y_f32, mean, rstd, M, f16);
+    // (two rows per wave: the 1- and 4-row variants measured slower on cold input, tools/ln_bench.py)
+    hipLaunchKernelGGL(layernorm_fwd_kernel<2>, dim3(cdiv(M, 8)), dim3(256), 0, stream, x, gamma, beta, eps, in_scale,
+                       (bf16_t*)y_bf16, y_f32, mean, rstd, M, f16);
     return sed_check_launch();
 }
 

@@ -216,7 +216,7 @@ class SedEngine:
         return None
 
     def _zeros(self, key, shape, dtype, dev, pooled=True):
-        if not pooled or os.environ.get("SED_ZERO_POOL", "1") == "0":
+        if not pooled:
             return torch.zeros(*shape, dtype=dtype, device=dev)
         t = self._zpool.get(key)
         if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != dev:
@@ -242,21 +242,6 @@ class SedEngine:
             names += ["mlm_mlp.0.weight", "mlm_mlp.2.weight"]
         if m.has_at:
             names += ["at_adpater.0.frequency_att.in_proj_weight"]
-        if os.environ.get("SED_WIMG_BATCH", "1") == "0":   # one transpose (+ split) launch per weight: A/B switch
-            for n in names:
-                w32 = self.P(n).detach()
-                n_out = w32.shape[0]
-                w2 = w32.reshape(n_out, -1)
-                k_in = w2.shape[1]
-                ent = self.cache.get(n)
-                if ent is None or ent.w.device != w32.device:
-                    ent = _W(torch.empty(n_out, k_in, dtype=self.act, device=w32.device),
-                             torch.empty(k_in, n_out, dtype=BF16, device=w32.device))
-                    self.cache[n] = ent
-                transpose_bf16(w2, n_out, k_in, ent.wt, out_s=ent.w)
-                if self.split and (n.startswith("decoder.") or n.startswith("mlm_mlp")):
-                    ent.ws = split3(w2.contiguous(), n_out, k_in, weight=True)
-            return self.cache
         ptrs = tuple(self.P(n).data_ptr() for n in names) + (bool(need_t), self.split)
         if getattr(self, "_wimg_key", None) != ptrs:
             # descriptor table of sed_weight_images: rebuilt only when a master moved (optimizer arenas, .to(device))
@@ -355,7 +340,7 @@ class SedEngine:
             # (slab-major planes are addressed through one 32-bit buffer range: a plane has to stay below 2 GiB -- M < 1.4 M tokens for the
             #  stream planes, M < 349 k for the fc1 activation; beyond that the f16 planes / the row-major activation)
             lo8 = self.ln_lo8 and M * D * 2 < 2 ** 31
-            slab_ok = lo8 and os.environ.get("SED_SLAB_ACT", "1") != "0"
+            slab_ok = lo8
             x16f, xlo, partf, statf = E(M, D, dt=F16), E(M, D, dt=torch.uint8 if lo8 else F16), E(M, D // 64, 2), E(M, 2)
             lnp = "sed_gemm_nt_lnp8" if lo8 else "sed_gemm_nt_lnp"      # (lnp8: both planes slab-major, read back by the *_lnc8 consumers)
             qkv_lnc, nt_lnc = ("sed_gemm_qkv_lnc8", "sed_gemm_nt_lnc8") if lo8 else ("sed_gemm_qkv_lnc", "sed_gemm_nt_lnc")
@@ -988,7 +973,7 @@ class SedEngine:
             g16 = E(M, n_out, dt=BF16) if dy.dtype == F32 else None
             # bias gradient: with a 16-bit dy the TN kernel sums its own dY fragments (no extra pass over dy); an fp32 dy needs the
             # cast pass anyway, which also yields the column sums
-            bias_in_gemm = g16 is None and bias is not None and gW is not None and Mt == M and os.environ.get("SED_TN_BIAS", "1") != "0"
+            bias_in_gemm = g16 is None and bias is not None and gW is not None and Mt == M
             if g16 is not None or (bias is not None and not bias_in_gemm):
                 transpose_bf16(dy, M, n_out, None, out_s=g16, colsum=bias)   # cast and/or column sums only, one pass
             dy16 = g16 if g16 is not None else dy

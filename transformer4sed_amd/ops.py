@@ -38,8 +38,6 @@ def h2d(x, dtype, dev):
     t = t.to(dtype).contiguous()
     if t.device.type != "cpu":
         return t.to(dev)
-    if os.environ.get("SED_H2D_RING", "1") == "0":      # A/B: a fresh pinned allocation per call
-        return t.pin_memory().to(dev, non_blocking=True)
     key = (tuple(t.shape), dtype)
     ring = _PIN_RINGS.get(key)
     if ring is None:

@@ -368,7 +368,7 @@ class MatSedTrainer:
         the features and of the labels (frame shift and mixup of both groups are one `sed_roll_mix` pass each: per-clip shift, partner and
         mixing weights), and one warp + filter pass per view."""
         tr = self.cfg["training"]
-        if tr["transform"]["choice"][1] or tr["transform"]["choice"][2] or not wav.is_cuda or os.environ.get("SED_PREPROCESS_BATCHED", "1") == "0":
+        if tr["transform"]["choice"][1] or tr["transform"]["choice"][2] or not wav.is_cuda or not getattr(self, "preprocess_batched", True):
             return self._preprocess_calls(wav, label, strong_n, weak_n)
         from .ops import UploadBlock
         ext = self.net.get_feature_extractor()
