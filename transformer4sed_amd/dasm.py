@@ -54,13 +54,13 @@ class DasmHead:
             raise NotImplementedError("head_dim must be 32 or 64")
         self.p = {k: v.detach().to(F32).contiguous() for k, v in params.items()}
         self.L, self.H, self.Dd, self.dh = n_layers, num_heads, decoder_dim, decoder_dim // num_heads
-        self._fused = None
+        self._fused = self._fused_split = None
 
     def refresh(self, params=None):
         """Call after the weights changed (the folded memory projection is cached)."""
         if params is not None:
             self.p = {k: v.detach().to(F32).contiguous() for k, v in params.items()}
-        self._fused = None
+        self._fused = self._fused_split = None
 
     def _memory_weights(self):
         """[K_0 | V_0 | K_1 | V_1 | ...] projections of the patch tokens with the at_projector folded in:
@@ -88,8 +88,19 @@ class DasmHead:
         E = lambda *s: torch.empty(*s, dtype=F32, device=dev)
         # ---- memory side: K / V of every layer from the patch tokens, one GEMM
         wkv, bkv = self._memory_weights()
-        KV = gemm_f32(frame_tokens.view(B * P, Din), wkv, bias=bkv)              # [B P, 2 L Dd]
         ldkv = 2 * L * Dd
+        if B * P >= 1024 and Din % 64 == 0 and ldkv % 256 == 0:
+            # the one large GEMM of the head (B P x 2 L Dd x 768) on the 16-bit matrix pipe in split precision: f16 hi / lo images of the
+            # tokens and of the folded weight, x_hi W_hi + x_lo W_hi + x_hi W_lo accumulated in fp32 (the context network's form,
+            # ~2^-20 of the product) -- 3 x the f16 FLOPs at ~10 x the fp32-MFMA rate
+            from . import ops
+            if self._fused_split is None or self._fused_split.device != dev:
+                self._fused_split = ops.split3(wkv, ldkv, Din, weight=True)
+            KV = E(B * P, ldkv)
+            with ops.split_precision():
+                ops.gemm_nt(ops.split3(frame_tokens.view(B * P, Din), B * P, Din), self._fused_split, ops.EPI_F32, bias=bkv, outF=KV)
+        else:
+            KV = gemm_f32(frame_tokens.view(B * P, Din), wkv, bias=bkv)          # [B P, 2 L Dd]
         # ---- queries (detect_any_sound.py:283-299): nn.Linear + GELU on the embeddings
         q_in = (p["at_query"] if query is None else query.to(device=dev, dtype=F32)).contiguous()
         Q = q_in.shape[0]
