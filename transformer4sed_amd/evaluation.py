@@ -206,29 +206,9 @@ class Evaluator:
         kw = self.config[self.net.get_model_name()]["val_kwargs"]
         labels_weak = (labels.sum(-1) >= 1)
         out = {}
-        # Round 5: the two no-grad forwards are independent -- the teacher's is issued on a second HIP stream beside the student's (their
-        # workgroups fill each other's partially occupied rounds, like the train step's teacher pass), and the host-side halves (score
-        # tables, event lists: pandas) of the student then run while the teacher's kernels are still going.  `overlap = False` serialises.
-        fwd = {}
-        if getattr(self, "overlap", True) and feat.is_cuda:
-            main = torch.cuda.current_stream()
-            if getattr(self, "_side", None) is None:
-                self._side = torch.cuda.Stream()
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                fwd["teacher"] = self.ema_net(feat, pad_mask=pad_mask, **kw)
-            fwd["student"] = self.net(feat, pad_mask=pad_mask, **kw)
-            feat.record_stream(self._side)
         for who, model, raw_buf, post_buf in (("student", self.net, self.scores.raw_student, self.scores.post_student),
                                               ("teacher", self.ema_net, self.scores.raw_teacher, self.scores.post_teacher)):
-            if who in fwd:
-                if who == "teacher":
-                    torch.cuda.current_stream().wait_stream(self._side)
-                    for t in (fwd[who][0], fwd[who][1], fwd[who][2]["at_out"]):
-                        t.record_stream(torch.cuda.current_stream())
-                strong, weak, other = fwd[who]
-            else:
-                strong, weak, other = model(feat, pad_mask=pad_mask, **kw)
+            strong, weak, other = model(feat, pad_mask=pad_mask, **kw)
             self.weak_f1[who].update(other["at_out"], labels_weak)
             raw, post = batched_decode_preds(strong, paths, self.encoder, filter=self.median_filter, weak_preds=weak,
                                              need_weak_mask=self.weak_mask, filter_type=self.filter_type)
