@@ -601,6 +601,10 @@ def main():
                             "instrumented_steps": f"{timed_steps_with_events} of the {a.steps} timed steps",
                             "gemm_share_of_step": round(ms / timed_steps_with_events / (1000 * dt / a.steps), 3),
                             "flops_per_launch": round(fl / max(1, n) / 1e9, 3)}
+        clk = ((gpu_state or {}).get("sclk_MHz") or {}).get("mean")
+        if clk:      # the same rate against what the matrix pipes can do at the clock the step actually ran at (the chip clocks to its power budget)
+            line["roofline"]["sclk_MHz_mean"] = clk
+            line["roofline"]["frac_at_measured_clock"] = round(ach / (PEAK_BF16_TFLOPS * clk / 2400.0), 4)
     if a.mode in ("finetune1", "pretrain"):
         line["config"]["workload"] = {"finetune1": "MAT-SED base finetune1 step (config/mat-sed/base/finetune1.yaml): encoder and context "
                                                    "net frozen, heads trained, mean-teacher losses, teacher without windows",
