@@ -4,6 +4,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -47,3 +48,36 @@ def test_dasm_oracle_vs_reference_forward(golden):
     # the novel queries do not disturb the base queries' outputs (what the demo's attention mask is for)
     s_ov, _, a_ov, _ = dasm_oracle.dasm_head(sd, frame, x_dec, query=ext, tgt_mask=tmask, temp_w=0.1, n_layers=CFG["at_layers"])
     assert float((a_ov[:, :8] - a).abs().max()) < 1e-5 and float((s_ov[:, :8] - s).abs().max()) < 1e-4
+
+
+def test_dasm_state_dict_uses_the_reference_key_names():
+    """transformer4sed_amd.dasm.DASM keeps its trunk under this package's names (`decoder.`, `out_norm.`) and exposes the reference's
+    (`sed_decoder.`, `norm_before_pool.`) in state_dict() / load_state_dict() -- also inside a wrapper module (prefix).  CPU only."""
+    from transformer4sed_amd.dasm import DASM
+    cnn = dict(n_in_channel=1, activation="cg", conv_dropout=0.5, kernel_size=[3] * 10, padding=[1] * 10, stride=[1] * 10,
+               nb_filters=list(synth.PMAM_FILTERS), pooling=[list(p) for p in synth.PMAM_POOLING])
+
+    def make():
+        return DASM(cnn_param=cnn, backbone_param=dict(embed_dim=768, passt_feature_layer=10, pretrain_model_path=None, lora_config=None),
+                    at_param=dict(at_decoder_layer=2, query_projector=True, query_dim=1024, out_type="sigmoid", query=torch.zeros(8, 1024)),
+                    decoder="transformerXL", decoder_layer_num=3, decoder_dim=768, num_heads=12, class_num=8)
+    net = make()
+    sd = net.state_dict()
+    ref = synth.dasm_full_state_dict_np(n_queries=8, query_dim=1024)
+    assert {k for k in sd if not k.startswith("mel_trans.")} == set(ref)
+    assert all(tuple(sd[k].shape) == tuple(np.asarray(v).shape) for k, v in ref.items())
+    r = net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in ref.items()}, strict=False)
+    assert not r.unexpected_keys and all(k.startswith("mel_trans.") for k in r.missing_keys)
+    assert torch.equal(net.decoder.encoder_blocks[0].norm1.weight, torch.from_numpy(ref["sed_decoder.encoder_blocks.0.norm1.weight"]))
+    assert torch.equal(net.out_norm.bias, torch.from_numpy(ref["norm_before_pool.bias"]))
+
+    class Wrap(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.module = make()
+    w = Wrap()
+    sdw = w.state_dict()
+    assert "module.sed_decoder.encoder_blocks.0.norm1.weight" in sdw and not any(k.startswith(("module.decoder.", "module.out_norm.")) for k in sdw)
+    Wrap().load_state_dict(sdw, strict=True)
+    with pytest.raises(NotImplementedError):
+        DASM(cnn_param=cnn, decoder="gru")

@@ -230,31 +230,30 @@ class DASM(PaSST_CNN):
         self.dasm_head = None
         self._dasm_query = self._dasm_tgt_mask = None
         self._head_generation = -1
+        self._register_state_dict_hook(DASM._sd_rename_out)
+        self._register_load_state_dict_pre_hook(DASM._sd_rename_in, with_module=True)
         self._index_params()
 
-    # ---- state_dict under the reference's names
-    def state_dict(self, *a, **k):
-        sd = super().state_dict(*a, **k)
-        out = type(sd)()
-        for key, v in sd.items():
+    # ---- state_dict under the reference's names (hooks: they also apply when the model sits inside a wrapper module, with its prefix)
+    @staticmethod
+    def _sd_rename_out(module, state_dict, prefix, local_metadata):
+        for key in [k for k in state_dict if k.startswith(prefix)]:
+            tail = key[len(prefix):]
             for mine, ref in _RENAME:
-                if key.startswith(mine):
-                    key = ref + key[len(mine):]
+                if tail.startswith(mine):
+                    state_dict[prefix + ref + tail[len(mine):]] = state_dict.pop(key)
                     break
-            out[key] = v
-        return out
+        return state_dict
 
-    def load_state_dict(self, state_dict, strict=True, **k):
-        sd = {}
-        for key, v in state_dict.items():
+    @staticmethod
+    def _sd_rename_in(module, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        for key in [k for k in state_dict if k.startswith(prefix)]:
+            tail = key[len(prefix):]
             for mine, ref in _RENAME:
-                if key.startswith(ref):
-                    key = mine + key[len(ref):]
+                if tail.startswith(ref):
+                    state_dict[prefix + mine + tail[len(ref):]] = state_dict.pop(key)
                     break
-            sd[key] = v
-        r = super().load_state_dict(sd, strict=strict, **k)
-        self._head_generation = -1
-        return r
+        module._head_generation = -1
 
     _HEAD_PREFIXES = ("at_projector.", "query_projector.", "at_query", "at_decoder.", "at_head.", "mask_embedding_layer.", "sed_head.")
 
