@@ -628,7 +628,7 @@ def main():
                                       "EMA teacher forward with val_kwargs (17 windows of 512 frames, step 31, temp 0.5), soft-masked "
                                       "scipy-median score tables and half-point event decoding")
         line["config"].pop("final_loss", None)
-    if rank == 0 and not a.no_cpu_baseline and a.mode == "finetune2":
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.mode == "finetune2" and not pipe:      # (N = 1 only: the other ranks would sit in the final barrier meanwhile)
         line["cpu_baseline"] = cpu_baseline(a.depth)
     # RCCL writes its version banner through C stdio (block-buffered when piped): every rank pushes it out before the last
     # barrier so that rank 0's JSON line is the last thing on the job's stdout
