@@ -11,8 +11,8 @@
 //                         (exact fp32 products and accumulation at the fp32 vector rate, without one VALU instruction per FMA and
 //                         with a 64 x 64 output tile fed from LDS: MI355X_MICROARCH.md "FP32-input MFMA");
 //   * sed_xattn_f32_fwd   softmax(q k^T / sqrt(dh) + mask) v for query counts that differ from the key count (cross attention over the
-//                         patch tokens, self attention among the queries with the open-vocabulary mask), one lane per query, four
-//                         waves splitting the key tiles, K / V tiles broadcast from LDS, online softmax over 16-key chunks;
+//                         patch tokens, self attention among the queries with the open-vocabulary mask), both products on the same
+//                         fp32 matrix instruction, 32 queries per workgroup, four waves splitting the key tiles;
 //   * sed_dasm_head_fwd   the dual-stream finish on the [B, T, Q] logits: sigmoid / temperature, times the clip-level tagging
 //                         probability, pad mask, clamp, transposed store [B, Q, T], linear-softmax pooling.
 #include "common.h"
@@ -108,132 +108,145 @@ extern "C" int sed_gemm_f32_nt(const float* A, const float* B, const float* bias
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// attention with Nq != Nk, fp32: O[b, i, h*DH + d] = sum_j softmax_j(q_i . k_j / sqrt(DH) + mask_ij) v_j[d]
-// One workgroup per (64 queries, head, clip): lane = query, the four waves take every fourth key tile each.  Per 64-key tile the K and V rows (DH floats each, row pitch DH + 4 so that the
-// 16-byte row writes of 8 lanes cover all banks) sit in LDS and are read as broadcasts (every lane the same address); the lane keeps
-// its query (pre-scaled by log2(e) / sqrt(DH)) and its output row in registers.  Online softmax over chunks of 16 keys: one rescale of
-// the output row per chunk.  Q rows / K rows / V rows are addressed through their own leading dimensions, so the packed in_proj outputs
-// ([.., 3 D] self attention, [.., 2 L D] memory projections of all layers) are read in place.
+// attention with Nq != Nk, fp32, on v_mfma_f32_32x32x2_f32:   O[b, i, h*DH + d] = sum_j softmax_j(q_i . k_j / sqrt(DH) + mask_ij) v_j[d]
+// One workgroup per (32 queries, head, clip); its four waves take every fourth 32-key tile each and merge their partial (max, sum,
+// output) triples through LDS at the end (log-sum-exp combination).  Per tile and wave, in the "swapped" form of the encoder attention
+// (a lane owns one query column of every accumulator: lane = (query q = lane & 31, half g = lane >> 5)):
+//   S^T[key, q]  = sum_d K[key, d] Q[q, d]     DH / 2 MFMAs; A = K rows out of the wave-private LDS tile (row pitch DH + 4 floats), B = the
+//                                              query row held in DH / 2 registers (pre-scaled by log2(e) / sqrt(DH))
+//   online softmax along the 16 accumulator registers + one cross-half shuffle
+//   O^T[d, q]   += sum_key V^T[d, key] P^T[key, q]     DH / 2 MFMAs; B = the S^T accumulator registers themselves (register r of the two
+//                                              halves holds exactly the key pair (row(r, 0), row(r, 1)) of one k step), A = V rows from LDS
+// fp32 operands and accumulation throughout (the matrix instruction runs at the fp32 vector rate, but without an LDS operand read and a
+// VALU issue slot per FMA: the first version of this kernel, one lane per query with broadcast K / V reads, spent 128 FMA instructions and
+// 32 ds_read_b128 per key and wave).  Q / K / V rows are addressed through their own leading dimensions (packed in_proj outputs are read
+// in place); mask [Nq, Nk] bytes, non-zero = not allowed.
 // ---------------------------------------------------------------------------------------------------------------------
 #define XA_WAVES 4
+#define XA_KT 32
 template <int DH, bool MASK>
 __global__ __launch_bounds__(64 * XA_WAVES) void xattn_f32_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ Kp,
                                                                       const float* __restrict__ Vp, float* __restrict__ O,
                                                                       const unsigned char* __restrict__ mask, int Nq, int Nk, int ldq, int ldk,
                                                                       int ldv, int ldo, long long q_bstride) {
-    // Four waves share the 64 queries of the workgroup and split the KEY tiles between them (wave w takes tiles w, w + 4, ...: with
-    // ~300 workgroups per launch a single wave per CU would leave every LDS / FMA latency exposed); their partial (max, sum, output row)
-    // triples are merged through LDS at the end -- the usual log-sum-exp combination.
-    constexpr int LDK = DH + 4;
+    constexpr int LDK = DH + 4, NDB = DH / 32, MS = DH + 2;
     extern __shared__ __attribute__((aligned(16))) float xa_lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = blockIdx.y, b = blockIdx.z;
-    float* Ks = xa_lds + wave * (2 * 64 * LDK);
-    float* Vs = Ks + 64 * LDK;
-    const int qi = blockIdx.x * 64 + lane;
+    const int lq = lane & 31, lg = lane >> 5;
+    float* Ks = xa_lds + wave * (2 * XA_KT * LDK);
+    float* Vs = Ks + XA_KT * LDK;
+    const int qi = blockIdx.x * 32 + lq;
     const int qc = qi < Nq ? qi : Nq - 1;
     const float sc = 1.4426950408889634f * rsqrtf((float)DH);
-    float q[DH], o[DH];
+    // B operand of the score product: Q[q][2 j + g], j = 0 .. DH / 2 - 1
+    float qf[DH / 2];
     {
-        const float* qp = Q + (size_t)b * q_bstride + (size_t)qc * ldq + h * DH;
+        const float* qp = Q + (size_t)b * q_bstride + (size_t)qc * ldq + h * DH + lg;
 #pragma unroll
-        for (int d = 0; d < DH; d += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(qp + d);
-            q[d] = v.x * sc; q[d + 1] = v.y * sc; q[d + 2] = v.z * sc; q[d + 3] = v.w * sc;
-        }
+        for (int j = 0; j < DH / 2; ++j) qf[j] = qp[2 * j] * sc;
     }
+    f32x16 o[NDB];
 #pragma unroll
-    for (int d = 0; d < DH; ++d) o[d] = 0.f;
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     const float* kb = Kp + (size_t)b * Nk * ldk + h * DH;
     const float* vb = Vp + (size_t)b * Nk * ldv + h * DH;
-    for (int j0 = wave * 64; j0 < Nk; j0 += 64 * XA_WAVES) {
+    // tile loader: lane -> (key row lane >> 1, half row lane & 1): DH / 2 floats = DH / 8 float4 of K and of V
+    const int trow = lane >> 1, thalf = (lane & 1) * (DH / 2);
+    for (int j0 = wave * XA_KT; j0 < Nk; j0 += XA_KT * XA_WAVES) {
         {
-            // rows past the end re-read the last key (their scores are masked below, their V rows meet p = 0): plain loads, no selects
-            const int j = (j0 + lane) < Nk ? (j0 + lane) : Nk - 1;
-            const float* kr = kb + (size_t)j * ldk;
-            const float* vr = vb + (size_t)j * ldv;
-            float4 kreg[DH / 4], vreg[DH / 4];
+            const int j = (j0 + trow) < Nk ? (j0 + trow) : Nk - 1;      // (rows past the end: their scores are masked, their V rows meet p = 0)
+            const float4* kr = reinterpret_cast<const float4*>(kb + (size_t)j * ldk + thalf);
+            const float4* vr = reinterpret_cast<const float4*>(vb + (size_t)j * ldv + thalf);
+            float4 kreg[DH / 8], vreg[DH / 8];
 #pragma unroll
-            for (int d = 0; d < DH / 4; ++d) { kreg[d] = reinterpret_cast<const float4*>(kr)[d]; vreg[d] = reinterpret_cast<const float4*>(vr)[d]; }
-            __builtin_amdgcn_wave_barrier();      // (the tile buffers are private to the wave: no workgroup barrier)
+            for (int d = 0; d < DH / 8; ++d) { kreg[d] = kr[d]; vreg[d] = vr[d]; }
+            __builtin_amdgcn_wave_barrier();      // (the tile buffers are private to the wave: the previous tile's reads are behind us in program order)
 #pragma unroll
-            for (int d = 0; d < DH / 4; ++d) {
-                *reinterpret_cast<float4*>(Ks + lane * LDK + 4 * d) = kreg[d];
-                *reinterpret_cast<float4*>(Vs + lane * LDK + 4 * d) = vreg[d];
+            for (int d = 0; d < DH / 8; ++d) {
+                *reinterpret_cast<float4*>(Ks + trow * LDK + thalf + 4 * d) = kreg[d];
+                *reinterpret_cast<float4*>(Vs + trow * LDK + thalf + 4 * d) = vreg[d];
             }
             __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        const int nj = (Nk - j0) < 64 ? (Nk - j0) : 64;
-        for (int c0 = 0; c0 < nj; c0 += 16) {
-            float s[16];
-            float cmax = -INFINITY;
+        // ---- S^T[key, q]: A = K[key = lq][2 j + lg]
+        f32x16 st;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;      // four independent chains: a single one is latency-bound
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
-                for (int d = 0; d < DH; d += 4) {
-                    const float4 kv = *reinterpret_cast<const float4*>(Ks + (c0 + c) * LDK + d);
-                    a0 = fmaf(q[d], kv.x, a0); a1 = fmaf(q[d + 1], kv.y, a1); a2 = fmaf(q[d + 2], kv.z, a2); a3 = fmaf(q[d + 3], kv.w, a3);
-                }
-                __builtin_amdgcn_sched_barrier(0);      // (keeps the 16 keys' LDS reads from being hoisted into 500 live registers)
-                const int j = j0 + c0 + c;
-                bool dead = j >= Nk;
-                if (MASK) dead = dead || mask[(size_t)qc * Nk + (j < Nk ? j : Nk - 1)] != 0;      // (branch-free: a select, not a jump per key)
-                s[c] = dead ? -INFINITY : (a0 + a1) + (a2 + a3);
-                cmax = fmaxf(cmax, s[c]);
-            }
-            const float m_new = fmaxf(m_run, cmax);
-            // (a chunk whose keys are all masked for this query leaves m_new = -inf while nothing has been seen: alpha = 1, p = 0 then)
-            const float alpha = m_new == -INFINITY ? 1.f : exp2f(m_run - m_new);
-            float psum = 0.f;
+        for (int j = 0; j < DH / 2; ++j) st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[lq * LDK + 2 * j + lg], qf[j], st, 0, 0, 0);
+        // ---- online softmax over the lane's 16 keys (register r <-> key j0 + mfma32_row(r, lg)) and the other half's 16
+        float cmax = -INFINITY;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                s[c] = m_new == -INFINITY ? 0.f : exp2f(s[c] - m_new);
-                psum += s[c];
-            }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
+        for (int r = 0; r < 16; ++r) {
+            const int j = j0 + mfma32_row(r, lg);
+            bool dead = j >= Nk;
+            if (MASK) dead = dead || mask[(size_t)qc * Nk + (j < Nk ? j : Nk - 1)] != 0;
+            st[r] = dead ? -INFINITY : st[r];
+            cmax = fmaxf(cmax, st[r]);
+        }
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        const float m_new = fmaxf(m_run, cmax);
+        // (a tile whose keys are all masked for this query while nothing has been seen yet: m_new = -inf, alpha = 1, p = 0)
+        const float alpha = m_new == -INFINITY ? 1.f : exp2f(m_run - m_new);
+        float psum = 0.f;
 #pragma unroll
-            for (int d = 0; d < DH; ++d) o[d] *= alpha;
+        for (int r = 0; r < 16; ++r) {
+            st[r] = m_new == -INFINITY ? 0.f : exp2f(st[r] - m_new);
+            psum += st[r];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
+        for (int db = 0; db < NDB; ++db)
 #pragma unroll
-                for (int d = 0; d < DH; d += 4) {
-                    const float4 vv = *reinterpret_cast<const float4*>(Vs + (c0 + c) * LDK + d);
-                    o[d] = fmaf(s[c], vv.x, o[d]); o[d + 1] = fmaf(s[c], vv.y, o[d + 1]); o[d + 2] = fmaf(s[c], vv.z, o[d + 2]); o[d + 3] = fmaf(s[c], vv.w, o[d + 3]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        // ---- O^T[d, q] += V^T[d, key] P^T[key, q]: k step r = the key pair (row(r, 0), row(r, 1)); A = V[row(r, lg)][32 db + lq], B = st[r]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* vrow = Vs + mfma32_row(r, lg) * LDK + lq;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32 * db], st[r], o[db], 0, 0, 0);
         }
     }
-    // merge the four waves' partial results: slot [wave][lane][DH + 2] in the (now idle) tile buffers
+    // ---- merge the four waves' partial results: slot [wave][query][DH + 2]; lane (q, g) owns d = 32 db + mfma32_row(r, g)
     __syncthreads();
-    constexpr int MS = DH + 2;
-    float* mg = xa_lds + (size_t)(wave * 64 + lane) * MS;
+    {
+        float* mg = xa_lds + (size_t)(wave * 32 + lq) * MS;
 #pragma unroll
-    for (int d = 0; d < DH; ++d) mg[d] = o[d];
-    mg[DH] = m_run; mg[DH + 1] = l_run;
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mg[32 * db + mfma32_row(r, lg)] = o[db][r];
+        if (lg == 0) { mg[DH] = m_run; mg[DH + 1] = l_run; }
+    }
     __syncthreads();
-    if (wave == 0 && qi < Nq) {
+    // every wave finishes a quarter of the output columns of the 32 queries: lane -> (query lq, column group)
+    {
+        constexpr int CW = DH / (2 * XA_WAVES);            // columns per lane: DH / 8
+        const int d0 = (wave * 2 + lg) * CW;
         float mx = -INFINITY;
 #pragma unroll
-        for (int w = 0; w < XA_WAVES; ++w) mx = fmaxf(mx, xa_lds[(size_t)(w * 64 + lane) * MS + DH]);
-        float l = 0.f;
+        for (int w = 0; w < XA_WAVES; ++w) mx = fmaxf(mx, xa_lds[(size_t)(w * 32 + lq) * MS + DH]);
+        float l = 0.f, acc[CW];
 #pragma unroll
-        for (int d = 0; d < DH; ++d) o[d] = 0.f;
+        for (int d = 0; d < CW; ++d) acc[d] = 0.f;
 #pragma unroll
         for (int w = 0; w < XA_WAVES; ++w) {
-            const float* pw = xa_lds + (size_t)(w * 64 + lane) * MS;
+            const float* pw = xa_lds + (size_t)(w * 32 + lq) * MS;
             const float f = pw[DH] == -INFINITY ? 0.f : exp2f(pw[DH] - mx);
             l = fmaf(pw[DH + 1], f, l);
 #pragma unroll
-            for (int d = 0; d < DH; ++d) o[d] = fmaf(pw[d], f, o[d]);
+            for (int d = 0; d < CW; ++d) acc[d] = fmaf(pw[d0 + d], f, acc[d]);
         }
-        const float inv = 1.0f / l;      // (a query with every key masked: 0 / 0 = NaN, like torch's softmax over an all -inf row)
-        float* op = O + ((size_t)b * Nq + qi) * ldo + h * DH;
+        if (qi < Nq) {
+            const float inv = 1.0f / l;      // (a query with every key masked: 0 / 0 = NaN, like torch's softmax over an all -inf row)
+            float* op = O + ((size_t)b * Nq + qi) * ldo + h * DH + d0;
 #pragma unroll
-        for (int d = 0; d < DH; d += 4) *reinterpret_cast<float4*>(op + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+            for (int d = 0; d < CW; d += 4) *reinterpret_cast<float4*>(op + d) = make_float4(acc[d] * inv, acc[d + 1] * inv, acc[d + 2] * inv, acc[d + 3] * inv);
+        }
     }
 }
 
@@ -243,10 +256,11 @@ extern "C" int sed_xattn_f32_fwd(const float* Q, const float* K, const float* V,
     if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0 || (head_dim != 32 && head_dim != 64) || ((ldq | ldk | ldv | ldo) & 3) || B > 65535 || H > 65535)
         return SED_ERR_ARG;
     if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)O) & 15) return SED_ERR_ARG;
-    const dim3 grid(cdiv(Nq, 64), H, B);
+    const dim3 grid(cdiv(Nq, 32), H, B);
 #define XATTN_LAUNCH(DH_, MK_)                                                                                                   \
     {                                                                                                                            \
-        const int lds_ = XA_WAVES * 2 * 64 * (DH_ + 4) * 4;                                                                      \
+        const int tile_ = XA_WAVES * 2 * XA_KT * (DH_ + 4) * 4, merge_ = XA_WAVES * 32 * (DH_ + 2) * 4;                          \
+        const int lds_ = tile_ > merge_ ? tile_ : merge_;                                                                        \
         static bool attr_ = false;                                                                                               \
         if (!attr_) { (void)hipFuncSetAttribute((const void*)xattn_f32_fwd_kernel<DH_, MK_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); attr_ = true; } \
         hipLaunchKernelGGL((xattn_f32_fwd_kernel<DH_, MK_>), grid, dim3(64 * XA_WAVES), lds_, stream, Q, K, V, O, mask, Nq, Nk, ldq, ldk, ldv, ldo, \
