@@ -110,6 +110,18 @@ int sed_gemm_nt_w2(const void* A, const void* B, int M, int N, int K, int lda, i
                    const float* resF, float* outF, void* outH, void* outH2, int ldc, int f16, hipStream_t stream);
 int sed_gemm_qkv_w2(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq, int seq_pad, void* q,
                     void* k, void* v, int f16, hipStream_t stream);
+/* ... with the lo product x . (W - f16(W))^T on the fp8 matrix path (v_mfma_scale_f32_16x16x128_f8f6f4): half of an f16 K pass for a
+ * term that is 2^-12 of the result and needs ~4 significant bits of either factor.  Operand rows carry both images: A [M][K f16 | K e4m3]
+ * (row pitch lda halfs >= 3K / 2; the e4m3 half = 2^-2 x the activation: sed_fp8_tail, or the producing kernels' fp8 flags), B [N][K f16 |
+ * K e4m3] = sed_weight_two_term_f8(W, s) with f8_exp = s.  K % 128 == 0; otherwise like sed_gemm_nt_w2 / sed_gemm_qkv_w2. */
+int sed_gemm_nt_w2f8(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi, const float* bias,
+                     const float* resF, float* outF, void* outH, void* outH2, int ldc, int f8_exp, hipStream_t stream);
+int sed_gemm_qkv_w2f8(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq, int seq_pad, void* q,
+                      void* k, void* v, int f8_exp, hipStream_t stream);
+/* x rows [K f16 | K e4m3] of pitch ld halfs: fills the e4m3 half (OCP e4m3, round to nearest even, clamped to +-448) with 2^-2 x the f16 half */
+int sed_fp8_tail(void* x, int M, int K, int ld, hipStream_t stream);
+/* fp32 weight [N, K] -> out rows [f16(W) | e4m3(2^s (W - f16(W)))], 3K bytes each */
+int sed_weight_two_term_f8(const float* w, void* out, int64_t N, int K, int s, hipStream_t stream);
 /* LayerNorm FOLDED into the two Linear layers around it -- timm Block.forward `x = x + attn(norm1(x))`, `x = x + mlp(norm2(x))`
  * (src/models/passt/passt.py:360-363 with the F.linear calls of :332,342 and Mlp fc1 / fc2) for no-grad f16 passes (teacher, inference), so
  * that the normalised tensor never exists in memory:

@@ -271,6 +271,74 @@ def test_gemm_two_term_weights_and_row_group_bias():
         gemm_nt(x[:512], W2[:768], ops.EPI_F32_RESID, bias=b[:768], res=torch.zeros(512, 768, device=DEV), outF=torch.zeros(512, 768, device=DEV), two_term=True)
 
 
+def test_gemm_two_term_fp8_lo():
+    """Two-term weights with the lo product on the fp8 matrix path (sed_gemm_nt_w2f8 / sed_gemm_qkv_w2f8): the e4m3 images against
+    torch's float8_e4m3fn, the GEMM against the exact value of what it is defined to compute, and its distance to the fp64 product against
+    the all-f16 two-term form's."""
+    from transformer4sed_amd.ops import two_term_weight, two_term_weight_f8, fp8_rows, fp8_tail, gemm_nt_w2f8
+    E4 = torch.float8_e4m3fn
+    for (M, N, K) in ((2 * 1190, 768, 768), (2048, 768, 3072), (1190 * 2, 3072, 768)):
+        x = rnd(M, K, seed=91) * (1.0 + 3.0 * (rnd(1, K, seed=92) > 1.5))       # a few loud channels
+        W = rnd(N, K, scale=0.03, seed=93); bias = rnd(N, seed=94); res = rnd(M, N, seed=95)
+        A = fp8_rows(M, K, DEV)
+        A[:, :K] = x.to(F16)
+        A[:, K:] = 0
+        fp8_tail(A, K)
+        a16 = A[:, :K].float()
+        a8 = A[:, K:].contiguous().view(torch.uint8).view(M, K)
+        want8 = (0.25 * a16).clamp(-448, 448).to(E4).view(torch.uint8)
+        assert torch.equal(a8, want8)
+        img, s = two_term_weight_f8(W)
+        hi = W.to(F16)
+        lo = W - hi.float()
+        assert s % 2 == 0 and float(lo.abs().max()) * 2.0 ** s <= 448.0 < float(lo.abs().max()) * 2.0 ** (s + 2)
+        assert torch.equal(img[:, :2 * K].contiguous().view(F16).view(N, K), hi)
+        w8 = img[:, 2 * K:].contiguous()
+        assert torch.equal(w8, (lo * 2.0 ** s).clamp(-448, 448).to(E4).view(torch.uint8))
+        out = torch.empty(M, N, device=DEV)
+        gemm_nt_w2f8(A, img, s, ops.EPI_F32_RESID, K, bias=bias, res=res, outF=out)
+        # what it is defined to compute, in fp64
+        defined = (a16.double() @ hi.double().t() + (a8.view(E4).double() @ w8.view(E4).double().t()) * 2.0 ** (2 - s) + bias.double() + res.double())
+        e_def = maxerr(out, defined.float())
+        ref = (a16.double() @ W.double().t() + bias.double() + res.double()).float()
+        e8 = maxerr(out, ref)
+        two = torch.empty(M, N, device=DEV)
+        gemm_nt(A[:, :K].contiguous(), two_term_weight(W), ops.EPI_F32_RESID, bias=bias, res=res, outF=two, two_term=True)
+        e2 = maxerr(two, ref)
+        one = torch.empty(M, N, device=DEV)
+        gemm_nt(A[:, :K].contiguous(), hi, ops.EPI_F32_RESID, bias=bias, res=res, outF=one)
+        e1 = maxerr(one, ref)
+        report(f"fp8 lo product {M}x{N}x{K}: vs definition {e_def:.2e}, vs fp64 {e8:.2e} (f16 two-term {e2:.2e}, f16 weight {e1:.2e})", e8, float(ref.abs().max()))
+        assert e_def < 3e-6 * float(ref.abs().max()) * math.sqrt(K / 768)
+        # e1 is the size of the lo product itself (what an f16 weight drops); e4m3 keeps ~2^-4.5 of each factor -> the lo product to ~0.05 of itself
+        assert e2 < e8 < e1 / 12
+        act = torch.empty(M, N, dtype=F16, device=DEV)
+        gemm_nt_w2f8(A, img, s, ops.EPI_GELU, K, bias=bias, outH2=act)
+        pre = defined.float() - res
+        assert maxerr(act.float(), torch.nn.functional.gelu(pre)) < 1.2 * 2 ** -11 * float(pre.abs().max()) + 1e-6
+    # beyond the e4m3 range after the 2^-2: clamps to +-448 (not NaN)
+    A = fp8_rows(1024, 128, DEV); A.zero_(); A[5, 7] = 3000.0; A[6, 9] = -60000.0; fp8_tail(A, 128)
+    t8 = A[:, 128:].contiguous().view(torch.uint8).view(1024, 128).view(E4).float()
+    assert float(t8[5, 7]) == 448.0 and float(t8[6, 9]) == -448.0 and int((t8 != 0).sum()) == 2
+    # head-split form
+    B, Ntok, Hh, K = 2, 602, 12, 768
+    M = B * Ntok
+    x = rnd(M, K, seed=96); W = rnd(2304, K, scale=0.03, seed=97); b = rnd(2304, seed=98)
+    A = fp8_rows(M, K, DEV); A[:, :K] = x.to(F16); fp8_tail(A, K)
+    img, s = two_term_weight_f8(W)
+    mk = lambda: torch.empty(B * Hh, Ntok, 64, dtype=F16, device=DEV)
+    q, k, v = mk(), mk(), mk()
+    call("sed_gemm_qkv_w2f8", A, img, b, M, K, Hh, Ntok, pad64(Ntok), q, k, v, s)
+    ref = (A[:, :K].double() @ W.double().t() + b.double()).float().view(B, Ntok, 3, Hh, 64).permute(2, 0, 3, 1, 4)
+    for got, i in ((q, 0), (k, 1), (v, 2)):
+        want = ref[i].reshape(B * Hh, Ntok, 64)
+        assert maxerr(got.float(), want) < 1.1 * 2 ** -11 * float(want.abs().max())     # the f16 output rounding and nothing else
+    with pytest.raises(RuntimeError):       # odd scale exponent / outside the 256^2 kernel's domain
+        call("sed_gemm_qkv_w2f8", A, img, b, M, K, Hh, Ntok, pad64(Ntok), q, k, v, s + 1)
+    with pytest.raises(RuntimeError):
+        gemm_nt_w2f8(A[:512], img[:768], s, ops.EPI_F32_RESID, K, bias=b[:768], res=torch.zeros(512, 768, device=DEV), outF=torch.zeros(512, 768, device=DEV))
+
+
 def test_gemm_layernorm_fold():
     """LayerNorm folded into the GEMMs around it (sed_gemm_nt_lnp -> sed_ln_fold_stats -> sed_gemm_nt_lnc / sed_gemm_qkv_lnc with
     sed_ln_fold_weight images) against Linear(LayerNorm(x)) in fp64, and against the unfolded HIP path (LayerNorm kernel -> f16 -> GEMM):

@@ -19,7 +19,10 @@
 #define WINOFF 112
 #define NMEL 128
 #define NBIN 513
-#define FR_PER_WG 8
+#ifndef FR_PER_WG
+#define FR_PER_WG 8      // frames per workgroup (multiple of 8).  More frames per workgroup amortise the setup but measured slower (B = 32: 100 us at 8, 119 at 16, 131 at 32, 136 at 64): the kernel is bound by barrier latency and wants many workgroups
+#endif
+#define FR_TILE 8        // frames per staged output tile
 
 __global__ void zero_u32_kernel(unsigned* __restrict__ p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -76,7 +79,7 @@ __device__ __forceinline__ f32x2v cmul_tw(f32x2v z, f32x2v tw, f32x2v twp) {   /
 }
 __device__ __forceinline__ f32x2v mul_neg_i(f32x2v d) { return f32x2v{d.y, -d.x}; }
 
-// One workgroup = 8 frames as 4 pairs; a pair of real frames is one 1024-point complex radix-4 Stockham FFT in LDS.  Everything a
+// One workgroup = FR_PER_WG frames as pairs; a pair of real frames is one 1024-point complex radix-4 Stockham FFT in LDS.  Everything a
 // pair needs besides its samples lives on chip for the whole workgroup: the window taps and the 12 twiddle factors of a lane in
 // registers, the non-zero filterbank weights as a CSR image in LDS; the samples of the next pair are requested before the current
 // pair's FFT.  The arithmetic is packed fp32 on (re, im) pairs.
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
                                                      float* __restrict__ out, int L, int T, int do_log) {
     __shared__ f32x2v z[2][NFFT];
     __shared__ float pw[2][NBIN + 3];
-    __shared__ float ostage[NMEL][FR_PER_WG];
+    __shared__ float ostage[NMEL][FR_TILE];
     __shared__ float wcsr[MEL_CSR_CAP];
     __shared__ int moff[NMEL + 1];
     const int tid = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * FR_PER_WG;
@@ -156,8 +159,10 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
         for (int q = 0; q < 4; ++q)
             z[0][tid + 256 * q] = f32x2v{wv[q] * (sa[q][1] - 0.97f * sa[q][0]), wv[q] * (sb[q][1] - 0.97f * sb[q][0])};
         __syncthreads();
-        if (pair + 1 < FR_PER_WG / 2) fetch(pair + 1);       // in flight during the FFT
+        const bool last = pair + 1 == FR_PER_WG / 2 || t0 + 2 * pair + 2 >= T;      // workgroup-uniform
+        if (!last) fetch(pair + 1);                          // in flight during the FFT
         int cur = 0;
+#ifndef FE_ABL_NO_FFT      // (timing ablations, tools/ablate/build_variant.sh: results are not a spectrogram)
 #pragma unroll
         for (int st = 0; st < 5; ++st) {
             const int Ns = 1 << (2 * st);
@@ -184,6 +189,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
             __syncthreads();
             cur = nxt;
         }
+#endif
         // split the two real spectra: Xa = (Z[k] + conj Z[N-k]) / 2, Xb = (Z[k] - conj Z[N-k]) / (2i); power
         for (int k = tid; k < NBIN; k += 256) {
             const int kn = (NFFT - k) & (NFFT - 1);
@@ -198,6 +204,9 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
         __syncthreads();
         {
             float acc = 0.f;
+#ifdef FE_ABL_NO_MEL
+            acc = pw[which][k0];
+#else
             if (csr) {
                 const float* wr = wcsr + off;
                 const float* pp = pw[which] + k0;
@@ -209,20 +218,23 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
                 const float* wrow = melw + (size_t)mm * NBIN;
                 for (int k = k0; k < k1; ++k) acc += wrow[k] * pw[which][k];
             }
-            ostage[mm][2 * pair + which] = do_log ? (__logf(acc + 1e-5f) + 4.5f) / 5.0f : acc;
+#endif
+            ostage[mm][(2 * pair + which) & (FR_TILE - 1)] = do_log ? (__logf(acc + 1e-5f) + 4.5f) / 5.0f : acc;
         }
         __syncthreads();
-    }
-    // 128 x 8 tile -> global: thread (m, half) writes 4 consecutive frames
-    {
-        const int m = tid >> 1, half = tid & 1, t = t0 + 4 * half;
-        float* dst = out + ((size_t)b * NMEL + m) * T + t;
-        if (t + 3 < T && (T & 3) == 0) {
-            *reinterpret_cast<float4*>(dst) = make_float4(ostage[m][4 * half], ostage[m][4 * half + 1],
-                                                          ostage[m][4 * half + 2], ostage[m][4 * half + 3]);
-        } else {
-            for (int i = 0; i < 4; ++i) if (t + i < T) dst[i] = ostage[m][4 * half + i];
+        // 128 x 8 tile -> global every fourth pair (and after the last one): thread (m, half) writes 4 consecutive frames.  The tile is
+        // next written in the following pair's filterbank step, five barriers on.
+        if ((pair & 3) == 3 || last) {
+            const int m = tid >> 1, half = tid & 1, t = t0 + FR_TILE * (pair >> 2) + 4 * half;
+            float* dst = out + ((size_t)b * NMEL + m) * T + t;
+            if (t + 3 < T && (T & 3) == 0) {
+                *reinterpret_cast<float4*>(dst) = make_float4(ostage[m][4 * half], ostage[m][4 * half + 1],
+                                                              ostage[m][4 * half + 2], ostage[m][4 * half + 3]);
+            } else {
+                for (int i = 0; i < 4; ++i) if (t + i < T) dst[i] = ostage[m][4 * half + i];
+            }
         }
+        if (last) break;
     }
 }
 

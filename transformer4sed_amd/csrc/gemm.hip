@@ -14,6 +14,7 @@
 // timm Mlp fc1/fc2 in the context blocks; the conv2d of passt.py:307 (as im2col GEMM);
 // src/models/passt/passt_sed.py:196 (mlm_mlp) and their autograd backward GEMMs.
 #include <stdlib.h>
+#include <algorithm>
 #include <atomic>
 
 #include "common.h"
@@ -62,6 +63,16 @@ struct GemmArgs {
     // K tiles to skip once the A panel has wrapped: the walk then multiplies A . hi^T and A . lo^T (b_skip = k_wrap), dropping the a_lo
     // term of the three-term product.
     int b_skip;
+    // Two-term weights with the lo product on the fp8 matrix path (256^2 kernel, evaluation-mode encoder; k8 != 0): A rows are
+    // [K f16 | K e4m3] (the activation and its OCP-e4m3 image, scaled by 2^-2: sed_fp8_tail or the producing kernels), B rows
+    // [f16(W) | e4m3(2^s (W - f16(W)))] (sed_weight_two_term_f8); both with a row pitch of 3 K bytes.  The K walk is K / 64 f16 tiles followed
+    // by k8 = K / 128 fp8 tiles of the same 128 bytes per row: same DMA, same LDS image, same fragment reads -- the 32 bytes a lane holds
+    // of a row are the operand of ONE v_mfma_scale_f32_16x16x128_f8f6f4 instead of two v_mfma_f32_16x16x32_f16 (the k order inside a
+    // tile is the same permutation for both operands).  f8_scale = the e8m0 byte 128 - s / 2 replicated four times, used as BOTH operands' block
+    // scale (s even): the hardware scales the lo product back by 2^-(s - 2).  W_lo is 2^-12 of the result and e4m3 keeps 2^-4 of either factor: the lo product to ~2^-15 of the
+    // result for half of an f16 pass (`profiles/r4_fp8_mfma_probe.txt`).
+    int k8;
+    int f8_scale;
     // Persistent 256^2 kernel: workgroups with an odd (blockIdx.x >> 3) start `stagger` ticks of the 100 MHz real-time counter late, so
     // that their store phases fall into the other half's main loops instead of all 256 CUs hitting HBM in lock-step.  0 = off.
     int stagger;
@@ -1356,7 +1367,23 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // LDS rows are still filled so that every wave keeps the same DMA count for the counted waits).  With M = 38080 tokens on 256 CUs the
 // N = 768 / 2304 GEMMs are 447 / 1341 tiles of 256 rows = 1.75 / 5.24 rounds, i.e. 2 / 6 rounds with 13 % of the last ones empty; as
 // 510 / 1530 tiles of 224 rows they are 1.99 / 5.98 rounds of tiles that are 12.5 % shorter -- launch_gemm picks the cheaper height.
-template <int EPI, bool F16, int GB = 0, int RB = 8>
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ i32x8_t cat32(s16x8_t a, s16x8_t b) {
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    const i32x4_t x = __builtin_bit_cast(i32x4_t, a), y = __builtin_bit_cast(i32x4_t, b);
+    return i32x8_t{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+}
+// The F8 variants pin their accumulators: with the compiler's untied MFMA forms (vdst != srcC allowed) and 250 of 256 registers in use
+// the allocator moved accumulator tuples between K tiles and spilled some (scratch reloads behind s_waitcnt vmcnt(0): the end of the DMA
+// pipeline).  Tied inline-asm forms leave it nothing to move.  Back-to-back accumulation into the same vdst needs no wait states; the
+// epilogue's first VALU read of an accumulator is kept >= 18 cycles behind the last MFMA by hand (pp kernel, after the K loop).
+__device__ __forceinline__ void mfma16_f16_tied(f32x4_t& c, s16x8_t a, s16x8_t b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma128_e4m3_tied(f32x4_t& c, i32x8_t a, i32x8_t b, int sc) {
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(a), "v"(b), "v"(sc));
+}
+template <int EPI, bool F16, int GB = 0, int RB = 8, bool F8 = false>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     constexpr int TM = 32 * RB;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
@@ -1443,7 +1470,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     }
 #define PP_DMA_R(RA_, RB_, SL, KT)                                                                                        \
     {                                                                                                                     \
-        const int kt_ = ((GB == 2 || GB == 8) && (KT) >= g.k_wrap) ? (((SL) == 0 || (SL) == 3) ? (KT) - g.k_wrap : (KT) + g.b_skip) : (KT); \
+        const int kt_ = ((GB == 2 || GB == 8) && !F8 && (KT) >= g.k_wrap) ? (((SL) == 0 || (SL) == 3) ? (KT) - g.k_wrap : (KT) + g.b_skip) : (KT); \
         const int so_ = kt_ * (((SL) == 1 || (SL) == 2) ? BK * 2 : a_kst), st_ = ((KT) & 1) << 15;                        \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? RB_ : RA_, (lds_ptr_t)(lds3 + st_ + ld_[SL][0]), 16, vo[SL][0], so_, 0, 0); \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(((SL) == 1 || (SL) == 2) ? RB_ : RA_, (lds_ptr_t)(lds3 + st_ + ld_[SL][1]), 16, vo[SL][1], so_, 0, 0); \
@@ -1482,27 +1509,43 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);                                                                                    \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                      \
         _Pragma("unroll") for (int ii = 0; ii < ((IH) == 1 ? RB - 4 : 4); ++ii)                                           \
-            _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                              \
-                acc[4 * (IH) + ii][2 * (JH) + jj] = mfma16t<F16>(fb[SET][jj][ks], fa[ii][ks], acc[4 * (IH) + ii][2 * (JH) + jj]); \
+            _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                            \
+                if constexpr (F8) mfma16_f16_tied(acc[4 * (IH) + ii][2 * (JH) + jj], fb[SET][jj][ks], fa[ii][ks]);           \
+                else acc[4 * (IH) + ii][2 * (JH) + jj] = mfma16t<F16>(fb[SET][jj][ks], fa[ii][ks], acc[4 * (IH) + ii][2 * (JH) + jj]); \
+            }                                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    __builtin_amdgcn_s_barrier();                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);
+    // fp8 K tile (F8): the two 16-byte fragments of a row block are one 32-byte e4m3 operand
+#define PP_MFMA8(IH, JH, SET)                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    __builtin_amdgcn_s_barrier();                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    _Pragma("unroll") for (int ii = 0; ii < ((IH) == 1 ? RB - 4 : 4); ++ii)                                               \
+        _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                                  \
+            mfma128_e4m3_tied(acc[4 * (IH) + ii][2 * (JH) + jj], cat32(fb[SET][jj][0], fb[SET][jj][1]), cat32(fa[ii][0], fa[ii][1]), f8s); \
     __builtin_amdgcn_sched_barrier(0);                                                                                    \
     __builtin_amdgcn_s_barrier();                                                                                         \
     __builtin_amdgcn_sched_barrier(0);
     // one K tile; X = B register set holding this tile's half 0, Y = the other set
-#define PP_TILE(T_, X, Y)                                                                                                 \
+#define PP_TILE_(MF, T_, X, Y)                                                                                            \
     if ((T_) + 1 < nk) PP_DMA(3, (T_) + 1)                                                                                \
     PP_RD_A(0)                                                                                                            \
-    PP_MFMA(0, 0, X)                                                                                                      \
+    MF(0, 0, X)                                                                                                           \
     if ((T_) + 2 < nk) PP_DMA(1, (T_) + 2)                                                                                \
     PP_RD_B(Y, 1, 0)                                                                                                      \
-    PP_MFMA(0, 1, Y)                                                                                                      \
+    MF(0, 1, Y)                                                                                                           \
     if ((T_) + 2 < nk) { PP_DMA(0, (T_) + 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }                           \
     else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }                                                             \
     PP_RD_A(1)                                                                                                            \
-    PP_MFMA(1, 1, Y)                                                                                                      \
+    MF(1, 1, Y)                                                                                                           \
     if ((T_) + 2 < nk) PP_DMA(2, (T_) + 2)                                                                                \
     if ((T_) + 1 < nk) { PP_RD_B(Y, 0, 0x8000) }                                                                          \
-    PP_MFMA(1, 0, X)                                                                                                      \
+    MF(1, 0, X)                                                                                                           \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) { aaddr[ks] ^= 0x8000; baddr[ks] ^= 0x8000; }
+#define PP_TILE(T_, X, Y) PP_TILE_(PP_MFMA, T_, X, Y)
+#define PP_TILE8(T_, X, Y) PP_TILE_(PP_MFMA8, T_, X, Y)
 
 #ifdef GX_TRACE
     unsigned long long gx_t[8];
@@ -1523,11 +1566,26 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     if (wm == 1) __builtin_amdgcn_s_barrier();   // second wave row: half a phase behind
     PP_RD_B(0, 0, 0)
     int it = 0;
+    if constexpr (F8) {
+        const int f8s = g.f8_scale;
+        const int nk16 = nk - g.k8;          // even (K % 128 == 0)
+        for (; it < nk16; it += 2) {
+            PP_TILE(it, 0, 1)
+            PP_TILE(it + 1, 1, 0)
+        }
+        for (; it + 1 < nk; it += 2) {
+            PP_TILE8(it, 0, 1)
+            PP_TILE8(it + 1, 1, 0)
+        }
+        if (it < nk) { PP_TILE8(it, 0, 1) }
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");      // last (16-pass) MFMA -> the epilogue's accumulator reads
+    } else {
     for (; it + 1 < nk; it += 2) {
         PP_TILE(it, 0, 1)
         PP_TILE(it + 1, 1, 0)
     }
     if (it < nk) { PP_TILE(it, 0, 1) }
+    }
     GX_STAMP(2)
     if (wm == 0) __builtin_amdgcn_s_barrier();   // pairs with the last barrier of waves 4-7: nobody reads the stages any more
     GX_STAMP(3)
@@ -1552,7 +1610,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
 #undef PP_RD_A
 #undef PP_RD_B
 #undef PP_MFMA
+#undef PP_MFMA8
 #undef PP_TILE
+#undef PP_TILE8
+#undef PP_TILE_
 #ifdef GX_TRACE
     pp_epilogue<EPI, F16, GB, RB>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * (16 * RB), n0 + wn * 64, lane, gx_t);
     GX_STAMP(5)
@@ -2037,7 +2098,7 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
         const int ntn = g.N / V3_T;
         const long long t8 = (long long)cdiv(g.M, 256) * ntn, t7 = (long long)cdiv(g.M, 224) * ntn;
         const long long c8 = ((t8 + ncu - 1) / ncu) * 256, c7 = ((t7 + ncu - 1) / ncu) * 224;
-        const bool use7 = g.gbias == nullptr && g.k_wrap == 0 && (rb_env == 7 || (rb_env == 0 && c7 * 100 < c8 * 97));
+        const bool use7 = g.gbias == nullptr && g.k_wrap == 0 && g.k8 == 0 && (rb_env == 7 || (rb_env == 0 && c7 * 100 < c8 * 97));
         dim3 grid3((unsigned)(use7 ? t7 : t8), 1);
         gg.persist = (persist_env && (int)grid3.x > ncu) ? 1 : 0;
         if (gg.persist) grid3.x = ncu;
@@ -2070,6 +2131,25 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
                     if (use7) PP_LN_LAUNCH(3, 7, 0) else PP_LN_LAUNCH(3, 8, 1)
                 }
 #undef PP_LN_LAUNCH
+                return sed_check_launch();
+            } else {
+                return SED_ERR_ARG;
+            }
+        }
+        if (g.k8 != 0) {
+            // two-term weights, lo product on the fp8 matrix path (GemmArgs.k8): the two-term variants' epilogues behind a K walk of f16
+            // tiles followed by e4m3 tiles
+            if constexpr (EPI == EPI_F32_RESID || EPI == EPI_GELU || EPI == EPI_QKV) {
+                if (!f16 || g.gbias != nullptr || g.k_wrap != 0 || g.a_slab || ((g.K / BK - g.k8) & 1) || g.k8 >= g.K / BK) return SED_ERR_ARG;
+                static bool attr9 = false;
+                if constexpr (EPI == EPI_QKV) {
+                    if (g.qt != nullptr || g.kt != nullptr || g.vt != nullptr || g.q2 != nullptr || g.q2t != nullptr || g.pu != nullptr) return SED_ERR_ARG;
+                    if (!attr9) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true, 8, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr9 = true; }
+                    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true, 8, 8, true>), grid3, dim3(512), V3_LDS, s, g);
+                } else {
+                    if (!attr9) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true, 2, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attr9 = true; }
+                    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true, 2, 8, true>), grid3, dim3(512), V3_LDS, s, g);
+                }
                 return sed_check_launch();
             } else {
                 return SED_ERR_ARG;
@@ -2135,7 +2215,7 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
 #undef SED_PP_LAUNCH
         return sed_check_launch();
     }
-    if (g.k_wrap != 0 || g.rowpart != nullptr || g.rowstat != nullptr) return SED_ERR_ARG;   // 256^2-kernel-only modes (N % 256 == 0, M >= 1024)
+    if (g.k_wrap != 0 || g.k8 != 0 || g.rowpart != nullptr || g.rowstat != nullptr) return SED_ERR_ARG;   // 256^2-kernel-only modes (N % 256 == 0, M >= 1024)
     dim3 grid(cdiv(g.M, TILE) * (g.N / TILE), g.ksplit);
     if (f16) hipLaunchKernelGGL((gemm_nt_kernel<EPI, true>), grid, dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm_nt_kernel<EPI, false>), grid, dim3(256), 0, s, g);
@@ -2144,10 +2224,15 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
 
 static int gemm_nt_impl(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi, const float* bias,
                         const float* resF, float* outF, void* outH, void* outH2, const void* auxH, int ldc, float alpha,
-                        int ksplit, int f16, int ncols, hipStream_t stream, const float* gbias = nullptr, int gb_rows = 0, int two_term = 0) {
+                        int ksplit, int f16, int ncols, hipStream_t stream, const float* gbias = nullptr, int gb_rows = 0, int two_term = 0,
+                        int f8_scale = 0) {
     (void)hipGetLastError();
     GemmArgs g = {};
-    if (two_term) {      // A [M, K] against B [N, 2K]
+    if (two_term == 3) {      // A [M, K f16 | K e4m3] against B [N, K f16 | K e4m3]: K / 64 f16 tiles + K / 128 fp8 tiles
+        if (K % 128 || epi == EPI_ATOMIC || epi == EPI_DGELU || gbias != nullptr || ksplit > 1) return SED_ERR_ARG;
+        g.k8 = K / 128; g.f8_scale = f8_scale;
+        K += K / 2;
+    } else if (two_term) {      // A [M, K] against B [N, 2K]
         if (K % BK || epi == EPI_ATOMIC || epi == EPI_DGELU || gbias != nullptr || ksplit > 1) return SED_ERR_ARG;
         g.k_wrap = K / BK;
         K *= 2;
@@ -2191,6 +2276,19 @@ extern "C" int sed_gemm_nt_w2(const void* A, const void* B, int M, int N, int K,
                               int ldc, int f16, hipStream_t stream) {
     if (!(f16 & 1) || N % 256 || M < 1024) return SED_ERR_ARG;
     return gemm_nt_impl(A, B, M, N, K, lda, ldb, epi, bias, resF, outF, outH, outH2, nullptr, ldc, 1.f, 1, f16, N, stream, nullptr, 0, 1);
+}
+// ... with the lo product on the fp8 matrix path: A [M][K f16 | K e4m3] (row pitch lda halfs >= 3K / 2; the e4m3 half is the activation
+// times 2^-2: sed_fp8_tail), B [N][K f16 | K e4m3] = sed_weight_two_term_f8's image with its scale exponent s; f8_exp = s.  K % 128 == 0.
+static int f8_scale_word(int s) {       // both operands' scale registers are the same one: e8m0 byte of 2^-(s - 2) / 2, replicated; s even
+    const int e = 128 - s / 2;
+    return (s & 1) || e < 1 || e > 254 ? -1 : e * 0x01010101;
+}
+extern "C" int sed_gemm_nt_w2f8(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi,
+                                const float* bias, const float* resF, float* outF, void* outH, void* outH2,
+                                int ldc, int f8_exp, hipStream_t stream) {
+    if (N % 256 || M < 1024 || f8_scale_word(f8_exp) < 0) return SED_ERR_ARG;
+    return gemm_nt_impl(A, B, M, N, K, lda, ldb, epi, bias, resF, outF, outH, outH2, nullptr, ldc, 1.f, 1, 1, N, stream, nullptr, 0, 3,
+                        f8_scale_word(f8_exp));
 }
 // LayerNorm folded into the two GEMMs around it (no-grad f16 passes; 256^2 kernel only: N % 256 == 0, M >= 1024).
 // producer = sed_gemm_nt with EPI_F32_RESID that ALSO writes x16 [M, N] (f16 image of the new residual stream) and rowpart [M][N / 64][2]
@@ -2257,7 +2355,8 @@ extern "C" int sed_gemm_nt_cols(const void* A, const void* B, int M, int N, int 
 
 static int gemm_qkv_impl(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq,
                          int seq_pad, void* q, void* k, void* v, void* qt, void* kt, void* vt, void* q2,
-                         void* q2t, const float* pos_u, const float* pos_v, int f16, const float* gbias, int gb_rows, hipStream_t stream, int two_term = 0);
+                         void* q2t, const float* pos_u, const float* pos_v, int f16, const float* gbias, int gb_rows, hipStream_t stream, int two_term = 0,
+                         int f8_scale = 0);
 // the context network's in_proj on TWO of the three split-precision terms: A = plain f16 activations [M, K], W = the split weight image
 // [N, 3K] = [hi | hi | lo] (sed_weight_images); computes A . (hi + lo)^T -- the weight to ~2^-22, the activation rounded once.  Which terms
 // the posteriors need per GEMM: tools/err_sim.py (SIM_DEC_TERMS=1): in_proj is insensitive to the activation's lo part (logit error
@@ -2307,16 +2406,28 @@ extern "C" int sed_gemm_qkv_w2(const void* A, const void* W, const float* bias, 
     return gemm_qkv_impl(A, W, bias, M, K, heads, seq, seq_pad, q, k, v, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, f16,
                          nullptr, 0, stream, 1);
 }
+// ... lo product on the fp8 matrix path (see sed_gemm_nt_w2f8): A [M][K f16 | K e4m3], W [3 * heads * 64][K f16 | K e4m3], both with
+// a row pitch of 3K / 2 halfs
+extern "C" int sed_gemm_qkv_w2f8(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq,
+                                 int seq_pad, void* q, void* k, void* v, int f8_exp, hipStream_t stream) {
+    if (M < 1024 || K % 128 || f8_scale_word(f8_exp) < 0) return SED_ERR_ARG;
+    return gemm_qkv_impl(A, W, bias, M, K, heads, seq, seq_pad, q, k, v, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1,
+                         nullptr, 0, stream, 3, f8_scale_word(f8_exp));
+}
 static int gemm_qkv_impl(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq,
                          int seq_pad, void* q, void* k, void* v, void* qt, void* kt, void* vt, void* q2,
-                         void* q2t, const float* pos_u, const float* pos_v, int f16, const float* gbias, int gb_rows, hipStream_t stream, int two_term) {
+                         void* q2t, const float* pos_u, const float* pos_v, int f16, const float* gbias, int gb_rows, hipStream_t stream, int two_term,
+                         int f8_scale) {
     (void)hipGetLastError();
     GemmArgs g = {};
     if (gbias != nullptr && (gb_rows < 128 || M % gb_rows)) return SED_ERR_ARG;
     g.gbias = gbias; g.gb_rows = gb_rows;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)W;
     g.M = M; g.N = 3 * heads * 64; g.K = K; g.lda = K; g.ldb = K; g.ldc = g.N; g.ksplit = 1; g.alpha = 1.f;
-    if (two_term) {
+    if (two_term == 3) {
+        if (K % 128 || gbias != nullptr) return SED_ERR_ARG;
+        g.k8 = K / 128; g.f8_scale = f8_scale; g.K = K + K / 2; g.lda = g.K; g.ldb = g.K;
+    } else if (two_term) {
         if (K % BK || gbias != nullptr) return SED_ERR_ARG;
         g.k_wrap = K / BK; g.K = 2 * K; g.ldb = 2 * K;
         if (two_term == 2) { g.ldb = 3 * K; g.b_skip = K / BK; }      // W = [hi | hi | lo]: walk hi, then lo
@@ -2631,6 +2742,59 @@ __global__ void weight_residual_kernel(const float* __restrict__ w, bf16_t* __re
         p.y = (unsigned)f2h(scale * (v.z - h2f(f2h(v.z)))) | ((unsigned)f2h(scale * (v.w - h2f(f2h(v.w)))) << 16);
         reinterpret_cast<uint2*>(out)[i] = p;
     }
+}
+// e4m3 (OCP) images for the fp8 lo product (GemmArgs.k8).  v_cvt_pk_fp8_f32 rounds to nearest even; values are clamped to +-448 first.
+__device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d) {
+    const float lim = 448.f;
+    a = fminf(fmaxf(a, -lim), lim); b = fminf(fmaxf(b, -lim), lim); c = fminf(fmaxf(c, -lim), lim); d = fminf(fmaxf(d, -lim), lim);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
+// rows of [K f16 | K e4m3] (pitch ld halfs): the e4m3 half = 2^-2 x the f16 half
+__global__ __launch_bounds__(256) void fp8_tail_kernel(bf16_t* __restrict__ x, int M, int K, int ld) {
+    const int per_row = K / 8;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)M * per_row; i += (size_t)gridDim.x * 256) {
+        const size_t m = i / per_row;
+        const int c = (int)(i - m * per_row);
+        bf16_t* row = x + m * ld;
+        const uint4 v = *reinterpret_cast<const uint4*>(row + 8 * c);
+        const f16x8_t h = __builtin_bit_cast(f16x8_t, v);
+        uint2 o;
+        o.x = pack4_e4m3(0.25f * (float)h[0], 0.25f * (float)h[1], 0.25f * (float)h[2], 0.25f * (float)h[3]);
+        o.y = pack4_e4m3(0.25f * (float)h[4], 0.25f * (float)h[5], 0.25f * (float)h[6], 0.25f * (float)h[7]);
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(row + K) + 8 * c) = o;
+    }
+}
+extern "C" int sed_fp8_tail(void* x, int M, int K, int ld, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (M <= 0 || K % 8 || ld % 8 || ld < K + K / 2) return SED_ERR_ARG;
+    const size_t n = (size_t)M * (K / 8);
+    hipLaunchKernelGGL(fp8_tail_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, stream, (bf16_t*)x, M, K, ld);
+    return sed_check_launch();
+}
+// fp32 weight [N, K] -> rows [f16(W) | e4m3(2^s (W - f16(W)))] (3 K bytes per row)
+__global__ __launch_bounds__(256) void weight_two_term_f8_kernel(const float* __restrict__ w, unsigned char* __restrict__ out, size_t N, int K, float scale) {
+    const int per_row = K / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < N * per_row; i += (size_t)gridDim.x * 256) {
+        const size_t n = i / per_row;
+        const int c = (int)(i - n * per_row);
+        const float4 v = *reinterpret_cast<const float4*>(w + n * K + 4 * c);
+        const _Float16 h0 = (_Float16)v.x, h1 = (_Float16)v.y, h2 = (_Float16)v.z, h3 = (_Float16)v.w;
+        unsigned char* row = out + n * (size_t)(3 * K);
+        typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<f16x4_t*>(row + 8 * c) = f16x4_t{h0, h1, h2, h3};
+        *reinterpret_cast<unsigned*>(row + 2 * K + 4 * c) =
+            pack4_e4m3(scale * (v.x - (float)h0), scale * (v.y - (float)h1), scale * (v.z - (float)h2), scale * (v.w - (float)h3));
+    }
+}
+extern "C" int sed_weight_two_term_f8(const float* w, void* out, int64_t N, int K, int s, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (N <= 0 || K % 8 || s < -100 || s > 100) return SED_ERR_ARG;
+    const size_t n = (size_t)N * (K / 4);
+    hipLaunchKernelGGL(weight_two_term_f8_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, stream, w,
+                       (unsigned char*)out, (size_t)N, K, ldexpf(1.f, s));
+    return sed_check_launch();
 }
 extern "C" int sed_weight_residual_f16(const float* w, void* out, int64_t n, float scale, hipStream_t stream) {
     (void)hipGetLastError();

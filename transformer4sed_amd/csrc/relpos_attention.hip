@@ -790,7 +790,14 @@ __global__ __launch_bounds__(512) void relpos_bwd_dkdv_stream_kernel(const bf16_
     uint4 ta, tb;
     s16x8_t fs[2], fp[2];
     // (one tile of slab rows in flight per wave; two were slower: 424 vs 402 us)
-    auto gload = [&](int t) {
+#ifdef RP_ROT
+    const int rot = (RP_ROT * blockIdx.x + blockIdx.y) % ntiles;
+#else
+    const int rot = 0;
+#endif
+    auto gload = [&](int t0_) {
+        int t = t0_ + rot;
+        t = t >= ntiles ? t - ntiles : t;
         ta = *reinterpret_cast<const uint4*>(Qut + hbt + (size_t)trow * Tpad + 64 * t + 8 * tch);
         tb = *reinterpret_cast<const uint4*>(dOt + hbt + (size_t)trow * Tpad + 64 * t + 8 * tch);
 #pragma unroll

@@ -1,5 +1,6 @@
 """Thin tensor-level wrappers over the C ABI (include/sed_hip.h).  torch is used for device memory and the
 current HIP stream only; every op here launches hand-written gfx950 kernels and raises if it cannot."""
+import math
 import os
 
 import torch
@@ -157,11 +158,11 @@ class plain_precision:
 
 
 def _flops_of(name, args):
-    if name in ("sed_gemm_nt", "sed_gemm_nt_gb", "sed_gemm_nt_w2", "sed_gemm_nt_lnp", "sed_gemm_nt_lnp8", "sed_gemm_nt_lnc", "sed_gemm_nt_lnc8"):       # (w2: the logical 2 M N K, half of the MFMA FLOPs issued)
+    if name in ("sed_gemm_nt", "sed_gemm_nt_gb", "sed_gemm_nt_w2", "sed_gemm_nt_w2f8", "sed_gemm_nt_lnp", "sed_gemm_nt_lnp8", "sed_gemm_nt_lnc", "sed_gemm_nt_lnc8"):       # (w2: the logical 2 M N K, half of the MFMA FLOPs issued)
         return 2.0 * args[2] * args[3] * args[4]
     if name in ("sed_gemm_qkv_lnc", "sed_gemm_qkv_lnc8"):
         return 2.0 * args[5] * args[6] * (3 * args[7] * 64)
-    if name in ("sed_gemm_qkv", "sed_gemm_qkv_gb", "sed_gemm_qkv_w2", "sed_gemm_qkv_w2s"):
+    if name in ("sed_gemm_qkv", "sed_gemm_qkv_gb", "sed_gemm_qkv_w2", "sed_gemm_qkv_w2f8", "sed_gemm_qkv_w2s"):
         return 2.0 * args[3] * args[4] * (3 * args[5] * 64)
     if name == "sed_gemm_dw_tn":
         return 2.0 * args[3] * args[4] * args[5]
@@ -176,8 +177,10 @@ def _shape_of(name, args):
         return (args[2], args[3], args[4], "epi%d" % args[7] + ("gb" if name.endswith("_gb") else ""))
     if name in ("sed_gemm_qkv_gb", "sed_gemm_qkv_w2"):
         return (args[3], 3 * args[5] * 64, args[4], "qkv3" + name[-2:])
-    if name == "sed_gemm_nt_w2":
-        return (args[2], args[3], args[4], "epi%dw2" % args[7])
+    if name == "sed_gemm_qkv_w2f8":
+        return (args[3], 3 * args[5] * 64, args[4], "qkv3w2f8")
+    if name in ("sed_gemm_nt_w2", "sed_gemm_nt_w2f8"):
+        return (args[2], args[3], args[4], "epi%d" % args[7] + name[12:])
     if name in ("sed_gemm_nt_lnp", "sed_gemm_nt_lnp8", "sed_gemm_nt_lnc", "sed_gemm_nt_lnc8"):
         return (args[2], args[3], args[4], "epi3lnc" if "lnc" in name else "epi1lnp")
     if name in ("sed_gemm_qkv_lnc", "sed_gemm_qkv_lnc8"):
@@ -191,8 +194,10 @@ def _shape_of(name, args):
 
 def _bytes_of(name, args):
     """Algorithmic HBM bytes of one GEMM launch: operands once + every output / side input once."""
-    if name in ("sed_gemm_qkv_gb", "sed_gemm_qkv_w2"):
+    if name in ("sed_gemm_qkv_gb", "sed_gemm_qkv_w2", "sed_gemm_qkv_w2f8"):
         M, K, D = args[3], args[4], args[5] * 64
+        if name.endswith("f8"):
+            return 3.0 * K * (M + 3 * D) + 2.0 * M * D * 3
         return 2.0 * K * (M + 3 * D * (2 if name.endswith("w2") else 1)) + 2.0 * M * D * 3
     if name in ("sed_gemm_nt_lnp", "sed_gemm_nt_lnp8"):
         # operands + the residual read (fp32 4 B / f16 planes 4 B / f16 + byte planes 3 B) + fp32 and f16 image (6 B) or the two planes (4 B / 3 B)
@@ -205,10 +210,10 @@ def _bytes_of(name, args):
     if name in ("sed_gemm_qkv_lnc", "sed_gemm_qkv_lnc8"):
         M, K, D = args[5], args[6], args[7] * 64
         return 2.0 * K * (M + 3 * D) + 2.0 * M * D * 3
-    if name == "sed_gemm_nt_w2":
+    if name in ("sed_gemm_nt_w2", "sed_gemm_nt_w2f8"):
         M, N, K, epi = args[2], args[3], args[4], args[7]
         out = {1: 8, 3: 2 * ((args[11] is not None) + (args[12] is not None))}.get(epi, 4)
-        return 2.0 * K * (M + 2 * N) + float(out) * M * N
+        return (3.0 * K * (M + N) if name.endswith("f8") else 2.0 * K * (M + 2 * N)) + float(out) * M * N
     if name in ("sed_gemm_nt", "sed_gemm_nt_gb"):
         M, N, K, epi = args[2], args[3], args[4], args[7]
         out = {0: 4, 1: 8, 2: 2, 3: 2 * ((args[11] is not None) + (args[12] is not None)), 4: 4, 5: 8, 7: 6, 8: 6}.get(epi, 4)
@@ -386,6 +391,38 @@ def two_term_weight(w32):
     out = torch.empty(N, 2 * K, dtype=F16, device=w32.device)
     call("sed_split3_f16", w32.contiguous(), out, N, K, 2)
     return out
+
+
+def two_term_weight_f8(w32):
+    """fp32 weight [N, K] -> (uint8 image [N, 3K] with rows [f16(W) | e4m3(2^s (W - f16(W)))], s) for gemm_nt_w2f8 / sed_gemm_qkv_w2f8.
+    s (even) puts the largest rounding residual just below the e4m3 maximum of 448."""
+    N, K = w32.shape
+    w32 = w32.contiguous()
+    m = float((w32 - w32.to(F16).float()).abs().max())
+    s = 0 if m == 0.0 else int(math.floor(math.log2(448.0 / m)))
+    s = max(-60, min(60, s)) & ~1
+    out = torch.empty(N, 3 * K, dtype=torch.uint8, device=w32.device)
+    call("sed_weight_two_term_f8", w32, out, N, K, s)
+    return out, s
+
+
+def fp8_rows(M, K, device, dtype=F16):
+    """[M, 3K / 2] 16-bit buffer whose rows are [K f16 | K e4m3]; `[:, :K]` is the activation, the rest its e4m3 image (sed_fp8_tail)."""
+    return torch.empty(M, K + K // 2, dtype=dtype, device=device)
+
+
+def fp8_tail(x, K):
+    """fills the e4m3 half of rows [K f16 | K e4m3] (x: [M, 3K / 2] f16) from their f16 half."""
+    call("sed_fp8_tail", x, x.shape[0], K, x.shape[1])
+
+
+def gemm_nt_w2f8(A, Bimg, s, epi, K, bias=None, res=None, outF=None, outH=None, outH2=None, ldc=None):
+    """gemm_nt(two_term=True) with the lo product on the fp8 matrix path: A [M, 3K / 2] f16 rows [K f16 | K e4m3] (fp8_rows / fp8_tail),
+    (Bimg, s) = two_term_weight_f8(W)."""
+    M, N = A.shape[0], Bimg.shape[0]
+    if A.dtype != F16 or Bimg.dtype != torch.uint8 or Bimg.shape[1] != 3 * K or A.shape[1] < K + K // 2:
+        raise RuntimeError("gemm_nt_w2f8: A is f16 [M, 3K / 2], B the uint8 image [N, 3K] of two_term_weight_f8")
+    call("sed_gemm_nt_w2f8", A, Bimg, M, N, K, A.shape[1], 3 * K // 2, epi, bias, res, outF, outH, outH2, ldc or N, s)
 
 
 def o_kind(t):
