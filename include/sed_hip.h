@@ -115,9 +115,14 @@ int sed_gemm_qkv_w2(const void* A, const void* W, const float* bias, int M, int 
  * (row pitch lda halfs >= 3K / 2; the e4m3 half = 2^-2 x the activation: sed_fp8_tail, or the producing kernels' fp8 flags), B [N][K f16 |
  * K e4m3] = sed_weight_two_term_f8(W, s) with f8_exp = s.  K % 128 == 0; otherwise like sed_gemm_nt_w2 / sed_gemm_qkv_w2. */
 int sed_gemm_nt_w2f8(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi, const float* bias,
-                     const float* resF, float* outF, void* outH, void* outH2, int ldc, int f8_exp, hipStream_t stream);
+                     const float* resF, float* outF, void* outH, void* outH2, int ldc, int out_e4m3, int f8_exp, hipStream_t stream);
+/* (out_e4m3 != 0, epi 3 with outH NULL: outH2 rows are [N f16 | N e4m3], ldc >= 3N / 2 -- the fc1 activation leaves as fc2's A operand) */
 int sed_gemm_qkv_w2f8(const void* A, const void* W, const float* bias, int M, int K, int heads, int seq, int seq_pad, void* q,
                       void* k, void* v, int f8_exp, hipStream_t stream);
+/* sed_gemm_nt_gb with epi 3 (fused GELU, outH NULL) whose result leaves as rows [N f16 | N e4m3] (ldc >= 3N / 2): fc1 of the evaluation-mode
+ * encoder on f16 weights + the per-clip mean correction, writing fc2's two-image A operand.  N % 256 == 0, M >= 1024, f16. */
+int sed_gemm_nt_gb_e4m3(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* bias, void* outH2, int ldc,
+                        const float* gbias, int gb_rows, hipStream_t stream);
 /* x rows [K f16 | K e4m3] of pitch ld halfs: fills the e4m3 half (OCP e4m3, round to nearest even, clamped to +-448) with 2^-2 x the f16 half */
 int sed_fp8_tail(void* x, int M, int K, int ld, hipStream_t stream);
 /* fp32 weight [N, K] -> out rows [f16(W) | e4m3(2^s (W - f16(W)))], 3K bytes each */
@@ -163,6 +168,8 @@ int sed_gemm_qkv_lnc(const void* A, const void* W, const float* colC, const floa
 /* operands of that correction: per-clip token means of a 16-bit activation x [groups * rows, K] -> [groups, K] (K % 256 == 0; every
  * step-th token), and the f16 image of scale * (w - f16(w)) for an fp32 weight of n (multiple of 4) elements */
 int sed_group_colmean(const void* x, void* out, int groups, int rows, int K, int step, int f16, hipStream_t stream);
+/* ... over rows of pitch ld >= K elements (the f16 half of rows [K f16 | K e4m3]) */
+int sed_group_colmean_ld(const void* x, void* out, int groups, int rows, int K, int ld, int step, int f16, hipStream_t stream);
 int sed_weight_residual_f16(const float* w, void* out, int64_t n, float scale, hipStream_t stream);
 /* sed_gemm_nt with a narrow result: A / B are padded to N (a multiple of 128, not of 256) but only the first ncols (multiple of 4)
  * output columns exist in memory -- bias [ncols], residual and outputs [M, ldc] with ldc >= ncols.  The 16/32/64-filter layers of
@@ -201,7 +208,8 @@ int sed_small_linear_bwd(const float* a, const float* w, const float* out, const
 /* ------------------------------------------------------------------ attention */
 /* encoder MHSA (src/models/passt/passt.py:335-341), flash style; Q, K, V head-split [B*H, N, 64] 16-bit (V row-major: the kernel takes
    V^T out of its LDS tile with transposing reads); O [B,N,768] 16-bit, LSE [B*H,N] (log2 domain).
-   f16: bit 0 = IEEE half operands (else bf16); bit 1 = O head-major [H][B*N][64] (the slab-major A operand of sed_gemm_nt_lnp8, lda = 64) */
+   f16: bit 0 = IEEE half operands (else bf16); bit 1 = O head-major [H][B*N][64] (the slab-major A operand of sed_gemm_nt_lnp8, lda = 64);
+   bit 2 (with bit 0, without bit 1) = O rows [768 f16 | 768 e4m3], pitch 1152 halfs (the A operand of sed_gemm_nt_w2f8) */
 int sed_mhsa_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N, int Npad,
                  int f16, hipStream_t stream);
 int sed_mhsa_bwd_prep(const void* dO, const void* O, float* Dtmp, void* dOh, void* dOt, int B, int H, int N, int Npad,
@@ -229,7 +237,8 @@ int sed_relpos_attn_bwd(const void* Qu, const void* Qut, const void* Qv, const v
 /* ------------------------------------------------------------------ norms / glue / heads / optimiser */
 /* nn.LayerNorm over D=768 (passt.py:361-362,580; passt_sed.py:128; timm Block norms); y = LN(in_scale*x).
  * f16: 0 bf16 / 1 IEEE-half y_bf16 [M, D]; 4: y_bf16 is the split-precision operand image [M, 3 D] = [hi | lo | hi] f16 of the result
- * (the context-network GEMMs' A operand, transformerXL.py:31-35 -- what sed_split3_f16 would make from y_f32 in a second pass) */
+ * (the context-network GEMMs' A operand, transformerXL.py:31-35 -- what sed_split3_f16 would make from y_f32 in a second pass);
+ * 8: y_bf16 rows are [D f16 | D e4m3] (pitch 3 D / 2 halfs), the A operand of sed_gemm_nt_w2f8 / sed_gemm_qkv_w2f8 */
 int sed_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float in_scale, void* y_bf16,
                       float* y_f32, float* mean, float* rstd, int M, int D, int f16, hipStream_t stream);
 int sed_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,

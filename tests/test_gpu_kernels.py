@@ -333,6 +333,40 @@ def test_gemm_two_term_fp8_lo():
     for got, i in ((q, 0), (k, 1), (v, 2)):
         want = ref[i].reshape(B * Hh, Ntok, 64)
         assert maxerr(got.float(), want) < 1.1 * 2 ** -11 * float(want.abs().max())     # the f16 output rounding and nothing else
+    # the producers write the same rows as f16 output + sed_fp8_tail: LayerNorm (mode 8), attention (bit 2), fc1's epilogue (out_e4m3)
+    xs = rnd(M, K, seed=99) * 3.0; gam = 1.0 + 0.3 * rnd(K, seed=100); bet = 0.2 * rnd(K, seed=101)
+    plain = torch.empty(M, K, dtype=F16, device=DEV); both = fp8_rows(M, K, DEV); both.zero_()
+    call("sed_layernorm_fwd", xs, gam, bet, 1e-6, 1.0, plain, None, None, None, M, K, 1)
+    call("sed_layernorm_fwd", xs, gam, bet, 1e-6, 1.0, both, None, None, None, M, K, 8)
+    want = fp8_rows(M, K, DEV); want.zero_(); want[:, :K] = plain; fp8_tail(want, K)
+    assert torch.equal(both.view(torch.int16), want.view(torch.int16))
+    qq, kk, vv = [(rnd(B * Hh, Ntok, 64, seed=102 + i) * (2.0 if i == 2 else 1.0)).to(F16) for i in range(3)]
+    o_plain = torch.empty(M, K, dtype=F16, device=DEV); o_both = fp8_rows(M, K, DEV); o_both.zero_()
+    lse = torch.empty(B * Hh, Ntok, device=DEV)
+    call("sed_mhsa_fwd", qq, kk, vv, o_plain, lse, B, Hh, Ntok, pad64(Ntok), 1)
+    call("sed_mhsa_fwd", qq, kk, vv, o_both, lse, B, Hh, Ntok, pad64(Ntok), 1 | 4)
+    want = fp8_rows(M, K, DEV); want.zero_(); want[:, :K] = o_plain; fp8_tail(want, K)
+    assert torch.equal(o_both.view(torch.int16), want.view(torch.int16))
+    with pytest.raises(RuntimeError):
+        call("sed_mhsa_fwd", qq, kk, vv, o_both, lse, B, Hh, Ntok, pad64(Ntok), 1 | 2 | 4)
+    W1 = rnd(3072, K, scale=0.05, seed=105); b1 = rnd(3072, seed=106)
+    b1[::61] = 2500.0; b1[7] = 70000.0      # outputs beyond the e4m3 image's range (clamped to +-448 x 4) and beyond f16's (inf in the f16 half)
+    img1, s1 = two_term_weight_f8(W1)
+    a_plain = torch.empty(M, 3072, dtype=F16, device=DEV); a_both = fp8_rows(M, 3072, DEV); a_both.zero_()
+    gemm_nt_w2f8(A, img1, s1, ops.EPI_GELU, K, bias=b1, outH2=a_plain)
+    gemm_nt_w2f8(A, img1, s1, ops.EPI_GELU, K, bias=b1, outH2=a_both, out_e4m3=True)
+    want = fp8_rows(M, 3072, DEV); want.zero_(); want[:, :3072] = a_plain; fp8_tail(want, 3072)
+    assert torch.equal(a_both.view(torch.int16), want.view(torch.int16))      # (bit patterns: e4m3 byte pairs can look like f16 NaNs)
+    gbv = rnd(B, 3072, seed=107)          # ... and the row-group-bias form of fc1 (f16 weights + the per-clip mean correction)
+    gemm_nt(A[:, :K].contiguous(), W1.to(F16), ops.EPI_GELU, bias=b1, outH=None, outH2=a_plain, gbias=gbv, gb_rows=Ntok)
+    a_both.zero_()
+    call("sed_gemm_nt_gb_e4m3", A, W1.to(F16), M, 3072, K, A.shape[1], K, b1, a_both, a_both.shape[1], gbv, Ntok)
+    want = fp8_rows(M, 3072, DEV); want.zero_(); want[:, :3072] = a_plain; fp8_tail(want, 3072)
+    assert torch.equal(a_both.view(torch.int16), want.view(torch.int16))      # (bit patterns: e4m3 byte pairs can look like f16 NaNs)
+    mean = torch.empty(B, K, dtype=F16, device=DEV); mean_p = torch.empty(B, K, dtype=F16, device=DEV)
+    call("sed_group_colmean_ld", A, mean, B, Ntok, K, A.shape[1], 8, 1)
+    call("sed_group_colmean", A[:, :K].contiguous(), mean_p, B, Ntok, K, 8, 1)
+    assert torch.equal(mean, mean_p)
     with pytest.raises(RuntimeError):       # odd scale exponent / outside the 256^2 kernel's domain
         call("sed_gemm_qkv_w2f8", A, img, b, M, K, Hh, Ntok, pad64(Ntok), q, k, v, s + 1)
     with pytest.raises(RuntimeError):

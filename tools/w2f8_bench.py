@@ -46,3 +46,19 @@ q, k, v = mk(), mk(), mk()
 t2 = timeit(lambda: call("sed_gemm_qkv_w2", x, W2, b, Mq, 768, 12, N_TOK, pad64(N_TOK), q, k, v, 1))
 t8 = timeit(lambda: call("sed_gemm_qkv_w2f8", A, img, b, Mq, 768, 12, N_TOK, pad64(N_TOK), q, k, v, s))
 print(f"qkv   N=2304 K=768: two-term f16 {t2:7.1f} us | two-term fp8 lo {t8:7.1f} us ({t8 / t2:.2f}x)")
+# fc1 (fused GELU, 16-bit output): f16 weight / f16 weight + row-group bias (the mean correction's epilogue) / fp8 lo / fp8 lo + e4m3 image of the output
+N, K = 3072, 768
+W = g(N, K, sc=0.03); bias = g(N); x = g(M, K).to(F16)
+img, s = two_term_weight_f8(W)
+A = fp8_rows(M, K, dev); A[:, :K] = x; fp8_tail(A, K)
+act = torch.empty(M, N, dtype=F16, device=dev); act8 = fp8_rows(M, N, dev)
+rows = next(r for r in (N_TOK, 386, 602, 256, 128) if M % r == 0)
+gb = g(M // rows, N)
+w16 = W.to(F16)
+t1 = timeit(lambda: gemm_nt(x, w16, ops.EPI_GELU, bias=bias, outH=None, outH2=act))
+tg = timeit(lambda: gemm_nt(x, w16, ops.EPI_GELU, bias=bias, outH=None, outH2=act, gbias=gb, gb_rows=rows))
+t8 = timeit(lambda: gemm_nt_w2f8(A, img, s, ops.EPI_GELU, K, bias=bias, outH2=act))
+t8t = timeit(lambda: gemm_nt_w2f8(A, img, s, ops.EPI_GELU, K, bias=bias, outH2=act8, out_e4m3=True))
+print(f"fc1   N={N} K={K}: f16 weight {t1:7.1f} us | + row-group bias {tg:7.1f} us | fp8 lo {t8:7.1f} us | fp8 lo + e4m3 output image {t8t:7.1f} us")
+tge = timeit(lambda: call("sed_gemm_nt_gb_e4m3", A, w16, M, N, K, A.shape[1], K, bias, act8, act8.shape[1], gb, rows))
+print(f"fc1   N={N} K={K}: row-group bias + e4m3 output image (F8 kernel, no fp8 tiles) {tge:7.1f} us")

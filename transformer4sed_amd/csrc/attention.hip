@@ -140,6 +140,24 @@ __device__ __forceinline__ void softmax_tile(f32x16_t (&st)[2], f32x16_t (&o)[2]
 #ifndef WPE
 #define WPE 3  // 167 VGPRs: three waves per SIMD (four would spill)
 #endif
+// Output row of query q, head h (o_mode 0: token-major [B][N][H * 64]; 1: head-major [H][B * N][64], the slab-major A operand of the
+// LayerNorm-fold proj GEMM, csrc/gemm.hip a_slab; 2: token-major rows [H * 64 f16 | H * 64 e4m3] of pitch 3 H * 64 / 2 halfs, the A operand
+// of the two-term proj GEMM with the lo product on the fp8 path, gemm.hip GemmArgs.k8) -- pointer to the head's 64 columns.
+__device__ __forceinline__ bf16_t* attn_out_row(bf16_t* O, int o_mode, int b, int h, int q, int N, int H, int B) {
+    if (o_mode == 1) return O + ((size_t)h * B * N + (size_t)b * N + q) * HD;
+    const int pitch = o_mode == 2 ? H * HD + H * HD / 2 : H * HD;
+    return O + ((size_t)b * N + q) * pitch + h * HD;
+}
+// four consecutive outputs at column `col` of the head; tail_b >= 0: byte offset from the head's f16 columns to its e4m3 columns
+template <bool F16>
+__device__ __forceinline__ void attn_store4(bf16_t* orow, int col, float a, float b, float c, float d, int tail_b) {
+    uint2 pk;
+    pk.x = pack2<F16>(a, b);
+    pk.y = pack2<F16>(c, d);
+    *reinterpret_cast<uint2*>(orow + col) = pk;
+    if (tail_b >= 0)      // e4m3 of 2^-2 x the f16-rounded values (what sed_fp8_tail makes from the f16 half)
+        *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(orow) + tail_b + col) = e4m3x4_of_h4(pk.x, pk.y);
+}
 template <bool F16, int NQ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void mhsa_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
@@ -242,16 +260,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         if (q < N) {
             const float inv = 1.0f / l_run[u];
             // (o_slab: head-major output [H][B * N][64] -- the slab-major A operand of the LayerNorm-fold proj GEMM, csrc/gemm.hip a_slab)
-            bf16_t* orow = o_slab ? O + ((size_t)h * ((int)gridDim.y / H) * N + (size_t)b * N + q) * HD : O + ((size_t)b * N + q) * (H * HD) + h * HD;
+            bf16_t* orow = attn_out_row(O, o_slab, b, h, q, N, H, (int)gridDim.y / H);
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    uint2 pk;
-                    pk.x = pack2<F16>(o[u][db][4 * qd] * inv, o[u][db][4 * qd + 1] * inv);
-                    pk.y = pack2<F16>(o[u][db][4 * qd + 2] * inv, o[u][db][4 * qd + 3] * inv);
-                    *reinterpret_cast<uint2*>(orow + 32 * db + 8 * qd + 4 * lg) = pk;
-                }
+                for (int qd = 0; qd < 4; ++qd)
+                    attn_store4<F16>(orow, 32 * db + 8 * qd + 4 * lg, o[u][db][4 * qd] * inv, o[u][db][4 * qd + 1] * inv, o[u][db][4 * qd + 2] * inv,
+                                     o[u][db][4 * qd + 3] * inv, o_slab == 2 ? (H - h) * HD * 2 + h * HD : -1);
             if (lg == 0 && LSE != nullptr) LSE[(size_t)bh * N + q] = m_run[u] + log2f(l_run[u]);  // log2 domain
         }
     }
@@ -408,12 +423,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE_DMA, WP
         __syncthreads();                                      // ... and everybody's; nobody reads tile t any more
     }
 #undef ATT_DMA
-    const int q = q0 + lr;
-    if (q < N) {
+    // Output through a wave-private LDS tile (the K / V stages are free: everybody is behind the K loop's last barrier).  A lane's
+    // accumulators are 8-byte pieces of ONE query row -- stored directly, an instruction covers 32 rows x 16 bytes; read back as 16-byte
+    // chunks (lane -> row lane >> 3, chunk lane & 7) it covers 8 rows x 128 contiguous bytes, the e4m3 image (o_slab 2) 8 x 64.
+    // (o_slab 1: head-major output [H][B * N][64]: a workgroup's 128 queries are one contiguous 16 KB run, and the rows are the slab-major A
+    //  operand of the LayerNorm-fold proj GEMM, csrc/gemm.hip a_slab; token-major they are 128-byte pieces 1536 bytes apart)
+    {
+        unsigned char* ws = &lds[0][0][0] + wave * 8192;      // 32 rows x 144 bytes
         const float inv = 1.0f / l_run;
-        // (o_slab: head-major output [H][B * N][64]: a workgroup's 128 queries are one contiguous 16 KB run, and the rows are the slab-major A
-        //  operand of the LayerNorm-fold proj GEMM, csrc/gemm.hip a_slab; token-major they are 128-byte pieces 1536 bytes apart)
-        bf16_t* orow = o_slab ? O + ((size_t)h * ((int)gridDim.y / H) * N + (size_t)b * N + q) * HD : O + ((size_t)b * N + q) * (H * HD) + h * HD;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -421,9 +438,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE_DMA, WP
                 uint2 pk;
                 pk.x = pack2<F16>(o[db][4 * qd] * inv, o[db][4 * qd + 1] * inv);
                 pk.y = pack2<F16>(o[db][4 * qd + 2] * inv, o[db][4 * qd + 3] * inv);
-                *reinterpret_cast<uint2*>(orow + 32 * db + 8 * qd + 4 * lg) = pk;
+                *reinterpret_cast<uint2*>(ws + lr * 144 + (32 * db + 8 * qd + 4 * lg) * 2) = pk;
             }
-        if (lg == 0 && LSE != nullptr) LSE[(size_t)bh * N + q] = m_run + log2f(l_run);  // log2 domain
+        if (q0 + lr < N && lg == 0 && LSE != nullptr) LSE[(size_t)bh * N + q0 + lr] = m_run + log2f(l_run);  // log2 domain
+        __builtin_amdgcn_wave_barrier();
+        const int rr = lane >> 3, ch = lane & 7;
+        const int tail_b = (H - h) * HD * 2 + h * HD;      // o_slab 2: bytes from the head's f16 columns to its e4m3 columns
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * i + rr, q = q0 + row;
+            const uint4 v = *reinterpret_cast<const uint4*>(ws + row * 144 + ch * 16);
+            if (q < N) {
+                bf16_t* orow = attn_out_row(O, o_slab, b, h, q, N, H, (int)gridDim.y / H);
+                *reinterpret_cast<uint4*>(orow + 8 * ch) = v;
+                if (o_slab == 2)
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(orow) + tail_b + 8 * ch) =
+                        make_uint2(e4m3x4_of_h4(v.x, v.y), e4m3x4_of_h4(v.z, v.w));
+            }
+        }
     }
 }
 
@@ -447,9 +479,12 @@ extern "C" int sed_mhsa_fwd(const void* Q, const void* K, const void* V, void* O
                             int Npad, int f16, hipStream_t stream) {
     (void)hipGetLastError();
     if (N <= 0 || Npad % 64 || Npad < N) return SED_ERR_ARG;
-    // f16 bit 0: IEEE half operands (else bf16); bit 1: O head-major [H][B * N][64] instead of token-major [B][N][H * 64]
-    if (f16 & 1) launch_mhsa_fwd<true>(Q, K, V, O, LSE, B, H, N, Npad, (f16 >> 1) & 1, stream);
-    else launch_mhsa_fwd<false>(Q, K, V, O, LSE, B, H, N, Npad, (f16 >> 1) & 1, stream);
+    // f16 bit 0: IEEE half operands (else bf16); bit 1: O head-major [H][B * N][64] instead of token-major [B][N][H * 64]; bit 2 (f16 only):
+    // token-major rows [H * 64 f16 | H * 64 e4m3], pitch 3 H * 64 / 2 halfs (the A operand of sed_gemm_nt_w2f8)
+    if ((f16 & 4) && (f16 & 3) != 1) return SED_ERR_ARG;
+    const int o_mode = (f16 & 4) ? 2 : (f16 >> 1) & 1;
+    if (f16 & 1) launch_mhsa_fwd<true>(Q, K, V, O, LSE, B, H, N, Npad, o_mode, stream);
+    else launch_mhsa_fwd<false>(Q, K, V, O, LSE, B, H, N, Npad, o_mode, stream);
     return sed_check_launch();
 }
 

@@ -126,3 +126,29 @@ static inline int sed_check_launch() {
     return e == hipSuccess ? SED_OK : -(1000 + (int)e);  // -(1000 + hipError_t): decoded by the Python binding
 }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// four fp32 -> four OCP e4m3 bytes (little end first) for the fp8 lo product of the two-term GEMMs (gemm.hip GemmArgs.k8):
+// v_cvt_pk_fp8_f32 rounds to nearest even; values are clamped to +-448 first (an out-of-range input would convert to NaN).
+__device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d) {
+    const float lim = 448.f;
+    a = __builtin_amdgcn_fmed3f(a, -lim, lim); b = __builtin_amdgcn_fmed3f(b, -lim, lim);
+    c = __builtin_amdgcn_fmed3f(c, -lim, lim); d = __builtin_amdgcn_fmed3f(d, -lim, lim);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
+// The activation's e4m3 image is 2^-2 x the (f16) activation, clamped to the e4m3 range (|x| <= 1792): four packed halves -> four bytes.
+// v_cvt_scalef32_pk_fp8_f16 converts src / scale with round-to-nearest-even and does NOT saturate (tools/ablate/cvt_fp8_probe.hip:
+// 2000 / 4 -> 0x7f = NaN), hence the packed clamp in front.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned e4m3x4_of_h4(unsigned h01, unsigned h23) {
+    const f16x2_t lim = {(_Float16)1792.f, (_Float16)1792.f};
+    f16x2_t a = __builtin_bit_cast(f16x2_t, h01), b = __builtin_bit_cast(f16x2_t, h23);
+    a = __builtin_elementwise_min(__builtin_elementwise_max(a, -lim), lim);
+    b = __builtin_elementwise_min(__builtin_elementwise_max(b, -lim), lim);
+    s16x2_t r = {0, 0};
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, a, 4.0f, false);
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, b, 4.0f, true);
+    return __builtin_bit_cast(unsigned, r);
+}

@@ -73,6 +73,9 @@ struct GemmArgs {
     // result for half of an f16 pass (`profiles/r4_fp8_mfma_probe.txt`).
     int k8;
     int f8_scale;
+    // ... and the 16-bit output of such a GEMM (EPI_GELU's outH2: the fc1 activation, fc2's A operand) can carry its own e4m3 image:
+    // rows [N f16 | N e4m3], ldc >= 3N / 2 halfs
+    int out_e4m3;
     // Persistent 256^2 kernel: workgroups with an odd (blockIdx.x >> 3) start `stagger` ticks of the 100 MHz real-time counter late, so
     // that their store phases fall into the other half's main loops instead of all 256 CUs hitting HBM in lock-step.  0 = off.
     int stagger;
@@ -485,21 +488,37 @@ struct PPSinkLds {
     }
     __device__ __forceinline__ void row(int i, const uint4& a0, const uint4& a1) const { half(i, 0, a0); half(i, 1, a1); }
 };
-struct PPSinkRows {          // row-major [M][ldc] output
+template <bool TAIL = false>
+struct PPSinkRowsT {         // row-major [M][ldc] output
     bf16_t* base;            // row mb + (l15 & 7), column nb + 32 (l15 >> 3) + 8 lq
     bf16_t* hbase;           // row mb + l15, column nb + 8 lq   (un-swapped halves)
     int ld8;                 // 8 * ldc
     int mrem, hrem;          // rows left from base's / hbase's row
     bool lo;
+    // TAIL (F8 kernels): rows are [N f16 | N e4m3] and `tail` > 0 is the byte distance from a lane's 8 f16 outputs to their 8 e4m3 images
+    // (GemmArgs.out_e4m3: the next GEMM's A operand with both halves written here); 0 = no image.  What the image costs is its bytes
+    // (+50 % on the epilogue's writes: 70 us of 510 at M = 105 k, N = 3072), not its conversion: with MODE.FP16_OVFL = 1 the conversion
+    // saturates by itself (tools/ablate/cvt_fp8_probe.hip) and the packed clamps can go -- 4 instructions instead of 12 per 8 values --
+    // for no measurable change (726 vs 723 us).
+    int tail;
+    __device__ __forceinline__ void st16(bf16_t* p, const uint4& v) const {
+        v3_st<uint4>(p, v);
+        if constexpr (TAIL) {
+#ifndef ABL_NO_TAIL      // (timing ablation, tools/ablate/build_variant.sh)
+            if (tail > 0) v3_st<uint2>(reinterpret_cast<unsigned char*>(p) + tail, make_uint2(e4m3x4_of_h4(v.x, v.y), e4m3x4_of_h4(v.z, v.w)));
+#endif
+        }
+    }
     __device__ __forceinline__ void half(int i, int k, const uint4& v) const {
         if (16 * i < hrem) v3_st<uint4>(hbase + (size_t)(2 * i) * ld8 + 32 * k, v);
     }
     __device__ __forceinline__ void row(int i, uint4 a0, uint4 a1) const {
         pp_pair_swap(a0, a1, lo);
-        if (16 * i < mrem) v3_st<uint4>(base + (size_t)(2 * i) * ld8, a0);
-        if (16 * i + 8 < mrem) v3_st<uint4>(base + (size_t)(2 * i + 1) * ld8, a1);
+        if (16 * i < mrem) st16(base + (size_t)(2 * i) * ld8, a0);
+        if (16 * i + 8 < mrem) st16(base + (size_t)(2 * i + 1) * ld8, a1);
     }
 };
+typedef PPSinkRowsT<false> PPSinkRows;
 struct PPSinkHeads {         // head-split q / k / v: [clip * heads + h][seq][64]
     bf16_t* dst;             // + h * seq * 64 + 32 (l15 >> 3) + 8 lq already applied
     int b0, t0, seq, hs, mrem;   // clip / token of row mb + (l15 & 7); hs = heads * seq; rows left from there
@@ -1159,7 +1178,7 @@ __device__ __forceinline__ void v3_load_consts(V3Consts<EPI>& c, const GemmArgs&
     }
 }
 
-template <int EPI, bool F16, int GBM, int RB = 8>
+template <int EPI, bool F16, int GBM, int RB = 8, bool F8 = false>
 __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&acc)[8][4], const V3Consts<EPI>& cc,
                                             unsigned char* wl, int mb, int nb, int lane, unsigned long long* gxt = nullptr) {
     // mb = first row of this wave's 128 x 64 sub-tile, nb = its first column
@@ -1181,8 +1200,9 @@ __device__ __forceinline__ void pp_epilogue(const GemmArgs& g, const f32x4_t (&a
             // (slab-major output: the wave's 64 columns are slab nb / 64, rows 128 bytes apart)
             const int ldo = g.c_slab ? 64 : g.ldc;
             bf16_t* const ob = g.c_slab ? out + (size_t)(nb >> 6) * g.M * 64 : out + nb;
-            const PPSinkRows sink{ob + (size_t)(mb + r8) * ldo + 32 * hk + 8 * lq, ob + (size_t)(mb + lrow) * ldo + 8 * lq,
-                                  8 * ldo, g.M - mb - r8, g.M - mb - lrow, lrow < 8};
+            const PPSinkRowsT<F8> sink{ob + (size_t)(mb + r8) * ldo + 32 * hk + 8 * lq, ob + (size_t)(mb + lrow) * ldo + 8 * lq,
+                                       8 * ldo, g.M - mb - r8, g.M - mb - lrow, lrow < 8,
+                                       (F8 && g.out_e4m3) ? 2 * g.N - (nb + 32 * hk + 8 * lq) : 0};
             if constexpr (GB) {      // evaluation-mode encoder only (no saved pre-activation: one pass)
                 const float *rA, *rB;
                 const int bnd = gb_split(g, mb, rA, rB);
@@ -1615,7 +1635,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
 #undef PP_TILE8
 #undef PP_TILE_
 #ifdef GX_TRACE
-    pp_epilogue<EPI, F16, GB, RB>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * (16 * RB), n0 + wn * 64, lane, gx_t);
+    pp_epilogue<EPI, F16, GB, RB, F8>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * (16 * RB), n0 + wn * 64, lane, gx_t);
     GX_STAMP(5)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GX_STAMP(6)
@@ -1638,7 +1658,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
         }
     }
 #else
-    pp_epilogue<EPI, F16, GB, RB>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * (16 * RB), n0 + wn * 64, lane);
+    pp_epilogue<EPI, F16, GB, RB, F8>(g, acc, cc, lds3 + wave * V3_WLDS, m0 + wm * (16 * RB), n0 + wn * 64, lane);
 #endif
     if constexpr (DIRECT_EPI) {
         tl = tl_next;                        // (no barrier: nothing of this tile is left in the LDS)
@@ -2170,6 +2190,15 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
                         return sed_check_launch();
                     }
                 }
+                if constexpr (EPI == EPI_GELU) if (g.out_e4m3) {
+                    // row-group bias + the e4m3 image of the output (fc1 of the evaluation-mode encoder in its fp8 form: f16 weights + mean
+                    // correction, the activation leaves as fc2's two-image A operand): the F8 kernel with no fp8 K tiles
+                    if (g.k_wrap != 0 || ((g.K / BK) & 1)) return SED_ERR_ARG;
+                    static bool attrge = false;
+                    if (!attrge) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true, 1, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attrge = true; }
+                    hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true, 1, 8, true>), grid3, dim3(512), V3_LDS, s, g);
+                    return sed_check_launch();
+                }
                 if (g.k_wrap != 0) {
                     if (!attrg[1]) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<EPI, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS); attrg[1] = true; }
                     hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, true, 2>), grid3, dim3(512), V3_LDS, s, g);
@@ -2225,9 +2254,11 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
 static int gemm_nt_impl(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi, const float* bias,
                         const float* resF, float* outF, void* outH, void* outH2, const void* auxH, int ldc, float alpha,
                         int ksplit, int f16, int ncols, hipStream_t stream, const float* gbias = nullptr, int gb_rows = 0, int two_term = 0,
-                        int f8_scale = 0) {
+                        int f8_scale = 0, int out_e4m3 = 0) {
     (void)hipGetLastError();
     GemmArgs g = {};
+    if (out_e4m3 && ((two_term != 3 && gbias == nullptr) || epi != EPI_GELU || outH != nullptr || ldc < N + N / 2)) return SED_ERR_ARG;
+    g.out_e4m3 = out_e4m3;
     if (two_term == 3) {      // A [M, K f16 | K e4m3] against B [N, K f16 | K e4m3]: K / 64 f16 tiles + K / 128 fp8 tiles
         if (K % 128 || epi == EPI_ATOMIC || epi == EPI_DGELU || gbias != nullptr || ksplit > 1) return SED_ERR_ARG;
         g.k8 = K / 128; g.f8_scale = f8_scale;
@@ -2269,6 +2300,14 @@ extern "C" int sed_gemm_nt_gb(const void* A, const void* B, int M, int N, int K,
                               const void* auxH, int ldc, float alpha, int f16, const float* gbias, int gb_rows, hipStream_t stream) {
     return gemm_nt_impl(A, B, M, N, K, lda, ldb, epi, bias, resF, outF, outH, outH2, auxH, ldc, alpha, 1, f16, N, stream, gbias, gb_rows);
 }
+// ... fused GELU with the e4m3 image of the result in the same rows (outH2 [M][N f16 | N e4m3], ldc >= 3N / 2): the A operand of a following
+// sed_gemm_nt_w2f8
+extern "C" int sed_gemm_nt_gb_e4m3(const void* A, const void* B, int M, int N, int K, int lda, int ldb, const float* bias, void* outH2,
+                                   int ldc, const float* gbias, int gb_rows, hipStream_t stream) {
+    if (gbias == nullptr || N % 256 || M < 1024) return SED_ERR_ARG;
+    return gemm_nt_impl(A, B, M, N, K, lda, ldb, EPI_GELU, bias, nullptr, nullptr, nullptr, outH2, nullptr, ldc, 1.f, 1, 1, N, stream, gbias, gb_rows,
+                        0, 0, 1);
+}
 // Two-term weights: A [M, K] (f16) against B [N, 2K] = [f16(W) | f16(W - f16(W))] (sed_weight_two_term_f16); A is read twice, the
 // result is A . W^T with W good to ~2^-19 relative.  256^2 kernel only (N % 256 == 0, M >= 1024), epilogues EPI_F32_RESID / EPI_GELU.
 extern "C" int sed_gemm_nt_w2(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi,
@@ -2283,12 +2322,14 @@ static int f8_scale_word(int s) {       // both operands' scale registers are th
     const int e = 128 - s / 2;
     return (s & 1) || e < 1 || e > 254 ? -1 : e * 0x01010101;
 }
+// out_e4m3 != 0 (epi 3, outH NULL): outH2 rows are [N f16 | N e4m3] (ldc >= 3N / 2) -- the activation and its e4m3 image, the A operand
+// of the next sed_gemm_nt_w2f8
 extern "C" int sed_gemm_nt_w2f8(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi,
                                 const float* bias, const float* resF, float* outF, void* outH, void* outH2,
-                                int ldc, int f8_exp, hipStream_t stream) {
+                                int ldc, int out_e4m3, int f8_exp, hipStream_t stream) {
     if (N % 256 || M < 1024 || f8_scale_word(f8_exp) < 0) return SED_ERR_ARG;
     return gemm_nt_impl(A, B, M, N, K, lda, ldb, epi, bias, resF, outF, outH, outH2, nullptr, ldc, 1.f, 1, 1, N, stream, nullptr, 0, 3,
-                        f8_scale_word(f8_exp));
+                        f8_scale_word(f8_exp), out_e4m3);
 }
 // LayerNorm folded into the two GEMMs around it (no-grad f16 passes; 256^2 kernel only: N % 256 == 0, M >= 1024).
 // producer = sed_gemm_nt with EPI_F32_RESID that ALSO writes x16 [M, N] (f16 image of the new residual stream) and rowpart [M][N / 64][2]
@@ -2700,16 +2741,16 @@ extern "C" int sed_weight_images(const int64_t* desc, int n_desc, int total_tile
 // `step` > 1: every step-th token only -- an estimate of the mean (the correction needs it to a few per cent; the part of the dropped
 // product that varies from token to token is left uncorrected anyway), for 1 / step of the extra pass over the activation
 template <bool F16>
-__global__ __launch_bounds__(256) void group_colmean_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int rows, int K, int step) {
+__global__ __launch_bounds__(256) void group_colmean_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int rows, int K, int ld, int step) {
     __shared__ float part[8][256];
     const int grp = blockIdx.x, c0 = blockIdx.y * 256;
     // thread = (row slice of 8, 32 column groups of 8 columns = 16 bytes)
     const int cg = threadIdx.x & 31, sl = threadIdx.x >> 5;
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const bf16_t* base = x + (size_t)grp * rows * K + c0 + cg * 8;
+    const bf16_t* base = x + (size_t)grp * rows * ld + c0 + cg * 8;
     const int nvis = (rows + step - 1) / step;
     for (int r = sl * step; r < rows; r += 8 * step) {
-        const uint4 u = *reinterpret_cast<const uint4*>(base + (size_t)r * K);
+        const uint4 u = *reinterpret_cast<const uint4*>(base + (size_t)r * ld);
         const unsigned w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -2726,12 +2767,15 @@ __global__ __launch_bounds__(256) void group_colmean_kernel(const bf16_t* __rest
     for (int i = 0; i < 8; ++i) s += part[i][c];
     out[(size_t)grp * K + c0 + c] = to_16<F16>(s / (float)nvis);
 }
-extern "C" int sed_group_colmean(const void* x, void* out, int groups, int rows, int K, int step, int f16, hipStream_t stream) {
+extern "C" int sed_group_colmean_ld(const void* x, void* out, int groups, int rows, int K, int ld, int step, int f16, hipStream_t stream) {
     (void)hipGetLastError();
-    if (groups <= 0 || rows <= 0 || K % 256 || step < 1) return SED_ERR_ARG;
-    if (f16) hipLaunchKernelGGL(group_colmean_kernel<true>, dim3(groups, K / 256), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)out, rows, K, step);
-    else hipLaunchKernelGGL(group_colmean_kernel<false>, dim3(groups, K / 256), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)out, rows, K, step);
+    if (groups <= 0 || rows <= 0 || K % 256 || step < 1 || ld < K || ld % 8) return SED_ERR_ARG;
+    if (f16) hipLaunchKernelGGL(group_colmean_kernel<true>, dim3(groups, K / 256), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)out, rows, K, ld, step);
+    else hipLaunchKernelGGL(group_colmean_kernel<false>, dim3(groups, K / 256), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)out, rows, K, ld, step);
     return sed_check_launch();
+}
+extern "C" int sed_group_colmean(const void* x, void* out, int groups, int rows, int K, int step, int f16, hipStream_t stream) {
+    return sed_group_colmean_ld(x, out, groups, rows, K, K, step, f16, stream);
 }
 // out = f16(scale * (w - f16(w)))  -- what the straight f16 image of an fp32 weight dropped (scale 2^11 keeps it a normal number)
 __global__ void weight_residual_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, size_t n4, float scale) {
@@ -2743,14 +2787,7 @@ __global__ void weight_residual_kernel(const float* __restrict__ w, bf16_t* __re
         reinterpret_cast<uint2*>(out)[i] = p;
     }
 }
-// e4m3 (OCP) images for the fp8 lo product (GemmArgs.k8).  v_cvt_pk_fp8_f32 rounds to nearest even; values are clamped to +-448 first.
-__device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d) {
-    const float lim = 448.f;
-    a = fminf(fmaxf(a, -lim), lim); b = fminf(fmaxf(b, -lim), lim); c = fminf(fmaxf(c, -lim), lim); d = fminf(fmaxf(d, -lim), lim);
-    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-    return (unsigned)w;
-}
+// e4m3 (OCP) images for the fp8 lo product (GemmArgs.k8); pack4_e4m3: common.h
 // rows of [K f16 | K e4m3] (pitch ld halfs): the e4m3 half = 2^-2 x the f16 half
 __global__ __launch_bounds__(256) void fp8_tail_kernel(bf16_t* __restrict__ x, int M, int K, int ld) {
     const int per_row = K / 8;
@@ -2759,10 +2796,9 @@ __global__ __launch_bounds__(256) void fp8_tail_kernel(bf16_t* __restrict__ x, i
         const int c = (int)(i - m * per_row);
         bf16_t* row = x + m * ld;
         const uint4 v = *reinterpret_cast<const uint4*>(row + 8 * c);
-        const f16x8_t h = __builtin_bit_cast(f16x8_t, v);
         uint2 o;
-        o.x = pack4_e4m3(0.25f * (float)h[0], 0.25f * (float)h[1], 0.25f * (float)h[2], 0.25f * (float)h[3]);
-        o.y = pack4_e4m3(0.25f * (float)h[4], 0.25f * (float)h[5], 0.25f * (float)h[6], 0.25f * (float)h[7]);
+        o.x = e4m3x4_of_h4(v.x, v.y);
+        o.y = e4m3x4_of_h4(v.z, v.w);
         *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(row + K) + 8 * c) = o;
     }
 }

@@ -74,6 +74,21 @@ __device__ __forceinline__ void row_store_split3_nt(const Row& r, bf16_t* p, int
         __builtin_nontemporal_store(hi, q + 2 * (DM / 4));
     }
 }
+// rows [DM f16 | DM e4m3] (pitch 3 DM / 2 halfs): the A operand of the two-term GEMMs with the lo product on the fp8 path (gemm.hip
+// GemmArgs.k8); the e4m3 half is 2^-2 x the f16-ROUNDED value (what sed_fp8_tail makes from the f16 half in a pass of its own)
+__device__ __forceinline__ void row_store_f16_e4m3_nt(const Row& r, bf16_t* p, int lane) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float v[4] = {r.v[i].x, r.v[i].y, r.v[i].z, r.v[i].w};
+        bf16_t h[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = f2h(v[e]);
+        u32x2nt hi;
+        hi[0] = (unsigned)h[0] | ((unsigned)h[1] << 16); hi[1] = (unsigned)h[2] | ((unsigned)h[3] << 16);
+        __builtin_nontemporal_store(hi, reinterpret_cast<u32x2nt*>(p) + lane + 64 * i);
+        __builtin_nontemporal_store(e4m3x4_of_h4(hi[0], hi[1]), reinterpret_cast<unsigned*>(p + DM) + lane + 64 * i);
+    }
+}
 #define ROW_FOREACH(i, c) for (int i = 0; i < NV; ++i) for (int c = 0; c < 4; ++c)
 __device__ __forceinline__ float& f4(float4& v, int c) { return reinterpret_cast<float*>(&v)[c]; }
 __device__ __forceinline__ const float& f4(const float4& v, int c) { return reinterpret_cast<const float*>(&v)[c]; }
@@ -123,6 +138,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         ROW_FOREACH(i, c) f4(r[k].v[i], c) = (f4(r[k].v[i], c) - mu[k]) * rs[k] * f4(g.v[i], c) + f4(b.v[i], c);
         if (y16 != nullptr) {
             if (f16 == 4) row_store_split3_nt(r[k], y16 + (size_t)row * 3 * DM, lane);
+            else if (f16 == 8) row_store_f16_e4m3_nt(r[k], y16 + (size_t)row * (DM + DM / 2), lane);
             else row_store_bf16_nt(r[k], y16 + (size_t)row * DM, lane, f16);
         }
         if (y32 != nullptr) row_store_nt(r[k], y32 + (size_t)row * DM, lane);

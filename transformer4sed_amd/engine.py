@@ -17,6 +17,7 @@ from . import ops
 import os
 
 from .ops import BF16, F16, F32, call, h2d, gemm_nt, gemm_dw, gemm_dw_tn, dw_tn_ok, pad64, transpose_bf16, to_bf16_, is_f16, split3, o_kind, two_term_weight
+from .ops import two_term_weight_f8, gemm_nt_w2f8
 from .ops import EPI_F32, EPI_F32_RESID, EPI_BF16, EPI_GELU, EPI_DGELU, EPI_F32_BF16, EPI_GELU32
 
 D = 768
@@ -129,6 +130,21 @@ class SedEngine:
             self.wcorr = "exact"
         if self.wcorr not in ("0", "exact"):
             raise ValueError(f"SED_ENC_WCORR={self.wcorr!r}: expected 0 or exact")
+        # The lo product of the exact mode, x . (W - f16(W))^T, is 2^-12 of the result: it can run on the fp8 matrix path (e4m3 images of both
+        # factors, v_mfma_scale_f32_16x16x128_f8f6f4: half of an f16 K pass; csrc/gemm.hip GemmArgs.k8).  The activations' e4m3 images come
+        # out of the producing kernels (LayerNorm, attention, fc1's epilogue) in the same rows as the f16 values.  e4m3 keeps ~5 % of the lo
+        # product as error, which is not free here (every posterior of the validation configuration sits within 15 % of its bound), so the
+        # default takes the two GEMMs that pay for it: qkv and fc2.  Measured on the validation step (clips/s; worst posterior of the val12
+        # fixture, bound 7e-4; depth-2 fixture at temp 0.5, bound 1e-3):  f16 138.9 / 5.96e-4 / 6.3e-4;  fc2 141.6 / 5.5e-4 / 7.6e-4;
+        # proj,fc2 143.7 / 6.3e-4 / 6.8e-4;  qkv,fc2 146.7 / 6.2e-4 / 9.2e-4 (default);  qkv,proj 145.1 / 6.9e-4 / 9.0e-4;
+        # qkv,proj,fc2 146.9 / 6.8e-4 / 1.02e-3 (over the second bound: proj gains 36 us per launch and its image costs the attention as much).
+        # SED_ENC_W2=f16: both products in f16 (the round-3 / round-4 form); f8:<subset of qkv,proj,fc2>: that subset.
+        mode = os.environ.get("SED_ENC_W2", "f8")
+        head, _, which = mode.partition(":")
+        self.w2_f8_set = frozenset(w for w in (which.split(",") if which else ("qkv", "fc2")) if w)
+        if head not in ("f8", "f16") or (head == "f16" and which) or not self.w2_f8_set <= {"qkv", "proj", "fc2"}:
+            raise ValueError(f"SED_ENC_W2={mode!r}: expected f16, f8, or f8:<subset of qkv,proj,fc2>")
+        self.w2_f8 = head == "f8"
         self.wcorr_all = os.environ.get("SED_ENC_WCORR_ALL", "0") != "0"
         # fc1 inside the exact mode: its rounding matters least of the four weights (tools/err_sim.py) and it is a third of the encoder's
         # GEMM work -- f16 weights + the per-clip mean correction there (default) keep the posteriors where the all-two-term form has them
@@ -174,9 +190,20 @@ class SedEngine:
         """Two-term f16 image [n_out, 2 k_in] of an fp32 weight, cached per weight like `_wlo_image`."""
         ent = W[name]
         p = self.P(name)
-        key = (p.data_ptr(), p._version, self._gen(name))
+        key = (p.data_ptr(), p._version, self._gen(name), "f16")
         if ent.w2 is None or ent.w2_key != key or ent.w2.device != ent.w.device:
             ent.w2 = two_term_weight(p.detach().reshape(ent.w.shape))
+            ent.w2_key = key
+        return ent.w2
+
+    def _w2f8_image(self, W, name):
+        """(uint8 image [n_out, 3 k_in] = rows [f16(W) | e4m3(2^s (W - f16(W)))], s) of an fp32 weight, cached like `_w2_image` (same slot:
+        a module runs one of the two forms)."""
+        ent = W[name]
+        p = self.P(name)
+        key = (p.data_ptr(), p._version, self._gen(name), "f8")
+        if ent.w2 is None or ent.w2_key != key or ent.w2[0].device != ent.w.device:
+            ent.w2 = two_term_weight_f8(p.detach().reshape(ent.w.shape))
             ent.w2_key = key
         return ent.w2
 
@@ -194,12 +221,13 @@ class SedEngine:
             ent.wlo_key = key
         return ent.wlo
 
-    def _wcorr_bias(self, W, name, x16, groups, rows):
-        """Row-group bias [groups, n_out] = mean over the `rows` tokens of each clip of x16 . (W - f16(W))^T (fp32)."""
+    def _wcorr_bias(self, W, name, x16, groups, rows, ld=None):
+        """Row-group bias [groups, n_out] = mean over the `rows` tokens of each clip of x16 . (W - f16(W))^T (fp32).  `ld`: row pitch of
+        x16 when its rows carry more than the K operand columns (the [f16 | e4m3] rows of the fp8 form)."""
         wlo = self._wlo_image(W, name)
-        K = x16.shape[-1]
+        K = wlo.shape[1]
         mean = torch.empty(groups, K, dtype=x16.dtype, device=x16.device)
-        call("sed_group_colmean", x16, mean, groups, rows, K, self.wcorr_step, is_f16(x16))
+        call("sed_group_colmean_ld", x16, mean, groups, rows, K, ld or x16.shape[-1], self.wcorr_step, is_f16(x16))
         out = torch.empty(groups, wlo.shape[0], dtype=F32, device=x16.device)
         gemm_nt(mean, wlo, EPI_F32, outF=out, alpha=1.0 / 2048.0)
         return out
@@ -328,6 +356,12 @@ class SedEngine:
         pooled = None
         wc = self._wcorr_on(save) and N >= 128
         w2 = wc and self.wcorr == "exact" and M >= 1024      # (the 256^2 kernel's domain; tiny inputs take the mean correction)
+        w2f8 = w2 and self.w2_f8 and f16 == 1
+        # which of the two-term GEMMs take their lo product on the fp8 path (fc1: when it is two-term at all, SED_ENC_WCORR_FC1=1); the
+        # operand rows of those are [f16 | e4m3] -- pitch 3 D / 2
+        q8, p8, f28 = (w2f8 and "qkv" in self.w2_f8_set), (w2f8 and "proj" in self.w2_f8_set), (w2f8 and "fc2" in self.w2_f8_set)
+        f18 = w2f8 and not self.wcorr_fc1_mean and self.wcorr_fc1
+        pitch = lambda on: D + D // 2 if on else D
         # No-grad f16 passes that are not scored (the teacher inside the train step, frozen encoders): LayerNorm folded into the GEMMs around
         # it -- the residual GEMM writes the f16 image of the new stream + per-row partial sums, the next GEMM consumes the RAW image against
         # gamma-scaled weights and normalises in its epilogue (csrc/gemm.hip, GemmArgs.rowpart / rowstat).  Two passes over the stream less
@@ -352,13 +386,13 @@ class SedEngine:
             fold = fold_ok and not sv
             B16 = BF16 if sv else A16
             if sv or scratch is None:
-                h16 = E(M, D, dt=A16)
+                h16 = E(M, pitch(q8), dt=A16)
                 q, k, v = mk_qkv()
-                o16 = E(M, D, dt=A16)
+                o16 = E(M, pitch(p8), dt=A16)
                 lse = E(Bx * H, N)
-                h2 = E(M, D, dt=A16)
-                hpre = E(M, 4 * D, dt=B16)
-                act = E(M, 4 * D, dt=A16)
+                h2 = E(M, pitch(f18), dt=A16)
+                hpre = E(M, 4 * D, dt=B16) if not w2f8 else None
+                act = E(M, 4 * pitch(f28), dt=A16)
                 mean1, rstd1, mean2, rstd2 = (E(M), E(M), E(M), E(M)) if sv else (None, None, None, None)
                 scratch = (h16, q, k, v, o16, lse, h2, hpre, act)
             else:
@@ -367,7 +401,7 @@ class SedEngine:
             x_in = x
             if not (fold and have_stat):
                 call("sed_layernorm_fwd", x_in, self.P(p + "norm1.weight"), self.P(p + "norm1.bias"), 1e-6, 1.0, h16, None,
-                     mean1, rstd1, M, D, f16)
+                     mean1, rstd1, M, D, 8 if q8 else f16)
             if fold:
                 last = li + 1 == m.depth or (li + 1 == m.passt_feature_layer and not want_frame) or (save and li + 1 >= lo_f)
                 if have_stat:
@@ -410,6 +444,49 @@ class SedEngine:
                         x = x.clone()       # f_pool's backward reads the tensor it was given; the blocks above keep updating in place
                 if save:
                     ctx["layers"].append(None)
+                continue
+            if w2f8:    # evaluation mode, lo products on the fp8 matrix path: operand rows [f16 | e4m3], written by the producing kernels
+                bq, bp_, b1_, b2_ = (self.P(p + n) for n in ("attn.qkv.bias", "attn.proj.bias", "mlp.fc1.bias", "mlp.fc2.bias"))
+                if q8:
+                    wq, sq = self._w2f8_image(W, p + "attn.qkv.weight")
+                    call("sed_gemm_qkv_w2f8", h16, wq, bq, M, D, H, N, Npad, q, k, v, sq)
+                else:
+                    call("sed_gemm_qkv_w2", h16, self._w2_image(W, p + "attn.qkv.weight"), bq, M, D, H, N, Npad, q, k, v, f16)
+                call("sed_mhsa_fwd", q, k, v, o16, lse, Bx, H, N, Npad, 1 | (4 if p8 else 0))
+                if p8:
+                    wp, sp_ = self._w2f8_image(W, p + "attn.proj.weight")
+                    gemm_nt_w2f8(o16, wp, sp_, EPI_F32_RESID, D, bias=bp_, res=x_in, outF=x_in)
+                else:
+                    gemm_nt(o16, self._w2_image(W, p + "attn.proj.weight"), EPI_F32_RESID, bias=bp_, res=x_in, outF=x_in, two_term=True)
+                call("sed_layernorm_fwd", x_in, self.P(p + "norm2.weight"), self.P(p + "norm2.bias"), 1e-6, 1.0, h2, None,
+                     mean2, rstd2, M, D, 8 if f18 else f16)
+                if f18:
+                    w1_, s1_ = self._w2f8_image(W, p + "mlp.fc1.weight")
+                    gemm_nt_w2f8(h2, w1_, s1_, EPI_GELU, D, bias=b1_, outH2=act, out_e4m3=bool(f28))
+                elif self.wcorr_fc1:
+                    gemm_nt(h2, self._w2_image(W, p + "mlp.fc1.weight"), EPI_GELU, bias=b1_, outH=None, outH2=act, two_term=True,
+                            ldc=4 * pitch(f28))
+                    if f28:
+                        call("sed_fp8_tail", act, M, 4 * D, 4 * pitch(f28))
+                else:       # fc1 (the weight whose rounding matters least) on f16 weights (+ the per-clip mean correction, default)
+                    gb = self._wcorr_bias(W, p + "mlp.fc1.weight", h2, Bx, N) if self.wcorr_fc1_mean else None
+                    if f28:
+                        call("sed_gemm_nt_gb_e4m3", h2, W[p + "mlp.fc1.weight"].w, M, 4 * D, D, D, D, b1_, act, 4 * pitch(f28),
+                             gb if gb is not None else self._zeros("gb0", (Bx, 4 * D), F32, dev), N)
+                    elif gb is not None:
+                        gemm_nt(h2, W[p + "mlp.fc1.weight"].w, EPI_GELU, bias=b1_, outH=None, outH2=act, gbias=gb, gb_rows=N)
+                    else:
+                        gemm_nt(h2, W[p + "mlp.fc1.weight"].w, EPI_GELU, bias=b1_, outH=None, outH2=act)
+                if f28:
+                    w2_, s2_ = self._w2f8_image(W, p + "mlp.fc2.weight")
+                    gemm_nt_w2f8(act, w2_, s2_, EPI_F32_RESID, 4 * D, bias=b2_, res=x_in, outF=x_in)
+                else:
+                    gemm_nt(act, self._w2_image(W, p + "mlp.fc2.weight"), EPI_F32_RESID, bias=b2_, res=x_in, outF=x_in, two_term=True)
+                x = x_in
+                if li + 1 == m.passt_feature_layer:
+                    pooled = self._fpool_fwd(W, x, Bx, tp, save, ctx)
+                    if not want_frame:
+                        break
                 continue
             if w2:      # evaluation mode: every encoder GEMM against the two-term weight image
                 call("sed_gemm_qkv_w2", h16, self._w2_image(W, p + "attn.qkv.weight"), self.P(p + "attn.qkv.bias"), M, D, H, N, Npad, q, k, v, f16)

@@ -158,7 +158,7 @@ class plain_precision:
 
 
 def _flops_of(name, args):
-    if name in ("sed_gemm_nt", "sed_gemm_nt_gb", "sed_gemm_nt_w2", "sed_gemm_nt_w2f8", "sed_gemm_nt_lnp", "sed_gemm_nt_lnp8", "sed_gemm_nt_lnc", "sed_gemm_nt_lnc8"):       # (w2: the logical 2 M N K, half of the MFMA FLOPs issued)
+    if name in ("sed_gemm_nt", "sed_gemm_nt_gb", "sed_gemm_nt_gb_e4m3", "sed_gemm_nt_w2", "sed_gemm_nt_w2f8", "sed_gemm_nt_lnp", "sed_gemm_nt_lnp8", "sed_gemm_nt_lnc", "sed_gemm_nt_lnc8"):       # (w2: the logical 2 M N K, half of the MFMA FLOPs issued)
         return 2.0 * args[2] * args[3] * args[4]
     if name in ("sed_gemm_qkv_lnc", "sed_gemm_qkv_lnc8"):
         return 2.0 * args[5] * args[6] * (3 * args[7] * 64)
@@ -416,13 +416,14 @@ def fp8_tail(x, K):
     call("sed_fp8_tail", x, x.shape[0], K, x.shape[1])
 
 
-def gemm_nt_w2f8(A, Bimg, s, epi, K, bias=None, res=None, outF=None, outH=None, outH2=None, ldc=None):
+def gemm_nt_w2f8(A, Bimg, s, epi, K, bias=None, res=None, outF=None, outH=None, outH2=None, ldc=None, out_e4m3=False):
     """gemm_nt(two_term=True) with the lo product on the fp8 matrix path: A [M, 3K / 2] f16 rows [K f16 | K e4m3] (fp8_rows / fp8_tail),
-    (Bimg, s) = two_term_weight_f8(W)."""
+    (Bimg, s) = two_term_weight_f8(W).  out_e4m3 (epi GELU): outH2 is an fp8_rows buffer of N columns and gets both halves."""
     M, N = A.shape[0], Bimg.shape[0]
     if A.dtype != F16 or Bimg.dtype != torch.uint8 or Bimg.shape[1] != 3 * K or A.shape[1] < K + K // 2:
         raise RuntimeError("gemm_nt_w2f8: A is f16 [M, 3K / 2], B the uint8 image [N, 3K] of two_term_weight_f8")
-    call("sed_gemm_nt_w2f8", A, Bimg, M, N, K, A.shape[1], 3 * K // 2, epi, bias, res, outF, outH, outH2, ldc or N, s)
+    call("sed_gemm_nt_w2f8", A, Bimg, M, N, K, A.shape[1], 3 * K // 2, epi, bias, res, outF, outH, outH2, ldc or (N + N // 2 if out_e4m3 else N),
+         1 if out_e4m3 else 0, s)
 
 
 def o_kind(t):
