@@ -398,6 +398,7 @@ def main():
         trainer.ddp = GradBucketReducer(net, opt)
         trainer.ddp.force = force_ddp
 
+    finish = None       # mode-specific work that belongs to the timed steps but runs once behind them
     if a.mode == "val":
         from transformer4sed_amd.evaluation import Encoder, Evaluator
         enc = Encoder(["Alarm_bell_ringing", "Blender", "Cat", "Dishes", "Dog", "Electric_shaver_toothbrush", "Frying",
@@ -408,10 +409,17 @@ def main():
         pad_mask = torch.zeros(B, 1000, dtype=torch.bool)
         paths = [f"/synthetic/val/clip_{rank}_{i}.wav" for i in range(B)]
 
+        # one Evaluator for the whole run, like Trainer.validation over an epoch: the host half of a batch's decode runs under the next
+        # forward; `finish` (inside the timed region) completes the last batch's tables
+        ev = Evaluator(net, ema_net, enc, vcfg)
+
         def step(w=None):
-            ev = Evaluator(net, ema_net, enc, vcfg)
             ev.step(wav, labels, pad_mask, paths)
-            return {"loss_total": torch.tensor(float(len(ev.scores.post_student)))}
+            return {"loss_total": torch.tensor(float(B))}
+
+        def finish():
+            ev.flush()
+            assert len(ev.scores.post_student) == B and len(ev.scores.post_teacher) == B
     elif a.mode == "dasm":
         ext = net.get_feature_extractor()
 
@@ -433,6 +441,8 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    if os.environ.get("SED_SYNC_DEBUG"):      # developer switch: warn (with a stack) at every host synchronisation inside the steps
+        torch.cuda.set_sync_debug_mode(1)
     # HIP events bracket every GEMM launch of the FIRST timed step only: the event packets cost ~8 us of stream time per launch
     # (2.5 ms on a 138 ms step when every step is instrumented), which would otherwise be charged to `value`
     timer = None if a.no_kernel_timer else ops.KernelTimer(GEMM_KERNELS + list(ops.HBM_KERNELS) + (["sed_gemm_f32_nt", "sed_xattn_f32_fwd"] if a.mode == "dasm" else []))
@@ -453,6 +463,8 @@ def main():
     for i in range(a.steps):
         ops.TIMER = timer if i < timed_steps_with_events else None
         out = step()
+    if finish is not None:
+        finish()
     host_issue_s = time.perf_counter() - t0      # the Python schedule of the timed steps has been issued (the GPU is still running them)
     if world > 1:
         dist.barrier()

@@ -18,7 +18,7 @@ kernel; the K / V projections of ALL decoder layers are taken straight from the 
 weights (W_kv . W_at: one GEMM over the 1188 tokens instead of 1 + 2 L)."""
 import torch
 
-from .ops import call
+from .ops import call, h2d
 
 F32 = torch.float32
 
@@ -108,7 +108,7 @@ class DasmHead:
         x = q0.unsqueeze(0).expand(B, Q, Dd).contiguous().view(B * Q, Dd)
         mask8 = None
         if tgt_mask is not None:
-            mask8 = tgt_mask.to(device=dev).to(torch.uint8).contiguous()
+            mask8 = h2d(tgt_mask, torch.uint8, dev)
             if tuple(mask8.shape) != (Q, Q):
                 raise ValueError(f"tgt_mask must be [{Q}, {Q}]")
         M = B * Q
@@ -145,7 +145,7 @@ class DasmHead:
         logits = E(B, T, Q)
         gemm_f32(xs, e, M=T, N=Q, lda=Dd, ldb=Dd, out=logits, batch=B, strides=(T * Dd, Q * Dd, T * Q))
         strong, weak, at_out = E(B, Q, T), E(B, Q), E(B, Q)
-        pm = None if pad_mask is None else pad_mask.to(device=dev).to(torch.uint8).contiguous()
+        pm = None if pad_mask is None else h2d(pad_mask, torch.uint8, dev)
         call("sed_dasm_head_fwd", logits, at_logit, pm, float(temp_w), strong, weak, at_out, B, T, Q)
         return strong, weak, at_out, mask_feat.view(B, Q, Dd)
 

@@ -775,7 +775,7 @@ class SedEngine:
             sums = E(B, C, 2)
             pm = None
             if pad_mask is not None:
-                pm = pad_mask.to(device=dev, dtype=torch.uint8).contiguous()
+                pm = h2d(pad_mask, torch.uint8, dev)      # (pinned staging: a pageable .to(device) here blocks the host until the whole forward has run)
             call("sed_head_fwd", xd, self.P("classifier.weight"), self.P("classifier.bias"), float(temp_w), pm, strong,
                  weak, sums, B, Tdec, C)
             out["strong"], out["weak"] = strong, weak

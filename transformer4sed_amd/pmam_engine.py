@@ -583,7 +583,7 @@ class PmamEngine(SedEngine):
             w_pad = torch.zeros(C, D, dtype=F32, device=dev)
             w_pad[:, :Dd] = self.P("classifier.weight").detach()
             strong, weak, sums = E(B, C, Tdec), E(B, C), E(B, C, 2)
-            pm = None if pad_mask is None else pad_mask.to(device=dev, dtype=torch.uint8).contiguous()
+            pm = None if pad_mask is None else h2d(pad_mask, torch.uint8, dev)
             call("sed_head_fwd", xd_pad, w_pad, self.P("classifier.bias"), float(temp_w), pm, strong, weak, sums, B, Tdec, C)
             out["strong"], out["weak"] = strong, weak
             hctx = dict(strong=strong, sums=sums, temp=float(temp_w), xd_pad=xd_pad, w_pad=w_pad)
