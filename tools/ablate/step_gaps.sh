@@ -1,17 +1,21 @@
 #!/bin/bash
-# val_gaps.sh : where the GPU idles inside a validation step -- gaps > 50 us between consecutive kernels of the last of 3 steps (GPU box)
+# step_gaps.sh MODE [ENV=VAL ...] : where the GPU idles inside a step of bench.py --mode MODE -- gaps between consecutive kernels of the
+# last of 3 steps, from a rocprofv3 kernel trace (GPU box).  How the validation step's 14 ms of idle GPU were found (a blocking pad-mask upload).
 R=${GRAFT_REPO_ROOT:-/root/repo}
+mode=$1; shift
 cd /tmp && export TMPDIR=/tmp
-env "$@" SED_OVERLAP_TEACHER=0 rocprofv3 --kernel-trace --output-format csv -d /tmp/vg -o p -- python $R/bench.py --mode val --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timer > /dev/null 2>&1
+rm -rf /tmp/vg
+env "$@" SED_OVERLAP_TEACHER=0 rocprofv3 --kernel-trace --output-format csv -d /tmp/vg -o p -- python $R/bench.py --mode $mode --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timer > /dev/null 2>&1
 f=$(find /tmp/vg -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows))
 # last step: from the last logmel kernel on
-starts = [i for i, e in enumerate(ev) if "logmel_kernel" in e[2]]
-i0 = starts[-1]
-seg = ev[i0 - 2:]
+starts = [i for i, e in enumerate(ev) if "wav_absmax_kernel" in e[2]]
+# (the last step starts at the last frontend launch that is followed by a long run of kernels)
+i0 = starts[-1] if len(starts) < 2 or len(ev) - starts[-1] > 100 else starts[-2]
+seg = ev[max(0, i0 - 1):]
 t0, t1 = seg[0][0], max(e[1] for e in seg)
 busy = 0; cur_end = seg[0][0]; gaps = []
 for s, e, n in seg:

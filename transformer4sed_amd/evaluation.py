@@ -257,7 +257,7 @@ class Evaluator:
     forward: `step` queues the student's forward, filters and device-to-host copies, finishes the previous batch's teacher tables, queues
     the teacher, finishes the student's tables and returns with the teacher's still pending.  `scores`, `events`, `event_frame`,
     `write` and `flush` complete whatever is pending first, so what a caller reads is always whole.  (The synchronous form -- decode
-    right behind each forward with `.cpu()` -- left the GPU idle for 14 of a 212 ms validation step, tools/ablate/val_gaps.sh.)"""
+    right behind each forward with `.cpu()` -- left the GPU idle for 14 of a 212 ms validation step, tools/ablate/step_gaps.sh.)"""
 
     def __init__(self, net, ema_net, encoder, config):
         self.net, self.ema_net, self.encoder, self.config = net, ema_net, encoder, config
