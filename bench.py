@@ -101,7 +101,7 @@ GFLOP_PER_BATCH = 21.22       # batch-shared linear_pos GEMMs (b-term)
 GFLOP_SKIPPED = {"finetune2": 211.5, "val": 654.3}
 PEAK_BF16_TFLOPS = 2500.0     # dense 16-bit MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0         # HBM3E peak, MI355X_MICROARCH.md
-GEMM_KERNELS = ["sed_gemm_nt", "sed_gemm_qkv", "sed_gemm_qkv_w2s", "sed_gemm_dw_tn", "sed_gemm_nt_gb", "sed_gemm_qkv_gb", "sed_gemm_nt_w2", "sed_gemm_qkv_w2", "sed_gemm_nt_lnp", "sed_gemm_nt_lnp8", "sed_gemm_nt_lnc", "sed_gemm_qkv_lnc", "sed_gemm_nt_lnc8", "sed_gemm_qkv_lnc8"]
+GEMM_KERNELS = ["sed_gemm_nt", "sed_gemm_qkv", "sed_gemm_qkv_w2s", "sed_gemm_dw_tn", "sed_gemm_nt_gb", "sed_gemm_qkv_gb", "sed_gemm_nt_w2", "sed_gemm_qkv_w2", "sed_gemm_nt_w2f8", "sed_gemm_qkv_w2f8", "sed_gemm_nt_gb_e4m3", "sed_gemm_nt_lnp", "sed_gemm_nt_lnp8", "sed_gemm_nt_lnc", "sed_gemm_qkv_lnc", "sed_gemm_nt_lnc8", "sed_gemm_qkv_lnc8"]
 
 
 def build(per_gpu_batch, depth, device, mode="finetune2"):
@@ -596,7 +596,7 @@ def main():
                             "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                             "achieved_issued": round(fl_issued / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, 2),
                             "achieved_note": "achieved = algorithmic 2MNK (split-precision GEMMs counted at their logical K); "
-                                             "achieved_issued = MFMA FLOPs actually issued (3x K for the split-precision GEMMs, 2x K for the two-term-weight GEMMs of evaluation passes); "
+                                             "achieved_issued = MFMA FLOPs actually issued (3x K for the split-precision GEMMs, 2x K for the two-term-weight GEMMs of evaluation passes -- for sed_gemm_*_w2f8 the second K pass is e4m3 x e4m3 on the fp8 matrix path, counted here at its FLOPs); "
                                              "the GEMM launches of no-grad encoder passes also carry that block's LayerNorm (row statistics in the residual epilogue, "
                                              "normalisation in the next GEMM's epilogue; SED_LN_FOLD=0 separates them again): their time counts here, the LayerNorm passes "
                                              "they replace do not exist any more",

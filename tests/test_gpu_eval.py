@@ -102,6 +102,46 @@ def test_evaluator_step_depth2(tmp_path):
     assert ev.weak_f1["student"].compute() >= 0.0 and len(ev.event_frame("teacher").columns) in (0, 4)
 
 
+def test_evaluator_pipelined_steps_equal_synchronous(tmp_path):
+    """`Evaluator.step` leaves the teacher's tables pending and builds them under the next batch's forward: two batches through one
+    Evaluator must give exactly the tables / event lists / weak-F1 of two Evaluators that flush after every batch, whatever is read
+    first, and `out` must not depend on it."""
+    from copy import deepcopy
+    from test_gpu_model import _build
+    net, sd = _build(False, 2, 2)
+    ema = deepcopy(net)
+    with torch.no_grad():
+        for p_ in ema.parameters():
+            p_.mul_(1.01)
+    cfg = {"training": {"median_window": [5, 20, 5, 5, 5, 20, 20, 20, 5, 20], "filter_type": "median", "weak_mask": True},
+           "PaSST_SED": {"val_kwargs": {"encoder_win": True, "win_param": [512, 31], "mix_rate": 0.5, "temp_w": 0.5}}}
+    B = 2
+    batches = []
+    for i in range(2):
+        wav = torch.from_numpy(synth.synth_wav(B, seed=90 + i)).to(DEV)
+        labels = torch.from_numpy(synth.synth_batch_labels(B, 0, 0, seed=92 + i)).to(DEV)
+        pad = torch.zeros(B, 1000, dtype=torch.bool); pad[i, 700:] = True
+        batches.append((wav, labels, pad, [f"/x/val/b{i}_{j}.wav" for j in range(B)]))
+    piped = Evaluator(net, ema, _enc(), cfg)
+    outs = [piped.step(*b) for b in batches]
+    assert "teacher" in piped._pending and "student" not in piped._pending          # the last teacher decode is still to come
+    sync = Evaluator(net, ema, _enc(), cfg)
+    for b, o in zip(batches, outs):
+        o2 = sync.step(*b)
+        sync.flush()
+        for who in ("student", "teacher"):
+            assert all(torch.equal(x, y) for x, y in zip(o[who], o2[who]))
+    assert piped.event_frame("teacher").equals(sync.event_frame("teacher")) and not piped._pending
+    for name in ("raw_student", "raw_teacher", "post_student", "post_teacher"):
+        a, b_ = getattr(piped.scores, name), getattr(sync.scores, name)
+        assert sorted(a) == sorted(b_) == ["b0_0", "b0_1", "b1_0", "b1_1"]
+        assert all(a[k].equals(b_[k]) for k in a)
+    assert piped.event_frame("student").equals(sync.event_frame("student"))
+    for who in ("student", "teacher"):
+        assert piped.weak_f1[who].compute() == sync.weak_f1[who].compute()
+    assert float(outs[1]["teacher"][0][1, :, 700:].abs().max()) == 0.0 and float(outs[0]["teacher"][0][0, :, 700:].abs().max()) == 0.0
+
+
 # ------------------------------------------------------------------------------------------------ input pipeline on the device
 def test_device_resampler_vs_scipy():
     """`sed_resample_poly` against scipy.signal.resample_poly (the definition it implements; the reference's offline tool uses

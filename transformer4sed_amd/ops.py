@@ -280,8 +280,8 @@ def call(name, *args):
         e1.record()
         fi = _flops_of(name, args)
         by = _hbm_bytes_of(name, args) if name in HBM_KERNELS else _bytes_of(name, args)
-        two = name.endswith("_w2") or name.endswith("_w2s")
-        issued = fi * (2.0 if two else 1.0)      # two-term weights: the A panel is multiplied twice
+        two = name.endswith(("_w2", "_w2s", "_w2f8"))
+        issued = fi * (2.0 if two else 1.0)      # two-term weights: the A panel is multiplied twice (w2f8: the second time as e4m3 on the fp8 path)
         # (a two-term launch is given its LOGICAL K: no split-precision scaling even inside a split_precision() block)
         TIMER.records.append((name, e0, e1, fi * (1.0 if two else ALG_K_SCALE), by, issued, _shape_of(name, args)))
         return
