@@ -775,6 +775,9 @@ __global__ __launch_bounds__(512) void relpos_bwd_dq_kernel(
 //   lane (c, g) reads the 16 bytes q = 32 ks + 8 g .. + 7 of its key's slab row straight from global memory into the B operand, one
 //   tile ahead.  Output lane = key column, 4 consecutive d per block -> 8-byte stores.
 // ---------------------------------------------------------------------------------------------------
+// (round 5: a rotated tile order per workgroup changes nothing -- not channel hot-spotting; three workgroups per CU instead of two
+//  (80 VGPRs) run 515-537 us against 421-427: more bytes in flight do not help, the slab walk -- 128 bytes from each of 128 rows 2 KiB
+//  apart per step -- is what the memory system delivers at 3.8 TB/s)
 __global__ __launch_bounds__(512) void relpos_bwd_dkdv_stream_kernel(const bf16_t* __restrict__ Qut, const bf16_t* __restrict__ dOt,
                                                                      const bf16_t* __restrict__ dSt, const bf16_t* __restrict__ Pst,
                                                                      bf16_t* __restrict__ dqkv, int T, int Tpad, int H) {
@@ -790,14 +793,7 @@ __global__ __launch_bounds__(512) void relpos_bwd_dkdv_stream_kernel(const bf16_
     uint4 ta, tb;
     s16x8_t fs[2], fp[2];
     // (one tile of slab rows in flight per wave; two were slower: 424 vs 402 us)
-#ifdef RP_ROT
-    const int rot = (RP_ROT * blockIdx.x + blockIdx.y) % ntiles;
-#else
-    const int rot = 0;
-#endif
-    auto gload = [&](int t0_) {
-        int t = t0_ + rot;
-        t = t >= ntiles ? t - ntiles : t;
+    auto gload = [&](int t) {
         ta = *reinterpret_cast<const uint4*>(Qut + hbt + (size_t)trow * Tpad + 64 * t + 8 * tch);
         tb = *reinterpret_cast<const uint4*>(dOt + hbt + (size_t)trow * Tpad + 64 * t + 8 * tch);
 #pragma unroll
