@@ -42,11 +42,12 @@ def h2d(x, dtype, dev):
     key = (tuple(t.shape), dtype)
     ring = _PIN_RINGS.get(key)
     if ring is None:
-        ring = _PIN_RINGS[key] = dict(bufs=[], evs=[], i=0)
+        # (one pinned allocation for the whole ring: a slot allocated on first use costs ~1 ms each for the first 16 calls of a shape)
+        block = torch.empty((_PIN_DEPTH,) + tuple(t.shape), dtype=dtype).pin_memory()
+        ring = _PIN_RINGS[key] = dict(bufs=[block[j] for j in range(_PIN_DEPTH)], evs=[None] * _PIN_DEPTH, i=0)
     i = ring["i"]
-    if len(ring["bufs"]) <= i:
-        ring["bufs"].append(torch.empty(t.shape, dtype=dtype).pin_memory())
-        ring["evs"].append(torch.cuda.Event())
+    if ring["evs"][i] is None:
+        ring["evs"][i] = torch.cuda.Event()
     else:
         ring["evs"][i].synchronize()   # only waits when the host is a full ring (several steps) ahead of the GPU
     buf = ring["bufs"][i]
