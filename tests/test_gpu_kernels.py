@@ -731,7 +731,7 @@ def _split(B, N, seed, scale=1.0, dt=BF16):
 
 
 @pytest.mark.parametrize("DT", [BF16, F16])
-@pytest.mark.parametrize("B,N", [(1, 70), (2, 602), (2, 1190)])
+@pytest.mark.parametrize("B,N", [(1, 70), (2, 602), (2, 1190), (2, 386), (1, 80), (1, 81), (1, 96), (1, 97)])
 def test_mhsa_fwd_bwd(B, N, DT):
     Hh = 12
     f16 = 1 if DT == F16 else 0

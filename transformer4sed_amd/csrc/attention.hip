@@ -370,6 +370,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE_DMA, WP
         const unsigned char* lk = lds[buf][0];
         const unsigned char* lv = lds[buf][1];
         f32x16_t st[2];
+        // (round 5: a short path for a last tile that ends in its first 32 keys -- N = 2 + 12 tp leaves 2 / 26 keys there at 386 / 602 tokens:
+        //  one score block, softmax over it alone, 1-2 of the 4 P.V steps -- was bit-compatible and SLOWER: 167 instead of 144 VGPRs and a
+        //  second tile body cost the other 18 tiles more than the last one saved, 209 -> 220 us at N = 1190, 788 -> 797 at 602.  Not kept.)
         if (q0 < N) {        // (wave-uniform) a wave whose 32 queries all lie past the sequence end only stages tiles and joins the barriers
 #ifndef ATT_NO_KPRE
         {   // all eight K fragments requested before the first MFMA: their LDS latency is paid once per tile, not once per MFMA
