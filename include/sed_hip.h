@@ -241,6 +241,10 @@ int sed_relpos_attn_bwd(const void* Qu, const void* Qut, const void* Qv, const v
  * 8: y_bf16 rows are [D f16 | D e4m3] (pitch 3 D / 2 halfs), the A operand of sed_gemm_nt_w2f8 / sed_gemm_qkv_w2f8 */
 int sed_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float in_scale, void* y_bf16,
                       float* y_f32, float* mean, float* rstd, int M, int D, int f16, hipStream_t stream);
+/* ... with the result written twice, as IEEE half (y_f16: the forward GEMM's operand) and as bf16 (y_bf16: the saved operand of the backward's
+ * weight-gradient GEMM, rounded once from fp32) */
+int sed_layernorm_fwd_dual(const float* x, const float* gamma, const float* beta, float eps, float in_scale, void* y_f16, void* y_bf16,
+                           float* mean, float* rstd, int M, int D, hipStream_t stream);
 int sed_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                       float in_scale, float* dx, int accumulate, float* dgamma, float* dbeta, int M, int D,
                       hipStream_t stream);

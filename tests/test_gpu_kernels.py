@@ -852,6 +852,11 @@ def test_layernorm_fwd_bwd():
         yh = torch.empty(M, 768, dtype=F16, device=DEV)
         call("sed_layernorm_fwd", x, g, b, eps, in_scale, yh, None, None, None, M, 768, 1)
         assert torch.equal(yh, y32.to(F16))
+        # both 16-bit forms in one pass (f16 for the forward GEMM, bf16 for the backward's weight gradient), statistics included
+        yh2 = torch.empty(M, 768, dtype=F16, device=DEV); yb2 = torch.empty(M, 768, dtype=BF16, device=DEV)
+        mu2 = torch.empty(M, device=DEV); rs2 = torch.empty(M, device=DEV)
+        call("sed_layernorm_fwd_dual", x, g, b, eps, in_scale, yh2, yb2, mu2, rs2, M, 768)
+        assert torch.equal(yh2, yh) and torch.equal(yb2, y16) and torch.equal(mu2, mu) and torch.equal(rs2, rs)
         xx = x.clone().requires_grad_(True); gg = g.clone().requires_grad_(True); bb = b.clone().requires_grad_(True)
         ref = torch.nn.functional.layer_norm(xx * in_scale, (768,), gg, bb, eps)
         e = maxerr(y32, ref); report(f"layernorm fwd scale={in_scale:.1f}", e); assert e < 2e-5

@@ -104,7 +104,8 @@ template <int RW>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float eps, float in_scale,
                                                             bf16_t* __restrict__ y16, float* __restrict__ y32,
-                                                            float* __restrict__ mean, float* __restrict__ rstd, int M, int f16) {
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int M, int f16,
+                                                            bf16_t* __restrict__ y16b) {
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
     if (row0 >= M) return;
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             else if (f16 == 8) row_store_f16_e4m3_nt(r[k], y16 + (size_t)row * (DM + DM / 2), lane);
             else row_store_bf16_nt(r[k], y16 + (size_t)row * DM, lane, f16);
         }
+        if (y16b != nullptr) row_store_bf16_nt(r[k], y16b + (size_t)row * DM, lane, 0);      // bf16 copy for the backward's weight gradient
         if (y32 != nullptr) row_store_nt(r[k], y32 + (size_t)row * DM, lane);
         if (lane == 0 && mean != nullptr) { mean[row] = mu[k]; rstd[row] = rs[k]; }
     }
@@ -152,7 +154,17 @@ extern "C" int sed_layernorm_fwd(const float* x, const float* gamma, const float
     if (D != DM || M <= 0) return SED_ERR_ARG;
     // (two rows per wave: the 1- and 4-row variants measured slower on cold input, tools/ln_bench.py)
     hipLaunchKernelGGL(layernorm_fwd_kernel<2>, dim3(cdiv(M, 8)), dim3(256), 0, stream, x, gamma, beta, eps, in_scale,
-                       (bf16_t*)y_bf16, y_f32, mean, rstd, M, f16);
+                       (bf16_t*)y_bf16, y_f32, mean, rstd, M, f16, (bf16_t*)nullptr);
+    return sed_check_launch();
+}
+// ... writing the result twice: IEEE half (the forward GEMM's operand) and bf16 (what the backward's weight-gradient GEMM multiplies with:
+// its TN kernel otherwise converts the saved f16 fragments to bf16 in registers, 17-20 % of that launch -- tools/dw_xtype_bench.py)
+extern "C" int sed_layernorm_fwd_dual(const float* x, const float* gamma, const float* beta, float eps, float in_scale,
+                                      void* y_f16, void* y_bf16, float* mean, float* rstd, int M, int D, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (D != DM || M <= 0 || y_f16 == nullptr || y_bf16 == nullptr) return SED_ERR_ARG;
+    hipLaunchKernelGGL(layernorm_fwd_kernel<2>, dim3(cdiv(M, 8)), dim3(256), 0, stream, x, gamma, beta, eps, in_scale,
+                       (bf16_t*)y_f16, (float*)nullptr, mean, rstd, M, 1, (bf16_t*)y_bf16);
     return sed_check_launch();
 }
 

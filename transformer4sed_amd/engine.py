@@ -99,6 +99,7 @@ class SedEngine:
         self.ln_planes = os.environ.get("SED_LN_PLANES", "8")
         self.ln_lo8 = self.ln_planes == "8"
         self.ln_planes = self.ln_planes != "0"
+        self.ln_dual = os.environ.get("SED_LN_DUAL", "1") != "0"      # bf16 copies of the saved LayerNorm outputs for the weight gradients
         # Context-network GEMMs that do not need all three split-precision terms (tools/err_sim.py SIM_DEC_TERMS=1: logit error of the whole
         # decoder 3.96e-4 with three terms everywhere): in_proj without the activation's lo part (5.4e-4; the weight's lo part is the one that
         # matters there: 1.9e-3 without it) -> two K passes instead of three on the largest decoder GEMM, and its LayerNorm writes a plain f16
@@ -399,7 +400,14 @@ class SedEngine:
                 h16, q, k, v, o16, lse, h2, hpre, act = scratch
                 mean1 = rstd1 = mean2 = rstd2 = None
             x_in = x
-            if not (fold and have_stat):
+            # Saving blocks of an f16 pass: the LayerNorm writes its result twice -- f16 for the forward GEMM, bf16 for the backward's weight
+            # gradient, which otherwise converts the saved f16 fragments in registers (17-20 % of that launch).  The f16 tensors are not kept.
+            dual = sv and f16 == 1 and self.ln_dual and not getattr(m, "lora_r", 0)      # (LoRA factors take their gradients from the f16 operand)
+            h16s = h2s = None
+            if dual:
+                h16s, h2s = E(M, D, dt=BF16), E(M, D, dt=BF16)
+                call("sed_layernorm_fwd_dual", x_in, self.P(p + "norm1.weight"), self.P(p + "norm1.bias"), 1e-6, 1.0, h16, h16s, mean1, rstd1, M, D)
+            elif not (fold and have_stat):
                 call("sed_layernorm_fwd", x_in, self.P(p + "norm1.weight"), self.P(p + "norm1.bias"), 1e-6, 1.0, h16, None,
                      mean1, rstd1, M, D, 8 if q8 else f16)
             if fold:
@@ -538,15 +546,18 @@ class SedEngine:
             x_mid = E(Bx, N, D) if sv else x_in
             gemm_nt(o16, W[p + "attn.proj.weight"].w, EPI_F32_RESID, bias=self.P(p + "attn.proj.bias"), res=x_in,
                     outF=x_mid)
-            call("sed_layernorm_fwd", x_mid, self.P(p + "norm2.weight"), self.P(p + "norm2.bias"), 1e-6, 1.0, h2, None,
-                 mean2, rstd2, M, D, f16)
+            if dual:
+                call("sed_layernorm_fwd_dual", x_mid, self.P(p + "norm2.weight"), self.P(p + "norm2.bias"), 1e-6, 1.0, h2, h2s, mean2, rstd2, M, D)
+            else:
+                call("sed_layernorm_fwd", x_mid, self.P(p + "norm2.weight"), self.P(p + "norm2.bias"), 1e-6, 1.0, h2, None,
+                     mean2, rstd2, M, D, f16)
             gemm_nt(h2, W[p + "mlp.fc1.weight"].w, EPI_GELU, bias=self.P(p + "mlp.fc1.bias"), outH=hpre if sv else None,
                     outH2=act)
             x_out = E(Bx, N, D) if sv else x_mid
             gemm_nt(act, W[p + "mlp.fc2.weight"].w, EPI_F32_RESID, bias=self.P(p + "mlp.fc2.bias"), res=x_mid,
                     outF=x_out)
             if sv:
-                L.update(x_in=x_in, h16=h16, q=q, k=k, v=v, o16=o16, lse=lse, x_mid=x_mid, h2=h2,
+                L.update(x_in=x_in, h16=h16s if dual else h16, q=q, k=k, v=v, o16=o16, lse=lse, x_mid=x_mid, h2=h2s if dual else h2,
                          hpre=hpre, act=act, mean1=mean1, rstd1=rstd1, mean2=mean2, rstd2=rstd2)
                 ctx["layers"].append(L)
             elif save:
