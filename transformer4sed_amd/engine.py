@@ -135,14 +135,16 @@ class SedEngine:
         # factors, v_mfma_scale_f32_16x16x128_f8f6f4: half of an f16 K pass; csrc/gemm.hip GemmArgs.k8).  The activations' e4m3 images come
         # out of the producing kernels (LayerNorm, attention, fc1's epilogue) in the same rows as the f16 values.  e4m3 keeps ~5 % of the lo
         # product as error, which is not free here (every posterior of the validation configuration sits within 15 % of its bound), so the
-        # default takes the two GEMMs that pay for it: qkv and fc2.  Measured on the validation step (clips/s; worst posterior of the val12
-        # fixture, bound 7e-4; depth-2 fixture at temp 0.5, bound 1e-3):  f16 138.9 / 5.96e-4 / 6.3e-4;  fc2 141.6 / 5.5e-4 / 7.6e-4;
-        # proj,fc2 143.7 / 6.3e-4 / 6.8e-4;  qkv,fc2 146.7 / 6.2e-4 / 9.2e-4 (default);  qkv,proj 145.1 / 6.9e-4 / 9.0e-4;
+        # default takes only the GEMM that pays for it with margin to spare on BOTH fixtures: fc2.  Measured on the validation step (clips/s;
+        # worst posterior of the val12 fixture, bound 7e-4; depth-2 fixture at temp 0.5, bound 1e-3):  f16 138.9 / 5.96e-4 / 6.3e-4;
+        # fc2 141.6 / 5.5e-4 / 7.6e-4 (default);  proj,fc2 143.7 / 6.3e-4 / 6.8e-4;  qkv,fc2 146.7 / 6.2e-4 / 9.2e-4 (round 5's default: 8 %
+        # under the 1e-3 specification on synthetic weights -- e4m3 flushes |x| / 4 < 2^-9 and clamps at 1792, a checkpoint with louder
+        # channels can cross it unseen, so qkv is opt-in: SED_ENC_W2=f8:qkv,fc2);  qkv,proj 145.1 / 6.9e-4 / 9.0e-4;
         # qkv,proj,fc2 146.9 / 6.8e-4 / 1.02e-3 (over the second bound: proj gains 36 us per launch and its image costs the attention as much).
         # SED_ENC_W2=f16: both products in f16 (the round-3 / round-4 form); f8:<subset of qkv,proj,fc2>: that subset.
         mode = os.environ.get("SED_ENC_W2", "f8")
         head, _, which = mode.partition(":")
-        self.w2_f8_set = frozenset(w for w in (which.split(",") if which else ("qkv", "fc2")) if w)
+        self.w2_f8_set = frozenset(w for w in (which.split(",") if which else ("fc2",)) if w)
         if head not in ("f8", "f16") or (head == "f16" and which) or not self.w2_f8_set <= {"qkv", "proj", "fc2"}:
             raise ValueError(f"SED_ENC_W2={mode!r}: expected f16, f8, or f8:<subset of qkv,proj,fc2>")
         self.w2_f8 = head == "f8"
