@@ -20,7 +20,7 @@
  * one normally gets a new suffixed name instead, like sed_median_filter_k).  History: 3 = round 3 (sed_relpos_attn_fwd gained O_split,
  * sed_relpos_attn_bwd gained Pst, both in place); 4 = round 4.  A binding compares sed_abi_version() with the header it was written
  * against before the first call (transformer4sed_amd/_lib.py does). */
-#define SED_HIP_ABI_VERSION 6
+#define SED_HIP_ABI_VERSION 7
 
 #ifdef __cplusplus
 extern "C" {
@@ -457,9 +457,56 @@ int sed_xattn_f32_fwd(const float* Q, const float* K, const float* V, float* O, 
                       int head_dim, int ldq, int ldk, int ldv, int ldo, int64_t q_batch_stride, hipStream_t stream);
 /* dual-stream finish (detect_any_sound.py:317-319, 394-404): logits [B,T,Q], at_logit [B,Q], pad_mask [B,T] (nullable) ->
  * at_out = sigmoid(at_logit) [B,Q] (nullable), strong [B,Q,T] = clamp(pad ? 0 : sigmoid(logit / temp) * at_out, 1e-7, 1),
- * weak [B,Q] = clamp(sum_t strong^2 / sum_t strong, 1e-7, 1). */
+ * weak [B,Q] = clamp(sum_t strong^2 / sum_t strong, 1e-7, 1).  at_logit == NULL with clamp_strong == 0: the closed-set classifier head for
+ * any class count, strong = pad ? 0 : sigmoid(logit / temp) without a clamp (src/models/cnn_transformer/passt_cnn.py:74-86). */
 int sed_dasm_head_fwd(const float* logits, const float* at_logit, const uint8_t* pad_mask, float temp, float* strong, float* weak,
-                      float* at_out, int B, int T, int Q, hipStream_t stream);
+                      float* at_out, int B, int T, int Q, int clamp_strong, hipStream_t stream);
+
+/* ---- DASM / AudioSet-Strong TRAINING (recipes/audioset_strong/detect_any_sound/passt/train.py:66-120 `DASMTrainer.train`,
+ * recipes/audioset_strong/base/passt_cnn/train.py:103-140 `Trainer.train`): the backward of everything above, fp32.
+ *
+ * General fp32 GEMM on v_mfma_f32_32x32x2_f32:  C[z][m][n] (+)= drop(act(sum_k A(z,m,k) B(z,n,k) + bias[n])) (+ R[z][m][n]) with
+ * A(m,k) = transA ? A[k lda + m] : A[m lda + k], B(n,k) = transB ? B[k ldb + n] : B[n ldb + k] -- the three products of a Linear under
+ * autograd (y = x W^T; dx = dy W: transB; dW += dy^T x: transA + transB + accumulate, split over the tokens by `ksplit` with fp32
+ * atomics) and the einsum('bqc,bct->bqt') of detect_any_sound.py:378 with its gradients (batched).  Any M, N, K and leading dimensions
+ * (operands that are not float4-addressable are read element-wise).  pre (nullable): the value before the activation (what the GELU
+ * backward needs).  drop_p > 0: inverted dropout after the activation, before the residual, with the counter-based bits
+ * keep(drop_seed, drop_site, (z M + m) N + n) that sed_gelu_bwd_f32 / sed_dropout_f32 re-evaluate (nn.TransformerDecoderLayer's
+ * dropout1/2/3 and FFN dropout in train mode, at_adapter.py:37-45).  accumulate != 0: C += (no epilogue terms allowed). */
+int sed_gemm_f32(const float* A, const float* B, const float* bias, const float* R, float* C, float* pre, int M, int N, int K, int lda,
+                 int ldb, int ldc, int transA, int transB, int batch, int64_t strideA, int64_t strideB, int64_t strideC, int act,
+                 int accumulate, int ksplit, float drop_p, int64_t drop_seed, int drop_site, hipStream_t stream);
+/* sed_xattn_f32_fwd for a pass whose backward follows: also writes lse [B, H, Nq] (log2 of sum_j 2^(log2(e) s_ij)) and applies
+ * attention-probability dropout (torch.nn.MultiheadAttention(dropout=p).train(): softmax -> dropout -> . v) with the bits
+ * keep(seed, site, ((b H + h) Nq + i) Nk + j). */
+int sed_xattn_f32_fwd_train(const float* Q, const float* K, const float* V, float* O, const uint8_t* mask, float* lse, int B, int H, int Nq,
+                            int Nk, int head_dim, int ldq, int ldk, int ldv, int ldo, int64_t q_batch_stride, float drop_p, int64_t drop_seed,
+                            int drop_site, hipStream_t stream);
+/* its backward: dQ [B, Nq, lddq], dK / dV [B, Nk, lddk / lddv] at column h * head_dim (overwritten, packed projections are addressed in
+ * place through the leading dimensions); O, dO [B, Nq, ldo]; Dq [B, H, Nq] scratch (dO_i . O_i). */
+int sed_xattn_f32_bwd(const float* Q, const float* K, const float* V, const float* O, const float* dO, const float* lse, float* Dq, float* dQ,
+                      float* dK, float* dV, const uint8_t* mask, int B, int H, int Nq, int Nk, int head_dim, int ldq, int ldk, int ldv, int ldo,
+                      int lddq, int lddk, int lddv, int64_t q_batch_stride, float drop_p, int64_t drop_seed, int drop_site,
+                      hipStream_t stream);
+/* backward of sed_dasm_head_fwd: d strong [B,Q,T], d weak [B,Q], d at_out [B,Q] (each nullable) -> d logits [B,T,Q], d at_logit [B,Q].
+ * at_logit == dat_logit == NULL: the closed-set head strong = sigmoid(logit / temp) for any class count (passt_cnn.py:74-86 with the 407
+ * AudioSet-Strong classes).  scratch: 3 B Q floats. */
+int sed_dasm_head_bwd(const float* logits, const float* at_logit, const uint8_t* pad_mask, float temp, const float* strong,
+                      const float* dstrong, const float* dweak, const float* dat_out, float* dlogits, float* dat_logit, float* scratch, int B,
+                      int T, int Q, int clamp_strong, hipStream_t stream);
+/* out = dy o keep / (1 - p) o gelu'(pre) over n elements (keep bits of element index i: see sed_gemm_f32) */
+int sed_gelu_bwd_f32(const float* dy, const float* pre, float* out, int64_t n, float drop_p, int64_t drop_seed, int drop_site,
+                     hipStream_t stream);
+/* out = x o keep / (1 - p) (nullable) and / or the keep bits themselves as bytes (nullable; test aid for the CPU oracle) */
+int sed_dropout_f32(const float* x, float* out, uint8_t* mask_u8, int64_t n, float drop_p, int64_t drop_seed, int drop_site,
+                    hipStream_t stream);
+/* out[c] += sum_r x[r ld + c] */
+int sed_colsum_f32(const float* x, float* out, int rows, int cols, int64_t ld, hipStream_t stream);
+/* supervised losses of src/functional/loss/__init__.py (loss_function_factory), mean over n elements, loss[0] += value (caller zeroes),
+ * grad (nullable) = d loss / d pred.  kind 0: -[(1-p)^gamma_pos t max(log p, -100) + pm^gamma_neg (1-t) max(log(1-pm), -100)],
+ * pm = max(p - margin, 0): BCELoss (0, 0, 0), AsymmetricalFocalLoss(gamma, zeta), AslLoss(rp, rn, margin); kind 1: MSELoss. */
+int sed_sup_loss(const float* pred, const float* target, float* loss, float* grad, int64_t n, int kind, float gamma_pos, float gamma_neg,
+                 float margin, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,8 @@ and dual-stream head of the reference (BASELINE.json config #5):
     clamp(1e-7, 1), linear-softmax pooling
 
 Pinned against outputs of the reference's own DASM.forward (tests/golden/dasm_head.npz, oracle/make_golden.py:gen_dasm) by
-tests/test_dasm_oracle.py."""
+tests/test_dasm_oracle.py; its gradients (torch autograd through this restatement) against the reference's own backward
+(tests/golden/dasm_head_train.npz, gen_dasm_head_train).  Train-mode dropout of the decoder layers: injected keep masks (`drops`)."""
 import math
 
 import torch
@@ -33,7 +34,17 @@ def _mlp(x, sd, name, n):
     return x
 
 
-def _mha(q_in, kv_in, sd, name, heads, mask=None):
+def _drop(x, drops, key):
+    """Inverted dropout with an INJECTED keep mask (tests: the bits the HIP kernels evaluate, dumped through sed_dropout_f32); drops =
+    {"p": p, (layer, site): keep mask}.  Sites per decoder layer as torch applies them in nn.TransformerDecoderLayer.train():
+    0 cross-attention probabilities, 1 dropout2 (cross-attention output), 2 self-attention probabilities, 3 dropout1 (self-attention
+    output), 4 FFN activation, 5 dropout3 (FFN output)."""
+    if drops is None or key not in drops:
+        return x
+    return x * drops[key].to(x.dtype).view(x.shape) / (1.0 - drops["p"])
+
+
+def _mha(q_in, kv_in, sd, name, heads, mask=None, drops=None, dkey=None):
     """torch.nn.MultiheadAttention (batch_first) forward: q_in [B, Lq, d], kv_in [B, Lk, d]; mask [Lq, Lk] bool, True = not allowed."""
     w, b = sd[name + ".in_proj_weight"], sd[name + ".in_proj_bias"]
     d = q_in.shape[-1]
@@ -48,30 +59,32 @@ def _mha(q_in, kv_in, sd, name, heads, mask=None):
     s = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
     if mask is not None:
         s = s.masked_fill(mask[None, None], float("-inf"))
-    o = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, Lq, d)
+    o = (_drop(torch.softmax(s, dim=-1), drops, dkey) @ v).transpose(1, 2).reshape(B, Lq, d)
     return _lin(o, sd, name + ".out_proj")
 
 
-def at_decoder(memory, queries, sd, n_layers, heads, tgt_mask=None):
+def at_decoder(memory, queries, sd, n_layers, heads, tgt_mask=None, drops=None):
     """at_adapter.py:24-32 (norm_first False): cross attention FIRST, then self attention among the queries, then the FFN."""
     x = queries
     for l in range(n_layers):
         p = f"at_decoder.decoder.layers.{l}"
-        x = F.layer_norm(x + _mha(x, memory, sd, p + ".multihead_attn", heads), (x.shape[-1],), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"])
-        x = F.layer_norm(x + _mha(x, x, sd, p + ".self_attn", heads, tgt_mask), (x.shape[-1],), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"])
-        ff = _lin(F.gelu(_lin(x, sd, p + ".linear1")), sd, p + ".linear2")
+        ca = _drop(_mha(x, memory, sd, p + ".multihead_attn", heads, drops=drops, dkey=(l, 0)), drops, (l, 1))
+        x = F.layer_norm(x + ca, (x.shape[-1],), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"])
+        sa = _drop(_mha(x, x, sd, p + ".self_attn", heads, tgt_mask, drops=drops, dkey=(l, 2)), drops, (l, 3))
+        x = F.layer_norm(x + sa, (x.shape[-1],), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"])
+        ff = _drop(_lin(_drop(F.gelu(_lin(x, sd, p + ".linear1")), drops, (l, 4)), sd, p + ".linear2"), drops, (l, 5))
         x = F.layer_norm(x + ff, (x.shape[-1],), sd[p + ".norm3.weight"], sd[p + ".norm3.bias"])
     return x
 
 
-def dasm_head(sd, frame_tokens, x_dec, query=None, tgt_mask=None, temp_w=0.1, pad_mask=None, n_layers=2, heads=12):
+def dasm_head(sd, frame_tokens, x_dec, query=None, tgt_mask=None, temp_w=0.1, pad_mask=None, n_layers=2, heads=12, drops=None):
     """frame_tokens [B, P, 768] = passt_out_dict['frame'].transpose(1, 2)[:, 2:, :]; x_dec [B, T, Dd] = output of the SED decoder.
     -> strong [B, Q, T], weak [B, Q], at_out [B, Q], mask_feat [B, Q, Dd]."""
     sd = {k: (v if torch.is_tensor(v) else torch.from_numpy(v)) for k, v in sd.items()}
     at_feat = _lin(frame_tokens, sd, "at_projector")                                     # :365
     q = sd["at_query"] if query is None else query
     q = F.gelu(_lin(q, sd, "query_projector.0"))                                          # :298, 138
-    mask_feat = at_decoder(at_feat, q.expand(at_feat.shape[0], -1, -1), sd, n_layers, heads, tgt_mask)   # :311-315
+    mask_feat = at_decoder(at_feat, q.expand(at_feat.shape[0], -1, -1), sd, n_layers, heads, tgt_mask, drops=drops)   # :291-295
     at_out = torch.sigmoid(_mlp(mask_feat, sd, "at_head", 2).squeeze(-1))                 # :317-319
     x = _lin(x_dec, sd, "sed_head")                                                       # :392
     emb = _mlp(mask_feat, sd, "mask_embedding_layer", 3)                                  # :393

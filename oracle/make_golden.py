@@ -1296,6 +1296,196 @@ def gen_dasm_full():
          nam_s=t2n(taps["nam"][:, ::25, ::16]), xdec_s=t2n(taps["xin"][:, ::25, ::16]), xdec_mean=t2n(taps["xin"].mean(dim=(0, 1))))
 
 
+DASMSTEP_CFG = dict(   # no YAML for this recipe exists in the reference: this fixture's configuration, values in the style of config/pmam
+    training=dict(w_AT=0.5, clip_grad=True,
+                  transform=dict(n_transform=1, choice=[1, 0, 0, 1], filter_db_range=[-26, 26], filter_bands=[2, 5],
+                                 filter_minimum_bandwidth=4, filter_type="step")),
+    class_loss=dict(loss_name="BCELoss", kwargs=None),
+    DASM=dict(train_kwargs=dict(encoder_win=False, temp_w=0.5),
+              init_kwargs=dict(at_param=dict(at_decoder_layer=2, query_projector=True, query_dim=1024, out_type="sigmoid"))),
+    # (learning rates a tenth of config/pmam's: with the synthetic weights the full rates move the frame logits by several units per step)
+    opt=dict(param_groups=dict(cnn=dict(lr=1.5e-5, weight_decay=1.0e-4), passt=dict(lr=5.0e-6, weight_decay=1.0e-4, freeze_layer=0, step_lr=0),
+                               decoder=dict(lr=1.5e-5, weight_decay=1.0e-4), head=dict(lr=2.0e-5))))
+DASMSTEP_SCHED = dict(n_epochs=30, n_epochs_cut=10, exponent=-1.5, warmup_epochs=1, warmup_rate=0.1, epoch_len=4)
+DASMSTEP_SEEDS = (41, 42, 43)
+DASMSTEP_PROBES = ["backbone.blocks.1.attn.qkv.weight", "backbone.blocks.0.mlp.fc2.weight", "backbone.patch_embed.proj.weight", "backbone.norm.weight",
+                   "backbone.norm.bias", "cnn.cnn.conv0.weight", "cnn.cnn.conv5.weight", "cnn_projector.weight", "transformer_projector.bias",
+                   "f_pool_module.f_att_token", "norm_before_pool.weight", "norm_after_merge.weight", "norm_after_merge.bias",
+                   "sed_decoder.encoder_blocks.0.attn.in_proj.weight", "sed_decoder.encoder_blocks.2.attn.linear_pos.weight",
+                   "at_projector.weight", "at_projector.bias", "query_projector.0.weight", "query_projector.0.bias", "at_query",
+                   "at_decoder.decoder.layers.0.multihead_attn.in_proj_weight", "at_decoder.decoder.layers.0.multihead_attn.in_proj_bias",
+                   "at_decoder.decoder.layers.1.multihead_attn.out_proj.weight", "at_decoder.decoder.layers.0.self_attn.in_proj_weight",
+                   "at_decoder.decoder.layers.1.self_attn.out_proj.bias", "at_decoder.decoder.layers.0.linear1.weight",
+                   "at_decoder.decoder.layers.1.linear2.weight", "at_decoder.decoder.layers.0.norm1.weight", "at_decoder.decoder.layers.1.norm3.bias",
+                   "at_head.layers.0.weight", "at_head.layers.1.weight", "at_head.layers.1.bias", "mask_embedding_layer.layers.0.weight",
+                   "mask_embedding_layer.layers.2.weight", "sed_head.weight", "sed_head.bias"]
+
+
+def build_reference_dasm(depth, n_queries=8, qdim=1024, sed_head_bias=None):
+    """The reference's DASM (src/models/detect_any_sound/detect_any_sound.py) with the synthetic weights of synth.dasm_full_state_dict_np; a
+    `depth` below 12 truncates the encoder's block list (feature layer = depth), as build_reference_pmam does.  The query decoder's
+    dropout (torch's nn.TransformerDecoderLayer default 0.1: at_adapter.py:39-45 passes none) and the CNN's are set to 0 on the instance:
+    torch's own dropout bits cannot be injected into another implementation -- the dropout path is covered oracle-vs-HIP with injected
+    bits (tests/test_gpu_dasm_train.py)."""
+    from src.models.detect_any_sound.detect_any_sound import DASM
+    cnn = dict(n_in_channel=1, activation="cg", conv_dropout=0.0, kernel_size=[3] * 10, padding=[1] * 10, stride=[1] * 10,
+               nb_filters=list(synth.PMAM_FILTERS), pooling=[list(p) for p in synth.PMAM_POOLING])
+    sd_np = synth.dasm_full_state_dict_np(n_queries=n_queries, query_dim=qdim)
+    if sed_head_bias is not None:
+        sd_np["sed_head.bias"] = sed_head_bias
+    net = DASM(cnn_param=cnn, backbone_param=dict(embed_dim=768, passt_feature_layer=min(depth, 10), pretrain_model_path=None, lora_config=None),
+               at_param=dict(at_decoder_layer=2, query_projector=True, query_dim=qdim, out_type="sigmoid",
+                             query=torch.from_numpy(sd_np["at_query"]).clone()),
+               decoder="transformerXL", decoder_layer_num=3, decoder_dim=768, num_heads=12, class_num=n_queries)
+    own = net.state_dict()
+    missing = [k for k in own if k not in sd_np and not k.startswith("mel_trans.")]
+    assert not missing and all(tuple(own[k].shape) == tuple(v.shape) for k, v in sd_np.items()), missing[:5]
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=False)
+    if depth < 12:
+        net.backbone.blocks = net.backbone.blocks[:depth]
+    for mod in net.at_decoder.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    return net
+
+
+def _dasm_trainer(net, cfg):
+    """The reference's DASMTrainer around `net` with AdamW / ExponentialDown wired as recipes/audioset_strong/setting.py:217-245 does and the
+    parameter groups of recipes/desed/finetune/cnn_trans/setting.py:get_param_lr (what the closed-set main.py of the same recipe family uses;
+    the DASM main.py imports a module that does not exist)."""
+    import logging
+    from recipes.audioset_strong.detect_any_sound.passt.train import DASMTrainer
+    from recipes.desed.finetune.cnn_trans.setting import get_param_lr
+    from src.utils.scheduler import ExponentialDown
+    groups = get_param_lr(net, cfg, logging.getLogger("golden"))
+    opt = torch.optim.AdamW(groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-8)
+    sc = DASMSTEP_SCHED
+    sch = ExponentialDown(optimizer=opt, start_iter=sc["n_epochs_cut"] * sc["epoch_len"], total_iter=sc["n_epochs"] * sc["epoch_len"],
+                          exponent=sc["exponent"], warmup_iter=sc["warmup_epochs"] * sc["epoch_len"], warmup_rate=sc["warmup_rate"])
+    scalars = []
+
+    class _TB:
+        def add_scalar(self, key, value, global_step=None):
+            scalars[-1][key.split("/", 1)[1]] = float(value)
+
+    class _Log:
+        tensorboard_writer = _TB()
+        logger = logging.getLogger("golden")
+
+    tr = DASMTrainer(optimizer=opt, my_logger=_Log(), net=net, scheduler=sch, encoder=types.SimpleNamespace(sr=16000), train_loader=None,
+                     val_loader=None, test_loader=None, config=cfg, device="cpu")
+    return tr, opt, scalars
+
+
+def gen_dasm_train():
+    """DASM TRAINING (row (g)): the reference's own `DASMTrainer.train` (recipes/audioset_strong/detect_any_sound/passt/train.py:66-120:
+    preprocess with frame_shift / mixup / FilterAugment, forward in train mode, BCE on the frame posteriors + w_AT x BCE on the tagging
+    probabilities, backward, AdamW, ExponentialDown) -- `dasmstep`: three consecutive steps at encoder depth 2, batch 3; `dasmstep12`: one
+    step at the real depth 12, batch 2.  Recorded per step: the logged loss terms, learning rates, the first 256 elements of 36 probe
+    parameters after the step; for the first step also the L2 norm of EVERY parameter's gradient (a backward hook on the optimizer step)."""
+    for tag, depth, B, steps in (("dasmstep", 2, 3, 3), ("dasmstep12", 12, 2, 1)):
+        cfg = json.loads(json.dumps(DASMSTEP_CFG))
+        net = build_reference_dasm(depth)
+        tr, opt, scalars = _dasm_trainer(net, cfg)
+        random.seed(DASMSTEP_SEEDS[0]); np.random.seed(DASMSTEP_SEEDS[1]); torch.manual_seed(DASMSTEP_SEEDS[2])
+        names = dict(net.named_parameters())
+        probes = [n for n in DASMSTEP_PROBES if n in names]
+        assert len(probes) == len(DASMSTEP_PROBES), [n for n in DASMSTEP_PROBES if n not in names]
+        out = dict(probe_names=np.array(probes), trainable=np.array([n for n, p in net.named_parameters() if p.requires_grad]))
+        gnorms = {}
+        o_step = opt.step
+
+        def step_hook(*a, **k):
+            if not gnorms:
+                for n, p in net.named_parameters():
+                    gnorms[n] = float(p.grad.norm()) if p.grad is not None else -1.0
+            return o_step(*a, **k)
+        opt.step = step_hook
+        for step in range(steps):
+            wav = torch.from_numpy(synth.synth_wav(B, seed=3100 + step))
+            labels = torch.from_numpy(synth.synth_strong_labels(B, n_classes=8, seed=700 + step))
+            tr.train_loader = [(wav, labels, None, None)]
+            scalars.append({})
+            rec = DrawRecorder()
+            with rec.recording():
+                tr.train(step)
+            for k, v in scalars[-1].items():
+                out[f"s{step}_{k}"] = np.float64(v)
+            out[f"s{step}_lrs"] = np.array([g["lr"] for g in opt.param_groups], dtype=np.float64)
+            out[f"s{step}_draw_kinds"] = np.array([k for k, _ in rec.log])
+            sp = dict(net.named_parameters())
+            for i, n in enumerate(probes):
+                out[f"s{step}_p{i}"] = t2n(sp[n]).reshape(-1)[:256].astype(np.float32).copy()
+            print(f"   {tag} step {step}: " + " ".join(f"{k}={v:.6f}" for k, v in scalars[-1].items()), flush=True)
+        out["gnorm_names"] = np.array(list(gnorms))
+        out["gnorm_values"] = np.array([gnorms[n] for n in gnorms], dtype=np.float64)
+        out["group_sizes"] = np.array([len(g["params"]) for g in opt.param_groups])
+        out["config_json"] = np.array(json.dumps(dict(cfg=DASMSTEP_CFG, sched=DASMSTEP_SCHED, seeds=DASMSTEP_SEEDS, wav_seed0=3100, label_seed0=700,
+                                                      depth=depth, B=B, steps=steps)))
+        save(tag, **out)
+
+
+def gen_dasm_head_train():
+    """Gradients of the reference's own DASM.forward in train mode (dropout 0) through query decoder + dual-stream head, on the stubbed
+    configuration of `gen_dasm` (backbone / CNN replaced by fixed feature maps, decoder 'no'): loss = sum(strong * R1) + sum(weak * R2)
+    + sum(at_out * R3) with fixed random cotangents; recorded: every head parameter's gradient norm and its first 64 elements -- the pin
+    of oracle/dasm_oracle.py under autograd (tests/test_dasm_oracle.py)."""
+    from src.models.detect_any_sound.detect_any_sound import DASM
+    from oracle import dasm_oracle
+    c = DASM_HEAD
+    B, tdim, nb, nn_, qdim = c["B"], c["tdim"], c["n_base"], c["n_novel"], c["qdim"]
+    T, P = (tdim + 1) * 10, 12 * tdim
+    tag = "dasm_head"
+    cnn = dict(n_in_channel=1, activation="cg", conv_dropout=0.5, kernel_size=[3] * 10, padding=[1] * 10, stride=[1] * 10,
+               nb_filters=list(synth.PMAM_FILTERS), pooling=[list(p) for p in synth.PMAM_POOLING])
+    sd_np = synth.dasm_state_dict_np(n_queries=nb, query_dim=qdim, at_layers=c["at_layers"])
+    net = DASM(cnn_param=cnn, backbone_param=dict(embed_dim=768, passt_feature_layer=10, pretrain_model_path=None, lora_config=None),
+               at_param=dict(at_decoder_layer=c["at_layers"], query_projector=True, query_dim=qdim, out_type="sigmoid",
+                             query=torch.from_numpy(sd_np["at_query"]).clone()),
+               decoder="no", decoder_dim=768, num_heads=12, class_num=nb)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=False)
+    for mod in net.at_decoder.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    net.train()
+    L10 = torch.from_numpy(synth.det_uniform(f"{tag}/layer10", (B, 768, P + 2), -1.5, 1.5))
+    FR = torch.from_numpy(synth.det_uniform(f"{tag}/frame", (B, 768, P + 2), -1.5, 1.5)).requires_grad_(True)
+    CF = torch.from_numpy(synth.det_uniform(f"{tag}/cnn", (B, 384, c["cnn_t"], 1), -1.0, 1.0))
+
+    class StubBackbone(torch.nn.Module):
+        def forward(self, x):
+            return {"layer10_out": L10, "frame": FR, "f_dim": 12, "t_dim": tdim}
+
+    class StubCnn(torch.nn.Module):
+        def forward(self, x):
+            return CF
+    net.backbone, net.cnn = StubBackbone(), StubCnn()
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    pad[1, T - 13:] = True
+    R1 = torch.from_numpy(synth.det_normal("dasm_head_train/r1", (B, nb, T))) / T
+    R2 = torch.from_numpy(synth.det_normal("dasm_head_train/r2", (B, nb)))
+    R3 = torch.from_numpy(synth.det_normal("dasm_head_train/r3", (B, nb)))
+    s, w, o = net(torch.zeros(B, 128, 1000), temp_w=0.5, pad_mask=pad)
+    ((s * R1).sum() + (w * R2).sum() + (o["at_out"] * R3).sum()).backward()
+    out = {}
+    head_names = [n for n, p in net.named_parameters() if n.startswith(("at_projector.", "query_projector.", "at_query", "at_decoder.", "at_head.",
+                                                                         "mask_embedding_layer.", "sed_head."))]
+    out["names"] = np.array(head_names)
+    sp = dict(net.named_parameters())
+    out["gnorm"] = np.array([float(sp[n].grad.norm()) for n in head_names], dtype=np.float64)
+    for i, n in enumerate(head_names):
+        out[f"g{i}"] = t2n(sp[n].grad).reshape(-1)[:64].astype(np.float32).copy()
+    out["dframe_s"] = t2n(FR.grad.transpose(1, 2)[:, 2:, :][:, ::7, ::16])
+    out["strong"], out["weak"], out["at_out"] = t2n(s), t2n(w), t2n(o["at_out"])
+    save("dasm_head_train", **out)
+
+
+GENS["dasm_train"] = gen_dasm_train
+GENS["dasm_head_train"] = gen_dasm_head_train
 GENS["dasm_full"] = gen_dasm_full
 GENS["dasm"] = gen_dasm
 

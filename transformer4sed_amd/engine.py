@@ -783,16 +783,24 @@ class SedEngine:
             hctx = dict(xd16=xd16, hpre=hpre, act=act)
         else:
             C = m.class_num
-            strong = E(B, C, Tdec)
-            weak = E(B, C)
-            sums = E(B, C, 2)
-            pm = None
-            if pad_mask is not None:
-                pm = h2d(pad_mask, torch.uint8, dev)      # (pinned staging: a pageable .to(device) here blocks the host until the whole forward has run)
-            call("sed_head_fwd", xd, self.P("classifier.weight"), self.P("classifier.bias"), float(temp_w), pm, strong,
-                 weak, sums, B, Tdec, C)
+            if C > NCLS_MAX or (save and C != 10):
+                # any class count (AudioSet-Strong's 407): logits on the fp32 matrix instruction + the transposing sigmoid / pooling kernel
+                # (dasm.wide_head_fwd); the dedicated kernels below serve the 10-class DESED head
+                from .dasm import wide_head_fwd
+                strong, weak, hctx = wide_head_fwd(xd.view(B * Tdec, D), self.P("classifier.weight").detach(), self.P("classifier.bias").detach(),
+                                                   temp_w, pad_mask, B, Tdec, save)
+                hctx = hctx or {}
+            else:
+                strong = E(B, C, Tdec)
+                weak = E(B, C)
+                sums = E(B, C, 2)
+                pm = None
+                if pad_mask is not None:
+                    pm = h2d(pad_mask, torch.uint8, dev)      # (pinned staging: a pageable .to(device) here blocks the host until the whole forward has run)
+                call("sed_head_fwd", xd, self.P("classifier.weight"), self.P("classifier.bias"), float(temp_w), pm, strong,
+                     weak, sums, B, Tdec, C)
+                hctx = dict(strong=strong, sums=sums, temp=float(temp_w))
             out["strong"], out["weak"] = strong, weak
-            hctx = dict(strong=strong, sums=sums, temp=float(temp_w))
         ctx = None
         if save:
             ctx = dict(B=B, T=T, tp=tp, Tdec=Tdec, ectx=ectx, dctx=dctx, actx=actx, hctx=hctx, xd=xd, W=W,
@@ -875,6 +883,9 @@ class SedEngine:
             g = E(B, Tdec, D)
             if ds is None and dw is None:
                 g.zero_()
+            elif hc.get("wide"):
+                from .dasm import wide_head_bwd
+                g = wide_head_bwd(hc, self.P("classifier.weight").detach(), ds, dw, G("classifier.weight"), G("classifier.bias")).view(B, Tdec, D)
             else:
                 ds = None if ds is None else ds.contiguous().float()
                 dw = None if dw is None else dw.contiguous().float()

@@ -169,12 +169,14 @@ class _SedFunction(torch.autograd.Function):
     backward assigns / accumulates `p.grad` itself, as views of the flat gradient arena."""
 
     @staticmethod
-    def forward(ctx, module, kw, mel, anchor):
+    def forward(ctx, module, kw, mel, anchor, *extras):
+        # (`extras`: differentiable inputs other than the parameters -- DASM's external query embeddings, dasm.py; the engine reads them from
+        #  the module, they are arguments here so that autograd routes their gradients)
         save = kw.pop("save")
         ctx.set_materialize_grads(False)
         out, ectx = module.engine.forward(mel, save=save, **kw)
         keys = [k for k in ("strong", "weak", "at_out", "mlm_pred", "frame_before_mask") if k in out]
-        ctx.module, ctx.ectx, ctx.keys = module, ectx, keys
+        ctx.module, ctx.ectx, ctx.keys, ctx.n_extras = module, ectx, keys, len(extras)
         module._last_mask_ids = out.get("mask_id_seq")
         module._out_keys = keys
         return tuple(out[k] for k in keys)
@@ -219,7 +221,10 @@ class _SedFunction(torch.autograd.Function):
         for n, p in live:
             if n in touched or (accumulate and p.grad is not None):
                 p.grad = views[n]
-        return None, None, None, None
+        eg = list(getattr(module, "_extra_input_grads", None) or [])
+        module._extra_input_grads = None
+        eg = (eg + [None] * ctx.n_extras)[:ctx.n_extras]
+        return (None, None, None, None, *eg)
 
 
 class PaSST_SED(SEDModel):
@@ -236,7 +241,6 @@ class PaSST_SED(SEDModel):
             if embed_dim != D or decoder_dim != D: unsupported.append("embed_dim/decoder_dim != 768")
             if f_pool != "mean_pool": unsupported.append(f"f_pool={f_pool!r}")
             if lora_config is not None: unsupported.append("LoRA")
-            if class_num > 16: unsupported.append("class_num > 16")
         if decoder != "transformerXL": unsupported.append(f"decoder={decoder!r}")
         if s_patchout_f or s_patchout_t: unsupported.append("patchout")
         if decoder_win_len is not None: unsupported.append("decoder_win_len")
@@ -392,7 +396,8 @@ class PaSST_SED(SEDModel):
         anchor = getattr(self, "_anchor", None)
         if anchor is None or anchor.device != input.device:
             anchor = self._anchor = torch.zeros(1, device=input.device, requires_grad=True)
-        outs = _SedFunction.apply(self, kw, input, anchor if need_grad else anchor.detach())
+        extras = [t for t in getattr(self, "_extra_inputs", ()) if need_grad]
+        outs = _SedFunction.apply(self, kw, input, anchor if need_grad else anchor.detach(), *extras)
         o = dict(zip(self._out_keys, outs))
         other = {"frame_before_mask": o["frame_before_mask"]}
         if self.mlm:

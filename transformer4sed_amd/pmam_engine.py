@@ -485,8 +485,6 @@ class PmamEngine(SedEngine):
         out = {}
         tp = 99
         dasm = getattr(m, "dasm_head", None)       # DASM (dasm.py): same trunk, LayerNorm after the merge, query decoder + dual-stream head
-        if dasm is not None and save:
-            raise NotImplementedError("DASM runs forward only (inference / open-vocabulary detection); call it under torch.no_grad()")
         pooled, frame16, ectx = self._encoder_fwd(W, mel, [0], tp, [0], save, want_frame=m.has_at or dasm is not None)
         Tdec = (tp + 1) * m.decode_ratio
         feat, cctx = self._cnn_fwd(W, mel, train=m.training, save=save, drop_masks=drop_masks)
@@ -534,10 +532,14 @@ class PmamEngine(SedEngine):
                 gemm_nt(split3(pooled.view(B * tp, D), B * tp, D), W["transformer_projector.weight"].ws, EPI_F32,
                         bias=self.P("transformer_projector.bias"), outF=P1)
             call("sed_pmam_merge", P1, P2, self.P("merge_weight"), xg, B, tp, 1, m.decode_ratio, Tc, Tdec // Tc, Dd)
-        if dasm is not None:      # norm_after_merge (detect_any_sound.py:361)
+        nam = None
+        if dasm is not None:      # norm_after_merge (detect_any_sound.py:346)
             xn = E(B, Tdec, Dd)
+            nm_, nr_ = (E(B * Tdec), E(B * Tdec)) if save else (None, None)
             call("sed_layernorm_fwd", xg.view(B * Tdec, Dd), self.P("norm_after_merge.weight"), self.P("norm_after_merge.bias"), 1e-5, 1.0,
-                 None, xn.view(B * Tdec, Dd), None, None, B * Tdec, Dd, 0)
+                 None, xn.view(B * Tdec, Dd), nm_, nr_, B * Tdec, Dd, 0)
+            if save:
+                nam = dict(x=xg, mean=nm_, rstd=nr_)
             xg = xn
         out["frame_before_mask"] = xg
         dec_in = xg
@@ -559,9 +561,12 @@ class PmamEngine(SedEngine):
             N = 2 + 12 * tp
             ft = self._frame32.view(B, N, D)[:, 2:, :].contiguous()
             m._last_x_dec = xd            # (kept for tests / inspection: the SED decoder's output that sed_head reads)
-            strong, weak, at_out, _ = dasm.forward(ft, xd, query=m._dasm_query, tgt_mask=m._dasm_tgt_mask, temp_w=float(temp_w), pad_mask=pad_mask)
-            out["strong"], out["weak"], out["at_out"] = strong, weak, at_out
-            hctx = None
+            hd = dasm.forward(ft, xd, query=m._dasm_query, tgt_mask=m._dasm_tgt_mask, temp_w=float(temp_w), pad_mask=pad_mask,
+                              query_type=m._dasm_query_type, save=save, train=bool(m.training), drop_seed=m._next_drop_seed() if (save and m.training) else 0)
+            out["strong"], out["weak"], out["at_out"] = hd[0], hd[1], hd[2]
+            hctx = hd[4] if save else None
+            if save:
+                hctx["query_grads"] = list(getattr(m, "_dasm_query_grads", ()) or ()) or None
         elif m.mlm:
             hpre = E(M, Dd, dt=BF16 if save else self.act)
             act = E(M, Dd)
@@ -578,19 +583,24 @@ class PmamEngine(SedEngine):
             # classifier + sigmoid + linear-softmax pooling (passt_cnn.py:74-86) on the 768-wide head kernel: decoder output and
             # classifier weight zero-padded from Dd to 768 columns (the dot products are unchanged)
             C = m.class_num
-            xd_pad = torch.zeros(B, Tdec, D, dtype=F32, device=dev)
-            xd_pad[:, :, :Dd] = xd
-            w_pad = torch.zeros(C, D, dtype=F32, device=dev)
-            w_pad[:, :Dd] = self.P("classifier.weight").detach()
-            strong, weak, sums = E(B, C, Tdec), E(B, C), E(B, C, 2)
-            pm = None if pad_mask is None else h2d(pad_mask, torch.uint8, dev)
-            call("sed_head_fwd", xd_pad, w_pad, self.P("classifier.bias"), float(temp_w), pm, strong, weak, sums, B, Tdec, C)
+            if C != 10:      # any class count (the 407 AudioSet-Strong classes): GEMM head, dasm.wide_head_fwd
+                from .dasm import wide_head_fwd
+                strong, weak, hctx = wide_head_fwd(xd.view(M, Dd), self.P("classifier.weight").detach(), self.P("classifier.bias").detach(), temp_w,
+                                                   pad_mask, B, Tdec, save)
+            else:
+                xd_pad = torch.zeros(B, Tdec, D, dtype=F32, device=dev)
+                xd_pad[:, :, :Dd] = xd
+                w_pad = torch.zeros(C, D, dtype=F32, device=dev)
+                w_pad[:, :Dd] = self.P("classifier.weight").detach()
+                strong, weak, sums = E(B, C, Tdec), E(B, C), E(B, C, 2)
+                pm = None if pad_mask is None else h2d(pad_mask, torch.uint8, dev)
+                call("sed_head_fwd", xd_pad, w_pad, self.P("classifier.bias"), float(temp_w), pm, strong, weak, sums, B, Tdec, C)
+                hctx = dict(strong=strong, sums=sums, temp=float(temp_w), xd_pad=xd_pad, w_pad=w_pad)
             out["strong"], out["weak"] = strong, weak
-            hctx = dict(strong=strong, sums=sums, temp=float(temp_w), xd_pad=xd_pad, w_pad=w_pad)
         ctx = None
         if save:
             ctx = dict(B=B, T=T, tp=tp, Tdec=Tdec, ectx=ectx, dctx=dctx, actx=actx, cctx=cctx, xd=xd, W=W, pooled=pooled, feat=feat, P1=P1,
-                       P2=P2, hctx=hctx, mlm_plan=plan if (plan is not None and plan["effective"]) else None, lease=lease)
+                       P2=P2, hctx=hctx, mlm_plan=plan if (plan is not None and plan["effective"]) else None, lease=lease, nam=nam)
         self._lease_ok = False
         return out, ctx
 
@@ -890,7 +900,16 @@ class PmamEngine(SedEngine):
         G = garena
         M = B * Tdec
         hc = ctx["hctx"]
-        if m.mlm:
+        dasm = getattr(m, "dasm_head", None)
+        dframe = None
+        if dasm is not None:
+            # query decoder + dual-stream head (dasm.py): gradients of the SED decoder's output and of the backbone's frame tokens
+            lowest_fwd = self._lowest_trainable_fwd(m.depth)
+            norm_train = G("backbone.norm.weight") is not None
+            dframe, g = dasm.backward(hc, grads.get("strong"), grads.get("weak"), grads.get("at_out"), G,
+                                      need_dframe=lowest_fwd < m.depth or norm_train)
+            m._extra_input_grads = [d for d, want in zip(hc.get("dquery") or [], hc.get("query_grads") or []) if want]
+        elif m.mlm:
             dpred = grads.get("mlm_pred")
             if dpred is None:
                 g = Z(B, Tdec, Dd)
@@ -901,6 +920,9 @@ class PmamEngine(SedEngine):
             ds, dw = grads.get("strong"), grads.get("weak")
             if ds is None and dw is None:
                 g = Z(B, Tdec, Dd)
+            elif hc.get("wide"):
+                from .dasm import wide_head_bwd
+                g = wide_head_bwd(hc, self.P("classifier.weight").detach(), ds, dw, G("classifier.weight"), G("classifier.bias")).view(B, Tdec, Dd)
             else:
                 ds = None if ds is None else ds.contiguous().float()
                 dw = None if dw is None else dw.contiguous().float()
@@ -930,6 +952,12 @@ class PmamEngine(SedEngine):
         dfbm = grads.get("frame_before_mask")
         if dfbm is not None:
             g = g + dfbm.contiguous().float()
+        if ctx.get("nam") is not None:      # norm_after_merge (DASM)
+            nam = ctx["nam"]
+            gm = E(B, Tdec, Dd)
+            call("sed_layernorm_bwd", g.contiguous().view(M, Dd), nam["x"].view(M, Dd), nam["mean"], nam["rstd"], self.P("norm_after_merge.weight"), 1.0,
+                 gm.view(M, Dd), 0, G("norm_after_merge.weight"), G("norm_after_merge.bias"), M, Dd)
+            g = gm
         # projector merge and the two projections
         Tc = ctx["cctx"]["Tc"]
         dP1, dP2 = E(B * tp, Dd), E(B * Tc, Dd)
@@ -959,6 +987,15 @@ class PmamEngine(SedEngine):
         m._at_grad_seen = m.has_at and grads.get("at_out") is not None
         if m._at_grad_seen:
             genc = self._at_bwd(W, ctx["actx"], ectx, grads["at_out"].contiguous().float(), G, need_dx=need_dx)
+        if dframe is not None:
+            # DASM: the tagging stream reads the final-norm patch tokens (detect_any_sound.py:350): through backbone.norm into the top of the stack
+            dfull = Z(B, N, D)
+            dfull[:, 2:, :] = dframe
+            genc = E(B, N, D)
+            call("sed_layernorm_bwd", dfull.view(B * N, D), ectx["x_final"], ectx["fmean"], ectx["frstd"], self.P("backbone.norm.weight"), 1.0,
+                 genc.view(B * N, D), 0, G("backbone.norm.weight"), G("backbone.norm.bias"), B * N, D)
+            if not need_dx:
+                genc = None
         gpool = self._fpool_bwd(W, ectx, dpooled, B, tp, G)
         if hook is not None:
             hook("heads")
