@@ -524,7 +524,7 @@ class DASM(PaSST_CNN):
         self.merge_weight.requires_grad_(False)    # (detect_any_sound.py:73: trainable only with an mlm_dict)
         self.dasm_head = DasmHead(self._head_param, self.at_layers, num_heads, decoder_dim, dropout=self.at_dropout)
         self.dasm_head.generation = self._head_generation
-        self._dasm_query = self._dasm_tgt_mask = self._dasm_query_type = None
+        self.__dict__["_dasm_call"] = dict(query=None, tgt_mask=None, query_type=None)      # (plain dict: a ParameterList here must not become a child module)
         self._dasm_external_query = False
         self._drop_gen = None
         self._register_state_dict_hook(DASM._sd_rename_out)
@@ -592,7 +592,7 @@ class DASM(PaSST_CNN):
                 raise AttributeError("DASM was built without at_param['query']: pass `query=` (the reference fails the same way, detect_any_sound.py:267)")
             query = self.at_query if isinstance(self.at_query, nn.ParameterList) else None      # (None: DasmHead reads the single `at_query`)
         self.dasm_head.dropout = float(self.at_dropout)
-        self._dasm_query, self._dasm_tgt_mask, self._dasm_query_type = query, tgt_mask, query_type
+        self.__dict__["_dasm_call"] = dict(query=query, tgt_mask=tgt_mask, query_type=query_type)
         # external query embeddings that are part of an autograd graph (the open-vocabulary trainer hands over rows of `at_query`,
         # open_vocabulary.py:20-31; a text tower being trained would too) are inputs of the model's autograd node: their gradient is returned
         ext = [] if not self._dasm_external_query else (list(query) if isinstance(query, (list, tuple)) else [query])
@@ -601,7 +601,7 @@ class DASM(PaSST_CNN):
         try:
             return super().forward(input, encoder_win=encoder_win, mix_rate=mix_rate, win_param=win_param, temp_w=temp_w, pad_mask=pad_mask)
         finally:
-            self._dasm_query = self._dasm_tgt_mask = self._dasm_query_type = None
+            self.__dict__["_dasm_call"] = dict(query=None, tgt_mask=None, query_type=None)
             self._extra_inputs = []
 
     def get_model_name(self):

@@ -561,8 +561,9 @@ class PmamEngine(SedEngine):
             N = 2 + 12 * tp
             ft = self._frame32.view(B, N, D)[:, 2:, :].contiguous()
             m._last_x_dec = xd            # (kept for tests / inspection: the SED decoder's output that sed_head reads)
-            hd = dasm.forward(ft, xd, query=m._dasm_query, tgt_mask=m._dasm_tgt_mask, temp_w=float(temp_w), pad_mask=pad_mask,
-                              query_type=m._dasm_query_type, save=save, train=bool(m.training), drop_seed=m._next_drop_seed() if (save and m.training) else 0)
+            dc = m.__dict__["_dasm_call"]
+            hd = dasm.forward(ft, xd, query=dc["query"], tgt_mask=dc["tgt_mask"], temp_w=float(temp_w), pad_mask=pad_mask,
+                              query_type=dc["query_type"], save=save, train=bool(m.training), drop_seed=m._next_drop_seed() if (save and m.training) else 0)
             out["strong"], out["weak"], out["at_out"] = hd[0], hd[1], hd[2]
             hctx = hd[4] if save else None
             if save:
