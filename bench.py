@@ -84,13 +84,29 @@ PMAM = {
                              "passt": {"lr": 5.0e-6, "weight_decay": 1, "freeze_layer": 8, "step_lr": 0},
                              "decoder": {"lr": 1.5e-4, "weight_decay": 1.0e-4}, "head": {"lr": 2.0e-4}}},
 }
-MODE_CFG = {"finetune2": FINETUNE2, "val": FINETUNE2, "finetune1": FINETUNE1, "pretrain": PRETRAIN, "pmam": PMAM, "dasm": PMAM}
+# DASM training (recipes/audioset_strong/detect_any_sound/passt/train.py:66-120).  The reference ships no YAML for this recipe (and its
+# main.py imports a module that does not exist): values in the style of config/pmam -- BCE on both streams, w_AT 0.5, temperature 0.5, the
+# FilterAugment / frequency-warp transform of the other recipes, PMAM's learning rates with the whole encoder trainable.
+DASM_TRAIN = {
+    "training": {"w_AT": 0.5, "clip_grad": True,
+                 "scheduler": {"n_epochs": 30, "n_epochs_cut": 10, "exponent": -1.5, "lr_warmup_rate": 0.1, "lr_warmup_epochs": 0},
+                 "transform": {"n_transform": 1, "choice": [1, 0, 0, 1], "filter_db_range": [-26, 26], "filter_bands": [2, 5],
+                               "filter_minimum_bandwidth": 4, "filter_type": "step"}},
+    "class_loss": {"loss_name": "BCELoss", "kwargs": None},
+    "DASM": {"train_kwargs": {"encoder_win": False, "temp_w": 0.5}},
+    "opt": {"param_groups": {"cnn": {"lr": 1.5e-4, "weight_decay": 1.0e-4}, "passt": {"lr": 5.0e-6, "weight_decay": 1.0e-4, "freeze_layer": 0, "step_lr": 0},
+                             "decoder": {"lr": 1.5e-4, "weight_decay": 1.0e-4}, "head": {"lr": 2.0e-4}}},
+}
+MODE_CFG = {"finetune2": FINETUNE2, "val": FINETUNE2, "finetune1": FINETUNE1, "pretrain": PRETRAIN, "pmam": PMAM, "dasm": PMAM, "dasm_train": DASM_TRAIN}
 MODE_GFLOP = {"finetune2": (2463.16, 21.22), "finetune1": (649.13, 14.15), "pretrain": (383.68, 14.15), "val": (2 * 2264.3, 2 * 7.07),
               # PMAM post-pretrain step: FlopCounterMode on the reference's own PaSST_CNN (depth 12, LoRA r = 8, freeze_layer 8, forward + loss +
               # backward) at B = 1, 2 -- oracle/make_golden.py gen_pmamflops.  (The reference never forms the full dW of a LoRA layer; this
               # build does, as an intermediate of dA / dB: those FLOPs are not credited.)
               "pmam": (433.06, 3.54),
-              "dasm": (None, None)}       # (no FlopCounter figure of the reference's DASM was recorded)
+              "dasm": (None, None),       # (no FlopCounter figure of the reference's DASM inference was recorded)
+              # DASM train step: FlopCounterMode on the reference's own DASM (depth 12, everything trainable, the 407 AudioSet-Strong classes
+              # as learned queries, forward + BCE losses + backward) at B = 1, 2 -- oracle/make_golden.py gen_dasmflops
+              "dasm_train": (961.73, 16.07)}
 GFLOP_PER_CLIP = 2463.16      # finetune2 step, algorithmic GEMM+conv FLOPs per clip of the REFERENCE's schedule (a-term)
 GFLOP_PER_BATCH = 21.22       # batch-shared linear_pos GEMMs (b-term)
 # What this build does not execute: the teacher's 11 sliding windows stop after the tapped block 10 (blocks 11-12 of a window feed
@@ -191,6 +207,37 @@ def build_dasm(depth, device, n_queries):
     return net, q.to(device), mask.to(device)
 
 
+def build_dasm_train(depth, device, n_classes):
+    """DASM + DasmTrainer for the closed-vocabulary training recipe: every class a learned query (`at_query`), whole model trainable, fused
+    AdamW over the parameter groups of recipes/desed/finetune/cnn_trans/setting.py:get_param_lr (what the recipe family's main.py uses)."""
+    from transformer4sed_amd import synth
+    from transformer4sed_amd.dasm import DASM
+    from transformer4sed_amd.dasm_trainer import DasmTrainer
+    from transformer4sed_amd.pmam_trainer import get_param_lr
+    from transformer4sed_amd.scheduler import ExponentialDown
+    from transformer4sed_amd.trainer import FusedAdamWEMA
+    cfg = json.loads(json.dumps(DASM_TRAIN))
+    cnn = {"n_in_channel": 1, "activation": "cg", "conv_dropout": 0.5, "kernel_size": [3] * 10, "padding": [1] * 10, "stride": [1] * 10,
+           "nb_filters": list(synth.PMAM_FILTERS), "pooling": [list(p) for p in synth.PMAM_POOLING]}
+    sd = synth.dasm_full_state_dict_np(n_queries=n_classes, query_dim=1024)
+    net = DASM(cnn_param=cnn, backbone_param={"embed_dim": 768, "passt_feature_layer": min(10, depth), "pretrain_model_path": None, "lora_config": None},
+               at_param={"at_decoder_layer": 2, "query_projector": True, "query_dim": 1024, "out_type": "sigmoid",
+                         "query": torch.from_numpy(np.asarray(sd["at_query"])).clone()},
+               decoder="transformerXL", decoder_layer_num=3, decoder_dim=768, num_heads=12, class_num=n_classes, _encoder_depth=depth)
+    # synthetic sed_head of a fifth the synthetic size (as the training fixtures, oracle/make_golden.py gen_dasm_train): frame logits of order 1
+    sd["sed_head.weight"] = np.asarray(sd["sed_head.weight"]) * np.float32(0.2)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=False)
+    net = net.to(device)
+    groups = get_param_lr(net, cfg["opt"]["param_groups"])
+    opt = FusedAdamWEMA(net, groups, ema_net=None, betas=(0.9, 0.999), eps=1e-8)
+    sc = cfg["training"]["scheduler"]
+    epoch_len = 1000
+    sched = ExponentialDown(opt, start_iter=sc["n_epochs_cut"] * epoch_len, total_iter=sc["n_epochs"] * epoch_len, exponent=sc["exponent"],
+                            warmup_iter=sc["lr_warmup_epochs"] * epoch_len, warmup_rate=sc["lr_warmup_rate"])
+    net.train()
+    return net, opt, DasmTrainer(net, opt, sched, cfg, sr=16000)
+
+
 def cpu_baseline(depth, batch=4, budget_s=330):
     """Oracle (torch CPU fp32) timed on the host cores in a child process with a hard time budget: the full finetune2 step
     (train-mode frontend, full augmentation, student fwd+bwd, 11-window teacher fwd, losses, AdamW, EMA) at batch `batch`,
@@ -288,16 +335,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default 32; 24 for --mode pmam, the reference's batch)")
     ap.add_argument("--depth", type=int, default=12)
-    ap.add_argument("--mode", default="finetune2", choices=["finetune2", "finetune1", "pretrain", "val", "pmam", "pipe", "dasm"],
+    ap.add_argument("--mode", default="finetune2", choices=["finetune2", "finetune1", "pretrain", "val", "pmam", "pipe", "dasm", "dasm_train"],
                     help="finetune2 = the headline train step (default); finetune1 / pretrain = the other two training stages of "
                          "the MAT-SED recipe; val = Trainer.validation's per-batch body (student + teacher, 17 sliding windows, "
                          "score tables + event decoding), SURVEY 8(f) rank 1; pmam = the PMAM post-pretrain step (PaSST_CNN, SURVEY 8(f) rank 3)")
     ap.add_argument("--pipe-step", default="finetune2", choices=["finetune2", "pretrain"],
                     help="--mode pipe: which train step consumes the file stream (synthetic 16 kHz RIFF files -> data.WavBatchStream -> "
                          "device resampler -> step); the line reports end-to-end clips/s beside the resident-input rate of the same process")
-    ap.add_argument("--dasm-queries", type=int, default=64,
+    ap.add_argument("--dasm-queries", type=int, default=None,
                     help="--mode dasm: number of query embeddings per call (half of them 'base' queries, half novel ones behind the "
-                         "open-vocabulary attention mask); 407 = every AudioSet-strong class")
+                         "open-vocabulary attention mask; default 64); --mode dasm_train: number of classes = learned queries "
+                         "(default 407 = every AudioSet-strong class, the configuration the step's FLOP figure was counted on)")
     ap.add_argument("--pipe-workers", type=int, default=2)
     ap.add_argument("--pipe-depth", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -372,8 +420,15 @@ def main():
     import random
     random.seed(1000 + rank); np.random.seed(1000 + rank); torch.manual_seed(1000 + rank)
 
-    B = a.batch or (24 if a.mode in ("pmam", "dasm") else 32)
-    if a.mode == "dasm":
+    if a.dasm_queries is None:
+        a.dasm_queries = 407 if a.mode == "dasm_train" else 64
+    B = a.batch or (24 if a.mode in ("pmam", "dasm", "dasm_train") else 32)
+    if a.mode == "dasm_train":
+        if a.depth != 12:
+            raise SystemExit("--mode dasm_train runs the reference's depth (12): DASM builds its PaSST with depth 12 (detect_any_sound.py:213)")
+        net, opt, trainer = build_dasm_train(a.depth, dev, a.dasm_queries)
+        ema_net = None
+    elif a.mode == "dasm":
         net, dasm_q, dasm_mask = build_dasm(a.depth, dev, a.dasm_queries)
         ema_net = opt = trainer = None
     elif a.mode == "pmam":
@@ -387,11 +442,15 @@ def main():
     un = B - sn - wn
     if trainer is not None:
         trainer.cfg = json.loads(json.dumps(MODE_CFG[a.mode]))
-    if a.mode not in ("pretrain", "pmam", "dasm"):
+    if a.mode == "dasm_train":
+        trainer.config = trainer.cfg
+    if a.mode not in ("pretrain", "pmam", "dasm", "dasm_train"):
         trainer.cfg["training"]["batch_size"] = [sn, 0, wn, un]
     wav = torch.from_numpy(synth.synth_wav(B, seed=1000 + rank)).to(dev)
     if a.mode == "pmam":   # frame-wise pseudo labels over the 30 GMM prototypes (FrameWiseLabeledDataset, pmam/setting.py:47-70)
         labels = torch.from_numpy(synth.synth_strong_labels(B, n_classes=30, seed=1000 + rank)).to(dev)
+    elif a.mode == "dasm_train":   # strong labels over the query classes (StronglyLabeledDataset, recipes/audioset_strong/setting.py:161-166)
+        labels = torch.from_numpy(synth.synth_strong_labels(B, n_classes=a.dasm_queries, seed=1000 + rank)).to(dev)
     else:
         labels = torch.from_numpy(synth.synth_batch_labels(sn, wn, un, seed=1000 + rank)).to(dev)
     if (world > 1 or force_ddp) and trainer is not None:
@@ -432,7 +491,7 @@ def main():
         def step(w=None):
             out = trainer.pretrain_step(wav if w is None else w)
             return {"loss_total": out["loss"]}
-    elif a.mode == "pmam":
+    elif a.mode in ("pmam", "dasm_train"):
         def step(w=None):
             return trainer.step(wav, labels.clone())
     else:
@@ -445,7 +504,7 @@ def main():
         torch.cuda.set_sync_debug_mode(1)
     # HIP events bracket every GEMM launch of the FIRST timed step only: the event packets cost ~8 us of stream time per launch
     # (2.5 ms on a 138 ms step when every step is instrumented), which would otherwise be charged to `value`
-    timer = None if a.no_kernel_timer else ops.KernelTimer(GEMM_KERNELS + list(ops.HBM_KERNELS) + (["sed_gemm_f32_nt", "sed_xattn_f32_fwd"] if a.mode == "dasm" else []))
+    timer = None if a.no_kernel_timer else ops.KernelTimer(GEMM_KERNELS + list(ops.HBM_KERNELS) + (["sed_gemm_f32", "sed_xattn_f32_fwd", "sed_xattn_f32_fwd_train", "sed_xattn_f32_bwd"] if a.mode in ("dasm", "dasm_train") else []))
     timed_steps_with_events = 1
     if timer is not None:       # one untimed instrumented step creates the event objects; the timed step reuses them
         ops.TIMER = timer
@@ -505,13 +564,16 @@ def main():
     clips = a.steps * B * world
     value = clips / dt
     gflop_clip, gflop_batch = MODE_GFLOP[a.mode]
+    if a.mode == "dasm_train" and a.dasm_queries != 407:
+        gflop_clip = gflop_batch = None      # (the reference's FLOPs were counted with 407 queries)
     line = {
         "metric": {"finetune2": "clips/sec (10 s clips) MAT-SED finetune2 train step",
                    "finetune1": "clips/sec (10 s clips) MAT-SED finetune1 train step",
                    "pretrain": "clips/sec (10 s clips) MAT-SED masked-reconstruction pretrain step",
                    "val": "clips/sec (10 s clips) MAT-SED validation step (student + teacher, 17 windows, score tables + events)",
                    "pmam": "clips/sec (10 s clips) PMAM post-pretrain step (PaSST_CNN: LoRA encoder + CNN branch, prototype BCE)",
-                   "dasm": "clips/sec (10 s clips) DASM open-vocabulary inference (frontend + PaSST + CNN + SED decoder + query decoder + dual-stream head)"}[a.mode],
+                   "dasm": "clips/sec (10 s clips) DASM open-vocabulary inference (frontend + PaSST + CNN + SED decoder + query decoder + dual-stream head)",
+                   "dasm_train": "clips/sec (10 s clips) DASM train step (DASMTrainer.train: frontend + augmentation, forward, BCE on frame posteriors + tagging, backward, AdamW)"}[a.mode],
         "value": round(value, 3), "unit": "clips/s",
         "n_gpus": world, "ranks": dist.get_world_size() if dist.is_initialized() else 1,
         "collective_backend": (dist.get_backend() if dist.is_initialized() else None), "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1000 * dt / a.steps, 3),
@@ -564,12 +626,15 @@ def main():
              "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "peak_GB/s": PEAK_HBM_GBS,
              "frac_of_8TB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
             for k, v in summ_all.items() if k in what and v["ms"] > 0]
-        if a.mode == "dasm" and "sed_gemm_f32_nt" in summ_all:
-            v, x = summ_all["sed_gemm_f32_nt"], summ_all.get("sed_xattn_f32_fwd", {"ms": 0.0, "launches": 0})
-            line["roofline_f32"] = {"kernel": "gemm_f32_nt_kernel (query decoder / head linears, folded memory projection, per-clip einsum) on v_mfma_f32_32x32x2_f32",
+        if a.mode in ("dasm", "dasm_train") and "sed_gemm_f32" in summ_all:
+            v = summ_all["sed_gemm_f32"]
+            xs_ = [summ_all[k] for k in ("sed_xattn_f32_fwd", "sed_xattn_f32_fwd_train", "sed_xattn_f32_bwd") if k in summ_all]
+            x = {"ms": sum(t["ms"] for t in xs_), "launches": sum(t["launches"] for t in xs_), "flops": sum(t["flops"] for t in xs_)}
+            line["roofline_f32"] = {"kernel": "gemm_f32_kernel (query decoder / head linears and their dX / dW products, folded memory projection, per-clip einsum) on v_mfma_f32_32x32x2_f32",
                                     "bound": "mfma", "achieved": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
                                     "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / 157.3, 4), "launches": v["launches"], "ms": round(v["ms"], 3),
                                     "xattn_f32_ms": round(x["ms"], 3), "xattn_f32_launches": x["launches"],
+                                    "xattn_f32_TFLOP/s": round(x["flops"] / (x["ms"] * 1e-3) / 1e12, 2) if x["ms"] > 0 else None,
                                     "note": "fp32-input MFMA peak = the fp32 vector peak (MI355X_MICROARCH.md); exact fp32 products and accumulation"}
         ms = sum(v["ms"] for v in summ.values())
         fl = sum(v["flops"] for v in summ.values())
@@ -635,6 +700,14 @@ def main():
         line["config"]["model"] = "DASM depth 12 (PaSST + CNN + Transformer-XL + query decoder, 119.7 M params), synthetic weights and query embeddings"
         line["config"].pop("final_loss", None)
         line["dtype"] = "f16 MFMA operands in the encoder / SED decoder (split precision there), fp32 (fp32-input MFMA) in the query decoder and head"
+    if a.mode == "dasm_train":
+        line["config"]["workload"] = (f"DASM train step (recipes/audioset_strong/detect_any_sound/passt/train.py:66-120): train-mode frontend, frame_shift / "
+                                      f"mixup / FilterAugment, PaSST depth 12 + CNN branch + Transformer-XL SED decoder + 2-layer query decoder (dropout 0.1) over "
+                                      f"the 1188 patch tokens with {a.dasm_queries} learned class queries, BCE on [B, {a.dasm_queries}, 1000] frame posteriors + 0.5 x "
+                                      f"BCE on the tagging probabilities, backward through everything (whole model trainable), fused AdamW")
+        line["config"]["model"] = "DASM depth 12 (PaSST + CNN + Transformer-XL + query decoder), synthetic weights and query embeddings"
+        line["dtype"] = ("f16 fwd / bf16 bwd MFMA operands in the encoder / CNN / SED decoder (split precision there), fp32 (fp32-input MFMA) forward "
+                         "and backward in the query decoder and dual-stream head")
     if a.mode == "val":
         line["config"]["workload"] = ("MAT-SED validation batch (recipes/desed/finetune/train.py:296-366): eval frontend, student and "
                                       "EMA teacher forward with val_kwargs (17 windows of 512 frames, step 31, temp 0.5), soft-masked "

@@ -1503,6 +1503,30 @@ def gen_dasm_head_train():
     save("dasm_head_train", **out)
 
 
+def gen_dasmflops():
+    """Algorithmic GEMM + conv FLOPs of one DASM train step of the REFERENCE (what `bench.py --mode dasm_train` prices its step at):
+    torch.utils.flop_counter.FlopCounterMode around forward + BCE losses + backward of the reference's own DASM at depth 12, everything
+    trainable, with the 407 AudioSet-Strong classes as learned queries, at B = 1 and B = 2 -> F(B) = a + b / B per clip as BASELINE.md
+    section 2 does for the MAT-SED steps.  Prints the two coefficients (kept as constants in bench.py)."""
+    from torch.utils.flop_counter import FlopCounterMode
+    tot = {}
+    for B in (1, 2):
+        net = build_reference_dasm(12, n_queries=407)
+        net.train()
+        mel = torch.from_numpy(synth.det_uniform("dasmflops/mel", (B, 128, 1000), -1.2, 1.2))
+        lab = torch.zeros(B, 407, 1000)
+        with FlopCounterMode(display=False) as fc:
+            s, w, o = net(mel, encoder_win=False, temp_w=0.5)
+            loss = torch.nn.functional.binary_cross_entropy(s, lab) + 0.5 * torch.nn.functional.binary_cross_entropy(o["at_out"], lab[:, :, 0])
+            loss.backward()
+        tot[B] = fc.get_total_flops() / 1e9
+        print(f"   B={B}: {tot[B]:.2f} GFLOP per step, {tot[B] / B:.2f} per clip", flush=True)
+    b = 2 * (tot[1] - tot[2] / 2)
+    a = tot[1] - b
+    print(f"   DASM train step (407 queries): a = {a:.2f} GFLOP/clip, b = {b:.2f} GFLOP/batch")
+
+
+GENS["dasmflops"] = gen_dasmflops
 GENS["dasm_train"] = gen_dasm_train
 GENS["dasm_head_train"] = gen_dasm_head_train
 GENS["dasm_full"] = gen_dasm_full

@@ -237,6 +237,12 @@ def _trainer_worker(rank, world, port, kind, q):
             labels = torch.from_numpy(synth.synth_batch_labels(2, 2, 2, seed=60 + rank)).to(dev)
             step = lambda wav: trainer.finetune_step(wav, labels.clone())
             assert trainer.overlap_teacher      # the teacher's windows run on the second stream (and the dW GEMMs on the side stream)
+        elif kind == "dasm":      # DASMTrainer.train (row (g)): query decoder + dual-stream head gradients ride the "decoder" stage
+            B = 3
+            net, opt, trainer = bench.build_dasm_train(DEPTH, dev, 12)
+            ema_net = None
+            labels = torch.from_numpy(synth.synth_strong_labels(B, n_classes=12, seed=60 + rank)).to(dev)
+            step = lambda wav: trainer.step(wav, labels.clone())
         else:
             B = 4
             net, opt, trainer = bench.build_pmam(DEPTH, dev)
@@ -282,7 +288,7 @@ def _trainer_worker(rank, world, port, kind, q):
         raise
 
 
-@pytest.mark.parametrize("kind", ["matsed", "pmam"])
+@pytest.mark.parametrize("kind", ["matsed", "pmam", "dasm"])
 def test_two_rank_trainer_steps_keep_replicas_identical(kind):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")

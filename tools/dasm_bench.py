@@ -18,7 +18,7 @@ sd = synth.dasm_state_dict_np(n_queries=8, query_dim=1024, at_layers=2)
 head = DasmHead({k: torch.from_numpy(v).to(dev) for k, v in sd.items()}, 2)
 frame = torch.randn(B, 1188, 768, device=dev)
 x_dec = torch.randn(B, 1000, 768, device=dev)
-names = ["sed_gemm_f32_nt", "sed_gemm_nt", "sed_split3_f16", "sed_xattn_f32_fwd", "sed_layernorm_fwd", "sed_dasm_head_fwd"]
+names = ["sed_gemm_f32", "sed_gemm_nt", "sed_split3_f16", "sed_xattn_f32_fwd", "sed_layernorm_fwd", "sed_dasm_head_fwd"]
 for Q in QS:
     q = torch.nn.functional.normalize(torch.randn(Q, 1024, device=dev), dim=-1)
     mask = torch.ones(Q, Q, dtype=torch.bool)
@@ -45,4 +45,4 @@ for Q in QS:
     fl = 2.0 * Q * 1024 * Dd + L * 2.0 * B * Q * Dd * Dd * 8 + 2.0 * B * Q * Dd * Dd * 4 + 2.0 * B * Q * Dd \
         + 2.0 * B * T * Dd * Dd + 2.0 * B * T * Q * Dd
     print(f"B={B} Q={Q:4d}  head forward {ms:7.3f} ms   " + "  ".join(f"{k.replace('sed_', '')} x{v[0]} {v[1]:.3f} ms" for k, v in per.items())
-          + f"   fp32 GEMMs {fl / 1e9:.1f} GFLOP -> {fl / (per['sed_gemm_f32_nt'][1] * 1e-3) / 1e12:.1f} TFLOP/s (fp32-MFMA peak 157.3)")
+          + f"   fp32 GEMMs {fl / 1e9:.1f} GFLOP -> {fl / (per['sed_gemm_f32'][1] * 1e-3) / 1e12:.1f} TFLOP/s (fp32-MFMA peak 157.3)")

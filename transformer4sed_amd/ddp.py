@@ -20,7 +20,10 @@ def stage_of(name, depth):
         return ("block", int(re.match(r"backbone\.blocks\.(\d+)\.", name).group(1)))
     if name.startswith("decoder.") or name.startswith("classifier.") or name.startswith("mlm_mlp") or name == "mask_token":
         return "decoder"
-    if name.startswith("at_adpater") or name.startswith("out_norm") or name.startswith("backbone.norm"):
+    # DASM (dasm.py): the query decoder / dual-stream head run their whole backward before the SED decoder's -- final at the "decoder" hook
+    if name.startswith(("at_decoder.", "at_head.", "at_projector.", "at_query", "query_projector.", "mask_embedding_layer.", "sed_head.")):
+        return "decoder"
+    if name.startswith("at_adpater") or name.startswith("out_norm") or name.startswith("backbone.norm") or name.startswith("norm_after_merge"):
         return "heads"
     return "embed"
 

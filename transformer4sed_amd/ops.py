@@ -169,6 +169,14 @@ def _flops_of(name, args):
         return 2.0 * args[3] * args[4] * args[5]
     if name == "sed_gemm_f32_nt":                # (A, B, bias, R, C, M, N, K, lda, ldb, ldc, batch, ...): fp32-input MFMA, its own roofline
         return 2.0 * args[5] * args[6] * args[7] * args[11]
+    if name == "sed_gemm_f32":                   # (A, B, bias, R, C, pre, M, N, K, lda, ldb, ldc, transA, transB, batch, ...)
+        return 2.0 * args[6] * args[7] * args[8] * args[14]
+    if name in ("sed_xattn_f32_fwd", "sed_xattn_f32_fwd_train", "sed_xattn_f32_bwd"):
+        # (Q, K, V, O, mask, [lse,] B, H, Nq, Nk, head_dim, ...): 2 products forward, 5 backward (S, dP, dQ, dK, dV) -- the backward's two
+        # launches recompute S and dP once more each: 7 issued, 5 algorithmic
+        o = {"sed_xattn_f32_fwd": 5, "sed_xattn_f32_fwd_train": 6, "sed_xattn_f32_bwd": 11}[name]
+        B, H, Nq, Nk, dh = args[o:o + 5]
+        return (10.0 if name.endswith("bwd") else 4.0) * B * H * Nq * Nk * dh
     return 0.0
 
 
