@@ -273,7 +273,10 @@ def test_dasm_head_forward_backward_vs_oracle_autograd(B, P, T, Q, pdrop, extern
         worst[k] = relerr(grads[k], v.grad)
     worst["frame_tokens"] = relerr(dframe, fr.grad)
     worst["x_dec"] = relerr(dxdec, xd.grad)
-    bad = {k: f"{e:.2e}" for k, e in worst.items() if e > 2e-4}
+    # fp32 throughout: 2e-4.  At the real size the memory-side projection pair (B P x 2 L Dd x 768) runs its backward on the 16-bit matrix
+    # pipe with bf16 gradient operands like the trunk's weight / input gradients: 3e-3 for what comes out of it
+    bf = ("at_projector.", "frame_tokens") if B * P >= 1024 else ()
+    bad = {k: f"{e:.2e}" for k, e in worst.items() if e > (3e-3 if (k.startswith(bf) or (bf and "multihead_attn.in_proj" in k)) else 2e-4)}
     print("DASM head backward, worst relative gradient errors:", sorted(((e, k) for k, e in worst.items()), reverse=True)[:5])
     assert not bad, bad
 

@@ -35,15 +35,21 @@
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // counter-based dropout bits: keep(seed, site, element index) -- the forward and the backward kernels of one dropout site evaluate the same
-// function (no mask tensor is stored), `sed_dropout_mask_u8` dumps it for the tests' CPU oracle.  splitmix64 finaliser, top 24 bits.
-__device__ __forceinline__ bool drop_keep(unsigned long long seed, unsigned sid, unsigned long long idx, unsigned thr24) {
-    unsigned long long z = idx + (seed ^ ((unsigned long long)sid << 48)) * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull * (sid + 1u);
+// function (no mask tensor is stored), `sed_dropout_f32` dumps it for the tests' CPU oracle.  One splitmix64 finaliser serves FOUR
+// consecutive elements (its four 16-bit fields against a 16-bit threshold: p to 1.5e-5): the attention kernels hold four consecutive keys
+// in four consecutive accumulator registers, so a lane hashes once per register quad (the per-element hash was ~150 issue cycles beside
+// the 64 of the MFMA it sits next to).
+__device__ __forceinline__ unsigned long long drop_hash4(unsigned long long seed, unsigned sid, unsigned long long idx4) {
+    unsigned long long z = idx4 + (seed ^ ((unsigned long long)sid << 48)) * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull * (sid + 1u);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (unsigned)(z >> 40) >= thr24;
+    return z ^ (z >> 31);
 }
-static inline unsigned drop_thr24(float p) { return p <= 0.f ? 0u : (unsigned)(p * 16777216.0f + 0.5f); }
+__device__ __forceinline__ bool drop_keep_of(unsigned long long z, unsigned lane4, unsigned thr16) { return ((unsigned)(z >> (16u * lane4)) & 0xffffu) >= thr16; }
+__device__ __forceinline__ bool drop_keep(unsigned long long seed, unsigned sid, unsigned long long idx, unsigned thr16) {
+    return drop_keep_of(drop_hash4(seed, sid, idx >> 2), (unsigned)idx & 3u, thr16);
+}
+static inline unsigned drop_thr24(float p) { return p <= 0.f ? 0u : (unsigned)(p * 65536.0f + 0.5f); }      // (16-bit threshold; name kept)
 
 struct GemmF32Args {
     const float *A, *B, *bias, *R;
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args g) {
             const int r = row0 + l_hi + 32 * i, k = k0 + l_lo;
             if (r < rows) {
                 const float* p = base + (size_t)r * ld + k;
-                if (!SAFE) { v = *reinterpret_cast<const float4*>(p); }
+                if (!SAFE) { if (k < kend) v = *reinterpret_cast<const float4*>(p); }      // (K and the split boundaries are multiples of 4 here)
                 else {
                     if (k + 0 < kend) v.x = p[0];
                     if (k + 1 < kend) v.y = p[1];
@@ -177,8 +183,10 @@ extern "C" int sed_gemm_f32(const float* A, const float* B, const float* bias, c
         return SED_ERR_ARG;
     if (accumulate && (bias != nullptr || R != nullptr || pre != nullptr || act != 0 || drop_p > 0.f)) return SED_ERR_ARG;
     if (ksplit > 1 && !accumulate) return SED_ERR_ARG;
-    // float4 path: both operands 16-byte addressable along their contiguous dimension, contraction length a multiple of the K tile
-    const bool vec = !(((uintptr_t)A | (uintptr_t)B) & 15) && !((lda | ldb) & 3) && !((strideA | strideB) & 3) && (K % F32_BK) == 0;
+    // float4 path: both operands 16-byte addressable along their contiguous dimension; an operand whose contiguous dimension is the
+    // contraction needs its length to be a multiple of 4 (the tail of the last K tile is masked per float4), a row-contiguous
+    // (transposed) operand takes any contraction length -- the token count of a weight gradient
+    const bool vec = !(((uintptr_t)A | (uintptr_t)B) & 15) && !((lda | ldb) & 3) && !((strideA | strideB) & 3) && ((transA && transB) || (K & 3) == 0);
     GemmF32Args g;
     g.A = A; g.B = B; g.bias = bias; g.R = R; g.C = C; g.pre = pre;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ksplit = ksplit; g.act = act; g.accumulate = accumulate;
@@ -275,11 +283,16 @@ __global__ __launch_bounds__(64 * XA_WAVES) void xattn_f32_fwd_kernel(const floa
             __builtin_amdgcn_wave_barrier();
         }
         // ---- S^T[key, q]: A = K[key = lq][2 j + lg]
-        f32x16 st;
+        f32x16 st, st1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+        for (int r = 0; r < 16; ++r) { st[r] = 0.f; st1[r] = 0.f; }
 #pragma unroll
-        for (int j = 0; j < DH / 2; ++j) st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[lq * LDK + 2 * j + lg], qf[j], st, 0, 0, 0);
+        for (int j = 0; j < DH / 2; j += 2) {      // two accumulator chains (a dependent MFMA waits out the previous one's 16 passes)
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[lq * LDK + 2 * j + lg], qf[j], st, 0, 0, 0);
+            st1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[lq * LDK + 2 * j + 2 + lg], qf[j + 1], st1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] += st1[r];
         // ---- online softmax over the lane's 16 keys (register r <-> key j0 + mfma32_row(r, lg)) and the other half's 16
         float cmax = -INFINITY;
 #pragma unroll
@@ -306,9 +319,16 @@ __global__ __launch_bounds__(64 * XA_WAVES) void xattn_f32_fwd_kernel(const floa
         if (TRAIN && dr.thr != 0u) {      // dropout acts on the normalised probabilities: the denominator above keeps every key
             const unsigned long long rowbase = (((unsigned long long)b * gridDim.y + h) * Nq + qc) * (unsigned long long)Nk;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = j0 + mfma32_row(r, lg);
-                st[r] = (j < Nk && drop_keep(dr.seed, dr.sid, rowbase + j, dr.thr)) ? st[r] * dr.scale : 0.f;
+            for (int rq = 0; rq < 4; ++rq) {      // registers 4 rq .. 4 rq + 3 = keys j0 + 8 rq + 4 lg + (0 .. 3)
+                const int jq = j0 + 8 * rq + 4 * lg;
+                if ((Nk & 3) == 0) {               // (a row's keys start on a multiple of 4 of the flat index: one hash per quad)
+                    const unsigned long long z = drop_hash4(dr.seed, dr.sid, (rowbase + jq) >> 2);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) st[4 * rq + i] = (jq + i < Nk && drop_keep_of(z, i, dr.thr)) ? st[4 * rq + i] * dr.scale : 0.f;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) st[4 * rq + i] = (jq + i < Nk && drop_keep(dr.seed, dr.sid, rowbase + jq + i, dr.thr)) ? st[4 * rq + i] * dr.scale : 0.f;
+                }
             }
         }
 #pragma unroll
@@ -501,13 +521,53 @@ __global__ __launch_bounds__(64 * XA_WAVES) void xattn_f32_bwd_kernel(const floa
 #pragma unroll
         for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-        for (int j = 0; j < DH / 2; ++j) {
+        for (int j = 0; j < DH / 2; ++j) {      // two independent accumulator chains, interleaved: back-to-back issue
             st = __builtin_amdgcn_mfma_f32_32x32x2f32(T0[lq * LDK + 2 * j + lg], fa[j], st, 0, 0, 0);
-            if (MODE == 0) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(T1[lq * LDK + 2 * j + lg], fb[j], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(T1[lq * LDK + 2 * j + lg], fb[j], dp, 0, 0, 0);
         }
-        if (MODE == 1) {
+        // dropout bits of the tile's 16 elements of this lane, as a mask (bit r = keep).  Four consecutive keys share one hash (drop_hash4):
+        // in MODE 0 they are four consecutive registers of the lane; in MODE 1 (a lane = one key, registers = queries) the four lanes of a
+        // quad hold the four keys of a group -- each lane hashes the rows r = 4 i + (lane & 3) and the quad exchanges them (DPP quad_perm)
+        unsigned keepm = 0xffffu;
+        if (dr.thr != 0u) {
+            keepm = 0u;
+            if ((Nk & 3) == 0) {
+                if (MODE == 0) {
 #pragma unroll
-            for (int j = 0; j < DH / 2; ++j) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(T1[lq * LDK + 2 * j + lg], fb[j], dp, 0, 0, 0);
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const int jq = r0 + 8 * rq + 4 * lg;
+                        const unsigned long long z = drop_hash4(dr.seed, dr.sid, ((bh * Nq + cc) * (unsigned long long)Nk + (jq < Nk ? jq : 0)) >> 2);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) keepm |= (drop_keep_of(z, i, dr.thr) ? 1u : 0u) << (4 * rq + i);
+                    }
+                } else {
+                    unsigned zlo[4], zhi[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int rr = r0 + mfma32_row(4 * i + (lane & 3), lg);
+                        const unsigned long long z = drop_hash4(dr.seed, dr.sid, ((bh * Nq + (rr < Nq ? rr : Nq - 1)) * (unsigned long long)Nk + (cc & ~3)) >> 2);
+                        zlo[i] = (unsigned)z; zhi[i] = (unsigned)(z >> 32);
+                    }
+                    const unsigned l4 = (unsigned)cc & 3u;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#define XA_QB(K_) (((unsigned long long)(unsigned)__builtin_amdgcn_mov_dpp((int)zhi[i], (K_) * 0x55, 0xf, 0xf, true) << 32) | \
+                   (unsigned)__builtin_amdgcn_mov_dpp((int)zlo[i], (K_) * 0x55, 0xf, 0xf, true))
+                        keepm |= (drop_keep_of(XA_QB(0), l4, dr.thr) ? 1u : 0u) << (4 * i + 0);
+                        keepm |= (drop_keep_of(XA_QB(1), l4, dr.thr) ? 1u : 0u) << (4 * i + 1);
+                        keepm |= (drop_keep_of(XA_QB(2), l4, dr.thr) ? 1u : 0u) << (4 * i + 2);
+                        keepm |= (drop_keep_of(XA_QB(3), l4, dr.thr) ? 1u : 0u) << (4 * i + 3);
+#undef XA_QB
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ri = r0 + mfma32_row(r, lg);
+                    const int qi = MODE == 0 ? cc : (ri < Nq ? ri : Nq - 1), kj = MODE == 0 ? (ri < Nk ? ri : Nk - 1) : cc;
+                    keepm |= (drop_keep(dr.seed, dr.sid, (bh * Nq + qi) * (unsigned long long)Nk + kj, dr.thr) ? 1u : 0u) << r;
+                }
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -520,7 +580,7 @@ __global__ __launch_bounds__(64 * XA_WAVES) void xattn_f32_bwd_kernel(const floa
             const float pr = dead ? 0.f : exp2f(st[r] - l2);
             float dpv = dp[r], pd = pr;
             if (dr.thr != 0u) {
-                const bool keep = drop_keep(dr.seed, dr.sid, (bh * Nq + qi) * (unsigned long long)Nk + kj, dr.thr);
+                const bool keep = (keepm >> r) & 1u;
                 dpv = keep ? dpv * dr.scale : 0.f;
                 pd = keep ? pr * dr.scale : 0.f;
             }

@@ -409,8 +409,21 @@ class DasmHead:
         ctx["dquery"] = dqueries
         # ---- memory side: gradient of the folded projection, then of its two factors
         gwf, gbf = Z(ldkv, 768), Z(ldkv)
-        gemm_dw(dKV, ctx["ft2"], gwf, B * Pn, ldkv, 768)
-        colsum(dKV, gbf, B * Pn, ldkv)
+        big = B * Pn >= 1024 and ldkv % 256 == 0
+        g16 = None
+        if big:
+            # the one large product pair of the backward (B P x 2 L Dd x 768, twice) on the 16-bit matrix pipe with bf16 gradient operands, like
+            # every weight / input gradient of the trunk: one pass casts dKV (and yields the bias gradient), the TN kernel forms dW_fused
+            from . import ops
+            M_ = B * Pn
+            g16 = torch.empty(M_, ldkv, dtype=ops.BF16, device=dev)
+            ops.transpose_bf16(dKV, M_, ldkv, None, out_s=g16, colsum=gbf)
+            x16 = torch.empty(M_, 768, dtype=ops.BF16, device=dev)
+            ops.transpose_bf16(ctx["ft2"], M_, 768, None, out_s=x16)
+            ops.gemm_dw_tn(g16, x16, gwf)
+        else:
+            gemm_dw(dKV, ctx["ft2"], gwf, B * Pn, ldkv, 768)
+            colsum(dKV, gbf, B * Pn, ldkv)
         wkv_raw = ctx["wkv_raw"]
         for l in range(L):
             pre = f"at_decoder.decoder.layers.{l}.multihead_attn."
@@ -430,7 +443,13 @@ class DasmHead:
         if gbat is not None:        # d b_at = W_kv^T d b_fused
             call("sed_gemm_f32", gbf, wkv_raw, None, None, gbat, None, 1, Dd, ldkv, ldkv, Dd, Dd, 0, 1, 1, 0, 0, 0, 0, 1, 1, 0.0, 0, 0)
         dframe = None
-        if need_dframe:
+        if need_dframe and g16 is not None:
+            from . import ops
+            wt16 = torch.empty(768, ops.pad64(ldkv), dtype=ops.BF16, device=dev)
+            ops.transpose_bf16(ctx["wkv"], ldkv, 768, wt16)
+            dframe = torch.empty(B, Pn, 768, dtype=F32, device=dev)
+            ops.gemm_nt(g16, wt16, ops.EPI_F32, outF=dframe.view(B * Pn, 768), K=ldkv)
+        elif need_dframe:
             dframe = gemm_dx(dKV, ctx["wkv"], B * Pn, ldkv, 768).view(B, Pn, 768)
         return dframe, (None if dx_dec is None else dx_dec.view(B, T, Dd))
 
