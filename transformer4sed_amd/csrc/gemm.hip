@@ -1464,7 +1464,11 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(const GemmArgs g) {
     const int a_ld2 = a_slab ? 128 : g.lda * 2, a_kst = a_slab ? g.M * 128 : BK * 2;
     const __amdgpu_buffer_rsrc_t ra = a_slab
         ? __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)m0 * 64), 0, (unsigned)((size_t)(g.K / BK) * g.M * 128 - (size_t)m0 * 128), 0x00020000)
+#ifdef ABL_A_ALIAS   /* experiment (tools/ablate): every row panel reads the first 1024 rows of A -- the operand then lives in L2, results are wrong */
+        : __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)(m0 % 1024) * g.lda), 0, rows_a * g.lda * 2, 0x00020000);
+#else
         : __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + (size_t)m0 * g.lda), 0, rows_a * g.lda * 2, 0x00020000);
+#endif
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(g.B + (size_t)n0 * g.ldb), 0, V3_T * g.ldb * 2, 0x00020000);
     // DMA pieces of this wave: slot piece index p = 2 wave + e.  Slot 0 = A rows of half 0 (wave-row * 128 + 0..63), slot 3 = A rows
     // of half 1, slot 1 = B rows of half 0 (wave-column * 64 + 0..31), slot 2 = B rows of half 1
