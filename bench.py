@@ -15,7 +15,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP initialises: see transformer4sed_amd/__init__.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP initialises: the entry point's job (transformer4sed_amd/__init__.py, hostcpu.recommended_env)
 
 import numpy as np
 import torch
@@ -117,6 +117,7 @@ GFLOP_PER_BATCH = 21.22       # batch-shared linear_pos GEMMs (b-term)
 GFLOP_SKIPPED = {"finetune2": 211.5, "val": 654.3}
 PEAK_BF16_TFLOPS = 2500.0     # dense 16-bit MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0         # HBM3E peak, MI355X_MICROARCH.md
+MEASURED_HBM_GBS = 6300.0     # achievable streaming rate measured on the part (same guide)
 GEMM_KERNELS = ["sed_gemm_nt", "sed_gemm_qkv", "sed_gemm_qkv_w2s", "sed_gemm_dw_tn", "sed_gemm_nt_gb", "sed_gemm_qkv_gb", "sed_gemm_nt_w2", "sed_gemm_qkv_w2", "sed_gemm_nt_w2f8", "sed_gemm_qkv_w2f8", "sed_gemm_nt_gb_e4m3", "sed_gemm_nt_lnp", "sed_gemm_nt_lnp8", "sed_gemm_nt_lnc", "sed_gemm_qkv_lnc", "sed_gemm_nt_lnc8", "sed_gemm_qkv_lnc8"]
 
 
@@ -624,7 +625,9 @@ def main():
         line["roofline_hbm"] = [
             {"kernel": k, "what": what[k], "launches": v["launches"], "bytes": round(v["bytes"]), "us": round(1000 * v["ms"], 1),
              "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "peak_GB/s": PEAK_HBM_GBS,
-             "frac_of_8TB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+             "frac_of_8TB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+             # (beside the data-sheet figure: what a pure streaming kernel reaches on this part, MI355X_MICROARCH.md's measured HBM rate)
+             "frac_of_measured_6.3TB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / MEASURED_HBM_GBS, 4)}
             for k, v in summ_all.items() if k in what and v["ms"] > 0]
         if a.mode in ("dasm", "dasm_train") and "sed_gemm_f32" in summ_all:
             v = summ_all["sed_gemm_f32"]
@@ -648,7 +651,7 @@ def main():
         def prof(kind):
             if a.depth != 12 or a.batch is not None:
                 return None, None
-            for rnd in ("r5", "r4", "r3", "r2"):
+            for rnd in ("r6", "r5", "r4", "r3", "r2"):
                 path = os.path.join(ROOT, "profiles", f"{rnd}_gemm_{kind}_{a.mode}.json")
                 if os.path.exists(path):
                     return json.load(open(path)), os.path.relpath(path, ROOT)
@@ -713,6 +716,10 @@ def main():
                                       "EMA teacher forward with val_kwargs (17 windows of 512 frames, step 31, temp 0.5), soft-masked "
                                       "scipy-median score tables and half-point event decoding")
         line["config"].pop("final_loss", None)
+        w2 = getattr(getattr(net, "engine", None), "w2_f8_set", None) if getattr(getattr(net, "engine", None), "w2_f8", False) else None
+        line["dtype"] = ("evaluation-mode encoder on two-term f16 weights [f16(W) | W - f16(W)]: hi products f16 x f16 MFMA, lo products " +
+                         (f"e4m3 x e4m3 on the fp8 matrix path for {sorted(w2)} (SED_ENC_W2), f16 x f16 for the other GEMMs" if w2 else "f16 x f16") +
+                         "; fp32 accumulate + residual stream; context network in split precision")
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.mode == "finetune2" and not pipe:      # (N = 1 only: the other ranks would sit in the final barrier meanwhile)
         line["cpu_baseline"] = cpu_baseline(a.depth)
     # RCCL writes its version banner through C stdio (block-buffered when piped): every rank pushes it out before the last

@@ -64,12 +64,29 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--eps", type=float, default=1e-3)
     ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--envelope", type=int, default=0, help="K > 0: K noisy runs with different noise seeds -> tests/golden/trajectory_envelope.npz "
+                    "(per step and term: the largest |relative difference| to the reference log any of the K runs showed)")
     a = ap.parse_args()
     torch.set_num_threads(min(8, os.cpu_count() or 8))
     g = np.load(os.path.join(ROOT, "tests", "golden", "trajectory.npz"))
     meta = json.loads(str(g["config_json"]))
     ref = np.asarray([[float(g[f"s{s}_{k}"]) for k in TERMS] for s in range(a.steps)])
     np.set_printoptions(linewidth=220, precision=2)
+    if a.envelope > 0:
+        rs = []
+        for k in range(a.envelope):
+            x = run(g, meta, a.steps, a.eps, noise_seed=1234 + 17 * k)
+            rs.append((x - ref) / np.maximum(np.abs(ref), 0.02))
+            print(f"seed {k}: max |rel| per term", np.abs(rs[-1]).max(0), flush=True)
+        rs = np.asarray(rs)                                   # [K, steps, terms]
+        env = np.abs(rs).max(0)                               # [steps, terms]
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", "trajectory_envelope.npz"), envelope=env.astype(np.float32), runs=rs.astype(np.float32),
+                            terms=np.asarray(TERMS), eps=np.float64(a.eps), seeds=np.asarray([1234 + 17 * k for k in range(a.envelope)]),
+                            note=np.asarray("oracle/trajectory_sensitivity.py --envelope: the fp32 reference ALGORITHM (oracle/train_step.py) with "
+                                            "g += eps rms(g) N(0,1) on every gradient tensor before AdamW; relative difference of each loss term to "
+                                            "the reference trainer's log (tests/golden/trajectory.npz), floor 0.02 in the denominator"))
+        print("envelope (max over seeds), per step x term:"); print(env)
+        return
     for name, eps in (("A: oracle, exact gradients", 0.0), (f"B: oracle, gradients + {a.eps:g} rms noise", a.eps)):
         x = run(g, meta, a.steps, eps)
         r = (x - ref) / np.maximum(np.abs(ref), 0.02)

@@ -12,6 +12,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # The test processes also run the CPU oracle (torch fp32): give it every CPU the container may really use (affinity / cgroup quota)
 # instead of the product's host-thread cap (transformer4sed_amd/hostcpu.py) or torch's default of half the visible cores.
 os.environ.setdefault("SED_HOST_THREADS", "0")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # (what an entry point sets before HIP initialises: transformer4sed_amd.hostcpu.recommended_env)
 
 
 def pytest_configure(config):

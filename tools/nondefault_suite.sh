@@ -1,8 +1,10 @@
-# The GPU suite under the user-selectable non-default switches: each line = one full `pytest -m gpu` run.
-#   gpurun --timeout 1800 -- 'bash tools/nondefault_suite.sh r5'   -> gpurun_out/<tag>/nondefault_suite.txt
-TAG=${1:-r5}; O=gpurun_out/$TAG; mkdir -p $O; OUT=$O/nondefault_suite.txt; : > $OUT
-for env in "SED_DDP_COMM_DTYPE=bf16" "SED_GEMM_DYN=0" "SED_LN_FOLD=0" "SED_ENC_W2=f16" "SED_LN_DUAL=0"; do
+#!/bin/bash
+# The GPU suite once per user-selectable non-default value of every environment switch the product still reads (round 6: ten of them;
+# README "Environment switches").  -> gpurun_out/<tag>_nondefault_suite.txt     usage: bash tools/nondefault_suite.sh r6
+TAG=${1:-r6}; OUT=gpurun_out/${TAG}_nondefault_suite.txt; : > $OUT
+for env in "SED_DDP_COMM_DTYPE=bf16" "SED_GEMM_DYN=0" "SED_LN_FOLD=0" "SED_ENC_W2=f16" "SED_ENC_W2=f8:qkv,fc2" "SED_DW_STREAM=0" "SED_OVERLAP_TEACHER=0" \
+           "SED_GEMM_CUS=224" "SED_GEMM_RB=7" "SED_HOST_THREADS=4"; do
   echo "== $env" >> $OUT
-  env $env python -m pytest tests -m gpu -q -x > $O/nondefault_$$.log 2>&1; grep -E "passed|failed|error|Error|assert" $O/nondefault_$$.log | tail -6 >> $OUT; rm -f $O/nondefault_$$.log
+  env $env python -m pytest tests -m gpu -q -x 2>&1 | tail -2 >> $OUT
 done
 cat $OUT

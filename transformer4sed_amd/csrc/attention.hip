@@ -158,122 +158,8 @@ __device__ __forceinline__ void attn_store4(bf16_t* orow, int col, float a, floa
     if (tail_b >= 0)      // e4m3 of 2^-2 x the f16-rounded values (what sed_fp8_tail makes from the f16 half)
         *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(orow) + tail_b + col) = e4m3x4_of_h4(pk.x, pk.y);
 }
-template <bool F16, int NQ>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void mhsa_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                       const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
-                                                       float* __restrict__ LSE, int N, int Npad, int H, int q_begin, int o_slab) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][KVB * 128];  // [buf][K | Vt]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lg = lane >> 5;
-    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
-    const int q0 = q_begin + blockIdx.x * (128 * NQ) + wave * (32 * NQ);
-    const bf16_t* Qb = Q + (size_t)bh * N * HD;
-    const bf16_t* Kb = K + (size_t)bh * N * HD;
-    const bf16_t* Vb = Vt + (size_t)bh * N * HD;      // V row-major [N][64]: its transpose is taken by the LDS reads
-
-    s16x8_t qf[NQ][4];
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-        int qrow = q0 + 32 * u + lr;
-        qrow = qrow < N ? qrow : N - 1;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) qf[u][s] = *reinterpret_cast<const s16x8_t*>(Qb + (size_t)qrow * HD + 16 * s + 8 * lg);
-    }
-    f32x16_t o[NQ][2];
-    float m_run[NQ], l_run[NQ];
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-        m_run[u] = -1e30f; l_run[u] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[u][i][r] = 0.f;
-    }
-    const int ntiles = (N + KVB - 1) / KVB;
-    TileRegs rk, rv;
-    tile_gload(rk, Kb, 0, N, HD, 0, tid);
-    tile_gload(rv, Vb, 0, N, HD, 0, tid);
-    tile_lstore_rows(rk, lds[0][0], tid);
-    tile_lstore_vrows(rv, lds[0][1], tid);
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) pin_frags(qf[u]);
-    __syncthreads();
-
-    for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1, j0 = t * KVB;
-        if (t + 1 < ntiles) {
-            tile_gload(rk, Kb, j0 + KVB, N, HD, 0, tid);
-            tile_gload(rv, Vb, j0 + KVB, N, HD, 0, tid);
-        }
-        const unsigned char* lk = lds[buf][0];
-        const unsigned char* lv = lds[buf][1];
-        f32x16_t st[NQ][2];
-#ifdef ATT_QKIL
-        // the two key blocks' accumulator chains interleaved: consecutive MFMAs never depend on each other
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const s16x8_t kfr = lds_frag_rows(lk, 32 * kb + lr, 2 * s + lg);
-#pragma unroll
-                for (int u = 0; u < NQ; ++u) st[u][kb] = mfma32t<F16>(kfr, qf[u][s], s == 0 ? zero16 : st[u][kb]);
-            }
-#else
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const s16x8_t kfr = lds_frag_rows(lk, 32 * kb + lr, 2 * s + lg);
-#pragma unroll
-                for (int u = 0; u < NQ; ++u) st[u][kb] = mfma32t<F16>(kfr, qf[u][s], s == 0 ? zero16 : st[u][kb]);  // C = inline 0
-            }
-#endif
-        // online softmax per query block (log2 domain); keys >= N are masked on the last tile only
-#pragma unroll
-        for (int u = 0; u < NQ; ++u) {
-            if (j0 + KVB > N) softmax_tile<true>(st[u], o[u], m_run[u], l_run[u], j0, N, lg);
-            else softmax_tile<false>(st[u], o[u], m_run[u], l_run[u], j0, N, lg);
-        }
-        // O^T[d, q] += V^T[d, key] P^T[key, q]
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                s16x8_t pf[NQ];
-#pragma unroll
-                for (int u = 0; u < NQ; ++u) pf[u] = pack_frag_t<F16>(st[u][kb], s);
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    const s16x8_t vfr = lds_frag_vt(lv, db, 8 * kb + 4 * s + lg, lane);
-#pragma unroll
-                    for (int u = 0; u < NQ; ++u) o[u][db] = mfma32t<F16>(vfr, pf[u], o[u][db]);
-                }
-            }
-        if (t + 1 < ntiles) {
-            tile_lstore_rows(rk, lds[buf ^ 1][0], tid);
-            tile_lstore_vrows(rv, lds[buf ^ 1][1], tid);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-        const int q = q0 + 32 * u + lr;
-        if (q < N) {
-            const float inv = 1.0f / l_run[u];
-            // (o_slab: head-major output [H][B * N][64] -- the slab-major A operand of the LayerNorm-fold proj GEMM, csrc/gemm.hip a_slab)
-            bf16_t* orow = attn_out_row(O, o_slab, b, h, q, N, H, (int)gridDim.y / H);
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd)
-                    attn_store4<F16>(orow, 32 * db + 8 * qd + 4 * lg, o[u][db][4 * qd] * inv, o[u][db][4 * qd + 1] * inv, o[u][db][4 * qd + 2] * inv,
-                                     o[u][db][4 * qd + 3] * inv, o_slab == 2 ? (H - h) * HD * 2 + h * HD : -1);
-            if (lg == 0 && LSE != nullptr) LSE[(size_t)bh * N + q] = m_run[u] + log2f(l_run[u]);  // log2 domain
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------
-// forward, K / V tiles staged by LDS-DMA (round 4).  Same arithmetic, tile images and fragment reads as mhsa_fwd_kernel; what changes is how
+// forward, K / V tiles staged by LDS-DMA (round 4).  Same arithmetic, tile images and fragment reads as the round-3 register-staged kernel (removed in round 6); what changes is how
 // a tile reaches LDS: `buffer_load ... lds` (1 KiB = 8 rows per wave-instruction, 4 per wave and tile) instead of global -> 16 VGPRs ->
 // ds_write_b128.  The register path cost the LDS as much as the fragment reads did (a ds_write_b128 moves its 5 source dwords at 2
 // cycles each: ~13 cycles per KiB against 4 for a read) and its 16 staging registers.  The DMA writes lane l's 16 bytes at piece base
@@ -465,17 +351,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE_DMA, WP
 template <bool F16>
 static void launch_mhsa_fwd(const void* Q, const void* K, const void* Vt, void* O, float* LSE, int B, int H, int N, int Npad, int o_slab,
                             hipStream_t stream) {
-    // NQ = 2 (256-query workgroups) halves LDS traffic per MFMA but drops to one wave per SIMD (202 VGPRs) and measured
-    // slower on MI355X (24.9 vs 20.8 ms/step); NQ = 1 (two waves per SIMD) is the shipped configuration.
-    // SED_MHSA_FWD=reg: the register-staged kernel (A/B, tests); default: K / V tiles by LDS-DMA (needs N * 128 B < 2 GiB per head: always)
-    static const bool reg_path = getenv("SED_MHSA_FWD") && !strcmp(getenv("SED_MHSA_FWD"), "reg");
-    if (!reg_path) {
-        hipLaunchKernelGGL((mhsa_fwd_dma_kernel<F16>), dim3(cdiv(N, 128), B * H), dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,
-                           (const bf16_t*)Vt, (bf16_t*)O, LSE, N, H, o_slab);
-        return;
-    }
-    hipLaunchKernelGGL((mhsa_fwd_kernel<F16, 1>), dim3(cdiv(N, 128), B * H), dim3(256), 0, stream, (const bf16_t*)Q,
-                       (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)O, LSE, N, Npad, H, 0, o_slab);
+    // K / V tiles by LDS-DMA (needs N * 128 B < 2 GiB per head: always).  (The round-3 register-staged kernel and its SED_MHSA_FWD=reg
+    // switch went in round 6: it had served as the A/B reference of the DMA form)
+    (void)Npad;
+    hipLaunchKernelGGL((mhsa_fwd_dma_kernel<F16>), dim3(cdiv(N, 128), B * H), dim3(256), 0, stream, (const bf16_t*)Q, (const bf16_t*)K,
+                       (const bf16_t*)Vt, (bf16_t*)O, LSE, N, H, o_slab);
 }
 
 extern "C" int sed_mhsa_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int B, int H, int N,

@@ -2102,7 +2102,7 @@ static int launch_gemm(const GemmArgs& g, int f16, hipStream_t s) {
         // from the Infinity Cache -- while the time is best at 4 (fc2 1186 vs 998 TFLOP/s at 2): the counter does not track the time.
         GemmArgs gg = g;
         gg.group_m = 4;
-        static const int persist_env = getenv("SED_GEMM_PERSIST") ? atoi(getenv("SED_GEMM_PERSIST")) : 1;
+        const int persist_env = 1;      // (round 6: SED_GEMM_PERSIST=0, one workgroup per tile, lost its A/B in round 3 and is gone)
         // SED_GEMM_RB (read per launch): 7 / 8 force a tile height (A/B and the bit-exactness test), 0 = choose by the round count below.
         // Default 8: alone on the GPU the 224-row form wins 3-4 % on the N = 768 shapes, but inside the train step the teacher's and the
         // weight-gradient streams fill the last round's idle CUs anyway and the shorter tiles cost 0.25 % (104.03 vs 103.77 ms, 3 A/B pairs).

@@ -308,9 +308,8 @@ extern "C" int sed_relpos_attn_fwd(const void* Qu, const void* Qv, const void* K
     (void)hipGetLastError();
     if (T <= 0 || (T % 8) || Tpad % 64 || Tpad < T || Rpad % 64 || Rpad < 2 * T - 1 || (O_split != nullptr && !o_f32)) return SED_ERR_ARG;
     // 16 waves (256 queries) per workgroup when the sequence is long enough to fill them: four waves per SIMD, K / V^T tiles staged once per
-    // 256 queries; SED_RELPOS_FWD_NW=8 selects the 8-wave form (A/B)
-    static const int nw_env = getenv("SED_RELPOS_FWD_NW") ? atoi(getenv("SED_RELPOS_FWD_NW")) : 16;
-    const bool big = nw_env == 16 && T > 128;
+    // 256 queries (the 8-wave form serves short sequences)
+    const bool big = T > 128;
 #define SED_RP_FWD(F, O32) { if (big) launch_relpos_fwd<F, O32, 16>(Qu, Qv, K, Vt, P, O, O_split, LSE, B, H, T, Tpad, Rpad, stream); \
                              else launch_relpos_fwd<F, O32, 8>(Qu, Qv, K, Vt, P, O, O_split, LSE, B, H, T, Tpad, Rpad, stream); }
     if (f16 && o_f32) SED_RP_FWD(true, true)

@@ -69,8 +69,7 @@ class GradBucketReducer:
         the stage fires, reduced on the collective stream, and written back into the fp32 arena before the optimiser reads it.
         Environment default: SED_DDP_COMM_DTYPE=bf16|fp32.
         `reserve_cus`: CUs left to the communication kernels while this reducer lives -- until `close()` / the end of a `with` block / its
-        destruction restores the full grid (sed_gemm_set_cu_budget(total - reserve) now, (0) then; default
-        SED_DDP_RESERVE_CUS or 0).  With the dynamic tile walk of the persistent GEMMs a reserve is not needed for correctness of the
+        destruction restores the full grid (sed_gemm_set_cu_budget(total - reserve) now, (0) then; default 0).  With the dynamic tile walk of the persistent GEMMs a reserve is not needed for correctness of the
         overlap -- a late workgroup costs nothing (profiles/r4_cu_steal.txt) -- it only avoids queueing workgroups that will find no tile."""
         import os
         self.net, self.opt, self.group = net, optimizer, group
@@ -87,7 +86,7 @@ class GradBucketReducer:
         self.last_stats = dict(collectives=0, bytes=0)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         if reserve_cus is None:
-            reserve_cus = int(os.environ.get("SED_DDP_RESERVE_CUS", "0"))
+            reserve_cus = 0
         self.reserve_cus = int(reserve_cus)
         self._budget_set = False
         if self.reserve_cus > 0 and self.world > 1 and torch.cuda.is_available():

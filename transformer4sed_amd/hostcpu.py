@@ -66,3 +66,10 @@ def cap_torch_threads():
         log.info("host threads: torch intra-op pool %d -> %d (usable CPUs %d; SED_HOST_THREADS=0 keeps torch's setting)",
                  torch.get_num_threads(), cap, usable_cpus())
         torch.set_num_threads(cap)
+
+
+def recommended_env():
+    """Process environment an entry point should set BEFORE HIP initialises (transformer4sed_amd/__init__.py): os.environ.setdefault(k, v)
+    for each item.  bench.py and tests/conftest.py do."""
+    return {"GPU_MAX_HW_QUEUES": "8"}
+

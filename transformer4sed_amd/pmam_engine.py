@@ -44,9 +44,11 @@ class _LoraSlot:
 class PmamEngine(SedEngine):
     def __init__(self, module):
         super().__init__(module)
-        self.lora_skinny = os.environ.get("SED_LORA_SKINNY", "1") != "0"
-        self.small_dw = os.environ.get("SED_SMALL_DW", "1") != "0"
-        self.cg_fused16 = os.environ.get("SED_CG_FUSED16", "1") != "0"
+        # (round 6: the three PMAM A/B switches SED_LORA_SKINNY / SED_SMALL_DW / SED_CG_FUSED16 are gone -- results in DESIGN section 8; the
+        #  attributes remain for the kernel tests that exercise the general paths)
+        self.lora_skinny = True
+        self.small_dw = True
+        self.cg_fused16 = True
         if not self.split:
             raise RuntimeError("the PMAM path runs its 384-wide context network in split precision (SED_DECODER_SPLIT=1, f16 forward)")
         self.dec_terms2 = False      # (its own context-network schedule below keeps three terms in every GEMM)

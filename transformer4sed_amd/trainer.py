@@ -305,7 +305,7 @@ class MatSedTrainer:
         cap_torch_threads()     # a training loop is the one place where the host-thread cap matters (hostcpu.py); opt out: SED_HOST_THREADS=0
         # the no-grad teacher forward runs on a second HIP stream beside the student forward (+1.4 % clips/s); SED_OVERLAP_TEACHER=0 serialises
         self.overlap_teacher = os.environ.get("SED_OVERLAP_TEACHER", "1") != "0"
-        self.fused_losses = os.environ.get("SED_FUSED_LOSSES", "1") != "0"      # 0: the torch BCELoss / MSELoss modules (A/B reference)
+        self.fused_losses = True      # (False: the torch BCELoss / MSELoss modules, the A/B reference of the fused kernel's test)
         self._side = None
 
     # ---- checkpoint / resume.  Weights use the reference's state_dict keys, so `best_student.pt` /
