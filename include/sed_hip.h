@@ -31,7 +31,8 @@ int sed_abi_version(int reserved);
 /* ------------------------------------------------------------------ frontend / augment / post-process */
 /* PasstFeatureExtractor.forward + .normalize (src/models/passt/passt_feature_extraction.py:46-94).
  * wav [B,L] f32 -> out [B,128,T] f32; window [800] symmetric Hann, twiddle [1024] float2 exp(-2 pi i k/1024),
- * melw [128,513] dense Kaldi bank (host-built per (fmin,fmax)), mel_range [128,2] non-zero bin range. */
+ * melw [128,513] dense Kaldi bank (host-built per (fmin,fmax)), mel_range [128,2] non-zero bin range.  maxbits_tmp: scratch of 32 B words
+ * (32 partial |max| values per clip).  do_log bit 0: (log(mel + 1e-5) + 4.5) / 5; bit 1 (test aid): the round-5 kernel. */
 int sed_logmel_fwd(const float* wav, float* out, uint32_t* maxbits_tmp, const float* window, const float* twiddle,
                    const float* melw, const int* mel_range, int B, int L, int T, int do_log, hipStream_t stream);
 /* Polyphase FIR resampler, the device counterpart of the offline tool src/utils/resample.py:10-14 (16 kHz -> 32 kHz): x [B,L] ->

@@ -30,6 +30,7 @@ __global__ void zero_u32_kernel(unsigned* __restrict__ p, int n) {
 }
 
 // |max| per clip: 16-byte loads, 8 independent loads in flight per lane (the scalar 4-byte version ran at 0.55 TB/s)
+#define ABSMAX_PARTS 32      // partial maxima per clip (grid.x of wav_absmax_kernel); sed_logmel_fwd's scratch holds B x 32 words
 __global__ __launch_bounds__(256) void wav_absmax_kernel(const float* __restrict__ wav, unsigned* __restrict__ maxbits, int L) {
     const int b = blockIdx.y;
     const float* w = wav + (size_t)b * L;
@@ -61,7 +62,9 @@ __global__ __launch_bounds__(256) void wav_absmax_kernel(const float* __restrict
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(&maxbits[b], __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));  // non-negative floats order as uints
+    // one word per (clip, workgroup): partial maxima, reduced by the log-mel kernel's workgroups (no zero-fill launch, no atomics: the B
+    // atomic targets shared a cache line and retired at ~9 ns each)
+    if (threadIdx.x == 0) maxbits[(size_t)b * ABSMAX_PARTS + blockIdx.x] = __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
 }
 
 // pre-emphasised, reflect-padded signal sample n of the padded axis (n = 0 .. Ly + 1023), Ly = L - 1, from the raw samples
@@ -96,7 +99,9 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
     __shared__ int moff[NMEL + 1];
     const int tid = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * FR_PER_WG;
     const float* w = wav + (size_t)b * L;
-    const float rinv = 1.0f / (__uint_as_float(maxbits[b]) + 1e-10f);
+    float cmax = 0.f;
+    for (int i = 0; i < ABSMAX_PARTS; ++i) cmax = fmaxf(cmax, __uint_as_float(maxbits[(size_t)b * ABSMAX_PARTS + i]));      // (uniform: scalar loads)
+    const float rinv = 1.0f / (cmax + 1e-10f);
     const int Ly = L - 1;
     // ---- per-lane constants
     float wv[4];
@@ -238,21 +243,278 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Round 6: the same transform with ONE WAVE per frame pair and no workgroup barrier inside the FFT.  The 1024-point complex FFT of a pair
+// (frame a = real part, frame b = imaginary part) is three register stages, n = 64 a + b, k = c + 16 (g + 4 h):
+//   A  lane b:        Y[b][c]   = W1024^(b c)  sum_a x[64 a + b] W16^(a c)            16-point DFT in registers, lane twiddles in registers
+//   B  lane (c, fq):  T[c][f][g] = W64^(f g)   sum_e Y[16 e + f][c] W4^(e g)           f = fq + 4 fi: four 4-point DFTs
+//   C  lane (c, g):   X[c + 16 g + 64 h]     = sum_f T[c][f][g] W16^(f h)             16-point DFT in registers
+// with two exchanges through a WAVE-PRIVATE 8.5 KB LDS buffer between them (a wave's DS operations execute in order: no barrier), the
+// spectrum back through the same buffer for the conjugate-pair split, power -> filterbank (CSR weights in LDS, shared by the workgroup's
+// four waves) -> one staged [128][16] output tile per workgroup.  Workgroup barriers: one after the CSR build, one before the tile goes
+// out.  The round-5 kernel (radix-4 Stockham in LDS, 256 threads per pair) spent ~9 barriers per pair and measured latency-bound at every
+// frames-per-workgroup setting; `logmel_kernel` above is kept as the reference of this one's test.
+// ---------------------------------------------------------------------------------------------------
+#ifndef FRW
+#define FRW 16                 // frames per workgroup: 8 pairs, two per wave (measured at B = 32: 83.5 us at 16, 105.9 at 32, 97.5 at 64)
+#endif
+#define FEW_LDS_BYTES (4 * 16 * ZS * 8 + NMEL * FRW * 4 + MEL_CSR_CAP * 4 + (NMEL + 1) * 4)
+#ifndef FEW_BOUNDS
+#define FEW_BOUNDS __launch_bounds__(256)
+#endif
+#define ZS 68                  // row pitch (complex elements) of the exchange layouts: 2-way bank conflicts at worst
+__device__ __forceinline__ f32x2v cmulc(f32x2v z, float cr, float ci) {      // z * (cr + i ci), compile-time constant
+    return f32x2v{z.x, z.x} * f32x2v{cr, ci} + f32x2v{z.y, z.y} * f32x2v{-ci, cr};
+}
+__device__ __forceinline__ void dft4(f32x2v& a0, f32x2v& a1, f32x2v& a2, f32x2v& a3) {     // X[g] = sum_e a[e] (-i)^(e g)
+    const f32x2v v0 = a0 + a2, v1 = a0 - a2, v2 = a1 + a3, v3 = mul_neg_i(a1 - a3);
+    a0 = v0 + v2; a1 = v1 + v3; a2 = v0 - v2; a3 = v1 - v3;
+}
+// 16-point DFT in place; output X[c] is left at position (c >> 2) + 4 (c & 3)
+__device__ __forceinline__ void dft16(f32x2v (&x)[16]) {
+#pragma unroll
+    for (int a0 = 0; a0 < 4; ++a0) dft4(x[a0], x[a0 + 4], x[a0 + 8], x[a0 + 12]);        // position a0 + 4 c1 = u[a0][c1]
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
+    x[1 + 4] = cmulc(x[1 + 4], C1, -S1);   x[1 + 8] = cmulc(x[1 + 8], H, -H);      x[1 + 12] = cmulc(x[1 + 12], S1, -C1);      // W16^1, ^2, ^3
+    x[2 + 4] = cmulc(x[2 + 4], H, -H);     x[2 + 8] = mul_neg_i(x[2 + 8]);         x[2 + 12] = cmulc(x[2 + 12], -H, -H);       // W16^2, ^4, ^6
+    x[3 + 4] = cmulc(x[3 + 4], S1, -C1);   x[3 + 8] = cmulc(x[3 + 8], -H, -H);     x[3 + 12] = cmulc(x[3 + 12], -C1, S1);      // W16^3, ^6, ^9
+#pragma unroll
+    for (int c1 = 0; c1 < 4; ++c1) dft4(x[4 * c1], x[4 * c1 + 1], x[4 * c1 + 2], x[4 * c1 + 3]);   // position c0 + 4 c1 = X[c1 + 4 c0]
+}
+#define DFT16_POS(C) (((C) >> 2) + 4 * ((C) & 3))
+
+__global__ FEW_BOUNDS void logmel_wave_kernel(const float* __restrict__ wav, const unsigned* __restrict__ maxbits,
+                                                          const float* __restrict__ window, const float2* __restrict__ twiddle,
+                                                          const float* __restrict__ melw, const int* __restrict__ mel_range,
+                                                          float* __restrict__ out, int L, int T, int do_log) {
+    // dynamic LDS (FEW_LDS_BYTES = 48.5 KB: three workgroups per CU): exchange buffers (also the power spectra), output tile, CSR weights, band offsets
+    extern __shared__ __attribute__((aligned(16))) unsigned char few_lds[];
+    f32x2v (*zb)[16 * ZS] = reinterpret_cast<f32x2v (*)[16 * ZS]>(few_lds);
+    float (*ostage)[FRW] = reinterpret_cast<float (*)[FRW]>(few_lds + 4 * 16 * ZS * 8);
+    float* wcsr = reinterpret_cast<float*>(few_lds + 4 * 16 * ZS * 8 + NMEL * FRW * 4);
+    int* moff = reinterpret_cast<int*>(wcsr + MEL_CSR_CAP);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, t0 = blockIdx.x * FRW;
+    const float* w = wav + (size_t)b * L;
+    float cmax = 0.f;
+    for (int i = 0; i < ABSMAX_PARTS; ++i) cmax = fmaxf(cmax, __uint_as_float(maxbits[(size_t)b * ABSMAX_PARTS + i]));      // (uniform: scalar loads)
+    const float rinv = 1.0f / (cmax + 1e-10f);
+    const int Ly = L - 1;
+    // ---- filterbank as CSR in LDS (as in logmel_kernel)
+    {
+        const int mm = tid & 127, which = tid >> 7;
+        const int k0 = mel_range[2 * mm], k1 = mel_range[2 * mm + 1];
+        int incl = k1 - k0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            if ((tid & 63) >= o) incl += up;
+        }
+        if (tid == 63) moff[NMEL] = incl;
+        __syncthreads();
+        const int base = (tid >= 64 && tid < NMEL) ? moff[NMEL] : 0;
+        __syncthreads();
+        if (tid < NMEL) moff[tid + 1] = incl + base;
+        if (tid == 0) moff[0] = 0;
+        __syncthreads();
+        if (moff[NMEL] <= MEL_CSR_CAP) {
+            const int off = moff[mm];
+            for (int k = k0 + which; k < k1; k += 2) wcsr[off + k - k0] = melw[(size_t)mm * NBIN + k];
+        }
+    }
+    const bool csr = moff[NMEL] <= MEL_CSR_CAP;
+    // ---- per-lane constants: window taps of n = 64 a + lane, stage-A twiddles W1024^(lane c), stage-B twiddles W64^(f g)
+    float wv[16];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        const int n = 64 * a + lane;
+        wv[a] = (n >= WINOFF && n < WINOFF + WINLEN) ? window[n - WINOFF] * rinv : 0.f;
+    }
+    f32x2v twa[15], twa_p[15];
+#pragma unroll
+    for (int c = 1; c < 16; ++c) {
+        const float2 t = twiddle[lane * c];
+        twa[c - 1] = f32x2v{t.x, t.y};
+        twa_p[c - 1] = f32x2v{-t.y, t.x};
+    }
+    const int cB = lane >> 2, fq = lane & 3;      // stage B: lane = (c, fq); stage C: lane = (c, g) with g = fq
+    f32x2v twb[4][3], twb_p[4][3];
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+        for (int g = 1; g < 4; ++g) {
+            const float2 t = twiddle[16 * (fq + 4 * fi) * g];
+            twb[fi][g - 1] = f32x2v{t.x, t.y};
+            twb_p[fi][g - 1] = f32x2v{-t.y, t.x};
+        }
+    // the two bands of this lane (mel = lane, lane + 64)
+    int mk0[2], mk1[2], mo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        mk0[i] = mel_range[2 * (lane + 64 * i)];
+        mk1[i] = mel_range[2 * (lane + 64 * i) + 1];
+    }
+    __syncthreads();      // CSR image complete
+#pragma unroll
+    for (int i = 0; i < 2; ++i) mo[i] = moff[lane + 64 * i];
+    f32x2v* z = zb[wave];
+    for (int pi = 0; pi < FRW / 8; ++pi) {
+        const int pair = wave + 4 * pi, ta = t0 + 2 * pair, tb = ta + 1;
+        if (ta >= T) break;                       // (wave-uniform)
+        // ---- windowed, pre-emphasised samples: x[a] = (frame a, frame b) at n = 64 a + lane
+        f32x2v x[16];
+        x[0] = f32x2v{0.f, 0.f};
+        x[15] = f32x2v{0.f, 0.f};
+        const int base = HOP * ta - NFFT / 2;       // sample index of n = 0 of frame a on the un-padded axis
+#ifdef FEW_ABL_NOSAMPLES      // (timing ablations, tools/ablate/build_variant.sh: results are not a spectrogram)
+#pragma unroll
+        for (int a = 1; a < 15; ++a) x[a] = f32x2v{wv[a], wv[a]};
+#else
+        if (base + 64 >= 0 && base + HOP + 15 * 64 <= Ly - 1 && tb < T) {
+            // interior pair (all but the first two and last two frames of a clip): frame b is frame a moved by HOP = 5 x 64 samples, and
+            // y[n] = w[n + 1] - 0.97 w[n] takes its second operand from the next lane -- 19 coalesced row loads per lane instead of 112 scalar
+            // ones with reflected indices (the loads were 41 of the kernel's 96 us)
+            float raw[20];
+#pragma unroll
+            for (int r = 1; r < 20; ++r) raw[r] = w[base + 64 * r + lane];
+            float d[20];
+#pragma unroll
+            for (int r = 1; r < 20; ++r) {
+                float nx = __shfl_down(raw[r], 1, 64);
+                const float first_next = r < 19 ? __shfl(raw[r < 19 ? r + 1 : r], 0, 64) : 0.f;      // (row 19 is used by lanes < 16 only: taps beyond n = 911 are zero)
+                nx = lane == 63 ? first_next : nx;
+                d[r] = nx - 0.97f * raw[r];
+            }
+#pragma unroll
+            for (int a = 1; a < 15; ++a) x[a] = f32x2v{wv[a] * d[a], wv[a] * d[a + 5]};
+        } else {
+#pragma unroll
+            for (int a = 1; a < 15; ++a) {
+                const int n = 64 * a + lane;
+                float va = 0.f, vb = 0.f;
+                if (n >= WINOFF && n < WINOFF + WINLEN) {
+                    const int ma = ypad_index(HOP * ta + n, Ly);
+                    va = w[ma + 1] - 0.97f * w[ma];
+                    if (tb < T) { const int mb = ypad_index(HOP * tb + n, Ly); vb = w[mb + 1] - 0.97f * w[mb]; }
+                }
+                x[a] = f32x2v{wv[a] * va, wv[a] * vb};
+            }
+        }
+#endif
+#ifndef FEW_ABL_NOFFT
+        // ---- stage A
+        dft16(x);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            f32x2v y = x[DFT16_POS(c)];
+            if (c > 0) y = cmul_tw(y, twa[c - 1], twa_p[c - 1]);
+            z[ZS * c + lane] = y;                                           // Y[b = lane][c]
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- stage B: lane (c, fq), f = fq + 4 fi: 4-point DFT over e of Y[16 e + f][c], then W64^(f g)
+        f32x2v tq[16];
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi) {
+            const int f = fq + 4 * fi;
+            f32x2v e0 = z[ZS * cB + f], e1 = z[ZS * cB + 16 + f], e2 = z[ZS * cB + 32 + f], e3 = z[ZS * cB + 48 + f];
+            dft4(e0, e1, e2, e3);
+            tq[4 * fi] = e0;
+            tq[4 * fi + 1] = cmul_tw(e1, twb[fi][0], twb_p[fi][0]);
+            tq[4 * fi + 2] = cmul_tw(e2, twb[fi][1], twb_p[fi][1]);
+            tq[4 * fi + 3] = cmul_tw(e3, twb[fi][2], twb_p[fi][2]);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) z[ZS * cB + 17 * g + fq + 4 * fi] = tq[4 * fi + g];      // T[c][f][g] at c ZS + 17 g + f
+        __builtin_amdgcn_wave_barrier();
+        // ---- stage C: lane (c, g): 16-point DFT over f
+#pragma unroll
+        for (int f = 0; f < 16; ++f) x[f] = z[ZS * cB + 17 * fq + f];
+        __builtin_amdgcn_wave_barrier();
+        dft16(x);
+#pragma unroll
+        for (int h = 0; h < 16; ++h) z[cB + 16 * fq + 64 * h] = x[DFT16_POS(h)];                 // X[k], k = c + 16 g + 64 h, natural order
+        __builtin_amdgcn_wave_barrier();
+#else
+#pragma unroll
+        for (int h = 0; h < 16; ++h) z[lane + 64 * h] = x[h];
+        __builtin_amdgcn_wave_barrier();
+#endif
+        // ---- split the two real spectra and take the power: bins lane + 64 i (i = 0 .. 7) and 512.  IN PLACE: z[k] becomes (|Xa[k]|^2,
+        // |Xb[k]|^2) -- an iteration reads z[k] and z[1024 - k] >= 513 (never written) before it writes z[k], and a wave's DS operations
+        // execute in order; the filterbank then gets both frames' powers of a bin from one 8-byte read
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int k = lane + 64 * i;
+            if (i < 8 || lane == 0) {
+                const f32x2v zk = z[k], zn = z[(NFFT - k) & (NFFT - 1)];
+                const float yr = zn.x, yi = -zn.y;
+                const float ar = 0.5f * (zk.x + yr), ai = 0.5f * (zk.y + yi);
+                const float dr = zk.x - yr, di = zk.y - yi;
+                const float br = 0.5f * di, bi = -0.5f * dr;
+                z[k] = f32x2v{ar * ar + ai * ai, br * br + bi * bi};
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- filterbank: bands lane and lane + 64 of both frames
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float acc0 = 0.f, acc1 = 0.f;
+            const int k0 = mk0[i], n = mk1[i] - k0;
+#ifdef FEW_ABL_NOMEL
+            if (true) { acc0 = z[k0].x; acc1 = z[k0].y; } else
+#endif
+            if (csr) {
+                // (a float4 form over rows padded to whole groups of four bins measured SLOWER: 113.8 against 83.1 us per call at B = 32)
+                const float* wr = wcsr + mo[i];
+                f32x2v acc = {0.f, 0.f};
+                for (int j = 0; j < n; ++j) { const float wgt = wr[j]; acc = f32x2v{wgt, wgt} * z[k0 + j] + acc; }
+                acc0 = acc.x; acc1 = acc.y;
+            } else {
+                const float* wrow = melw + (size_t)(lane + 64 * i) * NBIN + k0;
+                for (int j = 0; j < n; ++j) { const float wgt = wrow[j]; acc0 = fmaf(wgt, z[k0 + j].x, acc0); acc1 = fmaf(wgt, z[k0 + j].y, acc1); }
+            }
+            ostage[lane + 64 * i][2 * pair] = do_log ? (__logf(acc0 + 1e-5f) + 4.5f) / 5.0f : acc0;
+            ostage[lane + 64 * i][2 * pair + 1] = do_log ? (__logf(acc1 + 1e-5f) + 4.5f) / 5.0f : acc1;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // ---- [128][FRW] tile -> global: thread (m, half) writes FRW / 2 consecutive frames
+    {
+        const int m = tid >> 1, half = tid & 1, t = t0 + (FRW / 2) * half;
+        float* dst = out + ((size_t)b * NMEL + m) * T + t;
+#pragma unroll
+        for (int i = 0; i < FRW / 2; i += 4) {
+            if (t + i + 3 < T && (T & 3) == 0)
+                *reinterpret_cast<float4*>(dst + i) = make_float4(ostage[m][(FRW / 2) * half + i], ostage[m][(FRW / 2) * half + i + 1],
+                                                                  ostage[m][(FRW / 2) * half + i + 2], ostage[m][(FRW / 2) * half + i + 3]);
+            else
+                for (int j = 0; j < 4; ++j) if (t + i + j < T) dst[i + j] = ostage[m][(FRW / 2) * half + i + j];
+        }
+    }
+}
+
 extern "C" int sed_logmel_fwd(const float* wav, float* out, uint32_t* maxbits_tmp, const float* window,
                               const float* twiddle, const float* melw, const int* mel_range, int B, int L, int T,
                               int do_log, hipStream_t stream) {
     (void)hipGetLastError();
     if (B <= 0 || T != 1 + (L - 1) / HOP || L < NFFT) return SED_ERR_ARG;
-    hipLaunchKernelGGL(zero_u32_kernel, dim3(cdiv(B, 256)), dim3(256), 0, stream, maxbits_tmp, B);
+    // |max| per clip as ABSMAX_PARTS partial maxima (every slot is written: workgroups past the clip's end write 0)
+    hipLaunchKernelGGL(wav_absmax_kernel, dim3(ABSMAX_PARTS, B), dim3(256), 0, stream, wav, maxbits_tmp, L);
+    // do_log bit 1 (test aid): the round-5 kernel, four waves per frame pair with the FFT in LDS -- the reference the wave-per-pair kernel
+    // is checked against bit for bit in structure (same window, pre-emphasis, split, filterbank order per band)
+    if (do_log & 2)
+        hipLaunchKernelGGL(logmel_kernel, dim3(cdiv(T, FR_PER_WG), B), dim3(256), 0, stream, wav, maxbits_tmp, window,
+                           (const float2*)twiddle, melw, mel_range, out, L, T, do_log & 1);
+    else
     {
-        // 8 x 16 bytes per lane per trip = 32 Ki samples per workgroup trip; enough workgroups to cover the 256 CUs twice
-        int bx = cdiv(L, 32768);
-        if (bx * B < 512) bx = cdiv(512, B);
-        if (bx > cdiv(L, 1024)) bx = cdiv(L, 1024);
-        hipLaunchKernelGGL(wav_absmax_kernel, dim3(bx, B), dim3(256), 0, stream, wav, maxbits_tmp, L);
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)logmel_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FEW_LDS_BYTES); attr = true; }
+        hipLaunchKernelGGL(logmel_wave_kernel, dim3(cdiv(T, FRW), B), dim3(256), FEW_LDS_BYTES, stream, wav, maxbits_tmp, window,
+                           (const float2*)twiddle, melw, mel_range, out, L, T, do_log & 1);
     }
-    hipLaunchKernelGGL(logmel_kernel, dim3(cdiv(T, FR_PER_WG), B), dim3(256), 0, stream, wav, maxbits_tmp, window,
-                       (const float2*)twiddle, melw, mel_range, out, L, T, do_log);
     return sed_check_launch();
 }
 

@@ -114,7 +114,7 @@ class PasstFeatureExtractor(nn.Module):
         T = 1 + (L - 1) // self.hopsize
         melw, rng = bank if bank is not None else self._bank(fmin, fmax, x.device)
         out = torch.empty(B, self.n_mels, T, dtype=torch.float32, device=x.device)
-        tmp = torch.empty(B, dtype=torch.int32, device=x.device)
+        tmp = torch.empty(B * 32, dtype=torch.int32, device=x.device)      # 32 partial |max| words per clip
         call("sed_logmel_fwd", x, out, tmp, self.window, self.twiddle, melw, rng, B, L, T, do_log)
         return out
 
