@@ -235,7 +235,7 @@ struct XaDrop {      // attention-probability dropout of one site (torch.nn.Mult
     unsigned long long seed;
 };
 template <int DH, bool MASK, bool TRAIN>
-__global__ __launch_bounds__(64 * XA_WAVES) void xattn_f32_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ Kp,
+__global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ Kp,
                                                                       const float* __restrict__ Vp, float* __restrict__ O,
                                                                       const unsigned char* __restrict__ mask, int Nq, int Nk, int ldq, int ldk,
                                                                       int ldv, int ldo, long long q_bstride, float* __restrict__ lse_out,
@@ -252,9 +252,12 @@ __global__ __launch_bounds__(64 * XA_WAVES) void xattn_f32_fwd_kernel(const floa
     // B operand of the score product: Q[q][2 j + g], j = 0 .. DH / 2 - 1
     float qf[DH / 2];
     {
-        const float* qp = Q + (size_t)b * q_bstride + (size_t)qc * ldq + h * DH + lg;
+        // k step j of lane half lg contracts d = (DH / 2) lg + j: a lane's A-operand values of consecutive k steps are CONTIGUOUS in the tile
+        // row -- 16-byte LDS reads, conflict-free at the DH + 4 row pitch (the 2 j + lg interleave read single words 4-way conflicted: 53-80 %
+        // of the kernels' LDS cycles, profiles/r6_dasm_pmc.json)
+        const float* qp = Q + (size_t)b * q_bstride + (size_t)qc * ldq + h * DH + (DH / 2) * lg;
 #pragma unroll
-        for (int j = 0; j < DH / 2; ++j) qf[j] = qp[2 * j] * sc;
+        for (int j = 0; j < DH / 2; ++j) qf[j] = qp[j] * sc;
     }
     f32x16 o[NDB];
 #pragma unroll
@@ -287,9 +290,12 @@ __global__ __launch_bounds__(64 * XA_WAVES) void xattn_f32_fwd_kernel(const floa
 #pragma unroll
         for (int r = 0; r < 16; ++r) { st[r] = 0.f; st1[r] = 0.f; }
 #pragma unroll
-        for (int j = 0; j < DH / 2; j += 2) {      // two accumulator chains (a dependent MFMA waits out the previous one's 16 passes)
-            st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[lq * LDK + 2 * j + lg], qf[j], st, 0, 0, 0);
-            st1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[lq * LDK + 2 * j + 2 + lg], qf[j + 1], st1, 0, 0, 0);
+        for (int j = 0; j < DH / 2; j += 4) {      // two accumulator chains (a dependent MFMA waits out the previous one's 16 passes)
+            const float4 k4 = *reinterpret_cast<const float4*>(Ks + lq * LDK + (DH / 2) * lg + j);
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.x, qf[j], st, 0, 0, 0);
+            st1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.y, qf[j + 1], st1, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.z, qf[j + 2], st, 0, 0, 0);
+            st1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, qf[j + 3], st1, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] += st1[r];
@@ -436,7 +442,7 @@ extern "C" int sed_xattn_f32_fwd_train(const float* Q, const float* K, const flo
 // The partial sums of the four waves are added through LDS at the end.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int DH, bool MASK, int MODE>
-__global__ __launch_bounds__(64 * XA_WAVES) void xattn_f32_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ Kp, const float* __restrict__ Vp,
+__global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ Kp, const float* __restrict__ Vp,
                                                                       const float* __restrict__ O, const float* __restrict__ dO,
                                                                       const float* __restrict__ lse, float* __restrict__ Dq, float* __restrict__ dQ,
                                                                       float* __restrict__ dK, float* __restrict__ dV,
@@ -463,24 +469,24 @@ __global__ __launch_bounds__(64 * XA_WAVES) void xattn_f32_bwd_kernel(const floa
     float fa[DH / 2], fb[DH / 2];
     float lse_c = 0.f, D_c = 0.f;
     if (MODE == 0) {
-        const float* qp = qb + (size_t)cc * ldq + lg;
-        const float* dp_ = dob + (size_t)cc * ldo + lg;
-        const float* op = ob + (size_t)cc * ldo + lg;
+        const float* qp = qb + (size_t)cc * ldq + (DH / 2) * lg;      // (k step j of lane half lg <-> d = (DH / 2) lg + j, as in the forward)
+        const float* dp_ = dob + (size_t)cc * ldo + (DH / 2) * lg;
+        const float* op = ob + (size_t)cc * ldo + (DH / 2) * lg;
         float part = 0.f;
 #pragma unroll
         for (int j = 0; j < DH / 2; ++j) {
-            fa[j] = qp[2 * j] * sc;
-            fb[j] = dp_[2 * j];
-            part = fmaf(fb[j], op[2 * j], part);
+            fa[j] = qp[j] * sc;
+            fb[j] = dp_[j];
+            part = fmaf(fb[j], op[j], part);
         }
         D_c = part + __shfl_xor(part, 32, 64);
         lse_c = lse[statbase + cc];
         if (wave == 0 && lg == 0 && c < Nq && Dq != nullptr) Dq[statbase + c] = D_c;
     } else {
-        const float* kp = kb + (size_t)cc * ldk + lg;
-        const float* vp = vb + (size_t)cc * ldv + lg;
+        const float* kp = kb + (size_t)cc * ldk + (DH / 2) * lg;
+        const float* vp = vb + (size_t)cc * ldv + (DH / 2) * lg;
 #pragma unroll
-        for (int j = 0; j < DH / 2; ++j) { fa[j] = kp[2 * j] * sc; fb[j] = vp[2 * j]; }
+        for (int j = 0; j < DH / 2; ++j) { fa[j] = kp[j] * sc; fb[j] = vp[j]; }
     }
     f32x16 acc0[NDB], acc1[NDB];      // MODE 0: acc0 = dQ^T;  MODE 1: acc0 = dK^T, acc1 = dV^T   ([d, column])
 #pragma unroll
@@ -521,9 +527,17 @@ __global__ __launch_bounds__(64 * XA_WAVES) void xattn_f32_bwd_kernel(const floa
 #pragma unroll
         for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-        for (int j = 0; j < DH / 2; ++j) {      // two independent accumulator chains, interleaved: back-to-back issue
-            st = __builtin_amdgcn_mfma_f32_32x32x2f32(T0[lq * LDK + 2 * j + lg], fa[j], st, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(T1[lq * LDK + 2 * j + lg], fb[j], dp, 0, 0, 0);
+        for (int j = 0; j < DH / 2; j += 4) {      // two independent accumulator chains, interleaved; 16-byte operand reads
+            const float4 a4 = *reinterpret_cast<const float4*>(T0 + lq * LDK + (DH / 2) * lg + j);
+            const float4 b4 = *reinterpret_cast<const float4*>(T1 + lq * LDK + (DH / 2) * lg + j);
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, fa[j], st, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b4.x, fb[j], dp, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, fa[j + 1], st, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b4.y, fb[j + 1], dp, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, fa[j + 2], st, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b4.z, fb[j + 2], dp, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, fa[j + 3], st, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b4.w, fb[j + 3], dp, 0, 0, 0);
         }
         // dropout bits of the tile's 16 elements of this lane, as a mask (bit r = keep).  Four consecutive keys share one hash (drop_hash4):
         // in MODE 0 they are four consecutive registers of the lane; in MODE 1 (a lane = one key, registers = queries) the four lanes of a

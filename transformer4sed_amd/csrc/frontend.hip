@@ -258,9 +258,12 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ w
 #ifndef FRW
 #define FRW 16                 // frames per workgroup: 8 pairs, two per wave (measured at B = 32: 83.5 us at 16, 105.9 at 32, 97.5 at 64)
 #endif
-#define FEW_LDS_BYTES (4 * 16 * ZS * 8 + NMEL * FRW * 4 + MEL_CSR_CAP * 4 + (NMEL + 1) * 4)
+#define ZW 1280                // complex elements of a wave's buffer: the spectrum sits at SPOS(k) = k + 4 (k >> 4) < 1280 (exchanges need 16 ZS = 1088)
+#define SPOS(K) ((K) + 4 * ((K) >> 4))      // the stage-C writes k = c + 16 g + 64 h land on distinct 8-byte bank pairs; consecutive k stay consecutive inside 16-blocks
+#define OSP (NMEL + 1)         // row pitch of the transposed output tile [frame][mel]
+#define FEW_LDS_BYTES (4 * ZW * 8 + FRW * OSP * 4 + MEL_CSR_CAP * 4 + (NMEL + 1) * 4)
 #ifndef FEW_BOUNDS
-#define FEW_BOUNDS __launch_bounds__(256)
+#define FEW_BOUNDS __launch_bounds__(256, 2)      // two workgroups per CU: at most 256 registers (the compiler took 270 and one wave per SIMD when left alone: 78 -> 110 us)
 #endif
 #define ZS 68                  // row pitch (complex elements) of the exchange layouts: 2-way bank conflicts at worst
 __device__ __forceinline__ f32x2v cmulc(f32x2v z, float cr, float ci) {      // z * (cr + i ci), compile-time constant
@@ -289,9 +292,9 @@ __global__ FEW_BOUNDS void logmel_wave_kernel(const float* __restrict__ wav, con
                                                           float* __restrict__ out, int L, int T, int do_log) {
     // dynamic LDS (FEW_LDS_BYTES = 48.5 KB: three workgroups per CU): exchange buffers (also the power spectra), output tile, CSR weights, band offsets
     extern __shared__ __attribute__((aligned(16))) unsigned char few_lds[];
-    f32x2v (*zb)[16 * ZS] = reinterpret_cast<f32x2v (*)[16 * ZS]>(few_lds);
-    float (*ostage)[FRW] = reinterpret_cast<float (*)[FRW]>(few_lds + 4 * 16 * ZS * 8);
-    float* wcsr = reinterpret_cast<float*>(few_lds + 4 * 16 * ZS * 8 + NMEL * FRW * 4);
+    f32x2v (*zb)[ZW] = reinterpret_cast<f32x2v (*)[ZW]>(few_lds);
+    float (*ostage)[OSP] = reinterpret_cast<float (*)[OSP]>(few_lds + 4 * ZW * 8);      // [frame][mel]: a wave's 64 bands go to 64 consecutive words
+    float* wcsr = reinterpret_cast<float*>(few_lds + 4 * ZW * 8 + FRW * OSP * 4);
     int* moff = reinterpret_cast<int*>(wcsr + MEL_CSR_CAP);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, t0 = blockIdx.x * FRW;
     const float* w = wav + (size_t)b * L;
@@ -434,7 +437,7 @@ __global__ FEW_BOUNDS void logmel_wave_kernel(const float* __restrict__ wav, con
         __builtin_amdgcn_wave_barrier();
         dft16(x);
 #pragma unroll
-        for (int h = 0; h < 16; ++h) z[cB + 16 * fq + 64 * h] = x[DFT16_POS(h)];                 // X[k], k = c + 16 g + 64 h, natural order
+        for (int h = 0; h < 16; ++h) z[SPOS(cB + 16 * fq + 64 * h)] = x[DFT16_POS(h)];           // X[k], k = c + 16 g + 64 h, at SPOS(k)
         __builtin_amdgcn_wave_barrier();
 #else
 #pragma unroll
@@ -448,12 +451,12 @@ __global__ FEW_BOUNDS void logmel_wave_kernel(const float* __restrict__ wav, con
         for (int i = 0; i < 9; ++i) {
             const int k = lane + 64 * i;
             if (i < 8 || lane == 0) {
-                const f32x2v zk = z[k], zn = z[(NFFT - k) & (NFFT - 1)];
+                const f32x2v zk = z[SPOS(k)], zn = z[SPOS((NFFT - k) & (NFFT - 1))];
                 const float yr = zn.x, yi = -zn.y;
                 const float ar = 0.5f * (zk.x + yr), ai = 0.5f * (zk.y + yi);
                 const float dr = zk.x - yr, di = zk.y - yi;
                 const float br = 0.5f * di, bi = -0.5f * dr;
-                z[k] = f32x2v{ar * ar + ai * ai, br * br + bi * bi};
+                z[SPOS(k)] = f32x2v{ar * ar + ai * ai, br * br + bi * bi};
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -463,35 +466,35 @@ __global__ FEW_BOUNDS void logmel_wave_kernel(const float* __restrict__ wav, con
             float acc0 = 0.f, acc1 = 0.f;
             const int k0 = mk0[i], n = mk1[i] - k0;
 #ifdef FEW_ABL_NOMEL
-            if (true) { acc0 = z[k0].x; acc1 = z[k0].y; } else
+            if (true) { acc0 = z[SPOS(k0)].x; acc1 = z[SPOS(k0)].y; } else
 #endif
             if (csr) {
                 // (a float4 form over rows padded to whole groups of four bins measured SLOWER: 113.8 against 83.1 us per call at B = 32)
                 const float* wr = wcsr + mo[i];
                 f32x2v acc = {0.f, 0.f};
-                for (int j = 0; j < n; ++j) { const float wgt = wr[j]; acc = f32x2v{wgt, wgt} * z[k0 + j] + acc; }
+                for (int j = 0; j < n; ++j) { const float wgt = wr[j]; acc = f32x2v{wgt, wgt} * z[SPOS(k0 + j)] + acc; }
                 acc0 = acc.x; acc1 = acc.y;
             } else {
                 const float* wrow = melw + (size_t)(lane + 64 * i) * NBIN + k0;
-                for (int j = 0; j < n; ++j) { const float wgt = wrow[j]; acc0 = fmaf(wgt, z[k0 + j].x, acc0); acc1 = fmaf(wgt, z[k0 + j].y, acc1); }
+                for (int j = 0; j < n; ++j) { const float wgt = wrow[j]; acc0 = fmaf(wgt, z[SPOS(k0 + j)].x, acc0); acc1 = fmaf(wgt, z[SPOS(k0 + j)].y, acc1); }
             }
-            ostage[lane + 64 * i][2 * pair] = do_log ? (__logf(acc0 + 1e-5f) + 4.5f) / 5.0f : acc0;
-            ostage[lane + 64 * i][2 * pair + 1] = do_log ? (__logf(acc1 + 1e-5f) + 4.5f) / 5.0f : acc1;
+            ostage[2 * pair][lane + 64 * i] = do_log ? (__logf(acc0 + 1e-5f) + 4.5f) / 5.0f : acc0;
+            ostage[2 * pair + 1][lane + 64 * i] = do_log ? (__logf(acc1 + 1e-5f) + 4.5f) / 5.0f : acc1;
         }
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    // ---- [128][FRW] tile -> global: thread (m, half) writes FRW / 2 consecutive frames
+    // ---- [FRW][128] tile -> global: thread (m, half) writes FRW / 2 consecutive frames of mel row m
     {
         const int m = tid >> 1, half = tid & 1, t = t0 + (FRW / 2) * half;
         float* dst = out + ((size_t)b * NMEL + m) * T + t;
 #pragma unroll
         for (int i = 0; i < FRW / 2; i += 4) {
+            const int f = (FRW / 2) * half + i;
             if (t + i + 3 < T && (T & 3) == 0)
-                *reinterpret_cast<float4*>(dst + i) = make_float4(ostage[m][(FRW / 2) * half + i], ostage[m][(FRW / 2) * half + i + 1],
-                                                                  ostage[m][(FRW / 2) * half + i + 2], ostage[m][(FRW / 2) * half + i + 3]);
+                *reinterpret_cast<float4*>(dst + i) = make_float4(ostage[f][m], ostage[f + 1][m], ostage[f + 2][m], ostage[f + 3][m]);
             else
-                for (int j = 0; j < 4; ++j) if (t + i + j < T) dst[i + j] = ostage[m][(FRW / 2) * half + i + j];
+                for (int j = 0; j < 4; ++j) if (t + i + j < T) dst[i + j] = ostage[f + j][m];
         }
     }
 }
