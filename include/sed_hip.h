@@ -501,6 +501,9 @@ int sed_gelu_bwd_f32(const float* dy, const float* pre, float* out, int64_t n, f
 /* out = x o keep / (1 - p) (nullable) and / or the keep bits themselves as bytes (nullable; test aid for the CPU oracle) */
 int sed_dropout_f32(const float* x, float* out, uint8_t* mask_u8, int64_t n, float drop_p, int64_t drop_seed, int drop_site,
                     hipStream_t stream);
+/* out = drop(act(x)) (+ res) over n elements; act 1 = GELU; dropout bits of element index i (see sed_gemm_f32) */
+int sed_act_drop_res_f32(const float* x, const float* res, float* out, int64_t n, int act, float drop_p, int64_t drop_seed, int drop_site,
+                         hipStream_t stream);
 /* out[c] += sum_r x[r ld + c] */
 int sed_colsum_f32(const float* x, float* out, int rows, int cols, int64_t ld, hipStream_t stream);
 /* supervised losses of src/functional/loss/__init__.py (loss_function_factory), mean over n elements, loss[0] += value (caller zeroes),

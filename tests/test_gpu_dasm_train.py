@@ -224,7 +224,8 @@ def _head(n_base=8, qdim=1024, layers=2):
     return DasmHead({k: torch.from_numpy(v).to(DEV) for k, v in sd.items()}, layers), {k: torch.from_numpy(v) for k, v in sd.items()}
 
 
-@pytest.mark.parametrize("B,P,T,Q,pdrop,external", [(2, 60, 60, 8, 0.0, False), (2, 60, 60, 12, 0.1, True), (2, 1188, 1000, 40, 0.1, True)])
+@pytest.mark.parametrize("B,P,T,Q,pdrop,external", [(2, 60, 60, 8, 0.0, False), (2, 60, 60, 12, 0.1, True), (2, 1188, 1000, 40, 0.1, True),
+                                                     (3, 60, 120, 407, 0.1, True)])
 def test_dasm_head_forward_backward_vs_oracle_autograd(B, P, T, Q, pdrop, external):
     """Query decoder + dual-stream head, train mode: outputs, the gradient of every parameter, of the frame tokens and of the SED decoder's
     output against torch autograd through oracle/dasm_oracle.py (fp64), with the dropout bits the kernels use injected into the oracle."""
@@ -273,10 +274,17 @@ def test_dasm_head_forward_backward_vs_oracle_autograd(B, P, T, Q, pdrop, extern
         worst[k] = relerr(grads[k], v.grad)
     worst["frame_tokens"] = relerr(dframe, fr.grad)
     worst["x_dec"] = relerr(dxdec, xd.grad)
-    # fp32 throughout: 2e-4.  At the real size the memory-side projection pair (B P x 2 L Dd x 768) runs its backward on the 16-bit matrix
-    # pipe with bf16 gradient operands like the trunk's weight / input gradients: 3e-3 for what comes out of it
-    bf = ("at_projector.", "frame_tokens") if B * P >= 1024 else ()
-    bad = {k: f"{e:.2e}" for k, e in worst.items() if e > (3e-3 if (k.startswith(bf) or (bf and "multihead_attn.in_proj" in k)) else 2e-4)}
+    # fp32 throughout: 2e-4.  A Linear with >= 1024 rows (dasm.DasmHead._big) runs its forward in split precision and its two backward
+    # products on the 16-bit matrix pipe with bf16 gradient operands like the trunk's weight / input gradients: 3e-3 for what comes out of
+    # those -- the memory-side projection and sed_head at the real token / frame counts, every layer at 407 queries
+    if B * Q >= 1024:
+        # (`relerr` is the relative L2 error of the whole tensor, element by element: with every product of the chain on bf16 operands that is
+        #  2^-8 .. 2^-7 -- measured 6.4e-3 at worst; the NORMS, what the trainer fixtures bound at 3e-3, are a magnitude closer)
+        tol = lambda k: 1e-2
+    else:
+        bf = (("at_projector.", "frame_tokens") if B * P >= 1024 else ()) + (("sed_head.", "x_dec") if B * T >= 1024 else ())
+        tol = lambda k: 3e-3 if (k.startswith(bf) or (B * P >= 1024 and "multihead_attn.in_proj" in k)) else 2e-4
+    bad = {k: f"{e:.2e}" for k, e in worst.items() if e > tol(k)}
     print("DASM head backward, worst relative gradient errors:", sorted(((e, k) for k, e in worst.items()), reverse=True)[:5])
     assert not bad, bad
 

@@ -879,6 +879,27 @@ extern "C" int sed_dropout_f32(const float* x, float* out, uint8_t* mask_u8, int
                        1.0f / (1.0f - drop_p), (unsigned long long)drop_seed);
     return sed_check_launch();
 }
+// out = drop(act(x)) (+ res): the elementwise tail of a Linear whose product ran on the 16-bit matrix pipe (dasm.py, large query counts):
+// act 1 = GELU; dropout bits of element index i as in sed_gemm_f32's epilogue
+__global__ __launch_bounds__(256) void act_drop_res_f32_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ out,
+                                                               long long n, int act, unsigned thr, unsigned sid, float scale, unsigned long long seed) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float v = x[i];
+        if (act == 1) v = gelu_fast(v);
+        if (thr != 0u) v = drop_keep(seed, sid, (unsigned long long)i, thr) ? v * scale : 0.f;
+        if (res != nullptr) v += res[i];
+        out[i] = v;
+    }
+}
+extern "C" int sed_act_drop_res_f32(const float* x, const float* res, float* out, int64_t n, int act, float drop_p, int64_t drop_seed, int drop_site,
+                                    hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n <= 0 || act < 0 || act > 1 || !(drop_p >= 0.f && drop_p < 1.f)) return SED_ERR_ARG;
+    const int blocks = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+    hipLaunchKernelGGL(act_drop_res_f32_kernel, dim3(blocks), dim3(256), 0, stream, x, res, out, (long long)n, act, drop_thr24(drop_p), (unsigned)drop_site,
+                       1.0f / (1.0f - drop_p), (unsigned long long)drop_seed);
+    return sed_check_launch();
+}
 // out[c] += sum_r x[r ld + c]: bias gradients (column sums over the tokens), the gradient of the shared queries (sum over the clips)
 __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ x, float* __restrict__ out, int rows, int cols, long long ld,
                                                          int rows_per_block) {

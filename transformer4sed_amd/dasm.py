@@ -154,6 +154,88 @@ class DasmHead:
             self._fused, self._fused_key, self._fused_split = (w, b, wkv), key, None
         return self._fused
 
+    # ------------------------------------------------------------------ Linear layers: fp32 MFMA, or the 16-bit matrix pipe when large
+    @staticmethod
+    def _big(M, N, K):
+        """The 256^2 GEMM kernel's domain.  Above it a Linear runs its forward product in split precision (f16 hi / lo images of input and
+        weight, three term products accumulated in fp32: ~2^-20 of the product, the context network's form) and its two backward products
+        on bf16 operands like every gradient GEMM of the trunk -- 3-10 x the fp32-MFMA rate; below it (the tests' small shapes, any one-column
+        head) everything stays on `sed_gemm_f32`."""
+        return M >= 1024 and N % 256 == 0 and K % 64 == 0
+
+    def _lin(self, x, name, act=0, res=None, save=False, drop=NO_DROP, N=None, row0=0, xs=None, packed=False):
+        """y = drop(act(x W^T + b)) (+ res) for the parameter `name`(.weight / .bias; `packed`: `name`_weight / _bias, rows row0 .. row0 + N).
+        -> (y, ctx) with ctx what `_lin_bwd2` needs when `save`.  `xs`: an already made split image of x (several Linears share an input)."""
+        from . import ops
+        W = self.P(name + ("_weight" if packed else ".weight"))
+        b = self.P(name + ("_bias" if packed else ".bias"))
+        N = W.shape[0] if N is None else N
+        W, b = W[row0:row0 + N], b[row0:row0 + N]
+        M, K = x.shape[0], W.shape[1]
+        dev = x.device
+        if not self._big(M, N, K):
+            pre = torch.empty(M, N, dtype=F32, device=dev) if (save and act == 1) else None
+            y = gemm_f32(x, W, bias=b, res=res, act=act, pre=pre, drop=drop, N=N)
+            return y, (dict(kind="f32", x=x, pre=pre, name=name, packed=packed, N=N, row0=row0, act=act, drop=drop) if save else None)
+        if xs is None:
+            xs = ops.split3(x, M, K)
+        ws = ops.split3(W, N, K, weight=True)
+        tail = act == 1 or drop[0] > 0
+        y = torch.empty(M, N, dtype=F32, device=dev)
+        with ops.split_precision():
+            if res is not None and not tail:
+                ops.gemm_nt(xs, ws, ops.EPI_F32_RESID, bias=b, res=res, outF=y)
+            else:
+                ops.gemm_nt(xs, ws, ops.EPI_F32, bias=b, outF=y)
+        pre = None
+        if tail:
+            pre = y if act == 1 else None
+            out = torch.empty_like(y) if (act == 1 and save) else y
+            call("sed_act_drop_res_f32", y, res, out, M * N, int(act), float(drop[0]), int(drop[1]), int(drop[2]))
+            y = out
+        return y, (dict(kind="16", xs=xs, pre=pre, name=name, packed=packed, N=N, row0=row0, act=act, drop=drop, K=K) if save else None)
+
+    def _lin_bwd2(self, c, dy, G, M, res=None, need_dx=True):
+        """Backward of `_lin` from its ctx: dy is the gradient of the OUTPUT (after activation / dropout); gradients of weight and bias are
+        accumulated into G(...) (rows row0 .. row0 + N for packed projections); -> dx (+ res)."""
+        from . import ops
+        name, N, row0 = c["name"], c["N"], c["row0"]
+        wn, bn = name + ("_weight" if c["packed"] else ".weight"), name + ("_bias" if c["packed"] else ".bias")
+        W = self.P(wn)[row0:row0 + N]
+        gW, gb = G(wn), G(bn)
+        gW = None if gW is None else gW[row0:row0 + N]
+        gb = None if gb is None else gb[row0:row0 + N]
+        dev = dy.device
+        if c["act"] == 1 or c["drop"][0] > 0:      # through dropout and the activation: d pre = dy o keep / (1 - p) o act'(pre)
+            d = torch.empty_like(dy)
+            if c["act"] == 1:
+                call("sed_gelu_bwd_f32", dy, c["pre"], d, dy.numel(), float(c["drop"][0]), int(c["drop"][1]), int(c["drop"][2]))
+            else:
+                call("sed_dropout_f32", dy, d, None, dy.numel(), float(c["drop"][0]), int(c["drop"][1]), int(c["drop"][2]))
+            dy = d
+        if c["kind"] == "f32":
+            K = W.shape[1]
+            if gW is not None:
+                gemm_dw(dy, c["x"], gW, M, N, K, lda=dy.stride(0), ldb=c["x"].stride(0))
+            if gb is not None:
+                colsum(dy, gb, M, N, ld=dy.stride(0))
+            return gemm_dx(dy, W, M, N, K, res=res, lda=dy.stride(0)) if need_dx else None
+        K = c["K"]
+        g16 = torch.empty(M, N, dtype=ops.BF16, device=dev)
+        ops.transpose_bf16(dy, M, N, None, out_s=g16, colsum=gb)            # one pass: the bf16 operand and the bias gradient
+        if gW is not None:
+            ops.gemm_dw_tn(g16, c["xs"], gW, k_in=K)                         # (the split image's first third is the f16 input)
+        if not need_dx:
+            return None
+        wt16 = torch.empty(K, ops.pad64(N), dtype=ops.BF16, device=dev)
+        ops.transpose_bf16(W, N, K, wt16)
+        dx = torch.empty(M, K, dtype=F32, device=dev)
+        if res is not None:
+            ops.gemm_nt(g16, wt16, ops.EPI_F32_RESID, res=res, outF=dx, K=N)
+        else:
+            ops.gemm_nt(g16, wt16, ops.EPI_F32, outF=dx, K=N)
+        return dx
+
     # ------------------------------------------------------------------ queries (detect_any_sound.py:266-289)
     def _queries(self, query, query_type, dev, save):
         """-> (q0 [Q, Dd], ctx) with q0 = GELU(Linear(query embeddings)); a list of per-modality embeddings: one projector each and a random
@@ -241,10 +323,8 @@ class DasmHead:
         layers = []
         for l in range(L):
             pre = f"at_decoder.decoder.layers.{l}."
-            x_in = x
             # cross attention first (at_adapter.py:28): queries over the patch tokens
-            w_in, b_in = P(pre + "multihead_attn.in_proj_weight"), P(pre + "multihead_attn.in_proj_bias")
-            qc = gemm_f32(x, w_in, bias=b_in, N=Dd)                                # rows 0 .. Dd-1 of the packed in_proj = W_q
+            qc, c_q = self._lin(x, pre + "multihead_attn.in_proj", N=Dd, save=save, packed=True)      # rows 0 .. Dd-1 of the packed in_proj = W_q
             oc = E(M, Dd)
             kp = KV.data_ptr() + 4 * (2 * l * Dd)           # column blocks of the packed projection, read in place (ld = 2 L Dd)
             lse_c = S(B * H * Q)
@@ -252,10 +332,10 @@ class DasmHead:
                 call("sed_xattn_f32_fwd_train", qc, kp, kp + 4 * Dd, oc, None, lse_c, B, H, Q, Pn, dh, Dd, ldkv, ldkv, Dd, Q * Dd, *D_(8 * l + 0))
             else:
                 call("sed_xattn_f32_fwd", qc, kp, kp + 4 * Dd, oc, None, B, H, Q, Pn, dh, Dd, ldkv, ldkv, Dd, Q * Dd)
-            y1 = gemm_f32(oc, P(pre + "multihead_attn.out_proj.weight"), bias=P(pre + "multihead_attn.out_proj.bias"), res=x, drop=D_(8 * l + 1))
+            y1, c_oc = self._lin(oc, pre + "multihead_attn.out_proj", res=x, drop=D_(8 * l + 1), save=save)
             x1, m1, r1 = layer_norm(y1, P(pre + "norm1.weight"), P(pre + "norm1.bias"), stats=True) if save else (layer_norm(y1, P(pre + "norm1.weight"), P(pre + "norm1.bias")), None, None)
             # self attention among the queries (tgt_mask: the open-vocabulary mask)
-            qkv = gemm_f32(x1, P(pre + "self_attn.in_proj_weight"), bias=P(pre + "self_attn.in_proj_bias"))      # [M, 3 Dd]
+            qkv, c_qkv = self._lin(x1, pre + "self_attn.in_proj", save=save, packed=True)                 # [M, 3 Dd]
             osf = E(M, Dd)
             lse_s = S(B * H * Q)
             if save:
@@ -264,27 +344,26 @@ class DasmHead:
             else:
                 call("sed_xattn_f32_fwd", qkv, qkv.data_ptr() + 4 * Dd, qkv.data_ptr() + 8 * Dd, osf, mask8, B, H, Q, Q, dh, 3 * Dd, 3 * Dd, 3 * Dd, Dd,
                      Q * 3 * Dd)
-            y2 = gemm_f32(osf, P(pre + "self_attn.out_proj.weight"), bias=P(pre + "self_attn.out_proj.bias"), res=x1, drop=D_(8 * l + 3))
+            y2, c_os = self._lin(osf, pre + "self_attn.out_proj", res=x1, drop=D_(8 * l + 3), save=save)
             x2, m2, r2 = layer_norm(y2, P(pre + "norm2.weight"), P(pre + "norm2.bias"), stats=True) if save else (layer_norm(y2, P(pre + "norm2.weight"), P(pre + "norm2.bias")), None, None)
             # feed-forward (GELU)
-            hpre = S(M, P(pre + "linear1.weight").shape[0])
-            h = gemm_f32(x2, P(pre + "linear1.weight"), bias=P(pre + "linear1.bias"), act=1, pre=hpre, drop=D_(8 * l + 4))
-            y3 = gemm_f32(h, P(pre + "linear2.weight"), bias=P(pre + "linear2.bias"), res=x2, drop=D_(8 * l + 5))
+            h, c_l1 = self._lin(x2, pre + "linear1", act=1, drop=D_(8 * l + 4), save=save)
+            y3, c_l2 = self._lin(h, pre + "linear2", res=x2, drop=D_(8 * l + 5), save=save)
             x, m3, r3 = layer_norm(y3, P(pre + "norm3.weight"), P(pre + "norm3.bias"), stats=True) if save else (layer_norm(y3, P(pre + "norm3.weight"), P(pre + "norm3.bias")), None, None)
             if save:
-                layers.append(dict(x_in=x_in, qc=qc, oc=oc, lse_c=lse_c, y1=y1, m1=m1, r1=r1, x1=x1, qkv=qkv, osf=osf, lse_s=lse_s, y2=y2, m2=m2, r2=r2,
-                                   x2=x2, hpre=hpre, h=h, y3=y3, m3=m3, r3=r3))
+                layers.append(dict(c_q=c_q, qc=qc, oc=oc, lse_c=lse_c, c_oc=c_oc, y1=y1, m1=m1, r1=r1, c_qkv=c_qkv, qkv=qkv, osf=osf, lse_s=lse_s, c_os=c_os,
+                                   y2=y2, m2=m2, r2=r2, c_l1=c_l1, c_l2=c_l2, y3=y3, m3=m3, r3=r3))
         mask_feat = x                                                              # [B Q, Dd]
+        from . import ops
+        mf_s = ops.split3(mask_feat, M, Dd) if self._big(M, Dd, Dd) else None      # (the two MLPs read the same input)
         # ---- tagging stream: at_head = MLP(Dd, Dd, 1, 2), sigmoid (detect_any_sound.py:296-299)
-        hpre_a = S(M, Dd)
-        h_a = gemm_f32(mask_feat, P("at_head.layers.0.weight"), bias=P("at_head.layers.0.bias"), act=1, pre=hpre_a)
-        at_logit = gemm_f32(h_a, P("at_head.layers.1.weight"), bias=P("at_head.layers.1.bias"))          # [B Q, 1]
+        h_a, c_a0 = self._lin(mask_feat, "at_head.layers.0", act=1, save=save, xs=mf_s)
+        at_logit, c_a1 = self._lin(h_a, "at_head.layers.1", save=save)                                    # [B Q, 1]
         # ---- detection stream: mask embedding x sed_head(frames) (detect_any_sound.py:376-378)
-        e1p, e2p = S(M, Dd), S(M, Dd)
-        e1 = gemm_f32(mask_feat, P("mask_embedding_layer.layers.0.weight"), bias=P("mask_embedding_layer.layers.0.bias"), act=1, pre=e1p)
-        e2 = gemm_f32(e1, P("mask_embedding_layer.layers.1.weight"), bias=P("mask_embedding_layer.layers.1.bias"), act=1, pre=e2p)
-        e = gemm_f32(e2, P("mask_embedding_layer.layers.2.weight"), bias=P("mask_embedding_layer.layers.2.bias"))
-        xs = gemm_f32(x_dec.view(B * T, Dd), P("sed_head.weight"), bias=P("sed_head.bias"))              # [B T, Dd]
+        e1, c_e0 = self._lin(mask_feat, "mask_embedding_layer.layers.0", act=1, save=save, xs=mf_s)
+        e2, c_e1 = self._lin(e1, "mask_embedding_layer.layers.1", act=1, save=save)
+        e, c_e2 = self._lin(e2, "mask_embedding_layer.layers.2", save=save)
+        xs, c_sh = self._lin(x_dec.view(B * T, Dd), "sed_head", save=save)                                # [B T, Dd]
         logits = E(B, T, Q)
         gemm_f32(xs, e, M=T, N=Q, lda=Dd, ldb=Dd, out=logits, batch=B, strides=(T * Dd, Q * Dd, T * Q))
         strong, weak, at_out = E(B, Q, T), E(B, Q), E(B, Q)
@@ -292,9 +371,9 @@ class DasmHead:
         call("sed_dasm_head_fwd", logits, at_logit, pm, float(temp_w), strong, weak, at_out, B, T, Q, 1)
         if not save:
             return strong, weak, at_out, mask_feat.view(B, Q, Dd)
-        ctx = dict(B=B, Pn=Pn, T=T, Q=Q, ft2=ft2, x_dec=x_dec.view(B * T, Dd), KV=KV, wkv=wkv, wkv_raw=wkv_raw, qctx=qctx, mask8=mask8, layers=layers,
-                   mask_feat=mask_feat, hpre_a=hpre_a, h_a=h_a, at_logit=at_logit, e1p=e1p, e1=e1, e2p=e2p, e2=e2, e=e, xs=xs, logits=logits,
-                   strong=strong, pm=pm, temp=float(temp_w), pdrop=pdrop, seed=drop_seed)
+        ctx = dict(B=B, Pn=Pn, T=T, Q=Q, ft2=ft2, KV=KV, wkv=wkv, wkv_raw=wkv_raw, qctx=qctx, mask8=mask8, layers=layers, c_a0=c_a0, c_a1=c_a1, c_e0=c_e0,
+                   c_e1=c_e1, c_e2=c_e2, c_sh=c_sh, at_logit=at_logit, e=e, xs=xs, logits=logits, strong=strong, pm=pm, temp=float(temp_w), pdrop=pdrop,
+                   seed=drop_seed)
         return strong, weak, at_out, mask_feat.view(B, Q, Dd), ctx
 
     # ------------------------------------------------------------------ backward
@@ -334,16 +413,13 @@ class DasmHead:
         call("sed_gemm_f32", dlogits, ctx["xs"], None, None, de, None, Q, Dd, T, Q, Dd, Dd, 1, 1, B, T * Q, T * Dd, Q * Dd, 0, 0, 1, 0.0, 0, 0)
         dxs = E(B * T, Dd)
         call("sed_gemm_f32", dlogits, ctx["e"], None, None, dxs, None, T, Dd, Q, Q, Dd, Dd, 0, 1, B, T * Q, Q * Dd, T * Dd, 0, 0, 1, 0.0, 0, 0)
-        dx_dec = self._lin_bwd(dxs, ctx["x_dec"], "sed_head", G, B * T, need_dx=need_dxdec)
+        dx_dec = self._lin_bwd2(ctx["c_sh"], dxs, G, B * T, need_dx=need_dxdec)
         # ---- mask embedding MLP (3 layers), tagging MLP (2 layers) -> d mask_feat
-        d = self._lin_bwd(de, ctx["e2"], "mask_embedding_layer.layers.2", G, M)
-        call("sed_gelu_bwd_f32", d, ctx["e2p"], d, M * Dd, 0.0, 0, 0)
-        d = self._lin_bwd(d, ctx["e1"], "mask_embedding_layer.layers.1", G, M)
-        call("sed_gelu_bwd_f32", d, ctx["e1p"], d, M * Dd, 0.0, 0, 0)
-        dmf = self._lin_bwd(d, ctx["mask_feat"], "mask_embedding_layer.layers.0", G, M)
-        d = self._lin_bwd(dat_logit, ctx["h_a"], "at_head.layers.1", G, M)
-        call("sed_gelu_bwd_f32", d, ctx["hpre_a"], d, M * Dd, 0.0, 0, 0)
-        dx = self._lin_bwd(d, ctx["mask_feat"], "at_head.layers.0", G, M, res=dmf)
+        d = self._lin_bwd2(ctx["c_e2"], de, G, M)
+        d = self._lin_bwd2(ctx["c_e1"], d, G, M)
+        dmf = self._lin_bwd2(ctx["c_e0"], d, G, M)
+        d = self._lin_bwd2(ctx["c_a1"], dat_logit, G, M)
+        dx = self._lin_bwd2(ctx["c_a0"], d, G, M, res=dmf)
         # ---- decoder layers, top down
         ldkv = 2 * L * Dd
         dKV = E(B * Pn, ldkv)
@@ -351,43 +427,29 @@ class DasmHead:
         for l in range(L - 1, -1, -1):
             pre = f"at_decoder.decoder.layers.{l}."
             c = ctx["layers"][l]
-            Dff = c["h"].shape[1]
             # x = norm3(x2 + dropout3(linear2(dropout(gelu(linear1(x2))))))
             dy3 = E(M, Dd)
             call("sed_layernorm_bwd", dx, c["y3"], c["m3"], c["r3"], P(pre + "norm3.weight"), 1.0, dy3, 0, G(pre + "norm3.weight"), G(pre + "norm3.bias"), M, Dd)
-            dff = dy3
-            if pdrop > 0:
-                dff = E(M, Dd)
-                call("sed_dropout_f32", dy3, dff, None, M * Dd, *D_(8 * l + 5))
-            dh_ = self._lin_bwd(dff, c["h"], pre + "linear2", G, M)
-            call("sed_gelu_bwd_f32", dh_, c["hpre"], dh_, M * Dff, *(D_(8 * l + 4) if pdrop > 0 else NO_DROP))
-            dx2 = self._lin_bwd(dh_, c["x2"], pre + "linear1", G, M, res=dy3)
+            dh_ = self._lin_bwd2(c["c_l2"], dy3, G, M)
+            dx2 = self._lin_bwd2(c["c_l1"], dh_, G, M, res=dy3)
             # x2 = norm2(x1 + dropout1(out_proj(self_attention(in_proj(x1)))))
             dy2 = E(M, Dd)
             call("sed_layernorm_bwd", dx2, c["y2"], c["m2"], c["r2"], P(pre + "norm2.weight"), 1.0, dy2, 0, G(pre + "norm2.weight"), G(pre + "norm2.bias"), M, Dd)
-            do = dy2
-            if pdrop > 0:
-                do = E(M, Dd)
-                call("sed_dropout_f32", dy2, do, None, M * Dd, *D_(8 * l + 3))
-            dosf = self._lin_bwd(do, c["osf"], pre + "self_attn.out_proj", G, M)
+            dosf = self._lin_bwd2(c["c_os"], dy2, G, M)
             dqkv = E(M, 3 * Dd)
             qkv = c["qkv"]
             call("sed_xattn_f32_bwd", qkv, qkv.data_ptr() + 4 * Dd, qkv.data_ptr() + 8 * Dd, c["osf"], dosf, c["lse_s"], Dq, dqkv, dqkv.data_ptr() + 4 * Dd,
                  dqkv.data_ptr() + 8 * Dd, ctx["mask8"], B, H, Q, Q, dh, 3 * Dd, 3 * Dd, 3 * Dd, Dd, 3 * Dd, 3 * Dd, 3 * Dd, Q * 3 * Dd, *D_(8 * l + 2))
-            dx1 = self._lin_bwd(dqkv, c["x1"], pre + "self_attn.in_proj", G, M, res=dy2, w=P(pre + "self_attn.in_proj_weight"))
+            dx1 = self._lin_bwd2(c["c_qkv"], dqkv, G, M, res=dy2)
             # x1 = norm1(x_in + dropout2(out_proj(cross_attention(q(x_in), K_l, V_l))))
             dy1 = E(M, Dd)
             call("sed_layernorm_bwd", dx1, c["y1"], c["m1"], c["r1"], P(pre + "norm1.weight"), 1.0, dy1, 0, G(pre + "norm1.weight"), G(pre + "norm1.bias"), M, Dd)
-            do = dy1
-            if pdrop > 0:
-                do = E(M, Dd)
-                call("sed_dropout_f32", dy1, do, None, M * Dd, *D_(8 * l + 1))
-            doc = self._lin_bwd(do, c["oc"], pre + "multihead_attn.out_proj", G, M)
+            doc = self._lin_bwd2(c["c_oc"], dy1, G, M)
             dqc = E(M, Dd)
             kp, dkp = ctx["KV"].data_ptr() + 4 * (2 * l * Dd), dKV.data_ptr() + 4 * (2 * l * Dd)
             call("sed_xattn_f32_bwd", c["qc"], kp, kp + 4 * Dd, c["oc"], doc, c["lse_c"], Dq, dqc, dkp, dkp + 4 * Dd, None, B, H, Q, Pn, dh, Dd, ldkv, ldkv,
                  Dd, Dd, ldkv, ldkv, Q * Dd, *D_(8 * l + 0))
-            dx = self._lin_bwd(dqc, c["x_in"], pre + "multihead_attn.in_proj", G, M, res=dy1, w=P(pre + "multihead_attn.in_proj_weight"), N=Dd)
+            dx = self._lin_bwd2(c["c_q"], dqc, G, M, res=dy1)
             ctx["layers"][l] = None
         # ---- the queries: every clip saw the same projected embeddings
         dq0 = Z(Q, Dd)
