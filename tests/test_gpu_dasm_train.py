@@ -77,6 +77,13 @@ def test_gemm_f32_all_forms_vs_torch():
     torch.nn.functional.gelu(xx).backward(dy.double() * keep / (1 - p))
     assert float((o1.cpu().double() - xx.grad).abs().max()) < 2e-5
     assert float((o2.cpu().double() - dy.double() * keep / (1 - p)).abs().max()) < 1e-6
+    # GELU epilogue on non-finite pre-activations (common.h gelu_fast2): NaN stays NaN, +-inf becomes NaN -- never a finite value
+    xe = torch.zeros(64, 32); xe[0, 0] = 1.0; xe[1, 0] = float("nan"); xe[2, 0] = float("inf"); xe[3, 0] = float("-inf")
+    We = torch.zeros(64, 32); We[:, 0] = 1.0
+    oe = torch.empty(64, 64, device=DEV)
+    call("sed_gemm_f32", xe.to(DEV), We.to(DEV), None, None, oe, None, 64, 64, 32, 32, 32, 64, 0, 0, 1, 0, 0, 0, 1, 0, 1, 0.0, 0, 0)
+    oe = oe.cpu()
+    assert abs(float(oe[0, 0]) - 0.8413447) < 1e-5 and bool(torch.isnan(oe[1:4, 0]).all()) and bool(torch.isfinite(oe[4:]).all())
     # column sums (+=)
     xm = R(333, 1000)
     acc = torch.ones(1000, device=DEV)

@@ -96,6 +96,10 @@ __device__ __forceinline__ f32x2v gelu_tail2(f32x2v a) {   // Q(a) = upper-tail 
     return f32x2v{__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
 }
 __device__ __forceinline__ f32x2v gelu_fast2(f32x2v x) {
+    // Non-finite inputs: NaN -> NaN (a = NaN poisons the tail term), and +-inf -> NaN as well (inf * 2^-inf = inf * 0), where the erf form
+    // gave +inf / -0.  An infinite pre-activation is an already diverged run, and NaN is the louder of the two signals; clamping |x| for the
+    // tail term (one v_min per element in the hottest epilogue of the model) would also swallow NaN inputs (fmin(NaN, 14) = 14).  Kernel test:
+    // tests/test_gpu_dasm_train.py::test_gemm_f32_all_forms_vs_torch.
     const f32x2v a = {fabsf(x.x), fabsf(x.y)};
     const f32x2v q = gelu_tail2(a);
     const f32x2v r = {fmaxf(x.x, 0.0f), fmaxf(x.y, 0.0f)};

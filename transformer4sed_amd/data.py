@@ -317,7 +317,9 @@ class RankShardedBatchSampler(ConcatDatasetBatchSampler):
 
     def state_dict(self):
         """{"epoch": next pass's epoch}: MatSedTrainer.state_dict() stores it when the trainer was given the sampler (`trainer.sampler`),
-        so a resumed run continues the batch order instead of replaying epoch 0."""
+        so a resumed run continues the batch order instead of replaying epoch 0.  Resume granularity is ONE EPOCH: a checkpoint taken in the
+        middle of a pass resumes with the NEXT permutation, the rest of the interrupted pass is not replayed (no position inside the epoch is
+        kept -- the reference, which checkpoints weights only at epoch ends, has no mid-epoch resume either: recipes/desed/finetune/passt/main.py:82-96)."""
         return {"epoch": int(self.epoch)}
 
     def load_state_dict(self, sd):
@@ -473,21 +475,24 @@ class WavBatchStream:
         q = queue.Queue(maxsize=self.depth - 1)
         stop = threading.Event()
 
+        def put(item):      # every hand-over -- batches, the end sentinel, an exception -- gives up once the consumer has left
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return
+                except queue.Full:
+                    pass
+
         def run():
             try:
                 for k, idx in enumerate(self.batches):
                     if stop.is_set():
                         return
                     item = self._produce(k, list(idx))
-                    while not stop.is_set():
-                        try:
-                            q.put(item, timeout=0.1)
-                            break
-                        except queue.Full:
-                            pass
-                q.put(None)
+                    put(item)
+                put(None)
             except BaseException as e:      # surfaces in the consumer
-                q.put(e)
+                put(e)
         thr = threading.Thread(target=run, daemon=True)
         thr.start()
         try:
@@ -508,3 +513,15 @@ class WavBatchStream:
 
     def __len__(self):
         return len(self.batches)
+
+    def close(self):
+        """Shut the reader threads down and drop the pinned staging blocks (also the context manager's exit)."""
+        self.pool.shutdown(wait=True, cancel_futures=True)
+        self._slots = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False

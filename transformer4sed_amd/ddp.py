@@ -62,6 +62,8 @@ def broadcast_buffers(net, src=0, group=None):
 
 
 class GradBucketReducer:
+    _budget_owner = None      # the reducer whose CU reservation is in force (process-global setting)
+
     def __init__(self, net, optimizer, group=None, min_bytes=8 << 20, comm_dtype=None, reserve_cus=None):
         """`comm_dtype`: torch.float32 (default) exchanges the fp32 arena slices in place; torch.bfloat16 exchanges a bf16 image of every
         slice -- half the bytes on the xGMI links (200 MB instead of 400 MB per finetune2 step) for one rounding of the
@@ -94,6 +96,7 @@ class GradBucketReducer:
             total = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
             call("sed_gemm_set_cu_budget", max(8, total - self.reserve_cus))
             self._budget_set = True
+            GradBucketReducer._budget_owner = self
         # a stage whose slices are smaller than this is not worth a collective of its own: it is carried to the next stage hook (or
         # to the end of backward) and merged with adjacent slices there
         self.min_elems = min_bytes // 4
@@ -217,10 +220,11 @@ class GradBucketReducer:
     def close(self):
         """Give the GEMMs their full grid back (the CU budget is process-global: a reducer that reserved CUs for the collectives must not
         leave validation-only or single-GPU code of the same process on the reduced grid) and detach from the model."""
-        if self._budget_set:
+        if self._budget_set and GradBucketReducer._budget_owner is self:      # (only the reducer that made the current reservation undoes it)
             from .ops import call
             call("sed_gemm_set_cu_budget", 0)
-            self._budget_set = False
+            GradBucketReducer._budget_owner = None
+        self._budget_set = False
         if getattr(self.net, "_grad_ready_hook", None) == self.on_stage:
             self.net._grad_ready_hook = None
 
@@ -232,8 +236,12 @@ class GradBucketReducer:
         return False
 
     def __del__(self):
+        # No launch from a finaliser: the CU budget is process-global, and a reducer collected after its successor was constructed would wipe
+        # the successor's reservation (or call into the HIP library during interpreter shutdown).  `close()` / the `with` block are the way
+        # to give the CUs back; a reducer that is simply dropped only detaches its hook.
         try:
-            self.close()
+            if getattr(self.net, "_grad_ready_hook", None) == self.on_stage:
+                self.net._grad_ready_hook = None
         except Exception:
             pass
 
