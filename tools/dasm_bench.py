@@ -39,10 +39,9 @@ for Q in QS:
     ops.TIMER = None
     torch.cuda.synchronize()
     per = {k: (v["launches"], v["ms"]) for k, v in timer.summarize().items()}
-    # fp32 FLOPs of the GEMMs: memory projection + query-side linears + einsum
-    Dd, L, P, T = 768, 2, 1188, 1000
-    # (the memory projection B P x 2 L Dd x 768 = %.1f GFLOP runs as a split-precision f16 GEMM, `sed_gemm_nt`: not in this figure)
-    fl = 2.0 * Q * 1024 * Dd + L * 2.0 * B * Q * Dd * Dd * 8 + 2.0 * B * Q * Dd * Dd * 4 + 2.0 * B * Q * Dd \
-        + 2.0 * B * T * Dd * Dd + 2.0 * B * T * Q * Dd
-    print(f"B={B} Q={Q:4d}  head forward {ms:7.3f} ms   " + "  ".join(f"{k.replace('sed_', '')} x{v[0]} {v[1]:.3f} ms" for k, v in per.items())
-          + f"   fp32 GEMMs {fl / 1e9:.1f} GFLOP -> {fl / (per['sed_gemm_f32'][1] * 1e-3) / 1e12:.1f} TFLOP/s (fp32-MFMA peak 157.3)")
+    # (round 6: Linears with >= 1024 rows run as split-precision 16-bit GEMMs, `sed_split3_f16` + `sed_gemm_nt`; what is left on `sed_gemm_f32` is
+    # the query projector, the per-clip einsum and the small heads -- no single "fp32 GEMM rate" describes the mix any more, bench.py's
+    # `roofline_f32` reports the fp32-MFMA launches of a whole step)
+    rest = ms - sum(v[1] for v in per.values())
+    print(f"B={B} Q={Q:4d}  head forward {ms:7.3f} ms wall   " + "  ".join(f"{k.replace('sed_', '')} x{v[0]} {v[1]:.3f} ms" for k, v in per.items())
+          + f"   not in the timed entry points (elementwise launches, host issue time): {rest:.3f} ms")
