@@ -67,7 +67,17 @@ def test_xattn_f32_vs_torch():
         out = torch.empty(B, Nq, D, device=DEV)
         m8 = None if mask is None else mask.to(torch.uint8).to(DEV)
         call("sed_xattn_f32_fwd", q.to(DEV), k.to(DEV), v.to(DEV), out, m8, B, H, Nq, Nk, dh, D, D, D, D, 0 if shared_q else Nq * D)
-        assert float((out.cpu().double() - want).abs().max()) < 2e-5, (B, H, Nq, Nk, dh)
+        e = float((out.cpu().double() - want).abs().max())
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/dasm_errors.log", "a") as f:
+            f.write(f"xattn fwd B={B} H={H} Nq={Nq} Nk={Nk} dh={dh}: out {e:.2e}\n")
+        assert e < 2e-5, (B, H, Nq, Nk, dh, e)
+
+
+def _log(msg):
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/dasm_errors.log", "a") as f:
+        f.write(msg + "\n")
 
 
 def test_dasm_head_vs_reference_golden(golden):
@@ -77,14 +87,16 @@ def test_dasm_head_vs_reference_golden(golden):
     sd, frame, x_dec, ext, tmask, pad = head_inputs(g)
     s, w, a, _ = head.forward(frame.to(DEV), x_dec.to(DEV), query=ext.to(DEV), tgt_mask=tmask, temp_w=0.5, pad_mask=pad)
     e = float((s.cpu() - torch.from_numpy(g["ov_strong"])).abs().max()); assert e < 1e-3, e      # BASELINE.json: 1e-3 on frame posteriors
-    assert e < 1e-4, e                                                                             # (the fp32 path holds 10x better)
-    assert float((w.cpu() - torch.from_numpy(g["ov_weak"])).abs().max()) < 1e-4
-    assert float((a.cpu() - torch.from_numpy(g["ov_at"])).abs().max()) < 1e-5
+    ew, ea = float((w.cpu() - torch.from_numpy(g["ov_weak"])).abs().max()), float((a.cpu() - torch.from_numpy(g["ov_at"])).abs().max())
+    _log(f"DASM head vs reference golden, open vocabulary T 0.5: strong {e:.2e} weak {ew:.2e} at {ea:.2e}")
+    assert e < 1e-4, e                                                                             # (the head alone holds 10x better)
+    assert ew < 1e-4 and ea < 1e-5, (ew, ea)
     assert float(s[1, :, -13:].max()) == np.float32(1e-7)
     s, w, a, _ = head.forward(frame.to(DEV), x_dec.to(DEV), temp_w=0.1)
-    assert float((s.cpu() - torch.from_numpy(g["cs_strong"])).abs().max()) < 5e-4             # temperature 0.1
-    assert float((w.cpu() - torch.from_numpy(g["cs_weak"])).abs().max()) < 1e-4
-    assert float((a.cpu() - torch.from_numpy(g["cs_at"])).abs().max()) < 1e-5
+    e, ew, ea = (float((x_.cpu() - torch.from_numpy(g[k_])).abs().max()) for x_, k_ in ((s, "cs_strong"), (w, "cs_weak"), (a, "cs_at")))
+    _log(f"DASM head vs reference golden, closed set T 0.1: strong {e:.2e} weak {ew:.2e} at {ea:.2e}")
+    assert e < 5e-4, e             # temperature 0.1
+    assert ew < 1e-4 and ea < 1e-5, (ew, ea)
 
 
 @pytest.mark.parametrize("B,Q", [(2, 16), (4, 407)])
@@ -103,8 +115,10 @@ def test_dasm_head_full_size_vs_oracle(B, Q):
     so, wo, ao, mo = dasm_oracle.dasm_head(sd, frame, x_dec, query=ext, tgt_mask=tmask, temp_w=0.5, pad_mask=pad, n_layers=2)
     s, w, a, m = head.forward(frame.to(DEV), x_dec.to(DEV), query=ext.to(DEV), tgt_mask=tmask, temp_w=0.5, pad_mask=pad)
     assert s.shape == (B, Q, T)
-    assert float((m.cpu() - mo).abs().max()) < 1e-4
-    assert float((s.cpu() - so).abs().max()) < 1e-4 and float((w.cpu() - wo).abs().max()) < 1e-4 and float((a.cpu() - ao).abs().max()) < 1e-5
+    em, es, ew, ea = (float((x_.cpu() - y_).abs().max()) for x_, y_ in ((m, mo), (s, so), (w, wo), (a, ao)))
+    _log(f"DASM head full size B={B} Q={Q} vs oracle: mask_feat {em:.2e} strong {es:.2e} weak {ew:.2e} at {ea:.2e}")
+    assert em < 1e-4, em
+    assert es < 1e-4 and ew < 1e-4 and ea < 1e-5, (es, ew, ea)
 
 
 def test_dasm_full_model_vs_reference(golden):

@@ -26,6 +26,13 @@ def relerr(got, want):
     return float((got.cpu().double() - want).norm() / want.norm().clamp_min(1e-30))
 
 
+def logerr(msg):
+    """measured errors of the precision-relevant asserts -> gpurun_out/dasm_errors.log (margins of the split-precision attention products)"""
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/dasm_errors.log", "a") as f:
+        f.write(msg + "\n")
+
+
 def keep_mask(n, p, seed, site):
     from transformer4sed_amd.ops import call
     m = torch.empty(n, dtype=torch.uint8, device=DEV)
@@ -139,11 +146,18 @@ def test_xattn_f32_train_fwd_bwd_vs_torch_autograd(B, H, Nq, Nk, dh, masked, p):
         call("sed_xattn_f32_fwd_train", q.to(DEV), k.to(DEV), v.to(DEV), out, m8, lse, B, H, Nq, Nk, dh, D, D, D, D, Nq * D, p, seed, site)
         call("sed_xattn_f32_bwd", q.to(DEV), k.to(DEV), v.to(DEV), out, dO.to(DEV), lse, Dq, dq, dk, dv, m8, B, H, Nq, Nk, dh, D, D, D, D, D, D, D, Nq * D,
              p, seed, site)
-    assert float((out.cpu().double() - want.detach()).abs().max()) < 3e-5
+    e_out = float((out.cpu().double() - want.detach()).abs().max())
     lse_want = torch.logsumexp(s.detach(), -1) * 1.4426950408889634
-    assert float((lse.view(B, H, Nq).cpu().double() - lse_want).abs().max()) < 1e-4
-    for name, got, ref in (("dq", dq, qd.grad), ("dk", dk, kd.grad), ("dv", dv, vd.grad)):
-        assert relerr(got, ref) < 1e-5, (name, relerr(got, ref))
+    e_lse = float((lse.view(B, H, Nq).cpu().double() - lse_want).abs().max())
+    e_g = {name: relerr(got, ref) for name, got, ref in (("dq", dq, qd.grad), ("dk", dk, kd.grad), ("dv", dv, vd.grad))}
+    logerr(f"xattn train B={B} H={H} Nq={Nq} Nk={Nk} dh={dh} masked={masked} p={p}: out {e_out:.2e} lse {e_lse:.2e} " + " ".join(f"{k} {v:.2e}" for k, v in e_g.items()))
+    # Three-term split-precision products (csrc/dasm.hip XA_SPLIT16): the forward's q, k, v, P as IEEE-half pairs (2^-22 per product), everything
+    # that carries a gradient as bf16 pairs (2^-17 = 7.6e-6 per product, fp32 accumulation) -- bounds at ~3x the measured values, three
+    # orders of magnitude inside the model-level parity bounds they feed (1e-3 posteriors, 3e-3 gradient norms)
+    assert e_out < 3e-5, e_out
+    assert e_lse < 1e-4, e_lse
+    for name, e in e_g.items():
+        assert e < 3e-5, (name, e)
 
 
 def test_dasm_head_finish_bwd_and_sup_loss_vs_torch():

@@ -236,7 +236,9 @@ def _trainer_worker(rank, world, port, kind, q):
             trainer.cfg["training"]["batch_size"] = [2, 0, 2, 2]
             labels = torch.from_numpy(synth.synth_batch_labels(2, 2, 2, seed=60 + rank)).to(dev)
             step = lambda wav: trainer.finetune_step(wav, labels.clone())
-            assert trainer.overlap_teacher      # the teacher's windows run on the second stream (and the dW GEMMs on the side stream)
+            # the teacher's windows run on the second stream (and the dW GEMMs on the side stream) -- unless the single-stream profiling
+            # switch of tools/nondefault_suite.sh turned that off for this run
+            assert trainer.overlap_teacher or os.environ.get("SED_OVERLAP_TEACHER") == "0"
         elif kind == "dasm":      # DASMTrainer.train (row (g)): query decoder + dual-stream head gradients ride the "decoder" stage
             B = 3
             net, opt, trainer = bench.build_dasm_train(DEPTH, dev, 12)

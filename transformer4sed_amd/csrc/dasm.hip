@@ -229,6 +229,43 @@ extern "C" int sed_gemm_f32_nt(const float* A, const float* B, const float* bias
 // ---------------------------------------------------------------------------------------------------------------------
 #define XA_WAVES 4
 #define XA_KT 32
+// Round 6 (second half): every product of the three attention kernels as a THREE-TERM split-precision product on the 16-bit matrix pipe,
+//   x y ~ xh yh + xl yh + xh yl,   xh = rn16(x), xl = rn16(x - xh),   fp32 accumulation (v_mfma_f32_32x32x16_{f16,bf16}: same accumulator
+// layout as the fp32 instruction, a lane half supplies EIGHT consecutive k values instead of one) -- 12 x 32 issue cycles per 32 x 32 x 64
+// product instead of 32 x 64, for ~16 vector instructions per operand octet.  The dropped term xl yl is 2^-22 of the product with IEEE-half
+// pairs (scores and probabilities: q, k, v, P -- O(1) values) and 2^-17 with bf16 pairs (everything that carries a gradient: dO, dS, the
+// dropped probabilities they meet, and the tile rows of the products that contract over the streamed rows -- bf16 keeps the fp32 exponent
+// range, loss-scaled gradients of 1e-8 survive).  The forward's S and the backward's recomputed S use the same operand split and the same
+// accumulation order, so P is reproduced exactly in the query-stationary pass.  -DXA_SPLIT16=0 builds the fp32-MFMA form (A/B, tests).
+#ifndef XA_SPLIT16
+#define XA_SPLIT16 1
+#endif
+template <bool F16> __device__ __forceinline__ void xa_split8(const float (&x)[8], s16x8_t& hi, s16x8_t& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = pack2<F16>(x[2 * i], x[2 * i + 1]);
+        l[i] = pack2<F16>(x[2 * i] - to_f32<F16>((bf16_t)(h[i] & 0xffffu)), x[2 * i + 1] - to_f32<F16>((bf16_t)(h[i] >> 16)));
+    }
+    hi = __builtin_bit_cast(s16x8_t, make_uint4(h[0], h[1], h[2], h[3]));
+    lo = __builtin_bit_cast(s16x8_t, make_uint4(l[0], l[1], l[2], l[3]));
+}
+// c += (ah + al) (bh + bl) without the al bl term; A rows / B columns as in mfma32t
+template <bool F16> __device__ __forceinline__ f32x16_t xa_mfma3(s16x8_t ah, s16x8_t al, s16x8_t bh, s16x8_t bl, f32x16_t c) {
+    c = mfma32t<F16>(ah, bh, c);
+    c = mfma32t<F16>(al, bh, c);
+    return mfma32t<F16>(ah, bl, c);
+}
+// eight consecutive floats of a tile row (16-byte aligned) / eight elements of one tile COLUMN at the rows a lane's accumulator registers
+// 8 m .. 8 m + 7 stand for
+__device__ __forceinline__ void xa_row8(const float* p, float (&x)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+}
+template <int LDK_> __device__ __forceinline__ void xa_col8(const float* tile, int m, int lg, int col, float (&x)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = tile[mfma32_row(8 * m + i, lg) * LDK_ + col];
+}
 struct XaDrop {      // attention-probability dropout of one site (torch.nn.MultiheadAttention(dropout=p) in train mode); thr 0 = off
     unsigned thr, sid;
     float scale;
@@ -249,6 +286,20 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_fwd_kernel(const f
     const int qi = blockIdx.x * 32 + lq;
     const int qc = qi < Nq ? qi : Nq - 1;
     const float sc = 1.4426950408889634f * rsqrtf((float)DH);
+#if XA_SPLIT16
+    // B operand of the score product: lane half lg holds d = 16 jb + 8 lg .. + 7 of its query's (pre-scaled) row as an IEEE-half hi / lo pair
+    s16x8_t qh[DH / 16], ql[DH / 16];
+    {
+        const float* qp = Q + (size_t)b * q_bstride + (size_t)qc * ldq + h * DH + 8 * lg;
+#pragma unroll
+        for (int jb = 0; jb < DH / 16; ++jb) {
+            float x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = qp[16 * jb + i] * sc;
+            xa_split8<true>(x, qh[jb], ql[jb]);
+        }
+    }
+#else
     // B operand of the score product: Q[q][2 j + g], j = 0 .. DH / 2 - 1
     float qf[DH / 2];
     {
@@ -259,6 +310,7 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_fwd_kernel(const f
 #pragma unroll
         for (int j = 0; j < DH / 2; ++j) qf[j] = qp[j] * sc;
     }
+#endif
     f32x16 o[NDB];
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
@@ -289,6 +341,17 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_fwd_kernel(const f
         f32x16 st, st1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { st[r] = 0.f; st1[r] = 0.f; }
+#if XA_SPLIT16
+#pragma unroll
+        for (int jb = 0; jb < DH / 16; ++jb) {      // two accumulator chains, even / odd k blocks (the backward recomputes S in this order)
+            float kx[8];
+            xa_row8(Ks + lq * LDK + 16 * jb + 8 * lg, kx);
+            s16x8_t kh, kl;
+            xa_split8<true>(kx, kh, kl);
+            if (jb & 1) st1 = xa_mfma3<true>(kh, kl, qh[jb], ql[jb], st1);
+            else st = xa_mfma3<true>(kh, kl, qh[jb], ql[jb], st);
+        }
+#else
 #pragma unroll
         for (int j = 0; j < DH / 2; j += 4) {      // two accumulator chains (a dependent MFMA waits out the previous one's 16 passes)
             const float4 k4 = *reinterpret_cast<const float4*>(Ks + lq * LDK + (DH / 2) * lg + j);
@@ -297,6 +360,7 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_fwd_kernel(const f
             st = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.z, qf[j + 2], st, 0, 0, 0);
             st1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, qf[j + 3], st1, 0, 0, 0);
         }
+#endif
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] += st1[r];
         // ---- online softmax over the lane's 16 keys (register r <-> key j0 + mfma32_row(r, lg)) and the other half's 16
@@ -342,12 +406,32 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_fwd_kernel(const f
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
         // ---- O^T[d, q] += V^T[d, key] P^T[key, q]: k step r = the key pair (row(r, 0), row(r, 1)); A = V[row(r, lg)][32 db + lq], B = st[r]
+#if XA_SPLIT16
+        // (k block m = the keys of the lane's accumulator registers 8 m .. 8 m + 7: B = those registers as a half pair, A = V[key][32 db + lq])
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            float px[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) px[i] = st[8 * m + i];
+            s16x8_t ph, pl;
+            xa_split8<true>(px, ph, pl);
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                float vx[8];
+                xa_col8<LDK>(Vs, m, lg, lq + 32 * db, vx);
+                s16x8_t vh, vl;
+                xa_split8<true>(vx, vh, vl);
+                o[db] = xa_mfma3<true>(vh, vl, ph, pl, o[db]);
+            }
+        }
+#else
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float* vrow = Vs + mfma32_row(r, lg) * LDK + lq;
 #pragma unroll
             for (int db = 0; db < NDB; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32 * db], st[r], o[db], 0, 0, 0);
         }
+#endif
     }
     // ---- merge the four waves' partial results: slot [wave][query][DH + 2]; lane (q, g) owns d = 32 db + mfma32_row(r, g)
     __syncthreads();
@@ -465,9 +549,38 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_bwd_kernel(const f
     const float* ob = O + (size_t)b * Nq * ldo + h * DH;
     const float* dob = dO + (size_t)b * Nq * ldo + h * DH;
     const size_t statbase = ((size_t)b * Hn + h) * Nq;
+    float lse_c = 0.f, D_c = 0.f;
+#if XA_SPLIT16
+    // stationary operands, lane half lg = elements 16 jb + 8 lg .. + 7 of the column's row: fa (score product, IEEE-half pair, pre-scaled like the
+    // forward's) and fb (dO V^T product, bf16 pair)
+    s16x8_t fah[DH / 16], fal[DH / 16], fbh[DH / 16], fbl[DH / 16];
+    {
+        const float *pa, *pb;
+        if (MODE == 0) { pa = qb + (size_t)cc * ldq + 8 * lg; pb = dob + (size_t)cc * ldo + 8 * lg; }
+        else { pa = kb + (size_t)cc * ldk + 8 * lg; pb = vb + (size_t)cc * ldv + 8 * lg; }
+        const float* op = ob + (size_t)cc * ldo + 8 * lg;
+        float part = 0.f;
+#pragma unroll
+        for (int jb = 0; jb < DH / 16; ++jb) {
+            float xa[8], xb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                xa[i] = pa[16 * jb + i] * sc;
+                xb[i] = pb[16 * jb + i];
+                if (MODE == 0) part = fmaf(xb[i], op[16 * jb + i], part);
+            }
+            xa_split8<true>(xa, fah[jb], fal[jb]);
+            xa_split8<false>(xb, fbh[jb], fbl[jb]);
+        }
+        if (MODE == 0) {
+            D_c = part + __shfl_xor(part, 32, 64);
+            lse_c = lse[statbase + cc];
+            if (wave == 0 && lg == 0 && c < Nq && Dq != nullptr) Dq[statbase + c] = D_c;
+        }
+    }
+#else
     // stationary operands: fa[j] feeds the score product, fb[j] the dO V^T product (element 2 j + lg of the column's row)
     float fa[DH / 2], fb[DH / 2];
-    float lse_c = 0.f, D_c = 0.f;
     if (MODE == 0) {
         const float* qp = qb + (size_t)cc * ldq + (DH / 2) * lg;      // (k step j of lane half lg <-> d = (DH / 2) lg + j, as in the forward)
         const float* dp_ = dob + (size_t)cc * ldo + (DH / 2) * lg;
@@ -488,6 +601,7 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_bwd_kernel(const f
 #pragma unroll
         for (int j = 0; j < DH / 2; ++j) { fa[j] = kp[j] * sc; fb[j] = vp[j]; }
     }
+#endif
     f32x16 acc0[NDB], acc1[NDB];      // MODE 0: acc0 = dQ^T;  MODE 1: acc0 = dK^T, acc1 = dV^T   ([d, column])
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
@@ -526,6 +640,27 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_bwd_kernel(const f
         f32x16 st, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#if XA_SPLIT16
+        {
+            f32x16 st1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st1[r] = 0.f;
+#pragma unroll
+            for (int jb = 0; jb < DH / 16; ++jb) {      // S exactly as the forward computes it (even / odd k blocks on two chains); dP on bf16 pairs
+                float ax[8], bx[8];
+                xa_row8(T0 + lq * LDK + 16 * jb + 8 * lg, ax);
+                xa_row8(T1 + lq * LDK + 16 * jb + 8 * lg, bx);
+                s16x8_t ah, al, bh_, bl_;
+                xa_split8<true>(ax, ah, al);
+                xa_split8<false>(bx, bh_, bl_);
+                if (jb & 1) st1 = xa_mfma3<true>(ah, al, fah[jb], fal[jb], st1);
+                else st = xa_mfma3<true>(ah, al, fah[jb], fal[jb], st);
+                dp = xa_mfma3<false>(bh_, bl_, fbh[jb], fbl[jb], dp);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] += st1[r];
+        }
+#else
 #pragma unroll
         for (int j = 0; j < DH / 2; j += 4) {      // two independent accumulator chains, interleaved; 16-byte operand reads
             const float4 a4 = *reinterpret_cast<const float4*>(T0 + lq * LDK + (DH / 2) * lg + j);
@@ -539,6 +674,7 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_bwd_kernel(const f
             st = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, fa[j + 3], st, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b4.w, fb[j + 3], dp, 0, 0, 0);
         }
+#endif
         // dropout bits of the tile's 16 elements of this lane, as a mask (bit r = keep).  Four consecutive keys share one hash (drop_hash4):
         // in MODE 0 they are four consecutive registers of the lane; in MODE 1 (a lane = one key, registers = queries) the four lanes of a
         // quad hold the four keys of a group -- each lane hashes the rows r = 4 i + (lane & 3) and the quad exchanges them (DPP quad_perm)
@@ -601,6 +737,31 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_bwd_kernel(const f
             st[r] = pr * (dpv - Dr);      // dS (before the 1 / sqrt(dh) of the score scale)
             dp[r] = pd;                   // dropped probabilities: B operand of dV
         }
+#if XA_SPLIT16
+        // products that contract over the streamed rows, bf16 pairs: k block m = the rows of the lane's accumulator registers 8 m .. 8 m + 7
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            float sx[8], px[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { sx[i] = st[8 * m + i]; px[i] = dp[8 * m + i]; }
+            s16x8_t sh, sl, ph, pl;
+            xa_split8<false>(sx, sh, sl);
+            if (MODE == 1) xa_split8<false>(px, ph, pl);
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) {
+                float ax[8];
+                xa_col8<LDK>(T0, m, lg, lq + 32 * db, ax);
+                s16x8_t ah, al;
+                xa_split8<false>(ax, ah, al);
+                acc0[db] = xa_mfma3<false>(ah, al, sh, sl, acc0[db]);     // dQ += dS K   /  dK += dS^T Q
+                if (MODE == 1) {
+                    xa_col8<LDK>(T1, m, lg, lq + 32 * db, ax);
+                    xa_split8<false>(ax, ah, al);
+                    acc1[db] = xa_mfma3<false>(ah, al, ph, pl, acc1[db]);      // dV += Pd^T dO
+                }
+            }
+        }
+#else
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float* a0 = T0 + mfma32_row(r, lg) * LDK + lq;
@@ -611,6 +772,7 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_bwd_kernel(const f
                 if (MODE == 1) acc1[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[32 * db], dp[r], acc1[db], 0, 0, 0);      // dV += Pd^T dO
             }
         }
+#endif
     }
     // ---- add the four waves' partial sums: slot [wave][column][MS]; lane (column, g) owns d = 32 db + mfma32_row(r, g)
     __syncthreads();
