@@ -236,10 +236,9 @@ extern "C" int sed_gemm_f32_nt(const float* A, const float* B, const float* bias
 // pairs (scores and probabilities: q, k, v, P -- O(1) values) and 2^-17 with bf16 pairs (everything that carries a gradient: dO, dS, the
 // dropped probabilities they meet, and the tile rows of the products that contract over the streamed rows -- bf16 keeps the fp32 exponent
 // range, loss-scaled gradients of 1e-8 survive).  The forward's S and the backward's recomputed S use the same operand split and the same
-// accumulation order, so P is reproduced exactly in the query-stationary pass.  -DXA_SPLIT16=0 builds the fp32-MFMA form (A/B, tests).
-#ifndef XA_SPLIT16
-#define XA_SPLIT16 1
-#endif
+// accumulation order, so P is reproduced exactly in the query-stationary pass.  The fp32-input-MFMA form these kernels had until then
+// (v_mfma_f32_32x32x2_f32, exact fp32 products) measured 334 / 457 / 955 us for forward / query-stationary / key-stationary backward at the
+// dasm_train shape (24 clips, 407 queries over 1188 tokens) against 258 / 303 / 630 now; it is in the history (commit 661841a), not in the tree.
 template <bool F16> __device__ __forceinline__ void xa_split8(const float (&x)[8], s16x8_t& hi, s16x8_t& lo) {
     unsigned h[4], l[4];
 #pragma unroll
@@ -266,6 +265,28 @@ template <int LDK_> __device__ __forceinline__ void xa_col8(const float* tile, i
 #pragma unroll
     for (int i = 0; i < 8; ++i) x[i] = tile[mfma32_row(8 * m + i, lg) * LDK_ + col];
 }
+// A wave's next pair of tile half-rows on its way from global memory to LDS: N4 = DH / 8 float4 of each tile per lane.  Named members, not
+// arrays: a loop-carried float4 array that is assigned under a condition is left in scratch memory by the compiler (global load ->
+// scratch store -> scratch load -> LDS store, with the load's latency waited out at once -- measured in the first version of the prefetch).
+struct XaTileRegs { f32x4_t a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7; };      // (native vectors: a HIP float4 assignment from global memory is a memcpy the optimiser does not split)
+template <int N4> __device__ __forceinline__ void xa_regs_gload(XaTileRegs& r, const float* g0, const float* g1) {
+    const f32x4_t *p0 = reinterpret_cast<const f32x4_t*>(g0), *p1 = reinterpret_cast<const f32x4_t*>(g1);
+    r.a0 = p0[0]; r.a1 = p0[1]; r.a2 = p0[2]; r.a3 = p0[3];
+    r.b0 = p1[0]; r.b1 = p1[1]; r.b2 = p1[2]; r.b3 = p1[3];
+    if constexpr (N4 == 8) {
+        r.a4 = p0[4]; r.a5 = p0[5]; r.a6 = p0[6]; r.a7 = p0[7];
+        r.b4 = p1[4]; r.b5 = p1[5]; r.b6 = p1[6]; r.b7 = p1[7];
+    }
+}
+template <int N4> __device__ __forceinline__ void xa_regs_lstore(const XaTileRegs& r, float* t0, float* t1) {
+    f32x4_t *q0 = reinterpret_cast<f32x4_t*>(t0), *q1 = reinterpret_cast<f32x4_t*>(t1);
+    q0[0] = r.a0; q0[1] = r.a1; q0[2] = r.a2; q0[3] = r.a3;
+    q1[0] = r.b0; q1[1] = r.b1; q1[2] = r.b2; q1[3] = r.b3;
+    if constexpr (N4 == 8) {
+        q0[4] = r.a4; q0[5] = r.a5; q0[6] = r.a6; q0[7] = r.a7;
+        q1[4] = r.b4; q1[5] = r.b5; q1[6] = r.b6; q1[7] = r.b7;
+    }
+}
 struct XaDrop {      // attention-probability dropout of one site (torch.nn.MultiheadAttention(dropout=p) in train mode); thr 0 = off
     unsigned thr, sid;
     float scale;
@@ -286,7 +307,6 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_fwd_kernel(const f
     const int qi = blockIdx.x * 32 + lq;
     const int qc = qi < Nq ? qi : Nq - 1;
     const float sc = 1.4426950408889634f * rsqrtf((float)DH);
-#if XA_SPLIT16
     // B operand of the score product: lane half lg holds d = 16 jb + 8 lg .. + 7 of its query's (pre-scaled) row as an IEEE-half hi / lo pair
     s16x8_t qh[DH / 16], ql[DH / 16];
     {
@@ -299,18 +319,6 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_fwd_kernel(const f
             xa_split8<true>(x, qh[jb], ql[jb]);
         }
     }
-#else
-    // B operand of the score product: Q[q][2 j + g], j = 0 .. DH / 2 - 1
-    float qf[DH / 2];
-    {
-        // k step j of lane half lg contracts d = (DH / 2) lg + j: a lane's A-operand values of consecutive k steps are CONTIGUOUS in the tile
-        // row -- 16-byte LDS reads, conflict-free at the DH + 4 row pitch (the 2 j + lg interleave read single words 4-way conflicted: 53-80 %
-        // of the kernels' LDS cycles, profiles/r6_dasm_pmc.json)
-        const float* qp = Q + (size_t)b * q_bstride + (size_t)qc * ldq + h * DH + (DH / 2) * lg;
-#pragma unroll
-        for (int j = 0; j < DH / 2; ++j) qf[j] = qp[j] * sc;
-    }
-#endif
     f32x16 o[NDB];
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
@@ -321,48 +329,35 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_fwd_kernel(const f
     const float* vb = Vp + (size_t)b * Nk * ldv + h * DH;
     // tile loader: lane -> (key row lane >> 1, half row lane & 1): DH / 2 floats = DH / 8 float4 of K and of V
     const int trow = lane >> 1, thalf = (lane & 1) * (DH / 2);
+    // The wave's NEXT tile is in flight (in registers) while the current one is computed: with the products on the 16-bit pipe a tile is
+    // ~1500 issue cycles, less than one trip to L2 / HBM -- loaded at the top of its own iteration, as the fp32 form did, the kernel waits.
+    XaTileRegs tr;
+#define XA_FWD_GLOAD(J0_)                                                                                                                  \
+    {                                                                                                                                      \
+        const int j_ = ((J0_) + trow) < Nk ? ((J0_) + trow) : Nk - 1;      /* rows past the end: their scores are masked, their V rows meet p = 0 */ \
+        xa_regs_gload<DH / 8>(tr, kb + (size_t)j_ * ldk + thalf, vb + (size_t)j_ * ldv + thalf);                                            \
+    }
+    if (wave * XA_KT < Nk) XA_FWD_GLOAD(wave * XA_KT)
     for (int j0 = wave * XA_KT; j0 < Nk; j0 += XA_KT * XA_WAVES) {
         {
-            const int j = (j0 + trow) < Nk ? (j0 + trow) : Nk - 1;      // (rows past the end: their scores are masked, their V rows meet p = 0)
-            const float4* kr = reinterpret_cast<const float4*>(kb + (size_t)j * ldk + thalf);
-            const float4* vr = reinterpret_cast<const float4*>(vb + (size_t)j * ldv + thalf);
-            float4 kreg[DH / 8], vreg[DH / 8];
-#pragma unroll
-            for (int d = 0; d < DH / 8; ++d) { kreg[d] = kr[d]; vreg[d] = vr[d]; }
             __builtin_amdgcn_wave_barrier();      // (the tile buffers are private to the wave: the previous tile's reads are behind us in program order)
-#pragma unroll
-            for (int d = 0; d < DH / 8; ++d) {
-                *reinterpret_cast<float4*>(Ks + trow * LDK + thalf + 4 * d) = kreg[d];
-                *reinterpret_cast<float4*>(Vs + trow * LDK + thalf + 4 * d) = vreg[d];
-            }
+            xa_regs_lstore<DH / 8>(tr, Ks + trow * LDK + thalf, Vs + trow * LDK + thalf);
             __builtin_amdgcn_wave_barrier();
+            if (j0 + XA_KT * XA_WAVES < Nk) XA_FWD_GLOAD(j0 + XA_KT * XA_WAVES)
         }
+#undef XA_FWD_GLOAD
         // ---- S^T[key, q]: A = K[key = lq][2 j + lg]
-        f32x16 st, st1;
+        f32x16 st;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { st[r] = 0.f; st1[r] = 0.f; }
-#if XA_SPLIT16
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
-        for (int jb = 0; jb < DH / 16; ++jb) {      // two accumulator chains, even / odd k blocks (the backward recomputes S in this order)
+        for (int jb = 0; jb < DH / 16; ++jb) {      // ONE accumulator chain, k blocks in order: the backward recomputes S exactly like this
             float kx[8];
             xa_row8(Ks + lq * LDK + 16 * jb + 8 * lg, kx);
             s16x8_t kh, kl;
             xa_split8<true>(kx, kh, kl);
-            if (jb & 1) st1 = xa_mfma3<true>(kh, kl, qh[jb], ql[jb], st1);
-            else st = xa_mfma3<true>(kh, kl, qh[jb], ql[jb], st);
+            st = xa_mfma3<true>(kh, kl, qh[jb], ql[jb], st);
         }
-#else
-#pragma unroll
-        for (int j = 0; j < DH / 2; j += 4) {      // two accumulator chains (a dependent MFMA waits out the previous one's 16 passes)
-            const float4 k4 = *reinterpret_cast<const float4*>(Ks + lq * LDK + (DH / 2) * lg + j);
-            st = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.x, qf[j], st, 0, 0, 0);
-            st1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.y, qf[j + 1], st1, 0, 0, 0);
-            st = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.z, qf[j + 2], st, 0, 0, 0);
-            st1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, qf[j + 3], st1, 0, 0, 0);
-        }
-#endif
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[r] += st1[r];
         // ---- online softmax over the lane's 16 keys (register r <-> key j0 + mfma32_row(r, lg)) and the other half's 16
         float cmax = -INFINITY;
 #pragma unroll
@@ -406,7 +401,6 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_fwd_kernel(const f
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
         // ---- O^T[d, q] += V^T[d, key] P^T[key, q]: k step r = the key pair (row(r, 0), row(r, 1)); A = V[row(r, lg)][32 db + lq], B = st[r]
-#if XA_SPLIT16
         // (k block m = the keys of the lane's accumulator registers 8 m .. 8 m + 7: B = those registers as a half pair, A = V[key][32 db + lq])
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -424,14 +418,6 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_fwd_kernel(const f
                 o[db] = xa_mfma3<true>(vh, vl, ph, pl, o[db]);
             }
         }
-#else
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float* vrow = Vs + mfma32_row(r, lg) * LDK + lq;
-#pragma unroll
-            for (int db = 0; db < NDB; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32 * db], st[r], o[db], 0, 0, 0);
-        }
-#endif
     }
     // ---- merge the four waves' partial results: slot [wave][query][DH + 2]; lane (q, g) owns d = 32 db + mfma32_row(r, g)
     __syncthreads();
@@ -550,7 +536,6 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_bwd_kernel(const f
     const float* dob = dO + (size_t)b * Nq * ldo + h * DH;
     const size_t statbase = ((size_t)b * Hn + h) * Nq;
     float lse_c = 0.f, D_c = 0.f;
-#if XA_SPLIT16
     // stationary operands, lane half lg = elements 16 jb + 8 lg .. + 7 of the column's row: fa (score product, IEEE-half pair, pre-scaled like the
     // forward's) and fb (dO V^T product, bf16 pair)
     s16x8_t fah[DH / 16], fal[DH / 16], fbh[DH / 16], fbl[DH / 16];
@@ -578,30 +563,6 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_bwd_kernel(const f
             if (wave == 0 && lg == 0 && c < Nq && Dq != nullptr) Dq[statbase + c] = D_c;
         }
     }
-#else
-    // stationary operands: fa[j] feeds the score product, fb[j] the dO V^T product (element 2 j + lg of the column's row)
-    float fa[DH / 2], fb[DH / 2];
-    if (MODE == 0) {
-        const float* qp = qb + (size_t)cc * ldq + (DH / 2) * lg;      // (k step j of lane half lg <-> d = (DH / 2) lg + j, as in the forward)
-        const float* dp_ = dob + (size_t)cc * ldo + (DH / 2) * lg;
-        const float* op = ob + (size_t)cc * ldo + (DH / 2) * lg;
-        float part = 0.f;
-#pragma unroll
-        for (int j = 0; j < DH / 2; ++j) {
-            fa[j] = qp[j] * sc;
-            fb[j] = dp_[j];
-            part = fmaf(fb[j], op[j], part);
-        }
-        D_c = part + __shfl_xor(part, 32, 64);
-        lse_c = lse[statbase + cc];
-        if (wave == 0 && lg == 0 && c < Nq && Dq != nullptr) Dq[statbase + c] = D_c;
-    } else {
-        const float* kp = kb + (size_t)cc * ldk + (DH / 2) * lg;
-        const float* vp = vb + (size_t)cc * ldv + (DH / 2) * lg;
-#pragma unroll
-        for (int j = 0; j < DH / 2; ++j) { fa[j] = kp[j] * sc; fb[j] = vp[j]; }
-    }
-#endif
     f32x16 acc0[NDB], acc1[NDB];      // MODE 0: acc0 = dQ^T;  MODE 1: acc0 = dK^T, acc1 = dV^T   ([d, column])
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
@@ -609,72 +570,56 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_bwd_kernel(const f
         for (int r = 0; r < 16; ++r) { acc0[db][r] = 0.f; acc1[db][r] = 0.f; }
     const int trow = lane >> 1, thalf = (lane & 1) * (DH / 2);
     const unsigned long long bh = (unsigned long long)b * Hn + h;
+    // The wave's next tile travels in registers while the current one is computed, as in the forward -- in the query-stationary pass only: the
+    // key-stationary one (two output accumulator sets, 256 registers) has no 64 registers to spare; with the prefetch it spilled 57 of them
+    // through scratch memory, whose loads queue behind the prefetch in the same counter (630 -> 838 us; MODE 0: 343 -> 303, forward 287 -> 258).
+    constexpr bool PF = MODE == 0;
+    XaTileRegs tr;
+    float stat = 0.f;
+#define XA_BWD_GLOAD(R0_)                                                                                                                  \
+    {                                                                                                                                      \
+        const int rr_ = ((R0_) + trow) < Nrow ? ((R0_) + trow) : Nrow - 1;                                                                  \
+        const float *p0_, *p1_;                                                                                                            \
+        if (MODE == 0) {                                                                                                                   \
+            p0_ = kb + (size_t)rr_ * ldk + thalf;                                                          \
+            p1_ = vb + (size_t)rr_ * ldv + thalf;                                                          \
+        } else {                                                                                                                           \
+            p0_ = qb + (size_t)rr_ * ldq + thalf;                                                          \
+            p1_ = dob + (size_t)rr_ * ldo + thalf;                                                         \
+        }                                                                                                                                  \
+        xa_regs_gload<DH / 8>(tr, p0_, p1_);                                                                                                \
+        if (MODE == 1) {                                                                                                                   \
+            const int ri_ = ((R0_) + lq) < Nq ? ((R0_) + lq) : Nq - 1;                                                                      \
+            stat = lg == 0 ? lse[statbase + ri_] : Dq[statbase + ri_];                                                                      \
+        }                                                                                                                                  \
+    }
+    if (PF && wave * XA_KT < Nrow) XA_BWD_GLOAD(wave * XA_KT)
     for (int r0 = wave * XA_KT; r0 < Nrow; r0 += XA_KT * XA_WAVES) {
         {
-            const int rr = (r0 + trow) < Nrow ? (r0 + trow) : Nrow - 1;
-            const float4 *p0, *p1;
-            if (MODE == 0) {
-                p0 = reinterpret_cast<const float4*>(kb + (size_t)rr * ldk + thalf);
-                p1 = reinterpret_cast<const float4*>(vb + (size_t)rr * ldv + thalf);
-            } else {
-                p0 = reinterpret_cast<const float4*>(qb + (size_t)rr * ldq + thalf);
-                p1 = reinterpret_cast<const float4*>(dob + (size_t)rr * ldo + thalf);
-            }
-            float4 g0[DH / 8], g1[DH / 8];
-#pragma unroll
-            for (int d = 0; d < DH / 8; ++d) { g0[d] = p0[d]; g1[d] = p1[d]; }
-            float stat = 0.f;
-            if (MODE == 1) {
-                const int ri = (r0 + lq) < Nq ? (r0 + lq) : Nq - 1;
-                stat = lg == 0 ? lse[statbase + ri] : Dq[statbase + ri];
-            }
+            if (!PF) XA_BWD_GLOAD(r0)
             __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int d = 0; d < DH / 8; ++d) {
-                *reinterpret_cast<float4*>(T0 + trow * LDK + thalf + 4 * d) = g0[d];
-                *reinterpret_cast<float4*>(T1 + trow * LDK + thalf + 4 * d) = g1[d];
-            }
+            xa_regs_lstore<DH / 8>(tr, T0 + trow * LDK + thalf, T1 + trow * LDK + thalf);
             if (MODE == 1) rowc[lane] = stat;
             __builtin_amdgcn_wave_barrier();
+            if (PF && r0 + XA_KT * XA_WAVES < Nrow) XA_BWD_GLOAD(r0 + XA_KT * XA_WAVES)
         }
+#undef XA_BWD_GLOAD
         f32x16 st, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
-#if XA_SPLIT16
         {
-            f32x16 st1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st1[r] = 0.f;
-#pragma unroll
-            for (int jb = 0; jb < DH / 16; ++jb) {      // S exactly as the forward computes it (even / odd k blocks on two chains); dP on bf16 pairs
+            for (int jb = 0; jb < DH / 16; ++jb) {      // S exactly as the forward computes it (one chain, k blocks in order); dP on bf16 pairs
                 float ax[8], bx[8];
                 xa_row8(T0 + lq * LDK + 16 * jb + 8 * lg, ax);
                 xa_row8(T1 + lq * LDK + 16 * jb + 8 * lg, bx);
                 s16x8_t ah, al, bh_, bl_;
                 xa_split8<true>(ax, ah, al);
                 xa_split8<false>(bx, bh_, bl_);
-                if (jb & 1) st1 = xa_mfma3<true>(ah, al, fah[jb], fal[jb], st1);
-                else st = xa_mfma3<true>(ah, al, fah[jb], fal[jb], st);
+                st = xa_mfma3<true>(ah, al, fah[jb], fal[jb], st);
                 dp = xa_mfma3<false>(bh_, bl_, fbh[jb], fbl[jb], dp);
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[r] += st1[r];
         }
-#else
-#pragma unroll
-        for (int j = 0; j < DH / 2; j += 4) {      // two independent accumulator chains, interleaved; 16-byte operand reads
-            const float4 a4 = *reinterpret_cast<const float4*>(T0 + lq * LDK + (DH / 2) * lg + j);
-            const float4 b4 = *reinterpret_cast<const float4*>(T1 + lq * LDK + (DH / 2) * lg + j);
-            st = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, fa[j], st, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b4.x, fb[j], dp, 0, 0, 0);
-            st = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, fa[j + 1], st, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b4.y, fb[j + 1], dp, 0, 0, 0);
-            st = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, fa[j + 2], st, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b4.z, fb[j + 2], dp, 0, 0, 0);
-            st = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, fa[j + 3], st, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(b4.w, fb[j + 3], dp, 0, 0, 0);
-        }
-#endif
         // dropout bits of the tile's 16 elements of this lane, as a mask (bit r = keep).  Four consecutive keys share one hash (drop_hash4):
         // in MODE 0 they are four consecutive registers of the lane; in MODE 1 (a lane = one key, registers = queries) the four lanes of a
         // quad hold the four keys of a group -- each lane hashes the rows r = 4 i + (lane & 3) and the quad exchanges them (DPP quad_perm)
@@ -737,7 +682,6 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_bwd_kernel(const f
             st[r] = pr * (dpv - Dr);      // dS (before the 1 / sqrt(dh) of the score scale)
             dp[r] = pd;                   // dropped probabilities: B operand of dV
         }
-#if XA_SPLIT16
         // products that contract over the streamed rows, bf16 pairs: k block m = the rows of the lane's accumulator registers 8 m .. 8 m + 7
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -761,18 +705,6 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_bwd_kernel(const f
                 }
             }
         }
-#else
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float* a0 = T0 + mfma32_row(r, lg) * LDK + lq;
-            const float* a1 = T1 + mfma32_row(r, lg) * LDK + lq;
-#pragma unroll
-            for (int db = 0; db < NDB; ++db) {
-                acc0[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[32 * db], st[r], acc0[db], 0, 0, 0);     // dQ += dS K   /  dK += dS^T Q
-                if (MODE == 1) acc1[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[32 * db], dp[r], acc1[db], 0, 0, 0);      // dV += Pd^T dO
-            }
-        }
-#endif
     }
     // ---- add the four waves' partial sums: slot [wave][column][MS]; lane (column, g) owns d = 32 db + mfma32_row(r, g)
     __syncthreads();
