@@ -638,7 +638,10 @@ def main():
                                     "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / 157.3, 4), "launches": v["launches"], "ms": round(v["ms"], 3),
                                     "xattn_f32_ms": round(x["ms"], 3), "xattn_f32_launches": x["launches"],
                                     "xattn_f32_TFLOP/s": round(x["flops"] / (x["ms"] * 1e-3) / 1e12, 2) if x["ms"] > 0 else None,
-                                    "note": "fp32-input MFMA peak = the fp32 vector peak (MI355X_MICROARCH.md); exact fp32 products and accumulation"}
+                                    "xattn_note": "sed_xattn_f32_* (fp32 in / out; the name is the interface): every product as a three-term split-precision product on the "
+                                                  "16-bit matrix pipe (f16 pairs for q, k, v, P; bf16 pairs for gradient operands; fp32 accumulation) -- algorithmic FLOPs "
+                                                  "here, 3x as many issued; NOT priced against the fp32-MFMA peak of this block",
+                                    "note": "fp32-input MFMA peak = the fp32 vector peak (MI355X_MICROARCH.md); exact fp32 products and accumulation (GEMMs of this block)"}
         ms = sum(v["ms"] for v in summ.values())
         fl = sum(v["flops"] for v in summ.values())
         n = sum(v["launches"] for v in summ.values())
@@ -702,15 +705,17 @@ def main():
                                       f"open-vocabulary attention mask), temperature 0.5; forward only")
         line["config"]["model"] = "DASM depth 12 (PaSST + CNN + Transformer-XL + query decoder, 119.7 M params), synthetic weights and query embeddings"
         line["config"].pop("final_loss", None)
-        line["dtype"] = "f16 MFMA operands in the encoder / SED decoder (split precision there), fp32 (fp32-input MFMA) in the query decoder and head"
+        line["dtype"] = ("f16 MFMA operands in the encoder / SED decoder (split precision there); query decoder and head: fp32-input MFMA GEMMs, attention as "
+                         "three-term f16-pair products with fp32 accumulation")
     if a.mode == "dasm_train":
         line["config"]["workload"] = (f"DASM train step (recipes/audioset_strong/detect_any_sound/passt/train.py:66-120): train-mode frontend, frame_shift / "
                                       f"mixup / FilterAugment, PaSST depth 12 + CNN branch + Transformer-XL SED decoder + 2-layer query decoder (dropout 0.1) over "
                                       f"the 1188 patch tokens with {a.dasm_queries} learned class queries, BCE on [B, {a.dasm_queries}, 1000] frame posteriors + 0.5 x "
                                       f"BCE on the tagging probabilities, backward through everything (whole model trainable), fused AdamW")
         line["config"]["model"] = "DASM depth 12 (PaSST + CNN + Transformer-XL + query decoder), synthetic weights and query embeddings"
-        line["dtype"] = ("f16 fwd / bf16 bwd MFMA operands in the encoder / CNN / SED decoder (split precision there), fp32 (fp32-input MFMA) forward "
-                         "and backward in the query decoder and dual-stream head")
+        line["dtype"] = ("f16 fwd / bf16 bwd MFMA operands in the encoder / CNN / SED decoder (split precision there); query decoder and dual-stream head: "
+                         "fp32-input MFMA GEMMs (16-bit split precision for Linears with >= 1024 rows), attention forward and backward as three-term "
+                         "split-precision products (f16 pairs for q, k, v, P; bf16 pairs for gradient operands), fp32 accumulation")
     if a.mode == "val":
         line["config"]["workload"] = ("MAT-SED validation batch (recipes/desed/finetune/train.py:296-366): eval frontend, student and "
                                       "EMA teacher forward with val_kwargs (17 windows of 512 frames, step 31, temp 0.5), soft-masked "
