@@ -5,14 +5,15 @@
 // mask_embedding MLP, einsum('bqc,bct->bqt'), sigmoid(x / temp) * at_out, pad mask, clamp, linear-softmax pooling).
 //
 // Everything on the query side is small (Q = 10 .. a few hundred queries per clip against 1188 patch tokens / 1000 frames) and sits
-// directly in front of a sigmoid with temperature 0.1 .. 0.5, i.e. it is precision-critical, not throughput-critical: the kernels here
-// compute in fp32 throughout --
+// directly in front of a sigmoid with temperature 0.1 .. 0.5, i.e. it is precision-critical: the kernels here take and return fp32 and keep
+// fp32-level products (exact fp32 MFMA products in the GEMM; since round 6 three-term split-precision products, 2^-22 / 2^-17, in the
+// attention, see "Round 6 (second half)" below) with fp32 accumulation --
 //   * sed_gemm_f32_nt     C = act(A . B^T + bias) (+ residual), batched, on the fp32-input matrix instruction v_mfma_f32_32x32x2_f32
 //                         (exact fp32 products and accumulation at the fp32 vector rate, without one VALU instruction per FMA and
 //                         with a 64 x 64 output tile fed from LDS: MI355X_MICROARCH.md "FP32-input MFMA");
 //   * sed_xattn_f32_fwd   softmax(q k^T / sqrt(dh) + mask) v for query counts that differ from the key count (cross attention over the
-//                         patch tokens, self attention among the queries with the open-vocabulary mask), both products on the same
-//                         fp32 matrix instruction, 32 queries per workgroup, four waves splitting the key tiles;
+//                         patch tokens, self attention among the queries with the open-vocabulary mask), 32 queries per workgroup, four
+//                         waves splitting the key tiles;
 //   * sed_dasm_head_fwd   the dual-stream finish on the [B, T, Q] logits: sigmoid / temperature, times the clip-level tagging
 //                         probability, pad mask, clamp, transposed store [B, Q, T], linear-softmax pooling.
 #include "common.h"
@@ -236,7 +237,9 @@ extern "C" int sed_gemm_f32_nt(const float* A, const float* B, const float* bias
 // pairs (scores and probabilities: q, k, v, P -- O(1) values) and 2^-17 with bf16 pairs (everything that carries a gradient: dO, dS, the
 // dropped probabilities they meet, and the tile rows of the products that contract over the streamed rows -- bf16 keeps the fp32 exponent
 // range, loss-scaled gradients of 1e-8 survive).  The forward's S and the backward's recomputed S use the same operand split and the same
-// accumulation order, so P is reproduced exactly in the query-stationary pass.  The fp32-input-MFMA form these kernels had until then
+// accumulation order, so P is reproduced exactly in the query-stationary pass.  Range: the half pairs need |q| / sqrt(dh), |k|, |v| < 65504
+// (LayerNorm-ed activations through a Linear: O(1 .. 100)); below 6e-5 a half hi term is subnormal and the pair carries less than 22 bits of a
+// value that no longer matters beside O(1) neighbours.  The fp32-input-MFMA form these kernels had until then
 // (v_mfma_f32_32x32x2_f32, exact fp32 products) measured 334 / 457 / 955 us for forward / query-stationary / key-stationary backward at the
 // dasm_train shape (24 clips, 407 queries over 1188 tokens) against 258 / 303 / 630 now; it is in the history (commit 661841a), not in the tree.
 template <bool F16> __device__ __forceinline__ void xa_split8(const float (&x)[8], s16x8_t& hi, s16x8_t& lo) {
