@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_fwd_kernel(const f
                                                                       const unsigned char* __restrict__ mask, int Nq, int Nk, int ldq, int ldk,
                                                                       int ldv, int ldo, long long q_bstride, float* __restrict__ lse_out,
                                                                       const XaDrop dr) {
-    constexpr int LDK = DH + 4, NDB = DH / 32, MS = DH + 2;
+    constexpr int LDK = DH + 4, NDB = DH / 32, MS = DH + 3;      // merge pitch: ODD -- the 32 query slots of a wave then sit in 32 different banks (DH + 2 was 2-way)
     extern __shared__ __attribute__((aligned(16))) float xa_lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = blockIdx.y, b = blockIdx.z;
     const int lq = lane & 31, lg = lane >> 5;
@@ -330,8 +330,10 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_fwd_kernel(const f
     float m_run = -INFINITY, l_run = 0.f;
     const float* kb = Kp + (size_t)b * Nk * ldk + h * DH;
     const float* vb = Vp + (size_t)b * Nk * ldv + h * DH;
-    // tile loader: lane -> (key row lane >> 1, half row lane & 1): DH / 2 floats = DH / 8 float4 of K and of V
-    const int trow = lane >> 1, thalf = (lane & 1) * (DH / 2);
+    // tile loader: lane -> (key row lane & 31, half row lane >> 5): DH / 2 floats = DH / 8 float4 of K and of V.  (Eight consecutive lanes -- one
+    // ds_write_b128 group -- are eight ROWS at 4 banks each = all 32 banks; with (row lane >> 1, half lane & 1) the two halves of a row, 32 floats
+    // apart, met in the same banks: every tile store 2-way conflicted.)
+    const int trow = lane & 31, thalf = (lane >> 5) * (DH / 2);
     // The wave's NEXT tile is in flight (in registers) while the current one is computed: with the products on the 16-bit pipe a tile is
     // ~1500 issue cycles, less than one trip to L2 / HBM -- loaded at the top of its own iteration, as the fp32 form did, the kernel waits.
     XaTileRegs tr;
@@ -475,7 +477,7 @@ static int xattn_fwd_launch(const float* Q, const float* K, const float* V, floa
     const dim3 grid(cdiv(Nq, 32), H, B);
 #define XATTN_LAUNCH(DH_, MK_, TR_)                                                                                              \
     {                                                                                                                            \
-        const int tile_ = XA_WAVES * 2 * XA_KT * (DH_ + 4) * 4, merge_ = XA_WAVES * 32 * (DH_ + 2) * 4;                          \
+        const int tile_ = XA_WAVES * 2 * XA_KT * (DH_ + 4) * 4, merge_ = XA_WAVES * 32 * (DH_ + 3) * 4;                          \
         const int lds_ = tile_ > merge_ ? tile_ : merge_;                                                                        \
         static bool attr_ = false;                                                                                               \
         if (!attr_) { (void)hipFuncSetAttribute((const void*)xattn_f32_fwd_kernel<DH_, MK_, TR_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); attr_ = true; } \
@@ -514,14 +516,22 @@ extern "C" int sed_xattn_f32_fwd_train(const float* Q, const float* K, const flo
 // products that contract over the streamed rows (register r of the two lane halves = one k step, as in the forward's P V).
 // The partial sums of the four waves are added through LDS at the end.
 // ---------------------------------------------------------------------------------------------------------------------
+#define XA_BWD_NW(MODE_) ((MODE_) == 0 ? XA_WAVES : 1)
 template <int DH, bool MASK, int MODE>
-__global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ Kp, const float* __restrict__ Vp,
+__global__ __launch_bounds__(64 * XA_BWD_NW(MODE), 2) void xattn_f32_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ Kp, const float* __restrict__ Vp,
                                                                       const float* __restrict__ O, const float* __restrict__ dO,
                                                                       const float* __restrict__ lse, float* __restrict__ Dq, float* __restrict__ dQ,
                                                                       float* __restrict__ dK, float* __restrict__ dV,
                                                                       const unsigned char* __restrict__ mask, int Nq, int Nk, int ldq, int ldk, int ldv,
                                                                       int ldo, int lddq, int lddk, int lddv, long long q_bstride, const XaDrop dr) {
-    constexpr int LDK = DH + 4, NDB = DH / 32, WS = 2 * XA_KT * LDK + 64, MS = MODE == 0 ? DH : 2 * DH;
+    // MW: floats per column in the final merge; MS = its slot pitch, ODD: with pitch DH / 2 DH the 32 columns of a wave all fell into ONE bank --
+    // every merge access 32-way conflicted, 50 % (MODE 0) and 79 % (MODE 1) of the kernels' LDS cycles (profiles/r6_dasm_pmc.json) for a
+    // step that runs once per workgroup beside only 3-4 tiles per wave
+    constexpr int LDK = DH + 4, NDB = DH / 32, WS = 2 * XA_KT * LDK + 64, MW = MODE == 0 ? DH : 2 * DH, MS = MW + 1;
+    // Waves per workgroup.  MODE 0 has 13 column blocks x 38 tiles per (clip, head) at the training shape: four waves split the tiles and merge.
+    // MODE 1 has 38 column blocks x 13 tiles: ONE wave per workgroup walks them all -- no cross-wave merge, no workgroup barrier, and the
+    // stationary rows are loaded and split once per column block instead of once per wave (432 -> see profiles/r6_dasm_xattn_split16.txt).
+    constexpr int NWV = XA_BWD_NW(MODE);
     extern __shared__ __attribute__((aligned(16))) float xa_lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = blockIdx.y, b = blockIdx.z, Hn = gridDim.y;
     const int lq = lane & 31, lg = lane >> 5;
@@ -571,7 +581,7 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_bwd_kernel(const f
     for (int db = 0; db < NDB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[db][r] = 0.f; acc1[db][r] = 0.f; }
-    const int trow = lane >> 1, thalf = (lane & 1) * (DH / 2);
+    const int trow = lane & 31, thalf = (lane >> 5) * (DH / 2);      // (see the forward's tile loader)
     const unsigned long long bh = (unsigned long long)b * Hn + h;
     // The wave's next tile travels in registers while the current one is computed, as in the forward -- in the query-stationary pass only: the
     // key-stationary one (two output accumulator sets, 256 registers) has no 64 registers to spare; with the prefetch it spilled 57 of them
@@ -597,14 +607,14 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_bwd_kernel(const f
         }                                                                                                                                  \
     }
     if (PF && wave * XA_KT < Nrow) XA_BWD_GLOAD(wave * XA_KT)
-    for (int r0 = wave * XA_KT; r0 < Nrow; r0 += XA_KT * XA_WAVES) {
+    for (int r0 = wave * XA_KT; r0 < Nrow; r0 += XA_KT * NWV) {
         {
             if (!PF) XA_BWD_GLOAD(r0)
             __builtin_amdgcn_wave_barrier();
             xa_regs_lstore<DH / 8>(tr, T0 + trow * LDK + thalf, T1 + trow * LDK + thalf);
             if (MODE == 1) rowc[lane] = stat;
             __builtin_amdgcn_wave_barrier();
-            if (PF && r0 + XA_KT * XA_WAVES < Nrow) XA_BWD_GLOAD(r0 + XA_KT * XA_WAVES)
+            if (PF && r0 + XA_KT * NWV < Nrow) XA_BWD_GLOAD(r0 + XA_KT * NWV)
         }
 #undef XA_BWD_GLOAD
         f32x16 st, dp;
@@ -723,13 +733,13 @@ __global__ __launch_bounds__(64 * XA_WAVES, 2) void xattn_f32_bwd_kernel(const f
     }
     __syncthreads();
     {
-        constexpr int CW = MS / (2 * XA_WAVES);
+        constexpr int CW = MW / (2 * NWV);
         const int d0 = (wave * 2 + lg) * CW;
         float out[CW];
 #pragma unroll
         for (int d = 0; d < CW; ++d) out[d] = 0.f;
 #pragma unroll
-        for (int w = 0; w < XA_WAVES; ++w) {
+        for (int w = 0; w < NWV; ++w) {
             const float* pw = xa_lds + (size_t)(w * 32 + lq) * MS + d0;
 #pragma unroll
             for (int d = 0; d < CW; ++d) out[d] += pw[d];
@@ -760,11 +770,12 @@ extern "C" int sed_xattn_f32_bwd(const float* Q, const float* K, const float* V,
     dr.thr = drop_thr24(drop_p); dr.sid = (unsigned)drop_site; dr.scale = 1.0f / (1.0f - drop_p); dr.seed = (unsigned long long)drop_seed;
 #define XBWD_LAUNCH(DH_, MK_, MODE_)                                                                                             \
     {                                                                                                                            \
-        const int tile_ = XA_WAVES * (2 * XA_KT * (DH_ + 4) + 64) * 4, merge_ = XA_WAVES * 32 * ((MODE_) == 0 ? DH_ : 2 * DH_) * 4; \
+        const int nw_ = XA_BWD_NW(MODE_);                                                                                        \
+        const int tile_ = nw_ * (2 * XA_KT * (DH_ + 4) + 64) * 4, merge_ = nw_ * 32 * (((MODE_) == 0 ? DH_ : 2 * DH_) + 1) * 4;   \
         const int lds_ = tile_ > merge_ ? tile_ : merge_;                                                                        \
         static bool attr_ = false;                                                                                               \
         if (!attr_) { (void)hipFuncSetAttribute((const void*)xattn_f32_bwd_kernel<DH_, MK_, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); attr_ = true; } \
-        hipLaunchKernelGGL((xattn_f32_bwd_kernel<DH_, MK_, MODE_>), dim3(cdiv((MODE_) == 0 ? Nq : Nk, 32), H, B), dim3(64 * XA_WAVES), lds_, stream, \
+        hipLaunchKernelGGL((xattn_f32_bwd_kernel<DH_, MK_, MODE_>), dim3(cdiv((MODE_) == 0 ? Nq : Nk, 32), H, B), dim3(64 * nw_), lds_, stream, \
                            Q, K, V, O, dO, lse, Dq, dQ, dK, dV, mask, Nq, Nk, ldq, ldk, ldv, ldo, lddq, lddk, lddv, (long long)q_batch_stride, dr); \
     }
 #define XBWD_PICK(MODE_)                                                                                                         \
