@@ -160,6 +160,38 @@ def test_xattn_f32_train_fwd_bwd_vs_torch_autograd(B, H, Nq, Nk, dh, masked, p):
         assert e < 3e-5, (name, e)
 
 
+def test_xattn_split_precision_range_sharp_scores_large_values_tiny_gradients():
+    """The split-precision attention (csrc/dasm.hip) at the edges of its operand formats: scores of standard deviation ~16 (a near one-hot
+    softmax), values of magnitude 1e3 (IEEE-half hi terms up to 65504 / lo terms down to the subnormals), and output gradients of 1e-9 (bf16
+    pairs keep the fp32 exponent range) -- against fp64 autograd, errors relative to the size of what they are compared with."""
+    from transformer4sed_amd.ops import call
+    g = torch.Generator().manual_seed(7)
+    B, H, Nq, Nk, dh = 2, 4, 40, 100, 64
+    D = H * dh
+    q, k = 4.0 * torch.randn(B, Nq, D, generator=g), 4.0 * torch.randn(B, Nk, D, generator=g)
+    v = 1e3 * torch.randn(B, Nk, D, generator=g)
+    dO = 1e-9 * torch.randn(B, Nq, D, generator=g)
+    qd, kd, vd = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    qh, kh, vh = (t.view(B, -1, H, dh).transpose(1, 2) for t in (qd, kd, vd))
+    s = qh @ kh.transpose(-1, -2) / dh ** 0.5
+    assert float(torch.softmax(s, -1).max(-1).values.mean()) > 0.8          # sharp: most rows are dominated by one key
+    want = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Nq, D)
+    want.backward(dO.double())
+    out, lse, Dq = torch.empty(B, Nq, D, device=DEV), torch.empty(B * H * Nq, device=DEV), torch.empty(B * H * Nq, device=DEV)
+    dq, dk, dv = torch.empty(B, Nq, D, device=DEV), torch.empty(B, Nk, D, device=DEV), torch.empty(B, Nk, D, device=DEV)
+    call("sed_xattn_f32_fwd_train", q.to(DEV), k.to(DEV), v.to(DEV), out, None, lse, B, H, Nq, Nk, dh, D, D, D, D, Nq * D, 0.0, 1, 0)
+    call("sed_xattn_f32_bwd", q.to(DEV), k.to(DEV), v.to(DEV), out, dO.to(DEV), lse, Dq, dq, dk, dv, None, B, H, Nq, Nk, dh, D, D, D, D, D, D, D, Nq * D,
+         0.0, 1, 0)
+    e_out = relerr(out, want.detach())
+    e_g = {n: relerr(got, ref) for n, got, ref in (("dq", dq, qd.grad), ("dk", dk, kd.grad), ("dv", dv, vd.grad))}
+    logerr(f"xattn range test (scores sd 16, |v| 1e3, |dO| 1e-9): out {e_out:.2e} " + " ".join(f"{n} {e:.2e}" for n, e in e_g.items()))
+    assert bool(torch.isfinite(out).all()) and all(bool(torch.isfinite(t).all()) for t in (dq, dk, dv))
+    # a near one-hot softmax turns a score error d into a relative probability error d on the runner-up keys: 2^-21 |s| ~ 3e-5 here
+    assert e_out < 1e-4, e_out
+    for n, e in e_g.items():
+        assert e < 3e-4, (n, e)
+
+
 def test_dasm_head_finish_bwd_and_sup_loss_vs_torch():
     from transformer4sed_amd.ops import call
     g = torch.Generator().manual_seed(5)
