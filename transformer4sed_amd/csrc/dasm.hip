@@ -525,7 +525,7 @@ __global__ __launch_bounds__(64 * XA_BWD_NW(MODE), 2) void xattn_f32_bwd_kernel(
                                                                       const unsigned char* __restrict__ mask, int Nq, int Nk, int ldq, int ldk, int ldv,
                                                                       int ldo, int lddq, int lddk, int lddv, long long q_bstride, const XaDrop dr) {
     // MW: floats per column in the final merge; MS = its slot pitch, ODD: with pitch DH / 2 DH the 32 columns of a wave all fell into ONE bank --
-    // every merge access 32-way conflicted, 50 % (MODE 0) and 79 % (MODE 1) of the kernels' LDS cycles (profiles/r6_dasm_pmc.json) for a
+    // every merge access 32-way conflicted, 50 % (MODE 0) and 79 % (MODE 1) of the kernels' LDS cycles (profiles/r6_dasm_pmc_fp32attn.json) for a
     // step that runs once per workgroup beside only 3-4 tiles per wave
     constexpr int LDK = DH + 4, NDB = DH / 32, WS = 2 * XA_KT * LDK + 64, MW = MODE == 0 ? DH : 2 * DH, MS = MW + 1;
     // Waves per workgroup.  MODE 0 has 13 column blocks x 38 tiles per (clip, head) at the training shape: four waves split the tiles and merge.
