@@ -174,7 +174,7 @@ def test_xattn_split_precision_range_sharp_scores_large_values_tiny_gradients():
     qd, kd, vd = (t.double().clone().requires_grad_(True) for t in (q, k, v))
     qh, kh, vh = (t.view(B, -1, H, dh).transpose(1, 2) for t in (qd, kd, vd))
     s = qh @ kh.transpose(-1, -2) / dh ** 0.5
-    assert float(torch.softmax(s, -1).max(-1).values.mean()) > 0.8          # sharp: most rows are dominated by one key
+    assert float(torch.softmax(s.detach(), -1).max(-1).values.mean()) > 0.8          # sharp: most rows are dominated by one key
     want = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Nq, D)
     want.backward(dO.double())
     out, lse, Dq = torch.empty(B, Nq, D, device=DEV), torch.empty(B * H * Nq, device=DEV), torch.empty(B * H * Nq, device=DEV)
@@ -186,10 +186,11 @@ def test_xattn_split_precision_range_sharp_scores_large_values_tiny_gradients():
     e_g = {n: relerr(got, ref) for n, got, ref in (("dq", dq, qd.grad), ("dk", dk, kd.grad), ("dv", dv, vd.grad))}
     logerr(f"xattn range test (scores sd 16, |v| 1e3, |dO| 1e-9): out {e_out:.2e} " + " ".join(f"{n} {e:.2e}" for n, e in e_g.items()))
     assert bool(torch.isfinite(out).all()) and all(bool(torch.isfinite(t).all()) for t in (dq, dk, dv))
-    # a near one-hot softmax turns a score error d into a relative probability error d on the runner-up keys: 2^-21 |s| ~ 3e-5 here
-    assert e_out < 1e-4, e_out
+    # a near one-hot softmax turns a score error d into a relative probability error d on the runner-up keys (2^-21 |s| ~ 3e-5 here).
+    # Measured: out 8.9e-7, dq / dk 1.8e-5, dv 6.0e-6
+    assert e_out < 1e-5, e_out
     for n, e in e_g.items():
-        assert e < 3e-4, (n, e)
+        assert e < 6e-5, (n, e)
 
 
 def test_dasm_head_finish_bwd_and_sup_loss_vs_torch():
