@@ -25,7 +25,11 @@ NAMES = ["backbone.blocks.0.attn.qkv.weight", "backbone.blocks.0.mlp.fc1.weight"
          "classifier.weight", "out_norm.weight", "at_adpater.1.weight",
          # PMAM variant (PaSST_CNN): LoRA factors ride with their block, everything else with the last stage
          "backbone.blocks.1.attn.qkv.lora_A", "cnn.cnn.conv0.weight", "cnn.cnn.batchnorm3.weight", "f_pool_module.f_att_token",
-         "transformer_projector.weight", "merge_weight", "mask_token", "mlm_mlp.2.weight"]
+         "transformer_projector.weight", "merge_weight", "mask_token", "mlm_mlp.2.weight",
+         # DASM (row (g)): the query decoder and the dual-stream head finish their backward before the SED decoder's -- "decoder" stage;
+         # norm_after_merge sits between the trunk and the head -- "heads"
+         "at_decoder.layers.0.self_attn.in_proj_weight", "at_decoder.layers.1.multihead_attn.out_proj.weight", "at_projector.weight",
+         "query_projector.0.weight", "at_query", "mask_embedding_layer.0.weight", "sed_head.weight", "at_head.bias", "norm_after_merge.weight"]
 
 
 def _layout():
@@ -92,6 +96,17 @@ def test_bucketed_allreduce_bf16_exchange_world2():
     port = s.getsockname()[1]
     s.close()
     mp.spawn(_worker, args=(2, port, False, torch.bfloat16), nprocs=2, join=True)
+
+
+def test_dasm_parameters_ride_the_decoder_and_heads_stages():
+    """ddp.stage_of for the names transformer4sed_amd.dasm.DASM registers (detect_any_sound.py:149-260): a name that fell through to the last
+    stage ("embed") would still be exchanged, but only after the whole backward -- the overlap the stage hooks exist for would be lost."""
+    from transformer4sed_amd.ddp import stage_of
+    for n in NAMES:
+        if n.startswith(("at_decoder.", "at_projector.", "query_projector.", "at_query", "mask_embedding_layer.", "sed_head.", "at_head.")):
+            assert stage_of(n, 12) == "decoder", n
+    assert stage_of("norm_after_merge.weight", 12) == "heads"
+    assert stage_of("at_query.1", 12) == "decoder"          # multi-modal query lists: one parameter per modality
 
 
 def test_stage_partition_covers_arena_once():
@@ -179,7 +194,9 @@ def test_small_stages_are_carried_and_merged(monkeypatch):
         assert red.carry == [] and red.fired == set()
         return at_hook, len(calls)
     eager, n_eager = run(0)
-    lazy, n_lazy = run(4 * 2500)
+    # threshold just above the first stage's own size ("decoder": the context network, the heads and -- for DASM -- the query decoder)
+    first = sum(b - a for a, b in GradBucketReducer(_FakeNet2(), _FakeOpt(_layout()), min_bytes=0).ranges["decoder"])
+    lazy, n_lazy = run(4 * (first + 1))
     assert eager[0] > 0 and lazy[0] == 0          # the first (small) stage waits for company
     assert n_lazy < n_eager                        # carried slices merge with their arena neighbours
 
