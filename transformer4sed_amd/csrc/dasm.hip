@@ -39,7 +39,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // function (no mask tensor is stored), `sed_dropout_f32` dumps it for the tests' CPU oracle.  One splitmix64 finaliser serves FOUR
 // consecutive elements (its four 16-bit fields against a 16-bit threshold: p to 1.5e-5): the attention kernels hold four consecutive keys
 // in four consecutive accumulator registers, so a lane hashes once per register quad (the per-element hash was ~150 issue cycles beside
-// the 64 of the MFMA it sits next to).
+// the 64 of the MFMA it sits next to).  (Round 6, with the products on the 16-bit pipe: replacing the finaliser by one multiply-add changes the
+// three attention kernels by 3-4 % -- 354 -> 342, 289 -> 279, 256 -> 247 us at the dasm_train shape: a cheaper hash is not worth its risk.)
 __device__ __forceinline__ unsigned long long drop_hash4(unsigned long long seed, unsigned sid, unsigned long long idx4) {
     unsigned long long z = idx4 + (seed ^ ((unsigned long long)sid << 48)) * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull * (sid + 1u);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
