@@ -904,10 +904,10 @@ def gen_datapipe():
 PMAM_SYNTH = dict(gmm_name="pmam/gmm_means", label_seed=500)
 
 
-def build_reference_pmam(depth, feature_layer, conv_dropout, mlm=True, lora=True, class_num=30):
+def build_reference_pmam(depth, feature_layer, conv_dropout, mlm=True, lora=True, class_num=30, at_adapter=True):
     """PaSST_CNN of the reference with config/pmam/post_pretrain.yaml:47-80 and the synthetic weights of synth.pmam_state_dict_np."""
     from src.models.cnn_transformer.passt_cnn import PaSST_CNN
-    passt = dict(passt_feature_layer=feature_layer, class_num=class_num, f_pool="attention", decode_ratio=10, at_adapter=True,
+    passt = dict(passt_feature_layer=feature_layer, class_num=class_num, f_pool="attention", decode_ratio=10, at_adapter=at_adapter,
                  decoder="transformerXL", decoder_layer_num=3, decoder_pos_emd_len=1000, decoder_dim=384, mlm=mlm)
     if lora:
         passt["lora_config"] = dict(r=8, lora_alpha=1, requires_grad_pretrain=False)
@@ -922,6 +922,8 @@ def build_reference_pmam(depth, feature_layer, conv_dropout, mlm=True, lora=True
     finally:
         torch.load = o_load
     sd_np = synth.pmam_state_dict_np(depth=12, mlm=mlm, lora_r=8 if lora else 0, class_num=class_num)
+    if not at_adapter:      # (the synthetic state dict always carries the tagging head; a model built without one has no such keys)
+        sd_np = {k: v for k, v in sd_np.items() if not k.startswith("at_adpater")}
     ref_shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
     assert ref_shapes == {k: tuple(v.shape) for k, v in sd_np.items()}, "PaSST_CNN state_dict contract drifted"
     net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=True)
@@ -1538,6 +1540,96 @@ def gen_dasmflops():
     print(f"   DASM train step (407 queries): a = {a:.2f} GFLOP/clip, b = {b:.2f} GFLOP/batch")
 
 
+ASSTEP_CFG = dict(   # no YAML for this recipe exists in the reference: values in the style of config/pmam/finetune*.yaml, 407 AudioSet-Strong classes
+    training=dict(clip_grad=True, transform=dict(n_transform=1, choice=[1, 0, 0, 1], filter_db_range=[-26, 26], filter_bands=[2, 5],
+                                                 filter_minimum_bandwidth=4, filter_type="step")),
+    class_loss=dict(loss_name="BCELoss", kwargs=None),
+    PaSST_CNN=dict(train_kwargs=dict(encoder_win=False, temp_w=1)),
+    opt=dict(param_groups=dict(cnn=dict(lr=1.0e-4, weight_decay=1.0e-4), passt=dict(lr=1.0e-5, weight_decay=1.0e-4, freeze_layer=0, step_lr=0),
+                               decoder=dict(lr=1.0e-4, weight_decay=1.0e-4), head=dict(lr=2.0e-4))))
+ASSTEP_SCHED = dict(n_epochs=30, n_epochs_cut=10, exponent=-1.5, warmup_epochs=1, warmup_rate=0.1, epoch_len=4)
+ASSTEP_SEEDS = (51, 52, 53)
+ASSTEP_PROBES = ["backbone.blocks.1.attn.qkv.weight", "backbone.blocks.0.mlp.fc2.weight", "backbone.patch_embed.proj.weight", "cnn.cnn.conv0.weight",
+                 "cnn.cnn.conv5.weight", "cnn.cnn.batchnorm2.weight", "cnn_projector.weight", "transformer_projector.bias", "f_pool_module.f_att_token",
+                 "merge_weight", "decoder.encoder_blocks.0.attn.in_proj.weight", "decoder.encoder_blocks.2.attn.linear_pos.weight",
+                 "decoder.encoder_blocks.1.mlp.fc1.weight", "classifier.weight", "classifier.bias"]
+
+
+def gen_asstep():
+    """The CLOSED-SET AudioSet-Strong loop (row (g), item (c)): the reference's own `Trainer.train` of
+    recipes/audioset_strong/base/passt_cnn/train.py:103-147 -- preprocess with frame_shift (max_shift_frame 2 x sr) / mixup under a coin flip /
+    FilterAugment, forward of PaSST_CNN with the 407-class head in train mode (BatchNorm batch statistics, conv dropout 0), BCE on the frame
+    posteriors, backward, AdamW, ExponentialDown -- two consecutive steps at encoder depth 2, batch 2 (`asstep.npz`).  Recorded per step: the
+    logged loss and lr scale, learning rates, the first 256 elements of the probe parameters after the step; for the first step the L2 norm
+    of EVERY parameter's gradient.  Parameter groups: recipes/desed/finetune/cnn_trans/setting.py:get_param_lr, what the recipe's main.py uses."""
+    import logging
+    from recipes.audioset_strong.base.passt_cnn.train import Trainer
+    from recipes.desed.finetune.cnn_trans.setting import get_param_lr
+    from src.utils.scheduler import ExponentialDown
+    C, depth, B, steps = 407, 2, 2, 2
+    cfg = json.loads(json.dumps(ASSTEP_CFG))
+    net = build_reference_pmam(depth, depth, conv_dropout=0.0, mlm=False, lora=False, class_num=C, at_adapter=False)
+    groups = get_param_lr(net, cfg, logging.getLogger("golden"))
+    opt = torch.optim.AdamW(groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-8)
+    sc = ASSTEP_SCHED
+    sch = ExponentialDown(optimizer=opt, start_iter=sc["n_epochs_cut"] * sc["epoch_len"], total_iter=sc["n_epochs"] * sc["epoch_len"],
+                          exponent=sc["exponent"], warmup_iter=sc["warmup_epochs"] * sc["epoch_len"], warmup_rate=sc["warmup_rate"])
+    scalars = []
+
+    class _TB:
+        def add_scalar(self, key, value, global_step=None):
+            scalars[-1][key.split("/", 1)[1]] = float(value)
+
+    class _Log:
+        tensorboard_writer = _TB()
+        logger = logging.getLogger("golden")
+
+    tr = Trainer(optimizer=opt, my_logger=_Log(), net=net, scheduler=sch, encoder=types.SimpleNamespace(sr=16000), train_loader=None,
+                 val_loader=None, test_loader=None, config=cfg, device="cpu")
+    random.seed(ASSTEP_SEEDS[0]); np.random.seed(ASSTEP_SEEDS[1]); torch.manual_seed(ASSTEP_SEEDS[2])
+    names = dict(net.named_parameters())
+    probes = [n for n in ASSTEP_PROBES if n in names]
+    assert len(probes) == len(ASSTEP_PROBES), [n for n in ASSTEP_PROBES if n not in names]
+    out = dict(probe_names=np.array(probes), trainable=np.array([n for n, p in net.named_parameters() if p.requires_grad]))
+    gnorms = {}
+    o_step = opt.step
+
+    def step_hook(*a, **k):
+        if not gnorms:
+            for n, p in net.named_parameters():
+                gnorms[n] = float(p.grad.norm()) if p.grad is not None else -1.0
+        return o_step(*a, **k)
+    opt.step = step_hook
+    for step in range(steps):
+        wav = torch.from_numpy(synth.synth_wav(B, seed=5100 + step))
+        labels = torch.from_numpy(synth.synth_strong_labels(B, n_classes=C, seed=950 + step))
+        tr.train_loader = [(wav, labels, None, None)]
+        scalars.append({})
+        rec = DrawRecorder()
+        with rec.recording():
+            tr.train(step)
+        for k, v in scalars[-1].items():
+            out[f"s{step}_{k}"] = np.float64(v)
+        out[f"s{step}_lrs"] = np.array([g["lr"] for g in opt.param_groups], dtype=np.float64)
+        out[f"s{step}_draw_kinds"] = np.array([k for k, _ in rec.log])
+        sp = dict(net.named_parameters())
+        for i, n in enumerate(probes):
+            out[f"s{step}_p{i}"] = t2n(sp[n]).reshape(-1)[:256].astype(np.float32).copy()
+        print(f"   asstep step {step}: " + " ".join(f"{k}={v:.6f}" for k, v in scalars[-1].items()), flush=True)
+    with torch.no_grad():      # how saturated the fixture is: posteriors of the last batch in eval mode
+        net.eval()
+        ext = net.get_feature_extractor()
+        s_, w_, _ = net(ext.normalize(ext(torch.from_numpy(synth.synth_wav(B, seed=5100)))), encoder_win=False, temp_w=1)
+        print("   posteriors: min %.3e  median %.3f  max %.6f" % (float(s_.min()), float(s_.median()), float(s_.max())))
+    out["gnorm_names"] = np.array(list(gnorms))
+    out["gnorm_values"] = np.array([gnorms[n] for n in gnorms], dtype=np.float64)
+    out["group_sizes"] = np.array([len(g["params"]) for g in opt.param_groups])
+    out["config_json"] = np.array(json.dumps(dict(cfg=ASSTEP_CFG, sched=ASSTEP_SCHED, seeds=ASSTEP_SEEDS, wav_seed0=5100, label_seed0=950,
+                                                  depth=depth, B=B, steps=steps, class_num=C)))
+    save("asstep", **out)
+
+
+GENS["asstep"] = gen_asstep
 GENS["dasmflops"] = gen_dasmflops
 GENS["trajectory12"] = gen_trajectory12
 GENS["dasm_train"] = gen_dasm_train

@@ -504,6 +504,78 @@ def test_dasm_train_mode_dropout_multimodal_and_external_query_grad():
             net2(mel, temp_w=0.5, query=torch.from_numpy(sd["at_query"]).to(DEV))
 
 
+def test_audioset_strong_trainer_steps_vs_reference_trainer(golden):
+    """`AudiosetStrongTrainer.step` (HIP path, fused AdamW) against what the REFERENCE's closed-set loop logged and left behind
+    (tests/golden/asstep.npz: two steps of `Trainer.train`, recipes/audioset_strong/base/passt_cnn/train.py:103-147, on PaSST_CNN with the 407
+    AudioSet-Strong classes at encoder depth 2, batch 2; oracle/make_golden.py:gen_asstep): the logged loss and lr scale of both steps, the
+    gradient norm of every parameter at the first step, the probe parameters after every step.  Same seeds => same augmentation draws."""
+    import json
+    import random
+    from transformer4sed_amd.dasm_trainer import AudiosetStrongTrainer
+    from transformer4sed_amd.passt_cnn import PaSST_CNN
+    from transformer4sed_amd.pmam_trainer import get_param_lr
+    from transformer4sed_amd.scheduler import ExponentialDown
+    from transformer4sed_amd.trainer import FusedAdamWEMA
+    g = golden("asstep")
+    meta = json.loads(str(g["config_json"]))
+    cfg, sc, depth, B, steps, C = meta["cfg"], meta["sched"], meta["depth"], meta["B"], meta["steps"], meta["class_num"]
+    passt = dict(passt_feature_layer=depth, class_num=C, f_pool="attention", decode_ratio=10, at_adapter=False, decoder="transformerXL",
+                 decoder_layer_num=3, decoder_pos_emd_len=1000, decoder_dim=384, mlm=False, load_pretrained_model=False, encoder_depth=depth)
+    net = PaSST_CNN(passt_sed_param=passt, cnn_param=dict(CNN))
+    sd = synth.pmam_state_dict_np(depth=12, mlm=False, lora_r=0, class_num=C)
+    own = net.state_dict()
+    net.load_state_dict({k: torch.from_numpy(np.asarray(sd[k])) for k in own if k in sd}, strict=False)
+    net = net.to(DEV)
+    groups = get_param_lr(net, cfg["opt"]["param_groups"])
+    assert [len(x["params"]) for x in groups] == list(g["group_sizes"])
+    assert sorted(n for n, p in net.named_parameters() if p.requires_grad) == sorted(str(n) for n in g["trainable"])
+    opt = FusedAdamWEMA(net, groups, ema_net=None, betas=(0.9, 0.999), eps=1e-8)
+    sched = ExponentialDown(opt, start_iter=sc["n_epochs_cut"] * sc["epoch_len"], total_iter=sc["n_epochs"] * sc["epoch_len"],
+                            exponent=sc["exponent"], warmup_iter=sc["warmup_epochs"] * sc["epoch_len"], warmup_rate=sc["warmup_rate"])
+    tr = AudiosetStrongTrainer(net, opt, sched, cfg, sr=16000)
+    random.seed(meta["seeds"][0]); np.random.seed(meta["seeds"][1]); torch.manual_seed(meta["seeds"][2])
+    names = [str(n) for n in g["probe_names"]]
+    mine = dict(net.named_parameters())
+    for step in range(steps):
+        wav = torch.from_numpy(synth.synth_wav(B, seed=meta["wav_seed0"] + step)).to(DEV)
+        labels = torch.from_numpy(synth.synth_strong_labels(B, n_classes=C, seed=meta["label_seed0"] + step)).to(DEV)
+        out = tr.step(wav, labels)
+        ref, got = float(g[f"s{step}_loss_class_strong"]), float(out["loss_class_strong"])
+        logerr(f"asstep step {step} loss_class_strong: got {got:.6f} ref {ref:.6f} ({abs(got - ref) / ref:.2e})")
+        assert abs(got - ref) <= 3e-3 * ref, (step, got, ref)
+        assert abs(sched._get_scale() - float(g[f"s{step}_lr_scaler"])) < 1e-12
+        np.testing.assert_allclose([x["lr"] for x in opt.param_groups], g[f"s{step}_lrs"], rtol=1e-12)
+        if step == 0:
+            gn = dict(zip((str(n) for n in g["gnorm_names"]), g["gnorm_values"]))
+            rows = []
+            for n, p in mine.items():
+                ref = gn[n]
+                if ref < 0:
+                    assert p.grad is None, n
+                    continue
+                got = float(p.grad.norm())
+                if n.startswith("cnn.cnn.conv") and n.endswith(".bias"):      # (zero in exact arithmetic: in front of a train-mode BatchNorm)
+                    wn = gn[n[:-4] + "weight"]
+                    assert ref < 2e-3 * wn and got < 2e-3 * wn, (n, got, ref, wn)
+                    continue
+                rows.append((abs(got - ref) / max(ref, 1e-12), n, got, ref))
+            rows.sort(reverse=True)
+            logerr(f"asstep: first-step gradient norms vs the reference, worst five of {len(rows)}: " + "; ".join(f"{n} {e:.2e}" for e, n, _, _ in rows[:5]))
+            # the bounds of the PMAM trunk's own suite (tests/test_gpu_pmam.py): 2e-2 per tensor (`merge_weight`, one scalar of cancelling
+            # products: 3e-2), the median of all tensors under 3e-3; the 407-class head itself within 3e-3
+            bad = [(n, f"{e:.2e}") for e, n, _, _ in rows if e > (3e-3 if n.startswith("classifier.") else 3e-2 if n == "merge_weight" else 2e-2)]
+            assert not bad, bad
+            assert sorted(e for e, _, _, _ in rows)[len(rows) // 2] < 3e-3
+        worst = 0.0
+        for i, n in enumerate(names):
+            lr = max(x["lr"] for x in opt.param_groups if n in x["names"])
+            d = mine[n].detach().reshape(-1)[:256].cpu().numpy() - g[f"s{step}_p{i}"]
+            ms = float(np.abs(d).mean()) / lr
+            worst = max(worst, ms)
+            assert ms < 0.15, (step, n, ms)
+        logerr(f"asstep step {step}: worst probe mean|dp| / lr {worst:.4f}")
+
+
 def test_audioset_strong_closed_set_step_407_classes():
     """`AudiosetStrongTrainer.step` = `Trainer.train` of recipes/audioset_strong/base/passt_cnn/train.py:103-140 on PaSST_CNN with the 407
     AudioSet-Strong classes (the head that was capped at 16 classes until round 6): loss and every gradient against torch autograd through
