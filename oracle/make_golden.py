@@ -1629,6 +1629,85 @@ def gen_asstep():
     save("asstep", **out)
 
 
+MLMSTEP_CFG = dict(   # config/mat-sed/base/pretrain.yaml values (lines 8-26 training, 88-101 opt); encoder frozen (lr 0), context network + MLM head trained
+    training=dict(encoder_win=False,
+                  transform=dict(n_transform=1, choice=[1, 0, 0, 1], filter_db_range=[-26, 26], filter_bands=[2, 5], filter_minimum_bandwidth=4,
+                                 filter_type="step")),
+    opt=dict(param_groups=dict(encoder=dict(lr=0, weight_decay=1.0e-4, freeze_layer=0, step_lr=4), decoder=dict(lr=1.0e-4, weight_decay=1.0e-4),
+                               head=dict(lr=1.0e-4, weight_decay=1.0e-4))))
+MLMSTEP_SCHED = dict(epoch_len=4, n_epochs=15, n_epochs_cut=10, exponent=-0.5, warmup_epochs=1, warmup_rate=0.1)
+MLMSTEP_SEEDS = (61, 62, 63)
+MLMSTEP_PROBES = ["decoder.encoder_blocks.0.attn.in_proj.weight", "decoder.encoder_blocks.1.attn.pos_bias_u", "decoder.encoder_blocks.1.attn.pos_bias_v",
+                  "decoder.encoder_blocks.2.attn.linear_pos.weight", "decoder.encoder_blocks.2.mlp.fc1.weight", "decoder.encoder_blocks.0.norm1.weight",
+                  "mlm_mlp.0.weight", "mlm_mlp.2.weight", "mlm_mlp.2.bias", "out_norm.weight", "backbone.blocks.1.attn.qkv.weight"]
+
+
+def gen_mlmstep():
+    """The masked-reconstruction PRETRAIN step of MAT-SED: the reference's own `MLMTrainer.train`
+    (recipes/desed/mlm/mlm_passt/train.py:16-49: frontend, frame_shift, FilterAugment, forward with the MLM mask plan drawn inside the model,
+    MSE on the masked frames, backward, AdamW over recipes/desed/finetune/passt/setting.py:get_params groups as mlm_passt/main.py:95-113 wires
+    them, ExponentialDown) -- three consecutive steps at encoder depth 2, batch 4, encoder_win False (where quirk 15 applies: the mask does
+    not reach the decoder's input).  Recorded per step: the loss, learning rates, the first 256 elements of the probe parameters after the
+    step (a frozen encoder tensor among them: it must not move); for the first step the L2 norm of EVERY parameter's gradient."""
+    import logging
+    from recipes.desed.mlm.mlm_passt.train import MLMTrainer
+    from recipes.desed.finetune.passt.setting import get_params
+    from src.utils.scheduler import ExponentialDown
+    depth, B, steps = 2, 4, 3
+    cfg = json.loads(json.dumps(MLMSTEP_CFG))
+    net = build_reference_model(768, True, depth, depth)
+    groups = get_params(net, cfg, logging.getLogger("golden"))
+    opt = torch.optim.AdamW(groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)      # mlm_passt/main.py:96-99
+    sc = MLMSTEP_SCHED
+    sch = ExponentialDown(optimizer=opt, start_iter=sc["n_epochs_cut"] * sc["epoch_len"], total_iter=sc["n_epochs"] * sc["epoch_len"],
+                          exponent=sc["exponent"], warmup_iter=sc["warmup_epochs"] * sc["epoch_len"], warmup_rate=sc["warmup_rate"])
+    tr = MLMTrainer(net=net, train_loader=None, val_loader=None, config=cfg, optimizer=opt, scheduler=sch, encoder=types.SimpleNamespace(sr=16000),
+                    logger=logging.getLogger("golden"), device="cpu")
+    losses = []
+    o_loss = tr.reconstruction_loss
+
+    def loss_hook(a, b):
+        v = o_loss(a, b)
+        losses.append((float(v), int(a.shape[0])))
+        return v
+    tr.reconstruction_loss = loss_hook
+    random.seed(MLMSTEP_SEEDS[0]); np.random.seed(MLMSTEP_SEEDS[1]); torch.manual_seed(MLMSTEP_SEEDS[2])
+    names = dict(net.named_parameters())
+    probes = [n for n in MLMSTEP_PROBES if n in names]
+    assert len(probes) == len(MLMSTEP_PROBES), [n for n in MLMSTEP_PROBES if n not in names]
+    out = dict(probe_names=np.array(probes), trainable=np.array([n for n, p in net.named_parameters() if p.requires_grad]))
+    gnorms = {}
+    o_step = opt.step
+
+    def step_hook(*a, **k):
+        if not gnorms:
+            for n, p in net.named_parameters():
+                gnorms[n] = float(p.grad.norm()) if p.grad is not None else -1.0
+        return o_step(*a, **k)
+    opt.step = step_hook
+    for step in range(steps):
+        wav = torch.from_numpy(synth.synth_wav(B, seed=6100 + step))
+        tr.train_loader = [(wav, None, None, None)]
+        rec = DrawRecorder()
+        with rec.recording():
+            tr.train(step)
+        out[f"s{step}_loss"] = np.float64(losses[-1][0])
+        out[f"s{step}_masked_rows"] = np.int64(losses[-1][1])
+        out[f"s{step}_lr_scaler"] = np.float64(sch._get_scale())
+        out[f"s{step}_lrs"] = np.array([g["lr"] for g in opt.param_groups], dtype=np.float64)
+        out[f"s{step}_draw_kinds"] = np.array([k for k, _ in rec.log])
+        sp = dict(net.named_parameters())
+        for i, n in enumerate(probes):
+            out[f"s{step}_p{i}"] = t2n(sp[n]).reshape(-1)[:256].astype(np.float32).copy()
+        print(f"   mlmstep step {step}: loss={losses[-1][0]:.6f} over {losses[-1][1]} masked frames, lr scale {sch._get_scale():.4f}", flush=True)
+    out["gnorm_names"] = np.array(list(gnorms))
+    out["gnorm_values"] = np.array([gnorms[n] for n in gnorms], dtype=np.float64)
+    out["group_sizes"] = np.array([len(g["params"]) for g in opt.param_groups])
+    out["config_json"] = np.array(json.dumps(dict(cfg=MLMSTEP_CFG, sched=MLMSTEP_SCHED, seeds=MLMSTEP_SEEDS, wav_seed0=6100, depth=depth, B=B, steps=steps)))
+    save("mlmstep", **out)
+
+
+GENS["mlmstep"] = gen_mlmstep
 GENS["asstep"] = gen_asstep
 GENS["dasmflops"] = gen_dasmflops
 GENS["trajectory12"] = gen_trajectory12
