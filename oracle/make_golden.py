@@ -1696,6 +1696,10 @@ def gen_mlmstep():
         out[f"s{step}_lr_scaler"] = np.float64(sch._get_scale())
         out[f"s{step}_lrs"] = np.array([g["lr"] for g in opt.param_groups], dtype=np.float64)
         out[f"s{step}_draw_kinds"] = np.array([k for k, _ in rec.log])
+        # the model-side draws of the step (mask.py:59-83: block noise, style probabilities, the 'random token' indices) -- the CUDA generator of
+        # a GPU run cannot reproduce a CPU generator's stream, so the test injects them and advances its CPU generator by the same draws
+        ru, ri = rec.of("rand"), rec.of("randint")
+        out[f"s{step}_mlm_noise"], out[f"s{step}_mlm_probs"], out[f"s{step}_mlm_rand_idx"] = t2n(ru[-2]), t2n(ru[-1]), t2n(ri[-1])
         sp = dict(net.named_parameters())
         for i, n in enumerate(probes):
             out[f"s{step}_p{i}"] = t2n(sp[n]).reshape(-1)[:256].astype(np.float32).copy()
