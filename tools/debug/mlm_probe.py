@@ -1,4 +1,5 @@
-"""Debug aid: first pretrain step of tests/golden/mlmstep.npz -- per-element update of a probe tensor, HIP path vs the reference trainer."""
+"""Debug aid: first pretrain step of tests/golden/mlmstep.npz WITHOUT the recorded mask plan injected -- per-element update of the probe tensors, HIP path
+vs the reference trainer (what a different mask does to the positional tensors' gradients: 68 % sign agreement on linear_pos.weight row 0)."""
 import json, os, random, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
