@@ -627,7 +627,7 @@ TRAINSTEP_PROBES = ["backbone.patch_embed.proj.weight", "backbone.blocks.1.attn.
                     "classifier.weight", "at_adpater.0.mha.in_proj_weight", "at_adpater.1.bias"]
 
 
-def gen_trainstep(tag="trainstep", depth=2, feature_layer=2, n_steps=3, sizes=(2, 2, 2), extra_probes=(), probe_steps=None):
+def gen_trainstep(tag="trainstep", depth=2, feature_layer=2, n_steps=3, sizes=(2, 2, 2), extra_probes=(), probe_steps=None, base_cfg=None, sched=None):
     """Three consecutive optimisation steps of the REFERENCE trainer itself (recipes/desed/finetune/train.py:Trainer.train,
     finetune2 settings: global student, sliding-window EMA teacher in train mode, AdamW groups from
     recipes/desed/finetune/passt/setting.py:get_params, ExponentialDown, update_ema), each run as a one-batch epoch so the
@@ -638,7 +638,7 @@ def gen_trainstep(tag="trainstep", depth=2, feature_layer=2, n_steps=3, sizes=(2
     from recipes.desed.finetune.train import Trainer
     from recipes.desed.finetune.passt.setting import get_params
     from src.utils.scheduler import ExponentialDown
-    cfg = json.loads(json.dumps(TRAINSTEP_CFG))
+    cfg = json.loads(json.dumps(TRAINSTEP_CFG if base_cfg is None else base_cfg))
     cfg["training"]["batch_size"] = [sizes[0] - sizes[0] // 2, sizes[0] // 2, sizes[1], sizes[2]]
     net = build_reference_model(768, False, depth, feature_layer)
     probes = [n for n in list(TRAINSTEP_PROBES) + list(extra_probes) if n in dict(net.named_parameters())]
@@ -648,7 +648,7 @@ def gen_trainstep(tag="trainstep", depth=2, feature_layer=2, n_steps=3, sizes=(2
         prm.detach_()
     groups = get_params(net, cfg, logging.getLogger("golden"))
     opt = torch.optim.AdamW(groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-8)   # recipes/desed/setting.py:256-258
-    sc = TRAINSTEP_SCHED
+    sc = TRAINSTEP_SCHED if sched is None else sched
     sch = ExponentialDown(optimizer=opt, start_iter=sc["n_epochs_cut"] * sc["epoch_len"], total_iter=sc["n_epochs"] * sc["epoch_len"],
                           exponent=sc["exponent"], warmup_iter=sc["warmup_epochs"] * sc["epoch_len"], warmup_rate=sc["warmup_rate"])
 
@@ -691,11 +691,31 @@ def gen_trainstep(tag="trainstep", depth=2, feature_layer=2, n_steps=3, sizes=(2
             out[f"s{step}_ema{i}"] = t2n(ep[n]).reshape(-1)[:512].astype(np.float32).copy()
         print(f"   step {step}: " + " ".join(f"{k}={v:.6f}" for k, v in scalars[-1].items()), flush=True)
     out["n_steps"] = np.int64(n_steps)
-    out["config_json"] = np.array(json.dumps(dict(cfg=cfg, sched=TRAINSTEP_SCHED, seeds=TRAINSTEP_SEEDS,
+    out["config_json"] = np.array(json.dumps(dict(cfg=cfg, sched=sc, seeds=TRAINSTEP_SEEDS,
                                                   wav_seed0=2000, label_seed0=300, groups=list(sizes), depth=depth,
                                                   feature_layer=feature_layer)))
     out["group_sizes"] = np.array([len(g["params"]) for g in opt.param_groups])
     save(tag, **out)
+
+
+TRAINSTEP_FT1_CFG = dict(  # config/mat-sed/base/finetune1.yaml values (lines 11-36, 70-95, 128-142): encoder and context network at lr 0, heads trained,
+    # linear consistency ramp over 8 epochs to w_cons_max 2, the teacher WITHOUT sliding windows
+    training=dict(batch_size=[1, 1, 2, 2], clip_grad=True, self_loss_warmup=8, cons_scheduler_name="Linear",
+                  ema_factor=0.999, w_weak=0.5, w_cons_max=2, w_cons_min=0, w_weak_cons=0.5, w_AT=2,
+                  transform=dict(n_transform=2, choice=[1, 0, 0, 1], filter_db_range=[-26, 26], filter_bands=[2, 5],
+                                 filter_minimum_bandwidth=4, filter_type="step")),
+    PaSST_SED=dict(train_stu_kwargs=dict(encoder_win=False, win_param=[512, 49], mix_rate=0.5, temp_w=1),
+                   train_tch_kwargs=dict(encoder_win=False, win_param=[512, 49], mix_rate=0.5, temp_w=1)),
+    opt=dict(param_groups=dict(encoder=dict(lr=0, weight_decay=1.0e-4, freeze_layer=0, step_lr=4),
+                               decoder=dict(lr=0, weight_decay=1.0e-4), head=dict(lr=2.0e-4, weight_decay=1.0e-4))),
+)
+TRAINSTEP_FT1_SCHED = dict(epoch_len=4, n_epochs=15, n_epochs_cut=10, exponent=-1, warmup_epochs=0, warmup_rate=0.1)
+
+
+def gen_trainstep_ft1():
+    """The finetune1 stage (heads only, linear consistency ramp, teacher without windows): three consecutive steps of the reference's
+    Trainer.train under config/mat-sed/base/finetune1.yaml's values at depth 2."""
+    gen_trainstep(tag="trainstep_ft1", base_cfg=TRAINSTEP_FT1_CFG, sched=TRAINSTEP_FT1_SCHED)
 
 
 def gen_trajectory():
@@ -1712,6 +1732,7 @@ def gen_mlmstep():
 
 
 GENS["mlmstep"] = gen_mlmstep
+GENS["trainstep_ft1"] = gen_trainstep_ft1
 GENS["asstep"] = gen_asstep
 GENS["dasmflops"] = gen_dasmflops
 GENS["trajectory12"] = gen_trajectory12
