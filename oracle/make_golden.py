@@ -1031,7 +1031,7 @@ def gen_pmam():
         save(tag, **out)
 
 
-PMAMSTEP_CFG = dict(   # config/pmam/post_pretrain.yaml values; batch 2 + 2 + 2, depth-2 encoder (feature layer 2), conv dropout 0
+PMAMSTEP_CFG = dict(   # config/pmam/post_pretrain.yaml values except: batch 2 + 2 + 2, depth-2 encoder (feature layer 2, freeze_layer 1 of 2 instead of 8 of 12), conv dropout 0, passt lr 5e-5 (YAML: 5e-6) -- tests/test_config_yaml.py
     training=dict(batch_size=[2, 2, 2], w_AT=0.1, clip_grad=True,
                   transform=dict(n_transform=1, choice=[1, 0, 0, 1], filter_db_range=[-26, 26], filter_bands=[2, 5],
                                  filter_minimum_bandwidth=4, filter_type="step")),
