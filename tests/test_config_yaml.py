@@ -86,3 +86,26 @@ def test_trainer_fixture_configurations_restate_the_reference_yamls():
     for sc, ys in ((mg.TRAINSTEP_SCHED, ft2["training"]["scheduler"]), (mg.TRAINSTEP_FT1_SCHED, ft1["training"]["scheduler"]), (mg.MLMSTEP_SCHED, flat)):
         assert (sc["n_epochs"], sc["n_epochs_cut"], float(sc["exponent"]), sc["warmup_epochs"], float(sc["warmup_rate"])) == \
                (ys["n_epochs"], ys["n_epochs_cut"], float(ys["exponent"]), ys["lr_warmup_epochs"], float(ys["lr_warmup_rate"])), (sc, ys)
+
+
+@pytest.mark.parametrize("rel", ["mat-sed/base/finetune1.yaml", "mat-sed/base/finetune2.yaml", "mat-sed/base/pretrain.yaml",
+                                 "pmam/post_pretrain.yaml", "pmam/finetune1.yaml", "pmam/finetune2.yaml"])
+def test_drop_in_classes_take_the_reference_yamls_unchanged(rel):
+    """`PaSST_SED(**configs["PaSST_SED"]["init_kwargs"])` / `PaSST_CNN(**configs["PaSST_CNN"]["init_kwargs"])` as the recipes' setting.py files
+    call them (recipes/desed/finetune/passt/setting.py:5-12, mlm_passt/passt_mlm_setting.py:5-8, pmam/main.py:97): every key of every shipped
+    YAML is accepted (construction needs no GPU; the only addition is `load_pretrained_model=False`, there is no checkpoint here), and the
+    parameter count is the reference model's."""
+    from transformer4sed_amd.passt_cnn import PaSST_CNN
+    from transformer4sed_amd.passt_sed import PaSST_SED
+    y = load("config/" + rel)
+    if "PaSST_CNN" in y:
+        kw = dict(y["PaSST_CNN"].get("init_kwargs", y["PaSST_CNN"]))
+        kw["passt_sed_param"] = dict(kw["passt_sed_param"], load_pretrained_model=False)
+        net = PaSST_CNN(**kw)
+        want = {"pmam/post_pretrain.yaml": 97847387}.get(rel, 96180035)
+    else:
+        kw = dict(y["PaSST_SED"].get("init_kwargs", y["PaSST_SED"]), load_pretrained_model=False)
+        net = PaSST_SED(**kw)
+        want = 102129714 if kw.get("mlm") else 100947762          # 100.95 M (SURVEY section 8: the finetune model), + the MLM head and mask token
+    assert sum(p.numel() for p in net.parameters()) == want
+    assert net.get_model_name() == ("PaSST_CNN" if "PaSST_CNN" in y else "PaSST_SED")
