@@ -627,7 +627,8 @@ TRAINSTEP_PROBES = ["backbone.patch_embed.proj.weight", "backbone.blocks.1.attn.
                     "classifier.weight", "at_adpater.0.mha.in_proj_weight", "at_adpater.1.bias"]
 
 
-def gen_trainstep(tag="trainstep", depth=2, feature_layer=2, n_steps=3, sizes=(2, 2, 2), extra_probes=(), probe_steps=None, base_cfg=None, sched=None):
+def gen_trainstep(tag="trainstep", depth=2, feature_layer=2, n_steps=3, sizes=(2, 2, 2), extra_probes=(), probe_steps=None, base_cfg=None, sched=None,
+                  pmam=False, probe_names=None):
     """Three consecutive optimisation steps of the REFERENCE trainer itself (recipes/desed/finetune/train.py:Trainer.train,
     finetune2 settings: global student, sliding-window EMA teacher in train mode, AdamW groups from
     recipes/desed/finetune/passt/setting.py:get_params, ExponentialDown, update_ema), each run as a one-batch epoch so the
@@ -640,8 +641,13 @@ def gen_trainstep(tag="trainstep", depth=2, feature_layer=2, n_steps=3, sizes=(2
     from src.utils.scheduler import ExponentialDown
     cfg = json.loads(json.dumps(TRAINSTEP_CFG if base_cfg is None else base_cfg))
     cfg["training"]["batch_size"] = [sizes[0] - sizes[0] // 2, sizes[0] // 2, sizes[1], sizes[2]]
-    net = build_reference_model(768, False, depth, feature_layer)
-    probes = [n for n in list(TRAINSTEP_PROBES) + list(extra_probes) if n in dict(net.named_parameters())]
+    if pmam:      # the PMAM finetune stage: PaSST_CNN (10 classes, no LoRA, no MLM head; conv dropout 0: torch's bits cannot be injected elsewhere) in the SAME loop
+        from recipes.desed.finetune.cnn_trans.train import PaSST_CNN_Trainer as Trainer      # (subclass of the trainer above, nothing overridden)
+        from recipes.desed.finetune.cnn_trans.setting import get_param_lr as get_params
+        net = build_reference_pmam(depth, feature_layer, conv_dropout=0.0, mlm=False, lora=False, class_num=10)
+    else:
+        net = build_reference_model(768, False, depth, feature_layer)
+    probes = [n for n in list(TRAINSTEP_PROBES if probe_names is None else probe_names) + list(extra_probes) if n in dict(net.named_parameters())]
     assert len(probes) >= 10, [n for n in TRAINSTEP_PROBES if n not in probes]
     ema_net = deepcopy(net)
     for prm in ema_net.parameters():
@@ -716,6 +722,32 @@ def gen_trainstep_ft1():
     """The finetune1 stage (heads only, linear consistency ramp, teacher without windows): three consecutive steps of the reference's
     Trainer.train under config/mat-sed/base/finetune1.yaml's values at depth 2."""
     gen_trainstep(tag="trainstep_ft1", base_cfg=TRAINSTEP_FT1_CFG, sched=TRAINSTEP_FT1_SCHED)
+
+
+PMAMFTSTEP_CFG = dict(  # config/pmam/finetune2.yaml values (lines: training, PaSST_CNN train kwargs, opt); miniature batch, conv dropout 0
+    training=dict(batch_size=[1, 1, 2, 2], clip_grad=True, self_loss_warmup=15, cons_scheduler_name="Sigmoid",
+                  ema_factor=0.999, w_weak=0.5, w_cons_max=40, w_cons_min=0, w_weak_cons=0.5, w_AT=2,
+                  transform=dict(n_transform=2, choice=[1, 0, 0, 1], filter_db_range=[-26, 26], filter_bands=[2, 5],
+                                 filter_minimum_bandwidth=4, filter_type="step")),
+    PaSST_CNN=dict(train_stu_kwargs=dict(encoder_win=False, win_param=[512, 49], mix_rate=0.5, temp_w=1),
+                   train_tch_kwargs=dict(encoder_win=True, win_param=[512, 49], mix_rate=0.5, temp_w=1)),
+    opt=dict(param_groups=dict(cnn=dict(lr=1.5e-4, weight_decay=1.0e-4), passt=dict(lr=7.5e-6, weight_decay=1.0e-4, freeze_layer=0, step_lr=4),
+                               decoder=dict(lr=1.5e-4, weight_decay=1.0e-4), head=dict(lr=2.0e-4, weight_decay=1.0e-4))),
+)
+PMAMFTSTEP_SCHED = dict(epoch_len=4, n_epochs=30, n_epochs_cut=15, exponent=-1.5, warmup_epochs=1, warmup_rate=0.1)
+PMAMFTSTEP_PROBES = ["backbone.patch_embed.proj.weight", "backbone.blocks.1.attn.qkv.weight", "backbone.blocks.1.mlp.fc2.bias", "backbone.norm.weight",
+                     "cnn.cnn.conv0.weight", "cnn.cnn.conv5.weight", "cnn.cnn.batchnorm2.weight", "cnn.cnn.cg7.linear.weight", "cnn_projector.weight",
+                     "transformer_projector.bias", "merge_weight", "f_pool_module.f_att_token", "decoder.encoder_blocks.0.attn.in_proj.weight",
+                     "decoder.encoder_blocks.1.attn.pos_bias_u", "decoder.encoder_blocks.2.attn.linear_pos.weight", "classifier.weight",
+                     "at_adpater.0.mha.in_proj_weight", "at_adpater.1.bias", "out_norm.weight"]
+
+
+def gen_pmamftstep():
+    """The PMAM FINETUNE stage in the mean-teacher loop (recipes/desed/finetune/cnn_trans/train.py: PaSST_CNN_Trainer, a subclass of the MAT-SED
+    trainer with nothing overridden; groups from cnn_trans/setting.py:get_param_lr): three consecutive steps of the reference trainer with
+    config/pmam/finetune2.yaml's values at depth 2 -- PaSST_CNN student, EMA teacher with sliding windows in train mode (its BatchNorm
+    statistics move too), six loss terms, AdamW, update_ema."""
+    gen_trainstep(tag="pmamftstep", base_cfg=PMAMFTSTEP_CFG, sched=PMAMFTSTEP_SCHED, pmam=True, probe_names=PMAMFTSTEP_PROBES)
 
 
 def gen_trajectory():
@@ -1733,6 +1765,7 @@ def gen_mlmstep():
 
 GENS["mlmstep"] = gen_mlmstep
 GENS["trainstep_ft1"] = gen_trainstep_ft1
+GENS["pmamftstep"] = gen_pmamftstep
 GENS["asstep"] = gen_asstep
 GENS["dasmflops"] = gen_dasmflops
 GENS["trajectory12"] = gen_trajectory12

@@ -392,3 +392,59 @@ def test_pmam_finetune_trainer_runs_mean_teacher_steps():
         ema(torch.randn(2, 128, 1000, device="cuda"), **cfg["PaSST_CNN"]["train_stu_kwargs"])
     img = ema.engine.cache[n].w
     assert torch.equal(img, master.to(img.dtype)), float((img.float() - master).abs().max())
+
+
+def report(name, err, extra=""):
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/pmam_errors.log", "a") as f:
+        f.write(f"{name}: {err:.4e} {extra}\n")
+
+
+def test_pmam_finetune_trainer_steps_vs_reference_trainer(golden):
+    """The PMAM finetune stage in the mean-teacher loop against the REFERENCE's own `PaSST_CNN_Trainer.train`
+    (recipes/desed/finetune/cnn_trans/train.py, tests/golden/pmamftstep.npz: three steps with config/pmam/finetune2.yaml's values at depth 2,
+    conv dropout 0): the seven logged loss terms, w_cons and the learning rates of every step, student and EMA probe parameters after every
+    step (CNN, BatchNorm, LoRA-free encoder, context network, heads) -- PaSST_CNN student, EMA teacher with sliding windows in train mode."""
+    import json, random
+    from copy import deepcopy
+    from transformer4sed_amd.pmam_trainer import get_param_lr
+    from transformer4sed_amd.scheduler import ExponentialDown
+    from transformer4sed_amd.trainer import FusedAdamWEMA, MatSedTrainer
+    g = golden("pmamftstep")
+    meta = json.loads(str(g["config_json"]))
+    cfg, sc = meta["cfg"], meta["sched"]
+    net = build_ft(dropout=0.0)
+    ema = deepcopy(net)
+    for p in ema.parameters():
+        p.detach_()
+    groups = get_param_lr(net, cfg["opt"]["param_groups"])
+    assert [len(x["params"]) for x in groups] == list(g["group_sizes"])
+    opt = FusedAdamWEMA(net, groups, ema_net=ema, betas=(0.9, 0.999), eps=1e-8)
+    sched = ExponentialDown(opt, start_iter=sc["n_epochs_cut"] * sc["epoch_len"], total_iter=sc["n_epochs"] * sc["epoch_len"],
+                            exponent=sc["exponent"], warmup_iter=sc["warmup_epochs"] * sc["epoch_len"], warmup_rate=sc["warmup_rate"])
+    net.train(); ema.train()
+    tr = MatSedTrainer(net, ema, opt, sched, cfg, epoch_len=1)
+    random.seed(meta["seeds"][0]); np.random.seed(meta["seeds"][1]); torch.manual_seed(meta["seeds"][2])
+    names = [str(n) for n in g["probe_names"]]
+    for step in range(int(g["n_steps"])):
+        wav = torch.from_numpy(synth.synth_wav(sum(meta["groups"]), seed=meta["wav_seed0"] + step)).cuda()
+        labels = torch.from_numpy(synth.synth_batch_labels(*meta["groups"], seed=meta["label_seed0"] + step)).cuda()
+        out = tr.finetune_step(wav, labels)
+        for k in ("loss_total", "loss_class_strong", "loss_class_weak", "loss_class_at_specific", "loss_cons_strong", "loss_cons_weak",
+                  "loss_cons_at_specific"):
+            ref, got = float(g[f"s{step}_{k}"]), float(out[k])
+            report(f"PMAM finetune trainer step {step} {k}", abs(got - ref), f"ref {ref:.6f}")
+            assert abs(got - ref) <= 4e-3 * max(abs(ref), 0.05), (step, k, got, ref)
+        assert abs(float(out["w_cons"]) - float(g[f"s{step}_w_cons"])) < 1e-9
+        assert abs(sched._get_scale() - float(g[f"s{step}_lr_scaler"])) < 1e-12
+        np.testing.assert_allclose([x["lr"] for x in opt.param_groups], g[f"s{step}_lrs"], rtol=1e-12)
+        sp, ep = dict(net.named_parameters()), dict(ema.named_parameters())
+        worst = 0.0
+        for i, n in enumerate(names):
+            lr = max(x["lr"] for x in opt.param_groups if n in x["names"])
+            ms = float(np.abs(sp[n].detach().reshape(-1)[:512].cpu().numpy() - g[f"s{step}_stu{i}"]).mean()) / lr
+            me = float(np.abs(ep[n].detach().reshape(-1)[:512].cpu().numpy() - g[f"s{step}_ema{i}"]).mean()) / lr
+            worst = max(worst, ms)
+            assert ms < 0.15 and me < 0.15, (step, n, ms, me)
+        report(f"PMAM finetune trainer step {step} worst probe mean|dp|/lr", worst)
