@@ -82,6 +82,12 @@ def test_trainer_fixture_configurations_restate_the_reference_yamls():
         [".training.batch_size[0]", ".training.batch_size[1]", ".training.batch_size[2]",      # 2 + 2 + 2 clips instead of 6 + 6 + 12
          ".opt.param_groups.passt.lr",                                                           # 5e-5 instead of 5e-6: three steps must move the LoRA probes visibly
          ".opt.param_groups.passt.freeze_layer"])                                                # 1 of 2 blocks instead of 8 of 12
+    pft2 = load("config/pmam/finetune2.yaml")
+    assert subset_mismatches(without_batch(mg.PMAMFTSTEP_CFG), pft2) == []
+    ys = pft2["training"]["scheduler"]
+    sc = mg.PMAMFTSTEP_SCHED
+    assert (sc["n_epochs"], sc["n_epochs_cut"], float(sc["exponent"]), sc["warmup_epochs"], float(sc["warmup_rate"])) == \
+           (ys["n_epochs"], ys["n_epochs_cut"], float(ys["exponent"]), ys["lr_warmup_epochs"], float(ys["lr_warmup_rate"]))
     flat = dict(pre["training"], exponent=pre["opt"]["exponent"])          # (pretrain.yaml's flat layout)
     for sc, ys in ((mg.TRAINSTEP_SCHED, ft2["training"]["scheduler"]), (mg.TRAINSTEP_FT1_SCHED, ft1["training"]["scheduler"]), (mg.MLMSTEP_SCHED, flat)):
         assert (sc["n_epochs"], sc["n_epochs_cut"], float(sc["exponent"]), sc["warmup_epochs"], float(sc["warmup_rate"])) == \
