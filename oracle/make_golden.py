@@ -1694,7 +1694,12 @@ MLMSTEP_PROBES = ["decoder.encoder_blocks.0.attn.in_proj.weight", "decoder.encod
                   "mlm_mlp.0.weight", "mlm_mlp.2.weight", "mlm_mlp.2.bias", "out_norm.weight", "backbone.blocks.1.attn.qkv.weight"]
 
 
-def gen_mlmstep():
+def gen_mlmstep12():
+    """The same at the REAL depth (12 blocks, feature layer 10): one step, 2 clips (`mlmstep12.npz`)."""
+    gen_mlmstep(tag="mlmstep12", depth=12, feature_layer=10, B=2, steps=1)
+
+
+def gen_mlmstep(tag="mlmstep", depth=2, feature_layer=2, B=4, steps=3):
     """The masked-reconstruction PRETRAIN step of MAT-SED: the reference's own `MLMTrainer.train`
     (recipes/desed/mlm/mlm_passt/train.py:16-49: frontend, frame_shift, FilterAugment, forward with the MLM mask plan drawn inside the model,
     MSE on the masked frames, backward, AdamW over recipes/desed/finetune/passt/setting.py:get_params groups as mlm_passt/main.py:95-113 wires
@@ -1705,9 +1710,8 @@ def gen_mlmstep():
     from recipes.desed.mlm.mlm_passt.train import MLMTrainer
     from recipes.desed.finetune.passt.setting import get_params
     from src.utils.scheduler import ExponentialDown
-    depth, B, steps = 2, 4, 3
     cfg = json.loads(json.dumps(MLMSTEP_CFG))
-    net = build_reference_model(768, True, depth, depth)
+    net = build_reference_model(768, True, depth, feature_layer)
     groups = get_params(net, cfg, logging.getLogger("golden"))
     opt = torch.optim.AdamW(groups, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)      # mlm_passt/main.py:96-99
     sc = MLMSTEP_SCHED
@@ -1755,15 +1759,17 @@ def gen_mlmstep():
         sp = dict(net.named_parameters())
         for i, n in enumerate(probes):
             out[f"s{step}_p{i}"] = t2n(sp[n]).reshape(-1)[:256].astype(np.float32).copy()
-        print(f"   mlmstep step {step}: loss={losses[-1][0]:.6f} over {losses[-1][1]} masked frames, lr scale {sch._get_scale():.4f}", flush=True)
+        print(f"   {tag} step {step}: loss={losses[-1][0]:.6f} over {losses[-1][1]} masked frames, lr scale {sch._get_scale():.4f}", flush=True)
     out["gnorm_names"] = np.array(list(gnorms))
     out["gnorm_values"] = np.array([gnorms[n] for n in gnorms], dtype=np.float64)
     out["group_sizes"] = np.array([len(g["params"]) for g in opt.param_groups])
-    out["config_json"] = np.array(json.dumps(dict(cfg=MLMSTEP_CFG, sched=MLMSTEP_SCHED, seeds=MLMSTEP_SEEDS, wav_seed0=6100, depth=depth, B=B, steps=steps)))
-    save("mlmstep", **out)
+    out["config_json"] = np.array(json.dumps(dict(cfg=MLMSTEP_CFG, sched=MLMSTEP_SCHED, seeds=MLMSTEP_SEEDS, wav_seed0=6100, depth=depth,
+                                                  feature_layer=feature_layer, B=B, steps=steps)))
+    save(tag, **out)
 
 
 GENS["mlmstep"] = gen_mlmstep
+GENS["mlmstep12"] = gen_mlmstep12
 GENS["trainstep_ft1"] = gen_trainstep_ft1
 GENS["pmamftstep"] = gen_pmamftstep
 GENS["asstep"] = gen_asstep
